@@ -1,0 +1,168 @@
+/*
+ * itsx_hip.h -- C ABI of the MI355X (gfx950) ITS-trimming engine.
+ *
+ * Drop-in boundary for ONE path of USDA-ARS-GBRU/itsxpress: dereplicate reads ->
+ * score the representatives against the ITSx profile HMMs -> per-read trim
+ * coordinates.  In the reference this path is three Python methods that shell
+ * out to vsearch / hmmsearch and two parsers that re-read their output files.
+ * Every entry point below names the reference interface it replaces.
+ *
+ * Conventions: plain C types only; every call returns 0 on success or a negative
+ * ITSX_E_* code, with text available from itsx_last_error(); the caller owns all
+ * output arrays; nothing throws across the boundary.  One context drives one GPU
+ * (one process per GPU); a context is not thread-safe.  There is no CPU fallback:
+ * itsx_create fails if no gfx950 device is usable.
+ */
+#ifndef ITSX_HIP_H
+#define ITSX_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITSX_ABI_VERSION 1
+
+enum {
+  ITSX_OK            =  0,
+  ITSX_E_ARG         = -1,   /* bad argument / call order */
+  ITSX_E_IO          = -2,   /* file could not be read or written */
+  ITSX_E_FORMAT      = -3,   /* malformed HMMER3/f or FASTA/FASTQ text, illegal residue */
+  ITSX_E_DEVICE      = -4,   /* HIP error or no usable device */
+  ITSX_E_UNSUPPORTED = -5,   /* e.g. model longer than 48 nodes, cluster id < 1.0 */
+  ITSX_E_COLLISION   = -6,   /* 64-bit hash collision survived every reseed (never observed) */
+  ITSX_E_NOMEM       = -7
+};
+
+typedef struct itsx_ctx itsx_ctx;
+
+/* One reported-or-not domain, in hmmsearch --domtblout row order (profile file order,
+ * then target index, then domain index).  Replaces one text row of domtbl.txt as
+ * consumed by ItsPosition.parse (itsxpress/SeqSample.py:431-461): ll[0]=target name
+ * -> rep, ll[2]=tlen, ll[3]=query name -> prof, ll[13]=domain score -> bitscore,
+ * ll[19]/ll[20] = env from/to -> ienv/jenv. */
+typedef struct {
+  int64_t rep;            /* index of the representative in the unique list (see itsx_get_uniques) */
+  int32_t prof;           /* profile index in file order */
+  int32_t tlen;
+  int32_t ienv, jenv;     /* 1-based envelope coordinates */
+  int32_t dom_idx, ndom;
+  int32_t flags;          /* bit0: region looked multidomain; it was kept as ONE envelope */
+  float   envsc;          /* nats */
+  float   domcorrection;  /* nats */
+  float   dombias;        /* nats */
+  float   bitscore;       /* bits (column 14 of domtblout, before %.1f) */
+  double  lnP;
+  float   seq_score;      /* bits (column 8) */
+  float   seq_bias;       /* bits */
+  int32_t seq_reported;   /* per-sequence score >= T */
+  int32_t dom_reported;   /* exp(lnP) * domZ <= domE, set by itsx_search_finalize */
+} itsx_domain;
+
+/* per (representative, profile) filter trace for parity tests; only pairs past the MSV filter */
+typedef struct {
+  int64_t rep; int32_t prof;
+  int32_t msv_xj;         /* final xJ byte of the MSV filter; 255 = overflow (score +inf) */
+  int32_t pass_msv, pass_bias, pass_fwd;
+  float   msv_sc, filtersc, fwdsc, bcksc, nullsc;
+  int32_t nregions, ndom;
+} itsx_pairtrace;
+
+typedef struct {
+  int64_t n_reads, n_unique, n_dropped_short;
+  int64_t n_pairs, n_past_msv, n_past_bias, n_past_fwd, n_regions, n_multidomain, n_domains;
+  int64_t n_domain_overflow;      /* (rep,profile) pairs with more regions than the engine keeps (8) */
+  int32_t n_profiles, hash_reseeds;
+  /* device time of the last call of each stage, milliseconds (HIP events on the engine's stream) */
+  float   ms_derep, ms_msv, ms_filters, ms_domains, ms_finalize;
+  /* dominant-kernel accounting for bench.py's roofline block */
+  float   ms_msv_kernel;  int64_t msv_cells;  int64_t msv_launches;
+  float   ms_fwd_kernel, ms_bwd_kernel;  int64_t fwd_rows;
+} itsx_stats;
+
+int         itsx_abi_version(void);
+/* itsx_last_error(NULL) returns the message of the last failed itsx_create. */
+const char *itsx_last_error(const itsx_ctx *ctx);
+
+/* Replaces: process start-up of the vsearch / hmmsearch subprocesses
+ * (itsxpress/SeqSample.py:117,162,210).  device_id = HIP ordinal; flags = 0. */
+itsx_ctx   *itsx_create(int device_id, int flags);
+void        itsx_destroy(itsx_ctx *ctx);
+
+/* ---- profiles: replaces hmmsearch reading `hmmfile` (itsxpress/SeqSample.py:207), the
+ * HMMER3/f text written by create_runtime_hmm (itsxpress/main.py:176-231). */
+int itsx_load_profiles_file(itsx_ctx *ctx, const char *hmm_path, int *n_profiles);
+int itsx_load_profiles_mem(itsx_ctx *ctx, const char *text, int64_t len, int *n_profiles);
+int itsx_profile_name(const itsx_ctx *ctx, int i, char *buf, int buflen);
+/* table parity: copy out the configured MSV byte costs [18][M+1], striped odds ratios
+ * rfv [18][Q][4] / tfv [8Q][4], and {M, Q, base, bias, tbm, tec}. */
+int itsx_profile_tables(const itsx_ctx *ctx, int i, uint8_t *rbv, float *rfv, float *tfv, int32_t *params6);
+
+/* ---- reads: replaces vsearch/hmmsearch reading self.seq_file / rep.fa
+ * (itsxpress/SeqSample.py:109,208).  ASCII bases, IUPAC allowed, case-insensitive, U == T.
+ * offsets has n+1 entries.  names may be NULL (then the writers emit r%09d).
+ * The reads are packed 2 bits/base (+ an exception list for non-ACGT) and are resident in
+ * HBM when the call returns. */
+int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n,
+                   const char *names, const int64_t *name_offsets);
+/* FASTA or FASTQ file, plain or gzip (.gz): native parser for the same input. */
+int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
+
+/* ---- a1: SeqSample.deduplicate (itsxpress/SeqSample.py:93-131)
+ * = vsearch --fastx_uniques --strand both; minseqlength 32 is vsearch's default. */
+int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_unique);
+/* ---- a2: SeqSample.cluster (itsxpress/SeqSample.py:133-176) = vsearch --cluster_size.
+ * Round 1: only id == 1.0 (pure dereplication) is implemented; otherwise ITSX_E_UNSUPPORTED. */
+int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique);
+/* Dedup.parse's matchdict (itsxpress/SeqSample.py:542-562) as arrays over reads:
+ * rep_of[i] = read index of the cluster seed (first occurrence), -1 if the read was dropped;
+ * strand[i] = +1 / -1 (uc column 5); uniq_of[i] = index into the unique list, -1 if dropped. */
+int itsx_get_derep(const itsx_ctx *ctx, int64_t *rep_of, int8_t *strand, int64_t *uniq_of);
+/* read index of each unique (rep.fa order = input order of seeds), abundance of its cluster */
+int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance);
+
+/* ---- a4: SeqSample._search (itsxpress/SeqSample.py:178-225)
+ * = hmmsearch --domtblout -T <T> --F1 --F2 --F3 (domE = 10).  F2 must equal F1 (the
+ * reference's flags); the Viterbi filter, which then never runs, is not implemented.
+ * itsx_search runs every stage up to per-sequence reporting and counts, per profile, the
+ * reported representatives (hmmsearch's domZ).  itsx_search_finalize applies the
+ * domain threshold.  Between the two a multi-GPU driver all-reduces domZ. */
+int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3);
+int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ /* [n_profiles] */);
+int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ /* [n_profiles] */);
+int itsx_search_finalize(itsx_ctx *ctx, double domE);
+int64_t itsx_num_domains(const itsx_ctx *ctx);
+int itsx_get_domains(const itsx_ctx *ctx, itsx_domain *rows /* [itsx_num_domains] */);
+int64_t itsx_num_pairtraces(const itsx_ctx *ctx);
+int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows);
+
+/* ---- a5/a6/a7: ItsPosition.parse/_score/get_position (itsxpress/SeqSample.py:400-498)
+ * composed with Dedup.matchdict: per READ, start = left.env_to, stop = right.env_from - 1,
+ * tlen = length of the representative; -1 where the reference returns None; in_ddict[i] = 0
+ * where ItsPosition.get_position would raise KeyError (or the read was dropped). */
+int itsx_trim_coords(itsx_ctx *ctx, const char *left_prefix, const char *right_prefix,
+                     int32_t *start, int32_t *stop, int32_t *tlen, int32_t *in_ddict);
+/* same, per unique representative */
+int itsx_rep_coords(itsx_ctx *ctx, const char *left_prefix, const char *right_prefix,
+                    int32_t *start, int32_t *stop, int32_t *tlen, int32_t *in_ddict);
+
+/* ---- file-compatible outputs (users pass --keeptemp; itsxpress/SeqSample.py:104-105,190) */
+int itsx_write_uc(const itsx_ctx *ctx, const char *path);
+int itsx_write_rep_fasta(const itsx_ctx *ctx, const char *path);
+int itsx_write_domtbl(const itsx_ctx *ctx, const char *path);
+
+int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out);
+
+/* ---- test hooks (parity tests only) */
+/* XXH64 of each read's packed forward / reverse-complement key, as computed on the device */
+int itsx_debug_read_hashes(itsx_ctx *ctx, uint64_t *fwd, uint64_t *rc);
+/* packed representation of read i: words [ceil(len/16)], exception list (pos<<4|code) */
+int itsx_debug_packed_read(const itsx_ctx *ctx, int64_t i, uint32_t *words, int32_t *nwords,
+                           uint32_t *exc, int32_t *nexc);
+/* deterministic log/exp evaluated ON THE DEVICE for n inputs */
+int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_log, double *out_exp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

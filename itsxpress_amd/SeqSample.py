@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Same class names, method names, argument meaning, attributes and error behaviour as
+itsxpress/SeqSample.py (SeqSample:18-225, ItsPosition:368-498, Dedup:501-562), but where the
+reference shells out to `vsearch` / `hmmsearch` and then re-parses their text output, these
+methods drive the in-process HIP engine (itsxpress_amd.engine.Engine -> libitsx_hip.so).
+
+File-compatible: deduplicate()/cluster()/_search() still create tempdir/uc.txt, rep.fa and
+domtbl.txt (users pass --keeptemp; ItsPosition/Dedup of the *reference* can read them).
+Array fast path: ItsPosition.from_engine / Dedup.from_engine / SeqSample.trim_coordinates
+skip the text round trip.
+
+Out of scope here (SURVEY.md section 8 "next"): read merging, orientation, trimming/writing
+FASTQ -- the consumers of the coordinates.
+"""
+import logging
+import os
+from typing import Any, Dict, Optional, Tuple, Union
+
+from .engine import Engine
+from ._lib import EngineError
+
+logger = logging.getLogger(__name__)
+
+_REGION_PREFIX = {"ITS2": ("3_", "4_"), "ITS1": ("1_", "2_"), "ALL": ("1_", "4_")}
+
+
+class SeqSample:
+    """Base class: dereplicate -> search, as the reference's SeqSample (SeqSample.py:18-225)."""
+
+    def __init__(self, fastq: str, tempdir: str) -> None:
+        self.tempdir: str = tempdir
+        self.fastq: str = fastq
+        self.uc_file: Optional[str] = None
+        self.rep_file: Optional[str] = None
+        self.dom_file: Optional[str] = None
+        self.seq_file: Optional[str] = None
+        self.r1: Optional[str] = None
+        self.fastq2: Optional[str] = None
+        self._engine: Optional[Engine] = None
+
+    # -- engine plumbing -------------------------------------------------------------
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            try:
+                self._engine = Engine()
+            except FileNotFoundError:
+                logger.error("The HIP engine (libitsx_hip.so) was not found; build it first")
+                raise
+        return self._engine
+
+    def _load_reads(self) -> None:
+        eng = self.engine
+        if getattr(self, "_reads_loaded_from", None) != self.seq_file:
+            eng.load_reads_file(self.seq_file)
+            self._reads_loaded_from = self.seq_file
+
+    # -- a1 --------------------------------------------------------------------------
+    def deduplicate(self, threads: Union[int, str] = 1) -> None:
+        """Replaces `vsearch --fastx_uniques ... --strand both` (SeqSample.py:93-131)."""
+        try:
+            self.uc_file = os.path.join(self.tempdir, "uc.txt")
+            self.rep_file = os.path.join(self.tempdir, "rep.fa")
+            self._load_reads()
+            n = self.engine.derep(strand_both=True, minseqlength=32)
+            self.engine.write_uc(self.uc_file)
+            self.engine.write_rep_fasta(self.rep_file)
+            logging.info("itsx_hip derep: %d reads -> %d unique sequences", self.engine.n_reads, n)
+        except EngineError as e:
+            logging.exception("Could not perform dereplication with the HIP engine: %s", e)
+            raise e
+        except FileNotFoundError as f:
+            logging.error("The HIP engine or its input was not found")
+            raise f
+
+    # -- a2 --------------------------------------------------------------------------
+    def cluster(self, threads: Union[int, str], cluster_id: float = 0.995) -> None:
+        """Replaces `vsearch --cluster_size ... --id X` (SeqSample.py:133-176).
+
+        Only cluster_id == 1.0 (pure dereplication) is implemented in this round; other
+        values raise EngineError (a SubprocessError, as a failing vsearch would)."""
+        try:
+            self.uc_file = os.path.join(self.tempdir, "uc.txt")
+            self.rep_file = os.path.join(self.tempdir, "rep.fa")
+            self._load_reads()
+            self.engine.cluster(float(cluster_id), strand_both=True)
+            self.engine.write_uc(self.uc_file)
+            self.engine.write_rep_fasta(self.rep_file)
+        except EngineError as e:
+            logging.exception("Could not perform clustering with the HIP engine: %s", e)
+            raise e
+        except FileNotFoundError as f:
+            logging.error("The HIP engine or its input was not found")
+            raise f
+
+    # -- a4 --------------------------------------------------------------------------
+    def _search(self, hmmfile: str, threads: Union[int, str]) -> None:
+        """Replaces `hmmsearch --domtblout ... -T 10 --F1 1e-6 --F2 1e-6 --F3 1e-6` (SeqSample.py:178-225)."""
+        try:
+            self.dom_file = os.path.join(self.tempdir, "domtbl.txt")
+            eng = self.engine
+            if eng.n_unique == 0 and self.rep_file and os.path.exists(self.rep_file) and eng.n_reads == 0:
+                # _search called on a rep.fa produced elsewhere (the reference's tests do this)
+                eng.load_reads_file(self.rep_file)
+                eng.derep(strand_both=False, minseqlength=0)
+            eng.load_profiles(path=hmmfile)
+            eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
+            eng.finalize(domE=10.0)
+            eng.write_domtbl(self.dom_file)
+        except EngineError as e:
+            logging.exception("Could not perform ITS identification with the HIP engine: %s", e)
+            raise e
+        except FileNotFoundError as f:
+            logging.error("The HIP engine or the HMM file was not found")
+            raise f
+
+    # -- array fast path (a5/a6/a7 composed) ----------------------------------------------
+    def trim_coordinates(self, region: str):
+        """Per-read (start, stop, tlen, in_ddict) arrays straight from the device; -1 = None."""
+        left, right = _REGION_PREFIX[region]
+        return self.engine.trim_coords(left, right)
+
+
+class SeqSampleNotPaired(SeqSample):
+    """Unpaired input (SeqSample.py:228-241)."""
+
+    def __init__(self, fastq: str, tempdir: str) -> None:
+        SeqSample.__init__(self, fastq, tempdir)
+        self.seq_file = self.fastq
+        self.r1 = self.fastq
+        self.fastq2 = None
+
+
+class SeqSamplePairedNotInterleaved(SeqSample):
+    """Paired input in two files (SeqSample.py:244-264).  Merging the pairs is upstream of the
+    hot path and not part of this engine: set `seq_file` to the merged reads."""
+
+    def __init__(self, fastq: str, tempdir: str, fastq2: str, reversed_primers: bool = False) -> None:
+        SeqSample.__init__(self, fastq, tempdir)
+        if reversed_primers:
+            self.r1 = fastq2
+            self.fastq2 = fastq
+        else:
+            self.r1 = fastq
+            self.fastq2 = fastq2
+
+
+class ItsPosition:
+    """ITS boundary positions per representative (mirror of SeqSample.py:368-498).
+
+    `ddict` has the reference's shape: {seq: {"left": {"score","to_pos","from_pos"},
+    "right": {...}, "tlen": n}}.  The FIRST row with a strictly greater score wins."""
+
+    def __init__(self, domtable: Optional[str], region: str) -> None:
+        self.domtable = domtable
+        self.ddict: Dict[str, Any] = {}
+        self.leftprefix, self.rightprefix = _REGION_PREFIX[region]
+        if domtable is not None:
+            self.parse()
+
+    def _score(self, sequence: str, stype: str, score: float, from_pos: int, to_pos: int, tlen: int) -> None:
+        entry = self.ddict[sequence]
+        if stype in entry:
+            if score > entry[stype]["score"]:
+                entry[stype].update(score=score, to_pos=to_pos, from_pos=from_pos)
+        else:
+            entry[stype] = {"score": score, "to_pos": to_pos, "from_pos": from_pos}
+            entry["tlen"] = tlen
+
+    def parse(self) -> None:
+        try:
+            with open(self.domtable, "r") as f:
+                for line in f:
+                    if line.startswith("#"):
+                        continue
+                    ll = line.split()
+                    sequence, tlen, hmmprofile = ll[0], int(ll[2]), ll[3]
+                    score, from_pos, to_pos = float(ll[13]), int(ll[19]), int(ll[20])
+                    if sequence not in self.ddict:
+                        self.ddict[sequence] = {}
+                    if hmmprofile.startswith(self.leftprefix):
+                        self._score(sequence, "left", score, from_pos, to_pos, tlen)
+                    elif hmmprofile.startswith(self.rightprefix):
+                        self._score(sequence, "right", score, from_pos, to_pos, tlen)
+        except Exception as e:
+            logging.error("Exception occurred when parsing HMMSearch results")
+            raise e
+
+    @classmethod
+    def from_engine(cls, engine: Engine, region: str, names) -> "ItsPosition":
+        """Build the same ddict from the engine's domain rows (no text round trip).
+        `names[i]` is the label of unique representative i."""
+        self = cls(None, region)
+        prof = engine.profile_names()
+        for d in engine.domains():
+            if not d["dom_reported"]:
+                continue
+            seq = names[int(d["rep"])]
+            if seq not in self.ddict:
+                self.ddict[seq] = {}
+            score = float("%.1f" % d["bitscore"])
+            p = prof[int(d["prof"])]
+            if p.startswith(self.leftprefix):
+                self._score(seq, "left", score, int(d["ienv"]), int(d["jenv"]), int(d["tlen"]))
+            elif p.startswith(self.rightprefix):
+                self._score(seq, "right", score, int(d["ienv"]), int(d["jenv"]), int(d["tlen"]))
+        return self
+
+    def get_position(self, sequence: str) -> Tuple[Optional[int], Optional[int], Optional[int]]:
+        try:
+            entry = self.ddict[sequence]
+        except KeyError:
+            logging.debug("No ITS stop or start sites were identified for sequence {}, skipping.".format(sequence))
+            raise KeyError
+        start = int(entry["left"]["to_pos"]) if "left" in entry else None
+        stop = int(entry["right"]["from_pos"]) - 1 if "right" in entry else None
+        tlen = int(entry["tlen"]) if "tlen" in entry else None
+        return (start, stop, tlen)
+
+
+class Dedup:
+    """read -> representative map (mirror of SeqSample.py:501-562; trimming/writing is out of scope)."""
+
+    def __init__(self, uc_file: Optional[str], rep_file: str, seq_file: str,
+                 fastq: Optional[str] = None, fastq2: Optional[str] = None) -> None:
+        self.matchdict: Optional[Dict[str, str]] = None
+        self.uc_file = uc_file
+        self.rep_file = rep_file
+        self.seq_file = seq_file
+        self.fastq = fastq
+        self.fastq2 = fastq2
+        if uc_file is not None:
+            self.parse()
+
+    def parse(self) -> None:
+        try:
+            with open(self.uc_file, "r") as f:
+                self.matchdict = {}
+                for line in f:
+                    ll = line.split()
+                    if ll[0] == "S":
+                        self.matchdict[ll[8]] = ll[8]
+                    elif ll[0] == "H":
+                        self.matchdict[ll[8]] = ll[9]
+        except Exception as e:
+            logging.exception("Could not parse the '.uc' file.")
+            raise e
+
+    @classmethod
+    def from_engine(cls, engine: Engine, names) -> "Dedup":
+        """matchdict from the engine's arrays (names[i] = label of read i)."""
+        self = cls(None, "", "")
+        rep_of, _, _ = engine.get_derep()
+        self.matchdict = {names[i]: names[int(r)] for i, r in enumerate(rep_of) if r >= 0}
+        return self
+
+
+def install():
+    """Swap the engine into an importable reference package: after this call
+    `itsxpress.SeqSample.SeqSample.{deduplicate,cluster,_search}` run on the GPU while the CLI,
+    ItsPosition, Dedup and the QIIME 2 plugin stay untouched."""
+    import itsxpress.SeqSample as ref  # noqa: the reference package must be installed
+
+    def _eng(obj):
+        if getattr(obj, "_engine", None) is None:
+            obj._engine = Engine()
+        return obj._engine
+
+    ref.SeqSample.engine = property(_eng)
+    ref.SeqSample._load_reads = SeqSample._load_reads
+    ref.SeqSample.deduplicate = SeqSample.deduplicate
+    ref.SeqSample.cluster = SeqSample.cluster
+    ref.SeqSample._search = SeqSample._search
+    ref.SeqSample.trim_coordinates = SeqSample.trim_coordinates

@@ -1,0 +1,108 @@
+"""ctypes binding of the engine's C ABI (include/itsx_hip.h -> itsxpress_amd/libitsx_hip.so).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C itsxpress_amd/csrc`.
+There is no fallback: if the shared object is missing, or no gfx950 device is usable, the
+calls below raise -- FileNotFoundError for a missing engine (the class the reference raises
+when vsearch/hmmsearch are missing, itsxpress/SeqSample.py:127-131,221-225), EngineError for
+everything the engine reports.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libitsx_hip.so")
+_LIB = None
+
+
+class EngineError(subprocess.SubprocessError):
+    """Raised when the HIP engine reports an error (plays the part of CalledProcessError)."""
+
+    def __init__(self, code, message):
+        super().__init__("itsx_hip error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+DOMAIN_DTYPE = np.dtype([("rep", "<i8"), ("prof", "<i4"), ("tlen", "<i4"), ("ienv", "<i4"), ("jenv", "<i4"),
+                         ("dom_idx", "<i4"), ("ndom", "<i4"), ("flags", "<i4"), ("envsc", "<f4"),
+                         ("domcorrection", "<f4"), ("dombias", "<f4"), ("bitscore", "<f4"), ("lnP", "<f8"),
+                         ("seq_score", "<f4"), ("seq_bias", "<f4"), ("seq_reported", "<i4"),
+                         ("dom_reported", "<i4")], align=True)
+TRACE_DTYPE = np.dtype([("rep", "<i8"), ("prof", "<i4"), ("msv_xj", "<i4"), ("pass_msv", "<i4"),
+                        ("pass_bias", "<i4"), ("pass_fwd", "<i4"), ("msv_sc", "<f4"), ("filtersc", "<f4"),
+                        ("fwdsc", "<f4"), ("bcksc", "<f4"), ("nullsc", "<f4"), ("nregions", "<i4"),
+                        ("ndom", "<i4")], align=True)
+STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i8"), ("n_pairs", "<i8"),
+                ("n_past_msv", "<i8"), ("n_past_bias", "<i8"), ("n_past_fwd", "<i8"), ("n_regions", "<i8"),
+                ("n_multidomain", "<i8"), ("n_domains", "<i8"), ("n_domain_overflow", "<i8"),
+                ("n_profiles", "<i4"), ("hash_reseeds", "<i4"), ("ms_derep", "<f4"), ("ms_msv", "<f4"),
+                ("ms_filters", "<f4"), ("ms_domains", "<f4"), ("ms_finalize", "<f4"), ("ms_msv_kernel", "<f4"),
+                ("msv_cells", "<i8"), ("msv_launches", "<i8"), ("ms_fwd_kernel", "<f4"), ("ms_bwd_kernel", "<f4"),
+                ("fwd_rows", "<i8")]
+STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
+
+# every symbol include/itsx_hip.h declares
+EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy", "itsx_load_profiles_file",
+           "itsx_load_profiles_mem", "itsx_profile_name", "itsx_profile_tables", "itsx_set_reads",
+           "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_derep", "itsx_get_uniques",
+           "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
+           "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
+           "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
+           "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath"]
+
+
+def lib():
+    """Load libitsx_hip.so (once).  Raises FileNotFoundError if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C itsxpress_amd/csrc). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64, cp = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_char_p
+    sig = {
+        "itsx_abi_version": (i32, []),
+        "itsx_last_error": (cp, [vp]),
+        "itsx_create": (vp, [i32, i32]),
+        "itsx_destroy": (None, [vp]),
+        "itsx_load_profiles_file": (i32, [vp, cp, vp]),
+        "itsx_load_profiles_mem": (i32, [vp, cp, i64, vp]),
+        "itsx_profile_name": (i32, [vp, i32, vp, i32]),
+        "itsx_profile_tables": (i32, [vp, i32, vp, vp, vp, vp]),
+        "itsx_set_reads": (i32, [vp, vp, vp, i64, vp, vp]),
+        "itsx_load_reads_file": (i32, [vp, cp, vp]),
+        "itsx_derep": (i32, [vp, i32, i32, vp]),
+        "itsx_cluster": (i32, [vp, f64, i32, vp]),
+        "itsx_get_derep": (i32, [vp, vp, vp, vp]),
+        "itsx_get_uniques": (i32, [vp, vp, vp]),
+        "itsx_search": (i32, [vp, f64, f64, f64, f64]),
+        "itsx_get_domz": (i32, [vp, vp]),
+        "itsx_set_domz": (i32, [vp, vp]),
+        "itsx_search_finalize": (i32, [vp, f64]),
+        "itsx_num_domains": (i64, [vp]),
+        "itsx_get_domains": (i32, [vp, vp]),
+        "itsx_num_pairtraces": (i64, [vp]),
+        "itsx_get_pairtraces": (i32, [vp, vp]),
+        "itsx_trim_coords": (i32, [vp, cp, cp, vp, vp, vp, vp]),
+        "itsx_rep_coords": (i32, [vp, cp, cp, vp, vp, vp, vp]),
+        "itsx_write_uc": (i32, [vp, cp]),
+        "itsx_write_rep_fasta": (i32, [vp, cp]),
+        "itsx_write_domtbl": (i32, [vp, cp]),
+        "itsx_get_stats": (i32, [vp, vp]),
+        "itsx_debug_read_hashes": (i32, [vp, vp, vp]),
+        "itsx_debug_packed_read": (i32, [vp, i64, vp, vp, vp, vp]),
+        "itsx_debug_detmath": (i32, [vp, vp, i64, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    if L.itsx_abi_version() != 1:
+        raise EngineError(-1, "ABI version mismatch")
+    _LIB = L
+    return L

@@ -1,0 +1,88 @@
+// engine.h -- internal declarations of the gfx950 ITS-trimming engine (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/itsx_hip.h"
+
+namespace itsx {
+
+constexpr int KP = 18;          // A C G T - R Y M K S W H B V D N * ~  (HMMER's DNA digital alphabet)
+constexpr int NCODE = 16;       // codes that can occur in a read: 0..15 (4 = gap never does)
+constexpr int QMAX = 12;        // float striping segment length the device kernels are unrolled for
+constexpr int MMAX = 46;        // longest model the MSV kernel holds in registers (23 packed pairs)
+constexpr int MSV_REGS = 23;
+constexpr int MAXDOM = 8;       // regions kept per (rep, profile)
+
+// ---- host-side model (profile configuration happens once per model, on the host, with libm) ----
+struct HostProfile {
+  std::string name;
+  int M = 0, Q = 0;
+  float compo[4];
+  float evparam[6];
+  std::vector<float> t, mat, tsc, msc;
+  float scale_b; int base_b, bias_b, tbm_b, tec_b;
+  std::vector<uint8_t> rbv;   // [KP][M+1]
+  std::vector<float> rfv;     // [KP][Q][4]
+  std::vector<float> tfv;     // [8Q][4]
+  float ft10, ft11, fpi0, fpi1;
+  float feo[KP][2];
+};
+// returns "" on success, else an error message; appends to out
+std::string parse_hmm_text(const char *text, int64_t len, std::vector<HostProfile> &out);
+uint8_t host_tjb_b(int L);
+
+// ---- device-side model block: one per profile, read with scalar loads (wave-uniform) ----
+struct DevProfile {
+  float tf[QMAX * 8 * 4];       // [q][t][z], t: BM MM IM DM MD MI II DD
+  float rf[NCODE * QMAX * 4];   // [code][q][z] match emission odds ratios
+  float feo[NCODE * 2];         // bias-filter emission odds [code][state]
+  float ft10, ft11, fpi0, fpi1; // bias-filter HMM
+  float ev[6];                  // MSV mu,lambda  VIT mu,lambda  FWD tau,lambda
+  int   M, Q;
+  int   pad[2];
+};
+
+struct LenTables {              // per target length L, built on the host with libm
+  float   nullsc;               // L*log(p1) + log(1-p1)
+  float   bias_a;               // (float)L * logf(p1)
+  float   bias_b;               // logf(1-p1)
+  float   p1;
+  double  lognn3;               // log((float)L/(float)(L+3))
+  int     tjb;                  // MSV J->B / N->B cost byte
+  int     pad;
+};
+
+// a surviving (representative, profile) comparison
+struct PairRec {
+  int32_t  useq;                // index in the length-sorted unique list
+  int32_t  prof;
+  int32_t  xj;                  // MSV xJ byte (255 = overflow)
+  int32_t  L;
+};
+struct PairOut {                // filled by the filter/DP kernels
+  float filtersc, fwdsc, bcksc, nullsc, msv_sc;
+  int32_t pass_bias, pass_fwd, nregions, ndom, flags;
+};
+struct RegionRec {              // one envelope to re-score
+  int32_t pair;                 // index into the pair list
+  int32_t ienv, jenv;
+  int32_t multi;
+};
+struct RegionOut {
+  float envsc;
+  float n2log[NCODE];           // log null2 odds per residue code
+  int32_t ok;
+};
+
+#define HIPCHK(expr)                                                                            \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) {                                                                    \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e__));                            \
+      return ITSX_E_DEVICE;                                                                     \
+    }                                                                                           \
+  } while (0)
+
+}  // namespace itsx

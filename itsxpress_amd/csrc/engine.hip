@@ -1,0 +1,1073 @@
+// engine.hip -- host orchestration and the C ABI (include/itsx_hip.h) of the gfx950 engine.
+//
+// The path it drives (reference: itsxpress/SeqSample.py:93-225 + 368-562, main.py:176-231):
+//   reads (packed, resident in HBM) -> derep (k_derep) -> uniques ordered by length ->
+//   MSV for every (unique, profile) (k_msv) -> survivor list grouped by profile ->
+//   bias filter + Forward -> Backward + posterior decoding + regions -> envelope re-scoring
+//   (k_float) -> scores, per-profile reported counts (domZ) -> domain thresholds ->
+//   ItsPosition argmax -> per-read (start, stop, tlen).
+// Everything numeric runs on the device; the host parses text, packs reads, sizes buffers,
+// builds per-length constant tables with libm (as hmmsearch does on its host), and sorts rows
+// for the file-compatible writers.  There is no CPU fallback for any stage.
+#include <zlib.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <thread>
+#include "detmath.h"
+#include "engine.h"
+#include "k_api.h"
+
+namespace itsx {
+void launch_region_counts(const PairOut *pout, int64_t npairs, int32_t *cnt, hipStream_t st);
+void launch_region_offsets(int64_t npairs, const PairRec *pairs, const int32_t *pref, const int64_t *seg_pair_start,
+                           const int64_t *seg_region_start, int64_t *pair_region0, hipStream_t st);
+void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int64_t *pair_region0, RegionRec *out, hipStream_t st);
+void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, hipStream_t st);
+void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, unsigned long long *bl, unsigned long long *br,
+                      int32_t *in_ddict, hipStream_t st);
+
+// ---- a few tiny kernels that only the orchestration needs --------------------------------
+__global__ void k_wave_rows_pairs(const WaveDesc *w, int nw, const PairRec *pairs, int32_t *rows)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nw) rows[i] = pairs[w[i].first + w[i].count - 1].L + 1;       // ascending length inside a segment
+}
+__global__ void k_wave_rows_regions(const WaveDesc *w, int nw, const RegionRec *rg, int32_t *rows)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nw) return;
+  int mx = 0;
+  for (int k = 0; k < w[i].count; k++) { const RegionRec r = rg[w[i].first + k]; mx = max(mx, r.jenv - r.ienv + 1); }
+  rows[i] = mx + 1;
+}
+__global__ void k_gather_i32(const int32_t *src, const int64_t *idx, int n, int32_t *out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = src[idx[i]];
+}
+__global__ void k_rep_coords(int32_t U, const unsigned long long *bl, const unsigned long long *br, const int32_t *ind,
+                             const int32_t *seed_read, const int32_t *len, int32_t *start, int32_t *stop, int32_t *tlen)
+{
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  const unsigned long long l = bl[u], r = br[u];
+  start[u] = l ? (int32_t)(l & 0xffff) : -1;
+  stop[u] = r ? (int32_t)(r & 0xffff) - 1 : -1;
+  tlen[u] = (l || r) ? len[seed_read[u]] : -1;
+  (void)ind;
+}
+__global__ void k_read_coords(int64_t n, const int32_t *uniq_of, const int32_t *us, const int32_t *ue, const int32_t *ut, const int32_t *uind,
+                              int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int u = uniq_of[r];
+  if (u < 0) { start[r] = stop[r] = tlen[r] = -1; ind[r] = 0; return; }
+  start[r] = us[u]; stop[r] = ue[u]; tlen[r] = ut[u]; ind[r] = uind[u];
+}
+}  // namespace itsx
+
+using namespace itsx;
+
+static std::string g_create_error;
+
+template <class T> struct DBuf {
+  T *p = nullptr; size_t n = 0;
+  hipError_t alloc(size_t count) { release(); n = count; if (!count) return hipSuccess; return hipMalloc((void **)&p, count * sizeof(T)); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~DBuf() { release(); }
+};
+
+struct itsx_ctx {
+  int device = 0;
+  hipStream_t st = nullptr;
+  mutable std::string err;
+  void set_error(const std::string &m) const { err = m; }
+  itsx_stats stats{};
+
+  // ---- profiles
+  std::vector<HostProfile> profs;
+  int P = 0, G = 0;
+  DBuf<DevProfile> d_prof;
+  DBuf<uint32_t> d_etab;
+  DBuf<int32_t> d_pbias, d_ptec, d_ptbm;
+  DBuf<float> d_flogsum;
+  std::vector<char> generic_q;          // per profile: needs the runtime-Q kernels
+
+  // ---- reads
+  int64_t N = 0;
+  std::string h_bases;                   // original text (rep.fa keeps the input's case)
+  std::vector<int64_t> h_off;
+  std::vector<std::string> h_names;
+  std::vector<uint32_t> h_words, h_exc;
+  std::vector<int64_t> h_woff, h_excoff;
+  std::vector<int32_t> h_len;
+  DBuf<uint32_t> d_words, d_exc;
+  DBuf<int64_t> d_woff, d_excoff;
+  DBuf<int32_t> d_len;
+  ReadsDev rd{};
+  int Lmax = 0;
+
+  // ---- derep
+  bool have_derep = false;
+  int32_t U = 0;
+  DBuf<int32_t> d_rep_of, d_uniq_of, d_seed_read, d_abund, d_sorted_uniq, d_ulen;
+  DBuf<int8_t> d_strand;
+  std::vector<int32_t> h_rep_of, h_uniq_of, h_seed_read, h_abund, h_sorted_uniq;
+  std::vector<int8_t> h_strand;
+
+  // ---- search
+  bool have_search = false, have_final = false;
+  double T = 10.0;
+  int64_t npairs_padded = 0, nregions_padded = 0;
+  DBuf<PairRec> d_pairs;
+  DBuf<PairOut> d_pout;
+  DBuf<RegionRec> d_regions;
+  DBuf<RegionOut> d_rout;
+  DBuf<int64_t> d_pair_region0;
+  DBuf<itsx_domain> d_dom;
+  DBuf<int32_t> d_domz32;
+  DBuf<LenTables> d_lt;
+  std::vector<int64_t> domz;
+  std::vector<itsx_domain> h_dom;        // valid rows, domtblout order
+  std::vector<itsx_pairtrace> h_trace;
+};
+
+#define CTXCHK(c)                                   \
+  if (!(c)) return ITSX_E_ARG;
+#define SET_ERR(ctx, code, msg) do { (ctx)->set_error(msg); return (code); } while (0)
+#undef HIPCHK
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess) { ctx->set_error(std::string(#expr) + ": " + hipGetErrorString(e__)); return ITSX_E_DEVICE; } \
+  } while (0)
+
+template <class T> static hipError_t upload(DBuf<T> &d, const std::vector<T> &h, hipStream_t st, size_t min_elems = 1)
+{
+  hipError_t e = d.alloc(std::max(h.size(), min_elems));
+  if (e != hipSuccess) return e;
+  if (h.empty()) return hipSuccess;
+  return hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+}
+
+struct StageTimer {
+  hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
+  explicit StageTimer(hipStream_t s) : st(s) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+  float stop() { (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+  ~StageTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+extern "C" {
+
+int itsx_abi_version(void) { return ITSX_ABI_VERSION; }
+
+const char *itsx_last_error(const itsx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+itsx_ctx *itsx_create(int device_id, int flags)
+{
+  (void)flags;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) { g_create_error = "no HIP device is visible (the engine has no CPU fallback)"; return nullptr; }
+  if (device_id < 0 || device_id >= ndev) { g_create_error = "device ordinal out of range"; return nullptr; }
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return nullptr; }
+  if (std::string(prop.gcnArchName).compare(0, 6, "gfx950") != 0) {
+    g_create_error = std::string("device is ") + prop.gcnArchName + "; this engine ships gfx950 code only";
+    return nullptr;
+  }
+  itsx_ctx *ctx = new itsx_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreate(&ctx->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete ctx; return nullptr; }
+  // p7_FLogsum's table, built with libm exactly as hmmsearch builds it at start-up
+  std::vector<float> tbl(16000);
+  for (int i = 0; i < 16000; i++) tbl[i] = (float)log(1. + exp((double)-i / 1000.f));
+  if (upload(ctx->d_flogsum, tbl, ctx->st) != hipSuccess) { g_create_error = "device allocation failed"; delete ctx; return nullptr; }
+  (void)hipStreamSynchronize(ctx->st);
+  return ctx;
+}
+
+void itsx_destroy(itsx_ctx *ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->st);
+  (void)hipStreamDestroy(ctx->st);
+  delete ctx;
+}
+
+// ------------------------------------------------------------------------------ profiles
+static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_profiles)
+{
+  for (auto &p : pv) {
+    if (p.M > MMAX || p.Q > QMAX) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "model '" + p.name + "' has more than 46 nodes; the device kernels hold at most 46");
+    if (p.base_b + p.bias_b >= 255) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "model '" + p.name + "': MSV bias too large");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->profs = std::move(pv);
+  const int P = (int)ctx->profs.size();
+  ctx->P = P; ctx->G = (P + 63) / 64;
+  const int Ppad = ctx->G * 64;
+  std::vector<DevProfile> dp(std::max(P, 1));
+  ctx->generic_q.assign(P, 0);
+  std::vector<uint32_t> etab((size_t)std::max(ctx->G, 1) * 16 * MSV_REGS * 64, 0);
+  std::vector<int32_t> pb(std::max(Ppad, 64), 0), pt(std::max(Ppad, 64), 0), pm(std::max(Ppad, 64), 0);
+  // padding lanes: cost 255 everywhere, bias 0 -> their cells never rise above 0
+  for (size_t i = 0; i < etab.size(); i++) etab[i] = 0xFF01FF01u;   // (0 - 255) as int16, twice
+  for (int i = 0; i < P; i++) {
+    const HostProfile &h = ctx->profs[i];
+    DevProfile &d = dp[i];
+    memset(&d, 0, sizeof(d));
+    for (int q = 0; q < h.Q; q++) {
+      for (int t = 0; t < 7; t++) for (int z = 0; z < 4; z++) d.tf[(q * 8 + t) * 4 + z] = h.tfv[((size_t)q * 7 + t) * 4 + z];
+      for (int z = 0; z < 4; z++) d.tf[(q * 8 + 7) * 4 + z] = h.tfv[((size_t)7 * h.Q + q) * 4 + z];
+    }
+    for (int x = 0; x < NCODE; x++)
+      for (int q = 0; q < h.Q; q++) for (int z = 0; z < 4; z++) d.rf[(x * QMAX + q) * 4 + z] = h.rfv[((size_t)x * h.Q + q) * 4 + z];
+    for (int x = 0; x < NCODE; x++) { d.feo[x * 2] = h.feo[x][0]; d.feo[x * 2 + 1] = h.feo[x][1]; }
+    d.ft10 = h.ft10; d.ft11 = h.ft11; d.fpi0 = h.fpi0; d.fpi1 = h.fpi1;
+    for (int k = 0; k < 6; k++) d.ev[k] = h.evparam[k];
+    d.M = h.M; d.Q = h.Q;
+    ctx->generic_q[i] = (h.Q != QMAX);
+    const int g = i / 64, lane = i % 64;
+    for (int x = 0; x < NCODE; x++)
+      for (int r = 0; r < MSV_REGS; r++) {
+        uint32_t packed = 0;
+        for (int half = 0; half < 2; half++) {
+          const int k = 2 * r + half + 1;
+          const int cost = (k <= h.M) ? h.rbv[(size_t)x * (h.M + 1) + k] : 255;
+          const int16_t e = (int16_t)(h.bias_b - cost);
+          packed |= (uint32_t)(uint16_t)e << (16 * half);
+        }
+        etab[(((size_t)g * 16 + x) * MSV_REGS + r) * 64 + lane] = packed;
+      }
+    pb[i] = h.bias_b; pt[i] = h.tec_b; pm[i] = h.tbm_b;
+  }
+  HIPCHK(upload(ctx->d_prof, dp, ctx->st));
+  HIPCHK(upload(ctx->d_etab, etab, ctx->st));
+  HIPCHK(upload(ctx->d_pbias, pb, ctx->st));
+  HIPCHK(upload(ctx->d_ptec, pt, ctx->st));
+  HIPCHK(upload(ctx->d_ptbm, pm, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->stats.n_profiles = P;
+  ctx->have_search = ctx->have_final = false;
+  if (n_profiles) *n_profiles = P;
+  return ITSX_OK;
+}
+
+int itsx_load_profiles_mem(itsx_ctx *ctx, const char *text, int64_t len, int *n_profiles)
+{
+  CTXCHK(ctx && text && len >= 0);
+  std::vector<HostProfile> pv;
+  const std::string e = parse_hmm_text(text, len, pv);
+  if (!e.empty()) SET_ERR(ctx, ITSX_E_FORMAT, e);
+  return install_profiles(ctx, pv, n_profiles);
+}
+
+static int slurp(const char *path, std::string &out)
+{
+  gzFile f = gzopen(path, "rb");      // transparently reads plain files too
+  if (!f) return -1;
+  char buf[1 << 16];
+  int n;
+  while ((n = gzread(f, buf, sizeof(buf))) > 0) out.append(buf, (size_t)n);
+  gzclose(f);
+  return n < 0 ? -1 : 0;
+}
+
+int itsx_load_profiles_file(itsx_ctx *ctx, const char *hmm_path, int *n_profiles)
+{
+  CTXCHK(ctx && hmm_path);
+  std::string text;
+  if (slurp(hmm_path, text) != 0) SET_ERR(ctx, ITSX_E_IO, std::string("cannot read ") + hmm_path);
+  return itsx_load_profiles_mem(ctx, text.data(), (int64_t)text.size(), n_profiles);
+}
+
+int itsx_profile_name(const itsx_ctx *ctx, int i, char *buf, int buflen)
+{
+  CTXCHK(ctx && buf && buflen > 0 && i >= 0 && i < ctx->P);
+  snprintf(buf, (size_t)buflen, "%s", ctx->profs[i].name.c_str());
+  return ITSX_OK;
+}
+
+int itsx_profile_tables(const itsx_ctx *ctx, int i, uint8_t *rbv, float *rfv, float *tfv, int32_t *params6)
+{
+  CTXCHK(ctx && i >= 0 && i < ctx->P);
+  const HostProfile &h = ctx->profs[i];
+  if (rbv) memcpy(rbv, h.rbv.data(), h.rbv.size());
+  if (rfv) memcpy(rfv, h.rfv.data(), h.rfv.size() * sizeof(float));
+  if (tfv) memcpy(tfv, h.tfv.data(), h.tfv.size() * sizeof(float));
+  if (params6) { params6[0] = h.M; params6[1] = h.Q; params6[2] = h.base_b; params6[3] = h.bias_b; params6[4] = h.tbm_b; params6[5] = h.tec_b; }
+  return ITSX_OK;
+}
+
+// ------------------------------------------------------------------------------ reads
+static int8_t g_code[256];
+static bool g_code_init = false;
+static void init_codes()
+{
+  if (g_code_init) return;
+  memset(g_code, -1, sizeof(g_code));
+  const char *sym = "ACGT-RYMKSWHBVDN";
+  for (int i = 0; i < 16; i++) { g_code[(unsigned char)sym[i]] = (int8_t)i; g_code[(unsigned char)(sym[i] | 0x20)] = (int8_t)i; }
+  g_code[(unsigned char)'-'] = -1;
+  g_code[(unsigned char)'U'] = g_code[(unsigned char)'u'] = 3;
+  g_code[(unsigned char)'X'] = g_code[(unsigned char)'x'] = 15;
+  g_code_init = true;
+}
+
+static int pack_and_upload(itsx_ctx *ctx)
+{
+  init_codes();
+  const int64_t n = ctx->N;
+  ctx->h_len.resize((size_t)n); ctx->h_woff.assign((size_t)n + 1, 0); ctx->h_excoff.assign((size_t)n + 1, 0);
+  int64_t bad = -1;
+  int Lmax = 0;
+  for (int64_t r = 0; r < n; r++) {
+    const int64_t L = ctx->h_off[r + 1] - ctx->h_off[r];
+    if (L > 65535) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "reads longer than 65535 bases are not supported");
+    ctx->h_len[r] = (int32_t)L;
+    Lmax = std::max(Lmax, (int)L);
+    int64_t ne = 0;
+    const char *s = ctx->h_bases.data() + ctx->h_off[r];
+    for (int64_t i = 0; i < L; i++) { const int c = g_code[(unsigned char)s[i]]; if (c < 0) bad = r; else if (c > 3) ne++; }
+    ctx->h_woff[r + 1] = ctx->h_woff[r] + std::max<int64_t>(1, (L + 15) / 16);
+    ctx->h_excoff[r + 1] = ctx->h_excoff[r] + ne;
+  }
+  if (bad >= 0) SET_ERR(ctx, ITSX_E_FORMAT, "read " + std::to_string(bad) + " contains a symbol outside the IUPAC DNA alphabet");
+  ctx->Lmax = Lmax;
+  ctx->h_words.assign((size_t)ctx->h_woff[n] + 1, 0u);
+  ctx->h_exc.assign((size_t)ctx->h_excoff[n] + 1, 0u);
+  {
+    auto work = [ctx](int64_t r0, int64_t r1) {
+      for (int64_t r = r0; r < r1; r++) {
+        const int64_t L = ctx->h_len[r];
+        const char *s = ctx->h_bases.data() + ctx->h_off[r];
+        uint32_t *w = ctx->h_words.data() + ctx->h_woff[r];
+        uint32_t *e = ctx->h_exc.data() + ctx->h_excoff[r];
+        for (int64_t i = 0; i < L; i++) {
+          const int c = g_code[(unsigned char)s[i]];
+          if (c <= 3) w[i >> 4] |= (uint32_t)c << (2 * (i & 15));
+          else *e++ = ((uint32_t)i << 4) | (uint32_t)c;
+        }
+      }
+    };
+    int nt = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<int64_t>(1, n / 65536));
+    if (const char *e = getenv("ITSX_HOST_THREADS")) nt = std::max(1, atoi(e));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+    for (auto &t : th) t.join();
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(upload(ctx->d_words, ctx->h_words, ctx->st));
+  HIPCHK(upload(ctx->d_exc, ctx->h_exc, ctx->st));
+  HIPCHK(upload(ctx->d_woff, ctx->h_woff, ctx->st));
+  HIPCHK(upload(ctx->d_excoff, ctx->h_excoff, ctx->st));
+  HIPCHK(upload(ctx->d_len, ctx->h_len, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->rd.words = ctx->d_words.p; ctx->rd.woff = ctx->d_woff.p; ctx->rd.len = ctx->d_len.p;
+  ctx->rd.excoff = ctx->d_excoff.p; ctx->rd.exc = ctx->d_exc.p; ctx->rd.n = n;
+  ctx->have_derep = ctx->have_search = ctx->have_final = false;
+  ctx->stats.n_reads = n;
+  return ITSX_OK;
+}
+
+int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n, const char *names, const int64_t *name_offsets)
+{
+  CTXCHK(ctx && offsets && n >= 0 && (bases || offsets[n] == 0));
+  if (n >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
+  ctx->N = n;
+  ctx->h_off.assign(offsets, offsets + n + 1);
+  const int64_t base0 = offsets[0];
+  for (auto &o : ctx->h_off) o -= base0;
+  ctx->h_bases.assign(bases + base0, (size_t)(offsets[n] - base0));
+  ctx->h_names.clear();
+  if (names && name_offsets) {
+    ctx->h_names.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) ctx->h_names[i].assign(names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i]));
+  }
+  return pack_and_upload(ctx);
+}
+
+int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
+{
+  CTXCHK(ctx && path);
+  std::string text;
+  if (slurp(path, text) != 0) SET_ERR(ctx, ITSX_E_IO, std::string("cannot read ") + path);
+  ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
+  const char *s = text.data(), *end = s + text.size();
+  auto next_line = [&](const char *&b, const char *&e) -> bool {
+    if (s >= end) return false;
+    b = s; const char *nl = (const char *)memchr(s, '\n', (size_t)(end - s));
+    e = nl ? nl : end; s = nl ? nl + 1 : end;
+    if (e > b && e[-1] == '\r') e--;
+    return true;
+  };
+  const char *b, *e;
+  bool pending = false;                  // a header line already read into b,e
+  while (pending || next_line(b, e)) {
+    pending = false;
+    if (b == e) continue;
+    if (*b == '@') {                     // FASTQ record: 4 lines
+      const char *ne = b + 1; while (ne < e && *ne != ' ' && *ne != '\t') ne++;
+      ctx->h_names.emplace_back(b + 1, ne);
+      const char *sb, *se, *pb, *pe, *qb, *qe;
+      if (!next_line(sb, se) || !next_line(pb, pe) || !next_line(qb, qe) || pb == pe || *pb != '+' || (qe - qb) != (se - sb))
+        SET_ERR(ctx, ITSX_E_FORMAT, "malformed FASTQ record near read " + std::to_string(ctx->h_names.size()));
+      ctx->h_bases.append(sb, se);
+      ctx->h_off.push_back((int64_t)ctx->h_bases.size());
+    } else if (*b == '>') {              // FASTA record: header + sequence lines
+      const char *ne = b + 1; while (ne < e && *ne != ' ' && *ne != '\t') ne++;
+      ctx->h_names.emplace_back(b + 1, ne);
+      while (next_line(b, e)) {
+        if (b < e && *b == '>') { pending = true; break; }
+        ctx->h_bases.append(b, e);
+      }
+      ctx->h_off.push_back((int64_t)ctx->h_bases.size());
+    } else SET_ERR(ctx, ITSX_E_FORMAT, "input is neither FASTA nor FASTQ");
+  }
+  ctx->N = (int64_t)ctx->h_names.size();
+  if (n_reads) *n_reads = ctx->N;
+  return pack_and_upload(ctx);
+}
+
+// ------------------------------------------------------------------------------ derep
+int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_unique)
+{
+  CTXCHK(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->N;
+  StageTimer tm(ctx->st);
+  DBuf<uint64_t> hf, hr; DBuf<unsigned long long> keys; DBuf<int32_t> vals, is_seed, seed_rank, scan_tmp; DBuf<uint32_t> slot_of; DBuf<unsigned int> ncoll;
+  HIPCHK(hf.alloc((size_t)n + 1)); HIPCHK(hr.alloc((size_t)n + 1));
+  uint64_t tsize = 1024; while (tsize < (uint64_t)n * 2 + 16) tsize <<= 1;
+  HIPCHK(keys.alloc(tsize)); HIPCHK(vals.alloc(tsize)); HIPCHK(slot_of.alloc((size_t)n + 1)); HIPCHK(ncoll.alloc(1));
+  HIPCHK(is_seed.alloc((size_t)n + 1)); HIPCHK(seed_rank.alloc((size_t)n + 1)); HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(n + 1)));
+  HIPCHK(hipMemsetAsync(is_seed.p, 0, ((size_t)n + 1) * sizeof(int32_t), ctx->st));
+  HIPCHK(ctx->d_rep_of.alloc((size_t)n + 1)); HIPCHK(ctx->d_strand.alloc((size_t)n + 1)); HIPCHK(ctx->d_uniq_of.alloc((size_t)n + 1));
+  unsigned int hcoll = 0;
+  uint64_t seed = 0;
+  ctx->stats.hash_reseeds = 0;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    HIPCHK(hipMemsetAsync(keys.p, 0, tsize * sizeof(unsigned long long), ctx->st));
+    HIPCHK(hipMemsetAsync(vals.p, 0x7f, tsize * sizeof(int32_t), ctx->st));
+    HIPCHK(hipMemsetAsync(ncoll.p, 0, sizeof(unsigned int), ctx->st));
+    if (n > 0) {
+      launch_hash_reads(ctx->rd, seed, strand_both, hf.p, hr.p, ctx->st);
+      launch_table_insert(n, ctx->rd.len, minseqlength, hf.p, hr.p, keys.p, vals.p, tsize - 1, slot_of.p, ctx->st);
+      launch_table_resolve(ctx->rd, hf.p, vals.p, slot_of.p, ctx->d_rep_of.p, ctx->d_strand.p, is_seed.p, ncoll.p, ctx->st);
+    }
+    HIPCHK(hipMemcpyAsync(&hcoll, ncoll.p, sizeof(hcoll), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    if (hcoll == 0) break;
+    seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;
+    ctx->stats.hash_reseeds++;
+  }
+  if (hcoll != 0) SET_ERR(ctx, ITSX_E_COLLISION, "64-bit key collisions survived 4 reseeds");
+  // unique list = seeds in input order
+  int32_t U = 0;
+  if (n > 0) {
+    launch_exclusive_scan(is_seed.p, seed_rank.p, n + 1, scan_tmp.p, ctx->st);   // element n = total (is_seed[n] unused but allocated)
+    HIPCHK(hipMemcpyAsync(&U, seed_rank.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
+  ctx->U = U;
+  HIPCHK(ctx->d_seed_read.alloc((size_t)U + 1)); HIPCHK(ctx->d_abund.alloc((size_t)U + 1)); HIPCHK(ctx->d_sorted_uniq.alloc((size_t)U + 1));
+  HIPCHK(ctx->d_ulen.alloc((size_t)U + 1));
+  HIPCHK(hipMemsetAsync(ctx->d_abund.p, 0, ((size_t)U + 1) * sizeof(int32_t), ctx->st));
+  if (n > 0) launch_uniques(n, ctx->d_rep_of.p, seed_rank.p, ctx->d_uniq_of.p, ctx->d_seed_read.p, ctx->d_abund.p, ctx->st);
+  // order the uniques by length (counting sort) for the HMM stages
+  if (U > 0) {
+    const int32_t lcap = 65536;
+    DBuf<int32_t> hist, cursor, tmp2;
+    HIPCHK(hist.alloc(lcap)); HIPCHK(cursor.alloc(lcap)); HIPCHK(tmp2.alloc((size_t)scan_tmp_elems(lcap)));
+    HIPCHK(hipMemsetAsync(hist.p, 0, lcap * sizeof(int32_t), ctx->st));
+    launch_len_hist(U, ctx->d_seed_read.p, ctx->rd.len, hist.p, lcap, ctx->st);
+    launch_exclusive_scan(hist.p, cursor.p, lcap, tmp2.p, ctx->st);
+    launch_len_scatter(U, ctx->d_seed_read.p, ctx->rd.len, cursor.p, lcap, ctx->d_sorted_uniq.p, ctx->st);
+    launch_fill_ulen(U, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, ctx->rd.len, ctx->d_ulen.p, ctx->st);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
+  ctx->stats.ms_derep = tm.stop();
+  // host mirrors (writers, getters)
+  ctx->h_rep_of.resize((size_t)n); ctx->h_strand.resize((size_t)n); ctx->h_uniq_of.resize((size_t)n);
+  ctx->h_seed_read.resize((size_t)U); ctx->h_abund.resize((size_t)U); ctx->h_sorted_uniq.resize((size_t)U);
+  if (n > 0) {
+    HIPCHK(hipMemcpy(ctx->h_rep_of.data(), ctx->d_rep_of.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_strand.data(), ctx->d_strand.p, (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_uniq_of.data(), ctx->d_uniq_of.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  if (U > 0) {
+    HIPCHK(hipMemcpy(ctx->h_seed_read.data(), ctx->d_seed_read.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_abund.data(), ctx->d_abund.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_sorted_uniq.data(), ctx->d_sorted_uniq.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+  }
+  int64_t dropped = 0;
+  for (int64_t r = 0; r < n; r++) dropped += ctx->h_rep_of[r] < 0;
+  ctx->stats.n_unique = U; ctx->stats.n_dropped_short = dropped;
+  ctx->have_derep = true; ctx->have_search = ctx->have_final = false;
+  if (n_unique) *n_unique = U;
+  return ITSX_OK;
+}
+
+int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
+{
+  CTXCHK(ctx);
+  if (id < 1.0) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "greedy clustering at id < 1.0 (vsearch --cluster_size) is not implemented; only id == 1.0");
+  return itsx_derep(ctx, strand_both, 32, n_unique);
+}
+
+int itsx_get_derep(const itsx_ctx *ctx, int64_t *rep_of, int8_t *strand, int64_t *uniq_of)
+{
+  CTXCHK(ctx && ctx->have_derep);
+  for (int64_t r = 0; r < ctx->N; r++) {
+    if (rep_of) rep_of[r] = ctx->h_rep_of[r];
+    if (strand) strand[r] = ctx->h_strand[r];
+    if (uniq_of) uniq_of[r] = ctx->h_uniq_of[r];
+  }
+  return ITSX_OK;
+}
+int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance)
+{
+  CTXCHK(ctx && ctx->have_derep);
+  for (int32_t u = 0; u < ctx->U; u++) { if (seed_read) seed_read[u] = ctx->h_seed_read[u]; if (abundance) abundance[u] = ctx->h_abund[u]; }
+  return ITSX_OK;
+}
+
+// ------------------------------------------------------------------------------ search
+static float msv_score_from_byte(int xj, int tjb)
+{
+  float sc = ((float)(xj - tjb) - 190.0f);
+  sc /= (float)(3.0 / 0.69314718055994529);
+  sc -= 3.0f;
+  return sc;
+}
+
+int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
+{
+  CTXCHK(ctx);
+  if (!ctx->have_derep) SET_ERR(ctx, ITSX_E_ARG, "itsx_search called before itsx_derep / itsx_cluster");
+  if (ctx->P <= 0) SET_ERR(ctx, ITSX_E_ARG, "no profiles loaded");
+  if (F2 != F1) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "F2 != F1 would enable hmmsearch's Viterbi filter, which this engine does not implement");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->st;
+  const int P = ctx->P, G = ctx->G, Ppad = G * 64, U = ctx->U;
+  ctx->T = T;
+  ctx->h_dom.clear(); ctx->h_trace.clear();
+  ctx->domz.assign((size_t)P, 0);
+  itsx_stats &S = ctx->stats;
+  S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0;
+  ctx->npairs_padded = ctx->nregions_padded = 0;
+  ctx->have_search = true; ctx->have_final = false;
+  if (U == 0) return ITSX_OK;
+
+  // ---- per-length constants (host libm, as hmmsearch computes them per target)
+  const int Lcap = ctx->Lmax + 1;
+  std::vector<LenTables> lt((size_t)Lcap);
+  std::vector<int32_t> tjb((size_t)Lcap, 0);
+  std::vector<char> present((size_t)Lcap, 0);
+  for (int32_t u = 0; u < U; u++) present[ctx->h_len[ctx->h_seed_read[u]]] = 1;
+  for (int L = 0; L < Lcap; L++) {
+    LenTables &t = lt[L]; memset(&t, 0, sizeof(t));
+    if (L == 0) continue;
+    const float p1 = (float)L / (float)(L + 1);
+    t.p1 = p1;
+    t.nullsc = (float)((double)(float)L * log((double)p1) + log(1. - (double)p1));
+    t.bias_a = (float)L * logf(p1);
+    t.bias_b = logf((float)(1. - (double)p1));
+    t.lognn3 = log((double)((float)L / (float)(L + 3)));
+    t.tjb = host_tjb_b(L);
+    tjb[L] = t.tjb;
+  }
+  // MSV pass threshold on the final xJ byte, per (length, profile): P(score) <= F1
+  std::vector<uint16_t> thr((size_t)Lcap * Ppad, 257);
+  for (int L = 1; L < Lcap; L++) {
+    if (!present[L]) continue;
+    for (int p = 0; p < P; p++) {
+      const HostProfile &h = ctx->profs[p];
+      auto passes = [&](int xj) {
+        const float usc = msv_score_from_byte(xj, lt[L].tjb);
+        const double Pv = gumbel_surv((double)(usc - lt[L].nullsc) / 0.69314718055994529, (double)h.evparam[0], (double)h.evparam[1]);
+        return !(Pv > F1);
+      };
+      int lo = 0, hi = 255;             // smallest xj in [0,254] that passes; 256 if none
+      if (!passes(254)) { thr[(size_t)L * Ppad + p] = 256; continue; }
+      while (lo < hi) { const int mid = (lo + hi) / 2; if (passes(mid)) hi = mid; else lo = mid + 1; }
+      thr[(size_t)L * Ppad + p] = (uint16_t)lo;
+    }
+  }
+  DBuf<uint16_t> d_thr; DBuf<int32_t> d_tjb;
+  HIPCHK(upload(ctx->d_lt, lt, st)); HIPCHK(upload(d_thr, thr, st)); HIPCHK(upload(d_tjb, tjb, st));
+
+  // ---- MSV for every (unique, profile)
+  DBuf<uint16_t> d_res;
+  HIPCHK(d_res.alloc((size_t)Ppad * U));
+  {
+    MsvArgs a{};
+    a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.U = U; a.G = G;
+    a.etab = ctx->d_etab.p; a.pbias = ctx->d_pbias.p; a.ptec = ctx->d_ptec.p; a.ptbm = ctx->d_ptbm.p;
+    a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = d_res.p;
+    // enough waves to fill 256 CUs x 8 waves several times over, but >= 8 sequences per wave to amortise the table load
+    int spw = (int)std::max<int64_t>(8, std::min<int64_t>(256, ((int64_t)U * G) / (256 * 8 * 8) + 1));
+    a.seqs_per_wave = spw; a.nchunks = (U + spw - 1) / spw;
+    StageTimer tm(st);
+    launch_msv(a, st);
+    S.ms_msv_kernel = tm.stop();
+    S.msv_launches = 1;
+    int64_t cells = 0;
+    for (int32_t u = 0; u < U; u++) cells += (int64_t)ctx->h_len[ctx->h_seed_read[u]];
+    int64_t msum = 0; for (auto &h : ctx->profs) msum += h.M;
+    S.msv_cells = cells * msum;
+  }
+  StageTimer tm_list(st);
+  // ---- survivor list grouped by profile (64-aligned segments, ascending length)
+  const int nchunks = (U + CHUNK - 1) / CHUNK;
+  DBuf<int32_t> d_cnt, d_total;
+  HIPCHK(d_cnt.alloc((size_t)P * nchunks)); HIPCHK(d_total.alloc((size_t)P));
+  launch_pair_count(d_res.p, P, U, nchunks, d_cnt.p, st);
+  launch_chunk_scan(d_cnt.p, P, nchunks, d_total.p, st);
+  std::vector<int32_t> total((size_t)P);
+  HIPCHK(hipMemcpyAsync(total.data(), d_total.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<int64_t> seg_start((size_t)P + 1, 0);
+  for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; S.n_past_msv += total[p]; }
+  const int64_t NP = seg_start[P];
+  ctx->npairs_padded = NP;
+  S.ms_msv = S.ms_msv_kernel;
+  if (NP == 0) { S.ms_msv += tm_list.stop(); return ITSX_OK; }
+  if (NP >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 surviving (representative, profile) pairs");
+  DBuf<int64_t> d_seg_start;
+  HIPCHK(upload(d_seg_start, seg_start, st));
+  HIPCHK(ctx->d_pairs.alloc((size_t)NP)); HIPCHK(ctx->d_pout.alloc((size_t)NP));
+  HIPCHK(hipMemsetAsync(ctx->d_pairs.p, 0xFF, (size_t)NP * sizeof(PairRec), st));
+  HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)NP * sizeof(PairOut), st));
+  launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p, ctx->d_pairs.p, st);
+  d_res.release();
+  // ---- wave descriptors
+  std::vector<WaveDesc> waves;
+  std::vector<char> wgeneric;
+  for (int pass = 0; pass < 2; pass++)           // fast (Q == 12) waves first, then runtime-Q waves
+    for (int p = 0; p < P; p++) {
+      if ((int)ctx->generic_q[p] != pass) continue;
+      for (int64_t k = 0; k < total[p]; k += 64) {
+        WaveDesc w{}; w.prof = p; w.first = seg_start[p] + k; w.count = (int32_t)std::min<int64_t>(64, total[p] - k);
+        waves.push_back(w); wgeneric.push_back((char)pass);
+      }
+    }
+  const int NW = (int)waves.size();
+  DBuf<WaveDesc> d_waves; DBuf<int32_t> d_rows;
+  HIPCHK(upload(d_waves, waves, st)); HIPCHK(d_rows.alloc((size_t)NW));
+  hipLaunchKernelGGL(k_wave_rows_pairs, dim3((NW + 255) / 256), dim3(256), 0, st, d_waves.p, NW, ctx->d_pairs.p, d_rows.p);
+  std::vector<int32_t> rows((size_t)NW);
+  HIPCHK(hipMemcpyAsync(rows.data(), d_rows.p, (size_t)NW * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  S.ms_msv += tm_list.stop();
+
+  // ---- batches of waves sized to the slab budget
+  double slab_gb = 16.0;
+  if (const char *e = getenv("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));
+  const int64_t row_bytes = 14 * 64 * 4;
+  const int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
+  DBuf<RegionRec> d_raw;
+  HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));
+  {
+    StageTimer tm(st);
+    DBuf<float> d_slab;
+    int64_t slab_rows_alloc = 0;
+    int w0 = 0;
+    while (w0 < NW) {
+      int w1 = w0; int64_t r = 0;
+      while (w1 < NW && wgeneric[w1] == wgeneric[w0] && (w1 == w0 || r + rows[w1] <= budget_rows)) { waves[w1].slab = r; waves[w1].rows = rows[w1]; r += rows[w1]; w1++; }
+      if (r > slab_rows_alloc) { HIPCHK(d_slab.alloc((size_t)r * 14 * 64)); slab_rows_alloc = r; }
+      HIPCHK(hipMemcpyAsync(d_waves.p + w0, waves.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
+      FloatArgs a{};
+      a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+      a.flogsum = ctx->d_flogsum.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
+      a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
+      { StageTimer k(st); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); S.ms_fwd_kernel += k.stop(); }
+      { StageTimer k(st); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); S.ms_bwd_kernel += k.stop(); }
+      for (int w = w0; w < w1; w++) S.fwd_rows += (int64_t)(rows[w] - 1) * waves[w].count;
+      w0 = w1;
+    }
+    S.ms_filters = tm.stop();
+  }
+  StageTimer tm_dom(st);
+  // ---- compact regions into a profile-grouped list
+  DBuf<int32_t> d_rcnt, d_rpref, d_scan_tmp;
+  HIPCHK(d_rcnt.alloc((size_t)NP + 1)); HIPCHK(d_rpref.alloc((size_t)NP + 1)); HIPCHK(d_scan_tmp.alloc((size_t)scan_tmp_elems(NP + 1)));
+  HIPCHK(hipMemsetAsync(d_rcnt.p, 0, ((size_t)NP + 1) * 4, st));
+  launch_region_counts(ctx->d_pout.p, NP, d_rcnt.p, st);
+  launch_exclusive_scan(d_rcnt.p, d_rpref.p, NP + 1, d_scan_tmp.p, st);
+  std::vector<int32_t> bound((size_t)P + 1);
+  {
+    DBuf<int64_t> d_idx; DBuf<int32_t> d_b;
+    HIPCHK(upload(d_idx, seg_start, st)); HIPCHK(d_b.alloc((size_t)P + 1));
+    hipLaunchKernelGGL(k_gather_i32, dim3((P + 1 + 255) / 256), dim3(256), 0, st, d_rpref.p, d_idx.p, P + 1, d_b.p);
+    HIPCHK(hipMemcpyAsync(bound.data(), d_b.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  std::vector<int64_t> rseg((size_t)P + 1, 0);
+  std::vector<int32_t> rtotal((size_t)P);
+  for (int p = 0; p < P; p++) { rtotal[p] = bound[p + 1] - bound[p]; rseg[p + 1] = rseg[p] + ((int64_t)rtotal[p] + 63) / 64 * 64; S.n_domains += rtotal[p]; }
+  const int64_t NR = rseg[P];
+  ctx->nregions_padded = NR;
+  HIPCHK(ctx->d_pair_region0.alloc((size_t)NP));
+  HIPCHK(ctx->d_regions.alloc((size_t)std::max<int64_t>(NR, 1))); HIPCHK(ctx->d_rout.alloc((size_t)std::max<int64_t>(NR, 1)));
+  HIPCHK(ctx->d_dom.alloc((size_t)std::max<int64_t>(NR, 1)));
+  HIPCHK(hipMemsetAsync(ctx->d_dom.p, 0xFF, (size_t)std::max<int64_t>(NR, 1) * sizeof(itsx_domain), st));
+  HIPCHK(hipMemsetAsync(ctx->d_rout.p, 0, (size_t)std::max<int64_t>(NR, 1) * sizeof(RegionOut), st));
+  HIPCHK(ctx->d_domz32.alloc((size_t)P));
+  HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * 4, st));
+  if (NR > 0) {
+    DBuf<int64_t> d_rseg;
+    HIPCHK(upload(d_rseg, rseg, st));
+    launch_region_offsets(NP, ctx->d_pairs.p, d_rpref.p, d_seg_start.p, d_rseg.p, ctx->d_pair_region0.p, st);
+    launch_region_fill(ctx->d_pout.p, d_raw.p, NP, ctx->d_pair_region0.p, ctx->d_regions.p, st);
+    d_raw.release();
+    std::vector<WaveDesc> rw; std::vector<char> rgen;
+    for (int pass = 0; pass < 2; pass++)
+      for (int p = 0; p < P; p++) {
+        if ((int)ctx->generic_q[p] != pass) continue;
+        for (int64_t k = 0; k < rtotal[p]; k += 64) {
+          WaveDesc w{}; w.prof = p; w.first = rseg[p] + k; w.count = (int32_t)std::min<int64_t>(64, rtotal[p] - k);
+          rw.push_back(w); rgen.push_back((char)pass);
+        }
+      }
+    const int NRW = (int)rw.size();
+    DBuf<WaveDesc> d_rw; DBuf<int32_t> d_rrows;
+    HIPCHK(upload(d_rw, rw, st)); HIPCHK(d_rrows.alloc((size_t)NRW));
+    hipLaunchKernelGGL(k_wave_rows_regions, dim3((NRW + 255) / 256), dim3(256), 0, st, d_rw.p, NRW, ctx->d_regions.p, d_rrows.p);
+    std::vector<int32_t> rrows((size_t)NRW);
+    HIPCHK(hipMemcpyAsync(rrows.data(), d_rrows.p, (size_t)NRW * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int64_t erow_bytes = 204 * 64 * 4;
+    const int64_t ebudget = (int64_t)(slab_gb * (1 << 30)) / erow_bytes;
+    DBuf<float> d_eslab; int64_t ealloc = 0;
+    int w0 = 0;
+    while (w0 < NRW) {
+      int w1 = w0; int64_t r = 0;
+      while (w1 < NRW && rgen[w1] == rgen[w0] && (w1 == w0 || r + rrows[w1] <= ebudget)) { rw[w1].slab = r; rw[w1].rows = rrows[w1]; r += rrows[w1]; w1++; }
+      if (r > ealloc) { HIPCHK(d_eslab.alloc((size_t)r * 204 * 64)); ealloc = r; }
+      HIPCHK(hipMemcpyAsync(d_rw.p + w0, rw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
+      EnvArgs a{};
+      a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+      a.pairs = ctx->d_pairs.p; a.regions = ctx->d_regions.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
+      launch_envelopes(a, w1 - w0, w0, rgen[w0], st);
+      HIPCHK(hipStreamSynchronize(st));
+      w0 = w1;
+    }
+    ScoreArgs sa{};
+    sa.rd = ctx->rd; sa.sorted_uniq = ctx->d_sorted_uniq.p; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
+    sa.flogsum = ctx->d_flogsum.p; sa.pairs = ctx->d_pairs.p; sa.pout = ctx->d_pout.p; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
+    sa.pair_region0 = ctx->d_pair_region0.p; sa.dom = ctx->d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p;
+    launch_score(sa, st);
+  }
+  std::vector<int32_t> dz32((size_t)P, 0);
+  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int p = 0; p < P; p++) ctx->domz[p] = dz32[p];
+  S.ms_domains = tm_dom.stop();
+  // filter counters (one pass over the pair outputs on the host; small next to the DP work)
+  {
+    std::vector<PairOut> po((size_t)NP);
+    HIPCHK(hipMemcpy(po.data(), ctx->d_pout.p, (size_t)NP * sizeof(PairOut), hipMemcpyDeviceToHost));
+    for (auto &o : po) { S.n_past_bias += o.pass_bias; S.n_past_fwd += o.pass_fwd; S.n_regions += o.pass_fwd ? o.nregions : 0; S.n_domain_overflow += (o.flags & 2) ? 1 : 0; }
+  }
+  return ITSX_OK;
+}
+
+int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ)
+{
+  CTXCHK(ctx && domZ && ctx->have_search);
+  for (int p = 0; p < ctx->P; p++) domZ[p] = ctx->domz[p];
+  return ITSX_OK;
+}
+int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ)
+{
+  CTXCHK(ctx && domZ && ctx->have_search);
+  for (int p = 0; p < ctx->P; p++) ctx->domz[p] = domZ[p];
+  return ITSX_OK;
+}
+
+int itsx_search_finalize(itsx_ctx *ctx, double domE)
+{
+  CTXCHK(ctx && ctx->have_search);
+  HIPCHK(hipSetDevice(ctx->device));
+  StageTimer tm(ctx->st);
+  ctx->h_dom.clear();
+  const int64_t NR = ctx->nregions_padded;
+  if (NR > 0) {
+    DBuf<int64_t> d_dz;
+    HIPCHK(upload(d_dz, ctx->domz, ctx->st));
+    launch_finalize(ctx->d_dom.p, NR, d_dz.p, domE, ctx->st);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
+  ctx->stats.ms_finalize = tm.stop();
+  ctx->have_final = true;
+  return ITSX_OK;
+}
+
+static int fetch_domains(const itsx_ctx *cctx)
+{
+  itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
+  if (!ctx->h_dom.empty() || ctx->nregions_padded == 0) return ITSX_OK;
+  std::vector<itsx_domain> all((size_t)ctx->nregions_padded);
+  HIPCHK(hipMemcpy(all.data(), ctx->d_dom.p, all.size() * sizeof(itsx_domain), hipMemcpyDeviceToHost));
+  for (auto &d : all) if (d.dom_idx >= 0 && d.prof >= 0) ctx->h_dom.push_back(d);
+  std::sort(ctx->h_dom.begin(), ctx->h_dom.end(), [](const itsx_domain &a, const itsx_domain &b) {
+    if (a.prof != b.prof) return a.prof < b.prof;
+    if (a.rep != b.rep) return a.rep < b.rep;
+    return a.dom_idx < b.dom_idx;
+  });
+  return ITSX_OK;
+}
+
+int64_t itsx_num_domains(const itsx_ctx *ctx)
+{
+  if (!ctx || !ctx->have_search) return -1;
+  if (fetch_domains(ctx) != ITSX_OK) return -1;
+  return (int64_t)ctx->h_dom.size();
+}
+int itsx_get_domains(const itsx_ctx *ctx, itsx_domain *rows)
+{
+  CTXCHK(ctx && rows && ctx->have_search);
+  const int rc = fetch_domains(ctx);
+  if (rc != ITSX_OK) return rc;
+  if (!ctx->h_dom.empty()) memcpy(rows, ctx->h_dom.data(), ctx->h_dom.size() * sizeof(itsx_domain));
+  return ITSX_OK;
+}
+
+static int fetch_traces(const itsx_ctx *cctx)
+{
+  itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
+  if (!ctx->h_trace.empty() || ctx->npairs_padded == 0) return ITSX_OK;
+  const int64_t NP = ctx->npairs_padded;
+  std::vector<PairRec> pr((size_t)NP); std::vector<PairOut> po((size_t)NP);
+  HIPCHK(hipMemcpy(pr.data(), ctx->d_pairs.p, (size_t)NP * sizeof(PairRec), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(po.data(), ctx->d_pout.p, (size_t)NP * sizeof(PairOut), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < NP; i++) {
+    if (pr[i].prof < 0) continue;
+    itsx_pairtrace t{};
+    t.rep = ctx->h_sorted_uniq[pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
+    t.pass_bias = po[i].pass_bias; t.pass_fwd = po[i].pass_fwd; t.msv_sc = po[i].msv_sc; t.filtersc = po[i].filtersc;
+    t.fwdsc = po[i].fwdsc; t.bcksc = po[i].bcksc; t.nullsc = po[i].nullsc; t.nregions = po[i].nregions; t.ndom = po[i].ndom;
+    ctx->h_trace.push_back(t);
+  }
+  std::sort(ctx->h_trace.begin(), ctx->h_trace.end(), [](const itsx_pairtrace &a, const itsx_pairtrace &b) {
+    if (a.prof != b.prof) return a.prof < b.prof;
+    return a.rep < b.rep;
+  });
+  return ITSX_OK;
+}
+int64_t itsx_num_pairtraces(const itsx_ctx *ctx)
+{
+  if (!ctx || !ctx->have_search) return -1;
+  if (fetch_traces(ctx) != ITSX_OK) return -1;
+  return (int64_t)ctx->h_trace.size();
+}
+int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows)
+{
+  CTXCHK(ctx && rows && ctx->have_search);
+  const int rc = fetch_traces(ctx);
+  if (rc != ITSX_OK) return rc;
+  if (!ctx->h_trace.empty()) memcpy(rows, ctx->h_trace.data(), ctx->h_trace.size() * sizeof(itsx_pairtrace));
+  return ITSX_OK;
+}
+
+// ------------------------------------------------------------------------------ coordinates
+static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per_read, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
+{
+  CTXCHK(ctx && lp && rp && start && stop && tlen && ind);
+  if (!ctx->have_final) SET_ERR(ctx, ITSX_E_ARG, "coordinates requested before itsx_search_finalize");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->st;
+  const int32_t U = ctx->U; const int64_t n = ctx->N;
+  std::vector<int8_t> side((size_t)std::max(ctx->P, 1), 0);
+  const size_t ll = strlen(lp), rl = strlen(rp);
+  for (int p = 0; p < ctx->P; p++) {
+    const std::string &nm = ctx->profs[p].name;
+    if (nm.compare(0, ll, lp) == 0) side[p] = 1;
+    else if (nm.compare(0, rl, rp) == 0) side[p] = 2;
+  }
+  DBuf<int8_t> d_side; DBuf<unsigned long long> bl, br; DBuf<int32_t> uind, us, ue, ut;
+  HIPCHK(upload(d_side, side, st));
+  HIPCHK(bl.alloc((size_t)U + 1)); HIPCHK(br.alloc((size_t)U + 1)); HIPCHK(uind.alloc((size_t)U + 1));
+  HIPCHK(us.alloc((size_t)U + 1)); HIPCHK(ue.alloc((size_t)U + 1)); HIPCHK(ut.alloc((size_t)U + 1));
+  HIPCHK(hipMemsetAsync(bl.p, 0, ((size_t)U + 1) * 8, st)); HIPCHK(hipMemsetAsync(br.p, 0, ((size_t)U + 1) * 8, st));
+  HIPCHK(hipMemsetAsync(uind.p, 0, ((size_t)U + 1) * 4, st));
+  launch_positions(ctx->d_dom.p, ctx->nregions_padded, d_side.p, bl.p, br.p, uind.p, st);
+  if (U > 0) hipLaunchKernelGGL(k_rep_coords, dim3((U + 255) / 256), dim3(256), 0, st, U, bl.p, br.p, uind.p, ctx->d_seed_read.p, ctx->rd.len, us.p, ue.p, ut.p);
+  if (!per_read) {
+    if (U > 0) {
+      HIPCHK(hipMemcpyAsync(start, us.p, (size_t)U * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(stop, ue.p, (size_t)U * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(tlen, ut.p, (size_t)U * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(ind, uind.p, (size_t)U * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return ITSX_OK;
+  }
+  DBuf<int32_t> rs, re, rt, ri;
+  HIPCHK(rs.alloc((size_t)n + 1)); HIPCHK(re.alloc((size_t)n + 1)); HIPCHK(rt.alloc((size_t)n + 1)); HIPCHK(ri.alloc((size_t)n + 1));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_read_coords, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ctx->d_uniq_of.p, us.p, ue.p, ut.p, uind.p, rs.p, re.p, rt.p, ri.p);
+    HIPCHK(hipMemcpyAsync(start, rs.p, (size_t)n * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(stop, re.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(tlen, rt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(ind, ri.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return ITSX_OK;
+}
+int itsx_trim_coords(itsx_ctx *ctx, const char *lp, const char *rp, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
+{ return coords_common(ctx, lp, rp, true, start, stop, tlen, ind); }
+int itsx_rep_coords(itsx_ctx *ctx, const char *lp, const char *rp, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
+{ return coords_common(ctx, lp, rp, false, start, stop, tlen, ind); }
+
+// ------------------------------------------------------------------------------ writers
+static std::string read_name(const itsx_ctx *ctx, int64_t r)
+{
+  if (!ctx->h_names.empty()) return ctx->h_names[(size_t)r];
+  char b[32]; snprintf(b, sizeof(b), "r%09lld", (long long)r); return b;
+}
+// clusters in vsearch's output order: abundance descending, ties by label
+static std::vector<int32_t> cluster_order(const itsx_ctx *ctx)
+{
+  std::vector<int32_t> ord((size_t)ctx->U);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::vector<std::string> lab((size_t)ctx->U);
+  for (int32_t u = 0; u < ctx->U; u++) lab[u] = read_name(ctx, ctx->h_seed_read[u]);
+  std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+    if (ctx->h_abund[a] != ctx->h_abund[b]) return ctx->h_abund[a] > ctx->h_abund[b];
+    return strcmp(lab[a].c_str(), lab[b].c_str()) < 0;
+  });
+  return ord;
+}
+
+int itsx_write_uc(const itsx_ctx *ctx, const char *path)
+{
+  CTXCHK(ctx && path && ctx->have_derep);
+  FILE *f = fopen(path, "w");
+  if (!f) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + path);
+  const std::vector<int32_t> ord = cluster_order(ctx);
+  std::vector<std::vector<int64_t>> members((size_t)ctx->U);
+  for (int64_t r = 0; r < ctx->N; r++) { const int32_t u = ctx->h_uniq_of[r]; if (u >= 0 && ctx->h_rep_of[r] != r) members[u].push_back(r); }
+  for (size_t c = 0; c < ord.size(); c++) {
+    const int32_t u = ord[c]; const int64_t s = ctx->h_seed_read[u];
+    const std::string sl = read_name(ctx, s);
+    fprintf(f, "S\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_len[s], sl.c_str());
+    for (int64_t r : members[u])
+      fprintf(f, "H\t%zu\t%d\t100.0\t%c\t0\t0\t*\t%s\t%s\n", c, ctx->h_len[r], ctx->h_strand[r] < 0 ? '-' : '+', read_name(ctx, r).c_str(), sl.c_str());
+  }
+  for (size_t c = 0; c < ord.size(); c++) {
+    const int32_t u = ord[c];
+    fprintf(f, "C\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_abund[u], read_name(ctx, ctx->h_seed_read[u]).c_str());
+  }
+  fclose(f);
+  return ITSX_OK;
+}
+
+int itsx_write_rep_fasta(const itsx_ctx *ctx, const char *path)
+{
+  CTXCHK(ctx && path && ctx->have_derep);
+  FILE *f = fopen(path, "w");
+  if (!f) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + path);
+  for (int32_t u : cluster_order(ctx)) {
+    const int64_t s = ctx->h_seed_read[u];
+    fprintf(f, ">%s\n", read_name(ctx, s).c_str());
+    const char *b = ctx->h_bases.data() + ctx->h_off[s]; const int64_t L = ctx->h_len[s];
+    for (int64_t i = 0; i < L; i += 80) { fwrite(b + i, 1, (size_t)std::min<int64_t>(80, L - i), f); fputc('\n', f); }
+  }
+  fclose(f);
+  return ITSX_OK;
+}
+
+int itsx_write_domtbl(const itsx_ctx *ctx, const char *path)
+{
+  CTXCHK(ctx && path && ctx->have_final);
+  const int rc = fetch_domains(ctx);
+  if (rc != ITSX_OK) return rc;
+  FILE *f = fopen(path, "w");
+  if (!f) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + path);
+  fprintf(f, "#                                                                            --- full sequence --- -------------- this domain -------------   hmm coord   ali coord   env coord\n");
+  fprintf(f, "# target name        accession   tlen query name           accession   qlen   E-value  score  bias   #  of  c-Evalue  i-Evalue  score  bias  from    to  from    to  from    to  acc description of target\n");
+  // rows: profile order; within a profile, targets; within a target, reported domains renumbered
+  size_t i = 0;
+  const std::vector<itsx_domain> &D = ctx->h_dom;
+  while (i < D.size()) {
+    size_t j = i; int nrep = 0;
+    while (j < D.size() && D[j].prof == D[i].prof && D[j].rep == D[i].rep) { nrep += D[j].dom_reported; j++; }
+    int k = 0;
+    for (size_t d = i; d < j; d++) {
+      if (!D[d].dom_reported) continue;
+      k++;
+      const HostProfile &h = ctx->profs[D[d].prof];
+      const double Z = (double)ctx->U, dz = (double)ctx->domz[D[d].prof];
+      const double seqE = Z * det_exp(exp_logsurv((double)D[d].seq_score, (double)h.evparam[4], (double)h.evparam[5]));
+      const double P = det_exp(D[d].lnP);
+      // hmm/ali coordinates and acc need the optimal-accuracy alignment, which the engine does not compute:
+      // envelope coordinates are written in their place (the reference reads only env coords and the score).
+      fprintf(f, "%-20s %-10s %5d %-20s %-10s %5d %9.2g %6.1f %5.1f %3d %3d %9.2g %9.2g %6.1f %5.1f %5d %5d %5d %5d %5d %5d %4.2f %s\n",
+              read_name(ctx, ctx->h_seed_read[D[d].rep]).c_str(), "-", D[d].tlen, h.name.c_str(), "-", h.M, seqE, D[d].seq_score, D[d].seq_bias,
+              k, nrep, P * dz, P * Z, D[d].bitscore, D[d].dombias / 0.69314718055994529, 1, h.M, D[d].ienv, D[d].jenv, D[d].ienv, D[d].jenv, 0.0, "-");
+    }
+    i = j;
+  }
+  fclose(f);
+  return ITSX_OK;
+}
+
+int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out)
+{
+  CTXCHK(ctx && out);
+  *out = ctx->stats;
+  return ITSX_OK;
+}
+
+// ------------------------------------------------------------------------------ test hooks
+int itsx_debug_read_hashes(itsx_ctx *ctx, uint64_t *fwd, uint64_t *rc)
+{
+  CTXCHK(ctx && fwd && rc);
+  HIPCHK(hipSetDevice(ctx->device));
+  DBuf<uint64_t> hf, hr;
+  HIPCHK(hf.alloc((size_t)ctx->N + 1)); HIPCHK(hr.alloc((size_t)ctx->N + 1));
+  if (ctx->N > 0) {
+    launch_hash_reads(ctx->rd, 0, 1, hf.p, hr.p, ctx->st);
+    HIPCHK(hipMemcpyAsync(fwd, hf.p, (size_t)ctx->N * 8, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(rc, hr.p, (size_t)ctx->N * 8, hipMemcpyDeviceToHost, ctx->st));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
+
+int itsx_debug_packed_read(const itsx_ctx *ctx, int64_t i, uint32_t *words, int32_t *nwords, uint32_t *exc, int32_t *nexc)
+{
+  CTXCHK(ctx && i >= 0 && i < ctx->N && nwords && nexc);
+  const int32_t nw = (int32_t)(ctx->h_woff[i + 1] - ctx->h_woff[i]), ne = (int32_t)(ctx->h_excoff[i + 1] - ctx->h_excoff[i]);
+  if (words) memcpy(words, ctx->h_words.data() + ctx->h_woff[i], (size_t)nw * 4);
+  if (exc) memcpy(exc, ctx->h_exc.data() + ctx->h_excoff[i], (size_t)ne * 4);
+  *nwords = nw; *nexc = ne;
+  return ITSX_OK;
+}
+
+int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_log, double *out_exp)
+{
+  CTXCHK(ctx && x && out_log && out_exp && n >= 0);
+  HIPCHK(hipSetDevice(ctx->device));
+  DBuf<double> dx, dl, de;
+  HIPCHK(dx.alloc((size_t)n + 1)); HIPCHK(dl.alloc((size_t)n + 1)); HIPCHK(de.alloc((size_t)n + 1));
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->st));
+    launch_detmath(dx.p, n, dl.p, de.p, ctx->st);
+    HIPCHK(hipMemcpyAsync(out_log, dl.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(out_exp, de.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
+
+}  // extern "C"

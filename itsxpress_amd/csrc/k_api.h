@@ -1,0 +1,120 @@
+// k_api.h -- device-side argument blocks and host launchers shared by the engine's kernels.
+#pragma once
+#include "engine.h"
+
+namespace itsx {
+
+struct ReadsDev {
+  const uint32_t *words;    // 2-bit packed bases, 16 per word
+  const int64_t  *woff;     // [n+1] word offset of each read
+  const int32_t  *len;      // [n]
+  const int64_t  *excoff;   // [n+1]
+  const uint32_t *exc;      // (pos<<4 | code) for non-ACGT symbols
+  int64_t         n;
+};
+
+// ---- k_derep.hip
+void launch_hash_reads(const ReadsDev &rd, uint64_t seed, int strand_both, uint64_t *hf, uint64_t *hr, hipStream_t st);
+void launch_table_insert(int64_t n, const int32_t *len, int minlen, const uint64_t *hf, const uint64_t *hr,
+                         unsigned long long *keys, int32_t *vals, uint64_t mask, uint32_t *slot_of, hipStream_t st);
+void launch_table_resolve(const ReadsDev &rd, const uint64_t *hf, const int32_t *vals, const uint32_t *slot_of,
+                          int32_t *rep_of, int8_t *strand, int32_t *is_seed, unsigned int *n_collisions, hipStream_t st);
+void launch_uniques(int64_t n, const int32_t *rep_of, const int32_t *seed_rank, int32_t *uniq_of, int32_t *seed_read,
+                    int32_t *abundance, hipStream_t st);
+void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *hist, int32_t lcap, hipStream_t st);
+void launch_len_scatter(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *cursor, int32_t lcap,
+                        int32_t *sorted_uniq, hipStream_t st);
+
+// ---- k_util.hip
+// exclusive prefix sum of n int32 values (n < 2^31); tmp must hold scan_tmp_elems(n) int32
+int64_t scan_tmp_elems(int64_t n);
+void    launch_exclusive_scan(const int32_t *in, int32_t *out, int64_t n, int32_t *tmp, hipStream_t st);
+void    launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st);
+
+// ---- k_msv.hip
+struct MsvArgs {
+  ReadsDev rd;
+  const int32_t *sorted_uniq;   // [U] unique index, ascending length
+  const int32_t *seed_read;     // [U] read index of each unique
+  int32_t U;
+  int32_t G;                    // profile groups of 64
+  const uint32_t *etab;         // [G][16 codes][23][64] packed int16x2 of (bias - cost)
+  const int32_t *pbias, *ptec, *ptbm;   // [G*64]
+  const uint16_t *thr;          // [Lcap][G*64] smallest passing xJ, 256 = only overflow passes
+  const int32_t *tjb;           // [Lcap]
+  int32_t Lcap;
+  uint16_t *res;                // [G*64][U]  bit8 = passed, low byte = xJ (255 = overflow)
+  int32_t seqs_per_wave;
+  int32_t nchunks;
+};
+void launch_msv(const MsvArgs &a, hipStream_t st);
+
+// survivor list: pairs grouped by profile, 64-aligned segments, ascending length inside a segment
+constexpr int CHUNK = 2048;
+void launch_pair_count(const uint16_t *res, int32_t P, int32_t U, int32_t nchunks, int32_t *cnt /*[P][nchunks]*/, hipStream_t st);
+void launch_chunk_scan(int32_t *cnt, int32_t P, int32_t nchunks, int32_t *total /*[P]*/, hipStream_t st);
+void launch_pair_fill(const uint16_t *res, int32_t P, int32_t U, int32_t nchunks, const int32_t *cnt,
+                      const int64_t *seg_start /*[P]*/, const int32_t *ulen /*[U] length by sorted position*/,
+                      PairRec *pairs, hipStream_t st);
+void launch_fill_ulen(int32_t U, const int32_t *sorted_uniq, const int32_t *seed_read, const int32_t *len, int32_t *ulen, hipStream_t st);
+
+// ---- k_float.hip
+struct WaveDesc {               // one wave = up to 64 items that share a profile
+  int32_t prof;
+  int32_t count;
+  int64_t first;                // first item index
+  int64_t slab;                 // slab offset of this wave, in rows of 64 lanes
+  int32_t rows;                 // slab rows reserved per field block
+  int32_t pad;
+};
+struct FloatArgs {
+  ReadsDev rd;
+  const int32_t *sorted_uniq, *seed_read;
+  const DevProfile *prof;
+  const LenTables *lt;
+  const float *flogsum;         // [16000]
+  const PairRec *pairs;
+  PairOut *pout;
+  const WaveDesc *waves;
+  float *slab;                  // xmx rows: [row][12][64] per wave
+  RegionRec *regions;           // [npairs][MAXDOM] raw, before compaction
+  double F1, F3;
+};
+void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
+void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
+
+struct EnvArgs {
+  ReadsDev rd;
+  const int32_t *sorted_uniq, *seed_read;
+  const DevProfile *prof;
+  const LenTables *lt;
+  const PairRec *pairs;
+  const RegionRec *regions;     // compacted, grouped by profile
+  RegionOut *rout;
+  const WaveDesc *waves;
+  float *slab;                  // per wave: [row][2 passes][96][64]
+};
+void launch_envelopes(const EnvArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
+
+struct ScoreArgs {
+  ReadsDev rd;
+  const int32_t *sorted_uniq, *seed_read;
+  const DevProfile *prof;
+  const LenTables *lt;
+  const float *flogsum;
+  const PairRec *pairs;
+  const PairOut *pout;
+  const RegionRec *regions;     // compacted
+  const RegionOut *rout;
+  const int64_t *pair_region0;  // [npairs] index of the pair's first compacted region
+  itsx_domain *dom;             // one per region
+  int64_t npairs;
+  double T;
+  int32_t *domz;                // [P] reported targets per profile
+};
+void launch_score(const ScoreArgs &a, hipStream_t st);
+void launch_region_count_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *pref,
+                              const int64_t *seg_pair_start, const int64_t *seg_region_start, const int32_t *seg_of_pair_base,
+                              RegionRec *out, hipStream_t st);
+
+}  // namespace itsx

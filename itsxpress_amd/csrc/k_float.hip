@@ -1,0 +1,844 @@
+// k_float.hip -- stages C-F of the path: bias filter, Forward, Backward, posterior domain
+// definition, per-envelope re-scoring with null2, and bit scores.
+//
+// Replaces the float half of hmmsearch (reference call site itsxpress/SeqSample.py:191-209):
+// p7_bg_FilterScore, p7_ForwardParser, p7_BackwardParser, p7_domaindef_ByPosteriorHeuristics,
+// rescore_isolated_domain + p7_Null2_ByExpectation, and the score bookkeeping of p7_Pipeline.
+//
+// CDNA4 mapping.  These are serial recurrences over (row, node); the float results must not
+// depend on how the work is scheduled, because the consumer compares scores after %.1f
+// rounding (ItsPosition._score, itsxpress/SeqSample.py:400-429).  So:
+//   * one LANE owns one (representative, profile) comparison and evaluates HMMER's own
+//     4-lane x Q striped recurrence literally, in registers (3 x 4Q floats of DP row), in the
+//     same operation order (separate mul/add, no FMA: built with -ffp-contract=off; f32
+//     denormals flushed like HMMER's FTZ/DAZ: -fgpu-flush-denormals-to-zero).  No cross-lane
+//     traffic, no wavefront shuffles: a shuffle-carried scan would change the association
+//     order of the D->D path and of the E-state sum.
+//   * one WAVE holds 64 comparisons against the SAME profile (work lists are grouped by
+//     profile, ascending length), so transition odds are wave-uniform and stream through
+//     scalar loads into SGPR operands; match-emission odds (16 codes x 4Q floats, 3 KB) sit
+//     in LDS and are read with one ds_read_b128 per vector, conflict-free across A/C/G/T.
+//   * packed f32 math (float2 -> v_pk_mul_f32 / v_pk_add_f32) carries two of the four
+//     emulated SSE lanes per instruction.
+//   * per-row special-state values go to an HBM slab laid out [row][field][lane] so that
+//     every store/load is one coalesced 256-byte line per wave.
+// No MFMA: nothing here is a contraction.
+#include "engine.h"
+#include "k_api.h"
+#include "detmath.h"
+
+namespace itsx {
+
+#define DEV __device__ __forceinline__
+static constexpr double kLn2 = 0.69314718055994529;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct V4 { f2 a, b; };
+DEV V4 vset(float x) { V4 r; r.a = (f2){x, x}; r.b = (f2){x, x}; return r; }
+DEV V4 vzero() { return vset(0.0f); }
+DEV V4 vadd(V4 x, V4 y) { V4 r; r.a = x.a + y.a; r.b = x.b + y.b; return r; }
+DEV V4 vmul(V4 x, V4 y) { V4 r; r.a = x.a * y.a; r.b = x.b * y.b; return r; }
+DEV V4 vrsh(V4 v) { V4 r; r.a = (f2){0.0f, v.a.x}; r.b = (f2){v.a.y, v.b.x}; return r; }   // [0 a b c]
+DEV V4 vlsh(V4 v) { V4 r; r.a = (f2){v.a.y, v.b.x}; r.b = (f2){v.b.y, 0.0f}; return r; }   // [b c d 0]
+DEV float vhsum(V4 v) { return (v.a.x + v.a.y) + (v.b.x + v.b.y); }
+DEV V4 vld(const float *p) { const f4 t = *(const f4 *)p; V4 r; r.a = (f2){t.x, t.y}; r.b = (f2){t.z, t.w}; return r; }
+// The transition table is read through the constant address space: with a wave-uniform address the
+// backend then selects scalar loads (s_load_dwordx4..x16 into SGPRs) even though the kernel also
+// stores to global memory (a plain global pointer would get vector loads).
+typedef const f4 __attribute__((address_space(4))) *cf4p;
+DEV V4 vldc(const float *p) { const f4 t = *(cf4p)(uintptr_t)p; V4 r; r.a = (f2){t.x, t.y}; r.b = (f2){t.z, t.w}; return r; }
+DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// A scalar zero the optimizer cannot see through.  Added to the (wave-uniform) transition-table
+// pointer once per DP row, it keeps the 96 transition vectors as per-row scalar loads into SGPR
+// operands; without it loop-invariant code motion hoists all 384 floats into VGPR/AGPRs.
+DEV int opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
+
+// transition vector `idx` of the wave's profile: [q*8 + t] -> 4 floats (uniform address)
+#define TF(q, t) vldc(tf + ((q) * 8 + (t)) * 4)
+enum { tBM = 0, tMM, tIM, tDM, tMD, tMI, tII, tDD };
+
+struct Specials { float E, N, J, B, C, SCALE; };
+
+template <int QT> struct Row { V4 m[QMAX], d[QMAX], i[QMAX]; };
+
+// ---- per-lane view of one packed read ---------------------------------------------------
+struct Seq {
+  const uint32_t *w; const uint32_t *exc; int nexc; int L;
+  DEV int code(int pos0) const   // digital code of base pos0 (0-based)
+  {
+    int x = (int)((w[pos0 >> 4] >> (2 * (pos0 & 15))) & 3u);
+    for (int e = 0; e < nexc; e++) { const uint32_t v = exc[e]; if ((int)(v >> 4) == pos0) x = (int)(v & 15u); }
+    return x;
+  }
+};
+DEV Seq open_seq(const ReadsDev &rd, int read)
+{
+  Seq s; const int64_t wo = rd.woff[read], eo = rd.excoff[read];
+  s.w = rd.words + wo; s.exc = rd.exc + eo; s.nexc = (int)(rd.excoff[read + 1] - eo); s.L = rd.len[read];
+  return s;
+}
+
+// ---- one Forward row: HMMER's striped forward_engine inner body, literally --------------
+template <int QT>
+DEV void fwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const float *rfx /* LDS: &rf[x][0][0] */,
+                 float &xN, float &xB, float &xJ, float &xC, float &xE,
+                 const float pmove, const float ploop, const float eloop, const float emove)
+{
+  tf += opaque_zero();
+  V4 dcv = vzero(), xEv = vzero();
+  const V4 xBv = vset(xB);
+  V4 mpv = vrsh(R.m[Q - 1]), dpv = vrsh(R.d[Q - 1]), ipv = vrsh(R.i[Q - 1]);
+  V4 sv;
+#pragma unroll
+  for (int q = 0; q < (QT ? QT : QMAX); q++) {
+    if (QT == 0 && q >= Q) break;
+    sv = vmul(xBv, TF(q, tBM));
+    sv = vadd(sv, vmul(mpv, TF(q, tMM)));
+    sv = vadd(sv, vmul(ipv, TF(q, tIM)));
+    sv = vadd(sv, vmul(dpv, TF(q, tDM)));
+    sv = vmul(sv, vld(rfx + q * 4));
+    xEv = vadd(xEv, sv);
+    mpv = R.m[q]; dpv = R.d[q]; ipv = R.i[q];
+    R.m[q] = sv; R.d[q] = dcv;
+    dcv = vmul(sv, TF(q, tMD));
+    sv = vmul(mpv, TF(q, tMI));
+    R.i[q] = vadd(sv, vmul(ipv, TF(q, tII)));
+  }
+  dcv = vrsh(dcv);
+  R.d[0] = vzero();
+#pragma unroll
+  for (int q = 0; q < (QT ? QT : QMAX); q++) {
+    if (QT == 0 && q >= Q) break;
+    R.d[q] = vadd(dcv, R.d[q]);
+    dcv = vmul(R.d[q], TF(q, tDD));
+  }
+#pragma unroll
+  for (int j = 1; j < 4; j++) {
+    dcv = vrsh(dcv);
+#pragma unroll
+    for (int q = 0; q < (QT ? QT : QMAX); q++) {
+      if (QT == 0 && q >= Q) break;
+      R.d[q] = vadd(dcv, R.d[q]);
+      dcv = vmul(dcv, TF(q, tDD));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < (QT ? QT : QMAX); q++) { if (QT == 0 && q >= Q) break; xEv = vadd(R.d[q], xEv); }
+  xE = vhsum(xEv);
+  xN = xN * ploop;
+  xC = (xC * ploop) + (xE * emove);
+  xJ = (xJ * ploop) + (xE * eloop);
+  xB = (xJ * pmove) + (xN * pmove);
+}
+
+template <int QT>
+DEV void scale_row(Row<QT> &R, const int Q, const float s)
+{
+  const V4 sc = vset((float)(1.0 / (double)s));
+#pragma unroll
+  for (int q = 0; q < (QT ? QT : QMAX); q++) {
+    if (QT == 0 && q >= Q) break;
+    R.m[q] = vmul(R.m[q], sc); R.d[q] = vmul(R.d[q], sc); R.i[q] = vmul(R.i[q], sc);
+  }
+}
+
+// D->D / M->D completion shared by Backward's row L and rows L-1..1 (phases 3-5 of HMMER's engine)
+template <int QT>
+DEV void bwd_dd_md(Row<QT> &R, const int Q, const float *__restrict__ tf, const V4 xEv, const bool rowL)
+{
+  tf += opaque_zero();
+  V4 dpv, dcv = vzero();
+  if (rowL) dpv = vlsh(R.d[Q - 1]);
+  else      dpv = vlsh(vadd(R.d[0], xEv));
+#pragma unroll
+  for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
+    if (QT == 0 && q >= Q) continue;
+    dcv = vmul(dpv, TF(q, tDD));
+    if (rowL) R.d[q] = vadd(R.d[q], dcv);
+    else { R.d[q] = vadd(R.d[q], vadd(dcv, xEv)); R.m[q] = vadd(R.m[q], xEv); }
+    dpv = R.d[q];
+  }
+#pragma unroll
+  for (int j = 1; j < 4; j++) {
+    dcv = vlsh(dcv);
+#pragma unroll
+    for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
+      if (QT == 0 && q >= Q) continue;
+      dcv = vmul(dcv, TF(q, tDD));
+      R.d[q] = vadd(R.d[q], dcv);
+    }
+  }
+  dcv = vlsh(R.d[0]);
+#pragma unroll
+  for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
+    if (QT == 0 && q >= Q) continue;
+    R.m[q] = vadd(R.m[q], vmul(dcv, TF(q, tMD)));
+    dcv = R.d[q];
+  }
+}
+
+// one Backward row i (L-1 >= i >= 1): consumes residue x_{i+1}
+template <int QT>
+DEV void bwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const float *rfx,
+                 float &xN, float &xB, float &xJ, float &xC, float &xE,
+                 const float pmove, const float ploop, const float eloop, const float emove)
+{
+  tf += opaque_zero();
+  V4 tmmv = vlsh(TF(0, tMM)), timv = vlsh(TF(0, tIM)), tdmv = vlsh(TF(0, tDM));
+  V4 mpv = vlsh(vmul(R.m[0], vld(rfx)));
+  V4 xBv = vzero(), ipv, mcv;
+#pragma unroll
+  for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
+    if (QT == 0 && q >= Q) continue;
+    ipv = R.i[q];
+    R.i[q] = vadd(vmul(ipv, TF(q, tII)), vmul(mpv, timv));
+    R.d[q] = vmul(mpv, tdmv);
+    mcv = vadd(vmul(ipv, TF(q, tMI)), vmul(mpv, tmmv));
+    mpv = vmul(R.m[q], vld(rfx + q * 4));
+    R.m[q] = mcv;
+    tdmv = TF(q, tDM); timv = TF(q, tIM); tmmv = TF(q, tMM);
+    xBv = vadd(xBv, vmul(mpv, TF(q, tBM)));
+  }
+  xB = vhsum(xBv);
+  xC = xC * ploop;
+  xJ = (xB * pmove) + (xJ * ploop);
+  xN = (xB * pmove) + (xN * ploop);
+  xE = (xC * emove) + (xJ * eloop);
+  bwd_dd_md<QT>(R, Q, tf, vset(xE), false);
+}
+
+// ---- slab addressing: [row][field][lane] ---------------------------------------------------
+constexpr int XF = 14;     // fields per row in the parser slab: fwd E N J B C S | bck E N J B C S | btot etot
+DEV float *slab_at(float *slab, int64_t row0, int row, int nfields, int field, int lane)
+{
+  return slab + (((row0 + row) * nfields + field) * 64 + lane);
+}
+
+DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
+{
+  for (int i = threadIdx.x; i < NCODE * QMAX * 4; i += 64) rf_s[i] = pp->rf[i];
+  __syncthreads();
+}
+
+// =========================================================================================
+// K1: bias filter + Forward parser + F3 test, for one wave of survivors of the MSV filter
+template <int QT>
+__global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
+{
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
+  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  const DevProfile *pp = a.prof + uni(wd.prof);
+  fill_lds_rf(rf_s, pp);
+  const float *tf = pp->tf;
+  const int Q = QT ? QT : uni(pp->Q);
+  const bool active = lane < wd.count;
+  const int64_t pi = wd.first + (active ? lane : 0);
+  const PairRec pr = a.pairs[pi];
+  const int L = pr.L;
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  const LenTables lt = a.lt[L];
+  PairOut po;
+  po.nullsc = lt.nullsc; po.pass_bias = 0; po.pass_fwd = 0; po.nregions = 0; po.ndom = 0; po.flags = 0;
+  po.filtersc = 0.f; po.fwdsc = 0.f; po.bcksc = 0.f;
+  // MSV score back from its byte
+  float usc;
+  if (pr.xj == 255) usc = __builtin_inff();
+  else { usc = ((float)(pr.xj - lt.tjb) - 190.0f); usc /= (float)(3.0 / kLn2); usc -= 3.0f; }
+  po.msv_sc = usc;
+  const int Lw = wd.rows - 1;       // longest sequence in this wave
+
+  // ---- bias-composition filter: 2-state HMM forward, rescaled by the row max every row
+  {
+    const float t00 = lt.p1, t01 = 1.0f - lt.p1, t10 = pp->ft10, t11 = pp->ft11;
+    float d0 = 0.f, d1 = 0.f, logsc = 0.0f;
+    for (int i = 1; i <= Lw; i++) {
+      if (i <= L) {
+        const int x = sq.code(i - 1);
+        float n0, n1;
+        if (i == 1) { n0 = pp->feo[x * 2] * pp->fpi0; n1 = pp->feo[x * 2 + 1] * pp->fpi1; }
+        else {
+          n0 = 0.0f; n0 += d0 * t00; n0 += d1 * t10; n0 *= pp->feo[x * 2];
+          n1 = 0.0f; n1 += d0 * t01; n1 += d1 * t11; n1 *= pp->feo[x * 2 + 1];
+        }
+        float mx = 0.0f; if (n0 > mx) mx = n0; if (n1 > mx) mx = n1;
+        d0 = n0 / mx; d1 = n1 / mx;
+        logsc += (float)det_log((double)mx);
+      }
+    }
+    float e = 0.0f; e += d0 * 1.0f; e += d1 * 1.0f;
+    logsc += (float)det_log((double)e);
+    po.filtersc = logsc + lt.bias_a + lt.bias_b;
+  }
+  {
+    double P = gumbel_surv((double)(usc - po.filtersc) / kLn2, (double)pp->ev[0], (double)pp->ev[1]);
+    po.pass_bias = !(P > a.F1);
+  }
+
+  // ---- Forward parser
+  {
+    Row<QT> R;
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
+    const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
+    const float ploop = 1.0f - pmove;
+    float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f, totscale = 0.0f;
+    const int64_t r0 = wd.slab;
+    *slab_at(a.slab, r0, 0, XF, 0, lane) = xE; *slab_at(a.slab, r0, 0, XF, 1, lane) = xN;
+    *slab_at(a.slab, r0, 0, XF, 2, lane) = xJ; *slab_at(a.slab, r0, 0, XF, 3, lane) = xB;
+    *slab_at(a.slab, r0, 0, XF, 4, lane) = xC; *slab_at(a.slab, r0, 0, XF, 5, lane) = 1.0f;
+    for (int i = 1; i <= Lw; i++) {
+      if (i <= L) {
+        const int x = sq.code(i - 1);
+        fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);
+        float sc = 1.0f;
+        if (xE > 1.0e4f) {
+          xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+          scale_row<QT>(R, Q, xE);
+          sc = xE;
+          totscale = (float)((double)totscale + det_log((double)xE));
+          xE = 1.0f;
+        }
+        *slab_at(a.slab, r0, i, XF, 0, lane) = xE; *slab_at(a.slab, r0, i, XF, 1, lane) = xN;
+        *slab_at(a.slab, r0, i, XF, 2, lane) = xJ; *slab_at(a.slab, r0, i, XF, 3, lane) = xB;
+        *slab_at(a.slab, r0, i, XF, 4, lane) = xC; *slab_at(a.slab, r0, i, XF, 5, lane) = sc;
+      }
+    }
+    const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
+    po.fwdsc = (float)((double)totscale + det_log((double)(xC * pmove)));
+    const double P = exp_surv((double)(po.fwdsc - po.filtersc) / kLn2, (double)pp->ev[4], (double)pp->ev[5]);
+    po.pass_fwd = po.pass_bias && !bad && !(P > a.F3);
+  }
+  if (active) a.pout[pi] = po;
+}
+
+// =========================================================================================
+// K2: Backward parser + posterior decoding of B/E/occupancy + region scan
+template <int QT>
+__global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
+{
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
+  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  const DevProfile *pp = a.prof + uni(wd.prof);
+  fill_lds_rf(rf_s, pp);
+  const float *tf = pp->tf;
+  const int Q = QT ? QT : uni(pp->Q);
+  const bool active = lane < wd.count;
+  const int64_t pi = wd.first + (active ? lane : 0);
+  const PairRec pr = a.pairs[pi];
+  PairOut po = a.pout[pi];
+  const bool alive = active && po.pass_fwd;
+  if (__ballot(alive) == 0ull) return;
+  const int L = pr.L;
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  const int Lw = wd.rows - 1;
+  const int64_t r0 = wd.slab;
+  const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
+  const float ploop = 1.0f - pmove;
+  int own = 0;
+  bool bad = false;
+  {
+    Row<QT> R;
+    float xJ = 0.f, xB = 0.f, xN = 0.f, xC = pmove, xE = xC * 0.5f, totscale;
+    {
+      const V4 xEv = vset(xE);
+#pragma unroll
+      for (int q = 0; q < QMAX; q++) { R.m[q] = xEv; R.d[q] = xEv; R.i[q] = vzero(); }
+      bwd_dd_md<QT>(R, Q, tf, xEv, true);
+    }
+    // rows are walked from the wave's longest length down; a lane joins at its own L
+    float sL = 1.0f;
+    if (alive) sL = *slab_at(a.slab, r0, L, XF, 5, lane);
+    if (sL > 1.0f) {
+      xE = xE / sL; xN = xN / sL; xC = xC / sL; xJ = xJ / sL; xB = xB / sL;
+      scale_row<QT>(R, Q, sL);
+    }
+    totscale = (float)det_log((double)sL);
+    if (alive) {
+      *slab_at(a.slab, r0, L, XF, 6, lane) = xE; *slab_at(a.slab, r0, L, XF, 7, lane) = xN;
+      *slab_at(a.slab, r0, L, XF, 8, lane) = xJ; *slab_at(a.slab, r0, L, XF, 9, lane) = xB;
+      *slab_at(a.slab, r0, L, XF, 10, lane) = xC; *slab_at(a.slab, r0, L, XF, 11, lane) = sL;
+    }
+    for (int i = Lw - 1; i >= 1; i--) {
+      if (alive && i <= L - 1) {
+        const int x = sq.code(i);          // residue i+1, 0-based index i
+        bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);
+        if (xB > 1.0e16f) own = 1;
+        float s;
+        if (own) s = (xB > 1.0e4f) ? xB : 1.0f;
+        else     s = *slab_at(a.slab, r0, i, XF, 5, lane);
+        if (s > 1.0f) {
+          xE /= s; xN /= s; xJ /= s; xB /= s; xC /= s;
+          scale_row<QT>(R, Q, s);
+          totscale = (float)((double)totscale + det_log((double)s));
+        }
+        *slab_at(a.slab, r0, i, XF, 6, lane) = xE; *slab_at(a.slab, r0, i, XF, 7, lane) = xN;
+        *slab_at(a.slab, r0, i, XF, 8, lane) = xJ; *slab_at(a.slab, r0, i, XF, 9, lane) = xB;
+        *slab_at(a.slab, r0, i, XF, 10, lane) = xC; *slab_at(a.slab, r0, i, XF, 11, lane) = s;
+      }
+    }
+    // row 0
+    if (alive) {
+      const int x = sq.code(0);
+      const float *rfx = rf_s + x * QMAX * 4;
+      V4 xBv = vzero();
+#pragma unroll
+      for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
+        if (QT == 0 && q >= Q) continue;
+        const V4 mpv = vmul(R.m[q], vld(rfx + q * 4));
+        xBv = vadd(xBv, vmul(mpv, TF(q, tBM)));
+      }
+      xB = vhsum(xBv);
+      xN = (xB * pmove) + (xN * ploop);
+      *slab_at(a.slab, r0, 0, XF, 6, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 7, lane) = xN;
+      *slab_at(a.slab, r0, 0, XF, 8, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 9, lane) = xB;
+      *slab_at(a.slab, r0, 0, XF, 10, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 11, lane) = 1.0f;
+      bad = (xN != xN) || (xN == 0.0f) || (xN == __builtin_inff());
+      po.bcksc = (float)((double)totscale + det_log((double)xN));
+    }
+  }
+  // ---- posterior decoding + region scan, rows ascending (the order the sums are defined in)
+  int nreg = 0, nkept = 0, flags = 0;
+  if (alive && !bad) {
+    const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+    float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, XF, 7, lane));
+    float btot = 0.f, etot = 0.f;
+    *slab_at(a.slab, r0, 0, XF, 12, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 13, lane) = 0.f;
+    float fN = *slab_at(a.slab, r0, 0, XF, 1, lane), fJ = *slab_at(a.slab, r0, 0, XF, 2, lane);
+    float fB = *slab_at(a.slab, r0, 0, XF, 3, lane), fC = *slab_at(a.slab, r0, 0, XF, 4, lane);
+    float fS = *slab_at(a.slab, r0, 0, XF, 5, lane);
+    float bB = *slab_at(a.slab, r0, 0, XF, 9, lane), bS = *slab_at(a.slab, r0, 0, XF, 11, lane);
+    int ri = -1; bool triggered = false;
+    for (int j = 1; j <= L; j++) {
+      const float btot_prev = btot, etot_prev = etot;
+      btot = btot + (fB * bB * fS * scaleproduct);
+      if (own) scaleproduct *= fS / bS;
+      const float fEj = *slab_at(a.slab, r0, j, XF, 0, lane), fSj = *slab_at(a.slab, r0, j, XF, 5, lane);
+      const float bEj = *slab_at(a.slab, r0, j, XF, 6, lane), bNj = *slab_at(a.slab, r0, j, XF, 7, lane);
+      const float bJj = *slab_at(a.slab, r0, j, XF, 8, lane), bCj = *slab_at(a.slab, r0, j, XF, 10, lane);
+      etot = etot + (fEj * bEj * fSj * scaleproduct);
+      float njcp;
+      njcp = fN * bNj * ploop * scaleproduct;
+      njcp += fJ * bJj * ploop * scaleproduct;
+      njcp += fC * bCj * ploop * scaleproduct;
+      const float mocc = (float)(1. - (double)njcp);
+      *slab_at(a.slab, r0, j, XF, 12, lane) = btot; *slab_at(a.slab, r0, j, XF, 13, lane) = etot;
+      // advance the "previous row" registers
+      fN = *slab_at(a.slab, r0, j, XF, 1, lane); fJ = *slab_at(a.slab, r0, j, XF, 2, lane);
+      fB = *slab_at(a.slab, r0, j, XF, 3, lane); fC = *slab_at(a.slab, r0, j, XF, 4, lane); fS = fSj;
+      bB = *slab_at(a.slab, r0, j, XF, 9, lane); bS = *slab_at(a.slab, r0, j, XF, 11, lane);
+      if (!triggered) {
+        if (mocc - (btot - btot_prev) < rt2) ri = j;
+        else if (ri == -1) ri = j;
+        if (mocc >= rt1) triggered = true;
+      } else if (mocc - (etot - etot_prev) < rt2) {
+        nreg++;
+        float mx = -1.0f;
+        const float et0 = *slab_at(a.slab, r0, ri - 1, XF, 13, lane);
+        for (int z = ri; z <= j; z++) {
+          const float ea = *slab_at(a.slab, r0, z, XF, 13, lane) - et0;
+          const float bb = btot - *slab_at(a.slab, r0, z - 1, XF, 12, lane);
+          const float e = ea < bb ? ea : bb;
+          mx = e > mx ? e : mx;
+        }
+        const int multi = (mx >= rt3);
+        if (nkept < MAXDOM) {
+          RegionRec rr; rr.pair = (int32_t)pi; rr.ienv = ri; rr.jenv = j; rr.multi = multi;
+          a.regions[pi * MAXDOM + nkept] = rr;
+          nkept++;
+        } else flags |= 2;
+        ri = -1; triggered = false;
+      }
+    }
+    if (scaleproduct == __builtin_inff()) { nreg = 0; nkept = 0; }
+  }
+  if (active) { po.nregions = nreg; po.ndom = nkept; po.flags = flags; a.pout[pi] = po; }
+}
+
+// =========================================================================================
+// K3: re-score one envelope per lane in unihit mode (Forward, Backward, decoding, null2)
+constexpr int EF = 204;    // per row: fwd M,I (96) | bck M,I (96) | fwd E N J B C S | bck E N J B C S
+template <int QT>
+__global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
+{
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
+  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  const DevProfile *pp = a.prof + uni(wd.prof);
+  fill_lds_rf(rf_s, pp);
+  const float *tf = pp->tf;
+  const int Q = QT ? QT : uni(pp->Q);
+  const bool active = lane < wd.count;
+  const int64_t ri = wd.first + (active ? lane : 0);
+  const RegionRec rg = a.regions[ri];
+  const PairRec pr = a.pairs[rg.pair];
+  const int L = pr.L;
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  const int Ld = rg.jenv - rg.ienv + 1;
+  const int off = rg.ienv - 1;              // 0-based index of the envelope's first residue
+  const int Lw = wd.rows - 1;
+  const int64_t r0 = wd.slab;
+  const float pmove = 2.0f / ((float)L + 2.0f);
+  const float ploop = 1.0f - pmove;
+  RegionOut ro; ro.ok = 0; ro.envsc = 0.f;
+#pragma unroll
+  for (int x = 0; x < NCODE; x++) ro.n2log[x] = 0.f;
+  bool bad = false;
+  // ---- Forward over the envelope, keeping every row's M and I
+  {
+    Row<QT> R;
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
+    float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f, totscale = 0.0f;
+    *slab_at(a.slab, r0, 0, EF, 192, lane) = xE; *slab_at(a.slab, r0, 0, EF, 193, lane) = xN;
+    *slab_at(a.slab, r0, 0, EF, 194, lane) = xJ; *slab_at(a.slab, r0, 0, EF, 195, lane) = xB;
+    *slab_at(a.slab, r0, 0, EF, 196, lane) = xC; *slab_at(a.slab, r0, 0, EF, 197, lane) = 1.0f;
+    for (int i = 1; i <= Lw; i++) {
+      if (active && i <= Ld) {
+        const int x = sq.code(off + i - 1);
+        fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
+        float sc = 1.0f;
+        if (xE > 1.0e4f) {
+          xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+          scale_row<QT>(R, Q, xE);
+          sc = xE;
+          totscale = (float)((double)totscale + det_log((double)xE));
+          xE = 1.0f;
+        }
+        *slab_at(a.slab, r0, i, EF, 192, lane) = xE; *slab_at(a.slab, r0, i, EF, 193, lane) = xN;
+        *slab_at(a.slab, r0, i, EF, 194, lane) = xJ; *slab_at(a.slab, r0, i, EF, 195, lane) = xB;
+        *slab_at(a.slab, r0, i, EF, 196, lane) = xC; *slab_at(a.slab, r0, i, EF, 197, lane) = sc;
+#pragma unroll
+        for (int q = 0; q < (QT ? QT : QMAX); q++) {
+          if (QT == 0 && q >= Q) break;
+          float *d = slab_at(a.slab, r0, i, EF, q * 8, lane);
+          d[0] = R.m[q].a.x; d[64] = R.m[q].a.y; d[128] = R.m[q].b.x; d[192] = R.m[q].b.y;
+          d[256] = R.i[q].a.x; d[320] = R.i[q].a.y; d[384] = R.i[q].b.x; d[448] = R.i[q].b.y;
+        }
+      }
+    }
+    bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
+    ro.envsc = (float)((double)totscale + det_log((double)(xC * pmove)));
+  }
+  // ---- Backward over the envelope
+  int own = 0;
+  {
+    Row<QT> R;
+    float xJ = 0.f, xB = 0.f, xN = 0.f, xC = pmove, xE = xC * 1.0f;
+    {
+      const V4 xEv = vset(xE);
+#pragma unroll
+      for (int q = 0; q < QMAX; q++) { R.m[q] = xEv; R.d[q] = xEv; R.i[q] = vzero(); }
+      bwd_dd_md<QT>(R, Q, tf, xEv, true);
+    }
+    float sL = 1.0f;
+    if (active) sL = *slab_at(a.slab, r0, Ld, EF, 197, lane);
+    if (sL > 1.0f) {
+      xE = xE / sL; xN = xN / sL; xC = xC / sL; xJ = xJ / sL; xB = xB / sL;
+      scale_row<QT>(R, Q, sL);
+    }
+    auto store_row = [&](int i, float s) {
+      *slab_at(a.slab, r0, i, EF, 198, lane) = xE; *slab_at(a.slab, r0, i, EF, 199, lane) = xN;
+      *slab_at(a.slab, r0, i, EF, 200, lane) = xJ; *slab_at(a.slab, r0, i, EF, 201, lane) = xB;
+      *slab_at(a.slab, r0, i, EF, 202, lane) = xC; *slab_at(a.slab, r0, i, EF, 203, lane) = s;
+#pragma unroll
+      for (int q = 0; q < (QT ? QT : QMAX); q++) {
+        if (QT == 0 && q >= Q) break;
+        float *d = slab_at(a.slab, r0, i, EF, 96 + q * 8, lane);
+        d[0] = R.m[q].a.x; d[64] = R.m[q].a.y; d[128] = R.m[q].b.x; d[192] = R.m[q].b.y;
+        d[256] = R.i[q].a.x; d[320] = R.i[q].a.y; d[384] = R.i[q].b.x; d[448] = R.i[q].b.y;
+      }
+    };
+    if (active) store_row(Ld, sL);
+    for (int i = Lw - 1; i >= 1; i--) {
+      if (active && i <= Ld - 1) {
+        const int x = sq.code(off + i);
+        bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
+        if (xB > 1.0e16f) own = 1;
+        float s;
+        if (own) s = (xB > 1.0e4f) ? xB : 1.0f;
+        else     s = *slab_at(a.slab, r0, i, EF, 197, lane);
+        if (s > 1.0f) {
+          xE /= s; xN /= s; xJ /= s; xB /= s; xC /= s;
+          scale_row<QT>(R, Q, s);
+        }
+        store_row(i, s);
+      }
+    }
+    if (active) {
+      const int x = sq.code(off);
+      const float *rfx = rf_s + x * QMAX * 4;
+      V4 xBv = vzero();
+#pragma unroll
+      for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
+        if (QT == 0 && q >= Q) continue;
+        const V4 mpv = vmul(R.m[q], vld(rfx + q * 4));
+        xBv = vadd(xBv, vmul(mpv, TF(q, tBM)));
+      }
+      xB = vhsum(xBv);
+      xN = (xB * pmove) + (xN * ploop);
+      bad = bad || (xN != xN) || (xN == 0.0f) || (xN == __builtin_inff());
+      *slab_at(a.slab, r0, 0, EF, 199, lane) = xN;
+    }
+  }
+  // ---- posterior decoding: expected use of every emitting state, rows summed in ascending order
+  if (active && !bad) {
+    float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, EF, 199, lane));
+    V4 accM[QMAX], accI[QMAX];
+    float accN = 0.f, accC = 0.f, accJ = 0.f;
+    float fNp = *slab_at(a.slab, r0, 0, EF, 193, lane), fJp = *slab_at(a.slab, r0, 0, EF, 194, lane);
+    float fCp = *slab_at(a.slab, r0, 0, EF, 196, lane);
+    for (int r = 1; r <= Ld; r++) {
+      const float fS = *slab_at(a.slab, r0, r, EF, 197, lane);
+      const V4 totrv = vset(scaleproduct * fS);
+#pragma unroll
+      for (int q = 0; q < (QT ? QT : QMAX); q++) {
+        if (QT == 0 && q >= Q) break;
+        const float *f = slab_at(a.slab, r0, r, EF, q * 8, lane);
+        const float *b = slab_at(a.slab, r0, r, EF, 96 + q * 8, lane);
+        V4 fm, fi, bm, bi;
+        fm.a = (f2){f[0], f[64]}; fm.b = (f2){f[128], f[192]}; fi.a = (f2){f[256], f[320]}; fi.b = (f2){f[384], f[448]};
+        bm.a = (f2){b[0], b[64]}; bm.b = (f2){b[128], b[192]}; bi.a = (f2){b[256], b[320]}; bi.b = (f2){b[384], b[448]};
+        const V4 pm = vmul(vmul(fm, bm), totrv);
+        const V4 pi = vmul(vmul(fi, bi), totrv);
+        if (r == 1) { accM[q] = pm; accI[q] = pi; }
+        else { accM[q] = vadd(pm, accM[q]); accI[q] = vadd(pi, accI[q]); }
+      }
+      const float bN = *slab_at(a.slab, r0, r, EF, 199, lane), bJ = *slab_at(a.slab, r0, r, EF, 200, lane);
+      const float bC = *slab_at(a.slab, r0, r, EF, 202, lane), bS = *slab_at(a.slab, r0, r, EF, 203, lane);
+      const float pN = fNp * bN * ploop * scaleproduct;
+      const float pJ = fJp * bJ * ploop * scaleproduct;
+      const float pC = fCp * bC * ploop * scaleproduct;
+      if (r == 1) { accN = pN; accC = pC; accJ = pJ; } else { accN += pN; accC += pC; accJ += pJ; }
+      if (own) scaleproduct *= fS / bS;
+      fNp = *slab_at(a.slab, r0, r, EF, 193, lane); fJp = *slab_at(a.slab, r0, r, EF, 194, lane);
+      fCp = *slab_at(a.slab, r0, r, EF, 196, lane);
+    }
+    if (scaleproduct != __builtin_inff()) {
+      const float norm = (float)(1.0 / (double)(float)Ld);
+      const V4 nv = vset(norm);
+#pragma unroll
+      for (int q = 0; q < (QT ? QT : QMAX); q++) { if (QT == 0 && q >= Q) break; accM[q] = vmul(accM[q], nv); accI[q] = vmul(accI[q], nv); }
+      accN *= norm; accC *= norm; accJ *= norm;
+      const float xfactor = accN + accC + accJ;
+      float null2[NCODE];
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        V4 sv = vzero();
+#pragma unroll
+        for (int q = 0; q < (QT ? QT : QMAX); q++) {
+          if (QT == 0 && q >= Q) break;
+          sv = vadd(sv, vmul(accM[q], vld(rf_s + x * QMAX * 4 + q * 4)));
+          sv = vadd(sv, accI[q]);
+        }
+        null2[x] = vhsum(sv);
+        null2[x] += xfactor;
+      }
+      null2[4] = 1.0f;
+      // degenerate codes: mean of the member odds (order A,C,G,T)
+      const unsigned short dm[16] = {1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15};
+#pragma unroll
+      for (int x = 5; x < 16; x++) {
+        float acc = 0.f; int nd = 0;
+#pragma unroll
+        for (int y = 0; y < 4; y++) if (dm[x] >> y & 1) { acc += null2[y]; nd++; }
+        null2[x] = acc / (float)nd;
+      }
+#pragma unroll
+      for (int x = 0; x < NCODE; x++) ro.n2log[x] = det_logf(null2[x]);
+      ro.ok = 1;
+    }
+  }
+  if (active) a.rout[ri] = ro;
+}
+
+// =========================================================================================
+// K4: per pair, chain its envelopes in order: null2 corrections, bit scores, reporting
+DEV float flogsum_dev(const float *tbl, float x, float y)
+{
+  const float mx = x > y ? x : y, mn = x > y ? y : x;
+  return (mn == -__builtin_inff() || (mx - mn) >= 15.7f) ? mx : mx + tbl[(int)((mx - mn) * 1000.f)];
+}
+
+__global__ void __launch_bounds__(256) k_score(ScoreArgs a)
+{
+  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= a.npairs) return;
+  const PairOut po = a.pout[pi];
+  if (!po.pass_fwd || po.ndom <= 0) return;
+  const PairRec pr = a.pairs[pi];
+  const DevProfile *pp = a.prof + pr.prof;
+  const int L = pr.L;
+  const LenTables lt = a.lt[L];
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  const double log_omega = -5.545177444479562;   // log(1/256), the null2 prior
+  const int64_t g0 = a.pair_region0[pi];
+  const int nd_all = po.ndom;
+  // pass 1: domcorrection per envelope, and the chained per-sequence sum over all envelope positions
+  float seqbias = 0.0f;
+  float domcorr[MAXDOM]; int okd[MAXDOM]; int ndom = 0;
+  for (int d = 0; d < nd_all; d++) {
+    const RegionOut ro = a.rout[g0 + d];
+    const RegionRec rg = a.regions[g0 + d];
+    okd[d] = ro.ok;
+    float dc = 0.0f;
+    if (ro.ok) {
+      for (int pos = rg.ienv; pos <= rg.jenv; pos++) {
+        const float v = ro.n2log[sq.code(pos - 1)];
+        dc += v; seqbias += v;
+      }
+      ndom++;
+    }
+    domcorr[d] = dc;
+  }
+  if (ndom == 0) return;
+  seqbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)seqbias));
+  const float nullsc = po.nullsc;
+  float seq_score = (float)((double)(po.fwdsc - (nullsc + seqbias)) / kLn2);
+  float sum_score = 0.0f, sbias = 0.0f; int Ldsum = 0;
+  for (int d = 0; d < nd_all; d++) {
+    if (!okd[d]) continue;
+    const RegionOut ro = a.rout[g0 + d];
+    const RegionRec rg = a.regions[g0 + d];
+    if (ro.envsc - domcorr[d] > 0.0f) { sum_score += ro.envsc; Ldsum += rg.jenv - rg.ienv + 1; sbias += domcorr[d]; }
+  }
+  sbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)sbias));
+  sum_score = (float)((double)sum_score + (double)(L - Ldsum) * lt.lognn3);
+  sum_score = (float)((double)(sum_score - (nullsc + sbias)) / kLn2);
+  float final_bias = seqbias;
+  if (Ldsum > 0 && sum_score > seq_score) { seq_score = sum_score; final_bias = sbias; }
+  const int seq_rep = ((double)seq_score >= a.T);
+  int k = 0;
+  for (int d = 0; d < nd_all; d++) {
+    itsx_domain o;
+    const RegionOut ro = a.rout[g0 + d];
+    const RegionRec rg = a.regions[g0 + d];
+    const int Ld = rg.jenv - rg.ienv + 1;
+    float bits = (float)((double)ro.envsc + (double)(L - Ld) * lt.lognn3);
+    const float dombias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)domcorr[d]));
+    bits = (float)((double)(bits - (nullsc + dombias)) / kLn2);
+    o.rep = a.sorted_uniq[pr.useq]; o.prof = pr.prof; o.tlen = L; o.ienv = rg.ienv; o.jenv = rg.jenv;
+    o.dom_idx = okd[d] ? k : -1; o.ndom = ndom; o.flags = (rg.multi ? 1 : 0) | po.flags;
+    o.envsc = ro.envsc; o.domcorrection = domcorr[d]; o.dombias = dombias; o.bitscore = bits;
+    o.lnP = exp_logsurv((double)bits, (double)pp->ev[4], (double)pp->ev[5]);
+    o.seq_score = seq_score; o.seq_bias = (float)((double)final_bias / kLn2);
+    o.seq_reported = okd[d] ? seq_rep : 0; o.dom_reported = 0;
+    a.dom[g0 + d] = o;
+    if (okd[d]) k++;
+  }
+  if (seq_rep) atomicAdd(&a.domz[pr.prof], 1);
+}
+
+// compaction of raw per-pair region slots into the profile-grouped region list
+__global__ void __launch_bounds__(256) k_region_fill(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, int64_t npairs,
+                                                     const int64_t *__restrict__ pair_region0, RegionRec *__restrict__ out)
+{
+  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= npairs) return;
+  const int n = pout[pi].pass_fwd ? pout[pi].ndom : 0;
+  const int64_t o = pair_region0[pi];
+  for (int k = 0; k < n; k++) out[o + k] = raw[pi * MAXDOM + k];
+}
+__global__ void __launch_bounds__(256) k_region_counts(const PairOut *__restrict__ pout, int64_t npairs, int32_t *__restrict__ cnt)
+{
+  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi < npairs) cnt[pi] = pout[pi].pass_fwd ? pout[pi].ndom : 0;
+}
+// pair_region0[pi] = seg_region_start[seg] + (pref[pi] - pref[seg_pair_start[seg]])
+__global__ void __launch_bounds__(256) k_region_offsets(int64_t npairs, const PairRec *__restrict__ pairs, const int32_t *__restrict__ pref,
+                                                        const int64_t *__restrict__ seg_pair_start, const int64_t *__restrict__ seg_region_start,
+                                                        int64_t *__restrict__ pair_region0)
+{
+  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= npairs) return;
+  const int seg = pairs[pi].prof;
+  if (seg < 0) { pair_region0[pi] = 0; return; }
+  pair_region0[pi] = seg_region_start[seg] + (int64_t)(pref[pi] - pref[seg_pair_start[seg]]);
+}
+
+// final thresholds + the ItsPosition argmax
+__global__ void __launch_bounds__(256) k_finalize(itsx_domain *__restrict__ dom, int64_t n, const int64_t *__restrict__ domz, double domE)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  itsx_domain d = dom[i];
+  if (d.dom_idx < 0) return;
+  const int rep = d.seq_reported && (det_exp(d.lnP) * (double)domz[d.prof] <= domE);
+  dom[i].dom_reported = rep;
+}
+// key = [24b tenths+bias][20b ~prof][4b ~dom][16b coordinate]; atomicMax picks the highest %.1f score,
+// then the earliest profile, then the earliest domain -- ItsPosition._score's "first strictly greater".
+__global__ void __launch_bounds__(256) k_positions(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ side /*[P] 1 left 2 right*/,
+                                                   unsigned long long *__restrict__ best_l, unsigned long long *__restrict__ best_r,
+                                                   int32_t *__restrict__ in_ddict)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const itsx_domain d = dom[i];
+  if (d.dom_idx < 0 || !d.dom_reported) return;
+  in_ddict[d.rep] = 1;
+  const int sd = side[d.prof];
+  if (sd == 0) return;
+  long long tenths = (long long)__builtin_rint((double)d.bitscore * 10.0) + (1ll << 23);
+  if (tenths < 0) tenths = 0; if (tenths > (1ll << 24) - 1) tenths = (1ll << 24) - 1;
+  const unsigned long long coord = (unsigned long long)((sd == 1 ? d.jenv : d.ienv) & 0xffff);
+  const unsigned long long key = ((unsigned long long)tenths << 40) | ((unsigned long long)(0xFFFFF - d.prof) << 20) |
+                                 ((unsigned long long)(15 - (d.dom_idx & 15)) << 16) | coord;
+  atomicMax(sd == 1 ? &best_l[d.rep] : &best_r[d.rep], key);
+}
+
+// ---- host launchers -----------------------------------------------------------------------
+void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
+{
+  if (nwaves <= 0) return;
+  if (generic_q) hipLaunchKernelGGL(k_filters_fwd<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  else           hipLaunchKernelGGL(k_filters_fwd<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+}
+void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
+{
+  if (nwaves <= 0) return;
+  if (generic_q) hipLaunchKernelGGL(k_bwd_decode<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  else           hipLaunchKernelGGL(k_bwd_decode<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+}
+void launch_envelopes(const EnvArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
+{
+  if (nwaves <= 0) return;
+  if (generic_q) hipLaunchKernelGGL(k_envelopes<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  else           hipLaunchKernelGGL(k_envelopes<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+}
+void launch_score(const ScoreArgs &a, hipStream_t st)
+{
+  if (a.npairs <= 0) return;
+  hipLaunchKernelGGL(k_score, dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_region_counts(const PairOut *pout, int64_t npairs, int32_t *cnt, hipStream_t st)
+{
+  if (npairs <= 0) return;
+  hipLaunchKernelGGL(k_region_counts, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, npairs, cnt);
+}
+void launch_region_offsets(int64_t npairs, const PairRec *pairs, const int32_t *pref, const int64_t *seg_pair_start,
+                           const int64_t *seg_region_start, int64_t *pair_region0, hipStream_t st)
+{
+  if (npairs <= 0) return;
+  hipLaunchKernelGGL(k_region_offsets, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, npairs, pairs, pref, seg_pair_start, seg_region_start, pair_region0);
+}
+void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int64_t *pair_region0, RegionRec *out, hipStream_t st)
+{
+  if (npairs <= 0) return;
+  hipLaunchKernelGGL(k_region_fill, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, pair_region0, out);
+}
+void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, domz, domE);
+}
+void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, unsigned long long *bl, unsigned long long *br,
+                      int32_t *in_ddict, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, side, bl, br, in_ddict);
+}
+
+}  // namespace itsx

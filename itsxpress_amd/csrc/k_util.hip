@@ -1,0 +1,76 @@
+// k_util.hip -- small device utilities: multi-level exclusive scan, device detmath probe.
+#include "engine.h"
+#include "k_api.h"
+#include "detmath.h"
+
+namespace itsx {
+
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;   // 2048 elements per block
+
+// per-block exclusive scan; block totals to sums[blockIdx.x]
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                           int64_t n, int32_t *__restrict__ sums)
+{
+  __shared__ int32_t wsum[SCAN_BLOCK / 64];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int32_t v[SCAN_ITEMS];
+  int32_t tsum = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0; tsum += v[i]; }
+  // inclusive scan of tsum across the wave
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int32_t inc = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  int32_t woff = 0;
+  for (int w = 0; w < wid; w++) woff += wsum[w];
+  int32_t run = woff + inc - tsum;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+  if (threadIdx.x == SCAN_BLOCK - 1 && sums) sums[blockIdx.x] = run;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(int32_t *__restrict__ out, int64_t n, const int32_t *__restrict__ offs)
+{
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  const int32_t o = offs[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) out[base + i] += o;
+}
+
+int64_t scan_tmp_elems(int64_t n)
+{
+  int64_t tot = 0;
+  while (n > SCAN_TILE) { n = (n + SCAN_TILE - 1) / SCAN_TILE; tot += n + 8; }
+  return tot + 8;
+}
+
+void launch_exclusive_scan(const int32_t *in, int32_t *out, int64_t n, int32_t *tmp, hipStream_t st)
+{
+  if (n <= 0) return;
+  const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb == 1) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, st, in, out, n, (int32_t *)nullptr);
+    return;
+  }
+  int32_t *sums = tmp;
+  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, in, out, n, sums);
+  launch_exclusive_scan(sums, sums, nb, tmp + nb + 8, st);   // in-place is safe: each block reads its tile before writing it
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, out, n, sums);
+}
+
+__global__ void k_detmath(const double *__restrict__ x, int64_t n, double *__restrict__ ol, double *__restrict__ oe)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { ol[i] = det_log(x[i]); oe[i] = det_exp(x[i]); }
+}
+void launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_detmath, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, ol, oe);
+}
+
+}  // namespace itsx

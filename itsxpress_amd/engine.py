@@ -1,0 +1,257 @@
+"""Engine: a thin object wrapper over the C ABI (one context = one GPU).
+
+Nothing here computes: every method forwards to libitsx_hip.so and copies results into numpy
+arrays the caller owns.  See include/itsx_hip.h for the reference interface each call replaces.
+"""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import DOMAIN_DTYPE, STATS_DTYPE, TRACE_DTYPE, EngineError
+
+
+def _device_from_env():
+    for k in ("ITSXPRESS_GPU", "LOCAL_RANK"):
+        v = os.environ.get(k)
+        if v is not None and v.strip() != "":
+            return int(v)
+    return 0
+
+
+class Engine:
+    def __init__(self, device=None):
+        self.L = _lib.lib()
+        if device is None:
+            device = _device_from_env()
+        self.h = self.L.itsx_create(int(device), 0)
+        if not self.h:
+            msg = self.L.itsx_last_error(None).decode()
+            raise EngineError(-4, msg)
+        self.device = int(device)
+        self.n_reads = 0
+        self.n_unique = 0
+        self.n_profiles = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.itsx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.L.itsx_last_error(self.h).decode())
+
+    # ---- profiles
+    def load_profiles(self, path=None, text=None):
+        n = C.c_int(0)
+        if path is not None:
+            if not os.path.exists(path):
+                raise FileNotFoundError(path)
+            self._chk(self.L.itsx_load_profiles_file(self.h, os.fsencode(path), C.byref(n)))
+        else:
+            if isinstance(text, str):
+                text = text.encode()
+            self._chk(self.L.itsx_load_profiles_mem(self.h, text, len(text), C.byref(n)))
+        self.n_profiles = n.value
+        return n.value
+
+    def profile_names(self):
+        buf = C.create_string_buffer(256)
+        out = []
+        for i in range(self.n_profiles):
+            self._chk(self.L.itsx_profile_name(self.h, i, buf, 256))
+            out.append(buf.value.decode())
+        return out
+
+    def profile_tables(self, i):
+        p = np.zeros(6, np.int32)
+        self._chk(self.L.itsx_profile_tables(self.h, i, None, None, None, p.ctypes.data))
+        M, Q = int(p[0]), int(p[1])
+        rbv = np.zeros((18, M + 1), np.uint8)
+        rfv = np.zeros((18, Q, 4), np.float32)
+        tfv = np.zeros((8 * Q, 4), np.float32)
+        self._chk(self.L.itsx_profile_tables(self.h, i, rbv.ctypes.data, rfv.ctypes.data, tfv.ctypes.data, p.ctypes.data))
+        return dict(M=M, Q=Q, base=int(p[2]), bias=int(p[3]), tbm=int(p[4]), tec=int(p[5]), rbv=rbv, rfv=rfv, tfv=tfv)
+
+    # ---- reads
+    def set_reads(self, seqs, names=None):
+        """seqs: list[str] (or list[bytes]); names: optional list[str]."""
+        n = len(seqs)
+        lens = np.fromiter((len(s) for s in seqs), np.int64, n)
+        offs = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=offs[1:])
+        blob = ("".join(seqs)).encode() if (n and isinstance(seqs[0], str)) else b"".join(seqs)
+        return self.set_reads_buffer(blob, offs, names)
+
+    def set_reads_buffer(self, blob, offsets, names=None):
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        nb = no = None
+        if names is not None:
+            nl = np.fromiter((len(s) for s in names), np.int64, n)
+            no = np.zeros(n + 1, np.int64)
+            np.cumsum(nl, out=no[1:])
+            nb = "".join(names).encode()
+        cbuf = C.c_char_p(blob) if len(blob) else C.c_char_p(b"")
+        self._keep = (blob, offsets, nb, no)
+        self._chk(self.L.itsx_set_reads(self.h, C.cast(cbuf, C.c_void_p), offsets.ctypes.data, n,
+                                        C.cast(C.c_char_p(nb), C.c_void_p) if nb is not None else None,
+                                        no.ctypes.data if no is not None else None))
+        self.n_reads = n
+        return n
+
+    def load_reads_file(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        n = C.c_int64(0)
+        self._chk(self.L.itsx_load_reads_file(self.h, os.fsencode(path), C.byref(n)))
+        self.n_reads = n.value
+        return n.value
+
+    # ---- derep
+    def derep(self, strand_both=True, minseqlength=32):
+        n = C.c_int64(0)
+        self._chk(self.L.itsx_derep(self.h, int(strand_both), int(minseqlength), C.byref(n)))
+        self.n_unique = n.value
+        return n.value
+
+    def cluster(self, cluster_id, strand_both=True):
+        n = C.c_int64(0)
+        self._chk(self.L.itsx_cluster(self.h, float(cluster_id), int(strand_both), C.byref(n)))
+        self.n_unique = n.value
+        return n.value
+
+    def get_derep(self):
+        rep_of = np.zeros(self.n_reads, np.int64)
+        strand = np.zeros(self.n_reads, np.int8)
+        uniq_of = np.zeros(self.n_reads, np.int64)
+        self._chk(self.L.itsx_get_derep(self.h, rep_of.ctypes.data, strand.ctypes.data, uniq_of.ctypes.data))
+        return rep_of, strand, uniq_of
+
+    def get_uniques(self):
+        seed = np.zeros(self.n_unique, np.int64)
+        ab = np.zeros(self.n_unique, np.int64)
+        self._chk(self.L.itsx_get_uniques(self.h, seed.ctypes.data, ab.ctypes.data))
+        return seed, ab
+
+    # ---- search
+    def search(self, T=10.0, F1=1e-6, F2=1e-6, F3=1e-6):
+        self._chk(self.L.itsx_search(self.h, T, F1, F2, F3))
+
+    def get_domz(self):
+        z = np.zeros(self.n_profiles, np.int64)
+        self._chk(self.L.itsx_get_domz(self.h, z.ctypes.data))
+        return z
+
+    def set_domz(self, z):
+        z = np.ascontiguousarray(z, np.int64)
+        self._chk(self.L.itsx_set_domz(self.h, z.ctypes.data))
+
+    def finalize(self, domE=10.0):
+        self._chk(self.L.itsx_search_finalize(self.h, domE))
+
+    def domains(self):
+        n = self.L.itsx_num_domains(self.h)
+        if n < 0:
+            raise EngineError(-1, self.L.itsx_last_error(self.h).decode())
+        out = np.zeros(n, DOMAIN_DTYPE)
+        if n:
+            self._chk(self.L.itsx_get_domains(self.h, out.ctypes.data))
+        return out
+
+    def pairtraces(self):
+        n = self.L.itsx_num_pairtraces(self.h)
+        if n < 0:
+            raise EngineError(-1, self.L.itsx_last_error(self.h).decode())
+        out = np.zeros(n, TRACE_DTYPE)
+        if n:
+            self._chk(self.L.itsx_get_pairtraces(self.h, out.ctypes.data))
+        return out
+
+    def _coords(self, fn, n, left, right):
+        a = [np.zeros(max(n, 1), np.int32) for _ in range(4)]
+        self._chk(fn(self.h, left.encode(), right.encode(), *[x.ctypes.data for x in a]))
+        return tuple(x[:n] for x in a)
+
+    def trim_coords(self, left, right):
+        """per READ: start, stop, tlen (-1 = None), in_ddict."""
+        return self._coords(self.L.itsx_trim_coords, self.n_reads, left, right)
+
+    def rep_coords(self, left, right):
+        return self._coords(self.L.itsx_rep_coords, self.n_unique, left, right)
+
+    # ---- writers
+    def write_uc(self, path):
+        self._chk(self.L.itsx_write_uc(self.h, os.fsencode(path)))
+
+    def write_rep_fasta(self, path):
+        self._chk(self.L.itsx_write_rep_fasta(self.h, os.fsencode(path)))
+
+    def write_domtbl(self, path):
+        self._chk(self.L.itsx_write_domtbl(self.h, os.fsencode(path)))
+
+    def stats(self):
+        s = np.zeros(1, STATS_DTYPE)
+        self._chk(self.L.itsx_get_stats(self.h, s.ctypes.data))
+        return {k: s[0][k].item() for k in STATS_DTYPE.names}
+
+    # ---- test hooks
+    def debug_read_hashes(self):
+        f = np.zeros(self.n_reads, np.uint64)
+        r = np.zeros(self.n_reads, np.uint64)
+        self._chk(self.L.itsx_debug_read_hashes(self.h, f.ctypes.data, r.ctypes.data))
+        return f, r
+
+    def debug_packed_read(self, i):
+        nw, ne = C.c_int32(0), C.c_int32(0)
+        self._chk(self.L.itsx_debug_packed_read(self.h, i, None, C.byref(nw), None, C.byref(ne)))
+        w = np.zeros(max(nw.value, 1), np.uint32)
+        e = np.zeros(max(ne.value, 1), np.uint32)
+        self._chk(self.L.itsx_debug_packed_read(self.h, i, w.ctypes.data, C.byref(nw), e.ctypes.data, C.byref(ne)))
+        return w[:nw.value], e[:ne.value]
+
+    def debug_detmath(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        a = np.zeros_like(x)
+        b = np.zeros_like(x)
+        self._chk(self.L.itsx_debug_detmath(self.h, x.ctypes.data, len(x), a.ctypes.data, b.ctypes.data))
+        return a, b
+
+
+def read_fastx(path):
+    """Minimal FASTA/FASTQ(.gz) reader used by tests and the bench: returns (names, seqs)."""
+    op = gzip.open if str(path).endswith(".gz") else open
+    names, seqs = [], []
+    with op(path, "rt") as f:
+        first = f.readline()
+        if not first:
+            return names, seqs
+        if first[0] == "@":
+            line = first
+            while line:
+                names.append(line[1:].split()[0])
+                seqs.append(f.readline().rstrip("\n"))
+                f.readline()
+                f.readline()
+                line = f.readline()
+        else:
+            cur = []
+            names.append(first[1:].split()[0])
+            for line in f:
+                if line[0] == ">":
+                    seqs.append("".join(cur))
+                    cur = []
+                    names.append(line[1:].split()[0])
+                else:
+                    cur.append(line.strip())
+            seqs.append("".join(cur))
+    return names, seqs

@@ -1,0 +1,71 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def gold():
+    return GOLD
+
+
+@pytest.fixture(scope="session")
+def fixture_reads():
+    import gzip
+    names, seqs = [], []
+    with gzip.open(os.path.join(GOLD, "fixture_reads.fa.gz"), "rt") as f:
+        for line in f:
+            if line[0] == ">":
+                names.append(line[1:].strip())
+            else:
+                seqs.append(line.strip())
+    return names, seqs
+
+
+@pytest.fixture(scope="session")
+def mini_hmm_text():
+    with open(os.path.join(GOLD, "mini.hmm")) as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def t_hmm_text():
+    import gzip
+    with gzip.open(os.path.join(GOLD, "T.hmm.gz"), "rt") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def engine():
+    from itsxpress_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()

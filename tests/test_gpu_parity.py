@@ -1,0 +1,296 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle and the golden
+fixtures.  Bar: bit-exact -- trim coordinates, cluster maps, MSV bytes and every float score
+are compared for equality, not closeness.  Run on the GPU box with `pytest -m gpu`.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _its2_subset(hmm_text, n3=None, n4=None):
+    blocks = [b + "//\n" for b in hmm_text.split("//\n") if "NAME  " in b]
+    l3 = [b for b in blocks if b.split("NAME  ")[1].startswith("3_")]
+    l4 = [b for b in blocks if b.split("NAME  ")[1].startswith("4_")]
+    return "".join(l3[:n3] + l4[:n4])
+
+
+# --------------------------------------------------------------------------------------------
+def test_library_loads_and_reports_device(engine):
+    assert engine.L.itsx_abi_version() == 1
+
+
+def test_detmath_device_matches_oracle_bitwise(engine):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.exp(rng.uniform(-80, 80, 200000)), rng.uniform(1e-3, 4e4, 100000),
+                        np.float32(rng.uniform(0.5, 1.5, 100000)).astype(np.float64)])
+    dl, _ = engine.debug_detmath(x)
+    L = orc.lib()
+    ol = np.array([L.orc_det_log(float(v)) for v in x[:50000]])
+    assert np.array_equal(dl[:50000].view(np.uint64), ol.view(np.uint64))
+    y = rng.uniform(-60, 60, 50000)
+    _, de = engine.debug_detmath(y)
+    oe = np.array([L.orc_det_exp(float(v)) for v in y])
+    assert np.array_equal(de.view(np.uint64), oe.view(np.uint64))
+    # and both agree with libm after rounding to float (what the pipeline stores)
+    assert np.array_equal(np.float32(dl), np.float32(np.log(x)))
+
+
+def test_profile_tables_match_oracle(engine, mini_hmm_text):
+    n = engine.load_profiles(text=mini_hmm_text)
+    hs = orc.HmmSet(text=mini_hmm_text)
+    assert n == hs.n and engine.profile_names() == hs.names
+    for i in range(n):
+        t = engine.profile_tables(i)
+        assert t["M"] == hs.M[i]
+        assert np.array_equal(t["rbv"], hs.rbv(i))
+        assert np.array_equal(_bits(t["rfv"]), _bits(hs.rfv(i)))
+        assert np.array_equal(_bits(t["tfv"]), _bits(hs.tfv(i)))
+        assert {k: t[k] for k in ("base", "bias", "tbm", "tec")} == hs.msvparams(i)
+
+
+def test_packed_keys_hash_like_xxhash(engine):
+    import xxhash
+    rng = np.random.default_rng(5)
+    seqs = []
+    for L in [32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 129, 300, 301, 441, 1000]:
+        s = "".join(rng.choice(list("ACGT"), L))
+        seqs.append(s)
+        s2 = list(s)
+        for p in rng.choice(L, 3, replace=False):
+            s2[p] = rng.choice(list("NRYKMSWBDHV"))
+        seqs.append("".join(s2))
+    engine.set_reads(seqs)
+    hf, hr = engine.debug_read_hashes()
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "R": "Y", "Y": "R", "M": "K", "K": "M",
+            "S": "S", "W": "W", "H": "D", "D": "H", "B": "V", "V": "B"}
+    code = {c: i for i, c in enumerate("ACGT-RYMKSWHBVDN")}
+
+    def key_bytes(s):
+        nw = max(1, (len(s) + 15) // 16)
+        w = np.zeros(nw, np.uint32)
+        exc = []
+        for i, ch in enumerate(s):
+            c = code[ch]
+            if c <= 3:
+                w[i >> 4] |= np.uint32(c << (2 * (i & 15)))
+            else:
+                exc.append((i << 4) | c)
+        return w.tobytes() + np.array(exc, np.uint32).tobytes() + np.uint32(len(s)).tobytes()
+
+    for i, s in enumerate(seqs):
+        w, e = engine.debug_packed_read(i)
+        assert (w.tobytes() + e.tobytes() + np.uint32(len(s)).tobytes()) == key_bytes(s)
+        assert int(hf[i]) == xxhash.xxh64(key_bytes(s), seed=0).intdigest(), (i, len(s))
+        rc = "".join(comp[c] for c in reversed(s))
+        assert int(hr[i]) == xxhash.xxh64(key_bytes(rc), seed=0).intdigest(), (i, len(s))
+
+
+# --------------------------------------------------------------------------------------------
+def test_derep_reproduces_reference_fixture(engine, fixture_reads, gold, tmp_path):
+    """a1 + a7: the frozen vsearch output of the reference's own tests (ex_tmpdir/uc.txt, rep.fa)."""
+    names, seqs = fixture_reads
+    engine.set_reads(seqs, names)
+    nu = engine.derep()
+    assert nu == 137
+    rep_of, strand, uniq_of = engine.get_derep()
+    md = json.load(open(os.path.join(gold, "matchdict.json")))
+    assert len(md) == 227
+    for i, nm in enumerate(names):
+        assert names[int(rep_of[i])] == md[nm]
+    assert (strand == 1).all()
+    uc, fa = str(tmp_path / "uc.txt"), str(tmp_path / "rep.fa")
+    engine.write_uc(uc)
+    engine.write_rep_fasta(fa)
+    assert open(uc).read() == open(os.path.join(gold, "fixture_uc.txt")).read()
+    assert open(fa).read() == open(os.path.join(gold, "fixture_rep.fa")).read()
+
+
+def test_derep_matches_oracle_on_synthetic(engine, t_hmm_text):
+    blob, offs = synth.make_reads(t_hmm_text, 50000, seed=11)
+    seqs = synth.to_strings(blob, offs)
+    # edge cases: empty-ish/short reads (dropped), palindromes, an exact reverse complement pair with N
+    seqs += ["ACGT" * 7, "ACGT" * 8, "ACGT" * 8, "A" * 31, "ACGTNACGT" * 5, "ACGTNACGT"[::-1].translate(str.maketrans("ACGT", "TGCA")) * 5]
+    engine.set_reads(seqs)
+    nu = engine.derep()
+    rep_of, strand, _ = engine.get_derep()
+    codes, o = orc.digitize(seqs)
+    nc, orep, ostrand = orc.derep(codes, o)
+    assert nu == nc
+    assert np.array_equal(rep_of, orep)
+    assert np.array_equal(strand, ostrand)
+    assert (strand == -1).sum() > 100 and (rep_of == -1).sum() == 2
+    st = engine.stats()
+    assert st["hash_reseeds"] == 0
+
+
+def test_derep_forward_only_and_ragged_lengths(engine):
+    rng = np.random.default_rng(3)
+    base = ["".join(rng.choice(list("ACGT"), int(L))) for L in rng.integers(32, 700, 300)]
+    seqs = [base[i] for i in rng.integers(0, 300, 2000)]
+    engine.set_reads(seqs)
+    for both in (True, False):
+        nu = engine.derep(strand_both=both)
+        rep_of, strand, _ = engine.get_derep()
+        codes, o = orc.digitize(seqs)
+        nc, orep, ostrand = orc.derep(codes, o, strand_both=both)
+        assert nu == nc and np.array_equal(rep_of, orep) and np.array_equal(strand, ostrand)
+
+
+# --------------------------------------------------------------------------------------------
+def _run_both(engine, hmm_text, seqs, threads=8):
+    engine.load_profiles(text=hmm_text)
+    engine.set_reads(seqs)
+    engine.derep()
+    engine.search()
+    engine.finalize()
+    seed, _ = engine.get_uniques()
+    useqs = [seqs[int(i)] for i in seed]
+    codes, o = orc.digitize(useqs)
+    res = orc.SearchResult(orc.HmmSet(text=hmm_text), codes, o, threads=threads, keep_trace=1)
+    return res
+
+
+def _compare(engine, res, left="3_", right="4_"):
+    tr = engine.pairtraces()
+    ot = res.trace
+    assert len(tr) == len(ot), (len(tr), len(ot))
+    assert np.array_equal(tr["rep"], ot["seq"]) and np.array_equal(tr["prof"], ot["prof"])
+    assert np.array_equal(tr["msv_xj"], ot["msv_xj"])
+    for f in ("msv_sc", "nullsc", "filtersc"):
+        assert np.array_equal(_bits(tr[f]), _bits(ot[f])), f
+    assert np.array_equal(tr["pass_bias"], ot["pass_bias"])
+    pb = ot["pass_bias"] == 1
+    assert np.array_equal(_bits(tr["fwdsc"][pb]), _bits(ot["fwdsc"][pb]))
+    assert np.array_equal(tr["pass_fwd"], ot["pass_fwd"])
+    pf = ot["pass_fwd"] == 1
+    assert np.array_equal(_bits(tr["bcksc"][pf]), _bits(ot["bcksc"][pf]))
+    assert np.array_equal(tr["nregions"][pf], ot["nregions"][pf])
+    assert np.array_equal(tr["ndom"][pf], ot["ndom"][pf])
+    d, od = engine.domains(), res.domains
+    assert len(d) == len(od)
+    for f in ("rep", "prof", "tlen", "ienv", "jenv", "dom_idx", "ndom", "seq_reported", "dom_reported"):
+        assert np.array_equal(d[f], od["seq" if f == "rep" else f]), f
+    assert np.array_equal(d["flags"] & 1, od["flags"] & 1)
+    for f in ("envsc", "domcorrection", "dombias", "bitscore", "seq_score", "seq_bias"):
+        assert np.array_equal(_bits(d[f]), _bits(od[f])), f
+    assert np.array_equal(d["lnP"].view(np.uint64), od["lnP"].view(np.uint64))
+    got = engine.rep_coords(left, right)
+    exp = res.positions(left, right)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    c = res.counts
+    s = engine.stats()
+    assert (s["n_past_msv"], s["n_past_bias"], s["n_past_fwd"]) == (c["past_msv"], c["past_bias"], c["past_fwd"])
+
+
+def test_search_fixture_mini_profiles(engine, fixture_reads, mini_hmm_text):
+    """a4-a6 on the reference's fixture reads, 10 profiles incl. the two short (M=25, 11) models."""
+    names, seqs = fixture_reads
+    res = _run_both(engine, mini_hmm_text, seqs)
+    _compare(engine, res)
+    _compare(engine, res, "1_", "2_")
+    _compare(engine, res, "1_", "4_")
+
+
+def test_search_synthetic_tracheophyta_its2(engine, t_hmm_text):
+    """stand-in taxon (Tracheophyta), ITS2 profiles, synthetic reads incl. N and reverse complements."""
+    blob, offs = synth.make_reads(t_hmm_text, 600, seed=21)
+    seqs = synth.to_strings(blob, offs)
+    hmm = _its2_subset(t_hmm_text)
+    res = _run_both(engine, hmm, seqs)
+    assert res.counts["past_fwd"] > 1000
+    _compare(engine, res)
+
+
+def test_search_ragged_lengths_and_edge_cases(engine, t_hmm_text):
+    blob, offs = synth.make_reads(t_hmm_text, 300, seed=22, fixed_len=0, len_range=(120, 520))
+    seqs = synth.to_strings(blob, offs)
+    rng = np.random.default_rng(9)
+    seqs += ["".join(rng.choice(list("ACGT"), 40)), "N" * 64, "ACGTRYKMSWBDHVN" * 8, seqs[0] + seqs[1]]
+    hmm = _its2_subset(t_hmm_text, 20, 20)
+    res = _run_both(engine, hmm, seqs)
+    _compare(engine, res)
+
+
+def test_trim_coords_per_read_follow_matchdict(engine, fixture_reads, mini_hmm_text):
+    names, seqs = fixture_reads
+    res = _run_both(engine, mini_hmm_text, seqs)
+    start, stop, tlen, ind = engine.trim_coords("3_", "4_")
+    _, _, uniq_of = engine.get_derep()
+    us, ue, ut, ui = res.positions("3_", "4_")
+    assert np.array_equal(start, us[uniq_of]) and np.array_equal(stop, ue[uniq_of])
+    assert np.array_equal(tlen, ut[uniq_of]) and np.array_equal(ind, ui[uniq_of])
+
+
+def test_domz_override_changes_only_domain_reporting(engine, fixture_reads, mini_hmm_text):
+    """multi-GPU hook: the all-reduced domZ is applied by itsx_search_finalize."""
+    names, seqs = fixture_reads
+    res = _run_both(engine, mini_hmm_text, seqs)
+    z = engine.get_domz()
+    big = z * 10 ** 9
+    engine.set_domz(big)
+    engine.finalize()
+    d = engine.domains()
+    res2 = orc.SearchResult(res.hs, *res._keep, threads=4, domZ=big)
+    assert np.array_equal(d["dom_reported"], res2.domains["dom_reported"])
+    assert d["dom_reported"].sum() < res.domains["dom_reported"].sum()
+
+
+def test_file_compatible_outputs_feed_the_reference_parsers(engine, fixture_reads, mini_hmm_text, tmp_path):
+    """SeqSample.deduplicate/_search write uc.txt / rep.fa / domtbl.txt that the mirror parsers read back
+    into the same dicts the array fast path gives."""
+    from itsxpress_amd import Dedup, ItsPosition, SeqSampleNotPaired
+    names, seqs = fixture_reads
+    fq = tmp_path / "seq.fq"
+    with open(fq, "w") as f:
+        for n, s in zip(names, seqs):
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    hmm = tmp_path / "mini.hmm"
+    hmm.write_text(mini_hmm_text)
+    s = SeqSampleNotPaired(str(fq), str(tmp_path))
+    s.deduplicate(threads=1)
+    s._search(hmmfile=str(hmm), threads=1)
+    assert os.path.exists(s.uc_file) and os.path.exists(s.rep_file) and os.path.exists(s.dom_file)
+    dd = Dedup(s.uc_file, s.rep_file, s.seq_file)
+    assert len(dd.matchdict) == 227
+    ip = ItsPosition(s.dom_file, "ITS2")
+    seed, _ = s.engine.get_uniques()
+    unames = [names[int(i)] for i in seed]
+    ip2 = ItsPosition.from_engine(s.engine, "ITS2", unames)
+    assert ip.ddict == ip2.ddict
+    start, stop, tlen, ind = s.trim_coordinates("ITS2")
+    for i, nm in enumerate(names):
+        rep = dd.matchdict[nm]
+        if rep in ip.ddict:
+            a, b, t = ip.get_position(rep)
+            assert (a if a is not None else -1, b if b is not None else -1, t if t is not None else -1) == \
+                (int(start[i]), int(stop[i]), int(tlen[i]))
+        else:
+            assert ind[i] == 0
+
+
+def test_errors_are_loud(engine, tmp_path):
+    from itsxpress_amd import EngineError
+    with pytest.raises(EngineError):
+        engine.load_profiles(text="HMMER3/f\nNAME x\nLENG 3\n")
+    with pytest.raises(EngineError):
+        engine.set_reads(["ACGT!ACGT" * 5])
+    with pytest.raises(FileNotFoundError):
+        engine.load_profiles(path=str(tmp_path / "nope.hmm"))
+    engine.set_reads(["ACGT" * 10])
+    with pytest.raises(EngineError):
+        engine.cluster(0.995)
+    engine.derep()
+    with pytest.raises(EngineError):
+        engine.search(F1=1e-6, F2=1e-3)

@@ -651,7 +651,7 @@ orc_results *orc_search(const orc_hmmset *hs, const uint8_t *codes, const int64_
     workspace w; memset(&w, 0, sizeof(w));
     uint8_t *dsq = NULL; int64_t dcap = 0;
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 16)
+#pragma omp for schedule(dynamic, 1)
 #endif
     for (int64_t s = 0; s < nseq; s++) {
       int L = (int)(offsets[s + 1] - offsets[s]);

@@ -36,6 +36,8 @@ uint8_t host_tjb_b(int L);
 // ---- device-side model block: one per profile, read with scalar loads (wave-uniform) ----
 struct DevProfile {
   float tf[QMAX * 8 * 4];       // [q][t][z], t: BM MM IM DM MD MI II DD
+  float tb[QMAX * 6 * 4];       // Backward's main loop, per q: II(q) MI(q) BM(q) MM(q+1) IM(q+1) DM(q+1), the
+                                // wrap-around at q = Q-1 (left shift of group 0) already applied
   float rf[NCODE * QMAX * 4];   // [code][q][z] match emission odds ratios
   float feo[NCODE * 2];         // bias-filter emission odds [code][state]
   float ft10, ft11, fpi0, fpi1; // bias-filter HMM
@@ -72,6 +74,7 @@ struct RegionRec {              // one envelope to re-score
 };
 struct RegionOut {
   float envsc;
+  float domcorrection;          // sum of n2log over the envelope's residues
   float n2log[NCODE];           // log null2 odds per residue code
   int32_t ok;
 };

@@ -44,6 +44,16 @@ __global__ void k_wave_rows_regions(const WaveDesc *w, int nw, const RegionRec *
   for (int k = 0; k < w[i].count; k++) { const RegionRec r = rg[w[i].first + k]; mx = max(mx, r.jenv - r.ienv + 1); }
   rows[i] = mx + 1;
 }
+__global__ void k_pair_counters(const PairOut *po, int64_t n, unsigned long long *c)
+{
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const PairOut o = po[i];
+    a0 += o.pass_bias; a1 += o.pass_fwd; a2 += o.pass_fwd ? o.nregions : 0; a3 += (o.flags & 2) ? 1 : 0;
+  }
+  for (int d = 32; d >= 1; d >>= 1) { a0 += __shfl_down(a0, d, 64); a1 += __shfl_down(a1, d, 64); a2 += __shfl_down(a2, d, 64); a3 += __shfl_down(a3, d, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&c[0], a0); atomicAdd(&c[1], a1); atomicAdd(&c[2], a2); atomicAdd(&c[3], a3); }
+}
 __global__ void k_gather_i32(const int32_t *src, const int64_t *idx, int n, int32_t *out)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,10 +85,24 @@ using namespace itsx;
 
 static std::string g_create_error;
 
+// device buffer that only ever grows: hipMalloc/hipFree of multi-GB buffers costs far more than the
+// kernels that use them, so every work buffer is kept in the context between calls
 template <class T> struct DBuf {
-  T *p = nullptr; size_t n = 0;
-  hipError_t alloc(size_t count) { release(); n = count; if (!count) return hipSuccess; return hipMalloc((void **)&p, count * sizeof(T)); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  T *p = nullptr; size_t n = 0, cap = 0;
+  hipError_t alloc(size_t count)
+  {
+    n = count;
+    if (count <= cap && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    if (!count) return hipSuccess;
+    const size_t want = count + count / 8 + 64;
+    hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (e != hipSuccess) { e = hipMalloc((void **)&p, count * sizeof(T)); if (e != hipSuccess) return e; cap = count; return e; }
+    cap = want;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; cap = 0; }
   ~DBuf() { release(); }
 };
 
@@ -135,6 +159,14 @@ struct itsx_ctx {
   std::vector<int64_t> domz;
   std::vector<itsx_domain> h_dom;        // valid rows, domtblout order
   std::vector<itsx_pairtrace> h_trace;
+
+  // ---- persistent work buffers (see DBuf)
+  DBuf<uint64_t> w_hf, w_hr; DBuf<unsigned long long> w_keys; DBuf<int32_t> w_vals, w_is_seed, w_seed_rank, w_scan_tmp, w_hist, w_cursor, w_tmp2;
+  DBuf<uint32_t> w_slot_of; DBuf<unsigned int> w_ncoll;
+  DBuf<uint16_t> w_thr, w_res; DBuf<int32_t> w_tjb, w_cnt, w_total, w_rows, w_rcnt, w_rpref, w_scan2, w_b, w_rrows;
+  DBuf<int64_t> w_seg_start, w_idx, w_rseg, w_dz, w_counters;
+  DBuf<WaveDesc> w_waves, w_rw; DBuf<RegionRec> w_raw; DBuf<float> w_slab, w_eslab;
+  DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri;
 };
 
 #define CTXCHK(c)                                   \
@@ -228,6 +260,17 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
     for (int q = 0; q < h.Q; q++) {
       for (int t = 0; t < 7; t++) for (int z = 0; z < 4; z++) d.tf[(q * 8 + t) * 4 + z] = h.tfv[((size_t)q * 7 + t) * 4 + z];
       for (int z = 0; z < 4; z++) d.tf[(q * 8 + 7) * 4 + z] = h.tfv[((size_t)7 * h.Q + q) * 4 + z];
+    }
+    for (int q = 0; q < h.Q; q++) {
+      const int order[3] = {6, 5, 0};      // II MI BM of this group
+      for (int k = 0; k < 3; k++) for (int z = 0; z < 4; z++) d.tb[(q * 6 + k) * 4 + z] = d.tf[(q * 8 + order[k]) * 4 + z];
+      for (int k = 0; k < 3; k++)          // MM IM DM of the next group; group Q-1 wraps to group 0 shifted left by one lane
+        for (int z = 0; z < 4; z++) {
+          float v;
+          if (q + 1 < h.Q) v = d.tf[((q + 1) * 8 + 1 + k) * 4 + z];
+          else v = (z < 3) ? d.tf[(0 * 8 + 1 + k) * 4 + z + 1] : 0.0f;
+          d.tb[(q * 6 + 3 + k) * 4 + z] = v;
+        }
     }
     for (int x = 0; x < NCODE; x++)
       for (int q = 0; q < h.Q; q++) for (int z = 0; z < 4; z++) d.rf[(x * QMAX + q) * 4 + z] = h.rfv[((size_t)x * h.Q + q) * 4 + z];
@@ -445,7 +488,9 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = ctx->N;
   StageTimer tm(ctx->st);
-  DBuf<uint64_t> hf, hr; DBuf<unsigned long long> keys; DBuf<int32_t> vals, is_seed, seed_rank, scan_tmp; DBuf<uint32_t> slot_of; DBuf<unsigned int> ncoll;
+  DBuf<uint64_t> &hf = ctx->w_hf, &hr = ctx->w_hr; DBuf<unsigned long long> &keys = ctx->w_keys;
+  DBuf<int32_t> &vals = ctx->w_vals, &is_seed = ctx->w_is_seed, &seed_rank = ctx->w_seed_rank, &scan_tmp = ctx->w_scan_tmp;
+  DBuf<uint32_t> &slot_of = ctx->w_slot_of; DBuf<unsigned int> &ncoll = ctx->w_ncoll;
   HIPCHK(hf.alloc((size_t)n + 1)); HIPCHK(hr.alloc((size_t)n + 1));
   uint64_t tsize = 1024; while (tsize < (uint64_t)n * 2 + 16) tsize <<= 1;
   HIPCHK(keys.alloc(tsize)); HIPCHK(vals.alloc(tsize)); HIPCHK(slot_of.alloc((size_t)n + 1)); HIPCHK(ncoll.alloc(1));
@@ -486,7 +531,7 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
   // order the uniques by length (counting sort) for the HMM stages
   if (U > 0) {
     const int32_t lcap = 65536;
-    DBuf<int32_t> hist, cursor, tmp2;
+    DBuf<int32_t> &hist = ctx->w_hist, &cursor = ctx->w_cursor, &tmp2 = ctx->w_tmp2;
     HIPCHK(hist.alloc(lcap)); HIPCHK(cursor.alloc(lcap)); HIPCHK(tmp2.alloc((size_t)scan_tmp_elems(lcap)));
     HIPCHK(hipMemsetAsync(hist.p, 0, lcap * sizeof(int32_t), ctx->st));
     launch_len_hist(U, ctx->d_seed_read.p, ctx->rd.len, hist.p, lcap, ctx->st);
@@ -604,11 +649,11 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       thr[(size_t)L * Ppad + p] = (uint16_t)lo;
     }
   }
-  DBuf<uint16_t> d_thr; DBuf<int32_t> d_tjb;
+  DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
   HIPCHK(upload(ctx->d_lt, lt, st)); HIPCHK(upload(d_thr, thr, st)); HIPCHK(upload(d_tjb, tjb, st));
 
   // ---- MSV for every (unique, profile)
-  DBuf<uint16_t> d_res;
+  DBuf<uint16_t> &d_res = ctx->w_res;
   HIPCHK(d_res.alloc((size_t)Ppad * U));
   {
     MsvArgs a{};
@@ -630,7 +675,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   StageTimer tm_list(st);
   // ---- survivor list grouped by profile (64-aligned segments, ascending length)
   const int nchunks = (U + CHUNK - 1) / CHUNK;
-  DBuf<int32_t> d_cnt, d_total;
+  DBuf<int32_t> &d_cnt = ctx->w_cnt, &d_total = ctx->w_total;
   HIPCHK(d_cnt.alloc((size_t)P * nchunks)); HIPCHK(d_total.alloc((size_t)P));
   launch_pair_count(d_res.p, P, U, nchunks, d_cnt.p, st);
   launch_chunk_scan(d_cnt.p, P, nchunks, d_total.p, st);
@@ -644,13 +689,12 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   S.ms_msv = S.ms_msv_kernel;
   if (NP == 0) { S.ms_msv += tm_list.stop(); return ITSX_OK; }
   if (NP >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 surviving (representative, profile) pairs");
-  DBuf<int64_t> d_seg_start;
+  DBuf<int64_t> &d_seg_start = ctx->w_seg_start;
   HIPCHK(upload(d_seg_start, seg_start, st));
   HIPCHK(ctx->d_pairs.alloc((size_t)NP)); HIPCHK(ctx->d_pout.alloc((size_t)NP));
   HIPCHK(hipMemsetAsync(ctx->d_pairs.p, 0xFF, (size_t)NP * sizeof(PairRec), st));
   HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)NP * sizeof(PairOut), st));
   launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p, ctx->d_pairs.p, st);
-  d_res.release();
   // ---- wave descriptors
   std::vector<WaveDesc> waves;
   std::vector<char> wgeneric;
@@ -663,7 +707,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       }
     }
   const int NW = (int)waves.size();
-  DBuf<WaveDesc> d_waves; DBuf<int32_t> d_rows;
+  DBuf<WaveDesc> &d_waves = ctx->w_waves; DBuf<int32_t> &d_rows = ctx->w_rows;
   HIPCHK(upload(d_waves, waves, st)); HIPCHK(d_rows.alloc((size_t)NW));
   hipLaunchKernelGGL(k_wave_rows_pairs, dim3((NW + 255) / 256), dim3(256), 0, st, d_waves.p, NW, ctx->d_pairs.p, d_rows.p);
   std::vector<int32_t> rows((size_t)NW);
@@ -676,12 +720,12 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   if (const char *e = getenv("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));
   const int64_t row_bytes = 14 * 64 * 4;
   const int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
-  DBuf<RegionRec> d_raw;
+  DBuf<RegionRec> &d_raw = ctx->w_raw;
   HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));
   {
     StageTimer tm(st);
-    DBuf<float> d_slab;
-    int64_t slab_rows_alloc = 0;
+    DBuf<float> &d_slab = ctx->w_slab;
+    int64_t slab_rows_alloc = (int64_t)(d_slab.cap / (14 * 64));
     int w0 = 0;
     while (w0 < NW) {
       int w1 = w0; int64_t r = 0;
@@ -701,14 +745,14 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   }
   StageTimer tm_dom(st);
   // ---- compact regions into a profile-grouped list
-  DBuf<int32_t> d_rcnt, d_rpref, d_scan_tmp;
+  DBuf<int32_t> &d_rcnt = ctx->w_rcnt, &d_rpref = ctx->w_rpref, &d_scan_tmp = ctx->w_scan2;
   HIPCHK(d_rcnt.alloc((size_t)NP + 1)); HIPCHK(d_rpref.alloc((size_t)NP + 1)); HIPCHK(d_scan_tmp.alloc((size_t)scan_tmp_elems(NP + 1)));
   HIPCHK(hipMemsetAsync(d_rcnt.p, 0, ((size_t)NP + 1) * 4, st));
   launch_region_counts(ctx->d_pout.p, NP, d_rcnt.p, st);
   launch_exclusive_scan(d_rcnt.p, d_rpref.p, NP + 1, d_scan_tmp.p, st);
   std::vector<int32_t> bound((size_t)P + 1);
   {
-    DBuf<int64_t> d_idx; DBuf<int32_t> d_b;
+    DBuf<int64_t> &d_idx = ctx->w_idx; DBuf<int32_t> &d_b = ctx->w_b;
     HIPCHK(upload(d_idx, seg_start, st)); HIPCHK(d_b.alloc((size_t)P + 1));
     hipLaunchKernelGGL(k_gather_i32, dim3((P + 1 + 255) / 256), dim3(256), 0, st, d_rpref.p, d_idx.p, P + 1, d_b.p);
     HIPCHK(hipMemcpyAsync(bound.data(), d_b.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, st));
@@ -727,11 +771,10 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(ctx->d_domz32.alloc((size_t)P));
   HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * 4, st));
   if (NR > 0) {
-    DBuf<int64_t> d_rseg;
+    DBuf<int64_t> &d_rseg = ctx->w_rseg;
     HIPCHK(upload(d_rseg, rseg, st));
     launch_region_offsets(NP, ctx->d_pairs.p, d_rpref.p, d_seg_start.p, d_rseg.p, ctx->d_pair_region0.p, st);
     launch_region_fill(ctx->d_pout.p, d_raw.p, NP, ctx->d_pair_region0.p, ctx->d_regions.p, st);
-    d_raw.release();
     std::vector<WaveDesc> rw; std::vector<char> rgen;
     for (int pass = 0; pass < 2; pass++)
       for (int p = 0; p < P; p++) {
@@ -742,26 +785,25 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
         }
       }
     const int NRW = (int)rw.size();
-    DBuf<WaveDesc> d_rw; DBuf<int32_t> d_rrows;
+    DBuf<WaveDesc> &d_rw = ctx->w_rw; DBuf<int32_t> &d_rrows = ctx->w_rrows;
     HIPCHK(upload(d_rw, rw, st)); HIPCHK(d_rrows.alloc((size_t)NRW));
     hipLaunchKernelGGL(k_wave_rows_regions, dim3((NRW + 255) / 256), dim3(256), 0, st, d_rw.p, NRW, ctx->d_regions.p, d_rrows.p);
     std::vector<int32_t> rrows((size_t)NRW);
     HIPCHK(hipMemcpyAsync(rrows.data(), d_rrows.p, (size_t)NRW * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const int64_t erow_bytes = 204 * 64 * 4;
+    const int64_t erow_bytes = 101 * 64 * 4;
     const int64_t ebudget = (int64_t)(slab_gb * (1 << 30)) / erow_bytes;
-    DBuf<float> d_eslab; int64_t ealloc = 0;
+    DBuf<float> &d_eslab = ctx->w_eslab; int64_t ealloc = (int64_t)(d_eslab.cap / (101 * 64));
     int w0 = 0;
     while (w0 < NRW) {
       int w1 = w0; int64_t r = 0;
       while (w1 < NRW && rgen[w1] == rgen[w0] && (w1 == w0 || r + rrows[w1] <= ebudget)) { rw[w1].slab = r; rw[w1].rows = rrows[w1]; r += rrows[w1]; w1++; }
-      if (r > ealloc) { HIPCHK(d_eslab.alloc((size_t)r * 204 * 64)); ealloc = r; }
+      if (r > ealloc) { HIPCHK(d_eslab.alloc((size_t)r * 101 * 64)); ealloc = r; }
       HIPCHK(hipMemcpyAsync(d_rw.p + w0, rw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       EnvArgs a{};
       a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
       a.pairs = ctx->d_pairs.p; a.regions = ctx->d_regions.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
       launch_envelopes(a, w1 - w0, w0, rgen[w0], st);
-      HIPCHK(hipStreamSynchronize(st));
       w0 = w1;
     }
     ScoreArgs sa{};
@@ -775,11 +817,16 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(hipStreamSynchronize(st));
   for (int p = 0; p < P; p++) ctx->domz[p] = dz32[p];
   S.ms_domains = tm_dom.stop();
-  // filter counters (one pass over the pair outputs on the host; small next to the DP work)
+  // filter counters
   {
-    std::vector<PairOut> po((size_t)NP);
-    HIPCHK(hipMemcpy(po.data(), ctx->d_pout.p, (size_t)NP * sizeof(PairOut), hipMemcpyDeviceToHost));
-    for (auto &o : po) { S.n_past_bias += o.pass_bias; S.n_past_fwd += o.pass_fwd; S.n_regions += o.pass_fwd ? o.nregions : 0; S.n_domain_overflow += (o.flags & 2) ? 1 : 0; }
+    DBuf<int64_t> &d_c = ctx->w_counters;
+    HIPCHK(d_c.alloc(8));
+    HIPCHK(hipMemsetAsync(d_c.p, 0, 8 * sizeof(int64_t), st));
+    hipLaunchKernelGGL(k_pair_counters, dim3((unsigned)std::min<int64_t>(4096, (NP + 255) / 256)), dim3(256), 0, st, ctx->d_pout.p, NP, (unsigned long long *)d_c.p);
+    int64_t hc[8];
+    HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    S.n_past_bias = hc[0]; S.n_past_fwd = hc[1]; S.n_regions = hc[2]; S.n_domain_overflow = hc[3];
   }
   return ITSX_OK;
 }
@@ -805,7 +852,7 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
   ctx->h_dom.clear();
   const int64_t NR = ctx->nregions_padded;
   if (NR > 0) {
-    DBuf<int64_t> d_dz;
+    DBuf<int64_t> &d_dz = ctx->w_dz;
     HIPCHK(upload(d_dz, ctx->domz, ctx->st));
     launch_finalize(ctx->d_dom.p, NR, d_dz.p, domE, ctx->st);
     HIPCHK(hipStreamSynchronize(ctx->st));
@@ -897,7 +944,7 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
     if (nm.compare(0, ll, lp) == 0) side[p] = 1;
     else if (nm.compare(0, rl, rp) == 0) side[p] = 2;
   }
-  DBuf<int8_t> d_side; DBuf<unsigned long long> bl, br; DBuf<int32_t> uind, us, ue, ut;
+  DBuf<int8_t> &d_side = ctx->w_side; DBuf<unsigned long long> &bl = ctx->w_bl, &br = ctx->w_br; DBuf<int32_t> &uind = ctx->w_uind, &us = ctx->w_us, &ue = ctx->w_ue, &ut = ctx->w_ut;
   HIPCHK(upload(d_side, side, st));
   HIPCHK(bl.alloc((size_t)U + 1)); HIPCHK(br.alloc((size_t)U + 1)); HIPCHK(uind.alloc((size_t)U + 1));
   HIPCHK(us.alloc((size_t)U + 1)); HIPCHK(ue.alloc((size_t)U + 1)); HIPCHK(ut.alloc((size_t)U + 1));
@@ -913,7 +960,7 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
     HIPCHK(hipStreamSynchronize(st));
     return ITSX_OK;
   }
-  DBuf<int32_t> rs, re, rt, ri;
+  DBuf<int32_t> &rs = ctx->w_rs, &re = ctx->w_re, &rt = ctx->w_rt, &ri = ctx->w_ri;
   HIPCHK(rs.alloc((size_t)n + 1)); HIPCHK(re.alloc((size_t)n + 1)); HIPCHK(rt.alloc((size_t)n + 1)); HIPCHK(ri.alloc((size_t)n + 1));
   if (n > 0) {
     hipLaunchKernelGGL(k_read_coords, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ctx->d_uniq_of.p, us.p, ue.p, ut.p, uind.p, rs.p, re.p, rt.p, ri.p);

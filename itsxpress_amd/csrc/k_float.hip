@@ -79,6 +79,23 @@ DEV Seq open_seq(const ReadsDev &rd, int read)
   return s;
 }
 
+// ---- transition operands ------------------------------------------------------------------
+// The 96 transition vectors of a profile are wave-uniform.  They are fetched with scalar loads and
+// used as SGPR operands of the packed multiplies.  Left alone, the scheduler hoists all of a row's
+// loads to the top of the row and spills hundreds of SGPRs to VGPR lanes; so the row loops are
+// software-pipelined by hand: the vectors of node-group q+1 are requested while group q is being
+// computed (two buffers of 28 SGPRs), and a sched_barrier at the end of every group keeps the
+// compiler from undoing that.
+struct T7 { V4 bm, mm, im, dm, md, mi, ii; };
+DEV T7 ld7(const float *tf, int q)
+{
+  T7 t;
+  t.bm = TF(q, tBM); t.mm = TF(q, tMM); t.im = TF(q, tIM); t.dm = TF(q, tDM);
+  t.md = TF(q, tMD); t.mi = TF(q, tMI); t.ii = TF(q, tII);
+  return t;
+}
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // ---- one Forward row: HMMER's striped forward_engine inner body, literally --------------
 template <int QT>
 DEV void fwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const float *rfx /* LDS: &rf[x][0][0] */,
@@ -90,41 +107,77 @@ DEV void fwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
   const V4 xBv = vset(xB);
   V4 mpv = vrsh(R.m[Q - 1]), dpv = vrsh(R.d[Q - 1]), ipv = vrsh(R.i[Q - 1]);
   V4 sv;
+  if constexpr (QT != 0) {
+    T7 cur = ld7(tf, 0);
 #pragma unroll
-  for (int q = 0; q < (QT ? QT : QMAX); q++) {
-    if (QT == 0 && q >= Q) break;
-    sv = vmul(xBv, TF(q, tBM));
-    sv = vadd(sv, vmul(mpv, TF(q, tMM)));
-    sv = vadd(sv, vmul(ipv, TF(q, tIM)));
-    sv = vadd(sv, vmul(dpv, TF(q, tDM)));
-    sv = vmul(sv, vld(rfx + q * 4));
-    xEv = vadd(xEv, sv);
-    mpv = R.m[q]; dpv = R.d[q]; ipv = R.i[q];
-    R.m[q] = sv; R.d[q] = dcv;
-    dcv = vmul(sv, TF(q, tMD));
-    sv = vmul(mpv, TF(q, tMI));
-    R.i[q] = vadd(sv, vmul(ipv, TF(q, tII)));
-  }
-  dcv = vrsh(dcv);
-  R.d[0] = vzero();
-#pragma unroll
-  for (int q = 0; q < (QT ? QT : QMAX); q++) {
-    if (QT == 0 && q >= Q) break;
-    R.d[q] = vadd(dcv, R.d[q]);
-    dcv = vmul(R.d[q], TF(q, tDD));
-  }
-#pragma unroll
-  for (int j = 1; j < 4; j++) {
-    dcv = vrsh(dcv);
-#pragma unroll
-    for (int q = 0; q < (QT ? QT : QMAX); q++) {
-      if (QT == 0 && q >= Q) break;
-      R.d[q] = vadd(dcv, R.d[q]);
-      dcv = vmul(dcv, TF(q, tDD));
+    for (int q = 0; q < QT; q++) {
+      T7 nxt = cur;
+      if (q + 1 < QT) nxt = ld7(tf, q + 1);
+      sv = vmul(xBv, cur.bm);
+      sv = vadd(sv, vmul(mpv, cur.mm));
+      sv = vadd(sv, vmul(ipv, cur.im));
+      sv = vadd(sv, vmul(dpv, cur.dm));
+      sv = vmul(sv, vld(rfx + q * 4));
+      xEv = vadd(xEv, sv);
+      mpv = R.m[q]; dpv = R.d[q]; ipv = R.i[q];
+      R.m[q] = sv; R.d[q] = dcv;
+      dcv = vmul(sv, cur.md);
+      sv = vmul(mpv, cur.mi);
+      R.i[q] = vadd(sv, vmul(ipv, cur.ii));
+      SCHED_FENCE();
+      cur = nxt;
     }
-  }
+    V4 dd[QT];
 #pragma unroll
-  for (int q = 0; q < (QT ? QT : QMAX); q++) { if (QT == 0 && q >= Q) break; xEv = vadd(R.d[q], xEv); }
+    for (int q = 0; q < QT; q++) dd[q] = TF(q, tDD);
+    dcv = vrsh(dcv);
+    R.d[0] = vzero();
+#pragma unroll
+    for (int q = 0; q < QT; q++) {
+      R.d[q] = vadd(dcv, R.d[q]);
+      dcv = vmul(R.d[q], dd[q]);
+    }
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+      dcv = vrsh(dcv);
+#pragma unroll
+      for (int q = 0; q < QT; q++) {
+        R.d[q] = vadd(dcv, R.d[q]);
+        dcv = vmul(dcv, dd[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QT; q++) xEv = vadd(R.d[q], xEv);
+    SCHED_FENCE();
+  } else {
+    for (int q = 0; q < Q; q++) {
+      sv = vmul(xBv, TF(q, tBM));
+      sv = vadd(sv, vmul(mpv, TF(q, tMM)));
+      sv = vadd(sv, vmul(ipv, TF(q, tIM)));
+      sv = vadd(sv, vmul(dpv, TF(q, tDM)));
+      sv = vmul(sv, vld(rfx + q * 4));
+      xEv = vadd(xEv, sv);
+      mpv = R.m[q]; dpv = R.d[q]; ipv = R.i[q];
+      R.m[q] = sv; R.d[q] = dcv;
+      dcv = vmul(sv, TF(q, tMD));
+      sv = vmul(mpv, TF(q, tMI));
+      R.i[q] = vadd(sv, vmul(ipv, TF(q, tII)));
+    }
+    dcv = vrsh(dcv);
+    R.d[0] = vzero();
+    for (int q = 0; q < Q; q++) {
+      R.d[q] = vadd(dcv, R.d[q]);
+      dcv = vmul(R.d[q], TF(q, tDD));
+    }
+    for (int j = 1; j < 4; j++) {
+      dcv = vrsh(dcv);
+      for (int q = 0; q < Q; q++) {
+        R.d[q] = vadd(dcv, R.d[q]);
+        dcv = vmul(dcv, TF(q, tDD));
+      }
+    }
+    for (int q = 0; q < Q; q++) xEv = vadd(R.d[q], xEv);
+  }
   xE = vhsum(xEv);
   xN = xN * ploop;
   xC = (xC * ploop) + (xE * emove);
@@ -151,54 +204,108 @@ DEV void bwd_dd_md(Row<QT> &R, const int Q, const float *__restrict__ tf, const 
   V4 dpv, dcv = vzero();
   if (rowL) dpv = vlsh(R.d[Q - 1]);
   else      dpv = vlsh(vadd(R.d[0], xEv));
+  if constexpr (QT != 0) {
+    {
+      V4 dd[QT];
 #pragma unroll
-  for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
-    if (QT == 0 && q >= Q) continue;
-    dcv = vmul(dpv, TF(q, tDD));
-    if (rowL) R.d[q] = vadd(R.d[q], dcv);
-    else { R.d[q] = vadd(R.d[q], vadd(dcv, xEv)); R.m[q] = vadd(R.m[q], xEv); }
-    dpv = R.d[q];
-  }
+      for (int q = 0; q < QT; q++) dd[q] = TF(q, tDD);
 #pragma unroll
-  for (int j = 1; j < 4; j++) {
-    dcv = vlsh(dcv);
+      for (int q = QT - 1; q >= 0; q--) {
+        dcv = vmul(dpv, dd[q]);
+        if (rowL) R.d[q] = vadd(R.d[q], dcv);
+        else { R.d[q] = vadd(R.d[q], vadd(dcv, xEv)); R.m[q] = vadd(R.m[q], xEv); }
+        dpv = R.d[q];
+      }
 #pragma unroll
-    for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
-      if (QT == 0 && q >= Q) continue;
-      dcv = vmul(dcv, TF(q, tDD));
-      R.d[q] = vadd(R.d[q], dcv);
+      for (int j = 1; j < 4; j++) {
+        dcv = vlsh(dcv);
+#pragma unroll
+        for (int q = QT - 1; q >= 0; q--) {
+          dcv = vmul(dcv, dd[q]);
+          R.d[q] = vadd(R.d[q], dcv);
+        }
+      }
     }
-  }
-  dcv = vlsh(R.d[0]);
+    SCHED_FENCE();
+    V4 md[QT];
 #pragma unroll
-  for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
-    if (QT == 0 && q >= Q) continue;
-    R.m[q] = vadd(R.m[q], vmul(dcv, TF(q, tMD)));
-    dcv = R.d[q];
+    for (int q = 0; q < QT; q++) md[q] = TF(q, tMD);
+    dcv = vlsh(R.d[0]);
+#pragma unroll
+    for (int q = QT - 1; q >= 0; q--) {
+      R.m[q] = vadd(R.m[q], vmul(dcv, md[q]));
+      dcv = R.d[q];
+    }
+    SCHED_FENCE();
+  } else {
+    for (int q = Q - 1; q >= 0; q--) {
+      dcv = vmul(dpv, TF(q, tDD));
+      if (rowL) R.d[q] = vadd(R.d[q], dcv);
+      else { R.d[q] = vadd(R.d[q], vadd(dcv, xEv)); R.m[q] = vadd(R.m[q], xEv); }
+      dpv = R.d[q];
+    }
+    for (int j = 1; j < 4; j++) {
+      dcv = vlsh(dcv);
+      for (int q = Q - 1; q >= 0; q--) {
+        dcv = vmul(dcv, TF(q, tDD));
+        R.d[q] = vadd(R.d[q], dcv);
+      }
+    }
+    dcv = vlsh(R.d[0]);
+    for (int q = Q - 1; q >= 0; q--) {
+      R.m[q] = vadd(R.m[q], vmul(dcv, TF(q, tMD)));
+      dcv = R.d[q];
+    }
   }
 }
 
 // one Backward row i (L-1 >= i >= 1): consumes residue x_{i+1}
+struct T6 { V4 ii, mi, bm, mmn, imn, dmn; };
+DEV T6 ld6(const float *tb, int q)
+{
+  T6 t;
+  t.ii = vldc(tb + (q * 6 + 0) * 4); t.mi = vldc(tb + (q * 6 + 1) * 4); t.bm = vldc(tb + (q * 6 + 2) * 4);
+  t.mmn = vldc(tb + (q * 6 + 3) * 4); t.imn = vldc(tb + (q * 6 + 4) * 4); t.dmn = vldc(tb + (q * 6 + 5) * 4);
+  return t;
+}
 template <int QT>
 DEV void bwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const float *rfx,
                  float &xN, float &xB, float &xJ, float &xC, float &xE,
                  const float pmove, const float ploop, const float eloop, const float emove)
 {
-  tf += opaque_zero();
-  V4 tmmv = vlsh(TF(0, tMM)), timv = vlsh(TF(0, tIM)), tdmv = vlsh(TF(0, tDM));
   V4 mpv = vlsh(vmul(R.m[0], vld(rfx)));
   V4 xBv = vzero(), ipv, mcv;
+  if constexpr (QT != 0) {
+    // tb = the Backward re-ordering of the same transition table (DevProfile::tb follows tf)
+    const float *tb = tf + QMAX * 8 * 4 + opaque_zero();
+    T6 cur = ld6(tb, QT - 1);
 #pragma unroll
-  for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
-    if (QT == 0 && q >= Q) continue;
-    ipv = R.i[q];
-    R.i[q] = vadd(vmul(ipv, TF(q, tII)), vmul(mpv, timv));
-    R.d[q] = vmul(mpv, tdmv);
-    mcv = vadd(vmul(ipv, TF(q, tMI)), vmul(mpv, tmmv));
-    mpv = vmul(R.m[q], vld(rfx + q * 4));
-    R.m[q] = mcv;
-    tdmv = TF(q, tDM); timv = TF(q, tIM); tmmv = TF(q, tMM);
-    xBv = vadd(xBv, vmul(mpv, TF(q, tBM)));
+    for (int q = QT - 1; q >= 0; q--) {
+      T6 nxt = cur;
+      if (q > 0) nxt = ld6(tb, q - 1);
+      ipv = R.i[q];
+      R.i[q] = vadd(vmul(ipv, cur.ii), vmul(mpv, cur.imn));
+      R.d[q] = vmul(mpv, cur.dmn);
+      mcv = vadd(vmul(ipv, cur.mi), vmul(mpv, cur.mmn));
+      mpv = vmul(R.m[q], vld(rfx + q * 4));
+      R.m[q] = mcv;
+      xBv = vadd(xBv, vmul(mpv, cur.bm));
+      SCHED_FENCE();
+      cur = nxt;
+    }
+  } else {
+    const float *tfo = tf + opaque_zero();
+    V4 tmmv = vlsh(vldc(tfo + (0 * 8 + tMM) * 4)), timv = vlsh(vldc(tfo + (0 * 8 + tIM) * 4)), tdmv = vlsh(vldc(tfo + (0 * 8 + tDM) * 4));
+    for (int q = Q - 1; q >= 0; q--) {
+      ipv = R.i[q];
+      R.i[q] = vadd(vmul(ipv, vldc(tfo + (q * 8 + tII) * 4)), vmul(mpv, timv));
+      R.d[q] = vmul(mpv, tdmv);
+      mcv = vadd(vmul(ipv, vldc(tfo + (q * 8 + tMI) * 4)), vmul(mpv, tmmv));
+      mpv = vmul(R.m[q], vld(rfx + q * 4));
+      R.m[q] = mcv;
+      tdmv = vldc(tfo + (q * 8 + tDM) * 4); timv = vldc(tfo + (q * 8 + tIM) * 4); tmmv = vldc(tfo + (q * 8 + tMM) * 4);
+      xBv = vadd(xBv, vmul(mpv, vldc(tfo + (q * 8 + tBM) * 4)));
+    }
   }
   xB = vhsum(xBv);
   xC = xC * ploop;
@@ -366,9 +473,11 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
         const int x = sq.code(i);          // residue i+1, 0-based index i
         bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);
         if (xB > 1.0e16f) own = 1;
-        float s;
-        if (own) s = (xB > 1.0e4f) ? xB : 1.0f;
-        else     s = *slab_at(a.slab, r0, i, XF, 5, lane);
+        // branch-free on purpose: a branch here lets the optimizer sink the whole row update below it,
+        // stretching the live ranges of every transition operand (hundreds of SGPR spills)
+        const float sfw = *slab_at(a.slab, r0, i, XF, 5, lane);
+        const float sown = (xB > 1.0e4f) ? xB : 1.0f;
+        const float s = own ? sown : sfw;
         if (s > 1.0f) {
           xE /= s; xN /= s; xJ /= s; xB /= s; xC /= s;
           scale_row<QT>(R, Q, s);
@@ -458,8 +567,16 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
 }
 
 // =========================================================================================
-// K3: re-score one envelope per lane in unihit mode (Forward, Backward, decoding, null2)
-constexpr int EF = 204;    // per row: fwd M,I (96) | bck M,I (96) | fwd E N J B C S | bck E N J B C S
+// K3: re-score one envelope per lane in unihit mode (Forward, Backward, decoding, null2).
+// Three sweeps over the envelope's rows; only the Backward rows go through HBM:
+//   A. Forward, keeping nothing but each row's scale factor          (write 1 float / row)
+//   B. Backward with those scale factors, storing M and I of every row (write 100 floats / row)
+//   C. Forward again (same arithmetic, same values) combining each freshly computed row with the
+//      stored Backward row into the posterior sums, rows ascending as HMMER sums them
+//                                                                     (read 100 floats / row)
+// Recomputing Forward costs one more sweep of ALU work and halves the slab traffic that bounded
+// the first version of this kernel (fwd rows + bck rows written, both read back).
+constexpr int EF = 101;    // per row: bck M,I (96) | bck N J C S | fwd S
 template <int QT>
 __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
 {
@@ -482,19 +599,16 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
   const int64_t r0 = wd.slab;
   const float pmove = 2.0f / ((float)L + 2.0f);
   const float ploop = 1.0f - pmove;
-  RegionOut ro; ro.ok = 0; ro.envsc = 0.f;
+  RegionOut ro; ro.ok = 0; ro.envsc = 0.f; ro.domcorrection = 0.f;
 #pragma unroll
   for (int x = 0; x < NCODE; x++) ro.n2log[x] = 0.f;
   bool bad = false;
-  // ---- Forward over the envelope, keeping every row's M and I
+  // ---- sweep A: Forward, scale factors only
   {
     Row<QT> R;
 #pragma unroll
     for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
     float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f, totscale = 0.0f;
-    *slab_at(a.slab, r0, 0, EF, 192, lane) = xE; *slab_at(a.slab, r0, 0, EF, 193, lane) = xN;
-    *slab_at(a.slab, r0, 0, EF, 194, lane) = xJ; *slab_at(a.slab, r0, 0, EF, 195, lane) = xB;
-    *slab_at(a.slab, r0, 0, EF, 196, lane) = xC; *slab_at(a.slab, r0, 0, EF, 197, lane) = 1.0f;
     for (int i = 1; i <= Lw; i++) {
       if (active && i <= Ld) {
         const int x = sq.code(off + i - 1);
@@ -507,23 +621,15 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
           totscale = (float)((double)totscale + det_log((double)xE));
           xE = 1.0f;
         }
-        *slab_at(a.slab, r0, i, EF, 192, lane) = xE; *slab_at(a.slab, r0, i, EF, 193, lane) = xN;
-        *slab_at(a.slab, r0, i, EF, 194, lane) = xJ; *slab_at(a.slab, r0, i, EF, 195, lane) = xB;
-        *slab_at(a.slab, r0, i, EF, 196, lane) = xC; *slab_at(a.slab, r0, i, EF, 197, lane) = sc;
-#pragma unroll
-        for (int q = 0; q < (QT ? QT : QMAX); q++) {
-          if (QT == 0 && q >= Q) break;
-          float *d = slab_at(a.slab, r0, i, EF, q * 8, lane);
-          d[0] = R.m[q].a.x; d[64] = R.m[q].a.y; d[128] = R.m[q].b.x; d[192] = R.m[q].b.y;
-          d[256] = R.i[q].a.x; d[320] = R.i[q].a.y; d[384] = R.i[q].b.x; d[448] = R.i[q].b.y;
-        }
+        *slab_at(a.slab, r0, i, EF, 100, lane) = sc;
       }
     }
     bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
     ro.envsc = (float)((double)totscale + det_log((double)(xC * pmove)));
   }
-  // ---- Backward over the envelope
+  // ---- sweep B: Backward, rows to the slab
   int own = 0;
+  float bN0 = 0.f;
   {
     Row<QT> R;
     float xJ = 0.f, xB = 0.f, xN = 0.f, xC = pmove, xE = xC * 1.0f;
@@ -534,19 +640,18 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
       bwd_dd_md<QT>(R, Q, tf, xEv, true);
     }
     float sL = 1.0f;
-    if (active) sL = *slab_at(a.slab, r0, Ld, EF, 197, lane);
+    if (active) sL = *slab_at(a.slab, r0, Ld, EF, 100, lane);
     if (sL > 1.0f) {
       xE = xE / sL; xN = xN / sL; xC = xC / sL; xJ = xJ / sL; xB = xB / sL;
       scale_row<QT>(R, Q, sL);
     }
     auto store_row = [&](int i, float s) {
-      *slab_at(a.slab, r0, i, EF, 198, lane) = xE; *slab_at(a.slab, r0, i, EF, 199, lane) = xN;
-      *slab_at(a.slab, r0, i, EF, 200, lane) = xJ; *slab_at(a.slab, r0, i, EF, 201, lane) = xB;
-      *slab_at(a.slab, r0, i, EF, 202, lane) = xC; *slab_at(a.slab, r0, i, EF, 203, lane) = s;
+      *slab_at(a.slab, r0, i, EF, 96, lane) = xN; *slab_at(a.slab, r0, i, EF, 97, lane) = xJ;
+      *slab_at(a.slab, r0, i, EF, 98, lane) = xC; *slab_at(a.slab, r0, i, EF, 99, lane) = s;
 #pragma unroll
       for (int q = 0; q < (QT ? QT : QMAX); q++) {
         if (QT == 0 && q >= Q) break;
-        float *d = slab_at(a.slab, r0, i, EF, 96 + q * 8, lane);
+        float *d = slab_at(a.slab, r0, i, EF, q * 8, lane);
         d[0] = R.m[q].a.x; d[64] = R.m[q].a.y; d[128] = R.m[q].b.x; d[192] = R.m[q].b.y;
         d[256] = R.i[q].a.x; d[320] = R.i[q].a.y; d[384] = R.i[q].b.x; d[448] = R.i[q].b.y;
       }
@@ -557,9 +662,9 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
         const int x = sq.code(off + i);
         bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
         if (xB > 1.0e16f) own = 1;
-        float s;
-        if (own) s = (xB > 1.0e4f) ? xB : 1.0f;
-        else     s = *slab_at(a.slab, r0, i, EF, 197, lane);
+        const float sfw = *slab_at(a.slab, r0, i, EF, 100, lane);
+        const float sown = (xB > 1.0e4f) ? xB : 1.0f;
+        const float s = own ? sown : sfw;
         if (s > 1.0f) {
           xE /= s; xN /= s; xJ /= s; xB /= s; xC /= s;
           scale_row<QT>(R, Q, s);
@@ -580,43 +685,55 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
       xB = vhsum(xBv);
       xN = (xB * pmove) + (xN * ploop);
       bad = bad || (xN != xN) || (xN == 0.0f) || (xN == __builtin_inff());
-      *slab_at(a.slab, r0, 0, EF, 199, lane) = xN;
+      bN0 = xN;
     }
   }
-  // ---- posterior decoding: expected use of every emitting state, rows summed in ascending order
-  if (active && !bad) {
-    float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, EF, 199, lane));
-    V4 accM[QMAX], accI[QMAX];
-    float accN = 0.f, accC = 0.f, accJ = 0.f;
-    float fNp = *slab_at(a.slab, r0, 0, EF, 193, lane), fJp = *slab_at(a.slab, r0, 0, EF, 194, lane);
-    float fCp = *slab_at(a.slab, r0, 0, EF, 196, lane);
-    for (int r = 1; r <= Ld; r++) {
-      const float fS = *slab_at(a.slab, r0, r, EF, 197, lane);
-      const V4 totrv = vset(scaleproduct * fS);
+  // ---- sweep C: Forward again; posterior sums (expected use of every emitting state), rows ascending
+  {
+    Row<QT> R;
 #pragma unroll
-      for (int q = 0; q < (QT ? QT : QMAX); q++) {
-        if (QT == 0 && q >= Q) break;
-        const float *f = slab_at(a.slab, r0, r, EF, q * 8, lane);
-        const float *b = slab_at(a.slab, r0, r, EF, 96 + q * 8, lane);
-        V4 fm, fi, bm, bi;
-        fm.a = (f2){f[0], f[64]}; fm.b = (f2){f[128], f[192]}; fi.a = (f2){f[256], f[320]}; fi.b = (f2){f[384], f[448]};
-        bm.a = (f2){b[0], b[64]}; bm.b = (f2){b[128], b[192]}; bi.a = (f2){b[256], b[320]}; bi.b = (f2){b[384], b[448]};
-        const V4 pm = vmul(vmul(fm, bm), totrv);
-        const V4 pi = vmul(vmul(fi, bi), totrv);
-        if (r == 1) { accM[q] = pm; accI[q] = pi; }
-        else { accM[q] = vadd(pm, accM[q]); accI[q] = vadd(pi, accI[q]); }
+    for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
+    float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f;
+    float scaleproduct = (float)(1.0 / (double)bN0);
+    V4 accM[QMAX], accI[QMAX];
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) { accM[q] = vzero(); accI[q] = vzero(); }
+    float accN = 0.f, accC = 0.f, accJ = 0.f;
+    const bool go = active && !bad;
+    for (int r = 1; r <= Lw; r++) {
+      if (go && r <= Ld) {
+        const float fNp = xN, fJp = xJ, fCp = xC;
+        const int x = sq.code(off + r - 1);
+        fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
+        float fS = 1.0f;
+        if (xE > 1.0e4f) {
+          xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+          scale_row<QT>(R, Q, xE);
+          fS = xE;
+          xE = 1.0f;
+        }
+        const V4 totrv = vset(scaleproduct * fS);
+#pragma unroll
+        for (int q = 0; q < (QT ? QT : QMAX); q++) {
+          if (QT == 0 && q >= Q) break;
+          const float *b = slab_at(a.slab, r0, r, EF, q * 8, lane);
+          V4 bm, bi;
+          bm.a = (f2){b[0], b[64]}; bm.b = (f2){b[128], b[192]}; bi.a = (f2){b[256], b[320]}; bi.b = (f2){b[384], b[448]};
+          const V4 pm = vmul(vmul(R.m[q], bm), totrv);
+          const V4 pi = vmul(vmul(R.i[q], bi), totrv);
+          if (r == 1) { accM[q] = pm; accI[q] = pi; }
+          else { accM[q] = vadd(pm, accM[q]); accI[q] = vadd(pi, accI[q]); }
+        }
+        const float bN = *slab_at(a.slab, r0, r, EF, 96, lane), bJ = *slab_at(a.slab, r0, r, EF, 97, lane);
+        const float bC = *slab_at(a.slab, r0, r, EF, 98, lane), bS = *slab_at(a.slab, r0, r, EF, 99, lane);
+        const float pN = fNp * bN * ploop * scaleproduct;
+        const float pJ = fJp * bJ * ploop * scaleproduct;
+        const float pC = fCp * bC * ploop * scaleproduct;
+        if (r == 1) { accN = pN; accC = pC; accJ = pJ; } else { accN += pN; accC += pC; accJ += pJ; }
+        if (own) scaleproduct *= fS / bS;
       }
-      const float bN = *slab_at(a.slab, r0, r, EF, 199, lane), bJ = *slab_at(a.slab, r0, r, EF, 200, lane);
-      const float bC = *slab_at(a.slab, r0, r, EF, 202, lane), bS = *slab_at(a.slab, r0, r, EF, 203, lane);
-      const float pN = fNp * bN * ploop * scaleproduct;
-      const float pJ = fJp * bJ * ploop * scaleproduct;
-      const float pC = fCp * bC * ploop * scaleproduct;
-      if (r == 1) { accN = pN; accC = pC; accJ = pJ; } else { accN += pN; accC += pC; accJ += pJ; }
-      if (own) scaleproduct *= fS / bS;
-      fNp = *slab_at(a.slab, r0, r, EF, 193, lane); fJp = *slab_at(a.slab, r0, r, EF, 194, lane);
-      fCp = *slab_at(a.slab, r0, r, EF, 196, lane);
     }
-    if (scaleproduct != __builtin_inff()) {
+    if (go && scaleproduct != __builtin_inff()) {
       const float norm = (float)(1.0 / (double)(float)Ld);
       const V4 nv = vset(norm);
 #pragma unroll
@@ -648,6 +765,16 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
       }
 #pragma unroll
       for (int x = 0; x < NCODE; x++) ro.n2log[x] = det_logf(null2[x]);
+      // null2 correction of this envelope: sum over its residues, in order
+      float dc = 0.0f;
+      for (int pos = 0; pos < Ld; pos++) {
+        const int x = sq.code(off + pos);
+        float v = ro.n2log[0];
+#pragma unroll
+        for (int c = 1; c < NCODE; c++) v = (x == c) ? ro.n2log[c] : v;
+        dc += v;
+      }
+      ro.domcorrection = dc;
       ro.ok = 1;
     }
   }
@@ -676,22 +803,22 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   const double log_omega = -5.545177444479562;   // log(1/256), the null2 prior
   const int64_t g0 = a.pair_region0[pi];
   const int nd_all = po.ndom;
-  // pass 1: domcorrection per envelope, and the chained per-sequence sum over all envelope positions
+  // pass 1: domcorrection per envelope (from k_envelopes), and the per-sequence sum over all envelope
+  // positions, which HMMER accumulates as ONE running float sum across envelopes
   float seqbias = 0.0f;
   float domcorr[MAXDOM]; int okd[MAXDOM]; int ndom = 0;
   for (int d = 0; d < nd_all; d++) {
     const RegionOut ro = a.rout[g0 + d];
-    const RegionRec rg = a.regions[g0 + d];
     okd[d] = ro.ok;
-    float dc = 0.0f;
+    domcorr[d] = ro.ok ? ro.domcorrection : 0.0f;
     if (ro.ok) {
-      for (int pos = rg.ienv; pos <= rg.jenv; pos++) {
-        const float v = ro.n2log[sq.code(pos - 1)];
-        dc += v; seqbias += v;
+      if (ndom == 0) seqbias = ro.domcorrection;           // first envelope: same sum, same order
+      else {
+        const RegionRec rg = a.regions[g0 + d];
+        for (int pos = rg.ienv; pos <= rg.jenv; pos++) seqbias += ro.n2log[sq.code(pos - 1)];
       }
       ndom++;
     }
-    domcorr[d] = dc;
   }
   if (ndom == 0) return;
   seqbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)seqbias));

@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=1200, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20 s of CPU work)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,8 +148,10 @@ def main():
                      "bwd_rows_per_s": st["fwd_rows"] / (kern["k_bwd_decode"] * 1e-3) if kern["k_bwd_decode"] > 0 else None,
                      "peak_lane_gops": VALU_PEAK_GOPS},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample != 0:
             threads = os.cpu_count() or 1
+            if args.cpu_sample < 0:                      # ~1 s per 80 reads per core on the scalar port
+                args.cpu_sample = int(min(40000, max(1200, 120 * threads)))
             v, cdt, nc = cpu_baseline(hmm, blob, offs, min(args.cpu_sample, args.reads), threads)
             res["cpu_baseline"] = {"value": v, "unit": "reads/s", "cores": threads, "kind": "port",
                                    "sample": "first %d reads of the same workload (%d unique), derep+search+argmax, %.1f s" % (min(args.cpu_sample, args.reads), nc, cdt)}

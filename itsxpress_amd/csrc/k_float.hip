@@ -581,6 +581,9 @@ template <int QT>
 __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
 {
   __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
+  // sweep C needs the DP row (144 registers) plus 96 posterior sums per lane; the 48 insert-state sums
+  // live in LDS ([q][lane] x float4: conflict-free b128 accesses) so the rest fits in 256 VGPRs
+  __shared__ f4 accI_s[QMAX * 64];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const DevProfile *pp = a.prof + uni(wd.prof);
@@ -695,9 +698,9 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
     for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
     float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f;
     float scaleproduct = (float)(1.0 / (double)bN0);
-    V4 accM[QMAX], accI[QMAX];
+    V4 accM[QMAX];
 #pragma unroll
-    for (int q = 0; q < QMAX; q++) { accM[q] = vzero(); accI[q] = vzero(); }
+    for (int q = 0; q < QMAX; q++) { accM[q] = vzero(); accI_s[q * 64 + lane] = (f4){0.f, 0.f, 0.f, 0.f}; }
     float accN = 0.f, accC = 0.f, accJ = 0.f;
     const bool go = active && !bad;
     for (int r = 1; r <= Lw; r++) {
@@ -721,8 +724,14 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
           bm.a = (f2){b[0], b[64]}; bm.b = (f2){b[128], b[192]}; bi.a = (f2){b[256], b[320]}; bi.b = (f2){b[384], b[448]};
           const V4 pm = vmul(vmul(R.m[q], bm), totrv);
           const V4 pi = vmul(vmul(R.i[q], bi), totrv);
-          if (r == 1) { accM[q] = pm; accI[q] = pi; }
-          else { accM[q] = vadd(pm, accM[q]); accI[q] = vadd(pi, accI[q]); }
+          if (r == 1) { accM[q] = pm; accI_s[q * 64 + lane] = (f4){pi.a.x, pi.a.y, pi.b.x, pi.b.y}; }
+          else {
+            accM[q] = vadd(pm, accM[q]);
+            const f4 o = accI_s[q * 64 + lane];
+            V4 ai; ai.a = (f2){o.x, o.y}; ai.b = (f2){o.z, o.w};
+            ai = vadd(pi, ai);
+            accI_s[q * 64 + lane] = (f4){ai.a.x, ai.a.y, ai.b.x, ai.b.y};
+          }
         }
         const float bN = *slab_at(a.slab, r0, r, EF, 96, lane), bJ = *slab_at(a.slab, r0, r, EF, 97, lane);
         const float bC = *slab_at(a.slab, r0, r, EF, 98, lane), bS = *slab_at(a.slab, r0, r, EF, 99, lane);
@@ -736,8 +745,14 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
     if (go && scaleproduct != __builtin_inff()) {
       const float norm = (float)(1.0 / (double)(float)Ld);
       const V4 nv = vset(norm);
+      V4 accI[QMAX];
 #pragma unroll
-      for (int q = 0; q < (QT ? QT : QMAX); q++) { if (QT == 0 && q >= Q) break; accM[q] = vmul(accM[q], nv); accI[q] = vmul(accI[q], nv); }
+      for (int q = 0; q < (QT ? QT : QMAX); q++) {
+        if (QT == 0 && q >= Q) break;
+        const f4 o = accI_s[q * 64 + lane];
+        accI[q].a = (f2){o.x, o.y}; accI[q].b = (f2){o.z, o.w};
+        accM[q] = vmul(accM[q], nv); accI[q] = vmul(accI[q], nv);
+      }
       accN *= norm; accC *= norm; accJ *= norm;
       const float xfactor = accN + accC + accJ;
       float null2[NCODE];

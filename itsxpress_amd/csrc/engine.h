@@ -76,7 +76,9 @@ struct RegionOut {
   float envsc;
   float domcorrection;          // sum of n2log over the envelope's residues
   float n2log[NCODE];           // log null2 odds per residue code
-  int32_t ok;
+  int32_t ok;                   // -1 unusable, 0 sweeps pending, 1 complete
+  int32_t own;                  // Backward had to switch to its own scale factors
+  float bN0;                    // Backward's N at row 0 (total probability)
 };
 
 #define HIPCHK(expr)                                                                            \

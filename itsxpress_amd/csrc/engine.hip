@@ -791,14 +791,14 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     std::vector<int32_t> rrows((size_t)NRW);
     HIPCHK(hipMemcpyAsync(rrows.data(), d_rrows.p, (size_t)NRW * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    const int64_t erow_bytes = 101 * 64 * 4;
+    const int64_t erow_bytes = 104 * 64 * 4;
     const int64_t ebudget = (int64_t)(slab_gb * (1 << 30)) / erow_bytes;
-    DBuf<float> &d_eslab = ctx->w_eslab; int64_t ealloc = (int64_t)(d_eslab.cap / (101 * 64));
+    DBuf<float> &d_eslab = ctx->w_eslab; int64_t ealloc = (int64_t)(d_eslab.cap / (104 * 64));
     int w0 = 0;
     while (w0 < NRW) {
       int w1 = w0; int64_t r = 0;
       while (w1 < NRW && rgen[w1] == rgen[w0] && (w1 == w0 || r + rrows[w1] <= ebudget)) { rw[w1].slab = r; rw[w1].rows = rrows[w1]; r += rrows[w1]; w1++; }
-      if (r > ealloc) { HIPCHK(d_eslab.alloc((size_t)r * 101 * 64)); ealloc = r; }
+      if (r > ealloc) { HIPCHK(d_eslab.alloc((size_t)r * 104 * 64)); ealloc = r; }
       HIPCHK(hipMemcpyAsync(d_rw.p + w0, rw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       EnvArgs a{};
       a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;

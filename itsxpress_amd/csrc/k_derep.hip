@@ -217,18 +217,42 @@ __global__ void __launch_bounds__(256) k_uniques(int64_t n, const int32_t *__res
 __global__ void __launch_bounds__(256) k_len_hist(int32_t U, const int32_t *__restrict__ seed_read, const int32_t *__restrict__ len,
                                                   int32_t *__restrict__ hist, int32_t lcap)
 {
-  for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
-    int L = len[seed_read[u]]; if (L >= lcap) L = lcap - 1;
-    atomicAdd(&hist[L], 1);
+  // amplicon lengths cluster on a few values: one atomic per distinct length per wave, not per lane
+  const int32_t stride = gridDim.x * blockDim.x;
+  for (int32_t u0 = blockIdx.x * blockDim.x; u0 < U; u0 += stride) {
+    const int32_t u = u0 + threadIdx.x;
+    const bool ok = u < U;
+    int L = ok ? len[seed_read[u]] : -1; if (L >= lcap) L = lcap - 1;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int L0 = __shfl(L, leader, 64);
+      const unsigned long long same = __ballot(ok && L == L0) & todo;
+      if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[L0], __popcll(same));
+      todo &= ~same;
+    }
   }
 }
 __global__ void __launch_bounds__(256) k_len_scatter(int32_t U, const int32_t *__restrict__ seed_read, const int32_t *__restrict__ len,
                                                      int32_t *__restrict__ cursor, int32_t lcap, int32_t *__restrict__ sorted_uniq)
 {
-  for (int32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
-    int L = len[seed_read[u]]; if (L >= lcap) L = lcap - 1;
-    const int32_t pos = atomicAdd(&cursor[L], 1);
-    sorted_uniq[pos] = u;
+  const int32_t stride = gridDim.x * blockDim.x;
+  for (int32_t u0 = blockIdx.x * blockDim.x; u0 < U; u0 += stride) {
+    const int32_t u = u0 + threadIdx.x;
+    const bool ok = u < U;
+    int L = ok ? len[seed_read[u]] : -1; if (L >= lcap) L = lcap - 1;
+    unsigned long long todo = __ballot(ok);
+    const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int L0 = __shfl(L, leader, 64);
+      const unsigned long long same = __ballot(ok && L == L0) & todo;
+      int32_t base = 0;
+      if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&cursor[L0], __popcll(same));
+      base = __shfl(base, leader, 64);
+      if (ok && L == L0 && (same >> (threadIdx.x & 63) & 1)) sorted_uniq[base + __popcll(same & below)] = u;
+      todo &= ~same;
+    }
   }
 }
 

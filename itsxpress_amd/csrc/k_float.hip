@@ -568,21 +568,163 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
 
 // =========================================================================================
 // K3: re-score one envelope per lane in unihit mode (Forward, Backward, decoding, null2).
-// Three sweeps over the envelope's rows; only the Backward rows go through HBM:
-//   A. Forward, keeping nothing but each row's scale factor          (write 1 float / row)
-//   B. Backward with those scale factors, storing M and I of every row (write 100 floats / row)
-//   C. Forward again (same arithmetic, same values) combining each freshly computed row with the
-//      stored Backward row into the posterior sums, rows ascending as HMMER sums them
-//                                                                     (read 100 floats / row)
+// Three sweeps over the envelope's rows, one kernel each (separate kernels keep every sweep
+// inside 256 VGPRs without spills); only the Backward rows go through HBM:
+//   A. k_env_fwd : Forward, keeping nothing but each row's scale factor     (write 1 float / row)
+//   B. k_env_bwd : Backward with those scale factors, M and I of every row  (write 100 floats / row)
+//   C. k_env_post: Forward again (same arithmetic, same values), each freshly computed row combined
+//      with the stored Backward row into the posterior sums, rows ascending as HMMER sums them
+//      (read 100 floats / row); then null2 and the envelope's null2 correction.
 // Recomputing Forward costs one more sweep of ALU work and halves the slab traffic that bounded
-// the first version of this kernel (fwd rows + bck rows written, both read back).
-constexpr int EF = 101;    // per row: bck M,I (96) | bck N J C S | fwd S
+// the first version of this stage (fwd rows + bck rows written, both read back).
+constexpr int EV = 26;     // float4 vectors per row: bck M,I of each q (24) | bck (N J C S) | (fwd S, -, -, -)
+// 16 bytes per lane per access: one global_store_dwordx4 / global_load_dwordx4 moves 1 KiB per wave
+DEV f4 *eslab_at(float *slab, int64_t row0, int row, int v, int lane)
+{
+  return (f4 *)slab + (((row0 + row) * EV + v) * 64 + lane);
+}
+
+struct EnvLane {           // what every sweep needs to know about its lane's envelope
+  Seq sq; int L, Ld, off, Lw; int64_t r0, ri; float pmove, ploop; bool active;
+};
+DEV EnvLane env_lane(const EnvArgs &a, const WaveDesc &wd, int lane)
+{
+  EnvLane e;
+  e.active = lane < wd.count;
+  e.ri = wd.first + (e.active ? lane : 0);
+  const RegionRec rg = a.regions[e.ri];
+  const PairRec pr = a.pairs[rg.pair];
+  e.L = pr.L;
+  e.sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  e.Ld = rg.jenv - rg.ienv + 1;
+  e.off = rg.ienv - 1;
+  e.Lw = wd.rows - 1;
+  e.r0 = wd.slab;
+  e.pmove = 2.0f / ((float)e.L + 2.0f);
+  e.ploop = 1.0f - e.pmove;
+  return e;
+}
+
 template <int QT>
-__global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
+__global__ void __launch_bounds__(64, 2) k_env_fwd(EnvArgs a, int wave0)
 {
   __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
-  // sweep C needs the DP row (144 registers) plus 96 posterior sums per lane; the 48 insert-state sums
-  // live in LDS ([q][lane] x float4: conflict-free b128 accesses) so the rest fits in 256 VGPRs
+  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  const DevProfile *pp = a.prof + uni(wd.prof);
+  fill_lds_rf(rf_s, pp);
+  const float *tf = pp->tf;
+  const int Q = QT ? QT : uni(pp->Q);
+  const EnvLane e = env_lane(a, wd, lane);
+  Row<QT> R;
+#pragma unroll
+  for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
+  float xE = 0.f, xN = 1.f, xJ = 0.f, xB = e.pmove, xC = 0.f, totscale = 0.0f;
+  for (int i = 1; i <= e.Lw; i++) {
+    if (e.active && i <= e.Ld) {
+      const int x = e.sq.code(e.off + i - 1);
+      fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, e.pmove, e.ploop, 0.0f, 1.0f);
+      float sc = 1.0f;
+      if (xE > 1.0e4f) {
+        xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+        scale_row<QT>(R, Q, xE);
+        sc = xE;
+        totscale = (float)((double)totscale + det_log((double)xE));
+        xE = 1.0f;
+      }
+      eslab_at(a.slab, e.r0, i, 25, lane)->x = sc;
+    }
+  }
+  if (e.active) {
+    RegionOut ro;
+#pragma unroll
+    for (int x = 0; x < NCODE; x++) ro.n2log[x] = 0.f;
+    ro.domcorrection = 0.f;
+    const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
+    ro.envsc = (float)((double)totscale + det_log((double)(xC * e.pmove)));
+    ro.ok = bad ? -1 : 0;                 // -1: unusable; 0: not finished yet; 1: complete
+    ro.own = 0; ro.bN0 = 0.f;
+    a.rout[e.ri] = ro;
+  }
+}
+
+template <int QT>
+__global__ void __launch_bounds__(64, 2) k_env_bwd(EnvArgs a, int wave0)
+{
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
+  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  const DevProfile *pp = a.prof + uni(wd.prof);
+  fill_lds_rf(rf_s, pp);
+  const float *tf = pp->tf;
+  const int Q = QT ? QT : uni(pp->Q);
+  const EnvLane e = env_lane(a, wd, lane);
+  const int Ld = e.Ld; const int64_t r0 = e.r0; const bool active = e.active;
+  const float pmove = e.pmove, ploop = e.ploop;
+  int own = 0;
+  Row<QT> R;
+  float xJ = 0.f, xB = 0.f, xN = 0.f, xC = pmove, xE = xC * 1.0f;
+  {
+    const V4 xEv = vset(xE);
+#pragma unroll
+    for (int q = 0; q < QMAX; q++) { R.m[q] = xEv; R.d[q] = xEv; R.i[q] = vzero(); }
+    bwd_dd_md<QT>(R, Q, tf, xEv, true);
+  }
+  float sL = 1.0f;
+  if (active) sL = eslab_at(a.slab, r0, Ld, 25, lane)->x;
+  if (sL > 1.0f) {
+    xE = xE / sL; xN = xN / sL; xC = xC / sL; xJ = xJ / sL; xB = xB / sL;
+    scale_row<QT>(R, Q, sL);
+  }
+  auto store_row = [&](int i, float s) {
+    *eslab_at(a.slab, r0, i, 24, lane) = (f4){xN, xJ, xC, s};
+#pragma unroll
+    for (int q = 0; q < (QT ? QT : QMAX); q++) {
+      if (QT == 0 && q >= Q) break;
+      *eslab_at(a.slab, r0, i, q * 2, lane) = (f4){R.m[q].a.x, R.m[q].a.y, R.m[q].b.x, R.m[q].b.y};
+      *eslab_at(a.slab, r0, i, q * 2 + 1, lane) = (f4){R.i[q].a.x, R.i[q].a.y, R.i[q].b.x, R.i[q].b.y};
+    }
+  };
+  if (active) store_row(Ld, sL);
+  for (int i = e.Lw - 1; i >= 1; i--) {
+    if (active && i <= Ld - 1) {
+      const int x = e.sq.code(e.off + i);
+      bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
+      if (xB > 1.0e16f) own = 1;
+      const float sfw = eslab_at(a.slab, r0, i, 25, lane)->x;
+      const float sown = (xB > 1.0e4f) ? xB : 1.0f;
+      const float s = own ? sown : sfw;
+      if (s > 1.0f) {
+        xE /= s; xN /= s; xJ /= s; xB /= s; xC /= s;
+        scale_row<QT>(R, Q, s);
+      }
+      store_row(i, s);
+    }
+  }
+  if (active) {
+    const int x = e.sq.code(e.off);
+    const float *rfx = rf_s + x * QMAX * 4;
+    V4 xBv = vzero();
+#pragma unroll
+    for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
+      if (QT == 0 && q >= Q) continue;
+      const V4 mpv = vmul(R.m[q], vld(rfx + q * 4));
+      xBv = vadd(xBv, vmul(mpv, TF(q, tBM)));
+    }
+    xB = vhsum(xBv);
+    xN = (xB * pmove) + (xN * ploop);
+    const bool bad = (xN != xN) || (xN == 0.0f) || (xN == __builtin_inff());
+    if (bad) a.rout[e.ri].ok = -1;
+    a.rout[e.ri].own = own; a.rout[e.ri].bN0 = xN;
+  }
+}
+
+template <int QT>
+__global__ void __launch_bounds__(64, 2) k_env_post(EnvArgs a, int wave0)
+{
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
+  // this sweep needs the DP row (144 registers) plus 96 posterior sums per lane; the 48 insert-state
+  // sums live in LDS ([q][lane] x float4: conflict-free b128 accesses) so the rest fits in 256 VGPRs
   __shared__ f4 accI_s[QMAX * 64];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
@@ -590,218 +732,152 @@ __global__ void __launch_bounds__(64, 2) k_envelopes(EnvArgs a, int wave0)
   fill_lds_rf(rf_s, pp);
   const float *tf = pp->tf;
   const int Q = QT ? QT : uni(pp->Q);
-  const bool active = lane < wd.count;
-  const int64_t ri = wd.first + (active ? lane : 0);
-  const RegionRec rg = a.regions[ri];
-  const PairRec pr = a.pairs[rg.pair];
-  const int L = pr.L;
-  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
-  const int Ld = rg.jenv - rg.ienv + 1;
-  const int off = rg.ienv - 1;              // 0-based index of the envelope's first residue
-  const int Lw = wd.rows - 1;
-  const int64_t r0 = wd.slab;
-  const float pmove = 2.0f / ((float)L + 2.0f);
-  const float ploop = 1.0f - pmove;
-  RegionOut ro; ro.ok = 0; ro.envsc = 0.f; ro.domcorrection = 0.f;
+  const EnvLane e = env_lane(a, wd, lane);
+  const int Ld = e.Ld; const int64_t r0 = e.r0;
+  const float pmove = e.pmove, ploop = e.ploop;
+  RegionOut ro = a.rout[e.ri];
+  const int own = ro.own;
+  const bool go = e.active && ro.ok == 0;
+  Row<QT> R;
 #pragma unroll
-  for (int x = 0; x < NCODE; x++) ro.n2log[x] = 0.f;
-  bool bad = false;
-  // ---- sweep A: Forward, scale factors only
-  {
-    Row<QT> R;
+  for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
+  float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f;
+  float scaleproduct = (float)(1.0 / (double)ro.bN0);
+  V4 accM[QMAX];
 #pragma unroll
-    for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
-    float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f, totscale = 0.0f;
-    for (int i = 1; i <= Lw; i++) {
-      if (active && i <= Ld) {
-        const int x = sq.code(off + i - 1);
-        fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
-        float sc = 1.0f;
-        if (xE > 1.0e4f) {
-          xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
-          scale_row<QT>(R, Q, xE);
-          sc = xE;
-          totscale = (float)((double)totscale + det_log((double)xE));
-          xE = 1.0f;
-        }
-        *slab_at(a.slab, r0, i, EF, 100, lane) = sc;
+  for (int q = 0; q < QMAX; q++) { accM[q] = vzero(); accI_s[q * 64 + lane] = (f4){0.f, 0.f, 0.f, 0.f}; }
+  float accN = 0.f, accC = 0.f, accJ = 0.f;
+  for (int r = 1; r <= e.Lw; r++) {
+    if (go && r <= Ld) {
+      const float fNp = xN, fJp = xJ, fCp = xC;
+      const int x = e.sq.code(e.off + r - 1);
+      fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
+      float fS = 1.0f;
+      if (xE > 1.0e4f) {
+        xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+        scale_row<QT>(R, Q, xE);
+        fS = xE;
+        xE = 1.0f;
       }
-    }
-    bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
-    ro.envsc = (float)((double)totscale + det_log((double)(xC * pmove)));
-  }
-  // ---- sweep B: Backward, rows to the slab
-  int own = 0;
-  float bN0 = 0.f;
-  {
-    Row<QT> R;
-    float xJ = 0.f, xB = 0.f, xN = 0.f, xC = pmove, xE = xC * 1.0f;
-    {
-      const V4 xEv = vset(xE);
-#pragma unroll
-      for (int q = 0; q < QMAX; q++) { R.m[q] = xEv; R.d[q] = xEv; R.i[q] = vzero(); }
-      bwd_dd_md<QT>(R, Q, tf, xEv, true);
-    }
-    float sL = 1.0f;
-    if (active) sL = *slab_at(a.slab, r0, Ld, EF, 100, lane);
-    if (sL > 1.0f) {
-      xE = xE / sL; xN = xN / sL; xC = xC / sL; xJ = xJ / sL; xB = xB / sL;
-      scale_row<QT>(R, Q, sL);
-    }
-    auto store_row = [&](int i, float s) {
-      *slab_at(a.slab, r0, i, EF, 96, lane) = xN; *slab_at(a.slab, r0, i, EF, 97, lane) = xJ;
-      *slab_at(a.slab, r0, i, EF, 98, lane) = xC; *slab_at(a.slab, r0, i, EF, 99, lane) = s;
+      const V4 totrv = vset(scaleproduct * fS);
 #pragma unroll
       for (int q = 0; q < (QT ? QT : QMAX); q++) {
         if (QT == 0 && q >= Q) break;
-        float *d = slab_at(a.slab, r0, i, EF, q * 8, lane);
-        d[0] = R.m[q].a.x; d[64] = R.m[q].a.y; d[128] = R.m[q].b.x; d[192] = R.m[q].b.y;
-        d[256] = R.i[q].a.x; d[320] = R.i[q].a.y; d[384] = R.i[q].b.x; d[448] = R.i[q].b.y;
-      }
-    };
-    if (active) store_row(Ld, sL);
-    for (int i = Lw - 1; i >= 1; i--) {
-      if (active && i <= Ld - 1) {
-        const int x = sq.code(off + i);
-        bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
-        if (xB > 1.0e16f) own = 1;
-        const float sfw = *slab_at(a.slab, r0, i, EF, 100, lane);
-        const float sown = (xB > 1.0e4f) ? xB : 1.0f;
-        const float s = own ? sown : sfw;
-        if (s > 1.0f) {
-          xE /= s; xN /= s; xJ /= s; xB /= s; xC /= s;
-          scale_row<QT>(R, Q, s);
+        const f4 bm4 = *eslab_at(a.slab, r0, r, q * 2, lane), bi4 = *eslab_at(a.slab, r0, r, q * 2 + 1, lane);
+        V4 bm, bi;
+        bm.a = (f2){bm4.x, bm4.y}; bm.b = (f2){bm4.z, bm4.w}; bi.a = (f2){bi4.x, bi4.y}; bi.b = (f2){bi4.z, bi4.w};
+        const V4 pm = vmul(vmul(R.m[q], bm), totrv);
+        const V4 pi = vmul(vmul(R.i[q], bi), totrv);
+        if (r == 1) { accM[q] = pm; accI_s[q * 64 + lane] = (f4){pi.a.x, pi.a.y, pi.b.x, pi.b.y}; }
+        else {
+          accM[q] = vadd(pm, accM[q]);
+          const f4 o = accI_s[q * 64 + lane];
+          V4 ai; ai.a = (f2){o.x, o.y}; ai.b = (f2){o.z, o.w};
+          ai = vadd(pi, ai);
+          accI_s[q * 64 + lane] = (f4){ai.a.x, ai.a.y, ai.b.x, ai.b.y};
         }
-        store_row(i, s);
       }
-    }
-    if (active) {
-      const int x = sq.code(off);
-      const float *rfx = rf_s + x * QMAX * 4;
-      V4 xBv = vzero();
-#pragma unroll
-      for (int q = (QT ? QT : QMAX) - 1; q >= 0; q--) {
-        if (QT == 0 && q >= Q) continue;
-        const V4 mpv = vmul(R.m[q], vld(rfx + q * 4));
-        xBv = vadd(xBv, vmul(mpv, TF(q, tBM)));
-      }
-      xB = vhsum(xBv);
-      xN = (xB * pmove) + (xN * ploop);
-      bad = bad || (xN != xN) || (xN == 0.0f) || (xN == __builtin_inff());
-      bN0 = xN;
+      const f4 bsp = *eslab_at(a.slab, r0, r, 24, lane);
+      const float bN = bsp.x, bJ = bsp.y, bC = bsp.z, bS = bsp.w;
+      const float pN = fNp * bN * ploop * scaleproduct;
+      const float pJ = fJp * bJ * ploop * scaleproduct;
+      const float pC = fCp * bC * ploop * scaleproduct;
+      if (r == 1) { accN = pN; accC = pC; accJ = pJ; } else { accN += pN; accC += pC; accJ += pJ; }
+      if (own) scaleproduct *= fS / bS;
     }
   }
-  // ---- sweep C: Forward again; posterior sums (expected use of every emitting state), rows ascending
-  {
-    Row<QT> R;
+  int ok = ro.ok;
+  if (go && scaleproduct != __builtin_inff()) {
+    const float norm = (float)(1.0 / (double)(float)Ld);
+    const V4 nv = vset(norm);
+    V4 accI[QMAX];
 #pragma unroll
-    for (int q = 0; q < QMAX; q++) { R.m[q] = vzero(); R.d[q] = vzero(); R.i[q] = vzero(); }
-    float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f;
-    float scaleproduct = (float)(1.0 / (double)bN0);
-    V4 accM[QMAX];
-#pragma unroll
-    for (int q = 0; q < QMAX; q++) { accM[q] = vzero(); accI_s[q * 64 + lane] = (f4){0.f, 0.f, 0.f, 0.f}; }
-    float accN = 0.f, accC = 0.f, accJ = 0.f;
-    const bool go = active && !bad;
-    for (int r = 1; r <= Lw; r++) {
-      if (go && r <= Ld) {
-        const float fNp = xN, fJp = xJ, fCp = xC;
-        const int x = sq.code(off + r - 1);
-        fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.0f, 1.0f);
-        float fS = 1.0f;
-        if (xE > 1.0e4f) {
-          xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
-          scale_row<QT>(R, Q, xE);
-          fS = xE;
-          xE = 1.0f;
-        }
-        const V4 totrv = vset(scaleproduct * fS);
-#pragma unroll
-        for (int q = 0; q < (QT ? QT : QMAX); q++) {
-          if (QT == 0 && q >= Q) break;
-          const float *b = slab_at(a.slab, r0, r, EF, q * 8, lane);
-          V4 bm, bi;
-          bm.a = (f2){b[0], b[64]}; bm.b = (f2){b[128], b[192]}; bi.a = (f2){b[256], b[320]}; bi.b = (f2){b[384], b[448]};
-          const V4 pm = vmul(vmul(R.m[q], bm), totrv);
-          const V4 pi = vmul(vmul(R.i[q], bi), totrv);
-          if (r == 1) { accM[q] = pm; accI_s[q * 64 + lane] = (f4){pi.a.x, pi.a.y, pi.b.x, pi.b.y}; }
-          else {
-            accM[q] = vadd(pm, accM[q]);
-            const f4 o = accI_s[q * 64 + lane];
-            V4 ai; ai.a = (f2){o.x, o.y}; ai.b = (f2){o.z, o.w};
-            ai = vadd(pi, ai);
-            accI_s[q * 64 + lane] = (f4){ai.a.x, ai.a.y, ai.b.x, ai.b.y};
-          }
-        }
-        const float bN = *slab_at(a.slab, r0, r, EF, 96, lane), bJ = *slab_at(a.slab, r0, r, EF, 97, lane);
-        const float bC = *slab_at(a.slab, r0, r, EF, 98, lane), bS = *slab_at(a.slab, r0, r, EF, 99, lane);
-        const float pN = fNp * bN * ploop * scaleproduct;
-        const float pJ = fJp * bJ * ploop * scaleproduct;
-        const float pC = fCp * bC * ploop * scaleproduct;
-        if (r == 1) { accN = pN; accC = pC; accJ = pJ; } else { accN += pN; accC += pC; accJ += pJ; }
-        if (own) scaleproduct *= fS / bS;
-      }
+    for (int q = 0; q < (QT ? QT : QMAX); q++) {
+      if (QT == 0 && q >= Q) break;
+      const f4 o = accI_s[q * 64 + lane];
+      accI[q].a = (f2){o.x, o.y}; accI[q].b = (f2){o.z, o.w};
+      accM[q] = vmul(accM[q], nv); accI[q] = vmul(accI[q], nv);
     }
-    if (go && scaleproduct != __builtin_inff()) {
-      const float norm = (float)(1.0 / (double)(float)Ld);
-      const V4 nv = vset(norm);
-      V4 accI[QMAX];
+    accN *= norm; accC *= norm; accJ *= norm;
+    const float xfactor = accN + accC + accJ;
+    float null2[NCODE];
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      V4 sv = vzero();
 #pragma unroll
       for (int q = 0; q < (QT ? QT : QMAX); q++) {
         if (QT == 0 && q >= Q) break;
-        const f4 o = accI_s[q * 64 + lane];
-        accI[q].a = (f2){o.x, o.y}; accI[q].b = (f2){o.z, o.w};
-        accM[q] = vmul(accM[q], nv); accI[q] = vmul(accI[q], nv);
+        sv = vadd(sv, vmul(accM[q], vld(rf_s + x * QMAX * 4 + q * 4)));
+        sv = vadd(sv, accI[q]);
       }
-      accN *= norm; accC *= norm; accJ *= norm;
-      const float xfactor = accN + accC + accJ;
-      float null2[NCODE];
-#pragma unroll
-      for (int x = 0; x < 4; x++) {
-        V4 sv = vzero();
-#pragma unroll
-        for (int q = 0; q < (QT ? QT : QMAX); q++) {
-          if (QT == 0 && q >= Q) break;
-          sv = vadd(sv, vmul(accM[q], vld(rf_s + x * QMAX * 4 + q * 4)));
-          sv = vadd(sv, accI[q]);
-        }
-        null2[x] = vhsum(sv);
-        null2[x] += xfactor;
-      }
-      null2[4] = 1.0f;
-      // degenerate codes: mean of the member odds (order A,C,G,T)
-      const unsigned short dm[16] = {1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15};
-#pragma unroll
-      for (int x = 5; x < 16; x++) {
-        float acc = 0.f; int nd = 0;
-#pragma unroll
-        for (int y = 0; y < 4; y++) if (dm[x] >> y & 1) { acc += null2[y]; nd++; }
-        null2[x] = acc / (float)nd;
-      }
-#pragma unroll
-      for (int x = 0; x < NCODE; x++) ro.n2log[x] = det_logf(null2[x]);
-      // null2 correction of this envelope: sum over its residues, in order
-      float dc = 0.0f;
-      for (int pos = 0; pos < Ld; pos++) {
-        const int x = sq.code(off + pos);
-        float v = ro.n2log[0];
-#pragma unroll
-        for (int c = 1; c < NCODE; c++) v = (x == c) ? ro.n2log[c] : v;
-        dc += v;
-      }
-      ro.domcorrection = dc;
-      ro.ok = 1;
+      null2[x] = vhsum(sv);
+      null2[x] += xfactor;
     }
+    null2[4] = 1.0f;
+    // degenerate codes: mean of the member odds (order A,C,G,T)
+    const unsigned short dm[16] = {1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15};
+#pragma unroll
+    for (int x = 5; x < 16; x++) {
+      float acc = 0.f; int nd = 0;
+#pragma unroll
+      for (int y = 0; y < 4; y++) if (dm[x] >> y & 1) { acc += null2[y]; nd++; }
+      null2[x] = acc / (float)nd;
+    }
+#pragma unroll
+    for (int x = 0; x < NCODE; x++) ro.n2log[x] = det_logf(null2[x]);
+    // null2 correction of this envelope: sum over its residues, in order
+    float dc = 0.0f;
+    for (int pos = 0; pos < Ld; pos++) {
+      const int x = e.sq.code(e.off + pos);
+      float v = ro.n2log[0];
+#pragma unroll
+      for (int c = 1; c < NCODE; c++) v = (x == c) ? ro.n2log[c] : v;
+      dc += v;
+    }
+    ro.domcorrection = dc;
+    ok = 1;
   }
-  if (active) a.rout[ri] = ro;
+  if (e.active) { ro.ok = ok > 0 ? 1 : 0; a.rout[e.ri] = ro; }
 }
 
 // =========================================================================================
 // K4: per pair, chain its envelopes in order: null2 corrections, bit scores, reporting
+// count one "reported target" for profile `prof` per flagged lane, with one atomic per distinct profile per
+// wave: the work lists are grouped by profile, so per-lane atomics would all hit the same address
+DEV void count_reported(int32_t *domz, int prof, bool flag)
+{
+  unsigned long long todo = __ballot(flag);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int p0 = __shfl(prof, leader, 64);
+    const unsigned long long same = __ballot(flag && prof == p0) & todo;
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&domz[p0], __popcll(same));
+    todo &= ~same;
+  }
+}
+
 DEV float flogsum_dev(const float *tbl, float x, float y)
 {
   const float mx = x > y ? x : y, mn = x > y ? y : x;
   return (mn == -__builtin_inff() || (mx - mn) >= 15.7f) ? mx : mx + tbl[(int)((mx - mn) * 1000.f)];
+}
+
+DEV void emit_domain(const ScoreArgs &a, int64_t slot, const PairRec &pr, const DevProfile *pp, const RegionRec &rg, const RegionOut &ro,
+                     float domcorr, int dom_idx, int ndom, int poflags, float nullsc, float seq_score, float final_bias, int seq_rep,
+                     int L, double lognn3, double log_omega)
+{
+  itsx_domain o;
+  const int Ld = rg.jenv - rg.ienv + 1;
+  float bits = (float)((double)ro.envsc + (double)(L - Ld) * lognn3);
+  const float dombias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)domcorr));
+  bits = (float)((double)(bits - (nullsc + dombias)) / kLn2);
+  o.rep = a.sorted_uniq[pr.useq]; o.prof = pr.prof; o.tlen = L; o.ienv = rg.ienv; o.jenv = rg.jenv;
+  o.dom_idx = dom_idx; o.ndom = ndom; o.flags = (rg.multi ? 1 : 0) | poflags;
+  o.envsc = ro.envsc; o.domcorrection = domcorr; o.dombias = dombias; o.bitscore = bits;
+  o.lnP = exp_logsurv((double)bits, (double)pp->ev[4], (double)pp->ev[5]);
+  o.seq_score = seq_score; o.seq_bias = (float)((double)final_bias / kLn2);
+  o.seq_reported = dom_idx >= 0 ? seq_rep : 0; o.dom_reported = 0;
+  a.dom[slot] = o;
 }
 
 __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
@@ -814,37 +890,69 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   const DevProfile *pp = a.prof + pr.prof;
   const int L = pr.L;
   const LenTables lt = a.lt[L];
-  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
   const double log_omega = -5.545177444479562;   // log(1/256), the null2 prior
   const int64_t g0 = a.pair_region0[pi];
   const int nd_all = po.ndom;
-  // pass 1: domcorrection per envelope (from k_envelopes), and the per-sequence sum over all envelope
-  // positions, which HMMER accumulates as ONE running float sum across envelopes
+  const float nullsc = po.nullsc;
+  if (nd_all == 1) {
+    // the common case, one envelope: every running sum of the general path collapses to one term
+    const RegionOut ro = a.rout[g0];
+    if (!ro.ok) return;
+    const RegionRec rg = a.regions[g0];
+    const float dc = ro.domcorrection;
+    const float seqbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)dc));
+    float seq_score = (float)((double)(po.fwdsc - (nullsc + seqbias)) / kLn2);
+    float final_bias = seqbias;
+    if (ro.envsc - dc > 0.0f) {
+      const int Ld = rg.jenv - rg.ienv + 1;
+      float sum_score = 0.0f; sum_score += ro.envsc;
+      float sb = 0.0f; sb += dc;
+      sb = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)sb));
+      sum_score = (float)((double)sum_score + (double)(L - Ld) * lt.lognn3);
+      sum_score = (float)((double)(sum_score - (nullsc + sb)) / kLn2);
+      if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; final_bias = sb; }
+    } else {
+      float sb = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + 0.0));
+      float sum_score = (float)(0.0 + (double)L * lt.lognn3);
+      sum_score = (float)((double)(sum_score - (nullsc + sb)) / kLn2);
+      (void)sum_score;                      // Ld == 0: the reconstruction score cannot override
+    }
+    const int seq_rep = ((double)seq_score >= a.T);
+    emit_domain(a, g0, pr, pp, rg, ro, dc, 0, 1, po.flags, nullsc, seq_score, final_bias, seq_rep, L, lt.lognn3, log_omega);
+    count_reported(a.domz, pr.prof, seq_rep != 0);
+    return;
+  }
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  // domcorrection per envelope (from k_env_post), and the per-sequence sum over all envelope positions,
+  // which HMMER accumulates as ONE running float sum across envelopes
   float seqbias = 0.0f;
-  float domcorr[MAXDOM]; int okd[MAXDOM]; int ndom = 0;
+  int ndom = 0;
   for (int d = 0; d < nd_all; d++) {
     const RegionOut ro = a.rout[g0 + d];
-    okd[d] = ro.ok;
-    domcorr[d] = ro.ok ? ro.domcorrection : 0.0f;
     if (ro.ok) {
       if (ndom == 0) seqbias = ro.domcorrection;           // first envelope: same sum, same order
       else {
         const RegionRec rg = a.regions[g0 + d];
-        for (int pos = rg.ienv; pos <= rg.jenv; pos++) seqbias += ro.n2log[sq.code(pos - 1)];
+        for (int pos = rg.ienv; pos <= rg.jenv; pos++) {
+          const int x = sq.code(pos - 1);
+          float v = ro.n2log[0];
+#pragma unroll
+          for (int c = 1; c < NCODE; c++) v = (x == c) ? ro.n2log[c] : v;
+          seqbias += v;
+        }
       }
       ndom++;
     }
   }
   if (ndom == 0) return;
   seqbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)seqbias));
-  const float nullsc = po.nullsc;
   float seq_score = (float)((double)(po.fwdsc - (nullsc + seqbias)) / kLn2);
   float sum_score = 0.0f, sbias = 0.0f; int Ldsum = 0;
   for (int d = 0; d < nd_all; d++) {
-    if (!okd[d]) continue;
     const RegionOut ro = a.rout[g0 + d];
+    if (!ro.ok) continue;
     const RegionRec rg = a.regions[g0 + d];
-    if (ro.envsc - domcorr[d] > 0.0f) { sum_score += ro.envsc; Ldsum += rg.jenv - rg.ienv + 1; sbias += domcorr[d]; }
+    if (ro.envsc - ro.domcorrection > 0.0f) { sum_score += ro.envsc; Ldsum += rg.jenv - rg.ienv + 1; sbias += ro.domcorrection; }
   }
   sbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)sbias));
   sum_score = (float)((double)sum_score + (double)(L - Ldsum) * lt.lognn3);
@@ -854,23 +962,13 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   const int seq_rep = ((double)seq_score >= a.T);
   int k = 0;
   for (int d = 0; d < nd_all; d++) {
-    itsx_domain o;
     const RegionOut ro = a.rout[g0 + d];
     const RegionRec rg = a.regions[g0 + d];
-    const int Ld = rg.jenv - rg.ienv + 1;
-    float bits = (float)((double)ro.envsc + (double)(L - Ld) * lt.lognn3);
-    const float dombias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)domcorr[d]));
-    bits = (float)((double)(bits - (nullsc + dombias)) / kLn2);
-    o.rep = a.sorted_uniq[pr.useq]; o.prof = pr.prof; o.tlen = L; o.ienv = rg.ienv; o.jenv = rg.jenv;
-    o.dom_idx = okd[d] ? k : -1; o.ndom = ndom; o.flags = (rg.multi ? 1 : 0) | po.flags;
-    o.envsc = ro.envsc; o.domcorrection = domcorr[d]; o.dombias = dombias; o.bitscore = bits;
-    o.lnP = exp_logsurv((double)bits, (double)pp->ev[4], (double)pp->ev[5]);
-    o.seq_score = seq_score; o.seq_bias = (float)((double)final_bias / kLn2);
-    o.seq_reported = okd[d] ? seq_rep : 0; o.dom_reported = 0;
-    a.dom[g0 + d] = o;
-    if (okd[d]) k++;
+    emit_domain(a, g0 + d, pr, pp, rg, ro, ro.ok ? ro.domcorrection : 0.0f, ro.ok ? k : -1, ndom, po.flags, nullsc, seq_score, final_bias,
+                seq_rep, L, lt.lognn3, log_omega);
+    if (ro.ok) k++;
   }
-  if (seq_rep) atomicAdd(&a.domz[pr.prof], 1);
+  count_reported(a.domz, pr.prof, seq_rep != 0);
 }
 
 // compaction of raw per-pair region slots into the profile-grouped region list
@@ -947,8 +1045,15 @@ void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q,
 void launch_envelopes(const EnvArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
 {
   if (nwaves <= 0) return;
-  if (generic_q) hipLaunchKernelGGL(k_envelopes<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
-  else           hipLaunchKernelGGL(k_envelopes<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  if (generic_q) {
+    hipLaunchKernelGGL(k_env_fwd<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+    hipLaunchKernelGGL(k_env_bwd<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+    hipLaunchKernelGGL(k_env_post<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  } else {
+    hipLaunchKernelGGL(k_env_fwd<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+    hipLaunchKernelGGL(k_env_bwd<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+    hipLaunchKernelGGL(k_env_post<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  }
 }
 void launch_score(const ScoreArgs &a, hipStream_t st)
 {

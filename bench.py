@@ -119,7 +119,7 @@ def main():
         value = total_reads / dt
         K = args.steps
         kern = {"k_msv": acc["ms_msv_kernel"] / K, "k_filters_fwd": acc["ms_fwd_kernel"] / K,
-                "k_bwd_decode": acc["ms_bwd_kernel"] / K}
+                "k_bwd_decode": acc["ms_bwd_kernel"] / K, "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K}
         dom = max(kern, key=kern.get)
         # algorithmic HBM bytes of the dominant kernel, per step
         U, L = st["n_unique"], 300
@@ -127,8 +127,10 @@ def main():
             alg_bytes = U * ((nprof + 63) // 64) * ((L + 15) // 16 * 4) + 2 * ((nprof + 63) // 64 * 64) * U
         elif dom == "k_filters_fwd":
             alg_bytes = st["n_past_msv"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 24
-        else:
+        elif dom == "k_bwd_decode":
             alg_bytes = st["n_past_fwd"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 48
+        else:   # envelope sweeps: Backward rows written once, read once (26 float4 per row), + 88 B result per envelope
+            alg_bytes = st["env_rows"] * 2 * 26 * 16 + st["n_domains"] * (16 + 88)
         achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
         trimmed = int(((out[0][:, 0] >= 0) & (out[0][:, 1] >= 0) & (out[0][:, 0] < out[0][:, 1])).sum())
         res = {
@@ -146,6 +148,7 @@ def main():
             "valu": {"msv_gcups": st["msv_cells"] / (kern["k_msv"] * 1e-3) / 1e9 if kern["k_msv"] > 0 else None,
                      "fwd_rows_per_s": st["fwd_rows"] / (kern["k_filters_fwd"] * 1e-3) if kern["k_filters_fwd"] > 0 else None,
                      "bwd_rows_per_s": st["fwd_rows"] / (kern["k_bwd_decode"] * 1e-3) if kern["k_bwd_decode"] > 0 else None,
+                     "env_rows_per_s_x3_sweeps": 3 * st["env_rows"] / (kern["k_env_fwd+k_env_bwd+k_env_post"] * 1e-3) if kern["k_env_fwd+k_env_bwd+k_env_post"] > 0 else None,
                      "peak_lane_gops": VALU_PEAK_GOPS},
         }
         if args.cpu_sample != 0:

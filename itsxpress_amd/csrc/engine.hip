@@ -153,6 +153,8 @@ struct itsx_ctx {
   DBuf<RegionRec> d_regions;
   DBuf<RegionOut> d_rout;
   DBuf<int64_t> d_pair_region0;
+  DBuf<int32_t> d_upos;                  // region -> index of its (shared) result
+  DBuf<RegionRec> d_ulist;               // distinct envelopes, grouped by profile
   DBuf<itsx_domain> d_dom;
   DBuf<int32_t> d_domz32;
   DBuf<LenTables> d_lt;
@@ -164,7 +166,8 @@ struct itsx_ctx {
   DBuf<uint64_t> w_hf, w_hr; DBuf<unsigned long long> w_keys; DBuf<int32_t> w_vals, w_is_seed, w_seed_rank, w_scan_tmp, w_hist, w_cursor, w_tmp2;
   DBuf<uint32_t> w_slot_of; DBuf<unsigned int> w_ncoll;
   DBuf<uint16_t> w_thr, w_res; DBuf<int32_t> w_tjb, w_cnt, w_total, w_rows, w_rcnt, w_rpref, w_scan2, w_b, w_rrows;
-  DBuf<int64_t> w_seg_start, w_idx, w_rseg, w_dz, w_counters;
+  DBuf<int64_t> w_seg_start, w_idx, w_rseg, w_dz, w_counters, w_useg;
+  DBuf<int32_t> w_rrep, w_ruq, w_rurank;
   DBuf<WaveDesc> w_waves, w_rw; DBuf<RegionRec> w_raw; DBuf<float> w_slab, w_eslab;
   DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri;
 };
@@ -609,7 +612,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = ctx->nregions_padded = 0;
   ctx->have_search = true; ctx->have_final = false;
   if (U == 0) return ITSX_OK;
@@ -764,30 +767,61 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   const int64_t NR = rseg[P];
   ctx->nregions_padded = NR;
   HIPCHK(ctx->d_pair_region0.alloc((size_t)NP));
-  HIPCHK(ctx->d_regions.alloc((size_t)std::max<int64_t>(NR, 1))); HIPCHK(ctx->d_rout.alloc((size_t)std::max<int64_t>(NR, 1)));
+  HIPCHK(ctx->d_regions.alloc((size_t)std::max<int64_t>(NR, 1)));
   HIPCHK(ctx->d_dom.alloc((size_t)std::max<int64_t>(NR, 1)));
   HIPCHK(hipMemsetAsync(ctx->d_dom.p, 0xFF, (size_t)std::max<int64_t>(NR, 1) * sizeof(itsx_domain), st));
-  HIPCHK(hipMemsetAsync(ctx->d_rout.p, 0, (size_t)std::max<int64_t>(NR, 1) * sizeof(RegionOut), st));
   HIPCHK(ctx->d_domz32.alloc((size_t)P));
   HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * 4, st));
   if (NR > 0) {
     DBuf<int64_t> &d_rseg = ctx->w_rseg;
     HIPCHK(upload(d_rseg, rseg, st));
     launch_region_offsets(NP, ctx->d_pairs.p, d_rpref.p, d_seg_start.p, d_rseg.p, ctx->d_pair_region0.p, st);
+    HIPCHK(hipMemsetAsync(ctx->d_regions.p, 0xFF, (size_t)NR * sizeof(RegionRec), st));     // padding slots: pair = -1
     launch_region_fill(ctx->d_pout.p, d_raw.p, NP, ctx->d_pair_region0.p, ctx->d_regions.p, st);
+    // ---- envelope memoisation: only distinct (profile, L, residues) envelopes are re-scored
+    DBuf<unsigned long long> &rkeys = ctx->w_keys; DBuf<int32_t> &rvals = ctx->w_vals; DBuf<uint32_t> &rslot = ctx->w_slot_of;
+    DBuf<int32_t> &rrep = ctx->w_rrep, &ruq = ctx->w_ruq, &rurank = ctx->w_rurank, &rscan = ctx->w_scan_tmp;
+    uint64_t tsize = 1024; while (tsize < (uint64_t)NR * 2 + 16) tsize <<= 1;
+    HIPCHK(rkeys.alloc(tsize)); HIPCHK(rvals.alloc(tsize)); HIPCHK(rslot.alloc((size_t)NR + 1));
+    HIPCHK(rrep.alloc((size_t)NR + 1)); HIPCHK(ruq.alloc((size_t)NR + 1)); HIPCHK(rurank.alloc((size_t)NR + 1));
+    HIPCHK(rscan.alloc((size_t)scan_tmp_elems(NR + 1))); HIPCHK(ctx->d_upos.alloc((size_t)NR + 1));
+    HIPCHK(hipMemsetAsync(rkeys.p, 0, tsize * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(rvals.p, 0x7f, tsize * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(ruq.p, 0, ((size_t)NR + 1) * sizeof(int32_t), st));
+    launch_region_keys(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
+    launch_region_resolve(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
+    launch_exclusive_scan(ruq.p, rurank.p, NR + 1, rscan.p, st);
+    std::vector<int32_t> ub((size_t)P + 1);
+    {
+      DBuf<int64_t> &d_idx = ctx->w_idx; DBuf<int32_t> &d_b = ctx->w_b;
+      HIPCHK(upload(d_idx, rseg, st)); HIPCHK(d_b.alloc((size_t)P + 1));
+      hipLaunchKernelGGL(k_gather_i32, dim3((P + 1 + 255) / 256), dim3(256), 0, st, rurank.p, d_idx.p, P + 1, d_b.p);
+      HIPCHK(hipMemcpyAsync(ub.data(), d_b.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    std::vector<int64_t> useg((size_t)P + 1, 0);
+    std::vector<int32_t> utotal((size_t)P);
+    for (int p = 0; p < P; p++) { utotal[p] = ub[p + 1] - ub[p]; useg[p + 1] = useg[p] + ((int64_t)utotal[p] + 63) / 64 * 64; S.n_env_unique += utotal[p]; }
+    const int64_t NU = useg[P];
+    DBuf<int64_t> &d_useg = ctx->w_useg;
+    HIPCHK(upload(d_useg, useg, st));
+    HIPCHK(ctx->d_ulist.alloc((size_t)std::max<int64_t>(NU, 1))); HIPCHK(ctx->d_rout.alloc((size_t)std::max<int64_t>(NU, 1)));
+    HIPCHK(hipMemsetAsync(ctx->d_rout.p, 0, (size_t)std::max<int64_t>(NU, 1) * sizeof(RegionOut), st));
+    launch_region_upos(NR, ctx->d_regions.p, ctx->d_pairs.p, ruq.p, rurank.p, d_rseg.p, d_useg.p, ctx->d_upos.p, ctx->d_ulist.p, st);
+    launch_region_upos_follow(NR, rrep.p, ruq.p, ctx->d_upos.p, st);
     std::vector<WaveDesc> rw; std::vector<char> rgen;
     for (int pass = 0; pass < 2; pass++)
       for (int p = 0; p < P; p++) {
         if ((int)ctx->generic_q[p] != pass) continue;
-        for (int64_t k = 0; k < rtotal[p]; k += 64) {
-          WaveDesc w{}; w.prof = p; w.first = rseg[p] + k; w.count = (int32_t)std::min<int64_t>(64, rtotal[p] - k);
+        for (int64_t k = 0; k < utotal[p]; k += 64) {
+          WaveDesc w{}; w.prof = p; w.first = useg[p] + k; w.count = (int32_t)std::min<int64_t>(64, utotal[p] - k);
           rw.push_back(w); rgen.push_back((char)pass);
         }
       }
     const int NRW = (int)rw.size();
     DBuf<WaveDesc> &d_rw = ctx->w_rw; DBuf<int32_t> &d_rrows = ctx->w_rrows;
     HIPCHK(upload(d_rw, rw, st)); HIPCHK(d_rrows.alloc((size_t)NRW));
-    hipLaunchKernelGGL(k_wave_rows_regions, dim3((NRW + 255) / 256), dim3(256), 0, st, d_rw.p, NRW, ctx->d_regions.p, d_rrows.p);
+    hipLaunchKernelGGL(k_wave_rows_regions, dim3((NRW + 255) / 256), dim3(256), 0, st, d_rw.p, NRW, ctx->d_ulist.p, d_rrows.p);
     std::vector<int32_t> rrows((size_t)NRW);
     HIPCHK(hipMemcpyAsync(rrows.data(), d_rrows.p, (size_t)NRW * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -802,14 +836,15 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       HIPCHK(hipMemcpyAsync(d_rw.p + w0, rw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       EnvArgs a{};
       a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
-      a.pairs = ctx->d_pairs.p; a.regions = ctx->d_regions.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
-      launch_envelopes(a, w1 - w0, w0, rgen[w0], st);
+      a.pairs = ctx->d_pairs.p; a.regions = ctx->d_ulist.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
+      { StageTimer k(st); launch_envelopes(a, w1 - w0, w0, rgen[w0], st); S.ms_env_kernel += k.stop(); }
+      for (int w = w0; w < w1; w++) S.env_rows += (int64_t)(rrows[w] - 1) * rw[w].count;
       w0 = w1;
     }
     ScoreArgs sa{};
     sa.rd = ctx->rd; sa.sorted_uniq = ctx->d_sorted_uniq.p; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
     sa.flogsum = ctx->d_flogsum.p; sa.pairs = ctx->d_pairs.p; sa.pout = ctx->d_pout.p; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
-    sa.pair_region0 = ctx->d_pair_region0.p; sa.dom = ctx->d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p;
+    sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = ctx->d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p;
     launch_score(sa, st);
   }
   std::vector<int32_t> dz32((size_t)P, 0);

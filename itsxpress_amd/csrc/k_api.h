@@ -25,6 +25,14 @@ void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, in
 void launch_len_scatter(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *cursor, int32_t lcap,
                         int32_t *sorted_uniq, hipStream_t st);
 
+void launch_region_keys(const ReadsDev &rd, const RegionRec *regions, int64_t nr, const PairRec *pairs, const int32_t *sorted_uniq,
+                        const int32_t *seed_read, unsigned long long *keys, int32_t *vals, uint64_t mask, uint32_t *slot_of, hipStream_t st);
+void launch_region_resolve(const ReadsDev &rd, const RegionRec *regions, int64_t nr, const PairRec *pairs, const int32_t *sorted_uniq,
+                           const int32_t *seed_read, const int32_t *vals, const uint32_t *slot_of, int32_t *rep_region, int32_t *is_uniq, hipStream_t st);
+void launch_region_upos(int64_t nr, const RegionRec *regions, const PairRec *pairs, const int32_t *is_uniq, const int32_t *urank,
+                        const int64_t *rseg, const int64_t *useg, int32_t *upos, RegionRec *ulist, hipStream_t st);
+void launch_region_upos_follow(int64_t nr, const int32_t *rep_region, const int32_t *is_uniq, int32_t *upos, hipStream_t st);
+
 // ---- k_util.hip
 // exclusive prefix sum of n int32 values (n < 2^31); tmp must hold scan_tmp_elems(n) int32
 int64_t scan_tmp_elems(int64_t n);
@@ -107,6 +115,7 @@ struct ScoreArgs {
   const RegionRec *regions;     // compacted
   const RegionOut *rout;
   const int64_t *pair_region0;  // [npairs] index of the pair's first compacted region
+  const int32_t *upos;          // [nregions] index into rout (distinct envelopes) of each region's result
   itsx_domain *dom;             // one per region
   int64_t npairs;
   double T;

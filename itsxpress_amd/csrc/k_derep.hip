@@ -256,6 +256,125 @@ __global__ void __launch_bounds__(256) k_len_scatter(int32_t U, const int32_t *_
   }
 }
 
+// ---- envelope memoisation ---------------------------------------------------------------------
+// Re-scoring an envelope (unihit Forward/Backward/decoding/null2) depends only on the profile, the
+// target length L (length model) and the envelope's residues.  Amplicon reads share their conserved
+// flanks, so many (representative, profile) pairs ask for the SAME computation: regions are keyed by
+// XXH64(profile, L, Ld, residues), grouped with the same table kernels as the reads, verified exactly,
+// and only the distinct ones are re-scored.  Results are bit-identical by construction.
+struct RegKey {   // key words of one region: 2-bit residues re-packed from an arbitrary offset, exceptions, ids
+  const uint32_t *w; const uint32_t *exc; int nexc, nw_read, off, Ld, prof, L;
+  int nwd, nex_in;
+  __device__ __forceinline__ uint32_t word(int j) const
+  {
+    const int start = off + 16 * j;
+    const int a = start >> 4, s = (start & 15) * 2;
+    const uint32_t lo = w[a];
+    const uint32_t up = (a + 1 < nw_read) ? w[a + 1] : 0u;
+    uint32_t W = s ? ((lo >> s) | (up << (32 - s))) : lo;
+    const int cnt = Ld - 16 * j;
+    if (cnt < 16) W &= (1u << (2 * cnt)) - 1u;
+    return W;
+  }
+  __device__ __forceinline__ uint32_t operator()(int j) const
+  {
+    if (j < nwd) return word(j);
+    j -= nwd;
+    if (j < nex_in) {                       // the j-th exception inside [off, off+Ld)
+      int seen = 0;
+      for (int e = 0; e < nexc; e++) {
+        const int p = (int)(exc[e] >> 4);
+        if (p >= off && p < off + Ld) { if (seen == j) return ((uint32_t)(p - off) << 4) | (exc[e] & 15u); seen++; }
+      }
+      return 0u;
+    }
+    j -= nex_in;
+    return j == 0 ? (uint32_t)prof : j == 1 ? (uint32_t)L : (uint32_t)Ld;
+  }
+};
+__device__ __forceinline__ RegKey make_regkey(const ReadsDev &rd, int read, int ienv, int jenv, int prof, int L)
+{
+  RegKey k;
+  const int64_t wo = rd.woff[read], eo = rd.excoff[read];
+  k.w = rd.words + wo; k.exc = rd.exc + eo; k.nexc = (int)(rd.excoff[read + 1] - eo); k.nw_read = (int)(rd.woff[read + 1] - wo);
+  k.off = ienv - 1; k.Ld = jenv - ienv + 1; k.prof = prof; k.L = L;
+  k.nwd = (k.Ld + 15) >> 4;
+  int n = 0;
+  for (int e = 0; e < k.nexc; e++) { const int p = (int)(k.exc[e] >> 4); n += (p >= k.off && p < k.off + k.Ld); }
+  k.nex_in = n;
+  return k;
+}
+
+__global__ void __launch_bounds__(256) k_region_keys(ReadsDev rd, const RegionRec *__restrict__ regions, int64_t nr, const PairRec *__restrict__ pairs,
+                                                     const int32_t *__restrict__ sorted_uniq, const int32_t *__restrict__ seed_read,
+                                                     unsigned long long *__restrict__ keys, int32_t *__restrict__ vals, uint64_t mask,
+                                                     uint32_t *__restrict__ slot_of)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nr; g += (int64_t)gridDim.x * blockDim.x) {
+    const RegionRec rg = regions[g];
+    if (rg.pair < 0) { slot_of[g] = 0xFFFFFFFFu; continue; }
+    const PairRec pr = pairs[rg.pair];
+    const RegKey rk = make_regkey(rd, seed_read[sorted_uniq[pr.useq]], rg.ienv, rg.jenv, pr.prof, pr.L);
+    uint64_t key = xxh64_words(rk, rk.nwd + rk.nex_in + 3, 0x9E3779B97F4A7C15ULL);
+    if (key == 0) key = 1;
+    uint64_t slot = (key * 0x9E3779B97F4A7C15ULL >> 20) & mask;
+    for (;;) {
+      const unsigned long long old = atomicCAS(&keys[slot], 0ull, (unsigned long long)key);
+      if (old == 0ull || old == key) { atomicMin(&vals[slot], (int32_t)g); slot_of[g] = (uint32_t)slot; break; }
+      slot = (slot + 1) & mask;
+    }
+  }
+}
+// rep_region[g] = smallest region index with the same key AND the same content; is_uniq[g] = (rep == g).
+// A key collision between different contents just leaves the later region un-shared.
+__global__ void __launch_bounds__(256) k_region_resolve(ReadsDev rd, const RegionRec *__restrict__ regions, int64_t nr, const PairRec *__restrict__ pairs,
+                                                        const int32_t *__restrict__ sorted_uniq, const int32_t *__restrict__ seed_read,
+                                                        const int32_t *__restrict__ vals, const uint32_t *__restrict__ slot_of,
+                                                        int32_t *__restrict__ rep_region, int32_t *__restrict__ is_uniq)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nr; g += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t slot = slot_of[g];
+    if (slot == 0xFFFFFFFFu) { rep_region[g] = -1; is_uniq[g] = 0; continue; }
+    int32_t s = vals[slot];
+    if (s != (int32_t)g) {
+      const RegionRec a = regions[g], b = regions[s];
+      const PairRec pa = pairs[a.pair], pb = pairs[b.pair];
+      bool same = pa.prof == pb.prof && pa.L == pb.L && (a.jenv - a.ienv) == (b.jenv - b.ienv);
+      if (same) {
+        const RegKey ka = make_regkey(rd, seed_read[sorted_uniq[pa.useq]], a.ienv, a.jenv, pa.prof, pa.L);
+        const RegKey kb = make_regkey(rd, seed_read[sorted_uniq[pb.useq]], b.ienv, b.jenv, pb.prof, pb.L);
+        same = ka.nex_in == kb.nex_in;
+        for (int j = 0; same && j < ka.nwd + ka.nex_in; j++) same = ka(j) == kb(j);
+      }
+      if (!same) s = (int32_t)g;
+    }
+    rep_region[g] = s; is_uniq[g] = (s == (int32_t)g);
+  }
+}
+// position of every region's result in the list of distinct regions
+__global__ void __launch_bounds__(256) k_region_upos(int64_t nr, const RegionRec *__restrict__ regions, const PairRec *__restrict__ pairs,
+                                                     const int32_t *__restrict__ is_uniq, const int32_t *__restrict__ urank,
+                                                     const int64_t *__restrict__ rseg, const int64_t *__restrict__ useg,
+                                                     int32_t *__restrict__ upos, RegionRec *__restrict__ ulist)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nr; g += (int64_t)gridDim.x * blockDim.x) {
+    if (!is_uniq[g]) continue;
+    const RegionRec rg = regions[g];
+    const int p = pairs[rg.pair].prof;
+    const int64_t pos = useg[p] + (int64_t)(urank[g] - urank[rseg[p]]);
+    upos[g] = (int32_t)pos;
+    ulist[pos] = rg;
+  }
+}
+__global__ void __launch_bounds__(256) k_region_upos_follow(int64_t nr, const int32_t *__restrict__ rep_region, const int32_t *__restrict__ is_uniq,
+                                                            int32_t *__restrict__ upos)
+{
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nr; g += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t s = rep_region[g];
+    if (s >= 0 && !is_uniq[g]) upos[g] = upos[s];
+  }
+}
+
 // ---- host launchers ----
 static inline int grid_for(int64_t n, int block = 256, int cap = 8192)
 {
@@ -287,6 +406,25 @@ void launch_uniques(int64_t n, const int32_t *rep_of, const int32_t *seed_rank, 
 void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *hist, int32_t lcap, hipStream_t st)
 {
   hipLaunchKernelGGL(k_len_hist, dim3(grid_for(U)), dim3(256), 0, st, U, seed_read, len, hist, lcap);
+}
+void launch_region_keys(const ReadsDev &rd, const RegionRec *regions, int64_t nr, const PairRec *pairs, const int32_t *sorted_uniq,
+                        const int32_t *seed_read, unsigned long long *keys, int32_t *vals, uint64_t mask, uint32_t *slot_of, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_region_keys, dim3(grid_for(nr)), dim3(256), 0, st, rd, regions, nr, pairs, sorted_uniq, seed_read, keys, vals, mask, slot_of);
+}
+void launch_region_resolve(const ReadsDev &rd, const RegionRec *regions, int64_t nr, const PairRec *pairs, const int32_t *sorted_uniq,
+                           const int32_t *seed_read, const int32_t *vals, const uint32_t *slot_of, int32_t *rep_region, int32_t *is_uniq, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_region_resolve, dim3(grid_for(nr)), dim3(256), 0, st, rd, regions, nr, pairs, sorted_uniq, seed_read, vals, slot_of, rep_region, is_uniq);
+}
+void launch_region_upos(int64_t nr, const RegionRec *regions, const PairRec *pairs, const int32_t *is_uniq, const int32_t *urank,
+                        const int64_t *rseg, const int64_t *useg, int32_t *upos, RegionRec *ulist, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_region_upos, dim3(grid_for(nr)), dim3(256), 0, st, nr, regions, pairs, is_uniq, urank, rseg, useg, upos, ulist);
+}
+void launch_region_upos_follow(int64_t nr, const int32_t *rep_region, const int32_t *is_uniq, int32_t *upos, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_region_upos_follow, dim3(grid_for(nr)), dim3(256), 0, st, nr, rep_region, is_uniq, upos);
 }
 void launch_len_scatter(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *cursor, int32_t lcap,
                         int32_t *sorted_uniq, hipStream_t st)

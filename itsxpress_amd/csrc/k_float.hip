@@ -515,29 +515,36 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
     float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, XF, 7, lane));
     float btot = 0.f, etot = 0.f;
     *slab_at(a.slab, r0, 0, XF, 12, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 13, lane) = 0.f;
-    float fN = *slab_at(a.slab, r0, 0, XF, 1, lane), fJ = *slab_at(a.slab, r0, 0, XF, 2, lane);
-    float fB = *slab_at(a.slab, r0, 0, XF, 3, lane), fC = *slab_at(a.slab, r0, 0, XF, 4, lane);
-    float fS = *slab_at(a.slab, r0, 0, XF, 5, lane);
-    float bB = *slab_at(a.slab, r0, 0, XF, 9, lane), bS = *slab_at(a.slab, r0, 0, XF, 11, lane);
+    // one row of special-state values; the next row is requested while the current one is consumed, so the
+    // serial chain of sums never waits on HBM latency
+    struct DRow { float fE, fN, fJ, fB, fC, fS, bE, bN, bJ, bB, bC, bS; };
+    auto load_row = [&](int j) {
+      DRow d;
+      d.fE = *slab_at(a.slab, r0, j, XF, 0, lane); d.fN = *slab_at(a.slab, r0, j, XF, 1, lane);
+      d.fJ = *slab_at(a.slab, r0, j, XF, 2, lane); d.fB = *slab_at(a.slab, r0, j, XF, 3, lane);
+      d.fC = *slab_at(a.slab, r0, j, XF, 4, lane); d.fS = *slab_at(a.slab, r0, j, XF, 5, lane);
+      d.bE = *slab_at(a.slab, r0, j, XF, 6, lane); d.bN = *slab_at(a.slab, r0, j, XF, 7, lane);
+      d.bJ = *slab_at(a.slab, r0, j, XF, 8, lane); d.bB = *slab_at(a.slab, r0, j, XF, 9, lane);
+      d.bC = *slab_at(a.slab, r0, j, XF, 10, lane); d.bS = *slab_at(a.slab, r0, j, XF, 11, lane);
+      return d;
+    };
+    DRow prv = load_row(0);
+    DRow nxt = load_row(L >= 1 ? 1 : 0);
     int ri = -1; bool triggered = false;
     for (int j = 1; j <= L; j++) {
+      const DRow cur = nxt;
+      if (j < L) nxt = load_row(j + 1);
       const float btot_prev = btot, etot_prev = etot;
-      btot = btot + (fB * bB * fS * scaleproduct);
-      if (own) scaleproduct *= fS / bS;
-      const float fEj = *slab_at(a.slab, r0, j, XF, 0, lane), fSj = *slab_at(a.slab, r0, j, XF, 5, lane);
-      const float bEj = *slab_at(a.slab, r0, j, XF, 6, lane), bNj = *slab_at(a.slab, r0, j, XF, 7, lane);
-      const float bJj = *slab_at(a.slab, r0, j, XF, 8, lane), bCj = *slab_at(a.slab, r0, j, XF, 10, lane);
-      etot = etot + (fEj * bEj * fSj * scaleproduct);
+      btot = btot + (prv.fB * prv.bB * prv.fS * scaleproduct);
+      if (own) scaleproduct *= prv.fS / prv.bS;
+      etot = etot + (cur.fE * cur.bE * cur.fS * scaleproduct);
       float njcp;
-      njcp = fN * bNj * ploop * scaleproduct;
-      njcp += fJ * bJj * ploop * scaleproduct;
-      njcp += fC * bCj * ploop * scaleproduct;
+      njcp = prv.fN * cur.bN * ploop * scaleproduct;
+      njcp += prv.fJ * cur.bJ * ploop * scaleproduct;
+      njcp += prv.fC * cur.bC * ploop * scaleproduct;
       const float mocc = (float)(1. - (double)njcp);
       *slab_at(a.slab, r0, j, XF, 12, lane) = btot; *slab_at(a.slab, r0, j, XF, 13, lane) = etot;
-      // advance the "previous row" registers
-      fN = *slab_at(a.slab, r0, j, XF, 1, lane); fJ = *slab_at(a.slab, r0, j, XF, 2, lane);
-      fB = *slab_at(a.slab, r0, j, XF, 3, lane); fC = *slab_at(a.slab, r0, j, XF, 4, lane); fS = fSj;
-      bB = *slab_at(a.slab, r0, j, XF, 9, lane); bS = *slab_at(a.slab, r0, j, XF, 11, lane);
+      prv = cur;
       if (!triggered) {
         if (mocc - (btot - btot_prev) < rt2) ri = j;
         else if (ri == -1) ri = j;
@@ -677,12 +684,12 @@ __global__ void __launch_bounds__(64, 2) k_env_bwd(EnvArgs a, int wave0)
     scale_row<QT>(R, Q, sL);
   }
   auto store_row = [&](int i, float s) {
-    *eslab_at(a.slab, r0, i, 24, lane) = (f4){xN, xJ, xC, s};
+    __builtin_nontemporal_store((f4){xN, xJ, xC, s}, eslab_at(a.slab, r0, i, 24, lane));
 #pragma unroll
     for (int q = 0; q < (QT ? QT : QMAX); q++) {
       if (QT == 0 && q >= Q) break;
-      *eslab_at(a.slab, r0, i, q * 2, lane) = (f4){R.m[q].a.x, R.m[q].a.y, R.m[q].b.x, R.m[q].b.y};
-      *eslab_at(a.slab, r0, i, q * 2 + 1, lane) = (f4){R.i[q].a.x, R.i[q].a.y, R.i[q].b.x, R.i[q].b.y};
+      __builtin_nontemporal_store((f4){R.m[q].a.x, R.m[q].a.y, R.m[q].b.x, R.m[q].b.y}, eslab_at(a.slab, r0, i, q * 2, lane));
+      __builtin_nontemporal_store((f4){R.i[q].a.x, R.i[q].a.y, R.i[q].b.x, R.i[q].b.y}, eslab_at(a.slab, r0, i, q * 2 + 1, lane));
     }
   };
   if (active) store_row(Ld, sL);
@@ -763,7 +770,7 @@ __global__ void __launch_bounds__(64, 2) k_env_post(EnvArgs a, int wave0)
 #pragma unroll
       for (int q = 0; q < (QT ? QT : QMAX); q++) {
         if (QT == 0 && q >= Q) break;
-        const f4 bm4 = *eslab_at(a.slab, r0, r, q * 2, lane), bi4 = *eslab_at(a.slab, r0, r, q * 2 + 1, lane);
+        const f4 bm4 = __builtin_nontemporal_load(eslab_at(a.slab, r0, r, q * 2, lane)), bi4 = __builtin_nontemporal_load(eslab_at(a.slab, r0, r, q * 2 + 1, lane));
         V4 bm, bi;
         bm.a = (f2){bm4.x, bm4.y}; bm.b = (f2){bm4.z, bm4.w}; bi.a = (f2){bi4.x, bi4.y}; bi.b = (f2){bi4.z, bi4.w};
         const V4 pm = vmul(vmul(R.m[q], bm), totrv);
@@ -777,7 +784,7 @@ __global__ void __launch_bounds__(64, 2) k_env_post(EnvArgs a, int wave0)
           accI_s[q * 64 + lane] = (f4){ai.a.x, ai.a.y, ai.b.x, ai.b.y};
         }
       }
-      const f4 bsp = *eslab_at(a.slab, r0, r, 24, lane);
+      const f4 bsp = __builtin_nontemporal_load(eslab_at(a.slab, r0, r, 24, lane));
       const float bN = bsp.x, bJ = bsp.y, bC = bsp.z, bS = bsp.w;
       const float pN = fNp * bN * ploop * scaleproduct;
       const float pJ = fJp * bJ * ploop * scaleproduct;
@@ -896,7 +903,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   const float nullsc = po.nullsc;
   if (nd_all == 1) {
     // the common case, one envelope: every running sum of the general path collapses to one term
-    const RegionOut ro = a.rout[g0];
+    const RegionOut ro = a.rout[a.upos[g0]];
     if (!ro.ok) return;
     const RegionRec rg = a.regions[g0];
     const float dc = ro.domcorrection;
@@ -928,7 +935,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   float seqbias = 0.0f;
   int ndom = 0;
   for (int d = 0; d < nd_all; d++) {
-    const RegionOut ro = a.rout[g0 + d];
+    const RegionOut ro = a.rout[a.upos[g0 + d]];
     if (ro.ok) {
       if (ndom == 0) seqbias = ro.domcorrection;           // first envelope: same sum, same order
       else {
@@ -949,7 +956,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   float seq_score = (float)((double)(po.fwdsc - (nullsc + seqbias)) / kLn2);
   float sum_score = 0.0f, sbias = 0.0f; int Ldsum = 0;
   for (int d = 0; d < nd_all; d++) {
-    const RegionOut ro = a.rout[g0 + d];
+    const RegionOut ro = a.rout[a.upos[g0 + d]];
     if (!ro.ok) continue;
     const RegionRec rg = a.regions[g0 + d];
     if (ro.envsc - ro.domcorrection > 0.0f) { sum_score += ro.envsc; Ldsum += rg.jenv - rg.ienv + 1; sbias += ro.domcorrection; }
@@ -962,7 +969,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   const int seq_rep = ((double)seq_score >= a.T);
   int k = 0;
   for (int d = 0; d < nd_all; d++) {
-    const RegionOut ro = a.rout[g0 + d];
+    const RegionOut ro = a.rout[a.upos[g0 + d]];
     const RegionRec rg = a.regions[g0 + d];
     emit_domain(a, g0 + d, pr, pp, rg, ro, ro.ok ? ro.domcorrection : 0.0f, ro.ok ? k : -1, ndom, po.flags, nullsc, seq_score, final_bias,
                 seq_rep, L, lt.lognn3, log_omega);

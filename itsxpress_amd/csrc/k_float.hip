@@ -95,6 +95,10 @@ DEV T7 ld7(const float *tf, int q)
   return t;
 }
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// wait for everything requested during the previous node-group (scalar operands + the LDS emission vector),
+// BEFORE the next group's requests are issued: otherwise the wait at the first use of the current operands
+// (scalar loads return out of order, so it can only be lgkmcnt(0)) would also wait for the prefetch
+#define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
 // ---- one Forward row: HMMER's striped forward_engine inner body, literally --------------
 template <int QT>
@@ -109,15 +113,18 @@ DEV void fwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
   V4 sv;
   if constexpr (QT != 0) {
     T7 cur = ld7(tf, 0);
+    V4 ecur = vld(rfx);
 #pragma unroll
     for (int q = 0; q < QT; q++) {
+      WAIT_LGKM0();
       T7 nxt = cur;
-      if (q + 1 < QT) nxt = ld7(tf, q + 1);
+      V4 enxt = ecur;
+      if (q + 1 < QT) { nxt = ld7(tf, q + 1); enxt = vld(rfx + (q + 1) * 4); }   // next group's operands fly during this group
       sv = vmul(xBv, cur.bm);
       sv = vadd(sv, vmul(mpv, cur.mm));
       sv = vadd(sv, vmul(ipv, cur.im));
       sv = vadd(sv, vmul(dpv, cur.dm));
-      sv = vmul(sv, vld(rfx + q * 4));
+      sv = vmul(sv, ecur);
       xEv = vadd(xEv, sv);
       mpv = R.m[q]; dpv = R.d[q]; ipv = R.i[q];
       R.m[q] = sv; R.d[q] = dcv;
@@ -125,7 +132,7 @@ DEV void fwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
       sv = vmul(mpv, cur.mi);
       R.i[q] = vadd(sv, vmul(ipv, cur.ii));
       SCHED_FENCE();
-      cur = nxt;
+      cur = nxt; ecur = enxt;
     }
     V4 dd[QT];
 #pragma unroll
@@ -279,19 +286,22 @@ DEV void bwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
     // tb = the Backward re-ordering of the same transition table (DevProfile::tb follows tf)
     const float *tb = tf + QMAX * 8 * 4 + opaque_zero();
     T6 cur = ld6(tb, QT - 1);
+    V4 ecur = vld(rfx + (QT - 1) * 4);
 #pragma unroll
     for (int q = QT - 1; q >= 0; q--) {
+      WAIT_LGKM0();
       T6 nxt = cur;
-      if (q > 0) nxt = ld6(tb, q - 1);
+      V4 enxt = ecur;
+      if (q > 0) { nxt = ld6(tb, q - 1); enxt = vld(rfx + (q - 1) * 4); }
       ipv = R.i[q];
       R.i[q] = vadd(vmul(ipv, cur.ii), vmul(mpv, cur.imn));
       R.d[q] = vmul(mpv, cur.dmn);
       mcv = vadd(vmul(ipv, cur.mi), vmul(mpv, cur.mmn));
-      mpv = vmul(R.m[q], vld(rfx + q * 4));
+      mpv = vmul(R.m[q], ecur);
       R.m[q] = mcv;
       xBv = vadd(xBv, vmul(mpv, cur.bm));
       SCHED_FENCE();
-      cur = nxt;
+      cur = nxt; ecur = enxt;
     }
   } else {
     const float *tfo = tf + opaque_zero();
@@ -315,6 +325,12 @@ DEV void bwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
   bwd_dd_md<QT>(R, Q, tf, vset(xE), false);
 }
 
+DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
+{
+  for (int i = threadIdx.x; i < NCODE * QMAX * 4; i += 64) rf_s[i] = pp->rf[i];
+  __syncthreads();
+}
+
 // ---- slab addressing: [row][field][lane] ---------------------------------------------------
 constexpr int XF = 14;     // fields per row in the parser slab: fwd E N J B C S | bck E N J B C S | btot etot
 DEV float *slab_at(float *slab, int64_t row0, int row, int nfields, int field, int lane)
@@ -322,21 +338,16 @@ DEV float *slab_at(float *slab, int64_t row0, int row, int nfields, int field, i
   return slab + (((row0 + row) * nfields + field) * 64 + lane);
 }
 
-DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
-{
-  for (int i = threadIdx.x; i < NCODE * QMAX * 4; i += 64) rf_s[i] = pp->rf[i];
-  __syncthreads();
-}
 
 // =========================================================================================
 // K1: bias filter + Forward parser + F3 test, for one wave of survivors of the MSV filter
 template <int QT>
 __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
 {
-  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const DevProfile *pp = a.prof + uni(wd.prof);
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   fill_lds_rf(rf_s, pp);
   const float *tf = pp->tf;
   const int Q = QT ? QT : uni(pp->Q);
@@ -370,7 +381,9 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
           n1 = 0.0f; n1 += d0 * t01; n1 += d1 * t11; n1 *= pp->feo[x * 2 + 1];
         }
         float mx = 0.0f; if (n0 > mx) mx = n0; if (n1 > mx) mx = n1;
-        d0 = n0 / mx; d1 = n1 / mx;
+        // x / x == 1 exactly: only the smaller state needs the division
+        const float q01 = ((n0 > n1) ? n1 : n0) / mx;
+        d0 = (n0 == mx) ? 1.0f : q01; d1 = (n1 == mx) ? 1.0f : q01;
         logsc += (float)det_log((double)mx);
       }
     }
@@ -395,9 +408,11 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
     *slab_at(a.slab, r0, 0, XF, 0, lane) = xE; *slab_at(a.slab, r0, 0, XF, 1, lane) = xN;
     *slab_at(a.slab, r0, 0, XF, 2, lane) = xJ; *slab_at(a.slab, r0, 0, XF, 3, lane) = xB;
     *slab_at(a.slab, r0, 0, XF, 4, lane) = xC; *slab_at(a.slab, r0, 0, XF, 5, lane) = 1.0f;
+    int xnext = sq.code(0);                  // residue of the NEXT row: its loads fly during the current row
     for (int i = 1; i <= Lw; i++) {
       if (i <= L) {
-        const int x = sq.code(i - 1);
+        const int x = xnext;
+        if (i < L) xnext = sq.code(i);
         fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);
         float sc = 1.0f;
         if (xE > 1.0e4f) {
@@ -425,10 +440,10 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
 template <int QT>
 __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
 {
-  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const DevProfile *pp = a.prof + uni(wd.prof);
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   fill_lds_rf(rf_s, pp);
   const float *tf = pp->tf;
   const int Q = QT ? QT : uni(pp->Q);
@@ -468,14 +483,18 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
       *slab_at(a.slab, r0, L, XF, 8, lane) = xJ; *slab_at(a.slab, r0, L, XF, 9, lane) = xB;
       *slab_at(a.slab, r0, L, XF, 10, lane) = xC; *slab_at(a.slab, r0, L, XF, 11, lane) = sL;
     }
+    int xnext = (alive && L >= 2) ? sq.code(L - 1) : 0;
+    float sfw_next = (alive && L >= 2) ? *slab_at(a.slab, r0, L - 1, XF, 5, lane) : 1.0f;
     for (int i = Lw - 1; i >= 1; i--) {
       if (alive && i <= L - 1) {
-        const int x = sq.code(i);          // residue i+1, 0-based index i
+        const int x = xnext;               // residue i+1, 0-based index i
+        xnext = sq.code(i - 1);            // the next row down needs residue i (0-based i-1); row 0 reuses it
+        const float sfw = sfw_next;        // Forward's scale factor of this row, requested one row ago
+        if (i > 1) sfw_next = *slab_at(a.slab, r0, i - 1, XF, 5, lane);
         bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);
         if (xB > 1.0e16f) own = 1;
         // branch-free on purpose: a branch here lets the optimizer sink the whole row update below it,
         // stretching the live ranges of every transition operand (hundreds of SGPR spills)
-        const float sfw = *slab_at(a.slab, r0, i, XF, 5, lane);
         const float sown = (xB > 1.0e4f) ? xB : 1.0f;
         const float s = own ? sown : sfw;
         if (s > 1.0f) {
@@ -615,10 +634,10 @@ DEV EnvLane env_lane(const EnvArgs &a, const WaveDesc &wd, int lane)
 template <int QT>
 __global__ void __launch_bounds__(64, 2) k_env_fwd(EnvArgs a, int wave0)
 {
-  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const DevProfile *pp = a.prof + uni(wd.prof);
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   fill_lds_rf(rf_s, pp);
   const float *tf = pp->tf;
   const int Q = QT ? QT : uni(pp->Q);
@@ -658,10 +677,10 @@ __global__ void __launch_bounds__(64, 2) k_env_fwd(EnvArgs a, int wave0)
 template <int QT>
 __global__ void __launch_bounds__(64, 2) k_env_bwd(EnvArgs a, int wave0)
 {
-  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const DevProfile *pp = a.prof + uni(wd.prof);
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   fill_lds_rf(rf_s, pp);
   const float *tf = pp->tf;
   const int Q = QT ? QT : uni(pp->Q);
@@ -729,13 +748,13 @@ __global__ void __launch_bounds__(64, 2) k_env_bwd(EnvArgs a, int wave0)
 template <int QT>
 __global__ void __launch_bounds__(64, 2) k_env_post(EnvArgs a, int wave0)
 {
-  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   // this sweep needs the DP row (144 registers) plus 96 posterior sums per lane; the 48 insert-state
   // sums live in LDS ([q][lane] x float4: conflict-free b128 accesses) so the rest fits in 256 VGPRs
   __shared__ f4 accI_s[QMAX * 64];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const DevProfile *pp = a.prof + uni(wd.prof);
+  __shared__ __attribute__((aligned(16))) float rf_s[NCODE * QMAX * 4];
   fill_lds_rf(rf_s, pp);
   const float *tf = pp->tf;
   const int Q = QT ? QT : uni(pp->Q);

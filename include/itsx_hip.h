@@ -78,8 +78,9 @@ typedef struct {
   /* dominant-kernel accounting for bench.py's roofline block */
   float   ms_msv_kernel;  int64_t msv_cells;  int64_t msv_launches;
   float   ms_fwd_kernel, ms_bwd_kernel;  int64_t fwd_rows;   /* lane-rows: sum of target lengths over surviving pairs */
-  float   ms_env_kernel;  int32_t pad0;  int64_t env_rows;    /* the three envelope sweeps together; lane-rows per sweep */
+  float   ms_env_kernel;  float ms_bias_kernel;  int64_t env_rows;    /* the three envelope sweeps together; lane-rows per sweep */
   int64_t n_env_unique;           /* distinct (profile, length, envelope subsequence) actually re-scored */
+  float   ms_decode_kernel;  int32_t pad1;
 } itsx_stats;
 
 int         itsx_abi_version(void);

@@ -612,7 +612,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = ctx->nregions_padded = 0;
   ctx->have_search = true; ctx->have_final = false;
   if (U == 0) return ITSX_OK;
@@ -727,6 +727,12 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));
   {
     StageTimer tm(st);
+    {   // bias-composition filter for every survivor (its own, full-occupancy kernel)
+      FloatArgs a{};
+      a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+      a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.F1 = F1; a.F3 = F3;
+      StageTimer k(st); launch_bias(a, NP, st); S.ms_bias_kernel = k.stop();
+    }
     DBuf<float> &d_slab = ctx->w_slab;
     int64_t slab_rows_alloc = (int64_t)(d_slab.cap / (14 * 64));
     int w0 = 0;
@@ -741,6 +747,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
       { StageTimer k(st); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); S.ms_fwd_kernel += k.stop(); }
       { StageTimer k(st); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); S.ms_bwd_kernel += k.stop(); }
+      { StageTimer k(st); launch_decode(a, w1 - w0, w0, st); S.ms_decode_kernel += k.stop(); }
       for (int w = w0; w < w1; w++) S.fwd_rows += (int64_t)(rows[w] - 1) * waves[w].count;
       w0 = w1;
     }

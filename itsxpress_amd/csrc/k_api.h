@@ -88,8 +88,10 @@ struct FloatArgs {
   RegionRec *regions;           // [npairs][MAXDOM] raw, before compaction
   double F1, F3;
 };
+void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st);
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
+void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st);
 
 struct EnvArgs {
   ReadsDev rd;

@@ -340,6 +340,56 @@ DEV float *slab_at(float *slab, int64_t row0, int row, int nfields, int field, i
 
 
 // =========================================================================================
+// K0: bias-composition filter for every MSV survivor (HMMER p7_bg_FilterScore): a 2-state HMM forward
+// over the whole target, rescaled by the row maximum with one deterministic log per residue.  Its own
+// kernel: it needs ~40 registers, so it runs at full occupancy instead of inside the 2-wave Forward kernel.
+__global__ void __launch_bounds__(256) k_bias(FloatArgs a, int64_t npairs)
+{
+  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= npairs) return;
+  const PairRec pr = a.pairs[pi];
+  if (pr.prof < 0) return;
+  const DevProfile *pp = a.prof + pr.prof;
+  const int L = pr.L;
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  const LenTables lt = a.lt[L];
+  PairOut po;
+  po.nullsc = lt.nullsc; po.pass_bias = 0; po.pass_fwd = 0; po.nregions = 0; po.ndom = 0; po.flags = 0;
+  po.filtersc = 0.f; po.fwdsc = 0.f; po.bcksc = 0.f;
+  float usc;
+  if (pr.xj == 255) usc = __builtin_inff();
+  else { usc = ((float)(pr.xj - lt.tjb) - 190.0f); usc /= (float)(3.0 / kLn2); usc -= 3.0f; }
+  po.msv_sc = usc;
+  {
+    const float t00 = lt.p1, t01 = 1.0f - lt.p1, t10 = pp->ft10, t11 = pp->ft11;
+    float d0 = 0.f, d1 = 0.f, logsc = 0.0f;
+    uint32_t w = 0;
+    for (int i = 1; i <= L; i++) {
+      if (((i - 1) & 15) == 0) w = sq.w[(i - 1) >> 4];
+      int x = (int)(w & 3u); w >>= 2;
+      for (int e = 0; e < sq.nexc; e++) { const uint32_t v = sq.exc[e]; if ((int)(v >> 4) == i - 1) x = (int)(v & 15u); }
+      float n0, n1;
+      if (i == 1) { n0 = pp->feo[x * 2] * pp->fpi0; n1 = pp->feo[x * 2 + 1] * pp->fpi1; }
+      else {
+        n0 = 0.0f; n0 += d0 * t00; n0 += d1 * t10; n0 *= pp->feo[x * 2];
+        n1 = 0.0f; n1 += d0 * t01; n1 += d1 * t11; n1 *= pp->feo[x * 2 + 1];
+      }
+      float mx = 0.0f; if (n0 > mx) mx = n0; if (n1 > mx) mx = n1;
+      // x / x == 1 exactly: only the smaller state needs the division
+      const float q01 = ((n0 > n1) ? n1 : n0) / mx;
+      d0 = (n0 == mx) ? 1.0f : q01; d1 = (n1 == mx) ? 1.0f : q01;
+      logsc += (float)det_log((double)mx);
+    }
+    float e = 0.0f; e += d0 * 1.0f; e += d1 * 1.0f;
+    logsc += (float)det_log((double)e);
+    po.filtersc = logsc + lt.bias_a + lt.bias_b;
+  }
+  const double P = gumbel_surv((double)(usc - po.filtersc) / kLn2, (double)pp->ev[0], (double)pp->ev[1]);
+  po.pass_bias = !(P > a.F1);
+  a.pout[pi] = po;
+}
+
+// =========================================================================================
 // K1: bias filter + Forward parser + F3 test, for one wave of survivors of the MSV filter
 template <int QT>
 __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
@@ -357,44 +407,8 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
   const int L = pr.L;
   const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
   const LenTables lt = a.lt[L];
-  PairOut po;
-  po.nullsc = lt.nullsc; po.pass_bias = 0; po.pass_fwd = 0; po.nregions = 0; po.ndom = 0; po.flags = 0;
-  po.filtersc = 0.f; po.fwdsc = 0.f; po.bcksc = 0.f;
-  // MSV score back from its byte
-  float usc;
-  if (pr.xj == 255) usc = __builtin_inff();
-  else { usc = ((float)(pr.xj - lt.tjb) - 190.0f); usc /= (float)(3.0 / kLn2); usc -= 3.0f; }
-  po.msv_sc = usc;
+  PairOut po = a.pout[pi];            // filtersc / pass_bias come from k_bias
   const int Lw = wd.rows - 1;       // longest sequence in this wave
-
-  // ---- bias-composition filter: 2-state HMM forward, rescaled by the row max every row
-  {
-    const float t00 = lt.p1, t01 = 1.0f - lt.p1, t10 = pp->ft10, t11 = pp->ft11;
-    float d0 = 0.f, d1 = 0.f, logsc = 0.0f;
-    for (int i = 1; i <= Lw; i++) {
-      if (i <= L) {
-        const int x = sq.code(i - 1);
-        float n0, n1;
-        if (i == 1) { n0 = pp->feo[x * 2] * pp->fpi0; n1 = pp->feo[x * 2 + 1] * pp->fpi1; }
-        else {
-          n0 = 0.0f; n0 += d0 * t00; n0 += d1 * t10; n0 *= pp->feo[x * 2];
-          n1 = 0.0f; n1 += d0 * t01; n1 += d1 * t11; n1 *= pp->feo[x * 2 + 1];
-        }
-        float mx = 0.0f; if (n0 > mx) mx = n0; if (n1 > mx) mx = n1;
-        // x / x == 1 exactly: only the smaller state needs the division
-        const float q01 = ((n0 > n1) ? n1 : n0) / mx;
-        d0 = (n0 == mx) ? 1.0f : q01; d1 = (n1 == mx) ? 1.0f : q01;
-        logsc += (float)det_log((double)mx);
-      }
-    }
-    float e = 0.0f; e += d0 * 1.0f; e += d1 * 1.0f;
-    logsc += (float)det_log((double)e);
-    po.filtersc = logsc + lt.bias_a + lt.bias_b;
-  }
-  {
-    double P = gumbel_surv((double)(usc - po.filtersc) / kLn2, (double)pp->ev[0], (double)pp->ev[1]);
-    po.pass_bias = !(P > a.F1);
-  }
 
   // ---- Forward parser
   {
@@ -527,6 +541,28 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
       po.bcksc = (float)((double)totscale + det_log((double)xN));
     }
   }
+  if (active) { po.nregions = 0; po.ndom = 0; po.flags = (own ? 4 : 0) | (bad ? 8 : 0); a.pout[pi] = po; }
+}
+
+// =========================================================================================
+// K2b: posterior decoding of domain starts / ends / occupancy and the region scan, rows ascending (the order
+// the sums are defined in).  ~25 flops per row on 12 values streamed from the slab: latency-bound, so it is
+// its own low-register kernel and runs at full occupancy instead of at the DP kernels' 2 waves per SIMD.
+__global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
+{
+  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  const bool active = lane < wd.count;
+  const int64_t pi = wd.first + (active ? lane : 0);
+  const PairRec pr = a.pairs[pi];
+  PairOut po = a.pout[pi];
+  const bool alive = active && po.pass_fwd;
+  const int own = (po.flags & 4) ? 1 : 0;
+  const bool bad = (po.flags & 8) != 0;
+  const int L = pr.L;
+  const int64_t r0 = wd.slab;
+  const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
+  const float ploop = 1.0f - pmove;
   // ---- posterior decoding + region scan, rows ascending (the order the sums are defined in)
   int nreg = 0, nkept = 0, flags = 0;
   if (alive && !bad) {
@@ -589,7 +625,7 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
     }
     if (scaleproduct == __builtin_inff()) { nreg = 0; nkept = 0; }
   }
-  if (active) { po.nregions = nreg; po.ndom = nkept; po.flags = flags; a.pout[pi] = po; }
+  if (active && alive) { po.nregions = nreg; po.ndom = nkept; po.flags = flags; a.pout[pi] = po; }
 }
 
 // =========================================================================================
@@ -1056,6 +1092,11 @@ __global__ void __launch_bounds__(256) k_positions(const itsx_domain *__restrict
 }
 
 // ---- host launchers -----------------------------------------------------------------------
+void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st)
+{
+  if (npairs <= 0) return;
+  hipLaunchKernelGGL(k_bias, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, a, npairs);
+}
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
 {
   if (nwaves <= 0) return;
@@ -1067,6 +1108,11 @@ void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q,
   if (nwaves <= 0) return;
   if (generic_q) hipLaunchKernelGGL(k_bwd_decode<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
   else           hipLaunchKernelGGL(k_bwd_decode<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+}
+void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st)
+{
+  if (nwaves <= 0) return;
+  hipLaunchKernelGGL(k_decode, dim3(nwaves), dim3(64), 0, st, a, wave0);
 }
 void launch_envelopes(const EnvArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
 {

@@ -144,13 +144,21 @@ DEV void fwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
       R.d[q] = vadd(dcv, R.d[q]);
       dcv = vmul(R.d[q], dd[q]);
     }
+    // passes 2-4 only extend D->D across lanes: after j shifts the j lowest lanes of dcv are +0 and stay +0,
+    // and x + (+0) == x bit-for-bit for the non-negative DP values, so passes 3 and 4 skip the low lane pair
+    dcv = vrsh(dcv);
 #pragma unroll
-    for (int j = 1; j < 4; j++) {
+    for (int q = 0; q < QT; q++) {
+      R.d[q] = vadd(dcv, R.d[q]);
+      dcv = vmul(dcv, dd[q]);
+    }
+#pragma unroll
+    for (int j = 2; j < 4; j++) {
       dcv = vrsh(dcv);
 #pragma unroll
       for (int q = 0; q < QT; q++) {
-        R.d[q] = vadd(dcv, R.d[q]);
-        dcv = vmul(dcv, dd[q]);
+        R.d[q].b = dcv.b + R.d[q].b;
+        dcv.b = dcv.b * dd[q].b;
       }
     }
 #pragma unroll
@@ -223,13 +231,20 @@ DEV void bwd_dd_md(Row<QT> &R, const int Q, const float *__restrict__ tf, const 
         else { R.d[q] = vadd(R.d[q], vadd(dcv, xEv)); R.m[q] = vadd(R.m[q], xEv); }
         dpv = R.d[q];
       }
+      // as in Forward: after j left shifts the j highest lanes of dcv are +0, so passes 3 and 4 skip the high pair
+      dcv = vlsh(dcv);
 #pragma unroll
-      for (int j = 1; j < 4; j++) {
+      for (int q = QT - 1; q >= 0; q--) {
+        dcv = vmul(dcv, dd[q]);
+        R.d[q] = vadd(R.d[q], dcv);
+      }
+#pragma unroll
+      for (int j = 2; j < 4; j++) {
         dcv = vlsh(dcv);
 #pragma unroll
         for (int q = QT - 1; q >= 0; q--) {
-          dcv = vmul(dcv, dd[q]);
-          R.d[q] = vadd(R.d[q], dcv);
+          dcv.a = dcv.a * dd[q].a;
+          R.d[q].a = R.d[q].a + dcv.a;
         }
       }
     }
@@ -492,19 +507,38 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
       scale_row<QT>(R, Q, sL);
     }
     totscale = (float)det_log((double)sL);
-    if (alive) {
-      *slab_at(a.slab, r0, L, XF, 6, lane) = xE; *slab_at(a.slab, r0, L, XF, 7, lane) = xN;
-      *slab_at(a.slab, r0, L, XF, 8, lane) = xJ; *slab_at(a.slab, r0, L, XF, 9, lane) = xB;
-      *slab_at(a.slab, r0, L, XF, 10, lane) = xC; *slab_at(a.slab, r0, L, XF, 11, lane) = sL;
-    }
+    // The posterior-decoding pass needs, per row, five products of Forward and Backward special-state values.
+    // They are formed here (the Forward row is prefetched while the Backward row is computed) in exactly the
+    // association order of the decoding formulas -- ((f*b)*c), later times the running scale product -- so the
+    // decoding kernel streams 5 floats per row instead of 12:
+    //   field 9 : T1[i] = (fB[i]*bB[i])*fS[i]         -> btot[i+1]        field 6 : T2[i] = (fE[i]*bE[i])*fS[i] -> etot[i]
+    //   field 7/8/10 : (fN|fJ|fC)[i-1]*b(N|J|C)[i]*ploop -> occupancy       field 11: fS[i]/bS[i] (used only with own scales)
+    struct FRow { float E, N, J, B, C, S; };
+    auto load_f = [&](int i) {
+      FRow f;
+      f.E = *slab_at(a.slab, r0, i, XF, 0, lane); f.N = *slab_at(a.slab, r0, i, XF, 1, lane); f.J = *slab_at(a.slab, r0, i, XF, 2, lane);
+      f.B = *slab_at(a.slab, r0, i, XF, 3, lane); f.C = *slab_at(a.slab, r0, i, XF, 4, lane); f.S = *slab_at(a.slab, r0, i, XF, 5, lane);
+      return f;
+    };
+    auto store_terms = [&](int i, const FRow &fc, const FRow &fp, float s) {
+      *slab_at(a.slab, r0, i, XF, 6, lane) = fc.E * xE * fc.S;
+      *slab_at(a.slab, r0, i, XF, 7, lane) = fp.N * xN * ploop;
+      *slab_at(a.slab, r0, i, XF, 8, lane) = fp.J * xJ * ploop;
+      *slab_at(a.slab, r0, i, XF, 9, lane) = fc.B * xB * fc.S;
+      *slab_at(a.slab, r0, i, XF, 10, lane) = fp.C * xC * ploop;
+      *slab_at(a.slab, r0, i, XF, 11, lane) = fc.S / s;
+    };
+    FRow fcur, fprv;
+    fcur.E = fcur.N = fcur.J = fcur.B = fcur.C = 0.f; fcur.S = sL; fprv = fcur;
+    if (alive) { fcur = load_f(L); fprv = load_f(L >= 1 ? L - 1 : 0); store_terms(L, fcur, fprv, sL); }
     int xnext = (alive && L >= 2) ? sq.code(L - 1) : 0;
-    float sfw_next = (alive && L >= 2) ? *slab_at(a.slab, r0, L - 1, XF, 5, lane) : 1.0f;
     for (int i = Lw - 1; i >= 1; i--) {
       if (alive && i <= L - 1) {
         const int x = xnext;               // residue i+1, 0-based index i
         xnext = sq.code(i - 1);            // the next row down needs residue i (0-based i-1); row 0 reuses it
-        const float sfw = sfw_next;        // Forward's scale factor of this row, requested one row ago
-        if (i > 1) sfw_next = *slab_at(a.slab, r0, i - 1, XF, 5, lane);
+        fcur = fprv;                       // Forward's row i, requested one row ago
+        fprv = load_f(i - 1);
+        const float sfw = fcur.S;
         bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);
         if (xB > 1.0e16f) own = 1;
         // branch-free on purpose: a branch here lets the optimizer sink the whole row update below it,
@@ -516,9 +550,7 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
           scale_row<QT>(R, Q, s);
           totscale = (float)((double)totscale + det_log((double)s));
         }
-        *slab_at(a.slab, r0, i, XF, 6, lane) = xE; *slab_at(a.slab, r0, i, XF, 7, lane) = xN;
-        *slab_at(a.slab, r0, i, XF, 8, lane) = xJ; *slab_at(a.slab, r0, i, XF, 9, lane) = xB;
-        *slab_at(a.slab, r0, i, XF, 10, lane) = xC; *slab_at(a.slab, r0, i, XF, 11, lane) = s;
+        store_terms(i, fcur, fprv, s);
       }
     }
     // row 0
@@ -534,9 +566,10 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
       }
       xB = vhsum(xBv);
       xN = (xB * pmove) + (xN * ploop);
-      *slab_at(a.slab, r0, 0, XF, 6, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 7, lane) = xN;
-      *slab_at(a.slab, r0, 0, XF, 8, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 9, lane) = xB;
-      *slab_at(a.slab, r0, 0, XF, 10, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 11, lane) = 1.0f;
+      const FRow f0 = (L >= 2) ? fprv : load_f(0);     // L == 1: the row loop never ran
+      *slab_at(a.slab, r0, 0, XF, 7, lane) = xN;       // Backward's N at row 0 = total probability (the decoder's 1/x)
+      *slab_at(a.slab, r0, 0, XF, 9, lane) = f0.B * xB * f0.S;
+      *slab_at(a.slab, r0, 0, XF, 11, lane) = f0.S / 1.0f;
       bad = (xN != xN) || (xN == 0.0f) || (xN == __builtin_inff());
       po.bcksc = (float)((double)totscale + det_log((double)xN));
     }
@@ -570,17 +603,15 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
     float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, XF, 7, lane));
     float btot = 0.f, etot = 0.f;
     *slab_at(a.slab, r0, 0, XF, 12, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 13, lane) = 0.f;
-    // one row of special-state values; the next row is requested while the current one is consumed, so the
-    // serial chain of sums never waits on HBM latency
-    struct DRow { float fE, fN, fJ, fB, fC, fS, bE, bN, bJ, bB, bC, bS; };
+    // one row of decoding terms (see k_bwd_decode); the next row is requested while the current one is consumed,
+    // so the serial chain of sums never waits on HBM latency
+    struct DRow { float t2, t3, t4, t1, t5, rs; };
     auto load_row = [&](int j) {
       DRow d;
-      d.fE = *slab_at(a.slab, r0, j, XF, 0, lane); d.fN = *slab_at(a.slab, r0, j, XF, 1, lane);
-      d.fJ = *slab_at(a.slab, r0, j, XF, 2, lane); d.fB = *slab_at(a.slab, r0, j, XF, 3, lane);
-      d.fC = *slab_at(a.slab, r0, j, XF, 4, lane); d.fS = *slab_at(a.slab, r0, j, XF, 5, lane);
-      d.bE = *slab_at(a.slab, r0, j, XF, 6, lane); d.bN = *slab_at(a.slab, r0, j, XF, 7, lane);
-      d.bJ = *slab_at(a.slab, r0, j, XF, 8, lane); d.bB = *slab_at(a.slab, r0, j, XF, 9, lane);
-      d.bC = *slab_at(a.slab, r0, j, XF, 10, lane); d.bS = *slab_at(a.slab, r0, j, XF, 11, lane);
+      d.t2 = *slab_at(a.slab, r0, j, XF, 6, lane); d.t3 = *slab_at(a.slab, r0, j, XF, 7, lane);
+      d.t4 = *slab_at(a.slab, r0, j, XF, 8, lane); d.t1 = *slab_at(a.slab, r0, j, XF, 9, lane);
+      d.t5 = *slab_at(a.slab, r0, j, XF, 10, lane);
+      d.rs = own ? *slab_at(a.slab, r0, j, XF, 11, lane) : 1.0f;
       return d;
     };
     DRow prv = load_row(0);
@@ -590,13 +621,13 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
       const DRow cur = nxt;
       if (j < L) nxt = load_row(j + 1);
       const float btot_prev = btot, etot_prev = etot;
-      btot = btot + (prv.fB * prv.bB * prv.fS * scaleproduct);
-      if (own) scaleproduct *= prv.fS / prv.bS;
-      etot = etot + (cur.fE * cur.bE * cur.fS * scaleproduct);
+      btot = btot + (prv.t1 * scaleproduct);
+      if (own) scaleproduct *= prv.rs;
+      etot = etot + (cur.t2 * scaleproduct);
       float njcp;
-      njcp = prv.fN * cur.bN * ploop * scaleproduct;
-      njcp += prv.fJ * cur.bJ * ploop * scaleproduct;
-      njcp += prv.fC * cur.bC * ploop * scaleproduct;
+      njcp = cur.t3 * scaleproduct;
+      njcp += cur.t4 * scaleproduct;
+      njcp += cur.t5 * scaleproduct;
       const float mocc = (float)(1. - (double)njcp);
       *slab_at(a.slab, r0, j, XF, 12, lane) = btot; *slab_at(a.slab, r0, j, XF, 13, lane) = etot;
       prv = cur;

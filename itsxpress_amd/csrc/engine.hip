@@ -135,6 +135,7 @@ struct itsx_ctx {
   DBuf<int32_t> d_len;
   ReadsDev rd{};
   int Lmax = 0;
+  double slab_gb = 0.0;                  // HBM budget for per-batch DP slabs
 
   // ---- derep
   bool have_derep = false;
@@ -189,6 +190,22 @@ template <class T> static hipError_t upload(DBuf<T> &d, const std::vector<T> &h,
   if (h.empty()) return hipSuccess;
   return hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
 }
+
+// kernel timers that do not stall the stream: event pairs are recorded around launches and read back once,
+// after the whole stage has been enqueued
+struct LazyTimers {
+  struct Rec { hipEvent_t a, b; float *acc; };
+  std::vector<Rec> recs; hipStream_t st;
+  explicit LazyTimers(hipStream_t s) : st(s) {}
+  size_t begin(float *acc) { Rec r; (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.acc = acc; (void)hipEventRecord(r.a, st); recs.push_back(r); return recs.size() - 1; }
+  void end(size_t i) { (void)hipEventRecord(recs[i].b, st); }
+  void collect()
+  {
+    for (auto &r : recs) { (void)hipEventSynchronize(r.b); float ms = 0; (void)hipEventElapsedTime(&ms, r.a, r.b); *r.acc += ms; (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    recs.clear();
+  }
+  ~LazyTimers() { collect(); }
+};
 
 struct StageTimer {
   hipEvent_t a = nullptr, b = nullptr; hipStream_t st;
@@ -719,8 +736,13 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   S.ms_msv += tm_list.stop();
 
   // ---- batches of waves sized to the slab budget
-  double slab_gb = 16.0;
-  if (const char *e = getenv("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));
+  if (ctx->slab_gb <= 0.0) {            // decided once per context: a quarter of the free HBM, at most 64 GB
+    ctx->slab_gb = 16.0;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) ctx->slab_gb = std::min(64.0, std::max(1.0, (double)fr / (double)(1ull << 30) / 4.0));
+    if (const char *e = getenv("ITSX_SLAB_GB")) ctx->slab_gb = std::max(0.25, atof(e));
+  }
+  const double slab_gb = ctx->slab_gb;
   const int64_t row_bytes = 14 * 64 * 4;
   const int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
   DBuf<RegionRec> &d_raw = ctx->w_raw;
@@ -733,6 +755,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.F1 = F1; a.F3 = F3;
       StageTimer k(st); launch_bias(a, NP, st); S.ms_bias_kernel = k.stop();
     }
+    LazyTimers lazy(st);
     DBuf<float> &d_slab = ctx->w_slab;
     int64_t slab_rows_alloc = (int64_t)(d_slab.cap / (14 * 64));
     int w0 = 0;
@@ -745,12 +768,13 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
       a.flogsum = ctx->d_flogsum.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
       a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
-      { StageTimer k(st); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); S.ms_fwd_kernel += k.stop(); }
-      { StageTimer k(st); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); S.ms_bwd_kernel += k.stop(); }
-      { StageTimer k(st); launch_decode(a, w1 - w0, w0, st); S.ms_decode_kernel += k.stop(); }
+      { const size_t t = lazy.begin(&S.ms_fwd_kernel); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
+      { const size_t t = lazy.begin(&S.ms_bwd_kernel); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
+      { const size_t t = lazy.begin(&S.ms_decode_kernel); launch_decode(a, w1 - w0, w0, st); lazy.end(t); }
       for (int w = w0; w < w1; w++) S.fwd_rows += (int64_t)(rows[w] - 1) * waves[w].count;
       w0 = w1;
     }
+    lazy.collect();
     S.ms_filters = tm.stop();
   }
   StageTimer tm_dom(st);
@@ -834,6 +858,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     HIPCHK(hipStreamSynchronize(st));
     const int64_t erow_bytes = 104 * 64 * 4;
     const int64_t ebudget = (int64_t)(slab_gb * (1 << 30)) / erow_bytes;
+    LazyTimers elazy(st);
     DBuf<float> &d_eslab = ctx->w_eslab; int64_t ealloc = (int64_t)(d_eslab.cap / (104 * 64));
     int w0 = 0;
     while (w0 < NRW) {
@@ -844,7 +869,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       EnvArgs a{};
       a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
       a.pairs = ctx->d_pairs.p; a.regions = ctx->d_ulist.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
-      { StageTimer k(st); launch_envelopes(a, w1 - w0, w0, rgen[w0], st); S.ms_env_kernel += k.stop(); }
+      { const size_t t = elazy.begin(&S.ms_env_kernel); launch_envelopes(a, w1 - w0, w0, rgen[w0], st); elazy.end(t); }
       for (int w = w0; w < w1; w++) S.env_rows += (int64_t)(rrows[w] - 1) * rw[w].count;
       w0 = w1;
     }

@@ -25,6 +25,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# HBM bytes per lane-row measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), see
+# profiles/round1_pmc_hbm_traffic_200k.md.  WRITE_SIZE is exact for these stores; FETCH_SIZE is NOT doubled
+# (uncalibrated for 4-byte-per-lane loads on gfx950), so the read side is a lower bound.
+PMC_BYTES_PER_ROW = {"k_filters_fwd": 0.6 + 24.2, "k_bwd_decode": 13.4 + 24.2, "k_decode": 18.4 + 8.3}
 VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # lane-ops/ns: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
 
 
@@ -119,19 +123,25 @@ def main():
         value = total_reads / dt
         K = args.steps
         kern = {"k_msv": acc["ms_msv_kernel"] / K, "k_filters_fwd": acc["ms_fwd_kernel"] / K,
-                "k_bwd_decode": acc["ms_bwd_kernel"] / K, "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K}
+                "k_bwd_decode": acc["ms_bwd_kernel"] / K, "k_decode": acc["ms_decode_kernel"] / K,
+                "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K}
         dom = max(kern, key=kern.get)
         # algorithmic HBM bytes of the dominant kernel, per step
         U, L = st["n_unique"], 300
         if dom == "k_msv":
             alg_bytes = U * ((nprof + 63) // 64) * ((L + 15) // 16 * 4) + 2 * ((nprof + 63) // 64 * 64) * U
-        elif dom == "k_filters_fwd":
+        elif dom == "k_filters_fwd":      # per pair: packed read + PairRec/PairOut; per row: 6 special-state floats written
             alg_bytes = st["n_past_msv"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 24
-        elif dom == "k_bwd_decode":
+        elif dom == "k_bwd_decode":       # per row: Forward's 6 floats read, 6 decoding terms written
             alg_bytes = st["n_past_fwd"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 48
+        elif dom == "k_decode":           # per row: 5 terms read, btot/etot written
+            alg_bytes = st["n_past_fwd"] * (16 + 40) + st["fwd_rows"] * 28
         else:   # envelope sweeps: Backward rows written once, read once (26 float4 per row), + 88 B result per envelope
             alg_bytes = st["env_rows"] * 2 * 26 * 16 + st["n_domains"] * (16 + 88)
         achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
+        # launches of the dominant kernel in one step, for per-launch figures
+        nl = {"k_msv": 1}.get(dom, max(1, int(st.get("n_batches", 1))))
+        traffic = PMC_BYTES_PER_ROW[dom] * st["fwd_rows"] / nl if dom in PMC_BYTES_PER_ROW else None
         trimmed = int(((out[0][:, 0] >= 0) & (out[0][:, 1] >= 0) & (out[0][:, 0] < out[0][:, 1])).sum())
         res = {
             "metric": "reads/sec trimmed (ITS2, stand-in taxon Tracheophyta for Fungi)", "value": value, "unit": "reads/s",
@@ -143,8 +153,11 @@ def main():
                        "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed, "parallelism": "reads sharded x%d" % world},
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "the dominant kernels are VALU-bound scans (SURVEY 8d): see 'valu'"},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl, "alg_bytes_per_launch": alg_bytes / nl,
+                         "traffic": traffic,
+                         "note": "achieved = algorithmic bytes / HIP-event time of the kernel; the dominant kernels are VALU-bound scans "
+                                 "(SURVEY 8d), see 'valu'; traffic = PMC bytes per lane-row (profiles/round1_pmc_hbm_traffic_200k.md) x rows per launch"},
             "valu": {"msv_gcups": st["msv_cells"] / (kern["k_msv"] * 1e-3) / 1e9 if kern["k_msv"] > 0 else None,
                      "fwd_rows_per_s": st["fwd_rows"] / (kern["k_filters_fwd"] * 1e-3) if kern["k_filters_fwd"] > 0 else None,
                      "bwd_rows_per_s": st["fwd_rows"] / (kern["k_bwd_decode"] * 1e-3) if kern["k_bwd_decode"] > 0 else None,

@@ -80,7 +80,7 @@ typedef struct {
   float   ms_fwd_kernel, ms_bwd_kernel;  int64_t fwd_rows;   /* lane-rows: sum of target lengths over surviving pairs */
   float   ms_env_kernel;  float ms_bias_kernel;  int64_t env_rows;    /* the three envelope sweeps together; lane-rows per sweep */
   int64_t n_env_unique;           /* distinct (profile, length, envelope subsequence) actually re-scored */
-  float   ms_decode_kernel;  int32_t pad1;
+  float   ms_decode_kernel;  int32_t n_batches;          /* launches of each DP kernel in the last search */
 } itsx_stats;
 
 int         itsx_abi_version(void);

@@ -42,7 +42,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("ms_filters", "<f4"), ("ms_domains", "<f4"), ("ms_finalize", "<f4"), ("ms_msv_kernel", "<f4"),
                 ("msv_cells", "<i8"), ("msv_launches", "<i8"), ("ms_fwd_kernel", "<f4"), ("ms_bwd_kernel", "<f4"),
                 ("fwd_rows", "<i8"), ("ms_env_kernel", "<f4"), ("ms_bias_kernel", "<f4"), ("env_rows", "<i8"),
-                ("n_env_unique", "<i8"), ("ms_decode_kernel", "<f4"), ("pad1", "<i4")]
+                ("n_env_unique", "<i8"), ("ms_decode_kernel", "<f4"), ("n_batches", "<i4")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares

@@ -629,7 +629,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = ctx->nregions_padded = 0;
   ctx->have_search = true; ctx->have_final = false;
   if (U == 0) return ITSX_OK;
@@ -772,6 +772,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       { const size_t t = lazy.begin(&S.ms_bwd_kernel); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
       { const size_t t = lazy.begin(&S.ms_decode_kernel); launch_decode(a, w1 - w0, w0, st); lazy.end(t); }
       for (int w = w0; w < w1; w++) S.fwd_rows += (int64_t)(rows[w] - 1) * waves[w].count;
+      S.n_batches++;
       w0 = w1;
     }
     lazy.collect();

@@ -49,8 +49,10 @@ def gather_coords(start, stop, tlen, in_ddict, device=None, dst=0):
     t = torch.from_numpy(pad)
     if device is not None:
         t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(ws)] if rank == dst else None
-    dist.gather(t, out, dst=dst)
+    # all_gather (the collective every backend implements) rather than gather: the blocks are tiny next to the
+    # DP work (16 B per read), and rank dst simply keeps what it needs
+    out = [torch.empty_like(t) for _ in range(ws)]
+    dist.all_gather(out, t)
     if rank != dst:
         return None
     return [o.cpu().numpy()[:int(s.item())] for o, s in zip(out, sizes)]

@@ -69,8 +69,10 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("ITSX_FORCE_DIST") == "1"     # the latter: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from itsxpress_amd import Engine
@@ -88,15 +90,15 @@ def main():
     def step():
         eng.derep(strand_both=True, minseqlength=32)
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
-        if world > 1:
+        if use_dist:
             eng.set_domz(allreduce_domz(eng.get_domz(), dev))
         eng.finalize(domE=10.0)
         c = eng.trim_coords("3_", "4_")
-        return gather_coords(*c, device=dev) if world > 1 else [np.stack(c, axis=1)]
+        return gather_coords(*c, device=dev) if use_dist else [np.stack(c, axis=1)]
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -109,10 +111,10 @@ def main():
             if k.startswith("ms_"):
                 acc[k] = acc.get(k, 0.0) + v
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -172,7 +174,7 @@ def main():
             res["cpu_baseline"] = {"value": v, "unit": "reads/s", "cores": threads, "kind": "port",
                                    "sample": "first %d reads of the same workload (%d unique), derep+search+argmax, %.1f s" % (min(args.cpu_sample, args.reads), nc, cdt)}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

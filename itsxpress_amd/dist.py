@@ -23,7 +23,7 @@ def allreduce_domz(domz, device=None):
     import torch
     import torch.distributed as dist
     z = np.ascontiguousarray(domz, np.int64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return z
     t = torch.from_numpy(z.copy())
     if device is not None:
@@ -37,7 +37,7 @@ def gather_coords(start, stop, tlen, in_ddict, device=None, dst=0):
     import torch
     import torch.distributed as dist
     block = np.stack([start, stop, tlen, in_ddict], axis=1).astype(np.int32)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [block]
     ws, rank = dist.get_world_size(), dist.get_rank()
     n = torch.tensor([block.shape[0]], dtype=torch.int64, device=device)

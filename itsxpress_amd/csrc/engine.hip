@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <numeric>
 #include <thread>
 #include "detmath.h"
@@ -148,7 +149,7 @@ struct itsx_ctx {
   // ---- search
   bool have_search = false, have_final = false;
   double T = 10.0;
-  int64_t npairs_padded = 0, nregions_padded = 0;
+  int64_t npairs_padded = 0;
   DBuf<PairRec> d_pairs;
   DBuf<PairOut> d_pout;
   DBuf<RegionRec> d_regions;
@@ -156,7 +157,9 @@ struct itsx_ctx {
   DBuf<int64_t> d_pair_region0;
   DBuf<int32_t> d_upos;                  // region -> index of its (shared) result
   DBuf<RegionRec> d_ulist;               // distinct envelopes, grouped by profile
-  DBuf<itsx_domain> d_dom;
+  std::vector<std::unique_ptr<DBuf<itsx_domain>>> dom_bufs;   // one segment per chunk of uniques
+  std::vector<int64_t> dom_n;            // padded rows in each segment
+  int64_t pair_budget = 0; int32_t trace_u0 = 0; int n_chunks = 0; bool keep_trace = false, trace_sorted = false;
   DBuf<int32_t> d_domz32;
   DBuf<LenTables> d_lt;
   std::vector<int64_t> domz;
@@ -615,6 +618,9 @@ static float msv_score_from_byte(int xj, int tjb)
   return sc;
 }
 
+static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, double T, double F1, double F3);
+static int append_traces(itsx_ctx *ctx);
+
 int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
 {
   CTXCHK(ctx);
@@ -625,12 +631,12 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   hipStream_t st = ctx->st;
   const int P = ctx->P, G = ctx->G, Ppad = G * 64, U = ctx->U;
   ctx->T = T;
-  ctx->h_dom.clear(); ctx->h_trace.clear();
+  ctx->h_dom.clear(); ctx->h_trace.clear(); ctx->trace_sorted = false;
   ctx->domz.assign((size_t)P, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
   S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
-  ctx->npairs_padded = ctx->nregions_padded = 0;
+  ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false;
   if (U == 0) return ITSX_OK;
 
@@ -672,12 +678,58 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
   HIPCHK(upload(ctx->d_lt, lt, st)); HIPCHK(upload(d_thr, thr, st)); HIPCHK(upload(d_tjb, tjb, st));
 
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(ctx->d_domz32.alloc((size_t)P));
+  HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * 4, st));
+  {
+    int64_t cells = 0;
+    for (int32_t u = 0; u < U; u++) cells += (int64_t)ctx->h_len[ctx->h_seed_read[u]];
+    int64_t msum = 0; for (auto &h : ctx->profs) msum += h.M;
+    S.msv_cells = cells * msum;
+  }
+  // ---- the unique reads are searched in chunks so that every work list of a chunk fits a fixed share of HBM
+  // (about 400 B per potential (unique, profile) pair); one chunk covers the 1 M-read bench
+  if (ctx->pair_budget <= 0) {
+    size_t fr = 0, tot = 0;
+    double gb = 32.0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::max(1.0, (double)fr / (double)(1ull << 30) / 4.0);
+    ctx->pair_budget = (int64_t)(gb * (double)(1ull << 30) / 400.0);
+  }
+  int64_t Uc = std::max<int64_t>(1, ctx->pair_budget / std::max(P, 1));
+  Uc = std::min<int64_t>(Uc, ((1ll << 31) - 4096) / std::max(Ppad, 1));
+  if (const char *e = getenv("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
+  ctx->keep_trace = getenv("ITSX_KEEP_TRACE") != nullptr;
+  int ci = 0;
+  for (int64_t u0 = 0; u0 < U; u0 += Uc, ci++) {
+    const int rc = search_chunk(ctx, ci, (int32_t)u0, (int32_t)std::min<int64_t>(Uc, U - u0), Lcap, T, F1, F3);
+    if (rc != ITSX_OK) return rc;
+  }
+  ctx->n_chunks = ci;
+  std::vector<int32_t> dz32((size_t)P, 0);
+  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int p = 0; p < P; p++) ctx->domz[p] = dz32[p];
+  return ITSX_OK;
+}
+
+// one chunk [u0, u0+U) of the length-sorted unique list through every stage up to per-sequence reporting
+static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, double T, double F1, double F3)
+{
+  hipStream_t st = ctx->st;
+  const int P = ctx->P, G = ctx->G, Ppad = G * 64;
+  itsx_stats &S = ctx->stats;
+  const int32_t *d_sorted = ctx->d_sorted_uniq.p + u0;     // PairRec::useq is relative to the chunk
+  DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
+  while ((int)ctx->dom_bufs.size() <= ci) ctx->dom_bufs.emplace_back(new DBuf<itsx_domain>());
+  DBuf<itsx_domain> &d_dom = *ctx->dom_bufs[ci];
+  ctx->dom_n.push_back(0);
+  ctx->trace_u0 = u0;
   // ---- MSV for every (unique, profile)
   DBuf<uint16_t> &d_res = ctx->w_res;
   HIPCHK(d_res.alloc((size_t)Ppad * U));
   {
     MsvArgs a{};
-    a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.U = U; a.G = G;
+    a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.U = U; a.G = G;
     a.etab = ctx->d_etab.p; a.pbias = ctx->d_pbias.p; a.ptec = ctx->d_ptec.p; a.ptbm = ctx->d_ptbm.p;
     a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = d_res.p;
     // enough waves to fill 256 CUs x 8 waves several times over, but >= 8 sequences per wave to amortise the table load
@@ -685,12 +737,9 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     a.seqs_per_wave = spw; a.nchunks = (U + spw - 1) / spw;
     StageTimer tm(st);
     launch_msv(a, st);
-    S.ms_msv_kernel = tm.stop();
-    S.msv_launches = 1;
-    int64_t cells = 0;
-    for (int32_t u = 0; u < U; u++) cells += (int64_t)ctx->h_len[ctx->h_seed_read[u]];
-    int64_t msum = 0; for (auto &h : ctx->profs) msum += h.M;
-    S.msv_cells = cells * msum;
+    const float ms = tm.stop();
+    S.ms_msv_kernel += ms; S.ms_msv += ms;
+    S.msv_launches += 1;
   }
   StageTimer tm_list(st);
   // ---- survivor list grouped by profile (64-aligned segments, ascending length)
@@ -706,7 +755,6 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; S.n_past_msv += total[p]; }
   const int64_t NP = seg_start[P];
   ctx->npairs_padded = NP;
-  S.ms_msv = S.ms_msv_kernel;
   if (NP == 0) { S.ms_msv += tm_list.stop(); return ITSX_OK; }
   if (NP >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 surviving (representative, profile) pairs");
   DBuf<int64_t> &d_seg_start = ctx->w_seg_start;
@@ -714,7 +762,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(ctx->d_pairs.alloc((size_t)NP)); HIPCHK(ctx->d_pout.alloc((size_t)NP));
   HIPCHK(hipMemsetAsync(ctx->d_pairs.p, 0xFF, (size_t)NP * sizeof(PairRec), st));
   HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)NP * sizeof(PairOut), st));
-  launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p, ctx->d_pairs.p, st);
+  launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p + u0, ctx->d_pairs.p, st);
   // ---- wave descriptors
   std::vector<WaveDesc> waves;
   std::vector<char> wgeneric;
@@ -751,9 +799,9 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     StageTimer tm(st);
     {   // bias-composition filter for every survivor (its own, full-occupancy kernel)
       FloatArgs a{};
-      a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+      a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
       a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.F1 = F1; a.F3 = F3;
-      StageTimer k(st); launch_bias(a, NP, st); S.ms_bias_kernel = k.stop();
+      StageTimer k(st); launch_bias(a, NP, st); S.ms_bias_kernel += k.stop();
     }
     LazyTimers lazy(st);
     DBuf<float> &d_slab = ctx->w_slab;
@@ -765,7 +813,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       if (r > slab_rows_alloc) { HIPCHK(d_slab.alloc((size_t)r * 14 * 64)); slab_rows_alloc = r; }
       HIPCHK(hipMemcpyAsync(d_waves.p + w0, waves.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       FloatArgs a{};
-      a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+      a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
       a.flogsum = ctx->d_flogsum.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
       a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
       { const size_t t = lazy.begin(&S.ms_fwd_kernel); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
@@ -776,7 +824,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       w0 = w1;
     }
     lazy.collect();
-    S.ms_filters = tm.stop();
+    S.ms_filters += tm.stop();
   }
   StageTimer tm_dom(st);
   // ---- compact regions into a profile-grouped list
@@ -797,13 +845,11 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   std::vector<int32_t> rtotal((size_t)P);
   for (int p = 0; p < P; p++) { rtotal[p] = bound[p + 1] - bound[p]; rseg[p + 1] = rseg[p] + ((int64_t)rtotal[p] + 63) / 64 * 64; S.n_domains += rtotal[p]; }
   const int64_t NR = rseg[P];
-  ctx->nregions_padded = NR;
+  ctx->dom_n[ci] = NR;
   HIPCHK(ctx->d_pair_region0.alloc((size_t)NP));
   HIPCHK(ctx->d_regions.alloc((size_t)std::max<int64_t>(NR, 1)));
-  HIPCHK(ctx->d_dom.alloc((size_t)std::max<int64_t>(NR, 1)));
-  HIPCHK(hipMemsetAsync(ctx->d_dom.p, 0xFF, (size_t)std::max<int64_t>(NR, 1) * sizeof(itsx_domain), st));
-  HIPCHK(ctx->d_domz32.alloc((size_t)P));
-  HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * 4, st));
+  HIPCHK(d_dom.alloc((size_t)std::max<int64_t>(NR, 1)));
+  HIPCHK(hipMemsetAsync(d_dom.p, 0xFF, (size_t)std::max<int64_t>(NR, 1) * sizeof(itsx_domain), st));
   if (NR > 0) {
     DBuf<int64_t> &d_rseg = ctx->w_rseg;
     HIPCHK(upload(d_rseg, rseg, st));
@@ -820,8 +866,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     HIPCHK(hipMemsetAsync(rkeys.p, 0, tsize * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(rvals.p, 0x7f, tsize * sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(ruq.p, 0, ((size_t)NR + 1) * sizeof(int32_t), st));
-    launch_region_keys(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
-    launch_region_resolve(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
+    launch_region_keys(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
+    launch_region_resolve(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
     launch_exclusive_scan(ruq.p, rurank.p, NR + 1, rscan.p, st);
     std::vector<int32_t> ub((size_t)P + 1);
     {
@@ -868,23 +914,19 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       if (r > ealloc) { HIPCHK(d_eslab.alloc((size_t)r * 104 * 64)); ealloc = r; }
       HIPCHK(hipMemcpyAsync(d_rw.p + w0, rw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       EnvArgs a{};
-      a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+      a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
       a.pairs = ctx->d_pairs.p; a.regions = ctx->d_ulist.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
       { const size_t t = elazy.begin(&S.ms_env_kernel); launch_envelopes(a, w1 - w0, w0, rgen[w0], st); elazy.end(t); }
       for (int w = w0; w < w1; w++) S.env_rows += (int64_t)(rrows[w] - 1) * rw[w].count;
       w0 = w1;
     }
     ScoreArgs sa{};
-    sa.rd = ctx->rd; sa.sorted_uniq = ctx->d_sorted_uniq.p; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
+    sa.rd = ctx->rd; sa.sorted_uniq = d_sorted; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
     sa.flogsum = ctx->d_flogsum.p; sa.pairs = ctx->d_pairs.p; sa.pout = ctx->d_pout.p; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
-    sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = ctx->d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p;
+    sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p;
     launch_score(sa, st);
   }
-  std::vector<int32_t> dz32((size_t)P, 0);
-  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  for (int p = 0; p < P; p++) ctx->domz[p] = dz32[p];
-  S.ms_domains = tm_dom.stop();
+  S.ms_domains += tm_dom.stop();
   // filter counters
   {
     DBuf<int64_t> &d_c = ctx->w_counters;
@@ -894,8 +936,9 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     int64_t hc[8];
     HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    S.n_past_bias = hc[0]; S.n_past_fwd = hc[1]; S.n_regions = hc[2]; S.n_domain_overflow = hc[3];
+    S.n_past_bias += hc[0]; S.n_past_fwd += hc[1]; S.n_regions += hc[2]; S.n_domain_overflow += hc[3];
   }
+  if (ctx->keep_trace) { const int rc = append_traces(ctx); if (rc != ITSX_OK) return rc; }
   return ITSX_OK;
 }
 
@@ -918,11 +961,11 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
   HIPCHK(hipSetDevice(ctx->device));
   StageTimer tm(ctx->st);
   ctx->h_dom.clear();
-  const int64_t NR = ctx->nregions_padded;
-  if (NR > 0) {
+  {
     DBuf<int64_t> &d_dz = ctx->w_dz;
     HIPCHK(upload(d_dz, ctx->domz, ctx->st));
-    launch_finalize(ctx->d_dom.p, NR, d_dz.p, domE, ctx->st);
+    for (size_t c = 0; c < ctx->dom_n.size(); c++)
+      if (ctx->dom_n[c] > 0) launch_finalize(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, domE, ctx->st);
     HIPCHK(hipStreamSynchronize(ctx->st));
   }
   ctx->stats.ms_finalize = tm.stop();
@@ -933,10 +976,13 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
 static int fetch_domains(const itsx_ctx *cctx)
 {
   itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
-  if (!ctx->h_dom.empty() || ctx->nregions_padded == 0) return ITSX_OK;
-  std::vector<itsx_domain> all((size_t)ctx->nregions_padded);
-  HIPCHK(hipMemcpy(all.data(), ctx->d_dom.p, all.size() * sizeof(itsx_domain), hipMemcpyDeviceToHost));
-  for (auto &d : all) if (d.dom_idx >= 0 && d.prof >= 0) ctx->h_dom.push_back(d);
+  if (!ctx->h_dom.empty()) return ITSX_OK;
+  for (size_t c = 0; c < ctx->dom_n.size(); c++) {
+    if (ctx->dom_n[c] <= 0) continue;
+    std::vector<itsx_domain> all((size_t)ctx->dom_n[c]);
+    HIPCHK(hipMemcpy(all.data(), ctx->dom_bufs[c]->p, all.size() * sizeof(itsx_domain), hipMemcpyDeviceToHost));
+    for (auto &d : all) if (d.dom_idx >= 0 && d.prof >= 0) ctx->h_dom.push_back(d);
+  }
   std::sort(ctx->h_dom.begin(), ctx->h_dom.end(), [](const itsx_domain &a, const itsx_domain &b) {
     if (a.prof != b.prof) return a.prof < b.prof;
     if (a.rep != b.rep) return a.rep < b.rep;
@@ -960,26 +1006,40 @@ int itsx_get_domains(const itsx_ctx *ctx, itsx_domain *rows)
   return ITSX_OK;
 }
 
-static int fetch_traces(const itsx_ctx *cctx)
+// copy the current chunk's pair records into the host trace list
+static int append_traces(itsx_ctx *ctx)
 {
-  itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
-  if (!ctx->h_trace.empty() || ctx->npairs_padded == 0) return ITSX_OK;
   const int64_t NP = ctx->npairs_padded;
+  if (NP == 0) return ITSX_OK;
   std::vector<PairRec> pr((size_t)NP); std::vector<PairOut> po((size_t)NP);
   HIPCHK(hipMemcpy(pr.data(), ctx->d_pairs.p, (size_t)NP * sizeof(PairRec), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(po.data(), ctx->d_pout.p, (size_t)NP * sizeof(PairOut), hipMemcpyDeviceToHost));
   for (int64_t i = 0; i < NP; i++) {
     if (pr[i].prof < 0) continue;
     itsx_pairtrace t{};
-    t.rep = ctx->h_sorted_uniq[pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
+    t.rep = ctx->h_sorted_uniq[(size_t)ctx->trace_u0 + pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
     t.pass_bias = po[i].pass_bias; t.pass_fwd = po[i].pass_fwd; t.msv_sc = po[i].msv_sc; t.filtersc = po[i].filtersc;
     t.fwdsc = po[i].fwdsc; t.bcksc = po[i].bcksc; t.nullsc = po[i].nullsc; t.nregions = po[i].nregions; t.ndom = po[i].ndom;
     ctx->h_trace.push_back(t);
   }
-  std::sort(ctx->h_trace.begin(), ctx->h_trace.end(), [](const itsx_pairtrace &a, const itsx_pairtrace &b) {
-    if (a.prof != b.prof) return a.prof < b.prof;
-    return a.rep < b.rep;
-  });
+  return ITSX_OK;
+}
+// traces are fetched lazily when the search ran as one chunk; multi-chunk runs keep them only with ITSX_KEEP_TRACE=1
+static int fetch_traces(const itsx_ctx *cctx)
+{
+  itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
+  if (ctx->h_trace.empty() && !ctx->keep_trace) {
+    if (ctx->n_chunks > 1) SET_ERR(ctx, ITSX_E_ARG, "pair traces of a multi-chunk search are kept only when ITSX_KEEP_TRACE=1");
+    const int rc = append_traces(ctx);
+    if (rc != ITSX_OK) return rc;
+  }
+  if (!ctx->trace_sorted) {
+    std::sort(ctx->h_trace.begin(), ctx->h_trace.end(), [](const itsx_pairtrace &a, const itsx_pairtrace &b) {
+      if (a.prof != b.prof) return a.prof < b.prof;
+      return a.rep < b.rep;
+    });
+    ctx->trace_sorted = true;
+  }
   return ITSX_OK;
 }
 int64_t itsx_num_pairtraces(const itsx_ctx *ctx)
@@ -1018,7 +1078,8 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
   HIPCHK(us.alloc((size_t)U + 1)); HIPCHK(ue.alloc((size_t)U + 1)); HIPCHK(ut.alloc((size_t)U + 1));
   HIPCHK(hipMemsetAsync(bl.p, 0, ((size_t)U + 1) * 8, st)); HIPCHK(hipMemsetAsync(br.p, 0, ((size_t)U + 1) * 8, st));
   HIPCHK(hipMemsetAsync(uind.p, 0, ((size_t)U + 1) * 4, st));
-  launch_positions(ctx->d_dom.p, ctx->nregions_padded, d_side.p, bl.p, br.p, uind.p, st);
+  for (size_t c = 0; c < ctx->dom_n.size(); c++)
+    if (ctx->dom_n[c] > 0) launch_positions(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_side.p, bl.p, br.p, uind.p, st);
   if (U > 0) hipLaunchKernelGGL(k_rep_coords, dim3((U + 255) / 256), dim3(256), 0, st, U, bl.p, br.p, uind.p, ctx->d_seed_read.p, ctx->rd.len, us.p, ue.p, ut.p);
   if (!per_read) {
     if (U > 0) {

@@ -294,3 +294,19 @@ def test_errors_are_loud(engine, tmp_path):
     engine.derep()
     with pytest.raises(EngineError):
         engine.search(F1=1e-6, F2=1e-3)
+
+
+def test_chunked_search_is_identical_to_one_chunk(engine, t_hmm_text, monkeypatch):
+    """Large inputs are searched in chunks of unique reads; a forced tiny chunk size must not change anything
+    (domZ, thresholds and the argmax span chunks)."""
+    blob, offs = synth.make_reads(t_hmm_text, 500, seed=23, fixed_len=0, len_range=(200, 420))
+    seqs = synth.to_strings(blob, offs)
+    hmm = _its2_subset(t_hmm_text, 25, 25)
+    monkeypatch.setenv("ITSX_CHUNK_UNIQUES", "37")
+    monkeypatch.setenv("ITSX_KEEP_TRACE", "1")
+    res = _run_both(engine, hmm, seqs)
+    _compare(engine, res)
+    start, stop, tlen, ind = engine.trim_coords("3_", "4_")
+    _, _, uniq_of = engine.get_derep()
+    us, ue, ut, ui = res.positions("3_", "4_")
+    assert np.array_equal(start, us[uniq_of]) and np.array_equal(stop, ue[uniq_of])

@@ -156,6 +156,21 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path);
 
 int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out);
 
+/* ---- f1 ("next"): native FASTQ parse -> slice -> write.  Host-only and context-free.
+ * itsx_write_trimmed_fastq replaces Dedup.create_trimmed_seqs (itsxpress/SeqSample.py:886-949): record i of
+ * seq_path (plain or .gz) is written as record[start[i]:stop[i]] iff both are >= 0 and start < stop.
+ * itsx_write_trimmed_paired replaces Dedup.create_paired_trimmed_seqs (SeqSample.py:713-790): R1/R2 pair k is
+ * looked up by the id of its R1 title among `names` (the merged reads the coordinates belong to) and sliced
+ * with the reference's r2start = tlen - stop / r2end = tlen - start arithmetic.  trim_ccs stitches the CCS
+ * primers with quality 93.  Errors: negative code, text from itsx_trim_last_error(). */
+int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int gzipped, int trim_ccs,
+                             const int32_t *start, const int32_t *stop, int64_t n_records,
+                             int64_t *n_written, int64_t *total_len);
+int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const char *out1_path, const char *out2_path,
+                              int gzipped, int trim_ccs, const char *names, const int64_t *name_offsets, int64_t n_names,
+                              const int32_t *start, const int32_t *stop, const int32_t *tlen, int64_t *n_written);
+const char *itsx_trim_last_error(void);
+
 /* ---- test hooks (parity tests only) */
 /* XXH64 of each read's packed forward / reverse-complement key, as computed on the device */
 int itsx_debug_read_hashes(itsx_ctx *ctx, uint64_t *fwd, uint64_t *rc);

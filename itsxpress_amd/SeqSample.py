@@ -255,6 +255,35 @@ class Dedup:
             logging.exception("Could not parse the '.uc' file.")
             raise e
 
+    # -- f1: the consumers of the coordinates, native writers (SeqSample.py:713-790, 886-949) ------------
+    def create_trimmed_seqs(self, outfile: str, gzipped: bool, zstd_file: bool, itspos: "ItsPosition",
+                            wri_file: bool, tempdir: str = "", trim_ccs: bool = False) -> None:
+        """Single-end: write seq_file's records trimmed to record[start:stop] (same filter as the reference)."""
+        from .engine import read_fastx
+        from .trim import coords_from_dicts, write_trimmed_fastq
+        if zstd_file:
+            raise ValueError("zstd output is not supported by the native writer; write .gz or plain")
+        if not wri_file:
+            return
+        names, _ = read_fastx(self.seq_file)
+        start, stop, _ = coords_from_dicts(names, self.matchdict, itspos)
+        write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs)
+
+    def create_paired_trimmed_seqs(self, outfile1: str, outfile2: str, gzipped: bool, zstd_file: bool,
+                                   itspos: "ItsPosition", wri_file: bool, trim_ccs: bool = False) -> None:
+        """Paired: slice the ORIGINAL R1/R2 records with the merged read's coordinates."""
+        from .trim import coords_from_dicts, write_trimmed_paired
+        if self.fastq is None or self.fastq2 is None:
+            raise ValueError("Both fastq and fastq2 paths must be defined to create paired trimmed sequences.")
+        if zstd_file:
+            raise ValueError("zstd output is not supported by the native writer; write .gz or plain")
+        if not wri_file:
+            return
+        names = list(self.matchdict.keys())
+        start, stop, tlen = coords_from_dicts(names, self.matchdict, itspos)
+        write_trimmed_paired(self.fastq, self.fastq2, outfile1, outfile2, names, start, stop, tlen,
+                             gzipped=gzipped, trim_ccs=trim_ccs)
+
     @classmethod
     def from_engine(cls, engine: Engine, names) -> "Dedup":
         """matchdict from the engine's arrays (names[i] = label of read i)."""

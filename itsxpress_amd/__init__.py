@@ -9,5 +9,6 @@ from .engine import Engine, read_fastx  # noqa: F401
 from .SeqSample import (Dedup, ItsPosition, SeqSample, SeqSampleNotPaired,  # noqa: F401
                         SeqSamplePairedNotInterleaved, install)
 from .main import create_runtime_hmm  # noqa: F401
+from .trim import write_trimmed_fastq, write_trimmed_paired  # noqa: F401
 
 __version__ = "0.1.0"

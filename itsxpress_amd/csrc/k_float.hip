@@ -421,7 +421,6 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
   const PairRec pr = a.pairs[pi];
   const int L = pr.L;
   const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
-  const LenTables lt = a.lt[L];
   PairOut po = a.pout[pi];            // filtersc / pass_bias come from k_bias
   const int Lw = wd.rows - 1;       // longest sequence in this wave
 
@@ -594,8 +593,6 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
   const bool bad = (po.flags & 8) != 0;
   const int L = pr.L;
   const int64_t r0 = wd.slab;
-  const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
-  const float ploop = 1.0f - pmove;
   // ---- posterior decoding + region scan, rows ascending (the order the sums are defined in)
   int nreg = 0, nkept = 0, flags = 0;
   if (alive && !bad) {

@@ -1,0 +1,77 @@
+"""Trimmed-FASTQ writers: the consumers of the coordinates.
+
+Thin wrappers over the native, context-free writers in libitsx_hip.so (trim_host.cpp); they
+replace the Biopython loops of Dedup.create_trimmed_seqs / create_paired_trimmed_seqs
+(itsxpress/SeqSample.py:713-790, 886-949).  No GPU is needed for these calls.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import EngineError
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def write_trimmed_fastq(seq_file, outfile, start, stop, gzipped=False, trim_ccs=False):
+    """record i of seq_file -> record[start[i]:stop[i]] when both >= 0 and start < stop.
+    Returns (records written, summed trimmed length)."""
+    if not os.path.exists(seq_file):
+        raise FileNotFoundError(seq_file)
+    L = _lib.lib()
+    start, stop = _i32(start), _i32(stop)
+    n, tot = C.c_int64(0), C.c_int64(0)
+    rc = L.itsx_write_trimmed_fastq(os.fsencode(seq_file), os.fsencode(outfile), int(gzipped), int(trim_ccs),
+                                    start.ctypes.data, stop.ctypes.data, len(start), C.byref(n), C.byref(tot))
+    if rc != 0:
+        raise EngineError(rc, L.itsx_trim_last_error().decode())
+    return n.value, tot.value
+
+
+def write_trimmed_paired(fastq, fastq2, outfile1, outfile2, names, start, stop, tlen, gzipped=False, trim_ccs=False):
+    """names[i] = id of merged read i; start/stop/tlen per merged read.  Returns pairs written."""
+    for p in (fastq, fastq2):
+        if not os.path.exists(p):
+            raise FileNotFoundError(p)
+    gz = [str(p).endswith(".gz") for p in (fastq, fastq2)]
+    if gz[0] != gz[1]:
+        raise ValueError("Fastq and Fastq2 files should both be gzipped (.gz) or both be uncompressed. "
+                         "Mixed input is not accepted.")
+    L = _lib.lib()
+    start, stop, tlen = _i32(start), _i32(stop), _i32(tlen)
+    no = np.zeros(len(names) + 1, np.int64)
+    np.cumsum([len(s) for s in names], out=no[1:])
+    blob = "".join(names).encode()
+    n = C.c_int64(0)
+    rc = L.itsx_write_trimmed_paired(os.fsencode(fastq), os.fsencode(fastq2), os.fsencode(outfile1), os.fsencode(outfile2),
+                                     int(gzipped), int(trim_ccs), C.cast(C.c_char_p(blob), C.c_void_p), no.ctypes.data,
+                                     len(names), start.ctypes.data, stop.ctypes.data, tlen.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise EngineError(rc, L.itsx_trim_last_error().decode())
+    return n.value
+
+
+def coords_from_dicts(names, matchdict, itspos):
+    """(start, stop, tlen) arrays over `names` from the reference-shaped dicts (-1 = None / unknown),
+    i.e. what Dedup._filterfunc/map_func look up per record (SeqSample.py:814-865)."""
+    n = len(names)
+    start = np.full(n, -1, np.int32)
+    stop = np.full(n, -1, np.int32)
+    tlen = np.full(n, -1, np.int32)
+    cache = {}
+    for i, nm in enumerate(names):
+        rep = matchdict.get(nm)
+        if rep is None:
+            continue
+        if rep not in cache:
+            try:
+                a, b, t = itspos.get_position(rep)
+            except KeyError:
+                a = b = t = None
+            cache[rep] = (-1 if a is None else a, -1 if b is None else b, -1 if t is None else t)
+        start[i], stop[i], tlen[i] = cache[rep]
+    return start, stop, tlen

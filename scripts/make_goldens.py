@@ -15,6 +15,8 @@ Outputs
   runtime_hmm_names.json     create_runtime_hmm(taxa, region) NAME lists for the taxon files present
   itsposition_cases.json     synthetic domtbl texts + the ddict/get_position the reference class returns
   xxh64_kat.json             XXH64 known answers from the `xxhash` library
+  4774-1-MSITS3_R{1,2}.fastq.gz, seq.fq.gz, t2_r{1,2}.fq.gz
+                             inputs and byte-compared outputs of the reference's trimming tests (data)
   T.hmm.gz, mini.hmm         ITSx profile DATA: Tracheophyta set (stand-in taxon for the bench),
                              and a 6-profile subset for fast tests
 """
@@ -75,6 +77,13 @@ def main():
             f.write(">%s\n%s\n" % (rid, s))
     shutil.copyfile(os.path.join(TD, "ex_tmpdir", "uc.txt"), os.path.join(OUT, "fixture_uc.txt"))
     shutil.copyfile(os.path.join(TD, "ex_tmpdir", "rep.fa"), os.path.join(OUT, "fixture_rep.fa"))
+    # inputs and byte-compared outputs of the reference's trimming tests (test_main_pytest.py:378-397): data files
+    for fn in ("4774-1-MSITS3_R1.fastq.gz", "4774-1-MSITS3_R2.fastq.gz"):
+        shutil.copyfile(os.path.join(TD, fn), os.path.join(OUT, fn))
+    shutil.copyfile(os.path.join(TD, "ex_tmpdir", "seq.fq.gz"), os.path.join(OUT, "seq.fq.gz"))
+    for fn in ("t2_r1.fq", "t2_r2.fq"):
+        with open(os.path.join(TD, fn), "rb") as f, gzip.GzipFile(os.path.join(OUT, fn + ".gz"), "wb", mtime=0) as g:
+            g.write(f.read())
 
     # --- P1: matchdict as the reference's Dedup.parse builds it
     dd = S.Dedup(uc_file=os.path.join(TD, "ex_tmpdir", "uc.txt"), rep_file="", seq_file="")

@@ -1,0 +1,136 @@
+"""f1: the native FASTQ slice/write path against the reference's byte-compared goldens
+(tests/test_main_pytest.py:68-161, 350-397).  No GPU needed: the writers are host-only and context-free."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from itsxpress_amd import Dedup, ItsPosition, EngineError
+from itsxpress_amd.engine import read_fastx
+from itsxpress_amd.trim import write_trimmed_fastq, write_trimmed_paired
+
+
+def _read(path):
+    op = gzip.open if str(path).endswith(".gz") else open
+    with op(path, "rt") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="module")
+def golden_coords(gold):
+    rows = [ln.split("\t") for ln in open(os.path.join(gold, "fungi_its2_coords.tsv")).read().strip().split("\n")[1:]]
+    return {r[0]: (int(r[2]), int(r[3]), int(r[4])) for r in rows}
+
+
+@pytest.fixture(scope="module")
+def raw_fastqs(gold, tmp_path_factory):
+    d = tmp_path_factory.mktemp("raw")
+    out = []
+    for fn in ("4774-1-MSITS3_R1.fastq", "4774-1-MSITS3_R2.fastq"):
+        p = d / fn
+        p.write_text(_read(os.path.join(gold, fn + ".gz")))
+        out.append(str(p))
+    return out
+
+
+def test_paired_writer_reproduces_reference_goldens_byte_for_byte(gold, golden_coords, raw_fastqs, tmp_path):
+    names, _ = read_fastx(os.path.join(gold, "seq.fq.gz"))           # the 227 merged reads
+    start = np.array([golden_coords.get(n, (-1, -1, -1))[0] for n in names], np.int32)
+    stop = np.array([golden_coords.get(n, (-1, -1, -1))[1] for n in names], np.int32)
+    tlen = np.array([golden_coords.get(n, (-1, -1, -1))[2] for n in names], np.int32)
+    o1, o2 = str(tmp_path / "t2_r1.fq"), str(tmp_path / "t2_r2.fq")
+    n = write_trimmed_paired(raw_fastqs[0], raw_fastqs[1], o1, o2, names, start, stop, tlen)
+    assert n == 226
+    assert open(o1).read() == _read(os.path.join(gold, "t2_r1.fq.gz"))
+    assert open(o2).read() == _read(os.path.join(gold, "t2_r2.fq.gz"))
+    # gz inputs and gz outputs carry the same bytes
+    g1, g2 = str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq.gz")
+    n = write_trimmed_paired(os.path.join(gold, "4774-1-MSITS3_R1.fastq.gz"), os.path.join(gold, "4774-1-MSITS3_R2.fastq.gz"),
+                             g1, g2, names, start, stop, tlen, gzipped=True)
+    assert n == 226 and _read(g1) == open(o1).read() and _read(g2) == open(o2).read()
+
+
+def test_single_end_writer_matches_reference_counts(gold, golden_coords, tmp_path):
+    """test_dedup_create_trimmed_seqs asserts n == 226 and a summed length of 42637 on seq.fq.gz."""
+    seq = os.path.join(gold, "seq.fq.gz")
+    names, seqs = read_fastx(seq)
+    md = Dedup(os.path.join(gold, "fixture_uc.txt"), "", seq).matchdict
+    start = np.array([golden_coords.get(md[n], (-1, -1, -1))[0] for n in names], np.int32)
+    stop = np.array([golden_coords.get(md[n], (-1, -1, -1))[1] for n in names], np.int32)
+    out = str(tmp_path / "trimmed.fastq")
+    n, tot = write_trimmed_fastq(seq, out, start, stop)
+    assert (n, tot) == (226, 42637)
+    recs = open(out).read().split("\n")
+    assert len(recs) == 226 * 4 + 1 and all(recs[i] == "+" for i in range(2, 226 * 4, 4))
+    k = names.index(recs[0][1:].split()[0])
+    assert recs[1] == seqs[k][start[k]:stop[k]]
+    outz = str(tmp_path / "trimmed.fastq.gz")
+    assert write_trimmed_fastq(seq, outz, start, stop, gzipped=True) == (226, 42637)
+    assert _read(outz) == open(out).read()
+
+
+def test_mirror_dedup_writers_take_the_reference_dict_route(gold, golden_coords, raw_fastqs, tmp_path):
+    """Dedup.create_paired_trimmed_seqs / create_trimmed_seqs with an ItsPosition whose ddict holds the golden rows."""
+    seq = os.path.join(gold, "seq.fq.gz")
+    dd = Dedup(os.path.join(gold, "fixture_uc.txt"), os.path.join(gold, "fixture_rep.fa"), seq, fastq=raw_fastqs[0], fastq2=raw_fastqs[1])
+    ip = ItsPosition(None, "ITS2")
+    for rid, (a, b, t) in golden_coords.items():
+        rep = dd.matchdict[rid]
+        ip.ddict[rep] = {"left": {"score": 50.0, "to_pos": a, "from_pos": a - 44},
+                         "right": {"score": 50.0, "to_pos": b + 45, "from_pos": b + 1}, "tlen": t}
+    o1, o2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    dd.create_paired_trimmed_seqs(o1, o2, False, False, ip, True)
+    assert open(o1).read() == _read(os.path.join(gold, "t2_r1.fq.gz"))
+    assert open(o2).read() == _read(os.path.join(gold, "t2_r2.fq.gz"))
+    o3 = str(tmp_path / "single.fq")
+    dd.create_trimmed_seqs(o3, False, False, ip, True, str(tmp_path))
+    assert open(o3).read().count("\n+\n") == 226
+    with pytest.raises(ValueError):
+        dd.create_trimmed_seqs(o3, False, True, ip, True, str(tmp_path))
+
+
+def test_slice_rules_match_python_semantics(tmp_path):
+    """start >= stop dropped; stop beyond the read clamps; stop > tlen opens R1's slice; negative r2start wraps."""
+    rng = np.random.default_rng(0)
+    n = 60
+    seqs = ["".join(rng.choice(list("ACGT"), int(L))) for L in rng.integers(20, 60, n)]
+    quals = ["".join(chr(33 + int(q)) for q in rng.integers(2, 41, len(s))) for s in seqs]
+    names = ["r%d" % i for i in range(n)]
+    f1, f2 = tmp_path / "a.fastq", tmp_path / "b.fastq"
+    with open(f1, "w") as a, open(f2, "w") as b:
+        for nm, s, q in zip(names, seqs, quals):
+            a.write("@%s 1:N:0\n%s\n+\n%s\n" % (nm, s, q))
+            b.write("@%s 2:N:0\n%s\n+\n%s\n" % (nm, s[::-1], q[::-1]))
+    start = rng.integers(-1, 40, n).astype(np.int32)
+    stop = rng.integers(-1, 90, n).astype(np.int32)
+    tlen = rng.integers(30, 80, n).astype(np.int32)
+    out = tmp_path / "o.fastq"
+    nw, tot = write_trimmed_fastq(str(f1), str(out), start, stop, trim_ccs=True)
+    exp = []
+    for i in range(n):
+        if start[i] >= 0 and stop[i] >= 0 and start[i] < stop[i]:
+            s, q = seqs[i][start[i]:stop[i]], quals[i][start[i]:stop[i]]
+            exp.append("@%s 1:N:0\nGACAGGTACAAGAAGGA%sTTAACCCAGTCTCCAGT\n+\n%s%s%s\n" % (names[i], s, "~" * 17, q, "~" * 17))
+    assert out.read_text() == "".join(exp) and nw == len(exp)
+    o1, o2 = tmp_path / "p1.fastq", tmp_path / "p2.fastq"
+    write_trimmed_paired(str(f1), str(f2), str(o1), str(o2), names[::-1], start[::-1], stop[::-1], tlen[::-1])
+    e1, e2 = [], []
+    for i in range(n):
+        a, b, t = int(start[i]), int(stop[i]), int(tlen[i])
+        if a >= 0 and b >= 0 and a < b:
+            r2s, r2e = t - b, t - a
+            s1 = slice(a, None) if b > t else slice(a, b)
+            s2 = slice(r2s, None) if r2e > t else slice(r2s, r2e)
+            e1.append("@%s 1:N:0\n%s\n+\n%s\n" % (names[i], seqs[i][s1], quals[i][s1]))
+            e2.append("@%s 2:N:0\n%s\n+\n%s\n" % (names[i], seqs[i][::-1][s2], quals[i][::-1][s2]))
+    assert o1.read_text() == "".join(e1) and o2.read_text() == "".join(e2)
+
+
+def test_writer_errors(tmp_path):
+    bad = tmp_path / "bad.fastq"
+    bad.write_text("@r1\nACGT\n+\nII\n")
+    with pytest.raises(EngineError):
+        write_trimmed_fastq(str(bad), str(tmp_path / "o.fq"), [0], [3])
+    with pytest.raises(FileNotFoundError):
+        write_trimmed_fastq(str(tmp_path / "nope.fq"), str(tmp_path / "o.fq"), [0], [3])

@@ -59,15 +59,31 @@ __global__ void __launch_bounds__(64) k_msv(MsvArgs a)
   const int base = 190;
   const int s0 = chunk * a.seqs_per_wave;
   int s1 = s0 + a.seqs_per_wave; if (s1 > a.U) s1 = a.U;
-  for (int s = s0; s < s1; s++) {
+  // per-sequence metadata is a chain of dependent scalar loads (sorted position -> unique -> read -> offsets);
+  // the next sequence's chain is started before the current sequence's rows so its latency is hidden
+  struct Meta { int L, nexc, tjb; int64_t wo, eo; uint32_t w0; };
+  auto fetch = [&](int s) {
+    Meta m;
     const int u = uni(a.sorted_uniq[s]);
     const int r = uni(a.seed_read[u]);
-    int L = uni(a.rd.len[r]);
-    const int64_t wo = a.rd.woff[r];
-    const int64_t eo = a.rd.excoff[r];
-    const int nexc = uni((int)(a.rd.excoff[r + 1] - eo));
+    m.L = uni(a.rd.len[r]);
+    m.wo = a.rd.woff[r];
+    m.eo = a.rd.excoff[r];
+    m.nexc = uni((int)(a.rd.excoff[r + 1] - m.eo));
+    const int Lt = m.L < a.Lcap ? m.L : a.Lcap - 1;
+    m.tjb = uni(a.tjb[Lt]);
+    m.w0 = (uint32_t)uni((int)a.rd.words[m.wo]);
+    return m;
+  };
+  Meta nx = fetch(s0 < s1 ? s0 : 0);
+  for (int s = s0; s < s1; s++) {
+    const Meta cur = nx;
+    if (s + 1 < s1) nx = fetch(s + 1);
+    const int L = cur.L;
+    const int64_t eo = cur.eo;
+    const int nexc = cur.nexc;
     const int Lt = L < a.Lcap ? L : a.Lcap - 1;
-    const int tjbm = uni(a.tjb[Lt]) + tbm;
+    const int tjbm = cur.tjb + tbm;
     int xJ = 0;
     int xB = base - tjbm; xB = xB < 0 ? 0 : xB;
     uint32_t dp[MSV_REGS];
@@ -76,9 +92,11 @@ __global__ void __launch_bounds__(64) k_msv(MsvArgs a)
     int ovf = 0;
     int ei = 0;
     int next_exc = nexc > 0 ? uni((int)(a.rd.exc[eo] >> 4)) : 0x7fffffff;
-    const uint32_t *wp = a.rd.words + wo;
+    const uint32_t *wp = a.rd.words + cur.wo;
+    uint32_t wnext = cur.w0;
     for (int i0 = 0; i0 < L; i0 += 16) {
-      uint32_t w = (uint32_t)uni((int)wp[i0 >> 4]);
+      uint32_t w = wnext;
+      if (i0 + 16 < L) wnext = (uint32_t)uni((int)wp[(i0 >> 4) + 1]);     // the next 16 bases fly during these 16 rows
       int cnt = L - i0; cnt = cnt > 16 ? 16 : cnt;
       for (int t = 0; t < cnt; t++) {
         const s2 xBv = as_s2((uint32_t)xB * 0x10001u);

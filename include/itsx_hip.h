@@ -81,6 +81,8 @@ typedef struct {
   float   ms_env_kernel;  float ms_bias_kernel;  int64_t env_rows;    /* the three envelope sweeps together; lane-rows per sweep */
   int64_t n_env_unique;           /* distinct (profile, length, envelope subsequence) actually re-scored */
   float   ms_decode_kernel;  int32_t n_batches;          /* launches of each DP kernel in the last search */
+  float   ms_cluster;        int32_t pad0;               /* itsx_cluster at id < 1: whole call */
+  int64_t cl_windows, cl_cuts, cl_alignments;            /* speculative windows, windows cut by validation, alignments */
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -114,9 +116,15 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
 /* ---- a1: SeqSample.deduplicate (itsxpress/SeqSample.py:93-131)
  * = vsearch --fastx_uniques --strand both; minseqlength 32 is vsearch's default. */
 int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_unique);
-/* ---- a2: SeqSample.cluster (itsxpress/SeqSample.py:133-176) = vsearch --cluster_size.
- * Round 1: only id == 1.0 (pure dereplication) is implemented; otherwise ITSX_E_UNSUPPORTED. */
+/* ---- a2: SeqSample.cluster (itsxpress/SeqSample.py:133-176) = vsearch --cluster_size --id X --strand both:
+ * greedy centroid clustering in label order (8-mer candidate ranking, global alignment, --iddef 2 identity,
+ * maxaccepts 1 / maxrejects 32), restated in oracle/orc_cluster.c (parity unpinned: the reference holds no
+ * fixture for it).  id == 1.0 is exact dereplication (itsx_derep), which is what the reference runs at 1.0
+ * (main.py:534-537).  Fills the same arrays as itsx_derep. */
 int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique);
+/* after itsx_cluster at id < 1: pct_id[n_reads] = identity of each member with its centroid (uc column 4; -1 for
+ * centroids and dropped reads), order[n_order] = kept reads in processing order (the order of uc's S/H rows). */
+int itsx_get_cluster(const itsx_ctx *ctx, double *pct_id, int64_t *order, int64_t *n_order);
 /* Dedup.parse's matchdict (itsxpress/SeqSample.py:542-562) as arrays over reads:
  * rep_of[i] = read index of the cluster seed (first occurrence), -1 if the read was dropped;
  * strand[i] = +1 / -1 (uc column 5); uniq_of[i] = index into the unique list, -1 if dropped. */

@@ -76,22 +76,14 @@ class SeqSample:
 
     # -- a2 --------------------------------------------------------------------------
     def cluster(self, threads: Union[int, str], cluster_id: float = 0.995) -> None:
-        """Replaces `vsearch --cluster_size ... --id X` (SeqSample.py:133-176).
-
-        Only cluster_id == 1.0 (pure dereplication) is implemented in this round; other
-        values raise EngineError (a SubprocessError, as a failing vsearch would) -- unless
-        ITSXPRESS_CLUSTER_FALLBACK=derep is set, in which case exact dereplication is used
-        instead (more representatives are scored, every read still gets the coordinates of an
-        identical representative) and a warning is logged."""
+        """Replaces `vsearch --cluster_size ... --id X --strand both` (SeqSample.py:133-176): greedy centroid
+        clustering on the GPU (k_cluster.hip; oracle/orc_cluster.c restates the procedure, parity unpinned).
+        cluster_id == 1.0 is exact dereplication, as in main.py:534-537."""
         try:
             self.uc_file = os.path.join(self.tempdir, "uc.txt")
             self.rep_file = os.path.join(self.tempdir, "rep.fa")
             self._load_reads()
             cid = float(cluster_id)
-            if cid < 1.0 and os.environ.get("ITSXPRESS_CLUSTER_FALLBACK") == "derep":
-                logging.warning("cluster_id %.4f < 1.0 is not implemented on the HIP engine; dereplicating exactly "
-                                "(ITSXPRESS_CLUSTER_FALLBACK=derep)", cid)
-                cid = 1.0
             self.engine.cluster(cid, strand_both=True)
             self.engine.write_uc(self.uc_file)
             self.engine.write_rep_fasta(self.rep_file)

@@ -42,13 +42,14 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("ms_filters", "<f4"), ("ms_domains", "<f4"), ("ms_finalize", "<f4"), ("ms_msv_kernel", "<f4"),
                 ("msv_cells", "<i8"), ("msv_launches", "<i8"), ("ms_fwd_kernel", "<f4"), ("ms_bwd_kernel", "<f4"),
                 ("fwd_rows", "<i8"), ("ms_env_kernel", "<f4"), ("ms_bias_kernel", "<f4"), ("env_rows", "<i8"),
-                ("n_env_unique", "<i8"), ("ms_decode_kernel", "<f4"), ("n_batches", "<i4")]
+                ("n_env_unique", "<i8"), ("ms_decode_kernel", "<f4"), ("n_batches", "<i4"), ("ms_cluster", "<f4"),
+                ("pad0", "<i4"), ("cl_windows", "<i8"), ("cl_cuts", "<i8"), ("cl_alignments", "<i8")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares
 EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy", "itsx_load_profiles_file",
            "itsx_load_profiles_mem", "itsx_profile_name", "itsx_profile_tables", "itsx_set_reads",
-           "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_derep", "itsx_get_uniques",
+           "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_cluster", "itsx_get_derep", "itsx_get_uniques",
            "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
            "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
@@ -80,6 +81,7 @@ def lib():
         "itsx_load_reads_file": (i32, [vp, cp, vp]),
         "itsx_derep": (i32, [vp, i32, i32, vp]),
         "itsx_cluster": (i32, [vp, f64, i32, vp]),
+        "itsx_get_cluster": (i32, [vp, vp, vp, vp]),
         "itsx_get_derep": (i32, [vp, vp, vp, vp]),
         "itsx_get_uniques": (i32, [vp, vp, vp]),
         "itsx_search": (i32, [vp, f64, f64, f64, f64]),

@@ -145,6 +145,9 @@ struct itsx_ctx {
   DBuf<int8_t> d_strand;
   std::vector<int32_t> h_rep_of, h_uniq_of, h_seed_read, h_abund, h_sorted_uniq;
   std::vector<int8_t> h_strand;
+  bool clustered = false;                // last grouping came from itsx_cluster at id < 1 (uc rows carry identities)
+  std::vector<double> h_pct;             // per read: identity of its H row, -1 for centroids / dropped reads
+  std::vector<int32_t> h_order;          // kept reads in processing (label) order
 
   // ---- search
   bool have_search = false, have_final = false;
@@ -505,6 +508,55 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
 }
 
 // ------------------------------------------------------------------------------ derep
+// uniques = seeds in input order, then ordered by length for the HMM stages (shared by derep and cluster)
+static int build_unique_lists(itsx_ctx *ctx)
+{
+  const int64_t n = ctx->N;
+  DBuf<int32_t> &is_seed = ctx->w_is_seed, &seed_rank = ctx->w_seed_rank, &scan_tmp = ctx->w_scan_tmp;
+  int32_t U = 0;
+  if (n > 0) {
+    launch_exclusive_scan(is_seed.p, seed_rank.p, n + 1, scan_tmp.p, ctx->st);   // element n = total (is_seed[n] unused but allocated)
+    HIPCHK(hipMemcpyAsync(&U, seed_rank.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
+  ctx->U = U;
+  HIPCHK(ctx->d_seed_read.alloc((size_t)U + 1)); HIPCHK(ctx->d_abund.alloc((size_t)U + 1)); HIPCHK(ctx->d_sorted_uniq.alloc((size_t)U + 1));
+  HIPCHK(ctx->d_ulen.alloc((size_t)U + 1));
+  HIPCHK(hipMemsetAsync(ctx->d_abund.p, 0, ((size_t)U + 1) * sizeof(int32_t), ctx->st));
+  if (n > 0) launch_uniques(n, ctx->d_rep_of.p, seed_rank.p, ctx->d_uniq_of.p, ctx->d_seed_read.p, ctx->d_abund.p, ctx->st);
+  // order the uniques by length (counting sort) for the HMM stages
+  if (U > 0) {
+    const int32_t lcap = 65536;
+    DBuf<int32_t> &hist = ctx->w_hist, &cursor = ctx->w_cursor, &tmp2 = ctx->w_tmp2;
+    HIPCHK(hist.alloc(lcap)); HIPCHK(cursor.alloc(lcap)); HIPCHK(tmp2.alloc((size_t)scan_tmp_elems(lcap)));
+    HIPCHK(hipMemsetAsync(hist.p, 0, lcap * sizeof(int32_t), ctx->st));
+    launch_len_hist(U, ctx->d_seed_read.p, ctx->rd.len, hist.p, lcap, ctx->st);
+    launch_exclusive_scan(hist.p, cursor.p, lcap, tmp2.p, ctx->st);
+    launch_len_scatter(U, ctx->d_seed_read.p, ctx->rd.len, cursor.p, lcap, ctx->d_sorted_uniq.p, ctx->st);
+    launch_fill_ulen(U, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, ctx->rd.len, ctx->d_ulen.p, ctx->st);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
+  return ITSX_OK;
+}
+static int mirror_derep(itsx_ctx *ctx)
+{
+  const int64_t n = ctx->N; const int32_t U = ctx->U;
+  // host mirrors (writers, getters)
+  ctx->h_rep_of.resize((size_t)n); ctx->h_strand.resize((size_t)n); ctx->h_uniq_of.resize((size_t)n);
+  ctx->h_seed_read.resize((size_t)U); ctx->h_abund.resize((size_t)U); ctx->h_sorted_uniq.resize((size_t)U);
+  if (n > 0) {
+    HIPCHK(hipMemcpy(ctx->h_rep_of.data(), ctx->d_rep_of.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_strand.data(), ctx->d_strand.p, (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_uniq_of.data(), ctx->d_uniq_of.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  if (U > 0) {
+    HIPCHK(hipMemcpy(ctx->h_seed_read.data(), ctx->d_seed_read.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_abund.data(), ctx->d_abund.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_sorted_uniq.data(), ctx->d_sorted_uniq.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+  }
+  return ITSX_OK;
+}
+
 int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_unique)
 {
   CTXCHK(ctx);
@@ -539,57 +591,161 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
     ctx->stats.hash_reseeds++;
   }
   if (hcoll != 0) SET_ERR(ctx, ITSX_E_COLLISION, "64-bit key collisions survived 4 reseeds");
-  // unique list = seeds in input order
-  int32_t U = 0;
-  if (n > 0) {
-    launch_exclusive_scan(is_seed.p, seed_rank.p, n + 1, scan_tmp.p, ctx->st);   // element n = total (is_seed[n] unused but allocated)
-    HIPCHK(hipMemcpyAsync(&U, seed_rank.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-  }
-  ctx->U = U;
-  HIPCHK(ctx->d_seed_read.alloc((size_t)U + 1)); HIPCHK(ctx->d_abund.alloc((size_t)U + 1)); HIPCHK(ctx->d_sorted_uniq.alloc((size_t)U + 1));
-  HIPCHK(ctx->d_ulen.alloc((size_t)U + 1));
-  HIPCHK(hipMemsetAsync(ctx->d_abund.p, 0, ((size_t)U + 1) * sizeof(int32_t), ctx->st));
-  if (n > 0) launch_uniques(n, ctx->d_rep_of.p, seed_rank.p, ctx->d_uniq_of.p, ctx->d_seed_read.p, ctx->d_abund.p, ctx->st);
-  // order the uniques by length (counting sort) for the HMM stages
-  if (U > 0) {
-    const int32_t lcap = 65536;
-    DBuf<int32_t> &hist = ctx->w_hist, &cursor = ctx->w_cursor, &tmp2 = ctx->w_tmp2;
-    HIPCHK(hist.alloc(lcap)); HIPCHK(cursor.alloc(lcap)); HIPCHK(tmp2.alloc((size_t)scan_tmp_elems(lcap)));
-    HIPCHK(hipMemsetAsync(hist.p, 0, lcap * sizeof(int32_t), ctx->st));
-    launch_len_hist(U, ctx->d_seed_read.p, ctx->rd.len, hist.p, lcap, ctx->st);
-    launch_exclusive_scan(hist.p, cursor.p, lcap, tmp2.p, ctx->st);
-    launch_len_scatter(U, ctx->d_seed_read.p, ctx->rd.len, cursor.p, lcap, ctx->d_sorted_uniq.p, ctx->st);
-    launch_fill_ulen(U, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, ctx->rd.len, ctx->d_ulen.p, ctx->st);
-    HIPCHK(hipStreamSynchronize(ctx->st));
-  }
+  { const int rc_ = build_unique_lists(ctx); if (rc_ != ITSX_OK) return rc_; }
   ctx->stats.ms_derep = tm.stop();
-  // host mirrors (writers, getters)
-  ctx->h_rep_of.resize((size_t)n); ctx->h_strand.resize((size_t)n); ctx->h_uniq_of.resize((size_t)n);
-  ctx->h_seed_read.resize((size_t)U); ctx->h_abund.resize((size_t)U); ctx->h_sorted_uniq.resize((size_t)U);
-  if (n > 0) {
-    HIPCHK(hipMemcpy(ctx->h_rep_of.data(), ctx->d_rep_of.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ctx->h_strand.data(), ctx->d_strand.p, (size_t)n, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ctx->h_uniq_of.data(), ctx->d_uniq_of.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  }
-  if (U > 0) {
-    HIPCHK(hipMemcpy(ctx->h_seed_read.data(), ctx->d_seed_read.p, (size_t)U * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ctx->h_abund.data(), ctx->d_abund.p, (size_t)U * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ctx->h_sorted_uniq.data(), ctx->d_sorted_uniq.p, (size_t)U * 4, hipMemcpyDeviceToHost));
-  }
+  { const int rc_ = mirror_derep(ctx); if (rc_ != ITSX_OK) return rc_; }
+  const int32_t U = ctx->U;
   int64_t dropped = 0;
   for (int64_t r = 0; r < n; r++) dropped += ctx->h_rep_of[r] < 0;
   ctx->stats.n_unique = U; ctx->stats.n_dropped_short = dropped;
-  ctx->have_derep = true; ctx->have_search = ctx->have_final = false;
+  ctx->have_derep = true; ctx->have_search = ctx->have_final = false; ctx->clustered = false;
   if (n_unique) *n_unique = U;
   return ITSX_OK;
 }
 
+// a2: greedy centroid clustering (k_cluster.hip explains the speculative windows)
 int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
 {
   CTXCHK(ctx);
-  if (id < 1.0) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "greedy clustering at id < 1.0 (vsearch --cluster_size) is not implemented; only id == 1.0");
-  return itsx_derep(ctx, strand_both, 32, n_unique);
+  if (!(id > 0.0 && id <= 1.0)) SET_ERR(ctx, ITSX_E_ARG, "cluster id must be in (0, 1]");
+  if (id == 1.0) return itsx_derep(ctx, strand_both, 32, n_unique);      // main.py:534-537 never clusters at 1.0
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->N;
+  const int minlen = 32;
+  StageTimer tm(ctx->st);
+  // processing order: abundance (all 1) descending, then label, then input position
+  std::vector<int32_t> ord; ord.reserve((size_t)n);
+  int Lmax = 1;
+  for (int64_t r = 0; r < n; r++) if (ctx->h_len[r] >= minlen) { ord.push_back((int32_t)r); Lmax = std::max(Lmax, (int)ctx->h_len[r]); }
+  if (!ctx->h_names.empty())
+    std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+      const int c = strcmp(ctx->h_names[a].c_str(), ctx->h_names[b].c_str());
+      return c < 0 || (c == 0 && a < b);
+    });
+  const int32_t nk = (int32_t)ord.size();
+  int Bmax = 4096;
+  if (const char *e = getenv("ITSX_CL_WINDOW")) Bmax = std::max(1, atoi(e));
+  int rows_per_lane = (Lmax + 1 <= 320) ? 5 : 10;
+  if (const char *e = getenv("ITSX_CL_ROWS")) rows_per_lane = atoi(e) <= 5 ? 5 : 10;
+  const bool multipass = Lmax + 1 > 64 * rows_per_lane;
+  const int32_t scratch_pitch = Lmax + 1;
+  if (multipass) while (Bmax > 64 && 32LL * Bmax * scratch_pitch > (2LL << 30)) Bmax /= 2;
+  const int32_t kcap = std::max(8, ((Lmax - 7 + 7) / 8) * 8);
+  const int64_t cnt_budget = 8LL << 30;
+
+  DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, cand, acc_col, n_found, is_new, new_rank, first_aff, scan_tmp;
+  DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct;
+  DBuf<uint16_t> klist, cnt; DBuf<unsigned long long> prev, bound, curkey, scratch, n_align;
+  DBuf<uint32_t> bitsA, bitsB;
+  DBuf<uint32_t> *bits = &bitsA, *bits_other = &bitsB;
+  HIPCHK(upload(d_order, ord, ctx->st));
+  const size_t ccap = (size_t)nk + 2048;
+  HIPCHK(cent_len.alloc(ccap)); HIPCHK(cent_pos.alloc(ccap)); HIPCHK(cent_read.alloc(ccap));
+  HIPCHK(res_col.alloc((size_t)nk + 1)); HIPCHK(res_strand.alloc((size_t)nk + 1)); HIPCHK(res_id.alloc((size_t)nk + 1));
+  const size_t nqs = 2 * (size_t)Bmax;
+  HIPCHK(klist.alloc(nqs * kcap)); HIPCHK(knk.alloc(nqs)); HIPCHK(state.alloc(nqs)); HIPCHK(rejects.alloc(nqs)); HIPCHK(cand.alloc(nqs));
+  HIPCHK(acc_col.alloc(nqs)); HIPCHK(prev.alloc(nqs)); HIPCHK(bound.alloc(nqs)); HIPCHK(curkey.alloc(nqs)); HIPCHK(acc_id.alloc(nqs));
+  HIPCHK(n_found.alloc(32)); HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(first_aff.alloc(1));
+  HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(Bmax + 1))); HIPCHK(n_align.alloc(1));
+  HIPCHK(scratch.alloc(multipass ? nqs * (size_t)scratch_pitch * 2 : 2));
+  HIPCHK(hipMemsetAsync(n_align.p, 0, sizeof(unsigned long long), ctx->st));
+  int64_t capC = 2048;
+  while (capC < std::min<int64_t>(nk, 262144)) capC *= 2;
+  HIPCHK(bits->alloc((size_t)65536 * (size_t)(capC / 32)));
+  HIPCHK(hipMemsetAsync(bits->p, 0, (size_t)65536 * (size_t)(capC / 32) * 4, ctx->st));
+
+  ClusterArgs a{};
+  a.rd = ctx->rd; a.order = d_order.p; a.strand_both = strand_both ? 1 : 0;
+  a.cent_len = cent_len.p; a.cent_pos = cent_pos.p; a.cent_read = cent_read.p;
+  a.klist = klist.p; a.kcap = kcap; a.nk = knk.p;
+  a.state = state.p; a.rejects = rejects.p; a.cand = cand.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.curkey = curkey.p;
+  a.acc_id = acc_id.p; a.n_found = n_found.p; a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
+  a.is_new = is_new.p; a.new_rank = new_rank.p; a.first_affected = first_aff.p; a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
+  a.thr = 100.0 * id; a.n_align = n_align.p;
+
+  int32_t f = 0, C = 0;
+  int B = std::min(Bmax, 256);
+  int64_t windows = 0, cuts = 0;
+  std::vector<int32_t> h_new((size_t)Bmax + 1);
+  while (f < nk) {
+    int nq = std::min<int32_t>(B, nk - f);
+    auto pitch_for = [&](int q) { return ((((int64_t)C + q - 1) >> 11) + 1) * 2048; };
+    while (nq > 1 && 4LL * nq * pitch_for(nq) > cnt_budget) nq /= 2;
+    const int64_t cpitch = pitch_for(nq);
+    if ((int64_t)C + nq > capC) {                           // grow the column capacity of the index
+      int64_t ncap = capC;
+      while (ncap < (int64_t)C + nq) ncap *= 2;
+      HIPCHK(bits_other->alloc((size_t)65536 * (size_t)(ncap / 32)));
+      HIPCHK(hipMemsetAsync(bits_other->p, 0, (size_t)65536 * (size_t)(ncap / 32) * 4, ctx->st));
+      launch_cl_relayout(bits->p, capC / 32, bits_other->p, ncap / 32, ctx->st);
+      HIPCHK(hipStreamSynchronize(ctx->st));
+      std::swap(bits, bits_other); bits_other->release();
+      capC = ncap;
+    }
+    HIPCHK(cnt.alloc((size_t)(2 * (int64_t)nq * cpitch)));
+    a.f = f; a.nq = nq; a.C = C; a.bits = bits->p; a.stride = capC / 32; a.cnt = cnt.p; a.cpitch = cpitch;
+    launch_cl_kmers(a, ctx->st);
+    launch_cl_count(a, 0, (C + 2047) >> 11, ctx->st);
+    launch_cl_init(a, ctx->st);
+    for (int round = 0; round < 32 && C > 0; round++) {
+      launch_cl_round(a, round, rows_per_lane, ctx->st);
+      if (round == 0 || round == 1 || round == 3 || round == 7 || round == 15) {
+        int32_t found = 0;
+        HIPCHK(hipMemcpyAsync(&found, n_found.p + round, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        if (found == 0) break;
+      }
+    }
+    launch_cl_outcome(a, ctx->st);
+    launch_exclusive_scan(is_new.p, new_rank.p, nq + 1, scan_tmp.p, ctx->st);
+    launch_cl_columns(a, 0, 0, ctx->st);
+    const int tile0 = C >> 11;
+    launch_cl_count(a, tile0, (int)((((int64_t)C + nq - 1) >> 11) - tile0 + 1), ctx->st);
+    launch_cl_affected(a, ctx->st);
+    int32_t cut = nq;
+    HIPCHK(hipMemcpyAsync(&cut, first_aff.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(h_new.data(), is_new.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    if (cut < 1 || cut > nq) SET_ERR(ctx, ITSX_E_DEVICE, "clustering window validation returned an impossible cut");
+    int32_t n_new = 0, n_keep = 0;
+    for (int q = 0; q < nq; q++) { n_new += h_new[q]; if (q < cut) n_keep += h_new[q]; }
+    if (n_keep < n_new) launch_cl_columns(a, 1, cut, ctx->st);         // roll the speculative centroids after the cut back
+    C += n_keep; f += cut; windows++; cuts += cut < nq;
+    B = cut == nq ? std::min(Bmax, std::max(B, nq) * 2) : std::min(Bmax, std::max(64, 2 * cut));
+  }
+
+  HIPCHK(ctx->d_rep_of.alloc((size_t)n + 1)); HIPCHK(ctx->d_strand.alloc((size_t)n + 1)); HIPCHK(ctx->d_uniq_of.alloc((size_t)n + 1));
+  HIPCHK(ctx->w_is_seed.alloc((size_t)n + 1)); HIPCHK(ctx->w_seed_rank.alloc((size_t)n + 1)); HIPCHK(ctx->w_scan_tmp.alloc((size_t)scan_tmp_elems(n + 1)));
+  HIPCHK(d_pct.alloc((size_t)n + 1));
+  HIPCHK(hipMemsetAsync(ctx->w_is_seed.p, 0, ((size_t)n + 1) * sizeof(int32_t), ctx->st));
+  HIPCHK(hipMemsetAsync(ctx->d_rep_of.p, 0xff, ((size_t)n + 1) * sizeof(int32_t), ctx->st));
+  HIPCHK(hipMemsetAsync(ctx->d_strand.p, 1, (size_t)n + 1, ctx->st));
+  HIPCHK(hipMemsetAsync(d_pct.p, 0, ((size_t)n + 1) * sizeof(double), ctx->st));
+  launch_cl_finalize(nk, d_order.p, res_col.p, res_strand.p, res_id.p, cent_read.p, ctx->d_rep_of.p, ctx->d_strand.p, d_pct.p, ctx->w_is_seed.p, ctx->st);
+  { const int rc_ = build_unique_lists(ctx); if (rc_ != ITSX_OK) return rc_; }
+  unsigned long long naln = 0;
+  HIPCHK(hipMemcpy(&naln, n_align.p, sizeof(naln), hipMemcpyDeviceToHost));
+  ctx->stats.ms_cluster = tm.stop();
+  { const int rc_ = mirror_derep(ctx); if (rc_ != ITSX_OK) return rc_; }
+  ctx->h_pct.assign((size_t)n, -1.0);
+  if (n > 0) HIPCHK(hipMemcpy(ctx->h_pct.data(), d_pct.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < n; r++) if (ctx->h_rep_of[r] < 0 || ctx->h_rep_of[r] == r) ctx->h_pct[r] = -1.0;
+  ctx->h_order = ord;
+  ctx->stats.n_unique = ctx->U; ctx->stats.n_dropped_short = n - nk;
+  ctx->stats.cl_windows = windows; ctx->stats.cl_cuts = cuts; ctx->stats.cl_alignments = (int64_t)naln;
+  ctx->have_derep = true; ctx->have_search = ctx->have_final = false; ctx->clustered = true;
+  if (ctx->U != C) SET_ERR(ctx, ITSX_E_DEVICE, "clustering bookkeeping mismatch (centroids " + std::to_string(C) + " vs uniques " + std::to_string(ctx->U) + ")");
+  if (n_unique) *n_unique = ctx->U;
+  return ITSX_OK;
+}
+
+int itsx_get_cluster(const itsx_ctx *ctx, double *pct_id, int64_t *order, int64_t *n_order)
+{
+  CTXCHK(ctx && ctx->have_derep && ctx->clustered);
+  if (pct_id) for (int64_t r = 0; r < ctx->N; r++) pct_id[r] = ctx->h_pct[r];
+  if (order) for (size_t i = 0; i < ctx->h_order.size(); i++) order[i] = ctx->h_order[i];
+  if (n_order) *n_order = (int64_t)ctx->h_order.size();
+  return ITSX_OK;
 }
 
 int itsx_get_derep(const itsx_ctx *ctx, int64_t *rep_of, int8_t *strand, int64_t *uniq_of)
@@ -1113,6 +1269,12 @@ static std::string read_name(const itsx_ctx *ctx, int64_t r)
 // clusters in vsearch's output order: abundance descending, ties by label
 static std::vector<int32_t> cluster_order(const itsx_ctx *ctx)
 {
+  if (ctx->clustered) {                  // --cluster_size: clusters are numbered as their centroids were created
+    std::vector<int32_t> ord;
+    ord.reserve((size_t)ctx->U);
+    for (int32_t r : ctx->h_order) if (ctx->h_rep_of[r] == r) ord.push_back(ctx->h_uniq_of[r]);
+    return ord;
+  }
   std::vector<int32_t> ord((size_t)ctx->U);
   std::iota(ord.begin(), ord.end(), 0);
   std::vector<std::string> lab((size_t)ctx->U);
@@ -1130,6 +1292,21 @@ int itsx_write_uc(const itsx_ctx *ctx, const char *path)
   FILE *f = fopen(path, "w");
   if (!f) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + path);
   const std::vector<int32_t> ord = cluster_order(ctx);
+  if (ctx->clustered) {
+    // vsearch --cluster_size writes the S and H rows as the queries are processed, then one C row per cluster
+    std::vector<int32_t> cno((size_t)ctx->U);
+    for (size_t c = 0; c < ord.size(); c++) cno[ord[c]] = (int32_t)c;
+    for (int32_t r : ctx->h_order) {
+      const int32_t u = ctx->h_uniq_of[r];
+      if (ctx->h_rep_of[r] == r) fprintf(f, "S\t%d\t%d\t*\t*\t*\t*\t*\t%s\t*\n", cno[u], ctx->h_len[r], read_name(ctx, r).c_str());
+      else fprintf(f, "H\t%d\t%d\t%.1f\t%c\t0\t0\t*\t%s\t%s\n", cno[u], ctx->h_len[r], ctx->h_pct[r], ctx->h_strand[r] < 0 ? '-' : '+',
+                   read_name(ctx, r).c_str(), read_name(ctx, ctx->h_rep_of[r]).c_str());
+    }
+    for (size_t c = 0; c < ord.size(); c++)
+      fprintf(f, "C\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_abund[ord[c]], read_name(ctx, ctx->h_seed_read[ord[c]]).c_str());
+    fclose(f);
+    return ITSX_OK;
+  }
   std::vector<std::vector<int64_t>> members((size_t)ctx->U);
   for (int64_t r = 0; r < ctx->N; r++) { const int32_t u = ctx->h_uniq_of[r]; if (u >= 0 && ctx->h_rep_of[r] != r) members[u].push_back(r); }
   for (size_t c = 0; c < ord.size(); c++) {

@@ -33,6 +33,40 @@ void launch_region_upos(int64_t nr, const RegionRec *regions, const PairRec *pai
                         const int64_t *rseg, const int64_t *useg, int32_t *upos, RegionRec *ulist, hipStream_t st);
 void launch_region_upos_follow(int64_t nr, const int32_t *rep_region, const int32_t *is_uniq, int32_t *upos, hipStream_t st);
 
+// ---- k_cluster.hip (row a2: greedy centroid clustering, speculative windows)
+struct ClusterArgs {
+  ReadsDev rd;
+  const int32_t *order;         // [nk] read index by processing position (label order)
+  int32_t f, nq;                // window = positions [f, f+nq)
+  int32_t strand_both;
+  uint32_t *bits;               // centroid index: [65536 words][stride] column bit matrix
+  int64_t stride;               // 32-bit words per row, a multiple of 64
+  int32_t *cent_len, *cent_pos, *cent_read;   // per centroid column
+  int32_t C;                    // centroids at the window start
+  uint16_t *klist; int32_t kcap; int32_t *nk;  // distinct words of each (query, strand): [2 nq][kcap], [2 nq]
+  uint16_t *cnt; int64_t cpitch;               // shared-word counts [2 nq][cpitch]
+  int32_t *state, *rejects, *cand, *acc_col;   // walk state per (query, strand): 0 active 1 accepted 2 32 rejects 3 exhausted
+  unsigned long long *prev, *bound, *curkey;
+  double *acc_id;
+  int32_t *n_found;             // [32] candidates found per round
+  int32_t *res_col; int8_t *res_strand; double *res_id;   // outcome by processing position
+  int32_t *is_new, *new_rank;   // [nq+1]
+  int32_t *first_affected;      // [1]
+  unsigned long long *scratch; int32_t scratch_pitch;     // alignment boundary rows [2 nq][pitch][2]
+  double thr;                   // 100 * id
+  unsigned long long *n_align;
+};
+void launch_cl_kmers(const ClusterArgs &a, hipStream_t st);
+void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st);
+void launch_cl_init(const ClusterArgs &a, hipStream_t st);
+void launch_cl_round(const ClusterArgs &a, int round, int rows_per_lane, hipStream_t st);
+void launch_cl_outcome(const ClusterArgs &a, hipStream_t st);
+void launch_cl_columns(const ClusterArgs &a, int clear, int qi_from, hipStream_t st);
+void launch_cl_affected(const ClusterArgs &a, hipStream_t st);
+void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
+                        const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st);
+void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride, hipStream_t st);
+
 // ---- k_util.hip
 // exclusive prefix sum of n int32 values (n < 2^31); tmp must hold scan_tmp_elems(n) int32
 int64_t scan_tmp_elems(int64_t n);

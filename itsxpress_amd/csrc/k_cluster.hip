@@ -1,0 +1,456 @@
+// k_cluster.hip -- row a2 of the path: greedy centroid clustering on the device.
+//
+// Replaces `vsearch --cluster_size IN --centroids rep.fa --uc uc.txt --strand both --id X`
+// (reference call site itsxpress/SeqSample.py:147-162).  The procedure is the one oracle/orc_cluster.c
+// restates (PARITY UNPINNED against a real vsearch: no fixture, no binary): queries in label order; per
+// strand the distinct unambiguous 8-mers of the query are counted against every centroid; candidates with
+// >= min(12, #words) shared words are tried in (shared words desc, length asc, position asc) order by a
+// global alignment (+2/-4, gaps 20+2k interior, 2+k terminal) until identity >= X accepts one or 32 are
+// rejected; a query without an accepted hit becomes a centroid.
+//
+// How a sequential greedy runs on 256 CUs and still gives the sequential answer:
+//  * speculate: a WINDOW of queries is searched against the centroids that exist at the window start, all
+//    queries in parallel;
+//  * validate: the queries that found nothing would become centroids; a later query of the same window is
+//    AFFECTED if such a new centroid would have entered its candidate walk (enough shared words and a rank
+//    above the point where the walk stopped).  The window is cut at the first affected query: everything
+//    before it is exactly what the sequential procedure produces, the rest is searched again in the next
+//    window against the enlarged centroid set.  The first query of a window is never affected, so the loop
+//    always advances; on amplicon data cuts are rare once a few hundred centroids exist.
+//
+// Data layout: the centroid index is a COLUMN BIT MATRIX bits[65536 words][stride]: row = 8-mer, bit c = centroid
+// c holds that word.  Counting the shared words of one query against 2048 centroids is then 64 lanes x one
+// 32-bit column word per query word, accumulated with carry-save adders on bit-sliced counters (Harley-Seal):
+// about 6 integer ops per query word per 32 centroids, coalesced 256-B row segments, no atomics.  Amplicons
+// share their conserved flanks, so nearly every centroid shares words with every query: the dense form is the
+// right one (an inverted index would touch the same cells one atomic at a time).
+// The alignment is one wave per (query, candidate): lane l owns S consecutive DP rows, columns advance as an
+// anti-diagonal wavefront, the row above arrives by a one-lane shift; every cell carries (score, matches,
+// counted columns) packed into one int64 so that integer max is the lexicographic max and no traceback exists.
+#include "engine.h"
+#include "k_api.h"
+
+namespace itsx {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+static constexpr int SH_S = 40, SH_M = 20;
+static constexpr i64 NEGV = -(1LL << 60);
+static constexpr i64 ONE_S = 1LL << SH_S, ONE_M = 1LL << SH_M;
+static constexpr i64 GOI = -22 * ONE_S - 1, GEI = -2 * ONE_S - 1, GOT = -3 * ONE_S, GET = -1 * ONE_S;
+static constexpr i64 D_MATCH = 2 * ONE_S + ONE_M - 1, D_MISMATCH = -4 * ONE_S - 1, D_AMB_MATCH = ONE_M - 1, D_AMB_MISMATCH = -1;
+static constexpr u64 MASK4_LUT = 0xFD7EB96C3A508421ULL;      // IUPAC set of each digital code, 4 bits each
+
+__device__ __forceinline__ uint32_t mask4(uint32_t code) { return (uint32_t)(MASK4_LUT >> (4 * code)) & 15u; }
+__device__ __forceinline__ uint32_t revmask4(uint32_t m) { return ((m & 1u) << 3) | ((m & 2u) << 1) | ((m & 4u) >> 1) | ((m & 8u) >> 3); }
+__device__ __forceinline__ bool unamb4(uint32_t m) { return __popc(m) == 1; }
+__device__ __forceinline__ i64 max64(i64 a, i64 b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t rc16(uint32_t k)
+{
+  uint32_t x = ~k & 0xffffu;
+  x = ((x & 0x3333u) << 2) | ((x >> 2) & 0x3333u);
+  x = ((x & 0x0f0fu) << 4) | ((x >> 4) & 0x0f0fu);
+  return ((x & 0x00ffu) << 8) | (x >> 8);
+}
+__device__ __forceinline__ u64 cand_key(uint32_t cnt, int32_t len, int32_t pos)
+{
+  return ((u64)cnt << 48) | ((u64)(65535 - len) << 32) | (u64)(0xffffffffu - (uint32_t)pos);
+}
+
+// ------------------------------------------------------------------ distinct 8-mers of each (query, strand)
+__global__ __launch_bounds__(256) void k_cl_kmers(ClusterArgs a)
+{
+  __shared__ uint32_t bm[2048];
+  __shared__ uint32_t bad[2048];
+  __shared__ int32_t part[256];
+  const int tid = threadIdx.x;
+  const int qs = blockIdx.x, qi = qs >> 1, s = qs & 1;
+  if (s && !a.strand_both) { if (tid == 0) a.nk[qs] = 0; return; }
+  const int64_t r = a.order[a.f + qi];
+  const int L = a.rd.len[r];
+  const uint32_t *w = a.rd.words + a.rd.woff[r];
+  const int64_t eo = a.rd.excoff[r];
+  const int nexc = (int)(a.rd.excoff[r + 1] - eo);
+  for (int i = tid; i < 2048; i += 256) { bm[i] = 0u; bad[i] = 0u; }
+  __syncthreads();
+  for (int e = tid; e < nexc; e += 256) {
+    const int pos = (int)(a.rd.exc[eo + e] >> 4);
+    for (int d = 0; d < 8; d++) { const int p = pos - d; if (p >= 0) atomicOr(&bad[p >> 5], 1u << (p & 31)); }
+  }
+  __syncthreads();
+  for (int i = tid; i + 8 <= L; i += 256) {
+    if ((bad[i >> 5] >> (i & 31)) & 1u) continue;
+    const int wi = i >> 4, sh = (i & 15) * 2;
+    uint32_t k = w[wi] >> sh;
+    if (sh > 16) k |= w[wi + 1] << (32 - sh);
+    k &= 0xffffu;
+    if (s) k = rc16(k);
+    atomicOr(&bm[k >> 5], 1u << (k & 31));
+  }
+  __syncthreads();
+  int c = 0;
+  for (int j = 0; j < 8; j++) c += __popc(bm[tid * 8 + j]);
+  part[tid] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - c;
+  uint16_t *out = a.klist + (size_t)qs * a.kcap;
+  for (int j = 0; j < 8; j++) {
+    uint32_t x = bm[tid * 8 + j];
+    while (x) { const int b = __ffs(x) - 1; out[pos++] = (uint16_t)((tid * 8 + j) * 32 + b); x &= x - 1; }
+  }
+  if (tid == 255) a.nk[qs] = part[255];
+}
+
+// ------------------------------------------------------------------ shared-word counts: bit-sliced carry-save counting
+#define CSA(h, l, x, y, z) { const uint32_t u_ = (x) ^ (y); h = ((x) & (y)) | (u_ & (z)); l = u_ ^ (z); }
+static constexpr int HCL = 13;          // counts/8 < 8192
+
+__global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int ntiles)
+{
+  const int qs = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int tile = tile0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= tile0 + ntiles) return;
+  const int n = a.nk[qs];
+  const uint16_t *kl = a.klist + (size_t)qs * a.kcap;
+  const uint32_t *col = a.bits + (size_t)tile * 64 + lane;
+  const size_t stride = (size_t)a.stride;
+  uint32_t ones = 0, twos = 0, fours = 0;
+  uint32_t hc[HCL];
+#pragma unroll
+  for (int b = 0; b < HCL; b++) hc[b] = 0;
+  int nlev = 1;
+  while ((n >> 3) >> nlev) nlev++;
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint32_t x[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) x[t] = col[(size_t)kl[i + t] * stride];
+    uint32_t ta, tb, fa, fb, eights;
+    CSA(ta, ones, ones, x[0], x[1])
+    CSA(tb, ones, ones, x[2], x[3])
+    CSA(fa, twos, twos, ta, tb)
+    CSA(ta, ones, ones, x[4], x[5])
+    CSA(tb, ones, ones, x[6], x[7])
+    CSA(fb, twos, twos, ta, tb)
+    CSA(eights, fours, fours, fa, fb)
+    uint32_t carry = eights;
+#pragma unroll
+    for (int b = 0; b < HCL; b++) if (b < nlev) { const uint32_t t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
+  }
+  for (; i < n; i++) {
+    uint32_t carry = col[(size_t)kl[i] * stride], t_;
+    t_ = ones & carry; ones ^= carry; carry = t_;
+    t_ = twos & carry; twos ^= carry; carry = t_;
+    t_ = fours & carry; fours ^= carry; carry = t_;
+#pragma unroll
+    for (int b = 0; b < HCL; b++) if (b < nlev) { t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
+  }
+  uint16_t *out = a.cnt + (size_t)qs * a.cpitch + (size_t)tile * 2048 + lane * 32;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    uint32_t pk[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      uint32_t v2[2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int bit = g * 8 + h * 2 + e;
+        uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
+#pragma unroll
+        for (int b = 0; b < HCL; b++) if (b < nlev) v |= ((hc[b] >> bit) & 1u) << (3 + b);
+        v2[e] = v;
+      }
+      pk[h] = v2[0] | (v2[1] << 16);
+    }
+    *reinterpret_cast<uint4 *>(out + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  }
+}
+
+// ------------------------------------------------------------------ the candidate walk
+__global__ void k_cl_init(ClusterArgs a)
+{
+  const int qs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qs == 0) { *a.first_affected = a.nq; for (int r = 0; r < 32; r++) a.n_found[r] = 0; }
+  if (qs >= 2 * a.nq) return;
+  a.state[qs] = (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;
+  a.rejects[qs] = 0; a.cand[qs] = -1; a.acc_col[qs] = -1;
+  a.prev[qs] = ~0ULL; a.bound[qs] = 0ULL; a.acc_id[qs] = -1.0;
+}
+
+// next best candidate strictly below the last one tried
+__global__ __launch_bounds__(256) void k_cl_next(ClusterArgs a, int round)
+{
+  __shared__ u64 red[4];
+  __shared__ u64 bestk;
+  const int qs = blockIdx.x, tid = threadIdx.x;
+  if (a.state[qs] != 0) return;
+  const int n = a.nk[qs];
+  const uint32_t minm = n < 12 ? n : 12;
+  const u64 prev = a.prev[qs];
+  const uint16_t *cn = a.cnt + (size_t)qs * a.cpitch;
+  u64 best = 0; int bestc = -1;
+  for (int c = tid; c < a.C; c += 256) {
+    const uint32_t v = cn[c];
+    if (v >= minm) {
+      const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
+      if (key < prev && key > best) { best = key; bestc = c; }
+    }
+  }
+  u64 m = best;
+  for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(m, off); m = o > m ? o : m; }
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    u64 b = red[0];
+    for (int i = 1; i < 4; i++) b = red[i] > b ? red[i] : b;
+    bestk = b;
+    if (b == 0) { a.state[qs] = 3; a.cand[qs] = -1; }
+    else { a.curkey[qs] = b; atomicAdd(&a.n_found[round], 1); }
+  }
+  __syncthreads();
+  if (bestk != 0 && best == bestk) a.cand[qs] = bestc;
+}
+
+__device__ __forceinline__ i64 shfl_up64(i64 v)
+{
+  int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);
+  lo = __shfl_up(lo, 1); hi = __shfl_up(hi, 1);
+  return ((i64)hi << 32) | (i64)(uint32_t)lo;
+}
+
+// one wave = one (query strand, candidate centroid) alignment
+template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
+{
+  const int qs = blockIdx.x, lane = threadIdx.x;
+  if (a.state[qs] != 0) return;
+  const int col = a.cand[qs];
+  if (col < 0) return;
+  const int qi = qs >> 1, s = qs & 1;
+  const int64_t rq = a.order[a.f + qi], rt = a.cent_read[col];
+  const int Lq = a.rd.len[rq], Lt = a.rd.len[rt];
+  const uint32_t *wq = a.rd.words + a.rd.woff[rq];
+  const uint32_t *wt = a.rd.words + a.rd.woff[rt];
+  const int64_t eoq = a.rd.excoff[rq], eot = a.rd.excoff[rt];
+  const int nexq = (int)(a.rd.excoff[rq + 1] - eoq), next_ = (int)(a.rd.excoff[rt + 1] - eot);
+  i64 *scr = reinterpret_cast<i64 *>(a.scratch) + (size_t)qs * a.scratch_pitch * 2;
+  const int RB = 64 * S;
+  const int npass = (Lq + 1 + RB - 1) / RB;
+  i64 res = NEGV; bool have = false;
+
+  for (int pass = 0; pass < npass; pass++) {
+    const int i0 = pass * RB + lane * S;
+    uint32_t qm[S]; bool qu[S], tE[S];
+#pragma unroll
+    for (int r = 0; r < S; r++) {
+      const int i = i0 + r;
+      uint32_t m = 0;
+      if (i >= 1 && i <= Lq) {
+        const int x = i - 1, o = s ? Lq - 1 - x : x;
+        const uint32_t c2 = (wq[o >> 4] >> ((o & 15) * 2)) & 3u;
+        m = 1u << (s ? 3u - c2 : c2);
+      }
+      qm[r] = m; tE[r] = (i == 0 || i == Lq);
+    }
+    for (int e = 0; e < nexq; e++) {
+      const uint32_t ex = a.rd.exc[eoq + e];
+      const int pos = (int)(ex >> 4);
+      const int i = (s ? Lq - 1 - pos : pos) + 1;
+      const uint32_t m = s ? revmask4(mask4(ex & 15u)) : mask4(ex & 15u);
+#pragma unroll
+      for (int r = 0; r < S; r++) if (i == i0 + r) qm[r] = m;
+    }
+#pragma unroll
+    for (int r = 0; r < S; r++) qu[r] = unamb4(qm[r]);
+
+    i64 Hl[S], El[S];
+#pragma unroll
+    for (int r = 0; r < S; r++) { Hl[r] = NEGV; El[r] = NEGV; }
+    i64 diag_carry = NEGV, pubH = NEGV, pubF = NEGV;
+    uint32_t pubT = 0;
+    int te = 0;                                          // exception cursor of the target (lane 0's stream)
+    int next_exc = next_ > 0 ? (int)(a.rd.exc[eot] >> 4) : 0x7fffffff;
+    const int nsteps = Lt + 1 + 63;
+    for (int t = 0; t < nsteps; t++) {
+      i64 upH = shfl_up64(pubH), upF = shfl_up64(pubF);
+      uint32_t tm = __shfl_up(pubT, 1);
+      // the target symbol of column t enters at lane 0
+      uint32_t t0 = 0;
+      if (t >= 1 && t <= Lt) {
+        const int o = t - 1;
+        if (o == next_exc) {
+          t0 = mask4(a.rd.exc[eot + te] & 15u);
+          te++;
+          next_exc = te < next_ ? (int)(a.rd.exc[eot + te] >> 4) : 0x7fffffff;
+        } else t0 = 1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u);
+      }
+      const int j = t - lane;
+      if (lane == 0) {
+        tm = t0;
+        if (pass > 0 && j <= Lt) {
+          upH = __hip_atomic_load(&scr[2 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          upF = __hip_atomic_load(&scr[2 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        else { upH = NEGV; upF = NEGV; }
+      }
+      if (j >= 0 && j <= Lt) {
+        const bool tF = (j == 0 || j == Lt);
+        const i64 goF = tF ? GOT : GOI, geF = tF ? GET : GEI;
+        const bool tu = unamb4(tm);
+        i64 aboveH = upH, aboveF = upF, dg = diag_carry;
+#pragma unroll
+        for (int r = 0; r < S; r++) {
+          const i64 goE = tE[r] ? GOT : GOI, geE = tE[r] ? GET : GEI;
+          const i64 E = max64(Hl[r] + goE, El[r] + geE);
+          const i64 F = max64(aboveH + goF, aboveF + geF);
+          const i64 D = (qu[r] && tu) ? (qm[r] == tm ? D_MATCH : D_MISMATCH) : ((qm[r] & tm) ? D_AMB_MATCH : D_AMB_MISMATCH);
+          i64 Hn = max64(max64(dg + D, E), F);
+          if (i0 + r == 0 && j == 0) Hn = 0;
+          dg = Hl[r];
+          Hl[r] = Hn; El[r] = E;
+          aboveH = Hn; aboveF = F;
+          if (i0 + r == Lq && j == Lt) { res = Hn; have = true; }
+        }
+        pubH = aboveH; pubF = aboveF; pubT = tm;
+        diag_carry = upH;
+        if (lane == 63 && pass + 1 < npass) {
+          __hip_atomic_store(&scr[2 * j], aboveH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&scr[2 * j + 1], aboveF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (pass + 1 < npass) __threadfence();
+  }
+  if (have) {
+    const i64 score = (res + (1LL << (SH_S - 1))) >> SH_S;
+    const i64 low = res - score * ONE_S;
+    const i64 matches = (low + (1LL << (SH_M - 1))) >> SH_M;
+    const i64 cols = matches * ONE_M - low;
+    const double pid = cols > 0 ? 100.0 * (double)matches / (double)cols : 0.0;
+    const u64 key = a.curkey[qs];
+    a.prev[qs] = key;
+    if (pid >= a.thr) { a.state[qs] = 1; a.acc_col[qs] = col; a.acc_id[qs] = pid; a.bound[qs] = key; }
+    else {
+      const int rj = a.rejects[qs] + 1;
+      a.rejects[qs] = rj;
+      if (rj >= 32) { a.state[qs] = 2; a.bound[qs] = key; }
+    }
+    atomicAdd(a.n_align, 1ULL);
+  }
+}
+
+// ------------------------------------------------------------------ outcomes, new centroids, validation
+__global__ void k_cl_outcome(ClusterArgs a)
+{
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= a.nq) return;
+  const bool p = a.state[2 * qi] == 1, m = a.state[2 * qi + 1] == 1;
+  const bool hit = p || m;
+  const bool minus = m && (!p || a.acc_id[2 * qi + 1] > a.acc_id[2 * qi]);
+  const int k = 2 * qi + (minus ? 1 : 0);
+  const int pos = a.f + qi;
+  a.res_col[pos] = hit ? a.acc_col[k] : -1;
+  a.res_strand[pos] = (int8_t)(hit && minus ? -1 : 1);
+  a.res_id[pos] = hit ? a.acc_id[k] : -1.0;
+  a.is_new[qi] = hit ? 0 : 1;
+  if (qi == 0) a.is_new[a.nq] = 0;
+}
+
+// set (or clear) the column of each new centroid; one wave per window query
+__global__ __launch_bounds__(64) void k_cl_columns(ClusterArgs a, int clear, int qi_from)
+{
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  if (qi < qi_from || !a.is_new[qi]) return;
+  const int col = a.C + a.new_rank[qi];
+  const int qs = 2 * qi;
+  const int n = a.nk[qs];
+  const uint16_t *kl = a.klist + (size_t)qs * a.kcap;
+  const uint32_t bit = 1u << (col & 31);
+  uint32_t *base = a.bits + (col >> 5);
+  for (int i = lane; i < n; i += 64) {
+    uint32_t *p = base + (size_t)kl[i] * (size_t)a.stride;
+    if (clear) atomicAnd(p, ~bit); else atomicOr(p, bit);
+  }
+  if (lane == 0 && !clear) {
+    const int64_t r = a.order[a.f + qi];
+    a.cent_len[col] = a.rd.len[r]; a.cent_pos[col] = a.f + qi; a.cent_read[col] = (int32_t)r;
+    a.res_col[a.f + qi] = col;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
+{
+  __shared__ int flag;
+  const int qs = blockIdx.x, tid = threadIdx.x;
+  const int n = a.nk[qs];
+  if (n == 0) return;
+  const int n_new = a.new_rank[a.nq];
+  if (n_new == 0) return;
+  if (tid == 0) flag = 0;
+  __syncthreads();
+  const int pos = a.f + (qs >> 1);
+  const uint32_t minm = n < 12 ? n : 12;
+  const u64 bound = a.state[qs] == 3 ? 0ULL : a.bound[qs];
+  const uint16_t *cn = a.cnt + (size_t)qs * a.cpitch;
+  for (int c = a.C + tid; c < a.C + n_new; c += 256) {
+    if (a.cent_pos[c] >= pos) break;
+    const uint32_t v = cn[c];
+    if (v >= minm && cand_key(v, a.cent_len[c], a.cent_pos[c]) > bound) flag = 1;
+  }
+  __syncthreads();
+  if (tid == 0 && flag) atomicMin(a.first_affected, qs >> 1);
+}
+
+__global__ void k_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
+                              const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nk) return;
+  const int32_t r = order[p];
+  const int32_t rep = cent_read[res_col[p]];
+  rep_of[r] = rep; strand[r] = res_strand[p]; pct[r] = res_id[p]; is_seed[r] = rep == r ? 1 : 0;
+}
+
+__global__ void k_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 65536 * sstride) return;
+  dst[(i / sstride) * dstride + (i % sstride)] = src[i];
+}
+
+// ------------------------------------------------------------------ launchers
+void launch_cl_kmers(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_kmers, dim3(2 * a.nq), dim3(256), 0, st, a); }
+void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st)
+{
+  if (ntiles <= 0) return;
+  hipLaunchKernelGGL(k_cl_count, dim3((ntiles + 3) / 4, 2 * a.nq), dim3(256), 0, st, a, tile0, ntiles);
+}
+void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
+void launch_cl_round(const ClusterArgs &a, int round, int rows_per_lane, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cl_next, dim3(2 * a.nq), dim3(256), 0, st, a, round);
+  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(2 * a.nq), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_cl_align<10>, dim3(2 * a.nq), dim3(64), 0, st, a);
+}
+void launch_cl_outcome(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_outcome, dim3((a.nq + 255) / 256), dim3(256), 0, st, a); }
+void launch_cl_columns(const ClusterArgs &a, int clear, int qi_from, hipStream_t st) { hipLaunchKernelGGL(k_cl_columns, dim3(a.nq), dim3(64), 0, st, a, clear, qi_from); }
+void launch_cl_affected(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a); }
+void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
+                        const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st)
+{
+  if (nk > 0) hipLaunchKernelGGL(k_cl_finalize, dim3((nk + 255) / 256), dim3(256), 0, st, nk, order, res_col, res_strand, res_id, cent_read, rep_of, strand, pct, is_seed);
+}
+void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride, hipStream_t st)
+{
+  const int64_t n = 65536 * sstride;
+  hipLaunchKernelGGL(k_cl_relayout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, sstride, dst, dstride);
+}
+
+}  // namespace itsx

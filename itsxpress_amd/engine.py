@@ -130,6 +130,14 @@ class Engine:
         self.n_unique = n.value
         return n.value
 
+    def get_cluster(self):
+        """After cluster(id < 1): (pct_id float64[n_reads] (-1 for centroids / dropped), order int64[kept])."""
+        pct = np.zeros(self.n_reads, np.float64)
+        order = np.zeros(max(1, self.n_reads), np.int64)
+        n = C.c_int64(0)
+        self._chk(self.L.itsx_get_cluster(self.h, pct.ctypes.data, order.ctypes.data, C.byref(n)))
+        return pct, order[:n.value]
+
     def get_derep(self):
         rep_of = np.zeros(self.n_reads, np.int64)
         strand = np.zeros(self.n_reads, np.int8)

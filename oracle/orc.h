@@ -15,6 +15,8 @@
  *     Forward -> Backward -> posterior domain definition -> per-envelope
  *     Forward + null2 -> thresholds, following HMMER's published algorithm and
  *     its SSE implementation's operation order (4-lane striping).
+ *   - vsearch --cluster_size ... --id X --strand both itsxpress/SeqSample.py:147-162
+ *     (orc_cluster.c; parity unpinned)
  *   - ItsPosition.parse/_score/get_position        itsxpress/SeqSample.py:400-498
  *   - Dedup.parse                                  itsxpress/SeqSample.py:542-562
  *
@@ -151,6 +153,13 @@ uint64_t orc_xxh64(const void *data, int64_t len, uint64_t seed);
 /* ---- deterministic math, exported for tests ---- */
 double orc_det_log(double x);
 double orc_det_exp(double x);
+
+/* ---- greedy centroid clustering (vsearch --cluster_size restated; orc_cluster.c; PARITY UNPINNED) ---- */
+void    orc_align_identity(const uint8_t *qmask, int Lq, const uint8_t *tmask, int Lt,
+                           int64_t *ret_score, int64_t *ret_matches, int64_t *ret_cols);
+int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, const char *labels, const int64_t *label_offsets,
+                    double id, int strand_both, int minlen, int64_t *rep_of, int8_t *strand, double *pct_id, int64_t *order,
+                    int64_t *stats);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,11 @@ def lib():
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_derep.restype = C.c_int64
     L.orc_derep.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_align_identity.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_align_identity.restype = None
+    L.orc_cluster.restype = C.c_int64
+    L.orc_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_xxh64.restype = C.c_uint64
     L.orc_xxh64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64]
     L.orc_det_log.restype = C.c_double
@@ -212,3 +217,37 @@ def derep(codes, offsets, strand_both=True, minlen=32):
 
 def xxh64(data: bytes, seed=0):
     return int(lib().orc_xxh64(data, len(data), seed))
+
+
+_MASK4 = np.array([1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15], np.uint8)
+
+
+def align_identity(q: str, t: str):
+    """(score, matches, counted columns) of the oracle's global alignment (orc_cluster.c)."""
+    cq, _ = digitize([q])
+    ct, _ = digitize([t])
+    mq = np.ascontiguousarray(_MASK4[cq[:len(q)]])
+    mt = np.ascontiguousarray(_MASK4[ct[:len(t)]])
+    out = (C.c_int64 * 3)()
+    lib().orc_align_identity(mq.ctypes.data, len(q), mt.ctypes.data, len(t), C.byref(out, 0), C.byref(out, 8), C.byref(out, 16))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def cluster(codes, offsets, labels=None, cluster_id=0.995, strand_both=True, minlen=32):
+    """Greedy clustering oracle: returns dict(rep_of, strand, pct_id, order, n_alignments, n_centroids)."""
+    n = len(offsets) - 1
+    rep_of = np.zeros(n, np.int64)
+    strand = np.zeros(n, np.int8)
+    pct = np.zeros(n, np.float64)
+    order = np.zeros(max(1, n), np.int64)
+    stats = np.zeros(2, np.int64)
+    lab = loff = None
+    if labels is not None:
+        enc = [x.encode() for x in labels]
+        loff = np.zeros(n + 1, np.int64)
+        loff[1:] = np.cumsum([len(x) for x in enc])
+        lab = b"".join(enc) + b"\0"
+    nk = lib().orc_cluster(codes.ctypes.data, offsets.ctypes.data, n, lab, loff.ctypes.data if loff is not None else None,
+                           float(cluster_id), int(strand_both), minlen, rep_of.ctypes.data, strand.ctypes.data,
+                           pct.ctypes.data, order.ctypes.data, stats.ctypes.data)
+    return dict(rep_of=rep_of, strand=strand, pct_id=pct, order=order[:nk], n_alignments=int(stats[0]), n_centroids=int(stats[1]))

@@ -1,0 +1,154 @@
+"""GPU parity tests for row a2 (greedy clustering, vsearch --cluster_size restated): the HIP engine through the
+C ABI against oracle/orc_cluster.c.  Bar: identical cluster maps, strands, processing order and identities
+(the identity is a ratio of two integers: compared as exact doubles).  The speculative-window scheme must give
+the sequential answer for every window size.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import synth
+
+pytestmark = pytest.mark.gpu
+
+_RC = str.maketrans("ACGTN", "TGCAN")
+
+
+def _noisy_library(seed, n_reads, n_tmpl, length, max_err=6, indel=True, n_rate=0.002, rc_rate=0.3, shared_flank=60):
+    """templates share a conserved flank (like 5.8S/LSU in amplicons); reads carry substitutions, a few indels, N"""
+    rng = np.random.default_rng(seed)
+    acgt = np.array(list("ACGT"))
+    flank_l = "".join(acgt[rng.integers(0, 4, shared_flank)])
+    flank_r = "".join(acgt[rng.integers(0, 4, shared_flank)])
+    lens = rng.integers(length[0], length[1] + 1, n_tmpl)
+    tmpl = [flank_l + "".join(acgt[rng.integers(0, 4, int(L) - 2 * shared_flank)]) + flank_r for L in lens]
+    # a few templates that are near copies of others (clusters that compete)
+    for t in range(1, n_tmpl, 5):
+        s = list(tmpl[t - 1])
+        for _ in range(int(rng.integers(1, 8))):
+            s[int(rng.integers(0, len(s)))] = str(acgt[rng.integers(0, 4)])
+        tmpl[t] = "".join(s)
+    reads, names = [], []
+    for i in range(n_reads):
+        s = list(tmpl[int(rng.integers(0, n_tmpl))])
+        for _ in range(int(rng.integers(0, max_err + 1)) if rng.random() < 0.6 else 0):
+            k = int(rng.integers(0, len(s)))
+            op = rng.random()
+            if indel and op < 0.15:
+                del s[k]
+            elif indel and op < 0.3:
+                s.insert(k, str(acgt[rng.integers(0, 4)]))
+            else:
+                s[k] = str(acgt[rng.integers(0, 4)])
+        if rng.random() < 0.1:                       # truncated copies: terminal gaps are not counted
+            cut = int(rng.integers(1, 12))
+            s = s[cut:] if rng.random() < 0.5 else s[:-cut]
+        s = "".join(s)
+        if n_rate:
+            s = "".join("N" if rng.random() < n_rate else c for c in s)
+        if rng.random() < rc_rate:
+            s = s[::-1].translate(_RC)
+        reads.append(s)
+        names.append("M0:%06d:%04d" % (int(rng.integers(0, 10 ** 6)), i % 977))
+    return reads, names
+
+
+def _compare(engine, reads, names, cid, strand_both=True):
+    engine.set_reads(reads, names)
+    engine.cluster(cid, strand_both=strand_both)
+    rep_of, strand, uniq_of = engine.get_derep()
+    pct, order = engine.get_cluster()
+    codes, off = orc.digitize(reads)
+    o = orc.cluster(codes, off, names, cid, strand_both=strand_both)
+    assert np.array_equal(order, o["order"])
+    assert np.array_equal(rep_of, o["rep_of"])
+    assert np.array_equal(strand, o["strand"])
+    assert np.array_equal(pct.view(np.uint64), o["pct_id"].view(np.uint64))
+    st = engine.stats()
+    assert st["n_unique"] == o["n_centroids"]
+    assert st["cl_alignments"] >= o["n_alignments"]          # speculation may redo alignments, never skips one
+    return o, st
+
+
+@pytest.mark.parametrize("cid", [0.97, 0.99, 0.995])
+def test_cluster_matches_oracle(engine, cid):
+    reads, names = _noisy_library(11, 3000, 60, (280, 310))
+    o, st = _compare(engine, reads, names, cid)
+    assert 60 <= o["n_centroids"] < 3000 and (o["strand"] < 0).sum() > 100
+
+
+@pytest.mark.parametrize("window", ["1", "7", "64", "4096"])
+def test_cluster_is_independent_of_the_window(engine, window, monkeypatch):
+    monkeypatch.setenv("ITSX_CL_WINDOW", window)
+    reads, names = _noisy_library(12, 700, 25, (120, 160), shared_flank=30)
+    _compare(engine, reads, names, 0.98)
+
+
+def test_cluster_plus_strand_only_and_no_names(engine):
+    reads, names = _noisy_library(13, 1200, 30, (200, 240))
+    _compare(engine, reads, names, 0.99, strand_both=False)
+    _compare(engine, reads, None, 0.99)
+
+
+def test_cluster_multipass_alignment(engine, monkeypatch):
+    # 5 rows per lane cover 320 DP rows: 400-base reads need two passes over the boundary-row scratch
+    monkeypatch.setenv("ITSX_CL_ROWS", "5")
+    reads, names = _noisy_library(14, 500, 12, (380, 420))
+    _compare(engine, reads, names, 0.985)
+    monkeypatch.delenv("ITSX_CL_ROWS")
+    reads, names = _noisy_library(15, 300, 8, (650, 700))
+    _compare(engine, reads, names, 0.99)
+
+
+def test_cluster_edge_cases(engine):
+    # short reads vanish; a read of only N has no words and becomes its own centroid; duplicates join at 100 %
+    base = "ACGTTGCAAGCTTAGGCTAACGGTCAGTCCATGGATCAGGCTTAAGCCGGTATCGATTACGGCAT" * 3
+    reads = [base, base, base[:20], "N" * 40, base[::-1].translate(_RC), base[:100] + "A" + base[101:], "N" * 40]
+    names = ["r%d" % i for i in range(len(reads))]
+    o, _ = _compare(engine, reads, names, 0.99)
+    assert o["rep_of"].tolist() == [0, 0, -1, 3, 0, 0, 6] and o["strand"][4] == -1
+    assert o["pct_id"][1] == 100.0 and o["pct_id"][5] == 100.0 * (len(base) - 1) / len(base)
+    # empty input and nothing kept
+    engine.set_reads([], [])
+    assert engine.cluster(0.99) == 0
+    engine.set_reads(["ACGT"], ["a"])
+    assert engine.cluster(0.99) == 0
+
+
+def test_cluster_then_search_and_files(engine, mini_hmm_text, tmp_path):
+    """SeqSample.cluster -> uc.txt / rep.fa -> Dedup.parse semantics, then the HMM stages run on the centroids."""
+    blob, offs = synth.make_reads(mini_hmm_text, 1500, seed=5, sub_rate=0.004)
+    reads = synth.to_strings(blob, offs)
+    names = ["q%05d" % ((i * 7919) % 100000) for i in range(len(reads))]
+    engine.load_profiles(text=mini_hmm_text)
+    engine.set_reads(reads, names)
+    nuniq = engine.derep()
+    ncl = engine.cluster(0.99)
+    assert 0 < ncl < nuniq
+    codes, off = orc.digitize(reads)
+    o = orc.cluster(codes, off, names, 0.99)
+    uc = str(tmp_path / "uc.txt")
+    rep = str(tmp_path / "rep.fa")
+    engine.write_uc(uc)
+    engine.write_rep_fasta(rep)
+    match = {}
+    rows = [ln.rstrip("\n").split("\t") for ln in open(uc)]
+    for ll in rows:                                   # Dedup.parse (itsxpress/SeqSample.py:542-562)
+        if ll[0] == "S":
+            match[ll[8]] = ll[8]
+        elif ll[0] == "H":
+            match[ll[8]] = ll[9]
+    assert match == {names[i]: names[int(o["rep_of"][i])] for i in range(len(reads)) if o["rep_of"][i] >= 0}
+    assert [ll[8] for ll in rows if ll[0] in "SH"] == [names[i] for i in o["order"]]
+    assert sum(ll[0] == "C" for ll in rows) == ncl
+    heads = [ln[1:].strip() for ln in open(rep) if ln[0] == ">"]
+    assert heads == [names[i] for i in o["order"] if o["rep_of"][i] == i]
+    # the centroids are what gets searched, and every read inherits its centroid's coordinates
+    engine.search()
+    engine.finalize()
+    start, stop, tlen, ind = engine.trim_coords("3_", "4_")
+    rs, re_, rt, _ = engine.rep_coords("3_", "4_")
+    _, _, uniq_of = engine.get_derep()
+    assert np.array_equal(start, rs[uniq_of]) and np.array_equal(stop, re_[uniq_of]) and (start >= 0).sum() > 1000

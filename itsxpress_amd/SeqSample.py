@@ -77,7 +77,7 @@ class SeqSample:
     # -- a2 --------------------------------------------------------------------------
     def cluster(self, threads: Union[int, str], cluster_id: float = 0.995) -> None:
         """Replaces `vsearch --cluster_size ... --id X --strand both` (SeqSample.py:133-176): greedy centroid
-        clustering on the GPU (k_cluster.hip; oracle/orc_cluster.c restates the procedure, parity unpinned).
+        clustering on the GPU (k_cluster.hip; the test oracle restates the procedure, parity unpinned).
         cluster_id == 1.0 is exact dereplication, as in main.py:534-537."""
         try:
             self.uc_file = os.path.join(self.tempdir, "uc.txt")

@@ -623,19 +623,20 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
       return c < 0 || (c == 0 && a < b);
     });
   const int32_t nk = (int32_t)ord.size();
-  int Bmax = 4096;
-  if (const char *e = getenv("ITSX_CL_WINDOW")) Bmax = std::max(1, atoi(e));
+  int Bmax = 4096;                                          // k_cl_resolve keeps the window's flags in LDS
+  if (const char *e = getenv("ITSX_CL_WINDOW")) Bmax = std::min(4096, std::max(1, atoi(e)));
   int rows_per_lane = (Lmax + 1 <= 320) ? 5 : 10;
   if (const char *e = getenv("ITSX_CL_ROWS")) rows_per_lane = atoi(e) <= 5 ? 5 : 10;
   const bool multipass = Lmax + 1 > 64 * rows_per_lane;
   const int32_t scratch_pitch = Lmax + 1;
-  if (multipass) while (Bmax > 64 && 32LL * Bmax * scratch_pitch > (2LL << 30)) Bmax /= 2;
+  if (multipass) while (Bmax > 16 && 2LL * Bmax * 32 * scratch_pitch * 16 > (4LL << 30)) Bmax /= 2;
   const int32_t kcap = std::max(8, ((Lmax - 7 + 7) / 8) * 8);
   const int64_t cnt_budget = 8LL << 30;
 
-  DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, cand, acc_col, n_found, is_new, new_rank, first_aff, scan_tmp;
-  DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct;
-  DBuf<uint16_t> klist, cnt; DBuf<unsigned long long> prev, bound, curkey, scratch, n_align;
+  DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, acc_col, is_new, new_rank, scan_tmp, xlist, xn, hard, dbg;
+  DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout;
+  DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct, selpid, wpid, xpid;
+  DBuf<uint16_t> klist, cnt; DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
   DBuf<uint32_t> bitsA, bitsB;
   DBuf<uint32_t> *bits = &bitsA, *bits_other = &bitsB;
   HIPCHK(upload(d_order, ord, ctx->st));
@@ -643,11 +644,15 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(cent_len.alloc(ccap)); HIPCHK(cent_pos.alloc(ccap)); HIPCHK(cent_read.alloc(ccap));
   HIPCHK(res_col.alloc((size_t)nk + 1)); HIPCHK(res_strand.alloc((size_t)nk + 1)); HIPCHK(res_id.alloc((size_t)nk + 1));
   const size_t nqs = 2 * (size_t)Bmax;
-  HIPCHK(klist.alloc(nqs * kcap)); HIPCHK(knk.alloc(nqs)); HIPCHK(state.alloc(nqs)); HIPCHK(rejects.alloc(nqs)); HIPCHK(cand.alloc(nqs));
-  HIPCHK(acc_col.alloc(nqs)); HIPCHK(prev.alloc(nqs)); HIPCHK(bound.alloc(nqs)); HIPCHK(curkey.alloc(nqs)); HIPCHK(acc_id.alloc(nqs));
-  HIPCHK(n_found.alloc(32)); HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(first_aff.alloc(1));
+  HIPCHK(klist.alloc(nqs * kcap)); HIPCHK(knk.alloc(nqs)); HIPCHK(state.alloc(nqs)); HIPCHK(rejects.alloc(nqs));
+  HIPCHK(acc_col.alloc(nqs)); HIPCHK(prev.alloc(nqs)); HIPCHK(bound.alloc(nqs)); HIPCHK(acc_id.alloc(nqs));
+  HIPCHK(sel.alloc(nqs * 32)); HIPCHK(selm.alloc(nqs)); HIPCHK(sel_short.alloc(nqs)); HIPCHK(selkey.alloc(nqs * 32)); HIPCHK(selpid.alloc(nqs * 32));
+  HIPCHK(wn.alloc(nqs)); HIPCHK(wcol.alloc(nqs * 32)); HIPCHK(wkey.alloc(nqs * 32)); HIPCHK(wpid.alloc(nqs * 32));
+  HIPCHK(xlist.alloc(nqs * 32)); HIPCHK(xn.alloc(nqs)); HIPCHK(hard.alloc(nqs)); HIPCHK(xkey.alloc(nqs * 32)); HIPCHK(xpid.alloc(nqs * 32));
+  HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(newq.alloc((size_t)Bmax + 1)); HIPCHK(rm.alloc((size_t)Bmax + 1));
+  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4));
   HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(Bmax + 1))); HIPCHK(n_align.alloc(1));
-  HIPCHK(scratch.alloc(multipass ? nqs * (size_t)scratch_pitch * 2 : 2));
+  HIPCHK(scratch.alloc(multipass ? nqs * 32 * (size_t)scratch_pitch * 2 : 2));
   HIPCHK(hipMemsetAsync(n_align.p, 0, sizeof(unsigned long long), ctx->st));
   int64_t capC = 2048;
   while (capC < std::min<int64_t>(nk, 262144)) capC *= 2;
@@ -658,15 +663,19 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.rd = ctx->rd; a.order = d_order.p; a.strand_both = strand_both ? 1 : 0;
   a.cent_len = cent_len.p; a.cent_pos = cent_pos.p; a.cent_read = cent_read.p;
   a.klist = klist.p; a.kcap = kcap; a.nk = knk.p;
-  a.state = state.p; a.rejects = rejects.p; a.cand = cand.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.curkey = curkey.p;
-  a.acc_id = acc_id.p; a.n_found = n_found.p; a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
-  a.is_new = is_new.p; a.new_rank = new_rank.p; a.first_affected = first_aff.p; a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
+  a.state = state.p; a.rejects = rejects.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.acc_id = acc_id.p;
+  a.sel = sel.p; a.selm = selm.p; a.sel_short = sel_short.p; a.selkey = selkey.p; a.selpid = selpid.p;
+  a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
+  a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
+  a.is_new = is_new.p; a.new_rank = new_rank.p; a.newq = newq.p; a.rm = rm.p;
+  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p;
+  a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
   a.thr = 100.0 * id; a.n_align = n_align.p;
 
-  int32_t f = 0, C = 0;
+  int32_t f = 0, C = 0, ncent = 0;
   int B = std::min(Bmax, 256);
   int64_t windows = 0, cuts = 0;
-  std::vector<int32_t> h_new((size_t)Bmax + 1);
+  const bool debug = getenv("ITSX_CL_DEBUG") != nullptr;
   while (f < nk) {
     int nq = std::min<int32_t>(B, nk - f);
     auto pitch_for = [&](int q) { return ((((int64_t)C + q - 1) >> 11) + 1) * 2048; };
@@ -687,30 +696,31 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
     launch_cl_kmers(a, ctx->st);
     launch_cl_count(a, 0, (C + 2047) >> 11, ctx->st);
     launch_cl_init(a, ctx->st);
-    for (int round = 0; round < 32 && C > 0; round++) {
-      launch_cl_round(a, round, rows_per_lane, ctx->st);
-      if (round == 0 || round == 1 || round == 3 || round == 7 || round == 15) {
-        int32_t found = 0;
-        HIPCHK(hipMemcpyAsync(&found, n_found.p + round, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipStreamSynchronize(ctx->st));
-        if (found == 0) break;
-      }
-    }
+    if (C > 0) launch_cl_walk(a, rows_per_lane, ctx->st);
     launch_cl_outcome(a, ctx->st);
     launch_exclusive_scan(is_new.p, new_rank.p, nq + 1, scan_tmp.p, ctx->st);
-    launch_cl_columns(a, 0, 0, ctx->st);
+    launch_cl_columns(a, 0, ctx->st);
     const int tile0 = C >> 11;
     launch_cl_count(a, tile0, (int)((((int64_t)C + nq - 1) >> 11) - tile0 + 1), ctx->st);
-    launch_cl_affected(a, ctx->st);
-    int32_t cut = nq;
-    HIPCHK(hipMemcpyAsync(&cut, first_aff.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(h_new.data(), is_new.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+    launch_cl_validate(a, rows_per_lane, ctx->st);
+    launch_cl_columns(a, 1, ctx->st);                       // roll back the speculative centroids that did not survive
+    int32_t wo[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(wo, wout.p, sizeof(wo), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
+    const int32_t cut = wo[0];
+    if (debug) {
+      int32_t d[4] = {0, 0, 0, 0};
+      (void)hipMemcpy(d, dbg.p, sizeof(d), hipMemcpyDeviceToHost);
+      std::vector<int32_t> hs(2 * (size_t)nq), hw(2 * (size_t)nq);
+      (void)hipMemcpy(hs.data(), state.p, hs.size() * 4, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(hw.data(), wn.p, hw.size() * 4, hipMemcpyDeviceToHost);
+      long sc[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0}, acc1 = 0;
+      for (size_t q = 0; q < hs.size(); q++) { sc[hs[q] & 3]++; sw[hs[q] & 3] += hw[q]; acc1 += hs[q] == 1 && hw[q] == 1; }
+      fprintf(stderr, "[cluster] f=%d nq=%d C=%d cut=%d cols=%d new=%d | hard=%d budget=%d joined_new=%d xaligns=%d | accept %ld (first try %ld, walk %ld) rej32 %ld exhausted %ld (walk %ld)\n",
+              f, nq, C, cut, wo[1], wo[2], d[0], d[1], d[2], d[3], sc[1], acc1, sw[1], sc[2], sc[3], sw[3]);
+    }
     if (cut < 1 || cut > nq) SET_ERR(ctx, ITSX_E_DEVICE, "clustering window validation returned an impossible cut");
-    int32_t n_new = 0, n_keep = 0;
-    for (int q = 0; q < nq; q++) { n_new += h_new[q]; if (q < cut) n_keep += h_new[q]; }
-    if (n_keep < n_new) launch_cl_columns(a, 1, cut, ctx->st);         // roll the speculative centroids after the cut back
-    C += n_keep; f += cut; windows++; cuts += cut < nq;
+    C += wo[1]; ncent += wo[2]; f += cut; windows++; cuts += cut < nq;
     B = cut == nq ? std::min(Bmax, std::max(B, nq) * 2) : std::min(Bmax, std::max(64, 2 * cut));
   }
 
@@ -734,7 +744,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   ctx->stats.n_unique = ctx->U; ctx->stats.n_dropped_short = n - nk;
   ctx->stats.cl_windows = windows; ctx->stats.cl_cuts = cuts; ctx->stats.cl_alignments = (int64_t)naln;
   ctx->have_derep = true; ctx->have_search = ctx->have_final = false; ctx->clustered = true;
-  if (ctx->U != C) SET_ERR(ctx, ITSX_E_DEVICE, "clustering bookkeeping mismatch (centroids " + std::to_string(C) + " vs uniques " + std::to_string(ctx->U) + ")");
+  if (ctx->U != ncent) SET_ERR(ctx, ITSX_E_DEVICE, "clustering bookkeeping mismatch (centroids " + std::to_string(ncent) + " vs uniques " + std::to_string(ctx->U) + ")");
   if (n_unique) *n_unique = ctx->U;
   return ITSX_OK;
 }

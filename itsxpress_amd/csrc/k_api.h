@@ -45,24 +45,28 @@ struct ClusterArgs {
   int32_t C;                    // centroids at the window start
   uint16_t *klist; int32_t kcap; int32_t *nk;  // distinct words of each (query, strand): [2 nq][kcap], [2 nq]
   uint16_t *cnt; int64_t cpitch;               // shared-word counts [2 nq][cpitch]
-  int32_t *state, *rejects, *cand, *acc_col;   // walk state per (query, strand): 0 active 1 accepted 2 32 rejects 3 exhausted
-  unsigned long long *prev, *bound, *curkey;
+  int32_t *state, *rejects, *acc_col;          // walk state per (query, strand): 0 active 1 accepted 2 32 rejects 3 exhausted
+  unsigned long long *prev, *bound;            // rank key of the last candidate tried / of the point where the walk stopped
   double *acc_id;
-  int32_t *n_found;             // [32] candidates found per round
+  int32_t *sel, *selm, *sel_short; unsigned long long *selkey; double *selpid;   // candidates of the current round [2 nq][32]
+  int32_t *wn, *wcol; unsigned long long *wkey; double *wpid;                    // the recorded walk [2 nq][32]
   int32_t *res_col; int8_t *res_strand; double *res_id;   // outcome by processing position
   int32_t *is_new, *new_rank;   // [nq+1]
-  int32_t *first_affected;      // [1]
-  unsigned long long *scratch; int32_t scratch_pitch;     // alignment boundary rows [2 nq][pitch][2]
+  int32_t *newq, *rm;           // [nq] window index of each speculative centroid; columns to clear after validation
+  int32_t *xlist, *xn, *hard; unsigned long long *xkey; double *xpid;            // speculative centroids entering a walk [2 nq][32]
+  int32_t *wout;                // [3] cut, columns consumed, true new centroids
+  int32_t *dbg;                 // [4] hard cuts, member->centroid cuts, centroid->member resolutions, validation alignments
+  unsigned long long *scratch; int32_t scratch_pitch;     // alignment boundary rows [2 nq * 32][pitch][2]
   double thr;                   // 100 * id
   unsigned long long *n_align;
 };
 void launch_cl_kmers(const ClusterArgs &a, hipStream_t st);
 void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st);
 void launch_cl_init(const ClusterArgs &a, hipStream_t st);
-void launch_cl_round(const ClusterArgs &a, int round, int rows_per_lane, hipStream_t st);
+void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st);
 void launch_cl_outcome(const ClusterArgs &a, hipStream_t st);
-void launch_cl_columns(const ClusterArgs &a, int clear, int qi_from, hipStream_t st);
-void launch_cl_affected(const ClusterArgs &a, hipStream_t st);
+void launch_cl_columns(const ClusterArgs &a, int clear, hipStream_t st);
+void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st);
 void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
                         const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st);
 void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride, hipStream_t st);

@@ -1,7 +1,7 @@
 // k_cluster.hip -- row a2 of the path: greedy centroid clustering on the device.
 //
 // Replaces `vsearch --cluster_size IN --centroids rep.fa --uc uc.txt --strand both --id X`
-// (reference call site itsxpress/SeqSample.py:147-162).  The procedure is the one oracle/orc_cluster.c
+// (reference call site itsxpress/SeqSample.py:147-162).  The procedure is the one the CPU test oracle
 // restates (PARITY UNPINNED against a real vsearch: no fixture, no binary): queries in label order; per
 // strand the distinct unambiguous 8-mers of the query are counted against every centroid; candidates with
 // >= min(12, #words) shared words are tried in (shared words desc, length asc, position asc) order by a
@@ -178,15 +178,15 @@ __global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int 
 __global__ void k_cl_init(ClusterArgs a)
 {
   const int qs = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qs == 0) { *a.first_affected = a.nq; for (int r = 0; r < 32; r++) a.n_found[r] = 0; }
+  if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; }
   if (qs >= 2 * a.nq) return;
   a.state[qs] = (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;
-  a.rejects[qs] = 0; a.cand[qs] = -1; a.acc_col[qs] = -1;
-  a.prev[qs] = ~0ULL; a.bound[qs] = 0ULL; a.acc_id[qs] = -1.0;
+  a.rejects[qs] = 0; a.acc_col[qs] = -1; a.wn[qs] = 0; a.selm[qs] = 0; a.sel_short[qs] = 0;
+  a.prev[qs] = ~0ULL; a.bound[qs] = 0ULL; a.acc_id[qs] = -1.0; a.xn[qs] = 0; a.hard[qs] = 0;
 }
 
-// next best candidate strictly below the last one tried
-__global__ __launch_bounds__(256) void k_cl_next(ClusterArgs a, int round)
+// the next (up to kmax, within the reject budget) candidates strictly below the last one tried, in rank order
+__global__ __launch_bounds__(256) void k_cl_select(ClusterArgs a, int kmax)
 {
   __shared__ u64 red[4];
   __shared__ u64 bestk;
@@ -194,29 +194,38 @@ __global__ __launch_bounds__(256) void k_cl_next(ClusterArgs a, int round)
   if (a.state[qs] != 0) return;
   const int n = a.nk[qs];
   const uint32_t minm = n < 12 ? n : 12;
-  const u64 prev = a.prev[qs];
+  u64 prev = a.prev[qs];
   const uint16_t *cn = a.cnt + (size_t)qs * a.cpitch;
-  u64 best = 0; int bestc = -1;
-  for (int c = tid; c < a.C; c += 256) {
-    const uint32_t v = cn[c];
-    if (v >= minm) {
-      const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
-      if (key < prev && key > best) { best = key; bestc = c; }
+  int need = 32 - a.rejects[qs];
+  need = need < kmax ? need : kmax;
+  int m = 0;
+  for (; m < need; m++) {
+    u64 best = 0; int bestc = -1;
+    for (int c = tid; c < a.C; c += 256) {
+      const uint32_t v = cn[c];
+      if (v >= minm) {
+        const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
+        if (key < prev && key > best) { best = key; bestc = c; }
+      }
     }
+    u64 mx = best;
+    for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      u64 b = red[0];
+      for (int i = 1; i < 4; i++) b = red[i] > b ? red[i] : b;
+      bestk = b;
+      if (b) a.selkey[qs * 32 + m] = b;
+    }
+    __syncthreads();
+    const u64 bk = bestk;
+    if (bk == 0) break;
+    if (best == bk) a.sel[qs * 32 + m] = bestc;
+    prev = bk;
+    __syncthreads();
   }
-  u64 m = best;
-  for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(m, off); m = o > m ? o : m; }
-  if ((tid & 63) == 0) red[tid >> 6] = m;
-  __syncthreads();
-  if (tid == 0) {
-    u64 b = red[0];
-    for (int i = 1; i < 4; i++) b = red[i] > b ? red[i] : b;
-    bestk = b;
-    if (b == 0) { a.state[qs] = 3; a.cand[qs] = -1; }
-    else { a.curkey[qs] = b; atomicAdd(&a.n_found[round], 1); }
-  }
-  __syncthreads();
-  if (bestk != 0 && best == bestk) a.cand[qs] = bestc;
+  if (tid == 0) { a.selm[qs] = m; a.sel_short[qs] = m < need ? 1 : 0; }
 }
 
 __device__ __forceinline__ i64 shfl_up64(i64 v)
@@ -227,12 +236,10 @@ __device__ __forceinline__ i64 shfl_up64(i64 v)
 }
 
 // one wave = one (query strand, candidate centroid) alignment
-template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
+// (lane l owns S consecutive DP rows; returns true on the lane that holds cell (Lq, Lt), with its packed value)
+template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a, int qs, int col, int scr_slot, i64 &res)
 {
-  const int qs = blockIdx.x, lane = threadIdx.x;
-  if (a.state[qs] != 0) return;
-  const int col = a.cand[qs];
-  if (col < 0) return;
+  const int lane = threadIdx.x;
   const int qi = qs >> 1, s = qs & 1;
   const int64_t rq = a.order[a.f + qi], rt = a.cent_read[col];
   const int Lq = a.rd.len[rq], Lt = a.rd.len[rt];
@@ -240,10 +247,10 @@ template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
   const uint32_t *wt = a.rd.words + a.rd.woff[rt];
   const int64_t eoq = a.rd.excoff[rq], eot = a.rd.excoff[rt];
   const int nexq = (int)(a.rd.excoff[rq + 1] - eoq), next_ = (int)(a.rd.excoff[rt + 1] - eot);
-  i64 *scr = reinterpret_cast<i64 *>(a.scratch) + (size_t)qs * a.scratch_pitch * 2;
+  i64 *scr = reinterpret_cast<i64 *>(a.scratch) + (size_t)scr_slot * a.scratch_pitch * 2;
   const int RB = 64 * S;
   const int npass = (Lq + 1 + RB - 1) / RB;
-  i64 res = NEGV; bool have = false;
+  res = NEGV; bool have = false;
 
   for (int pass = 0; pass < npass; pass++) {
     const int i0 = pass * RB + lane * S;
@@ -328,22 +335,46 @@ template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
     }
     if (pass + 1 < npass) __threadfence();
   }
-  if (have) {
-    const i64 score = (res + (1LL << (SH_S - 1))) >> SH_S;
-    const i64 low = res - score * ONE_S;
-    const i64 matches = (low + (1LL << (SH_M - 1))) >> SH_M;
-    const i64 cols = matches * ONE_M - low;
-    const double pid = cols > 0 ? 100.0 * (double)matches / (double)cols : 0.0;
-    const u64 key = a.curkey[qs];
-    a.prev[qs] = key;
-    if (pid >= a.thr) { a.state[qs] = 1; a.acc_col[qs] = col; a.acc_id[qs] = pid; a.bound[qs] = key; }
-    else {
-      const int rj = a.rejects[qs] + 1;
-      a.rejects[qs] = rj;
-      if (rj >= 32) { a.state[qs] = 2; a.bound[qs] = key; }
-    }
+  return have;
+}
+__device__ __forceinline__ double identity_of(i64 res)
+{
+  const i64 score = (res + (1LL << (SH_S - 1))) >> SH_S;
+  const i64 low = res - score * ONE_S;
+  const i64 matches = (low + (1LL << (SH_M - 1))) >> SH_M;
+  const i64 cols = matches * ONE_M - low;
+  return cols > 0 ? 100.0 * (double)matches / (double)cols : 0.0;
+}
+
+// one wave = one (query strand, selected candidate) alignment; the walk consumes the identities in rank order
+template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
+{
+  const int slot = blockIdx.x, qs = blockIdx.y;
+  if (slot >= a.selm[qs]) return;
+  i64 res;
+  if (align_pair<S>(a, qs, a.sel[qs * 32 + slot], qs * 32 + slot, res)) {
+    a.selpid[qs * 32 + slot] = identity_of(res);
     atomicAdd(a.n_align, 1ULL);
   }
+}
+
+__global__ void k_cl_walk(ClusterArgs a)
+{
+  const int qs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qs >= 2 * a.nq || a.state[qs] != 0) return;
+  const int m = a.selm[qs];
+  int w = a.wn[qs], rej = a.rejects[qs], st = 0;
+  for (int k = 0; k < m; k++) {
+    const u64 key = a.selkey[qs * 32 + k];
+    const double pid = a.selpid[qs * 32 + k];
+    a.wkey[qs * 32 + w] = key; a.wpid[qs * 32 + w] = pid; a.wcol[qs * 32 + w] = a.sel[qs * 32 + k];
+    w++;
+    if (pid >= a.thr) { st = 1; a.acc_col[qs] = a.sel[qs * 32 + k]; a.acc_id[qs] = pid; a.bound[qs] = key; break; }
+    rej++;
+    if (rej >= 32) { st = 2; a.bound[qs] = key; break; }
+  }
+  if (st == 0) { if (a.sel_short[qs]) st = 3; else if (m > 0) a.prev[qs] = a.selkey[qs * 32 + m - 1]; }
+  a.state[qs] = st; a.wn[qs] = w; a.rejects[qs] = rej; a.selm[qs] = 0;
 }
 
 // ------------------------------------------------------------------ outcomes, new centroids, validation
@@ -363,11 +394,11 @@ __global__ void k_cl_outcome(ClusterArgs a)
   if (qi == 0) a.is_new[a.nq] = 0;
 }
 
-// set (or clear) the column of each new centroid; one wave per window query
-__global__ __launch_bounds__(64) void k_cl_columns(ClusterArgs a, int clear, int qi_from)
+// set the column of each speculative centroid (mode 0) or clear the columns flagged in rm[] (mode 1); one wave per query
+__global__ __launch_bounds__(64) void k_cl_columns(ClusterArgs a, int clear)
 {
   const int qi = blockIdx.x, lane = threadIdx.x;
-  if (qi < qi_from || !a.is_new[qi]) return;
+  if (clear ? !a.rm[qi] : !a.is_new[qi]) return;
   const int col = a.C + a.new_rank[qi];
   const int qs = 2 * qi;
   const int n = a.nk[qs];
@@ -382,18 +413,22 @@ __global__ __launch_bounds__(64) void k_cl_columns(ClusterArgs a, int clear, int
     const int64_t r = a.order[a.f + qi];
     a.cent_len[col] = a.rd.len[r]; a.cent_pos[col] = a.f + qi; a.cent_read[col] = (int32_t)r;
     a.res_col[a.f + qi] = col;
+    a.newq[a.new_rank[qi]] = qi;
   }
 }
 
+// Which speculative centroids (new in this window, before the query) would enter the query's walk?  Those with enough
+// shared words and a rank above the point where the walk stopped.  They are aligned (k_cl_align_x) and k_cl_resolve
+// replays the walk with them merged in; more than 32 of them cut the window at this query.
 __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
 {
-  __shared__ int flag;
+  __shared__ int xcount;
   const int qs = blockIdx.x, tid = threadIdx.x;
   const int n = a.nk[qs];
   if (n == 0) return;
   const int n_new = a.new_rank[a.nq];
   if (n_new == 0) return;
-  if (tid == 0) flag = 0;
+  if (tid == 0) xcount = 0;
   __syncthreads();
   const int pos = a.f + (qs >> 1);
   const uint32_t minm = n < 12 ? n : 12;
@@ -402,10 +437,105 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
   for (int c = a.C + tid; c < a.C + n_new; c += 256) {
     if (a.cent_pos[c] >= pos) break;
     const uint32_t v = cn[c];
-    if (v >= minm && cand_key(v, a.cent_len[c], a.cent_pos[c]) > bound) flag = 1;
+    if (v >= minm) {
+      const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
+      if (key > bound) {
+        const int slot = atomicAdd(&xcount, 1);
+        if (slot < 32) { a.xlist[qs * 32 + slot] = c; a.xkey[qs * 32 + slot] = key; }
+      }
+    }
   }
   __syncthreads();
-  if (tid == 0 && flag) atomicMin(a.first_affected, qs >> 1);
+  if (tid == 0) { const int cnt = xcount; a.hard[qs] = cnt > 32; a.xn[qs] = cnt > 32 ? 0 : cnt; }
+}
+
+template <int S> __global__ __launch_bounds__(64) void k_cl_align_x(ClusterArgs a)
+{
+  const int slot = blockIdx.x, qs = blockIdx.y;
+  if (slot >= a.xn[qs]) return;
+  i64 res;
+  if (align_pair<S>(a, qs, a.xlist[qs * 32 + slot], qs * 32 + slot, res)) {
+    a.xpid[qs * 32 + slot] = identity_of(res);
+    atomicAdd(a.n_align, 1ULL);
+    atomicAdd(&a.dbg[3], 1);
+  }
+}
+
+// Replay, in processing order, the walk of every query that speculative centroids could enter: the recorded walk
+// (rank keys and identities of the old candidates tried) is merged with the entrants that are STILL centroids;
+// the first accepting element wins if fewer than 32 rejects precede it.  A query that turns from centroid into
+// member is dropped from the entrants of the queries after it; a query that would turn from member into centroid
+// (its accepted hit fell out of the reject budget) has no column in this window, so the window is cut there.
+// One wave: lanes 0-31 hold the walk, lanes 32-63 the entrants; the merge is a rank count over 64 keys.
+static constexpr int CL_MAXB = 4096;
+__global__ __launch_bounds__(64) void k_cl_resolve(ClusterArgs a)
+{
+  __shared__ uint8_t tnew[CL_MAXB];
+  __shared__ int32_t list[CL_MAXB];
+  __shared__ int nlist;
+  const int lane = threadIdx.x;
+  const int nq = a.nq;
+  for (int qi = lane; qi < nq; qi += 64) tnew[qi] = (uint8_t)a.is_new[qi];
+  if (lane == 0) nlist = 0;
+  __syncthreads();
+  for (int base = 0; base < nq; base += 64) {
+    const int qi = base + lane;
+    const bool flag = qi < nq && (a.xn[2 * qi] > 0 || a.xn[2 * qi + 1] > 0 || a.hard[2 * qi] || a.hard[2 * qi + 1]);
+    const u64 mask = __ballot(flag);
+    if (flag) list[nlist + __popcll(mask & ((1ULL << lane) - 1ULL))] = qi;
+    __syncthreads();
+    if (lane == 0) nlist += __popcll(mask);
+    __syncthreads();
+  }
+  int cut = nq;
+  const int nl = nlist;
+  for (int t = 0; t < nl; t++) {
+    const int qi = list[t];
+    if (a.hard[2 * qi] || a.hard[2 * qi + 1]) { cut = qi; if (lane == 0) atomicAdd(&a.dbg[0], 1); break; }
+    int hcol[2]; double hid[2];
+    for (int s = 0; s < 2; s++) {
+      const int qs = 2 * qi + s;
+      const int wn = a.wn[qs], xn = a.xn[qs];
+      u64 key = 0; double pid = -1.0; int col = -1;
+      if (lane < 32) { if (lane < wn) { key = a.wkey[qs * 32 + lane]; pid = a.wpid[qs * 32 + lane]; col = a.wcol[qs * 32 + lane]; } }
+      else if (lane - 32 < xn) {
+        const int c = a.xlist[qs * 32 + lane - 32];
+        if (tnew[a.newq[c - a.C]]) { key = a.xkey[qs * 32 + lane - 32]; pid = a.xpid[qs * 32 + lane - 32]; col = c; }
+      }
+      int rank = 0;
+      for (int j = 0; j < 64; j++) { const u64 kj = __shfl(key, j); rank += kj > key ? 1 : 0; }
+      const bool acc = key != 0 && pid >= a.thr;
+      int r = acc ? rank : 1 << 20;
+      for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(r, off); r = o < r ? o : r; }
+      hcol[s] = -1; hid[s] = -1.0;
+      if (r < 32) {
+        const u64 who = __ballot(acc && rank == r);
+        const int src = __ffsll((unsigned long long)who) - 1;
+        hcol[s] = __shfl(col, src); hid[s] = __shfl(pid, src);
+      }
+    }
+    const bool p = hcol[0] >= 0, m = hcol[1] >= 0;
+    const bool hit = p || m;
+    const bool minus = m && (!p || hid[1] > hid[0]);
+    if (!hit && !a.is_new[qi]) { cut = qi; if (lane == 0) atomicAdd(&a.dbg[1], 1); break; }
+    if (lane == 0) {
+      if (hit) {
+        const int pos = a.f + qi;
+        a.res_col[pos] = hcol[minus ? 1 : 0]; a.res_strand[pos] = (int8_t)(minus ? -1 : 1); a.res_id[pos] = hid[minus ? 1 : 0];
+        if (tnew[qi]) atomicAdd(&a.dbg[2], 1);
+      }
+      tnew[qi] = hit ? 0 : 1;
+    }
+    __syncthreads();
+  }
+  int ntrue = 0;
+  for (int qi = lane; qi < nq; qi += 64) {
+    const int isn = a.is_new[qi];
+    a.rm[qi] = (isn && (qi >= cut || !tnew[qi])) ? 1 : 0;
+    ntrue += (qi < cut && tnew[qi]) ? 1 : 0;
+  }
+  for (int off = 32; off; off >>= 1) ntrue += __shfl_xor(ntrue, off);
+  if (lane == 0) { a.wout[0] = cut; a.wout[1] = a.new_rank[cut]; a.wout[2] = ntrue; }
 }
 
 __global__ void k_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
@@ -433,15 +563,26 @@ void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st
   hipLaunchKernelGGL(k_cl_count, dim3((ntiles + 3) / 4, 2 * a.nq), dim3(256), 0, st, a, tile0, ntiles);
 }
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
-void launch_cl_round(const ClusterArgs &a, int round, int rows_per_lane, hipStream_t st)
+void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_cl_next, dim3(2 * a.nq), dim3(256), 0, st, a, round);
-  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(2 * a.nq), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL(k_cl_align<10>, dim3(2 * a.nq), dim3(64), 0, st, a);
+  // round 0: the best candidate of every query (most reads accept it); round 1: the whole remaining reject budget at once
+  for (int round = 0; round < 2; round++) {
+    const int kmax = round == 0 ? 1 : 31;
+    hipLaunchKernelGGL(k_cl_select, dim3(2 * a.nq), dim3(256), 0, st, a, kmax);
+    if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(kmax, 2 * a.nq), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_cl_align<10>, dim3(kmax, 2 * a.nq), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_cl_walk, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
+  }
 }
 void launch_cl_outcome(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_outcome, dim3((a.nq + 255) / 256), dim3(256), 0, st, a); }
-void launch_cl_columns(const ClusterArgs &a, int clear, int qi_from, hipStream_t st) { hipLaunchKernelGGL(k_cl_columns, dim3(a.nq), dim3(64), 0, st, a, clear, qi_from); }
-void launch_cl_affected(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a); }
+void launch_cl_columns(const ClusterArgs &a, int clear, hipStream_t st) { hipLaunchKernelGGL(k_cl_columns, dim3(a.nq), dim3(64), 0, st, a, clear); }
+void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a);
+  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(32, 2 * a.nq), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(32, 2 * a.nq), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k_cl_resolve, dim3(1), dim3(64), 0, st, a);
+}
 void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
                         const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st)
 {

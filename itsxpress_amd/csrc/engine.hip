@@ -634,7 +634,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   const int64_t cnt_budget = 8LL << 30;
 
   DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, acc_col, is_new, new_rank, scan_tmp, xlist, xn, hard, dbg;
-  DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout;
+  DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm;
   DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct, selpid, wpid, xpid;
   DBuf<uint16_t> klist, cnt; DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
   DBuf<uint32_t> bitsA, bitsB;
@@ -650,7 +650,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(wn.alloc(nqs)); HIPCHK(wcol.alloc(nqs * 32)); HIPCHK(wkey.alloc(nqs * 32)); HIPCHK(wpid.alloc(nqs * 32));
   HIPCHK(xlist.alloc(nqs * 32)); HIPCHK(xn.alloc(nqs)); HIPCHK(hard.alloc(nqs)); HIPCHK(xkey.alloc(nqs * 32)); HIPCHK(xpid.alloc(nqs * 32));
   HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(newq.alloc((size_t)Bmax + 1)); HIPCHK(rm.alloc((size_t)Bmax + 1));
-  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4));
+  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1));
   HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(Bmax + 1))); HIPCHK(n_align.alloc(1));
   HIPCHK(scratch.alloc(multipass ? nqs * 32 * (size_t)scratch_pitch * 2 : 2));
   HIPCHK(hipMemsetAsync(n_align.p, 0, sizeof(unsigned long long), ctx->st));
@@ -668,7 +668,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
   a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
   a.is_new = is_new.p; a.new_rank = new_rank.p; a.newq = newq.p; a.rm = rm.p;
-  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p;
+  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.replay = replay.p; a.skipm = skipm.p;
   a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
   a.thr = 100.0 * id; a.n_align = n_align.p;
 

@@ -54,6 +54,9 @@ struct ClusterArgs {
   int32_t *is_new, *new_rank;   // [nq+1]
   int32_t *newq, *rm;           // [nq] window index of each speculative centroid; columns to clear after validation
   int32_t *xlist, *xn, *hard; unsigned long long *xkey; double *xpid;            // speculative centroids entering a walk [2 nq][32]
+  int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[2]
+  int32_t *replay;              // [nq] queries whose walk must be replayed by k_cl_resolve
+  int32_t *skipm;               // [nq] minus-strand walk cut short because the plus strand holds a 100 % hit
   int32_t *wout;                // [3] cut, columns consumed, true new centroids
   int32_t *dbg;                 // [4] hard cuts, member->centroid cuts, centroid->member resolutions, validation alignments
   unsigned long long *scratch; int32_t scratch_pitch;     // alignment boundary rows [2 nq * 32][pitch][2]

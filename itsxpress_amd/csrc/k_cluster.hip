@@ -27,6 +27,7 @@
 // The alignment is one wave per (query, candidate): lane l owns S consecutive DP rows, columns advance as an
 // anti-diagonal wavefront, the row above arrives by a one-lane shift; every cell carries (score, matches,
 // counted columns) packed into one int64 so that integer max is the lexicographic max and no traceback exists.
+#include <algorithm>
 #include "engine.h"
 #include "k_api.h"
 
@@ -178,36 +179,51 @@ __global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int 
 __global__ void k_cl_init(ClusterArgs a)
 {
   const int qs = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; }
+  if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; a.work_n[0] = 0; a.work_n[1] = 0; }
+  if (qs < a.nq) { a.replay[qs] = 0; a.skipm[qs] = 0; }
   if (qs >= 2 * a.nq) return;
   a.state[qs] = (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;
   a.rejects[qs] = 0; a.acc_col[qs] = -1; a.wn[qs] = 0; a.selm[qs] = 0; a.sel_short[qs] = 0;
   a.prev[qs] = ~0ULL; a.bound[qs] = 0ULL; a.acc_id[qs] = -1.0; a.xn[qs] = 0; a.hard[qs] = 0;
 }
 
-// the next (up to kmax, within the reject budget) candidates strictly below the last one tried, in rank order
+// the next (up to kmax, within the reject budget) candidates strictly below the last one tried, in rank order.
+// Every thread keeps the best key of its own strided subset of the count row; the block maximum is consumed and only
+// its owner rescans (its subset, below the consumed key): one pass over the row plus need short rescans instead of
+// need passes.  The (query strand, slot) items are appended to a work list for the alignment kernel.
 __global__ __launch_bounds__(256) void k_cl_select(ClusterArgs a, int kmax)
 {
   __shared__ u64 red[4];
   __shared__ u64 bestk;
+  __shared__ int owner, ownc;
   const int qs = blockIdx.x, tid = threadIdx.x;
   if (a.state[qs] != 0) return;
+  if ((qs & 1) && kmax > 1 && a.state[qs - 1] == 1 && a.acc_id[qs - 1] == 100.0) {
+    // a minus-strand hit wins only with a HIGHER identity than the plus-strand hit: nothing beats 100 %, so the
+    // remaining 31 candidates of this strand cannot change the outcome (k_cl_resolve cuts the window if the plus hit is lost)
+    if (tid == 0) { a.state[qs] = 3; a.skipm[qs >> 1] = 1; }
+    return;
+  }
   const int n = a.nk[qs];
   const uint32_t minm = n < 12 ? n : 12;
-  u64 prev = a.prev[qs];
   const uint16_t *cn = a.cnt + (size_t)qs * a.cpitch;
   int need = 32 - a.rejects[qs];
   need = need < kmax ? need : kmax;
-  int m = 0;
-  for (; m < need; m++) {
-    u64 best = 0; int bestc = -1;
+  u64 lim = a.prev[qs];
+  u64 best = 0; int bestc = -1;
+  auto rescan = [&]() {
+    best = 0; bestc = -1;
     for (int c = tid; c < a.C; c += 256) {
       const uint32_t v = cn[c];
       if (v >= minm) {
         const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
-        if (key < prev && key > best) { best = key; bestc = c; }
+        if (key < lim && key > best) { best = key; bestc = c; }
       }
     }
+  };
+  rescan();
+  int m = 0;
+  for (; m < need; m++) {
     u64 mx = best;
     for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
     if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -221,11 +237,34 @@ __global__ __launch_bounds__(256) void k_cl_select(ClusterArgs a, int kmax)
     __syncthreads();
     const u64 bk = bestk;
     if (bk == 0) break;
-    if (best == bk) a.sel[qs * 32 + m] = bestc;
-    prev = bk;
+    if (best == bk) { a.sel[qs * 32 + m] = bestc; owner = tid; }
+    __syncthreads();
+    if (m + 1 >= need) { m++; break; }
+    // the owner's subset (columns = owner mod 256) is rescanned by the whole block, below the consumed key
+    const int ow = owner;
+    u64 nb = 0; int nbc = -1;
+    for (int c = ow + tid * 256; c < a.C; c += 256 * 256) {
+      const uint32_t v = cn[c];
+      if (v >= minm) {
+        const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
+        if (key < bk && key > nb) { nb = key; nbc = c; }
+      }
+    }
+    u64 mx2 = nb;
+    for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(mx2, off); mx2 = o > mx2 ? o : mx2; }
+    if ((tid & 63) == 0) red[tid >> 6] = mx2;
+    __syncthreads();
+    u64 b2 = red[0];
+    for (int i = 1; i < 4; i++) b2 = red[i] > b2 ? red[i] : b2;
+    if (nb == b2 && b2 != 0) ownc = nbc;
+    __syncthreads();
+    if (tid == ow) { best = b2; bestc = b2 ? ownc : -1; }
     __syncthreads();
   }
-  if (tid == 0) { a.selm[qs] = m; a.sel_short[qs] = m < need ? 1 : 0; }
+  if (tid == 0) {
+    a.selm[qs] = m; a.sel_short[qs] = m < need ? 1 : 0;
+    if (m > 0) { const int w0 = atomicAdd(&a.work_n[0], m); for (int k = 0; k < m; k++) a.work[w0 + k] = qs * 32 + k; }
+  }
 }
 
 __device__ __forceinline__ i64 shfl_up64(i64 v)
@@ -254,7 +293,7 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
 
   for (int pass = 0; pass < npass; pass++) {
     const int i0 = pass * RB + lane * S;
-    uint32_t qm[S]; bool qu[S], tE[S];
+    uint32_t qm[S]; bool qu[S]; i64 goE[S], geE[S];
 #pragma unroll
     for (int r = 0; r < S; r++) {
       const int i = i0 + r;
@@ -264,7 +303,7 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
         const uint32_t c2 = (wq[o >> 4] >> ((o & 15) * 2)) & 3u;
         m = 1u << (s ? 3u - c2 : c2);
       }
-      qm[r] = m; tE[r] = (i == 0 || i == Lq);
+      qm[r] = m; goE[r] = (i == 0 || i == Lq) ? GOT : GOI; geE[r] = (i == 0 || i == Lq) ? GET : GEI;
     }
     for (int e = 0; e < nexq; e++) {
       const uint32_t ex = a.rd.exc[eoq + e];
@@ -314,8 +353,7 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
         i64 aboveH = upH, aboveF = upF, dg = diag_carry;
 #pragma unroll
         for (int r = 0; r < S; r++) {
-          const i64 goE = tE[r] ? GOT : GOI, geE = tE[r] ? GET : GEI;
-          const i64 E = max64(Hl[r] + goE, El[r] + geE);
+          const i64 E = max64(Hl[r] + goE[r], El[r] + geE[r]);
           const i64 F = max64(aboveH + goF, aboveF + geF);
           const i64 D = (qu[r] && tu) ? (qm[r] == tm ? D_MATCH : D_MISMATCH) : ((qm[r] & tm) ? D_AMB_MATCH : D_AMB_MISMATCH);
           i64 Hn = max64(max64(dg + D, E), F);
@@ -349,12 +387,14 @@ __device__ __forceinline__ double identity_of(i64 res)
 // one wave = one (query strand, selected candidate) alignment; the walk consumes the identities in rank order
 template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
 {
-  const int slot = blockIdx.x, qs = blockIdx.y;
-  if (slot >= a.selm[qs]) return;
-  i64 res;
-  if (align_pair<S>(a, qs, a.sel[qs * 32 + slot], qs * 32 + slot, res)) {
-    a.selpid[qs * 32 + slot] = identity_of(res);
-    atomicAdd(a.n_align, 1ULL);
+  const int nw = a.work_n[0];
+  for (int w = blockIdx.x; w < nw; w += gridDim.x) {      // every wave drains its share of the list and exits
+    const int item = a.work[w];
+    i64 res;
+    if (align_pair<S>(a, item >> 5, a.sel[item], item, res)) {
+      a.selpid[item] = identity_of(res);
+      atomicAdd(a.n_align, 1ULL);
+    }
   }
 }
 
@@ -376,6 +416,7 @@ __global__ void k_cl_walk(ClusterArgs a)
   if (st == 0) { if (a.sel_short[qs]) st = 3; else if (m > 0) a.prev[qs] = a.selkey[qs * 32 + m - 1]; }
   a.state[qs] = st; a.wn[qs] = w; a.rejects[qs] = rej; a.selm[qs] = 0;
 }
+__global__ void k_cl_reset_work(ClusterArgs a, int which) { a.work_n[which] = 0; }
 
 // ------------------------------------------------------------------ outcomes, new centroids, validation
 __global__ void k_cl_outcome(ClusterArgs a)
@@ -428,6 +469,7 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
   if (n == 0) return;
   const int n_new = a.new_rank[a.nq];
   if (n_new == 0) return;
+  if ((qs & 1) && a.skipm[qs >> 1]) return;              // this strand's walk was cut short: it has no say (see k_cl_select)
   if (tid == 0) xcount = 0;
   __syncthreads();
   const int pos = a.f + (qs >> 1);
@@ -446,22 +488,36 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
     }
   }
   __syncthreads();
-  if (tid == 0) { const int cnt = xcount; a.hard[qs] = cnt > 32; a.xn[qs] = cnt > 32 ? 0 : cnt; }
+  if (tid == 0) {
+    const int cnt = xcount;
+    a.hard[qs] = cnt > 32; a.xn[qs] = cnt > 32 ? 0 : cnt;
+    if (cnt > 32) a.replay[qs >> 1] = 1;
+    else if (cnt > 0) {
+      if (a.state[qs] == 1 && a.rejects[qs] + cnt >= 32) a.replay[qs >> 1] = 1;     // the accepted hit could fall out of the reject budget
+      const int w0 = atomicAdd(&a.work_n[1], cnt);
+      for (int k = 0; k < cnt; k++) a.xwork[w0 + k] = qs * 32 + k;
+    }
+  }
 }
 
 template <int S> __global__ __launch_bounds__(64) void k_cl_align_x(ClusterArgs a)
 {
-  const int slot = blockIdx.x, qs = blockIdx.y;
-  if (slot >= a.xn[qs]) return;
-  i64 res;
-  if (align_pair<S>(a, qs, a.xlist[qs * 32 + slot], qs * 32 + slot, res)) {
-    a.xpid[qs * 32 + slot] = identity_of(res);
-    atomicAdd(a.n_align, 1ULL);
-    atomicAdd(&a.dbg[3], 1);
+  const int nw = a.work_n[1];
+  for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+    const int item = a.xwork[w];
+    i64 res;
+    if (align_pair<S>(a, item >> 5, a.xlist[item], item, res)) {
+      const double pid = identity_of(res);
+      a.xpid[item] = pid;
+      if (pid >= a.thr) a.replay[item >> 6] = 1;           // an entrant accepts this query: its walk must be replayed
+      atomicAdd(a.n_align, 1ULL);
+      atomicAdd(&a.dbg[3], 1);
+    }
   }
 }
 
-// Replay, in processing order, the walk of every query that speculative centroids could enter: the recorded walk
+// Replay, in processing order, the walk of every query that a speculative centroid ACCEPTS (or whose reject budget
+// could run out; a query whose entrants all reject keeps its outcome whatever becomes of them): the recorded walk
 // (rank keys and identities of the old candidates tried) is merged with the entrants that are STILL centroids;
 // the first accepting element wins if fewer than 32 rejects precede it.  A query that turns from centroid into
 // member is dropped from the entrants of the queries after it; a query that would turn from member into centroid
@@ -480,7 +536,7 @@ __global__ __launch_bounds__(64) void k_cl_resolve(ClusterArgs a)
   __syncthreads();
   for (int base = 0; base < nq; base += 64) {
     const int qi = base + lane;
-    const bool flag = qi < nq && (a.xn[2 * qi] > 0 || a.xn[2 * qi + 1] > 0 || a.hard[2 * qi] || a.hard[2 * qi + 1]);
+    const bool flag = qi < nq && a.replay[qi] != 0;
     const u64 mask = __ballot(flag);
     if (flag) list[nlist + __popcll(mask & ((1ULL << lane) - 1ULL))] = qi;
     __syncthreads();
@@ -513,6 +569,10 @@ __global__ __launch_bounds__(64) void k_cl_resolve(ClusterArgs a)
         const int src = __ffsll((unsigned long long)who) - 1;
         hcol[s] = __shfl(col, src); hid[s] = __shfl(pid, src);
       }
+    }
+    if (a.skipm[qi]) {
+      if (!(hcol[0] >= 0 && hid[0] == 100.0)) { cut = qi; if (lane == 0) atomicAdd(&a.dbg[1], 1); break; }   // the 100 % plus hit is gone: search again
+      hcol[1] = -1;
     }
     const bool p = hcol[0] >= 0, m = hcol[1] >= 0;
     const bool hit = p || m;
@@ -569,9 +629,11 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   for (int round = 0; round < 2; round++) {
     const int kmax = round == 0 ? 1 : 31;
     hipLaunchKernelGGL(k_cl_select, dim3(2 * a.nq), dim3(256), 0, st, a, kmax);
-    if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(kmax, 2 * a.nq), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(k_cl_align<10>, dim3(kmax, 2 * a.nq), dim3(64), 0, st, a);
+    const int grid = std::min(2 * a.nq * kmax, 16384);
+    if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(k_cl_align<10>, dim3(grid), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_cl_walk, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_cl_reset_work, dim3(1), dim3(1), 0, st, a, 0);
   }
 }
 void launch_cl_outcome(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_outcome, dim3((a.nq + 255) / 256), dim3(256), 0, st, a); }
@@ -579,8 +641,9 @@ void launch_cl_columns(const ClusterArgs &a, int clear, hipStream_t st) { hipLau
 void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
 {
   hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a);
-  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(32, 2 * a.nq), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(32, 2 * a.nq), dim3(64), 0, st, a);
+  const int grid = std::min(2 * a.nq * 32, 16384);
+  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(grid), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(grid), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k_cl_resolve, dim3(1), dim3(64), 0, st, a);
 }
 void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,

@@ -68,7 +68,9 @@ def _compare(engine, reads, names, cid, strand_both=True):
     assert np.array_equal(pct.view(np.uint64), o["pct_id"].view(np.uint64))
     st = engine.stats()
     assert st["n_unique"] == o["n_centroids"]
-    assert st["cl_alignments"] >= o["n_alignments"]          # speculation may redo alignments, never skips one
+    # the engine may redo alignments (speculation) and may skip ones that cannot change the outcome (minus strand when the
+    # plus strand holds a 100 % hit), so the counts are not comparable; the outcomes above are
+    assert st["cl_alignments"] > 0 or o["n_alignments"] == 0
     return o, st
 
 
@@ -84,6 +86,17 @@ def test_cluster_is_independent_of_the_window(engine, window, monkeypatch):
     monkeypatch.setenv("ITSX_CL_WINDOW", window)
     reads, names = _noisy_library(12, 700, 25, (120, 160), shared_flank=30)
     _compare(engine, reads, names, 0.98)
+
+
+@pytest.mark.parametrize("window", ["16", "4096"])
+def test_cluster_many_ambiguous_symbols(engine, window, monkeypatch):
+    # N matches anything: 100 % hits with fewer shared words than a worse-matching newcomer -- the walk replay,
+    # the reject budget and the 100 % plus-strand shortcut all get exercised
+    monkeypatch.setenv("ITSX_CL_WINDOW", window)
+    reads, names = _noisy_library(21, 1500, 10, (150, 170), max_err=3, n_rate=0.02, rc_rate=0.4, shared_flank=40)
+    _compare(engine, reads, names, 0.99)
+    reads, names = _noisy_library(22, 1500, 6, (100, 110), max_err=2, indel=False, n_rate=0.03, rc_rate=0.5, shared_flank=30)
+    _compare(engine, reads, names, 0.985)
 
 
 def test_cluster_plus_strand_only_and_no_names(engine):

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20 s of CPU work)")
     ap.add_argument("--cluster-id", type=float, default=1.0,
                     help="1.0 = exact dereplication (BASELINE configs[1], the default); < 1 runs row a2 (greedy clustering) instead")
+    ap.add_argument("--global-derep", action="store_true",
+                    help="N > 1: match the uniques across shards (exact global dereplication, SURVEY 8e option 2) instead of per-shard")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,7 +80,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from itsxpress_amd import Engine
-    from itsxpress_amd.dist import allreduce_domz, gather_coords
+    from itsxpress_amd.dist import allreduce_domz, exchange_coords, gather_coords, global_derep
     import synth
 
     with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
@@ -94,11 +96,19 @@ def main():
             eng.cluster(args.cluster_id, strand_both=True)
         else:
             eng.derep(strand_both=True, minseqlength=32)
+        g = global_derep(eng, args.reads, dev) if (use_dist and args.global_derep) else None
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
         if use_dist:
             eng.set_domz(allreduce_domz(eng.get_domz(), dev))
         eng.finalize(domE=10.0)
-        c = eng.trim_coords("3_", "4_")
+        if g is not None:            # coordinates of the uniques scored elsewhere arrive here, then fan out to the reads
+            us, ue, ut, ui = exchange_coords(g, *eng.rep_coords("3_", "4_"), device=dev)
+            uq = eng.get_derep()[2]
+            ok = uq >= 0
+            uq = np.maximum(uq, 0)
+            c = tuple(np.where(ok, a[uq], d).astype(np.int32) for a, d in ((us, -1), (ue, -1), (ut, -1), (ui, 0)))
+        else:
+            c = eng.trim_coords("3_", "4_")
         return gather_coords(*c, device=dev) if use_dist else [np.stack(c, axis=1)]
 
     for _ in range(args.warmup):
@@ -159,7 +169,7 @@ def main():
                        ("%d synthetic 300 bp single-end reads per GPU, ITS2, cluster_id=%g (greedy clustering, row a2)" % (args.reads, args.cluster_id)),
                        "taxon": "Tracheophyta (stand-in: F.hmm absent from the reference mount)", "profiles": nprof,
                        "unique": int(st["n_unique"]), "pairs_past_msv": int(st["n_past_msv"]), "pairs_past_fwd": int(st["n_past_fwd"]),
-                       "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed, "parallelism": "reads sharded x%d" % world},
+                       "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed, "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
             "cluster": None if args.cluster_id >= 1.0 else {"windows": int(st["cl_windows"]), "cut_windows": int(st["cl_cuts"]),
                                                             "alignments": int(st["cl_alignments"]), "centroids": int(st["n_unique"])},

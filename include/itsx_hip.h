@@ -129,6 +129,13 @@ int itsx_get_cluster(const itsx_ctx *ctx, double *pct_id, int64_t *order, int64_
  * rep_of[i] = read index of the cluster seed (first occurrence), -1 if the read was dropped;
  * strand[i] = +1 / -1 (uc column 5); uniq_of[i] = index into the unique list, -1 if dropped. */
 int itsx_get_derep(const itsx_ctx *ctx, int64_t *rep_of, int8_t *strand, int64_t *uniq_of);
+/* ---- multi-GPU exact dereplication (SURVEY 8e option 2; itsxpress_amd/dist.py:global_derep).
+ * itsx_unique_keys: XXH64 (given seed) of each local unique's packed forward strand and of its reverse complement,
+ * to be exchanged between ranks.  itsx_set_active_uniques: active[U] != 0 keeps a unique in the set the HMM stages
+ * score (a unique whose global first occurrence lives on another rank is scored THERE); inactive uniques get no
+ * domains, their coordinates arrive through the exchange.  A later itsx_derep / itsx_cluster resets the set. */
+int itsx_unique_keys(itsx_ctx *ctx, uint64_t seed, uint64_t *fwd, uint64_t *rc);
+int itsx_set_active_uniques(itsx_ctx *ctx, const uint8_t *active);
 /* read index of each unique (rep.fa order = input order of seeds), abundance of its cluster */
 int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance);
 

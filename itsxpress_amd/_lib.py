@@ -49,7 +49,7 @@ STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 # every symbol include/itsx_hip.h declares
 EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy", "itsx_load_profiles_file",
            "itsx_load_profiles_mem", "itsx_profile_name", "itsx_profile_tables", "itsx_set_reads",
-           "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_cluster", "itsx_get_derep", "itsx_get_uniques",
+           "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_cluster", "itsx_get_derep", "itsx_unique_keys", "itsx_set_active_uniques", "itsx_get_uniques",
            "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
            "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
@@ -82,6 +82,8 @@ def lib():
         "itsx_derep": (i32, [vp, i32, i32, vp]),
         "itsx_cluster": (i32, [vp, f64, i32, vp]),
         "itsx_get_cluster": (i32, [vp, vp, vp, vp]),
+        "itsx_unique_keys": (i32, [vp, C.c_uint64, vp, vp]),
+        "itsx_set_active_uniques": (i32, [vp, vp]),
         "itsx_get_derep": (i32, [vp, vp, vp, vp]),
         "itsx_get_uniques": (i32, [vp, vp, vp]),
         "itsx_search": (i32, [vp, f64, f64, f64, f64]),

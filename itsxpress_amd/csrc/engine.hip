@@ -141,6 +141,7 @@ struct itsx_ctx {
   // ---- derep
   bool have_derep = false;
   int32_t U = 0;
+  int32_t U_active = 0;                  // uniques this context scores (all of them unless itsx_set_active_uniques narrowed it)
   DBuf<int32_t> d_rep_of, d_uniq_of, d_seed_read, d_abund, d_sorted_uniq, d_ulen;
   DBuf<int8_t> d_strand;
   std::vector<int32_t> h_rep_of, h_uniq_of, h_seed_read, h_abund, h_sorted_uniq;
@@ -519,7 +520,7 @@ static int build_unique_lists(itsx_ctx *ctx)
     HIPCHK(hipMemcpyAsync(&U, seed_rank.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
   }
-  ctx->U = U;
+  ctx->U = U; ctx->U_active = U;
   HIPCHK(ctx->d_seed_read.alloc((size_t)U + 1)); HIPCHK(ctx->d_abund.alloc((size_t)U + 1)); HIPCHK(ctx->d_sorted_uniq.alloc((size_t)U + 1));
   HIPCHK(ctx->d_ulen.alloc((size_t)U + 1));
   HIPCHK(hipMemsetAsync(ctx->d_abund.p, 0, ((size_t)U + 1) * sizeof(int32_t), ctx->st));
@@ -775,6 +776,45 @@ int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance
   return ITSX_OK;
 }
 
+
+// ---- multi-GPU exact dereplication (SURVEY 8e option 2): keys out, active set in
+int itsx_unique_keys(itsx_ctx *ctx, uint64_t seed, uint64_t *fwd, uint64_t *rc)
+{
+  CTXCHK(ctx && ctx->have_derep && fwd && rc);
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->N;
+  if (n == 0 || ctx->U == 0) return ITSX_OK;
+  HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1));
+  launch_hash_reads(ctx->rd, seed, 1, ctx->w_hf.p, ctx->w_hr.p, ctx->st);
+  std::vector<uint64_t> hf((size_t)n), hr((size_t)n);
+  HIPCHK(hipMemcpyAsync(hf.data(), ctx->w_hf.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(hr.data(), ctx->w_hr.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  // trailing A's are zero bits in the packed words: the length is folded in so that a read and its A-extended copy differ
+  for (int32_t u = 0; u < ctx->U; u++) {
+    const size_t r = (size_t)ctx->h_seed_read[u];
+    const uint64_t lm = (uint64_t)ctx->h_len[r] * 0x9E3779B97F4A7C15ULL;
+    fwd[u] = hf[r] ^ lm; rc[u] = hr[r] ^ lm;
+  }
+  return ITSX_OK;
+}
+
+int itsx_set_active_uniques(itsx_ctx *ctx, const uint8_t *active)
+{
+  CTXCHK(ctx && ctx->have_derep && (active || ctx->U == 0));
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<int32_t> keep; keep.reserve((size_t)ctx->U);
+  for (int32_t s = 0; s < ctx->U; s++) { const int32_t u = ctx->h_sorted_uniq[(size_t)s]; if (active[u]) keep.push_back(u); }   // stays length-sorted
+  ctx->U_active = (int32_t)keep.size();
+  if (!keep.empty()) {
+    HIPCHK(hipMemcpyAsync(ctx->d_sorted_uniq.p, keep.data(), keep.size() * 4, hipMemcpyHostToDevice, ctx->st));
+    launch_fill_ulen(ctx->U_active, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, ctx->rd.len, ctx->d_ulen.p, ctx->st);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
+  ctx->have_search = ctx->have_final = false;
+  return ITSX_OK;
+}
+
 // ------------------------------------------------------------------------------ search
 static float msv_score_from_byte(int xj, int tjb)
 {
@@ -795,7 +835,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   if (F2 != F1) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "F2 != F1 would enable hmmsearch's Viterbi filter, which this engine does not implement");
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->st;
-  const int P = ctx->P, G = ctx->G, Ppad = G * 64, U = ctx->U;
+  const int P = ctx->P, G = ctx->G, Ppad = G * 64, U = ctx->U_active;
   ctx->T = T;
   ctx->h_dom.clear(); ctx->h_trace.clear(); ctx->trace_sorted = false;
   ctx->domz.assign((size_t)P, 0);
@@ -811,7 +851,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   std::vector<LenTables> lt((size_t)Lcap);
   std::vector<int32_t> tjb((size_t)Lcap, 0);
   std::vector<char> present((size_t)Lcap, 0);
-  for (int32_t u = 0; u < U; u++) present[ctx->h_len[ctx->h_seed_read[u]]] = 1;
+  for (int32_t u = 0; u < ctx->U; u++) present[ctx->h_len[ctx->h_seed_read[u]]] = 1;
   for (int L = 0; L < Lcap; L++) {
     LenTables &t = lt[L]; memset(&t, 0, sizeof(t));
     if (L == 0) continue;

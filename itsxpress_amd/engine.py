@@ -145,6 +145,18 @@ class Engine:
         self._chk(self.L.itsx_get_derep(self.h, rep_of.ctypes.data, strand.ctypes.data, uniq_of.ctypes.data))
         return rep_of, strand, uniq_of
 
+    def unique_keys(self, seed=0):
+        """XXH64(seed) of every local unique's forward strand and reverse complement (uint64[U] each)."""
+        kf = np.zeros(max(1, self.n_unique), np.uint64)
+        kr = np.zeros(max(1, self.n_unique), np.uint64)
+        self._chk(self.L.itsx_unique_keys(self.h, C.c_uint64(seed), kf.ctypes.data, kr.ctypes.data))
+        return kf[:self.n_unique], kr[:self.n_unique]
+
+    def set_active_uniques(self, active):
+        a = np.ascontiguousarray(active, np.uint8)
+        assert a.shape[0] == self.n_unique
+        self._chk(self.L.itsx_set_active_uniques(self.h, a.ctypes.data if a.size else None))
+
     def get_uniques(self):
         seed = np.zeros(self.n_unique, np.int64)
         ab = np.zeros(self.n_unique, np.int64)

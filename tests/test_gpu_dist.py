@@ -1,0 +1,95 @@
+"""Two ranks (gloo), one GPU: the sharded path with exact cross-shard dereplication (SURVEY 8e option 2) must give,
+read for read, what ONE engine computes on the concatenated input -- representatives, strands, coordinates.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import synth
+
+pytestmark = pytest.mark.gpu
+_RC = str.maketrans("ACGTN", "TGCAN")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _library(hmm_text):
+    blob, offs = synth.make_reads(hmm_text, 3000, seed=77, sub_rate=0.002)
+    reads = synth.to_strings(blob, offs)
+    # make sure the shards share sequences in both orientations: copy some of the first half into the second, some reversed
+    n = len(reads)
+    for k in range(0, 600):
+        src = reads[(k * 7) % (n // 2)]
+        reads[n // 2 + k] = src if k % 3 else src[::-1].translate(_RC)
+    return reads
+
+
+def _run_path(eng, reads, hmm_text, g_fn=None, x_fn=None, domz_fn=None):
+    eng.load_profiles(text=hmm_text)
+    eng.set_reads(reads)
+    eng.derep()
+    g = g_fn(eng, len(reads)) if g_fn else None
+    eng.search()
+    if domz_fn:
+        eng.set_domz(domz_fn(eng.get_domz()))
+    eng.finalize()
+    us, ue, ut, ui = eng.rep_coords("3_", "4_")
+    if x_fn:
+        us, ue, ut, ui = x_fn(g, us, ue, ut, ui)
+    rep_of, strand, uniq_of = eng.get_derep()
+    ok = uniq_of >= 0
+    start = np.where(ok, us[np.maximum(uniq_of, 0)], -1)
+    stop = np.where(ok, ue[np.maximum(uniq_of, 0)], -1)
+    tlen = np.where(ok, ut[np.maximum(uniq_of, 0)], -1)
+    return g, start, stop, tlen, rep_of, strand, uniq_of
+
+
+def _worker(rank, world, port, hmm_text, reads, q):
+    import torch.distributed as dist
+    from itsxpress_amd import Engine
+    from itsxpress_amd.dist import allreduce_domz, exchange_coords, global_derep, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(len(reads), world, rank)
+    eng = Engine(0)
+    g, start, stop, tlen, rep_of, strand, uniq_of = _run_path(eng, reads[lo:hi], hmm_text, global_derep, exchange_coords, allreduce_domz)
+    ok = uniq_of >= 0
+    grep = np.where(ok, g["seed_gidx"][np.maximum(uniq_of, 0)], -1)
+    gstrand = np.where(ok & g["flip"][np.maximum(uniq_of, 0)], -strand, strand)
+    q.put((rank, start, stop, tlen, grep, gstrand, int(g["active"].sum()), int(eng.n_unique)))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def test_two_ranks_equal_one_engine(engine, mini_hmm_text):
+    reads = _library(mini_hmm_text)
+    _, start, stop, tlen, rep_of, strand, _ = _run_path(engine, reads, mini_hmm_text)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mini_hmm_text, reads, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=600)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    cat = lambda k: np.concatenate([res[0][k], res[1][k]])
+    assert np.array_equal(cat(0), start) and np.array_equal(cat(1), stop) and np.array_equal(cat(2), tlen)
+    assert np.array_equal(cat(3), rep_of) and np.array_equal(cat(4), strand)
+    # the second shard really did leave sequences to the first one
+    assert res[1][5] < res[1][6] and res[0][5] == res[0][6] and (start >= 0).sum() > 2000

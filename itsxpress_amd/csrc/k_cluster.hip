@@ -40,7 +40,7 @@ static constexpr int SH_S = 40, SH_M = 20;
 static constexpr i64 NEGV = -(1LL << 60);
 static constexpr i64 ONE_S = 1LL << SH_S, ONE_M = 1LL << SH_M;
 static constexpr i64 GOI = -22 * ONE_S - 1, GEI = -2 * ONE_S - 1, GOT = -3 * ONE_S, GET = -1 * ONE_S;
-static constexpr i64 D_MATCH = 2 * ONE_S + ONE_M - 1, D_MISMATCH = -4 * ONE_S - 1, D_AMB_MATCH = ONE_M - 1, D_AMB_MISMATCH = -1;
+// diagonal increments: match 2*ONE_S + ONE_M - 1, mismatch -4*ONE_S - 1, compatible ambiguity ONE_M - 1, incompatible -1 (built in align_pair)
 static constexpr u64 MASK4_LUT = 0xFD7EB96C3A508421ULL;      // IUPAC set of each digital code, 4 bits each
 
 __device__ __forceinline__ uint32_t mask4(uint32_t code) { return (uint32_t)(MASK4_LUT >> (4 * code)) & 15u; }
@@ -276,7 +276,7 @@ __device__ __forceinline__ i64 shfl_up64(i64 v)
 
 // one wave = one (query strand, candidate centroid) alignment
 // (lane l owns S consecutive DP rows; returns true on the lane that holds cell (Lq, Lt), with its packed value)
-template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a, int qs, int col, int scr_slot, i64 &res)
+template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a, int qs, int col, int scr_slot, uint8_t *tmask, i64 &res)
 {
   const int lane = threadIdx.x;
   const int qi = qs >> 1, s = qs & 1;
@@ -290,6 +290,13 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
   const int RB = 64 * S;
   const int npass = (Lq + 1 + RB - 1) / RB;
   res = NEGV; bool have = false;
+
+  // the target's IUPAC sets go to LDS once; lane l then reads the symbol of its own column every step
+  __syncthreads();
+  for (int o = lane; o < Lt; o += 64) tmask[o] = (uint8_t)(1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u));
+  __syncthreads();
+  for (int e = lane; e < next_; e += 64) { const uint32_t ex = a.rd.exc[eot + e]; tmask[ex >> 4] = (uint8_t)mask4(ex & 15u); }
+  __syncthreads();
 
   for (int pass = 0; pass < npass; pass++) {
     const int i0 = pass * RB + lane * S;
@@ -319,27 +326,13 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
     i64 Hl[S], El[S];
 #pragma unroll
     for (int r = 0; r < S; r++) { Hl[r] = NEGV; El[r] = NEGV; }
-    i64 diag_carry = NEGV, pubH = NEGV, pubF = NEGV;
-    uint32_t pubT = 0;
-    int te = 0;                                          // exception cursor of the target (lane 0's stream)
-    int next_exc = next_ > 0 ? (int)(a.rd.exc[eot] >> 4) : 0x7fffffff;
+    // cell (0,0) is 0: its "diagonal" enters as +1 and meets the -1 of a column without symbol
+    i64 diag_carry = (pass == 0 && lane == 0) ? 1 : NEGV, pubH = NEGV, pubF = NEGV;
     const int nsteps = Lt + 1 + 63;
     for (int t = 0; t < nsteps; t++) {
       i64 upH = shfl_up64(pubH), upF = shfl_up64(pubF);
-      uint32_t tm = __shfl_up(pubT, 1);
-      // the target symbol of column t enters at lane 0
-      uint32_t t0 = 0;
-      if (t >= 1 && t <= Lt) {
-        const int o = t - 1;
-        if (o == next_exc) {
-          t0 = mask4(a.rd.exc[eot + te] & 15u);
-          te++;
-          next_exc = te < next_ ? (int)(a.rd.exc[eot + te] >> 4) : 0x7fffffff;
-        } else t0 = 1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u);
-      }
       const int j = t - lane;
       if (lane == 0) {
-        tm = t0;
         if (pass > 0 && j <= Lt) {
           upH = __hip_atomic_load(&scr[2 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           upF = __hip_atomic_load(&scr[2 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -347,6 +340,7 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
         else { upH = NEGV; upF = NEGV; }
       }
       if (j >= 0 && j <= Lt) {
+        const uint32_t tm = j >= 1 ? (uint32_t)tmask[j - 1] : 0u;
         const bool tF = (j == 0 || j == Lt);
         const i64 goF = tF ? GOT : GOI, geF = tF ? GET : GEI;
         const bool tu = unamb4(tm);
@@ -355,15 +349,19 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
         for (int r = 0; r < S; r++) {
           const i64 E = max64(Hl[r] + goE[r], El[r] + geE[r]);
           const i64 F = max64(aboveH + goF, aboveF + geF);
-          const i64 D = (qu[r] && tu) ? (qm[r] == tm ? D_MATCH : D_MISMATCH) : ((qm[r] & tm) ? D_AMB_MATCH : D_AMB_MISMATCH);
-          i64 Hn = max64(max64(dg + D, E), F);
-          if (i0 + r == 0 && j == 0) Hn = 0;
+          // D = score*2^40 + match*2^20 - 1 built from its 32-bit halves (no branches): compatible symbols are a match;
+          // the score is +2 / -4 only when both symbols are unambiguous
+          const bool compat = (qm[r] & tm) != 0u;
+          const bool bu = qu[r] && tu;
+          const uint32_t dlo = compat ? 0x000FFFFFu : 0xFFFFFFFFu;
+          const int32_t dhiA = compat ? 0 : -1, dhiU = compat ? 512 : -1025;
+          const i64 D = (i64)(((u64)(uint32_t)(bu ? dhiU : dhiA) << 32) | (u64)dlo);
+          const i64 Hn = max64(max64(dg + D, E), F);
           dg = Hl[r];
           Hl[r] = Hn; El[r] = E;
           aboveH = Hn; aboveF = F;
-          if (i0 + r == Lq && j == Lt) { res = Hn; have = true; }
         }
-        pubH = aboveH; pubF = aboveF; pubT = tm;
+        pubH = aboveH; pubF = aboveF;
         diag_carry = upH;
         if (lane == 63 && pass + 1 < npass) {
           __hip_atomic_store(&scr[2 * j], aboveH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -372,6 +370,10 @@ template <int S> __device__ __forceinline__ bool align_pair(const ClusterArgs &a
       }
     }
     if (pass + 1 < npass) __threadfence();
+    else {                                               // every row now holds its value in column Lt
+#pragma unroll
+      for (int r = 0; r < S; r++) if (i0 + r == Lq) { res = Hl[r]; have = true; }
+    }
   }
   return have;
 }
@@ -387,11 +389,12 @@ __device__ __forceinline__ double identity_of(i64 res)
 // one wave = one (query strand, selected candidate) alignment; the walk consumes the identities in rank order
 template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
 {
+  extern __shared__ uint8_t tmask_lds[];
   const int nw = a.work_n[0];
   for (int w = blockIdx.x; w < nw; w += gridDim.x) {      // every wave drains its share of the list and exits
     const int item = a.work[w];
     i64 res;
-    if (align_pair<S>(a, item >> 5, a.sel[item], item, res)) {
+    if (align_pair<S>(a, item >> 5, a.sel[item], item, tmask_lds, res)) {
       a.selpid[item] = identity_of(res);
       atomicAdd(a.n_align, 1ULL);
     }
@@ -502,11 +505,12 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
 
 template <int S> __global__ __launch_bounds__(64) void k_cl_align_x(ClusterArgs a)
 {
+  extern __shared__ uint8_t tmask_lds[];
   const int nw = a.work_n[1];
   for (int w = blockIdx.x; w < nw; w += gridDim.x) {
     const int item = a.xwork[w];
     i64 res;
-    if (align_pair<S>(a, item >> 5, a.xlist[item], item, res)) {
+    if (align_pair<S>(a, item >> 5, a.xlist[item], item, tmask_lds, res)) {
       const double pid = identity_of(res);
       a.xpid[item] = pid;
       if (pid >= a.thr) a.replay[item >> 6] = 1;           // an entrant accepts this query: its walk must be replayed
@@ -630,8 +634,9 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
     const int kmax = round == 0 ? 1 : 31;
     hipLaunchKernelGGL(k_cl_select, dim3(2 * a.nq), dim3(256), 0, st, a, kmax);
     const int grid = std::min(2 * a.nq * kmax, 16384);
-    if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(k_cl_align<10>, dim3(grid), dim3(64), 0, st, a);
+    const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
+    if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL(k_cl_align<10>, dim3(grid), dim3(64), lds, st, a);
     hipLaunchKernelGGL(k_cl_walk, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_cl_reset_work, dim3(1), dim3(1), 0, st, a, 0);
   }
@@ -642,8 +647,9 @@ void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
 {
   hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a);
   const int grid = std::min(2 * a.nq * 32, 16384);
-  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(grid), dim3(64), 0, st, a);
-  else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(grid), dim3(64), 0, st, a);
+  const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
+  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(grid), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(grid), dim3(64), lds, st, a);
   hipLaunchKernelGGL(k_cl_resolve, dim3(1), dim3(64), 0, st, a);
 }
 void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,

@@ -290,7 +290,9 @@ def test_errors_are_loud(engine, tmp_path):
         engine.load_profiles(path=str(tmp_path / "nope.hmm"))
     engine.set_reads(["ACGT" * 10])
     with pytest.raises(EngineError):
-        engine.cluster(0.995)
+        engine.cluster(1.5)                      # the identity must lie in (0, 1]
+    with pytest.raises(EngineError):
+        engine.get_cluster()                     # no clustering has run
     engine.derep()
     with pytest.raises(EngineError):
         engine.search(F1=1e-6, F2=1e-3)

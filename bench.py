@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20 s of CPU work)")
     ap.add_argument("--cluster-id", type=float, default=1.0,
                     help="1.0 = exact dereplication (BASELINE configs[1], the default); < 1 runs row a2 (greedy clustering) instead")
+    ap.add_argument("--taxa", choices=["T", "all"], default="T",
+                    help="T = the stand-in taxon of BASELINE configs[1] (155 ITS2 profiles); all = --taxa All --region ITS2 (814 profiles, configs[3])")
     ap.add_argument("--global-derep", action="store_true",
                     help="N > 1: match the uniques across shards (exact global dereplication, SURVEY 8e option 2) instead of per-shard")
     args = ap.parse_args()
@@ -86,6 +88,9 @@ def main():
     with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
         thmm = f.read()
     hmm = its2_profiles(thmm)
+    if args.taxa == "all":
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "all_its2.hmm.gz"), "rt") as f:
+            hmm = f.read()
     blob, offs = synth.make_reads(thmm, args.reads, config=2, seed=synth.SEED + 2 + 1000 * rank)
     eng = Engine(local_rank)
     nprof = eng.load_profiles(text=hmm)
@@ -165,9 +170,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d synthetic 300 bp single-end reads per GPU, ITS2, cluster_id=1.0 (pure derep)" % args.reads)
+                       if (args.cluster_id >= 1.0 and args.taxa == "T") else
+                       ("%d synthetic 300 bp single-end reads per GPU, --taxa All --region ITS2 (814 profiles, as configs[3]), cluster_id=1.0" % args.reads)
                        if args.cluster_id >= 1.0 else
                        ("%d synthetic 300 bp single-end reads per GPU, ITS2, cluster_id=%g (greedy clustering, row a2)" % (args.reads, args.cluster_id)),
-                       "taxon": "Tracheophyta (stand-in: F.hmm absent from the reference mount)", "profiles": nprof,
+                       "taxon": "Tracheophyta (stand-in: F.hmm absent from the reference mount)" if args.taxa == "T" else "All (every ITSx set in the mount; F.hmm absent)", "profiles": nprof,
                        "unique": int(st["n_unique"]), "pairs_past_msv": int(st["n_past_msv"]), "pairs_past_fwd": int(st["n_past_fwd"]),
                        "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed, "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},

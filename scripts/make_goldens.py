@@ -18,7 +18,8 @@ Outputs
   4774-1-MSITS3_R{1,2}.fastq.gz, seq.fq.gz, t2_r{1,2}.fq.gz
                              inputs and byte-compared outputs of the reference's trimming tests (data)
   T.hmm.gz, mini.hmm         ITSx profile DATA: Tracheophyta set (stand-in taxon for the bench),
-                             and a 6-profile subset for fast tests
+                             and a 10-profile subset for fast tests
+  all_its2.hmm.gz            the --taxa All --region ITS2 runtime profile set (814 profiles) as create_runtime_hmm writes it
 """
 import gzip
 import io
@@ -208,6 +209,11 @@ def main():
             keep.append(b + "//\n")
     with open(os.path.join(OUT, "mini.hmm"), "w") as f:
         f.write("".join(keep))
+    # --taxa All --region ITS2 (BASELINE configs[3]): the runtime file create_runtime_hmm writes, 814 profiles (F.hmm absent)
+    tmp = tempfile.mkdtemp()
+    with open(M.create_runtime_hmm("All", "ITS2", tmp), "rb") as f, gzip.GzipFile(os.path.join(OUT, "all_its2.hmm.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
+    shutil.rmtree(tmp)
     print("goldens written to", OUT)
 
 

@@ -64,6 +64,14 @@ def t_hmm_text():
 
 
 @pytest.fixture(scope="session")
+def all_its2_hmm_text():
+    """--taxa All --region ITS2 as create_runtime_hmm writes it (814 profiles; BASELINE configs[3])"""
+    import gzip
+    with gzip.open(os.path.join(GOLD, "all_its2.hmm.gz"), "rt") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
 def engine():
     from itsxpress_amd import Engine
     e = Engine(0)

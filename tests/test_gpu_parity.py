@@ -280,6 +280,16 @@ def test_file_compatible_outputs_feed_the_reference_parsers(engine, fixture_read
             assert ind[i] == 0
 
 
+def test_search_all_taxa_its2(engine, fixture_reads, all_its2_hmm_text, monkeypatch):
+    """BASELINE configs[3] profile set: --taxa All --region ITS2 = 814 profiles (13 groups of 64 lanes), every stage
+    bit-identical to the oracle on the reference's fixture reads."""
+    monkeypatch.setenv("ITSX_KEEP_TRACE", "1")
+    names, seqs = fixture_reads
+    res = _run_both(engine, all_its2_hmm_text, seqs[:90], threads=64)
+    assert engine.stats()["n_profiles"] == 814
+    _compare(engine, res)
+
+
 def test_errors_are_loud(engine, tmp_path):
     from itsxpress_amd import EngineError
     with pytest.raises(EngineError):

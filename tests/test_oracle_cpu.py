@@ -278,3 +278,14 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "liborc" not in text and "import orc" not in text and "orc_" not in text, fn
                 assert "../oracle" not in text and "oracle/" not in text, fn
+
+
+def test_all_taxa_its2_profile_set(gold):
+    """the 814-profile runtime file of --taxa All --region ITS2 parses, in create_runtime_hmm's order"""
+    import gzip
+    with gzip.open(os.path.join(gold, "all_its2.hmm.gz"), "rt") as f:
+        text = f.read()
+    hs = orc.HmmSet(text=text)
+    golden = json.load(open(os.path.join(gold, "runtime_hmm_names.json")))["names"]["All|ITS2"]
+    assert hs.n == 814 and hs.names == golden
+    assert all(n.startswith(("3_", "4_")) for n in hs.names) and max(hs.M) <= 46

@@ -280,6 +280,14 @@ def test_file_compatible_outputs_feed_the_reference_parsers(engine, fixture_read
             assert ind[i] == 0
 
 
+def test_search_long_reads(engine, mini_hmm_text, monkeypatch):
+    """PacBio-length targets (1.2-2.5 kb): slab rows, per-length tables and the MSV thresholds far from the 300-bp case"""
+    monkeypatch.setenv("ITSX_KEEP_TRACE", "1")
+    blob, offs = synth.make_reads(mini_hmm_text, 60, seed=31, fixed_len=0, len_range=(1200, 2500))
+    res = _run_both(engine, mini_hmm_text, synth.to_strings(blob, offs))
+    _compare(engine, res)
+
+
 def test_search_all_taxa_its2(engine, fixture_reads, all_its2_hmm_text, monkeypatch):
     """BASELINE configs[3] profile set: --taxa All --region ITS2 = 814 profiles (13 groups of 64 lanes), every stage
     bit-identical to the oracle on the reference's fixture reads."""

@@ -192,7 +192,7 @@ def main():
                      "env_rows_per_s_x3_sweeps": 3 * st["env_rows"] / (kern["k_env_fwd+k_env_bwd+k_env_post"] * 1e-3) if kern["k_env_fwd+k_env_bwd+k_env_post"] > 0 else None,
                      "peak_lane_gops": VALU_PEAK_GOPS},
         }
-        if args.cpu_sample != 0:
+        if args.cpu_sample != 0 and world == 1:          # the CPU baseline is a rank-0, N=1 leg only
             threads = os.cpu_count() or 1
             if args.cpu_sample < 0:                      # ~1 s per 80 reads per core on the scalar port
                 args.cpu_sample = int(min(40000, max(1200, 120 * threads)))

@@ -29,7 +29,7 @@ enum {
   ITSX_E_IO          = -2,   /* file could not be read or written */
   ITSX_E_FORMAT      = -3,   /* malformed HMMER3/f or FASTA/FASTQ text, illegal residue */
   ITSX_E_DEVICE      = -4,   /* HIP error or no usable device */
-  ITSX_E_UNSUPPORTED = -5,   /* e.g. model longer than 48 nodes, cluster id < 1.0 */
+  ITSX_E_UNSUPPORTED = -5,   /* e.g. model longer than 46 nodes, read longer than 65535 bases, F2 != F1 */
   ITSX_E_COLLISION   = -6,   /* 64-bit hash collision survived every reseed (never observed) */
   ITSX_E_NOMEM       = -7
 };

@@ -1,0 +1,95 @@
+"""An INDEPENDENT statement of the Plan7 local multihit model, for tests only: HMMER3/f text -> profile (occupancy
+entry distribution, local exits, length model) -> Forward in float64 log space, node by node (no striping, no odds
+ratios, no rescaling).  It shares no code with oracle/ and none of its numerics; tests compare the two at 1e-3 nats,
+which checks the oracle's profile configuration and recursion, not its bit patterns.
+"""
+import math
+
+import numpy as np
+
+NEG = -1e300
+
+
+def parse_hmms(text):
+    """list of dict(name, M, mat[M+1][4] (prob), t[M+1][7] (prob: MM MI MD IM II DM DD), node 0 = begin)"""
+    out = []
+    lines = text.split("\n")
+    i = 0
+    while i < len(lines):
+        if not lines[i].startswith("HMMER3"):
+            i += 1
+            continue
+        name, M = None, 0
+        while not lines[i].startswith("HMM "):
+            if lines[i].startswith("NAME"):
+                name = lines[i].split()[1]
+            if lines[i].startswith("LENG"):
+                M = int(lines[i].split()[1])
+            i += 1
+        i += 2                                   # header line + transition header
+        if lines[i].split()[0] == "COMPO":
+            i += 1
+        p = lambda tok: 0.0 if tok == "*" else math.exp(-float(tok))
+        mat = np.zeros((M + 1, 4))
+        t = np.zeros((M + 1, 7))
+        i += 1                                   # node-0 insert emissions
+        t[0] = [p(x) for x in lines[i].split()[:7]]
+        i += 1
+        for k in range(1, M + 1):
+            tok = lines[i].split()
+            assert int(tok[0]) == k
+            mat[k] = [p(x) for x in tok[1:5]]
+            i += 2                               # match line, insert line
+            t[k] = [p(x) for x in lines[i].split()[:7]]
+            i += 1
+        out.append(dict(name=name, M=M, mat=mat, t=t))
+    return out
+
+
+def forward_nats(h, seq, L_model=None, unihit=False):
+    """ln P(seq | local profile at target length L) - no null model subtracted; emissions as odds vs 0.25.
+    multihit (default): nj = 1, E->J and E->C at 1/2 each; unihit: nj = 0, E->C at 1 (the mode envelopes are re-scored in)"""
+    M, mat, t = h["M"], h["mat"], h["t"]
+    L = len(seq)
+    Lm = L if L_model is None else L_model
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    ln = lambda x: math.log(x) if x > 0 else NEG
+    # entry: match occupancy (p7_hmm_CalculateOccupancy) -> B->Mk = occ[k] / sum_k occ[k] (M-k+1)
+    occ = np.zeros(M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    bm = [NEG] + [ln(occ[k] / Z) for k in range(1, M + 1)]
+    lt = np.vectorize(ln)(t)
+    nj = 0.0 if unihit else 1.0
+    pmove = (2.0 + nj) / (Lm + 2.0 + nj)
+    lmove, lloop = math.log(pmove), math.log(1.0 - pmove)
+    lE = 0.0 if unihit else math.log(0.5)
+    code = {"A": (0,), "C": (1,), "G": (2,), "T": (3,), "U": (3,), "R": (0, 2), "Y": (1, 3), "M": (0, 1), "K": (2, 3), "S": (1, 2),
+            "W": (0, 3), "H": (0, 1, 3), "B": (1, 2, 3), "V": (0, 1, 2), "D": (0, 2, 3), "N": (0, 1, 2, 3)}
+    sc = np.log(mat / 0.25, where=mat > 0, out=np.full(mat.shape, NEG))
+    lse = np.logaddexp
+    Mv = np.full(M + 1, NEG); Iv = np.full(M + 1, NEG); Dv = np.full(M + 1, NEG)
+    xN, xB, xJ, xC = 0.0, lmove, NEG, NEG
+    for i in range(1, L + 1):
+        xs = code[seq[i - 1].upper()]
+        em = sc[:, xs[0]] if len(xs) == 1 else sc[:, list(xs)].mean(axis=1)      # a degenerate symbol scores its expected score
+        Mn = np.full(M + 1, NEG); In = np.full(M + 1, NEG); Dn = np.full(M + 1, NEG)
+        xE = NEG
+        for k in range(1, M + 1):
+            s = xB + bm[k]
+            if k > 1:
+                s = lse(s, lse(lse(Mv[k - 1] + lt[k - 1][MM], Iv[k - 1] + lt[k - 1][IM]), Dv[k - 1] + lt[k - 1][DM]))
+            Mn[k] = s + em[k]
+            if k < M:
+                In[k] = lse(Mv[k] + lt[k][MI], Iv[k] + lt[k][II])      # insert emission odds = 1
+            if k > 1:
+                Dn[k] = lse(Mn[k - 1] + lt[k - 1][MD], Dn[k - 1] + lt[k - 1][DD])
+            xE = lse(xE, lse(Mn[k], Dn[k]))                             # local exits cost nothing
+        xJ = NEG if unihit else lse(xJ + lloop, xE + lE)
+        xC = lse(xC + lloop, xE + lE)
+        xN = xN + lloop
+        xB = lse(xN + lmove, xJ + lmove)
+        Mv, Iv, Dv = Mn, In, Dn
+    return xC + lmove

@@ -289,3 +289,32 @@ def test_all_taxa_its2_profile_set(gold):
     golden = json.load(open(os.path.join(gold, "runtime_hmm_names.json")))["names"]["All|ITS2"]
     assert hs.n == 814 and hs.names == golden
     assert all(n.startswith(("3_", "4_")) for n in hs.names) and max(hs.M) <= 46
+
+
+def test_forward_agrees_with_an_independent_statement(fixture_reads, mini_hmm_text):
+    """Second opinion on the HMM restatement (which no hmmsearch binary pins): a float64 log-space Forward written
+    node by node from the Plan7 definition (tests/hmm_generic.py: occupancy entry, local exits, multihit length model,
+    expected score for degenerate symbols) must give the oracle's striped float32 odds-ratio Forward score to 2e-3 nats,
+    and the oracle's Backward must return the same total as its Forward."""
+    import hmm_generic
+    names, seqs = fixture_reads
+    seqs = seqs[:40]
+    hs = orc.HmmSet(text=mini_hmm_text)
+    hm = hmm_generic.parse_hmms(mini_hmm_text)
+    assert [h["name"] for h in hm] == hs.names and [h["M"] for h in hm] == list(hs.M)
+    codes, off = orc.digitize(seqs)
+    tr = orc.SearchResult(hs, codes, off, keep_trace=1, threads=8).trace
+    tr = tr[tr["pass_bias"] == 1]
+    assert len(tr) >= 20 and any("N" in seqs[int(r["seq"])] for r in tr)
+    for r in tr:
+        g = hmm_generic.forward_nats(hm[int(r["prof"])], seqs[int(r["seq"])])
+        assert abs(g - float(r["fwdsc"])) < 2e-3, (int(r["seq"]), int(r["prof"]), g, float(r["fwdsc"]))
+    pf = tr[tr["pass_fwd"] == 1]
+    assert len(pf) >= 10 and np.all(np.abs(pf["fwdsc"] - pf["bcksc"]) < 2e-3)
+    # envelopes are re-scored in unihit mode with the length model left at the full target length
+    dom = orc.SearchResult(hs, codes, off, keep_trace=1, threads=8).domains
+    assert len(dom) >= 10
+    for d in dom[:40]:
+        s = seqs[int(d["seq"])]
+        g = hmm_generic.forward_nats(hm[int(d["prof"])], s[int(d["ienv"]) - 1:int(d["jenv"])], L_model=len(s), unihit=True)
+        assert abs(g - float(d["envsc"])) < 2e-3, (int(d["seq"]), int(d["prof"]), g, float(d["envsc"]))

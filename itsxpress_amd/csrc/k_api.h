@@ -55,6 +55,8 @@ struct ClusterArgs {
   int32_t *newq, *rm;           // [nq] window index of each speculative centroid; columns to clear after validation
   int32_t *xlist, *xn, *hard; unsigned long long *xkey; double *xpid;            // speculative centroids entering a walk [2 nq][32]
   int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[2]
+  const uint64_t *rhash;        // [n reads] XXH64 of the packed forward strand
+  unsigned long long *ctab_key; int32_t *ctab_val; int32_t *canon;   // window-local table of identical reads; canon[nq]
   int32_t *replay;              // [nq] queries whose walk must be replayed by k_cl_resolve
   int32_t *skipm;               // [nq] minus-strand walk cut short because the plus strand holds a 100 % hit
   int32_t *wout;                // [3] cut, columns consumed, true new centroids

@@ -59,6 +59,46 @@ __device__ __forceinline__ u64 cand_key(uint32_t cnt, int32_t len, int32_t pos)
   return ((u64)cnt << 48) | ((u64)(65535 - len) << 32) | (u64)(0xffffffffu - (uint32_t)pos);
 }
 
+// ------------------------------------------------------------------ identical reads inside a window share one search
+// Exact duplicates have the same words, the same counts and the same walk against the same centroids, so only the
+// first copy in the window (its CANONICAL query) is searched; the copies read its state.  What differs is the
+// position: validation (entrants, replay) stays per query.  canon[qi] = window index of the first identical read.
+static constexpr int CTAB = 16384;
+__device__ __forceinline__ bool same_read(const ReadsDev &rd, int64_t x, int64_t y)
+{
+  const int L = rd.len[x];
+  if (L != rd.len[y]) return false;
+  const int64_t ex = rd.excoff[x], ey = rd.excoff[y];
+  const int ne = (int)(rd.excoff[x + 1] - ex);
+  if (ne != (int)(rd.excoff[y + 1] - ey)) return false;
+  const uint32_t *wx = rd.words + rd.woff[x], *wy = rd.words + rd.woff[y];
+  const int nw = (L + 15) >> 4;
+  for (int i = 0; i < nw; i++) if (wx[i] != wy[i]) return false;
+  for (int i = 0; i < ne; i++) if (rd.exc[ex + i] != rd.exc[ey + i]) return false;
+  return true;
+}
+__global__ void k_cl_canon_insert(ClusterArgs a)
+{
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= a.nq) return;
+  const u64 h = a.rhash[a.order[a.f + qi]] | 1ULL;
+  for (uint32_t slot = (uint32_t)(h >> 17) & (CTAB - 1);; slot = (slot + 1) & (CTAB - 1)) {
+    const u64 prev = atomicCAS(&a.ctab_key[slot], 0ULL, h);
+    if (prev == 0ULL || prev == h) { atomicMin(&a.ctab_val[slot], qi); break; }
+  }
+}
+__global__ void k_cl_canon_lookup(ClusterArgs a)
+{
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= a.nq) return;
+  const int64_t r = a.order[a.f + qi];
+  const u64 h = a.rhash[r] | 1ULL;
+  uint32_t slot = (uint32_t)(h >> 17) & (CTAB - 1);
+  while (a.ctab_key[slot] != h) slot = (slot + 1) & (CTAB - 1);
+  const int c = a.ctab_val[slot];
+  a.canon[qi] = (c < qi && same_read(a.rd, r, a.order[a.f + c])) ? c : qi;
+}
+
 // ------------------------------------------------------------------ distinct 8-mers of each (query, strand)
 __global__ __launch_bounds__(256) void k_cl_kmers(ClusterArgs a)
 {
@@ -67,6 +107,7 @@ __global__ __launch_bounds__(256) void k_cl_kmers(ClusterArgs a)
   __shared__ int32_t part[256];
   const int tid = threadIdx.x;
   const int qs = blockIdx.x, qi = qs >> 1, s = qs & 1;
+  if (a.canon[qi] != qi) return;
   if (s && !a.strand_both) { if (tid == 0) a.nk[qs] = 0; return; }
   const int64_t r = a.order[a.f + qi];
   const int L = a.rd.len[r];
@@ -116,6 +157,7 @@ static constexpr int HCL = 13;          // counts/8 < 8192
 __global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int ntiles)
 {
   const int qs = blockIdx.y;
+  if (a.canon[qs >> 1] != (qs >> 1)) return;
   const int lane = threadIdx.x & 63;
   const int tile = tile0 + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= tile0 + ntiles) return;
@@ -182,7 +224,7 @@ __global__ void k_cl_init(ClusterArgs a)
   if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; a.work_n[0] = 0; a.work_n[1] = 0; }
   if (qs < a.nq) { a.replay[qs] = 0; a.skipm[qs] = 0; }
   if (qs >= 2 * a.nq) return;
-  a.state[qs] = (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;
+  a.state[qs] = a.canon[qs >> 1] != (qs >> 1) ? 4 : (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;      // 4 = a copy: reads its canonical query's state
   a.rejects[qs] = 0; a.acc_col[qs] = -1; a.wn[qs] = 0; a.selm[qs] = 0; a.sel_short[qs] = 0;
   a.prev[qs] = ~0ULL; a.bound[qs] = 0ULL; a.acc_id[qs] = -1.0; a.xn[qs] = 0; a.hard[qs] = 0;
 }
@@ -426,10 +468,11 @@ __global__ void k_cl_outcome(ClusterArgs a)
 {
   const int qi = blockIdx.x * blockDim.x + threadIdx.x;
   if (qi >= a.nq) return;
-  const bool p = a.state[2 * qi] == 1, m = a.state[2 * qi + 1] == 1;
+  const int c2 = 2 * a.canon[qi];
+  const bool p = a.state[c2] == 1, m = a.state[c2 + 1] == 1;
   const bool hit = p || m;
-  const bool minus = m && (!p || a.acc_id[2 * qi + 1] > a.acc_id[2 * qi]);
-  const int k = 2 * qi + (minus ? 1 : 0);
+  const bool minus = m && (!p || a.acc_id[c2 + 1] > a.acc_id[c2]);
+  const int k = c2 + (minus ? 1 : 0);
   const int pos = a.f + qi;
   a.res_col[pos] = hit ? a.acc_col[k] : -1;
   a.res_strand[pos] = (int8_t)(hit && minus ? -1 : 1);
@@ -444,7 +487,7 @@ __global__ __launch_bounds__(64) void k_cl_columns(ClusterArgs a, int clear)
   const int qi = blockIdx.x, lane = threadIdx.x;
   if (clear ? !a.rm[qi] : !a.is_new[qi]) return;
   const int col = a.C + a.new_rank[qi];
-  const int qs = 2 * qi;
+  const int qs = 2 * a.canon[qi];
   const int n = a.nk[qs];
   const uint16_t *kl = a.klist + (size_t)qs * a.kcap;
   const uint32_t bit = 1u << (col & 31);
@@ -468,17 +511,19 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
 {
   __shared__ int xcount;
   const int qs = blockIdx.x, tid = threadIdx.x;
-  const int n = a.nk[qs];
+  const int cqi = a.canon[qs >> 1], cs = 2 * cqi + (qs & 1);      // search state lives with the canonical copy
+  const int n = a.nk[cs];
   if (n == 0) return;
   const int n_new = a.new_rank[a.nq];
   if (n_new == 0) return;
-  if ((qs & 1) && a.skipm[qs >> 1]) return;              // this strand's walk was cut short: it has no say (see k_cl_select)
+  if ((qs & 1) && a.skipm[cqi]) return;                  // this strand's walk was cut short: it has no say (see k_cl_select)
   if (tid == 0) xcount = 0;
   __syncthreads();
   const int pos = a.f + (qs >> 1);
   const uint32_t minm = n < 12 ? n : 12;
-  const u64 bound = a.state[qs] == 3 ? 0ULL : a.bound[qs];
-  const uint16_t *cn = a.cnt + (size_t)qs * a.cpitch;
+  const int state = a.state[cs];
+  const u64 bound = state == 3 ? 0ULL : a.bound[cs];
+  const uint16_t *cn = a.cnt + (size_t)cs * a.cpitch;
   for (int c = a.C + tid; c < a.C + n_new; c += 256) {
     if (a.cent_pos[c] >= pos) break;
     const uint32_t v = cn[c];
@@ -496,7 +541,7 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
     a.hard[qs] = cnt > 32; a.xn[qs] = cnt > 32 ? 0 : cnt;
     if (cnt > 32) a.replay[qs >> 1] = 1;
     else if (cnt > 0) {
-      if (a.state[qs] == 1 && a.rejects[qs] + cnt >= 32) a.replay[qs >> 1] = 1;     // the accepted hit could fall out of the reject budget
+      if (state == 1 && a.rejects[cs] + cnt >= 32) a.replay[qs >> 1] = 1;     // the accepted hit could fall out of the reject budget
       const int w0 = atomicAdd(&a.work_n[1], cnt);
       for (int k = 0; k < cnt; k++) a.xwork[w0 + k] = qs * 32 + k;
     }
@@ -553,11 +598,12 @@ __global__ __launch_bounds__(64) void k_cl_resolve(ClusterArgs a)
     const int qi = list[t];
     if (a.hard[2 * qi] || a.hard[2 * qi + 1]) { cut = qi; if (lane == 0) atomicAdd(&a.dbg[0], 1); break; }
     int hcol[2]; double hid[2];
+    const int cqi = a.canon[qi];
     for (int s = 0; s < 2; s++) {
-      const int qs = 2 * qi + s;
-      const int wn = a.wn[qs], xn = a.xn[qs];
+      const int qs = 2 * qi + s, cs = 2 * cqi + s;       // the walk was recorded for the canonical copy, the entrants are this query's
+      const int wn = a.wn[cs], xn = a.xn[qs];
       u64 key = 0; double pid = -1.0; int col = -1;
-      if (lane < 32) { if (lane < wn) { key = a.wkey[qs * 32 + lane]; pid = a.wpid[qs * 32 + lane]; col = a.wcol[qs * 32 + lane]; } }
+      if (lane < 32) { if (lane < wn) { key = a.wkey[cs * 32 + lane]; pid = a.wpid[cs * 32 + lane]; col = a.wcol[cs * 32 + lane]; } }
       else if (lane - 32 < xn) {
         const int c = a.xlist[qs * 32 + lane - 32];
         if (tnew[a.newq[c - a.C]]) { key = a.xkey[qs * 32 + lane - 32]; pid = a.xpid[qs * 32 + lane - 32]; col = c; }
@@ -574,7 +620,7 @@ __global__ __launch_bounds__(64) void k_cl_resolve(ClusterArgs a)
         hcol[s] = __shfl(col, src); hid[s] = __shfl(pid, src);
       }
     }
-    if (a.skipm[qi]) {
+    if (a.skipm[cqi]) {
       if (!(hcol[0] >= 0 && hid[0] == 100.0)) { cut = qi; if (lane == 0) atomicAdd(&a.dbg[1], 1); break; }   // the 100 % plus hit is gone: search again
       hcol[1] = -1;
     }
@@ -620,7 +666,14 @@ __global__ void k_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *ds
 }
 
 // ------------------------------------------------------------------ launchers
-void launch_cl_kmers(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_kmers, dim3(2 * a.nq), dim3(256), 0, st, a); }
+void launch_cl_kmers(const ClusterArgs &a, hipStream_t st)
+{
+  (void)hipMemsetAsync(a.ctab_key, 0, CTAB * sizeof(unsigned long long), st);
+  (void)hipMemsetAsync(a.ctab_val, 0x7f, CTAB * sizeof(int32_t), st);
+  hipLaunchKernelGGL(k_cl_canon_insert, dim3((a.nq + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_cl_canon_lookup, dim3((a.nq + 255) / 256), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_cl_kmers, dim3(2 * a.nq), dim3(256), 0, st, a);
+}
 void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st)
 {
   if (ntiles <= 0) return;

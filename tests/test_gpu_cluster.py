@@ -115,6 +115,18 @@ def test_cluster_multipass_alignment(engine, monkeypatch):
     _compare(engine, reads, names, 0.99)
 
 
+def test_cluster_index_growth(engine, monkeypatch):
+    # more centroids than the initial column capacity of the bit matrix: the index is re-laid out (twice) on the way
+    monkeypatch.setenv("ITSX_CL_CAPACITY", "2048")
+    rng = np.random.default_rng(5)
+    acgt = np.array(list("ACGT"))
+    reads = ["".join(acgt[rng.integers(0, 4, 60)]) for _ in range(7000)]          # unrelated: (almost) every read a centroid
+    reads += reads[:500]                                                          # and some duplicates that must find theirs
+    names = ["g%05d" % i for i in range(len(reads))]
+    o, st = _compare(engine, reads, names, 0.97)
+    assert o["n_centroids"] >= 6900
+
+
 def test_cluster_edge_cases(engine):
     # short reads vanish; a read of only N has no words and becomes its own centroid; duplicates join at 100 %
     base = "ACGTTGCAAGCTTAGGCTAACGGTCAGTCCATGGATCAGGCTTAAGCCGGTATCGATTACGGCAT" * 3

@@ -83,6 +83,7 @@ typedef struct {
   float   ms_decode_kernel;  int32_t n_batches;          /* launches of each DP kernel in the last search */
   float   ms_cluster;        int32_t pad0;               /* itsx_cluster at id < 1: whole call */
   int64_t cl_windows, cl_cuts, cl_alignments;            /* speculative windows, windows cut by validation, alignments */
+  float   ms_merge;          int32_t pad1;               /* k_merge of the last itsx_merge_* call */
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -112,6 +113,22 @@ int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int
                    const char *names, const int64_t *name_offsets);
 /* FASTA or FASTQ file, plain or gzip (.gz): native parser for the same input. */
 int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
+
+/* ---- f2: SeqSample._merge_reads (itsxpress/SeqSample.py:266-365) = vsearch --fastq_mergepairs R1 --reverse R2
+ * --fastqout seq.fq --fastq_maxdiffs 40 --fastq_maxee 2 --fastq_qmax 93 [--fastq_allowmergestagger]; restated in
+ * oracle/orc_merge.c (parity unpinned: the reference's merged fixture was made by another tool).
+ * itsx_merge_buffers: pair i = forward read fseq/fqual[foff[i]..foff[i+1]) and reverse read (as in the file)
+ * rseq/rqual[roff[i]..roff[i+1]); the merged read of pair i is written at out_seq/out_qual[foff[i] + roff[i]] with
+ * length out_len[i]; reason[i]: 0 merged, 1 no shared 5-mers, 2 several candidate alignments, 3 score < 16,
+ * 4 > maxdiffs, 5 overlap < 10, 6 staggered, 7 expected errors > maxee, 8 empty/too long.  score/shift may be NULL.
+ * itsx_merge_pairs_files: FASTQ (plain/gzip) in, plain FASTQ out, labels = forward identifier up to the first blank.
+ * itsx_merge_tables: the score / quality tables (context-free; tests compare them with the oracle's). */
+int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const int64_t *foff, const char *rseq, const char *rqual,
+                       const int64_t *roff, int64_t n, int maxdiffs, double maxee, int allow_stagger,
+                       char *out_seq, char *out_qual, int32_t *out_len, int32_t *reason, double *score, int32_t *shift);
+int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_path, const char *out_path, int maxdiffs, double maxee,
+                           int allow_stagger, int64_t *n_pairs, int64_t *n_merged);
+int itsx_merge_tables(double *q2p, double *match, double *mism, uint8_t *qsame, uint8_t *qdiff);
 
 /* ---- a1: SeqSample.deduplicate (itsxpress/SeqSample.py:93-131)
  * = vsearch --fastx_uniques --strand both; minseqlength 32 is vsearch's default. */

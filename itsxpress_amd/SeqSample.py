@@ -19,6 +19,7 @@ from typing import Any, Dict, Optional, Tuple, Union
 
 from .engine import Engine
 from ._lib import EngineError
+from .definitions import maxmismatches
 
 logger = logging.getLogger(__name__)
 
@@ -133,8 +134,7 @@ class SeqSampleNotPaired(SeqSample):
 
 
 class SeqSamplePairedNotInterleaved(SeqSample):
-    """Paired input in two files (SeqSample.py:244-264).  Merging the pairs is upstream of the
-    hot path and not part of this engine: set `seq_file` to the merged reads."""
+    """Paired input in two files (SeqSample.py:244-264)."""
 
     def __init__(self, fastq: str, tempdir: str, fastq2: str, reversed_primers: bool = False) -> None:
         SeqSample.__init__(self, fastq, tempdir)
@@ -144,6 +144,29 @@ class SeqSamplePairedNotInterleaved(SeqSample):
         else:
             self.r1 = fastq
             self.fastq2 = fastq2
+
+    # -- f2 --------------------------------------------------------------------------
+    def _merge_reads(self, threads: Union[int, str], stagger: bool = False) -> None:
+        """Replaces `vsearch --fastq_mergepairs R1 --reverse R2 --fastqout seq.fq --fastq_maxdiffs 40 --fastq_maxee 2
+        --fastq_qmax 93 [--fastq_allowmergestagger]` (SeqSample.py:266-365; constants definitions.py:79-82) with the
+        engine's merge kernel; writes tempdir/seq.fq and points seq_file at it, as the reference does."""
+        try:
+            if self.r1 is None or self.fastq2 is None:
+                raise ValueError("Both r1 and fastq2 paths must be defined to merge reads.")
+            if self.r1.endswith(".zst") or self.fastq2.endswith(".zst"):
+                raise EngineError(-5, "zstd-compressed input is not supported by the HIP engine (no libzstd in this build)")
+            os.makedirs(self.tempdir, exist_ok=True)
+            seq_file = os.path.join(self.tempdir, "seq.fq")
+            n, m = self.engine.merge_pairs_files(self.r1, self.fastq2, seq_file, maxdiffs=maxmismatches, maxee=2.0,
+                                                 allow_stagger=bool(stagger))
+            logging.info("%d pairs, %d merged", n, m)
+            self.seq_file = seq_file
+        except EngineError as e:
+            logging.exception("Could not perform read merging with the HIP engine: %s", e)
+            raise e
+        except FileNotFoundError as f:
+            logging.error("The HIP engine or its input was not found")
+            raise f
 
 
 class ItsPosition:

@@ -43,7 +43,8 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("msv_cells", "<i8"), ("msv_launches", "<i8"), ("ms_fwd_kernel", "<f4"), ("ms_bwd_kernel", "<f4"),
                 ("fwd_rows", "<i8"), ("ms_env_kernel", "<f4"), ("ms_bias_kernel", "<f4"), ("env_rows", "<i8"),
                 ("n_env_unique", "<i8"), ("ms_decode_kernel", "<f4"), ("n_batches", "<i4"), ("ms_cluster", "<f4"),
-                ("pad0", "<i4"), ("cl_windows", "<i8"), ("cl_cuts", "<i8"), ("cl_alignments", "<i8")]
+                ("pad0", "<i4"), ("cl_windows", "<i8"), ("cl_cuts", "<i8"), ("cl_alignments", "<i8"), ("ms_merge", "<f4"),
+                ("pad1", "<i4")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares
@@ -54,7 +55,8 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
            "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
            "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath",
-           "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error"]
+           "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
+           "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_tables"]
 
 
 def lib():
@@ -82,6 +84,9 @@ def lib():
         "itsx_derep": (i32, [vp, i32, i32, vp]),
         "itsx_cluster": (i32, [vp, f64, i32, vp]),
         "itsx_get_cluster": (i32, [vp, vp, vp, vp]),
+        "itsx_merge_buffers": (i32, [vp, cp, cp, vp, cp, cp, vp, i64, i32, f64, i32, vp, vp, vp, vp, vp, vp]),
+        "itsx_merge_pairs_files": (i32, [vp, cp, cp, cp, i32, f64, i32, vp, vp]),
+        "itsx_merge_tables": (i32, [vp, vp, vp, vp, vp]),
         "itsx_unique_keys": (i32, [vp, C.c_uint64, vp, vp]),
         "itsx_set_active_uniques": (i32, [vp, vp]),
         "itsx_get_derep": (i32, [vp, vp, vp, vp]),

@@ -1267,6 +1267,148 @@ int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows)
   return ITSX_OK;
 }
 
+
+// ------------------------------------------------------------------------------ f2: paired-end merge (k_merge.hip)
+extern "C++" {
+namespace {
+struct MergeTables {
+  std::vector<double> q2p, match, mism; std::vector<uint8_t> qsame, qdiff;
+  MergeTables() : q2p(128, 0.0), match(128 * 128, 0.0), mism(128 * 128, 0.0), qsame(128 * 128, 0), qdiff(128 * 128, 0)
+  {
+    // quality-aware scores and merged qualities of vsearch --fastq_mergepairs (Edgar & Flyvbjerg 2015), host libm
+    auto q_to_p = [](int c) { const int x = c - 33; return x < 2 ? 0.75 : pow(10.0, -(double)x / 10.0); };
+    auto qual_of = [](double p) { double q = rint(-10.0 * log10(p)); if (q > 41.0) q = 41.0; if (q < 0.0) q = 0.0; return (uint8_t)(33 + (int)q); };
+    for (int x = 33; x < 127; x++) {
+      const double px = q_to_p(x);
+      q2p[x] = px;
+      for (int y = 33; y < 127; y++) {
+        const double py = q_to_p(y);
+        qsame[x * 128 + y] = qual_of(px * py / 3.0 / (1.0 - px - py + 4.0 * px * py / 3.0));
+        qdiff[x * 128 + y] = qual_of(px * (1.0 - py / 3.0) / (px + py - 4.0 * px * py / 3.0));
+        match[x * 128 + y] = log2((1.0 - px - py + px * py * 4.0 / 3.0) / 0.25);
+        mism[x * 128 + y] = log2(((px + py) / 3.0 - px * py * 4.0 / 9.0) / 0.25);
+      }
+    }
+  }
+};
+const MergeTables &merge_tables() { static MergeTables t; return t; }
+}  // namespace
+}  // extern "C++"
+
+int itsx_merge_tables(double *q2p, double *match, double *mism, uint8_t *qsame, uint8_t *qdiff)
+{
+  const MergeTables &t = merge_tables();
+  if (q2p) memcpy(q2p, t.q2p.data(), 128 * sizeof(double));
+  if (match) memcpy(match, t.match.data(), 128 * 128 * sizeof(double));
+  if (mism) memcpy(mism, t.mism.data(), 128 * 128 * sizeof(double));
+  if (qsame) memcpy(qsame, t.qsame.data(), 128 * 128);
+  if (qdiff) memcpy(qdiff, t.qdiff.data(), 128 * 128);
+  return ITSX_OK;
+}
+
+int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const int64_t *foff, const char *rseq, const char *rqual,
+                       const int64_t *roff, int64_t n, int maxdiffs, double maxee, int allow_stagger,
+                       char *out_seq, char *out_qual, int32_t *out_len, int32_t *reason, double *score, int32_t *shift)
+{
+  CTXCHK(ctx && foff && roff && n >= 0 && out_len && reason && (n == 0 || (fseq && fqual && rseq && rqual && out_seq && out_qual)));
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n == 0) return ITSX_OK;
+  const int64_t fb = foff[n], rb = roff[n];
+  int64_t max_total = 2;
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t fl = foff[i + 1] - foff[i], rl = roff[i + 1] - roff[i];
+    if (fl < 0 || rl < 0) SET_ERR(ctx, ITSX_E_ARG, "offsets must be non-decreasing");
+    max_total = std::max(max_total, fl + rl);
+  }
+  if (max_total > 12000) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "read pairs longer than 12000 bases in total are not supported by the merge kernel");
+  for (int64_t i = 0; i < fb; i++) if ((unsigned char)fqual[i] < 33 || (unsigned char)fqual[i] > 126) SET_ERR(ctx, ITSX_E_FORMAT, "forward quality outside ASCII 33..126 (--fastq_qmax 93)");
+  for (int64_t i = 0; i < rb; i++) if ((unsigned char)rqual[i] < 33 || (unsigned char)rqual[i] > 126) SET_ERR(ctx, ITSX_E_FORMAT, "reverse quality outside ASCII 33..126 (--fastq_qmax 93)");
+  const MergeTables &t = merge_tables();
+  DBuf<uint8_t> d_fs, d_fq, d_rs, d_rq, d_os, d_oq, d_qs, d_qd; DBuf<int64_t> d_fo, d_ro; DBuf<int32_t> d_len, d_reason, d_shift; DBuf<double> d_q2p, d_m, d_x, d_score;
+  HIPCHK(d_fs.alloc((size_t)fb + 1)); HIPCHK(d_fq.alloc((size_t)fb + 1)); HIPCHK(d_rs.alloc((size_t)rb + 1)); HIPCHK(d_rq.alloc((size_t)rb + 1));
+  HIPCHK(d_os.alloc((size_t)(fb + rb) + 1)); HIPCHK(d_oq.alloc((size_t)(fb + rb) + 1));
+  HIPCHK(d_fo.alloc((size_t)n + 1)); HIPCHK(d_ro.alloc((size_t)n + 1)); HIPCHK(d_len.alloc((size_t)n)); HIPCHK(d_reason.alloc((size_t)n)); HIPCHK(d_shift.alloc((size_t)n)); HIPCHK(d_score.alloc((size_t)n));
+  HIPCHK(upload(d_q2p, t.q2p, ctx->st)); HIPCHK(upload(d_m, t.match, ctx->st)); HIPCHK(upload(d_x, t.mism, ctx->st));
+  HIPCHK(upload(d_qs, t.qsame, ctx->st)); HIPCHK(upload(d_qd, t.qdiff, ctx->st));
+  HIPCHK(hipMemcpyAsync(d_fs.p, fseq, (size_t)fb, hipMemcpyHostToDevice, ctx->st)); HIPCHK(hipMemcpyAsync(d_fq.p, fqual, (size_t)fb, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(d_rs.p, rseq, (size_t)rb, hipMemcpyHostToDevice, ctx->st)); HIPCHK(hipMemcpyAsync(d_rq.p, rqual, (size_t)rb, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(d_fo.p, foff, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->st)); HIPCHK(hipMemcpyAsync(d_ro.p, roff, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->st));
+  MergeArgs a{};
+  a.fseq = d_fs.p; a.fqual = d_fq.p; a.rseq = d_rs.p; a.rqual = d_rq.p; a.foff = d_fo.p; a.roff = d_ro.p; a.n = n; a.max_total = (int32_t)max_total;
+  a.maxdiffs = maxdiffs; a.allow_stagger = allow_stagger ? 1 : 0; a.maxee = maxee;
+  a.q2p = d_q2p.p; a.match = d_m.p; a.mism = d_x.p; a.qsame = d_qs.p; a.qdiff = d_qd.p;
+  a.out_seq = d_os.p; a.out_qual = d_oq.p; a.out_len = d_len.p; a.reason = d_reason.p; a.shift = d_shift.p; a.score = d_score.p;
+  StageTimer tm(ctx->st);
+  launch_merge(a, ctx->st);
+  ctx->stats.ms_merge = tm.stop();
+  HIPCHK(hipMemcpyAsync(out_seq, d_os.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st)); HIPCHK(hipMemcpyAsync(out_qual, d_oq.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(out_len, d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st)); HIPCHK(hipMemcpyAsync(reason, d_reason.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
+  if (score) HIPCHK(hipMemcpyAsync(score, d_score.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
+  if (shift) HIPCHK(hipMemcpyAsync(shift, d_shift.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
+
+// FASTQ in, FASTQ out: R1/R2 (plain or gzip) -> merged reads, labels = forward read's identifier up to the first blank
+int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_path, const char *out_path, int maxdiffs, double maxee,
+                           int allow_stagger, int64_t *n_pairs, int64_t *n_merged)
+{
+  CTXCHK(ctx && r1_path && r2_path && out_path);
+  struct Side { std::string seq, qual; std::vector<int64_t> off{0}; std::vector<std::string> ids; };
+  auto parse = [&](const char *path, Side &sd) -> int {
+    std::string text;
+    if (slurp(path, text) != 0) { ctx->set_error(std::string("cannot read ") + path); return ITSX_E_IO; }
+    const char *s = text.data(), *end = s + text.size();
+    auto line = [&](const char *&b, const char *&e) -> bool {
+      if (s >= end) return false;
+      b = s; const char *nl = (const char *)memchr(s, '\n', (size_t)(end - s));
+      e = nl ? nl : end; s = nl ? nl + 1 : end;
+      if (e > b && e[-1] == '\r') e--;
+      return true;
+    };
+    const char *b, *e;
+    while (line(b, e)) {
+      if (b == e) continue;
+      const char *sb, *se, *pb, *pe, *qb, *qe;
+      if (*b != '@' || !line(sb, se) || !line(pb, pe) || !line(qb, qe) || pb == pe || *pb != '+' || (qe - qb) != (se - sb)) {
+        ctx->set_error(std::string("malformed FASTQ record ") + std::to_string(sd.ids.size() + 1) + " in " + path); return ITSX_E_FORMAT;
+      }
+      const char *ne = b + 1; while (ne < e && *ne != ' ' && *ne != '\t') ne++;
+      sd.ids.emplace_back(b + 1, ne);
+      const size_t o = sd.seq.size();
+      sd.seq.append(sb, se); sd.qual.append(qb, qe);
+      for (size_t i = o; i < sd.seq.size(); i++) sd.seq[i] = (char)toupper((unsigned char)sd.seq[i]);
+      sd.off.push_back((int64_t)sd.seq.size());
+    }
+    return ITSX_OK;
+  };
+  Side f, r;
+  int rc = parse(r1_path, f); if (rc != ITSX_OK) return rc;
+  rc = parse(r2_path, r); if (rc != ITSX_OK) return rc;
+  if (f.ids.size() != r.ids.size()) SET_ERR(ctx, ITSX_E_FORMAT, "R1 and R2 hold different numbers of records");
+  const int64_t n = (int64_t)f.ids.size();
+  std::string oseq((size_t)(f.seq.size() + r.seq.size()) + 1, '\0'), oqual = oseq;
+  std::vector<int32_t> olen((size_t)n + 1), reason((size_t)n + 1);
+  rc = itsx_merge_buffers(ctx, f.seq.data(), f.qual.data(), f.off.data(), r.seq.data(), r.qual.data(), r.off.data(), n, maxdiffs, maxee, allow_stagger,
+                          &oseq[0], &oqual[0], olen.data(), reason.data(), nullptr, nullptr);
+  if (rc != ITSX_OK) return rc;
+  FILE *fo = fopen(out_path, "w");
+  if (!fo) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + out_path);
+  int64_t merged = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (reason[i] != 0) continue;
+    const size_t o = (size_t)(f.off[i] + r.off[i]);
+    fputc('@', fo); fwrite(f.ids[i].data(), 1, f.ids[i].size(), fo); fputc('\n', fo);
+    fwrite(oseq.data() + o, 1, (size_t)olen[i], fo); fputs("\n+\n", fo);
+    fwrite(oqual.data() + o, 1, (size_t)olen[i], fo); fputc('\n', fo);
+    merged++;
+  }
+  fclose(fo);
+  if (n_pairs) *n_pairs = n;
+  if (n_merged) *n_merged = merged;
+  return ITSX_OK;
+}
+
 // ------------------------------------------------------------------------------ coordinates
 static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per_read, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
 {

@@ -76,6 +76,20 @@ void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col
                         const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st);
 void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride, hipStream_t st);
 
+// ---- k_merge.hip (paired-end merge)
+struct MergeArgs {
+  const uint8_t *fseq, *fqual, *rseq, *rqual;   // ASCII bases / qualities of the forward and the reverse reads, concatenated
+  const int64_t *foff, *roff;                   // [n+1]
+  int64_t n;
+  int32_t max_total;                            // largest fl + rl (sizes the LDS)
+  int32_t maxdiffs, allow_stagger; double maxee;
+  const double *q2p, *match, *mism;             // [128], [128*128], [128*128]
+  const uint8_t *qsame, *qdiff;                 // [128*128]
+  uint8_t *out_seq, *out_qual;                  // merged read of pair i at foff[i] + roff[i]
+  int32_t *out_len, *reason, *shift; double *score;
+};
+void launch_merge(const MergeArgs &a, hipStream_t st);
+
 // ---- k_util.hip
 // exclusive prefix sum of n int32 values (n < 2^31); tmp must hold scan_tmp_elems(n) int32
 int64_t scan_tmp_elems(int64_t n);

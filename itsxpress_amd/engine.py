@@ -130,6 +130,42 @@ class Engine:
         self.n_unique = n.value
         return n.value
 
+    # ---- f2: paired-end merge
+    def merge_pairs(self, fwd, fqual, rev, rqual, maxdiffs=40, maxee=2.0, allow_stagger=False):
+        """Lists of equal length (str): forward reads / qualities, reverse reads / qualities as they are in the file.
+        Returns (reason int32[n], merged list[(seq, qual) or None], score float64[n], shift int32[n])."""
+        n = len(fwd)
+        enc = lambda xs: ("".join(xs)).encode()
+        fo = np.zeros(n + 1, np.int64); np.cumsum([len(x) for x in fwd], out=fo[1:])
+        ro = np.zeros(n + 1, np.int64); np.cumsum([len(x) for x in rev], out=ro[1:])
+        fs, fq, rs, rq = enc(fwd), enc(fqual), enc(rev), enc(rqual)
+        assert len(fs) == len(fq) and len(rs) == len(rq)
+        cap = int(fo[-1] + ro[-1]) + 1
+        oseq = C.create_string_buffer(cap)
+        oqual = C.create_string_buffer(cap)
+        olen = np.zeros(max(1, n), np.int32)
+        reason = np.zeros(max(1, n), np.int32)
+        score = np.zeros(max(1, n), np.float64)
+        shift = np.zeros(max(1, n), np.int32)
+        self._chk(self.L.itsx_merge_buffers(self.h, fs, fq, fo.ctypes.data, rs, rq, ro.ctypes.data, n, int(maxdiffs), float(maxee),
+                                            int(allow_stagger), oseq, oqual, olen.ctypes.data, reason.ctypes.data,
+                                            score.ctypes.data, shift.ctypes.data))
+        merged = []
+        for i in range(n):
+            o = int(fo[i] + ro[i])
+            merged.append((oseq.raw[o:o + olen[i]].decode(), oqual.raw[o:o + olen[i]].decode()) if reason[i] == 0 else None)
+        return reason[:n], merged, score[:n], shift[:n]
+
+    def merge_pairs_files(self, r1, r2, out, maxdiffs=40, maxee=2.0, allow_stagger=False):
+        for p in (r1, r2):
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+        n = C.c_int64(0)
+        m = C.c_int64(0)
+        self._chk(self.L.itsx_merge_pairs_files(self.h, os.fsencode(r1), os.fsencode(r2), os.fsencode(out), int(maxdiffs),
+                                                float(maxee), int(allow_stagger), C.byref(n), C.byref(m)))
+        return n.value, m.value
+
     def get_cluster(self):
         """After cluster(id < 1): (pct_id float64[n_reads] (-1 for centroids / dropped), order int64[kept])."""
         pct = np.zeros(self.n_reads, np.float64)

@@ -161,6 +161,11 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
                     double id, int strand_both, int minlen, int64_t *rep_of, int8_t *strand, double *pct_id, int64_t *order,
                     int64_t *stats);
 
+/* ---- paired-end merging (vsearch --fastq_mergepairs restated; orc_merge.c; PARITY UNPINNED) ---- */
+int  orc_merge_pair(const char *f, const char *fq, int fl, const char *r, const char *rq, int rl, int maxdiffs, double maxee,
+                    int allow_stagger, char *out_seq, char *out_qual, int *out_len, double *ret_score, int *ret_shift);
+void orc_merge_tables(double *q2p, double *match, double *mism, unsigned char *qsame, unsigned char *qdiff);
+
 #ifdef __cplusplus
 }
 #endif

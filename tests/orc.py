@@ -90,6 +90,11 @@ def lib():
     L.orc_cluster.restype = C.c_int64
     L.orc_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_merge_pair.restype = C.c_int
+    L.orc_merge_pair.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_merge_tables.restype = None
+    L.orc_merge_tables.argtypes = [C.c_void_p] * 5
     L.orc_xxh64.restype = C.c_uint64
     L.orc_xxh64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64]
     L.orc_det_log.restype = C.c_double
@@ -251,3 +256,29 @@ def cluster(codes, offsets, labels=None, cluster_id=0.995, strand_both=True, min
                            float(cluster_id), int(strand_both), minlen, rep_of.ctypes.data, strand.ctypes.data,
                            pct.ctypes.data, order.ctypes.data, stats.ctypes.data)
     return dict(rep_of=rep_of, strand=strand, pct_id=pct, order=order[:nk], n_alignments=int(stats[0]), n_centroids=int(stats[1]))
+
+
+MERGE_REASONS = ["ok", "nokmers", "repeat", "minscore", "maxdiffs", "minovlen", "staggered", "maxee", "empty"]
+
+
+def merge_pair(f, fq, r, rq, maxdiffs=40, maxee=2.0, allow_stagger=False):
+    """vsearch --fastq_mergepairs restated (orc_merge.c): returns (reason, merged_seq, merged_qual, score, shift)."""
+    fb, fqb, rb, rqb = f.encode(), fq.encode(), r.encode(), rq.encode()
+    out_s = C.create_string_buffer(len(fb) + len(rb) + 1)
+    out_q = C.create_string_buffer(len(fb) + len(rb) + 1)
+    n = C.c_int(0)
+    sc = C.c_double(0)
+    sh = C.c_int(0)
+    rc = lib().orc_merge_pair(fb, fqb, len(fb), rb, rqb, len(rb), maxdiffs, maxee, int(allow_stagger), out_s, out_q,
+                              C.byref(n), C.byref(sc), C.byref(sh))
+    return MERGE_REASONS[rc], out_s.raw[:n.value].decode(), out_q.raw[:n.value].decode(), sc.value, sh.value
+
+
+def merge_tables():
+    q2p = np.zeros(128, np.float64)
+    match = np.zeros((128, 128), np.float64)
+    mism = np.zeros((128, 128), np.float64)
+    qsame = np.zeros((128, 128), np.uint8)
+    qdiff = np.zeros((128, 128), np.uint8)
+    lib().orc_merge_tables(q2p.ctypes.data, match.ctypes.data, mism.ctypes.data, qsame.ctypes.data, qdiff.ctypes.data)
+    return q2p, match, mism, qsame, qdiff

@@ -114,6 +114,15 @@ int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int
 /* FASTA or FASTQ file, plain or gzip (.gz): native parser for the same input. */
 int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
 
+/* ---- f4: SeqSample.orient_reads (itsxpress/SeqSample.py:48-91) = vsearch --orient IN --db REF --fastqout OUT
+ * (12-mer presence counts on both strands, 4x rule; restated in oracle/orc_cluster.c, parity unpinned).
+ * itsx_orient_load_db: FASTA (plain/gzip) of reference sequences -> 12-mer bitmap on the device.
+ * itsx_orient: per loaded read strand = +1 forward, -1 reverse (to be reverse-complemented), 0 undetermined; counts may be NULL.
+ * itsx_write_oriented_fastq (host, context-free): the FASTQ vsearch would write for those orientations. */
+int itsx_orient_load_db(itsx_ctx *ctx, const char *fasta_path, int64_t *n_sequences);
+int itsx_orient(itsx_ctx *ctx, int8_t *strand, int32_t *count_fwd, int32_t *count_rev);
+int itsx_write_oriented_fastq(const char *seq_path, const char *out_path, const int8_t *strand, int64_t n_records, int64_t *n_written);
+
 /* ---- f2: SeqSample._merge_reads (itsxpress/SeqSample.py:266-365) = vsearch --fastq_mergepairs R1 --reverse R2
  * --fastqout seq.fq --fastq_maxdiffs 40 --fastq_maxee 2 --fastq_qmax 93 [--fastq_allowmergestagger]; restated in
  * oracle/orc_merge.c (parity unpinned: the reference's merged fixture was made by another tool).

@@ -57,6 +57,32 @@ class SeqSample:
             eng.load_reads_file(self.seq_file)
             self._reads_loaded_from = self.seq_file
 
+    # -- f4 --------------------------------------------------------------------------
+    def orient_reads(self, threads: Union[int, str] = 1) -> None:
+        """Replaces `vsearch --orient FASTQ --db universal_orient_ref_clean.fasta.gz --fastqout oriented.fq`
+        (SeqSample.py:48-91): 12-mer counts on both strands on the GPU, then the oriented FASTQ; the sample's
+        fastq / seq_file / r1 point at it afterwards, as in the reference."""
+        try:
+            from .definitions import ROOT_DIR
+            from .trim import write_oriented_fastq
+            orient_ref = os.path.join(ROOT_DIR, "universal_orient_ref_clean.fasta.gz")
+            oriented_fastq = os.path.join(self.tempdir, "oriented.fq")
+            os.makedirs(self.tempdir, exist_ok=True)
+            self.engine.orient_load_db(orient_ref)
+            self.engine.load_reads_file(self.fastq)
+            strand, _, _ = self.engine.orient()
+            write_oriented_fastq(self.fastq, oriented_fastq, strand)
+            self.fastq = oriented_fastq
+            self.seq_file = oriented_fastq
+            self.r1 = oriented_fastq
+            self._reads_loaded_from = None
+        except EngineError as e:
+            logging.exception("Could not orient reads with the HIP engine: %s", e)
+            raise e
+        except FileNotFoundError as f:
+            logging.error("The HIP engine, the reads or the orientation reference were not found")
+            raise f
+
     # -- a1 --------------------------------------------------------------------------
     def deduplicate(self, threads: Union[int, str] = 1) -> None:
         """Replaces `vsearch --fastx_uniques ... --strand both` (SeqSample.py:93-131)."""

@@ -56,7 +56,8 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
            "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath",
            "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
-           "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_tables"]
+           "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_tables",
+           "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq"]
 
 
 def lib():
@@ -87,6 +88,9 @@ def lib():
         "itsx_merge_buffers": (i32, [vp, cp, cp, vp, cp, cp, vp, i64, i32, f64, i32, vp, vp, vp, vp, vp, vp]),
         "itsx_merge_pairs_files": (i32, [vp, cp, cp, cp, i32, f64, i32, vp, vp]),
         "itsx_merge_tables": (i32, [vp, vp, vp, vp, vp]),
+        "itsx_orient_load_db": (i32, [vp, cp, vp]),
+        "itsx_orient": (i32, [vp, vp, vp, vp]),
+        "itsx_write_oriented_fastq": (i32, [cp, cp, vp, i64, vp]),
         "itsx_unique_keys": (i32, [vp, C.c_uint64, vp, vp]),
         "itsx_set_active_uniques": (i32, [vp, vp]),
         "itsx_get_derep": (i32, [vp, vp, vp, vp]),

@@ -146,6 +146,7 @@ struct itsx_ctx {
   DBuf<int8_t> d_strand;
   std::vector<int32_t> h_rep_of, h_uniq_of, h_seed_read, h_abund, h_sorted_uniq;
   std::vector<int8_t> h_strand;
+  DBuf<uint32_t> d_orient_db; bool have_orient_db = false;   // f4: the orientation database's 12-mer bitmap
   bool clustered = false;                // last grouping came from itsx_cluster at id < 1 (uc rows carry identities)
   std::vector<double> h_pct;             // per read: identity of its H row, -1 for centroids / dropped reads
   std::vector<int32_t> h_order;          // kept reads in processing (label) order
@@ -1267,6 +1268,53 @@ int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows)
   return ITSX_OK;
 }
 
+
+
+// ------------------------------------------------------------------------------ f4: read orientation
+int itsx_orient_load_db(itsx_ctx *ctx, const char *fasta_path, int64_t *n_sequences)
+{
+  CTXCHK(ctx && fasta_path);
+  HIPCHK(hipSetDevice(ctx->device));
+  init_codes();
+  std::string text;
+  if (slurp(fasta_path, text) != 0) SET_ERR(ctx, ITSX_E_IO, std::string("cannot read ") + fasta_path);
+  std::vector<uint32_t> bits(1u << 19, 0u);                 // 4^12 bits
+  int64_t nseq = 0;
+  uint32_t w = 0; int good = 0; bool header = false;
+  for (size_t i = 0; i < text.size(); i++) {
+    const char c = text[i];
+    if (c == '>') { header = true; nseq++; w = 0; good = 0; continue; }
+    if (c == '\n') { header = false; continue; }
+    if (header || c == '\r') continue;
+    const int code = g_code[(unsigned char)c];
+    if (code >= 0 && code <= 3) { w = (w >> 2) | ((uint32_t)code << 22); good++; } else { w = 0; good = 0; }
+    if (good >= 12) bits[w >> 5] |= 1u << (w & 31);
+  }
+  if (nseq == 0) SET_ERR(ctx, ITSX_E_FORMAT, std::string("no FASTA records in ") + fasta_path);
+  HIPCHK(upload(ctx->d_orient_db, bits, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->have_orient_db = true;
+  if (n_sequences) *n_sequences = nseq;
+  return ITSX_OK;
+}
+
+int itsx_orient(itsx_ctx *ctx, int8_t *strand, int32_t *count_fwd, int32_t *count_rev)
+{
+  CTXCHK(ctx && strand);
+  if (!ctx->have_orient_db) SET_ERR(ctx, ITSX_E_ARG, "itsx_orient called before itsx_orient_load_db");
+  if (ctx->Lmax - 11 > 12000) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "reads longer than 12011 bases are not supported by the orientation kernel");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->N;
+  if (n == 0) return ITSX_OK;
+  DBuf<int8_t> d_s; DBuf<int32_t> d_f, d_r;
+  HIPCHK(d_s.alloc((size_t)n)); HIPCHK(d_f.alloc((size_t)n)); HIPCHK(d_r.alloc((size_t)n));
+  launch_orient(ctx->rd, ctx->d_orient_db.p, d_s.p, d_f.p, d_r.p, ctx->st);
+  HIPCHK(hipMemcpyAsync(strand, d_s.p, (size_t)n, hipMemcpyDeviceToHost, ctx->st));
+  if (count_fwd) HIPCHK(hipMemcpyAsync(count_fwd, d_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
+  if (count_rev) HIPCHK(hipMemcpyAsync(count_rev, d_r.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
 
 // ------------------------------------------------------------------------------ f2: paired-end merge (k_merge.hip)
 extern "C++" {

@@ -76,6 +76,9 @@ void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col
                         const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st);
 void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride, hipStream_t st);
 
+// ---- f4: read orientation (k_cluster.hip)
+void launch_orient(const ReadsDev &rd, const uint32_t *dbbits /*4^12 bits*/, int8_t *strand, int32_t *cfwd, int32_t *crev, hipStream_t st);
+
 // ---- k_merge.hip (paired-end merge)
 struct MergeArgs {
   const uint8_t *fseq, *fqual, *rseq, *rqual;   // ASCII bases / qualities of the forward and the reverse reads, concatenated

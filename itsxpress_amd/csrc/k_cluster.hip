@@ -717,3 +717,72 @@ void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int
 }
 
 }  // namespace itsx
+
+// ------------------------------------------------------------------ f4: read orientation (vsearch --orient restated)
+// Reference call site itsxpress/SeqSample.py:48-91.  One block per read: its distinct unambiguous 12-mers (an LDS hash
+// set removes repeats) and their reverse complements are looked up in the database's 12-mer bitmap (2 MB, L2-resident);
+// forward when count_fwd >= 1 and >= 4 x count_rev, reverse when the mirror holds, otherwise undetermined.
+namespace itsx {
+static constexpr int OTAB = 16384;
+__device__ __forceinline__ uint32_t rc24(uint32_t k)
+{
+  uint32_t r = __brev(~k & 0xffffffu) >> 8;
+  return ((r >> 1) & 0x555555u) | ((r & 0x555555u) << 1);
+}
+__global__ __launch_bounds__(256) void k_orient(ReadsDev rd, const uint32_t *dbbits, int8_t *strand, int32_t *cfwd, int32_t *crev)
+{
+  __shared__ uint32_t tab[OTAB];
+  __shared__ uint32_t bad[2048];
+  __shared__ int cf, cr;
+  const int tid = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < rd.n; r += gridDim.x) {
+    const int L = rd.len[r];
+    const uint32_t *w = rd.words + rd.woff[r];
+    const int nw = (int)(rd.woff[r + 1] - rd.woff[r]);
+    const int64_t eo = rd.excoff[r];
+    const int nexc = (int)(rd.excoff[r + 1] - eo);
+    __syncthreads();
+    for (int i = tid; i < OTAB; i += 256) tab[i] = 0u;
+    for (int i = tid; i < 2048; i += 256) bad[i] = 0u;
+    if (tid == 0) { cf = 0; cr = 0; }
+    __syncthreads();
+    for (int e = tid; e < nexc; e += 256) {
+      const int pos = (int)(rd.exc[eo + e] >> 4);
+      for (int d = 0; d < 12; d++) { const int p = pos - d; if (p >= 0) atomicOr(&bad[p >> 5], 1u << (p & 31)); }
+    }
+    __syncthreads();
+    int f = 0, v = 0;
+    if (L - 11 <= 12000) {
+      for (int i = tid; i + 12 <= L; i += 256) {
+        if ((bad[i >> 5] >> (i & 31)) & 1u) continue;
+        const int wi = i >> 4, sh = (i & 15) * 2;
+        const unsigned long long lo = w[wi], hi = wi + 1 < nw ? w[wi + 1] : 0u;
+        const uint32_t k = (uint32_t)(((hi << 32) | lo) >> sh) & 0xffffffu;
+        for (uint32_t slot = (k * 2654435761u) >> 18;; slot = (slot + 1) & (OTAB - 1)) {
+          const uint32_t old = atomicCAS(&tab[slot], 0u, k + 1u);
+          if (old == 0u) {                                   // first occurrence of this word in the read
+            const uint32_t kr = rc24(k);
+            f += (dbbits[k >> 5] >> (k & 31)) & 1u;
+            v += (dbbits[kr >> 5] >> (kr & 31)) & 1u;
+            break;
+          }
+          if (old == k + 1u) break;
+        }
+      }
+    } else { f = 0; v = 0; }
+    if (f) atomicAdd(&cf, f);
+    if (v) atomicAdd(&cr, v);
+    __syncthreads();
+    if (tid == 0) {
+      const int a = cf, b = cr;
+      cfwd[r] = a; crev[r] = b;
+      strand[r] = (int8_t)((a >= 1 && a >= 4 * b) ? 1 : (b >= 1 && b >= 4 * a) ? -1 : 0);
+    }
+  }
+}
+void launch_orient(const ReadsDev &rd, const uint32_t *dbbits, int8_t *strand, int32_t *cfwd, int32_t *crev, hipStream_t st)
+{
+  if (rd.n <= 0) return;
+  hipLaunchKernelGGL(k_orient, dim3((unsigned)std::min<int64_t>(rd.n, 65536)), dim3(256), 0, st, rd, dbbits, strand, cfwd, crev);
+}
+}  // namespace itsx

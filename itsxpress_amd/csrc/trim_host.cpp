@@ -157,4 +157,38 @@ int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const ch
   return ITSX_OK;
 }
 
+// f4: write the reads vsearch --orient keeps (SeqSample.py:48-91): forward ones as they are, reverse ones
+// reverse-complemented (IUPAC complement, qualities reversed), undetermined ones dropped
+int itsx_write_oriented_fastq(const char *seq_path, const char *out_path, const int8_t *strand, int64_t n_records, int64_t *n_written)
+{
+  if (!seq_path || !out_path || !strand) { g_trim_error = "null argument"; return ITSX_E_ARG; }
+  LineReader in; Writer out;
+  if (!in.open(seq_path)) { g_trim_error = std::string("cannot read ") + seq_path; return ITSX_E_IO; }
+  if (!out.open(out_path, false)) { g_trim_error = std::string("cannot write ") + out_path; return ITSX_E_IO; }
+  static char comp[256];
+  static bool init = false;
+  if (!init) {
+    for (int i = 0; i < 256; i++) comp[i] = (char)i;
+    const char *a = "ACGTURYMKSWHBVDNacgturymkswhbvdn", *b = "TGCAAYRKMSWDVBHNtgcaayrkmswdvbhn";
+    for (int i = 0; a[i]; i++) comp[(unsigned char)a[i]] = b[i];
+    init = true;
+  }
+  Rec rec; int64_t i = 0, nw = 0; int rc;
+  while ((rc = next_record(in, rec)) == 1) {
+    if (i >= n_records) { g_trim_error = "more records in the file than orientations"; return ITSX_E_ARG; }
+    const int s = strand[i++];
+    if (s == 0) continue;
+    if (s < 0) {
+      std::string q(rec.qual.rbegin(), rec.qual.rend()), t(rec.seq.size(), 'N');
+      for (size_t k = 0; k < rec.seq.size(); k++) t[k] = comp[(unsigned char)rec.seq[rec.seq.size() - 1 - k]];
+      rec.seq.swap(t); rec.qual.swap(q);
+    }
+    emit(out, rec, 0, (int64_t)rec.seq.size(), false, nullptr);
+    nw++;
+  }
+  if (rc < 0) { g_trim_error = "malformed FASTQ record " + std::to_string(i); return ITSX_E_FORMAT; }
+  if (n_written) *n_written = nw;
+  return ITSX_OK;
+}
+
 }  // extern "C"

@@ -130,6 +130,22 @@ class Engine:
         self.n_unique = n.value
         return n.value
 
+    # ---- f4: read orientation
+    def orient_load_db(self, fasta_path):
+        if not os.path.exists(fasta_path):
+            raise FileNotFoundError(fasta_path)
+        n = C.c_int64(0)
+        self._chk(self.L.itsx_orient_load_db(self.h, os.fsencode(fasta_path), C.byref(n)))
+        return n.value
+
+    def orient(self):
+        """strand int8[n_reads] (+1 forward, -1 reverse, 0 undetermined), count_fwd, count_rev of the loaded reads"""
+        strand = np.zeros(max(1, self.n_reads), np.int8)
+        cf = np.zeros(max(1, self.n_reads), np.int32)
+        cr = np.zeros(max(1, self.n_reads), np.int32)
+        self._chk(self.L.itsx_orient(self.h, strand.ctypes.data, cf.ctypes.data, cr.ctypes.data))
+        return strand[:self.n_reads], cf[:self.n_reads], cr[:self.n_reads]
+
     # ---- f2: paired-end merge
     def merge_pairs(self, fwd, fqual, rev, rqual, maxdiffs=40, maxee=2.0, allow_stagger=False):
         """Lists of equal length (str): forward reads / qualities, reverse reads / qualities as they are in the file.

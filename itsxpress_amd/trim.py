@@ -75,3 +75,17 @@ def coords_from_dicts(names, matchdict, itspos):
             cache[rep] = (-1 if a is None else a, -1 if b is None else b, -1 if t is None else t)
         start[i], stop[i], tlen[i] = cache[rep]
     return start, stop, tlen
+
+
+def write_oriented_fastq(seq_path, out_path, strand):
+    """f4: the FASTQ `vsearch --orient --fastqout` writes for these orientations (+1 as is, -1 reverse-complemented,
+    0 dropped).  Returns the number of records written."""
+    if not os.path.exists(seq_path):
+        raise FileNotFoundError(seq_path)
+    st = np.ascontiguousarray(strand, np.int8)
+    n = C.c_int64(0)
+    L = _lib.lib()
+    rc = L.itsx_write_oriented_fastq(os.fsencode(seq_path), os.fsencode(out_path), st.ctypes.data, len(st), C.byref(n))
+    if rc != 0:
+        raise EngineError(rc, L.itsx_trim_last_error().decode())
+    return n.value

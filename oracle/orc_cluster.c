@@ -225,3 +225,54 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
   free(post); free(cent_pos); free(cnt); free(touched); free(cand); free(qm); free(tm); free(bitmap); free(klist); free(ord);
   return nk;
 }
+
+/*
+ * orc_orient -- ORACLE (test infrastructure only): read orientation, restating
+ *   vsearch --orient IN --db universal_orient_ref_clean.fasta.gz --fastqout oriented.fq
+ * (reference call site itsxpress/SeqSample.py:48-91).  PARITY UNPINNED (the reference holds no
+ * test or fixture for it).  The procedure: the distinct unambiguous 12-mers (--wordlength 12) of the query and of its
+ * reverse complement are looked up in the set of 12-mers of the database sequences; with count_fwd / count_rev hits the
+ * read is forward when count_fwd >= 1 and count_fwd >= 4 * count_rev, reverse (to be reverse-complemented) when
+ * count_rev >= 1 and count_rev >= 4 * count_fwd, otherwise undetermined (not written).  No DUST masking (vsearch masks
+ * query and database by default), as in the clustering restatement above.
+ *   dbbits: 4^12 bits (2 MB), bit k set when 12-mer k (first base in the low bits) occurs in the database.
+ */
+static inline uint32_t rc24(uint32_t k)
+{
+  uint32_t x = ~k & 0xffffffu, y = 0;
+  for (int t = 0; t < 12; t++) { y = (y << 2) | (x & 3u); x >>= 2; }
+  return y;
+}
+void orc_orient_db_add(uint8_t *dbbits, const uint8_t *codes, int64_t L)
+{
+  uint32_t w = 0; int good = 0;
+  for (int64_t i = 0; i < L; i++) {
+    if (codes[i] < 4) { w = (w >> 2) | ((uint32_t)codes[i] << 22); good++; } else { good = 0; w = 0; }
+    if (good >= 12) dbbits[w >> 3] |= (uint8_t)(1u << (w & 7));
+  }
+}
+void orc_orient(const uint8_t *dbbits, const uint8_t *codes, const int64_t *offsets, int64_t n, int8_t *strand, int32_t *cfwd, int32_t *crev)
+{
+  uint8_t *seen = (uint8_t *)calloc(1u << 21, 1);
+  uint32_t *list = NULL; int64_t cap = 0;
+  for (int64_t r = 0; r < n; r++) {
+    const int64_t L = offsets[r + 1] - offsets[r];
+    if (L > cap) { cap = L; list = (uint32_t *)realloc(list, sizeof(uint32_t) * (size_t)cap); }
+    int64_t nk = 0; uint32_t w = 0; int good = 0;
+    for (int64_t i = 0; i < L; i++) {
+      const uint8_t c = codes[offsets[r] + i];
+      if (c < 4) { w = (w >> 2) | ((uint32_t)c << 22); good++; } else { good = 0; w = 0; }
+      if (good >= 12 && !(seen[w >> 3] & (1u << (w & 7)))) { seen[w >> 3] |= (uint8_t)(1u << (w & 7)); list[nk++] = w; }
+    }
+    int32_t f = 0, v = 0;
+    for (int64_t a = 0; a < nk; a++) {
+      const uint32_t k = list[a], kr = rc24(k);
+      f += (dbbits[k >> 3] >> (k & 7)) & 1;
+      v += (dbbits[kr >> 3] >> (kr & 7)) & 1;
+      seen[k >> 3] &= (uint8_t)~(1u << (k & 7));
+    }
+    cfwd[r] = f; crev[r] = v;
+    strand[r] = (f >= 1 && f >= 4 * v) ? 1 : (v >= 1 && v >= 4 * f) ? -1 : 0;
+  }
+  free(seen); free(list);
+}

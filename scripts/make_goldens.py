@@ -209,6 +209,8 @@ def main():
             keep.append(b + "//\n")
     with open(os.path.join(OUT, "mini.hmm"), "w") as f:
         f.write("".join(keep))
+    # f4: the orientation reference ships with the reference package (DATA): vsearch --orient --db (SeqSample.py:59)
+    shutil.copyfile(os.path.join(D.ROOT_DIR, "universal_orient_ref_clean.fasta.gz"), os.path.join(OUT, "universal_orient_ref_clean.fasta.gz"))
     # --taxa All --region ITS2 (BASELINE configs[3]): the runtime file create_runtime_hmm writes, 814 profiles (F.hmm absent)
     tmp = tempfile.mkdtemp()
     with open(M.create_runtime_hmm("All", "ITS2", tmp), "rb") as f, gzip.GzipFile(os.path.join(OUT, "all_its2.hmm.gz"), "wb", mtime=0) as g:

@@ -95,6 +95,10 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_merge_tables.restype = None
     L.orc_merge_tables.argtypes = [C.c_void_p] * 5
+    L.orc_orient_db_add.restype = None
+    L.orc_orient_db_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.orc_orient.restype = None
+    L.orc_orient.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_xxh64.restype = C.c_uint64
     L.orc_xxh64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64]
     L.orc_det_log.restype = C.c_double
@@ -282,3 +286,18 @@ def merge_tables():
     qdiff = np.zeros((128, 128), np.uint8)
     lib().orc_merge_tables(q2p.ctypes.data, match.ctypes.data, mism.ctypes.data, qsame.ctypes.data, qdiff.ctypes.data)
     return q2p, match, mism, qsame, qdiff
+
+
+def orient(db_seqs, seqs):
+    """vsearch --orient restated: returns (strand int8[n] (+1 forward, -1 reverse, 0 undetermined), count_fwd, count_rev)."""
+    bits = np.zeros(1 << 21, np.uint8)
+    for d in db_seqs:
+        c, _ = digitize([d])
+        lib().orc_orient_db_add(bits.ctypes.data, c.ctypes.data, len(d))
+    codes, off = digitize(seqs)
+    n = len(seqs)
+    strand = np.zeros(max(1, n), np.int8)
+    cf = np.zeros(max(1, n), np.int32)
+    cr = np.zeros(max(1, n), np.int32)
+    lib().orc_orient(bits.ctypes.data, codes.ctypes.data, off.ctypes.data, n, strand.ctypes.data, cf.ctypes.data, cr.ctypes.data)
+    return strand[:n], cf[:n], cr[:n]

@@ -346,21 +346,11 @@ DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
   __syncthreads();
 }
 
-// ---- slab addressing: [row][group][lane][field in group] -------------------------------------
-// A row holds three groups that are always touched together: Forward's E N J B C S (6 floats per lane), the six
-// decoding terms Backward writes (6), btot/etot (2).  Inside a group a lane's fields are adjacent, so one
-// dwordx4 + one dwordx2 move a group (2 memory instructions instead of 6; a wave still covers one contiguous
-// 1.5-KB span per group and row).
-constexpr int XF = 14;     // fields per row in the parser slab: fwd E N J B C S | bck terms x6 | btot etot
+// ---- slab addressing: [row][field][lane] ---------------------------------------------------
+constexpr int XF = 14;     // fields per row in the parser slab: fwd E N J B C S | bck E N J B C S | btot etot
 DEV float *slab_at(float *slab, int64_t row0, int row, int nfields, int field, int lane)
 {
-#ifdef ITSX_SLAB_PLAIN
   return slab + (((row0 + row) * nfields + field) * 64 + lane);
-#endif
-  const int goff = field < 6 ? 0 : field < 12 ? 6 * 64 : 12 * 64;
-  const int gsz = field < 12 ? 6 : 2;
-  const int gfirst = field < 6 ? 0 : field < 12 ? 6 : 12;
-  return slab + ((row0 + row) * (int64_t)(nfields * 64) + goff + lane * gsz + (field - gfirst));
 }
 
 

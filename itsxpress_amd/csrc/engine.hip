@@ -1002,7 +1002,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     if (const char *e = getenv("ITSX_SLAB_GB")) ctx->slab_gb = std::max(0.25, atof(e));
   }
   const double slab_gb = ctx->slab_gb;
-  const int64_t row_bytes = 14 * 64 * 4;
+  const int64_t row_bytes = 12 * 64 * 4;                   // XF fields of k_float.hip's parser slab
   const int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
   DBuf<RegionRec> &d_raw = ctx->w_raw;
   HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));
@@ -1016,12 +1016,12 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     }
     LazyTimers lazy(st);
     DBuf<float> &d_slab = ctx->w_slab;
-    int64_t slab_rows_alloc = (int64_t)(d_slab.cap / (14 * 64));
+    int64_t slab_rows_alloc = (int64_t)(d_slab.cap / (12 * 64));
     int w0 = 0;
     while (w0 < NW) {
       int w1 = w0; int64_t r = 0;
       while (w1 < NW && wgeneric[w1] == wgeneric[w0] && (w1 == w0 || r + rows[w1] <= budget_rows)) { waves[w1].slab = r; waves[w1].rows = rows[w1]; r += rows[w1]; w1++; }
-      if (r > slab_rows_alloc) { HIPCHK(d_slab.alloc((size_t)r * 14 * 64)); slab_rows_alloc = r; }
+      if (r > slab_rows_alloc) { HIPCHK(d_slab.alloc((size_t)r * 12 * 64)); slab_rows_alloc = r; }
       HIPCHK(hipMemcpyAsync(d_waves.p + w0, waves.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       FloatArgs a{};
       a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;

@@ -347,7 +347,7 @@ DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
 }
 
 // ---- slab addressing: [row][field][lane] ---------------------------------------------------
-constexpr int XF = 14;     // fields per row in the parser slab: fwd E N J B C S | bck E N J B C S | btot etot
+constexpr int XF = 12;     // fields per row in the parser slab: fwd E N J B C S | the six decoding terms Backward writes
 DEV float *slab_at(float *slab, int64_t row0, int row, int nfields, int field, int lane)
 {
   return slab + (((row0 + row) * nfields + field) * 64 + lane);
@@ -599,7 +599,6 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
     const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
     float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, XF, 7, lane));
     float btot = 0.f, etot = 0.f;
-    *slab_at(a.slab, r0, 0, XF, 12, lane) = 0.f; *slab_at(a.slab, r0, 0, XF, 13, lane) = 0.f;
     // one row of decoding terms (see k_bwd_decode); the next row is requested while the current one is consumed,
     // so the serial chain of sums never waits on HBM latency
     struct DRow { float t2, t3, t4, t1, t5, rs; };
@@ -614,10 +613,13 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
     DRow prv = load_row(0);
     DRow nxt = load_row(L >= 1 ? 1 : 0);
     int ri = -1; bool triggered = false;
+    // The cumulative sums are NOT written back (8 B per row saved): a region's inner scan needs btot/etot of its own rows
+    // only, and those are rebuilt from a checkpoint taken where the region starts -- same operations, same order, same bits.
+    float ck_btot = 0.f, ck_etot = 0.f, ck_sp = scaleproduct, ck_t1 = prv.t1, ck_rs = prv.rs;
     for (int j = 1; j <= L; j++) {
       const DRow cur = nxt;
       if (j < L) nxt = load_row(j + 1);
-      const float btot_prev = btot, etot_prev = etot;
+      const float btot_prev = btot, etot_prev = etot, sp_prev = scaleproduct;
       btot = btot + (prv.t1 * scaleproduct);
       if (own) scaleproduct *= prv.rs;
       etot = etot + (cur.t2 * scaleproduct);
@@ -626,21 +628,31 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
       njcp += cur.t4 * scaleproduct;
       njcp += cur.t5 * scaleproduct;
       const float mocc = (float)(1. - (double)njcp);
-      *slab_at(a.slab, r0, j, XF, 12, lane) = btot; *slab_at(a.slab, r0, j, XF, 13, lane) = etot;
+      const float pt1 = prv.t1, prs = prv.rs;
       prv = cur;
       if (!triggered) {
-        if (mocc - (btot - btot_prev) < rt2) ri = j;
-        else if (ri == -1) ri = j;
+        bool set = false;
+        if (mocc - (btot - btot_prev) < rt2) { ri = j; set = true; }
+        else if (ri == -1) { ri = j; set = true; }
+        if (set) { ck_btot = btot_prev; ck_etot = etot_prev; ck_sp = sp_prev; ck_t1 = pt1; ck_rs = prs; }   // state just before row ri
         if (mocc >= rt1) triggered = true;
       } else if (mocc - (etot - etot_prev) < rt2) {
         nreg++;
         float mx = -1.0f;
-        const float et0 = *slab_at(a.slab, r0, ri - 1, XF, 13, lane);
+        float b = ck_btot, e = ck_etot, sp = ck_sp, t1p = ck_t1, rsp = ck_rs;
+        const float et0 = ck_etot;
         for (int z = ri; z <= j; z++) {
-          const float ea = *slab_at(a.slab, r0, z, XF, 13, lane) - et0;
-          const float bb = btot - *slab_at(a.slab, r0, z - 1, XF, 12, lane);
-          const float e = ea < bb ? ea : bb;
-          mx = e > mx ? e : mx;
+          const float t2z = *slab_at(a.slab, r0, z, XF, 6, lane), t1z = *slab_at(a.slab, r0, z, XF, 9, lane);
+          const float rsz = own ? *slab_at(a.slab, r0, z, XF, 11, lane) : 1.0f;
+          const float bprev = b;                         // btot[z-1]
+          b = b + (t1p * sp);
+          if (own) sp *= rsp;
+          e = e + (t2z * sp);                            // etot[z]
+          t1p = t1z; rsp = rsz;
+          const float ea = e - et0;
+          const float bb = btot - bprev;
+          const float m2 = ea < bb ? ea : bb;
+          mx = m2 > mx ? m2 : mx;
         }
         const int multi = (mx >= rt3);
         if (nkept < MAXDOM) {

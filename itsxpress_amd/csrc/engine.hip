@@ -128,8 +128,7 @@ struct itsx_ctx {
   std::string h_bases;                   // original text (rep.fa keeps the input's case)
   std::vector<int64_t> h_off;
   std::vector<std::string> h_names;
-  std::vector<uint32_t> h_words, h_exc;
-  std::vector<int64_t> h_woff, h_excoff;
+  std::vector<int64_t> h_woff;           // word offset of each read (the words themselves and the exceptions live on the device only)
   std::vector<int32_t> h_len;
   DBuf<uint32_t> d_words, d_exc;
   DBuf<int64_t> d_woff, d_excoff;
@@ -398,50 +397,39 @@ static int pack_and_upload(itsx_ctx *ctx)
 {
   init_codes();
   const int64_t n = ctx->N;
-  ctx->h_len.resize((size_t)n); ctx->h_woff.assign((size_t)n + 1, 0); ctx->h_excoff.assign((size_t)n + 1, 0);
-  int64_t bad = -1;
+  ctx->h_len.resize((size_t)n); ctx->h_woff.assign((size_t)n + 1, 0);
   int Lmax = 0;
   for (int64_t r = 0; r < n; r++) {
     const int64_t L = ctx->h_off[r + 1] - ctx->h_off[r];
     if (L > 65535) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "reads longer than 65535 bases are not supported");
     ctx->h_len[r] = (int32_t)L;
     Lmax = std::max(Lmax, (int)L);
-    int64_t ne = 0;
-    const char *s = ctx->h_bases.data() + ctx->h_off[r];
-    for (int64_t i = 0; i < L; i++) { const int c = g_code[(unsigned char)s[i]]; if (c < 0) bad = r; else if (c > 3) ne++; }
     ctx->h_woff[r + 1] = ctx->h_woff[r] + std::max<int64_t>(1, (L + 15) / 16);
-    ctx->h_excoff[r + 1] = ctx->h_excoff[r] + ne;
   }
-  if (bad >= 0) SET_ERR(ctx, ITSX_E_FORMAT, "read " + std::to_string(bad) + " contains a symbol outside the IUPAC DNA alphabet");
   ctx->Lmax = Lmax;
-  ctx->h_words.assign((size_t)ctx->h_woff[n] + 1, 0u);
-  ctx->h_exc.assign((size_t)ctx->h_excoff[n] + 1, 0u);
-  {
-    auto work = [ctx](int64_t r0, int64_t r1) {
-      for (int64_t r = r0; r < r1; r++) {
-        const int64_t L = ctx->h_len[r];
-        const char *s = ctx->h_bases.data() + ctx->h_off[r];
-        uint32_t *w = ctx->h_words.data() + ctx->h_woff[r];
-        uint32_t *e = ctx->h_exc.data() + ctx->h_excoff[r];
-        for (int64_t i = 0; i < L; i++) {
-          const int c = g_code[(unsigned char)s[i]];
-          if (c <= 3) w[i >> 4] |= (uint32_t)c << (2 * (i & 15));
-          else *e++ = ((uint32_t)i << 4) | (uint32_t)c;
-        }
-      }
-    };
-    int nt = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<int64_t>(1, n / 65536));
-    if (const char *e = getenv("ITSX_HOST_THREADS")) nt = std::max(1, atoi(e));
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
-    for (auto &t : th) t.join();
-  }
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(upload(ctx->d_words, ctx->h_words, ctx->st));
-  HIPCHK(upload(ctx->d_exc, ctx->h_exc, ctx->st));
-  HIPCHK(upload(ctx->d_woff, ctx->h_woff, ctx->st));
-  HIPCHK(upload(ctx->d_excoff, ctx->h_excoff, ctx->st));
-  HIPCHK(upload(ctx->d_len, ctx->h_len, ctx->st));
+  // the ASCII bases go up as they are and are packed on the device (k_util.hip): 2-bit words + exception list
+  const size_t nb = ctx->h_bases.size();
+  DBuf<uint8_t> d_raw; DBuf<int64_t> d_off; DBuf<int8_t> d_lut; DBuf<int32_t> d_excnt, d_exstart, d_tmp; DBuf<long long> d_bad;
+  HIPCHK(d_raw.alloc(nb + 16)); HIPCHK(d_off.alloc((size_t)n + 1)); HIPCHK(d_lut.alloc(256)); HIPCHK(d_excnt.alloc((size_t)n + 2)); HIPCHK(d_exstart.alloc((size_t)n + 2));
+  HIPCHK(d_tmp.alloc((size_t)scan_tmp_elems(n + 1))); HIPCHK(d_bad.alloc(1));
+  HIPCHK(ctx->d_words.alloc((size_t)ctx->h_woff[n] + 1)); HIPCHK(ctx->d_woff.alloc((size_t)n + 1)); HIPCHK(ctx->d_excoff.alloc((size_t)n + 1)); HIPCHK(ctx->d_len.alloc((size_t)n + 1));
+  if (nb) HIPCHK(hipMemcpyAsync(d_raw.p, ctx->h_bases.data(), nb, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(d_off.p, ctx->h_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(ctx->d_woff.p, ctx->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->st));
+  if (n) HIPCHK(hipMemcpyAsync(ctx->d_len.p, ctx->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemcpyAsync(d_lut.p, g_code, 256, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipMemsetAsync(d_bad.p, 0x7f, sizeof(long long), ctx->st));
+  HIPCHK(hipMemsetAsync(d_excnt.p, 0, ((size_t)n + 2) * 4, ctx->st));
+  launch_pack(d_raw.p, d_off.p, ctx->d_woff.p, n, d_lut.p, ctx->d_words.p, d_excnt.p, d_bad.p, ctx->st);
+  launch_exclusive_scan(d_excnt.p, d_exstart.p, n + 1, d_tmp.p, ctx->st);
+  long long bad = 0; int32_t nexc = 0;
+  HIPCHK(hipMemcpyAsync(&bad, d_bad.p, sizeof(bad), hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipMemcpyAsync(&nexc, d_exstart.p + n, sizeof(nexc), hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (bad >= 0 && bad < n) SET_ERR(ctx, ITSX_E_FORMAT, "read " + std::to_string(bad) + " contains a symbol outside the IUPAC DNA alphabet");
+  HIPCHK(ctx->d_exc.alloc((size_t)nexc + 1));
+  launch_pack_exc(d_raw.p, d_off.p, n, d_lut.p, d_excnt.p, d_exstart.p, ctx->d_excoff.p, ctx->d_exc.p, ctx->st);
   HIPCHK(hipStreamSynchronize(ctx->st));
   ctx->rd.words = ctx->d_words.p; ctx->rd.woff = ctx->d_woff.p; ctx->rd.len = ctx->d_len.p;
   ctx->rd.excoff = ctx->d_excoff.p; ctx->rd.exc = ctx->d_exc.p; ctx->rd.n = n;
@@ -1644,9 +1632,12 @@ int itsx_debug_read_hashes(itsx_ctx *ctx, uint64_t *fwd, uint64_t *rc)
 int itsx_debug_packed_read(const itsx_ctx *ctx, int64_t i, uint32_t *words, int32_t *nwords, uint32_t *exc, int32_t *nexc)
 {
   CTXCHK(ctx && i >= 0 && i < ctx->N && nwords && nexc);
-  const int32_t nw = (int32_t)(ctx->h_woff[i + 1] - ctx->h_woff[i]), ne = (int32_t)(ctx->h_excoff[i + 1] - ctx->h_excoff[i]);
-  if (words) memcpy(words, ctx->h_words.data() + ctx->h_woff[i], (size_t)nw * 4);
-  if (exc) memcpy(exc, ctx->h_exc.data() + ctx->h_excoff[i], (size_t)ne * 4);
+  HIPCHK(hipSetDevice(ctx->device));
+  int64_t eo[2] = {0, 0};
+  HIPCHK(hipMemcpy(eo, ctx->d_excoff.p + i, sizeof(eo), hipMemcpyDeviceToHost));
+  const int32_t nw = (int32_t)(ctx->h_woff[i + 1] - ctx->h_woff[i]), ne = (int32_t)(eo[1] - eo[0]);
+  if (words) HIPCHK(hipMemcpy(words, ctx->d_words.p + ctx->h_woff[i], (size_t)nw * 4, hipMemcpyDeviceToHost));
+  if (exc && ne) HIPCHK(hipMemcpy(exc, ctx->d_exc.p + eo[0], (size_t)ne * 4, hipMemcpyDeviceToHost));
   *nwords = nw; *nexc = ne;
   return ITSX_OK;
 }

@@ -97,6 +97,10 @@ void launch_merge(const MergeArgs &a, hipStream_t st);
 // exclusive prefix sum of n int32 values (n < 2^31); tmp must hold scan_tmp_elems(n) int32
 int64_t scan_tmp_elems(int64_t n);
 void    launch_exclusive_scan(const int32_t *in, int32_t *out, int64_t n, int32_t *tmp, hipStream_t st);
+void    launch_pack(const uint8_t *raw, const int64_t *off, const int64_t *woff, int64_t n, const int8_t *lut, uint32_t *words, int32_t *excnt,
+                    long long *first_bad, hipStream_t st);
+void    launch_pack_exc(const uint8_t *raw, const int64_t *off, int64_t n, const int8_t *lut, const int32_t *excnt, const int32_t *exstart,
+                        int64_t *excoff, uint32_t *exc, hipStream_t st);
 void    launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st);
 
 // ---- k_msv.hip

@@ -1,4 +1,5 @@
 // k_util.hip -- small device utilities: multi-level exclusive scan, device detmath probe.
+#include <algorithm>
 #include "engine.h"
 #include "k_api.h"
 #include "detmath.h"
@@ -73,4 +74,67 @@ void launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStrea
   hipLaunchKernelGGL(k_detmath, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, ol, oe);
 }
 
+}  // namespace itsx
+
+// ------------------------------------------------------------------ packing reads on the device
+// The boundary hands over ASCII bases; they are uploaded as they are and packed here (2 bits per base, 16 bases per
+// word, every read on a word boundary; non-ACGT symbols are 0 in the 2-bit plane and listed as (pos << 4 | code)
+// exceptions in position order).  One wave per read, one lane per 16-base word.
+namespace itsx {
+__global__ void __launch_bounds__(256) k_pack_words(const uint8_t *__restrict__ raw, const int64_t *__restrict__ off, const int64_t *__restrict__ woff,
+                                                    int64_t n, const int8_t *__restrict__ lut, uint32_t *__restrict__ words,
+                                                    int32_t *__restrict__ excnt, long long *__restrict__ first_bad)
+{
+  __shared__ int8_t code[256];
+  code[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < n; r += nwaves) {
+    const int64_t o = off[r];
+    const int L = (int)(off[r + 1] - o);
+    const int nw = L > 0 ? (L + 15) >> 4 : 1;
+    int ne = 0; bool bad = false;
+    for (int k = lane; k < nw; k += 64) {
+      uint32_t w = 0;
+      const int base = k * 16, m = L - base < 16 ? L - base : 16;
+      for (int t = 0; t < m; t++) {
+        const int c = code[raw[o + base + t]];
+        if (c < 0) bad = true;
+        else if (c <= 3) w |= (uint32_t)c << (2 * t);
+        else ne++;
+      }
+      words[woff[r] + k] = w;
+    }
+    for (int d = 32; d; d >>= 1) ne += __shfl_xor(ne, d);
+    if (lane == 0) excnt[r] = ne;
+    if (__ballot(bad) && lane == 0) atomicMin(first_bad, (long long)r);
+  }
+}
+// exceptions are rare: one thread per read that has any, positions ascending
+__global__ void __launch_bounds__(256) k_pack_exc(const uint8_t *__restrict__ raw, const int64_t *__restrict__ off, int64_t n, const int8_t *__restrict__ lut,
+                                                  const int32_t *__restrict__ excnt, const int32_t *__restrict__ exstart, int64_t *__restrict__ excoff,
+                                                  uint32_t *__restrict__ exc)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r == n) { excoff[n] = exstart[n]; return; }
+  excoff[r] = exstart[r];
+  if (excnt[r] == 0) return;
+  const int64_t o = off[r];
+  const int L = (int)(off[r + 1] - o);
+  uint32_t *e = exc + exstart[r];
+  for (int i = 0; i < L; i++) { const int c = lut[raw[o + i]]; if (c > 3) *e++ = ((uint32_t)i << 4) | (uint32_t)c; }
+}
+void launch_pack(const uint8_t *raw, const int64_t *off, const int64_t *woff, int64_t n, const int8_t *lut, uint32_t *words, int32_t *excnt,
+                 long long *first_bad, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pack_words, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 65536)), dim3(256), 0, st, raw, off, woff, n, lut, words, excnt, first_bad);
+}
+void launch_pack_exc(const uint8_t *raw, const int64_t *off, int64_t n, const int8_t *lut, const int32_t *excnt, const int32_t *exstart,
+                     int64_t *excoff, uint32_t *exc, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_pack_exc, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, raw, off, n, lut, excnt, exstart, excoff, exc);
+}
 }  // namespace itsx

@@ -336,7 +336,8 @@ class Dedup:
 
 def install():
     """Swap the engine into an importable reference package: after this call
-    `itsxpress.SeqSample.SeqSample.{deduplicate,cluster,_search}` run on the GPU while the CLI,
+    `itsxpress.SeqSample.SeqSample.{deduplicate,cluster,_search,orient_reads}` and the paired sample's
+    `_merge_reads` run on the GPU while the CLI,
     ItsPosition, Dedup and the QIIME 2 plugin stay untouched."""
     import itsxpress.SeqSample as ref  # noqa: the reference package must be installed
 
@@ -351,3 +352,7 @@ def install():
     ref.SeqSample.cluster = SeqSample.cluster
     ref.SeqSample._search = SeqSample._search
     ref.SeqSample.trim_coordinates = SeqSample.trim_coordinates
+    # either side of the path: orientation of CCS reads and paired-end merging
+    ref.SeqSample.orient_reads = SeqSample.orient_reads
+    if hasattr(ref, "SeqSamplePairedNotInterleaved"):
+        ref.SeqSamplePairedNotInterleaved._merge_reads = SeqSamplePairedNotInterleaved._merge_reads

@@ -28,7 +28,10 @@ __device__ __forceinline__ uint8_t comp_base(uint8_t c)
   return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : (c == 'T' || c == 'U') ? 'A' : 'N';
 }
 
-__global__ __launch_bounds__(64) void k_merge(MergeArgs a)
+// INDEXED: the shared 5-mers of every diagonal come from a 5-mer -> positions index of the forward read (LDS: 1024 chain
+// heads + one link per position), O(fl + rl + matches) instead of one compare per (diagonal, position); needs 13 B of LDS
+// per base, so pairs longer than 4096 bases in total take the plain variant.
+template <bool INDEXED> __global__ __launch_bounds__(64) void k_merge(MergeArgs a)
 {
   extern __shared__ uint8_t lds[];
   const int lane = threadIdx.x;
@@ -44,6 +47,8 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a)
     uint8_t *fs = lds, *fq = fs + fl, *rs = fq + fl, *rq = rs + rl, *mq = rq + rl;       // mq: merged qualities (fl + rl)
     uint16_t *f5 = reinterpret_cast<uint16_t *>(lds + ((2 * fl + 2 * rl + fl + rl + 1) & ~1));
     uint16_t *r5 = f5 + fl;
+    int32_t *head = reinterpret_cast<int32_t *>(lds + ((5 * (fl + rl) + 8) & ~3));      // INDEXED only: [1024], then next[fl], diag[fl + rl - 1]
+    int32_t *nextp = head + 1024, *diag = nextp + fl;
     for (int p = lane; p < fl; p += 64) { fs[p] = a.fseq[fo + p]; fq[p] = a.fqual[fo + p]; }
     for (int j = lane; j < rl; j += 64) { rs[j] = comp_base(a.rseq[ro + rl - 1 - j]); rq[j] = a.rqual[ro + rl - 1 - j]; }
     __syncthreads();
@@ -58,14 +63,27 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a)
       r5[p] = ok ? (uint16_t)v : (uint16_t)0xFFFE;             // a different sentinel: two invalid 5-mers never match
     }
     __syncthreads();
-    // ---- diagonals: idx 0 = the largest shift (fl - 1), ascending idx = the oracle's order
     const int ndiag = fl + rl - 1;
+    if (INDEXED) {
+      for (int i = lane; i < 1024; i += 64) head[i] = -1;
+      for (int i = lane; i < ndiag; i += 64) diag[i] = 0;
+      __syncthreads();
+      for (int p = lane; p < fl; p += 64) if (f5[p] != 0xFFFF) nextp[p] = atomicExch(&head[f5[p]], p);
+      __syncthreads();
+      for (int j = lane; j < rl; j += 64) {
+        if (r5[j] == 0xFFFE) continue;
+        for (int p = head[r5[j]]; p >= 0; p = nextp[p]) atomicAdd(&diag[fl - 1 - (p - j)], 1);
+      }
+      __syncthreads();
+    }
+    // ---- diagonals: idx 0 = the largest shift (fl - 1), ascending idx = the oracle's order
     double best = 0.0; int best_idx = 0x7fffffff, best_diffs = 0, hits = 0, kmers = 0;
     for (int idx = lane; idx < ndiag; idx += 64) {
       const int shift = fl - 1 - idx;
       const int lo = shift > 0 ? shift : 0, hi = (shift + rl < fl) ? shift + rl : fl;
       int cnt = 0;
-      for (int p = lo; p < hi; p++) cnt += (f5[p] == r5[p - shift]) ? 1 : 0;
+      if (INDEXED) cnt = diag[idx];
+      else for (int p = lo; p < hi; p++) cnt += (f5[p] == r5[p - shift]) ? 1 : 0;
       if (cnt < 4) continue;
       kmers = 1;
       double score = 0.0, high = 0.0, drop = 0.0;
@@ -130,9 +148,14 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a)
 void launch_merge(const MergeArgs &a, hipStream_t st)
 {
   if (a.n <= 0) return;
-  const size_t lds = (size_t)a.max_total * 5 + 16;           // bases, qualities, merged qualities (1 B each x 3) + 5-mer codes (2 B)
   const int grid = (int)std::min<int64_t>(a.n, 65536);
-  hipLaunchKernelGGL(k_merge, dim3(grid), dim3(64), lds, st, a);
+  if (a.max_total <= 4096) {
+    const size_t lds = (size_t)a.max_total * 13 + 4096 + 64;  // + chain heads, links and diagonal counters (4 B each)
+    hipLaunchKernelGGL(k_merge<true>, dim3(grid), dim3(64), lds, st, a);
+  } else {
+    const size_t lds = (size_t)a.max_total * 5 + 16;          // bases, qualities, merged qualities (1 B each x 3) + 5-mer codes (2 B)
+    hipLaunchKernelGGL(k_merge<false>, dim3(grid), dim3(64), lds, st, a);
+  }
 }
 
 }  // namespace itsx

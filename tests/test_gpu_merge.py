@@ -84,6 +84,10 @@ def test_merge_synthetic_pairs(engine):
     n1 = _check(engine, fwd, fq, rev, rq)
     n2 = _check(engine, fwd, fq, rev, rq, allow_stagger=True)
     assert 50 < n1 < n2
+    # a batch holding a long pair takes the kernel variant without the 5-mer index (LDS): same answers
+    frag = "".join(acgt[rng.integers(0, 4, 4200)])
+    lf, lr = frag[:2600], frag[1800:][::-1].translate(_COMP)
+    assert _check(engine, fwd[:40] + [lf], fq[:40] + ["I" * len(lf)], rev[:40] + [lr], rq[:40] + ["I" * len(lr)], maxee=50.0) >= 1
     # empty input, one-base reads
     assert _check(engine, ["A"], ["I"], ["T"], ["I"]) == 0
     reason, merged, _, _ = engine.merge_pairs([], [], [], [])

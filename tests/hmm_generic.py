@@ -93,3 +93,106 @@ def forward_nats(h, seq, L_model=None, unihit=False):
         xB = lse(xN + lmove, xJ + lmove)
         Mv, Iv, Dv = Mn, In, Dn
     return xC + lmove
+
+
+def decode_regions(h, seq):
+    """Posterior decoding of begin / end / occupancy (p7_DomainDecoding) and the region scan of
+    p7_domaindef_ByPosteriorHeuristics (rt1 0.25, rt2 0.10), all in float64 log space on the multihit model.
+    Returns [(i1, i2), ...] (1-based, inclusive)."""
+    M, mat, t = h["M"], h["mat"], h["t"]
+    L = len(seq)
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    ln = lambda x: math.log(x) if x > 0 else NEG
+    occ = np.zeros(M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    bm = np.array([NEG] + [ln(occ[k] / Z) for k in range(1, M + 1)])
+    lt = np.vectorize(ln)(t)
+    pmove = 3.0 / (L + 3.0)
+    lmove, lloop, lE = math.log(pmove), math.log(1.0 - pmove), math.log(0.5)
+    code = {"A": (0,), "C": (1,), "G": (2,), "T": (3,), "U": (3,), "R": (0, 2), "Y": (1, 3), "M": (0, 1), "K": (2, 3), "S": (1, 2),
+            "W": (0, 3), "H": (0, 1, 3), "B": (1, 2, 3), "V": (0, 1, 2), "D": (0, 2, 3), "N": (0, 1, 2, 3)}
+    sc = np.log(mat / 0.25, where=mat > 0, out=np.full(mat.shape, NEG))
+    em = np.full((L + 1, M + 1), NEG)
+    for i in range(1, L + 1):
+        xs = code[seq[i - 1].upper()]
+        em[i] = sc[:, xs[0]] if len(xs) == 1 else sc[:, list(xs)].mean(axis=1)
+    lse = np.logaddexp
+    # ---- Forward, keeping the special states of every row
+    fN = np.full(L + 1, NEG); fB = np.full(L + 1, NEG); fE = np.full(L + 1, NEG); fJ = np.full(L + 1, NEG); fC = np.full(L + 1, NEG)
+    fN[0] = 0.0; fB[0] = lmove
+    Mv = np.full(M + 1, NEG); Iv = np.full(M + 1, NEG); Dv = np.full(M + 1, NEG)
+    for i in range(1, L + 1):
+        Mn = np.full(M + 1, NEG); In = np.full(M + 1, NEG); Dn = np.full(M + 1, NEG)
+        xE = NEG
+        for k in range(1, M + 1):
+            s = fB[i - 1] + bm[k]
+            if k > 1:
+                s = lse(s, lse(lse(Mv[k - 1] + lt[k - 1][MM], Iv[k - 1] + lt[k - 1][IM]), Dv[k - 1] + lt[k - 1][DM]))
+            Mn[k] = s + em[i][k]
+            if k < M:
+                In[k] = lse(Mv[k] + lt[k][MI], Iv[k] + lt[k][II])
+            if k > 1:
+                Dn[k] = lse(Mn[k - 1] + lt[k - 1][MD], Dn[k - 1] + lt[k - 1][DD])
+            xE = lse(xE, lse(Mn[k], Dn[k]))
+        fE[i] = xE
+        fJ[i] = lse(fJ[i - 1] + lloop, xE + lE)
+        fC[i] = lse(fC[i - 1] + lloop, xE + lE)
+        fN[i] = fN[i - 1] + lloop
+        fB[i] = lse(fN[i] + lmove, fJ[i] + lmove)
+        Mv, Iv, Dv = Mn, In, Dn
+    total = fC[L] + lmove
+    # ---- Backward (b*[i] = ln P(x_{i+1..L} | state at i))
+    bN = np.full(L + 1, NEG); bB = np.full(L + 1, NEG); bE = np.full(L + 1, NEG); bJ = np.full(L + 1, NEG); bC = np.full(L + 1, NEG)
+    bC[L] = lmove
+    bE[L] = bC[L] + lE
+    Mb = np.full(M + 2, NEG); Ib = np.full(M + 2, NEG); Db = np.full(M + 2, NEG)
+    for k in range(M, 0, -1):                          # row L: exit directly, or through the delete states to the right
+        Mb[k] = bE[L] if k == M else lse(bE[L], lt[k][MD] + Db[k + 1])
+        Db[k] = bE[L] if k == M else lse(bE[L], lt[k][DD] + Db[k + 1])
+    for i in range(L - 1, -1, -1):
+        # B at row i enters a match state that emits residue i+1
+        xB = NEG
+        for k in range(1, M + 1):
+            xB = lse(xB, bm[k] + em[i + 1][k] + Mb[k])
+        bB[i] = xB
+        bJ[i] = lse(bJ[i + 1] + lloop, xB + lmove)
+        bC[i] = bC[i + 1] + lloop
+        bE[i] = lse(bJ[i] + lE, bC[i] + lE)
+        bN[i] = lse(bN[i + 1] + lloop, xB + lmove)
+        if i == 0:
+            break
+        Mn = np.full(M + 2, NEG); In = np.full(M + 2, NEG); Dn = np.full(M + 2, NEG)
+        for k in range(M, 0, -1):
+            nm = em[i + 1][k + 1] + Mb[k + 1] if k < M else NEG           # next row's match state k+1 (emits residue i+1)
+            Mn[k] = bE[i]
+            Dn[k] = bE[i]
+            if k < M:
+                Mn[k] = lse(Mn[k], lse(lse(lt[k][MM] + nm, lt[k][MI] + Ib[k]), lt[k][MD] + Dn[k + 1]))
+                In[k] = lse(lt[k][IM] + nm, lt[k][II] + Ib[k])
+                Dn[k] = lse(Dn[k], lse(lt[k][DM] + nm, lt[k][DD] + Dn[k + 1]))
+        Mb, Ib, Db = Mn, In, Dn
+    assert abs((bN[0]) - total) < 1e-6 * max(1.0, abs(total)), (bN[0], total)
+    # ---- decoding + region scan
+    btot = np.zeros(L + 1); etot = np.zeros(L + 1); mocc = np.zeros(L + 1)
+    for i in range(1, L + 1):
+        btot[i] = btot[i - 1] + math.exp(fB[i - 1] + bB[i - 1] - total)
+        etot[i] = etot[i - 1] + math.exp(fE[i] + bE[i] - total)
+        njcp = math.exp(fN[i - 1] + bN[i] + lloop - total) + math.exp(fJ[i - 1] + bJ[i] + lloop - total) + math.exp(fC[i - 1] + bC[i] + lloop - total)
+        mocc[i] = 1.0 - njcp
+    regions = []
+    i1, trig = -1, False
+    for i in range(1, L + 1):
+        if not trig:
+            if mocc[i] - (btot[i] - btot[i - 1]) < 0.10:
+                i1 = i
+            elif i1 == -1:
+                i1 = i
+            if mocc[i] >= 0.25:
+                trig = True
+        elif mocc[i] - (etot[i] - etot[i - 1]) < 0.10:
+            regions.append((i1, i))
+            i1, trig = -1, False
+    return regions

@@ -318,3 +318,24 @@ def test_forward_agrees_with_an_independent_statement(fixture_reads, mini_hmm_te
         s = seqs[int(d["seq"])]
         g = hmm_generic.forward_nats(hm[int(d["prof"])], s[int(d["ienv"]) - 1:int(d["jenv"])], L_model=len(s), unihit=True)
         assert abs(g - float(d["envsc"])) < 2e-3, (int(d["seq"]), int(d["prof"]), g, float(d["envsc"]))
+
+
+def test_envelopes_agree_with_an_independent_decoding(fixture_reads, mini_hmm_text):
+    """The envelope coordinates are the product of the path.  An independent float64 log-space Forward + Backward +
+    posterior decoding + region scan (tests/hmm_generic.py:decode_regions, written from the definition of
+    p7_DomainDecoding / p7_domaindef_ByPosteriorHeuristics) must find the same regions as the oracle's striped float32
+    implementation for every (read, profile) pair past the Forward filter."""
+    import hmm_generic
+    names, seqs = fixture_reads
+    seqs = seqs[:24]
+    hs = orc.HmmSet(text=mini_hmm_text)
+    hm = hmm_generic.parse_hmms(mini_hmm_text)
+    codes, off = orc.digitize(seqs)
+    res = orc.SearchResult(hs, codes, off, keep_trace=1, threads=8)
+    tr = res.trace[res.trace["pass_fwd"] == 1]
+    dom = res.domains
+    assert len(tr) >= 12
+    for r in tr:
+        got = hmm_generic.decode_regions(hm[int(r["prof"])], seqs[int(r["seq"])])
+        d = dom[(dom["seq"] == r["seq"]) & (dom["prof"] == r["prof"])]
+        assert got == [(int(x["ienv"]), int(x["jenv"])) for x in d], (int(r["seq"]), int(r["prof"]), got)

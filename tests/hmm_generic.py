@@ -196,3 +196,96 @@ def decode_regions(h, seq):
             regions.append((i1, i))
             i1, trig = -1, False
     return regions
+
+
+def domain_bits(h, seq, ienv, jenv):
+    """Bit score of one envelope as hmmsearch reports it (column 14 of --domtblout), independently in float64:
+    unihit Forward over the envelope with the length model at the full target length, + the flanks' N/C loops,
+    - null1, - the null2 bias correction (p7_Null2_ByExpectation: expected state usage from posterior decoding of the
+    envelope; prior omega = 1/256).  Returns (bits, domcorrection_nats, envsc_nats)."""
+    M, mat, t = h["M"], h["mat"], h["t"]
+    L = len(seq)
+    sub = seq[ienv - 1:jenv]
+    Ld = len(sub)
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    ln = lambda x: math.log(x) if x > 0 else NEG
+    occ = np.zeros(M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    bm = np.array([NEG] + [ln(occ[k] / Z) for k in range(1, M + 1)])
+    lt = np.vectorize(ln)(t)
+    pmove = 2.0 / (L + 2.0)                                  # unihit, length model stays at L
+    lmove, lloop = math.log(pmove), math.log(1.0 - pmove)
+    code = {"A": (0,), "C": (1,), "G": (2,), "T": (3,), "U": (3,), "R": (0, 2), "Y": (1, 3), "M": (0, 1), "K": (2, 3), "S": (1, 2),
+            "W": (0, 3), "H": (0, 1, 3), "B": (1, 2, 3), "V": (0, 1, 2), "D": (0, 2, 3), "N": (0, 1, 2, 3)}
+    odds = mat / 0.25
+    sc = np.log(odds, where=mat > 0, out=np.full(mat.shape, NEG))
+    em = np.full((Ld + 1, M + 1), NEG)
+    for i in range(1, Ld + 1):
+        xs = code[sub[i - 1].upper()]
+        em[i] = sc[:, xs[0]] if len(xs) == 1 else sc[:, list(xs)].mean(axis=1)
+    lse = np.logaddexp
+    fM = np.full((Ld + 1, M + 2), NEG); fI = np.full((Ld + 1, M + 2), NEG); fD = np.full((Ld + 1, M + 2), NEG)
+    fN = np.full(Ld + 1, NEG); fB = np.full(Ld + 1, NEG); fE = np.full(Ld + 1, NEG); fC = np.full(Ld + 1, NEG)
+    fN[0] = 0.0; fB[0] = lmove
+    for i in range(1, Ld + 1):
+        xE = NEG
+        for k in range(1, M + 1):
+            s = fB[i - 1] + bm[k]
+            if k > 1:
+                s = lse(s, lse(lse(fM[i - 1][k - 1] + lt[k - 1][MM], fI[i - 1][k - 1] + lt[k - 1][IM]), fD[i - 1][k - 1] + lt[k - 1][DM]))
+            fM[i][k] = s + em[i][k]
+            if k < M:
+                fI[i][k] = lse(fM[i - 1][k] + lt[k][MI], fI[i - 1][k] + lt[k][II])
+            if k > 1:
+                fD[i][k] = lse(fM[i][k - 1] + lt[k - 1][MD], fD[i][k - 1] + lt[k - 1][DD])
+            xE = lse(xE, lse(fM[i][k], fD[i][k]))
+        fE[i] = xE
+        fC[i] = lse(fC[i - 1] + lloop, xE)                   # unihit: E->C with probability 1
+        fN[i] = fN[i - 1] + lloop
+        fB[i] = fN[i] + lmove
+    envsc = fC[Ld] + lmove
+    bM = np.full((Ld + 2, M + 2), NEG); bI = np.full((Ld + 2, M + 2), NEG); bD = np.full((Ld + 2, M + 2), NEG)
+    bN = np.full(Ld + 2, NEG); bC = np.full(Ld + 2, NEG); bE = np.full(Ld + 2, NEG); bB = np.full(Ld + 2, NEG)
+    bC[Ld] = lmove
+    bE[Ld] = bC[Ld]
+    for k in range(M, 0, -1):
+        bM[Ld][k] = bE[Ld] if k == M else lse(bE[Ld], lt[k][MD] + bD[Ld][k + 1])
+        bD[Ld][k] = bE[Ld] if k == M else lse(bE[Ld], lt[k][DD] + bD[Ld][k + 1])
+    for i in range(Ld - 1, -1, -1):
+        xB = NEG
+        for k in range(1, M + 1):
+            xB = lse(xB, bm[k] + em[i + 1][k] + bM[i + 1][k])
+        bB[i] = xB
+        bC[i] = bC[i + 1] + lloop
+        bE[i] = bC[i]
+        bN[i] = lse(bN[i + 1] + lloop, xB + lmove)
+        if i == 0:
+            break
+        for k in range(M, 0, -1):
+            nm = em[i + 1][k + 1] + bM[i + 1][k + 1] if k < M else NEG
+            bM[i][k] = bE[i]
+            bD[i][k] = bE[i]
+            if k < M:
+                bM[i][k] = lse(bM[i][k], lse(lse(lt[k][MM] + nm, lt[k][MI] + bI[i + 1][k]), lt[k][MD] + bD[i][k + 1]))
+                bI[i][k] = lse(lt[k][IM] + nm, lt[k][II] + bI[i + 1][k])
+                bD[i][k] = lse(bD[i][k], lse(lt[k][DM] + nm, lt[k][DD] + bD[i][k + 1]))
+    # expected usage of the emitting states over the envelope
+    ppM = np.zeros(M + 1); ppI = 0.0; ppX = 0.0
+    for i in range(1, Ld + 1):
+        for k in range(1, M + 1):
+            ppM[k] += math.exp(fM[i][k] + bM[i][k] - envsc)
+            if k < M:
+                ppI += math.exp(fI[i][k] + bI[i][k] - envsc)
+        ppX += math.exp(fN[i - 1] + lloop + bN[i] - envsc) + math.exp(fC[i - 1] + lloop + bC[i] - envsc)
+    null2 = np.array([(sum(ppM[k] * odds[k][x] for k in range(1, M + 1)) + ppI + ppX) / Ld for x in range(4)])
+    domcorr = 0.0
+    for ch in sub:
+        xs = code[ch.upper()]
+        domcorr += math.log(null2[xs[0]]) if len(xs) == 1 else math.log(np.mean([null2[x] for x in xs]))
+    nullsc = L * math.log(L / (L + 1.0)) + math.log(1.0 / (L + 1.0))
+    dombias = math.log(1.0 + math.exp(math.log(1.0 / 256.0) + domcorr))
+    bits = (envsc + (L - Ld) * math.log(L / (L + 3.0)) - (nullsc + dombias)) / math.log(2.0)
+    return bits, domcorr, envsc

@@ -339,3 +339,22 @@ def test_envelopes_agree_with_an_independent_decoding(fixture_reads, mini_hmm_te
         got = hmm_generic.decode_regions(hm[int(r["prof"])], seqs[int(r["seq"])])
         d = dom[(dom["seq"] == r["seq"]) & (dom["prof"] == r["prof"])]
         assert got == [(int(x["ienv"]), int(x["jenv"])) for x in d], (int(r["seq"]), int(r["prof"]), got)
+
+
+def test_domain_bit_scores_agree_with_an_independent_statement(fixture_reads, mini_hmm_text):
+    """Column 14 of --domtblout, the number ItsPosition compares: an independent float64 statement (unihit Forward over
+    the envelope, flank loops, null1, null2 by expectation from posterior decoding, omega = 1/256;
+    tests/hmm_generic.py:domain_bits) must give the oracle's bit score and null2 correction to 1e-3."""
+    import hmm_generic
+    names, seqs = fixture_reads
+    seqs = seqs[:24]
+    hs = orc.HmmSet(text=mini_hmm_text)
+    hm = hmm_generic.parse_hmms(mini_hmm_text)
+    codes, off = orc.digitize(seqs)
+    dom = orc.SearchResult(hs, codes, off, keep_trace=1, threads=8).domains
+    assert len(dom) >= 12
+    for d in dom:
+        s = seqs[int(d["seq"])]
+        bits, corr, envsc = hmm_generic.domain_bits(hm[int(d["prof"])], s, int(d["ienv"]), int(d["jenv"]))
+        assert abs(bits - float(d["bitscore"])) < 1e-3 and abs(corr - float(d["domcorrection"])) < 1e-3, (int(d["seq"]), int(d["prof"]))
+        assert abs(envsc - float(d["envsc"])) < 2e-3

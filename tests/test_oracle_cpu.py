@@ -2,6 +2,7 @@
 C-ABI library's exports."""
 import gzip
 import json
+import math
 import os
 import re
 import subprocess
@@ -358,3 +359,12 @@ def test_domain_bit_scores_agree_with_an_independent_statement(fixture_reads, mi
         bits, corr, envsc = hmm_generic.domain_bits(hm[int(d["prof"])], s, int(d["ienv"]), int(d["jenv"]))
         assert abs(bits - float(d["bitscore"])) < 1e-3 and abs(corr - float(d["domcorrection"])) < 1e-3, (int(d["seq"]), int(d["prof"]))
         assert abs(envsc - float(d["envsc"])) < 2e-3
+        if int(d["ndom"]) == 1:
+            # per-sequence score of p7_Pipeline: the better of the whole-sequence Forward score and the reconstruction
+            # from the (single) domain, both corrected by null1 and the same null2 bias
+            L = len(s)
+            nullsc = L * math.log(L / (L + 1.0)) + math.log(1.0 / (L + 1.0))
+            bias = math.log(1.0 + math.exp(math.log(1.0 / 256.0) + corr))
+            whole = (hmm_generic.forward_nats(hm[int(d["prof"])], s) - nullsc - bias) / math.log(2.0)
+            expect = max(whole, bits) if envsc - corr > 0 else whole
+            assert abs(expect - float(d["seq_score"])) < 1e-3, (int(d["seq"]), int(d["prof"]), expect, float(d["seq_score"]))

@@ -289,3 +289,28 @@ def domain_bits(h, seq, ienv, jenv):
     dombias = math.log(1.0 + math.exp(math.log(1.0 / 256.0) + domcorr))
     bits = (envsc + (L - Ld) * math.log(L / (L + 3.0)) - (nullsc + dombias)) / math.log(2.0)
     return bits, domcorr, envsc
+
+
+def msv_nats(h, seq):
+    """Generic MSV score (p7_GMSV): best set of ungapped local diagonals, uniform entry 2/(M(M+1)), multihit."""
+    M, mat = h["M"], h["mat"]
+    L = len(seq)
+    tloop, tmove = math.log(L / (L + 3.0)), math.log(3.0 / (L + 3.0))
+    tbm, te = math.log(2.0 / (M * (M + 1.0))), math.log(0.5)
+    code = {"A": (0,), "C": (1,), "G": (2,), "T": (3,), "U": (3,), "R": (0, 2), "Y": (1, 3), "M": (0, 1), "K": (2, 3), "S": (1, 2),
+            "W": (0, 3), "H": (0, 1, 3), "B": (1, 2, 3), "V": (0, 1, 2), "D": (0, 2, 3), "N": (0, 1, 2, 3)}
+    sc = np.log(mat / 0.25, where=mat > 0, out=np.full(mat.shape, NEG))
+    prev = np.full(M + 1, NEG)
+    xN, xB, xJ, xC = 0.0, tmove, NEG, NEG
+    for ch in seq:
+        xs = code[ch.upper()]
+        em = sc[:, xs[0]] if len(xs) == 1 else sc[:, list(xs)].mean(axis=1)
+        cur = np.full(M + 1, NEG)
+        cur[1:] = em[1:] + np.maximum(prev[:-1], xB + tbm)
+        xE = cur[1:].max()
+        xJ = max(xJ + tloop, xE + te)
+        xC = max(xC + tloop, xE + te)
+        xN = xN + tloop
+        xB = max(xN + tmove, xJ + tmove)
+        prev = cur
+    return xC + tmove

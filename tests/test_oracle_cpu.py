@@ -368,3 +368,27 @@ def test_domain_bit_scores_agree_with_an_independent_statement(fixture_reads, mi
             whole = (hmm_generic.forward_nats(hm[int(d["prof"])], s) - nullsc - bias) / math.log(2.0)
             expect = max(whole, bits) if envsc - corr > 0 else whole
             assert abs(expect - float(d["seq_score"])) < 1e-3, (int(d["seq"]), int(d["prof"]), expect, float(d["seq_score"]))
+
+
+def test_msv_agrees_with_the_generic_filter(fixture_reads, mini_hmm_text):
+    """The byte MSV filter (1/3-bit units, loop costs folded into a constant 3 nats) against a float64 generic MSV
+    (uniform entry 2/(M(M+1)), multihit): within quantisation for every pair that passes without overflow, and an
+    overflowing byte score means a generic score beyond what bytes can hold."""
+    import hmm_generic
+    names, seqs = fixture_reads
+    seqs = seqs[:40]
+    hs = orc.HmmSet(text=mini_hmm_text)
+    hm = hmm_generic.parse_hmms(mini_hmm_text)
+    codes, off = orc.digitize(seqs)
+    tr = orc.SearchResult(hs, codes, off, keep_trace=2, threads=8).trace
+    tr = tr[tr["pass_msv"] == 1]
+    n_fin = n_ovf = 0
+    for r in tr:
+        g = hmm_generic.msv_nats(hm[int(r["prof"])], seqs[int(r["seq"])])
+        if r["msv_xj"] < 255:
+            assert abs(g - float(r["msv_sc"])) < 0.8, (int(r["seq"]), int(r["prof"]), g, float(r["msv_sc"]))
+            n_fin += 1
+        else:
+            assert g > 5.0                      # (255 - base 190 - tjb) / (3 / ln 2) - 3 is about 10 nats for these lengths
+            n_ovf += 1
+    assert n_fin >= 5 and n_ovf >= 20

@@ -25,7 +25,8 @@
  * real hmmsearch binary (none is available, and the Fungi model file F.hmm the
  * reference's golden outputs were made with is absent from the mount); they are
  * anchored only by the 226 golden trim coordinates (tests/golden/) as a
- * plausibility check with the other taxa's profiles.
+ * plausibility check with the other taxa's profiles, and cross-checked by an independent float64 log-space
+ * statement of the model (tests/hmm_generic.py: Forward scores, envelopes, domain and sequence bit scores, MSV).
  */
 #ifndef ORC_H
 #define ORC_H

@@ -27,9 +27,11 @@ def parse_hmms(text):
                 M = int(lines[i].split()[1])
             i += 1
         i += 2                                   # header line + transition header
-        if lines[i].split()[0] == "COMPO":
-            i += 1
         p = lambda tok: 0.0 if tok == "*" else math.exp(-float(tok))
+        compo = None
+        if lines[i].split()[0] == "COMPO":
+            compo = [p(x) for x in lines[i].split()[1:5]]
+            i += 1
         mat = np.zeros((M + 1, 4))
         t = np.zeros((M + 1, 7))
         i += 1                                   # node-0 insert emissions
@@ -42,7 +44,7 @@ def parse_hmms(text):
             i += 2                               # match line, insert line
             t[k] = [p(x) for x in lines[i].split()[:7]]
             i += 1
-        out.append(dict(name=name, M=M, mat=mat, t=t))
+        out.append(dict(name=name, M=M, mat=mat, t=t, compo=compo))
     return out
 
 
@@ -314,3 +316,28 @@ def msv_nats(h, seq):
         xB = max(xN + tmove, xJ + tmove)
         prev = cur
     return xC + tmove
+
+
+def bias_filter_nats(h, seq):
+    """p7_bg_FilterScore: ln P(seq | 2-state composition HMM) as odds against the iid background, plus the null length
+    model; state 0 = background (mean run 400, start 0.999, re-set to the target length), state 1 = the model's COMPO
+    (mean run M/8)."""
+    L = len(seq)
+    p1 = L / (L + 1.0)
+    L1 = h["M"] / 8.0
+    t = [[p1, 1.0 - p1], [1.0 / (L1 + 1.0), L1 / (L1 + 1.0)]]
+    sets = {"A": (0,), "C": (1,), "G": (2,), "T": (3,), "U": (3,), "R": (0, 2), "Y": (1, 3), "M": (0, 1), "K": (2, 3), "S": (1, 2),
+            "W": (0, 3), "H": (0, 1, 3), "B": (1, 2, 3), "V": (0, 1, 2), "D": (0, 2, 3), "N": (0, 1, 2, 3)}
+    e = [[0.25] * 4, list(h["compo"])]
+    def eo(k, ch):
+        xs = sets[ch.upper()]
+        return sum(e[k][x] for x in xs) / sum(0.25 for _ in xs)
+    a = [0.999 * eo(0, seq[0]), 0.001 * eo(1, seq[0])]
+    logsc = 0.0
+    for ch in seq[1:]:
+        m = max(a)
+        logsc += math.log(m)
+        a = [a[0] / m, a[1] / m]
+        a = [(a[0] * t[0][0] + a[1] * t[1][0]) * eo(0, ch), (a[0] * t[0][1] + a[1] * t[1][1]) * eo(1, ch)]
+    logsc += math.log(a[0] + a[1])
+    return logsc + L * math.log(p1) + math.log(1.0 - p1)

@@ -382,6 +382,9 @@ def test_msv_agrees_with_the_generic_filter(fixture_reads, mini_hmm_text):
     codes, off = orc.digitize(seqs)
     tr = orc.SearchResult(hs, codes, off, keep_trace=2, threads=8).trace
     tr = tr[tr["pass_msv"] == 1]
+    for r in tr:                                 # the bias-composition filter score of every pair that reaches it
+        b = hmm_generic.bias_filter_nats(hm[int(r["prof"])], seqs[int(r["seq"])])
+        assert abs(b - float(r["filtersc"])) < 1e-3, (int(r["seq"]), int(r["prof"]), b, float(r["filtersc"]))
     n_fin = n_ovf = 0
     for r in tr:
         g = hmm_generic.msv_nats(hm[int(r["prof"])], seqs[int(r["seq"])])

@@ -20,7 +20,11 @@ def parse_hmms(text):
             i += 1
             continue
         name, M = None, 0
+        stats = {}
         while not lines[i].startswith("HMM "):
+            if lines[i].startswith("STATS LOCAL"):
+                tok = lines[i].split()
+                stats[tok[2]] = (float(tok[3]), float(tok[4]))
             if lines[i].startswith("NAME"):
                 name = lines[i].split()[1]
             if lines[i].startswith("LENG"):
@@ -44,7 +48,7 @@ def parse_hmms(text):
             i += 2                               # match line, insert line
             t[k] = [p(x) for x in lines[i].split()[:7]]
             i += 1
-        out.append(dict(name=name, M=M, mat=mat, t=t, compo=compo))
+        out.append(dict(name=name, M=M, mat=mat, t=t, compo=compo, stats=stats))
     return out
 
 

@@ -359,6 +359,11 @@ def test_domain_bit_scores_agree_with_an_independent_statement(fixture_reads, mi
         bits, corr, envsc = hmm_generic.domain_bits(hm[int(d["prof"])], s, int(d["ienv"]), int(d["jenv"]))
         assert abs(bits - float(d["bitscore"])) < 1e-3 and abs(corr - float(d["domcorrection"])) < 1e-3, (int(d["seq"]), int(d["prof"]))
         assert abs(envsc - float(d["envsc"])) < 2e-3
+        # the domain's P-value is the exponential tail fitted to Forward scores (STATS LOCAL FORWARD tau lambda); it is
+        # reported when E = P * (number of reported sequences of that profile) <= 10
+        tau, lam = hm[int(d["prof"])]["stats"]["FORWARD"]
+        lnp = -lam * (float(d["bitscore"]) - tau) if float(d["bitscore"]) > tau else 0.0
+        assert abs(lnp - float(d["lnP"])) < 1e-4 * max(1.0, abs(lnp))
         if int(d["ndom"]) == 1:
             # per-sequence score of p7_Pipeline: the better of the whole-sequence Forward score and the reconstruction
             # from the (single) domain, both corrected by null1 and the same null2 bias

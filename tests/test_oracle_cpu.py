@@ -213,6 +213,28 @@ def test_oracle_vs_golden_trim_coordinates_plausibility(fixture_search, gold):
     assert ((de >= 0) & (de <= 3)).mean() >= 0.95
 
 
+def test_oracle_vs_golden_trim_coordinates_all_taxa(fixture_reads, gold):
+    """The same 226 golden coordinates against the --taxa All profile set (814 ITS2 profiles of every kingdom but Fungi,
+    whose file is absent): every read keeps both sides, the start is exact on 194 / 226 and never off by more than one
+    base, the stop is within 0..3 bases on 198.  Measured, not a parity claim: the models differ from the goldens'."""
+    import gzip
+    names, seqs = fixture_reads
+    codes, offs = orc.digitize(seqs)
+    _, rep_of, _ = orc.derep(codes, offs)
+    seeds = [i for i in range(len(seqs)) if rep_of[i] == i]
+    c2, o2 = orc.digitize([seqs[i] for i in seeds])
+    with gzip.open(os.path.join(gold, "all_its2.hmm.gz"), "rt") as f:
+        hs = orc.HmmSet(text=f.read())
+    start, stop, tlen, _ = orc.SearchResult(hs, c2, o2, threads=8).positions("3_", "4_")
+    pos = {names[seeds[j]]: (int(start[j]), int(stop[j]), int(tlen[j])) for j in range(len(seeds))}
+    rows = [ln.split("\t") for ln in open(os.path.join(gold, "fungi_its2_coords.tsv")).read().strip().split("\n")[1:]]
+    ds = np.array([pos[rep][0] - int(a) for _, rep, a, b, t in rows])
+    de = np.array([pos[rep][1] - int(b) for _, rep, a, b, t in rows])
+    assert all(pos[rep][0] >= 0 and pos[rep][1] >= 0 and pos[rep][2] == int(t) for _, rep, a, b, t in rows)
+    assert (ds == 0).sum() >= 190 and (np.abs(ds) <= 1).all()
+    assert ((de >= 0) & (de <= 3)).sum() >= 190
+
+
 def test_oracle_positions_equal_itsposition_on_its_own_rows(fixture_search, tmp_path):
     """orc_positions (the checker for the device argmax) == ItsPosition.parse on the same rows as text."""
     from itsxpress_amd import ItsPosition

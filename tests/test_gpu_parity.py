@@ -223,6 +223,48 @@ def test_search_ragged_lengths_and_edge_cases(engine, t_hmm_text):
     _compare(engine, res)
 
 
+def test_search_fuzz_odd_reads(engine, mini_hmm_text, monkeypatch):
+    """Reads nobody sequences: shorter than the models, homopolymers, consensus repeated many times (several domains per
+    read, strong scores that force rescaling), IUPAC soup, motif fragments glued in both orientations.  Every stage must
+    still equal the oracle bit for bit."""
+    monkeypatch.setenv("ITSX_KEEP_TRACE", "1")
+    rng = np.random.default_rng(77)
+    cons3 = synth.consensus_motifs(mini_hmm_text, "3_")
+    cons4 = synth.consensus_motifs(mini_hmm_text, "4_")
+    rc = lambda s: s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
+    seqs = []
+    for n in (33, 34, 40, 44, 45, 46, 60):
+        seqs.append(rnd(n))
+    seqs += ["A" * 200, "AC" * 150, "G" * 33, cons3[0] * 7, (cons3[0] + rnd(30) + cons4[0]) * 3, cons4[0][:20] + cons3[0] + cons4[0][20:]]
+    seqs += [rnd(50) + cons3[0] + rnd(120) + cons4[0] + rnd(40) + cons3[1] + rnd(100) + cons4[1] + rnd(30)]
+    seqs += [rc(cons3[0]) + rnd(80) + rc(cons4[0]), cons3[0][5:40] + rnd(10) + cons4[0][3:], "ACGTRYKMSWBDHVN" * 20 + cons3[0]]
+    for _ in range(40):
+        parts = []
+        for _ in range(int(rng.integers(1, 6))):
+            k = int(rng.integers(0, 5))
+            parts.append([rnd(int(rng.integers(1, 90))), cons3[int(rng.integers(0, len(cons3)))], cons4[int(rng.integers(0, len(cons4)))],
+                          "N" * int(rng.integers(1, 12)), rc(cons4[0])][k])
+        s = "".join(parts)
+        if len(s) >= 33:
+            s = list(s)
+            for _ in range(int(rng.integers(0, 6))):
+                s[int(rng.integers(0, len(s)))] = str(rng.choice(list("ACGTNRY")))
+            seqs.append("".join(s))
+    res = _run_both(engine, mini_hmm_text, seqs)
+    assert res.counts["past_fwd"] > 40 and (res.domains["ndom"] > 1).any()
+    _compare(engine, res)
+    _compare(engine, res, "1_", "2_")
+    assert engine.stats()["n_domain_overflow"] == 0
+    # the documented limit: at most 8 regions per (representative, profile) are kept, the rest are counted
+    engine.set_reads([cons3[0] * 12 + rnd(40)])
+    engine.derep()
+    engine.search()
+    engine.finalize()
+    st = engine.stats()
+    assert st["n_domain_overflow"] >= 1 and engine.domains()["ndom"].max() == 8
+
+
 def test_trim_coords_per_read_follow_matchdict(engine, fixture_reads, mini_hmm_text):
     names, seqs = fixture_reads
     res = _run_both(engine, mini_hmm_text, seqs)

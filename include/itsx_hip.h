@@ -84,6 +84,7 @@ typedef struct {
   float   ms_cluster;        int32_t pad0;               /* itsx_cluster at id < 1: whole call */
   int64_t cl_windows, cl_cuts, cl_alignments;            /* speculative windows, windows cut by validation, alignments */
   float   ms_merge;          int32_t pad1;               /* k_merge of the last itsx_merge_* call */
+  int64_t cl_certified;                                  /* candidate alignments proven rejections without the full DP */
 } itsx_stats;
 
 int         itsx_abi_version(void);

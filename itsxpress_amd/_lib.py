@@ -44,7 +44,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("fwd_rows", "<i8"), ("ms_env_kernel", "<f4"), ("ms_bias_kernel", "<f4"), ("env_rows", "<i8"),
                 ("n_env_unique", "<i8"), ("ms_decode_kernel", "<f4"), ("n_batches", "<i4"), ("ms_cluster", "<f4"),
                 ("pad0", "<i4"), ("cl_windows", "<i8"), ("cl_cuts", "<i8"), ("cl_alignments", "<i8"), ("ms_merge", "<f4"),
-                ("pad1", "<i4")]
+                ("pad1", "<i4"), ("cl_certified", "<i8")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares

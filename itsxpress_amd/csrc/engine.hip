@@ -624,8 +624,8 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   const int64_t cnt_budget = 8LL << 30;
 
   DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, acc_col, is_new, new_rank, scan_tmp, xlist, xn, hard, dbg;
-  DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm, canon, ctab_val;
-  DBuf<unsigned long long> ctab_key;
+  DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm, canon, ctab_val, need;
+  DBuf<unsigned long long> ctab_key, n_skipped, pre_stats;
   DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct, selpid, wpid, xpid;
   DBuf<uint16_t> klist, cnt; DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
   DBuf<uint32_t> bitsA, bitsB;
@@ -641,7 +641,8 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(wn.alloc(nqs)); HIPCHK(wcol.alloc(nqs * 32)); HIPCHK(wkey.alloc(nqs * 32)); HIPCHK(wpid.alloc(nqs * 32));
   HIPCHK(xlist.alloc(nqs * 32)); HIPCHK(xn.alloc(nqs)); HIPCHK(hard.alloc(nqs)); HIPCHK(xkey.alloc(nqs * 32)); HIPCHK(xpid.alloc(nqs * 32));
   HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(newq.alloc((size_t)Bmax + 1)); HIPCHK(rm.alloc((size_t)Bmax + 1));
-  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(ctab_key.alloc(16384)); HIPCHK(ctab_val.alloc(16384));
+  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(pre_stats.alloc(4)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 4 * sizeof(unsigned long long), ctx->st));
+  HIPCHK(hipMemsetAsync(n_skipped.p, 0, sizeof(unsigned long long), ctx->st)); HIPCHK(ctab_key.alloc(16384)); HIPCHK(ctab_val.alloc(16384));
   HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1));
   if (n > 0) launch_hash_reads(ctx->rd, 0, 0, ctx->w_hf.p, ctx->w_hr.p, ctx->st);      // identical reads of a window share one search
   HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(Bmax + 1))); HIPCHK(n_align.alloc(1));
@@ -662,7 +663,8 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
   a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
   a.is_new = is_new.p; a.new_rank = new_rank.p; a.newq = newq.p; a.rm = rm.p;
-  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.ctab_key = ctab_key.p; a.ctab_val = ctab_val.p; a.rhash = ctx->w_hf.p;
+  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p;
+  a.pre_k = std::min(16, (int)((double)Lmax * (1.0 - id) / id) + 1); a.ctab_key = ctab_key.p; a.ctab_val = ctab_val.p; a.rhash = ctx->w_hf.p;
   a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
   a.thr = 100.0 * id; a.n_align = n_align.p;
 
@@ -727,8 +729,14 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(hipMemsetAsync(d_pct.p, 0, ((size_t)n + 1) * sizeof(double), ctx->st));
   launch_cl_finalize(nk, d_order.p, res_col.p, res_strand.p, res_id.p, cent_read.p, ctx->d_rep_of.p, ctx->d_strand.p, d_pct.p, ctx->w_is_seed.p, ctx->st);
   { const int rc_ = build_unique_lists(ctx); if (rc_ != ITSX_OK) return rc_; }
-  unsigned long long naln = 0;
+  unsigned long long naln = 0, nskip = 0;
   HIPCHK(hipMemcpy(&naln, n_align.p, sizeof(naln), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&nskip, n_skipped.p, sizeof(nskip), hipMemcpyDeviceToHost));
+  if (debug) {
+    unsigned long long ps[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(ps, pre_stats.p, sizeof(ps), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[cluster] certificate: not applicable %llu, bound too weak %llu, path exists %llu, proven reject %llu; full alignments %llu\n", ps[0], ps[1], ps[2], ps[3], naln);
+  }
   ctx->stats.ms_cluster = tm.stop();
   { const int rc_ = mirror_derep(ctx); if (rc_ != ITSX_OK) return rc_; }
   ctx->h_pct.assign((size_t)n, -1.0);
@@ -736,7 +744,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   for (int64_t r = 0; r < n; r++) if (ctx->h_rep_of[r] < 0 || ctx->h_rep_of[r] == r) ctx->h_pct[r] = -1.0;
   ctx->h_order = ord;
   ctx->stats.n_unique = ctx->U; ctx->stats.n_dropped_short = n - nk;
-  ctx->stats.cl_windows = windows; ctx->stats.cl_cuts = cuts; ctx->stats.cl_alignments = (int64_t)naln;
+  ctx->stats.cl_windows = windows; ctx->stats.cl_cuts = cuts; ctx->stats.cl_alignments = (int64_t)naln; ctx->stats.cl_certified = (int64_t)nskip;
   ctx->have_derep = true; ctx->have_search = ctx->have_final = false; ctx->clustered = true;
   if (ctx->U != ncent) SET_ERR(ctx, ITSX_E_DEVICE, "clustering bookkeeping mismatch (centroids " + std::to_string(ncent) + " vs uniques " + std::to_string(ctx->U) + ")");
   if (n_unique) *n_unique = ctx->U;

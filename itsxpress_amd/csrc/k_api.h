@@ -64,6 +64,10 @@ struct ClusterArgs {
   unsigned long long *scratch; int32_t scratch_pitch;     // alignment boundary rows [2 nq * 32][pitch][2]
   double thr;                   // 100 * id
   unsigned long long *n_align;
+  int32_t *need; int32_t need_pitch;             // rejection certificate: need[which * pitch + item] = 0 when the full alignment is not needed (nullptr: off)
+  unsigned long long *n_skipped;
+  unsigned long long *pre_stats;                 // [4] certificate outcomes: not applicable, bound too weak, a path exists, proven reject
+  int32_t pre_k;                                 // largest edit budget K of this run (sizes the certificate's LDS rows)
 };
 void launch_cl_kmers(const ClusterArgs &a, hipStream_t st);
 void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st);

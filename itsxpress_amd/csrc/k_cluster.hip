@@ -428,6 +428,150 @@ __device__ __forceinline__ double identity_of(i64 res)
   return cols > 0 ? 100.0 * (double)matches / (double)cols : 0.0;
 }
 
+// ------------------------------------------------------------------ a rejection certificate before the full alignment
+// 96 % of the alignments end in a rejection.  Most of them can be PROVEN rejections for a fraction of the work:
+//  (1) an accepted alignment A (identity = M / (M + E) >= X, M matching columns, E mismatching pairs + interior gap
+//      columns) has E <= K, the largest E with 100 min(Lq, Lt) / (min(Lq, Lt) + E) >= 100 X (evaluated as the identity is);
+//  (2) every alignment scores at most 4 P - (Lq + Lt), P its aligned pairs (a pair is worth at most 2, every unpaired
+//      symbol costs at least 1), and the chosen alignment is score-optimal, so with the score LB of ANY alignment in
+//      hand -- here the better of "no pairs at all" and the ungapped alignment along the diagonal with most shared 8-mers --
+//      an accepted alignment has P >= (LB + Lq + Lt) / 4 =: Pmin;
+//  (3) so an accepted alignment is a path from the top/left border to the bottom/right border (whatever lies outside is
+//      terminal gap) with at most K unit-cost edits (compatible symbols match) spanning at least Pmin rows and columns.
+// Whether such a path exists is a k-differences question: furthest-reaching diagonals (Landau-Vishkin) from every border
+// cell that leaves enough room, one lane per start cell.  No such path => the candidate is rejected without the O(Lq Lt)
+// dynamic program; otherwise (all accepts, and the rare unlucky reject) the full alignment decides as before.
+// For unrelated candidates the walk dies after one or two symbols per start; for near misses (a family member with one
+// difference too many) Pmin is nearly the whole read and only a handful of start cells qualify.
+// the certificate is used for edit budgets K <= 16 (identity thresholds >= ~0.95 at 300 bases; engine.hip sets pre_k)
+static constexpr int PRE_LMAX = 2040;            // and reads up to this length (LDS); longer ones go straight to the full alignment
+
+__device__ __forceinline__ uint32_t read_mask(const ReadsDev &rd, const uint32_t *w, int pos) { return 1u << ((w[pos >> 4] >> ((pos & 15) * 2)) & 3u); }
+
+__device__ bool precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds)
+{
+  const int lane = threadIdx.x;
+  const int qi = qs >> 1, s = qs & 1;
+  const int64_t rq = a.order[a.f + qi], rt = a.cent_read[col];
+  const int Lq = a.rd.len[rq], Lt = a.rd.len[rt];
+  const int minL = Lq < Lt ? Lq : Lt;
+  // K = the largest E for which ANY alignment with M <= minL matches could pass: M / (M + E) grows with M, and the test is
+  // made with the very expression identity_of() evaluates, so rounding cannot open a gap between the two
+  int K = 0;
+  while (K <= a.pre_k && 100.0 * (double)minL / (double)(minL + K + 1) >= a.thr) K++;
+  if (K > a.pre_k || Lq > PRE_LMAX || Lt > PRE_LMAX || Lq < 8 || Lt < 8) { if (lane == 0) atomicAdd(&a.pre_stats[0], 1ULL); return true; }   // no certificate: align
+  uint8_t *qm = lds, *tm = qm + ((Lq + 3) & ~3);
+  int32_t *head = reinterpret_cast<int32_t *>(tm + ((Lt + 3) & ~3));      // [256] chain heads of q's 8-mers (hashed)
+  int32_t *nextp = head + 256;                                              // [Lq]
+  uint16_t *qk = reinterpret_cast<uint16_t *>(nextp + Lq);                  // [Lq] 8-mer at each q position (0xFFFF: none)
+  int32_t *votes = reinterpret_cast<int32_t *>(qk + ((Lq + 1) & ~1));       // [Lq + Lt]
+  int32_t *fr = votes + Lq + Lt;                                            // [64 lanes][2][2 pre_k + 3]
+  __shared__ int s_hit;
+  const uint32_t *wq = a.rd.words + a.rd.woff[rq];
+  const uint32_t *wt = a.rd.words + a.rd.woff[rt];
+  const int64_t eoq = a.rd.excoff[rq], eot = a.rd.excoff[rt];
+  const int nexq = (int)(a.rd.excoff[rq + 1] - eoq), next_ = (int)(a.rd.excoff[rt + 1] - eot);
+  __syncthreads();
+  for (int x = lane; x < Lq; x += 64) { const int o = s ? Lq - 1 - x : x; const uint32_t c2 = (wq[o >> 4] >> ((o & 15) * 2)) & 3u; qm[x] = (uint8_t)(1u << (s ? 3u - c2 : c2)); }
+  for (int o = lane; o < Lt; o += 64) tm[o] = (uint8_t)(1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u));
+  for (int i = lane; i < 256; i += 64) head[i] = -1;
+  for (int i = lane; i < Lq + Lt; i += 64) votes[i] = 0;
+  if (lane == 0) s_hit = 0;
+  __syncthreads();
+  for (int e = lane; e < nexq; e += 64) { const uint32_t ex = a.rd.exc[eoq + e]; const int pos = (int)(ex >> 4); const uint32_t m = mask4(ex & 15u); qm[s ? Lq - 1 - pos : pos] = (uint8_t)(s ? revmask4(m) : m); }
+  for (int e = lane; e < next_; e += 64) { const uint32_t ex = a.rd.exc[eot + e]; tm[ex >> 4] = (uint8_t)mask4(ex & 15u); }
+  __syncthreads();
+  // ---- the diagonal with most shared 8-mers (unambiguous symbols only)
+  auto kmer_at = [&](const uint8_t *m, int L, int p, uint32_t &k) {
+    if (p + 8 > L) return false;
+    k = 0;
+    for (int t = 0; t < 8; t++) { const uint32_t b = m[p + t]; if (__popc(b) != 1) return false; k |= (uint32_t)(__ffs(b) - 1) << (2 * t); }
+    return true;
+  };
+  for (int p = lane; p < Lq; p += 64) {
+    uint32_t k;
+    if (kmer_at(qm, Lq, p, k)) { qk[p] = (uint16_t)k; nextp[p] = atomicExch(&head[(k * 40503u >> 8) & 255u], p); } else qk[p] = 0xFFFF;
+  }
+  __syncthreads();
+  for (int j = lane; j < Lt; j += 64) {
+    uint32_t k;
+    if (!kmer_at(tm, Lt, j, k)) continue;
+    for (int p = head[(k * 40503u >> 8) & 255u]; p >= 0; p = nextp[p]) if (qk[p] == (uint16_t)k) atomicAdd(&votes[p - j + Lt - 1], 1);
+  }
+  __syncthreads();
+  int bv = -1, bd = 0;
+  for (int i = lane; i < Lq + Lt - 1; i += 64) if (votes[i] > bv) { bv = votes[i]; bd = i; }
+  for (int off = 32; off; off >>= 1) { const int ov = __shfl_xor(bv, off), od = __shfl_xor(bd, off); if (ov > bv || (ov == bv && od < bd)) { bv = ov; bd = od; } }
+  const int d = bd - (Lt - 1);                              // q index i pairs with t index i - d
+  // ---- LB: the ungapped alignment along that diagonal, its overhangs as terminal gaps
+  const int i_lo = d > 0 ? d : 0, i_hi = (Lt + d < Lq) ? Lt + d : Lq;
+  long long part = 0;
+  for (int i = i_lo + lane; i < i_hi; i += 64) {
+    const uint32_t x = qm[i], y = tm[i - d];
+    if (__popc(x) == 1 && __popc(y) == 1) part += (x == y) ? 2 : -4;
+  }
+  for (int off = 32; off; off >>= 1) part += __shfl_xor(part, off);
+  long long lb = -(long long)(Lq + Lt + 4);                 // no pairs at all: two terminal runs
+  if (bv > 0 && i_hi > i_lo) {
+    const int left = d > 0 ? d : -d;                        // one of the two reads overhangs on the left, one on the right
+    const int right = (Lq - i_hi) + (Lt - (i_hi - d));
+    const long long sc = part - (left ? 2 + left : 0) - (right ? 2 + right : 0);
+    if (sc > lb) lb = sc;
+  }
+  const long long num = lb + Lq + Lt;
+  const int Pmin = num <= 0 ? 0 : (int)((num + 3) / 4);
+  if (Pmin <= K + 4) { if (lane == 0) atomicAdd(&a.pre_stats[1], 1ULL); return true; }           // too weak to exclude chance overlaps: align
+  // ---- k-differences reachability from every border cell with room for Pmin rows and columns
+  const int W = 2 * K + 3, Wmax = 2 * a.pre_k + 3;
+  int32_t *cur = fr + lane * 2 * Wmax, *prv = cur + Wmax;
+  const int nstart = Lq + Lt + 1;                           // 0..Lq: (i0, 0); Lq+1..: (0, j0 = idx - Lq)
+  bool hit = false;
+  for (int st = lane; st < nstart && !hit; st += 64) {
+    const int i0 = st <= Lq ? st : 0, j0 = st <= Lq ? 0 : st - Lq;
+    if (Lq - i0 < Pmin || Lt - j0 < Pmin) continue;
+    for (int z = 0; z < W; z++) prv[z] = -1;
+    for (int e = 0; e <= K && !hit; e++) {
+      for (int z = 0; z < W; z++) cur[z] = -1;
+      for (int dl = -e; dl <= e; dl++) {                    // diagonal (i - j) - (i0 - j0) = dl, slot dl + K + 1
+        const int z = dl + K + 1;
+        int i;
+        if (e == 0) i = i0;
+        else {
+          i = -1;
+          if (prv[z] >= 0) i = prv[z] + 1;                                        // mismatching pair
+          if (prv[z - 1] >= 0 && prv[z - 1] + 1 > i) i = prv[z - 1] + 1;          // a q symbol against a gap
+          if (prv[z + 1] >= 0 && prv[z + 1] > i) i = prv[z + 1];                  // a t symbol against a gap
+          if (i < 0) continue;
+        }
+        int j = i - (i0 - j0) - dl;
+        if (i > Lq || j > Lt || j < j0 || i < i0) continue;
+        while (i < Lq && j < Lt && (qm[i] & tm[j])) { i++; j++; }
+        cur[z] = i;
+        if ((i == Lq || j == Lt) && i - i0 >= Pmin && j - j0 >= Pmin) { hit = true; break; }
+      }
+      int32_t *t_ = cur; cur = prv; prv = t_;
+    }
+  }
+  if (hit) s_hit = 1;
+  __syncthreads();
+  if (lane == 0) atomicAdd(&a.pre_stats[s_hit ? 2 : 3], 1ULL);
+  return s_hit != 0;
+}
+
+__global__ __launch_bounds__(64) void k_cl_precheck(ClusterArgs a, int which)
+{
+  extern __shared__ uint8_t pre_lds[];
+  const int nw = a.work_n[which];
+  const int32_t *work = which ? a.xwork : a.work;
+  const int32_t *cols = which ? a.xlist : a.sel;
+  for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+    const int item = work[w];
+    const bool need = precheck_pair(a, item >> 5, cols[item], pre_lds);
+    if (threadIdx.x == 0) a.need[which * a.need_pitch + item] = need ? 1 : 0;
+    __syncthreads();
+  }
+}
+
 // one wave = one (query strand, selected candidate) alignment; the walk consumes the identities in rank order
 template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
 {
@@ -435,6 +579,7 @@ template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
   const int nw = a.work_n[0];
   for (int w = blockIdx.x; w < nw; w += gridDim.x) {      // every wave drains its share of the list and exits
     const int item = a.work[w];
+    if (a.need && !a.need[item]) { if (threadIdx.x == 0) { a.selpid[item] = -1.0; atomicAdd(a.n_skipped, 1ULL); } continue; }   // proven reject
     i64 res;
     if (align_pair<S>(a, item >> 5, a.sel[item], item, tmask_lds, res)) {
       a.selpid[item] = identity_of(res);
@@ -554,6 +699,7 @@ template <int S> __global__ __launch_bounds__(64) void k_cl_align_x(ClusterArgs 
   const int nw = a.work_n[1];
   for (int w = blockIdx.x; w < nw; w += gridDim.x) {
     const int item = a.xwork[w];
+    if (a.need && !a.need[a.need_pitch + item]) { if (threadIdx.x == 0) { a.xpid[item] = -1.0; atomicAdd(a.n_skipped, 1ULL); } continue; }
     i64 res;
     if (align_pair<S>(a, item >> 5, a.xlist[item], item, tmask_lds, res)) {
       const double pid = identity_of(res);
@@ -680,6 +826,11 @@ void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st
   hipLaunchKernelGGL(k_cl_count, dim3((ntiles + 3) / 4, 2 * a.nq), dim3(256), 0, st, a, tile0, ntiles);
 }
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
+static size_t precheck_lds(const ClusterArgs &a)
+{
+  const size_t L = (size_t)std::min(a.scratch_pitch, PRE_LMAX + 1);      // masks, 8-mer index of the query, votes, per-lane LV rows
+  return 2 * (L + 4) + 1024 + 4 * L + 2 * (L + 2) + 8 * L + 64 * 2 * (2 * (size_t)a.pre_k + 3) * 4 + 64;
+}
 void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
 {
   // round 0: the best candidate of every query (most reads accept it); round 1: the whole remaining reject budget at once
@@ -688,6 +839,7 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
     hipLaunchKernelGGL(k_cl_select, dim3(2 * a.nq), dim3(256), 0, st, a, kmax);
     const int grid = std::min(2 * a.nq * kmax, 16384);
     const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
+    if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 0);
     if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), lds, st, a);
     else hipLaunchKernelGGL(k_cl_align<10>, dim3(grid), dim3(64), lds, st, a);
     hipLaunchKernelGGL(k_cl_walk, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
@@ -701,6 +853,7 @@ void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a);
   const int grid = std::min(2 * a.nq * 32, 16384);
   const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
+  if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 1);
   if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(grid), dim3(64), lds, st, a);
   else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(grid), dim3(64), lds, st, a);
   hipLaunchKernelGGL(k_cl_resolve, dim3(1), dim3(64), 0, st, a);

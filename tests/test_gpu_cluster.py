@@ -99,6 +99,17 @@ def test_cluster_many_ambiguous_symbols(engine, window, monkeypatch):
     _compare(engine, reads, names, 0.985)
 
 
+def test_cluster_rejection_certificate(engine, monkeypatch):
+    """Most candidate alignments are proven rejections without the dynamic program (k_cl_precheck); switching the
+    certificate off must not change a single outcome -- both runs are compared with the oracle -- and it must actually fire."""
+    reads, names = _noisy_library(31, 2500, 40, (250, 300), max_err=5, n_rate=0.004)
+    _, st = _compare(engine, reads, names, 0.99)
+    assert st["cl_certified"] > 5 * st["cl_alignments"] > 0
+    monkeypatch.setenv("ITSX_CL_NOPRECHECK", "1")
+    _, st0 = _compare(engine, reads, names, 0.99)
+    assert st0["cl_certified"] == 0 and st0["cl_alignments"] > 3 * st["cl_alignments"]
+
+
 def test_cluster_plus_strand_only_and_no_names(engine):
     reads, names = _noisy_library(13, 1200, 30, (200, 240))
     _compare(engine, reads, names, 0.99, strand_both=False)

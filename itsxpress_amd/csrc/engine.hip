@@ -625,7 +625,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
 
   DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, acc_col, is_new, new_rank, scan_tmp, xlist, xn, hard, dbg;
   DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm, canon, ctab_val, need;
-  DBuf<unsigned long long> ctab_key, n_skipped, pre_stats;
+  DBuf<unsigned long long> ctab_key, n_skipped, pre_stats, best0;
   DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct, selpid, wpid, xpid;
   DBuf<uint16_t> klist, cnt; DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
   DBuf<uint32_t> bitsA, bitsB;
@@ -641,7 +641,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(wn.alloc(nqs)); HIPCHK(wcol.alloc(nqs * 32)); HIPCHK(wkey.alloc(nqs * 32)); HIPCHK(wpid.alloc(nqs * 32));
   HIPCHK(xlist.alloc(nqs * 32)); HIPCHK(xn.alloc(nqs)); HIPCHK(hard.alloc(nqs)); HIPCHK(xkey.alloc(nqs * 32)); HIPCHK(xpid.alloc(nqs * 32));
   HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(newq.alloc((size_t)Bmax + 1)); HIPCHK(rm.alloc((size_t)Bmax + 1));
-  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(pre_stats.alloc(4)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 4 * sizeof(unsigned long long), ctx->st));
+  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(best0.alloc(nqs)); HIPCHK(pre_stats.alloc(4)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 4 * sizeof(unsigned long long), ctx->st));
   HIPCHK(hipMemsetAsync(n_skipped.p, 0, sizeof(unsigned long long), ctx->st)); HIPCHK(ctab_key.alloc(16384)); HIPCHK(ctab_val.alloc(16384));
   HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1));
   if (n > 0) launch_hash_reads(ctx->rd, 0, 0, ctx->w_hf.p, ctx->w_hr.p, ctx->st);      // identical reads of a window share one search
@@ -663,7 +663,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
   a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
   a.is_new = is_new.p; a.new_rank = new_rank.p; a.newq = newq.p; a.rm = rm.p;
-  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p;
+  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p; a.best0 = best0.p;
   a.pre_k = std::min(16, (int)((double)Lmax * (1.0 - id) / id) + 1); a.ctab_key = ctab_key.p; a.ctab_val = ctab_val.p; a.rhash = ctx->w_hf.p;
   a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
   a.thr = 100.0 * id; a.n_align = n_align.p;
@@ -690,14 +690,16 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
     HIPCHK(cnt.alloc((size_t)(2 * (int64_t)nq * cpitch)));
     a.f = f; a.nq = nq; a.C = C; a.bits = bits->p; a.stride = capC / 32; a.cnt = cnt.p; a.cpitch = cpitch;
     launch_cl_kmers(a, ctx->st);
-    launch_cl_count(a, 0, (C + 2047) >> 11, ctx->st);
+    HIPCHK(hipMemsetAsync(best0.p, 0, 2 * (size_t)nq * sizeof(unsigned long long), ctx->st));
+    a.use_best0 = (C >= 131072 || getenv("ITSX_CL_BEST0")) ? 1 : 0;                              // the fused best key pays once a count row is long (measured: -4 % at 271 k centroids, +10 % at 60 k)
+    launch_cl_count(a, 0, (C + 2047) >> 11, a.use_best0, ctx->st);
     launch_cl_init(a, ctx->st);
     if (C > 0) launch_cl_walk(a, rows_per_lane, ctx->st);
     launch_cl_outcome(a, ctx->st);
     launch_exclusive_scan(is_new.p, new_rank.p, nq + 1, scan_tmp.p, ctx->st);
     launch_cl_columns(a, 0, ctx->st);
     const int tile0 = C >> 11;
-    launch_cl_count(a, tile0, (int)((((int64_t)C + nq - 1) >> 11) - tile0 + 1), ctx->st);
+    launch_cl_count(a, tile0, (int)((((int64_t)C + nq - 1) >> 11) - tile0 + 1), 0, ctx->st);
     launch_cl_validate(a, rows_per_lane, ctx->st);
     launch_cl_columns(a, 1, ctx->st);                       // roll back the speculative centroids that did not survive
     int32_t wo[3] = {0, 0, 0};

@@ -57,6 +57,8 @@ struct ClusterArgs {
   int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[2]
   const uint64_t *rhash;        // [n reads] XXH64 of the packed forward strand
   unsigned long long *ctab_key; int32_t *ctab_val; int32_t *canon;   // window-local table of identical reads; canon[nq]
+  unsigned long long *best0;    // [2 nq] best candidate key left by the counting pass (round 0 of the walk)
+  int32_t use_best0;            // large centroid sets: round 0 takes best0 instead of scanning the count row
   int32_t *replay;              // [nq] queries whose walk must be replayed by k_cl_resolve
   int32_t *skipm;               // [nq] minus-strand walk cut short because the plus strand holds a 100 % hit
   int32_t *wout;                // [3] cut, columns consumed, true new centroids
@@ -70,7 +72,7 @@ struct ClusterArgs {
   int32_t pre_k;                                 // largest edit budget K of this run (sizes the certificate's LDS rows)
 };
 void launch_cl_kmers(const ClusterArgs &a, hipStream_t st);
-void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st);
+void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, int with_best, hipStream_t st);
 void launch_cl_init(const ClusterArgs &a, hipStream_t st);
 void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st);
 void launch_cl_outcome(const ClusterArgs &a, hipStream_t st);

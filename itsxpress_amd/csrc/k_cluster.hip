@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void k_cl_kmers(ClusterArgs a)
 #define CSA(h, l, x, y, z) { const uint32_t u_ = (x) ^ (y); h = ((x) & (y)) | (u_ & (z)); l = u_ ^ (z); }
 static constexpr int HCL = 13;          // counts/8 < 8192
 
-__global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int ntiles)
+// with_best: the launch over the old centroids also leaves each query strand's BEST candidate key in best0[] (round 0 of the
+// walk then needs no pass over the count row); keys are ordered by the count first, so length and position are fetched
+// only for columns that reach the lane's running maximum
+__global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int ntiles, int with_best)
 {
   const int qs = blockIdx.y;
   if (a.canon[qs >> 1] != (qs >> 1)) return;
@@ -215,6 +218,25 @@ __global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int 
     }
     *reinterpret_cast<uint4 *>(out + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
   }
+  if (with_best) {
+    const uint32_t minm = n < 12 ? n : 12;
+    u64 best = 0;
+    uint32_t bestv = minm > 0 ? minm : 1;
+    const int c0 = tile * 2048 + lane * 32;
+#pragma unroll
+    for (int bit = 0; bit < 32; bit++) {
+      uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
+#pragma unroll
+      for (int b = 0; b < HCL; b++) if (b < nlev) v |= ((hc[b] >> bit) & 1u) << (3 + b);
+      const int c = c0 + bit;
+      if (v >= bestv && c < a.C) {
+        const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
+        if (key > best) { best = key; bestv = v; }
+      }
+    }
+    for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(best, off); best = o > best ? o : best; }
+    if (lane == 0 && best) atomicMax(&a.best0[qs], best);
+  }
 }
 
 // ------------------------------------------------------------------ the candidate walk
@@ -227,6 +249,20 @@ __global__ void k_cl_init(ClusterArgs a)
   a.state[qs] = a.canon[qs >> 1] != (qs >> 1) ? 4 : (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;      // 4 = a copy: reads its canonical query's state
   a.rejects[qs] = 0; a.acc_col[qs] = -1; a.wn[qs] = 0; a.selm[qs] = 0; a.sel_short[qs] = 0;
   a.prev[qs] = ~0ULL; a.bound[qs] = 0ULL; a.acc_id[qs] = -1.0; a.xn[qs] = 0; a.hard[qs] = 0;
+}
+
+// round 0 of the walk: the best key left by the counting pass is the only selected candidate
+__global__ void k_cl_pick0(ClusterArgs a)
+{
+  const int qs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qs >= 2 * a.nq || a.state[qs] != 0) return;
+  const u64 key = a.best0[qs];
+  if (key == 0) { a.selm[qs] = 0; a.sel_short[qs] = 1; return; }
+  const int32_t pos = (int32_t)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
+  int lo = 0, hi = a.C - 1;                                 // cent_pos grows with the column index
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cent_pos[mid] < pos) lo = mid + 1; else hi = mid; }
+  a.sel[qs * 32] = lo; a.selkey[qs * 32] = key; a.selm[qs] = 1; a.sel_short[qs] = 0;
+  a.work[atomicAdd(&a.work_n[0], 1)] = qs * 32;
 }
 
 // the next (up to kmax, within the reject budget) candidates strictly below the last one tried, in rank order.
@@ -820,10 +856,10 @@ void launch_cl_kmers(const ClusterArgs &a, hipStream_t st)
   hipLaunchKernelGGL(k_cl_canon_lookup, dim3((a.nq + 255) / 256), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_cl_kmers, dim3(2 * a.nq), dim3(256), 0, st, a);
 }
-void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, hipStream_t st)
+void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, int with_best, hipStream_t st)
 {
   if (ntiles <= 0) return;
-  hipLaunchKernelGGL(k_cl_count, dim3((ntiles + 3) / 4, 2 * a.nq), dim3(256), 0, st, a, tile0, ntiles);
+  hipLaunchKernelGGL(k_cl_count, dim3((ntiles + 3) / 4, 2 * a.nq), dim3(256), 0, st, a, tile0, ntiles, with_best);
 }
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
 static size_t precheck_lds(const ClusterArgs &a)
@@ -836,7 +872,8 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   // round 0: the best candidate of every query (most reads accept it); round 1: the whole remaining reject budget at once
   for (int round = 0; round < 2; round++) {
     const int kmax = round == 0 ? 1 : 31;
-    hipLaunchKernelGGL(k_cl_select, dim3(2 * a.nq), dim3(256), 0, st, a, kmax);
+    if (round == 0 && a.use_best0) hipLaunchKernelGGL(k_cl_pick0, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_cl_select, dim3(2 * a.nq), dim3(256), 0, st, a, kmax);
     const int grid = std::min(2 * a.nq * kmax, 16384);
     const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
     if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 0);

@@ -81,6 +81,14 @@ def test_cluster_matches_oracle(engine, cid):
     assert 60 <= o["n_centroids"] < 3000 and (o["strand"] < 0).sum() > 100
 
 
+def test_cluster_fused_best_key_path(engine, monkeypatch):
+    # large centroid sets take round 0's candidate from the counting pass (best0) instead of a scan of the count row;
+    # forced here on a small library
+    monkeypatch.setenv("ITSX_CL_BEST0", "1")
+    reads, names = _noisy_library(41, 1500, 30, (200, 260), n_rate=0.01)
+    _compare(engine, reads, names, 0.985)
+
+
 @pytest.mark.parametrize("window", ["1", "7", "64", "4096"])
 def test_cluster_is_independent_of_the_window(engine, window, monkeypatch):
     monkeypatch.setenv("ITSX_CL_WINDOW", window)

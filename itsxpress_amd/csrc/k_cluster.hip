@@ -159,10 +159,12 @@ static constexpr int HCL = 13;          // counts/8 < 8192
 // only for columns that reach the lane's running maximum
 __global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int ntiles, int with_best)
 {
-  const int qs = blockIdx.y;
+  // query strands vary fastest over the grid: the blocks in flight share one group of 4 tiles, whose touched rows
+  // (1 KB each) then stay in L2 / MALL while every query of the window streams over them
+  const int qs = blockIdx.x;
   if (a.canon[qs >> 1] != (qs >> 1)) return;
   const int lane = threadIdx.x & 63;
-  const int tile = tile0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile = tile0 + blockIdx.y * 4 + (threadIdx.x >> 6);
   if (tile >= tile0 + ntiles) return;
   const int n = a.nk[qs];
   const uint16_t *kl = a.klist + (size_t)qs * a.kcap;
@@ -859,7 +861,7 @@ void launch_cl_kmers(const ClusterArgs &a, hipStream_t st)
 void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, int with_best, hipStream_t st)
 {
   if (ntiles <= 0) return;
-  hipLaunchKernelGGL(k_cl_count, dim3((ntiles + 3) / 4, 2 * a.nq), dim3(256), 0, st, a, tile0, ntiles, with_best);
+  hipLaunchKernelGGL(k_cl_count, dim3(2 * a.nq, (ntiles + 3) / 4), dim3(256), 0, st, a, tile0, ntiles, with_best);
 }
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
 static size_t precheck_lds(const ClusterArgs &a)

@@ -47,13 +47,13 @@ __global__ void k_wave_rows_regions(const WaveDesc *w, int nw, const RegionRec *
 }
 __global__ void k_pair_counters(const PairOut *po, int64_t n, unsigned long long *c)
 {
-  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const PairOut o = po[i];
-    a0 += o.pass_bias; a1 += o.pass_fwd; a2 += o.pass_fwd ? o.nregions : 0; a3 += (o.flags & 2) ? 1 : 0;
+    a0 += o.pass_bias; a1 += o.pass_fwd; a2 += o.pass_fwd ? o.nregions : 0; a3 += (o.flags & 2) ? 1 : 0; a4 += o.pass_fwd ? ((o.flags >> 8) & 0xff) : 0;
   }
-  for (int d = 32; d >= 1; d >>= 1) { a0 += __shfl_down(a0, d, 64); a1 += __shfl_down(a1, d, 64); a2 += __shfl_down(a2, d, 64); a3 += __shfl_down(a3, d, 64); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&c[0], a0); atomicAdd(&c[1], a1); atomicAdd(&c[2], a2); atomicAdd(&c[3], a3); }
+  for (int d = 32; d >= 1; d >>= 1) { a0 += __shfl_down(a0, d, 64); a1 += __shfl_down(a1, d, 64); a2 += __shfl_down(a2, d, 64); a3 += __shfl_down(a3, d, 64); a4 += __shfl_down(a4, d, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&c[0], a0); atomicAdd(&c[1], a1); atomicAdd(&c[2], a2); atomicAdd(&c[3], a3); atomicAdd(&c[4], a4); }
 }
 __global__ void k_gather_i32(const int32_t *src, const int64_t *idx, int n, int32_t *out)
 {
@@ -1145,7 +1145,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     int64_t hc[8];
     HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    S.n_past_bias += hc[0]; S.n_past_fwd += hc[1]; S.n_regions += hc[2]; S.n_domain_overflow += hc[3];
+    S.n_past_bias += hc[0]; S.n_past_fwd += hc[1]; S.n_regions += hc[2]; S.n_domain_overflow += hc[3]; S.n_multidomain += hc[4];
   }
   if (ctx->keep_trace) { const int rc = append_traces(ctx); if (rc != ITSX_OK) return rc; }
   return ITSX_OK;

@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
   const int L = pr.L;
   const int64_t r0 = wd.slab;
   // ---- posterior decoding + region scan, rows ascending (the order the sums are defined in)
-  int nreg = 0, nkept = 0, flags = 0;
+  int nreg = 0, nkept = 0, flags = 0, nmulti = 0;
   if (alive && !bad) {
     const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
     float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, XF, 7, lane));
@@ -655,6 +655,7 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
           mx = m2 > mx ? m2 : mx;
         }
         const int multi = (mx >= rt3);
+        nmulti += multi;
         if (nkept < MAXDOM) {
           RegionRec rr; rr.pair = (int32_t)pi; rr.ienv = ri; rr.jenv = j; rr.multi = multi;
           a.regions[pi * MAXDOM + nkept] = rr;
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
     }
     if (scaleproduct == __builtin_inff()) { nreg = 0; nkept = 0; }
   }
-  if (active && alive) { po.nregions = nreg; po.ndom = nkept; po.flags = flags; a.pout[pi] = po; }
+  if (active && alive) { po.nregions = nreg; po.ndom = nkept; po.flags = flags | ((nmulti > 255 ? 255 : nmulti) << 8); a.pout[pi] = po; }   // bits 8-15: multidomain regions (statistics)
 }
 
 // =========================================================================================
@@ -974,7 +975,7 @@ DEV void emit_domain(const ScoreArgs &a, int64_t slot, const PairRec &pr, const 
   const float dombias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)domcorr));
   bits = (float)((double)(bits - (nullsc + dombias)) / kLn2);
   o.rep = a.sorted_uniq[pr.useq]; o.prof = pr.prof; o.tlen = L; o.ienv = rg.ienv; o.jenv = rg.jenv;
-  o.dom_idx = dom_idx; o.ndom = ndom; o.flags = (rg.multi ? 1 : 0) | poflags;
+  o.dom_idx = dom_idx; o.ndom = ndom; o.flags = (rg.multi ? 1 : 0) | (poflags & 0xff);
   o.envsc = ro.envsc; o.domcorrection = domcorr; o.dombias = dombias; o.bitscore = bits;
   o.lnP = exp_logsurv((double)bits, (double)pp->ev[4], (double)pp->ev[5]);
   o.seq_score = seq_score; o.seq_bias = (float)((double)final_bias / kLn2);

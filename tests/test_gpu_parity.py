@@ -192,6 +192,7 @@ def _compare(engine, res, left="3_", right="4_"):
     c = res.counts
     s = engine.stats()
     assert (s["n_past_msv"], s["n_past_bias"], s["n_past_fwd"]) == (c["past_msv"], c["past_bias"], c["past_fwd"])
+    assert s["n_multidomain"] == c["multidomain"]
 
 
 def test_search_fixture_mini_profiles(engine, fixture_reads, mini_hmm_text):

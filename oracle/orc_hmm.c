@@ -310,7 +310,7 @@ orc_hmmset *orc_hmmset_parse(const char *text, int64_t len, char *err, int errle
     i++;                                          /* node-0 insert emissions (inserts are scored 0) */
     if (i >= nl) FAIL("truncated model");
     { int n = split_ws(lines[i], tok, 16); if (n < 7) FAIL("bad node-0 transition line");
-      for (int x = 0; x < 7; x++) p->t[x] = prob_from_tok(tok[x]); i++; }
+      for (int x = 0; x < 7; x++) { p->t[x] = prob_from_tok(tok[x]); } i++; }
     for (int k = 1; k <= M; k++) {
       if (i + 2 >= nl) FAIL("truncated model");
       int n = split_ws(lines[i], tok, 16);

@@ -2,7 +2,7 @@
  * orc_hmm.c -- ORACLE (test infrastructure only): HMMER3/f text parser and profile
  * configuration, restating what `hmmsearch` does to each query model before it
  * scores anything (reference call site: itsxpress/SeqSample.py:191-209; model
- * files: itsxpress/ITSx_db/HMMs/*.hmm; selection: itsxpress/main.py:176-231).
+ * files: itsxpress/ITSx_db/HMMs/ (one .hmm per taxon); selection: itsxpress/main.py:176-231).
  *
  * HMMER (>=3.1b2, recipes/itsxpress/meta.yaml:36) is not vendored in the
  * reference; this restates its published algorithm: p7_hmmfile (ASCII 3/f),

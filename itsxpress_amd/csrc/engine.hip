@@ -431,6 +431,7 @@ static int pack_and_upload(itsx_ctx *ctx)
   HIPCHK(ctx->d_exc.alloc((size_t)nexc + 1));
   launch_pack_exc(d_raw.p, d_off.p, n, d_lut.p, d_excnt.p, d_exstart.p, ctx->d_excoff.p, ctx->d_exc.p, ctx->st);
   HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipGetLastError());
   ctx->rd.words = ctx->d_words.p; ctx->rd.woff = ctx->d_woff.p; ctx->rd.len = ctx->d_len.p;
   ctx->rd.excoff = ctx->d_excoff.p; ctx->rd.exc = ctx->d_exc.p; ctx->rd.n = n;
   ctx->have_derep = ctx->have_search = ctx->have_final = false;
@@ -583,6 +584,7 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
   if (hcoll != 0) SET_ERR(ctx, ITSX_E_COLLISION, "64-bit key collisions survived 4 reseeds");
   { const int rc_ = build_unique_lists(ctx); if (rc_ != ITSX_OK) return rc_; }
   ctx->stats.ms_derep = tm.stop();
+  HIPCHK(hipGetLastError());
   { const int rc_ = mirror_derep(ctx); if (rc_ != ITSX_OK) return rc_; }
   const int32_t U = ctx->U;
   int64_t dropped = 0;
@@ -606,7 +608,8 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   // processing order: abundance (all 1) descending, then label, then input position
   std::vector<int32_t> ord; ord.reserve((size_t)n);
   int Lmax = 1;
-  for (int64_t r = 0; r < n; r++) if (ctx->h_len[r] >= minlen) { ord.push_back((int32_t)r); Lmax = std::max(Lmax, (int)ctx->h_len[r]); }
+  for (int64_t r = 0; r < n; r++)                          // vsearch defaults: --minseqlength 32, --maxseqlength 50000
+    if (ctx->h_len[r] >= minlen && ctx->h_len[r] <= 50000) { ord.push_back((int32_t)r); Lmax = std::max(Lmax, (int)ctx->h_len[r]); }
   if (!ctx->h_names.empty())
     std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
       const int c = strcmp(ctx->h_names[a].c_str(), ctx->h_names[b].c_str());
@@ -705,6 +708,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
     int32_t wo[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(wo, wout.p, sizeof(wo), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());                              // a kernel that failed to launch must not pass silently
     const int32_t cut = wo[0];
     if (debug) {
       int32_t d[4] = {0, 0, 0, 0};
@@ -1147,6 +1151,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     HIPCHK(hipStreamSynchronize(st));
     S.n_past_bias += hc[0]; S.n_past_fwd += hc[1]; S.n_regions += hc[2]; S.n_domain_overflow += hc[3]; S.n_multidomain += hc[4];
   }
+  HIPCHK(hipGetLastError());                                // a kernel of this chunk that failed to launch must not pass silently
   if (ctx->keep_trace) { const int rc = append_traces(ctx); if (rc != ITSX_OK) return rc; }
   return ITSX_OK;
 }
@@ -1307,6 +1312,7 @@ int itsx_orient(itsx_ctx *ctx, int8_t *strand, int32_t *count_fwd, int32_t *coun
   DBuf<int8_t> d_s; DBuf<int32_t> d_f, d_r;
   HIPCHK(d_s.alloc((size_t)n)); HIPCHK(d_f.alloc((size_t)n)); HIPCHK(d_r.alloc((size_t)n));
   launch_orient(ctx->rd, ctx->d_orient_db.p, d_s.p, d_f.p, d_r.p, ctx->st);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(strand, d_s.p, (size_t)n, hipMemcpyDeviceToHost, ctx->st));
   if (count_fwd) HIPCHK(hipMemcpyAsync(count_fwd, d_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
   if (count_rev) HIPCHK(hipMemcpyAsync(count_rev, d_r.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
@@ -1387,6 +1393,7 @@ int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const
   StageTimer tm(ctx->st);
   launch_merge(a, ctx->st);
   ctx->stats.ms_merge = tm.stop();
+  HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_seq, d_os.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st)); HIPCHK(hipMemcpyAsync(out_qual, d_oq.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipMemcpyAsync(out_len, d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st)); HIPCHK(hipMemcpyAsync(reason, d_reason.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
   if (score) HIPCHK(hipMemcpyAsync(score, d_score.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));

@@ -9,7 +9,7 @@
  * defaults; the engine (itsxpress_amd/csrc/k_cluster.hip) must equal THIS bit for bit.
  *
  * The procedure
- *  1. reads shorter than --minseqlength (32) are dropped; the rest are processed in order of
+ *  1. reads shorter than --minseqlength (32) or longer than --maxseqlength (50000) are dropped; the rest are processed in order of
  *     decreasing abundance (all 1: FASTQ input carries no ;size=), ties by label (strcmp), then by
  *     input position;
  *  2. a query is compared with the existing centroids on both strands.  Per strand: the DISTINCT
@@ -141,7 +141,7 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
   for (int64_t r = 0; r < n; r++) {
     const int64_t L = offsets[r + 1] - offsets[r];
     rep_of[r] = -1; strand[r] = 1; pct_id[r] = -1.0;
-    if (L < minlen) continue;
+    if (L < minlen || L > 50000) continue;                 /* --minseqlength 32, --maxseqlength 50000 (vsearch defaults) */
     if (L > Lmax) Lmax = L;
     ord[nk].idx = r;
     ord[nk].lab = labels ? labels + label_offsets[r] : "";

@@ -48,9 +48,12 @@ def cpu_baseline(hmm_its2, blob, offs, sample_reads, threads):
     seeds = [i for i in range(len(seqs)) if rep[i] == i]
     c2, o2 = orc.digitize([seqs[i] for i in seeds])
     res = orc.SearchResult(hs, c2, o2, threads=threads, keep_trace=0)
-    res.positions("3_", "4_")
+    us, ue, ut, ui = res.positions("3_", "4_")
     dt = time.time() - t0
-    return sample_reads / dt, dt, nc
+    uniq = np.cumsum(np.asarray(rep) == np.arange(len(seqs))) - 1          # unique index of each seed, in input order
+    uo = uniq[np.asarray(rep)]
+    coords = np.stack([us[uo], ue[uo], ut[uo]], axis=1)                      # per read of the sample: the baseline path's answer
+    return sample_reads / dt, dt, nc, coords
 
 
 def main():
@@ -196,9 +199,21 @@ def main():
             threads = os.cpu_count() or 1
             if args.cpu_sample < 0:                      # ~1 s per 80 reads per core on the scalar port
                 args.cpu_sample = int(min(40000, max(1200, 120 * threads)))
-            v, cdt, nc = cpu_baseline(hmm, blob, offs, min(args.cpu_sample, args.reads), threads)
+            m = min(args.cpu_sample, args.reads)
+            v, cdt, nc, ccoords = cpu_baseline(hmm, blob, offs, m, threads)
+            # trim-coordinate concordance (BASELINE metric): the engine on the very same sample against the baseline path
+            e2 = Engine(local_rank)
+            e2.load_profiles(text=hmm)
+            e2.set_reads_buffer(blob[:int(offs[m])], offs[:m + 1])
+            e2.derep(strand_both=True, minseqlength=32)
+            e2.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
+            e2.finalize(domE=10.0)
+            gs, ge, gt, _ = e2.trim_coords("3_", "4_")
+            e2.close()
+            conc = float((np.stack([gs, ge, gt], axis=1) == ccoords).all(axis=1).mean())
             res["cpu_baseline"] = {"value": v, "unit": "reads/s", "cores": threads, "kind": "port",
-                                   "sample": "first %d reads of the same workload (%d unique), derep+search+argmax, %.1f s" % (min(args.cpu_sample, args.reads), nc, cdt)}
+                                   "sample": "first %d reads of the same workload (%d unique), derep+search+argmax, %.1f s" % (m, nc, cdt),
+                                   "trim_coord_concordance": conc}
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -359,6 +359,17 @@ def test_errors_are_loud(engine, tmp_path):
         engine.search(F1=1e-6, F2=1e-3)
 
 
+def test_tiny_slab_budget_only_adds_batches(engine, t_hmm_text, monkeypatch):
+    """The DP slabs are cut into batches by an HBM budget; the smallest budget the engine accepts (0.25 GB, several batches
+    here instead of one) must not change a bit."""
+    monkeypatch.setenv("ITSX_SLAB_GB", "0.25")
+    monkeypatch.setenv("ITSX_KEEP_TRACE", "1")
+    blob, offs = synth.make_reads(t_hmm_text, 2500, seed=29, fixed_len=0, len_range=(150, 400))
+    res = _run_both(engine, _its2_subset(t_hmm_text, 30, 30), synth.to_strings(blob, offs), threads=64)
+    assert engine.stats()["n_batches"] >= 3
+    _compare(engine, res)
+
+
 def test_chunked_search_is_identical_to_one_chunk(engine, t_hmm_text, monkeypatch):
     """Large inputs are searched in chunks of unique reads; a forced tiny chunk size must not change anything
     (domZ, thresholds and the argmax span chunks)."""

@@ -272,6 +272,17 @@ def test_oracle_thread_count_does_not_change_results(fixture_reads, mini_hmm_tex
 
 
 # ---------------------------------------------------------------- the engine library, without a GPU
+def test_cabi_header_is_plain_c():
+    """the boundary is a C ABI: the header must compile as C99 (and as C++) on its own"""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "itsx_hip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", hdr], check=True)
+
+
 def test_cabi_library_exports_every_declared_symbol():
     from itsxpress_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "itsx_hip.h")).read()

@@ -151,18 +151,31 @@ def main():
                 "k_bwd_decode": acc["ms_bwd_kernel"] / K, "k_decode": acc["ms_decode_kernel"] / K,
                 "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K}
         dom = max(kern, key=kern.get)
-        # algorithmic HBM bytes of the dominant kernel, per step
+        # algorithmic HBM bytes of each main kernel, per step
         U, L = st["n_unique"], 300
-        if dom == "k_msv":
-            alg_bytes = U * ((nprof + 63) // 64) * ((L + 15) // 16 * 4) + 2 * ((nprof + 63) // 64 * 64) * U
-        elif dom == "k_filters_fwd":      # per pair: packed read + PairRec/PairOut; per row: 6 special-state floats written
-            alg_bytes = st["n_past_msv"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 24
-        elif dom == "k_bwd_decode":       # per row: Forward's 6 floats read, 6 decoding terms written
-            alg_bytes = st["n_past_fwd"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 48
-        elif dom == "k_decode":           # per row: 5 terms read, btot/etot written
-            alg_bytes = st["n_past_fwd"] * (16 + 40) + st["fwd_rows"] * 28
-        else:   # envelope sweeps: Backward rows written once, read once (26 float4 per row), + 88 B result per envelope
-            alg_bytes = st["env_rows"] * 2 * 26 * 16 + st["n_domains"] * (16 + 88)
+        alg = {
+            "k_msv": U * ((nprof + 63) // 64) * ((L + 15) // 16 * 4) + 2 * ((nprof + 63) // 64 * 64) * U,
+            # per pair: packed read + PairRec/PairOut; per row: 6 special-state floats written
+            "k_filters_fwd": st["n_past_msv"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 24,
+            # per row: Forward's 6 floats read, 6 decoding terms written
+            "k_bwd_decode": st["n_past_fwd"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 48,
+            # per row: 5 terms read (nothing written back)
+            "k_decode": st["n_past_fwd"] * (16 + 40) + st["fwd_rows"] * 20,
+            # envelope sweeps: Backward rows written once, read once (26 float4 per row), + 88 B result per envelope
+            "k_env_fwd+k_env_bwd+k_env_post": st["env_rows"] * 2 * 26 * 16 + st["n_domains"] * (16 + 88),
+        }
+        alg_bytes = alg[dom]
+        # what bounds each of them: wave instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles (VALU-bound scans),
+        # algorithmic GB/s against HBM for the streaming ones
+        WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4
+        vfrac = {
+            "k_msv": (st["msv_cells"] / 20.5) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 20.5 cells per wave instruction
+            "k_filters_fwd": (st["fwd_rows"] / 64 * 560) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
+            "k_bwd_decode": (st["fwd_rows"] / 64 * 560) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
+        }
+        kernel_table = {k: {"ms": round(kern[k], 3), "alg_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) if kern[k] > 0 else None,
+                            "hbm_frac": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern[k] > 0 else None,
+                            "valu_issue_frac": round(vfrac[k], 3) if vfrac.get(k) else None} for k in kern}
         achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
         # launches of the dominant kernel in one step, for per-launch figures
         nl = {"k_msv": 1}.get(dom, max(1, int(st.get("n_batches", 1))))
@@ -181,6 +194,7 @@ def main():
                        "unique": int(st["n_unique"]), "pairs_past_msv": int(st["n_past_msv"]), "pairs_past_fwd": int(st["n_past_fwd"]),
                        "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed, "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
+            "kernels": kernel_table,
             "cluster": None if args.cluster_id >= 1.0 else {"windows": int(st["cl_windows"]), "cut_windows": int(st["cl_cuts"]),
                                                             "alignments": int(st["cl_alignments"]), "centroids": int(st["n_unique"])},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

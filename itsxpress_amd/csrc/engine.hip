@@ -997,13 +997,13 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   S.ms_msv += tm_list.stop();
 
   // ---- batches of waves sized to the slab budget
-  if (ctx->slab_gb <= 0.0) {            // decided once per context: a quarter of the free HBM, at most 64 GB
+  if (ctx->slab_gb <= 0.0) {            // the default is decided once per context: a quarter of the free HBM, at most 64 GB
     ctx->slab_gb = 16.0;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) ctx->slab_gb = std::min(64.0, std::max(1.0, (double)fr / (double)(1ull << 30) / 4.0));
-    if (const char *e = getenv("ITSX_SLAB_GB")) ctx->slab_gb = std::max(0.25, atof(e));
   }
-  const double slab_gb = ctx->slab_gb;
+  double slab_gb = ctx->slab_gb;
+  if (const char *e = getenv("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));     // read at every call
   const int64_t row_bytes = 12 * 64 * 4;                   // XF fields of k_float.hip's parser slab
   const int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
   DBuf<RegionRec> &d_raw = ctx->w_raw;

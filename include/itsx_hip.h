@@ -204,14 +204,24 @@ int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out);
  * itsx_write_trimmed_paired replaces Dedup.create_paired_trimmed_seqs (SeqSample.py:713-790): R1/R2 pair k is
  * looked up by the id of its R1 title among `names` (the merged reads the coordinates belong to) and sliced
  * with the reference's r2start = tlen - stop / r2end = tlen - start arithmetic.  trim_ccs stitches the CCS
- * primers with quality 93.  Errors: negative code, text from itsx_trim_last_error(). */
-int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int gzipped, int trim_ccs,
+ * primers with quality 93.  Errors: negative code, text from itsx_trim_last_error().
+ * Inputs are plain, gzip or zstd (told apart by their magic bytes; the reference goes by .gz / .zst, main.py:296-330).
+ * `compression` of the output: 0 plain, 1 gzip, 2 zstd (the reference's gzipped / zstd_file flags, SeqSample.py:909-925).
+ * Compressed output is written as concatenated gzip members / zstd frames produced by a pool of threads
+ * (ITSX_IO_THREADS, default min(hardware threads, 32)); any gzip / zstd reader sees one stream. */
+int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int compression, int trim_ccs,
                              const int32_t *start, const int32_t *stop, int64_t n_records,
                              int64_t *n_written, int64_t *total_len);
 int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const char *out1_path, const char *out2_path,
-                              int gzipped, int trim_ccs, const char *names, const int64_t *name_offsets, int64_t n_names,
+                              int compression, int trim_ccs, const char *names, const int64_t *name_offsets, int64_t n_names,
                               const int32_t *start, const int32_t *stop, const int32_t *tlen, int64_t *n_written);
 const char *itsx_trim_last_error(void);
+/* The readers behind every *_file entry point, exposed for the host side (replaces gzip.open / pyzstd.open of
+ * main.py:296-330 and SeqSample.py:929-949): the decompressed content of a plain / gzip / zstd file in a buffer the
+ * caller releases with itsx_io_free.  itsx_io_codecs: bit 0 = libdeflate in use for gzip, bit 1 = libzstd available. */
+int  itsx_io_read(const char *path, char **text, int64_t *len);
+void itsx_io_free(char *text);
+int  itsx_io_codecs(void);
 
 /* ---- test hooks (parity tests only) */
 /* XXH64 of each read's packed forward / reverse-complement key, as computed on the device */

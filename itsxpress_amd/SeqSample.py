@@ -179,8 +179,6 @@ class SeqSamplePairedNotInterleaved(SeqSample):
         try:
             if self.r1 is None or self.fastq2 is None:
                 raise ValueError("Both r1 and fastq2 paths must be defined to merge reads.")
-            if self.r1.endswith(".zst") or self.fastq2.endswith(".zst"):
-                raise EngineError(-5, "zstd-compressed input is not supported by the HIP engine (no libzstd in this build)")
             os.makedirs(self.tempdir, exist_ok=True)
             seq_file = os.path.join(self.tempdir, "seq.fq")
             n, m = self.engine.merge_pairs_files(self.r1, self.fastq2, seq_file, maxdiffs=maxmismatches, maxee=2.0,
@@ -302,13 +300,11 @@ class Dedup:
         """Single-end: write seq_file's records trimmed to record[start:stop] (same filter as the reference)."""
         from .engine import read_fastx
         from .trim import coords_from_dicts, write_trimmed_fastq
-        if zstd_file:
-            raise ValueError("zstd output is not supported by the native writer; write .gz or plain")
         if not wri_file:
             return
         names, _ = read_fastx(self.seq_file)
         start, stop, _ = coords_from_dicts(names, self.matchdict, itspos)
-        write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs)
+        write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)
 
     def create_paired_trimmed_seqs(self, outfile1: str, outfile2: str, gzipped: bool, zstd_file: bool,
                                    itspos: "ItsPosition", wri_file: bool, trim_ccs: bool = False) -> None:
@@ -316,14 +312,12 @@ class Dedup:
         from .trim import coords_from_dicts, write_trimmed_paired
         if self.fastq is None or self.fastq2 is None:
             raise ValueError("Both fastq and fastq2 paths must be defined to create paired trimmed sequences.")
-        if zstd_file:
-            raise ValueError("zstd output is not supported by the native writer; write .gz or plain")
         if not wri_file:
             return
         names = list(self.matchdict.keys())
         start, stop, tlen = coords_from_dicts(names, self.matchdict, itspos)
         write_trimmed_paired(self.fastq, self.fastq2, outfile1, outfile2, names, start, stop, tlen,
-                             gzipped=gzipped, trim_ccs=trim_ccs)
+                             gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)
 
     @classmethod
     def from_engine(cls, engine: Engine, names) -> "Dedup":

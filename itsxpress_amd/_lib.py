@@ -57,7 +57,8 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath",
            "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
            "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_tables",
-           "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq"]
+           "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq",
+           "itsx_io_read", "itsx_io_free", "itsx_io_codecs"]
 
 
 def lib():
@@ -115,6 +116,9 @@ def lib():
         "itsx_write_trimmed_fastq": (i32, [cp, cp, i32, i32, vp, vp, i64, vp, vp]),
         "itsx_write_trimmed_paired": (i32, [cp, cp, cp, cp, i32, i32, vp, vp, i64, vp, vp, vp, vp]),
         "itsx_trim_last_error": (cp, []),
+        "itsx_io_read": (i32, [cp, vp, vp]),
+        "itsx_io_free": (None, [vp]),
+        "itsx_io_codecs": (i32, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -9,7 +9,6 @@
 // Everything numeric runs on the device; the host parses text, packs reads, sizes buffers,
 // builds per-length constant tables with libm (as hmmsearch does on its host), and sorts rows
 // for the file-compatible writers.  There is no CPU fallback for any stage.
-#include <zlib.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +20,7 @@
 #include "detmath.h"
 #include "engine.h"
 #include "k_api.h"
+#include "fastq_io.h"
 
 namespace itsx {
 void launch_region_counts(const PairOut *pout, int64_t npairs, int32_t *cnt, hipStream_t st);
@@ -341,23 +341,19 @@ int itsx_load_profiles_mem(itsx_ctx *ctx, const char *text, int64_t len, int *n_
   return install_profiles(ctx, pv, n_profiles);
 }
 
-static int slurp(const char *path, std::string &out)
+// whole file, decompressed by its magic bytes (fastq_io.h); read files stay in the text cache for the writers
+static std::shared_ptr<const std::string> slurp(const char *path, bool cacheable, std::string &err)
 {
-  gzFile f = gzopen(path, "rb");      // transparently reads plain files too
-  if (!f) return -1;
-  char buf[1 << 16];
-  int n;
-  while ((n = gzread(f, buf, sizeof(buf))) > 0) out.append(buf, (size_t)n);
-  gzclose(f);
-  return n < 0 ? -1 : 0;
+  return itsx_io::read_text(path, err, cacheable);
 }
 
 int itsx_load_profiles_file(itsx_ctx *ctx, const char *hmm_path, int *n_profiles)
 {
   CTXCHK(ctx && hmm_path);
-  std::string text;
-  if (slurp(hmm_path, text) != 0) SET_ERR(ctx, ITSX_E_IO, std::string("cannot read ") + hmm_path);
-  return itsx_load_profiles_mem(ctx, text.data(), (int64_t)text.size(), n_profiles);
+  std::string err;
+  const auto tp = slurp(hmm_path, false, err);
+  if (!tp) SET_ERR(ctx, ITSX_E_IO, err);
+  return itsx_load_profiles_mem(ctx, tp->data(), (int64_t)tp->size(), n_profiles);
 }
 
 int itsx_profile_name(const itsx_ctx *ctx, int i, char *buf, int buflen)
@@ -459,8 +455,10 @@ int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int
 int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
 {
   CTXCHK(ctx && path);
-  std::string text;
-  if (slurp(path, text) != 0) SET_ERR(ctx, ITSX_E_IO, std::string("cannot read ") + path);
+  std::string rerr;
+  const auto tp = slurp(path, true, rerr);
+  if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
+  const std::string &text = *tp;
   ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
   const char *s = text.data(), *end = s + text.size();
   auto next_line = [&](const char *&b, const char *&e) -> bool {
@@ -1279,8 +1277,10 @@ int itsx_orient_load_db(itsx_ctx *ctx, const char *fasta_path, int64_t *n_sequen
   CTXCHK(ctx && fasta_path);
   HIPCHK(hipSetDevice(ctx->device));
   init_codes();
-  std::string text;
-  if (slurp(fasta_path, text) != 0) SET_ERR(ctx, ITSX_E_IO, std::string("cannot read ") + fasta_path);
+  std::string rerr;
+  const auto tp = slurp(fasta_path, false, rerr);
+  if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
+  const std::string &text = *tp;
   std::vector<uint32_t> bits(1u << 19, 0u);                 // 4^12 bits
   int64_t nseq = 0;
   uint32_t w = 0; int good = 0; bool header = false;
@@ -1409,8 +1409,10 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   CTXCHK(ctx && r1_path && r2_path && out_path);
   struct Side { std::string seq, qual; std::vector<int64_t> off{0}; std::vector<std::string> ids; };
   auto parse = [&](const char *path, Side &sd) -> int {
-    std::string text;
-    if (slurp(path, text) != 0) { ctx->set_error(std::string("cannot read ") + path); return ITSX_E_IO; }
+    std::string rerr;
+    const auto tp = slurp(path, true, rerr);
+    if (!tp) { ctx->set_error(rerr); return ITSX_E_IO; }
+    const std::string &text = *tp;
     const char *s = text.data(), *end = s + text.size();
     auto line = [&](const char *&b, const char *&e) -> bool {
       if (s >= end) return false;

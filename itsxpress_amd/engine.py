@@ -4,7 +4,6 @@ Nothing here computes: every method forwards to libitsx_hip.so and copies result
 arrays the caller owns.  See include/itsx_hip.h for the reference interface each call replaces.
 """
 import ctypes as C
-import gzip
 import os
 
 import numpy as np
@@ -300,30 +299,28 @@ class Engine:
 
 
 def read_fastx(path):
-    """Minimal FASTA/FASTQ(.gz) reader used by tests and the bench: returns (names, seqs)."""
-    op = gzip.open if str(path).endswith(".gz") else open
+    """Minimal FASTA/FASTQ reader (plain, .gz or .zst, through the engine's file reader) used by the host side,
+    tests and the bench: returns (names, seqs)."""
+    from .trim import read_text
+    lines = read_text(path).decode().split("\n")
     names, seqs = [], []
-    with op(path, "rt") as f:
-        first = f.readline()
-        if not first:
-            return names, seqs
-        if first[0] == "@":
-            line = first
-            while line:
-                names.append(line[1:].split()[0])
-                seqs.append(f.readline().rstrip("\n"))
-                f.readline()
-                f.readline()
-                line = f.readline()
-        else:
-            cur = []
-            names.append(first[1:].split()[0])
-            for line in f:
-                if line[0] == ">":
+    if not lines or not lines[0]:
+        return names, seqs
+    if lines[0][0] == "@":
+        i = 0
+        while i < len(lines) and lines[i]:
+            names.append(lines[i][1:].split()[0])
+            seqs.append(lines[i + 1].rstrip("\r") if i + 1 < len(lines) else "")
+            i += 4
+    else:
+        cur = []
+        for line in lines:
+            if line[:1] == ">":
+                if names:
                     seqs.append("".join(cur))
-                    cur = []
-                    names.append(line[1:].split()[0])
-                else:
-                    cur.append(line.strip())
-            seqs.append("".join(cur))
+                cur = []
+                names.append(line[1:].split()[0])
+            else:
+                cur.append(line.strip())
+        seqs.append("".join(cur))
     return names, seqs

@@ -17,22 +17,44 @@ def _i32(a):
     return np.ascontiguousarray(a, np.int32)
 
 
-def write_trimmed_fastq(seq_file, outfile, start, stop, gzipped=False, trim_ccs=False):
+def _compression(gzipped, zstd_file):
+    """The reference's two flags (SeqSample.py:909-925; gzipped wins) -> the C ABI's compression kind."""
+    return 1 if gzipped else (2 if zstd_file else 0)
+
+
+def read_text(path):
+    """Decompressed bytes of a plain / gzip / zstd file through the engine's reader (gzip.open / pyzstd.open of
+    main.py:296-330)."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    L = _lib.lib()
+    buf, n = C.c_void_p(), C.c_int64(0)
+    rc = L.itsx_io_read(os.fsencode(path), C.byref(buf), C.byref(n))
+    if rc != 0:
+        raise EngineError(rc, L.itsx_trim_last_error().decode())
+    try:
+        return C.string_at(buf, n.value)
+    finally:
+        L.itsx_io_free(buf)
+
+
+def write_trimmed_fastq(seq_file, outfile, start, stop, gzipped=False, trim_ccs=False, zstd_file=False):
     """record i of seq_file -> record[start[i]:stop[i]] when both >= 0 and start < stop.
-    Returns (records written, summed trimmed length)."""
+    Output plain, gzip (gzipped) or zstd (zstd_file).  Returns (records written, summed trimmed length)."""
     if not os.path.exists(seq_file):
         raise FileNotFoundError(seq_file)
     L = _lib.lib()
     start, stop = _i32(start), _i32(stop)
     n, tot = C.c_int64(0), C.c_int64(0)
-    rc = L.itsx_write_trimmed_fastq(os.fsencode(seq_file), os.fsencode(outfile), int(gzipped), int(trim_ccs),
+    rc = L.itsx_write_trimmed_fastq(os.fsencode(seq_file), os.fsencode(outfile), _compression(gzipped, zstd_file), int(trim_ccs),
                                     start.ctypes.data, stop.ctypes.data, len(start), C.byref(n), C.byref(tot))
     if rc != 0:
         raise EngineError(rc, L.itsx_trim_last_error().decode())
     return n.value, tot.value
 
 
-def write_trimmed_paired(fastq, fastq2, outfile1, outfile2, names, start, stop, tlen, gzipped=False, trim_ccs=False):
+def write_trimmed_paired(fastq, fastq2, outfile1, outfile2, names, start, stop, tlen, gzipped=False, trim_ccs=False,
+                         zstd_file=False):
     """names[i] = id of merged read i; start/stop/tlen per merged read.  Returns pairs written."""
     for p in (fastq, fastq2):
         if not os.path.exists(p):
@@ -48,7 +70,7 @@ def write_trimmed_paired(fastq, fastq2, outfile1, outfile2, names, start, stop, 
     blob = "".join(names).encode()
     n = C.c_int64(0)
     rc = L.itsx_write_trimmed_paired(os.fsencode(fastq), os.fsencode(fastq2), os.fsencode(outfile1), os.fsencode(outfile2),
-                                     int(gzipped), int(trim_ccs), C.cast(C.c_char_p(blob), C.c_void_p), no.ctypes.data,
+                                     _compression(gzipped, zstd_file), int(trim_ccs), C.cast(C.c_char_p(blob), C.c_void_p), no.ctypes.data,
                                      len(names), start.ctypes.data, stop.ctypes.data, tlen.ctypes.data, C.byref(n))
     if rc != 0:
         raise EngineError(rc, L.itsx_trim_last_error().decode())

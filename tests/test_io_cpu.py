@@ -1,0 +1,182 @@
+"""Host-side file plumbing: the reader behind every *_file entry point and the block-parallel
+gzip / zstd writers.  CPU-only; the content written must be byte-identical to a single-stream writer's."""
+import gzip
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+from itsxpress_amd import _lib
+from itsxpress_amd._lib import EngineError
+from itsxpress_amd.engine import read_fastx
+from itsxpress_amd.trim import read_text, write_trimmed_fastq, write_trimmed_paired
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fastq(n, seed, lo=40, hi=400):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        s = "".join(rng.choice(list("ACGTN"), L, p=[.245, .245, .245, .245, .02]))
+        q = "".join(chr(33 + int(x)) for x in rng.integers(2, 41, L))
+        recs.append("@r%d extra words\n%s\n+\n%s\n" % (i, s, q))
+    return "".join(recs)
+
+
+def _expected(text, start, stop):
+    lines = text.split("\n")
+    out = []
+    for i in range(len(start)):
+        t, s, q = lines[4 * i], lines[4 * i + 1], lines[4 * i + 3]
+        a, b = int(start[i]), int(stop[i])
+        if a < 0 or b < 0 or not a < b:
+            continue
+        out.append("%s\n%s\n+\n%s\n" % (t, s[a:b], q[a:b]))
+    return "".join(out)
+
+
+@pytest.fixture(scope="module")
+def sample(tmp_path_factory):
+    d = tmp_path_factory.mktemp("io")
+    text = _fastq(3000, 5)
+    rng = np.random.default_rng(6)
+    start = rng.integers(-1, 60, 3000).astype(np.int32)
+    stop = rng.integers(20, 420, 3000).astype(np.int32)
+    plain = d / "in.fastq"
+    plain.write_text(text)
+    return d, text, start, stop, str(plain)
+
+
+def test_codecs_are_reported():
+    flags = _lib.lib().itsx_io_codecs()
+    assert flags & 2, "libzstd.so.1 is part of this image"
+
+
+def test_reader_takes_plain_gzip_multimember_and_zstd(sample):
+    d, text, start, stop, plain = sample
+    raw = text.encode()
+    one = d / "one.gz"
+    one.write_bytes(gzip.compress(raw, 1))
+    multi = d / "multi.gz"                     # concatenated members, as bgzip / pigz / cat a.gz b.gz produce
+    cut = [0, 1000, 1001, len(raw) // 2, len(raw)]
+    multi.write_bytes(b"".join(gzip.compress(raw[cut[i]:cut[i + 1]], 6) for i in range(4)) + gzip.compress(b""))
+    assert read_text(plain) == raw and read_text(str(one)) == raw and read_text(str(multi)) == raw
+    zst = d / "out.zst"
+    n, _ = write_trimmed_fastq(plain, str(zst), np.zeros(3000, np.int32), np.full(3000, 10000, np.int32), zstd_file=True)
+    assert n == 3000 and zst.read_bytes()[:4] == b"\x28\xb5\x2f\xfd"
+    assert read_text(str(zst)) == raw          # stop beyond the read clamps: the whole record
+    names, seqs = read_fastx(str(zst))
+    assert names[:2] == ["r0", "r1"] and len(seqs) == 3000 and seqs[7] == text.split("\n")[4 * 7 + 1]
+    empty = d / "empty.fq"
+    empty.write_bytes(b"")
+    assert read_text(str(empty)) == b"" and read_fastx(str(empty)) == ([], [])
+
+
+@pytest.mark.parametrize("env", [{"ITSX_IO_BLOCK_KB": "16", "ITSX_IO_THREADS": "5"},
+                                 {"ITSX_IO_BLOCK_KB": "16", "ITSX_IO_THREADS": "3", "ITSX_IO_LIBDEFLATE": "0"},
+                                 {"ITSX_IO_THREADS": "1"}])
+def test_block_parallel_output_is_one_stream_to_any_reader(sample, env):
+    """Many small blocks, several threads, both deflate implementations: Python's gzip / zlib must read back exactly
+    what the plain writer wrote (run in a child process: the knobs are read when the library first needs them)."""
+    d, text, start, stop, plain = sample
+    code = r"""
+import sys, gzip, zlib, numpy as np
+sys.path.insert(0, %r)
+from itsxpress_amd.trim import write_trimmed_fastq, read_text
+from itsxpress_amd import _lib
+d, plain = %r, %r
+start = np.load(d + '/start.npy'); stop = np.load(d + '/stop.npy')
+a = write_trimmed_fastq(plain, d + '/o.fq', start, stop)
+b = write_trimmed_fastq(plain, d + '/o.fq.gz', start, stop, gzipped=True)
+c = write_trimmed_fastq(plain, d + '/o.fq.zst', start, stop, zstd_file=True)
+assert a == b == c, (a, b, c)
+want = open(d + '/o.fq', 'rb').read()
+gz = open(d + '/o.fq.gz', 'rb').read()
+assert gzip.decompress(gz) == want
+members = 0; rest = gz
+while rest:
+    o = zlib.decompressobj(31); o.decompress(rest); rest = o.unused_data; members += 1
+assert read_text(d + '/o.fq.gz') == want and read_text(d + '/o.fq.zst') == want
+print(members, _lib.lib().itsx_io_codecs(), a[0])
+""" % (ROOT, str(d), plain)
+    np.save(str(d / "start.npy"), start)
+    np.save(str(d / "stop.npy"), stop)
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    members, flags, nrec = map(int, r.stdout.split())
+    assert open(str(d / "o.fq")).read() == _expected(text, start, stop) and nrec > 2000
+    if "ITSX_IO_BLOCK_KB" in env:
+        assert members > 20                    # ~1 MB of output in 16 KB blocks
+    else:
+        assert members == 1
+    if env.get("ITSX_IO_LIBDEFLATE") == "0":
+        assert flags & 1 == 0
+
+
+def test_empty_outputs_are_valid_files(sample, tmp_path):
+    d, text, start, stop, plain = sample
+    none = np.full(3000, -1, np.int32)
+    g, z, p = str(tmp_path / "e.gz"), str(tmp_path / "e.zst"), str(tmp_path / "e.fq")
+    assert write_trimmed_fastq(plain, g, none, none, gzipped=True) == (0, 0)
+    assert write_trimmed_fastq(plain, z, none, none, zstd_file=True) == (0, 0)
+    assert write_trimmed_fastq(plain, p, none, none) == (0, 0)
+    assert gzip.open(g).read() == b"" and read_text(z) == b"" and os.path.getsize(p) == 0 and os.path.getsize(z) > 0
+
+
+def test_rewritten_input_is_not_served_from_the_text_cache(tmp_path):
+    """The writers share the loader's decompressed text through a cache keyed on (path, size, mtime)."""
+    f = str(tmp_path / "x.fastq.gz")
+    a, b = _fastq(50, 1), _fastq(50, 2)
+    st, sp = np.zeros(50, np.int32), np.full(50, 1000, np.int32)
+    for text in (a, b, a):
+        with gzip.open(f, "wt") as g:
+            g.write(text)
+        out = str(tmp_path / "o.fq")
+        assert write_trimmed_fastq(f, out, st, sp)[0] == 50
+        assert open(out).read() == text.replace(" extra words\n", " extra words\n")
+
+
+def test_corrupt_and_missing_inputs_fail_loudly(sample, tmp_path):
+    d, text, start, stop, plain = sample
+    raw = gzip.compress(text.encode())
+    bad = tmp_path / "trunc.gz"
+    bad.write_bytes(raw[: len(raw) // 2])
+    with pytest.raises(EngineError):
+        read_text(str(bad))
+    with pytest.raises(EngineError):
+        write_trimmed_fastq(str(bad), str(tmp_path / "o.fq"), start, stop)
+    flipped = bytearray(raw)
+    flipped[len(raw) // 2] ^= 0xFF
+    (tmp_path / "flip.gz").write_bytes(bytes(flipped))
+    with pytest.raises(EngineError):
+        read_text(str(tmp_path / "flip.gz"))
+    with pytest.raises(FileNotFoundError):
+        read_text(str(tmp_path / "nope.fq"))
+    with pytest.raises(EngineError):           # unwritable destination
+        write_trimmed_fastq(plain, str(tmp_path / "no_such_dir" / "o.fq.gz"), start, stop, gzipped=True)
+
+
+def test_paired_writer_compressed_outputs_match_plain(tmp_path):
+    rng = np.random.default_rng(3)
+    t1, t2 = _fastq(400, 11, 100, 250), _fastq(400, 12, 100, 250)
+    f1, f2 = tmp_path / "a.fastq.gz", tmp_path / "b.fastq.gz"
+    f1.write_bytes(gzip.compress(t1.encode()))
+    f2.write_bytes(gzip.compress(t2.encode()))
+    names = ["r%d" % i for i in range(400)]
+    start = rng.integers(0, 40, 400).astype(np.int32)
+    stop = rng.integers(60, 300, 400).astype(np.int32)
+    tlen = rng.integers(200, 320, 400).astype(np.int32)
+    outs = {}
+    for kind, kw in (("plain", {}), ("gz", {"gzipped": True}), ("zst", {"zstd_file": True})):
+        o1, o2 = str(tmp_path / ("o1." + kind)), str(tmp_path / ("o2." + kind))
+        assert write_trimmed_paired(str(f1), str(f2), o1, o2, names, start, stop, tlen, **kw) == 400
+        outs[kind] = (read_text(o1), read_text(o2))
+    assert outs["plain"] == outs["gz"] == outs["zst"] and len(outs["plain"][0]) > 10000
+    assert open(str(tmp_path / "o1.gz"), "rb").read(2) == b"\x1f\x8b"

@@ -86,8 +86,10 @@ def test_mirror_dedup_writers_take_the_reference_dict_route(gold, golden_coords,
     o3 = str(tmp_path / "single.fq")
     dd.create_trimmed_seqs(o3, False, False, ip, True, str(tmp_path))
     assert open(o3).read().count("\n+\n") == 226
-    with pytest.raises(ValueError):
-        dd.create_trimmed_seqs(o3, False, True, ip, True, str(tmp_path))
+    o4 = str(tmp_path / "single.fq.zst")              # zstd_file=True, as the reference's .zst outputs
+    dd.create_trimmed_seqs(o4, False, True, ip, True, str(tmp_path))
+    from itsxpress_amd.trim import read_text
+    assert open(o4, "rb").read(4) == b"\x28\xb5\x2f\xfd" and read_text(o4).decode() == open(o3).read()
 
 
 def test_slice_rules_match_python_semantics(tmp_path):

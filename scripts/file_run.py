@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""File to file on one GPU: a gzip FASTQ of N synthetic 300-bp reads in, a compressed FASTQ of the trimmed reads out
+-- what a user of `itsxpress --fastq x.fq.gz --single_end --region ITS2 --outfile y.fq.gz` waits for, stage by stage
+(load = inflate + parse + upload + device packing; write = slice + block-parallel deflate; the input's text is shared
+between the two through the reader's cache, ITSX_TEXT_CACHE_GB=0 turns that off).
+Prints one JSON line.  usage: file_run.py [--reads 1000000] [--out-kind gz|zst|plain]"""
+import argparse
+import gzip
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=1000000)
+    ap.add_argument("--out-kind", default="gz", choices=["gz", "zst", "plain"])
+    args = ap.parse_args()
+    import synth
+    from bench import its2_profiles
+    from itsxpress_amd import Engine, _lib
+    from itsxpress_amd.trim import write_trimmed_fastq, read_text
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
+        thmm = f.read()
+    blob, offs = synth.make_reads(thmm, args.reads, config=2, seed=synth.SEED + 2)
+    n = args.reads
+    rng = np.random.default_rng(9)
+    tmp = tempfile.mkdtemp(prefix="itsx_file_run_")
+    try:
+        plain = os.path.join(tmp, "in.fastq")
+        bases = np.frombuffer(blob, np.uint8)
+        with open(plain, "wb") as f:                  # Illumina-like qualities: high, decaying along the read
+            for i in range(n):
+                s = bases[offs[i]:offs[i + 1]]
+                q = (np.clip(38 - (np.arange(len(s)) // 25) - rng.integers(0, 6, len(s)), 2, 40) + 33).astype(np.uint8)
+                f.write(b"@read%d 1:N:0:1\n" % i + s.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+        fq = os.path.join(tmp, "in.fastq.gz")
+        write_trimmed_fastq(plain, fq, np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32), gzipped=True)
+        in_bytes, in_gz = os.path.getsize(plain), os.path.getsize(fq)
+        os.remove(plain)
+
+        eng = Engine(0)
+        eng.load_profiles(text=its2_profiles(thmm))
+        # first-touch costs (context, code objects, allocator) outside the stages: one small pass of the whole path
+        eng.set_reads([bases[offs[i]:offs[i + 1]].tobytes().decode() for i in range(2000)], ["w%d" % i for i in range(2000)])
+        eng.derep()
+        eng.search()
+        eng.finalize()
+        t = {}
+        t0 = time.perf_counter()
+        eng.load_reads_file(fq)
+        t["load"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        nu = eng.derep()
+        eng.search()
+        eng.finalize()
+        start, stop, tlen, ind = eng.trim_coords("3_", "4_")
+        t["path"] = time.perf_counter() - t0
+        out = os.path.join(tmp, "trimmed.fastq" + {"gz": ".gz", "zst": ".zst", "plain": ""}[args.out_kind])
+        t0 = time.perf_counter()
+        nw, tot = write_trimmed_fastq(fq, out, start, stop, gzipped=args.out_kind == "gz", zstd_file=args.out_kind == "zst")
+        t["write"] = time.perf_counter() - t0
+        total = sum(t.values())
+        # the output holds exactly the kept reads, sliced: check a sample against the coordinates
+        lines = read_text(out).split(b"\n")
+        kept = np.flatnonzero((start >= 0) & (stop >= 0) & (start < stop))
+        assert nw == len(kept) and len(lines) == 4 * nw + 1
+        for k in (0, nw // 2, nw - 1):
+            i = int(kept[k])
+            assert lines[4 * k] == b"@read%d 1:N:0:1" % i
+            assert lines[4 * k + 1] == bases[offs[i]:offs[i + 1]].tobytes()[start[i]:stop[i]]
+        print(json.dumps({
+            "reads": n, "unique": int(nu), "written": int(nw), "out_kind": args.out_kind,
+            "input_MB": round(in_bytes / 1e6, 1), "input_gz_MB": round(in_gz / 1e6, 1), "output_MB": round(os.path.getsize(out) / 1e6, 1),
+            "s_load": round(t["load"], 3), "s_path": round(t["path"], 3), "s_write": round(t["write"], 3), "s_total": round(total, 3),
+            "reads_per_s_file_to_file": round(n / total), "io_threads": int(os.environ.get("ITSX_IO_THREADS", 0)) or min(os.cpu_count(), 32),
+            "codecs": _lib.lib().itsx_io_codecs()}))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

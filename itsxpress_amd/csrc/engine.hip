@@ -10,6 +10,7 @@
 // builds per-length constant tables with libm (as hmmsearch does on its host), and sorts rows
 // for the file-compatible writers.  There is no CPU fallback for any stage.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -98,7 +99,10 @@ template <class T> struct DBuf {
     p = nullptr; cap = 0;
     if (!count) return hipSuccess;
     const size_t want = count + count / 8 + 64;
+    static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+    if (trace) fprintf(stderr, "[itsx] hipMalloc %.3f GB: %.1f ms\n", want * sizeof(T) / 1073741824.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) { e = hipMalloc((void **)&p, count * sizeof(T)); if (e != hipSuccess) return e; cap = count; return e; }
     cap = want;
     return hipSuccess;
@@ -1408,10 +1412,9 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
 {
   CTXCHK(ctx && r1_path && r2_path && out_path);
   struct Side { std::string seq, qual; std::vector<int64_t> off{0}; std::vector<std::string> ids; };
-  auto parse = [&](const char *path, Side &sd) -> int {
-    std::string rerr;
-    const auto tp = slurp(path, true, rerr);
-    if (!tp) { ctx->set_error(rerr); return ITSX_E_IO; }
+  auto parse = [](const char *path, Side &sd, std::string &perr) -> int {      // no shared state: the two files are read side by side
+    const auto tp = slurp(path, true, perr);
+    if (!tp) return ITSX_E_IO;
     const std::string &text = *tp;
     const char *s = text.data(), *end = s + text.size();
     auto line = [&](const char *&b, const char *&e) -> bool {
@@ -1426,7 +1429,7 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
       if (b == e) continue;
       const char *sb, *se, *pb, *pe, *qb, *qe;
       if (*b != '@' || !line(sb, se) || !line(pb, pe) || !line(qb, qe) || pb == pe || *pb != '+' || (qe - qb) != (se - sb)) {
-        ctx->set_error(std::string("malformed FASTQ record ") + std::to_string(sd.ids.size() + 1) + " in " + path); return ITSX_E_FORMAT;
+        perr = std::string("malformed FASTQ record ") + std::to_string(sd.ids.size() + 1) + " in " + path; return ITSX_E_FORMAT;
       }
       const char *ne = b + 1; while (ne < e && *ne != ' ' && *ne != '\t') ne++;
       sd.ids.emplace_back(b + 1, ne);
@@ -1438,8 +1441,13 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
     return ITSX_OK;
   };
   Side f, r;
-  int rc = parse(r1_path, f); if (rc != ITSX_OK) return rc;
-  rc = parse(r2_path, r); if (rc != ITSX_OK) return rc;
+  std::string ferr, rerr2;
+  int rc2 = ITSX_OK;
+  std::thread other([&] { rc2 = parse(r2_path, r, rerr2); });
+  int rc = parse(r1_path, f, ferr);
+  other.join();
+  if (rc != ITSX_OK) { ctx->set_error(ferr); return rc; }
+  if (rc2 != ITSX_OK) { ctx->set_error(rerr2); return rc2; }
   if (f.ids.size() != r.ids.size()) SET_ERR(ctx, ITSX_E_FORMAT, "R1 and R2 hold different numbers of records");
   const int64_t n = (int64_t)f.ids.size();
   std::string oseq((size_t)(f.seq.size() + r.seq.size()) + 1, '\0'), oqual = oseq;

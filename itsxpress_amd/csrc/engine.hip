@@ -460,8 +460,11 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
 {
   CTXCHK(ctx && path);
   std::string rerr;
+  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  const auto tt0 = std::chrono::steady_clock::now();
   const auto tp = slurp(path, true, rerr);
   if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
+  const auto tt1 = std::chrono::steady_clock::now();
   const std::string &text = *tp;
   ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
   const char *s = text.data(), *end = s + text.size();
@@ -497,7 +500,13 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
   }
   ctx->N = (int64_t)ctx->h_names.size();
   if (n_reads) *n_reads = ctx->N;
-  return pack_and_upload(ctx);
+  const auto tt2 = std::chrono::steady_clock::now();
+  const int rc = pack_and_upload(ctx);
+  if (trace) {
+    const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[itsx] load %s: read+inflate %.0f ms, parse %.0f ms, upload+pack %.0f ms\n", path, ms(tt0, tt1), ms(tt1, tt2), ms(tt2, std::chrono::steady_clock::now()));
+  }
+  return rc;
 }
 
 // ------------------------------------------------------------------------------ derep

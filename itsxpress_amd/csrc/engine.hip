@@ -1464,18 +1464,23 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   rc = itsx_merge_buffers(ctx, f.seq.data(), f.qual.data(), f.off.data(), r.seq.data(), r.qual.data(), r.off.data(), n, maxdiffs, maxee, allow_stagger,
                           &oseq[0], &oqual[0], olen.data(), reason.data(), nullptr, nullptr);
   if (rc != ITSX_OK) return rc;
-  FILE *fo = fopen(out_path, "w");
-  if (!fo) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + out_path);
+  // seq.fq is read back by the loader and by the paired trimmer: written through the block writer, which also leaves
+  // its text in the reader's cache
+  itsx_io::BlockWriter bw;
+  std::string werr, buf;
+  if (!bw.open(out_path, itsx_io::PLAIN, werr, true)) SET_ERR(ctx, ITSX_E_IO, werr);
   int64_t merged = 0;
   for (int64_t i = 0; i < n; i++) {
     if (reason[i] != 0) continue;
     const size_t o = (size_t)(f.off[i] + r.off[i]);
-    fputc('@', fo); fwrite(f.ids[i].data(), 1, f.ids[i].size(), fo); fputc('\n', fo);
-    fwrite(oseq.data() + o, 1, (size_t)olen[i], fo); fputs("\n+\n", fo);
-    fwrite(oqual.data() + o, 1, (size_t)olen[i], fo); fputc('\n', fo);
+    buf += '@'; buf += f.ids[i]; buf += '\n';
+    buf.append(oseq.data() + o, (size_t)olen[i]); buf += "\n+\n";
+    buf.append(oqual.data() + o, (size_t)olen[i]); buf += '\n';
+    if (buf.size() >= (1u << 20)) { bw.put(buf); buf.clear(); }
     merged++;
   }
-  fclose(fo);
+  bw.put(buf);
+  if (!bw.close(werr)) SET_ERR(ctx, ITSX_E_IO, werr);
   if (n_pairs) *n_pairs = n;
   if (n_merged) *n_merged = merged;
   return ITSX_OK;

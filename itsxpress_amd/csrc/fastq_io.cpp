@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 #include <zlib.h>
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -73,12 +74,24 @@ int env_int(const char *name, int dflt) { const char *e = getenv(name); return e
 bool is_gzip(const std::string &r, size_t pos = 0) { return r.size() >= pos + 2 && (unsigned char)r[pos] == 0x1f && (unsigned char)r[pos + 1] == 0x8b; }
 bool is_zstd(const std::string &r) { return r.size() >= 4 && (unsigned char)r[0] == 0x28 && (unsigned char)r[1] == 0xb5 && (unsigned char)r[2] == 0x2f && (unsigned char)r[3] == 0xfd; }
 
+// The trailer's ISIZE (length mod 2^32 of the LAST member) is the whole length for the usual single-member file below
+// 4 GB; anything implausible falls back to 4x the compressed size.  Only a first guess: both inflaters grow on demand.
+size_t gzip_size_hint(const std::string &raw)
+{
+  const size_t guess = std::max<size_t>(raw.size() * 4, 1 << 20);
+  if (raw.size() < 18) return guess;
+  const unsigned char *t = (const unsigned char *)raw.data() + raw.size() - 4;
+  const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+  if (isize >= raw.size() / 2 && isize <= raw.size() * 40) return isize + 64;
+  return guess;
+}
+
 bool gunzip_libdeflate(const std::string &raw, std::string &out, std::string &err)
 {
   void *d = g_ld.alloc_d();
   if (!d) { err = "libdeflate: out of memory"; return false; }
   size_t pos = 0, opos = 0;
-  out.resize(std::max<size_t>(raw.size() * 4, 1 << 20));
+  out.resize(gzip_size_hint(raw));
   bool ok = true;
   while (pos < raw.size() && is_gzip(raw, pos)) {
     size_t ain = 0, aout = 0;
@@ -95,7 +108,7 @@ bool gunzip_zlib(const std::string &raw, std::string &out, std::string &err)
 {
   z_stream zs; memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "zlib: inflateInit2 failed"; return false; }
-  out.resize(std::max<size_t>(raw.size() * 4, 1 << 20));
+  out.resize(gzip_size_hint(raw));
   size_t pos = 0, opos = 0;
   bool ok = true;
   while (ok && pos < raw.size() && is_gzip(raw, pos)) {
@@ -166,6 +179,25 @@ bool stat_of(const char *path, int64_t &size, int64_t &mtime_ns)
 
 void cache_clear() { std::lock_guard<std::mutex> g(g_cache_mu); g_cache.clear(); }
 
+static void cache_insert(const char *path, int64_t fsize, int64_t mtime, std::shared_ptr<const std::string> text, double budget)
+{
+  std::lock_guard<std::mutex> g(g_cache_mu);
+  for (auto it = g_cache.begin(); it != g_cache.end(); ++it) if (it->path == path) { g_cache.erase(it); break; }
+  g_cache.push_back(CacheEntry{path, fsize, mtime, text});
+  double total = 0;
+  for (auto &e : g_cache) total += (double)e.text->size();
+  while (total > budget && g_cache.size() > 1) { total -= (double)g_cache.front().text->size(); g_cache.pop_front(); }
+}
+
+void cache_put(const char *path, std::shared_ptr<const std::string> text)
+{
+  const double budget = cache_budget_bytes();
+  int64_t fsize = 0, mtime = 0;
+  if (!text || budget <= 0 || (double)text->size() > budget || !stat_of(path, fsize, mtime)) return;
+  if (fsize != (int64_t)text->size()) return;          // only a plain file whose bytes are exactly `text`
+  cache_insert(path, fsize, mtime, text, budget);
+}
+
 int codec_flags() { codecs(); return (g_ld.ok ? 1 : 0) | (g_zs.ok ? 2 : 0); }
 
 int io_threads()
@@ -190,6 +222,8 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
         break;
       }
   }
+  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  const auto c0 = std::chrono::steady_clock::now();
   FILE *f = fopen(path, "rb");
   if (!f) { err = std::string("cannot read ") + path; return nullptr; }
   std::string raw;
@@ -203,6 +237,7 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
   const bool rerr = ferror(f) != 0;
   fclose(f);
   if (rerr) { err = std::string("read error on ") + path; return nullptr; }
+  const auto c1 = std::chrono::steady_clock::now();
   auto text = std::make_shared<std::string>();
   if (is_gzip(raw)) {
     const bool ok = g_ld.ok ? gunzip_libdeflate(raw, *text, err) : gunzip_zlib(raw, *text, err);
@@ -210,14 +245,10 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
   } else if (is_zstd(raw)) {
     if (!unzstd(raw, *text, err)) { err += std::string(" in ") + path; return nullptr; }
   } else text->swap(raw);
-  text->shrink_to_fit();
-  if (cacheable && budget > 0 && (double)text->size() <= budget) {
-    std::lock_guard<std::mutex> g(g_cache_mu);
-    g_cache.push_back(CacheEntry{path, fsize, mtime, text});
-    double total = 0;
-    for (auto &e : g_cache) total += (double)e.text->size();
-    while (total > budget && g_cache.size() > 1) { total -= (double)g_cache.front().text->size(); g_cache.pop_front(); }
-  }
+  if (text->capacity() > text->size() + text->size() / 4 + (1 << 20)) text->shrink_to_fit();      // a copy: only when it frees a lot
+  if (trace) fprintf(stderr, "[itsx] read %s: file %.0f ms, decode %.0f ms (%.1f MB -> %.1f MB)\n", path, std::chrono::duration<double, std::milli>(c1 - c0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1).count(), raw.size() / 1e6, text->size() / 1e6);
+  if (cacheable && budget > 0 && (double)text->size() <= budget) cache_insert(path, fsize, mtime, text, budget);
   return text;
 }
 
@@ -228,7 +259,8 @@ struct WriterImpl {
   FILE *fp = nullptr;
   int kind = PLAIN, level = 6;
   size_t block = 4u << 20;
-  std::string cur;
+  std::string cur, path;
+  std::shared_ptr<std::string> kept;       // PLAIN + keep_text: everything written
   bool failed = false;
   // pool
   std::vector<std::thread> workers;
@@ -315,7 +347,7 @@ struct WriterImpl {
 BlockWriter::BlockWriter() : w(new WriterImpl) {}
 BlockWriter::~BlockWriter() { std::string e; if (w->fp) close(e); delete w; }
 
-bool BlockWriter::open(const char *path, int kind, std::string &err)
+bool BlockWriter::open(const char *path, int kind, std::string &err, bool keep_text)
 {
   codecs();
   if (kind != PLAIN && kind != GZIP && kind != ZSTD) { err = "unknown compression kind"; return false; }
@@ -324,6 +356,8 @@ bool BlockWriter::open(const char *path, int kind, std::string &err)
   if (!w->fp) { err = std::string("cannot write ") + path; return false; }
   setvbuf(w->fp, nullptr, _IOFBF, 1 << 20);
   w->kind = kind;
+  w->path = path;
+  if (keep_text && kind == PLAIN && cache_budget_bytes() > 0) w->kept = std::make_shared<std::string>();
   w->level = std::min(9, std::max(1, env_int("ITSX_GZIP_LEVEL", 6)));
   w->block = (size_t)std::max(1, env_int("ITSX_IO_BLOCK_KB", 4096)) << 10;
   if (kind != PLAIN) {
@@ -336,7 +370,11 @@ bool BlockWriter::open(const char *path, int kind, std::string &err)
 void BlockWriter::put(const char *p, size_t n)
 {
   if (!w->fp || n == 0) return;
-  if (w->kind == PLAIN) { if (fwrite(p, 1, n, w->fp) != n) w->failed = true; return; }
+  if (w->kind == PLAIN) {
+    if (fwrite(p, 1, n, w->fp) != n) w->failed = true;
+    if (w->kept) { if ((double)(w->kept->size() + n) <= cache_budget_bytes()) w->kept->append(p, n); else w->kept.reset(); }
+    return;
+  }
   while (n > 0) {
     const size_t take = std::min(n, w->block - w->cur.size());
     w->cur.append(p, take); p += take; n -= take;
@@ -359,6 +397,7 @@ bool BlockWriter::close(std::string &err)
   if (fclose(w->fp) != 0) w->failed = true;
   w->fp = nullptr;
   if (w->failed) { err = "compressing or writing the output failed"; return false; }
+  if (w->kept) { cache_put(w->path.c_str(), w->kept); w->kept.reset(); }
   return true;
 }
 

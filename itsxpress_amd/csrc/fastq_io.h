@@ -26,6 +26,8 @@ enum Kind { PLAIN = 0, GZIP = 1, ZSTD = 2 };
 // Returns the decompressed content or nullptr (err set).  cacheable: keep / look up the text in the process-wide cache.
 std::shared_ptr<const std::string> read_text(const char *path, std::string &err, bool cacheable);
 void cache_clear();
+// Adopt `text` as the content of the file just written at `path` (temporary files the next stage reads back).
+void cache_put(const char *path, std::shared_ptr<const std::string> text);
 
 int io_threads();               // ITSX_IO_THREADS or min(hardware threads, 32)
 
@@ -34,7 +36,8 @@ class BlockWriter {
  public:
   BlockWriter();
   ~BlockWriter();
-  bool open(const char *path, int kind, std::string &err);
+  // keep_text (PLAIN only): the bytes written are also kept and handed to the text cache when the file is closed
+  bool open(const char *path, int kind, std::string &err, bool keep_text = false);
   void put(const char *p, size_t n);
   void put(const std::string &s) { put(s.data(), s.size()); }
   bool close(std::string &err);   // flushes; false when any block failed to compress or write

@@ -68,10 +68,10 @@ struct Records {
 struct Writer {
   itsx_io::BlockWriter w;
   std::string buf;
-  bool open(const char *path, int kind)
+  bool open(const char *path, int kind, bool keep_text = false)
   {
     std::string err;
-    if (!w.open(path, kind, err)) { g_trim_error = err; return false; }
+    if (!w.open(path, kind, err, keep_text)) { g_trim_error = err; return false; }
     buf.reserve(1 << 20);
     return true;
   }
@@ -189,7 +189,7 @@ int itsx_write_oriented_fastq(const char *seq_path, const char *out_path, const 
   if (!seq_path || !out_path || !strand) { g_trim_error = "null argument"; return ITSX_E_ARG; }
   Records in; Writer out;
   if (!in.open(seq_path)) return ITSX_E_IO;
-  if (!out.open(out_path, itsx_io::PLAIN)) return ITSX_E_IO;
+  if (!out.open(out_path, itsx_io::PLAIN, true)) return ITSX_E_IO;      // oriented.fq is read back by the loader and the trimmer
   static char comp[256];
   static bool init = false;
   if (!init) {

@@ -180,3 +180,26 @@ def test_paired_writer_compressed_outputs_match_plain(tmp_path):
         outs[kind] = (read_text(o1), read_text(o2))
     assert outs["plain"] == outs["gz"] == outs["zst"] and len(outs["plain"][0]) > 10000
     assert open(str(tmp_path / "o1.gz"), "rb").read(2) == b"\x1f\x8b"
+
+
+def test_temp_files_the_next_stage_reads_back_come_from_the_cache_and_stay_honest(tmp_path):
+    """oriented.fq / seq.fq are written with their text left in the reader's cache; the key is (path, size, mtime), so a
+    file changed behind the library's back is read again."""
+    from itsxpress_amd.trim import write_oriented_fastq
+    text = _fastq(200, 21, 60, 61)
+    src = tmp_path / "in.fq"
+    src.write_text(text)
+    strand = np.ones(200, np.int8)
+    strand[::3] = -1
+    strand[5] = 0
+    ori = str(tmp_path / "oriented.fq")
+    assert write_oriented_fastq(str(src), ori, strand) == 199
+    on_disk = open(ori).read()
+    out = str(tmp_path / "o.fq")
+    st, sp = np.zeros(199, np.int32), np.full(199, 1000, np.int32)
+    assert write_trimmed_fastq(ori, out, st, sp)[0] == 199 and open(out).read() == on_disk
+    swapped = on_disk.replace("A", "x").replace("C", "A").replace("x", "C")       # same length, other content
+    assert swapped != on_disk
+    with open(ori, "w") as f:
+        f.write(swapped)
+    assert write_trimmed_fastq(ori, out, st, sp)[0] == 199 and open(out).read() == swapped

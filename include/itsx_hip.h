@@ -115,6 +115,24 @@ int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int
 /* FASTA or FASTQ file, plain or gzip (.gz): native parser for the same input. */
 int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
 
+/* ---- f4, per-sample batching: the QIIME 2 plugin runs the whole path once per sample
+ * (itsxpress/q2_itsxpress.py:273-333: one SeqSample, one vsearch and one hmmsearch process per manifest row), which
+ * starves a GPU when samples are small.  Here many samples share ONE read set and one pass of every kernel while each
+ * keeps the results of its own run: reads are dereplicated only within their sample (the first occurrence INSIDE the
+ * sample is the representative, so orientation and labels are the sample's own), and hmmsearch's domZ -- the number
+ * of reported targets the domain E-value threshold is scaled by -- is counted per (sample, profile).
+ * itsx_load_reads_files: the samples' sequence files (FASTA/FASTQ, plain/gzip/zstd) in order; sample index = file index.
+ * itsx_set_samples: the same for reads handed over with itsx_set_reads (sample_of_read[n_reads], values in
+ * [0, n_samples)); NULL or n_samples <= 1 returns to one sample.  A new read set resets the batch to one sample.
+ * With S samples itsx_get_domz / itsx_set_domz move S * n_profiles counters ([sample][profile]).
+ * itsx_select_sample: the file writers (itsx_write_uc / _rep_fasta / _domtbl) emit that sample only (cluster numbers
+ * and the E-value columns as in a run of that sample alone); -1 = every sample.
+ * Not batched: itsx_cluster at id < 1 (sequential per sample) and itsx_unique_keys (shard whole samples instead). */
+int itsx_load_reads_files(itsx_ctx *ctx, const char *const *paths, int32_t n_paths, int64_t *n_reads_per_file);
+int itsx_set_samples(itsx_ctx *ctx, const int32_t *sample_of_read, int32_t n_samples);
+int itsx_num_samples(const itsx_ctx *ctx);
+int itsx_select_sample(itsx_ctx *ctx, int32_t sample);
+
 /* ---- f4: SeqSample.orient_reads (itsxpress/SeqSample.py:48-91) = vsearch --orient IN --db REF --fastqout OUT
  * (12-mer presence counts on both strands, 4x rule; restated in oracle/orc_cluster.c, parity unpinned).
  * itsx_orient_load_db: FASTA (plain/gzip) of reference sequences -> 12-mer bitmap on the device.
@@ -173,8 +191,8 @@ int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance
  * reported representatives (hmmsearch's domZ).  itsx_search_finalize applies the
  * domain threshold.  Between the two a multi-GPU driver all-reduces domZ. */
 int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3);
-int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ /* [n_profiles] */);
-int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ /* [n_profiles] */);
+int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ /* [n_samples][n_profiles] */);
+int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ /* [n_samples][n_profiles] */);
 int itsx_search_finalize(itsx_ctx *ctx, double domE);
 int64_t itsx_num_domains(const itsx_ctx *ctx);
 int itsx_get_domains(const itsx_ctx *ctx, itsx_domain *rows /* [itsx_num_domains] */);

@@ -28,7 +28,7 @@ void launch_region_counts(const PairOut *pout, int64_t npairs, int32_t *cnt, hip
 void launch_region_offsets(int64_t npairs, const PairRec *pairs, const int32_t *pref, const int64_t *seg_pair_start,
                            const int64_t *seg_region_start, int64_t *pair_region0, hipStream_t st);
 void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int64_t *pair_region0, RegionRec *out, hipStream_t st);
-void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, hipStream_t st);
+void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, const int32_t *usample, int P, hipStream_t st);
 void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, unsigned long long *bl, unsigned long long *br,
                       int32_t *in_ddict, hipStream_t st);
 
@@ -139,6 +139,14 @@ struct itsx_ctx {
   DBuf<int32_t> d_len;
   ReadsDev rd{};
   int Lmax = 0;
+  // per-sample batching: S samples share the context; reads group only within their sample and
+  // hmmsearch's domZ is kept per (sample, profile)
+  int32_t S = 1, sel_sample = -1;
+  std::vector<int32_t> h_sample, h_usample;          // per read / per unique; empty when S == 1
+  DBuf<int32_t> d_sample, d_usample;
+  const int32_t *dev_sample() const { return S > 1 ? d_sample.p : nullptr; }
+  const int32_t *dev_usample() const { return S > 1 ? d_usample.p : nullptr; }
+  int32_t usample(int64_t u) const { return S > 1 ? h_usample[(size_t)u] : 0; }
   double slab_gb = 0.0;                  // HBM budget for per-batch DP slabs
 
   // ---- derep
@@ -436,6 +444,7 @@ static int pack_and_upload(itsx_ctx *ctx)
   ctx->rd.excoff = ctx->d_excoff.p; ctx->rd.exc = ctx->d_exc.p; ctx->rd.n = n;
   ctx->have_derep = ctx->have_search = ctx->have_final = false;
   ctx->stats.n_reads = n;
+  ctx->S = 1; ctx->sel_sample = -1; ctx->h_sample.clear(); ctx->h_usample.clear();      // a new read set is one sample until told otherwise
   return ITSX_OK;
 }
 
@@ -456,17 +465,9 @@ int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int
   return pack_and_upload(ctx);
 }
 
-int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
+// FASTA / FASTQ text appended to the context's host-side read set (names up to the first blank, as vsearch labels them)
+static int parse_fastx_append(itsx_ctx *ctx, const std::string &text)
 {
-  CTXCHK(ctx && path);
-  std::string rerr;
-  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
-  const auto tt0 = std::chrono::steady_clock::now();
-  const auto tp = slurp(path, true, rerr);
-  if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
-  const auto tt1 = std::chrono::steady_clock::now();
-  const std::string &text = *tp;
-  ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
   const char *s = text.data(), *end = s + text.size();
   auto next_line = [&](const char *&b, const char *&e) -> bool {
     if (s >= end) return false;
@@ -498,6 +499,20 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
       ctx->h_off.push_back((int64_t)ctx->h_bases.size());
     } else SET_ERR(ctx, ITSX_E_FORMAT, "input is neither FASTA nor FASTQ");
   }
+  return ITSX_OK;
+}
+
+int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
+{
+  CTXCHK(ctx && path);
+  std::string rerr;
+  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  const auto tt0 = std::chrono::steady_clock::now();
+  const auto tp = slurp(path, true, rerr);
+  if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
+  const auto tt1 = std::chrono::steady_clock::now();
+  ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
+  { const int prc = parse_fastx_append(ctx, *tp); if (prc != ITSX_OK) return prc; }
   ctx->N = (int64_t)ctx->h_names.size();
   if (n_reads) *n_reads = ctx->N;
   const auto tt2 = std::chrono::steady_clock::now();
@@ -507,6 +522,53 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
     fprintf(stderr, "[itsx] load %s: read+inflate %.0f ms, parse %.0f ms, upload+pack %.0f ms\n", path, ms(tt0, tt1), ms(tt1, tt2), ms(tt2, std::chrono::steady_clock::now()));
   }
   return rc;
+}
+
+// ---- per-sample batching (q2_itsxpress.py:273-333 runs the whole path once per sample)
+int itsx_set_samples(itsx_ctx *ctx, const int32_t *sample_of_read, int32_t n_samples)
+{
+  CTXCHK(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->have_derep = ctx->have_search = ctx->have_final = false;
+  ctx->sel_sample = -1; ctx->h_usample.clear();
+  if (!sample_of_read || n_samples <= 1) { ctx->S = 1; ctx->h_sample.clear(); return ITSX_OK; }
+  if ((int64_t)n_samples * std::max(ctx->P, 1) > (1ll << 28)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "too many samples x profiles for one batch");
+  for (int64_t r = 0; r < ctx->N; r++)
+    if (sample_of_read[r] < 0 || sample_of_read[r] >= n_samples) SET_ERR(ctx, ITSX_E_ARG, "sample index of read " + std::to_string(r) + " is out of range");
+  ctx->h_sample.assign(sample_of_read, sample_of_read + ctx->N);
+  ctx->S = n_samples;
+  HIPCHK(upload(ctx->d_sample, ctx->h_sample, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
+int itsx_num_samples(const itsx_ctx *ctx) { return ctx ? ctx->S : ITSX_E_ARG; }
+int itsx_select_sample(itsx_ctx *ctx, int32_t sample)
+{
+  CTXCHK(ctx);
+  if (sample < -1 || sample >= ctx->S) SET_ERR(ctx, ITSX_E_ARG, "sample index out of range");
+  ctx->sel_sample = sample;
+  return ITSX_OK;
+}
+int itsx_load_reads_files(itsx_ctx *ctx, const char *const *paths, int32_t n_paths, int64_t *n_reads_per_file)
+{
+  CTXCHK(ctx && paths && n_paths >= 1);
+  ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
+  std::vector<int32_t> smp;
+  for (int32_t f = 0; f < n_paths; f++) {
+    CTXCHK(paths[f]);
+    std::string rerr;
+    const auto tp = slurp(paths[f], true, rerr);
+    if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
+    const size_t before = ctx->h_names.size();
+    { const int prc = parse_fastx_append(ctx, *tp); if (prc != ITSX_OK) { ctx->set_error(ctx->err + " (" + paths[f] + ")"); return prc; } }
+    if (n_reads_per_file) n_reads_per_file[f] = (int64_t)(ctx->h_names.size() - before);
+    smp.resize(ctx->h_names.size(), f);
+  }
+  ctx->N = (int64_t)ctx->h_names.size();
+  if (ctx->N >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
+  const int rc = pack_and_upload(ctx);
+  if (rc != ITSX_OK) return rc;
+  return itsx_set_samples(ctx, smp.data(), n_paths);
 }
 
 // ------------------------------------------------------------------------------ derep
@@ -556,6 +618,12 @@ static int mirror_derep(itsx_ctx *ctx)
     HIPCHK(hipMemcpy(ctx->h_abund.data(), ctx->d_abund.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ctx->h_sorted_uniq.data(), ctx->d_sorted_uniq.p, (size_t)U * 4, hipMemcpyDeviceToHost));
   }
+  if (ctx->S > 1) {
+    ctx->h_usample.resize((size_t)U);
+    for (int32_t u = 0; u < U; u++) ctx->h_usample[(size_t)u] = ctx->h_sample[(size_t)ctx->h_seed_read[(size_t)u]];
+    HIPCHK(upload(ctx->d_usample, ctx->h_usample, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+  }
   return ITSX_OK;
 }
 
@@ -582,9 +650,9 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
     HIPCHK(hipMemsetAsync(vals.p, 0x7f, tsize * sizeof(int32_t), ctx->st));
     HIPCHK(hipMemsetAsync(ncoll.p, 0, sizeof(unsigned int), ctx->st));
     if (n > 0) {
-      launch_hash_reads(ctx->rd, seed, strand_both, hf.p, hr.p, ctx->st);
+      launch_hash_reads(ctx->rd, seed, strand_both, hf.p, hr.p, ctx->st, ctx->dev_sample());
       launch_table_insert(n, ctx->rd.len, minseqlength, hf.p, hr.p, keys.p, vals.p, tsize - 1, slot_of.p, ctx->st);
-      launch_table_resolve(ctx->rd, hf.p, vals.p, slot_of.p, ctx->d_rep_of.p, ctx->d_strand.p, is_seed.p, ncoll.p, ctx->st);
+      launch_table_resolve(ctx->rd, hf.p, vals.p, slot_of.p, ctx->d_rep_of.p, ctx->d_strand.p, is_seed.p, ncoll.p, ctx->st, ctx->dev_sample());
     }
     HIPCHK(hipMemcpyAsync(&hcoll, ncoll.p, sizeof(hcoll), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
@@ -612,6 +680,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   CTXCHK(ctx);
   if (!(id > 0.0 && id <= 1.0)) SET_ERR(ctx, ITSX_E_ARG, "cluster id must be in (0, 1]");
   if (id == 1.0) return itsx_derep(ctx, strand_both, 32, n_unique);      // main.py:534-537 never clusters at 1.0
+  if (ctx->S > 1) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "greedy clustering (id < 1) is sequential per sample: run it one sample per call, not on a sample batch");
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = ctx->N;
   const int minlen = 32;
@@ -799,6 +868,7 @@ int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance
 int itsx_unique_keys(itsx_ctx *ctx, uint64_t seed, uint64_t *fwd, uint64_t *rc)
 {
   CTXCHK(ctx && ctx->have_derep && fwd && rc);
+  if (ctx->S > 1) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "cross-rank dereplication of a sample batch is not supported: shard whole samples across ranks");
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = ctx->N;
   if (n == 0 || ctx->U == 0) return ITSX_OK;
@@ -856,7 +926,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   const int P = ctx->P, G = ctx->G, Ppad = G * 64, U = ctx->U_active;
   ctx->T = T;
   ctx->h_dom.clear(); ctx->h_trace.clear(); ctx->trace_sorted = false;
-  ctx->domz.assign((size_t)P, 0);
+  ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
   S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
@@ -903,8 +973,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(upload(ctx->d_lt, lt, st)); HIPCHK(upload(d_thr, thr, st)); HIPCHK(upload(d_tjb, tjb, st));
 
   HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(ctx->d_domz32.alloc((size_t)P));
-  HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * 4, st));
+  HIPCHK(ctx->d_domz32.alloc((size_t)P * ctx->S));
+  HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * ctx->S * 4, st));
   {
     int64_t cells = 0;
     for (int32_t u = 0; u < U; u++) cells += (int64_t)ctx->h_len[ctx->h_seed_read[u]];
@@ -929,10 +999,10 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     if (rc != ITSX_OK) return rc;
   }
   ctx->n_chunks = ci;
-  std::vector<int32_t> dz32((size_t)P, 0);
-  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+  std::vector<int32_t> dz32((size_t)P * ctx->S, 0);
+  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  for (int p = 0; p < P; p++) ctx->domz[p] = dz32[p];
+  for (size_t p = 0; p < dz32.size(); p++) ctx->domz[p] = dz32[p];
   return ITSX_OK;
 }
 
@@ -1147,7 +1217,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     ScoreArgs sa{};
     sa.rd = ctx->rd; sa.sorted_uniq = d_sorted; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
     sa.flogsum = ctx->d_flogsum.p; sa.pairs = ctx->d_pairs.p; sa.pout = ctx->d_pout.p; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
-    sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p;
+    sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p; sa.usample = ctx->dev_usample(); sa.P = ctx->P;
     launch_score(sa, st);
   }
   S.ms_domains += tm_dom.stop();
@@ -1170,13 +1240,13 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
 int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ)
 {
   CTXCHK(ctx && domZ && ctx->have_search);
-  for (int p = 0; p < ctx->P; p++) domZ[p] = ctx->domz[p];
+  for (size_t p = 0; p < ctx->domz.size(); p++) domZ[p] = ctx->domz[p];
   return ITSX_OK;
 }
 int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ)
 {
   CTXCHK(ctx && domZ && ctx->have_search);
-  for (int p = 0; p < ctx->P; p++) ctx->domz[p] = domZ[p];
+  for (size_t p = 0; p < ctx->domz.size(); p++) ctx->domz[p] = domZ[p];
   return ITSX_OK;
 }
 
@@ -1190,7 +1260,7 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
     DBuf<int64_t> &d_dz = ctx->w_dz;
     HIPCHK(upload(d_dz, ctx->domz, ctx->st));
     for (size_t c = 0; c < ctx->dom_n.size(); c++)
-      if (ctx->dom_n[c] > 0) launch_finalize(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, domE, ctx->st);
+      if (ctx->dom_n[c] > 0) launch_finalize(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, domE, ctx->dev_usample(), ctx->P, ctx->st);
     HIPCHK(hipStreamSynchronize(ctx->st));
   }
   ctx->stats.ms_finalize = tm.stop();
@@ -1542,14 +1612,16 @@ static std::string read_name(const itsx_ctx *ctx, int64_t r)
 // clusters in vsearch's output order: abundance descending, ties by label
 static std::vector<int32_t> cluster_order(const itsx_ctx *ctx)
 {
+  const int32_t sel = ctx->S > 1 ? ctx->sel_sample : -1;      // writers restricted to one sample of a batch
   if (ctx->clustered) {                  // --cluster_size: clusters are numbered as their centroids were created
     std::vector<int32_t> ord;
     ord.reserve((size_t)ctx->U);
     for (int32_t r : ctx->h_order) if (ctx->h_rep_of[r] == r) ord.push_back(ctx->h_uniq_of[r]);
     return ord;
   }
-  std::vector<int32_t> ord((size_t)ctx->U);
-  std::iota(ord.begin(), ord.end(), 0);
+  std::vector<int32_t> ord;
+  ord.reserve((size_t)ctx->U);
+  for (int32_t u = 0; u < ctx->U; u++) if (sel < 0 || ctx->usample(u) == sel) ord.push_back(u);
   std::vector<std::string> lab((size_t)ctx->U);
   for (int32_t u = 0; u < ctx->U; u++) lab[u] = read_name(ctx, ctx->h_seed_read[u]);
   std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
@@ -1624,15 +1696,19 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path)
   // rows: profile order; within a profile, targets; within a target, reported domains renumbered
   size_t i = 0;
   const std::vector<itsx_domain> &D = ctx->h_dom;
+  std::vector<int64_t> Zs((size_t)ctx->S, 0);          // hmmsearch's Z: targets searched, per sample
+  for (int32_t u = 0; u < ctx->U; u++) Zs[(size_t)ctx->usample(u)]++;
   while (i < D.size()) {
     size_t j = i; int nrep = 0;
     while (j < D.size() && D[j].prof == D[i].prof && D[j].rep == D[i].rep) { nrep += D[j].dom_reported; j++; }
     int k = 0;
+    const int32_t smp = ctx->usample(D[i].rep);
+    if (ctx->S > 1 && ctx->sel_sample >= 0 && smp != ctx->sel_sample) { i = j; continue; }
     for (size_t d = i; d < j; d++) {
       if (!D[d].dom_reported) continue;
       k++;
       const HostProfile &h = ctx->profs[D[d].prof];
-      const double Z = (double)ctx->U, dz = (double)ctx->domz[D[d].prof];
+      const double Z = (double)Zs[(size_t)smp], dz = (double)ctx->domz[(size_t)smp * ctx->P + D[d].prof];
       const double seqE = Z * det_exp(exp_logsurv((double)D[d].seq_score, (double)h.evparam[4], (double)h.evparam[5]));
       const double P = det_exp(D[d].lnP);
       // hmm/ali coordinates and acc need the optimal-accuracy alignment, which the engine does not compute:

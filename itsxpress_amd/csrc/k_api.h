@@ -14,11 +14,13 @@ struct ReadsDev {
 };
 
 // ---- k_derep.hip
-void launch_hash_reads(const ReadsDev &rd, uint64_t seed, int strand_both, uint64_t *hf, uint64_t *hr, hipStream_t st);
+// sample (may be null): per-read sample index folded into the hash seed, so equal sequences of different samples get different keys
+void launch_hash_reads(const ReadsDev &rd, uint64_t seed, int strand_both, uint64_t *hf, uint64_t *hr, hipStream_t st, const int32_t *sample = nullptr);
 void launch_table_insert(int64_t n, const int32_t *len, int minlen, const uint64_t *hf, const uint64_t *hr,
                          unsigned long long *keys, int32_t *vals, uint64_t mask, uint32_t *slot_of, hipStream_t st);
 void launch_table_resolve(const ReadsDev &rd, const uint64_t *hf, const int32_t *vals, const uint32_t *slot_of,
-                          int32_t *rep_of, int8_t *strand, int32_t *is_seed, unsigned int *n_collisions, hipStream_t st);
+                          int32_t *rep_of, int8_t *strand, int32_t *is_seed, unsigned int *n_collisions, hipStream_t st,
+                          const int32_t *sample = nullptr);
 void launch_uniques(int64_t n, const int32_t *rep_of, const int32_t *seed_rank, int32_t *uniq_of, int32_t *seed_read,
                     int32_t *abundance, hipStream_t st);
 void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *hist, int32_t lcap, hipStream_t st);
@@ -191,7 +193,9 @@ struct ScoreArgs {
   itsx_domain *dom;             // one per region
   int64_t npairs;
   double T;
-  int32_t *domz;                // [P] reported targets per profile
+  int32_t *domz;                // [S][P] reported targets per (sample, profile); S = 1 without per-sample batching
+  const int32_t *usample;       // [U] sample of each unique (null: one sample)
+  int32_t P;
 };
 void launch_score(const ScoreArgs &a, hipStream_t st);
 void launch_region_count_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *pref,

@@ -116,10 +116,11 @@ __device__ __forceinline__ uint64_t xxh64_words(const F &get, int n, uint64_t se
   return h;
 }
 
-__global__ void __launch_bounds__(256) k_hash_reads(ReadsDev rd, uint64_t seed, int strand_both,
-                                                    uint64_t *__restrict__ hf, uint64_t *__restrict__ hr)
+__global__ void __launch_bounds__(256) k_hash_reads(ReadsDev rd, uint64_t seed0, int strand_both,
+                                                    uint64_t *__restrict__ hf, uint64_t *__restrict__ hr, const int32_t *__restrict__ sample)
 {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rd.n; r += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t seed = sample ? seed0 + (uint64_t)(uint32_t)sample[r] * XP3 : seed0;   // per-sample batching: samples never share a key
     const int L = rd.len[r];
     const int64_t wo = rd.woff[r];
     const int nw = (int)(rd.woff[r + 1] - wo);
@@ -182,7 +183,8 @@ __device__ bool rc_equals_forward(const ReadsDev &rd, int64_t a, int64_t b)   //
 __global__ void __launch_bounds__(256) k_table_resolve(ReadsDev rd, const uint64_t *__restrict__ hf,
                                                        const int32_t *__restrict__ vals, const uint32_t *__restrict__ slot_of,
                                                        int32_t *__restrict__ rep_of, int8_t *__restrict__ strand,
-                                                       int32_t *__restrict__ is_seed, unsigned int *__restrict__ n_collisions)
+                                                       int32_t *__restrict__ is_seed, unsigned int *__restrict__ n_collisions,
+                                                       const int32_t *__restrict__ sample)
 {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rd.n; r += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t slot = slot_of[r];
@@ -190,6 +192,7 @@ __global__ void __launch_bounds__(256) k_table_resolve(ReadsDev rd, const uint64
     const int32_t s = vals[slot];
     int8_t st = 0;
     if (s == (int32_t)r) st = 1;
+    else if (sample && sample[r] != sample[s]) st = 0;     // keys of two samples met: a collision like any other
     else if (hf[r] == hf[s] && same_forward(rd, r, s)) st = 1;
     else if (rc_equals_forward(rd, r, s)) st = -1;
     else if (same_forward(rd, r, s)) st = 1;
@@ -384,9 +387,9 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 8192)
   return (int)g;
 }
 
-void launch_hash_reads(const ReadsDev &rd, uint64_t seed, int strand_both, uint64_t *hf, uint64_t *hr, hipStream_t st)
+void launch_hash_reads(const ReadsDev &rd, uint64_t seed, int strand_both, uint64_t *hf, uint64_t *hr, hipStream_t st, const int32_t *sample)
 {
-  hipLaunchKernelGGL(k_hash_reads, dim3(grid_for(rd.n)), dim3(256), 0, st, rd, seed, strand_both, hf, hr);
+  hipLaunchKernelGGL(k_hash_reads, dim3(grid_for(rd.n)), dim3(256), 0, st, rd, seed, strand_both, hf, hr, sample);
 }
 void launch_table_insert(int64_t n, const int32_t *len, int minlen, const uint64_t *hf, const uint64_t *hr,
                          unsigned long long *keys, int32_t *vals, uint64_t mask, uint32_t *slot_of, hipStream_t st)
@@ -394,9 +397,10 @@ void launch_table_insert(int64_t n, const int32_t *len, int minlen, const uint64
   hipLaunchKernelGGL(k_table_insert, dim3(grid_for(n)), dim3(256), 0, st, n, len, minlen, hf, hr, keys, vals, mask, slot_of);
 }
 void launch_table_resolve(const ReadsDev &rd, const uint64_t *hf, const int32_t *vals, const uint32_t *slot_of,
-                          int32_t *rep_of, int8_t *strand, int32_t *is_seed, unsigned int *n_collisions, hipStream_t st)
+                          int32_t *rep_of, int8_t *strand, int32_t *is_seed, unsigned int *n_collisions, hipStream_t st,
+                          const int32_t *sample)
 {
-  hipLaunchKernelGGL(k_table_resolve, dim3(grid_for(rd.n)), dim3(256), 0, st, rd, hf, vals, slot_of, rep_of, strand, is_seed, n_collisions);
+  hipLaunchKernelGGL(k_table_resolve, dim3(grid_for(rd.n)), dim3(256), 0, st, rd, hf, vals, slot_of, rep_of, strand, is_seed, n_collisions, sample);
 }
 void launch_uniques(int64_t n, const int32_t *rep_of, const int32_t *seed_rank, int32_t *uniq_of, int32_t *seed_read,
                     int32_t *abundance, hipStream_t st)

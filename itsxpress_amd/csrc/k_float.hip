@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(64, 2) k_env_post(EnvArgs a, int wave0)
 // K4: per pair, chain its envelopes in order: null2 corrections, bit scores, reporting
 // count one "reported target" for profile `prof` per flagged lane, with one atomic per distinct profile per
 // wave: the work lists are grouped by profile, so per-lane atomics would all hit the same address
+// (`prof` is the counter's index: sample * P + profile when several samples share the batch)
 DEV void count_reported(int32_t *domz, int prof, bool flag)
 {
   unsigned long long todo = __ballot(flag);
@@ -1022,7 +1023,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
     }
     const int seq_rep = ((double)seq_score >= a.T);
     emit_domain(a, g0, pr, pp, rg, ro, dc, 0, 1, po.flags, nullsc, seq_score, final_bias, seq_rep, L, lt.lognn3, log_omega);
-    count_reported(a.domz, pr.prof, seq_rep != 0);
+    count_reported(a.domz, (a.usample ? a.usample[a.sorted_uniq[pr.useq]] * a.P : 0) + pr.prof, seq_rep != 0);
     return;
   }
   const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
@@ -1071,7 +1072,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
                 seq_rep, L, lt.lognn3, log_omega);
     if (ro.ok) k++;
   }
-  count_reported(a.domz, pr.prof, seq_rep != 0);
+  count_reported(a.domz, (a.usample ? a.usample[a.sorted_uniq[pr.useq]] * a.P : 0) + pr.prof, seq_rep != 0);
 }
 
 // compaction of raw per-pair region slots into the profile-grouped region list
@@ -1102,13 +1103,14 @@ __global__ void __launch_bounds__(256) k_region_offsets(int64_t npairs, const Pa
 }
 
 // final thresholds + the ItsPosition argmax
-__global__ void __launch_bounds__(256) k_finalize(itsx_domain *__restrict__ dom, int64_t n, const int64_t *__restrict__ domz, double domE)
+__global__ void __launch_bounds__(256) k_finalize(itsx_domain *__restrict__ dom, int64_t n, const int64_t *__restrict__ domz, double domE,
+                                                  const int32_t *__restrict__ usample, int P)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   itsx_domain d = dom[i];
   if (d.dom_idx < 0) return;
-  const int rep = d.seq_reported && (det_exp(d.lnP) * (double)domz[d.prof] <= domE);
+  const int rep = d.seq_reported && (det_exp(d.lnP) * (double)domz[(usample ? usample[d.rep] * P : 0) + d.prof] <= domE);
   dom[i].dom_reported = rep;
 }
 // key = [24b tenths+bias][20b ~prof][4b ~dom][16b coordinate]; atomicMax picks the highest %.1f score,
@@ -1189,10 +1191,10 @@ void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npair
   if (npairs <= 0) return;
   hipLaunchKernelGGL(k_region_fill, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, pair_region0, out);
 }
-void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, hipStream_t st)
+void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, const int32_t *usample, int P, hipStream_t st)
 {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, domz, domE);
+  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, domz, domE, usample, P);
 }
 void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, unsigned long long *bl, unsigned long long *br,
                       int32_t *in_ddict, hipStream_t st)

@@ -33,6 +33,7 @@ class Engine:
         self.n_reads = 0
         self.n_unique = 0
         self.n_profiles = 0
+        self.n_samples = 1
 
     def close(self):
         if getattr(self, "h", None):
@@ -106,6 +107,7 @@ class Engine:
                                         C.cast(C.c_char_p(nb), C.c_void_p) if nb is not None else None,
                                         no.ctypes.data if no is not None else None))
         self.n_reads = n
+        self.n_samples = 1
         return n
 
     def load_reads_file(self, path):
@@ -114,7 +116,36 @@ class Engine:
         n = C.c_int64(0)
         self._chk(self.L.itsx_load_reads_file(self.h, os.fsencode(path), C.byref(n)))
         self.n_reads = n.value
+        self.n_samples = 1
         return n.value
+
+    # ---- f4: per-sample batching (many samples, one pass of every kernel, per-sample results)
+    def load_reads_files(self, paths):
+        """One sequence file per sample, in order: sample index = position in `paths`.
+        Returns the read count of each file (reads of sample s are the s-th contiguous block)."""
+        for p in paths:
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        counts = np.zeros(max(1, len(paths)), np.int64)
+        self._chk(self.L.itsx_load_reads_files(self.h, arr, len(paths), counts.ctypes.data))
+        self.n_reads = int(counts[:len(paths)].sum())
+        self.n_samples = max(1, self.L.itsx_num_samples(self.h))
+        return counts[:len(paths)]
+
+    def set_samples(self, sample_of_read, n_samples):
+        """sample_of_read int32[n_reads] in [0, n_samples); None returns to one sample."""
+        if sample_of_read is None:
+            self._chk(self.L.itsx_set_samples(self.h, None, 1))
+        else:
+            a = np.ascontiguousarray(sample_of_read, np.int32)
+            assert a.shape[0] == self.n_reads
+            self._chk(self.L.itsx_set_samples(self.h, a.ctypes.data if a.size else None, int(n_samples)))
+        self.n_samples = max(1, self.L.itsx_num_samples(self.h))
+
+    def select_sample(self, sample):
+        """Restrict write_uc / write_rep_fasta / write_domtbl to one sample of the batch (-1 = all)."""
+        self._chk(self.L.itsx_select_sample(self.h, int(sample)))
 
     # ---- derep
     def derep(self, strand_both=True, minseqlength=32):
@@ -219,12 +250,13 @@ class Engine:
         self._chk(self.L.itsx_search(self.h, T, F1, F2, F3))
 
     def get_domz(self):
-        z = np.zeros(self.n_profiles, np.int64)
+        z = np.zeros(self.n_profiles * self.n_samples, np.int64)      # [sample][profile]
         self._chk(self.L.itsx_get_domz(self.h, z.ctypes.data))
         return z
 
     def set_domz(self, z):
         z = np.ascontiguousarray(z, np.int64)
+        assert z.size == self.n_profiles * self.n_samples
         self._chk(self.L.itsx_set_domz(self.h, z.ctypes.data))
 
     def finalize(self, domE=10.0):

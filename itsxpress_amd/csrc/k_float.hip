@@ -112,28 +112,36 @@ DEV void fwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
   V4 mpv = vrsh(R.m[Q - 1]), dpv = vrsh(R.d[Q - 1]), ipv = vrsh(R.i[Q - 1]);
   V4 sv;
   if constexpr (QT != 0) {
-    T7 cur = ld7(tf, 0);
-    V4 ecur = vld(rfx);
+    // The node groups are independent of one another within a row (group q reads the OLD row's group q-1), so they
+    // are evaluated from the last group down: every new value then overwrites an old one that nobody needs any more
+    // and the row state stays in the same registers from row to row (evaluated upwards, the new M/I vectors are born
+    // while the old ones are still live, and the loop back-edge pays ~47 register copies per row).  Every value is
+    // computed by the same operations on the same operands; xE's sum over the groups is taken afterwards, ascending.
+    T7 cur = ld7(tf, QT - 1);
+    V4 ecur = vld(rfx + (QT - 1) * 4);
 #pragma unroll
-    for (int q = 0; q < QT; q++) {
+    for (int q = QT - 1; q >= 0; q--) {
       WAIT_LGKM0();
       T7 nxt = cur;
       V4 enxt = ecur;
-      if (q + 1 < QT) { nxt = ld7(tf, q + 1); enxt = vld(rfx + (q + 1) * 4); }   // next group's operands fly during this group
+      if (q > 0) { nxt = ld7(tf, q - 1); enxt = vld(rfx + (q - 1) * 4); }   // next group's operands fly during this group
+      const V4 pm = q > 0 ? R.m[q - 1] : mpv, pi = q > 0 ? R.i[q - 1] : ipv, pd = q > 0 ? R.d[q - 1] : dpv;
+      // the insert state first: it is the last reader of the old M[q] and I[q], whose registers the new values then take
+      R.i[q] = vadd(vmul(R.m[q], cur.mi), vmul(R.i[q], cur.ii));
+      asm volatile("" : "+v"(R.i[q].a), "+v"(R.i[q].b));
       sv = vmul(xBv, cur.bm);
-      sv = vadd(sv, vmul(mpv, cur.mm));
-      sv = vadd(sv, vmul(ipv, cur.im));
-      sv = vadd(sv, vmul(dpv, cur.dm));
+      sv = vadd(sv, vmul(pm, cur.mm));
+      sv = vadd(sv, vmul(pi, cur.im));
+      sv = vadd(sv, vmul(pd, cur.dm));
       sv = vmul(sv, ecur);
-      xEv = vadd(xEv, sv);
-      mpv = R.m[q]; dpv = R.d[q]; ipv = R.i[q];
-      R.m[q] = sv; R.d[q] = dcv;
-      dcv = vmul(sv, cur.md);
-      sv = vmul(mpv, cur.mi);
-      R.i[q] = vadd(sv, vmul(ipv, cur.ii));
+      R.m[q] = sv;
+      if (q + 1 < QT) R.d[q + 1] = vmul(sv, cur.md); else dcv = vmul(sv, cur.md);
+      asm volatile("" : "+v"(R.m[q].a), "+v"(R.m[q].b));
       SCHED_FENCE();
       cur = nxt; ecur = enxt;
     }
+#pragma unroll
+    for (int q = 0; q < QT; q++) xEv = vadd(xEv, R.m[q]);
     V4 dd[QT];
 #pragma unroll
     for (int q = 0; q < QT; q++) dd[q] = TF(q, tDD);
@@ -315,6 +323,9 @@ DEV void bwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
       mpv = vmul(R.m[q], ecur);
       R.m[q] = mcv;
       xBv = vadd(xBv, vmul(mpv, cur.bm));
+      // pinned here: left free, instruction selection moves this accumulation chain behind the last group and keeps
+      // all twelve B->M operand vectors alive for it (86 SGPR spill moves through VGPR lanes per row)
+      asm volatile("" : "+v"(xBv.a), "+v"(xBv.b));
       SCHED_FENCE();
       cur = nxt; ecur = enxt;
     }

@@ -17,6 +17,9 @@
 #include <map>
 #include <memory>
 #include <numeric>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include "detmath.h"
 #include "engine.h"
@@ -232,6 +235,17 @@ struct StageTimer {
   float stop() { (void)hipEventRecord(b, st); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
   ~StageTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
+
+// run fn(t) on T host threads (the domain table of a large sample has millions of rows: ordering and formatting it on one
+// thread took longer than the whole GPU path)
+template <class F> static void on_threads(int T, F fn)
+{
+  if (T <= 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)T);
+  for (int t = 0; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
+  for (auto &x : th) x.join();
+}
 
 extern "C" {
 
@@ -1272,16 +1286,32 @@ static int fetch_domains(const itsx_ctx *cctx)
 {
   itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
   if (!ctx->h_dom.empty()) return ITSX_OK;
+  // domtblout order: profile, then target, then domain.  The device rows are grouped by profile already (not contiguously
+  // across chunks), so: counting sort by profile, then every profile's rows are ordered on their own by a pool of threads.
+  const int P = std::max(ctx->P, 1);
+  std::vector<itsx_domain> all;
+  std::vector<int64_t> start((size_t)P + 1, 0);
   for (size_t c = 0; c < ctx->dom_n.size(); c++) {
     if (ctx->dom_n[c] <= 0) continue;
-    std::vector<itsx_domain> all((size_t)ctx->dom_n[c]);
-    HIPCHK(hipMemcpy(all.data(), ctx->dom_bufs[c]->p, all.size() * sizeof(itsx_domain), hipMemcpyDeviceToHost));
-    for (auto &d : all) if (d.dom_idx >= 0 && d.prof >= 0) ctx->h_dom.push_back(d);
+    const size_t o = all.size();
+    all.resize(o + (size_t)ctx->dom_n[c]);
+    HIPCHK(hipMemcpy(all.data() + o, ctx->dom_bufs[c]->p, (size_t)ctx->dom_n[c] * sizeof(itsx_domain), hipMemcpyDeviceToHost));
   }
-  std::sort(ctx->h_dom.begin(), ctx->h_dom.end(), [](const itsx_domain &a, const itsx_domain &b) {
-    if (a.prof != b.prof) return a.prof < b.prof;
-    if (a.rep != b.rep) return a.rep < b.rep;
-    return a.dom_idx < b.dom_idx;
+  for (const auto &d : all) if (d.dom_idx >= 0 && d.prof >= 0 && d.prof < P) start[(size_t)d.prof + 1]++;
+  for (int p = 0; p < P; p++) start[(size_t)p + 1] += start[(size_t)p];
+  ctx->h_dom.resize((size_t)start[(size_t)P]);
+  {
+    std::vector<int64_t> cur(start.begin(), start.end() - 1);
+    for (const auto &d : all) if (d.dom_idx >= 0 && d.prof >= 0 && d.prof < P) ctx->h_dom[(size_t)cur[(size_t)d.prof]++] = d;
+  }
+  std::vector<itsx_domain>().swap(all);
+  std::atomic<int> next{0};
+  on_threads(std::min(itsx_io::io_threads(), P), [&](int) {
+    for (int p = next.fetch_add(1); p < P; p = next.fetch_add(1))
+      std::sort(ctx->h_dom.begin() + start[(size_t)p], ctx->h_dom.begin() + start[(size_t)p + 1], [](const itsx_domain &a, const itsx_domain &b) {
+        if (a.rep != b.rep) return a.rep < b.rep;
+        return a.dom_idx < b.dom_idx;
+      });
   });
   return ITSX_OK;
 }
@@ -1522,9 +1552,12 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   Side f, r;
   std::string ferr, rerr2;
   int rc2 = ITSX_OK;
+  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  const auto tm0 = std::chrono::steady_clock::now();
   std::thread other([&] { rc2 = parse(r2_path, r, rerr2); });
   int rc = parse(r1_path, f, ferr);
   other.join();
+  const auto tm1 = std::chrono::steady_clock::now();
   if (rc != ITSX_OK) { ctx->set_error(ferr); return rc; }
   if (rc2 != ITSX_OK) { ctx->set_error(rerr2); return rc2; }
   if (f.ids.size() != r.ids.size()) SET_ERR(ctx, ITSX_E_FORMAT, "R1 and R2 hold different numbers of records");
@@ -1534,6 +1567,7 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   rc = itsx_merge_buffers(ctx, f.seq.data(), f.qual.data(), f.off.data(), r.seq.data(), r.qual.data(), r.off.data(), n, maxdiffs, maxee, allow_stagger,
                           &oseq[0], &oqual[0], olen.data(), reason.data(), nullptr, nullptr);
   if (rc != ITSX_OK) return rc;
+  const auto tm2 = std::chrono::steady_clock::now();
   // seq.fq is read back by the loader and by the paired trimmer: written through the block writer, which also leaves
   // its text in the reader's cache
   itsx_io::BlockWriter bw;
@@ -1551,6 +1585,10 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   }
   bw.put(buf);
   if (!bw.close(werr)) SET_ERR(ctx, ITSX_E_IO, werr);
+  if (trace) {
+    const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[itsx] merge files: read+inflate+parse %.0f ms, upload+kernel+download %.0f ms, write %.0f ms\n", ms(tm0, tm1), ms(tm1, tm2), ms(tm2, std::chrono::steady_clock::now()));
+  }
   if (n_pairs) *n_pairs = n;
   if (n_merged) *n_merged = merged;
   return ITSX_OK;
@@ -1694,32 +1732,100 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path)
   fprintf(f, "#                                                                            --- full sequence --- -------------- this domain -------------   hmm coord   ali coord   env coord\n");
   fprintf(f, "# target name        accession   tlen query name           accession   qlen   E-value  score  bias   #  of  c-Evalue  i-Evalue  score  bias  from    to  from    to  from    to  acc description of target\n");
   // rows: profile order; within a profile, targets; within a target, reported domains renumbered
-  size_t i = 0;
   const std::vector<itsx_domain> &D = ctx->h_dom;
   std::vector<int64_t> Zs((size_t)ctx->S, 0);          // hmmsearch's Z: targets searched, per sample
   for (int32_t u = 0; u < ctx->U; u++) Zs[(size_t)ctx->usample(u)]++;
-  while (i < D.size()) {
-    size_t j = i; int nrep = 0;
-    while (j < D.size() && D[j].prof == D[i].prof && D[j].rep == D[i].rep) { nrep += D[j].dom_reported; j++; }
-    int k = 0;
-    const int32_t smp = ctx->usample(D[i].rep);
-    if (ctx->S > 1 && ctx->sel_sample >= 0 && smp != ctx->sel_sample) { i = j; continue; }
-    for (size_t d = i; d < j; d++) {
-      if (!D[d].dom_reported) continue;
-      k++;
-      const HostProfile &h = ctx->profs[D[d].prof];
-      const double Z = (double)Zs[(size_t)smp], dz = (double)ctx->domz[(size_t)smp * ctx->P + D[d].prof];
-      const double seqE = Z * det_exp(exp_logsurv((double)D[d].seq_score, (double)h.evparam[4], (double)h.evparam[5]));
-      const double P = det_exp(D[d].lnP);
-      // hmm/ali coordinates and acc need the optimal-accuracy alignment, which the engine does not compute:
-      // envelope coordinates are written in their place (the reference reads only env coords and the score).
-      fprintf(f, "%-20s %-10s %5d %-20s %-10s %5d %9.2g %6.1f %5.1f %3d %3d %9.2g %9.2g %6.1f %5.1f %5d %5d %5d %5d %5d %5d %4.2f %s\n",
-              read_name(ctx, ctx->h_seed_read[D[d].rep]).c_str(), "-", D[d].tlen, h.name.c_str(), "-", h.M, seqE, D[d].seq_score, D[d].seq_bias,
-              k, nrep, P * dz, P * Z, D[d].bitscore, D[d].dombias / 0.69314718055994529, 1, h.M, D[d].ienv, D[d].jenv, D[d].ienv, D[d].jenv, 0.0, "-");
+  // one (profile, target) group is formatted on its own, so the table is cut into blocks of whole groups that a pool of
+  // threads formats while this thread writes the finished blocks in order (a few blocks ahead at most)
+  std::vector<size_t> cut(1, 0);
+  {
+    const size_t target = 32768;
+    size_t i = 0, last = 0;
+    while (i < D.size()) {
+      size_t j = i;
+      while (j < D.size() && D[j].prof == D[i].prof && D[j].rep == D[i].rep) j++;
+      if (j - last >= target) { cut.push_back(j); last = j; }
+      i = j;
     }
-    i = j;
+    if (cut.back() != D.size()) cut.push_back(D.size());
   }
-  fclose(f);
+  const size_t nb = cut.size() - 1;
+  auto format_block = [&](size_t b, std::string &out) {
+    char line[1024];
+    size_t i = cut[b];
+    const size_t end = cut[b + 1];
+    while (i < end) {
+      size_t j = i; int nrep = 0;
+      while (j < end && D[j].prof == D[i].prof && D[j].rep == D[i].rep) { nrep += D[j].dom_reported; j++; }
+      int k = 0;
+      const int32_t smp = ctx->usample(D[i].rep);
+      if (ctx->S > 1 && ctx->sel_sample >= 0 && smp != ctx->sel_sample) { i = j; continue; }
+      const std::string tname = nrep ? read_name(ctx, ctx->h_seed_read[D[i].rep]) : std::string();
+      for (size_t d = i; d < j; d++) {
+        if (!D[d].dom_reported) continue;
+        k++;
+        const HostProfile &h = ctx->profs[D[d].prof];
+        const double Z = (double)Zs[(size_t)smp], dz = (double)ctx->domz[(size_t)smp * ctx->P + D[d].prof];
+        const double seqE = Z * det_exp(exp_logsurv((double)D[d].seq_score, (double)h.evparam[4], (double)h.evparam[5]));
+        const double P = det_exp(D[d].lnP);
+        // hmm/ali coordinates and acc need the optimal-accuracy alignment, which the engine does not compute:
+        // envelope coordinates are written in their place (the reference reads only env coords and the score).
+        const int len = snprintf(line, sizeof(line), "%-20s %-10s %5d %-20s %-10s %5d %9.2g %6.1f %5.1f %3d %3d %9.2g %9.2g %6.1f %5.1f %5d %5d %5d %5d %5d %5d %4.2f %s\n",
+              tname.c_str(), "-", D[d].tlen, h.name.c_str(), "-", h.M, seqE, D[d].seq_score, D[d].seq_bias,
+              k, nrep, P * dz, P * Z, D[d].bitscore, D[d].dombias / 0.69314718055994529, 1, h.M, D[d].ienv, D[d].jenv, D[d].ienv, D[d].jenv, 0.0, "-");
+        if (len < 0) continue;
+        if ((size_t)len < sizeof(line)) out.append(line, (size_t)len);
+        else {                                        // a label longer than the line buffer
+          std::string big((size_t)len + 1, '\0');
+          snprintf(&big[0], big.size(), "%-20s %-10s %5d %-20s %-10s %5d %9.2g %6.1f %5.1f %3d %3d %9.2g %9.2g %6.1f %5.1f %5d %5d %5d %5d %5d %5d %4.2f %s\n",
+              tname.c_str(), "-", D[d].tlen, h.name.c_str(), "-", h.M, seqE, D[d].seq_score, D[d].seq_bias,
+              k, nrep, P * dz, P * Z, D[d].bitscore, D[d].dombias / 0.69314718055994529, 1, h.M, D[d].ienv, D[d].jenv, D[d].ienv, D[d].jenv, 0.0, "-");
+          out.append(big.data(), (size_t)len);
+        }
+      }
+      i = j;
+    }
+  };
+  const int T = (int)std::min<size_t>((size_t)itsx_io::io_threads(), std::max<size_t>(nb, 1));
+  bool io_ok = true;
+  if (T <= 1 || nb <= 1) {
+    std::string out;
+    for (size_t b = 0; b < nb; b++) { out.clear(); format_block(b, out); if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) io_ok = false; }
+  } else {
+    std::vector<std::string> blocks(nb);
+    std::vector<char> ready(nb, 0);
+    std::mutex mu; std::condition_variable cv;
+    size_t next = 0, written = 0;
+    const size_t ahead = (size_t)T * 4;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([&] {
+        for (;;) {
+          size_t b;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return next >= nb || next < written + ahead; });
+            if (next >= nb) return;
+            b = next++;
+          }
+          std::string out;
+          out.reserve(32768 * 200);
+          format_block(b, out);
+          { std::lock_guard<std::mutex> lk(mu); blocks[b].swap(out); ready[b] = 1; }
+          cv.notify_all();
+        }
+      });
+    for (size_t b = 0; b < nb; b++) {
+      std::string out;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[b] != 0; }); out.swap(blocks[b]); }
+      if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) io_ok = false;
+      { std::lock_guard<std::mutex> lk(mu); written = b + 1; }
+      cv.notify_all();
+    }
+    for (auto &x : th) x.join();
+  }
+  if (fclose(f) != 0) io_ok = false;
+  if (!io_ok) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
   return ITSX_OK;
 }
 

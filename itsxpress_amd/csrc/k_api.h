@@ -156,7 +156,8 @@ struct FloatArgs {
   const PairRec *pairs;
   PairOut *pout;
   const WaveDesc *waves;
-  float *slab;                  // xmx rows: [row][12][64] per wave
+  float *slab;                  // xmx rows: two planes of [row][6][64] (k_float.hip: SLAB)
+  int64_t slab_plane;           // floats between the planes = rows of this batch x 6 x 64
   RegionRec *regions;           // [npairs][MAXDOM] raw, before compaction
   double F1, F3;
 };

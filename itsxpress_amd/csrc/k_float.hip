@@ -358,11 +358,12 @@ DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
 }
 
 // ---- slab addressing: [row][field][lane] ---------------------------------------------------
-constexpr int XF = 12;     // fields per row in the parser slab: fwd E N J B C S | the six decoding terms Backward writes
-DEV float *slab_at(float *slab, int64_t row0, int row, int nfields, int field, int lane)
-{
-  return slab + (((row0 + row) * nfields + field) * 64 + lane);
-}
+// The parser slab of a batch is two planes of [row][6 fields][64 lanes]: Forward's E N J B C S (fields 0-5), then --
+// slab_plane floats further -- the six decoding terms Backward writes (fields 6-11).  Every kernel then streams whole
+// 1.5-KB rows of ONE plane (Forward writes plane 0, Backward reads it and writes plane 1, the decoder reads plane 1)
+// instead of one half of interleaved 3-KB rows.
+#define SLAB(a, row0, row, field, lane) \
+  ((a).slab + ((field) >= 6 ? (a).slab_plane : (int64_t)0) + ((((row0) + (row)) * 6 + ((field) % 6)) * 64 + (lane)))
 
 
 // =========================================================================================
@@ -444,9 +445,9 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
     const float ploop = 1.0f - pmove;
     float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f, totscale = 0.0f;
     const int64_t r0 = wd.slab;
-    *slab_at(a.slab, r0, 0, XF, 0, lane) = xE; *slab_at(a.slab, r0, 0, XF, 1, lane) = xN;
-    *slab_at(a.slab, r0, 0, XF, 2, lane) = xJ; *slab_at(a.slab, r0, 0, XF, 3, lane) = xB;
-    *slab_at(a.slab, r0, 0, XF, 4, lane) = xC; *slab_at(a.slab, r0, 0, XF, 5, lane) = 1.0f;
+    *SLAB(a, r0, 0, 0, lane) = xE; *SLAB(a, r0, 0, 1, lane) = xN;
+    *SLAB(a, r0, 0, 2, lane) = xJ; *SLAB(a, r0, 0, 3, lane) = xB;
+    *SLAB(a, r0, 0, 4, lane) = xC; *SLAB(a, r0, 0, 5, lane) = 1.0f;
     int xnext = sq.code(0);                  // residue of the NEXT row: its loads fly during the current row
     for (int i = 1; i <= Lw; i++) {
       if (i <= L) {
@@ -461,9 +462,9 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
           totscale = (float)((double)totscale + det_log((double)xE));
           xE = 1.0f;
         }
-        *slab_at(a.slab, r0, i, XF, 0, lane) = xE; *slab_at(a.slab, r0, i, XF, 1, lane) = xN;
-        *slab_at(a.slab, r0, i, XF, 2, lane) = xJ; *slab_at(a.slab, r0, i, XF, 3, lane) = xB;
-        *slab_at(a.slab, r0, i, XF, 4, lane) = xC; *slab_at(a.slab, r0, i, XF, 5, lane) = sc;
+        *SLAB(a, r0, i, 0, lane) = xE; *SLAB(a, r0, i, 1, lane) = xN;
+        *SLAB(a, r0, i, 2, lane) = xJ; *SLAB(a, r0, i, 3, lane) = xB;
+        *SLAB(a, r0, i, 4, lane) = xC; *SLAB(a, r0, i, 5, lane) = sc;
       }
     }
     const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
     }
     // rows are walked from the wave's longest length down; a lane joins at its own L
     float sL = 1.0f;
-    if (alive) sL = *slab_at(a.slab, r0, L, XF, 5, lane);
+    if (alive) sL = *SLAB(a, r0, L, 5, lane);
     if (sL > 1.0f) {
       xE = xE / sL; xN = xN / sL; xC = xC / sL; xJ = xJ / sL; xB = xB / sL;
       scale_row<QT>(R, Q, sL);
@@ -526,17 +527,17 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
     struct FRow { float E, N, J, B, C, S; };
     auto load_f = [&](int i) {
       FRow f;
-      f.E = *slab_at(a.slab, r0, i, XF, 0, lane); f.N = *slab_at(a.slab, r0, i, XF, 1, lane); f.J = *slab_at(a.slab, r0, i, XF, 2, lane);
-      f.B = *slab_at(a.slab, r0, i, XF, 3, lane); f.C = *slab_at(a.slab, r0, i, XF, 4, lane); f.S = *slab_at(a.slab, r0, i, XF, 5, lane);
+      f.E = *SLAB(a, r0, i, 0, lane); f.N = *SLAB(a, r0, i, 1, lane); f.J = *SLAB(a, r0, i, 2, lane);
+      f.B = *SLAB(a, r0, i, 3, lane); f.C = *SLAB(a, r0, i, 4, lane); f.S = *SLAB(a, r0, i, 5, lane);
       return f;
     };
     auto store_terms = [&](int i, const FRow &fc, const FRow &fp, float s) {
-      *slab_at(a.slab, r0, i, XF, 6, lane) = fc.E * xE * fc.S;
-      *slab_at(a.slab, r0, i, XF, 7, lane) = fp.N * xN * ploop;
-      *slab_at(a.slab, r0, i, XF, 8, lane) = fp.J * xJ * ploop;
-      *slab_at(a.slab, r0, i, XF, 9, lane) = fc.B * xB * fc.S;
-      *slab_at(a.slab, r0, i, XF, 10, lane) = fp.C * xC * ploop;
-      *slab_at(a.slab, r0, i, XF, 11, lane) = fc.S / s;
+      *SLAB(a, r0, i, 6, lane) = fc.E * xE * fc.S;
+      *SLAB(a, r0, i, 7, lane) = fp.N * xN * ploop;
+      *SLAB(a, r0, i, 8, lane) = fp.J * xJ * ploop;
+      *SLAB(a, r0, i, 9, lane) = fc.B * xB * fc.S;
+      *SLAB(a, r0, i, 10, lane) = fp.C * xC * ploop;
+      *SLAB(a, r0, i, 11, lane) = fc.S / s;
     };
     FRow fcur, fprv;
     fcur.E = fcur.N = fcur.J = fcur.B = fcur.C = 0.f; fcur.S = sL; fprv = fcur;
@@ -577,9 +578,9 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
       xB = vhsum(xBv);
       xN = (xB * pmove) + (xN * ploop);
       const FRow f0 = (L >= 2) ? fprv : load_f(0);     // L == 1: the row loop never ran
-      *slab_at(a.slab, r0, 0, XF, 7, lane) = xN;       // Backward's N at row 0 = total probability (the decoder's 1/x)
-      *slab_at(a.slab, r0, 0, XF, 9, lane) = f0.B * xB * f0.S;
-      *slab_at(a.slab, r0, 0, XF, 11, lane) = f0.S / 1.0f;
+      *SLAB(a, r0, 0, 7, lane) = xN;       // Backward's N at row 0 = total probability (the decoder's 1/x)
+      *SLAB(a, r0, 0, 9, lane) = f0.B * xB * f0.S;
+      *SLAB(a, r0, 0, 11, lane) = f0.S / 1.0f;
       bad = (xN != xN) || (xN == 0.0f) || (xN == __builtin_inff());
       po.bcksc = (float)((double)totscale + det_log((double)xN));
     }
@@ -608,17 +609,17 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
   int nreg = 0, nkept = 0, flags = 0, nmulti = 0;
   if (alive && !bad) {
     const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
-    float scaleproduct = (float)(1.0 / (double)*slab_at(a.slab, r0, 0, XF, 7, lane));
+    float scaleproduct = (float)(1.0 / (double)*SLAB(a, r0, 0, 7, lane));
     float btot = 0.f, etot = 0.f;
     // one row of decoding terms (see k_bwd_decode); the next row is requested while the current one is consumed,
     // so the serial chain of sums never waits on HBM latency
     struct DRow { float t2, t3, t4, t1, t5, rs; };
     auto load_row = [&](int j) {
       DRow d;
-      d.t2 = *slab_at(a.slab, r0, j, XF, 6, lane); d.t3 = *slab_at(a.slab, r0, j, XF, 7, lane);
-      d.t4 = *slab_at(a.slab, r0, j, XF, 8, lane); d.t1 = *slab_at(a.slab, r0, j, XF, 9, lane);
-      d.t5 = *slab_at(a.slab, r0, j, XF, 10, lane);
-      d.rs = own ? *slab_at(a.slab, r0, j, XF, 11, lane) : 1.0f;
+      d.t2 = *SLAB(a, r0, j, 6, lane); d.t3 = *SLAB(a, r0, j, 7, lane);
+      d.t4 = *SLAB(a, r0, j, 8, lane); d.t1 = *SLAB(a, r0, j, 9, lane);
+      d.t5 = *SLAB(a, r0, j, 10, lane);
+      d.rs = own ? *SLAB(a, r0, j, 11, lane) : 1.0f;
       return d;
     };
     DRow prv = load_row(0);
@@ -653,8 +654,8 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
         float b = ck_btot, e = ck_etot, sp = ck_sp, t1p = ck_t1, rsp = ck_rs;
         const float et0 = ck_etot;
         for (int z = ri; z <= j; z++) {
-          const float t2z = *slab_at(a.slab, r0, z, XF, 6, lane), t1z = *slab_at(a.slab, r0, z, XF, 9, lane);
-          const float rsz = own ? *slab_at(a.slab, r0, z, XF, 11, lane) : 1.0f;
+          const float t2z = *SLAB(a, r0, z, 6, lane), t1z = *SLAB(a, r0, z, 9, lane);
+          const float rsz = own ? *SLAB(a, r0, z, 11, lane) : 1.0f;
           const float bprev = b;                         // btot[z-1]
           b = b + (t1p * sp);
           if (own) sp *= rsp;

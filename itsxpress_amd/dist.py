@@ -32,8 +32,28 @@ def allreduce_domz(domz, device=None):
     return t.cpu().numpy()
 
 
+_PINNED = {}
+
+
+def _pinned(shape, dtype):
+    """a cached page-locked host tensor (device -> host copies of the gathered block run at PCIe speed, not at the
+    pageable-copy rate); plain memory when no GPU is in use (gloo tests)"""
+    import torch
+    key = (tuple(shape), dtype)
+    t = _PINNED.get(key)
+    if t is None:
+        try:
+            t = torch.empty(shape, dtype=dtype, pin_memory=torch.cuda.is_available())
+        except RuntimeError:
+            t = torch.empty(shape, dtype=dtype)
+        _PINNED.clear()                                  # one shape at a time: a bench step always asks for the same one
+        _PINNED[key] = t
+    return t
+
+
 def gather_coords(start, stop, tlen, in_ddict, device=None, dst=0):
-    """rank dst receives every rank's [n_i, 4] int32 block (shards may differ in size)."""
+    """rank dst receives every rank's [n_i, 4] int32 block (shards may differ in size); the others get None.
+    The final gather of the path: 16 B per read, sent to dst only."""
     import torch
     import torch.distributed as dist
     block = np.stack([start, stop, tlen, in_ddict], axis=1).astype(np.int32)
@@ -43,19 +63,28 @@ def gather_coords(start, stop, tlen, in_ddict, device=None, dst=0):
     n = torch.tensor([block.shape[0]], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(ws)]
     dist.all_gather(sizes, n)
-    nmax = int(max(int(s.item()) for s in sizes))
-    pad = np.full((nmax, 4), -1, np.int32)
-    pad[:block.shape[0]] = block
-    t = torch.from_numpy(pad)
+    sizes = [int(x) for x in torch.cat(sizes).cpu().tolist()]
+    nmax = max(max(sizes), 1)
+    if block.shape[0] == nmax:
+        pad = block
+    else:
+        pad = np.full((nmax, 4), -1, np.int32)
+        pad[:block.shape[0]] = block
+    t = torch.from_numpy(np.ascontiguousarray(pad))
     if device is not None:
         t = t.to(device)
-    # all_gather (the collective every backend implements) rather than gather: the blocks are tiny next to the
-    # DP work (16 B per read), and rank dst simply keeps what it needs
-    out = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(out, t)
-    if rank != dst:
-        return None
-    return [o.cpu().numpy()[:int(s.item())] for o, s in zip(out, sizes)]
+    if rank == dst:
+        big = torch.empty((ws, nmax, 4), dtype=torch.int32, device=t.device)
+        dist.gather(t, [big[r] for r in range(ws)], dst=dst)
+        host = _pinned((ws, nmax, 4), torch.int32) if t.is_cuda else None
+        if host is not None:
+            host.copy_(big)
+            arr = host.numpy()
+        else:
+            arr = big.numpy()
+        return [arr[r, :sizes[r]].copy() for r in range(ws)]
+    dist.gather(t, None, dst=dst)
+    return None
 
 
 # ------------------------------------------------------------------------------------------------

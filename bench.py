@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # HBM bytes per lane-row measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), see
 # profiles/round1_pmc_hbm_traffic_200k.md.  WRITE_SIZE is exact for these stores; FETCH_SIZE is NOT doubled
 # (uncalibrated for 4-byte-per-lane loads on gfx950), so the read side is a lower bound.
-PMC_BYTES_PER_ROW = {"k_filters_fwd": 0.7 + 23.7, "k_bwd_decode": 13.3 + 23.6, "k_decode": 17.8 + 0.3}
+PMC_BYTES_PER_ROW = {"k_filters_fwd": 0.6 + 23.7, "k_bwd_decode": 13.2 + 23.6, "k_decode": 17.8 + 0.2}
 VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # lane-ops/ns: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
 
 

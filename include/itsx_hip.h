@@ -236,10 +236,15 @@ int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const ch
 const char *itsx_trim_last_error(void);
 /* The readers behind every *_file entry point, exposed for the host side (replaces gzip.open / pyzstd.open of
  * main.py:296-330 and SeqSample.py:929-949): the decompressed content of a plain / gzip / zstd file in a buffer the
- * caller releases with itsx_io_free.  itsx_io_codecs: bit 0 = libdeflate in use for gzip, bit 1 = libzstd available. */
+ * caller releases with itsx_io_free.  itsx_io_codecs: bit 0 = libdeflate in use for gzip, bit 1 = libzstd available.
+ * A single-member gzip file of more than a few MB is inflated by a pool of threads (csrc/pinflate.cpp: block starts are
+ * found inside the stream, every chunk is decoded with its unknown 32-KB history as markers, the markers are resolved
+ * front to back) and accepted only when length and CRC-32 match the trailer; everything else takes the serial inflater.
+ * itsx_io_parallel_inflates: files delivered that way since the library was loaded (ITSX_PARALLEL_INFLATE=0 turns it off). */
 int  itsx_io_read(const char *path, char **text, int64_t *len);
 void itsx_io_free(char *text);
 int  itsx_io_codecs(void);
+int64_t itsx_io_parallel_inflates(void);
 
 /* ---- test hooks (parity tests only) */
 /* XXH64 of each read's packed forward / reverse-complement key, as computed on the device */

@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -198,6 +199,9 @@ void cache_put(const char *path, std::shared_ptr<const std::string> text)
   cache_insert(path, fsize, mtime, text, budget);
 }
 
+static std::atomic<int64_t> g_parallel_inflates{0};
+int64_t parallel_inflates() { return g_parallel_inflates.load(); }
+
 int codec_flags() { codecs(); return (g_ld.ok ? 1 : 0) | (g_zs.ok ? 2 : 0); }
 
 int io_threads()
@@ -227,6 +231,7 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
   FILE *f = fopen(path, "rb");
   if (!f) { err = std::string("cannot read ") + path; return nullptr; }
   std::string raw;
+  raw.reserve((size_t)fsize + 64);
   raw.resize((size_t)fsize);
   size_t got = 0;
   while (got < raw.size()) { const size_t n = fread(&raw[got], 1, raw.size() - got, f); if (n == 0) break; got += n; }
@@ -239,14 +244,23 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
   if (rerr) { err = std::string("read error on ") + path; return nullptr; }
   const auto c1 = std::chrono::steady_clock::now();
   auto text = std::make_shared<std::string>();
+  bool par = false;
   if (is_gzip(raw)) {
-    const bool ok = g_ld.ok ? gunzip_libdeflate(raw, *text, err) : gunzip_zlib(raw, *text, err);
+    // large single-member files: block-parallel inflate, accepted only on a CRC-32 and length match (pinflate.cpp)
+    if (env_int("ITSX_PARALLEL_INFLATE", 1) != 0 && io_threads() > 1) {
+      const size_t n0 = raw.size();
+      raw.append(16, '\0');
+      par = gunzip_parallel(raw.data(), n0, *text, io_threads());
+      raw.resize(n0);
+      if (par) g_parallel_inflates.fetch_add(1);
+    }
+    const bool ok = par || (g_ld.ok ? gunzip_libdeflate(raw, *text, err) : gunzip_zlib(raw, *text, err));
     if (!ok) { err += std::string(" in ") + path; return nullptr; }
   } else if (is_zstd(raw)) {
     if (!unzstd(raw, *text, err)) { err += std::string(" in ") + path; return nullptr; }
   } else text->swap(raw);
   if (text->capacity() > text->size() + text->size() / 4 + (1 << 20)) text->shrink_to_fit();      // a copy: only when it frees a lot
-  if (trace) fprintf(stderr, "[itsx] read %s: file %.0f ms, decode %.0f ms (%.1f MB -> %.1f MB)\n", path, std::chrono::duration<double, std::milli>(c1 - c0).count(),
+  if (trace) fprintf(stderr, "[itsx] read %s: file %.0f ms, decode%s %.0f ms (%.1f MB -> %.1f MB)\n", path, par ? " (block-parallel)" : "", std::chrono::duration<double, std::milli>(c1 - c0).count(),
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1).count(), raw.size() / 1e6, text->size() / 1e6);
   if (cacheable && budget > 0 && (double)text->size() <= budget) cache_insert(path, fsize, mtime, text, budget);
   return text;

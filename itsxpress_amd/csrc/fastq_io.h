@@ -31,6 +31,11 @@ void cache_put(const char *path, std::shared_ptr<const std::string> text);
 
 int io_threads();               // ITSX_IO_THREADS or min(hardware threads, 32)
 
+// pinflate.cpp: block-parallel inflate of a single-member gzip buffer (data[n .. n+16) must be readable).  true = `out`
+// holds the content and its length and CRC-32 matched the trailer; false = not applicable or any doubt: inflate serially.
+bool gunzip_parallel(const char *data, size_t n, std::string &out, int threads);
+int64_t parallel_inflates();    // files the block-parallel inflater has delivered since the library was loaded
+
 struct WriterImpl;
 class BlockWriter {
  public:

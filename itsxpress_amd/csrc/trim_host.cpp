@@ -232,5 +232,6 @@ int itsx_io_read(const char *path, char **text, int64_t *len)
 }
 void itsx_io_free(char *text) { free(text); }
 int itsx_io_codecs(void) { return itsx_io::codec_flags(); }
+int64_t itsx_io_parallel_inflates(void) { return itsx_io::parallel_inflates(); }
 
 }  // extern "C"

@@ -203,3 +203,87 @@ def test_temp_files_the_next_stage_reads_back_come_from_the_cache_and_stay_hones
     with open(ori, "w") as f:
         f.write(swapped)
     assert write_trimmed_fastq(ori, out, st, sp)[0] == 199 and open(out).read() == swapped
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# block-parallel inflate of single-member gzip files (csrc/pinflate.cpp)
+def _amplicon_fastq(n, seed):
+    """FASTQ text with the redundancy of an amplicon run (so that back-references reach far back, across chunk borders)"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    tmpl = acgt[rng.integers(0, 4, (max(1, n // 40), 300))]
+    reads = tmpl[rng.integers(0, len(tmpl), n)].copy()
+    err = rng.random(reads.shape) < 0.003
+    reads[err] = acgt[rng.integers(0, 4, int(err.sum()))]
+    q = (np.clip(38 - (np.arange(300) // 25)[None, :] - rng.integers(0, 6, reads.shape), 2, 40) + 33).astype(np.uint8)
+    return b"".join(b"@read%d 1:N:0:1\n" % i + reads[i].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n" for i in range(n))
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_parallel_inflate_equals_the_serial_inflaters(tmp_path, monkeypatch, level):
+    text = _amplicon_fastq(12000, 40 + level)                     # 7.5 MB of text
+    p = tmp_path / ("in%d.fastq.gz" % level)
+    p.write_bytes(gzip.compress(text, level))
+    L = _lib.lib()
+    monkeypatch.setenv("ITSX_TEXT_CACHE_GB", "0")
+    monkeypatch.setenv("ITSX_IO_THREADS", "5")
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "100")           # ~30 chunks, several rounds of 5
+    before = L.itsx_io_parallel_inflates()
+    assert read_text(str(p)) == text
+    assert L.itsx_io_parallel_inflates() == before + 1, "the block-parallel inflater did not deliver this file"
+    monkeypatch.setenv("ITSX_PARALLEL_INFLATE", "0")
+    assert read_text(str(p)) == text
+    assert L.itsx_io_parallel_inflates() == before + 1
+
+
+def test_parallel_inflate_chunk_sizes_and_thread_counts(tmp_path, monkeypatch):
+    text = _amplicon_fastq(9000, 50)
+    p = tmp_path / "in.fastq.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    monkeypatch.setenv("ITSX_TEXT_CACHE_GB", "0")
+    L = _lib.lib()
+    for threads, kb in ((2, 500), (3, 64), (8, 16), (7, 37), (4, 1000)):
+        monkeypatch.setenv("ITSX_IO_THREADS", str(threads))
+        monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", str(kb))
+        before = L.itsx_io_parallel_inflates()
+        assert read_text(str(p)) == text, (threads, kb)
+        # 1000-KB chunks: the file is smaller than four chunks and goes to the serial inflater
+        assert L.itsx_io_parallel_inflates() == before + (0 if kb == 1000 else 1), (threads, kb)
+
+
+def test_parallel_inflate_multi_member_binary_stored_and_damaged(tmp_path, monkeypatch):
+    """Files of several members (two big ones; hundreds of small ones as bgzip / this package's own writers make them; an
+    empty member in between), a binary head, and stored blocks are read correctly by the pool; bytes behind the last
+    member send the file to the serial inflater; damaged data is rejected loudly.  The parallel result is only ever
+    accepted when every member's CRC-32 and length match its trailer."""
+    monkeypatch.setenv("ITSX_TEXT_CACHE_GB", "0")
+    monkeypatch.setenv("ITSX_IO_THREADS", "4")
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "64")
+    L = _lib.lib()
+    text = _amplicon_fastq(6000, 60)
+    half = len(text) // 2
+    small = b"".join(gzip.compress(text[i:i + 50000], 6) for i in range(0, len(text), 50000))
+    cases = {
+        "two_members": (gzip.compress(text[:half], 6) + gzip.compress(b"", 6) + gzip.compress(text[half:], 1), text, 1),
+        "small_members": (small, text, 1),
+        "binary_head": (gzip.compress(np.random.default_rng(1).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes() + text, 6), None, 1),
+        "stored": (gzip.compress(text, 0), text, 1),
+        "zeros_behind": (gzip.compress(text, 6) + b"\0" * 64, text, 0),
+    }
+    for name, (blob, want, parallel) in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        before = L.itsx_io_parallel_inflates()
+        got = read_text(str(p))
+        assert got == (want if want is not None else gzip.decompress(blob)), name
+        assert L.itsx_io_parallel_inflates() == before + parallel, name
+    # a flipped bit in the middle of the stream, a wrong CRC in a trailer (last and inner member): loud errors, never silent text
+    good = gzip.compress(text, 6)
+    two = gzip.compress(text[:half], 6)
+    for name, blob in (("flipped", good[:len(good) // 2] + bytes([good[len(good) // 2] ^ 0x10]) + good[len(good) // 2 + 1:]),
+                       ("trailer", good[:-8] + bytes([good[-8] ^ 1]) + good[-7:]),
+                       ("inner_trailer", two[:-8] + bytes([two[-8] ^ 1]) + two[-7:] + gzip.compress(text[half:], 6))):
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        with pytest.raises(EngineError):
+            read_text(str(p))

@@ -10,8 +10,9 @@ domtbl.txt (users pass --keeptemp; ItsPosition/Dedup of the *reference* can read
 Array fast path: ItsPosition.from_engine / Dedup.from_engine / SeqSample.trim_coordinates
 skip the text round trip.
 
-Out of scope here (SURVEY.md section 8 "next"): read merging, orientation, trimming/writing
-FASTQ -- the consumers of the coordinates.
+Either side of the path is mirrored too: read orientation (orient_reads), paired-end
+merging (_merge_reads), the trimmed-FASTQ writers (Dedup.create_*), and many samples as one batch
+(itsxpress_amd/batch.py).
 """
 import logging
 import os

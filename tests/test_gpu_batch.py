@@ -183,3 +183,27 @@ def test_batch_files_equal_single_sample_runs(engine, fixture_reads, t_hmm_text,
     assert sum(len(x["dom_file"]) for x in solo) > 20000
     with pytest.raises(Exception):
         b.cluster(threads=1, cluster_id=0.99)
+
+
+def test_domtbl_written_by_the_pool_equals_one_thread(engine, t_hmm_text, tmp_path, monkeypatch):
+    """domtbl.txt of a few hundred thousand rows: blocks formatted by a pool of threads are the file one thread writes."""
+    blob, offs = synth.make_reads(t_hmm_text, 4000, seed=35)
+    seqs = synth.to_strings(blob, offs)
+    engine.load_profiles(text=_its2_subset(t_hmm_text))
+    engine.set_reads(seqs)
+    engine.derep()
+    engine.search()
+    engine.finalize()
+    files = {}
+    for threads in ("1", "7"):
+        monkeypatch.setenv("ITSX_IO_THREADS", threads)
+        p = tmp_path / ("domtbl_%s.txt" % threads)
+        engine.write_domtbl(str(p))
+        files[threads] = p.read_bytes()
+    assert files["1"] == files["7"]
+    rows = [ln for ln in files["1"].split(b"\n") if ln and not ln.startswith(b"#")]
+    assert len(rows) > 150000                                      # several blocks of 32768 rows
+    # file order = profile order, then targets in rep.fa order, then domains
+    names = engine.profile_names()
+    seen = [(names.index(r.split()[3].decode()), int(r.split()[0][1:]), int(r.split()[9])) for r in rows[::97]]
+    assert seen == sorted(seen)

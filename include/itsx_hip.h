@@ -214,6 +214,11 @@ int itsx_write_uc(const itsx_ctx *ctx, const char *path);
 int itsx_write_rep_fasta(const itsx_ctx *ctx, const char *path);
 int itsx_write_domtbl(const itsx_ctx *ctx, const char *path);
 
+/* labels of the loaded reads in input order (what Dedup.matchdict is keyed by, itsxpress/SeqSample.py:542-562; the paired
+ * writer looks R1/R2 records up by them): concatenated into names[cap], offsets[n_reads + 1]; names == NULL fills the
+ * offsets only (offsets[n_reads] = bytes needed). */
+int itsx_get_read_names(const itsx_ctx *ctx, char *names, int64_t cap, int64_t *offsets);
+
 int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out);
 
 /* ---- f1 ("next"): native FASTQ parse -> slice -> write.  Host-only and context-free.

@@ -60,7 +60,7 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq",
            "itsx_io_read", "itsx_io_free", "itsx_io_codecs",
            "itsx_load_reads_files", "itsx_set_samples", "itsx_num_samples", "itsx_select_sample",
-           "itsx_io_parallel_inflates"]
+           "itsx_io_parallel_inflates", "itsx_get_read_names"]
 
 
 def lib():
@@ -122,6 +122,7 @@ def lib():
         "itsx_io_free": (None, [vp]),
         "itsx_io_codecs": (i32, []),
         "itsx_io_parallel_inflates": (i64, []),
+        "itsx_get_read_names": (i32, [vp, vp, i64, vp]),
         "itsx_load_reads_files": (i32, [vp, vp, i32, vp]),
         "itsx_set_samples": (i32, [vp, vp, i32]),
         "itsx_num_samples": (i32, [vp]),

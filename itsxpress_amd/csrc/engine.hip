@@ -479,16 +479,26 @@ int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int
   return pack_and_upload(ctx);
 }
 
-// FASTA / FASTQ text appended to the context's host-side read set (names up to the first blank, as vsearch labels them)
-static int parse_fastx_append(itsx_ctx *ctx, const std::string &text)
+// ---- FASTA / FASTQ text -> records (labels up to the first blank, as vsearch labels them).  Large texts are cut at record
+// starts and parsed by the I/O pool; the pieces are joined in order, so the result is the serial parser's.
+struct FastxPart {
+  std::string seq, qual; std::vector<int64_t> off{0}; std::vector<std::string> ids;
+  int rc = ITSX_OK; std::string err;
+};
+
+static void parse_fastx_range(const char *s, const char *end, bool want_qual, bool upper, FastxPart &out)
 {
-  const char *s = text.data(), *end = s + text.size();
   auto next_line = [&](const char *&b, const char *&e) -> bool {
     if (s >= end) return false;
     b = s; const char *nl = (const char *)memchr(s, '\n', (size_t)(end - s));
     e = nl ? nl : end; s = nl ? nl + 1 : end;
     if (e > b && e[-1] == '\r') e--;
     return true;
+  };
+  auto put_seq = [&](const char *b, const char *e) {
+    const size_t o = out.seq.size();
+    out.seq.append(b, e);
+    if (upper) for (size_t i = o; i < out.seq.size(); i++) out.seq[i] = (char)toupper((unsigned char)out.seq[i]);
   };
   const char *b, *e;
   bool pending = false;                  // a header line already read into b,e
@@ -497,22 +507,99 @@ static int parse_fastx_append(itsx_ctx *ctx, const std::string &text)
     if (b == e) continue;
     if (*b == '@') {                     // FASTQ record: 4 lines
       const char *ne = b + 1; while (ne < e && *ne != ' ' && *ne != '\t') ne++;
-      ctx->h_names.emplace_back(b + 1, ne);
+      out.ids.emplace_back(b + 1, ne);
       const char *sb, *se, *pb, *pe, *qb, *qe;
-      if (!next_line(sb, se) || !next_line(pb, pe) || !next_line(qb, qe) || pb == pe || *pb != '+' || (qe - qb) != (se - sb))
-        SET_ERR(ctx, ITSX_E_FORMAT, "malformed FASTQ record near read " + std::to_string(ctx->h_names.size()));
-      ctx->h_bases.append(sb, se);
-      ctx->h_off.push_back((int64_t)ctx->h_bases.size());
+      if (!next_line(sb, se) || !next_line(pb, pe) || !next_line(qb, qe) || pb == pe || *pb != '+' || (qe - qb) != (se - sb)) {
+        out.rc = ITSX_E_FORMAT; out.err = "malformed FASTQ record"; return;
+      }
+      put_seq(sb, se);
+      if (want_qual) out.qual.append(qb, qe);
+      out.off.push_back((int64_t)out.seq.size());
     } else if (*b == '>') {              // FASTA record: header + sequence lines
       const char *ne = b + 1; while (ne < e && *ne != ' ' && *ne != '\t') ne++;
-      ctx->h_names.emplace_back(b + 1, ne);
+      out.ids.emplace_back(b + 1, ne);
       while (next_line(b, e)) {
         if (b < e && *b == '>') { pending = true; break; }
-        ctx->h_bases.append(b, e);
+        put_seq(b, e);
       }
-      ctx->h_off.push_back((int64_t)ctx->h_bases.size());
-    } else SET_ERR(ctx, ITSX_E_FORMAT, "input is neither FASTA nor FASTQ");
+      if (want_qual) out.qual.resize(out.seq.size(), 'I');
+      out.off.push_back((int64_t)out.seq.size());
+    } else { out.rc = ITSX_E_FORMAT; out.err = "input is neither FASTA nor FASTQ"; return; }
   }
+}
+
+// first record start at or after `from`: FASTQ -- a line that starts with '@' whose second line below starts with '+' (a
+// quality line may start with '@', but then that line is a sequence line, which never starts with '+'); FASTA -- a '>' line
+static size_t next_record_start(const char *t, size_t n, size_t from, bool fastq)
+{
+  size_t q = from;
+  if (q > 0) { const char *nl = (const char *)memchr(t + q - 1, '\n', n - (q - 1)); if (!nl) return n; q = (size_t)(nl - t) + 1; }
+  while (q < n) {
+    if (!fastq) { if (t[q] == '>') return q; }
+    else if (t[q] == '@') {
+      const char *l1 = (const char *)memchr(t + q, '\n', n - q);
+      const char *l2 = l1 ? (const char *)memchr(l1 + 1, '\n', n - (size_t)(l1 + 1 - t)) : nullptr;
+      if (l2 && (size_t)(l2 + 1 - t) < n && l2[1] == '+') return q;
+    }
+    const char *nl = (const char *)memchr(t + q, '\n', n - q);
+    if (!nl) return n;
+    q = (size_t)(nl - t) + 1;
+  }
+  return n;
+}
+
+static int parse_fastx(const std::string &text, bool want_qual, bool upper, FastxPart &out, std::string &err)
+{
+  const size_t n = text.size();
+  int T = itsx_io::io_threads();
+  if (const char *e = getenv("ITSX_PARSE_MIN_MB")) { if (n < (size_t)atol(e) << 20) T = 1; }
+  else if (n < ((size_t)16 << 20)) T = 1;
+  size_t first = 0;
+  while (first < n && (text[first] == '\n' || text[first] == '\r')) first++;
+  if (first < n && text[first] != '@' && text[first] != '>') T = 1;          // the serial parser reports it
+  std::vector<size_t> cut(1, 0);
+  if (T > 1) {
+    const bool fastq = text[first] == '@';
+    for (int k = 1; k < T; k++) { const size_t c = next_record_start(text.data(), n, n / (size_t)T * (size_t)k, fastq); if (c > cut.back() && c < n) cut.push_back(c); }
+  }
+  cut.push_back(n);
+  const size_t np = cut.size() - 1;
+  if (np == 1) {
+    parse_fastx_range(text.data(), text.data() + n, want_qual, upper, out);
+    if (out.rc != ITSX_OK) err = out.err + (out.rc == ITSX_E_FORMAT && out.err[0] == 'm' ? " near read " + std::to_string(out.ids.size()) : "");
+    return out.rc;
+  }
+  std::vector<FastxPart> parts(np);
+  on_threads((int)np, [&](int k) { parse_fastx_range(text.data() + cut[(size_t)k], text.data() + cut[(size_t)k + 1], want_qual, upper, parts[(size_t)k]); });
+  size_t nrec = 0, nseq = 0;
+  for (size_t k = 0; k < np; k++) {
+    if (parts[k].rc != ITSX_OK) { err = parts[k].err + " near read " + std::to_string(nrec + parts[k].ids.size()); return parts[k].rc; }
+    nrec += parts[k].ids.size(); nseq += parts[k].seq.size();
+  }
+  const size_t rec0 = out.ids.size(), seq0 = out.seq.size();
+  out.ids.resize(rec0 + nrec); out.off.resize(rec0 + nrec + 1); out.seq.resize(seq0 + nseq);
+  if (want_qual) out.qual.resize(seq0 + nseq);
+  std::vector<size_t> rbase(np), sbase(np);
+  { size_t r = rec0, q = seq0; for (size_t k = 0; k < np; k++) { rbase[k] = r; sbase[k] = q; r += parts[k].ids.size(); q += parts[k].seq.size(); } }
+  on_threads((int)np, [&](int k) {
+    FastxPart &p = parts[(size_t)k];
+    memcpy(&out.seq[sbase[(size_t)k]], p.seq.data(), p.seq.size());
+    if (want_qual) memcpy(&out.qual[sbase[(size_t)k]], p.qual.data(), p.qual.size());
+    for (size_t i = 0; i < p.ids.size(); i++) { out.ids[rbase[(size_t)k] + i] = std::move(p.ids[i]); out.off[rbase[(size_t)k] + i + 1] = (int64_t)sbase[(size_t)k] + p.off[i + 1]; }
+  });
+  return ITSX_OK;
+}
+
+// appended to the context's host-side read set
+static int parse_fastx_append(itsx_ctx *ctx, const std::string &text)
+{
+  FastxPart part;
+  part.seq.swap(ctx->h_bases); part.off.swap(ctx->h_off); part.ids.swap(ctx->h_names);
+  if (part.off.empty()) part.off.assign(1, 0);
+  std::string err;
+  const int rc = parse_fastx(text, false, false, part, err);
+  ctx->h_bases.swap(part.seq); ctx->h_off.swap(part.off); ctx->h_names.swap(part.ids);
+  if (rc != ITSX_OK) SET_ERR(ctx, rc, err);
   return ITSX_OK;
 }
 
@@ -1520,34 +1607,14 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
                            int allow_stagger, int64_t *n_pairs, int64_t *n_merged)
 {
   CTXCHK(ctx && r1_path && r2_path && out_path);
-  struct Side { std::string seq, qual; std::vector<int64_t> off{0}; std::vector<std::string> ids; };
+  typedef FastxPart Side;
   auto parse = [](const char *path, Side &sd, std::string &perr) -> int {      // no shared state: the two files are read side by side
     const auto tp = slurp(path, true, perr);
     if (!tp) return ITSX_E_IO;
-    const std::string &text = *tp;
-    const char *s = text.data(), *end = s + text.size();
-    auto line = [&](const char *&b, const char *&e) -> bool {
-      if (s >= end) return false;
-      b = s; const char *nl = (const char *)memchr(s, '\n', (size_t)(end - s));
-      e = nl ? nl : end; s = nl ? nl + 1 : end;
-      if (e > b && e[-1] == '\r') e--;
-      return true;
-    };
-    const char *b, *e;
-    while (line(b, e)) {
-      if (b == e) continue;
-      const char *sb, *se, *pb, *pe, *qb, *qe;
-      if (*b != '@' || !line(sb, se) || !line(pb, pe) || !line(qb, qe) || pb == pe || *pb != '+' || (qe - qb) != (se - sb)) {
-        perr = std::string("malformed FASTQ record ") + std::to_string(sd.ids.size() + 1) + " in " + path; return ITSX_E_FORMAT;
-      }
-      const char *ne = b + 1; while (ne < e && *ne != ' ' && *ne != '\t') ne++;
-      sd.ids.emplace_back(b + 1, ne);
-      const size_t o = sd.seq.size();
-      sd.seq.append(sb, se); sd.qual.append(qb, qe);
-      for (size_t i = o; i < sd.seq.size(); i++) sd.seq[i] = (char)toupper((unsigned char)sd.seq[i]);
-      sd.off.push_back((int64_t)sd.seq.size());
-    }
-    return ITSX_OK;
+    if (!tp->empty() && (*tp)[0] != '@') { perr = std::string("malformed FASTQ record 1 in ") + path; return ITSX_E_FORMAT; }
+    const int prc = parse_fastx(*tp, true, true, sd, perr);
+    if (prc != ITSX_OK) perr += std::string(" in ") + path;
+    return prc;
   };
   Side f, r;
   std::string ferr, rerr2;
@@ -1826,6 +1893,22 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path)
   }
   if (fclose(f) != 0) io_ok = false;
   if (!io_ok) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
+  return ITSX_OK;
+}
+
+// labels of the loaded reads (identifier up to the first blank), concatenated; offsets[n+1].  names == NULL: offsets only
+// (offsets[n] = bytes needed).  Reads handed over without names are labelled r%09d, as the writers label them.
+int itsx_get_read_names(const itsx_ctx *ctx, char *names, int64_t cap, int64_t *offsets)
+{
+  CTXCHK(ctx && offsets);
+  int64_t o = 0;
+  for (int64_t r = 0; r < ctx->N; r++) {
+    offsets[r] = o;
+    const std::string nm = read_name(ctx, r);
+    if (names) { if (o + (int64_t)nm.size() > cap) SET_ERR(ctx, ITSX_E_ARG, "name buffer too small"); memcpy(names + o, nm.data(), nm.size()); }
+    o += (int64_t)nm.size();
+  }
+  offsets[ctx->N] = o;
   return ITSX_OK;
 }
 

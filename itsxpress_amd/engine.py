@@ -239,6 +239,21 @@ class Engine:
         assert a.shape[0] == self.n_unique
         self._chk(self.L.itsx_set_active_uniques(self.h, a.ctypes.data if a.size else None))
 
+    def read_names_raw(self):
+        """labels of the loaded reads, in input order: (bytes blob, int64 offsets[n_reads + 1]) -- the form the paired
+        writer takes without a detour through a million Python strings"""
+        offs = np.zeros(self.n_reads + 1, np.int64)
+        self._chk(self.L.itsx_get_read_names(self.h, None, 0, offs.ctypes.data))
+        buf = C.create_string_buffer(int(offs[-1]) + 1)
+        self._chk(self.L.itsx_get_read_names(self.h, buf, int(offs[-1]), offs.ctypes.data))
+        return buf.raw[:int(offs[-1])], offs
+
+    def read_names(self):
+        """labels of the loaded reads, in input order (list[str])"""
+        blob, offs = self.read_names_raw()
+        blob = blob.decode()
+        return [blob[offs[i]:offs[i + 1]] for i in range(self.n_reads)]
+
     def get_uniques(self):
         seed = np.zeros(self.n_unique, np.int64)
         ab = np.zeros(self.n_unique, np.int64)

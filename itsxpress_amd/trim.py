@@ -55,7 +55,8 @@ def write_trimmed_fastq(seq_file, outfile, start, stop, gzipped=False, trim_ccs=
 
 def write_trimmed_paired(fastq, fastq2, outfile1, outfile2, names, start, stop, tlen, gzipped=False, trim_ccs=False,
                          zstd_file=False):
-    """names[i] = id of merged read i; start/stop/tlen per merged read.  Returns pairs written."""
+    """names[i] = id of merged read i (a list of str, or Engine.read_names_raw()'s (blob, offsets) pair); start/stop/tlen
+    per merged read.  Returns pairs written."""
     for p in (fastq, fastq2):
         if not os.path.exists(p):
             raise FileNotFoundError(p)
@@ -65,13 +66,18 @@ def write_trimmed_paired(fastq, fastq2, outfile1, outfile2, names, start, stop, 
                          "Mixed input is not accepted.")
     L = _lib.lib()
     start, stop, tlen = _i32(start), _i32(stop), _i32(tlen)
-    no = np.zeros(len(names) + 1, np.int64)
-    np.cumsum([len(s) for s in names], out=no[1:])
-    blob = "".join(names).encode()
+    if isinstance(names, tuple):
+        blob, no = names[0], np.ascontiguousarray(names[1], np.int64)
+        n_names = len(no) - 1
+    else:
+        n_names = len(names)
+        no = np.zeros(n_names + 1, np.int64)
+        np.cumsum([len(s) for s in names], out=no[1:])
+        blob = "".join(names).encode()
     n = C.c_int64(0)
     rc = L.itsx_write_trimmed_paired(os.fsencode(fastq), os.fsencode(fastq2), os.fsencode(outfile1), os.fsencode(outfile2),
                                      _compression(gzipped, zstd_file), int(trim_ccs), C.cast(C.c_char_p(blob), C.c_void_p), no.ctypes.data,
-                                     len(names), start.ctypes.data, stop.ctypes.data, tlen.ctypes.data, C.byref(n))
+                                     n_names, start.ctypes.data, stop.ctypes.data, tlen.ctypes.data, C.byref(n))
     if rc != 0:
         raise EngineError(rc, L.itsx_trim_last_error().decode())
     return n.value

@@ -107,8 +107,7 @@ def main():
         t["search"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         start, stop, tl, ind = s.trim_coordinates("ITS2")
-        text = read_text(s.seq_file)
-        names = [ln[1:].split()[0].decode() for ln in text.split(b"\n")[0::4] if ln]
+        names = eng.read_names_raw()
         t["coords+names"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         o1, o2 = os.path.join(tmp, "o1.fastq.gz"), os.path.join(tmp, "o2.fastq.gz")
@@ -117,7 +116,7 @@ def main():
         total = sum(t.values())
         kept = int(((start >= 0) & (stop >= 0) & (start < stop)).sum())
         assert nw == kept, (nw, kept)
-        print(json.dumps({"pairs": n, "merged": len(names), "unique": int(nu), "pairs_written": int(nw), "array_path": bool(args.array_path),
+        print(json.dumps({"pairs": n, "merged": len(names[1]) - 1, "unique": int(nu), "pairs_written": int(nw), "array_path": bool(args.array_path),
                           **{"s_" + k: round(v, 3) for k, v in t.items()}, "s_total": round(total, 3),
                           "pairs_per_s_file_to_file": round(n / total)}))
     finally:

@@ -115,5 +115,15 @@ def test_merge_files_and_mirror(engine, gold, tmp_path, mini_hmm_text):
     s.deduplicate(threads=1)
     s._search(hmmfile=str(hmm), threads=1)
     assert os.path.getsize(s.uc_file) > 0 and os.path.exists(s.dom_file)
+    # the engine's read labels are the merged records' identifiers; the paired writer takes them as (blob, offsets) as well as a list
+    from itsxpress_amd.trim import write_trimmed_paired
+    assert s.engine.read_names() == heads
+    start, stop, tlen, _ = s.trim_coordinates("ITS2")
+    outs = []
+    for k, names in enumerate((heads, s.engine.read_names_raw())):
+        o1, o2 = str(tmp_path / ("o1_%d.fq" % k)), str(tmp_path / ("o2_%d.fq" % k))
+        n = write_trimmed_paired(r1, r2, o1, o2, names, start, stop, tlen)
+        outs.append((n, open(o1, "rb").read(), open(o2, "rb").read()))
+    assert outs[0] == outs[1] and outs[0][0] == int(((start >= 0) & (stop >= 0) & (start < stop)).sum())
     with pytest.raises(FileNotFoundError):
         SeqSamplePairedNotInterleaved(fastq=r1, tempdir=str(tmp_path), fastq2=str(tmp_path / "nope.fq"))._merge_reads(threads=1)

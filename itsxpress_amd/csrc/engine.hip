@@ -1187,7 +1187,17 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   double slab_gb = ctx->slab_gb;
   if (const char *e = getenv("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));     // read at every call
   const int64_t row_bytes = 12 * 64 * 4;                   // XF fields of k_float.hip's parser slab
-  const int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
+  int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
+  // A job that fits a few batches does not need the whole budget: eight batches already keep the launch tails small, and
+  // device memory is not free to get (20-40 ms per GB in a fresh process: a 64-GB slab costs more than the search of a
+  // 100 k-read sample).  Memory the context holds already is used in full.
+  static const bool adapt = !(getenv("ITSX_SLAB_ADAPT") && atoi(getenv("ITSX_SLAB_ADAPT")) == 0);
+  if (adapt && !getenv("ITSX_SLAB_GB")) {
+    int64_t total_rows = 0;
+    for (int w = 0; w < NW; w++) total_rows += rows[(size_t)w];
+    const int64_t floor_rows = ((int64_t)4 << 30) / row_bytes, have_rows = (int64_t)(ctx->w_slab.cap / (12 * 64));
+    budget_rows = std::min(budget_rows, std::max(std::max(total_rows / 8 + 1, floor_rows), have_rows));
+  }
   DBuf<RegionRec> &d_raw = ctx->w_raw;
   HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));
   {
@@ -1299,9 +1309,14 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     HIPCHK(hipMemcpyAsync(rrows.data(), d_rrows.p, (size_t)NRW * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const int64_t erow_bytes = 104 * 64 * 4;
-    const int64_t ebudget = (int64_t)(slab_gb * (1 << 30)) / erow_bytes;
+    int64_t ebudget = (int64_t)(slab_gb * (1 << 30)) / erow_bytes;
     LazyTimers elazy(st);
     DBuf<float> &d_eslab = ctx->w_eslab; int64_t ealloc = (int64_t)(d_eslab.cap / (104 * 64));
+    if (adapt && !getenv("ITSX_SLAB_GB")) {                  // as for the parser slab: four batches are enough here
+      int64_t total_rows = 0;
+      for (int w = 0; w < NRW; w++) total_rows += rrows[(size_t)w];
+      ebudget = std::min(ebudget, std::max(std::max(total_rows / 4 + 1, ((int64_t)2 << 30) / erow_bytes), ealloc));
+    }
     int w0 = 0;
     while (w0 < NRW) {
       int w1 = w0; int64_t r = 0;

@@ -116,7 +116,8 @@ template <class T> struct DBuf {
 
 struct itsx_ctx {
   int device = 0;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr;   // st2: the bias filter of the next batch beside the decoder of this one
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
   mutable std::string err;
   void set_error(const std::string &m) const { err = m; }
   itsx_stats stats{};
@@ -284,6 +285,7 @@ void itsx_destroy(itsx_ctx *ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->st);
+  if (ctx->st2) { (void)hipStreamSynchronize(ctx->st2); (void)hipStreamDestroy(ctx->st2); (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b); }
   (void)hipStreamDestroy(ctx->st);
   delete ctx;
 }
@@ -1202,32 +1204,65 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));
   {
     StageTimer tm(st);
-    {   // bias-composition filter for every survivor (its own, full-occupancy kernel)
-      FloatArgs a{};
-      a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
-      a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.F1 = F1; a.F3 = F3;
-      StageTimer k(st); launch_bias(a, NP, st); S.ms_bias_kernel += k.stop();
-    }
-    LazyTimers lazy(st);
-    DBuf<float> &d_slab = ctx->w_slab;
-    int64_t slab_rows_alloc = (int64_t)(d_slab.cap / (12 * 64));
-    int w0 = 0;
-    while (w0 < NW) {
+    // ---- batches of waves that fit the slab
+    struct Batch { int w0, w1; int64_t r; };
+    std::vector<Batch> batches;
+    int64_t rmax = 0;
+    for (int w0 = 0; w0 < NW;) {
       int w1 = w0; int64_t r = 0;
       while (w1 < NW && wgeneric[w1] == wgeneric[w0] && (w1 == w0 || r + rows[w1] <= budget_rows)) { waves[w1].slab = r; waves[w1].rows = rows[w1]; r += rows[w1]; w1++; }
-      if (r > slab_rows_alloc) { HIPCHK(d_slab.alloc((size_t)r * 12 * 64)); slab_rows_alloc = r; }
-      HIPCHK(hipMemcpyAsync(d_waves.p + w0, waves.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
-      FloatArgs a{};
-      a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
-      a.flogsum = ctx->d_flogsum.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p; a.slab_plane = r * 6 * 64;
-      a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
-      { const size_t t = lazy.begin(&S.ms_fwd_kernel); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
-      { const size_t t = lazy.begin(&S.ms_bwd_kernel); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
-      { const size_t t = lazy.begin(&S.ms_decode_kernel); launch_decode(a, w1 - w0, w0, st); lazy.end(t); }
-      for (int w = w0; w < w1; w++) S.fwd_rows += (int64_t)(rows[w] - 1) * waves[w].count;
-      S.n_batches++;
+      batches.push_back(Batch{w0, w1, r});
+      rmax = std::max(rmax, r);
       w0 = w1;
     }
+    DBuf<float> &d_slab = ctx->w_slab;
+    if ((size_t)rmax * 12 * 64 > d_slab.cap) HIPCHK(d_slab.alloc((size_t)rmax * 12 * 64));
+    HIPCHK(hipMemcpyAsync(d_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
+    FloatArgs a{};
+    a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+    a.flogsum = ctx->d_flogsum.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
+    a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
+    // The bias-composition filter of a batch (its own full-occupancy kernel, VALU-bound, ~48 registers) runs on a second
+    // stream beside the decoder of the batch before it (latency-bound, ~50 registers): the two share the SIMDs, which
+    // the 256-register DP kernels never do with anything.
+    static const bool overlap = !(getenv("ITSX_BIAS_OVERLAP") && atoi(getenv("ITSX_BIAS_OVERLAP")) == 0);
+    if (overlap && !ctx->st2) {
+      HIPCHK(hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+    }
+    LazyTimers lazy(st), lazy2(overlap ? ctx->st2 : st);
+    auto bias_batch = [&](const Batch &bt, hipStream_t s, LazyTimers &lz) {
+      // contiguous runs of pairs (the waves of one pass skip the profiles of the other pass)
+      int w = bt.w0;
+      while (w < bt.w1) {
+        int e = w + 1;
+        while (e < bt.w1 && waves[(size_t)e].first == waves[(size_t)e - 1].first + 64) e++;
+        FloatArgs ab = a;
+        ab.pairs = ctx->d_pairs.p + waves[(size_t)w].first; ab.pout = ctx->d_pout.p + waves[(size_t)w].first;
+        const size_t t = lz.begin(&S.ms_bias_kernel); launch_bias(ab, (int64_t)(e - w) * 64, s); lz.end(t);
+        w = e;
+      }
+    };
+    if (!batches.empty()) bias_batch(batches[0], st, lazy);
+    for (size_t bi = 0; bi < batches.size(); bi++) {
+      const Batch &bt = batches[bi];
+      const int w0 = bt.w0, w1 = bt.w1;
+      a.slab_plane = bt.r * 6 * 64;
+      const bool more = bi + 1 < batches.size();
+      { const size_t t = lazy.begin(&S.ms_fwd_kernel); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
+      { const size_t t = lazy.begin(&S.ms_bwd_kernel); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
+      if (more && overlap) {
+        HIPCHK(hipEventRecord(ctx->ev_a, st)); HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->ev_a, 0));
+        bias_batch(batches[bi + 1], ctx->st2, lazy2);
+        HIPCHK(hipEventRecord(ctx->ev_b, ctx->st2));
+      }
+      { const size_t t = lazy.begin(&S.ms_decode_kernel); launch_decode(a, w1 - w0, w0, st); lazy.end(t); }
+      if (more && overlap) HIPCHK(hipStreamWaitEvent(st, ctx->ev_b, 0));
+      else if (more) bias_batch(batches[bi + 1], st, lazy);
+      for (int w = w0; w < w1; w++) S.fwd_rows += (int64_t)(rows[w] - 1) * waves[w].count;
+      S.n_batches++;
+    }
+    lazy2.collect();
     lazy.collect();
     S.ms_filters += tm.stop();
   }

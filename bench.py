@@ -197,6 +197,7 @@ def main():
                        "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed, "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
             "kernels": kernel_table,
+            "concurrency": "k_bias of batch b+1 runs on a second stream beside k_decode of batch b: ms_bias_kernel is its stretched wall time, not extra step time",
             "cluster": None if args.cluster_id >= 1.0 else {"windows": int(st["cl_windows"]), "cut_windows": int(st["cl_cuts"]),
                                                             "alignments": int(st["cl_alignments"]), "centroids": int(st["n_unique"])},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

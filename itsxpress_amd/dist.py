@@ -18,6 +18,20 @@ def shard_bounds(n_items, world_size, rank):
     return lo, hi
 
 
+def assign_samples(reads_per_sample, world_size):
+    """Whole samples to ranks for a sample batch (itsxpress_amd/batch.py): samples are independent runs of the path
+    (dereplication and domZ are per sample), so a multi-GPU batch needs no exchange at all -- every rank batches its own
+    samples.  Longest-processing-time assignment on the read counts; returns one ascending list of sample indices per rank."""
+    order = sorted(range(len(reads_per_sample)), key=lambda i: (-int(reads_per_sample[i]), i))
+    load = [0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += int(reads_per_sample[i])
+    return [sorted(x) for x in out]
+
+
 def allreduce_domz(domz, device=None):
     """sum the per-profile counts over all ranks; returns int64 numpy array."""
     import torch

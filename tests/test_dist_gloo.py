@@ -127,3 +127,15 @@ def test_two_rank_global_derep():
     assert res[1][1] == [2, 0, 3, 11] and res[1][2] == [False, True, True, False]
     # coordinates of the inactive uniques come from the rank that scored the seed
     assert res[1][3] == [107, 105, 1090, 103] and res[1][4] == [108, 106, 1091, 104]
+
+
+def test_assign_samples_balances_whole_samples():
+    from itsxpress_amd.dist import assign_samples
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(100, 200000, 96)
+    for ws in (1, 2, 8):
+        parts = assign_samples(sizes, ws)
+        assert sorted(i for p in parts for i in p) == list(range(96))          # every sample exactly once
+        loads = [int(sizes[p].sum()) for p in parts]
+        assert max(loads) - min(loads) <= int(sizes.max())                       # LPT: within one sample of even
+    assert assign_samples([5, 1], 4) == [[0], [1], [], []]

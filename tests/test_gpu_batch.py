@@ -183,3 +183,28 @@ def test_batch_files_equal_single_sample_runs(engine, fixture_reads, t_hmm_text,
     assert sum(len(x["dom_file"]) for x in solo) > 20000
     with pytest.raises(Exception):
         b.cluster(threads=1, cluster_id=0.99)
+
+
+def test_load_reads_files_mixed_formats_and_names(engine, fixture_reads, tmp_path):
+    """itsx_load_reads_files: plain FASTQ, gzip FASTQ, FASTA and an empty file as four samples; labels and sample borders"""
+    import gzip
+    names, seqs = fixture_reads
+    a = tmp_path / "a.fq"
+    a.write_text("".join("@%s x\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, s in zip(names[:30], seqs[:30])))
+    b = tmp_path / "b.fq.gz"
+    b.write_bytes(gzip.compress("".join("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)) for n, s in zip(names[30:80], seqs[30:80])).encode()))
+    c = tmp_path / "c.fa"
+    c.write_text("".join(">%s\n%s\n" % (n, s) for n, s in zip(names[:20], seqs[:20])))
+    d = tmp_path / "empty.fq"
+    d.write_text("")
+    counts = engine.load_reads_files([str(a), str(b), str(c), str(d)])
+    assert list(counts) == [30, 50, 20, 0] and engine.n_samples == 4 and engine.n_reads == 100
+    assert engine.read_names() == names[:30] + names[30:80] + names[:20]
+    engine.derep()
+    rep_of, _, _ = engine.get_derep()
+    # sample c repeats sample a's first 20 reads: they group inside c, never with a
+    assert np.all(rep_of[80:] >= 80) and np.all(rep_of[:30] < 30)
+    engine.set_reads(["ACGT" * 10, "TTTT" * 10])
+    assert engine.read_names() == ["r000000000", "r000000001"]
+    with pytest.raises(FileNotFoundError):
+        engine.load_reads_files([str(a), str(tmp_path / "nope.fq")])

@@ -628,6 +628,45 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
     // The cumulative sums are NOT written back (8 B per row saved): a region's inner scan needs btot/etot of its own rows
     // only, and those are rebuilt from a checkpoint taken where the region starts -- same operations, same order, same bits.
     float ck_btot = 0.f, ck_etot = 0.f, ck_sp = scaleproduct, ck_t1 = prv.t1, ck_rs = prv.rs;
+    struct Pend { int ri, j, slot; float b, e, sp, t1, rs, btot; };
+    Pend p0, p1; int npend = 0;
+    p0.ri = p0.j = p0.slot = 0; p0.b = p0.e = p0.sp = p0.t1 = p0.rs = p0.btot = 0.f; p1 = p0;
+    // max over z in [ri, j] of min(etot[z] - etot[ri-1], btot[j] - btot[z-1]) >= rt3 ?  The sums are rebuilt from the
+    // checkpoint taken where the region starts, with the same operations in the same order as the row loop's
+    auto close_region = [&](const Pend &p) {
+      float mx = -1.0f;
+      float b = p.b, e = p.e, sp = p.sp, t1p = p.t1, rsp = p.rs;
+      const float et0 = p.e;
+      // four rows are requested before the first is used: the sums are a serial chain, the loads are not
+      for (int z0 = p.ri; z0 <= p.j; z0 += 4) {
+        float t2v[4], t1v[4], rsv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int z = z0 + k <= p.j ? z0 + k : p.j;
+          t2v[k] = *SLAB(a, r0, z, 6, lane); t1v[k] = *SLAB(a, r0, z, 9, lane);
+          rsv[k] = own ? *SLAB(a, r0, z, 11, lane) : 1.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (z0 + k > p.j) break;
+          const float bprev = b;                         // btot[z-1]
+          b = b + (t1p * sp);
+          if (own) sp *= rsp;
+          e = e + (t2v[k] * sp);                         // etot[z]
+          t1p = t1v[k]; rsp = rsv[k];
+          const float ea = e - et0;
+          const float bb = p.btot - bprev;
+          const float m2 = ea < bb ? ea : bb;
+          mx = m2 > mx ? m2 : mx;
+        }
+      }
+      const int multi = (mx >= rt3);
+      nmulti += multi;
+      if (p.slot >= 0) {
+        RegionRec rr; rr.pair = (int32_t)pi; rr.ienv = p.ri; rr.jenv = p.j; rr.multi = multi;
+        a.regions[pi * MAXDOM + p.slot] = rr;
+      }
+    };
     for (int j = 1; j <= L; j++) {
       const DRow cur = nxt;
       if (j < L) nxt = load_row(j + 1);
@@ -650,32 +689,24 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
         if (mocc >= rt1) triggered = true;
       } else if (mocc - (etot - etot_prev) < rt2) {
         nreg++;
-        float mx = -1.0f;
-        float b = ck_btot, e = ck_etot, sp = ck_sp, t1p = ck_t1, rsp = ck_rs;
-        const float et0 = ck_etot;
-        for (int z = ri; z <= j; z++) {
-          const float t2z = *SLAB(a, r0, z, 6, lane), t1z = *SLAB(a, r0, z, 9, lane);
-          const float rsz = own ? *SLAB(a, r0, z, 11, lane) : 1.0f;
-          const float bprev = b;                         // btot[z-1]
-          b = b + (t1p * sp);
-          if (own) sp *= rsp;
-          e = e + (t2z * sp);                            // etot[z]
-          t1p = t1z; rsp = rsz;
-          const float ea = e - et0;
-          const float bb = btot - bprev;
-          const float m2 = ea < bb ? ea : bb;
-          mx = m2 > mx ? m2 : mx;
+        // The multidomain test of a region re-reads the region's rows.  Done here it would run for ONE lane while the
+        // other 63 wait (lanes close their regions at different rows) and it is a chain of dependent single-lane loads;
+        // so the first two regions of a lane are only recorded, and tested after the row loop by all lanes together.
+        const int slot = nkept < MAXDOM ? nkept : -1;
+        if (slot >= 0) nkept++; else flags |= 2;
+        if (npend < 2) {
+          Pend &p = npend == 0 ? p0 : p1;
+          p.ri = ri; p.j = j; p.slot = slot; p.b = ck_btot; p.e = ck_etot; p.sp = ck_sp; p.t1 = ck_t1; p.rs = ck_rs; p.btot = btot;
+          npend++;
+        } else {
+          Pend p; p.ri = ri; p.j = j; p.slot = slot; p.b = ck_btot; p.e = ck_etot; p.sp = ck_sp; p.t1 = ck_t1; p.rs = ck_rs; p.btot = btot;
+          close_region(p);
         }
-        const int multi = (mx >= rt3);
-        nmulti += multi;
-        if (nkept < MAXDOM) {
-          RegionRec rr; rr.pair = (int32_t)pi; rr.ienv = ri; rr.jenv = j; rr.multi = multi;
-          a.regions[pi * MAXDOM + nkept] = rr;
-          nkept++;
-        } else flags |= 2;
         ri = -1; triggered = false;
       }
     }
+    if (npend > 0) close_region(p0);
+    if (npend > 1) close_region(p1);
     if (scaleproduct == __builtin_inff()) { nreg = 0; nkept = 0; }
   }
   if (active && alive) { po.nregions = nreg; po.ndom = nkept; po.flags = flags | ((nmulti > 255 ? 255 : nmulti) << 8); a.pout[pi] = po; }   // bits 8-15: multidomain regions (statistics)

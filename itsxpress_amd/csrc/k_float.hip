@@ -72,6 +72,51 @@ struct Seq {
     return x;
   }
 };
+// Residues of one read taken in order (ascending for Forward, descending for Backward), one per DP row.  Seq::code() costs a
+// global load per row and per exception, each followed by a wait that -- vmcnt being in order -- also drains the row's six
+// slab stores.  The stream keeps the current 16-base word and the next one in registers (the next word is requested a whole
+// word ahead), and knows the position of the next exception, so a row costs a shift, a mask and one compare.
+struct SeqStream {
+  const uint32_t *w; const uint32_t *exc;
+  uint32_t cur, nxt; int cur_i, nw, dir;
+  int e, nexc, epos;                      // next exception in walking order: index, count, its position (-1: none left)
+  DEV void open(const Seq &s, int first_pos, int direction)
+  {
+    w = s.w; exc = s.exc; nexc = s.nexc; dir = direction; nw = (s.L + 15) >> 4; if (nw < 1) nw = 1;
+    cur_i = first_pos >> 4; if (cur_i >= nw) cur_i = nw - 1;
+    cur = w[cur_i];
+    const int ni = cur_i + dir;
+    nxt = (ni >= 0 && ni < nw) ? w[ni] : 0u;
+    if (dir > 0) { e = 0; while (e < nexc && (int)(exc[e] >> 4) < first_pos) e++; }
+    else { e = nexc - 1; while (e >= 0 && (int)(exc[e] >> 4) > first_pos) e--; }
+    epos = (e >= 0 && e < nexc) ? (int)(exc[e] >> 4) : -1;
+    // nothing may still be in flight when the row loop is entered: a load pending at the loop's entry makes the compiler wait
+    // for ALL memory operations (the previous row's stores included) at the first use in every iteration
+    asm volatile("" : "+v"(cur), "+v"(nxt), "+v"(epos));
+  }
+  // positions must be taken in walking order, one step at a time, starting at first_pos
+  DEV int get(int pos)
+  {
+    const int wi = pos >> 4;
+    if (wi != cur_i) {                    // every 16th row: the word requested 16 rows ago moves up, the one after it is requested
+      cur = nxt; cur_i = wi;
+      asm volatile("" : "+v"(cur));        // stays a branch: as a select it would read nxt (and wait for its load) on every row
+      const int ni = wi + dir;
+      if (ni >= 0 && ni < nw) nxt = w[ni];
+    }
+    int x = (int)((cur >> (2 * (pos & 15))) & 3u);
+    if (pos == epos) {                    // rare; everything loaded here is also consumed here, so no wait leaks into the common path
+      x = (int)(exc[e] & 15u);
+      e += dir;
+      int np = -1;
+      if (e >= 0 && e < nexc) np = (int)(exc[e] >> 4);
+      epos = np;
+      asm volatile("" : "+v"(epos), "+v"(x));
+    }
+    return x;
+  }
+};
+
 DEV Seq open_seq(const ReadsDev &rd, int read)
 {
   Seq s; const int64_t wo = rd.woff[read], eo = rd.excoff[read];
@@ -448,11 +493,12 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
     *SLAB(a, r0, 0, 0, lane) = xE; *SLAB(a, r0, 0, 1, lane) = xN;
     *SLAB(a, r0, 0, 2, lane) = xJ; *SLAB(a, r0, 0, 3, lane) = xB;
     *SLAB(a, r0, 0, 4, lane) = xC; *SLAB(a, r0, 0, 5, lane) = 1.0f;
-    int xnext = sq.code(0);                  // residue of the NEXT row: its loads fly during the current row
+    SeqStream ss; ss.open(sq, 0, +1);
+    int xnext = ss.get(0);                   // residue of the NEXT row
     for (int i = 1; i <= Lw; i++) {
       if (i <= L) {
         const int x = xnext;
-        if (i < L) xnext = sq.code(i);
+        if (i < L) xnext = ss.get(i);
         fwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);
         float sc = 1.0f;
         if (xE > 1.0e4f) {
@@ -542,12 +588,16 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
     FRow fcur, fprv;
     fcur.E = fcur.N = fcur.J = fcur.B = fcur.C = 0.f; fcur.S = sL; fprv = fcur;
     if (alive) { fcur = load_f(L); fprv = load_f(L >= 1 ? L - 1 : 0); store_terms(L, fcur, fprv, sL); }
-    int xnext = (alive && L >= 2) ? sq.code(L - 1) : 0;
+    SeqStream ss; ss.open(sq, L >= 2 ? L - 1 : 0, -1);
+    int xnext = (alive && L >= 2) ? ss.get(L - 1) : 0;
     for (int i = Lw - 1; i >= 1; i--) {
       if (alive && i <= L - 1) {
-        const int x = xnext;               // residue i+1, 0-based index i
-        xnext = sq.code(i - 1);            // the next row down needs residue i (0-based i-1); row 0 reuses it
         fcur = fprv;                       // Forward's row i, requested one row ago
+        // taken here, before anything else of this row may issue a load: the wait is then "all but the six stores of the row
+        // before"; behind the stream's occasional load the compiler can only wait for everything, stores included
+        asm volatile("" : "+v"(fcur.E), "+v"(fcur.N), "+v"(fcur.J), "+v"(fcur.B), "+v"(fcur.C), "+v"(fcur.S));
+        const int x = xnext;               // residue i+1, 0-based index i
+        xnext = ss.get(i - 1);             // the next row down needs residue i (0-based i-1)
         fprv = load_f(i - 1);
         const float sfw = fcur.S;
         bwd_row<QT>(R, Q, tf, rf_s + x * QMAX * 4, xN, xB, xJ, xC, xE, pmove, ploop, 0.5f, 0.5f);

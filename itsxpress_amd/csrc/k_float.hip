@@ -435,11 +435,9 @@ __global__ void __launch_bounds__(256) k_bias(FloatArgs a, int64_t npairs)
   {
     const float t00 = lt.p1, t01 = 1.0f - lt.p1, t10 = pp->ft10, t11 = pp->ft11;
     float d0 = 0.f, d1 = 0.f, logsc = 0.0f;
-    uint32_t w = 0;
+    SeqStream ss; ss.open(sq, 0, +1);
     for (int i = 1; i <= L; i++) {
-      if (((i - 1) & 15) == 0) w = sq.w[(i - 1) >> 4];
-      int x = (int)(w & 3u); w >>= 2;
-      for (int e = 0; e < sq.nexc; e++) { const uint32_t v = sq.exc[e]; if ((int)(v >> 4) == i - 1) x = (int)(v & 15u); }
+      const int x = ss.get(i - 1);
       float n0, n1;
       if (i == 1) { n0 = pp->feo[x * 2] * pp->fpi0; n1 = pp->feo[x * 2 + 1] * pp->fpi1; }
       else {

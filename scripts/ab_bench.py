@@ -25,7 +25,7 @@ def main():
             print(arm, "FAILED", out.stderr[-500:])
             continue
         d = json.loads(line[-1])
-        print(arm, round(d["value"]), "reads/s  fwd %.1f ms  bwd %.1f ms  decode %.1f ms" % (d["stage_ms"]["ms_fwd_kernel"], d["stage_ms"]["ms_bwd_kernel"], d["stage_ms"]["ms_decode_kernel"]), flush=True)
+        print(arm, round(d["value"]), "reads/s  fwd %.1f ms  bwd %.1f ms  decode %.1f ms  env %.1f ms  bias %.1f ms  msv %.1f ms" % tuple(d["stage_ms"][k] for k in ("ms_fwd_kernel", "ms_bwd_kernel", "ms_decode_kernel", "ms_env_kernel", "ms_bias_kernel", "ms_msv_kernel")), flush=True)
 
 
 if __name__ == "__main__":

@@ -171,9 +171,9 @@ def main():
         vfrac = {
             "k_msv": (st["msv_cells"] / 20.5) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 20.5 cells per wave instruction
             # VALU instructions per DP row counted in the ISA of the unrolled loops (instruction audit):
-            # Forward 533, Backward 585 on the path without a rescale (480 of each are the recurrence's own packed mul/add)
+            # Forward 533, Backward 561 on the path without a rescale (480 of each are the recurrence's own packed mul/add)
             "k_filters_fwd": (st["fwd_rows"] / 64 * 533) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
-            "k_bwd_decode": (st["fwd_rows"] / 64 * 585) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
+            "k_bwd_decode": (st["fwd_rows"] / 64 * 561) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
         }
         kernel_table = {k: {"ms": round(kern[k], 3), "alg_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) if kern[k] > 0 else None,
                             "hbm_frac": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern[k] > 0 else None,

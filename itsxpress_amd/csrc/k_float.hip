@@ -362,11 +362,16 @@ DEV void bwd_row(Row<QT> &R, const int Q, const float *__restrict__ tf, const fl
       V4 enxt = ecur;
       if (q > 0) { nxt = ld6(tb, q - 1); enxt = vld(rfx + (q - 1) * 4); }
       ipv = R.i[q];
+      // the old M of this group is consumed first, so that the new one can take its registers (a value born while the one
+      // it replaces is still live makes its whole array move one slot per row: 24 register copies at the loop's end)
+      V4 mnext = vmul(R.m[q], ecur);
+      V4 imi = vmul(ipv, cur.mi);             // likewise: I*tMI before the new I, whose first product is then the old I's last use
+      asm volatile("" : "+v"(mnext.a), "+v"(mnext.b), "+v"(imi.a), "+v"(imi.b));
       R.i[q] = vadd(vmul(ipv, cur.ii), vmul(mpv, cur.imn));
       R.d[q] = vmul(mpv, cur.dmn);
-      mcv = vadd(vmul(ipv, cur.mi), vmul(mpv, cur.mmn));
-      mpv = vmul(R.m[q], ecur);
+      mcv = vadd(imi, vmul(mpv, cur.mmn));
       R.m[q] = mcv;
+      mpv = mnext;
       xBv = vadd(xBv, vmul(mpv, cur.bm));
       // pinned here: left free, instruction selection moves this accumulation chain behind the last group and keeps
       // all twelve B->M operand vectors alive for it (86 SGPR spill moves through VGPR lanes per row)

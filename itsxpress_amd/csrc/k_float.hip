@@ -586,7 +586,10 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
       *SLAB(a, r0, i, 8, lane) = fp.J * xJ * ploop;
       *SLAB(a, r0, i, 9, lane) = fc.B * xB * fc.S;
       *SLAB(a, r0, i, 10, lane) = fp.C * xC * ploop;
-      *SLAB(a, r0, i, 11, lane) = fc.S / s;
+      // Forward's scale over Backward's: 1 exactly (x / x) unless the lane rescaled on its own -- the division is taken only then
+      float ratio = 1.0f;
+      if (fc.S != s) { ratio = fc.S / s; asm volatile("" : "+v"(ratio)); }
+      *SLAB(a, r0, i, 11, lane) = ratio;
     };
     FRow fcur, fprv;
     fcur.E = fcur.N = fcur.J = fcur.B = fcur.C = 0.f; fcur.S = sL; fprv = fcur;

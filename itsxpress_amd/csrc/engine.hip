@@ -94,14 +94,15 @@ static std::string g_create_error;
 // kernels that use them, so every work buffer is kept in the context between calls
 template <class T> struct DBuf {
   T *p = nullptr; size_t n = 0, cap = 0;
-  hipError_t alloc(size_t count)
+  // exact: no growth headroom (the slabs: their size is a budget, not a data-dependent count)
+  hipError_t alloc(size_t count, bool exact = false)
   {
     n = count;
     if (count <= cap && p) return hipSuccess;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     if (!count) return hipSuccess;
-    const size_t want = count + count / 8 + 64;
+    const size_t want = exact ? count : count + count / 8 + 64;
     static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
@@ -1216,7 +1217,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       w0 = w1;
     }
     DBuf<float> &d_slab = ctx->w_slab;
-    if ((size_t)rmax * 12 * 64 > d_slab.cap) HIPCHK(d_slab.alloc((size_t)rmax * 12 * 64));
+    if ((size_t)rmax * 12 * 64 > d_slab.cap) HIPCHK(d_slab.alloc((size_t)rmax * 12 * 64, true));
     HIPCHK(hipMemcpyAsync(d_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
     FloatArgs a{};
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;

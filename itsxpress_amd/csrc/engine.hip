@@ -1217,7 +1217,9 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       w0 = w1;
     }
     DBuf<float> &d_slab = ctx->w_slab;
-    if ((size_t)rmax * 12 * 64 > d_slab.cap) HIPCHK(d_slab.alloc((size_t)rmax * 12 * 64, true));
+    // several batches: take the whole budget, so that the next job (whose fullest batch may be a few waves larger) fits too
+    const int64_t slab_rows = batches.size() > 1 ? std::max(rmax, budget_rows) : rmax;
+    if ((size_t)slab_rows * 12 * 64 > d_slab.cap) HIPCHK(d_slab.alloc((size_t)slab_rows * 12 * 64, true));
     HIPCHK(hipMemcpyAsync(d_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
     FloatArgs a{};
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;

@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- reads/sec trimmed on the hot path (BASELINE.json metric), 1..8 GPUs of one node.
 
-A "step" is one pass of the hot path over one batch of synthetic reads already packed and
-resident in HBM: derep -> MSV -> bias/Forward -> Backward/domain definition -> envelope
-re-scoring -> [all-reduce domZ] -> thresholds/argmax -> per-read (start, stop, tlen) on the
-host of every rank -> gather to rank 0.  Workload at N=1: BASELINE.json configs[1]
-(1M synthetic 300 bp single-end reads, ITS2, cluster_id=1.0); Fungi's model file is absent
-from the reference mount, so the stand-in taxon Tracheophyta (155 ITS2 profiles) is used and
-labelled.  Weak scaling: every rank processes its own shard of that size.
+Workload at N=1 (default): BASELINE.json configs[2] -- 10 M synthetic merged 2x300 bp reads (lengths 300-580, SURVEY 8d
+cfg3), ITS2, cluster_id = 1.0; Fungi's model file is absent from the reference mount, so the stand-in taxon Tracheophyta
+(155 ITS2 profiles) is used and labelled.  `--workload cfg1` is configs[1] (1 M x 300 bp single-end).
+
+A "step" is one pass of the hot path over one batch of reads whose ASCII text is resident in HBM when the timed region
+starts: 2-bit packing on the device -> derep -> MSV -> bias/Forward -> Backward/domain definition -> envelope re-scoring
+-> [all-reduce domZ] -> thresholds/argmax -> per-read (start, stop, tlen) on the host of every rank -> gather to rank 0.
+`host_handover` is the same step fed from a host buffer (staged PCIe upload included), measured in a leg of its own.
+
+`--gpus N`: when N > 1 and no launcher set WORLD_SIZE, this process starts N ranks of itself (before anything touches the
+GPU) and relays rank 0's line.  Weak scaling by default (every rank its own shard of the workload's size);
+`--total-reads T` shards T reads over the ranks (strong scaling; shards share their template library, so
+`--global-derep` has cross-shard duplicates to find).
 
 Prints ONE JSON line on rank 0.
 """
@@ -15,21 +21,36 @@ import argparse
 import gzip
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
-# HBM bytes per lane-row measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), see
-# profiles/round1_pmc_hbm_traffic_200k.md.  WRITE_SIZE is exact for these stores; FETCH_SIZE is NOT doubled
-# (uncalibrated for 4-byte-per-lane loads on gfx950), so the read side is a lower bound.
-PMC_BYTES_PER_ROW = {"k_filters_fwd": 0.6 + 23.7, "k_bwd_decode": 13.2 + 23.6, "k_decode": 17.8 + 0.2}
-VALU_PEAK_GOPS = 256 * 4 * 32 * 2.4   # lane-ops/ns: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s
+# fp32 VALU ceiling WITHOUT fused multiply-add: 256 CUs x 4 SIMDs x 32 lanes (packed f32: 2 x 16) x 2.4 GHz = 78.6 TFLOP/s.
+# HMMER rounds every product and every sum separately, so the DP kernels cannot use FMA (the 157 TFLOP/s figure).
+VALU_NOFMA_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4          # wave instructions per second: 1024 SIMDs, one VALU issue per 4 cycles
+# the recurrence's own work per DP lane-row (45-node model, Q = 12): 480 packed multiplies/adds = 960 flops;
+# the kernels issue 533 (Forward) / 561 (Backward) VALU instructions per row (instruction audit)
+FLOPS_PER_ROW = 960.0
+VALU_PER_ROW = {"k_filters_fwd": 533.0, "k_bwd_decode": 561.0}
+# HBM bytes per lane-row from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE corrected by the factor
+# calibrated with scripts/fetch_calib.py on the slab access pattern (profiles/round2_fetch_calibration.md)
+PMC_BYTES_PER_ROW = None         # filled from profiles/round2_pmc_bytes_per_row.json when present
+
+
+def _load_pmc():
+    global PMC_BYTES_PER_ROW
+    p = os.path.join(ROOT, "profiles", "round2_pmc_bytes_per_row.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            PMC_BYTES_PER_ROW = json.load(f)
 
 
 def its2_profiles(hmm_text):
@@ -37,10 +58,81 @@ def its2_profiles(hmm_text):
     return "".join(b for b in blocks if b.split("NAME  ")[1][:2] in ("3_", "4_"))
 
 
+def launch_ranks(n):
+    """N > 1 and no launcher: start N ranks of this script (nothing here has touched the GPU), relay rank 0's output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def launch_selftest(world, rank):
+    """CPU check of the launcher + the two exchange steps with gloo and no engine (tests/test_dist_gloo.py)."""
+    import numpy as np
+    import torch.distributed as dist
+    from itsxpress_amd.dist import allreduce_domz, gather_coords
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = allreduce_domz(np.full(5, rank + 1, np.int64))
+    n = 3 + rank
+    c = gather_coords(np.full(n, rank, np.int32), np.arange(n, dtype=np.int32), np.full(n, 7, np.int32), np.ones(n, np.int32))
+    dist.barrier()
+    if rank == 0:
+        ok = bool((z == world * (world + 1) // 2).all()) and [b.shape[0] for b in c] == [3 + r for r in range(world)] and \
+            all(int(b[0, 0]) == r for r, b in enumerate(c))
+        print(json.dumps({"metric": "launcher self-test (no engine, gloo)", "value": None, "n_gpus": world, "ok": ok}))
+    dist.destroy_process_group()
+
+
+def real_tools_baseline(hmm_its2, seqs, threads, tmp):
+    """SURVEY 8d's preferred baseline: the reference's own command lines (itsxpress/SeqSample.py:106-116, 191-209) when
+    vsearch and hmmsearch are on PATH.  Returns (seconds, per-read coordinates) or None."""
+    if shutil.which("vsearch") is None or shutil.which("hmmsearch") is None:
+        return None
+    import numpy as np
+    from itsxpress_amd.SeqSample import Dedup, ItsPosition
+    fq, hmm = os.path.join(tmp, "seq.fq"), os.path.join(tmp, "runtime.hmm")
+    with open(fq, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write("@r%09d\n%s\n+\n%s\n" % (i, s, "I" * len(s)))
+    with open(hmm, "w") as f:
+        f.write(hmm_its2)
+    uc, rep, dom = (os.path.join(tmp, n) for n in ("uc.txt", "rep.fa", "domtbl.txt"))
+    t0 = time.time()
+    subprocess.run(["vsearch", "--fastx_uniques", fq, "--fastaout", rep, "--uc", uc, "--strand", "both"], check=True,
+                   stderr=subprocess.DEVNULL)
+    subprocess.run(["hmmsearch", "--domtblout", dom, "-T", "10", "--cpu", str(threads), "--tformat", "fasta", "--F1", "1e-6",
+                    "--F2", "1e-6", "--F3", "1e-6", hmm, rep], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dd = Dedup(uc_file=uc, rep_file=rep, seq_file=fq)
+    pos = ItsPosition(domtable=dom, region="ITS2")
+    dt = time.time() - t0
+    coords = np.full((len(seqs), 3), -1, np.int32)
+    for i in range(len(seqs)):
+        r = dd.matchdict.get("r%09d" % i)
+        if r is None:
+            continue
+        try:
+            a, b, c = pos.get_position(r)
+        except KeyError:
+            continue
+        coords[i] = [-1 if a is None else a, -1 if b is None else b, -1 if c is None else c]
+    return dt, coords
+
+
 def cpu_baseline(hmm_its2, blob, offs, sample_reads, threads):
     """the oracle (a port of the reference's CPU path) timed on a bounded sample of the same workload"""
+    import numpy as np
     import orc
-    seqs = [blob[offs[i]:offs[i + 1]].decode() for i in range(sample_reads)]
+    raw = bytes(blob[:int(offs[sample_reads])])
+    seqs = [raw[offs[i]:offs[i + 1]].decode() for i in range(sample_reads)]
     hs = orc.HmmSet(text=hmm_its2)
     t0 = time.time()
     codes, o = orc.digitize(seqs)
@@ -53,7 +145,7 @@ def cpu_baseline(hmm_its2, blob, offs, sample_reads, threads):
     uniq = np.cumsum(np.asarray(rep) == np.arange(len(seqs))) - 1          # unique index of each seed, in input order
     uo = uniq[np.asarray(rep)]
     coords = np.stack([us[uo], ue[uo], ut[uo]], axis=1)                      # per read of the sample: the baseline path's answer
-    return sample_reads / dt, dt, nc, coords
+    return sample_reads / dt, dt, nc, coords, seqs
 
 
 def main():
@@ -61,19 +153,31 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20 s of CPU work)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg1"], default="cfg2",
+                    help="cfg2 = BASELINE configs[2] (10 M merged reads, 300-580 bases; the default), cfg1 = configs[1] (1 M x 300)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's own size)")
+    ap.add_argument("--total-reads", type=int, default=0,
+                    help="strong scaling: this many reads in total, sharded over the ranks (shards share their templates)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20-30 s of CPU work)")
+    ap.add_argument("--handover-steps", type=int, default=2, help="untimed-in-`value` steps fed from the host buffer (0 = skip)")
     ap.add_argument("--cluster-id", type=float, default=1.0,
-                    help="1.0 = exact dereplication (BASELINE configs[1], the default); < 1 runs row a2 (greedy clustering) instead")
+                    help="1.0 = exact dereplication (the default); < 1 runs row a2 (greedy clustering) instead")
     ap.add_argument("--taxa", choices=["T", "all"], default="T",
-                    help="T = the stand-in taxon of BASELINE configs[1] (155 ITS2 profiles); all = --taxa All --region ITS2 (814 profiles, configs[3])")
+                    help="T = the stand-in taxon (155 ITS2 profiles); all = --taxa All --region ITS2 (814 profiles, configs[3])")
     ap.add_argument("--global-derep", action="store_true",
                     help="N > 1: match the uniques across shards (exact global dereplication, SURVEY 8e option 2) instead of per-shard")
+    ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_selftest:
+        return launch_selftest(world, rank)
+    import numpy as np
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
@@ -87,6 +191,7 @@ def main():
     from itsxpress_amd import Engine
     from itsxpress_amd.dist import allreduce_domz, exchange_coords, gather_coords, global_derep
     import synth
+    _load_pmc()
 
     with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
         thmm = f.read()
@@ -94,17 +199,37 @@ def main():
     if args.taxa == "all":
         with gzip.open(os.path.join(ROOT, "tests", "golden", "all_its2.hmm.gz"), "rt") as f:
             hmm = f.read()
-    blob, offs = synth.make_reads(thmm, args.reads, config=2, seed=synth.SEED + 2 + 1000 * rank)
+    cfg2 = args.workload == "cfg2"
+    strong = args.total_reads > 0
+    if strong:
+        lo, hi = args.total_reads * rank // world, args.total_reads * (rank + 1) // world
+        n_local = hi - lo
+    else:
+        n_local = args.reads or (10000000 if cfg2 else 1000000)
+    t_gen = time.time()
+    gen = dict(config=3 if cfg2 else 2, seed=synth.SEED + (3 if cfg2 else 2) + 1000 * rank, as_array=True)
+    if cfg2:
+        gen.update(fixed_len=0, len_range=(300, 580))
+    if strong:                      # one template library for the whole job: 2 % of the TOTAL reads
+        gen.update(template_seed=synth.SEED + 77, frac_templates=0.02 * args.total_reads / max(n_local, 1))
+    blob, offs = synth.make_reads(thmm, n_local, **gen)
+    t_gen = time.time() - t_gen
+    mean_len = float(offs[-1]) / max(n_local, 1)
     eng = Engine(local_rank)
     nprof = eng.load_profiles(text=hmm)
-    eng.set_reads_buffer(blob, offs)          # pack + upload: inputs are resident in HBM before timing
+    d_blob = torch.from_numpy(blob).to(dev)      # the batch's ASCII text, resident in HBM before the timed region
+    torch.cuda.synchronize()
 
-    def step():
+    def step(from_host=False):
+        if from_host:
+            eng.set_reads_buffer(blob, offs)     # staged upload + device packing
+        else:
+            eng.set_reads_device(d_blob.data_ptr(), offs, keep=d_blob)     # device packing of the resident text
         if args.cluster_id < 1.0:
             eng.cluster(args.cluster_id, strand_both=True)
         else:
             eng.derep(strand_both=True, minseqlength=32)
-        g = global_derep(eng, args.reads, dev) if (use_dist and args.global_derep) else None
+        g = global_derep(eng, n_local, dev) if (use_dist and args.global_derep) else None
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
         if use_dist:
             eng.set_domz(allreduce_domz(eng.get_domz(), dev))
@@ -141,96 +266,163 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tot = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        total_local = int(tot.item())
+    else:
+        total_local = n_local
     st = eng.stats()
 
+    # the same step fed from the host buffer (PCIe-inclusive), never part of `value`
+    handover = None
+    if args.handover_steps > 0:
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        mp = 0.0
+        for _ in range(args.handover_steps):
+            step(from_host=True)
+            mp += eng.stats()["ms_pack"]
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        th = time.perf_counter() - th
+        if use_dist:
+            t = torch.tensor([th], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            th = float(t.item())
+        handover = {"value": total_local * args.handover_steps / th, "unit": "reads/s", "steps": args.handover_steps,
+                    "ms_per_step": th / args.handover_steps * 1e3, "ms_upload_and_pack": mp / args.handover_steps,
+                    "GB_per_step": float(offs[-1]) / 1e9,
+                    "note": "host buffer -> pinned staging -> HBM -> device packing inside the step (PCIe-inclusive); not `value`"}
+
     if rank == 0:
-        total_reads = args.reads * world * args.steps
+        total_reads = total_local * args.steps
         value = total_reads / dt
         K = args.steps
         kern = {"k_msv": acc["ms_msv_kernel"] / K, "k_filters_fwd": acc["ms_fwd_kernel"] / K,
                 "k_bwd_decode": acc["ms_bwd_kernel"] / K, "k_decode": acc["ms_decode_kernel"] / K,
                 "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K}
         dom = max(kern, key=kern.get)
-        # algorithmic HBM bytes of each main kernel, per step
-        U, L = st["n_unique"], 300
+        # algorithmic HBM bytes of each main kernel, per step; L = the mean read length
+        U, wbytes = st["n_unique"], 4.0 * ((mean_len + 15) // 16)
         alg = {
-            "k_msv": U * ((nprof + 63) // 64) * ((L + 15) // 16 * 4) + 2 * ((nprof + 63) // 64 * 64) * U,
+            "k_msv": U * ((nprof + 63) // 64) * wbytes + 2 * ((nprof + 63) // 64 * 64) * U,
             # per pair: packed read + PairRec/PairOut; per row: 6 special-state floats written
-            "k_filters_fwd": st["n_past_msv"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 24,
+            "k_filters_fwd": st["n_past_msv"] * (wbytes + 16 + 40) + st["fwd_rows"] * 24,
             # per row: Forward's 6 floats read, 6 decoding terms written
-            "k_bwd_decode": st["n_past_fwd"] * (((L + 15) // 16 * 4) + 16 + 40) + st["fwd_rows"] * 48,
+            "k_bwd_decode": st["n_past_fwd"] * (wbytes + 16 + 40) + st["fwd_rows"] * 48,
             # per row: 5 terms read (nothing written back)
             "k_decode": st["n_past_fwd"] * (16 + 40) + st["fwd_rows"] * 20,
             # envelope sweeps: Backward rows written once, read once (26 float4 per row), + 88 B result per envelope
             "k_env_fwd+k_env_bwd+k_env_post": st["env_rows"] * 2 * 26 * 16 + st["n_domains"] * (16 + 88),
         }
-        alg_bytes = alg[dom]
-        # what bounds each of them: wave instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles (VALU-bound scans),
-        # algorithmic GB/s against HBM for the streaming ones
-        WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4
+        # what bounds each of them: the DP scans are VALU-bound (no-FMA fp32), the streaming kernels HBM-bound
+        rows = st["fwd_rows"]
+        tfl = {k: (rows * FLOPS_PER_ROW / (kern[k] * 1e-3) / 1e12 if kern[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode")}
         vfrac = {
             "k_msv": (st["msv_cells"] / 20.5) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 20.5 cells per wave instruction
-            # VALU instructions per DP row counted in the ISA of the unrolled loops (instruction audit):
-            # Forward 533, Backward 561 on the path without a rescale (480 of each are the recurrence's own packed mul/add)
-            "k_filters_fwd": (st["fwd_rows"] / 64 * 533) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
-            "k_bwd_decode": (st["fwd_rows"] / 64 * 561) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
+            "k_filters_fwd": (rows / 64 * VALU_PER_ROW["k_filters_fwd"]) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
+            "k_bwd_decode": (rows / 64 * VALU_PER_ROW["k_bwd_decode"]) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
         }
         kernel_table = {k: {"ms": round(kern[k], 3), "alg_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) if kern[k] > 0 else None,
                             "hbm_frac": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern[k] > 0 else None,
+                            "nofma_tflops": round(tfl[k], 2) if tfl.get(k) else None,
                             "valu_issue_frac": round(vfrac[k], 3) if vfrac.get(k) else None} for k in kern}
-        achieved = alg_bytes / (kern[dom] * 1e-3) / 1e9
         # launches of the dominant kernel in one step, for per-launch figures
-        nl = {"k_msv": 1}.get(dom, max(1, int(st.get("n_batches", 1))))
-        traffic = PMC_BYTES_PER_ROW[dom] * st["fwd_rows"] / nl if dom in PMC_BYTES_PER_ROW else None
+        nl = {"k_msv": max(1, int(st.get("msv_launches", 1)))}.get(dom, max(1, int(st.get("n_batches", 1))))
+        traffic = None
+        if PMC_BYTES_PER_ROW and dom in PMC_BYTES_PER_ROW:
+            traffic = PMC_BYTES_PER_ROW[dom] * rows / nl
+        if dom in tfl and tfl[dom]:
+            roof = {"kernel": dom, "bound": "valu", "achieved": round(tfl[dom], 3), "peak": round(VALU_NOFMA_TFLOPS, 1), "unit": "TFLOP/s",
+                    "frac": tfl[dom] / VALU_NOFMA_TFLOPS, "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl,
+                    "alg_flops_per_launch": rows * FLOPS_PER_ROW / nl, "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
+                    "hbm_frac_on_alg_bytes": alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "a serial recurrence per (representative, profile): 960 no-FMA fp32 flops per lane-row (HMMER rounds products "
+                            "and sums separately) against 78.6 TFLOP/s = 1024 SIMDs x 32 lanes x 2.4 GHz; duration = HIP events on the "
+                            "engine's stream; traffic = PMC bytes per lane-row x rows per launch (profiles/round2_*)"}
+        else:
+            ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl, "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic}
         trimmed = int(((out[0][:, 0] >= 0) & (out[0][:, 1] >= 0) & (out[0][:, 0] < out[0][:, 1])).sum())
+        shape = ("merged reads of 300-580 bases (mean %.0f)" % mean_len) if cfg2 else "300 bp single-end reads"
+        wl = ("configs[2]" if cfg2 else "configs[1]") + ": %d synthetic %s per GPU" % (n_local, shape)
+        if strong:
+            wl = "%d synthetic %s in total, sharded over %d ranks (shared template library)" % (args.total_reads, shape, world)
+        wl += ", ITS2" + (", cluster_id=1.0 (pure derep)" if args.cluster_id >= 1.0 else ", cluster_id=%g (greedy clustering, row a2)" % args.cluster_id)
+        if args.taxa == "all":
+            wl += ", --taxa All (814 profiles, as configs[3])"
         res = {
             "metric": "reads/sec trimmed (ITS2, stand-in taxon Tracheophyta for Fungi)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+f32", "data": "synthetic",
-            "config": {"workload": ("configs[1]: %d synthetic 300 bp single-end reads per GPU, ITS2, cluster_id=1.0 (pure derep)" % args.reads)
-                       if (args.cluster_id >= 1.0 and args.taxa == "T") else
-                       ("%d synthetic 300 bp single-end reads per GPU, --taxa All --region ITS2 (814 profiles, as configs[3]), cluster_id=1.0" % args.reads)
-                       if args.cluster_id >= 1.0 else
-                       ("%d synthetic 300 bp single-end reads per GPU, ITS2, cluster_id=%g (greedy clustering, row a2)" % (args.reads, args.cluster_id)),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8+f32", "data": "synthetic",
+            "config": {"workload": wl,
                        "taxon": "Tracheophyta (stand-in: F.hmm absent from the reference mount)" if args.taxa == "T" else "All (every ITSx set in the mount; F.hmm absent)", "profiles": nprof,
+                       "reads_rank0": n_local, "mean_length": round(mean_len, 1), "generate_s": round(t_gen, 1),
                        "unique": int(st["n_unique"]), "pairs_past_msv": int(st["n_past_msv"]), "pairs_past_fwd": int(st["n_past_fwd"]),
-                       "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed, "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
+                       "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed,
+                       "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
+            "timed_region": "ASCII text resident in HBM -> device 2-bit packing -> derep -> MSV -> Forward/Backward -> domains -> "
+                            "thresholds -> per-read coordinates on the host (+ all-reduce / gather at N > 1)",
+            "host_handover": handover,
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
             "kernels": kernel_table,
+            "parity_risk": {"regions": int(st["n_regions"]), "regions_multidomain": int(st["n_multidomain"]),
+                            "uniques_winner_from_multidomain_region": int(st["n_uniq_multi_winner"]),
+                            "reads_winner_from_multidomain_region": int(st["n_reads_multi_winner"]),
+                            "pairs_over_region_cap": int(st["n_domain_overflow"]),
+                            "uniques_with_pair_over_region_cap": int(st["n_uniq_region_cap"]),
+                            "reads_with_pair_over_region_cap": int(st["n_reads_region_cap"])},
             "concurrency": "k_bias of batch b+1 runs on a second stream beside k_decode of batch b: ms_bias_kernel is its stretched wall time, not extra step time",
             "cluster": None if args.cluster_id >= 1.0 else {"windows": int(st["cl_windows"]), "cut_windows": int(st["cl_cuts"]),
                                                             "alignments": int(st["cl_alignments"]), "centroids": int(st["n_unique"])},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl, "alg_bytes_per_launch": alg_bytes / nl,
-                         "traffic": traffic,
-                         "note": "achieved = algorithmic bytes / HIP-event time of the kernel; the dominant kernels are VALU-bound scans "
-                                 "(SURVEY 8d), see 'valu'; traffic = PMC bytes per lane-row (profiles/round1_pmc_hbm_traffic_200k.md) x rows per launch"},
+            "roofline": roof,
             "valu": {"msv_gcups": st["msv_cells"] / (kern["k_msv"] * 1e-3) / 1e9 if kern["k_msv"] > 0 else None,
-                     "fwd_rows_per_s": st["fwd_rows"] / (kern["k_filters_fwd"] * 1e-3) if kern["k_filters_fwd"] > 0 else None,
-                     "bwd_rows_per_s": st["fwd_rows"] / (kern["k_bwd_decode"] * 1e-3) if kern["k_bwd_decode"] > 0 else None,
+                     "fwd_rows_per_s": rows / (kern["k_filters_fwd"] * 1e-3) if kern["k_filters_fwd"] > 0 else None,
+                     "bwd_rows_per_s": rows / (kern["k_bwd_decode"] * 1e-3) if kern["k_bwd_decode"] > 0 else None,
                      "env_rows_per_s_x3_sweeps": 3 * st["env_rows"] / (kern["k_env_fwd+k_env_bwd+k_env_post"] * 1e-3) if kern["k_env_fwd+k_env_bwd+k_env_post"] > 0 else None,
-                     "peak_lane_gops": VALU_PEAK_GOPS},
+                     "peak_nofma_tflops": VALU_NOFMA_TFLOPS},
         }
         if args.cpu_sample != 0 and world == 1:          # the CPU baseline is a rank-0, N=1 leg only
             threads = os.cpu_count() or 1
-            if args.cpu_sample < 0:                      # ~1 s per 80 reads per core on the scalar port
-                args.cpu_sample = int(min(40000, max(1200, 120 * threads)))
-            m = min(args.cpu_sample, args.reads)
-            v, cdt, nc, ccoords = cpu_baseline(hmm, blob, offs, m, threads)
+            if args.cpu_sample < 0:                      # the scalar port does ~55 (440-base) .. 80 (300-base) reads/s per core
+                args.cpu_sample = int(min(24000 if cfg2 else 40000, max(1200, (80 if cfg2 else 120) * threads)))
+            m = min(args.cpu_sample, n_local)
+            v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads)
             # trim-coordinate concordance (BASELINE metric): the engine on the very same sample against the baseline path
             e2 = Engine(local_rank)
             e2.load_profiles(text=hmm)
-            e2.set_reads_buffer(blob[:int(offs[m])], offs[:m + 1])
+            e2.set_reads_buffer(np.ascontiguousarray(blob[:int(offs[m])]), offs[:m + 1])
             e2.derep(strand_both=True, minseqlength=32)
             e2.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
             e2.finalize(domE=10.0)
             gs, ge, gt, _ = e2.trim_coords("3_", "4_")
             e2.close()
-            conc = float((np.stack([gs, ge, gt], axis=1) == ccoords).all(axis=1).mean())
+            got = np.stack([gs, ge, gt], axis=1)
+            conc = float((got == ccoords).all(axis=1).mean())
             res["cpu_baseline"] = {"value": v, "unit": "reads/s", "cores": threads, "kind": "port",
                                    "sample": "first %d reads of the same workload (%d unique), derep+search+argmax, %.1f s" % (m, nc, cdt),
-                                   "trim_coord_concordance": conc}
+                                   "trim_coord_concordance": conc,
+                                   "concordance_is": "engine vs oracle/ (our restatement), not vs vsearch+hmmsearch"}
+            # the real reference engines, when the box happens to have them (SURVEY 8d "preferred")
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                try:
+                    real = real_tools_baseline(hmm, seqs, threads, tmp)
+                except Exception as e:      # a tool that is present but fails is reported, not fatal
+                    real = None
+                    res["cpu_baseline"]["real_tools_error"] = repr(e)[:200]
+            if real is not None:
+                rdt, rcoords = real
+                res["cpu_baseline"].update({"value": m / rdt, "kind": "reference", "cores": threads,
+                                            "sample": "first %d reads of the same workload through vsearch --fastx_uniques + hmmsearch (--cpu %d) + "
+                                                      "the reference's parsers, %.1f s" % (m, threads, rdt),
+                                            "trim_coord_concordance": float((got == rcoords).all(axis=1).mean()),
+                                            "concordance_is": "engine vs the real vsearch + hmmsearch path",
+                                            "port_value": v, "port_concordance": conc})
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -85,6 +85,12 @@ typedef struct {
   int64_t cl_windows, cl_cuts, cl_alignments;            /* speculative windows, windows cut by validation, alignments */
   float   ms_merge;          int32_t pad1;               /* k_merge of the last itsx_merge_* call */
   int64_t cl_certified;                                  /* candidate alignments proven rejections without the full DP */
+  float   ms_pack;           int32_t pad2;               /* last hand-over of reads: staging + upload + device packing, host wall time */
+  /* parity-risk counters of the last itsx_trim_coords / itsx_rep_coords call (the prefixes decide which domains count):
+   * uniques / reads whose winning left or right domain came from a region hmmsearch resolves by stochastic clustering
+   * (itsx_domain.flags bit 0), and uniques / reads with a (representative, profile) pair that had more regions than
+   * the engine keeps (bit 1) among the domains of the two sides */
+  int64_t n_uniq_multi_winner, n_reads_multi_winner, n_uniq_region_cap, n_reads_region_cap;
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -112,6 +118,17 @@ int itsx_profile_tables(const itsx_ctx *ctx, int i, uint8_t *rbv, float *rfv, fl
  * HBM when the call returns. */
 int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n,
                    const char *names, const int64_t *name_offsets);
+/* The same without the host-side copy of the bases: the engine keeps the caller's `bases` pointer (itsx_write_rep_fasta
+ * reads the representatives from it), so the caller keeps that buffer valid and unchanged until the next reads call on
+ * this context or itsx_destroy.  offsets and names are copied as before. */
+int itsx_set_reads_view(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n,
+                        const char *names, const int64_t *name_offsets);
+/* The same for text that already lives in DEVICE memory (d_bases: a hipMalloc'ed buffer of ASCII bases on this
+ * context's GPU, e.g. the output of a device-side parser or of the merge kernel); offsets and names are host arrays.
+ * Nothing crosses PCIe but the offsets; the bases are packed where they are.  The caller keeps d_bases valid until the
+ * next reads call or itsx_destroy (itsx_write_rep_fasta copies the text back on demand). */
+int itsx_set_reads_device(itsx_ctx *ctx, const void *d_bases, const int64_t *offsets, int64_t n,
+                          const char *names, const int64_t *name_offsets);
 /* FASTA or FASTQ file, plain or gzip (.gz): native parser for the same input. */
 int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
 

@@ -44,12 +44,14 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("fwd_rows", "<i8"), ("ms_env_kernel", "<f4"), ("ms_bias_kernel", "<f4"), ("env_rows", "<i8"),
                 ("n_env_unique", "<i8"), ("ms_decode_kernel", "<f4"), ("n_batches", "<i4"), ("ms_cluster", "<f4"),
                 ("pad0", "<i4"), ("cl_windows", "<i8"), ("cl_cuts", "<i8"), ("cl_alignments", "<i8"), ("ms_merge", "<f4"),
-                ("pad1", "<i4"), ("cl_certified", "<i8")]
+                ("pad1", "<i4"), ("cl_certified", "<i8"), ("ms_pack", "<f4"), ("pad2", "<i4"),
+                ("n_uniq_multi_winner", "<i8"), ("n_reads_multi_winner", "<i8"), ("n_uniq_region_cap", "<i8"),
+                ("n_reads_region_cap", "<i8")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares
 EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy", "itsx_load_profiles_file",
-           "itsx_load_profiles_mem", "itsx_profile_name", "itsx_profile_tables", "itsx_set_reads",
+           "itsx_load_profiles_mem", "itsx_profile_name", "itsx_profile_tables", "itsx_set_reads", "itsx_set_reads_view", "itsx_set_reads_device",
            "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_cluster", "itsx_get_derep", "itsx_unique_keys", "itsx_set_active_uniques", "itsx_get_uniques",
            "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
@@ -84,6 +86,8 @@ def lib():
         "itsx_profile_name": (i32, [vp, i32, vp, i32]),
         "itsx_profile_tables": (i32, [vp, i32, vp, vp, vp, vp]),
         "itsx_set_reads": (i32, [vp, vp, vp, i64, vp, vp]),
+        "itsx_set_reads_view": (i32, [vp, vp, vp, i64, vp, vp]),
+        "itsx_set_reads_device": (i32, [vp, vp, vp, i64, vp, vp]),
         "itsx_load_reads_file": (i32, [vp, cp, vp]),
         "itsx_derep": (i32, [vp, i32, i32, vp]),
         "itsx_cluster": (i32, [vp, f64, i32, vp]),

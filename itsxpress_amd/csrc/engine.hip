@@ -34,6 +34,9 @@ void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npair
 void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, const int32_t *usample, int P, hipStream_t st);
 void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, unsigned long long *bl, unsigned long long *br,
                       int32_t *in_ddict, hipStream_t st);
+void launch_position_flags(const itsx_domain *dom, int64_t n, const int8_t *side, const unsigned long long *bl, const unsigned long long *br,
+                           int32_t *uflag, hipStream_t st);
+void launch_count_flags(const int32_t *uflag, int32_t U, const int32_t *uniq_of, int64_t n, unsigned long long *c, hipStream_t st);
 
 // ---- a few tiny kernels that only the orchestration needs --------------------------------
 __global__ void k_wave_rows_pairs(const WaveDesc *w, int nw, const PairRec *pairs, int32_t *rows)
@@ -135,6 +138,11 @@ struct itsx_ctx {
   // ---- reads
   int64_t N = 0;
   std::string h_bases;                   // original text (rep.fa keeps the input's case)
+  const char *bases_view = "";           // = h_bases.data(), or the caller's buffer after itsx_set_reads_view
+  const uint8_t *dev_bases = nullptr;    // after itsx_set_reads_device: the caller's device buffer (bases_view is fetched on demand)
+  static constexpr int NSTAGE = 3;       // pinned / device staging of the hand-over (pack_and_upload)
+  void *stage_pin[NSTAGE] = {nullptr, nullptr, nullptr}; DBuf<uint8_t> stage_dev[NSTAGE]; hipEvent_t stage_ev[NSTAGE] = {nullptr, nullptr, nullptr}; size_t stage_cap = 0;
+  DBuf<int64_t> w_pk_off; DBuf<int8_t> w_pk_lut; DBuf<int32_t> w_pk_excnt, w_pk_exstart, w_pk_tmp; DBuf<long long> w_pk_bad;
   std::vector<int64_t> h_off;
   std::vector<std::string> h_names;
   std::vector<int64_t> h_woff;           // word offset of each read (the words themselves and the exceptions live on the device only)
@@ -194,7 +202,7 @@ struct itsx_ctx {
   DBuf<int64_t> w_seg_start, w_idx, w_rseg, w_dz, w_counters, w_useg;
   DBuf<int32_t> w_rrep, w_ruq, w_rurank;
   DBuf<WaveDesc> w_waves, w_rw; DBuf<RegionRec> w_raw; DBuf<float> w_slab, w_eslab;
-  DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri;
+  DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri, w_uflag;
 };
 
 #define CTXCHK(c)                                   \
@@ -288,6 +296,7 @@ void itsx_destroy(itsx_ctx *ctx)
   (void)hipStreamSynchronize(ctx->st);
   if (ctx->st2) { (void)hipStreamSynchronize(ctx->st2); (void)hipStreamDestroy(ctx->st2); (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b); }
   (void)hipStreamDestroy(ctx->st);
+  for (int k = 0; k < itsx_ctx::NSTAGE; k++) { if (ctx->stage_pin[k]) (void)hipHostFree(ctx->stage_pin[k]); if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]); }
   delete ctx;
 }
 
@@ -418,14 +427,22 @@ static void init_codes()
   g_code_init = true;
 }
 
-static int pack_and_upload(itsx_ctx *ctx)
+// Hand-over of the reads: the ASCII bases travel in chunks of whole reads through three pinned staging buffers (a pool of
+// host threads copies chunk c+1 into its buffer while chunk c is on the bus and chunk c-1 is being packed), and are packed on
+// the device chunk by chunk (k_util.hip).  A pageable hipMemcpy of the whole text moved 4.4 GB (10 M merged reads) at ~5 GB/s.
+static int pack_and_upload(itsx_ctx *ctx, const char *view = nullptr, const uint8_t *dev_raw = nullptr)
 {
   init_codes();
+  const auto tp0 = std::chrono::steady_clock::now();
   const int64_t n = ctx->N;
+  ctx->dev_bases = dev_raw;
+  ctx->bases_view = dev_raw ? nullptr : (view ? view : ctx->h_bases.data());
+  const char *bases = ctx->bases_view;
   ctx->h_len.resize((size_t)n); ctx->h_woff.assign((size_t)n + 1, 0);
   int Lmax = 0;
   for (int64_t r = 0; r < n; r++) {
     const int64_t L = ctx->h_off[r + 1] - ctx->h_off[r];
+    if (L < 0) SET_ERR(ctx, ITSX_E_ARG, "read offsets must be non-decreasing");
     if (L > 65535) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "reads longer than 65535 bases are not supported");
     ctx->h_len[r] = (int32_t)L;
     Lmax = std::max(Lmax, (int)L);
@@ -433,53 +450,126 @@ static int pack_and_upload(itsx_ctx *ctx)
   }
   ctx->Lmax = Lmax;
   HIPCHK(hipSetDevice(ctx->device));
-  // the ASCII bases go up as they are and are packed on the device (k_util.hip): 2-bit words + exception list
-  const size_t nb = ctx->h_bases.size();
-  DBuf<uint8_t> d_raw; DBuf<int64_t> d_off; DBuf<int8_t> d_lut; DBuf<int32_t> d_excnt, d_exstart, d_tmp; DBuf<long long> d_bad;
-  HIPCHK(d_raw.alloc(nb + 16)); HIPCHK(d_off.alloc((size_t)n + 1)); HIPCHK(d_lut.alloc(256)); HIPCHK(d_excnt.alloc((size_t)n + 2)); HIPCHK(d_exstart.alloc((size_t)n + 2));
-  HIPCHK(d_tmp.alloc((size_t)scan_tmp_elems(n + 1))); HIPCHK(d_bad.alloc(1));
+  hipStream_t st = ctx->st;
+  const int64_t nb = n > 0 ? ctx->h_off[n] : 0;
+  int64_t CH = 64ll << 20;
+  if (const char *e = getenv("ITSX_PACK_CHUNK")) CH = std::max<int64_t>(70000, atoll(e));       // bytes; a read has at most 65535
+  CH = std::min<int64_t>(CH, std::max<int64_t>(nb, 70000));
+  constexpr int K = itsx_ctx::NSTAGE;
+  if (!dev_raw && (int64_t)ctx->stage_cap < CH) {
+    for (int k = 0; k < K; k++) {
+      if (ctx->stage_pin[k]) { (void)hipHostFree(ctx->stage_pin[k]); ctx->stage_pin[k] = nullptr; }
+      HIPCHK(hipHostMalloc(&ctx->stage_pin[k], (size_t)CH, hipHostMallocDefault));
+      HIPCHK(ctx->stage_dev[k].alloc((size_t)CH + 16, true));
+      if (!ctx->stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+    }
+    ctx->stage_cap = (size_t)CH;
+  }
+  DBuf<int64_t> &d_off = ctx->w_pk_off; DBuf<int8_t> &d_lut = ctx->w_pk_lut; DBuf<int32_t> &d_excnt = ctx->w_pk_excnt, &d_exstart = ctx->w_pk_exstart, &d_tmp = ctx->w_pk_tmp;
+  DBuf<long long> &d_bad = ctx->w_pk_bad;
+  HIPCHK(d_off.alloc((size_t)n + 1)); HIPCHK(d_lut.alloc(256)); HIPCHK(d_excnt.alloc((size_t)n + 2)); HIPCHK(d_exstart.alloc((size_t)n + 2));
+  HIPCHK(d_tmp.alloc((size_t)scan_tmp_elems(n + 2))); HIPCHK(d_bad.alloc(4));
   HIPCHK(ctx->d_words.alloc((size_t)ctx->h_woff[n] + 1)); HIPCHK(ctx->d_woff.alloc((size_t)n + 1)); HIPCHK(ctx->d_excoff.alloc((size_t)n + 1)); HIPCHK(ctx->d_len.alloc((size_t)n + 1));
-  if (nb) HIPCHK(hipMemcpyAsync(d_raw.p, ctx->h_bases.data(), nb, hipMemcpyHostToDevice, ctx->st));
-  HIPCHK(hipMemcpyAsync(d_off.p, ctx->h_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->st));
-  HIPCHK(hipMemcpyAsync(ctx->d_woff.p, ctx->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, ctx->st));
-  if (n) HIPCHK(hipMemcpyAsync(ctx->d_len.p, ctx->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->st));
-  HIPCHK(hipMemcpyAsync(d_lut.p, g_code, 256, hipMemcpyHostToDevice, ctx->st));
-  HIPCHK(hipMemsetAsync(d_bad.p, 0x7f, sizeof(long long), ctx->st));
-  HIPCHK(hipMemsetAsync(d_excnt.p, 0, ((size_t)n + 2) * 4, ctx->st));
-  launch_pack(d_raw.p, d_off.p, ctx->d_woff.p, n, d_lut.p, ctx->d_words.p, d_excnt.p, d_bad.p, ctx->st);
-  launch_exclusive_scan(d_excnt.p, d_exstart.p, n + 1, d_tmp.p, ctx->st);
-  long long bad = 0; int32_t nexc = 0;
-  HIPCHK(hipMemcpyAsync(&bad, d_bad.p, sizeof(bad), hipMemcpyDeviceToHost, ctx->st));
-  HIPCHK(hipMemcpyAsync(&nexc, d_exstart.p + n, sizeof(nexc), hipMemcpyDeviceToHost, ctx->st));
-  HIPCHK(hipStreamSynchronize(ctx->st));
-  if (bad >= 0 && bad < n) SET_ERR(ctx, ITSX_E_FORMAT, "read " + std::to_string(bad) + " contains a symbol outside the IUPAC DNA alphabet");
-  HIPCHK(ctx->d_exc.alloc((size_t)nexc + 1));
-  launch_pack_exc(d_raw.p, d_off.p, n, d_lut.p, d_excnt.p, d_exstart.p, ctx->d_excoff.p, ctx->d_exc.p, ctx->st);
-  HIPCHK(hipStreamSynchronize(ctx->st));
-  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(d_off.p, ctx->h_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->d_woff.p, ctx->h_woff.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+  if (n) HIPCHK(hipMemcpyAsync(ctx->d_len.p, ctx->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_lut.p, g_code, 256, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(d_excnt.p, 0, ((size_t)n + 2) * 4, st));
+  // the exception list is sized by a guess; a read set with more non-ACGT symbols than that repeats the exception pass
+  int64_t ecap = std::max<int64_t>((int64_t)ctx->d_exc.cap, nb / 256 + 4096);
+  if (const char *e = getenv("ITSX_PACK_ECAP")) ecap = std::max<int64_t>(1, atoll(e));
+  HIPCHK(ctx->d_exc.alloc((size_t)ecap));
+  int copy_threads = std::max(1, std::min(8, itsx_io::io_threads()));
+  long long hb[4] = {0, 0, 0, 0};                        // exceptions so far, list overflow, first illegal read, -
+  for (int pass = 0; pass < 2; pass++) {                 // pass 1 only when the exception list was too small
+    const long long init[4] = {0, 0, 0x7f7f7f7f7f7f7f7fll, 0};
+    HIPCHK(hipMemcpyAsync(d_bad.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    int64_t r0 = 0; int c = 0;
+    if (dev_raw && n > 0) {                              // the text is in device memory already: one chunk, no staging
+      if (pass == 0) launch_pack(dev_raw, 0, d_off.p, ctx->d_woff.p, 0, n, d_lut.p, ctx->d_words.p, d_excnt.p, d_bad.p + 2, st);
+      launch_exclusive_scan(d_excnt.p, d_exstart.p, n + 1, d_tmp.p, st);
+      launch_pack_exc(dev_raw, 0, d_off.p, 0, n, d_lut.p, d_excnt.p, d_exstart.p, d_bad.p, ecap, ctx->d_excoff.p, ctx->d_exc.p, st);
+      r0 = n;
+    }
+    while (r0 < n) {
+      // reads [r0, r1): as many whole reads as fit the staging buffer
+      const int64_t b0 = ctx->h_off[r0];
+      int64_t r1 = (int64_t)(std::upper_bound(ctx->h_off.begin() + r0, ctx->h_off.begin() + n + 1, b0 + CH) - ctx->h_off.begin()) - 1;
+      r1 = std::min<int64_t>(n, std::max<int64_t>(r1, r0 + 1));
+      const int64_t bytes = ctx->h_off[r1] - b0;
+      const int k = c % K;
+      if (c >= K) HIPCHK(hipEventSynchronize(ctx->stage_ev[k]));
+      if (bytes > 0) {
+        char *dst = (char *)ctx->stage_pin[k];
+        const int T = bytes >= (4 << 20) ? copy_threads : 1;
+        on_threads(T, [&](int t) { const int64_t lo = bytes * t / T, hi = bytes * (t + 1) / T; memcpy(dst + lo, bases + b0 + lo, (size_t)(hi - lo)); });
+        HIPCHK(hipMemcpyAsync(ctx->stage_dev[k].p, dst, (size_t)bytes, hipMemcpyHostToDevice, st));
+      }
+      if (pass == 0) launch_pack(ctx->stage_dev[k].p, b0, d_off.p, ctx->d_woff.p, r0, r1, d_lut.p, ctx->d_words.p, d_excnt.p, d_bad.p + 2, st);
+      launch_exclusive_scan(d_excnt.p + r0, d_exstart.p + r0, r1 - r0 + 1, d_tmp.p, st);
+      launch_pack_exc(ctx->stage_dev[k].p, b0, d_off.p, r0, r1, d_lut.p, d_excnt.p, d_exstart.p, d_bad.p, ecap, ctx->d_excoff.p, ctx->d_exc.p, st);
+      HIPCHK(hipEventRecord(ctx->stage_ev[k], st));
+      r0 = r1; c++;
+    }
+    if (n == 0) HIPCHK(hipMemsetAsync(ctx->d_excoff.p, 0, 8, st));
+    HIPCHK(hipMemcpyAsync(hb, d_bad.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (hb[2] >= 0 && hb[2] < n) SET_ERR(ctx, ITSX_E_FORMAT, "read " + std::to_string(hb[2]) + " contains a symbol outside the IUPAC DNA alphabet");
+    if (!hb[1]) break;
+    if (pass == 1) SET_ERR(ctx, ITSX_E_DEVICE, "exception list overflow after resizing");
+    ecap = hb[0] + 1;
+    HIPCHK(ctx->d_exc.alloc((size_t)ecap));
+  }
   ctx->rd.words = ctx->d_words.p; ctx->rd.woff = ctx->d_woff.p; ctx->rd.len = ctx->d_len.p;
   ctx->rd.excoff = ctx->d_excoff.p; ctx->rd.exc = ctx->d_exc.p; ctx->rd.n = n;
   ctx->have_derep = ctx->have_search = ctx->have_final = false;
   ctx->stats.n_reads = n;
   ctx->S = 1; ctx->sel_sample = -1; ctx->h_sample.clear(); ctx->h_usample.clear();      // a new read set is one sample until told otherwise
+  ctx->stats.ms_pack = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
   return ITSX_OK;
 }
 
-int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n, const char *names, const int64_t *name_offsets)
+static int set_reads_impl(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n, const char *names, const int64_t *name_offsets, bool borrow)
 {
-  CTXCHK(ctx && offsets && n >= 0 && (bases || offsets[n] == 0));
+  CTXCHK(ctx && offsets && n >= 0 && (bases || offsets[n] == offsets[0]));
   if (n >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
   ctx->N = n;
   ctx->h_off.assign(offsets, offsets + n + 1);
   const int64_t base0 = offsets[0];
   for (auto &o : ctx->h_off) o -= base0;
-  ctx->h_bases.assign(bases + base0, (size_t)(offsets[n] - base0));
+  const char *view = nullptr;
+  if (borrow) { std::string().swap(ctx->h_bases); view = bases ? bases + base0 : ""; }
+  else if (bases) ctx->h_bases.assign(bases + base0, (size_t)(offsets[n] - base0));
+  else ctx->h_bases.clear();
   ctx->h_names.clear();
   if (names && name_offsets) {
     ctx->h_names.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) ctx->h_names[i].assign(names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i]));
   }
-  return pack_and_upload(ctx);
+  return pack_and_upload(ctx, view);
+}
+int itsx_set_reads(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n, const char *names, const int64_t *name_offsets)
+{ return set_reads_impl(ctx, bases, offsets, n, names, name_offsets, false); }
+int itsx_set_reads_view(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n, const char *names, const int64_t *name_offsets)
+{ return set_reads_impl(ctx, bases, offsets, n, names, name_offsets, true); }
+// the text already lives in device memory (the output of a device-side parser or of the merge kernel): packed where it is
+int itsx_set_reads_device(itsx_ctx *ctx, const void *d_bases, const int64_t *offsets, int64_t n, const char *names, const int64_t *name_offsets)
+{
+  CTXCHK(ctx && offsets && n >= 0 && (d_bases || offsets[n] == offsets[0]));
+  if (n >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
+  ctx->N = n;
+  ctx->h_off.assign(offsets, offsets + n + 1);
+  const int64_t base0 = offsets[0];
+  for (auto &o : ctx->h_off) o -= base0;
+  std::string().swap(ctx->h_bases);
+  ctx->h_names.clear();
+  if (names && name_offsets) {
+    ctx->h_names.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) ctx->h_names[i].assign(names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i]));
+  }
+  static const uint8_t none = 0;
+  return pack_and_upload(ctx, nullptr, d_bases ? (const uint8_t *)d_bases + base0 : &none);
 }
 
 // ---- FASTA / FASTQ text -> records (labels up to the first blank, as vsearch labels them).  Large texts are cut at record
@@ -1738,6 +1828,18 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_positions(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_side.p, bl.p, br.p, uind.p, st);
   if (U > 0) hipLaunchKernelGGL(k_rep_coords, dim3((U + 255) / 256), dim3(256), 0, st, U, bl.p, br.p, uind.p, ctx->d_seed_read.p, ctx->rd.len, us.p, ue.p, ut.p);
+  {   // parity-risk counters (itsx_stats): winners out of clustered regions, pairs at the region cap
+    DBuf<int32_t> &uflag = ctx->w_uflag; DBuf<int64_t> &d_c = ctx->w_counters;
+    HIPCHK(uflag.alloc((size_t)U + 1)); HIPCHK(d_c.alloc(8));
+    HIPCHK(hipMemsetAsync(uflag.p, 0, ((size_t)U + 1) * 4, st)); HIPCHK(hipMemsetAsync(d_c.p, 0, 8 * sizeof(int64_t), st));
+    for (size_t c = 0; c < ctx->dom_n.size(); c++)
+      if (ctx->dom_n[c] > 0) launch_position_flags(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_side.p, bl.p, br.p, uflag.p, st);
+    launch_count_flags(uflag.p, U, ctx->d_uniq_of.p, n, (unsigned long long *)d_c.p, st);
+    int64_t hc[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->stats.n_uniq_multi_winner = hc[0]; ctx->stats.n_reads_multi_winner = hc[1]; ctx->stats.n_uniq_region_cap = hc[2]; ctx->stats.n_reads_region_cap = hc[3];
+  }
   if (!per_read) {
     if (U > 0) {
       HIPCHK(hipMemcpyAsync(start, us.p, (size_t)U * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(stop, ue.p, (size_t)U * 4, hipMemcpyDeviceToHost, st));
@@ -1827,15 +1929,21 @@ int itsx_write_uc(const itsx_ctx *ctx, const char *path)
   return ITSX_OK;
 }
 
-int itsx_write_rep_fasta(const itsx_ctx *ctx, const char *path)
+int itsx_write_rep_fasta(const itsx_ctx *cctx, const char *path)
 {
-  CTXCHK(ctx && path && ctx->have_derep);
+  CTXCHK(cctx && path && cctx->have_derep);
+  itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
+  if (!ctx->bases_view) {                                   // reads handed over in device memory: the text comes back once
+    ctx->h_bases.resize((size_t)ctx->h_off[(size_t)ctx->N]);
+    if (!ctx->h_bases.empty()) HIPCHK(hipMemcpy(&ctx->h_bases[0], ctx->dev_bases, ctx->h_bases.size(), hipMemcpyDeviceToHost));
+    ctx->bases_view = ctx->h_bases.data();
+  }
   FILE *f = fopen(path, "w");
   if (!f) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + path);
   for (int32_t u : cluster_order(ctx)) {
     const int64_t s = ctx->h_seed_read[u];
     fprintf(f, ">%s\n", read_name(ctx, s).c_str());
-    const char *b = ctx->h_bases.data() + ctx->h_off[s]; const int64_t L = ctx->h_len[s];
+    const char *b = ctx->bases_view + ctx->h_off[s]; const int64_t L = ctx->h_len[s];
     for (int64_t i = 0; i < L; i += 80) { fwrite(b + i, 1, (size_t)std::min<int64_t>(80, L - i), f); fputc('\n', f); }
   }
   fclose(f);

@@ -105,10 +105,11 @@ void launch_merge(const MergeArgs &a, hipStream_t st);
 // exclusive prefix sum of n int32 values (n < 2^31); tmp must hold scan_tmp_elems(n) int32
 int64_t scan_tmp_elems(int64_t n);
 void    launch_exclusive_scan(const int32_t *in, int32_t *out, int64_t n, int32_t *tmp, hipStream_t st);
-void    launch_pack(const uint8_t *raw, const int64_t *off, const int64_t *woff, int64_t n, const int8_t *lut, uint32_t *words, int32_t *excnt,
-                    long long *first_bad, hipStream_t st);
-void    launch_pack_exc(const uint8_t *raw, const int64_t *off, int64_t n, const int8_t *lut, const int32_t *excnt, const int32_t *exstart,
-                        int64_t *excoff, uint32_t *exc, hipStream_t st);
+void    launch_pack(const uint8_t *raw, int64_t raw_base, const int64_t *off, const int64_t *woff, int64_t r0, int64_t r1, const int8_t *lut,
+                    uint32_t *words, int32_t *excnt, long long *first_bad, hipStream_t st);
+// exstart: exclusive scan of excnt over reads [r0, r1] (exstart[r1] = the chunk's total); ebase[0] advances by it, excoff[r1] is set
+void    launch_pack_exc(const uint8_t *raw, int64_t raw_base, const int64_t *off, int64_t r0, int64_t r1, const int8_t *lut, const int32_t *excnt,
+                        const int32_t *exstart, long long *ebase, int64_t ecap, int64_t *excoff, uint32_t *exc, hipStream_t st);
 void    launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st);
 
 // ---- k_msv.hip

@@ -1214,6 +1214,14 @@ __global__ void __launch_bounds__(256) k_finalize(itsx_domain *__restrict__ dom,
 }
 // key = [24b tenths+bias][20b ~prof][4b ~dom][16b coordinate]; atomicMax picks the highest %.1f score,
 // then the earliest profile, then the earliest domain -- ItsPosition._score's "first strictly greater".
+DEV unsigned long long position_key(const itsx_domain &d, int sd)
+{
+  long long tenths = (long long)__builtin_rint((double)d.bitscore * 10.0) + (1ll << 23);
+  if (tenths < 0) tenths = 0; if (tenths > (1ll << 24) - 1) tenths = (1ll << 24) - 1;
+  const unsigned long long coord = (unsigned long long)((sd == 1 ? d.jenv : d.ienv) & 0xffff);
+  return ((unsigned long long)tenths << 40) | ((unsigned long long)(0xFFFFF - d.prof) << 20) |
+         ((unsigned long long)(15 - (d.dom_idx & 15)) << 16) | coord;
+}
 __global__ void __launch_bounds__(256) k_positions(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ side /*[P] 1 left 2 right*/,
                                                    unsigned long long *__restrict__ best_l, unsigned long long *__restrict__ best_r,
                                                    int32_t *__restrict__ in_ddict)
@@ -1225,12 +1233,35 @@ __global__ void __launch_bounds__(256) k_positions(const itsx_domain *__restrict
   in_ddict[d.rep] = 1;
   const int sd = side[d.prof];
   if (sd == 0) return;
-  long long tenths = (long long)__builtin_rint((double)d.bitscore * 10.0) + (1ll << 23);
-  if (tenths < 0) tenths = 0; if (tenths > (1ll << 24) - 1) tenths = (1ll << 24) - 1;
-  const unsigned long long coord = (unsigned long long)((sd == 1 ? d.jenv : d.ienv) & 0xffff);
-  const unsigned long long key = ((unsigned long long)tenths << 40) | ((unsigned long long)(0xFFFFF - d.prof) << 20) |
-                                 ((unsigned long long)(15 - (d.dom_idx & 15)) << 16) | coord;
-  atomicMax(sd == 1 ? &best_l[d.rep] : &best_r[d.rep], key);
+  atomicMax(sd == 1 ? &best_l[d.rep] : &best_r[d.rep], position_key(d, sd));
+}
+// parity-risk bookkeeping, after k_positions: uflag[rep] bit 0 = the winning left/right domain carries flags bit 0 (its
+// region is one hmmsearch resolves by stochastic clustering), bit 1 = a pair of either side hit the region cap
+__global__ void __launch_bounds__(256) k_position_flags(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ side,
+                                                        const unsigned long long *__restrict__ best_l, const unsigned long long *__restrict__ best_r,
+                                                        int32_t *__restrict__ uflag)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const itsx_domain d = dom[i];
+  if (d.dom_idx < 0 || !d.dom_reported) return;
+  const int sd = side[d.prof];
+  if (sd == 0) return;
+  int f = 0;
+  if ((d.flags & 1) && position_key(d, sd) == (sd == 1 ? best_l[d.rep] : best_r[d.rep])) f |= 1;
+  if (d.flags & 2) f |= 2;
+  if (f) atomicOr(&uflag[d.rep], f);
+}
+// c[0] uniques with bit 0, c[1] reads with bit 0, c[2] uniques with bit 1, c[3] reads with bit 1
+__global__ void __launch_bounds__(256) k_count_flags(const int32_t *__restrict__ uflag, int32_t U, const int32_t *__restrict__ uniq_of, int64_t n,
+                                                     unsigned long long *__restrict__ c)
+{
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t u = t0; u < U; u += stride) { const int f = uflag[u]; a0 += f & 1; a2 += (f >> 1) & 1; }
+  for (int64_t r = t0; r < n; r += stride) { const int u = uniq_of[r]; const int f = u >= 0 ? uflag[u] : 0; a1 += f & 1; a3 += (f >> 1) & 1; }
+  for (int d = 32; d >= 1; d >>= 1) { a0 += __shfl_down(a0, d, 64); a1 += __shfl_down(a1, d, 64); a2 += __shfl_down(a2, d, 64); a3 += __shfl_down(a3, d, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&c[0], a0); atomicAdd(&c[1], a1); atomicAdd(&c[2], a2); atomicAdd(&c[3], a3); }
 }
 
 // ---- host launchers -----------------------------------------------------------------------
@@ -1300,6 +1331,17 @@ void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, uns
 {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, side, bl, br, in_ddict);
+}
+
+void launch_position_flags(const itsx_domain *dom, int64_t n, const int8_t *side, const unsigned long long *bl, const unsigned long long *br,
+                           int32_t *uflag, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_position_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, side, bl, br, uflag);
+}
+void launch_count_flags(const int32_t *uflag, int32_t U, const int32_t *uniq_of, int64_t n, unsigned long long *c, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_count_flags, dim3(1024), dim3(256), 0, st, uflag, U, uniq_of, n, c);
 }
 
 }  // namespace itsx

@@ -77,22 +77,24 @@ void launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStrea
 }  // namespace itsx
 
 // ------------------------------------------------------------------ packing reads on the device
-// The boundary hands over ASCII bases; they are uploaded as they are and packed here (2 bits per base, 16 bases per
-// word, every read on a word boundary; non-ACGT symbols are 0 in the 2-bit plane and listed as (pos << 4 | code)
-// exceptions in position order).  One wave per read, one lane per 16-base word.
+// The boundary hands over ASCII bases; they are uploaded as they are -- in chunks of whole reads through pinned staging
+// buffers (engine.hip: pack_and_upload) -- and packed here (2 bits per base, 16 bases per word, every read on a word
+// boundary; non-ACGT symbols are 0 in the 2-bit plane and listed as (pos << 4 | code) exceptions in position order).
+// One wave per read, one lane per 16-base word.  `raw` holds the bases of reads [r0, r1) only: byte raw_base of the
+// whole read set is raw[0].
 namespace itsx {
-__global__ void __launch_bounds__(256) k_pack_words(const uint8_t *__restrict__ raw, const int64_t *__restrict__ off, const int64_t *__restrict__ woff,
-                                                    int64_t n, const int8_t *__restrict__ lut, uint32_t *__restrict__ words,
-                                                    int32_t *__restrict__ excnt, long long *__restrict__ first_bad)
+__global__ void __launch_bounds__(256) k_pack_words(const uint8_t *__restrict__ raw, int64_t raw_base, const int64_t *__restrict__ off,
+                                                    const int64_t *__restrict__ woff, int64_t r0, int64_t r1, const int8_t *__restrict__ lut,
+                                                    uint32_t *__restrict__ words, int32_t *__restrict__ excnt, long long *__restrict__ first_bad)
 {
   __shared__ int8_t code[256];
   code[threadIdx.x] = lut[threadIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t r = wave; r < n; r += nwaves) {
-    const int64_t o = off[r];
-    const int L = (int)(off[r + 1] - o);
+  for (int64_t r = r0 + wave; r < r1; r += nwaves) {
+    const int64_t o = off[r] - raw_base;
+    const int L = (int)(off[r + 1] - off[r]);
     const int nw = L > 0 ? (L + 15) >> 4 : 1;
     int ne = 0; bool bad = false;
     for (int k = lane; k < nw; k += 64) {
@@ -111,30 +113,39 @@ __global__ void __launch_bounds__(256) k_pack_words(const uint8_t *__restrict__ 
     if (__ballot(bad) && lane == 0) atomicMin(first_bad, (long long)r);
   }
 }
-// exceptions are rare: one thread per read that has any, positions ascending
-__global__ void __launch_bounds__(256) k_pack_exc(const uint8_t *__restrict__ raw, const int64_t *__restrict__ off, int64_t n, const int8_t *__restrict__ lut,
-                                                  const int32_t *__restrict__ excnt, const int32_t *__restrict__ exstart, int64_t *__restrict__ excoff,
-                                                  uint32_t *__restrict__ exc)
+// exceptions are rare: one thread per read that has any, positions ascending.  exstart = exclusive scan of excnt over THIS
+// chunk of reads; ebase[0] = exceptions of all chunks before it, ebase[1] = set when the list would outgrow `ecap`
+__global__ void __launch_bounds__(256) k_pack_exc(const uint8_t *__restrict__ raw, int64_t raw_base, const int64_t *__restrict__ off, int64_t r0, int64_t r1,
+                                                  const int8_t *__restrict__ lut, const int32_t *__restrict__ excnt, const int32_t *__restrict__ exstart,
+                                                  long long *__restrict__ ebase, int64_t ecap, int64_t *__restrict__ excoff, uint32_t *__restrict__ exc)
 {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > n) return;
-  if (r == n) { excoff[n] = exstart[n]; return; }
-  excoff[r] = exstart[r];
-  if (excnt[r] == 0) return;
-  const int64_t o = off[r];
-  const int L = (int)(off[r + 1] - o);
-  uint32_t *e = exc + exstart[r];
+  const int64_t r = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= r1) return;
+  const int64_t g = (int64_t)ebase[0] + exstart[r];
+  excoff[r] = g;
+  const int ne = excnt[r];
+  if (ne == 0) return;
+  if (g + ne > ecap) { ebase[1] = 1; return; }
+  const int64_t o = off[r] - raw_base;
+  const int L = (int)(off[r + 1] - off[r]);
+  uint32_t *e = exc + g;
   for (int i = 0; i < L; i++) { const int c = lut[raw[o + i]]; if (c > 3) *e++ = ((uint32_t)i << 4) | (uint32_t)c; }
 }
-void launch_pack(const uint8_t *raw, const int64_t *off, const int64_t *woff, int64_t n, const int8_t *lut, uint32_t *words, int32_t *excnt,
-                 long long *first_bad, hipStream_t st)
+__global__ void k_pack_advance(long long *__restrict__ ebase, const int32_t *__restrict__ chunk_total, int64_t *__restrict__ excoff_end)
 {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_pack_words, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 65536)), dim3(256), 0, st, raw, off, woff, n, lut, words, excnt, first_bad);
+  if (threadIdx.x == 0 && blockIdx.x == 0) { ebase[0] += chunk_total[0]; excoff_end[0] = (int64_t)ebase[0]; }
 }
-void launch_pack_exc(const uint8_t *raw, const int64_t *off, int64_t n, const int8_t *lut, const int32_t *excnt, const int32_t *exstart,
-                     int64_t *excoff, uint32_t *exc, hipStream_t st)
+void launch_pack(const uint8_t *raw, int64_t raw_base, const int64_t *off, const int64_t *woff, int64_t r0, int64_t r1, const int8_t *lut,
+                 uint32_t *words, int32_t *excnt, long long *first_bad, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_pack_exc, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, raw, off, n, lut, excnt, exstart, excoff, exc);
+  if (r1 <= r0) return;
+  hipLaunchKernelGGL(k_pack_words, dim3((unsigned)std::min<int64_t>((r1 - r0 + 3) / 4, 65536)), dim3(256), 0, st, raw, raw_base, off, woff, r0, r1, lut, words, excnt, first_bad);
+}
+void launch_pack_exc(const uint8_t *raw, int64_t raw_base, const int64_t *off, int64_t r0, int64_t r1, const int8_t *lut, const int32_t *excnt,
+                     const int32_t *exstart, long long *ebase, int64_t ecap, int64_t *excoff, uint32_t *exc, hipStream_t st)
+{
+  if (r1 > r0)
+    hipLaunchKernelGGL(k_pack_exc, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, st, raw, raw_base, off, r0, r1, lut, excnt, exstart, ebase, ecap, excoff, exc);
+  hipLaunchKernelGGL(k_pack_advance, dim3(1), dim3(64), 0, st, ebase, exstart + r1, excoff + r1);
 }
 }  // namespace itsx

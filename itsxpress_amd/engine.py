@@ -93,6 +93,8 @@ class Engine:
         return self.set_reads_buffer(blob, offs, names)
 
     def set_reads_buffer(self, blob, offsets, names=None):
+        """blob: bytes-like of ASCII bases (bytes, bytearray, numpy uint8 array); the engine keeps a pointer into it
+        (itsx_set_reads_view), and this object keeps the buffer alive until the next read set."""
         offsets = np.ascontiguousarray(offsets, np.int64)
         n = len(offsets) - 1
         nb = no = None
@@ -101,11 +103,28 @@ class Engine:
             no = np.zeros(n + 1, np.int64)
             np.cumsum(nl, out=no[1:])
             nb = "".join(names).encode()
-        cbuf = C.c_char_p(blob) if len(blob) else C.c_char_p(b"")
+        if isinstance(blob, np.ndarray):
+            blob = np.ascontiguousarray(blob, np.uint8)
+            cptr = C.c_void_p(blob.ctypes.data)
+        else:
+            if not isinstance(blob, bytes):
+                blob = bytes(blob)
+            cptr = C.cast(C.c_char_p(blob), C.c_void_p)
         self._keep = (blob, offsets, nb, no)
-        self._chk(self.L.itsx_set_reads(self.h, C.cast(cbuf, C.c_void_p), offsets.ctypes.data, n,
+        self._chk(self.L.itsx_set_reads_view(self.h, cptr, offsets.ctypes.data, n,
                                         C.cast(C.c_char_p(nb), C.c_void_p) if nb is not None else None,
                                         no.ctypes.data if no is not None else None))
+        self.n_reads = n
+        self.n_samples = 1
+        return n
+
+    def set_reads_device(self, dev_ptr, offsets, keep=None):
+        """ASCII bases already in device memory on this engine's GPU (dev_ptr: integer address); offsets int64[n+1] on the
+        host.  `keep`: any object that owns the device buffer (kept referenced until the next read set)."""
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        self._keep = (keep, offsets)
+        self._chk(self.L.itsx_set_reads_device(self.h, C.c_void_p(int(dev_ptr)), offsets.ctypes.data, n, None, None))
         self.n_reads = n
         self.n_samples = 1
         return n

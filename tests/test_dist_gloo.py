@@ -139,3 +139,20 @@ def test_assign_samples_balances_whole_samples():
         loads = [int(sizes[p].sum()) for p in parts]
         assert max(loads) - min(loads) <= int(sizes.max())                       # LPT: within one sample of even
     assert assign_samples([5, 1], 4) == [[0], [1], [], []]
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) must itself start two ranks and print one line with
+    n_gpus = 2: checked here with the engine-free self-test leg over gloo (the real leg needs GPUs)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ok"] is True

@@ -99,3 +99,108 @@ def test_search_is_invariant_under_permutation_revcomp_and_dereplication(engine,
     rep2, strand2, c2, z2 = run(reads[seeds])
     assert np.array_equal(rep2, np.arange(len(seeds))) and np.array_equal(z2, z0)
     assert np.array_equal(c2, c0[seeds])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: 10 M merged reads of 300-580 bases on one GPU -- the size bench.py's default line is quoted on.
+N_CFG2 = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def full2(engine, t_hmm_text):
+    import time
+    blob, offs = synth.make_reads(t_hmm_text, N_CFG2, config=3, fixed_len=0, len_range=(300, 580), as_array=True)
+    engine.load_profiles(text=_its2(t_hmm_text))
+    t0 = time.time()
+    engine.set_reads_buffer(blob, offs)
+    nu = engine.derep()
+    engine.search()
+    engine.finalize()
+    coords = engine.trim_coords("3_", "4_")
+    wall = time.time() - t0
+    rep_of, strand, uniq_of = engine.get_derep()
+    return dict(blob=blob, offs=offs, nu=nu, rep_of=rep_of, strand=strand, uniq_of=uniq_of, coords=coords,
+                stats=engine.stats(), domz=engine.get_domz(), wall=wall)
+
+
+def test_cfg2_size_runs_in_chunks_within_its_time_budget(full2):
+    st = full2["stats"]
+    assert st["n_reads"] == N_CFG2 and st["n_unique"] == full2["nu"] > N_CFG2 // 10
+    assert st["msv_launches"] > 1                                # the unique list went through several chunks
+    assert st["n_domain_overflow"] == 0 and st["hash_reseeds"] == 0
+    assert st["n_past_msv"] >= st["n_past_bias"] >= st["n_past_fwd"] > 0
+    assert st["n_reads_region_cap"] == 0
+    assert full2["wall"] < 90.0, "one cold pass over 10 M reads took %.1f s" % full2["wall"]     # ~10 s warm; first-use allocations included
+
+
+def test_cfg2_size_coordinates_are_cluster_consistent_and_in_range(full2):
+    start, stop, tlen, ind = full2["coords"]
+    r = full2["rep_of"]
+    lens = np.diff(full2["offs"])
+    assert (r >= 0).all() and np.array_equal(r[r], r) and (r <= np.arange(N_CFG2)).all()
+    for a in (start, stop, tlen, ind):
+        assert np.array_equal(a, a[r])                           # every read carries its representative's result
+    both = (start >= 0) & (stop >= 0)
+    assert both.mean() > 0.9
+    assert np.array_equal(tlen[both], lens[r][both])             # tlen = length of the representative
+    assert (lens == lens[r]).all()                               # exact dereplication: members have the seed's length
+    assert (start[both] >= 45).all() and (stop[both] <= tlen[both] - 44).all()
+    hit = ind > 0
+    assert ((start >= 0) | (stop >= 0))[~hit].sum() == 0         # no coordinates without a reported domain
+
+
+def test_cfg2_size_first_million_matches_an_independent_grouping(full2):
+    """first occurrences never look forward, so the engine's grouping of all 10 M reads, restricted to the first
+    million, must equal an independent grouping of that million alone"""
+    n = 1_000_000
+    blob, offs = full2["blob"], full2["offs"]
+    first = {}
+    exp_rep = np.empty(n, np.int64)
+    exp_strand = np.empty(n, np.int8)
+    raw = blob[:int(offs[n])].tobytes()
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    for i in range(n):
+        s = raw[offs[i]:offs[i + 1]]
+        k = first.get(s)
+        if k is None:
+            rcs = s.translate(comp)[::-1]
+            k = first.get(rcs)
+            if k is None:
+                first[s] = (i, s)
+                exp_rep[i] = i; exp_strand[i] = 1
+                continue
+        exp_rep[i] = k[0]
+        exp_strand[i] = 1 if k[1] == s else -1
+    assert np.array_equal(full2["rep_of"][:n], exp_rep)
+    assert np.array_equal(full2["strand"][:n], exp_strand)
+
+
+def test_cfg2_shape_is_invariant_under_permutation_and_dereplication(engine, t_hmm_text, full2):
+    """the checksum-of-the-whole-path properties of the 1 M test on half a million of the ragged reads"""
+    n = 500_000
+    blob, offs = full2["blob"], full2["offs"]
+    lens = np.diff(offs[:n + 1])
+    engine.load_profiles(text=_its2(t_hmm_text))
+
+    def take(idx):
+        ln = lens[idx]
+        o = np.zeros(len(idx) + 1, np.int64)
+        np.cumsum(ln, out=o[1:])
+        src = np.repeat(offs[idx] - o[:-1], ln) + np.arange(o[-1])
+        return blob[src], o
+
+    def run(b, o):
+        engine.set_reads_buffer(b, o)
+        engine.derep(strand_both=False)
+        engine.search()
+        engine.finalize()
+        rep_of, strand, uniq_of = engine.get_derep()
+        return rep_of, np.stack(engine.trim_coords("3_", "4_"), axis=1), engine.get_domz()
+
+    rep0, c0, z0 = run(blob[:int(offs[n])], offs[:n + 1])
+    perm = np.random.default_rng(6).permutation(n)
+    rep1, c1, z1 = run(*take(perm))
+    assert np.array_equal(z0, z1) and np.array_equal(c1, c0[perm])
+    seeds = np.flatnonzero(rep0 == np.arange(n))
+    rep2, c2, z2 = run(*take(seeds))
+    assert np.array_equal(rep2, np.arange(len(seeds))) and np.array_equal(z2, z0) and np.array_equal(c2, c0[seeds])

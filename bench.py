@@ -148,6 +148,9 @@ def cpu_baseline(hmm_its2, blob, offs, sample_reads, threads):
     return sample_reads / dt, dt, nc, coords, seqs
 
 
+T_START = time.time()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +162,10 @@ def main():
     ap.add_argument("--total-reads", type=int, default=0,
                     help="strong scaling: this many reads in total, sharded over the ranks (shards share their templates)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20-30 s of CPU work)")
-    ap.add_argument("--handover-steps", type=int, default=2, help="untimed-in-`value` steps fed from the host buffer (0 = skip)")
+    ap.add_argument("--handover-steps", type=int, default=1, help="steps fed from the host buffer, outside `value` (0 = skip)")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ITSX_BENCH_BUDGET_S", "540")),
+                    help="wall-clock budget of the whole run: the legs AFTER the K timed steps (host hand-over, CPU baseline) shrink or "
+                         "are skipped to stay inside it (the driver's limit is 600 s); the timed steps themselves are never cut")
     ap.add_argument("--cluster-id", type=float, default=1.0,
                     help="1.0 = exact dereplication (the default); < 1 runs row a2 (greedy clustering) instead")
     ap.add_argument("--taxa", choices=["T", "all"], default="T",
@@ -275,6 +281,15 @@ def main():
 
     # the same step fed from the host buffer (PCIe-inclusive), never part of `value`
     handover = None
+    step_s = dt / max(args.steps, 1)
+    left = torch.tensor([args.budget_s - (time.time() - T_START)], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(left, op=dist.ReduceOp.MIN)                      # every rank takes the same decision
+    left = float(left.item())
+    cpu_leg_s = 0.0 if (args.cpu_sample == 0 or world > 1) else 40.0
+    if args.handover_steps > 0 and left < args.handover_steps * step_s * 1.15 + cpu_leg_s + 15.0:
+        args.handover_steps = 0
+        handover = {"skipped": "wall-clock budget (--budget-s %.0f): %.0f s left after the timed steps" % (args.budget_s, left)}
     if args.handover_steps > 0:
         if use_dist:
             dist.barrier()
@@ -388,8 +403,10 @@ def main():
         }
         if args.cpu_sample != 0 and world == 1:          # the CPU baseline is a rank-0, N=1 leg only
             threads = os.cpu_count() or 1
-            if args.cpu_sample < 0:                      # the scalar port does ~55 (440-base) .. 80 (300-base) reads/s per core
-                args.cpu_sample = int(min(24000 if cfg2 else 40000, max(1200, (80 if cfg2 else 120) * threads)))
+            if args.cpu_sample < 0:                      # the scalar port does ~2.5 (440-base) .. 5 (300-base) reads/s per core
+                args.cpu_sample = int(min(24000 if cfg2 else 40000, max(1200, (64 if cfg2 else 120) * threads)))
+                room = args.budget_s - (time.time() - T_START) - 20.0     # ~25 s of CPU work, less when the budget is nearly spent
+                args.cpu_sample = int(max(600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
             m = min(args.cpu_sample, n_local)
             v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads)
             # trim-coordinate concordance (BASELINE metric): the engine on the very same sample against the baseline path

@@ -274,6 +274,10 @@ int itsx_debug_read_hashes(itsx_ctx *ctx, uint64_t *fwd, uint64_t *rc);
 /* packed representation of read i: words [ceil(len/16)], exception list (pos<<4|code) */
 int itsx_debug_packed_read(const itsx_ctx *ctx, int64_t i, uint32_t *words, int32_t *nwords,
                            uint32_t *exc, int32_t *nexc);
+/* PMC calibration (scripts/fetch_calib.py): stream `gbytes` GB `iters` times in one of the DP slab's access patterns --
+ * 0: read all 6 fields of a [row][6][64] float plane at 4 B per lane, 1: read 5 of the 6 fields (k_decode), 2: write all 6,
+ * 3: read 16 B per lane -- and report the bytes one launch touches, so rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled */
+int itsx_debug_calibrate(itsx_ctx *ctx, int pattern, double gbytes, int iters, int64_t *bytes_per_launch, double *ms_per_launch);
 /* deterministic log/exp evaluated ON THE DEVICE for n inputs */
 int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_log, double *out_exp);
 

@@ -2109,6 +2109,27 @@ int itsx_debug_packed_read(const itsx_ctx *ctx, int64_t i, uint32_t *words, int3
   return ITSX_OK;
 }
 
+// streams `gbytes` GB in slab pattern `pattern` (k_util.hip: launch_calib) `iters` times; returns the bytes one launch touches
+int itsx_debug_calibrate(itsx_ctx *ctx, int pattern, double gbytes, int iters, int64_t *bytes_per_launch, double *ms_per_launch)
+{
+  CTXCHK(ctx && pattern >= 0 && pattern <= 3 && gbytes > 0 && iters >= 1);
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t nwaves = 256 * 32;                          // 8 waves per SIMD, as k_decode runs
+  const int64_t row_floats = pattern == 3 ? 4 * 64 : 6 * 64;
+  const int64_t R = std::max<int64_t>(1, (int64_t)(gbytes * 1e9) / (nwaves * row_floats * 4));
+  DBuf<float> slab, out;
+  HIPCHK(slab.alloc((size_t)(nwaves * R * row_floats), true)); HIPCHK(out.alloc((size_t)nwaves * 64));
+  HIPCHK(hipMemsetAsync(slab.p, 0, (size_t)(nwaves * R * row_floats) * 4, ctx->st));
+  StageTimer tm(ctx->st);
+  for (int i = 0; i < iters; i++) launch_calib(pattern, slab.p, nwaves, R, out.p, ctx->st);
+  const float ms = tm.stop();
+  HIPCHK(hipGetLastError());
+  const int64_t touched = pattern == 1 ? 5 * 64 * 4 : row_floats * 4;
+  if (bytes_per_launch) *bytes_per_launch = nwaves * R * touched;
+  if (ms_per_launch) *ms_per_launch = ms / iters;
+  return ITSX_OK;
+}
+
 int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_log, double *out_exp)
 {
   CTXCHK(ctx && x && out_log && out_exp && n >= 0);

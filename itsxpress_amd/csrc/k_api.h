@@ -110,6 +110,8 @@ void    launch_pack(const uint8_t *raw, int64_t raw_base, const int64_t *off, co
 // exstart: exclusive scan of excnt over reads [r0, r1] (exstart[r1] = the chunk's total); ebase[0] advances by it, excoff[r1] is set
 void    launch_pack_exc(const uint8_t *raw, int64_t raw_base, const int64_t *off, int64_t r0, int64_t r1, const int8_t *lut, const int32_t *excnt,
                         const int32_t *exstart, long long *ebase, int64_t ecap, int64_t *excoff, uint32_t *exc, hipStream_t st);
+// PMC calibration streams: pattern 0 read 6 of 6 fields (4 B/lane), 1 read 5 of 6, 2 write 6 of 6, 3 read 16 B/lane
+void    launch_calib(int pattern, float *slab, int64_t nwaves, int64_t R, float *out, hipStream_t st);
 void    launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st);
 
 // ---- k_msv.hip

@@ -76,6 +76,44 @@ void launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStrea
 
 }  // namespace itsx
 
+// ------------------------------------------------------------------ PMC calibration streams (test hook)
+// Streams of known size in the slab access patterns of k_float.hip, so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be
+// calibrated for them (MI355X_MICROARCH.md, HBM: only 16-B-per-lane streams are calibrated there).  One wave per block;
+// wave w walks rows [w R, (w + 1) R) of a [row][6 fields][64 lanes] float plane, one row after the other, like k_decode.
+namespace itsx {
+__global__ void __launch_bounds__(64) k_calib_read4(const float *__restrict__ slab, int64_t R, int nf, float *__restrict__ out)
+{
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  float acc = 0.f;
+  for (int64_t r = 0; r < R; r++)
+    for (int f = 0; f < nf; f++) acc += slab[((r0 + r) * 6 + f) * 64 + lane];
+  out[(int64_t)blockIdx.x * 64 + lane] = acc;
+}
+__global__ void __launch_bounds__(64) k_calib_write4(float *__restrict__ slab, int64_t R, int nf)
+{
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  for (int64_t r = 0; r < R; r++)
+    for (int f = 0; f < nf; f++) slab[((r0 + r) * 6 + f) * 64 + lane] = (float)(r + f);
+}
+__global__ void __launch_bounds__(64) k_calib_read16(const float4 *__restrict__ slab, int64_t R, float *__restrict__ out)
+{
+  const int lane = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  float acc = 0.f;
+  for (int64_t r = 0; r < R; r++) { const float4 v = slab[(r0 + r) * 64 + lane]; acc += v.x + v.y + v.z + v.w; }
+  out[(int64_t)blockIdx.x * 64 + lane] = acc;
+}
+void launch_calib(int pattern, float *slab, int64_t nwaves, int64_t R, float *out, hipStream_t st)
+{
+  if (pattern == 0) hipLaunchKernelGGL(k_calib_read4, dim3((unsigned)nwaves), dim3(64), 0, st, slab, R, 6, out);
+  else if (pattern == 1) hipLaunchKernelGGL(k_calib_read4, dim3((unsigned)nwaves), dim3(64), 0, st, slab, R, 5, out);
+  else if (pattern == 2) hipLaunchKernelGGL(k_calib_write4, dim3((unsigned)nwaves), dim3(64), 0, st, slab, R, 6);
+  else hipLaunchKernelGGL(k_calib_read16, dim3((unsigned)nwaves), dim3(64), 0, st, (const float4 *)slab, R, out);
+}
+}  // namespace itsx
+
 // ------------------------------------------------------------------ packing reads on the device
 // The boundary hands over ASCII bases; they are uploaded as they are -- in chunks of whole reads through pinned staging
 // buffers (engine.hip: pack_and_upload) -- and packed here (2 bits per base, 16 bases per word, every read on a word

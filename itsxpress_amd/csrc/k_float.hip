@@ -414,6 +414,11 @@ DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
 // instead of one half of interleaved 3-KB rows.
 #define SLAB(a, row0, row, field, lane) \
   ((a).slab + ((field) >= 6 ? (a).slab_plane : (int64_t)0) + ((((row0) + (row)) * 6 + ((field) % 6)) * 64 + (lane)))
+// The slab rows are streamed once in each direction and never re-used from a cache: non-temporal accesses keep them from
+// evicting the profiles' transition tables (1.5 KB per wave-row through scalar loads) out of L2.  Same-box A/B at 1 M reads:
+// Forward 288.8 -> 284.1 ms, Backward 330.8 -> 323.5 ms, 1.041 M -> 1.060 M reads/s.
+#define SLAB_ST(p, v) __builtin_nontemporal_store((float)(v), (p))
+#define SLAB_LD(p) __builtin_nontemporal_load(p)
 
 
 // =========================================================================================
@@ -511,9 +516,9 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
           totscale = (float)((double)totscale + det_log((double)xE));
           xE = 1.0f;
         }
-        *SLAB(a, r0, i, 0, lane) = xE; *SLAB(a, r0, i, 1, lane) = xN;
-        *SLAB(a, r0, i, 2, lane) = xJ; *SLAB(a, r0, i, 3, lane) = xB;
-        *SLAB(a, r0, i, 4, lane) = xC; *SLAB(a, r0, i, 5, lane) = sc;
+        SLAB_ST(SLAB(a, r0, i, 0, lane), xE); SLAB_ST(SLAB(a, r0, i, 1, lane), xN);
+        SLAB_ST(SLAB(a, r0, i, 2, lane), xJ); SLAB_ST(SLAB(a, r0, i, 3, lane), xB);
+        SLAB_ST(SLAB(a, r0, i, 4, lane), xC); SLAB_ST(SLAB(a, r0, i, 5, lane), sc);
       }
     }
     const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
@@ -576,20 +581,20 @@ __global__ void __launch_bounds__(64, 2) k_bwd_decode(FloatArgs a, int wave0)
     struct FRow { float E, N, J, B, C, S; };
     auto load_f = [&](int i) {
       FRow f;
-      f.E = *SLAB(a, r0, i, 0, lane); f.N = *SLAB(a, r0, i, 1, lane); f.J = *SLAB(a, r0, i, 2, lane);
-      f.B = *SLAB(a, r0, i, 3, lane); f.C = *SLAB(a, r0, i, 4, lane); f.S = *SLAB(a, r0, i, 5, lane);
+      f.E = SLAB_LD(SLAB(a, r0, i, 0, lane)); f.N = SLAB_LD(SLAB(a, r0, i, 1, lane)); f.J = SLAB_LD(SLAB(a, r0, i, 2, lane));
+      f.B = SLAB_LD(SLAB(a, r0, i, 3, lane)); f.C = SLAB_LD(SLAB(a, r0, i, 4, lane)); f.S = SLAB_LD(SLAB(a, r0, i, 5, lane));
       return f;
     };
     auto store_terms = [&](int i, const FRow &fc, const FRow &fp, float s) {
-      *SLAB(a, r0, i, 6, lane) = fc.E * xE * fc.S;
-      *SLAB(a, r0, i, 7, lane) = fp.N * xN * ploop;
-      *SLAB(a, r0, i, 8, lane) = fp.J * xJ * ploop;
-      *SLAB(a, r0, i, 9, lane) = fc.B * xB * fc.S;
-      *SLAB(a, r0, i, 10, lane) = fp.C * xC * ploop;
+      SLAB_ST(SLAB(a, r0, i, 6, lane), fc.E * xE * fc.S);
+      SLAB_ST(SLAB(a, r0, i, 7, lane), fp.N * xN * ploop);
+      SLAB_ST(SLAB(a, r0, i, 8, lane), fp.J * xJ * ploop);
+      SLAB_ST(SLAB(a, r0, i, 9, lane), fc.B * xB * fc.S);
+      SLAB_ST(SLAB(a, r0, i, 10, lane), fp.C * xC * ploop);
       // Forward's scale over Backward's: 1 exactly (x / x) unless the lane rescaled on its own -- the division is taken only then
       float ratio = 1.0f;
       if (fc.S != s) { ratio = fc.S / s; asm volatile("" : "+v"(ratio)); }
-      *SLAB(a, r0, i, 11, lane) = ratio;
+      SLAB_ST(SLAB(a, r0, i, 11, lane), ratio);
     };
     FRow fcur, fprv;
     fcur.E = fcur.N = fcur.J = fcur.B = fcur.C = 0.f; fcur.S = sL; fprv = fcur;
@@ -672,9 +677,9 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
     struct DRow { float t2, t3, t4, t1, t5, rs; };
     auto load_row = [&](int j) {
       DRow d;
-      d.t2 = *SLAB(a, r0, j, 6, lane); d.t3 = *SLAB(a, r0, j, 7, lane);
-      d.t4 = *SLAB(a, r0, j, 8, lane); d.t1 = *SLAB(a, r0, j, 9, lane);
-      d.t5 = *SLAB(a, r0, j, 10, lane);
+      d.t2 = SLAB_LD(SLAB(a, r0, j, 6, lane)); d.t3 = SLAB_LD(SLAB(a, r0, j, 7, lane));
+      d.t4 = SLAB_LD(SLAB(a, r0, j, 8, lane)); d.t1 = SLAB_LD(SLAB(a, r0, j, 9, lane));
+      d.t5 = SLAB_LD(SLAB(a, r0, j, 10, lane));
       d.rs = own ? *SLAB(a, r0, j, 11, lane) : 1.0f;
       return d;
     };

@@ -47,7 +47,8 @@ typedef struct {
   int32_t tlen;
   int32_t ienv, jenv;     /* 1-based envelope coordinates */
   int32_t dom_idx, ndom;
-  int32_t flags;          /* bit0: region looked multidomain; it was kept as ONE envelope */
+  int32_t flags;          /* bit0: the envelope was defined by stochastic traceback clustering of a multidomain region
+                           * (hmmsearch's region_trace_ensemble); with ITSX_NO_ENSEMBLE=1: such a region kept as ONE envelope */
   float   envsc;          /* nats */
   float   domcorrection;  /* nats */
   float   dombias;        /* nats */
@@ -91,6 +92,10 @@ typedef struct {
    * (itsx_domain.flags bit 0), and uniques / reads with a (representative, profile) pair that had more regions than
    * the engine keeps (bit 1) among the domains of the two sides */
   int64_t n_uniq_multi_winner, n_reads_multi_winner, n_uniq_region_cap, n_reads_region_cap;
+  /* multidomain regions of the last search: resolved by stochastic traceback clustering (k_ensemble.hip), of which
+   * n_mr_failed hit a bookkeeping limit or an unsampleable matrix and yielded nothing; envelopes the clustering defined */
+  int64_t n_mr_clustered, n_mr_failed, n_mr_envelopes;
+  float   ms_ensemble;       int32_t pad3;
 } itsx_stats;
 
 int         itsx_abi_version(void);

@@ -202,6 +202,8 @@ struct itsx_ctx {
   DBuf<int64_t> w_seg_start, w_idx, w_rseg, w_dz, w_counters, w_useg;
   DBuf<int32_t> w_rrep, w_ruq, w_rurank;
   DBuf<WaveDesc> w_waves, w_rw; DBuf<RegionRec> w_raw; DBuf<float> w_slab, w_eslab;
+  DBuf<int32_t> w_mrcnt, w_mroff, w_mrlen, w_mrloff, w_mrrows; DBuf<MrRec> w_mr; DBuf<MrOut> w_mrout; DBuf<int64_t> w_n2off; DBuf<float> w_n2sc, w_mrslab;
+  DBuf<uint8_t> w_mrscratch; DBuf<WaveDesc> w_mrwaves;
   DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri, w_uflag;
 };
 
@@ -1123,7 +1125,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_failed = S.n_mr_envelopes = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false;
   if (U == 0) return ITSX_OK;
@@ -1360,6 +1362,62 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     S.ms_filters += tm.stop();
   }
   StageTimer tm_dom(st);
+  // ---- multidomain regions: resolved into envelopes by stochastic traceback clustering (k_ensemble.hip)
+  int64_t NMR = 0;
+  const bool ensemble = !(getenv("ITSX_NO_ENSEMBLE") && atoi(getenv("ITSX_NO_ENSEMBLE")) != 0);
+  if (ensemble) {
+    DBuf<int32_t> &mrcnt = ctx->w_mrcnt, &mroff = ctx->w_mroff, &mrlen = ctx->w_mrlen, &mrloff = ctx->w_mrloff, &stmp = ctx->w_scan2;
+    HIPCHK(mrcnt.alloc((size_t)NP + 2)); HIPCHK(mroff.alloc((size_t)NP + 2)); HIPCHK(mrlen.alloc((size_t)NP + 2)); HIPCHK(mrloff.alloc((size_t)NP + 2));
+    HIPCHK(stmp.alloc((size_t)scan_tmp_elems(NP + 2)));
+    launch_mr_count(ctx->d_pout.p, d_raw.p, NP, mrcnt.p, mrlen.p, st);
+    launch_exclusive_scan(mrcnt.p, mroff.p, NP + 1, stmp.p, st);
+    launch_exclusive_scan(mrlen.p, mrloff.p, NP + 1, stmp.p, st);
+    int32_t tot[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&tot[0], mroff.p + NP, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&tot[1], mrloff.p + NP, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    NMR = tot[0];
+    if (tot[1] < 0) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "multidomain regions of one chunk span more than 2^31 residues");
+    if (NMR > 0) {
+      StageTimer tm_e(st);
+      HIPCHK(ctx->w_mr.alloc((size_t)NMR)); HIPCHK(ctx->w_mrout.alloc((size_t)NMR)); HIPCHK(ctx->w_n2off.alloc((size_t)NMR + 1)); HIPCHK(ctx->w_n2sc.alloc((size_t)tot[1] + 1));
+      launch_mr_fill(ctx->d_pout.p, d_raw.p, NP, mroff.p, mrloff.p, ctx->w_mr.p, ctx->w_n2off.p, st);
+      const int NMW = (int)((NMR + 63) / 64);
+      std::vector<WaveDesc> mw((size_t)NMW);
+      for (int w = 0; w < NMW; w++) { mw[(size_t)w] = WaveDesc{}; mw[(size_t)w].prof = -1; mw[(size_t)w].first = (int64_t)w * 64; mw[(size_t)w].count = (int32_t)std::min<int64_t>(64, NMR - (int64_t)w * 64); }
+      HIPCHK(upload(ctx->w_mrwaves, mw, st)); HIPCHK(ctx->w_mrrows.alloc((size_t)NMW));
+      launch_mr_wave_rows(ctx->w_mrwaves.p, NMW, ctx->w_mr.p, ctx->w_mrrows.p, st);
+      std::vector<int32_t> mrows((size_t)NMW);
+      HIPCHK(hipMemcpyAsync(mrows.data(), ctx->w_mrrows.p, (size_t)NMW * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      const int64_t mrow_bytes = (int64_t)MRV * 64 * 16;
+      const int64_t mbudget = std::max<int64_t>(1, (int64_t)(std::min(slab_gb, 8.0) * (1 << 30)) / mrow_bytes);
+      const int64_t wave_cap = std::max<int64_t>(1, ((int64_t)2 << 30) / ((int64_t)MR_SCRATCH * 64));      // 2 GB of bookkeeping blocks per batch
+      int w0 = 0;
+      while (w0 < NMW) {
+        int w1 = w0; int64_t r = 0;
+        while (w1 < NMW && w1 - w0 < wave_cap && (w1 == w0 || r + mrows[(size_t)w1] <= mbudget)) { mw[(size_t)w1].slab = r; mw[(size_t)w1].rows = mrows[(size_t)w1]; r += mrows[(size_t)w1]; w1++; }
+        if ((size_t)r * MRV * 64 * 4 > ctx->w_mrslab.cap) HIPCHK(ctx->w_mrslab.alloc((size_t)r * MRV * 64 * 4));
+        HIPCHK(ctx->w_mrscratch.alloc((size_t)(w1 - w0) * 64 * MR_SCRATCH));
+        HIPCHK(hipMemcpyAsync(ctx->w_mrwaves.p + w0, mw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
+        MrArgs ma{};
+        ma.rd = ctx->rd; ma.sorted_uniq = d_sorted; ma.seed_read = ctx->d_seed_read.p; ma.prof = ctx->d_prof.p; ma.pairs = ctx->d_pairs.p;
+        ma.mr = ctx->w_mr.p; ma.mr0 = (int64_t)w0 * 64; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
+        ma.n2off = ctx->w_n2off.p; ma.n2sc = ctx->w_n2sc.p; ma.out = ctx->w_mrout.p; ma.scratch = ctx->w_mrscratch.p;
+        launch_mr_ensemble(ma, w1 - w0, w0, st);
+        w0 = w1;
+      }
+      DBuf<int64_t> &d_c = ctx->w_counters;
+      HIPCHK(d_c.alloc(8));
+      HIPCHK(hipMemsetAsync(d_c.p, 0, 8 * sizeof(int64_t), st));
+      launch_mr_apply(ctx->d_pout.p, d_raw.p, NP, mroff.p, ctx->w_mrout.p, (unsigned long long *)d_c.p, st);
+      int64_t hc[2] = {0, 0};
+      HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+      S.ms_ensemble += tm_e.stop();
+      HIPCHK(hipGetLastError());
+      S.n_mr_clustered += NMR; S.n_mr_failed += hc[0]; S.n_mr_envelopes += hc[1];
+    }
+  }
   // ---- compact regions into a profile-grouped list
   DBuf<int32_t> &d_rcnt = ctx->w_rcnt, &d_rpref = ctx->w_rpref, &d_scan_tmp = ctx->w_scan2;
   HIPCHK(d_rcnt.alloc((size_t)NP + 1)); HIPCHK(d_rpref.alloc((size_t)NP + 1)); HIPCHK(d_scan_tmp.alloc((size_t)scan_tmp_elems(NP + 1)));
@@ -1461,7 +1519,9 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     ScoreArgs sa{};
     sa.rd = ctx->rd; sa.sorted_uniq = d_sorted; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
     sa.flogsum = ctx->d_flogsum.p; sa.pairs = ctx->d_pairs.p; sa.pout = ctx->d_pout.p; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
-    sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = d_dom.p; sa.npairs = NP; sa.T = T; sa.domz = ctx->d_domz32.p; sa.usample = ctx->dev_usample(); sa.P = ctx->P;
+    sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = d_dom.p; sa.npairs = NP; sa.T = T;
+    if (NMR > 0) { sa.mr = ctx->w_mr.p; sa.mrout = ctx->w_mrout.p; sa.n2off = ctx->w_n2off.p; sa.n2sc = ctx->w_n2sc.p; sa.mr_off = ctx->w_mroff.p; }
+    sa.domz = ctx->d_domz32.p; sa.usample = ctx->dev_usample(); sa.P = ctx->P;
     launch_score(sa, st);
   }
   S.ms_domains += tm_dom.stop();

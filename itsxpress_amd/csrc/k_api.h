@@ -182,6 +182,36 @@ struct EnvArgs {
 };
 void launch_envelopes(const EnvArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 
+// ---- k_ensemble.hip: multidomain regions (stochastic traceback clustering)
+constexpr int MRV = 38;            // float4 vectors per matrix row: M, D, I of each of the 12 node groups | (E N J B) | (C SCALE - -)
+constexpr int MRENV = 4;           // envelopes kept per clustered region
+constexpr int MR_MAXD = 8;         // domains in one sampled path
+constexpr int MR_TCAP = 512;       // distinct sampled (i, j, k, m) tuples per region
+constexpr int MR_SCAP = 200 * MR_MAXD;
+constexpr int MR_NSIG = 32;        // clusters that reach the posterior threshold
+constexpr int MR_SCRATCH = 16384;  // bytes of per-region bookkeeping (k_ensemble.hip: MrScratch)
+struct MrRec { int32_t pair, slot, ireg, jreg; };
+struct MrOut { int32_t status, nenv; int32_t ei[MRENV], ej[MRENV]; };     // status 0 = resolved; else the region yields nothing
+struct MrArgs {
+  ReadsDev rd;
+  const int32_t *sorted_uniq, *seed_read;
+  const DevProfile *prof;
+  const PairRec *pairs;
+  const MrRec *mr;              // all multidomain regions of the chunk, in pair order
+  int64_t mr0;                  // first region of this batch (scratch blocks are per batch)
+  const WaveDesc *waves;        // first = region index, count, slab = row offset, rows
+  float4 *slab;                 // [row][MRV][64]
+  const int64_t *n2off;         // [nmr + 1] offset of each region's per-residue null2 scores
+  float *n2sc;
+  MrOut *out;
+  uint8_t *scratch;
+};
+void launch_mr_count(const PairOut *pout, const RegionRec *raw, int64_t npairs, int32_t *cnt, int32_t *len, hipStream_t st);
+void launch_mr_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *off, const int32_t *loff, MrRec *mr, int64_t *n2off, hipStream_t st);
+void launch_mr_wave_rows(const WaveDesc *w, int nw, const MrRec *mr, int32_t *rows, hipStream_t st);
+void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st);
+void launch_mr_apply(PairOut *pout, RegionRec *raw, int64_t npairs, const int32_t *off, const MrOut *out, unsigned long long *counters, hipStream_t st);
+
 struct ScoreArgs {
   ReadsDev rd;
   const int32_t *sorted_uniq, *seed_read;
@@ -197,6 +227,8 @@ struct ScoreArgs {
   itsx_domain *dom;             // one per region
   int64_t npairs;
   double T;
+  // clustered regions of the chunk (null when it has none): a pair's regions are mr[mr_off[pi] .. mr_off[pi + 1])
+  const MrRec *mr; const MrOut *mrout; const int64_t *n2off; const float *n2sc; const int32_t *mr_off;
   int32_t *domz;                // [S][P] reported targets per (sample, profile); S = 1 without per-sample batching
   const int32_t *usample;       // [U] sample of each unique (null: one sample)
   int32_t P;

@@ -26,33 +26,9 @@
 #include "engine.h"
 #include "k_api.h"
 #include "detmath.h"
+#include "k_vec.h"
 
 namespace itsx {
-
-#define DEV __device__ __forceinline__
-static constexpr double kLn2 = 0.69314718055994529;
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-struct V4 { f2 a, b; };
-DEV V4 vset(float x) { V4 r; r.a = (f2){x, x}; r.b = (f2){x, x}; return r; }
-DEV V4 vzero() { return vset(0.0f); }
-DEV V4 vadd(V4 x, V4 y) { V4 r; r.a = x.a + y.a; r.b = x.b + y.b; return r; }
-DEV V4 vmul(V4 x, V4 y) { V4 r; r.a = x.a * y.a; r.b = x.b * y.b; return r; }
-DEV V4 vrsh(V4 v) { V4 r; r.a = (f2){0.0f, v.a.x}; r.b = (f2){v.a.y, v.b.x}; return r; }   // [0 a b c]
-DEV V4 vlsh(V4 v) { V4 r; r.a = (f2){v.a.y, v.b.x}; r.b = (f2){v.b.y, 0.0f}; return r; }   // [b c d 0]
-DEV float vhsum(V4 v) { return (v.a.x + v.a.y) + (v.b.x + v.b.y); }
-DEV V4 vld(const float *p) { const f4 t = *(const f4 *)p; V4 r; r.a = (f2){t.x, t.y}; r.b = (f2){t.z, t.w}; return r; }
-// The transition table is read through the constant address space: with a wave-uniform address the
-// backend then selects scalar loads (s_load_dwordx4..x16 into SGPRs) even though the kernel also
-// stores to global memory (a plain global pointer would get vector loads).
-typedef const f4 __attribute__((address_space(4))) *cf4p;
-DEV V4 vldc(const float *p) { const f4 t = *(cf4p)(uintptr_t)p; V4 r; r.a = (f2){t.x, t.y}; r.b = (f2){t.z, t.w}; return r; }
-DEV int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// A scalar zero the optimizer cannot see through.  Added to the (wave-uniform) transition-table
-// pointer once per DP row, it keeps the 96 transition vectors as per-row scalar loads into SGPR
-// operands; without it loop-invariant code motion hoists all 384 floats into VGPR/AGPRs.
-DEV int opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
 
 // transition vector `idx` of the wave's profile: [q*8 + t] -> 4 floats (uniform address)
 #define TF(q, t) vldc(tf + ((q) * 8 + (t)) * 4)
@@ -62,16 +38,6 @@ struct Specials { float E, N, J, B, C, SCALE; };
 
 template <int QT> struct Row { V4 m[QMAX], d[QMAX], i[QMAX]; };
 
-// ---- per-lane view of one packed read ---------------------------------------------------
-struct Seq {
-  const uint32_t *w; const uint32_t *exc; int nexc; int L;
-  DEV int code(int pos0) const   // digital code of base pos0 (0-based)
-  {
-    int x = (int)((w[pos0 >> 4] >> (2 * (pos0 & 15))) & 3u);
-    for (int e = 0; e < nexc; e++) { const uint32_t v = exc[e]; if ((int)(v >> 4) == pos0) x = (int)(v & 15u); }
-    return x;
-  }
-};
 // Residues of one read taken in order (ascending for Forward, descending for Backward), one per DP row.  Seq::code() costs a
 // global load per row and per exception, each followed by a wait that -- vmcnt being in order -- also drains the row's six
 // slab stores.  The stream keeps the current 16-base word and the next one in registers (the next word is requested a whole
@@ -116,13 +82,6 @@ struct SeqStream {
     return x;
   }
 };
-
-DEV Seq open_seq(const ReadsDev &rd, int read)
-{
-  Seq s; const int64_t wo = rd.woff[read], eo = rd.excoff[read];
-  s.w = rd.words + wo; s.exc = rd.exc + eo; s.nexc = (int)(rd.excoff[read + 1] - eo); s.L = rd.len[read];
-  return s;
-}
 
 // ---- transition operands ------------------------------------------------------------------
 // The 96 transition vectors of a profile are wave-uniform.  They are fetched with scalar loads and
@@ -1102,7 +1061,8 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   const int64_t g0 = a.pair_region0[pi];
   const int nd_all = po.ndom;
   const float nullsc = po.nullsc;
-  if (nd_all == 1) {
+  const int mr0 = a.mr_off ? a.mr_off[pi] : 0, mr1 = a.mr_off ? a.mr_off[pi + 1] : 0;
+  if (nd_all == 1 && mr1 == mr0) {
     // the common case, one envelope: every running sum of the general path collapses to one term
     const RegionOut ro = a.rout[a.upos[g0]];
     if (!ro.ok) return;
@@ -1131,27 +1091,52 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
     return;
   }
   const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
-  // domcorrection per envelope (from k_env_post), and the per-sequence sum over all envelope positions,
-  // which HMMER accumulates as ONE running float sum across envelopes
+  // hmmsearch keeps one null2 score per residue (ddef->n2sc): a simple region's residues get log null2[x] of its envelope
+  // (k_env_post), a clustered region's residues the scores of its traceback ensemble (k_mr_trace).  The per-sequence
+  // correction is ONE running float sum over all residues in order; an envelope's own correction the sum over its residues.
+  auto add_region = [&](int m, float acc) {
+    if (a.mrout[m].status != 0) return acc;
+    const MrRec mr = a.mr[m];
+    const float *n2 = a.n2sc + a.n2off[m];
+    for (int pos = mr.ireg; pos <= mr.jreg; pos++) acc += n2[pos - mr.ireg];
+    return acc;
+  };
+  auto env_dc = [&](const RegionRec &rg, const RegionOut &ro) {
+    if (rg.multi == 0) return ro.domcorrection;
+    const int m = rg.multi - 1;
+    const float *n2 = a.n2sc + a.n2off[m];
+    const int ireg = a.mr[m].ireg;
+    float dc = 0.0f;
+    for (int pos = rg.ienv; pos <= rg.jenv; pos++) dc += n2[pos - ireg];
+    return dc;
+  };
   float seqbias = 0.0f;
-  int ndom = 0;
+  bool any = false;
+  int ndom = 0, mk = mr0;
   for (int d = 0; d < nd_all; d++) {
+    const RegionRec rg = a.regions[g0 + d];
     const RegionOut ro = a.rout[a.upos[g0 + d]];
-    if (ro.ok) {
-      if (ndom == 0) seqbias = ro.domcorrection;           // first envelope: same sum, same order
-      else {
-        const RegionRec rg = a.regions[g0 + d];
-        for (int pos = rg.ienv; pos <= rg.jenv; pos++) {
-          const int x = sq.code(pos - 1);
-          float v = ro.n2log[0];
+    if (rg.multi == 0) {
+      while (mk < mr1 && a.mr[mk].ireg < rg.ienv) { seqbias = add_region(mk, seqbias); any = true; mk++; }
+      if (ro.ok) {
+        if (!any) seqbias = ro.domcorrection;              // first term: same sum, same order
+        else
+          for (int pos = rg.ienv; pos <= rg.jenv; pos++) {
+            const int x = sq.code(pos - 1);
+            float v = ro.n2log[0];
 #pragma unroll
-          for (int c = 1; c < NCODE; c++) v = (x == c) ? ro.n2log[c] : v;
-          seqbias += v;
-        }
+            for (int c = 1; c < NCODE; c++) v = (x == c) ? ro.n2log[c] : v;
+            seqbias += v;
+          }
+        any = true;
+        ndom++;
       }
-      ndom++;
+    } else {
+      while (mk <= rg.multi - 1 && mk < mr1) { seqbias = add_region(mk, seqbias); any = true; mk++; }
+      if (ro.ok) ndom++;
     }
   }
+  while (mk < mr1) { seqbias = add_region(mk, seqbias); mk++; }
   if (ndom == 0) return;
   seqbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)seqbias));
   float seq_score = (float)((double)(po.fwdsc - (nullsc + seqbias)) / kLn2);
@@ -1160,7 +1145,8 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
     const RegionOut ro = a.rout[a.upos[g0 + d]];
     if (!ro.ok) continue;
     const RegionRec rg = a.regions[g0 + d];
-    if (ro.envsc - ro.domcorrection > 0.0f) { sum_score += ro.envsc; Ldsum += rg.jenv - rg.ienv + 1; sbias += ro.domcorrection; }
+    const float dc = env_dc(rg, ro);
+    if (ro.envsc - dc > 0.0f) { sum_score += ro.envsc; Ldsum += rg.jenv - rg.ienv + 1; sbias += dc; }
   }
   sbias = flogsum_dev(a.flogsum, 0.0f, (float)(log_omega + (double)sbias));
   sum_score = (float)((double)sum_score + (double)(L - Ldsum) * lt.lognn3);
@@ -1172,7 +1158,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   for (int d = 0; d < nd_all; d++) {
     const RegionOut ro = a.rout[a.upos[g0 + d]];
     const RegionRec rg = a.regions[g0 + d];
-    emit_domain(a, g0 + d, pr, pp, rg, ro, ro.ok ? ro.domcorrection : 0.0f, ro.ok ? k : -1, ndom, po.flags, nullsc, seq_score, final_bias,
+    emit_domain(a, g0 + d, pr, pp, rg, ro, ro.ok ? env_dc(rg, ro) : 0.0f, ro.ok ? k : -1, ndom, po.flags, nullsc, seq_score, final_bias,
                 seq_rep, L, lt.lognn3, log_omega);
     if (ro.ok) k++;
   }

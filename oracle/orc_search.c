@@ -172,9 +172,18 @@ float orc_bias_filtersc(const orc_profile *p, const uint8_t *dsq, int L)
 
 /* ------------------------------------------------------------------ Forward */
 /* rows: if non-NULL, receives M and I of every row i=1..L as [i][q][2] v4 (row 0 untouched) */
+/* full: if non-NULL, receives M, D and I of every row i=0..L as [i][q][3] v4 (p7_Forward's whole matrix, for the
+ * stochastic tracebacks of a multidomain region) */
+static int fwd_engine_x(const orc_profile *p, const uint8_t *dsq, int L,
+                        float pmove, float ploop, float eloop, float emove,
+                        xrow *xmx, v4 *rows, v4 *full, float *ret_sc);
 static int fwd_engine(const orc_profile *p, const uint8_t *dsq, int L,
                       float pmove, float ploop, float eloop, float emove,
                       xrow *xmx, v4 *rows, float *ret_sc)
+{ return fwd_engine_x(p, dsq, L, pmove, ploop, eloop, emove, xmx, rows, NULL, ret_sc); }
+static int fwd_engine_x(const orc_profile *p, const uint8_t *dsq, int L,
+                        float pmove, float ploop, float eloop, float emove,
+                        xrow *xmx, v4 *rows, v4 *full, float *ret_sc)
 {
   const int Q = p->Q;
   v4 mmx[QMAX], dmx[QMAX], imx[QMAX];
@@ -182,6 +191,7 @@ static int fwd_engine(const orc_profile *p, const uint8_t *dsq, int L,
   for (int q = 0; q < Q; q++) mmx[q] = dmx[q] = imx[q] = v4_zero();
   xE = 0.f; xN = 1.f; xJ = 0.f; xB = pmove; xC = 0.f;
   xmx[0].E = xE; xmx[0].N = xN; xmx[0].J = xJ; xmx[0].B = xB; xmx[0].C = xC; xmx[0].SCALE = 1.0f;
+  if (full) for (int q = 0; q < Q * 3; q++) full[q] = v4_zero();
   for (int i = 1; i <= L; i++) {
     const float *rp = p->rfv + (size_t)dsq[i] * Q * 4;
     const float *tp = p->tfv;
@@ -233,6 +243,7 @@ static int fwd_engine(const orc_profile *p, const uint8_t *dsq, int L,
     } else xmx[i].SCALE = 1.0f;
     xmx[i].E = xE; xmx[i].N = xN; xmx[i].J = xJ; xmx[i].B = xB; xmx[i].C = xC;
     if (rows) for (int q = 0; q < Q; q++) { rows[((size_t)i * Q + q) * 2] = mmx[q]; rows[((size_t)i * Q + q) * 2 + 1] = imx[q]; }
+    if (full) for (int q = 0; q < Q; q++) { full[((size_t)i * Q + q) * 3] = mmx[q]; full[((size_t)i * Q + q) * 3 + 1] = dmx[q]; full[((size_t)i * Q + q) * 3 + 2] = imx[q]; }
   }
   if (isnan(xC)) return -1;
   if (L > 0 && xC == 0.0f) return -2;      /* underflow */
@@ -394,6 +405,7 @@ typedef struct {
   xrow *xf, *xb, *ef, *eb;      /* parser specials; envelope specials */
   float *btot, *etot, *mocc, *n2sc;
   v4 *frows, *brows;            /* envelope M/I rows */
+  v4 *full;                     /* region Forward matrix, [row][q][M D I] */
   int cap;
 } workspace;
 
@@ -407,17 +419,18 @@ static void ws_grow(workspace *w, int L, int Q)
   w->mocc = (float *)realloc(w->mocc, sizeof(float) * cap); w->n2sc = (float *)realloc(w->n2sc, sizeof(float) * cap);
   w->frows = (v4 *)realloc(w->frows, sizeof(v4) * (size_t)cap * QMAX * 2);
   w->brows = (v4 *)realloc(w->brows, sizeof(v4) * (size_t)cap * QMAX * 2);
+  w->full = (v4 *)realloc(w->full, sizeof(v4) * (size_t)cap * QMAX * 3);
   w->cap = cap; (void)Q;
 }
 static void ws_free(workspace *w)
 {
-  free(w->xf); free(w->xb); free(w->ef); free(w->eb); free(w->btot); free(w->etot); free(w->mocc); free(w->n2sc); free(w->frows); free(w->brows);
+  free(w->xf); free(w->xb); free(w->ef); free(w->eb); free(w->btot); free(w->etot); free(w->mocc); free(w->n2sc); free(w->frows); free(w->brows); free(w->full);
 }
 
 typedef struct { int ienv, jenv, flags; float envsc, domcorrection; } domrec;
 
 /* Re-score one envelope i..j in unihit mode; fills n2sc[i..j]; returns 0 and a domain record, or <0 if skipped */
-static int rescore_domain(const orc_profile *p, const uint8_t *dsq, int L, int i, int j, workspace *w, domrec *out)
+static int rescore_domain(const orc_profile *p, const uint8_t *dsq, int L, int i, int j, int null2_is_done, workspace *w, domrec *out)
 {
   const int Q = p->Q;
   const int Ld = j - i + 1;
@@ -447,6 +460,12 @@ static int rescore_domain(const orc_profile *p, const uint8_t *dsq, int L, int i
     if (own) scaleproduct *= w->ef[r].SCALE / w->eb[r].SCALE;
   }
   if (isinf(scaleproduct)) return -2;
+  if (null2_is_done) {          /* an envelope out of a clustered region: n2sc[i..j] was set from the traceback ensemble */
+    float dc = 0.0f;
+    for (int pos = i; pos <= j; pos++) dc += w->n2sc[pos];
+    out->ienv = i; out->jenv = j; out->envsc = envsc; out->domcorrection = dc; out->flags = 1;
+    return 0;
+  }
   float norm = (float)(1.0 / (double)(float)Ld);
   for (int q = 0; q < Q; q++) { accM[q] = v4_mul(accM[q], v4_set1(norm)); accI[q] = v4_mul(accI[q], v4_set1(norm)); }
   accN *= norm; accC *= norm; accJ *= norm;
@@ -477,6 +496,331 @@ static int rescore_domain(const orc_profile *p, const uint8_t *dsq, int L, int i
   out->ienv = i; out->jenv = j; out->envsc = envsc; out->domcorrection = domcorrection; out->flags = 0;
   return 0;
 }
+
+/* ------------------------------------------------------------------ multidomain regions
+ * hmmsearch resolves a region whose posterior suggests more than one domain (is_multidomain_region, rt3 = 0.20) by
+ * p7_domaindef.c:region_trace_ensemble(): 200 stochastic tracebacks over the region's (multihit) Forward matrix, a null2
+ * score per residue from the traces, single-linkage clustering of the sampled domain coordinates (p7_spensemble.c) and
+ * removal of dominated clusters.  Restated from the published procedure (impl_sse/stotrace.c, impl_sse/null2.c:
+ * p7_Null2_ByTrace, p7_spensemble.c, esl_random.c); PARITY UNPINNED like the rest of the HMM half.  Choices that follow
+ * HMMER 3.1b2 and are version-sensitive: the pipeline's generator is esl_randomness_CreateFast(42) -- Knuth's linear
+ * congruential x <- 69069 x + 1 on 32 bits, state = esl_rnd_mix3(seed, 87654321, 12345678), re-initialised for every
+ * region (do_reseeding) -- NOT the Mersenne Twister of esl_randomness_Create(); esl_vec_FNorm sums plainly (no
+ * compensated summation); esl_rnd_FChoose accumulates in double. */
+typedef struct { uint32_t x; } orc_rng;
+static uint32_t rnd_mix3(uint32_t a, uint32_t b, uint32_t c)
+{
+  a -= b; a -= c; a ^= (c >> 13);
+  b -= c; b -= a; b ^= (a << 8);
+  c -= a; c -= b; c ^= (b >> 13);
+  a -= b; a -= c; a ^= (c >> 12);
+  b -= c; b -= a; b ^= (a << 16);
+  c -= a; c -= b; c ^= (b >> 5);
+  a -= b; a -= c; a ^= (c >> 3);
+  b -= c; b -= a; b ^= (a << 10);
+  c -= a; c -= b; c ^= (b >> 15);
+  return c;
+}
+static void rng_init(orc_rng *r, uint32_t seed) { r->x = rnd_mix3(seed, 87654321u, 12345678u); if (r->x == 0) r->x = 42; }
+static double rng_next(orc_rng *r) { r->x *= 69069u; r->x += 1u; return (double)r->x / 4294967296.0; }
+static void fnorm(float *v, int n)
+{
+  float sum = 0.f;
+  for (int x = 0; x < n; x++) sum += v[x];
+  if (sum != 0.0f) for (int x = 0; x < n; x++) v[x] /= sum;
+  else for (int x = 0; x < n; x++) v[x] = (float)(1. / (double)(float)n);
+}
+static int fchoose(orc_rng *r, const float *pv, int n)
+{
+  const double roll = rng_next(r);
+  double sum = 0.0;
+  for (int i = 0; i < n; i++) { sum += pv[i]; if (roll < sum) return i; }
+  int i;
+  do { i = (int)(rng_next(r) * n); } while (pv[i] == 0.f);
+  return i;
+}
+enum { ST_M = 1, ST_D, ST_I, ST_S, ST_N, ST_B, ST_E, ST_C, ST_T, ST_J };
+typedef struct { int idx, i, j, k, m; float prob; } spcoord;
+
+#define FULLV(row, q, s) full[((size_t)(row) * Q + (q)) * 3 + (s)]      /* s: 0 M, 1 D, 2 I */
+#define TFVQ(idx) v4_ld(p->tfv + (size_t)(idx) * 4)
+/* sample one path through the region's Forward matrix; reports its domains last-first through cb arrays */
+static int stochastic_trace(orc_rng *rng, const orc_profile *p, const v4 *full, const xrow *xf, int Lr, float pmove, float ploop,
+                            int *dfrom, int *dto, int *dk, int *dm, float *cntM /*[ndom][Q*4]*/, float *cntI, int maxdom)
+{
+  const int Q = p->Q;
+  int i = Lr, k = 0, s0 = ST_C, s1, nd = 0, cur = -1;
+  while (s0 != ST_S) {
+    float path[4];
+    switch (s0) {
+    case ST_M: {
+      const int q = (k - 1) % Q, r = (k - 1) / Q;
+      v4 mpv, dpv, ipv;
+      if (q > 0) { mpv = FULLV(i - 1, q - 1, 0); dpv = FULLV(i - 1, q - 1, 1); ipv = FULLV(i - 1, q - 1, 2); }
+      else { mpv = v4_rshift(FULLV(i - 1, Q - 1, 0)); dpv = v4_rshift(FULLV(i - 1, Q - 1, 1)); ipv = v4_rshift(FULLV(i - 1, Q - 1, 2)); }
+      const v4 xBv = v4_set1(xf[i - 1].B);
+      path[0] = v4_mul(xBv, TFVQ(7 * q + 0)).v[r];
+      path[1] = v4_mul(mpv, TFVQ(7 * q + 1)).v[r];
+      path[2] = v4_mul(ipv, TFVQ(7 * q + 2)).v[r];
+      path[3] = v4_mul(dpv, TFVQ(7 * q + 3)).v[r];
+      fnorm(path, 4);
+      static const int st4[4] = { ST_B, ST_M, ST_I, ST_D };
+      s1 = st4[fchoose(rng, path, 4)];
+      k--; i--;
+      break; }
+    case ST_D: {
+      const int q = (k - 1) % Q, r = (k - 1) / Q;
+      v4 mpv, dpv, tmdv, tddv;
+      if (q > 0) { mpv = FULLV(i, q - 1, 0); dpv = FULLV(i, q - 1, 1); tmdv = TFVQ(7 * (q - 1) + 4); tddv = TFVQ(7 * Q + (q - 1)); }
+      else { mpv = v4_rshift(FULLV(i, Q - 1, 0)); dpv = v4_rshift(FULLV(i, Q - 1, 1)); tmdv = v4_rshift(TFVQ(7 * (Q - 1) + 4)); tddv = v4_rshift(TFVQ(8 * Q - 1)); }
+      path[0] = mpv.v[r] * tmdv.v[r];
+      path[1] = dpv.v[r] * tddv.v[r];
+      fnorm(path, 2);
+      s1 = fchoose(rng, path, 2) == 0 ? ST_M : ST_D;
+      k--;
+      break; }
+    case ST_I: {
+      const int q = (k - 1) % Q, r = (k - 1) / Q;
+      path[0] = v4_mul(FULLV(i - 1, q, 0), TFVQ(7 * q + 5)).v[r];
+      path[1] = v4_mul(FULLV(i - 1, q, 2), TFVQ(7 * q + 6)).v[r];
+      fnorm(path, 2);
+      s1 = fchoose(rng, path, 2) == 0 ? ST_M : ST_I;
+      i--;
+      break; }
+    case ST_N: s1 = (i == 0) ? ST_S : ST_N; break;
+    case ST_C:
+      if (i < 1) return -3;
+      path[0] = xf[i - 1].C * ploop;
+      path[1] = xf[i].E * 0.5f * xf[i].SCALE;
+      fnorm(path, 2);
+      s1 = fchoose(rng, path, 2) == 0 ? ST_C : ST_E;
+      break;
+    case ST_J:
+      if (i < 1) return -3;
+      path[0] = xf[i - 1].J * ploop;
+      path[1] = xf[i].E * 0.5f * xf[i].SCALE;
+      fnorm(path, 2);
+      s1 = fchoose(rng, path, 2) == 0 ? ST_J : ST_E;
+      break;
+    case ST_E: {
+      double sum = 0.0;
+      const double roll = rng_next(rng);
+      const double norm = 1.0 / xf[i].E;
+      const v4 xEv = v4_set1((float)norm);
+      s1 = -1;
+      while (s1 < 0) {
+        for (int q = 0; q < Q && s1 < 0; q++) {
+          v4 u = v4_mul(FULLV(i, q, 0), xEv);
+          for (int r = 0; r < 4 && s1 < 0; r++) { sum += u.v[r]; if (roll < sum) { k = r * Q + q + 1; s1 = ST_M; } }
+          if (s1 >= 0) break;
+          u = v4_mul(FULLV(i, q, 1), xEv);
+          for (int r = 0; r < 4 && s1 < 0; r++) { sum += u.v[r]; if (roll < sum) { k = r * Q + q + 1; s1 = ST_D; } }
+        }
+        if (s1 < 0 && sum < 0.99) return -1;        /* HMMER throws: probabilities were not normalised */
+      }
+      /* a new domain opens (read backwards: this is its end) */
+      if (nd >= maxdom) return -2;
+      cur = nd++;
+      dfrom[cur] = dto[cur] = dk[cur] = dm[cur] = 0;
+      for (int z = 0; z < Q * 4; z++) cntM[(size_t)cur * QMAX * 4 + z] = cntI[(size_t)cur * QMAX * 4 + z] = 0.f;
+      break; }
+    case ST_B:
+      path[0] = xf[i].N * pmove;
+      path[1] = xf[i].J * pmove;
+      fnorm(path, 2);
+      s1 = fchoose(rng, path, 2) == 0 ? ST_N : ST_J;
+      break;
+    default: return -3;
+    }
+    /* the appended state (s1, k, i): match and insert states carry the coordinates p7_trace_Index / p7_Null2_ByTrace read */
+    if (s1 == ST_M) {
+      if (dto[cur] == 0) { dto[cur] = i; dm[cur] = k; }     /* first seen = last in the path */
+      dfrom[cur] = i; dk[cur] = k;
+      cntM[(size_t)cur * QMAX * 4 + ((k - 1) % Q) * 4 + (k - 1) / Q] += 1.0f;
+    } else if (s1 == ST_I) {
+      cntI[(size_t)cur * QMAX * 4 + ((k - 1) % Q) * 4 + (k - 1) / Q] += 1.0f;
+    }
+    if ((s1 == ST_N || s1 == ST_J || s1 == ST_C) && s1 == s0) i--;
+    s0 = s1;
+  }
+  return nd;
+}
+
+static int link_samples(const spcoord *h1, const spcoord *h2)
+{
+  const float min_overlap = 0.8f; const int max_diagdiff = 4;     /* of_smaller = TRUE */
+  int nov = (h1->j < h2->j ? h1->j : h2->j) - (h1->i > h2->i ? h1->i : h2->i) + 1;
+  int a = h1->j - h1->i + 1, b = h2->j - h2->i + 1;
+  int n = a < b ? a : b;
+  if ((float)nov / (float)n < min_overlap) return 0;
+  nov = (h1->m < h2->m ? h1->m : h2->m) - (h1->k > h2->k ? h1->k : h2->k);       /* as published: no "+ 1" on the model side */
+  a = h1->m - h1->k + 1; b = h2->m - h2->k + 1;
+  n = a < b ? a : b;
+  if ((float)nov / (float)n < min_overlap) return 0;
+  int d1 = h1->i - h1->k, d2 = h2->i - h2->k;
+  if (abs(d1 - d2) <= max_diagdiff) return 1;
+  d1 = h1->j - h1->m; d2 = h2->j - h2->m;
+  if (abs(d1 - d2) <= max_diagdiff) return 1;
+  return 0;
+}
+
+/* region ireg..jreg of dsq[1..L]: fills n2sc[ireg..jreg] and returns the cluster envelopes (absolute coordinates),
+ * ordered by start; ret < 0 if the ensemble could not be sampled (the region then yields no envelope) */
+static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L, int ireg, int jreg, workspace *w, int *env_i, int *env_j, int maxenv)
+{
+  const int Q = p->Q, Lr = jreg - ireg + 1, nsamples = 200;
+  const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f), ploop = 1.0f - pmove;   /* multihit, length model of the whole target */
+  float fsc;
+  fwd_engine_x(p, dsq + ireg - 1, Lr, pmove, ploop, 0.5f, 0.5f, w->ef, NULL, w->full, &fsc);
+  for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
+  orc_rng rng; rng_init(&rng, 42);
+  /* bookkeeping limits of the device kernel (k_ensemble.hip), mirrored so that both sides fail alike: at most 8 domains
+   * in one sampled path, 512 distinct (i, j, k, m) tuples, 32 reportable clusters, 4 envelopes per region; a region that
+   * exceeds one yields no envelope and no null2 correction (never seen so far; the engine counts such regions) */
+  enum { MAXD = 8, TCAP = 512, NSIG = 32, MRENV = 4 };
+  int dfrom[MAXD], dto[MAXD], dk[MAXD], dm[MAXD];
+  float *cntM = (float *)malloc(sizeof(float) * MAXD * QMAX * 4 * 2), *cntI = cntM + MAXD * QMAX * 4;
+  int cap = 1024, n = 0;
+  spcoord *sp = (spcoord *)malloc(sizeof(spcoord) * cap);
+  const uint8_t *degen = orc_degen_table();
+  int bad = 0;
+  for (int t = 0; t < nsamples && !bad; t++) {
+    const int nd = stochastic_trace(&rng, p, w->full, w->ef, Lr, pmove, ploop, dfrom, dto, dk, dm, cntM, cntI, MAXD);
+    if (nd < 0) { bad = 1; break; }
+    int hi = Lr;                                   /* positions above hi have had their contribution of this trace */
+    for (int d = 0; d < nd; d++) {                 /* domains last-first */
+      if (n == cap) { cap *= 2; sp = (spcoord *)realloc(sp, sizeof(spcoord) * cap); }
+      sp[n].idx = t; sp[n].i = dfrom[d] + ireg - 1; sp[n].j = dto[d] + ireg - 1; sp[n].k = dk[d]; sp[n].m = dm[d]; sp[n].prob = 0.f; n++;
+      /* p7_Null2_ByTrace over the domain's B..E segment: only match and insert states emit there */
+      const float *cm = cntM + (size_t)d * QMAX * 4, *ci = cntI + (size_t)d * QMAX * 4;
+      int Ld = 0;
+      for (int z = 0; z < Q * 4; z++) Ld += (int)cm[z] + (int)ci[z];
+      const float norm = (float)(1.0 / (double)(float)Ld);
+      float null2[ORC_KP];
+      const float xfactor = (0.0f * norm + 0.0f * norm) + 0.0f * norm;
+      for (int x = 0; x < 4; x++) {
+        v4 sv = v4_zero();
+        const float *rp = p->rfv + (size_t)x * Q * 4;
+        for (int q = 0; q < Q; q++) {
+          v4 mv = v4_mul(v4_ld(cm + q * 4), v4_set1(norm)), iv = v4_mul(v4_ld(ci + q * 4), v4_set1(norm));
+          sv = v4_add(sv, v4_mul(mv, v4_ld(rp))); rp += 4;
+          sv = v4_add(sv, iv);
+        }
+        null2[x] = v4_hsum(sv);
+        null2[x] += xfactor;
+      }
+      for (int x = 5; x <= 15; x++) {
+        float result = 0.f; int ndg = 0;
+        for (int y = 0; y < 4; y++) if (degen[x] & (1 << y)) { result += null2[y]; ndg++; }
+        null2[x] = result / (float)ndg;
+      }
+      null2[4] = null2[16] = null2[17] = 1.0f;
+      /* as published: residues up to AND INCLUDING the domain's first one count as outside (+1), the rest of it by null2 */
+      for (int pos = hi; pos > dto[d]; pos--) w->n2sc[ireg + pos - 1] += 1.0f;
+      for (int pos = dto[d]; pos > dfrom[d]; pos--) w->n2sc[ireg + pos - 1] += null2[dsq[ireg + pos - 1]];
+      hi = dfrom[d];
+    }
+    for (int pos = hi; pos >= 1; pos--) w->n2sc[ireg + pos - 1] += 1.0f;
+  }
+  if (bad) {          /* HMMER would have thrown; keep the region without envelopes and without a null2 correction */
+    for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
+    free(cntM); free(sp);
+    return -1;
+  }
+  if (!bad) {                                     /* distinct tuples, as the device counts them */
+    int ndist = 0;
+    for (int h = 0; h < n && ndist <= TCAP; h++) {
+      int seen = 0;
+      for (int u = 0; u < h && !seen; u++) seen = sp[u].i == sp[h].i && sp[u].j == sp[h].j && sp[u].k == sp[h].k && sp[u].m == sp[h].m;
+      ndist += !seen;
+    }
+    if (ndist > TCAP) bad = 1;
+  }
+  if (bad) {
+    for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
+    free(cntM); free(sp);
+    return -1;
+  }
+  for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = orc_logf(w->n2sc[pos] / (float)nsamples);
+
+  /* single-linkage clustering of the sampled (i, j, k, m); components numbered by their smallest member */
+  int *comp = (int *)malloc(sizeof(int) * (n + 1)), *stack = (int *)malloc(sizeof(int) * (n + 1));
+  for (int h = 0; h < n; h++) comp[h] = -1;
+  int nc = 0;
+  for (int h0 = 0; h0 < n; h0++) {
+    if (comp[h0] >= 0) continue;
+    int ns = 0; stack[ns++] = h0; comp[h0] = nc;
+    while (ns > 0) {
+      const int v = stack[--ns];
+      for (int u = 0; u < n; u++) if (comp[u] < 0 && link_samples(&sp[v], &sp[u])) { comp[u] = nc; stack[ns++] = u; }
+    }
+    nc++;
+  }
+  spcoord *sig = (spcoord *)malloc(sizeof(spcoord) * (nc + 1));
+  int nsig = 0;
+  int *epc = (int *)malloc(sizeof(int) * (L + p->M + 8));
+  for (int c = 0; c < nc; c++) {
+    int ninc = 0, last = -1;
+    for (int h = 0; h < n; h++) if (comp[h] == c) { if (sp[h].idx != last) ninc++; last = sp[h].idx; }
+    if ((float)ninc / (float)nsamples < 0.25f) continue;
+    int imin = 0, imax = 0, jmin = 0, jmax = 0, kmin = 0, kmax = 0, mmin = 0, mmax = 0;
+    for (int h = 0; h < n; h++) if (comp[h] == c) {
+      if (imin == 0) { imin = imax = sp[h].i; jmin = jmax = sp[h].j; kmin = kmax = sp[h].k; mmin = mmax = sp[h].m; }
+      else {
+        if (sp[h].i < imin) imin = sp[h].i;
+        if (sp[h].i > imax) imax = sp[h].i;
+        if (sp[h].j < jmin) jmin = sp[h].j;
+        if (sp[h].j > jmax) jmax = sp[h].j;
+        if (sp[h].k < kmin) kmin = sp[h].k;
+        if (sp[h].k > kmax) kmax = sp[h].k;
+        if (sp[h].m < mmin) mmin = sp[h].m;
+        if (sp[h].m > mmax) mmax = sp[h].m;
+      }
+    }
+    const int thr = (int)ceilf((float)ninc * 0.02f);
+    int best_i, best_j, best_k, best_m, am;
+#define HIST(field, lo, hi) do { for (int z = 0; z <= (hi) - (lo); z++) epc[z] = 0; \
+      for (int h = 0; h < n; h++) if (comp[h] == c) epc[sp[h].field - (lo)]++; \
+      am = 0; for (int z = 1; z <= (hi) - (lo); z++) if (epc[z] > epc[am]) am = z; } while (0)
+    HIST(i, imin, imax);
+    for (best_i = imin; best_i <= imax; best_i++) if (epc[best_i - imin] >= thr) break;
+    if (best_i > imax) best_i = imin + am;
+    HIST(k, kmin, kmax);
+    for (best_k = kmin; best_k <= kmax; best_k++) if (epc[best_k - kmin] >= thr) break;
+    if (best_k > kmax) best_k = kmin + am;
+    HIST(j, jmin, jmax);
+    for (best_j = jmax; best_j >= jmin; best_j--) if (epc[best_j - jmin] >= thr) break;
+    if (best_j < jmin) best_j = jmin + am;
+    HIST(m, mmin, mmax);
+    for (best_m = mmax; best_m >= mmin; best_m--) if (epc[best_m - mmin] >= thr) break;
+    if (best_m < mmin) best_m = mmin + am;
+#undef HIST
+    if (best_i > best_j || best_k > best_m) continue;
+    if (nsig >= NSIG) { bad = 1; break; }
+    sig[nsig].i = best_i; sig[nsig].j = best_j; sig[nsig].k = best_k; sig[nsig].m = best_m; sig[nsig].idx = c;
+    sig[nsig].prob = (float)ninc / (float)nsamples;
+    nsig++;
+  }
+  /* order by start (stable) */
+  for (int a = 1; a < nsig; a++) { spcoord t = sig[a]; int b = a - 1; while (b >= 0 && sig[b].i > t.i) { sig[b + 1] = sig[b]; b--; } sig[b + 1] = t; }
+  /* dominated clusters (>= 80 % overlap of the shorter one): the less probable goes */
+  int *dominated = (int *)calloc(nsig + 1, sizeof(int));
+  for (int d = 0; d < nsig; d++)
+    for (int d2 = d + 1; d2 < nsig; d2++) {
+      const int nov = (sig[d].j < sig[d2].j ? sig[d].j : sig[d2].j) - (sig[d].i > sig[d2].i ? sig[d].i : sig[d2].i) + 1;
+      if (nov == 0) break;
+      const int a = sig[d].j - sig[d].i + 1, b = sig[d2].j - sig[d2].i + 1;
+      const int nn = a < b ? a : b;
+      if ((float)nov / (float)nn >= 0.8f) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+    }
+  int ne = 0;
+  for (int d = 0; d < nsig && !bad; d++) if (!dominated[d]) { if (ne >= MRENV || ne >= maxenv) { bad = 1; break; } env_i[ne] = sig[d].i; env_j[ne] = sig[d].j; ne++; }
+  if (bad) { ne = -1; for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f; }
+  free(dominated); free(epc); free(sig); free(comp); free(stack); free(cntM); free(sp);
+  return ne;
+}
+#undef FULLV
+#undef TFVQ
 
 /* one (sequence, profile) comparison: everything p7_Pipeline does for it */
 static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uint8_t *dsq, int L,
@@ -560,9 +904,19 @@ static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uin
             if (e > max) max = e;
           }
           multi = (max >= rt3); }
-        if (ndom < 64) {
+        if (multi && !getenv("ORC_NO_ENSEMBLE")) {
+          /* the region is resolved into envelopes by stochastic traceback clustering; its null2 scores come from the traces */
+          int ei[16], ej[16];
+          r->n_multidomain++;
+          const int ne = region_trace_ensemble(p, dsq, L, i, j, w, ei, ej, 16);
+          for (int e = 0; e < ne; e++)
+            if (ndom < 64) {
+              domrec d;
+              if (rescore_domain(p, dsq, L, ei[e], ej[e], 1, w, &d) == 0) doms[ndom++] = d;
+            }
+        } else if (ndom < 64) {
           domrec d;
-          if (rescore_domain(p, dsq, L, i, j, w, &d) == 0) {
+          if (rescore_domain(p, dsq, L, i, j, 0, w, &d) == 0) {
             if (multi) { d.flags |= 1; r->n_multidomain++; }
             doms[ndom++] = d;
           }

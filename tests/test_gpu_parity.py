@@ -384,3 +384,28 @@ def test_chunked_search_is_identical_to_one_chunk(engine, t_hmm_text, monkeypatc
     _, _, uniq_of = engine.get_derep()
     us, ue, ut, ui = res.positions("3_", "4_")
     assert np.array_equal(start, us[uniq_of]) and np.array_equal(stop, ue[uniq_of])
+
+
+def test_multidomain_regions_are_resolved_by_traceback_clustering(engine, t_hmm_text, monkeypatch):
+    """hmmsearch resolves a region whose posterior suggests several domains by 200 stochastic tracebacks + clustering
+    (region_trace_ensemble).  Engine (k_ensemble.hip) and oracle must agree on every envelope, every per-residue null2
+    sum (domcorrection, seq_bias) and every score -- the random stream included -- on a workload with hundreds of such
+    regions; and with the stage switched off on both sides they must agree on the old one-envelope behaviour."""
+    blob, offs = synth.make_reads(t_hmm_text, 3000, seed=5, fixed_len=0, len_range=(300, 580))
+    seqs = synth.to_strings(blob, offs)
+    hmm = _its2_subset(t_hmm_text)
+    res = _run_both(engine, hmm, seqs, threads=os.cpu_count() or 8)
+    _compare(engine, res)
+    st = engine.stats()
+    assert res.counts["multidomain"] > 300
+    assert st["n_mr_clustered"] == res.counts["multidomain"] and st["n_mr_failed"] == 0
+    flagged = res.domains[(res.domains["flags"] & 1) == 1]
+    assert st["n_mr_envelopes"] == len(flagged) > 300
+    # a clustered region may yield several envelopes, or a narrower one than the region
+    d = engine.domains()
+    assert len(d) == len(res.domains)
+    monkeypatch.setenv("ITSX_NO_ENSEMBLE", "1")
+    monkeypatch.setenv("ORC_NO_ENSEMBLE", "1")
+    res0 = _run_both(engine, hmm, seqs, threads=os.cpu_count() or 8)
+    _compare(engine, res0)
+    assert engine.stats()["n_mr_clustered"] == 0 and res0.counts["multidomain"] == res.counts["multidomain"]

@@ -176,7 +176,8 @@ def _compare(engine, res, left="3_", right="4_"):
     pf = ot["pass_fwd"] == 1
     assert np.array_equal(_bits(tr["bcksc"][pf]), _bits(ot["bcksc"][pf]))
     assert np.array_equal(tr["nregions"][pf], ot["nregions"][pf])
-    assert np.array_equal(tr["ndom"][pf], ot["ndom"][pf])
+    bad = np.flatnonzero((tr["ndom"] != ot["ndom"]) & pf)
+    assert len(bad) == 0, [(int(tr["rep"][i]), int(tr["prof"][i]), int(tr["ndom"][i]), int(ot["ndom"][i]), int(tr["nregions"][i])) for i in bad[:8]]
     d, od = engine.domains(), res.domains
     assert len(d) == len(od)
     for f in ("rep", "prof", "tlen", "ienv", "jenv", "dom_idx", "ndom", "seq_reported", "dom_reported"):

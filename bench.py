@@ -386,8 +386,10 @@ def main():
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
             "kernels": kernel_table,
             "parity_risk": {"regions": int(st["n_regions"]), "regions_multidomain": int(st["n_multidomain"]),
-                            "uniques_winner_from_multidomain_region": int(st["n_uniq_multi_winner"]),
-                            "reads_winner_from_multidomain_region": int(st["n_reads_multi_winner"]),
+                            "uniques_winner_is_cluster_envelope": int(st["n_uniq_multi_winner"]),
+                            "reads_winner_is_cluster_envelope": int(st["n_reads_multi_winner"]),
+                            "regions_clustered": int(st["n_mr_clustered"]), "distinct_regions_sampled": int(st["n_mr_distinct"]), "regions_clustering_failed": int(st["n_mr_failed"]),
+                            "cluster_envelopes": int(st["n_mr_envelopes"]),
                             "pairs_over_region_cap": int(st["n_domain_overflow"]),
                             "uniques_with_pair_over_region_cap": int(st["n_uniq_region_cap"]),
                             "reads_with_pair_over_region_cap": int(st["n_reads_region_cap"])},

@@ -96,6 +96,7 @@ typedef struct {
    * n_mr_failed hit a bookkeeping limit or an unsampleable matrix and yielded nothing; envelopes the clustering defined */
   int64_t n_mr_clustered, n_mr_failed, n_mr_envelopes;
   float   ms_ensemble;       int32_t pad3;
+  int64_t n_mr_distinct;     /* distinct (profile, target length, residues) multidomain regions actually sampled */
 } itsx_stats;
 
 int         itsx_abi_version(void);

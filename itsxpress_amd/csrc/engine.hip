@@ -202,7 +202,7 @@ struct itsx_ctx {
   DBuf<int64_t> w_seg_start, w_idx, w_rseg, w_dz, w_counters, w_useg;
   DBuf<int32_t> w_rrep, w_ruq, w_rurank;
   DBuf<WaveDesc> w_waves, w_rw; DBuf<RegionRec> w_raw; DBuf<float> w_slab, w_eslab;
-  DBuf<int32_t> w_mrcnt, w_mroff, w_mrlen, w_mrloff, w_mrrows; DBuf<MrRec> w_mr; DBuf<MrOut> w_mrout; DBuf<int64_t> w_n2off; DBuf<float> w_n2sc, w_mrslab;
+  DBuf<int32_t> w_mrcnt, w_mroff, w_mrlen, w_mrloff, w_mrrows, w_mrulist, w_mrulist2, w_mru; DBuf<int64_t> w_mrrowoff; DBuf<MrRec> w_mr; DBuf<MrOut> w_mrout; DBuf<int64_t> w_n2off; DBuf<float> w_n2sc, w_mrslab;
   DBuf<uint8_t> w_mrscratch; DBuf<WaveDesc> w_mrwaves;
   DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri, w_uflag;
 };
@@ -1125,7 +1125,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_failed = S.n_mr_envelopes = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false;
   if (U == 0) return ITSX_OK;
@@ -1366,56 +1366,100 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   int64_t NMR = 0;
   const bool ensemble = !(getenv("ITSX_NO_ENSEMBLE") && atoi(getenv("ITSX_NO_ENSEMBLE")) != 0);
   if (ensemble) {
-    DBuf<int32_t> &mrcnt = ctx->w_mrcnt, &mroff = ctx->w_mroff, &mrlen = ctx->w_mrlen, &mrloff = ctx->w_mrloff, &stmp = ctx->w_scan2;
-    HIPCHK(mrcnt.alloc((size_t)NP + 2)); HIPCHK(mroff.alloc((size_t)NP + 2)); HIPCHK(mrlen.alloc((size_t)NP + 2)); HIPCHK(mrloff.alloc((size_t)NP + 2));
-    HIPCHK(stmp.alloc((size_t)scan_tmp_elems(NP + 2)));
-    launch_mr_count(ctx->d_pout.p, d_raw.p, NP, mrcnt.p, mrlen.p, st);
+    DBuf<int32_t> &mrcnt = ctx->w_mrcnt, &mroff = ctx->w_mroff, &stmp = ctx->w_scan2;
+    HIPCHK(mrcnt.alloc((size_t)NP + 2)); HIPCHK(mroff.alloc((size_t)NP + 2)); HIPCHK(stmp.alloc((size_t)scan_tmp_elems(NP + 2)));
+    launch_mr_count(ctx->d_pout.p, d_raw.p, NP, mrcnt.p, st);
     launch_exclusive_scan(mrcnt.p, mroff.p, NP + 1, stmp.p, st);
-    launch_exclusive_scan(mrlen.p, mrloff.p, NP + 1, stmp.p, st);
-    int32_t tot[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(&tot[0], mroff.p + NP, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&tot[1], mrloff.p + NP, 4, hipMemcpyDeviceToHost, st));
+    int32_t tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, mroff.p + NP, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    NMR = tot[0];
-    if (tot[1] < 0) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "multidomain regions of one chunk span more than 2^31 residues");
+    NMR = tot;
     if (NMR > 0) {
       StageTimer tm_e(st);
-      HIPCHK(ctx->w_mr.alloc((size_t)NMR)); HIPCHK(ctx->w_mrout.alloc((size_t)NMR)); HIPCHK(ctx->w_n2off.alloc((size_t)NMR + 1)); HIPCHK(ctx->w_n2sc.alloc((size_t)tot[1] + 1));
-      launch_mr_fill(ctx->d_pout.p, d_raw.p, NP, mroff.p, mrloff.p, ctx->w_mr.p, ctx->w_n2off.p, st);
-      const int NMW = (int)((NMR + 63) / 64);
-      std::vector<WaveDesc> mw((size_t)NMW);
-      for (int w = 0; w < NMW; w++) { mw[(size_t)w] = WaveDesc{}; mw[(size_t)w].prof = -1; mw[(size_t)w].first = (int64_t)w * 64; mw[(size_t)w].count = (int32_t)std::min<int64_t>(64, NMR - (int64_t)w * 64); }
-      HIPCHK(upload(ctx->w_mrwaves, mw, st)); HIPCHK(ctx->w_mrrows.alloc((size_t)NMW));
-      launch_mr_wave_rows(ctx->w_mrwaves.p, NMW, ctx->w_mr.p, ctx->w_mrrows.p, st);
-      std::vector<int32_t> mrows((size_t)NMW);
-      HIPCHK(hipMemcpyAsync(mrows.data(), ctx->w_mrrows.p, (size_t)NMW * 4, hipMemcpyDeviceToHost, st));
+      static_assert(sizeof(MrRec) == sizeof(RegionRec), "MrRec is handed to the region memoisation kernels as a RegionRec");
+      HIPCHK(ctx->w_mr.alloc((size_t)NMR));
+      launch_mr_fill(ctx->d_pout.p, d_raw.p, NP, mroff.p, ctx->w_mr.p, st);
+      // ---- memoisation: distinct (profile, target length, residues) regions
+      DBuf<unsigned long long> &rkeys = ctx->w_keys; DBuf<int32_t> &rvals = ctx->w_vals; DBuf<uint32_t> &rslot = ctx->w_slot_of;
+      DBuf<int32_t> &rrep = ctx->w_rrep, &ruq = ctx->w_ruq, &rurank = ctx->w_rurank, &rscan = ctx->w_scan_tmp;
+      uint64_t tsize = 1024; while (tsize < (uint64_t)NMR * 2 + 16) tsize <<= 1;
+      HIPCHK(rkeys.alloc(tsize)); HIPCHK(rvals.alloc(tsize)); HIPCHK(rslot.alloc((size_t)NMR + 1));
+      HIPCHK(rrep.alloc((size_t)NMR + 1)); HIPCHK(ruq.alloc((size_t)NMR + 1)); HIPCHK(rurank.alloc((size_t)NMR + 1)); HIPCHK(rscan.alloc((size_t)scan_tmp_elems(NMR + 1)));
+      HIPCHK(hipMemsetAsync(rkeys.p, 0, tsize * sizeof(unsigned long long), st));
+      HIPCHK(hipMemsetAsync(rvals.p, 0x7f, tsize * sizeof(int32_t), st));
+      HIPCHK(hipMemsetAsync(ruq.p, 0, ((size_t)NMR + 1) * sizeof(int32_t), st));
+      const RegionRec *mr_as_regions = (const RegionRec *)ctx->w_mr.p;
+      launch_region_keys(ctx->rd, mr_as_regions, NMR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
+      launch_region_resolve(ctx->rd, mr_as_regions, NMR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
+      launch_exclusive_scan(ruq.p, rurank.p, NMR + 1, rscan.p, st);
+      int32_t NU = 0;
+      HIPCHK(hipMemcpyAsync(&NU, rurank.p + NMR, 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      const int64_t mrow_bytes = (int64_t)MRV * 64 * 16;
-      const int64_t mbudget = std::max<int64_t>(1, (int64_t)(std::min(slab_gb, 8.0) * (1 << 30)) / mrow_bytes);
-      const int64_t wave_cap = std::max<int64_t>(1, ((int64_t)2 << 30) / ((int64_t)MR_SCRATCH * 64));      // 2 GB of bookkeeping blocks per batch
+      DBuf<int32_t> &ulist0 = ctx->w_mrulist, &ulist = ctx->w_mrulist2, &ulen = ctx->w_mrlen, &newpos = ctx->w_mrloff, &mru = ctx->w_mru;
+      HIPCHK(ulist0.alloc((size_t)NU + 1)); HIPCHK(ulist.alloc((size_t)NU + 1)); HIPCHK(ulen.alloc((size_t)NU + 2)); HIPCHK(newpos.alloc((size_t)NU + 2)); HIPCHK(mru.alloc((size_t)NMR + 1));
+      launch_mr_ulist(NMR, ctx->w_mr.p, rrep.p, ruq.p, rurank.p, ulist0.p, ulen.p, mru.p, st);
+      // the distinct regions are walked in order of length: the lanes of a wave then have paths and residue loops of like length
+      std::vector<int32_t> hlen((size_t)NU), ord((size_t)NU), hpos((size_t)NU);
+      HIPCHK(hipMemcpyAsync(hlen.data(), ulen.p, (size_t)NU * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      std::iota(ord.begin(), ord.end(), 0);
+      std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return hlen[(size_t)x] < hlen[(size_t)y]; });
+      std::vector<int64_t> hn2((size_t)NU + 1, 0), hrow((size_t)NU + 1, 0);
+      for (int32_t x = 0; x < NU; x++) {
+        const int32_t o = ord[(size_t)x];
+        hpos[(size_t)o] = x;
+        hn2[(size_t)x + 1] = hn2[(size_t)x] + hlen[(size_t)o];
+        hrow[(size_t)x + 1] = hrow[(size_t)x] + hlen[(size_t)o] + 1;
+      }
+      HIPCHK(hipMemcpyAsync(newpos.p, hpos.data(), (size_t)NU * 4, hipMemcpyHostToDevice, st));
+      launch_mr_reorder(NU, NMR, newpos.p, ulist0.p, ulist.p, mru.p, st);
+      HIPCHK(upload(ctx->w_n2off, hn2, st)); HIPCHK(upload(ctx->w_mrrowoff, hrow, st));
+      HIPCHK(ctx->w_mrout.alloc((size_t)NU)); HIPCHK(ctx->w_n2sc.alloc((size_t)hn2[(size_t)NU] + 1));
+      const int NMW = (int)(((int64_t)NU + 63) / 64);
+      std::vector<WaveDesc> mw((size_t)NMW);
+      for (int w = 0; w < NMW; w++) {
+        WaveDesc &d = mw[(size_t)w]; d = WaveDesc{};
+        d.prof = -1; d.first = (int64_t)w * 64; d.count = (int32_t)std::min<int64_t>(64, (int64_t)NU - (int64_t)w * 64);
+        d.rows = hlen[(size_t)ord[(size_t)(d.first + d.count - 1)]] + 1;                  // ascending length: the last lane's
+      }
+      HIPCHK(upload(ctx->w_mrwaves, mw, st));
+      const int64_t mrow_bytes = (int64_t)MRV * 16;
+      const int64_t mbudget = std::max<int64_t>(1, (int64_t)(std::min(slab_gb, 16.0) * (1 << 30)) / mrow_bytes);
+      const int64_t wave_cap = std::max<int64_t>(1, ((int64_t)6 << 30) / ((int64_t)MR_SCRATCH * 64));      // 6 GB of bookkeeping blocks per batch
       int w0 = 0;
       while (w0 < NMW) {
-        int w1 = w0; int64_t r = 0;
-        while (w1 < NMW && w1 - w0 < wave_cap && (w1 == w0 || r + mrows[(size_t)w1] <= mbudget)) { mw[(size_t)w1].slab = r; mw[(size_t)w1].rows = mrows[(size_t)w1]; r += mrows[(size_t)w1]; w1++; }
-        if ((size_t)r * MRV * 64 * 4 > ctx->w_mrslab.cap) HIPCHK(ctx->w_mrslab.alloc((size_t)r * MRV * 64 * 4));
+        int w1 = w0;
+        const int64_t row0 = hrow[(size_t)w0 * 64];
+        auto rows_to = [&](int w) { return hrow[(size_t)std::min<int64_t>((int64_t)w * 64, NU)] - row0; };
+        while (w1 < NMW && w1 - w0 < wave_cap && (w1 == w0 || rows_to(w1 + 1) <= mbudget)) w1++;
+        const int64_t r = rows_to(w1);
+        if ((size_t)r * MRV * 4 > ctx->w_mrslab.cap) HIPCHK(ctx->w_mrslab.alloc((size_t)r * MRV * 4));
         HIPCHK(ctx->w_mrscratch.alloc((size_t)(w1 - w0) * 64 * MR_SCRATCH));
-        HIPCHK(hipMemcpyAsync(ctx->w_mrwaves.p + w0, mw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
         MrArgs ma{};
         ma.rd = ctx->rd; ma.sorted_uniq = d_sorted; ma.seed_read = ctx->d_seed_read.p; ma.prof = ctx->d_prof.p; ma.pairs = ctx->d_pairs.p;
-        ma.mr = ctx->w_mr.p; ma.mr0 = (int64_t)w0 * 64; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
+        ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = (int64_t)w0 * 64; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
+        ma.rowoff = ctx->w_mrrowoff.p; ma.rowoff0 = row0;
         ma.n2off = ctx->w_n2off.p; ma.n2sc = ctx->w_n2sc.p; ma.out = ctx->w_mrout.p; ma.scratch = ctx->w_mrscratch.p;
+        static const bool mrdbg = getenv("ITSX_MR_DEBUG") != nullptr;
+        if (mrdbg) { HIPCHK(ctx->w_counters.alloc(8)); HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 64, st)); ma.dbg = (unsigned long long *)ctx->w_counters.p; }
         launch_mr_ensemble(ma, w1 - w0, w0, st);
+        if (mrdbg) {
+          unsigned long long d[4];
+          HIPCHK(hipMemcpyAsync(d, ctx->w_counters.p, 32, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+          fprintf(stderr, "[itsx] ensemble batch: %d waves, %lld matrix rows; per wave (100 MHz ticks): walk %.0f, close %.0f, cluster %.0f\n", w1 - w0, (long long)r,
+                  (double)d[0] / std::max<double>(1.0, (double)d[3]), (double)d[1] / std::max<double>(1.0, (double)d[3]), (double)d[2] / std::max<double>(1.0, (double)d[3]));
+        }
         w0 = w1;
       }
       DBuf<int64_t> &d_c = ctx->w_counters;
       HIPCHK(d_c.alloc(8));
       HIPCHK(hipMemsetAsync(d_c.p, 0, 8 * sizeof(int64_t), st));
-      launch_mr_apply(ctx->d_pout.p, d_raw.p, NP, mroff.p, ctx->w_mrout.p, (unsigned long long *)d_c.p, st);
+      launch_mr_apply(ctx->d_pout.p, d_raw.p, NP, mroff.p, mru.p, ctx->w_mrout.p, (unsigned long long *)d_c.p, st);
       int64_t hc[2] = {0, 0};
       HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
       S.ms_ensemble += tm_e.stop();
       HIPCHK(hipGetLastError());
-      S.n_mr_clustered += NMR; S.n_mr_failed += hc[0]; S.n_mr_envelopes += hc[1];
+      S.n_mr_clustered += NMR; S.n_mr_distinct += NU; S.n_mr_failed += hc[0]; S.n_mr_envelopes += hc[1];
     }
   }
   // ---- compact regions into a profile-grouped list
@@ -1520,7 +1564,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     sa.rd = ctx->rd; sa.sorted_uniq = d_sorted; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
     sa.flogsum = ctx->d_flogsum.p; sa.pairs = ctx->d_pairs.p; sa.pout = ctx->d_pout.p; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
     sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = d_dom.p; sa.npairs = NP; sa.T = T;
-    if (NMR > 0) { sa.mr = ctx->w_mr.p; sa.mrout = ctx->w_mrout.p; sa.n2off = ctx->w_n2off.p; sa.n2sc = ctx->w_n2sc.p; sa.mr_off = ctx->w_mroff.p; }
+    if (NMR > 0) { sa.mr = ctx->w_mr.p; sa.mr_u = ctx->w_mru.p; sa.mrout = ctx->w_mrout.p; sa.n2off = ctx->w_n2off.p; sa.n2sc = ctx->w_n2sc.p; sa.mr_off = ctx->w_mroff.p; }
     sa.domz = ctx->d_domz32.p; sa.usample = ctx->dev_usample(); sa.P = ctx->P;
     launch_score(sa, st);
   }

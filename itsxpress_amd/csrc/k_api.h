@@ -189,28 +189,39 @@ constexpr int MR_MAXD = 8;         // domains in one sampled path
 constexpr int MR_TCAP = 512;       // distinct sampled (i, j, k, m) tuples per region
 constexpr int MR_SCAP = 200 * MR_MAXD;
 constexpr int MR_NSIG = 32;        // clusters that reach the posterior threshold
-constexpr int MR_SCRATCH = 16384;  // bytes of per-region bookkeeping (k_ensemble.hip: MrScratch)
-struct MrRec { int32_t pair, slot, ireg, jreg; };
-struct MrOut { int32_t status, nenv; int32_t ei[MRENV], ej[MRENV]; };     // status 0 = resolved; else the region yields nothing
+constexpr int MR_HASH = 1024;      // slots of the per-region tuple index (a power of two >= 2 MR_TCAP)
+constexpr int MR_EPC = 256;        // widest endpoint histogram kept as an array (wider ones are counted pairwise)
+constexpr int MR_SCRATCH = 19456;  // bytes of per-region bookkeeping (k_ensemble.hip: MrScratch)
+struct MrRec { int32_t pair, ireg, jreg, slot; };                         // field for field a RegionRec (the memoisation kernels take it as one)
+struct MrOut { int32_t status, nenv; int32_t ei[MRENV], ej[MRENV]; };     // status 0 = resolved (else the region yields nothing); envelopes relative to the region (1-based)
 struct MrArgs {
   ReadsDev rd;
   const int32_t *sorted_uniq, *seed_read;
   const DevProfile *prof;
   const PairRec *pairs;
   const MrRec *mr;              // all multidomain regions of the chunk, in pair order
-  int64_t mr0;                  // first region of this batch (scratch blocks are per batch)
-  const WaveDesc *waves;        // first = region index, count, slab = row offset, rows
-  float4 *slab;                 // [row][MRV][64]
-  const int64_t *n2off;         // [nmr + 1] offset of each region's per-residue null2 scores
+  const int32_t *ulist;         // distinct regions (same profile, target length and residues): index into mr of each one's first copy
+  int64_t u0;                   // first distinct region of this batch (scratch blocks are per batch)
+  const WaveDesc *waves;        // first = index into ulist, count, rows = longest region of the wave + 1
+  float4 *slab;                 // a region's matrix is contiguous: [row 0..Lr][MRV]; region u starts at row rowoff[u] - rowoff0
+  const int64_t *rowoff;        // [distinct] first slab row of each distinct region (all batches; rowoff0 = the batch's first)
+  int64_t rowoff0;
+  const int64_t *n2off;         // [distinct] offset of each distinct region's per-residue null2 scores
   float *n2sc;
-  MrOut *out;
+  MrOut *out;                   // [distinct]
   uint8_t *scratch;
+  unsigned long long *dbg;      // optional [4]: wave-clock ticks spent walking paths, closing them, clustering (ITSX_MR_DEBUG)
 };
-void launch_mr_count(const PairOut *pout, const RegionRec *raw, int64_t npairs, int32_t *cnt, int32_t *len, hipStream_t st);
-void launch_mr_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *off, const int32_t *loff, MrRec *mr, int64_t *n2off, hipStream_t st);
-void launch_mr_wave_rows(const WaveDesc *w, int nw, const MrRec *mr, int32_t *rows, hipStream_t st);
+void launch_mr_count(const PairOut *pout, const RegionRec *raw, int64_t npairs, int32_t *cnt, hipStream_t st);
+void launch_mr_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *off, MrRec *mr, hipStream_t st);
+// distinct regions: ulist[urank[m]] = m and ulen = region length for the first copies; mr_u[m] = index of m's distinct region
+void launch_mr_ulist(int64_t nmr, const MrRec *mr, const int32_t *rep, const int32_t *is_uniq, const int32_t *urank, int32_t *ulist, int32_t *ulen,
+                     int32_t *mr_u, hipStream_t st);
+// regions ordered by length: ulist_out[newpos[u]] = ulist_in[u], mr_u[m] = newpos[mr_u[m]]
+void launch_mr_reorder(int64_t nu, int64_t nmr, const int32_t *newpos, const int32_t *ulist_in, int32_t *ulist_out, int32_t *mr_u, hipStream_t st);
 void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st);
-void launch_mr_apply(PairOut *pout, RegionRec *raw, int64_t npairs, const int32_t *off, const MrOut *out, unsigned long long *counters, hipStream_t st);
+void launch_mr_apply(PairOut *pout, RegionRec *raw, int64_t npairs, const int32_t *off, const int32_t *mr_u, const MrOut *out, unsigned long long *counters,
+                     hipStream_t st);
 
 struct ScoreArgs {
   ReadsDev rd;
@@ -228,7 +239,8 @@ struct ScoreArgs {
   int64_t npairs;
   double T;
   // clustered regions of the chunk (null when it has none): a pair's regions are mr[mr_off[pi] .. mr_off[pi + 1])
-  const MrRec *mr; const MrOut *mrout; const int64_t *n2off; const float *n2sc; const int32_t *mr_off;
+  // (mr_u[m] = the distinct region whose results m shares: mrout and n2off are indexed by it)
+  const MrRec *mr; const int32_t *mr_u; const MrOut *mrout; const int64_t *n2off; const float *n2sc; const int32_t *mr_off;
   int32_t *domz;                // [S][P] reported targets per (sample, profile); S = 1 without per-sample batching
   const int32_t *usample;       // [U] sample of each unique (null: one sample)
   int32_t P;

@@ -24,7 +24,9 @@ namespace itsx {
 enum { tBM = 0, tMM, tIM, tDM, tMD, tMI, tII, tDD };
 enum { ST_M = 1, ST_D, ST_I, ST_S, ST_N, ST_B, ST_E, ST_C, ST_T, ST_J };
 
-DEV f4 *mrslab(const MrArgs &a, int64_t r0, int row, int v, int lane) { return (f4 *)a.slab + (((r0 + row) * MRV + v) * 64 + lane); }
+// a region's matrix is contiguous (rows of MRV float4): a path moves to the neighbouring node group or to the row before, so
+// consecutive steps of a traceback stay within a cache line or two (interleaved by lane, every float4 of a step was a line of its own)
+DEV f4 *mrslab(const MrArgs &a, int64_t r0, int row, int v, int lane) { (void)lane; return (f4 *)a.slab + ((r0 + row) * MRV + v); }
 DEV float comp4(const f4 &t, int r) { return r == 0 ? t.x : r == 1 ? t.y : r == 2 ? t.z : t.w; }
 // component r of the vector right-shifted by one lane ([0 a b c])
 DEV float comp4_rsh(const f4 &t, int r) { return r == 0 ? 0.0f : r == 1 ? t.x : r == 2 ? t.y : t.z; }
@@ -38,15 +40,15 @@ DEV MrLane mr_lane(const MrArgs &a, const WaveDesc &wd, int lane)
 {
   MrLane e;
   e.active = lane < wd.count;
-  e.mi = wd.first + (e.active ? lane : 0);
-  e.m = a.mr[e.mi];
+  e.mi = wd.first + (e.active ? lane : 0);             // index of the distinct region
+  e.m = a.mr[a.ulist[e.mi]];
   const PairRec pr = a.pairs[e.m.pair];
   e.L = pr.L; e.Lr = e.m.jreg - e.m.ireg + 1; e.off = e.m.ireg - 1;
   e.pp = a.prof + pr.prof; e.Q = e.pp->Q;
   e.sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
   e.pmove = (2.0f + 1.0f) / ((float)e.L + 2.0f + 1.0f);       // multihit, length model of the whole target
   e.ploop = 1.0f - e.pmove;
-  e.r0 = wd.slab;
+  e.r0 = a.rowoff[e.mi] - a.rowoff0;
   return e;
 }
 
@@ -155,23 +157,12 @@ DEV uint32_t rnd_mix3(uint32_t a, uint32_t b, uint32_t c)
   return c;
 }
 DEV double rng_next(uint32_t &x) { x *= 69069u; x += 1u; return (double)x / 4294967296.0; }
-// esl_vec_FNorm + esl_rnd_FChoose over two or four path weights
-DEV int choose2(uint32_t &rng, float p0, float p1)
-{
-  float sum = 0.f; sum += p0; sum += p1;
-  if (sum != 0.0f) { p0 /= sum; p1 /= sum; } else { p0 = p1 = (float)(1. / (double)2.0f); }
-  const double roll = rng_next(rng);
-  double s = 0.0;
-  s += p0; if (roll < s) return 0;
-  s += p1; if (roll < s) return 1;
-  int i;
-  do { i = (int)(rng_next(rng) * 2); } while ((i == 0 ? p0 : p1) == 0.f);
-  return i;
-}
-DEV int choose4(uint32_t &rng, float p0, float p1, float p2, float p3)
+// esl_vec_FNorm + esl_rnd_FChoose over n = 2 or 4 path weights (w2 = w3 = 0 when n == 2: adding +0 leaves the sums as they are)
+DEV int choose_n(uint32_t &rng, int n, float p0, float p1, float p2, float p3)
 {
   float sum = 0.f; sum += p0; sum += p1; sum += p2; sum += p3;
-  if (sum != 0.0f) { p0 /= sum; p1 /= sum; p2 /= sum; p3 /= sum; } else { p0 = p1 = p2 = p3 = (float)(1. / (double)4.0f); }
+  if (sum != 0.0f) { p0 /= sum; p1 /= sum; p2 /= sum; p3 /= sum; }
+  else { p0 = p1 = (float)(1. / (double)(float)n); p2 = p3 = n == 4 ? p0 : 0.0f; }
   const double roll = rng_next(rng);
   double s = 0.0;
   s += p0; if (roll < s) return 0;
@@ -179,7 +170,7 @@ DEV int choose4(uint32_t &rng, float p0, float p1, float p2, float p3)
   s += p2; if (roll < s) return 2;
   s += p3; if (roll < s) return 3;
   int i;
-  do { i = (int)(rng_next(rng) * 4); } while ((i == 0 ? p0 : i == 1 ? p1 : i == 2 ? p2 : p3) == 0.f);
+  do { i = (int)(rng_next(rng) * n); } while ((i == 0 ? p0 : i == 1 ? p1 : i == 2 ? p2 : p3) == 0.f);
   return i;
 }
 
@@ -206,164 +197,228 @@ struct MrScratch {
   unsigned long long key[MR_TCAP];
   uint16_t tcount[MR_TCAP], comp[MR_TCAP], stack[MR_TCAP], ninc[MR_TCAP]; int16_t last[MR_TCAP];
   uint16_t tid[MR_SCAP]; uint8_t tidx[MR_SCAP];
+  uint16_t hslot[MR_HASH];                  // open-addressing index over key[]: tuple number + 1, 0 = empty
+  uint16_t epc[MR_EPC];                     // endpoint histogram of one coordinate of one cluster
   int32_t sig_i[MR_NSIG], sig_j[MR_NSIG]; float sig_p[MR_NSIG]; uint8_t dominated[MR_NSIG];
 };
 static_assert(sizeof(MrScratch) <= MR_SCRATCH, "scratch block too small");
 
 __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
 {
-  __shared__ float cnt_s[2][QMAX * 4][64];                  // match / insert usage of the domain being walked
+  // usage of the domain being walked: a match state is visited at most once per node (a bit mask), insert states are counted
+  __shared__ uint16_t cntI_s[QMAX * 4][64];
+  // the domains of the path being sampled, last first: first / last residue, first / last node, null2 odds of A C G T
+  __shared__ uint32_t dom_ij[MR_MAXD][64], dom_km[MR_MAXD][64];
+  __shared__ float dom_n2[MR_MAXD][4][64];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const MrLane e = mr_lane(a, wd, lane);
   if (!e.active) return;
-  const int Q = e.Q, Lr = e.Lr;
+  const int Q = e.Q, Lr = e.Lr, Lw = wd.rows - 1;
   const float *tf = e.pp->tf;
   const float pmove = e.pmove, ploop = e.ploop;
   float *n2 = a.n2sc + a.n2off[e.mi];                       // n2[pos - 1], pos = 1..Lr relative to the region
-  MrScratch &S = *(MrScratch *)(a.scratch + (int64_t)(e.mi - a.mr0) * MR_SCRATCH);
+  MrScratch &S = *(MrScratch *)(a.scratch + (int64_t)(e.mi - a.u0) * MR_SCRATCH);
   for (int pos = 0; pos < Lr; pos++) n2[pos] = 0.0f;
+  for (int z = 0; z < MR_HASH; z++) S.hslot[z] = 0;
   uint32_t rng = rnd_mix3(42u, 87654321u, 12345678u);
   if (rng == 0) rng = 42;
   int ntup = 0, nsamp = 0, status = 0;
   auto MV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 0, lane); };
   auto DV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 1, lane); };
   auto IV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 2, lane); };
-  auto TFC = [&](int q, int t, int r) { return tf[((q) * 8 + (t)) * 4 + r]; };
   const unsigned short dgm[16] = {1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15};
 
-  for (int t = 0; t < 200 && status == 0; t++) {
-    int i = Lr, k = 0, s0 = ST_C, s1 = 0, nd = 0, hi = Lr;
+  // The lanes of a wave sample different regions.  Left to themselves they would be in different states at any moment and
+  // the wave would run every state's code in every step (measured: 9 us per step, most of it the rare but long E and B
+  // states that SOME lane is always in).  Every path has the same shape -- C* E (M|D|I)* B [J* E (M|D|I)* B]* N* -- so the
+  // wave walks it in phases, all lanes in the same kind of state: the special-state loops, then E for every lane that reached
+  // it, then the core states, then B.  A lane's own sequence of random draws is untouched.  Inside the core phase the loads
+  // of a step are issued for all three states at once and the choice runs through one routine.  N -> N steps draw nothing
+  // and record nothing, so a path that enters N is finished.  What a finished domain needs done for its residues waits until
+  // the path is complete and is then done by all lanes together.
+  unsigned long long tk_walk = 0, tk_close = 0;
+  for (int t = 0; t < 200; t++) {
+    if (__ballot(status == 0) == 0ull) break;
+    const unsigned long long tk0 = wall_clock64();
+    int i = Lr, k = 0, s0 = status == 0 ? ST_C : ST_S, nd = 0;
     int dfrom = 0, dto = 0, dk = 0, dm = 0;
-    while (s0 != ST_S) {
-      switch (s0) {
-      case ST_M: {
-        const int q = (k - 1) % Q, r = (k - 1) / Q;
-        float mp, dp, ip;
-        if (q > 0) { mp = comp4(MV(i - 1, q - 1), r); dp = comp4(DV(i - 1, q - 1), r); ip = comp4(IV(i - 1, q - 1), r); }
-        else { mp = comp4_rsh(MV(i - 1, Q - 1), r); dp = comp4_rsh(DV(i - 1, Q - 1), r); ip = comp4_rsh(IV(i - 1, Q - 1), r); }
-        const float xB = mrslab(a, e.r0, i - 1, 36, lane)->w;
-        const int c = choose4(rng, xB * TFC(q, tBM, r), mp * TFC(q, tMM, r), ip * TFC(q, tIM, r), dp * TFC(q, tDM, r));
-        s1 = c == 0 ? ST_B : c == 1 ? ST_M : c == 2 ? ST_I : ST_D;
-        k--; i--;
-        break; }
-      case ST_D: {
-        const int q = (k - 1) % Q, r = (k - 1) / Q;
-        float mp, dp, tmd, tdd;
-        if (q > 0) { mp = comp4(MV(i, q - 1), r); dp = comp4(DV(i, q - 1), r); tmd = TFC(q - 1, tMD, r); tdd = TFC(q - 1, tDD, r); }
-        else {
-          mp = comp4_rsh(MV(i, Q - 1), r); dp = comp4_rsh(DV(i, Q - 1), r);
-          tmd = r == 0 ? 0.0f : TFC(Q - 1, tMD, r - 1); tdd = r == 0 ? 0.0f : TFC(Q - 1, tDD, r - 1);
-        }
-        s1 = choose2(rng, mp * tmd, dp * tdd) == 0 ? ST_M : ST_D;
-        k--;
-        break; }
-      case ST_I: {
-        const int q = (k - 1) % Q, r = (k - 1) / Q;
-        s1 = choose2(rng, comp4(MV(i - 1, q), r) * TFC(q, tMI, r), comp4(IV(i - 1, q), r) * TFC(q, tII, r)) == 0 ? ST_M : ST_I;
-        i--;
-        break; }
-      case ST_N: s1 = (i == 0) ? ST_S : ST_N; break;
-      case ST_C: {
-        if (i < 1) { status = 5; s1 = ST_S; break; }
-        const float cprev = mrslab(a, e.r0, i - 1, 37, lane)->x;
-        const f4 x0 = *mrslab(a, e.r0, i, 36, lane); const float scl = mrslab(a, e.r0, i, 37, lane)->y;
-        s1 = choose2(rng, cprev * ploop, x0.x * 0.5f * scl) == 0 ? ST_C : ST_E;
-        break; }
-      case ST_J: {
-        if (i < 1) { status = 5; s1 = ST_S; break; }
-        const float jprev = mrslab(a, e.r0, i - 1, 36, lane)->z;
-        const f4 x0 = *mrslab(a, e.r0, i, 36, lane); const float scl = mrslab(a, e.r0, i, 37, lane)->y;
-        s1 = choose2(rng, jprev * ploop, x0.x * 0.5f * scl) == 0 ? ST_J : ST_E;
-        break; }
-      case ST_E: {
-        double sum = 0.0;
-        const double roll = rng_next(rng);
-        const double norm = 1.0 / (double)mrslab(a, e.r0, i, 36, lane)->x;
-        const float xEv = (float)norm;
-        s1 = -1;
-        while (s1 < 0) {
-          for (int q = 0; q < Q && s1 < 0; q++) {
-            f4 u = MV(i, q);
-            for (int r = 0; r < 4 && s1 < 0; r++) { sum += (double)(comp4(u, r) * xEv); if (roll < sum) { k = r * Q + q + 1; s1 = ST_M; } }
-            if (s1 >= 0) break;
-            u = DV(i, q);
-            for (int r = 0; r < 4 && s1 < 0; r++) { sum += (double)(comp4(u, r) * xEv); if (roll < sum) { k = r * Q + q + 1; s1 = ST_D; } }
-          }
-          if (s1 < 0 && sum < 0.99) { status = 1; s1 = ST_S; }          // HMMER throws here
-        }
-        if (status) break;
-        if (nd >= MR_MAXD) { status = 2; s1 = ST_S; break; }
-        nd++;
-        dfrom = dto = dk = dm = 0;
-        for (int z = 0; z < Q * 4; z++) { cnt_s[0][z][lane] = 0.f; cnt_s[1][z][lane] = 0.f; }
-        break; }
-      case ST_B: {
-        const f4 x0 = *mrslab(a, e.r0, i, 36, lane);
-        s1 = choose2(rng, x0.y * pmove, x0.z * pmove) == 0 ? ST_N : ST_J;
-        // the domain that was being walked is complete: its sample, its null2 odds, its residues
-        if (nsamp >= MR_SCAP) { status = 3; s1 = ST_S; break; }
-        const unsigned long long key = pack_tup(dfrom + e.m.ireg - 1, dto + e.m.ireg - 1, dk, dm);
-        int tix = 0;
-        while (tix < ntup && S.key[tix] != key) tix++;
-        if (tix == ntup) {
-          if (ntup >= MR_TCAP) { status = 4; s1 = ST_S; break; }
-          S.key[ntup] = key; S.tcount[ntup] = 0; ntup++;
-        }
-        S.tcount[tix]++;
-        S.tid[nsamp] = (uint16_t)tix; S.tidx[nsamp] = (uint8_t)t; nsamp++;
-        int Ld = 0;
-        for (int z = 0; z < Q * 4; z++) Ld += (int)cnt_s[0][z][lane] + (int)cnt_s[1][z][lane];
-        const float norm = (float)(1.0 / (double)(float)Ld);
-        const float xfactor = (0.0f * norm + 0.0f * norm) + 0.0f * norm;
-        float null2[NCODE];
-        for (int x = 0; x < 4; x++) {
-          V4 sv = vzero();
-          const float *rp = e.pp->rf + x * QMAX * 4;
-          for (int q = 0; q < Q; q++) {
-            V4 mv, iv;
-            mv.a = (f2){cnt_s[0][q * 4 + 0][lane], cnt_s[0][q * 4 + 1][lane]}; mv.b = (f2){cnt_s[0][q * 4 + 2][lane], cnt_s[0][q * 4 + 3][lane]};
-            iv.a = (f2){cnt_s[1][q * 4 + 0][lane], cnt_s[1][q * 4 + 1][lane]}; iv.b = (f2){cnt_s[1][q * 4 + 2][lane], cnt_s[1][q * 4 + 3][lane]};
-            mv = vmul(mv, vset(norm)); iv = vmul(iv, vset(norm));
-            sv = vadd(sv, vmul(mv, vld(rp + q * 4)));
-            sv = vadd(sv, iv);
-          }
-          null2[x] = vhsum(sv);
-          null2[x] += xfactor;
-        }
-        null2[4] = 1.0f;
-        for (int x = 5; x < 16; x++) {
-          float acc = 0.f; int ndg = 0;
-          for (int y = 0; y < 4; y++) if (dgm[x] >> y & 1) { acc += null2[y]; ndg++; }
-          null2[x] = acc / (float)ndg;
-        }
-        // as published: residues up to AND INCLUDING the domain's first one count as outside (+1), the rest of it by null2
-        for (int pos = hi; pos > dto; pos--) n2[pos - 1] += 1.0f;
-        for (int pos = dto; pos > dfrom; pos--) {
-          const int x = e.sq.code(e.off + pos - 1);
-          float v = null2[0];
+    unsigned long long maskM = 0ull;
+    while (__ballot(s0 != ST_S) != 0ull) {
+      // ---- C* / J*: one draw per step
+      while (__ballot(s0 == ST_C || s0 == ST_J) != 0ull) {
+        if (!(s0 == ST_C || s0 == ST_J)) continue;
+        if (i < 1) { status = 5; s0 = ST_S; continue; }
+        const f4 sp0 = *mrslab(a, e.r0, i - 1, 36, lane), sp0b = *mrslab(a, e.r0, i - 1, 37, lane);
+        const f4 sp1 = *mrslab(a, e.r0, i, 36, lane), sp1b = *mrslab(a, e.r0, i, 37, lane);
+        const float w0 = (s0 == ST_C ? sp0b.x : sp0.z) * ploop, w1 = sp1.x * 0.5f * sp1b.y;
+        if (choose_n(rng, 2, w0, w1, 0.0f, 0.0f) == 0) i--; else s0 = ST_E;
+      }
+      // ---- E: which match or delete state the domain ends in
+      if (__ballot(s0 == ST_E) != 0ull) {
+        if (s0 == ST_E) {
+          double sum = 0.0;
+          const double roll = rng_next(rng);
+          const double norm = 1.0 / (double)mrslab(a, e.r0, i, 36, lane)->x;
+          const float xEv = (float)norm;
+          int s1 = -1;
+          while (s1 < 0) {
+            for (int q0 = 0; q0 < Q && s1 < 0; q0 += 3) {               // three node groups' M and D vectors requested at once
+              f4 um[3], ud[3];
 #pragma unroll
-          for (int c = 1; c < NCODE; c++) v = (x == c) ? null2[c] : v;
-          n2[pos - 1] += v;
+              for (int z = 0; z < 3; z++) { const int qq = q0 + z < Q ? q0 + z : Q - 1; um[z] = MV(i, qq); ud[z] = DV(i, qq); }
+#pragma unroll
+              for (int z = 0; z < 3; z++) {
+                if (q0 + z >= Q || s1 >= 0) continue;
+                const int qq = q0 + z;
+                for (int rr = 0; rr < 4 && s1 < 0; rr++) { sum += (double)(comp4(um[z], rr) * xEv); if (roll < sum) { k = rr * Q + qq + 1; s1 = ST_M; } }
+                for (int rr = 0; rr < 4 && s1 < 0; rr++) { sum += (double)(comp4(ud[z], rr) * xEv); if (roll < sum) { k = rr * Q + qq + 1; s1 = ST_D; } }
+              }
+            }
+            if (s1 < 0 && sum < 0.99) { status = 1; s1 = ST_S; }          // HMMER throws here
+          }
+          if (status == 0 && nd >= MR_MAXD) { status = 2; s1 = ST_S; }
+          if (status == 0) {
+            nd++;
+            dfrom = dto = dk = dm = 0;
+            maskM = 0ull;
+            for (int z = 0; z < Q * 4; z++) cntI_s[z][lane] = 0;
+            if (s1 == ST_M) { dto = i; dm = k; dfrom = i; dk = k; maskM |= 1ull << k; }
+          }
+          s0 = s1;
         }
-        hi = dfrom;
-        break; }
-      default: status = 5; s1 = ST_S; break;
       }
-      if (status) break;
-      if (s1 == ST_M) {
-        if (dto == 0) { dto = i; dm = k; }
-        dfrom = i; dk = k;
-        cnt_s[0][((k - 1) % Q) * 4 + (k - 1) / Q][lane] += 1.0f;
-      } else if (s1 == ST_I) {
-        cnt_s[1][((k - 1) % Q) * 4 + (k - 1) / Q][lane] += 1.0f;
+      // ---- (M | D | I)*: the loads of a step for whichever of the three the lane is in, then one choice
+      while (__ballot(s0 == ST_M || s0 == ST_D || s0 == ST_I) != 0ull) {
+        if (!(s0 == ST_M || s0 == ST_D || s0 == ST_I)) continue;
+        const int q = (k - 1) % Q, r = (k - 1) / Q;
+        const bool wrap = (s0 != ST_I) && q == 0;                       // predecessor group is Q-1, one SSE lane to the left
+        const int qa = (s0 == ST_I) ? q : (q > 0 ? q - 1 : Q - 1);
+        const int rowA = (s0 == ST_D) ? i : i - 1;
+        const f4 vm = MV(rowA, qa), vd = DV(rowA, qa), vi = IV(rowA, qa);
+        const float xB = mrslab(a, e.r0, i - 1, 36, lane)->w;
+        // transition operands: M uses BM MM IM DM of its own group, D uses MD DD of the predecessor group, I uses MI II of its own
+        const int tq = (s0 == ST_D) ? qa : q;
+        const int tr = (wrap && s0 == ST_D) ? (r > 0 ? r - 1 : 0) : r;
+        const int tb = (s0 == ST_M) ? tBM : (s0 == ST_D) ? tMD : tMI;
+        const float t0 = tf[(tq * 8 + tb) * 4 + tr];
+        const float t1 = tf[(tq * 8 + ((s0 == ST_M) ? tMM : (s0 == ST_D) ? tDD : tII)) * 4 + tr];
+        const float t2 = tf[(tq * 8 + tIM) * 4 + tr], t3 = tf[(tq * 8 + tDM) * 4 + tr];
+        const float pm = wrap ? comp4_rsh(vm, r) : comp4(vm, r), pd = wrap ? comp4_rsh(vd, r) : comp4(vd, r), pi = wrap ? comp4_rsh(vi, r) : comp4(vi, r);
+        const bool zero = s0 == ST_D && wrap && r == 0;                 // right-shifted operands: lane 0 holds 0
+        float w0, w1, w2 = 0.0f, w3 = 0.0f;
+        if (s0 == ST_M) { w0 = xB * t0; w1 = pm * t1; w2 = pi * t2; w3 = pd * t3; }
+        else if (s0 == ST_D) { w0 = pm * (zero ? 0.0f : t0); w1 = pd * (zero ? 0.0f : t1); }
+        else { w0 = pm * t0; w1 = pi * t1; }
+        const int c = choose_n(rng, s0 == ST_M ? 4 : 2, w0, w1, w2, w3);
+        int s1;
+        if (s0 == ST_M) { s1 = c == 0 ? ST_B : c == 1 ? ST_M : c == 2 ? ST_I : ST_D; k--; i--; }
+        else if (s0 == ST_D) { s1 = c == 0 ? ST_M : ST_D; k--; }
+        else { s1 = c == 0 ? ST_M : ST_I; i--; }
+        if (s1 == ST_M) {
+          if (dto == 0) { dto = i; dm = k; }
+          dfrom = i; dk = k;
+          maskM |= 1ull << k;
+        } else if (s1 == ST_I) {
+          cntI_s[((k - 1) % Q) * 4 + (k - 1) / Q][lane] += 1;
+        }
+        s0 = s1;
       }
-      if ((s1 == ST_N || s1 == ST_J || s1 == ST_C) && s1 == s0) i--;
-      s0 = s1;
+      // ---- B: where the domain was entered from, and p7_Null2_ByTrace over its states (only match and insert states emit)
+      if (__ballot(s0 == ST_B) != 0ull) {
+        if (s0 == ST_B) {
+          const f4 sp1 = *mrslab(a, e.r0, i, 36, lane);
+          s0 = choose_n(rng, 2, sp1.y * pmove, sp1.z * pmove, 0.0f, 0.0f) == 0 ? ST_S : ST_J;        // N: the path is finished
+          int Ld = __popcll(maskM);
+          for (int z = 0; z < Q * 4; z++) Ld += (int)cntI_s[z][lane];
+          const float norm = (float)(1.0 / (double)(float)Ld);
+          const float xfactor = (0.0f * norm + 0.0f * norm) + 0.0f * norm;
+          V4 sv[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) sv[x] = vzero();
+          for (int qq = 0; qq < Q; qq++) {
+            V4 mv, iv;
+            // node of (group qq, SSE lane z) = z Q + qq + 1; its match count is 1 or 0
+            mv.a = (f2){(float)((maskM >> (0 * Q + qq + 1)) & 1ull), (float)((maskM >> (1 * Q + qq + 1)) & 1ull)};
+            mv.b = (f2){(float)((maskM >> (2 * Q + qq + 1)) & 1ull), (float)((maskM >> (3 * Q + qq + 1)) & 1ull)};
+            iv.a = (f2){(float)cntI_s[qq * 4 + 0][lane], (float)cntI_s[qq * 4 + 1][lane]}; iv.b = (f2){(float)cntI_s[qq * 4 + 2][lane], (float)cntI_s[qq * 4 + 3][lane]};
+            mv = vmul(mv, vset(norm)); iv = vmul(iv, vset(norm));
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+              sv[x] = vadd(sv[x], vmul(mv, vld(e.pp->rf + x * QMAX * 4 + qq * 4)));
+              sv[x] = vadd(sv[x], iv);
+            }
+          }
+          dom_ij[nd - 1][lane] = (uint32_t)dfrom | ((uint32_t)dto << 16);
+          dom_km[nd - 1][lane] = (uint32_t)dk | ((uint32_t)dm << 8);
+#pragma unroll
+          for (int x = 0; x < 4; x++) { float v = vhsum(sv[x]); v += xfactor; dom_n2[nd - 1][x][lane] = v; }
+        }
+      }
     }
-    if (status) break;
-    for (int pos = hi; pos >= 1; pos--) n2[pos - 1] += 1.0f;
+    const unsigned long long tk1 = wall_clock64();
+    tk_walk += tk1 - tk0;
+    if (status) continue;
+    // ---- after the path, all lanes together: its samples ...
+    for (int d = 0; d < nd; d++) {
+      if (nsamp >= MR_SCAP) { status = 3; break; }
+      const uint32_t ij = dom_ij[d][lane], km = dom_km[d][lane];
+      const unsigned long long key = pack_tup((int)(ij & 0xffff), (int)(ij >> 16), (int)(km & 0xff), (int)(km >> 8));   // relative to the region
+      uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 40) & (MR_HASH - 1);
+      int tix = -1;
+      for (;;) {
+        const int v = S.hslot[h];
+        if (v == 0) break;
+        if (S.key[v - 1] == key) { tix = v - 1; break; }
+        h = (h + 1) & (MR_HASH - 1);
+      }
+      if (tix < 0) {
+        if (ntup >= MR_TCAP) { status = 4; break; }
+        tix = ntup; S.key[ntup] = key; S.tcount[ntup] = 0; ntup++;
+        S.hslot[h] = (uint16_t)(tix + 1);
+      }
+      S.tcount[tix]++;
+      S.tid[nsamp] = (uint16_t)tix; S.tidx[nsamp] = (uint8_t)t; nsamp++;
+    }
+    if (status) continue;
+    // ... and its residues' null2 terms.  As published: residues up to AND INCLUDING a domain's first one count as outside
+    // (+1), the rest of the domain by its null2 odds; a residue takes exactly one term per path, so their order is free.
+    {
+      int d = 0;
+      uint32_t cw = 0; int cwi = -1;
+      // four residues per round: their terms first, then four independent read-modify-writes in flight together
+      for (int p4 = Lw; p4 >= 1; p4 -= 4) {
+        float v[4];
+#pragma unroll
+        for (int z = 0; z < 4; z++) {
+          const int pos = p4 - z;
+          v[z] = 1.0f;
+          if (pos < 1 || pos > Lr) continue;
+          while (d < nd && pos <= (int)(dom_ij[d][lane] & 0xffff)) d++;
+          if (d < nd && pos <= (int)(dom_ij[d][lane] >> 16)) {
+            const int p0 = e.off + pos - 1;
+            int x;
+            if (e.sq.nexc == 0) { if ((p0 >> 4) != cwi) { cwi = p0 >> 4; cw = e.sq.w[cwi]; } x = (int)((cw >> (2 * (p0 & 15))) & 3u); }
+            else x = e.sq.code(p0);
+            if (x < 4) v[z] = dom_n2[d][x][lane];
+            else {
+              float acc = 0.f; int ndg = 0;
+#pragma unroll
+              for (int y = 0; y < 4; y++) if (dgm[x] >> y & 1) { acc += dom_n2[d][y][lane]; ndg++; }
+              v[z] = acc / (float)ndg;
+            }
+          }
+        }
+        float o[4];
+#pragma unroll
+        for (int z = 0; z < 4; z++) { const int pos = p4 - z; o[z] = (pos >= 1 && pos <= Lr) ? n2[pos - 1] : 0.0f; }
+#pragma unroll
+        for (int z = 0; z < 4; z++) { const int pos = p4 - z; if (pos >= 1 && pos <= Lr) n2[pos - 1] = o[z] + v[z]; }
+      }
+    }
+    tk_close += wall_clock64() - tk1;
   }
+  const unsigned long long tk2 = wall_clock64();
 
   MrOut out;
   out.status = status; out.nenv = 0;
@@ -410,24 +465,48 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
     const int ninc = S.ninc[c];
     if ((float)ninc / (float)200 < 0.25f) continue;
     const int thr = (int)ceilf((float)ninc * 0.02f);
-    // endpoint histograms without the arrays: weight of value v = copies of the cluster's tuples that carry it
+    // the cluster's members, then per coordinate the endpoint histogram (weight of a value = copies of the tuples carrying it)
+    int nm = 0;
+    int lo[4] = {1 << 30, 1 << 30, 1 << 30, 1 << 30}, hi[4] = {-1, -1, -1, -1};
+    for (int h = 0; h < ntup; h++) {
+      if (S.comp[h] != c) continue;
+      S.stack[nm++] = (uint16_t)h;
+      const Tup th = unpack_tup(S.key[h]);
+      const int v[4] = {th.i, th.k, th.j, th.m};
+#pragma unroll
+      for (int f = 0; f < 4; f++) { lo[f] = min(lo[f], v[f]); hi[f] = max(hi[f], v[f]); }
+    }
     int best[4];
     for (int f = 0; f < 4; f++) {
       const bool leftmost = f < 2;                    // i and k: leftmost value with enough endpoints; j and m: rightmost
+      const int W = hi[f] - lo[f] + 1;
       int pick = -1, am = -1, amw = -1;
-      for (int h = 0; h < ntup; h++) {
-        if (S.comp[h] != c) continue;
-        const Tup th = unpack_tup(S.key[h]);
-        const int v = f == 0 ? th.i : f == 1 ? th.k : f == 2 ? th.j : th.m;
-        int w = 0;
-        for (int u = 0; u < ntup; u++) {
-          if (S.comp[u] != c) continue;
-          const Tup tu = unpack_tup(S.key[u]);
-          const int vu = f == 0 ? tu.i : f == 1 ? tu.k : f == 2 ? tu.j : tu.m;
-          if (vu == v) w += S.tcount[u];
+      if (W <= MR_EPC) {
+        for (int z = 0; z < W; z++) S.epc[z] = 0;
+        for (int x = 0; x < nm; x++) {
+          const int h = S.stack[x];
+          const Tup th = unpack_tup(S.key[h]);
+          const int v = f == 0 ? th.i : f == 1 ? th.k : f == 2 ? th.j : th.m;
+          S.epc[v - lo[f]] += S.tcount[h];
         }
-        if (w >= thr && (pick < 0 || (leftmost ? v < pick : v > pick))) pick = v;
-        if (w > amw || (w == amw && v < am)) { amw = w; am = v; }        // esl_vec_IArgMax: the first (smallest) maximum
+        for (int z = 0; z < W; z++) {
+          const int w = S.epc[z];
+          if (w >= thr && (pick < 0 || !leftmost)) pick = lo[f] + z;           // first hit from the left / last hit from the right
+          if (w > amw) { amw = w; am = lo[f] + z; }                              // esl_vec_IArgMax: the first maximum
+        }
+      } else {
+        for (int x = 0; x < nm; x++) {
+          const Tup th = unpack_tup(S.key[S.stack[x]]);
+          const int v = f == 0 ? th.i : f == 1 ? th.k : f == 2 ? th.j : th.m;
+          int w = 0;
+          for (int y = 0; y < nm; y++) {
+            const Tup tu = unpack_tup(S.key[S.stack[y]]);
+            const int vu = f == 0 ? tu.i : f == 1 ? tu.k : f == 2 ? tu.j : tu.m;
+            if (vu == v) w += S.tcount[S.stack[y]];
+          }
+          if (w >= thr && (pick < 0 || (leftmost ? v < pick : v > pick))) pick = v;
+          if (w > amw || (w == amw && v < am)) { amw = w; am = v; }
+        }
       }
       best[f] = pick >= 0 ? pick : am;
     }
@@ -464,46 +543,58 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
   }
   out.status = status;
   a.out[e.mi] = out;
+  if (a.dbg && lane == 0) { atomicAdd(&a.dbg[0], tk_walk); atomicAdd(&a.dbg[1], tk_close); atomicAdd(&a.dbg[2], wall_clock64() - tk2); atomicAdd(&a.dbg[3], 1ull); }
 }
 
 // =========================================================================================
 // list building: multidomain regions of every pair, in pair order
 __global__ void __launch_bounds__(256) k_mr_count(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, int64_t npairs,
-                                                  int32_t *__restrict__ cnt, int32_t *__restrict__ len)
+                                                  int32_t *__restrict__ cnt)
 {
   const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pi > npairs) return;
-  int c = 0, l = 0;
+  int c = 0;
   if (pi < npairs && pout[pi].pass_fwd)
-    for (int k = 0; k < pout[pi].ndom; k++) { const RegionRec r = raw[pi * MAXDOM + k]; if (r.multi) { c++; l += r.jenv - r.ienv + 1; } }
-  cnt[pi] = c; len[pi] = l;
+    for (int k = 0; k < pout[pi].ndom; k++) c += raw[pi * MAXDOM + k].multi != 0;
+  cnt[pi] = c;
 }
 __global__ void __launch_bounds__(256) k_mr_fill(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, int64_t npairs,
-                                                 const int32_t *__restrict__ off, const int32_t *__restrict__ loff, MrRec *__restrict__ mr,
-                                                 int64_t *__restrict__ n2off)
+                                                 const int32_t *__restrict__ off, MrRec *__restrict__ mr)
 {
   const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= npairs || !pout[pi].pass_fwd) return;
-  int o = off[pi]; int64_t lo = loff[pi];
+  int o = off[pi];
   for (int k = 0; k < pout[pi].ndom; k++) {
     const RegionRec r = raw[pi * MAXDOM + k];
     if (!r.multi) continue;
     MrRec m; m.pair = (int32_t)pi; m.slot = k; m.ireg = r.ienv; m.jreg = r.jenv;
-    mr[o] = m; n2off[o] = lo;
-    o++; lo += r.jenv - r.ienv + 1;
+    mr[o++] = m;
   }
 }
-__global__ void k_mr_wave_rows(const WaveDesc *w, int nw, const MrRec *mr, int32_t *rows)
+// The ensemble of a region depends on nothing but (profile, target length, the region's residues) -- the random stream is
+// re-seeded for every region -- and amplicons share their conserved flanks, so the regions are memoised exactly like the
+// envelopes (k_derep.hip: k_region_keys / k_region_resolve): only the first copy of each distinct region is sampled.
+__global__ void __launch_bounds__(256) k_mr_ulist(int64_t nmr, const MrRec *__restrict__ mr, const int32_t *__restrict__ rep, const int32_t *__restrict__ is_uniq,
+                                                  const int32_t *__restrict__ urank, int32_t *__restrict__ ulist, int32_t *__restrict__ ulen,
+                                                  int32_t *__restrict__ mr_u)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nw) return;
-  int mx = 0;
-  for (int k = 0; k < w[i].count; k++) { const MrRec r = mr[w[i].first + k]; mx = max(mx, r.jreg - r.ireg + 1); }
-  rows[i] = mx + 1;
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nmr) return;
+  const int32_t r = rep[m] >= 0 ? rep[m] : (int32_t)m;
+  mr_u[m] = urank[r];
+  if (is_uniq[m]) { ulist[urank[m]] = (int32_t)m; ulen[urank[m]] = mr[m].jreg - mr[m].ireg + 1; }
+}
+__global__ void __launch_bounds__(256) k_mr_reorder(int64_t nu, int64_t nmr, const int32_t *__restrict__ newpos, const int32_t *__restrict__ ulist_in,
+                                                    int32_t *__restrict__ ulist_out, int32_t *__restrict__ mr_u)
+{
+  const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < nu) ulist_out[newpos[x]] = ulist_in[x];
+  if (x < nmr) mr_u[x] = newpos[mr_u[x]];
 }
 // every pair with multidomain regions gets its envelope list rebuilt: a clustered region is replaced by its envelopes
 __global__ void __launch_bounds__(256) k_mr_apply(PairOut *__restrict__ pout, RegionRec *__restrict__ raw, int64_t npairs,
-                                                  const int32_t *__restrict__ off, const MrOut *__restrict__ out, unsigned long long *__restrict__ counters)
+                                                  const int32_t *__restrict__ off, const int32_t *__restrict__ mr_u, const MrOut *__restrict__ out,
+                                                  unsigned long long *__restrict__ counters)
 {
   const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= npairs || !pout[pi].pass_fwd) return;
@@ -515,10 +606,10 @@ __global__ void __launch_bounds__(256) k_mr_apply(PairOut *__restrict__ pout, Re
   for (int k = 0; k < pout[pi].ndom; k++) {
     const RegionRec r = raw[pi * MAXDOM + k];
     if (!r.multi) { if (n < MAXDOM) tmp[n++] = r; else over = 1; continue; }
-    const MrOut o = out[mk];
+    const MrOut o = out[mr_u[mk]];
     nfail += o.status != 0; nenv += o.nenv;
     for (int z = 0; z < o.nenv; z++) {
-      RegionRec c; c.pair = (int32_t)pi; c.ienv = o.ei[z]; c.jenv = o.ej[z]; c.multi = mk + 1;
+      RegionRec c; c.pair = (int32_t)pi; c.ienv = o.ei[z] + r.ienv - 1; c.jenv = o.ej[z] + r.ienv - 1; c.multi = mk + 1;
       if (n < MAXDOM) tmp[n++] = c; else over = 1;
     }
     mk++;
@@ -530,19 +621,26 @@ __global__ void __launch_bounds__(256) k_mr_apply(PairOut *__restrict__ pout, Re
   if (nenv) atomicAdd(&counters[1], nenv);
 }
 
-void launch_mr_count(const PairOut *pout, const RegionRec *raw, int64_t npairs, int32_t *cnt, int32_t *len, hipStream_t st)
+void launch_mr_count(const PairOut *pout, const RegionRec *raw, int64_t npairs, int32_t *cnt, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_mr_count, dim3((unsigned)((npairs + 1 + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, cnt, len);
+  hipLaunchKernelGGL(k_mr_count, dim3((unsigned)((npairs + 1 + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, cnt);
 }
-void launch_mr_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *off, const int32_t *loff, MrRec *mr, int64_t *n2off, hipStream_t st)
+void launch_mr_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *off, MrRec *mr, hipStream_t st)
 {
   if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_mr_fill, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, off, loff, mr, n2off);
+  hipLaunchKernelGGL(k_mr_fill, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, off, mr);
 }
-void launch_mr_wave_rows(const WaveDesc *w, int nw, const MrRec *mr, int32_t *rows, hipStream_t st)
+void launch_mr_ulist(int64_t nmr, const MrRec *mr, const int32_t *rep, const int32_t *is_uniq, const int32_t *urank, int32_t *ulist, int32_t *ulen,
+                     int32_t *mr_u, hipStream_t st)
 {
-  if (nw <= 0) return;
-  hipLaunchKernelGGL(k_mr_wave_rows, dim3((nw + 255) / 256), dim3(256), 0, st, w, nw, mr, rows);
+  if (nmr <= 0) return;
+  hipLaunchKernelGGL(k_mr_ulist, dim3((unsigned)((nmr + 255) / 256)), dim3(256), 0, st, nmr, mr, rep, is_uniq, urank, ulist, ulen, mr_u);
+}
+void launch_mr_reorder(int64_t nu, int64_t nmr, const int32_t *newpos, const int32_t *ulist_in, int32_t *ulist_out, int32_t *mr_u, hipStream_t st)
+{
+  const int64_t n = nu > nmr ? nu : nmr;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_mr_reorder, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, nu, nmr, newpos, ulist_in, ulist_out, mr_u);
 }
 void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st)
 {
@@ -550,10 +648,11 @@ void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st)
   hipLaunchKernelGGL(k_mr_fwd, dim3(nwaves), dim3(64), 0, st, a, wave0);
   hipLaunchKernelGGL(k_mr_trace, dim3(nwaves), dim3(64), 0, st, a, wave0);
 }
-void launch_mr_apply(PairOut *pout, RegionRec *raw, int64_t npairs, const int32_t *off, const MrOut *out, unsigned long long *counters, hipStream_t st)
+void launch_mr_apply(PairOut *pout, RegionRec *raw, int64_t npairs, const int32_t *off, const int32_t *mr_u, const MrOut *out, unsigned long long *counters,
+                     hipStream_t st)
 {
   if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_mr_apply, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, off, out, counters);
+  hipLaunchKernelGGL(k_mr_apply, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, off, mr_u, out, counters);
 }
 
 }  // namespace itsx

@@ -1095,9 +1095,10 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   // (k_env_post), a clustered region's residues the scores of its traceback ensemble (k_mr_trace).  The per-sequence
   // correction is ONE running float sum over all residues in order; an envelope's own correction the sum over its residues.
   auto add_region = [&](int m, float acc) {
-    if (a.mrout[m].status != 0) return acc;
+    const int u = a.mr_u[m];
+    if (a.mrout[u].status != 0) return acc;
     const MrRec mr = a.mr[m];
-    const float *n2 = a.n2sc + a.n2off[m];
+    const float *n2 = a.n2sc + a.n2off[u];
     for (int pos = mr.ireg; pos <= mr.jreg; pos++) acc += n2[pos - mr.ireg];
     return acc;
   };
@@ -1107,7 +1108,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   auto env_dc = [&](const RegionRec &rg, const RegionOut &ro) {
     if (!have_mr || rg.multi == 0) return ro.domcorrection;
     const int m = rg.multi - 1;
-    const float *n2 = a.n2sc + a.n2off[m];
+    const float *n2 = a.n2sc + a.n2off[a.mr_u[m]];
     const int ireg = a.mr[m].ireg;
     float dc = 0.0f;
     for (int pos = rg.ienv; pos <= rg.jenv; pos++) dc += n2[pos - ireg];

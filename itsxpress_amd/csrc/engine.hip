@@ -1415,29 +1415,29 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       launch_mr_reorder(NU, NMR, newpos.p, ulist0.p, ulist.p, mru.p, st);
       HIPCHK(upload(ctx->w_n2off, hn2, st)); HIPCHK(upload(ctx->w_mrrowoff, hrow, st));
       HIPCHK(ctx->w_mrout.alloc((size_t)NU)); HIPCHK(ctx->w_n2sc.alloc((size_t)hn2[(size_t)NU] + 1));
-      const int NMW = (int)(((int64_t)NU + 63) / 64);
+      const int NMW = (int)(((int64_t)NU + MR_LANES - 1) / MR_LANES);
       std::vector<WaveDesc> mw((size_t)NMW);
       for (int w = 0; w < NMW; w++) {
         WaveDesc &d = mw[(size_t)w]; d = WaveDesc{};
-        d.prof = -1; d.first = (int64_t)w * 64; d.count = (int32_t)std::min<int64_t>(64, (int64_t)NU - (int64_t)w * 64);
+        d.prof = -1; d.first = (int64_t)w * MR_LANES; d.count = (int32_t)std::min<int64_t>(MR_LANES, (int64_t)NU - (int64_t)w * MR_LANES);
         d.rows = hlen[(size_t)ord[(size_t)(d.first + d.count - 1)]] + 1;                  // ascending length: the last lane's
       }
       HIPCHK(upload(ctx->w_mrwaves, mw, st));
       const int64_t mrow_bytes = (int64_t)MRV * 16;
       const int64_t mbudget = std::max<int64_t>(1, (int64_t)(std::min(slab_gb, 16.0) * (1 << 30)) / mrow_bytes);
-      const int64_t wave_cap = std::max<int64_t>(1, ((int64_t)6 << 30) / ((int64_t)MR_SCRATCH * 64));      // 6 GB of bookkeeping blocks per batch
+      const int64_t wave_cap = std::max<int64_t>(1, ((int64_t)6 << 30) / ((int64_t)MR_SCRATCH * MR_LANES));      // 6 GB of bookkeeping blocks per batch
       int w0 = 0;
       while (w0 < NMW) {
         int w1 = w0;
-        const int64_t row0 = hrow[(size_t)w0 * 64];
-        auto rows_to = [&](int w) { return hrow[(size_t)std::min<int64_t>((int64_t)w * 64, NU)] - row0; };
+        const int64_t row0 = hrow[(size_t)w0 * MR_LANES];
+        auto rows_to = [&](int w) { return hrow[(size_t)std::min<int64_t>((int64_t)w * MR_LANES, NU)] - row0; };
         while (w1 < NMW && w1 - w0 < wave_cap && (w1 == w0 || rows_to(w1 + 1) <= mbudget)) w1++;
         const int64_t r = rows_to(w1);
         if ((size_t)r * MRV * 4 > ctx->w_mrslab.cap) HIPCHK(ctx->w_mrslab.alloc((size_t)r * MRV * 4));
-        HIPCHK(ctx->w_mrscratch.alloc((size_t)(w1 - w0) * 64 * MR_SCRATCH));
+        HIPCHK(ctx->w_mrscratch.alloc((size_t)(w1 - w0) * MR_LANES * MR_SCRATCH));
         MrArgs ma{};
         ma.rd = ctx->rd; ma.sorted_uniq = d_sorted; ma.seed_read = ctx->d_seed_read.p; ma.prof = ctx->d_prof.p; ma.pairs = ctx->d_pairs.p;
-        ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = (int64_t)w0 * 64; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
+        ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = (int64_t)w0 * MR_LANES; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
         ma.rowoff = ctx->w_mrrowoff.p; ma.rowoff0 = row0;
         ma.n2off = ctx->w_n2off.p; ma.n2sc = ctx->w_n2sc.p; ma.out = ctx->w_mrout.p; ma.scratch = ctx->w_mrscratch.p;
         static const bool mrdbg = getenv("ITSX_MR_DEBUG") != nullptr;

@@ -206,10 +206,10 @@ static_assert(sizeof(MrScratch) <= MR_SCRATCH, "scratch block too small");
 __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
 {
   // usage of the domain being walked: a match state is visited at most once per node (a bit mask), insert states are counted
-  __shared__ uint16_t cntI_s[QMAX * 4][64];
+  __shared__ uint16_t cntI_s[QMAX * 4][MR_LANES];
   // the domains of the path being sampled, last first: first / last residue, first / last node, null2 odds of A C G T
-  __shared__ uint32_t dom_ij[MR_MAXD][64], dom_km[MR_MAXD][64];
-  __shared__ float dom_n2[MR_MAXD][4][64];
+  __shared__ uint32_t dom_ij[MR_MAXD][MR_LANES], dom_km[MR_MAXD][MR_LANES];
+  __shared__ float dom_n2[MR_MAXD][4][MR_LANES];
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
   const MrLane e = mr_lane(a, wd, lane);
@@ -409,11 +409,13 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
             }
           }
         }
-        float o[4];
+        // fire-and-forget float adds at L2 (global_atomic_add_f32, round to nearest even like v_add_f32): a residue's terms
+        // arrive in path order -- one wave, one address, one channel -- and nothing waits for them until the scores are read
 #pragma unroll
-        for (int z = 0; z < 4; z++) { const int pos = p4 - z; o[z] = (pos >= 1 && pos <= Lr) ? n2[pos - 1] : 0.0f; }
-#pragma unroll
-        for (int z = 0; z < 4; z++) { const int pos = p4 - z; if (pos >= 1 && pos <= Lr) n2[pos - 1] = o[z] + v[z]; }
+        for (int z = 0; z < 4; z++) {
+          const int pos = p4 - z;
+          if (pos >= 1 && pos <= Lr) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(n2 + pos - 1), v[z]);
+        }
       }
     }
     tk_close += wall_clock64() - tk1;
@@ -444,8 +446,16 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
       const int v = S.stack[--ns];
       members++;
       const Tup tv = unpack_tup(S.key[v]);
-      for (int u = 0; u < ntup; u++)
-        if (S.comp[u] == 0xffff && link_tup(tv, unpack_tup(S.key[u]))) { S.comp[u] = (uint16_t)nc; S.stack[ns++] = (uint16_t)u; }
+      for (int u0 = 0; u0 < ntup; u0 += 4) {                      // four candidates requested together
+        unsigned long long ku[4]; uint16_t cu[4];
+#pragma unroll
+        for (int z = 0; z < 4; z++) { const int u = u0 + z < ntup ? u0 + z : ntup - 1; ku[z] = S.key[u]; cu[z] = S.comp[u]; }
+#pragma unroll
+        for (int z = 0; z < 4; z++) {
+          const int u = u0 + z;
+          if (u < ntup && cu[z] == 0xffff && link_tup(tv, unpack_tup(ku[z]))) { S.comp[u] = (uint16_t)nc; S.stack[ns++] = (uint16_t)u; }
+        }
+      }
     }
     const Tup t0 = unpack_tup(S.key[h0]);
     S.ninc[nc] = (members == 1 && !link_tup(t0, t0)) ? 0xffff : 0;      // 0xffff: a set of singletons, never reported

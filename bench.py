@@ -195,7 +195,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from itsxpress_amd import Engine
-    from itsxpress_amd.dist import allreduce_domz, exchange_coords, gather_coords, global_derep
+    from itsxpress_amd.dist import allreduce_domz_device, exchange_rows, gather_rows, global_derep, read_rows
     import synth
     _load_pmc()
 
@@ -237,18 +237,17 @@ def main():
             eng.derep(strand_both=True, minseqlength=32)
         g = global_derep(eng, n_local, dev) if (use_dist and args.global_derep) else None
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
-        if use_dist:
-            eng.set_domz(allreduce_domz(eng.get_domz(), dev))
+        if not use_dist:
+            eng.finalize(domE=10.0)
+            return [np.stack(eng.trim_coords("3_", "4_"), axis=1)]
+        # N > 1: the two exchanges run on the engine's own device buffers (RCCL over xGMI), nothing bounces through numpy
+        allreduce_domz_device(eng, dev)                # hmmsearch's domZ is a count over the WHOLE data set
         eng.finalize(domE=10.0)
         if g is not None:            # coordinates of the uniques scored elsewhere arrive here, then fan out to the reads
-            us, ue, ut, ui = exchange_coords(g, *eng.rep_coords("3_", "4_"), device=dev)
-            uq = eng.get_derep()[2]
-            ok = uq >= 0
-            uq = np.maximum(uq, 0)
-            c = tuple(np.where(ok, a[uq], d).astype(np.int32) for a, d in ((us, -1), (ue, -1), (ut, -1), (ui, 0)))
+            rows = read_rows(eng, exchange_rows(g, eng.rep_coords_device("3_", "4_", dev)), dev)
         else:
-            c = eng.trim_coords("3_", "4_")
-        return gather_coords(*c, device=dev) if use_dist else [np.stack(c, axis=1)]
+            rows = eng.trim_coords_device("3_", "4_", dev)
+        return gather_rows(rows, dst=0)
 
     for _ in range(args.warmup):
         step()

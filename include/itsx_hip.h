@@ -232,6 +232,21 @@ int itsx_trim_coords(itsx_ctx *ctx, const char *left_prefix, const char *right_p
 int itsx_rep_coords(itsx_ctx *ctx, const char *left_prefix, const char *right_prefix,
                     int32_t *start, int32_t *stop, int32_t *tlen, int32_t *in_ddict);
 
+/* ---- device-resident exchange for multi-GPU drivers (itsxpress_amd/dist.py; RCCL over xGMI): the quantities the ranks
+ * exchange stay in the context's device memory, so a collective library reduces / gathers / scatters them where they are.
+ * Every pointer is valid until the next call that recomputes the same quantity on this context.
+ * itsx_domz_device: after itsx_search, int64[n_samples * n_profiles] reported-target counters; all-reduce them in place, then
+ *   call itsx_search_finalize (it uses the device values; itsx_set_domz returns to host values).
+ * itsx_trim_coords_device / itsx_rep_coords_device: int32 rows [n][4] = (start, stop, tlen, in_ddict) per read / representative.
+ * itsx_derep_device: rep_of / uniq_of (int32[n_reads]), strand (int8[n_reads]), seed_read (int32[n_unique]).
+ * itsx_unique_keys128_device: int64 rows [n_unique][4] = (key0, key1, gidx_base + first occurrence, 1 if the forward strand is
+ *   the canonical orientation): the orientation-free 128-bit key of each local unique (two XXH64 seeds). */
+int itsx_domz_device(itsx_ctx *ctx, int64_t **d_domz, int64_t *n);
+int itsx_trim_coords_device(itsx_ctx *ctx, const char *left_prefix, const char *right_prefix, int32_t **d_rows, int64_t *n_rows);
+int itsx_rep_coords_device(itsx_ctx *ctx, const char *left_prefix, const char *right_prefix, int32_t **d_rows, int64_t *n_rows);
+int itsx_derep_device(itsx_ctx *ctx, const int32_t **d_rep_of, const int32_t **d_uniq_of, const int8_t **d_strand, const int32_t **d_seed_read);
+int itsx_unique_keys128_device(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, int64_t gidx_base, int64_t **d_tuples, int64_t *n_unique);
+
 /* ---- file-compatible outputs (users pass --keeptemp; itsxpress/SeqSample.py:104-105,190) */
 int itsx_write_uc(const itsx_ctx *ctx, const char *path);
 int itsx_write_rep_fasta(const itsx_ctx *ctx, const char *path);

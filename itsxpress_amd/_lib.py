@@ -52,7 +52,8 @@ STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares
 EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy", "itsx_load_profiles_file",
-           "itsx_load_profiles_mem", "itsx_profile_name", "itsx_profile_tables", "itsx_set_reads", "itsx_set_reads_view", "itsx_set_reads_device",
+           "itsx_load_profiles_mem", "itsx_profile_name", "itsx_profile_tables", "itsx_set_reads", "itsx_set_reads_view", "itsx_set_reads_device", "itsx_domz_device", "itsx_trim_coords_device",
+           "itsx_rep_coords_device", "itsx_derep_device", "itsx_unique_keys128_device",
            "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_cluster", "itsx_get_derep", "itsx_unique_keys", "itsx_set_active_uniques", "itsx_get_uniques",
            "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
@@ -89,6 +90,11 @@ def lib():
         "itsx_set_reads": (i32, [vp, vp, vp, i64, vp, vp]),
         "itsx_set_reads_view": (i32, [vp, vp, vp, i64, vp, vp]),
         "itsx_set_reads_device": (i32, [vp, vp, vp, i64, vp, vp]),
+        "itsx_domz_device": (i32, [vp, vp, vp]),
+        "itsx_trim_coords_device": (i32, [vp, cp, cp, vp, vp]),
+        "itsx_rep_coords_device": (i32, [vp, cp, cp, vp, vp]),
+        "itsx_derep_device": (i32, [vp, vp, vp, vp, vp]),
+        "itsx_unique_keys128_device": (i32, [vp, C.c_uint64, C.c_uint64, i64, vp, vp]),
         "itsx_load_reads_file": (i32, [vp, cp, vp]),
         "itsx_derep": (i32, [vp, i32, i32, vp]),
         "itsx_cluster": (i32, [vp, f64, i32, vp]),

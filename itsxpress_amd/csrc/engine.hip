@@ -87,6 +87,32 @@ __global__ void k_read_coords(int64_t n, const int32_t *uniq_of, const int32_t *
   if (u < 0) { start[r] = stop[r] = tlen[r] = -1; ind[r] = 0; return; }
   start[r] = us[u]; stop[r] = ue[u]; tlen[r] = ut[u]; ind[r] = uind[u];
 }
+__global__ void k_pack_coords4(int64_t n, const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d, int32_t *out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { out[i * 4] = a[i]; out[i * 4 + 1] = b[i]; out[i * 4 + 2] = c[i]; out[i * 4 + 3] = d[i]; }
+}
+// per unique: the orientation-free 128-bit key (two XXH64 seeds over the packed read, length folded in; the smaller of
+// forward / reverse complement), the global index of its first occurrence, and whether the forward strand is the canonical one
+__global__ void k_unique_keys128(int32_t U, const int32_t *seed_read, const int32_t *len, const uint64_t *f0, const uint64_t *r0, const uint64_t *f1,
+                                 const uint64_t *r1, int64_t base, int64_t *out)
+{
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  const int32_t r = seed_read[u];
+  const uint64_t lm = (uint64_t)len[r] * 0x9E3779B97F4A7C15ULL;
+  const uint64_t kf0 = f0[r] ^ lm, kr0 = r0[r] ^ lm, kf1 = f1[r] ^ lm, kr1 = r1[r] ^ lm;
+  const bool fwd_le = (kf0 < kr0) || (kf0 == kr0 && kf1 <= kr1);
+  out[(int64_t)u * 4 + 0] = (int64_t)(fwd_le ? kf0 : kr0);
+  out[(int64_t)u * 4 + 1] = (int64_t)(fwd_le ? kf1 : kr1);
+  out[(int64_t)u * 4 + 2] = base + r;
+  out[(int64_t)u * 4 + 3] = fwd_le ? 1 : 0;
+}
+__global__ void k_widen_i32(int64_t n, const int32_t *in, int64_t *out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
 }  // namespace itsx
 
 using namespace itsx;
@@ -190,6 +216,9 @@ struct itsx_ctx {
   std::vector<int64_t> dom_n;            // padded rows in each segment
   int64_t pair_budget = 0; int32_t trace_u0 = 0; int n_chunks = 0; bool keep_trace = false, trace_sorted = false;
   DBuf<int32_t> d_domz32;
+  DBuf<int64_t> d_domz64; bool domz_on_device = false;     // itsx_domz_device: the caller reduces the counters where they are
+  DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
+  std::vector<int32_t> h_sorted_active;  // the length-sorted list the HMM stages walk (= h_sorted_uniq unless itsx_set_active_uniques narrowed it)
   DBuf<LenTables> d_lt;
   std::vector<int64_t> domz;
   std::vector<itsx_domain> h_dom;        // valid rows, domtblout order
@@ -814,6 +843,7 @@ static int mirror_derep(itsx_ctx *ctx)
     HIPCHK(hipMemcpy(ctx->h_abund.data(), ctx->d_abund.p, (size_t)U * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ctx->h_sorted_uniq.data(), ctx->d_sorted_uniq.p, (size_t)U * 4, hipMemcpyDeviceToHost));
   }
+  ctx->h_sorted_active = ctx->h_sorted_uniq;
   if (ctx->S > 1) {
     ctx->h_usample.resize((size_t)U);
     for (int32_t u = 0; u < U; u++) ctx->h_usample[(size_t)u] = ctx->h_sample[(size_t)ctx->h_seed_read[(size_t)u]];
@@ -1090,6 +1120,7 @@ int itsx_set_active_uniques(itsx_ctx *ctx, const uint8_t *active)
   std::vector<int32_t> keep; keep.reserve((size_t)ctx->U);
   for (int32_t s = 0; s < ctx->U; s++) { const int32_t u = ctx->h_sorted_uniq[(size_t)s]; if (active[u]) keep.push_back(u); }   // stays length-sorted
   ctx->U_active = (int32_t)keep.size();
+  ctx->h_sorted_active = keep;           // the traces and the searched-target count follow the active list
   if (!keep.empty()) {
     HIPCHK(hipMemcpyAsync(ctx->d_sorted_uniq.p, keep.data(), keep.size() * 4, hipMemcpyHostToDevice, ctx->st));
     launch_fill_ulen(ctx->U_active, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, ctx->rd.len, ctx->d_ulen.p, ctx->st);
@@ -1127,7 +1158,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
   S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
-  ctx->have_search = true; ctx->have_final = false;
+  ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
   if (U == 0) return ITSX_OK;
 
   // ---- per-length constants (host libm, as hmmsearch computes them per target)
@@ -1595,6 +1626,23 @@ int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ)
 {
   CTXCHK(ctx && domZ && ctx->have_search);
   for (size_t p = 0; p < ctx->domz.size(); p++) ctx->domz[p] = domZ[p];
+  ctx->domz_on_device = false;
+  return ITSX_OK;
+}
+
+// ---- device-resident exchange (multi-GPU): the caller reduces / gathers these buffers where they are (RCCL), nothing bounces
+// through host arrays.  Pointers stay valid until the next call that recomputes the same quantity.
+int itsx_domz_device(itsx_ctx *ctx, int64_t **d_domz, int64_t *n)
+{
+  CTXCHK(ctx && d_domz && ctx->have_search);
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t m = ctx->domz.size();
+  HIPCHK(ctx->d_domz64.alloc(std::max<size_t>(m, 1)));
+  if (m) HIPCHK(hipMemcpyAsync(ctx->d_domz64.p, ctx->domz.data(), m * 8, hipMemcpyHostToDevice, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  ctx->domz_on_device = true;
+  *d_domz = ctx->d_domz64.p;
+  if (n) *n = (int64_t)m;
   return ITSX_OK;
 }
 
@@ -1605,8 +1653,10 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
   StageTimer tm(ctx->st);
   ctx->h_dom.clear();
   {
-    DBuf<int64_t> &d_dz = ctx->w_dz;
-    HIPCHK(upload(d_dz, ctx->domz, ctx->st));
+    DBuf<int64_t> &d_dz = ctx->domz_on_device ? ctx->d_domz64 : ctx->w_dz;
+    if (ctx->domz_on_device) {             // reduced in place by the caller (RCCL): the host copy follows the device
+      if (!ctx->domz.empty()) HIPCHK(hipMemcpyAsync(ctx->domz.data(), d_dz.p, ctx->domz.size() * 8, hipMemcpyDeviceToHost, ctx->st));
+    } else HIPCHK(upload(d_dz, ctx->domz, ctx->st));
     for (size_t c = 0; c < ctx->dom_n.size(); c++)
       if (ctx->dom_n[c] > 0) launch_finalize(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, domE, ctx->dev_usample(), ctx->P, ctx->st);
     HIPCHK(hipStreamSynchronize(ctx->st));
@@ -1676,7 +1726,7 @@ static int append_traces(itsx_ctx *ctx)
   for (int64_t i = 0; i < NP; i++) {
     if (pr[i].prof < 0) continue;
     itsx_pairtrace t{};
-    t.rep = ctx->h_sorted_uniq[(size_t)ctx->trace_u0 + pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
+    t.rep = ctx->h_sorted_active[(size_t)ctx->trace_u0 + pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
     t.pass_bias = po[i].pass_bias; t.pass_fwd = po[i].pass_fwd; t.msv_sc = po[i].msv_sc; t.filtersc = po[i].filtersc;
     t.fwdsc = po[i].fwdsc; t.bcksc = po[i].bcksc; t.nullsc = po[i].nullsc; t.nregions = po[i].nregions; t.ndom = po[i].ndom;
     ctx->h_trace.push_back(t);
@@ -1911,7 +1961,9 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
 // ------------------------------------------------------------------------------ coordinates
 static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per_read, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
 {
-  CTXCHK(ctx && lp && rp && start && stop && tlen && ind);
+  CTXCHK(ctx && lp && rp);
+  const bool to_host = start && stop && tlen && ind;        // all four, or none (the results stay on the device)
+  if (!to_host && (start || stop || tlen || ind)) return ITSX_E_ARG;
   if (!ctx->have_final) SET_ERR(ctx, ITSX_E_ARG, "coordinates requested before itsx_search_finalize");
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->st;
@@ -1945,7 +1997,7 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
     ctx->stats.n_uniq_multi_winner = hc[0]; ctx->stats.n_reads_multi_winner = hc[1]; ctx->stats.n_uniq_region_cap = hc[2]; ctx->stats.n_reads_region_cap = hc[3];
   }
   if (!per_read) {
-    if (U > 0) {
+    if (U > 0 && to_host) {
       HIPCHK(hipMemcpyAsync(start, us.p, (size_t)U * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(stop, ue.p, (size_t)U * 4, hipMemcpyDeviceToHost, st));
       HIPCHK(hipMemcpyAsync(tlen, ut.p, (size_t)U * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(ind, uind.p, (size_t)U * 4, hipMemcpyDeviceToHost, st));
     }
@@ -1956,14 +2008,65 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
   HIPCHK(rs.alloc((size_t)n + 1)); HIPCHK(re.alloc((size_t)n + 1)); HIPCHK(rt.alloc((size_t)n + 1)); HIPCHK(ri.alloc((size_t)n + 1));
   if (n > 0) {
     hipLaunchKernelGGL(k_read_coords, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, ctx->d_uniq_of.p, us.p, ue.p, ut.p, uind.p, rs.p, re.p, rt.p, ri.p);
+    if (to_host) {
     HIPCHK(hipMemcpyAsync(start, rs.p, (size_t)n * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(stop, re.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(tlen, rt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(ind, ri.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    }
   }
   HIPCHK(hipStreamSynchronize(st));
   return ITSX_OK;
 }
 int itsx_trim_coords(itsx_ctx *ctx, const char *lp, const char *rp, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
 { return coords_common(ctx, lp, rp, true, start, stop, tlen, ind); }
+// the same results left on the device as [n][4] int32 rows (start, stop, tlen, in_ddict): per read / per representative
+static int coords_device(itsx_ctx *ctx, const char *lp, const char *rp, bool per_read, int32_t **d_rows, int64_t *n_rows)
+{
+  CTXCHK(ctx && d_rows);
+  const int rc = coords_common(ctx, lp, rp, per_read, nullptr, nullptr, nullptr, nullptr);
+  if (rc != ITSX_OK) return rc;
+  const int64_t n = per_read ? ctx->N : ctx->U;
+  HIPCHK(ctx->w_coords4.alloc((size_t)n * 4 + 4));
+  if (n > 0) {
+    if (per_read) hipLaunchKernelGGL(k_pack_coords4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->st, n, ctx->w_rs.p, ctx->w_re.p, ctx->w_rt.p, ctx->w_ri.p, ctx->w_coords4.p);
+    else hipLaunchKernelGGL(k_pack_coords4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->st, n, ctx->w_us.p, ctx->w_ue.p, ctx->w_ut.p, ctx->w_uind.p, ctx->w_coords4.p);
+  }
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipGetLastError());
+  *d_rows = ctx->w_coords4.p;
+  if (n_rows) *n_rows = n;
+  return ITSX_OK;
+}
+int itsx_trim_coords_device(itsx_ctx *ctx, const char *lp, const char *rp, int32_t **d_rows, int64_t *n_rows) { return coords_device(ctx, lp, rp, true, d_rows, n_rows); }
+int itsx_rep_coords_device(itsx_ctx *ctx, const char *lp, const char *rp, int32_t **d_rows, int64_t *n_rows) { return coords_device(ctx, lp, rp, false, d_rows, n_rows); }
+int itsx_derep_device(itsx_ctx *ctx, const int32_t **d_rep_of, const int32_t **d_uniq_of, const int8_t **d_strand, const int32_t **d_seed_read)
+{
+  CTXCHK(ctx && ctx->have_derep);
+  if (d_rep_of) *d_rep_of = ctx->d_rep_of.p;
+  if (d_uniq_of) *d_uniq_of = ctx->d_uniq_of.p;
+  if (d_strand) *d_strand = ctx->d_strand.p;
+  if (d_seed_read) *d_seed_read = ctx->d_seed_read.p;
+  return ITSX_OK;
+}
+int itsx_unique_keys128_device(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, int64_t gidx_base, int64_t **d_tuples, int64_t *n_unique)
+{
+  CTXCHK(ctx && ctx->have_derep && d_tuples);
+  if (ctx->S > 1) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "cross-rank dereplication of a sample batch is not supported: shard whole samples across ranks");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->N; const int32_t U = ctx->U;
+  HIPCHK(ctx->w_keys128.alloc((size_t)U * 4 + 4));
+  if (n > 0 && U > 0) {
+    HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1)); HIPCHK(ctx->w_hf1.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr1.alloc((size_t)n + 1));
+    launch_hash_reads(ctx->rd, seed_a, 1, ctx->w_hf.p, ctx->w_hr.p, ctx->st);
+    launch_hash_reads(ctx->rd, seed_b, 1, ctx->w_hf1.p, ctx->w_hr1.p, ctx->st);
+    hipLaunchKernelGGL(k_unique_keys128, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, ctx->st, U, ctx->d_seed_read.p, ctx->rd.len, ctx->w_hf.p, ctx->w_hr.p,
+                       ctx->w_hf1.p, ctx->w_hr1.p, gidx_base, ctx->w_keys128.p);
+  }
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipGetLastError());
+  *d_tuples = ctx->w_keys128.p;
+  if (n_unique) *n_unique = U;
+  return ITSX_OK;
+}
 int itsx_rep_coords(itsx_ctx *ctx, const char *lp, const char *rp, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
 { return coords_common(ctx, lp, rp, false, start, stop, tlen, ind); }
 

@@ -101,117 +101,202 @@ def gather_coords(start, stop, tlen, in_ddict, device=None, dst=0):
     return None
 
 
-# ------------------------------------------------------------------------------------------------
-# Exact dereplication across shards (option 2).
-#
-# Each rank dereplicates its own shard on its GPU (exact, verified word by word), then only the UNIQUES are
-# matched across ranks: per unique a 128-bit key (two XXH64 seeds over the packed read incl. its length), made
-# orientation-free by taking the smaller of (forward, reverse-complement) -- vsearch --strand both joins a read
-# to a seed that equals it or its reverse complement.  Every rank gets all keys (all_gather: 24 B per unique),
-# groups them with one sort, and learns for each of its uniques which rank holds the GLOBAL first occurrence.
-# That rank scores the sequence (it has the bases); the others mark the unique inactive and receive its
-# coordinates afterwards.  Result = what one GPU computes on the concatenated input: same representatives (and
-# orientation), same domZ, same per-read coordinates.  Cross-rank equality is by 128-bit key, not re-verified.
-_SEED_A, _SEED_B = 0x1F83D9ABFB41BD6B, 0x5BE0CD19137E2179
-
-
-def _all_gather_var(t, device):
-    """all_gather of 1-D/2-D tensors whose first dimension differs between ranks -> list of tensors."""
+def gather_rows(rows, dst=0):
+    """rows: [n_i, 4] int32 tensor per rank, WHEREVER it lives (the engine's device memory on the GPU box, host memory
+    under gloo).  Rank dst receives every rank's block as numpy arrays, the others None: the final gather of the path
+    (SURVEY 8e), 16 B per read over RCCL, straight out of the buffer the engine wrote."""
     import torch
     import torch.distributed as dist
-    ws = dist.get_world_size()
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [rows.cpu().numpy()]
+    if rows.is_cuda and _host_backend():
+        rows = rows.cpu()
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     sizes = [torch.zeros_like(n) for _ in range(ws)]
     dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = [int(x) for x in torch.cat(sizes).cpu().tolist()]
     nmax = max(max(sizes), 1)
-    pad = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=device)
-    pad[:t.shape[0]] = t
-    out = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(out, pad)
-    return [o[:s] for o, s in zip(out, sizes)]
+    if rows.shape[0] == nmax:
+        pad = rows.contiguous()
+    else:
+        pad = torch.full((nmax, 4), -1, dtype=torch.int32, device=rows.device)
+        pad[:rows.shape[0]] = rows
+    if rank == dst:
+        big = torch.empty((ws, nmax, 4), dtype=torch.int32, device=rows.device)
+        dist.gather(pad, [big[r] for r in range(ws)], dst=dst)
+        if big.is_cuda:
+            host = _pinned((ws, nmax, 4), torch.int32)
+            host.copy_(big)
+            arr = host.numpy()
+        else:
+            arr = big.numpy()
+        return [arr[r, :sizes[r]].copy() for r in range(ws)]
+    dist.gather(pad, None, dst=dst)
+    return None
 
 
-def group_keys(c0, c1, gidx, orient):
-    """Pure grouping step (also used by the CPU tests): int64 tensors of equal length.
-    Returns (seed_gidx, seed_orient) per element: the smallest gidx with the same (c0, c1) and its orient."""
+def _host_backend():
+    """gloo moves host memory: device tensors take a detour through the host there (tests); RCCL takes them as they are"""
+    import torch.distributed as dist
+    return dist.get_backend() == "gloo"
+
+
+def allreduce_domz_device(engine, device=None):
+    """sum hmmsearch's domZ over all ranks where the counters live: the engine's device buffer is all-reduced in place
+    (RCCL) and itsx_search_finalize then reads it there."""
+    import torch.distributed as dist
+    t = engine.domz_device(device)
+    if dist.is_available() and dist.is_initialized() and t.numel():
+        if t.is_cuda and _host_backend():
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# Exact dereplication across shards (SURVEY.md section 8e, option 2): hash-partitioned all-to-all.
+#
+# Each rank dereplicates its own shard on its GPU (exact, verified word by word).  Then only the UNIQUES meet: per unique a
+# 128-bit key (two XXH64 seeds over the packed read incl. its length), made orientation-free by taking the smaller of
+# (forward, reverse complement) -- vsearch --strand both joins a read to a seed that equals it or its reverse complement.
+# Every key has an OWNER rank (key mod world): one all-to-all carries (key, global index of the first occurrence, orientation
+# flag, local unique number) to the owners -- 40 B per unique, each rank receives ~1/world of them, nothing is replicated.
+# The owner groups its keys (one sort of its share) and decides, per distinct sequence: the global first occurrence (the
+# representative, whose orientation the cluster keeps) and the SCORER -- one of the ranks that hold the sequence in the
+# representative's orientation, picked by the key, so that the scoring work is spread evenly even when the shards share most
+# of their sequences (with "the first occurrence scores" the low ranks did all of it).  A second all-to-all returns the
+# verdicts.  After the search the coordinates travel the same way: holders ask the scorer (one all-to-all of unique numbers,
+# one of int32 x 4 rows).  Result = what one GPU computes on the concatenated input: same representatives (and orientation),
+# same domZ, same per-read coordinates.  Cross-rank equality is by 128-bit key, not re-verified.
+# All of it runs on tensors that live where the engine left them (device memory under RCCL, host memory under gloo).
+def _a2a_var(rows, dest, world):
+    """rows [n, w] to the ranks in dest [n] -> (received rows, recv counts, send counts, the permutation that grouped them)"""
     import torch
-    n = c0.shape[0]
-    if n == 0:
-        return gidx.clone(), orient.clone()
-    order = torch.argsort(gidx, stable=True)
-    order = order[torch.argsort(c1[order], stable=True)]
-    order = order[torch.argsort(c0[order], stable=True)]
-    s0, s1 = c0[order], c1[order]
-    first = torch.ones(n, dtype=torch.bool, device=c0.device)
-    first[1:] = (s0[1:] != s0[:-1]) | (s1[1:] != s1[:-1])
+    import torch.distributed as dist
+    order = torch.argsort(dest, stable=True)
+    send = rows[order].contiguous()
+    sc = torch.bincount(dest, minlength=world).to(torch.int64)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc)
+    rcl, scl = rc.cpu().tolist(), sc.cpu().tolist()
+    out = torch.empty((int(sum(rcl)),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_to_all_single(out, send, output_split_sizes=rcl, input_split_sizes=scl)
+    return out, rcl, scl, order
+
+
+def _a2a_back(rows, rcl, scl, order):
+    """answers to the rows received by _a2a_var, returned to their senders in the senders' original order"""
+    import torch
+    import torch.distributed as dist
+    back = torch.empty((int(sum(scl)),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_to_all_single(back, rows.contiguous(), output_split_sizes=scl, input_split_sizes=rcl)
+    out = torch.empty_like(back)
+    out[order] = back
+    return out
+
+
+def owner_verdicts(recv, src):
+    """The owner's step (pure; also run by the CPU tests): recv [m, 5] int64 = (key0, key1, gidx, fwd flag, local unique number)
+    from ranks src [m].  Returns [m, 4] int64 per row: gidx and orientation flag of the group's global first occurrence,
+    rank and local unique number of the holder that scores the sequence."""
+    import torch
+    m = recv.shape[0]
+    if m == 0:
+        return torch.zeros((0, 4), dtype=torch.int64, device=recv.device)
+    order = torch.argsort(recv[:, 2], stable=True)
+    order = order[torch.argsort(recv[order, 1], stable=True)]
+    order = order[torch.argsort(recv[order, 0], stable=True)]
+    s, ssrc = recv[order], src[order]
+    first = torch.ones(m, dtype=torch.bool, device=recv.device)
+    first[1:] = (s[1:, 0] != s[:-1, 0]) | (s[1:, 1] != s[:-1, 1])
     grp = torch.cumsum(first.to(torch.int64), 0) - 1
-    head = torch.nonzero(first).flatten()                     # position (in sorted order) of each group's first element
-    seed_sorted = gidx[order][head][grp]
-    orient_sorted = orient[order][head][grp]
-    seed = torch.empty_like(gidx)
-    so = torch.empty_like(orient)
-    seed[order] = seed_sorted
-    so[order] = orient_sorted
-    return seed, so
+    head = torch.nonzero(first).flatten()
+    seed_gidx, seed_fwd = s[head, 2][grp], s[head, 3][grp]
+    cand = (s[:, 3] == seed_fwd).to(torch.int64)                      # holders of the sequence in the representative's orientation
+    run = torch.cumsum(cand, 0) - cand                                # candidates before this row
+    pos = run - run[head][grp]                                        # ... inside the group
+    cnt = torch.zeros(head.shape[0], dtype=torch.int64, device=recv.device).index_add_(0, grp, cand)
+    pick = torch.remainder(s[head, 1], cnt)[grp]                      # by the key: even over the holders
+    chosen = (cand == 1) & (pos == pick)
+    sr = torch.zeros(head.shape[0], dtype=torch.int64, device=recv.device)
+    su = torch.zeros(head.shape[0], dtype=torch.int64, device=recv.device)
+    sr[grp[chosen]] = ssrc[chosen]
+    su[grp[chosen]] = s[chosen, 4]
+    ans = torch.stack([seed_gidx, seed_fwd, sr[grp], su[grp]], dim=1)
+    out = torch.empty_like(ans)
+    out[order] = ans
+    return out
 
 
 def global_derep(engine, n_reads_local, device=None):
-    """After engine.derep(): match the local uniques against every other rank's.  Marks the uniques whose global
-    first occurrence lives elsewhere inactive (engine.set_active_uniques) and returns the bookkeeping
-    exchange_coords() needs.  Without an initialised process group this is a no-op."""
+    """After engine.derep(): match the local uniques against every other rank's (hash-partitioned, see above).  Marks the
+    uniques another rank scores inactive (engine.set_active_uniques) and returns the bookkeeping exchange_coords() needs.
+    Without an initialised process group this is a no-op."""
     import torch
     import torch.distributed as dist
     U = engine.n_unique
-    seed_read, _ = engine.get_uniques()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return dict(active=np.ones(U, bool), gidx=seed_read.astype(np.int64), seed_gidx=seed_read.astype(np.int64),
-                    flip=np.zeros(U, bool), base=0)
-    rank = dist.get_rank()
+        seed_read, _ = engine.get_uniques()
+        return dict(active=np.ones(U, bool), seed_gidx=seed_read.astype(np.int64), flip=np.zeros(U, bool), base=0, scorer=None)
+    ws, rank = dist.get_world_size(), dist.get_rank()
     n = torch.tensor([int(n_reads_local)], dtype=torch.int64, device=device)
-    ns = [torch.zeros_like(n) for _ in range(dist.get_world_size())]
+    ns = [torch.zeros_like(n) for _ in range(ws)]
     dist.all_gather(ns, n)
     base = int(sum(int(x.item()) for x in ns[:rank]))
-    kf0, kr0 = engine.unique_keys(_SEED_A)
-    kf1, kr1 = engine.unique_keys(_SEED_B)
-    fwd_le = (kf0 < kr0) | ((kf0 == kr0) & (kf1 <= kr1))     # is the read in its canonical orientation?
-    c0 = np.where(fwd_le, kf0, kr0).view(np.int64)
-    c1 = np.where(fwd_le, kf1, kr1).view(np.int64)
-    gidx = seed_read.astype(np.int64) + base
-    loc = torch.from_numpy(np.stack([c0, c1, gidx, fwd_le.astype(np.int64)], axis=1).copy())
-    if device is not None:
-        loc = loc.to(device)
-    parts = _all_gather_var(loc, device)
-    allk = torch.cat(parts, 0)
-    seed, so = group_keys(allk[:, 0], allk[:, 1], allk[:, 2], allk[:, 3])
-    lo = sum(p.shape[0] for p in parts[:rank])
-    seed = seed[lo:lo + U].cpu().numpy()
-    so = so[lo:lo + U].cpu().numpy()
-    active = seed == gidx
-    engine.set_active_uniques(active)
-    return dict(active=active, gidx=gidx, seed_gidx=seed, flip=so.astype(bool) != fwd_le, base=base)
+    tup = engine.unique_tuples(base, device)                          # [U, 4]: key0, key1, gidx, fwd flag -- where the engine left them
+    if tup.is_cuda and _host_backend():
+        tup = tup.cpu()
+    lu = torch.arange(U, dtype=torch.int64, device=tup.device)
+    rows = torch.cat([tup, lu[:, None]], dim=1)
+    dest = torch.remainder(tup[:, 0], ws)
+    recv, rcl, scl, order = _a2a_var(rows, dest, ws)
+    src = torch.repeat_interleave(torch.arange(ws, dtype=torch.int64, device=tup.device), torch.tensor(rcl, dtype=torch.int64, device=tup.device))
+    verdict = _a2a_back(owner_verdicts(recv, src), rcl, scl, order)   # [U, 4]: seed gidx, seed fwd, scorer rank, scorer's unique number
+    active = (verdict[:, 2] == rank) & (verdict[:, 3] == lu)
+    engine.set_active_uniques(active.cpu().numpy())
+    return dict(active=active.cpu().numpy(), seed_gidx=verdict[:, 0].cpu().numpy(), flip=(verdict[:, 1] != tup[:, 3]).cpu().numpy(), base=base,
+                scorer=verdict[:, 2:4], active_t=active)
+
+
+def exchange_rows(g, rep_rows):
+    """After finalize(): rep_rows = [U, 4] int32 rows per local unique (engine.rep_coords_device).  The uniques another rank
+    scored get that rank's rows: one all-to-all of requests (the scorer's unique numbers), one of answers."""
+    import torch
+    import torch.distributed as dist
+    if g.get("scorer") is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return rep_rows
+    ws = dist.get_world_size()
+    if rep_rows.device != g["active_t"].device:
+        rep_rows = rep_rows.to(g["active_t"].device)
+    need = ~g["active_t"]
+    req = g["scorer"][need]
+    recv, rcl, scl, order = _a2a_var(req[:, 1:2].contiguous(), req[:, 0].contiguous(), ws)
+    ans = rep_rows[recv[:, 0]]
+    back = _a2a_back(ans, rcl, scl, order)
+    out = rep_rows.clone()
+    out[need] = back
+    return out
 
 
 def exchange_coords(g, start, stop, tlen, ind, device=None):
-    """After finalize(): start/stop/tlen/ind per local unique (engine.rep_coords).  Fills the inactive uniques from
-    the rank that scored their global first occurrence; returns the four completed arrays."""
+    """numpy front end of exchange_rows (tests, file-compatible callers): four arrays per local unique in, four out."""
     import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return start, stop, tlen, ind
-    act = g["active"]
-    mine = np.stack([g["gidx"][act], start[act].astype(np.int64), stop[act].astype(np.int64), tlen[act].astype(np.int64),
-                     ind[act].astype(np.int64)], axis=1) if act.any() else np.zeros((0, 5), np.int64)
-    t = torch.from_numpy(np.ascontiguousarray(mine))
+    rows = torch.from_numpy(np.stack([start, stop, tlen, ind], axis=1).astype(np.int32))
     if device is not None:
-        t = t.to(device)
-    tab = torch.cat(_all_gather_var(t, device), 0).cpu().numpy()
-    tab = tab[np.argsort(tab[:, 0], kind="stable")]
-    need = ~act
-    out = [start.copy(), stop.copy(), tlen.copy(), ind.copy()]
-    if need.any():
-        pos = np.searchsorted(tab[:, 0], g["seed_gidx"][need])
-        assert np.array_equal(tab[pos, 0], g["seed_gidx"][need]), "a global representative was scored by no rank"
-        for k in range(4):
-            out[k][need] = tab[pos, 1 + k].astype(out[k].dtype)
-    return tuple(out)
+        rows = rows.to(device)
+    out = exchange_rows(g, rows).cpu().numpy()
+    return tuple(out[:, k].astype(a.dtype) for k, a in enumerate((start, stop, tlen, ind)))
+
+
+def read_rows(engine, rep_rows, device=None):
+    """per-read rows from per-representative rows, on the device: rows[uniq_of], (-1, -1, -1, 0) for dropped reads"""
+    import torch
+    uq = engine.derep_device(device)["uniq_of"].to(torch.int64)
+    ok = uq >= 0
+    rows = rep_rows[uq.clamp(min=0)]
+    none = torch.tensor([-1, -1, -1, 0], dtype=torch.int32, device=rep_rows.device)
+    return torch.where(ok[:, None], rows, none[None, :])

@@ -20,6 +20,22 @@ def _device_from_env():
     return 0
 
 
+class _DevArray:
+    """a raw device pointer dressed up for torch.as_tensor (zero-copy): the engine keeps owning the memory"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+
+
+def _devtensor(ptr, shape, typestr, device):
+    import torch
+    dt = {"<i8": torch.int64, "<i4": torch.int32, "|i1": torch.int8}[typestr]
+    if not ptr or int(np.prod(shape)) == 0:
+        return torch.empty(tuple(shape), dtype=dt, device=device)
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=device)
+
+
 class Engine:
     def __init__(self, device=None):
         self.L = _lib.lib()
@@ -292,6 +308,44 @@ class Engine:
         z = np.ascontiguousarray(z, np.int64)
         assert z.size == self.n_profiles * self.n_samples
         self._chk(self.L.itsx_set_domz(self.h, z.ctypes.data))
+
+    # ---- device-resident exchange (multi-GPU drivers): torch tensors over the engine's own device memory, no copies
+    def _torch_device(self, device=None):
+        import torch
+        return device if device is not None else torch.device("cuda", self.device)
+
+    def domz_device(self, device=None):
+        """int64[n_samples * n_profiles] reported-target counters ON THE DEVICE: all-reduce in place, then finalize()."""
+        p, n = C.c_void_p(0), C.c_int64(0)
+        self._chk(self.L.itsx_domz_device(self.h, C.byref(p), C.byref(n)))
+        return _devtensor(p.value, (n.value,), "<i8", self._torch_device(device))
+
+    def _coords_device(self, fn, left, right, device):
+        p, n = C.c_void_p(0), C.c_int64(0)
+        self._chk(fn(self.h, left.encode(), right.encode(), C.byref(p), C.byref(n)))
+        return _devtensor(p.value, (n.value, 4), "<i4", self._torch_device(device))
+
+    def trim_coords_device(self, left, right, device=None):
+        """int32 [n_reads, 4] rows (start, stop, tlen, in_ddict) on the device."""
+        return self._coords_device(self.L.itsx_trim_coords_device, left, right, device)
+
+    def rep_coords_device(self, left, right, device=None):
+        return self._coords_device(self.L.itsx_rep_coords_device, left, right, device)
+
+    def derep_device(self, device=None):
+        """dict of device tensors: rep_of, uniq_of (int32[n_reads]), strand (int8[n_reads]), seed_read (int32[n_unique])."""
+        a, b, c, d = C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0)
+        self._chk(self.L.itsx_derep_device(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        dev = self._torch_device(device)
+        return dict(rep_of=_devtensor(a.value, (self.n_reads,), "<i4", dev), uniq_of=_devtensor(b.value, (self.n_reads,), "<i4", dev),
+                    strand=_devtensor(c.value, (self.n_reads,), "|i1", dev), seed_read=_devtensor(d.value, (self.n_unique,), "<i4", dev))
+
+    def unique_tuples(self, gidx_base, device=None, seeds=(0x1F83D9ABFB41BD6B, 0x5BE0CD19137E2179)):
+        """int64 [n_unique, 4] rows on the device: the orientation-free 128-bit key of each local unique (two XXH64 seeds),
+        gidx_base + index of its first occurrence, 1 if the forward strand is the canonical orientation."""
+        p, n = C.c_void_p(0), C.c_int64(0)
+        self._chk(self.L.itsx_unique_keys128_device(self.h, C.c_uint64(seeds[0]), C.c_uint64(seeds[1]), int(gidx_base), C.byref(p), C.byref(n)))
+        return _devtensor(p.value, (n.value, 4), "<i8", self._torch_device(device))
 
     def finalize(self, domE=10.0):
         self._chk(self.L.itsx_search_finalize(self.h, domE))

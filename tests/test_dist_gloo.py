@@ -63,50 +63,63 @@ def test_shard_bounds_cover_everything_in_order():
 
 # ---------------------------------------------------------------- exact dereplication across shards (SURVEY 8e option 2)
 class _FakeEngine:
-    """stands in for the GPU engine: uniques of a shard with made-up 64-bit keys (forward / reverse complement)"""
+    """stands in for the GPU engine: the uniques of a shard, "sequences" being integers s whose reverse complement is the
+    sequence 1000 - s; the orientation-free key is the smaller of the two"""
 
-    def __init__(self, seed_read, kf, kr):
-        self.n_unique = len(seed_read)
+    def __init__(self, seqs, seed_read):
+        self.n_unique = len(seqs)
+        self._seqs = np.asarray(seqs, np.int64)
         self._seed_read = np.asarray(seed_read, np.int64)
-        self._kf = np.asarray(kf, np.uint64)
-        self._kr = np.asarray(kr, np.uint64)
         self.active = None
 
     def get_uniques(self):
         return self._seed_read, np.ones(self.n_unique, np.int64)
 
-    def unique_keys(self, seed):
-        m = np.uint64(seed & 0xFFFF)
-        return self._kf * np.uint64(3) + m, self._kr * np.uint64(3) + m
+    def unique_tuples(self, base, device=None):
+        import torch
+        s = self._seqs
+        canon = np.minimum(s, 1000 - s)
+        rows = np.stack([canon * 2654435761 % 1000003 - 500000, canon * 7 + 1, self._seed_read + base, (s <= 1000 - s).astype(np.int64)], axis=1)
+        return torch.from_numpy(rows.astype(np.int64))
 
     def set_active_uniques(self, active):
         self.active = np.asarray(active, bool)
 
 
+def _shards(world):
+    """per rank: (sequences of its uniques, local read index of each one's first occurrence, reads in the shard)"""
+    if world == 2:       # shard 0 holds 5, 7, 990 ; shard 1 holds 7, 995 (= rc of 5), 10 (= rc of 990), 3
+        return [([5, 7, 990], [0, 2, 3], 6), ([7, 995, 10, 3], [0, 1, 4, 5], 8)]
+    rng = np.random.default_rng(11)
+    pool = rng.choice(np.arange(1, 500), 120, replace=False)           # 120 distinct sequences, none its own reverse complement
+    out = []
+    for r in range(world):
+        pick = rng.choice(pool, 70, replace=False)
+        seqs = np.where(rng.random(70) < 0.3, 1000 - pick, pick)        # some of them held reverse-complemented
+        out.append((seqs.tolist(), sorted(rng.choice(400, 70, replace=False).tolist()), 400))
+    return out
+
+
 def _worker_global(rank, world, port, q):
+    import torch
     import torch.distributed as dist
-    from itsxpress_amd.dist import exchange_coords, global_derep
+    from itsxpress_amd.dist import exchange_rows, global_derep
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # sequences are integers; key of sequence s = (s, 1000 - s) for (forward, reverse complement); the reverse
-    # complement of s is the sequence 1000 - s.  shard 0 holds 5, 7, 990 ; shard 1 holds 7, 995 (= rc of 5), 10, 3
-    if rank == 0:
-        seqs, seed_read, n_local = [5, 7, 990], [0, 2, 3], 6
-    else:
-        seqs, seed_read, n_local = [7, 995, 10, 3], [0, 1, 4, 5], 8
-    eng = _FakeEngine(seed_read, seqs, [1000 - s for s in seqs])
+    seqs, seed_read, n_local = _shards(world)[rank]
+    eng = _FakeEngine(seqs, seed_read)
     g = global_derep(eng, n_local)
-    start = np.array([100 + s for s in seqs], np.int32)
-    start[~g["active"]] = -1
-    out = exchange_coords(g, start, start + 1, start + 2, (start >= 0).astype(np.int32))
-    q.put((rank, eng.active.tolist(), g["seed_gidx"].tolist(), g["flip"].tolist(), out[0].tolist(), out[1].tolist()))
+    # every rank's rows say who computed them: (rank, unique number, sequence, 1); only scored uniques have rows
+    rows = torch.tensor([[rank, u, s, 1] if g["active"][u] else [-9, -9, -9, 0] for u, s in enumerate(seqs)], dtype=torch.int32)
+    out = exchange_rows(g, rows)
+    q.put((rank, eng.active.tolist(), g["seed_gidx"].tolist(), g["flip"].tolist(), out.tolist(), g["base"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_global_derep():
-    world, port = 2, _free_port()
+def _run_global(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_global, args=(r, world, port, q)) for r in range(world)]
@@ -114,19 +127,60 @@ def test_two_rank_global_derep():
         p.start()
     res = dict()
     for _ in range(world):
-        r = q.get(timeout=120)
+        r = q.get(timeout=180)
         res[r[0]] = r[1:]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    # shard 0: every unique is a global first occurrence
-    assert res[0][0] == [True, True, True] and res[0][1] == [0, 2, 3] and res[0][2] == [False, False, False]
+    return res
+
+
+def _check_global(world, res):
+    shards = _shards(world)
+    bases = np.cumsum([0] + [s[2] for s in shards])
+    # what one process would decide: per canonical sequence the global first occurrence and its orientation
+    first = {}
+    for r, (seqs, seed_read, _) in enumerate(shards):
+        for u, s in enumerate(seqs):
+            c = min(s, 1000 - s)
+            gi = int(bases[r] + seed_read[u])
+            if c not in first or gi < first[c][0]:
+                first[c] = (gi, s)
+    scorers = {}
+    for r, (seqs, seed_read, _) in enumerate(shards):
+        active, seed_gidx, flip, rows, base = res[r]
+        assert base == bases[r]
+        for u, s in enumerate(seqs):
+            c = min(s, 1000 - s)
+            assert seed_gidx[u] == first[c][0]                      # the representative is the global first occurrence
+            assert flip[u] == (s != first[c][1])                    # ... and a holder of the other orientation is flipped
+            if active[u]:
+                assert s == first[c][1]                             # the scorer holds the representative's orientation
+                scorers.setdefault(c, []).append((r, u))
+    assert all(len(v) == 1 for v in scorers.values()) and set(scorers) == set(first)   # exactly one scorer per sequence
+    for r, (seqs, _, _) in enumerate(shards):
+        rows = res[r][3]
+        for u, s in enumerate(seqs):
+            sr, su = scorers[min(s, 1000 - s)][0]
+            assert rows[u] == [sr, su, first[min(s, 1000 - s)][1], 1]            # everybody ends up with the scorer's rows
+    return scorers
+
+
+def test_two_rank_global_derep():
+    res = _run_global(2)
+    _check_global(2, res)
     # shard 1 (global index base 6): 7 -> seed at global 2 (same strand); 995 -> seed 5 at global 0, reverse complement;
     # 10 -> seed 990 at global 3, reverse complement; 3 is new
-    assert res[1][0] == [False, False, False, True]
     assert res[1][1] == [2, 0, 3, 11] and res[1][2] == [False, True, True, False]
-    # coordinates of the inactive uniques come from the rank that scored the seed
-    assert res[1][3] == [107, 105, 1090, 103] and res[1][4] == [108, 106, 1091, 104]
+
+
+def test_four_rank_global_derep_spreads_the_scoring():
+    """hash-partitioned matching on four ranks: one scorer per distinct sequence, in the representative's orientation, and
+    the scoring work is spread over the holders instead of piling onto the ranks with the first occurrences"""
+    res = _run_global(4)
+    scorers = _check_global(4, res)
+    load = np.bincount([v[0][0] for v in scorers.values()], minlength=4)
+    assert load.min() >= 0.5 * load.mean(), load
 
 
 def test_assign_samples_balances_whole_samples():

@@ -234,7 +234,7 @@ def main():
         if args.cluster_id < 1.0:
             eng.cluster(args.cluster_id, strand_both=True)
         else:
-            eng.derep(strand_both=True, minseqlength=32)
+            eng.derep(strand_both=True, minseqlength=1)
         g = global_derep(eng, n_local, dev) if (use_dist and args.global_derep) else None
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
         if not use_dist:
@@ -414,7 +414,7 @@ def main():
             e2 = Engine(local_rank)
             e2.load_profiles(text=hmm)
             e2.set_reads_buffer(np.ascontiguousarray(blob[:int(offs[m])]), offs[:m + 1])
-            e2.derep(strand_both=True, minseqlength=32)
+            e2.derep(strand_both=True, minseqlength=1)
             e2.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
             e2.finalize(domE=10.0)
             gs, ge, gt, _ = e2.trim_coords("3_", "4_")

@@ -97,6 +97,7 @@ typedef struct {
   int64_t n_mr_clustered, n_mr_failed, n_mr_envelopes;
   float   ms_ensemble;       int32_t pad3;
   int64_t n_mr_distinct;     /* distinct (profile, target length, residues) multidomain regions actually sampled */
+  int64_t n_slab_shrinks;    /* times the DP slab budget was halved because the device could not supply it */
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -285,6 +286,9 @@ const char *itsx_trim_last_error(void);
  * front to back) and accepted only when length and CRC-32 match the trailer; everything else takes the serial inflater.
  * itsx_io_parallel_inflates: files delivered that way since the library was loaded (ITSX_PARALLEL_INFLATE=0 turns it off). */
 int  itsx_io_read(const char *path, char **text, int64_t *len);
+/* identifiers of a FASTQ file's records (title up to the first blank) through the record parser the trimming writers use:
+ * names[offsets[i] .. offsets[i + 1]) is record i's; both buffers are released with itsx_io_free */
+int  itsx_fastq_ids(const char *path, char **names, int64_t **offsets, int64_t *n_records);
 void itsx_io_free(char *text);
 int  itsx_io_codecs(void);
 int64_t itsx_io_parallel_inflates(void);

@@ -91,7 +91,9 @@ class SeqSample:
             self.uc_file = os.path.join(self.tempdir, "uc.txt")
             self.rep_file = os.path.join(self.tempdir, "rep.fa")
             self._load_reads()
-            n = self.engine.derep(strand_both=True, minseqlength=32)
+            # vsearch's --minseqlength default is 32 for the clustering / derep_* / usearch_global commands and 1 for the
+            # others, --fastx_uniques among them: only empty reads vanish from uc.txt here
+            n = self.engine.derep(strand_both=True, minseqlength=1)
             self.engine.write_uc(self.uc_file)
             self.engine.write_rep_fasta(self.rep_file)
             logging.info("itsx_hip derep: %d reads -> %d unique sequences", self.engine.n_reads, n)
@@ -299,11 +301,10 @@ class Dedup:
     def create_trimmed_seqs(self, outfile: str, gzipped: bool, zstd_file: bool, itspos: "ItsPosition",
                             wri_file: bool, tempdir: str = "", trim_ccs: bool = False) -> None:
         """Single-end: write seq_file's records trimmed to record[start:stop] (same filter as the reference)."""
-        from .engine import read_fastx
-        from .trim import coords_from_dicts, write_trimmed_fastq
+        from .trim import coords_from_dicts, read_names, write_trimmed_fastq
         if not wri_file:
             return
-        names, _ = read_fastx(self.seq_file)
+        names = read_names(self.seq_file)           # the native writer's own record parser: names and records cannot disagree
         start, stop, _ = coords_from_dicts(names, self.matchdict, itspos)
         write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)
 

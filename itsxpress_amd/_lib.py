@@ -47,7 +47,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("pad1", "<i4"), ("cl_certified", "<i8"), ("ms_pack", "<f4"), ("pad2", "<i4"),
                 ("n_uniq_multi_winner", "<i8"), ("n_reads_multi_winner", "<i8"), ("n_uniq_region_cap", "<i8"),
                 ("n_reads_region_cap", "<i8"), ("n_mr_clustered", "<i8"), ("n_mr_failed", "<i8"), ("n_mr_envelopes", "<i8"),
-                ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8")]
+                ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares
@@ -62,7 +62,7 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
            "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_tables",
            "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq",
-           "itsx_io_read", "itsx_io_free", "itsx_io_codecs",
+           "itsx_io_read", "itsx_io_free", "itsx_io_codecs", "itsx_fastq_ids",
            "itsx_load_reads_files", "itsx_set_samples", "itsx_num_samples", "itsx_select_sample",
            "itsx_io_parallel_inflates", "itsx_get_read_names"]
 
@@ -131,6 +131,7 @@ def lib():
         "itsx_write_trimmed_paired": (i32, [cp, cp, cp, cp, i32, i32, vp, vp, i64, vp, vp, vp, vp]),
         "itsx_trim_last_error": (cp, []),
         "itsx_io_read": (i32, [cp, vp, vp]),
+        "itsx_fastq_ids": (i32, [cp, vp, vp, vp]),
         "itsx_io_free": (None, [vp]),
         "itsx_io_codecs": (i32, []),
         "itsx_io_parallel_inflates": (i64, []),

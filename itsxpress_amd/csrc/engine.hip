@@ -1156,7 +1156,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
   if (U == 0) return ITSX_OK;
@@ -1331,18 +1331,29 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     // ---- batches of waves that fit the slab
     struct Batch { int w0, w1; int64_t r; };
     std::vector<Batch> batches;
-    int64_t rmax = 0;
-    for (int w0 = 0; w0 < NW;) {
-      int w1 = w0; int64_t r = 0;
-      while (w1 < NW && wgeneric[w1] == wgeneric[w0] && (w1 == w0 || r + rows[w1] <= budget_rows)) { waves[w1].slab = r; waves[w1].rows = rows[w1]; r += rows[w1]; w1++; }
-      batches.push_back(Batch{w0, w1, r});
-      rmax = std::max(rmax, r);
-      w0 = w1;
-    }
     DBuf<float> &d_slab = ctx->w_slab;
-    // several batches: take the whole budget, so that the next job (whose fullest batch may be a few waves larger) fits too
-    const int64_t slab_rows = batches.size() > 1 ? std::max(rmax, budget_rows) : rmax;
-    if ((size_t)slab_rows * 12 * 64 > d_slab.cap) HIPCHK(d_slab.alloc((size_t)slab_rows * 12 * 64, true));
+    for (;;) {
+      batches.clear();
+      int64_t rmax = 0;
+      for (int w0 = 0; w0 < NW;) {
+        int w1 = w0; int64_t r = 0;
+        while (w1 < NW && wgeneric[w1] == wgeneric[w0] && (w1 == w0 || r + rows[w1] <= budget_rows)) { waves[w1].slab = r; waves[w1].rows = rows[w1]; r += rows[w1]; w1++; }
+        batches.push_back(Batch{w0, w1, r});
+        rmax = std::max(rmax, r);
+        w0 = w1;
+      }
+      // several batches: take the whole budget, so that the next job (whose fullest batch may be a few waves larger) fits too
+      const int64_t slab_rows = batches.size() > 1 ? std::max(rmax, budget_rows) : rmax;
+      if ((size_t)slab_rows * 12 * 64 <= d_slab.cap) break;
+      if (d_slab.alloc((size_t)slab_rows * 12 * 64, true) == hipSuccess) break;
+      // the budget asked for more memory than the device has left (ITSX_SLAB_GB above the free HBM, another tenant):
+      // halve it and batch again -- more, smaller launches -- rather than fail the search
+      (void)hipGetLastError();
+      if (budget_rows <= ((int64_t)64 << 20) / row_bytes) SET_ERR(ctx, ITSX_E_NOMEM, "not even 64 MB of device memory are left for the DP slab");
+      budget_rows = std::max<int64_t>(budget_rows / 2, ((int64_t)64 << 20) / row_bytes);
+      ctx->slab_gb = std::min(ctx->slab_gb, (double)(budget_rows * row_bytes) / (double)(1 << 30));
+      S.n_slab_shrinks++;
+    }
     HIPCHK(hipMemcpyAsync(d_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
     FloatArgs a{};
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
@@ -2116,7 +2127,8 @@ int itsx_write_uc(const itsx_ctx *ctx, const char *path)
     }
     for (size_t c = 0; c < ord.size(); c++)
       fprintf(f, "C\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_abund[ord[c]], read_name(ctx, ctx->h_seed_read[ord[c]]).c_str());
-    fclose(f);
+    const bool bad = ferror(f) != 0;
+    if (fclose(f) != 0 || bad) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
     return ITSX_OK;
   }
   std::vector<std::vector<int64_t>> members((size_t)ctx->U);
@@ -2132,7 +2144,9 @@ int itsx_write_uc(const itsx_ctx *ctx, const char *path)
     const int32_t u = ord[c];
     fprintf(f, "C\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_abund[u], read_name(ctx, ctx->h_seed_read[u]).c_str());
   }
-  fclose(f);
+  // a truncated uc.txt would silently shorten Dedup.parse's matchdict (vsearch exits non-zero on a full disk)
+  const bool bad = ferror(f) != 0;
+  if (fclose(f) != 0 || bad) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
   return ITSX_OK;
 }
 
@@ -2153,7 +2167,8 @@ int itsx_write_rep_fasta(const itsx_ctx *cctx, const char *path)
     const char *b = ctx->bases_view + ctx->h_off[s]; const int64_t L = ctx->h_len[s];
     for (int64_t i = 0; i < L; i += 80) { fwrite(b + i, 1, (size_t)std::min<int64_t>(80, L - i), f); fputc('\n', f); }
   }
-  fclose(f);
+  const bool bad = ferror(f) != 0;
+  if (fclose(f) != 0 || bad) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
   return ITSX_OK;
 }
 
@@ -2169,7 +2184,9 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path)
   // rows: profile order; within a profile, targets; within a target, reported domains renumbered
   const std::vector<itsx_domain> &D = ctx->h_dom;
   std::vector<int64_t> Zs((size_t)ctx->S, 0);          // hmmsearch's Z: targets searched, per sample
-  for (int32_t u = 0; u < ctx->U; u++) Zs[(size_t)ctx->usample(u)]++;
+  // (a context narrowed by itsx_set_active_uniques searched only its active targets: the E-value columns of a sharded run are
+  // this shard's own, the reported / not-reported decisions are global through the all-reduced domZ)
+  if (ctx->S == 1) Zs[0] = ctx->U_active; else for (int32_t u = 0; u < ctx->U; u++) Zs[(size_t)ctx->usample(u)]++;
   // one (profile, target) group is formatted on its own, so the table is cut into blocks of whole groups that a pool of
   // threads formats while this thread writes the finished blocks in order (a few blocks ahead at most)
   std::vector<size_t> cut(1, 0);

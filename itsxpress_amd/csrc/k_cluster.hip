@@ -31,6 +31,10 @@
 #include "engine.h"
 #include "k_api.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "this engine ships gfx950 code only (k_orient alone keeps 73 KB of LDS per workgroup: over the 64 KB of older targets)"
+#endif
+
 namespace itsx {
 
 typedef long long i64;

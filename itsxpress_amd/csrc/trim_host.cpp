@@ -231,6 +231,33 @@ int itsx_io_read(const char *path, char **text, int64_t *len)
   return ITSX_OK;
 }
 void itsx_io_free(char *text) { free(text); }
+
+// identifiers of a FASTQ file's records (title up to the first blank, without '@'), through the SAME record parser the
+// trimming writers use, so that coordinates looked up by these names line up with the records that are written
+int itsx_fastq_ids(const char *path, char **names, int64_t **offsets, int64_t *n_records)
+{
+  if (!path || !names || !offsets || !n_records) return ITSX_E_ARG;
+  Records in;
+  if (!in.open(path)) return ITSX_E_IO;
+  std::string blob; std::vector<int64_t> off(1, 0);
+  Rec rec;
+  for (;;) {
+    const int r = in.next(rec);
+    if (r == 0) break;
+    if (r < 0) { g_trim_error = std::string("malformed FASTQ record ") + std::to_string(off.size()) + " in " + path; return ITSX_E_FORMAT; }
+    const char *b = rec.title.p + 1, *e = rec.title.p + rec.title.n, *q = b;
+    while (q < e && *q != ' ' && *q != '\t') q++;
+    blob.append(b, q);
+    off.push_back((int64_t)blob.size());
+  }
+  char *nb = (char *)malloc(blob.size() + 1);
+  int64_t *ob = (int64_t *)malloc(off.size() * sizeof(int64_t));
+  if (!nb || !ob) { free(nb); free(ob); g_trim_error = "out of memory"; return ITSX_E_IO; }
+  memcpy(nb, blob.data(), blob.size()); nb[blob.size()] = 0;
+  memcpy(ob, off.data(), off.size() * sizeof(int64_t));
+  *names = nb; *offsets = ob; *n_records = (int64_t)off.size() - 1;
+  return ITSX_OK;
+}
 int itsx_io_codecs(void) { return itsx_io::codec_flags(); }
 int64_t itsx_io_parallel_inflates(void) { return itsx_io::parallel_inflates(); }
 

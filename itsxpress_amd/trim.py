@@ -22,6 +22,24 @@ def _compression(gzipped, zstd_file):
     return 1 if gzipped else (2 if zstd_file else 0)
 
 
+def read_names(path):
+    """labels of a FASTQ file's records, in order, from the native writers' own record parser (itsx_fastq_ids)"""
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    L = _lib.lib()
+    nb, ob, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+    rc = L.itsx_fastq_ids(os.fsencode(path), C.byref(nb), C.byref(ob), C.byref(n))
+    if rc != 0:
+        raise EngineError(rc, L.itsx_trim_last_error().decode())
+    try:
+        offs = np.ctypeslib.as_array(C.cast(ob, C.POINTER(C.c_int64)), shape=(n.value + 1,)).copy()
+        blob = C.string_at(nb, int(offs[-1]))
+    finally:
+        L.itsx_io_free(nb)
+        L.itsx_io_free(ob)
+    return [blob[offs[i]:offs[i + 1]].decode() for i in range(n.value)]
+
+
 def read_text(path):
     """Decompressed bytes of a plain / gzip / zstd file through the engine's reader (gzip.open / pyzstd.open of
     main.py:296-330)."""
@@ -60,9 +78,12 @@ def write_trimmed_paired(fastq, fastq2, outfile1, outfile2, names, start, stop, 
     for p in (fastq, fastq2):
         if not os.path.exists(p):
             raise FileNotFoundError(p)
-    gz = [str(p).endswith(".gz") for p in (fastq, fastq2)]
-    if gz[0] != gz[1]:
-        raise ValueError("Fastq and Fastq2 files should both be gzipped (.gz) or both be uncompressed. "
+    # the reference's suffix rule (SeqSample.py:766-787): both .gz, both .zst, or both plain (.fq / .fastq)
+    a, b = str(fastq), str(fastq2)
+    plain = (".fastq", ".fq")
+    if not ((a.endswith(".gz") and b.endswith(".gz")) or (a.endswith(".zst") and b.endswith(".zst")) or
+            (a.endswith(plain) and b.endswith(plain))):
+        raise ValueError("Fastq and Fastq2 files should both be gzipped (.gz), zstd compressed (.zst) or both be uncompressed. "
                          "Mixed input is not accepted.")
     L = _lib.lib()
     start, stop, tlen = _i32(start), _i32(stop), _i32(tlen)

@@ -136,3 +136,33 @@ def test_writer_errors(tmp_path):
         write_trimmed_fastq(str(bad), str(tmp_path / "o.fq"), [0], [3])
     with pytest.raises(FileNotFoundError):
         write_trimmed_fastq(str(tmp_path / "nope.fq"), str(tmp_path / "o.fq"), [0], [3])
+
+
+def test_record_names_come_from_the_writers_own_parser(tmp_path):
+    """blank lines between records: the Python line reader used to stop there while the native writer went on; names and
+    records now come from one parser (itsx_fastq_ids)"""
+    from itsxpress_amd.trim import read_names, write_trimmed_fastq
+    p = tmp_path / "x.fastq"
+    p.write_text("@a 1\nACGTACGT\n+\nIIIIIIII\n\n@b\tx\nGGGGCCCC\n+\nIIIIIIII\n\n\n@c\nTTTTAAAA\n+anything\nIIIIIIII\n")
+    assert read_names(str(p)) == ["a", "b", "c"]
+    out = tmp_path / "o.fastq"
+    import numpy as np
+    n, tot = write_trimmed_fastq(str(p), str(out), np.array([1, 0, 2], np.int32), np.array([5, 4, 8], np.int32))
+    assert (n, tot) == (3, 14) and out.read_text().split("\n")[1::4][:3] == ["CGTA", "GGGG", "TTAAAA"]
+    bad = tmp_path / "bad.fastq"
+    bad.write_text("@a\nACGT\n+\nII\n")
+    import pytest
+    from itsxpress_amd import EngineError
+    with pytest.raises(EngineError):
+        read_names(str(bad))
+
+
+def test_paired_writer_keeps_the_references_suffix_rule(tmp_path):
+    import pytest
+    from itsxpress_amd.trim import write_trimmed_paired
+    import numpy as np
+    a, b = tmp_path / "r1.fastq.gz", tmp_path / "r2.fastq"
+    a.write_bytes(b""); b.write_text("")
+    z = np.zeros(0, np.int32)
+    with pytest.raises(ValueError, match="zstd compressed"):
+        write_trimmed_paired(str(a), str(b), str(tmp_path / "o1"), str(tmp_path / "o2"), [], z, z, z)

@@ -1486,10 +1486,11 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
         if (mrdbg) { HIPCHK(ctx->w_counters.alloc(8)); HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 64, st)); ma.dbg = (unsigned long long *)ctx->w_counters.p; }
         launch_mr_ensemble(ma, w1 - w0, w0, st);
         if (mrdbg) {
-          unsigned long long d[4];
-          HIPCHK(hipMemcpyAsync(d, ctx->w_counters.p, 32, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
-          fprintf(stderr, "[itsx] ensemble batch: %d waves, %lld matrix rows; per wave (100 MHz ticks): walk %.0f, close %.0f, cluster %.0f\n", w1 - w0, (long long)r,
-                  (double)d[0] / std::max<double>(1.0, (double)d[3]), (double)d[1] / std::max<double>(1.0, (double)d[3]), (double)d[2] / std::max<double>(1.0, (double)d[3]));
+          unsigned long long d[5];
+          HIPCHK(hipMemcpyAsync(d, ctx->w_counters.p, 40, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+          fprintf(stderr, "[itsx] ensemble batch: %d waves, %lld matrix rows; per wave (100 MHz ticks): walk %.0f, close %.0f (samples %.0f), cluster %.0f\n", w1 - w0, (long long)r,
+                  (double)d[0] / std::max<double>(1.0, (double)d[3]), (double)d[1] / std::max<double>(1.0, (double)d[3]), (double)d[4] / std::max<double>(1.0, (double)d[3]),
+                  (double)d[2] / std::max<double>(1.0, (double)d[3]));
         }
         w0 = w1;
       }

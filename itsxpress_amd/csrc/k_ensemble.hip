@@ -228,6 +228,11 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
   auto DV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 1, lane); };
   auto IV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 2, lane); };
   const unsigned short dgm[16] = {1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15};
+  // Seq::code() walks the read's exception list through global loads on every call: the residue loop below would pay that for
+  // every residue of every path of a read that has a single N (15 % of the bench's reads have one)
+  int ex0p = -1, ex0c = 0, ex1p = -1, ex1c = 0;
+  if (e.sq.nexc >= 1 && e.sq.nexc <= 2) { const uint32_t v = e.sq.exc[0]; ex0p = (int)(v >> 4); ex0c = (int)(v & 15u); }
+  if (e.sq.nexc == 2) { const uint32_t v = e.sq.exc[1]; ex1p = (int)(v >> 4); ex1c = (int)(v & 15u); }
 
   // The lanes of a wave sample different regions.  Left to themselves they would be in different states at any moment and
   // the wave would run every state's code in every step (measured: 9 us per step, most of it the rare but long E and B
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
   // of a step are issued for all three states at once and the choice runs through one routine.  N -> N steps draw nothing
   // and record nothing, so a path that enters N is finished.  What a finished domain needs done for its residues waits until
   // the path is complete and is then done by all lanes together.
-  unsigned long long tk_walk = 0, tk_close = 0;
+  unsigned long long tk_walk = 0, tk_close = 0, tk_dedupe = 0;
   for (int t = 0; t < 200; t++) {
     if (__ballot(status == 0) == 0ull) break;
     const unsigned long long tk0 = wall_clock64();
@@ -380,6 +385,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
       S.tcount[tix]++;
       S.tid[nsamp] = (uint16_t)tix; S.tidx[nsamp] = (uint8_t)t; nsamp++;
     }
+    tk_dedupe += wall_clock64() - tk1;
     if (status) continue;
     // ... and its residues' null2 terms.  As published: residues up to AND INCLUDING a domain's first one count as outside
     // (+1), the rest of the domain by its null2 odds; a residue takes exactly one term per path, so their order is free.
@@ -398,8 +404,11 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
           if (d < nd && pos <= (int)(dom_ij[d][lane] >> 16)) {
             const int p0 = e.off + pos - 1;
             int x;
-            if (e.sq.nexc == 0) { if ((p0 >> 4) != cwi) { cwi = p0 >> 4; cw = e.sq.w[cwi]; } x = (int)((cw >> (2 * (p0 & 15))) & 3u); }
-            else x = e.sq.code(p0);
+            if (e.sq.nexc <= 2) {                       // the read's (at most two) non-ACGT symbols sit in registers
+              if ((p0 >> 4) != cwi) { cwi = p0 >> 4; cw = e.sq.w[cwi]; }
+              x = (int)((cw >> (2 * (p0 & 15))) & 3u);
+              x = p0 == ex0p ? ex0c : x; x = p0 == ex1p ? ex1c : x;
+            } else x = e.sq.code(p0);
             if (x < 4) v[z] = dom_n2[d][x][lane];
             else {
               float acc = 0.f; int ndg = 0;
@@ -553,7 +562,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
   }
   out.status = status;
   a.out[e.mi] = out;
-  if (a.dbg && lane == 0) { atomicAdd(&a.dbg[0], tk_walk); atomicAdd(&a.dbg[1], tk_close); atomicAdd(&a.dbg[2], wall_clock64() - tk2); atomicAdd(&a.dbg[3], 1ull); }
+  if (a.dbg && lane == 0) { atomicAdd(&a.dbg[0], tk_walk); atomicAdd(&a.dbg[1], tk_close); atomicAdd(&a.dbg[2], wall_clock64() - tk2); atomicAdd(&a.dbg[3], 1ull); atomicAdd(&a.dbg[4], tk_dedupe); }
 }
 
 // =========================================================================================

@@ -151,6 +151,12 @@ def cpu_baseline(hmm_its2, blob, offs, sample_reads, threads):
 T_START = time.time()
 
 
+def progress(msg):
+    """a line on stderr now and then: a run that is silent for minutes looks hung to the harness (stdout carries the ONE JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +218,7 @@ def main():
         n_local = hi - lo
     else:
         n_local = args.reads or (10000000 if cfg2 else 1000000)
+    progress("generating %d reads (%s)" % (n_local, args.workload))
     t_gen = time.time()
     gen = dict(config=3 if cfg2 else 2, seed=synth.SEED + (3 if cfg2 else 2) + 1000 * rank, as_array=True)
     if cfg2:
@@ -249,16 +256,19 @@ def main():
             rows = eng.trim_coords_device("3_", "4_", dev)
         return gather_rows(rows, dst=0)
 
-    for _ in range(args.warmup):
+    progress("reads generated in %.1f s, text resident in HBM; %d warm-up + %d timed steps" % (t_gen, args.warmup, args.steps))
+    for k in range(args.warmup):
         step()
+        progress("warm-up step %d/%d done" % (k + 1, args.warmup))
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     acc = {}
     out = None
-    for _ in range(args.steps):
+    for k in range(args.steps):
         out = step()
+        progress("timed step %d/%d done (%.2f s so far)" % (k + 1, args.steps, time.perf_counter() - t0))
         st = eng.stats()
         for k, v in st.items():
             if k.startswith("ms_"):
@@ -296,6 +306,7 @@ def main():
         th = time.perf_counter()
         mp = 0.0
         for _ in range(args.handover_steps):
+            progress("host hand-over step")
             step(from_host=True)
             mp += eng.stats()["ms_pack"]
         torch.cuda.synchronize()
@@ -409,7 +420,9 @@ def main():
                 room = args.budget_s - (time.time() - T_START) - 20.0     # ~25 s of CPU work, less when the budget is nearly spent
                 args.cpu_sample = int(max(600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
             m = min(args.cpu_sample, n_local)
+            progress("CPU baseline on %d reads, %d threads" % (m, threads))
             v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads)
+            progress("CPU baseline done in %.1f s" % cdt)
             # trim-coordinate concordance (BASELINE metric): the engine on the very same sample against the baseline path
             e2 = Engine(local_rank)
             e2.load_profiles(text=hmm)

@@ -169,7 +169,7 @@ def main():
                     help="strong scaling: this many reads in total, sharded over the ranks (shards share their templates)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20-30 s of CPU work)")
     ap.add_argument("--handover-steps", type=int, default=1, help="steps fed from the host buffer, outside `value` (0 = skip)")
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ITSX_BENCH_BUDGET_S", "540")),
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ITSX_BENCH_BUDGET_S", "520")),
                     help="wall-clock budget of the whole run: the legs AFTER the K timed steps (host hand-over, CPU baseline) shrink or "
                          "are skipped to stay inside it (the driver's limit is 600 s); the timed steps themselves are never cut")
     ap.add_argument("--cluster-id", type=float, default=1.0,
@@ -418,7 +418,7 @@ def main():
             if args.cpu_sample < 0:                      # the scalar port does ~2.5 (440-base) .. 5 (300-base) reads/s per core
                 args.cpu_sample = int(min(24000 if cfg2 else 40000, max(1200, (64 if cfg2 else 120) * threads)))
                 room = args.budget_s - (time.time() - T_START) - 20.0     # ~25 s of CPU work, less when the budget is nearly spent
-                args.cpu_sample = int(max(600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
+                args.cpu_sample = int(max(8192 if threads >= 64 else 600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
             m = min(args.cpu_sample, n_local)
             progress("CPU baseline on %d reads, %d threads" % (m, threads))
             v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads)

@@ -136,7 +136,12 @@ template <class T> struct DBuf {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
     if (trace) fprintf(stderr, "[itsx] hipMalloc %.3f GB: %.1f ms\n", want * sizeof(T) / 1073741824.0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (e != hipSuccess) { e = hipMalloc((void **)&p, count * sizeof(T)); if (e != hipSuccess) return e; cap = count; return e; }
+    if (e != hipSuccess) {               // no room for the growth headroom: the exact size, and the failed attempt's sticky error cleared
+      (void)hipGetLastError();
+      e = hipMalloc((void **)&p, count * sizeof(T));
+      if (e != hipSuccess) { p = nullptr; return e; }
+      cap = count; return e;
+    }
     cap = want;
     return hipSuccess;
   }
@@ -1312,6 +1317,14 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   }
   double slab_gb = ctx->slab_gb;
   if (const char *e = getenv("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));     // read at every call
+  {   // never more than a quarter of what the device has left right now (plus what the context's slab already holds): the stages
+      // after the DP kernels need room too.  A budget above that is cut here; one the allocator still refuses is halved below.
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      const double room = ((double)fr / 4.0 + (double)ctx->w_slab.cap * 4.0) / (double)(1ull << 30);
+      if (slab_gb > room) { slab_gb = std::max(0.0625, room); S.n_slab_shrinks++; }
+    }
+  }
   const int64_t row_bytes = 12 * 64 * 4;                   // XF fields of k_float.hip's parser slab
   int64_t budget_rows = (int64_t)(slab_gb * (1 << 30)) / row_bytes;
   // A job that fits a few batches does not need the whole budget: eight batches already keep the launch tails small, and
@@ -1469,14 +1482,21 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       const int64_t mbudget = std::max<int64_t>(1, (int64_t)(std::min(slab_gb, 16.0) * (1 << 30)) / mrow_bytes);
       const int64_t wave_cap = std::max<int64_t>(1, ((int64_t)6 << 30) / ((int64_t)MR_SCRATCH * MR_LANES));      // 6 GB of bookkeeping blocks per batch
       int w0 = 0;
+      int64_t mr_wave_cap = wave_cap;
       while (w0 < NMW) {
         int w1 = w0;
         const int64_t row0 = hrow[(size_t)w0 * MR_LANES];
         auto rows_to = [&](int w) { return hrow[(size_t)std::min<int64_t>((int64_t)w * MR_LANES, NU)] - row0; };
-        while (w1 < NMW && w1 - w0 < wave_cap && (w1 == w0 || rows_to(w1 + 1) <= mbudget)) w1++;
+        while (w1 < NMW && w1 - w0 < std::min(wave_cap, mr_wave_cap) && (w1 == w0 || rows_to(w1 + 1) <= mbudget)) w1++;
         const int64_t r = rows_to(w1);
-        if ((size_t)r * MRV * 4 > ctx->w_mrslab.cap) HIPCHK(ctx->w_mrslab.alloc((size_t)r * MRV * 4));
-        HIPCHK(ctx->w_mrscratch.alloc((size_t)(w1 - w0) * MR_LANES * MR_SCRATCH));
+        if (((size_t)r * MRV * 4 > ctx->w_mrslab.cap && ctx->w_mrslab.alloc((size_t)r * MRV * 4) != hipSuccess) ||
+            ctx->w_mrscratch.alloc((size_t)(w1 - w0) * MR_LANES * MR_SCRATCH) != hipSuccess) {
+          (void)hipGetLastError();
+          if (w1 - w0 <= 1) SET_ERR(ctx, ITSX_E_NOMEM, "no device memory left for the matrices of one wave of multidomain regions");
+          mr_wave_cap = std::max<int64_t>(1, (int64_t)(w1 - w0) / 2);     // half as many regions at a time
+          S.n_slab_shrinks++;
+          continue;
+        }
         MrArgs ma{};
         ma.rd = ctx->rd; ma.sorted_uniq = d_sorted; ma.seed_read = ctx->d_seed_read.p; ma.prof = ctx->d_prof.p; ma.pairs = ctx->d_pairs.p;
         ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = (int64_t)w0 * MR_LANES; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
@@ -1594,7 +1614,17 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     while (w0 < NRW) {
       int w1 = w0; int64_t r = 0;
       while (w1 < NRW && rgen[w1] == rgen[w0] && (w1 == w0 || r + rrows[w1] <= ebudget)) { rw[w1].slab = r; rw[w1].rows = rrows[w1]; r += rrows[w1]; w1++; }
-      if (r > ealloc) { HIPCHK(d_eslab.alloc((size_t)r * 104 * 64)); ealloc = r; }
+      if (r > ealloc) {
+        if (d_eslab.alloc((size_t)r * 104 * 64) != hipSuccess) {      // as for the parser slab: a budget the device cannot supply is halved
+          (void)hipGetLastError();
+          ealloc = 0;
+          if (w1 - w0 <= 1) SET_ERR(ctx, ITSX_E_NOMEM, "no device memory left for the envelope slab of a single wave");
+          ebudget = std::max<int64_t>(r / 2, rrows[(size_t)w0]);
+          S.n_slab_shrinks++;
+          continue;
+        }
+        ealloc = r;
+      }
       HIPCHK(hipMemcpyAsync(d_rw.p + w0, rw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       EnvArgs a{};
       a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;

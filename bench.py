@@ -192,13 +192,20 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    if os.environ.get("ITSX_BENCH_ONE_GPU") == "1":      # rehearsal of the N-rank code path on a one-GPU box (with ITSX_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("ITSX_FORCE_DIST") == "1"     # the latter: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("ITSX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if os.environ.get("ITSX_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")     # where the bench's own scalars are reduced
 
     from itsxpress_amd import Engine
     from itsxpress_amd.dist import allreduce_domz_device, exchange_rows, gather_rows, global_derep, read_rows
@@ -242,7 +249,7 @@ def main():
             eng.cluster(args.cluster_id, strand_both=True)
         else:
             eng.derep(strand_both=True, minseqlength=1)
-        g = global_derep(eng, n_local, dev) if (use_dist and args.global_derep) else None
+        g = global_derep(eng, n_local, cdev) if (use_dist and args.global_derep) else None
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
         if not use_dist:
             eng.finalize(domE=10.0)
@@ -278,10 +285,10 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         total_local = int(tot.item())
     else:
@@ -291,7 +298,7 @@ def main():
     # the same step fed from the host buffer (PCIe-inclusive), never part of `value`
     handover = None
     step_s = dt / max(args.steps, 1)
-    left = torch.tensor([args.budget_s - (time.time() - T_START)], dtype=torch.float64, device=dev)
+    left = torch.tensor([args.budget_s - (time.time() - T_START)], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(left, op=dist.ReduceOp.MIN)                      # every rank takes the same decision
     left = float(left.item())
@@ -314,7 +321,7 @@ def main():
             dist.barrier()
         th = time.perf_counter() - th
         if use_dist:
-            t = torch.tensor([th], dtype=torch.float64, device=dev)
+            t = torch.tensor([th], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             th = float(t.item())
         handover = {"value": total_local * args.handover_steps / th, "unit": "reads/s", "steps": args.handover_steps,

@@ -296,6 +296,8 @@ def read_rows(engine, rep_rows, device=None):
     """per-read rows from per-representative rows, on the device: rows[uniq_of], (-1, -1, -1, 0) for dropped reads"""
     import torch
     uq = engine.derep_device(device)["uniq_of"].to(torch.int64)
+    if rep_rows.device != uq.device:          # after a host-side exchange (gloo): back to where the reads' map lives
+        rep_rows = rep_rows.to(uq.device)
     ok = uq >= 0
     rows = rep_rows[uq.clamp(min=0)]
     none = torch.tensor([-1, -1, -1, 0], dtype=torch.int32, device=rep_rows.device)

@@ -112,3 +112,24 @@ def test_two_ranks_equal_one_engine(engine, mini_hmm_text):
     assert np.array_equal(cat(3), rep_of) and np.array_equal(cat(4), strand)
     # both shards left sequences to the other one (the scorer of a shared sequence is picked by its key, not by shard order)
     assert res[1][5] < res[1][6] and res[0][5] < res[0][6] and (start >= 0).sum() > 2000
+
+
+def test_bench_runs_its_n_rank_path_with_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` starts two ranks itself; here both share GPU 0 and talk over gloo (ITSX_BENCH_ONE_GPU /
+    ITSX_BENCH_BACKEND: RCCL needs a GPU per rank), so the step's N > 1 branch -- device-resident domZ all-reduce, gather of
+    the coordinate rows, and with --global-derep the hash-partitioned matching -- runs end to end and prints ONE line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(ITSX_BENCH_ONE_GPU="1", ITSX_BENCH_BACKEND="gloo")
+    for extra in (["--reads", "40000"], ["--total-reads", "80000", "--global-derep"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "1", "--warmup", "1",
+                            "--cpu-sample", "0", "--handover-steps", "0"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["reads_trimmed_rank0"] > 30000
+        assert rec["scaling"] == ("strong" if "--total-reads" in extra else "weak")

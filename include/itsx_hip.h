@@ -29,7 +29,7 @@ enum {
   ITSX_E_IO          = -2,   /* file could not be read or written */
   ITSX_E_FORMAT      = -3,   /* malformed HMMER3/f or FASTA/FASTQ text, illegal residue */
   ITSX_E_DEVICE      = -4,   /* HIP error or no usable device */
-  ITSX_E_UNSUPPORTED = -5,   /* e.g. model longer than 46 nodes, read longer than 65535 bases, F2 != F1 */
+  ITSX_E_UNSUPPORTED = -5,   /* e.g. model longer than 46 nodes, read longer than 65535 bases */
   ITSX_E_COLLISION   = -6,   /* 64-bit hash collision survived every reseed (never observed) */
   ITSX_E_NOMEM       = -7
 };
@@ -67,6 +67,9 @@ typedef struct {
   int32_t pass_msv, pass_bias, pass_fwd;
   float   msv_sc, filtersc, fwdsc, bcksc, nullsc;
   int32_t nregions, ndom;
+  int32_t ran_vit, pass_vit;   /* Viterbi filter: runs only for pairs whose bias-corrected MSV P-value exceeds F2 (none when F1 == F2) */
+  float   vitsc;
+  int32_t pad;
 } itsx_pairtrace;
 
 typedef struct {
@@ -98,6 +101,8 @@ typedef struct {
   float   ms_ensemble;       int32_t pad3;
   int64_t n_mr_distinct;     /* distinct (profile, target length, residues) multidomain regions actually sampled */
   int64_t n_slab_shrinks;    /* times the DP slab budget was halved because the device could not supply it */
+  float   ms_vit_kernel;     int32_t pad4;               /* Viterbi filter (F2 < F1 only) */
+  int64_t n_past_vit;
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -209,8 +214,8 @@ int itsx_set_active_uniques(itsx_ctx *ctx, const uint8_t *active);
 int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance);
 
 /* ---- a4: SeqSample._search (itsxpress/SeqSample.py:178-225)
- * = hmmsearch --domtblout -T <T> --F1 --F2 --F3 (domE = 10).  F2 must equal F1 (the
- * reference's flags); the Viterbi filter, which then never runs, is not implemented.
+ * = hmmsearch --domtblout -T <T> --F1 --F2 --F3 (domE = 10).  With the reference's flags (F1 == F2) the Viterbi filter never
+ * runs; with F2 < F1 (hmmsearch's own defaults: 0.02, 1e-3, 1e-5) it runs between the bias filter and Forward (k_vit).
  * itsx_search runs every stage up to per-sequence reporting and counts, per profile, the
  * reported representatives (hmmsearch's domZ).  itsx_search_finalize applies the
  * domain threshold.  Between the two a multi-GPU driver all-reduces domZ. */

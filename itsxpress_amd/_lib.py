@@ -34,7 +34,7 @@ DOMAIN_DTYPE = np.dtype([("rep", "<i8"), ("prof", "<i4"), ("tlen", "<i4"), ("ien
 TRACE_DTYPE = np.dtype([("rep", "<i8"), ("prof", "<i4"), ("msv_xj", "<i4"), ("pass_msv", "<i4"),
                         ("pass_bias", "<i4"), ("pass_fwd", "<i4"), ("msv_sc", "<f4"), ("filtersc", "<f4"),
                         ("fwdsc", "<f4"), ("bcksc", "<f4"), ("nullsc", "<f4"), ("nregions", "<i4"),
-                        ("ndom", "<i4")], align=True)
+                        ("ndom", "<i4"), ("ran_vit", "<i4"), ("pass_vit", "<i4"), ("vitsc", "<f4"), ("pad", "<i4")], align=True)
 STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i8"), ("n_pairs", "<i8"),
                 ("n_past_msv", "<i8"), ("n_past_bias", "<i8"), ("n_past_fwd", "<i8"), ("n_regions", "<i8"),
                 ("n_multidomain", "<i8"), ("n_domains", "<i8"), ("n_domain_overflow", "<i8"),
@@ -47,7 +47,8 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("pad1", "<i4"), ("cl_certified", "<i8"), ("ms_pack", "<f4"), ("pad2", "<i4"),
                 ("n_uniq_multi_winner", "<i8"), ("n_reads_multi_winner", "<i8"), ("n_uniq_region_cap", "<i8"),
                 ("n_reads_region_cap", "<i8"), ("n_mr_clustered", "<i8"), ("n_mr_failed", "<i8"), ("n_mr_envelopes", "<i8"),
-                ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8")]
+                ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8"), ("ms_vit_kernel", "<f4"), ("pad4", "<i4"),
+                ("n_past_vit", "<i8")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares

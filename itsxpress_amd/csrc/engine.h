@@ -28,6 +28,8 @@ struct HostProfile {
   std::vector<float> tfv;     // [8Q][4]
   float ft10, ft11, fpi0, fpi1;
   float feo[KP][2];
+  std::vector<int16_t> rww;   // Viterbi filter words [KP][M+1]
+  std::vector<int16_t> tww;   // [8][M+1]: BM MM IM DM into node k | MD MI II DD out of node k
 };
 // returns "" on success, else an error message; appends to out
 std::string parse_hmm_text(const char *text, int64_t len, std::vector<HostProfile> &out);
@@ -46,6 +48,7 @@ struct DevProfile {
   int   pad[2];
 };
 
+constexpr int VIT_TAB = 8 * (MMAX + 1) + NCODE * (MMAX + 1);   // int16 words of one profile's Viterbi-filter tables on the device
 struct LenTables {              // per target length L, built on the host with libm
   float   nullsc;               // L*log(p1) + log(1-p1)
   float   bias_a;               // (float)L * logf(p1)
@@ -53,7 +56,7 @@ struct LenTables {              // per target length L, built on the host with l
   float   p1;
   double  lognn3;               // log((float)L/(float)(L+3))
   int     tjb;                  // MSV J->B / N->B cost byte
-  int     pad;
+  int     vmove;                // Viterbi filter: wordify(logf(3 / (L + 3)))
 };
 
 // a surviving (representative, profile) comparison

@@ -220,6 +220,7 @@ struct itsx_ctx {
   std::vector<std::unique_ptr<DBuf<itsx_domain>>> dom_bufs;   // one segment per chunk of uniques
   std::vector<int64_t> dom_n;            // padded rows in each segment
   int64_t pair_budget = 0; int32_t trace_u0 = 0; int n_chunks = 0; bool keep_trace = false, trace_sorted = false;
+  DBuf<int16_t> d_vtab; DBuf<VitOut> d_vit; bool have_vit = false; double F2 = 1e-6;     // Viterbi filter (F2 < F1 only)
   DBuf<int32_t> d_domz32;
   DBuf<int64_t> d_domz64; bool domz_on_device = false;     // itsx_domz_device: the caller reduces the counters where they are
   DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
@@ -393,6 +394,16 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
         etab[(((size_t)g * 16 + x) * MSV_REGS + r) * 64 + lane] = packed;
       }
     pb[i] = h.bias_b; pt[i] = h.tec_b; pm[i] = h.tbm_b;
+  }
+  {   // Viterbi-filter word tables: per profile [8][47] transitions, [16][47] emissions
+    std::vector<int16_t> vt((size_t)std::max(P, 1) * VIT_TAB, (int16_t)-32768);
+    for (int i = 0; i < P; i++) {
+      const HostProfile &h = ctx->profs[i];
+      int16_t *t = vt.data() + (size_t)i * VIT_TAB;
+      for (int k8 = 0; k8 < 8; k8++) for (int k = 0; k <= h.M; k++) t[k8 * (MMAX + 1) + k] = h.tww[(size_t)k8 * (h.M + 1) + k];
+      for (int x = 0; x < NCODE; x++) for (int k = 0; k <= h.M; k++) t[(8 + x) * (MMAX + 1) + k] = h.rww[(size_t)x * (h.M + 1) + k];
+    }
+    HIPCHK(upload(ctx->d_vtab, vt, ctx->st));
   }
   HIPCHK(upload(ctx->d_prof, dp, ctx->st));
   HIPCHK(upload(ctx->d_etab, etab, ctx->st));
@@ -1152,7 +1163,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   CTXCHK(ctx);
   if (!ctx->have_derep) SET_ERR(ctx, ITSX_E_ARG, "itsx_search called before itsx_derep / itsx_cluster");
   if (ctx->P <= 0) SET_ERR(ctx, ITSX_E_ARG, "no profiles loaded");
-  if (F2 != F1) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "F2 != F1 would enable hmmsearch's Viterbi filter, which this engine does not implement");
+  ctx->F2 = F2; ctx->have_vit = F2 < F1;              // hmmsearch enters the Viterbi filter only for P > F2: never when F1 <= F2
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->st;
   const int P = ctx->P, G = ctx->G, Ppad = G * 64, U = ctx->U_active;
@@ -1161,7 +1172,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.ms_vit_kernel = 0; S.n_past_vit = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
   if (U == 0) return ITSX_OK;
@@ -1183,6 +1194,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     t.lognn3 = log((double)((float)L / (float)(L + 3)));
     t.tjb = host_tjb_b(L);
     tjb[L] = t.tjb;
+    { const float w = roundf((float)(500.0 / 0.69314718055994529) * logf((2.0f + 1.0f) / ((float)L + 2.0f + 1.0f)));
+      t.vmove = (w >= 32767.0f) ? 32767 : (w <= -32768.0f) ? -32768 : (int)w; }
   }
   // MSV pass threshold on the final xJ byte, per (length, profile): P(score) <= F1
   std::vector<uint16_t> thr((size_t)Lcap * Ppad, 257);
@@ -1372,6 +1385,14 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
     a.flogsum = ctx->d_flogsum.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
     a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
+    VitArgs va{};
+    if (ctx->have_vit) {
+      HIPCHK(ctx->d_vit.alloc((size_t)NP));
+      va.rd = ctx->rd; va.sorted_uniq = d_sorted; va.seed_read = ctx->d_seed_read.p; va.prof = ctx->d_prof.p; va.lt = ctx->d_lt.p;
+      va.pairs = ctx->d_pairs.p; va.pout = ctx->d_pout.p; va.waves = d_waves.p; va.vtab = ctx->d_vtab.p; va.vit = ctx->d_vit.p; va.F2 = ctx->F2;
+      va.eloop = (int32_t)roundf((float)(500.0 / 0.69314718055994529) * logf(0.5f));
+      a.vit = ctx->d_vit.p;
+    }
     // The bias-composition filter of a batch (its own full-occupancy kernel, VALU-bound, ~48 registers) runs on a second
     // stream beside the decoder of the batch before it (latency-bound, ~50 registers): the two share the SIMDs, which
     // the 256-register DP kernels never do with anything.
@@ -1399,6 +1420,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       const int w0 = bt.w0, w1 = bt.w1;
       a.slab_plane = bt.r * 6 * 64;
       const bool more = bi + 1 < batches.size();
+      if (ctx->have_vit) { const size_t t = lazy.begin(&S.ms_vit_kernel); launch_vit(va, w1 - w0, w0, st); lazy.end(t); }
       { const size_t t = lazy.begin(&S.ms_fwd_kernel); launch_filters_fwd(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
       { const size_t t = lazy.begin(&S.ms_bwd_kernel); launch_bwd_decode(a, w1 - w0, w0, wgeneric[w0], st); lazy.end(t); }
       if (more && overlap) {
@@ -1762,15 +1784,18 @@ static int append_traces(itsx_ctx *ctx)
 {
   const int64_t NP = ctx->npairs_padded;
   if (NP == 0) return ITSX_OK;
-  std::vector<PairRec> pr((size_t)NP); std::vector<PairOut> po((size_t)NP);
+  std::vector<PairRec> pr((size_t)NP); std::vector<PairOut> po((size_t)NP); std::vector<VitOut> vo;
   HIPCHK(hipMemcpy(pr.data(), ctx->d_pairs.p, (size_t)NP * sizeof(PairRec), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(po.data(), ctx->d_pout.p, (size_t)NP * sizeof(PairOut), hipMemcpyDeviceToHost));
+  if (ctx->have_vit) { vo.resize((size_t)NP); HIPCHK(hipMemcpy(vo.data(), ctx->d_vit.p, (size_t)NP * sizeof(VitOut), hipMemcpyDeviceToHost)); }
   for (int64_t i = 0; i < NP; i++) {
     if (pr[i].prof < 0) continue;
     itsx_pairtrace t{};
     t.rep = ctx->h_sorted_active[(size_t)ctx->trace_u0 + pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
     t.pass_bias = po[i].pass_bias; t.pass_fwd = po[i].pass_fwd; t.msv_sc = po[i].msv_sc; t.filtersc = po[i].filtersc;
     t.fwdsc = po[i].fwdsc; t.bcksc = po[i].bcksc; t.nullsc = po[i].nullsc; t.nregions = po[i].nregions; t.ndom = po[i].ndom;
+    const bool ran = ctx->have_vit && po[i].pass_bias && vo[(size_t)i].ran;
+    t.ran_vit = ran; t.vitsc = ran ? vo[(size_t)i].vitsc : 0.0f; t.pass_vit = po[i].pass_bias && (!ran || vo[(size_t)i].pass);
     ctx->h_trace.push_back(t);
   }
   return ITSX_OK;

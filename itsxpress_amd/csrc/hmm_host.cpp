@@ -129,6 +129,24 @@ static void configure(HostProfile &p)
       const int k = q + 1 + z * Q;
       p.tfv[((size_t)7 * Q + q) * 4 + z] = lane_expf(k < M ? p.tsc[(size_t)k * 8 + DD] : -INFINITY);
     }
+  // ---- Viterbi filter word model (p7_oprofile.c: vf_conversion), unstriped: scale 500/ln2; no transition above 0, no II above -1
+  {
+    const float scale_w = (float)(500.0 / 0.69314718055994529);
+    auto wordify = [&](float sc) { const float w = roundf(scale_w * sc); return (int16_t)((w >= 32767.0f) ? 32767 : (w <= -32768.0f) ? -32768 : (int)w); };
+    p.rww.assign((size_t)KP * (M + 1), (int16_t)-32768);
+    for (int x = 0; x < KP; x++) for (int kk = 1; kk <= M; kk++) p.rww[(size_t)x * (M + 1) + kk] = wordify(p.msc[(size_t)kk * KP + x]);
+    p.tww.assign((size_t)8 * (M + 1), (int16_t)-32768);
+    const int into[4] = {BM, MM, IM, DM}, outof[4] = {MD, MI, II, DD};
+    for (int kk = 1; kk <= M; kk++) {
+      for (int t = 0; t < 4; t++) { const int16_t v = wordify(p.tsc[(size_t)(kk - 1) * 8 + into[t]]); p.tww[(size_t)t * (M + 1) + kk] = v > 0 ? (int16_t)0 : v; }
+      for (int t = 0; t < 4; t++) {
+        int16_t v = -32768;
+        if (kk < M) v = wordify(p.tsc[(size_t)kk * 8 + outof[t]]);
+        const int16_t maxval = outof[t] == II ? -1 : 0;
+        p.tww[(size_t)(4 + t) * (M + 1) + kk] = outof[t] == DD ? v : (v > maxval ? maxval : v);
+      }
+    }
+  }
   // bias-composition filter: state 0 = background (its transitions follow the target length),
   // state 1 = the model's composition
   const float L1 = (float)((double)(float)M / 8.0);

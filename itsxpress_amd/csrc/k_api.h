@@ -150,6 +150,7 @@ struct WaveDesc {               // one wave = up to 64 items that share a profil
   int32_t rows;                 // slab rows reserved per field block
   int32_t pad;
 };
+struct VitOut { float vitsc; int32_t ran, pass; };      // k_vit.hip: verdict of the Viterbi filter for one pair
 struct FloatArgs {
   ReadsDev rd;
   const int32_t *sorted_uniq, *seed_read;
@@ -162,8 +163,24 @@ struct FloatArgs {
   float *slab;                  // xmx rows: two planes of [row][6][64] (k_float.hip: SLAB)
   int64_t slab_plane;           // floats between the planes = rows of this batch x 6 x 64
   RegionRec *regions;           // [npairs][MAXDOM] raw, before compaction
+  const VitOut *vit;            // Viterbi filter verdicts (null when the filter did not run: F2 >= F1)
   double F1, F3;
 };
+// ---- k_vit.hip: the Viterbi filter (runs only when F2 < F1; never under the reference's flags)
+struct VitArgs {
+  ReadsDev rd;
+  const int32_t *sorted_uniq, *seed_read;
+  const DevProfile *prof;
+  const LenTables *lt;
+  const PairRec *pairs;
+  const PairOut *pout;
+  const WaveDesc *waves;
+  const int16_t *vtab;          // [P][VIT_TAB]: per profile 8 x 47 transition words then 16 x 47 emission words
+  VitOut *vit;                  // [npairs]
+  int32_t eloop;                // wordify(logf(0.5))
+  double F2;
+};
+void launch_vit(const VitArgs &a, int nwaves, int wave0, hipStream_t st);
 void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st);
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);

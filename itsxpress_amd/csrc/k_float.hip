@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
     const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
     po.fwdsc = (float)((double)totscale + det_log((double)(xC * pmove)));
     const double P = exp_surv((double)(po.fwdsc - po.filtersc) / kLn2, (double)pp->ev[4], (double)pp->ev[5]);
-    po.pass_fwd = po.pass_bias && !bad && !(P > a.F3);
+    po.pass_fwd = po.pass_bias && (!a.vit || a.vit[pi].pass) && !bad && !(P > a.F3);
   }
   if (active) a.pout[pi] = po;
 }

@@ -62,6 +62,9 @@ typedef struct {
   float  ft[2][3];         /* t[m][k], k=2 is the end transition */
   float  fpi[2];
   float  feo[ORC_KP][2];   /* emission odds */
+  /* Viterbi filter word model (p7_oprofile.c: vf_conversion), unstriped: scale 500/ln2, base 12000 */
+  int16_t *rww;            /* [ORC_KP][M+1] match emission words */
+  int16_t *tww;            /* [8][M+1]: BM MM IM DM (into node k) | MD MI II DD (out of node k); -32768 = impossible */
 } orc_profile;
 
 typedef struct {
@@ -95,6 +98,9 @@ typedef struct {
   int32_t pass_msv, pass_bias, pass_fwd;
   float   msv_sc, filtersc, fwdsc, bcksc, nullsc;
   int32_t nregions, ndom;
+  int32_t ran_vit, pass_vit;   /* Viterbi filter: runs only when the bias-corrected MSV P-value exceeds F2 (never at F1 == F2) */
+  float   vitsc;
+  int32_t pad;
 } orc_pairtrace;
 
 typedef struct {
@@ -125,6 +131,8 @@ int orc_digitize(const char *ascii, int64_t len, uint8_t *out); /* returns 0, or
 int   orc_msv(const orc_profile *p, const uint8_t *dsq, int L, int *ret_xJ, float *ret_sc);
 float orc_nullsc(int L);
 float orc_bias_filtersc(const orc_profile *p, const uint8_t *dsq, int L);
+/* p7_ViterbiFilter restated without striping (max and saturating adds do not depend on it): returns 1 on overflow (+inf) */
+int   orc_vitfilter(const orc_profile *p, const uint8_t *dsq, int L, float *ret_sc);
 
 /* ---- the search (hmmsearch restated) ---- */
 orc_results *orc_search(const orc_hmmset *hs, const uint8_t *codes, const int64_t *offsets, int64_t nseq,

@@ -96,7 +96,7 @@ static float vec_expf(float x)
 
 static void profile_free_members(orc_profile *p)
 {
-  free(p->t); free(p->mat); free(p->tsc); free(p->msc); free(p->rbv); free(p->rfv); free(p->tfv);
+  free(p->t); free(p->mat); free(p->tsc); free(p->msc); free(p->rbv); free(p->rfv); free(p->tfv); free(p->rww); free(p->tww);
 }
 
 static float prob_from_tok(const char *tok)
@@ -202,6 +202,33 @@ static int configure(orc_profile *p)
       float v = (k < M) ? p->tsc[k * 8 + T_DD] : -INFINITY;
       p->tfv[(7 * Q + q) * 4 + z] = vec_expf(v);
     }
+
+  /* --- Viterbi filter word model (vf_conversion): wordify() every score, no transition above 0, no II above -1 --- */
+  {
+    const float scale_w = (float)(500.0 / LOG2);
+    p->rww = (int16_t *)malloc(sizeof(int16_t) * ORC_KP * (M + 1));
+    p->tww = (int16_t *)malloc(sizeof(int16_t) * 8 * (M + 1));
+#define WORDIFY(dst, scv) do { float w_ = roundf(scale_w * (scv)); (dst) = (w_ >= 32767.0f) ? 32767 : (w_ <= -32768.0f) ? -32768 : (int16_t)w_; } while (0)
+    for (int x = 0; x < ORC_KP; x++) {
+      p->rww[x * (M + 1)] = -32768;
+      for (int k = 1; k <= M; k++) WORDIFY(p->rww[x * (M + 1) + k], p->msc[k * ORC_KP + x]);
+    }
+    static const int into[4] = { T_BM, T_MM, T_IM, T_DM }, outof[4] = { T_MD, T_MI, T_II, T_DD };
+    for (int t = 0; t < 8; t++) p->tww[t * (M + 1)] = -32768;
+    for (int k = 1; k <= M; k++) {
+      for (int t = 0; t < 4; t++) {                      /* from node k-1 (B for BM) into node k */
+        int16_t v; WORDIFY(v, p->tsc[(k - 1) * 8 + into[t]]);
+        p->tww[t * (M + 1) + k] = v > 0 ? 0 : v;
+      }
+      for (int t = 0; t < 4; t++) {                      /* out of node k; the last node has none */
+        int16_t v = -32768;
+        if (k < M) WORDIFY(v, p->tsc[k * 8 + outof[t]]);
+        const int16_t maxval = (outof[t] == T_II) ? -1 : 0;
+        p->tww[(4 + t) * (M + 1) + k] = (outof[t] == T_DD) ? v : (v > maxval ? maxval : v);
+      }
+    }
+#undef WORDIFY
+  }
 
   /* --- bias-composition filter HMM --- */
   {

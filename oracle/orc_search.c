@@ -170,6 +170,61 @@ float orc_bias_filtersc(const orc_profile *p, const uint8_t *dsq, int L)
   return logsc + (float)L * logf(p1) + logf((float)(1. - (double)p1));
 }
 
+/* ------------------------------------------------------------------ Viterbi filter
+ * p7_ViterbiFilter (impl_sse/vitfilter.c): 16-bit saturating Viterbi, multihit local, NN/CC/JJ costs 0 with a flat -3 nat
+ * correction at the end.  HMMER evaluates it striped and skips the D->D paths of a row when they provably cannot matter
+ * ("lazy F"); maxima and saturating additions do not depend on the evaluation order and a skipped D->D path never raises a
+ * match cell of the next row, so the plain recurrence below gives the same xC.  Under the reference's flags (--F1 == --F2)
+ * the pipeline never calls it. */
+static inline int sat16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
+int orc_vitfilter(const orc_profile *p, const uint8_t *dsq, int L, float *ret_sc)
+{
+  const int M = p->M;
+  const int16_t *tbm = p->tww, *tmm = tbm + (M + 1), *tim = tmm + (M + 1), *tdm = tim + (M + 1);
+  const int16_t *tmd = tdm + (M + 1), *tmi = tmd + (M + 1), *tii = tmi + (M + 1), *tdd = tii + (M + 1);
+  const float scale_w = (float)(500.0 / LOG2);
+  const int base = 12000;
+  const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
+  int16_t xmove, eloop;
+  { float w = roundf(scale_w * logf(pmove)); xmove = (w >= 32767.0f) ? 32767 : (w <= -32768.0f) ? -32768 : (int16_t)w; }
+  { float w = roundf(scale_w * logf(0.5f)); eloop = (int16_t)w; }
+  int mm[4 * QMAX + 2], im[4 * QMAX + 2], dm[4 * QMAX + 2];
+  for (int k = 0; k <= M; k++) mm[k] = im[k] = dm[k] = -32768;
+  int16_t xN = (int16_t)base, xB = (int16_t)(xN + xmove), xJ = -32768, xC = -32768, xE;
+  for (int i = 1; i <= L; i++) {
+    const int16_t *rsc = p->rww + (size_t)dsq[i] * (M + 1);
+    int xe = -32768;
+    for (int k = M; k >= 1; k--) {                 /* descending: cell k-1 still holds the previous row */
+      const int ni = sat16(mm[k] + tmi[k]) > sat16(im[k] + tii[k]) ? sat16(mm[k] + tmi[k]) : sat16(im[k] + tii[k]);
+      int sv = sat16(xB + tbm[k]);
+      int v = sat16(mm[k - 1] + tmm[k]); if (v > sv) sv = v;
+      v = sat16(im[k - 1] + tim[k]); if (v > sv) sv = v;
+      v = sat16(dm[k - 1] + tdm[k]); if (v > sv) sv = v;
+      sv = sat16(sv + rsc[k]);
+      if (sv > xe) xe = sv;
+      mm[k] = sv; im[k] = ni;
+    }
+    dm[1] = -32768;
+    for (int k = 2; k <= M; k++) {
+      const int a = sat16(mm[k - 1] + tmd[k - 1]), b = sat16(dm[k - 1] + tdd[k - 1]);
+      dm[k] = a > b ? a : b;
+    }
+    xE = (int16_t)xe;
+    if (xE >= 32767) { *ret_sc = INFINITY; return 1; }
+    xN = (int16_t)(xN + 0);
+    { const int a = xC + 0, b = xE + eloop; xC = (int16_t)(a > b ? a : b); }           /* E->C and E->J both cost log(1/2) */
+    { const int a = xJ + 0, b = xE + eloop; xJ = (int16_t)(a > b ? a : b); }
+    { const int a = xJ + xmove, b = xN + xmove; xB = (int16_t)(a > b ? a : b); }
+  }
+  if (xC > -32768) {
+    float sc = (float)xC + (float)xmove - (float)base;
+    sc /= scale_w;
+    sc -= 3.0f;
+    *ret_sc = sc;
+  } else *ret_sc = -INFINITY;
+  return 0;
+}
+
 /* ------------------------------------------------------------------ Forward */
 /* rows: if non-NULL, receives M and I of every row i=1..L as [i][q][2] v4 (row 0 untouched) */
 /* full: if non-NULL, receives M, D and I of every row i=0..L as [i][q][3] v4 (p7_Forward's whole matrix, for the
@@ -848,9 +903,15 @@ static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uin
   P = gumbel_surv(seq_score_d, p->evparam[0], p->evparam[1]);
   if (P > F1) { if (keep_trace) res_push_trace(r, &tr); return; }
   tr.pass_bias = 1; r->n_past_bias++;
-  if (P > F2) { /* Viterbi filter would run here; unreachable when F1 == F2 (reference flags) */
-    fprintf(stderr, "orc_search: F2 > F1 requires the Viterbi filter, which the oracle does not restate\n"); abort();
+  if (P > F2) {                 /* second filter; never entered when F1 == F2 (the reference's flags) */
+    float vfsc;
+    orc_vitfilter(p, dsq, L, &vfsc);
+    tr.ran_vit = 1; tr.vitsc = vfsc;
+    seq_score_d = (double)(vfsc - filtersc) / LOG2;
+    P = gumbel_surv(seq_score_d, p->evparam[2], p->evparam[3]);
+    if (P > F2) { if (keep_trace) res_push_trace(r, &tr); return; }
   }
+  tr.pass_vit = 1;
   ws_grow(w, L, p->Q);
   const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
   const float ploop = 1.0f - pmove;

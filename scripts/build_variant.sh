@@ -9,7 +9,7 @@ OUT=$ROOT/build/$NAME
 mkdir -p $OUT
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fgpu-flush-denormals-to-zero -Wall -Wno-unused-function -Wno-unused-result $EXTRA"
 pids=""
-for f in engine k_util k_derep k_msv k_float k_ensemble k_cluster k_merge; do
+for f in engine k_util k_derep k_msv k_vit k_float k_ensemble k_cluster k_merge; do
   /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OUT/$f.o & pids="$pids $!"
 done
 for f in hmm_host trim_host fastq_io pinflate; do

@@ -101,6 +101,49 @@ def forward_nats(h, seq, L_model=None, unihit=False):
     return xC + lmove
 
 
+def viterbi_filter_nats(h, seq):
+    """The Viterbi filter's score in float64: the best single path of the multihit local model, exits from match states only,
+    N/C/J loops at no cost and a flat -3 nats for them at the end (HMMER's ViterbiFilter approximation); no null model."""
+    M, mat, t = h["M"], h["mat"], h["t"]
+    L = len(seq)
+    MM, MI, MD, IM, II, DM, DD = range(7)
+    ln = lambda x: math.log(x) if x > 0 else NEG
+    occ = np.zeros(M + 1)
+    occ[1] = t[0][MI] + t[0][MM]
+    for k in range(2, M + 1):
+        occ[k] = occ[k - 1] * (t[k - 1][MM] + t[k - 1][MI]) + (1.0 - occ[k - 1]) * t[k - 1][DM]
+    Z = sum(occ[k] * (M - k + 1) for k in range(1, M + 1))
+    bm = [NEG] + [ln(occ[k] / Z) for k in range(1, M + 1)]
+    lt = np.vectorize(ln)(t)
+    lmove = math.log(3.0 / (L + 3.0))
+    lE = math.log(0.5)
+    code = {"A": (0,), "C": (1,), "G": (2,), "T": (3,), "U": (3,), "R": (0, 2), "Y": (1, 3), "M": (0, 1), "K": (2, 3), "S": (1, 2),
+            "W": (0, 3), "H": (0, 1, 3), "B": (1, 2, 3), "V": (0, 1, 2), "D": (0, 2, 3), "N": (0, 1, 2, 3)}
+    sc = np.log(mat / 0.25, where=mat > 0, out=np.full(mat.shape, NEG))
+    Mv = np.full(M + 1, NEG); Iv = np.full(M + 1, NEG); Dv = np.full(M + 1, NEG)
+    xN, xB, xJ, xC = 0.0, lmove, NEG, NEG
+    for i in range(1, L + 1):
+        xs = code[seq[i - 1].upper()]
+        em = sc[:, xs[0]] if len(xs) == 1 else sc[:, list(xs)].mean(axis=1)
+        Mn = np.full(M + 1, NEG); In = np.full(M + 1, NEG); Dn = np.full(M + 1, NEG)
+        xE = NEG
+        for k in range(1, M + 1):
+            s = xB + bm[k]
+            if k > 1:
+                s = max(s, Mv[k - 1] + lt[k - 1][MM], Iv[k - 1] + lt[k - 1][IM], Dv[k - 1] + lt[k - 1][DM])
+            Mn[k] = s + em[k]
+            if k < M:
+                In[k] = max(Mv[k] + lt[k][MI], Iv[k] + lt[k][II])
+            if k > 1:
+                Dn[k] = max(Mn[k - 1] + lt[k - 1][MD], Dn[k - 1] + lt[k - 1][DD])
+            xE = max(xE, Mn[k])
+        xC = max(xC, xE + lE)
+        xJ = max(xJ, xE + lE)
+        xB = max(xN + lmove, xJ + lmove)
+        Mv, Iv, Dv = Mn, In, Dn
+    return xC + lmove - 3.0
+
+
 def decode_regions(h, seq):
     """Posterior decoding of begin / end / occupancy (p7_DomainDecoding) and the region scan of
     p7_domaindef_ByPosteriorHeuristics (rt1 0.25, rt2 0.10), all in float64 log space on the multihit model.

@@ -27,7 +27,8 @@ class PairTrace(C.Structure):
     _fields_ = [("seq", C.c_int64), ("prof", C.c_int32), ("msv_xj", C.c_int32),
                 ("pass_msv", C.c_int32), ("pass_bias", C.c_int32), ("pass_fwd", C.c_int32),
                 ("msv_sc", C.c_float), ("filtersc", C.c_float), ("fwdsc", C.c_float),
-                ("bcksc", C.c_float), ("nullsc", C.c_float), ("nregions", C.c_int32), ("ndom", C.c_int32)]
+                ("bcksc", C.c_float), ("nullsc", C.c_float), ("nregions", C.c_int32), ("ndom", C.c_int32),
+                ("ran_vit", C.c_int32), ("pass_vit", C.c_int32), ("vitsc", C.c_float), ("pad", C.c_int32)]
 
 
 DOMAIN_DTYPE = np.dtype([("seq", "<i8"), ("prof", "<i4"), ("tlen", "<i4"), ("ienv", "<i4"), ("jenv", "<i4"),
@@ -38,7 +39,7 @@ DOMAIN_DTYPE = np.dtype([("seq", "<i8"), ("prof", "<i4"), ("tlen", "<i4"), ("ien
 TRACE_DTYPE = np.dtype([("seq", "<i8"), ("prof", "<i4"), ("msv_xj", "<i4"), ("pass_msv", "<i4"),
                         ("pass_bias", "<i4"), ("pass_fwd", "<i4"), ("msv_sc", "<f4"), ("filtersc", "<f4"),
                         ("fwdsc", "<f4"), ("bcksc", "<f4"), ("nullsc", "<f4"), ("nregions", "<i4"),
-                        ("ndom", "<i4")], align=True)
+                        ("ndom", "<i4"), ("ran_vit", "<i4"), ("pass_vit", "<i4"), ("vitsc", "<f4"), ("pad", "<i4")], align=True)
 
 
 def build():

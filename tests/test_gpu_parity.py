@@ -148,16 +148,16 @@ def test_derep_forward_only_and_ragged_lengths(engine):
 
 
 # --------------------------------------------------------------------------------------------
-def _run_both(engine, hmm_text, seqs, threads=8):
+def _run_both(engine, hmm_text, seqs, threads=8, **flags):
     engine.load_profiles(text=hmm_text)
     engine.set_reads(seqs)
     engine.derep()
-    engine.search()
+    engine.search(**flags)
     engine.finalize()
     seed, _ = engine.get_uniques()
     useqs = [seqs[int(i)] for i in seed]
     codes, o = orc.digitize(useqs)
-    res = orc.SearchResult(orc.HmmSet(text=hmm_text), codes, o, threads=threads, keep_trace=1)
+    res = orc.SearchResult(orc.HmmSet(text=hmm_text), codes, o, threads=threads, keep_trace=1, **flags)
     return res
 
 
@@ -170,7 +170,10 @@ def _compare(engine, res, left="3_", right="4_"):
     for f in ("msv_sc", "nullsc", "filtersc"):
         assert np.array_equal(_bits(tr[f]), _bits(ot[f])), f
     assert np.array_equal(tr["pass_bias"], ot["pass_bias"])
-    pb = ot["pass_bias"] == 1
+    assert np.array_equal(tr["ran_vit"], ot["ran_vit"]) and np.array_equal(tr["pass_vit"], ot["pass_vit"])
+    rv = ot["ran_vit"] == 1
+    assert np.array_equal(_bits(tr["vitsc"][rv]), _bits(ot["vitsc"][rv]))
+    pb = ot["pass_vit"] == 1
     assert np.array_equal(_bits(tr["fwdsc"][pb]), _bits(ot["fwdsc"][pb]))
     assert np.array_equal(tr["pass_fwd"], ot["pass_fwd"])
     pf = ot["pass_fwd"] == 1
@@ -410,3 +413,26 @@ def test_multidomain_regions_are_resolved_by_traceback_clustering(engine, t_hmm_
     res0 = _run_both(engine, hmm, seqs, threads=os.cpu_count() or 8)
     _compare(engine, res0)
     assert engine.stats()["n_mr_clustered"] == 0 and res0.counts["multidomain"] == res.counts["multidomain"]
+
+
+def test_viterbi_filter_with_hmmsearch_default_thresholds(engine, t_hmm_text, mini_hmm_text, fixture_reads):
+    """--F1 0.02 --F2 1e-3 --F3 1e-5 (hmmsearch's own defaults; the reference passes 1e-6 three times, which skips this filter):
+    the 16-bit Viterbi filter runs between the bias filter and Forward for every pair above F2, and every later stage sees only
+    its survivors.  Engine == oracle on the filter's score bits, its verdicts and everything downstream."""
+    flags = dict(F1=0.02, F2=1e-3, F3=1e-5)
+    blob, offs = synth.make_reads(t_hmm_text, 500, seed=61, fixed_len=0, len_range=(150, 420))
+    seqs = synth.to_strings(blob, offs) + ["ACGTRYKMSWBDHVN" * 10, "A" * 64]
+    res = _run_both(engine, _its2_subset(t_hmm_text, 25, 25), seqs, **flags)
+    ran = res.trace["ran_vit"] == 1
+    assert ran.sum() > 1000 and (res.trace["pass_vit"][ran] == 0).sum() > 100 and (res.trace["pass_vit"][ran] == 1).sum() > 100
+    _compare(engine, res)
+    assert engine.stats()["ms_vit_kernel"] > 0
+    names, fseqs = fixture_reads
+    res = _run_both(engine, mini_hmm_text, fseqs, **flags)          # incl. the short (M = 25, 11) models
+    assert (res.trace["ran_vit"] == 1).sum() > 200
+    _compare(engine, res)
+    _compare(engine, res, "1_", "2_")
+    # the reference's flags: the filter never runs
+    res = _run_both(engine, mini_hmm_text, fseqs)
+    assert (res.trace["ran_vit"] == 0).all() and engine.stats()["ms_vit_kernel"] == 0
+    _compare(engine, res)

@@ -433,3 +433,29 @@ def test_msv_agrees_with_the_generic_filter(fixture_reads, mini_hmm_text):
             assert g > 5.0                      # (255 - base 190 - tjb) / (3 / ln 2) - 3 is about 10 nats for these lengths
             n_ovf += 1
     assert n_fin >= 5 and n_ovf >= 20
+
+
+def test_viterbi_filter_agrees_with_an_independent_statement(fixture_reads, mini_hmm_text):
+    """hmmsearch's second filter (16-bit words, 1/500 bit each; it runs only when --F2 < --F1, never under the reference's flags):
+    the oracle's restatement against a float64 Viterbi of the same model, within the words' quantisation; and the pipeline's
+    bookkeeping -- the filter runs exactly for the pairs whose bias-corrected MSV P-value exceeds F2, and only its survivors
+    reach Forward."""
+    import hmm_generic
+    names, seqs = fixture_reads
+    seqs = seqs[:60]
+    hs = orc.HmmSet(text=mini_hmm_text)
+    gen = hmm_generic.parse_hmms(mini_hmm_text)
+    codes, o = orc.digitize(seqs)
+    res = orc.SearchResult(hs, codes, o, F1=0.02, F2=1e-3, F3=1e-5, keep_trace=1, threads=4)
+    tr = res.trace
+    ran = tr[tr["ran_vit"] == 1]
+    assert len(ran) > 40 and (ran["pass_vit"] == 0).any() and (ran["pass_vit"] == 1).any()
+    assert (tr["pass_fwd"] <= tr["pass_vit"]).all() and (tr["pass_vit"] <= tr["pass_bias"]).all()
+    worst = 0.0
+    for row in ran[:: max(1, len(ran) // 60)]:
+        v = hmm_generic.viterbi_filter_nats(gen[int(row["prof"])], seqs[int(row["seq"])])
+        worst = max(worst, abs(v - float(row["vitsc"])))
+    assert worst < 0.05, worst                                  # a few hundred words of 0.0014 nats, each rounded (observed 0.017)
+    # with the reference's flags the filter never runs
+    res0 = orc.SearchResult(hs, codes, o, keep_trace=1, threads=4)
+    assert (res0.trace["ran_vit"] == 0).all()

@@ -102,7 +102,6 @@ typedef struct {
   int64_t n_mr_distinct;     /* distinct (profile, target length, residues) multidomain regions actually sampled */
   int64_t n_slab_shrinks;    /* times the DP slab budget was halved because the device could not supply it */
   float   ms_vit_kernel;     int32_t pad4;               /* Viterbi filter (F2 < F1 only) */
-  int64_t n_past_vit;
 } itsx_stats;
 
 int         itsx_abi_version(void);

@@ -260,7 +260,7 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
     if (!unzstd(raw, *text, err)) { err += std::string(" in ") + path; return nullptr; }
   } else text->swap(raw);
   if (text->capacity() > text->size() + text->size() / 4 + (1 << 20)) text->shrink_to_fit();      // a copy: only when it frees a lot
-  if (trace) fprintf(stderr, "[itsx] read %s: file %.0f ms, decode%s %.0f ms (%.1f MB -> %.1f MB)\n", path, par ? " (block-parallel)" : "", std::chrono::duration<double, std::milli>(c1 - c0).count(),
+  if (trace) fprintf(stderr, "[itsx] read %s: file %.0f ms, decode%s %.0f ms (%.1f MB -> %.1f MB)\n", path, std::chrono::duration<double, std::milli>(c1 - c0).count(), par ? " (block-parallel)" : "",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1).count(), raw.size() / 1e6, text->size() / 1e6);
   if (cacheable && budget > 0 && (double)text->size() <= budget) cache_insert(path, fsize, mtime, text, budget);
   return text;

@@ -264,9 +264,23 @@ def main():
         return gather_rows(rows, dst=0)
 
     progress("reads generated in %.1f s, text resident in HBM; %d warm-up + %d timed steps" % (t_gen, args.warmup, args.steps))
+    warm_done = 0
     for k in range(args.warmup):
+        tw = time.perf_counter()
         step()
-        progress("warm-up step %d/%d done" % (k + 1, args.warmup))
+        tw = time.perf_counter() - tw
+        warm_done += 1
+        progress("warm-up step %d/%d done (%.2f s)" % (k + 1, args.warmup, tw))
+        if k + 1 < args.warmup:
+            # The K timed steps are never cut.  Warm-up steps after the first are: when another one would push the K timed
+            # steps past --budget-s (a slow box, a cold page cache, N ranks on one host), warming up stops here and the line
+            # reports the number actually done ("warmup") beside the number asked for ("warmup_requested").
+            room = torch.tensor([args.budget_s - (time.time() - T_START) - tw - (args.steps * tw * 1.05 + 20.0)], dtype=torch.float64, device=cdev)
+            if use_dist:
+                dist.all_reduce(room, op=dist.ReduceOp.MIN)              # every rank takes the same decision
+            if float(room.item()) < 0:
+                progress("warm-up cut at %d of %d steps: the %d timed steps need the rest of the %.0f-s budget" % (warm_done, args.warmup, args.steps, args.budget_s))
+                break
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -389,7 +403,7 @@ def main():
             wl += ", --taxa All (814 profiles, as configs[3])"
         res = {
             "metric": "reads/sec trimmed (ITS2, stand-in taxon Tracheophyta for Fungi)", "value": value, "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": warm_done, "warmup_requested": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8+f32", "data": "synthetic",
             "config": {"workload": wl,
                        "taxon": "Tracheophyta (stand-in: F.hmm absent from the reference mount)" if args.taxa == "T" else "All (every ITSx set in the mount; F.hmm absent)", "profiles": nprof,

@@ -13,6 +13,7 @@ constexpr int NCODE = 16;       // codes that can occur in a read: 0..15 (4 = ga
 constexpr int QMAX = 12;        // float striping segment length the device kernels are unrolled for
 constexpr int MMAX = 46;        // longest model the MSV kernel holds in registers (23 packed pairs)
 constexpr int MSV_REGS = 23;
+constexpr int MSV_TW = 24;            // dwords per residue code in a profile's MSV emission table (MSV_REGS used)
 constexpr int MAXDOM = 8;       // regions kept per (rep, profile)
 
 // ---- host-side model (profile configuration happens once per model, on the host, with libm) ----

@@ -351,10 +351,9 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
   const int Ppad = ctx->G * 64;
   std::vector<DevProfile> dp(std::max(P, 1));
   ctx->generic_q.assign(P, 0);
-  std::vector<uint32_t> etab((size_t)std::max(ctx->G, 1) * 16 * MSV_REGS * 64, 0);
+  std::vector<uint32_t> etab((size_t)std::max(P, 1) * 16 * MSV_TW, 0);
   std::vector<int32_t> pb(std::max(Ppad, 64), 0), pt(std::max(Ppad, 64), 0), pm(std::max(Ppad, 64), 0);
-  // padding lanes: cost 255 everywhere, bias 0 -> their cells never rise above 0
-  for (size_t i = 0; i < etab.size(); i++) etab[i] = 0xFF01FF01u;   // (0 - 255) as int16, twice
+  for (size_t i = 0; i < etab.size(); i++) etab[i] = 0xFF01FF01u;   // (0 - 255) as int16, twice: cells past M never rise above 0
   for (int i = 0; i < P; i++) {
     const HostProfile &h = ctx->profs[i];
     DevProfile &d = dp[i];
@@ -381,17 +380,16 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
     for (int k = 0; k < 6; k++) d.ev[k] = h.evparam[k];
     d.M = h.M; d.Q = h.Q;
     ctx->generic_q[i] = (h.Q != QMAX);
-    const int g = i / 64, lane = i % 64;
     for (int x = 0; x < NCODE; x++)
       for (int r = 0; r < MSV_REGS; r++) {
         uint32_t packed = 0;
         for (int half = 0; half < 2; half++) {
-          const int k = 2 * r + half + 1;
+          const int k = half * MSV_REGS + r + 1;          // striped: register r = cells r and r + 23 (k_msv.hip)
           const int cost = (k <= h.M) ? h.rbv[(size_t)x * (h.M + 1) + k] : 255;
           const int16_t e = (int16_t)(h.bias_b - cost);
           packed |= (uint32_t)(uint16_t)e << (16 * half);
         }
-        etab[(((size_t)g * 16 + x) * MSV_REGS + r) * 64 + lane] = packed;
+        etab[((size_t)i * 16 + x) * MSV_TW + r] = packed;
       }
     pb[i] = h.bias_b; pt[i] = h.tec_b; pm[i] = h.tbm_b;
   }
@@ -1271,9 +1269,11 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.U = U; a.G = G;
     a.etab = ctx->d_etab.p; a.pbias = ctx->d_pbias.p; a.ptec = ctx->d_ptec.p; a.ptbm = ctx->d_ptbm.p;
     a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = d_res.p;
-    // enough waves to fill 256 CUs x 8 waves several times over, but >= 8 sequences per wave to amortise the table load
-    int spw = (int)std::max<int64_t>(8, std::min<int64_t>(256, ((int64_t)U * G) / (256 * 8 * 8) + 1));
-    a.seqs_per_wave = spw; a.nchunks = (U + spw - 1) / spw;
+    a.P = P;
+    // blocks of 256 sequences x PB profiles: a few thousand blocks at least, and up to 32 profiles per block so that a
+    // large job re-reads its sequences' packed words (from L2) 32 times less often than it has profiles
+    const int64_t tiles = ((int64_t)U + 255) / 256;
+    a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * P / 4096));
     StageTimer tm(st);
     launch_msv(a, st);
     const float ms = tm.stop();

@@ -120,15 +120,15 @@ struct MsvArgs {
   const int32_t *sorted_uniq;   // [U] unique index, ascending length
   const int32_t *seed_read;     // [U] read index of each unique
   int32_t U;
-  int32_t G;                    // profile groups of 64
-  const uint32_t *etab;         // [G][16 codes][23][64] packed int16x2 of (bias - cost)
+  int32_t G;                    // profile groups of 64 (the stride of thr)
+  int32_t P;                    // profiles
+  int32_t PB;                   // profiles one block takes its 256 sequences through (grid.y = ceil(P / PB))
+  const uint32_t *etab;         // [P][16 codes][MSV_TW] packed int16x2 of (bias - cost): dword r = cells r, r + 23
   const int32_t *pbias, *ptec, *ptbm;   // [G*64]
   const uint16_t *thr;          // [Lcap][G*64] smallest passing xJ, 256 = only overflow passes
   const int32_t *tjb;           // [Lcap]
   int32_t Lcap;
   uint16_t *res;                // [G*64][U]  bit8 = passed, low byte = xJ (255 = overflow)
-  int32_t seqs_per_wave;
-  int32_t nchunks;
 };
 void launch_msv(const MsvArgs &a, hipStream_t st);
 

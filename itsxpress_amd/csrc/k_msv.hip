@@ -5,18 +5,26 @@
 // --F1 1e-6).  This is U x P x L x M byte-cell updates -- the largest cell count on the path.
 //
 // CDNA4 mapping (no MFMA: this is a max/add scan, not a contraction):
-//   * one wave = ONE sequence x 64 profiles; lane = profile.  The residue stream is then
-//     wave-uniform (scalar loads + scalar control flow), every lane runs the same row
-//     update, and there is no length divergence inside a wave.
-//   * each lane keeps its own profile's emission costs for A/C/G/T in 4 x 23 VGPRs and the DP
-//     row in 23 VGPRs, two cells per register as packed int16 (v_pk_max_i16 / v_pk_add_i16):
-//     the inner loop touches no LDS and no memory.  Degenerate residues (rare) take a path
-//     that loads that code's costs from a table in HBM (coalesced, lane = profile).
-//   * HMMER's unsigned arithmetic floors cells at 0; cells here are signed and unfloored,
-//     which is equivalent because every cell is max'ed with xB >= 0 before it is used and
-//     xE starts at 0.  The upper saturation cannot trigger before the overflow test fires.
-//   * the P-value test is folded into a per-(length, profile) threshold on the final xJ
-//     byte, computed on the host with the same double arithmetic hmmsearch uses.
+//   * lane = SEQUENCE, profile = uniform over the block.  A block of 256 lanes takes 256 representatives (neighbours in
+//     ascending length, so a wave's lanes finish together) through MSV_PB... a.PB profiles, one after the other; the
+//     profile's emission table (16 residue codes x 23 registers' worth, 1.5 KB) sits in LDS, double-buffered, and every
+//     lane fetches the 96 bytes of ITS residue's row with six ds_read_b128 -- lanes with the same residue read the same
+//     banks (broadcast), the four nucleotides' rows start 8 banks apart.  There is no branch on the residue: the round-2
+//     kernel (lane = profile, emission rows in 92 registers, one copy of the row code per nucleotide) spent a sixth of
+//     its loop moving the row's registers back after the four-way branch, and could not be talked out of it.
+//   * each lane keeps the DP row in 23 VGPRs, two cells per register as packed int16 (v_pk_max_i16 / v_pk_add_u16),
+//     STRIPED: register r holds cells r (low half) and r + 23 (high half), so the cell before both halves of register r is
+//     register r - 1 as it stands; only register 0 takes its predecessors from a shifted copy of the old register 22.
+//     Three packed instructions per two cells (max with xB, add the emission, max into xE); the row is updated in place.
+//   * degenerate residues come from the read's exception list (position, code): one compare per row against the lane's
+//     next exception; their emission rows are in the same LDS table.
+//   * HMMER's unsigned arithmetic floors cells at 0; cells here are signed and unfloored, which is equivalent because
+//     every cell is max'ed with xB >= 0 before it is used and xE starts at 0.  HMMER returns at the first row whose
+//     xE + bias reaches 255; here the row maximum of xE is kept and tested once at the end -- after that row nothing
+//     else of the lane's state is used.
+//   * the P-value test is folded into a per-(length, profile) threshold on the final xJ byte, computed on the host with
+//     the same double arithmetic hmmsearch uses.
+//   * results go to res[profile][sorted position]: consecutive lanes, consecutive halfwords.
 #include "engine.h"
 #include "k_api.h"
 
@@ -27,119 +35,93 @@ __device__ __forceinline__ s2 as_s2(uint32_t u) { return __builtin_bit_cast(s2, 
 __device__ __forceinline__ uint32_t as_u(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-#define MSV_ROW(EXPR_E, TAG)                                                                   \
-  {                                                                                            \
-    _Pragma("unroll") for (int r = MSV_REGS - 1; r >= 0; r--) {                                \
-      const uint32_t prev = (r > 0) ? __builtin_amdgcn_alignbit(dp[r], dp[r - 1], 16) : (dp[0] << 16); \
-      s2 sv = __builtin_elementwise_max(as_s2(prev), xBv);                                     \
-      sv = sv + as_s2(EXPR_E);                                                                 \
-      xEv = __builtin_elementwise_max(xEv, sv);                                                \
-      dp[r] = as_u(sv);                                                                        \
-    }                                                                                          \
-    asm volatile("; msv row " TAG ::: "memory"); /* distinct tails: keeps the 4 variants from being merged behind 23 v_mov */ \
-  }
-
-__global__ void __launch_bounds__(64) k_msv(MsvArgs a)
+__global__ void __launch_bounds__(256) k_msv(MsvArgs a)
 {
-  const int lane = threadIdx.x;
-  const int g = blockIdx.x / a.nchunks;
-  const int chunk = blockIdx.x - g * a.nchunks;
-  const int p = g * 64 + lane;
-  const int Ppad = a.G * 64;
-  uint32_t eA[MSV_REGS], eC[MSV_REGS], eG[MSV_REGS], eT[MSV_REGS];
-  const uint32_t *tb = a.etab + (size_t)g * 16 * MSV_REGS * 64 + lane;
-#pragma unroll
-  for (int r = 0; r < MSV_REGS; r++) {
-    eA[r] = tb[(0 * MSV_REGS + r) * 64];
-    eC[r] = tb[(1 * MSV_REGS + r) * 64];
-    eG[r] = tb[(2 * MSV_REGS + r) * 64];
-    eT[r] = tb[(3 * MSV_REGS + r) * 64];
+  __shared__ __attribute__((aligned(16))) uint32_t tab[2][16 * MSV_TW];
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  int L = 0, nexc = 0, tjb = 0, Lt = 0;
+  const uint32_t *wp = a.rd.words;
+  const uint32_t *ep = a.rd.exc;
+  if (s < a.U) {
+    const int r = a.seed_read[a.sorted_uniq[s]];
+    L = a.rd.len[r];
+    wp = a.rd.words + a.rd.woff[r];
+    const int64_t eo = a.rd.excoff[r];
+    nexc = (int)(a.rd.excoff[r + 1] - eo);
+    ep = a.rd.exc + eo;
+    Lt = L < a.Lcap ? L : a.Lcap - 1;
+    tjb = a.tjb[Lt];
   }
-  const int bias = a.pbias[p], tec = a.ptec[p], tbm = a.ptbm[p];
+  int Lw = L;                                     // the wave runs to its longest sequence (lengths ascend: usually all equal)
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(Lw, d, 64); Lw = o > Lw ? o : Lw; }
+  Lw = uni(Lw);
+  const int Ppad = a.G * 64;
+  const int p0 = blockIdx.y * a.PB;
+  int p1 = p0 + a.PB; if (p1 > a.P) p1 = a.P;
   const int base = 190;
-  const int s0 = chunk * a.seqs_per_wave;
-  int s1 = s0 + a.seqs_per_wave; if (s1 > a.U) s1 = a.U;
-  // per-sequence metadata is a chain of dependent scalar loads (sorted position -> unique -> read -> offsets);
-  // the next sequence's chain is started before the current sequence's rows so its latency is hidden
-  struct Meta { int L, nexc, tjb; int64_t wo, eo; uint32_t w0; };
-  auto fetch = [&](int s) {
-    Meta m;
-    const int u = uni(a.sorted_uniq[s]);
-    const int r = uni(a.seed_read[u]);
-    m.L = uni(a.rd.len[r]);
-    m.wo = a.rd.woff[r];
-    m.eo = a.rd.excoff[r];
-    m.nexc = uni((int)(a.rd.excoff[r + 1] - m.eo));
-    const int Lt = m.L < a.Lcap ? m.L : a.Lcap - 1;
-    m.tjb = uni(a.tjb[Lt]);
-    m.w0 = (uint32_t)uni((int)a.rd.words[m.wo]);
-    return m;
-  };
-  Meta nx = fetch(s0 < s1 ? s0 : 0);
-  for (int s = s0; s < s1; s++) {
-    const Meta cur = nx;
-    if (s + 1 < s1) nx = fetch(s + 1);
-    const int L = cur.L;
-    const int64_t eo = cur.eo;
-    const int nexc = cur.nexc;
-    const int Lt = L < a.Lcap ? L : a.Lcap - 1;
-    const int tjbm = cur.tjb + tbm;
-    int xJ = 0;
-    int xB = base - tjbm; xB = xB < 0 ? 0 : xB;
+  for (int p = p0; p < p1; p++) {
+    uint32_t *tb = tab[(p - p0) & 1];
+    // every wave is past the barrier of profile p - 1, so none still reads the table of profile p - 2 in this buffer
+    for (int i = threadIdx.x; i < 16 * MSV_TW; i += 256) tb[i] = a.etab[(size_t)p * 16 * MSV_TW + i];
+    __syncthreads();
+    const int bias = uni(a.pbias[p]), tec = uni(a.ptec[p]), tbm = uni(a.ptbm[p]);
+    const int tjbm = tjb + tbm;
+    int bm0 = base - tjbm; bm0 = bm0 < 0 ? 0 : bm0;          // xB while xJ is below the base
+    int xJ = 0, xB = bm0, xEmax = 0;
     uint32_t dp[MSV_REGS];
 #pragma unroll
     for (int i = 0; i < MSV_REGS; i++) dp[i] = 0;
-    int ovf = 0;
     int ei = 0;
-    int next_exc = nexc > 0 ? uni((int)(a.rd.exc[eo] >> 4)) : 0x7fffffff;
-    const uint32_t *wp = a.rd.words + cur.wo;
-    uint32_t wnext = cur.w0;
-    for (int i0 = 0; i0 < L; i0 += 16) {
-      uint32_t w = wnext;
-      if (i0 + 16 < L) wnext = (uint32_t)uni((int)wp[(i0 >> 4) + 1]);     // the next 16 bases fly during these 16 rows
-      int cnt = L - i0; cnt = cnt > 16 ? 16 : cnt;
-      for (int t = 0; t < cnt; t++) {
-        const s2 xBv = as_s2((uint32_t)xB * 0x10001u);
-        s2 xEv = as_s2(0u);
-        if (i0 + t == next_exc) {
-          const int code = uni((int)(a.rd.exc[eo + ei] & 15u));
+    int next_exc = nexc > 0 ? (int)(ep[0] >> 4) : 0x7fffffff;
+    uint32_t w = 0, wnext = L > 0 ? wp[0] : 0u;
+    for (int pos = 0; pos < Lw; pos++) {
+      const int sh = (pos & 15) * 2;
+      if (sh == 0) { w = wnext; if (pos + 16 < L) wnext = wp[(pos >> 4) + 1]; }      // the next 16 bases fly during these 16 rows
+      if (pos < L) {
+        int code = (int)((w >> sh) & 3u);
+        if (pos == next_exc) {
+          code = (int)(ep[ei] & 15u);
           ei++;
-          next_exc = ei < nexc ? uni((int)(a.rd.exc[eo + ei] >> 4)) : 0x7fffffff;
-          const uint32_t *tc = tb + (size_t)code * MSV_REGS * 64;
-          uint32_t ex[MSV_REGS];
-#pragma unroll
-          for (int q = 0; q < MSV_REGS; q++) ex[q] = tc[q * 64];
-          MSV_ROW(ex[r], "degenerate")
-        } else {
-          const int x = (int)(w & 3u);
-          if (x == 0) MSV_ROW(eA[r], "A")
-          else if (x == 1) MSV_ROW(eC[r], "C")
-          else if (x == 2) MSV_ROW(eG[r], "G")
-          else MSV_ROW(eT[r], "T")
+          next_exc = ei < nexc ? (int)(ep[ei] >> 4) : 0x7fffffff;
         }
-        w >>= 2;
-        const uint32_t xe2 = as_u(xEv);
+        const uint4 *e4 = (const uint4 *)(tb + code * MSV_TW);
+        uint32_t e[MSV_TW];
+#pragma unroll
+        for (int q = 0; q < MSV_TW / 4; q++) { const uint4 v = e4[q]; e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w; }
+        const s2 xBv = as_s2((uint32_t)xB * 0x10001u);
+        const uint32_t wrap = dp[MSV_REGS - 1] << 16;
+        s2 xEa = as_s2(0u), xEb = as_s2(0u);
+#pragma unroll
+        for (int r = MSV_REGS - 1; r >= 0; r--) {
+          const uint32_t prev = (r > 0) ? dp[r > 0 ? r - 1 : 0] : wrap;
+          const s2 sv = __builtin_elementwise_max(as_s2(prev), xBv) + as_s2(e[r]);
+          if (r & 1) xEb = __builtin_elementwise_max(xEb, sv); else xEa = __builtin_elementwise_max(xEa, sv);
+          dp[r] = as_u(sv);
+        }
+        const uint32_t xe2 = as_u(__builtin_elementwise_max(xEa, xEb));
         int xE = (int)(xe2 & 0xffffu);
         const int xEh = (int)(xe2 >> 16);
         xE = xE > xEh ? xE : xEh;
-        ovf |= (xE + bias >= 255);
-        xE = xE > 255 ? 255 : xE;
-        xE -= tec; xE = xE < 0 ? 0 : xE;
+        xEmax = xEmax > xE ? xEmax : xE;
+        xE -= tec;
         xJ = xJ > xE ? xJ : xE;
-        xB = (base > xJ ? base : xJ) - tjbm; xB = xB < 0 ? 0 : xB;
+        xB = xJ - tjbm; xB = xB > bm0 ? xB : bm0;            // = max(max(base, xJ) - tjbm, 0)
       }
     }
-    const int thr = a.thr[(size_t)Lt * Ppad + p];
-    const int pass = ovf | (xJ >= thr);
-    const int xj = ovf ? 255 : xJ;
-    a.res[(size_t)p * a.U + s] = (uint16_t)(pass ? (0x100 | xj) : 0);
+    if (s < a.U) {
+      const int ovf = (xEmax + bias >= 255);
+      const int thr = a.thr[(size_t)Lt * Ppad + p];
+      const int pass = ovf | (xJ >= thr);
+      const int xj = ovf ? 255 : xJ;
+      a.res[(size_t)p * a.U + s] = (uint16_t)(pass ? (0x100 | xj) : 0);
+    }
   }
 }
 
 void launch_msv(const MsvArgs &a, hipStream_t st)
 {
-  if (a.U <= 0 || a.G <= 0) return;
-  hipLaunchKernelGGL(k_msv, dim3((unsigned)(a.G * a.nchunks)), dim3(64), 0, st, a);
+  if (a.U <= 0 || a.P <= 0) return;
+  hipLaunchKernelGGL(k_msv, dim3((unsigned)((a.U + 255) / 256), (unsigned)((a.P + a.PB - 1) / a.PB)), dim3(256), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -354,7 +354,8 @@ def main():
         # algorithmic HBM bytes of each main kernel, per step; L = the mean read length
         U, wbytes = st["n_unique"], 4.0 * ((mean_len + 15) // 16)
         alg = {
-            "k_msv": U * ((nprof + 63) // 64) * wbytes + 2 * ((nprof + 63) // 64 * 64) * U,
+            # a block of 256 representatives re-reads their packed words once per profile (from L2 after the first); 2 B per pair out
+            "k_msv": U * wbytes + 2 * nprof * U,
             # per pair: packed read + PairRec/PairOut; per row: 6 special-state floats written
             "k_filters_fwd": st["n_past_msv"] * (wbytes + 16 + 40) + st["fwd_rows"] * 24,
             # per row: Forward's 6 floats read, 6 decoding terms written
@@ -368,7 +369,7 @@ def main():
         rows = st["fwd_rows"]
         tfl = {k: (rows * FLOPS_PER_ROW / (kern[k] * 1e-3) / 1e12 if kern[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode")}
         vfrac = {
-            "k_msv": (st["msv_cells"] / 20.5) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 20.5 cells per wave instruction
+            "k_msv": (st["msv_cells"] / 32.7) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 64 lanes x 45 cells per 88 wave instructions of a row
             "k_filters_fwd": (rows / 64 * VALU_PER_ROW["k_filters_fwd"]) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
             "k_bwd_decode": (rows / 64 * VALU_PER_ROW["k_bwd_decode"]) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
         }

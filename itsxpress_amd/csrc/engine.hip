@@ -153,6 +153,10 @@ struct itsx_ctx {
   int device = 0;
   hipStream_t st = nullptr, st2 = nullptr;   // st2: the bias filter of the next batch beside the decoder of this one
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  // the MSV filter of chunk c + 1 runs on st2 beside the domain stage of chunk c (latency-bound kernels that leave the vector
+  // ALUs idle): ev_msv0/1 bracket it; msv_pre_u0 = the chunk it was launched for (-1: none)
+  hipEvent_t ev_msv0 = nullptr, ev_msv1 = nullptr, ev_c = nullptr;
+  int64_t msv_pre_u0 = -1, next_u0 = -1; int32_t next_U = 0;
   mutable std::string err;
   void set_error(const std::string &m) const { err = m; }
   itsx_stats stats{};
@@ -331,7 +335,8 @@ void itsx_destroy(itsx_ctx *ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->st);
-  if (ctx->st2) { (void)hipStreamSynchronize(ctx->st2); (void)hipStreamDestroy(ctx->st2); (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b); }
+  if (ctx->st2) { (void)hipStreamSynchronize(ctx->st2); (void)hipStreamDestroy(ctx->st2); (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b);
+                  if (ctx->ev_msv0) { (void)hipEventDestroy(ctx->ev_msv0); (void)hipEventDestroy(ctx->ev_msv1); (void)hipEventDestroy(ctx->ev_c); } }
   (void)hipStreamDestroy(ctx->st);
   for (int k = 0; k < itsx_ctx::NSTAGE; k++) { if (ctx->stage_pin[k]) (void)hipHostFree(ctx->stage_pin[k]); if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]); }
   delete ctx;
@@ -1237,7 +1242,11 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   if (const char *e = getenv("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
   ctx->keep_trace = getenv("ITSX_KEEP_TRACE") != nullptr;
   int ci = 0;
+  if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));      // a search that failed half-way may have left an MSV launch behind
+  ctx->msv_pre_u0 = -1;
   for (int64_t u0 = 0; u0 < U; u0 += Uc, ci++) {
+    ctx->next_u0 = (u0 + Uc < U) ? u0 + Uc : -1;
+    ctx->next_U = (int32_t)std::min<int64_t>(Uc, U - (u0 + Uc));
     const int rc = search_chunk(ctx, ci, (int32_t)u0, (int32_t)std::min<int64_t>(Uc, U - u0), Lcap, T, F1, F3);
     if (rc != ITSX_OK) return rc;
   }
@@ -1263,19 +1272,30 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   ctx->trace_u0 = u0;
   // ---- MSV for every (unique, profile)
   DBuf<uint16_t> &d_res = ctx->w_res;
-  HIPCHK(d_res.alloc((size_t)Ppad * U));
-  {
+  HIPCHK(d_res.alloc((size_t)Ppad * std::max<int64_t>(U, ctx->next_u0 >= 0 ? ctx->next_U : 0)));
+  auto msv_for = [&](int64_t cu0, int32_t cU, hipStream_t s, int lds_pad = 0) {
     MsvArgs a{};
-    a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.U = U; a.G = G;
+    a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p + cu0; a.seed_read = ctx->d_seed_read.p; a.U = cU; a.G = G;
     a.etab = ctx->d_etab.p; a.pbias = ctx->d_pbias.p; a.ptec = ctx->d_ptec.p; a.ptbm = ctx->d_ptbm.p;
     a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = d_res.p;
     a.P = P;
     // blocks of 256 sequences x PB profiles: a few thousand blocks at least, and up to 32 profiles per block so that a
     // large job re-reads its sequences' packed words (from L2) 32 times less often than it has profiles
-    const int64_t tiles = ((int64_t)U + 255) / 256;
+    const int64_t tiles = ((int64_t)cU + 255) / 256;
     a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * P / 4096));
+    launch_msv(a, s, lds_pad);
+  };
+  if (ctx->msv_pre_u0 == (int64_t)u0) {
+    // launched on st2 while the chunk before this one was in its domain stage
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_msv1, 0));
+    HIPCHK(hipEventSynchronize(ctx->ev_msv1));
+    float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev_msv0, ctx->ev_msv1);
+    S.ms_msv_kernel += ms;                       // its stretched wall time beside other kernels: not extra step time
+    S.msv_launches += 1;
+    ctx->msv_pre_u0 = -1;
+  } else {
     StageTimer tm(st);
-    launch_msv(a, st);
+    msv_for(u0, U, st);
     const float ms = tm.stop();
     S.ms_msv_kernel += ms; S.ms_msv += ms;
     S.msv_launches += 1;
@@ -1398,7 +1418,10 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     // the 256-register DP kernels never do with anything.
     static const bool overlap = !(getenv("ITSX_BIAS_OVERLAP") && atoi(getenv("ITSX_BIAS_OVERLAP")) == 0);
     if (overlap && !ctx->st2) {
-      HIPCHK(hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking));
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (getenv("ITSX_ST2_PRIO") && atoi(getenv("ITSX_ST2_PRIO")) == 0) least = 0;
+      HIPCHK(hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, least));     // what runs there fills gaps, it does not take turns
       HIPCHK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
     }
     LazyTimers lazy(st), lazy2(overlap ? ctx->st2 : st);
@@ -1437,6 +1460,23 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     lazy2.collect();
     lazy.collect();
     S.ms_filters += tm.stop();
+  }
+  {
+    // ---- the next chunk's MSV filter, on the second stream: the kernels of the domain stage below wait on memory most of the
+    // time (tracebacks, envelope slabs, hashing), the MSV kernel is pure VALU work at 75 registers -- the two share the SIMDs.
+    // Its result buffer is free: this chunk's survivor list was built from it before the DP batches.
+    static const bool msv_overlap = !(getenv("ITSX_MSV_OVERLAP") && atoi(getenv("ITSX_MSV_OVERLAP")) == 0);
+    if (msv_overlap && ctx->next_u0 >= 0 && ctx->st2 && !ctx->keep_trace) {
+      if (!ctx->ev_msv0) {
+        HIPCHK(hipEventCreate(&ctx->ev_msv0)); HIPCHK(hipEventCreate(&ctx->ev_msv1));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(ctx->ev_c, st)); HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->ev_c, 0));
+      HIPCHK(hipEventRecord(ctx->ev_msv0, ctx->st2));
+      msv_for(ctx->next_u0, ctx->next_U, ctx->st2, getenv("ITSX_MSV_PAD") ? atoi(getenv("ITSX_MSV_PAD")) : 40000);
+      HIPCHK(hipEventRecord(ctx->ev_msv1, ctx->st2));
+      ctx->msv_pre_u0 = ctx->next_u0;
+    }
   }
   StageTimer tm_dom(st);
   // ---- multidomain regions: resolved into envelopes by stochastic traceback clustering (k_ensemble.hip)

@@ -130,7 +130,7 @@ struct MsvArgs {
   int32_t Lcap;
   uint16_t *res;                // [G*64][U]  bit8 = passed, low byte = xJ (255 = overflow)
 };
-void launch_msv(const MsvArgs &a, hipStream_t st);
+void launch_msv(const MsvArgs &a, hipStream_t st, int lds_pad = 0);
 
 // survivor list: pairs grouped by profile, 64-aligned segments, ascending length inside a segment
 constexpr int CHUNK = 2048;
@@ -181,7 +181,7 @@ struct VitArgs {
   double F2;
 };
 void launch_vit(const VitArgs &a, int nwaves, int wave0, hipStream_t st);
-void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st);
+void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st, int lds_pad = 0);
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st);

@@ -1260,10 +1260,11 @@ __global__ void __launch_bounds__(256) k_count_flags(const int32_t *__restrict__
 }
 
 // ---- host launchers -----------------------------------------------------------------------
-void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st)
+// lds_pad: untouched dynamic LDS that caps the blocks per CU when the kernel runs beside another stream's (see launch_msv)
+void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st, int lds_pad)
 {
   if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_bias, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, a, npairs);
+  hipLaunchKernelGGL(k_bias, dim3((unsigned)((npairs + 255) / 256)), dim3(256), (size_t)lds_pad, st, a, npairs);
 }
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
 {

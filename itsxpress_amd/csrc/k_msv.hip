@@ -118,10 +118,12 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
   }
 }
 
-void launch_msv(const MsvArgs &a, hipStream_t st)
+// lds_pad: dynamic LDS the launch asks for and never touches -- a cap on the blocks a CU holds (160 KB per CU), for the launch that
+// runs beside another stream's kernels and must leave them their registers
+void launch_msv(const MsvArgs &a, hipStream_t st, int lds_pad)
 {
   if (a.U <= 0 || a.P <= 0) return;
-  hipLaunchKernelGGL(k_msv, dim3((unsigned)((a.U + 255) / 256), (unsigned)((a.P + a.PB - 1) / a.PB)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_msv, dim3((unsigned)((a.U + 255) / 256), (unsigned)((a.P + a.PB - 1) / a.PB)), dim3(256), (size_t)lds_pad, st, a);
 }
 
 // ---------------------------------------------------------------------------------------

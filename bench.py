@@ -36,9 +36,14 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # HMMER rounds every product and every sum separately, so the DP kernels cannot use FMA (the 157 TFLOP/s figure).
 VALU_NOFMA_TFLOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4          # wave instructions per second: 1024 SIMDs, one VALU issue per 4 cycles
-# the recurrence's own work per DP lane-row (45-node model, Q = 12): 480 packed multiplies/adds = 960 flops;
-# the kernels issue 533 (Forward) / 561 (Backward) VALU instructions per row (instruction audit)
-FLOPS_PER_ROW = 960.0
+# the recurrence's own work per DP lane-row (45-node model, Q = 12 striped vectors of 4 floats), every product and every sum one flop:
+#   Forward  (p7_ForwardParser): 16 vector operations per q (9 match, 1 + 2 + 1 delete, 3 insert) + two of the three lazy DD passes
+#            (2 per q each) = 20 x 12 x 4 = 960 flops;
+#   Backward (p7_BackwardParser): 3 (next row's M x emission, into B) + 7 (I, partial D, M) + 4 (first DD pass, E into D and M)
+#            + 3 x 2 (its three further DD passes are unconditional) + 2 (D into M) = 22 per q = 22 x 12 x 4 = 1056 flops;
+# the kernels issue 533 (Forward) / 561 (Backward) VALU instructions per row, 484 / 537 of them packed multiplies and adds
+# (instruction audit; Backward's include the five decoding products of the row)
+FLOPS_PER_ROW = {"k_filters_fwd": 960.0, "k_bwd_decode": 1056.0}
 VALU_PER_ROW = {"k_filters_fwd": 533.0, "k_bwd_decode": 561.0}
 # HBM bytes per lane-row from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE corrected by the factor
 # calibrated with scripts/fetch_calib.py on the slab access pattern (profiles/round2_fetch_calibration.md)
@@ -367,7 +372,7 @@ def main():
         }
         # what bounds each of them: the DP scans are VALU-bound (no-FMA fp32), the streaming kernels HBM-bound
         rows = st["fwd_rows"]
-        tfl = {k: (rows * FLOPS_PER_ROW / (kern[k] * 1e-3) / 1e12 if kern[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode")}
+        tfl = {k: (rows * FLOPS_PER_ROW[k] / (kern[k] * 1e-3) / 1e12 if kern[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode")}
         vfrac = {
             "k_msv": (st["msv_cells"] / 32.7) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 64 lanes x 45 cells per 88 wave instructions of a row
             "k_filters_fwd": (rows / 64 * VALU_PER_ROW["k_filters_fwd"]) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
@@ -385,10 +390,11 @@ def main():
         if dom in tfl and tfl[dom]:
             roof = {"kernel": dom, "bound": "valu", "achieved": round(tfl[dom], 3), "peak": round(VALU_NOFMA_TFLOPS, 1), "unit": "TFLOP/s",
                     "frac": tfl[dom] / VALU_NOFMA_TFLOPS, "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl,
-                    "alg_flops_per_launch": rows * FLOPS_PER_ROW / nl, "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
+                    "alg_flops_per_launch": rows * FLOPS_PER_ROW[dom] / nl, "alg_flops_per_lane_row": FLOPS_PER_ROW[dom], "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
                     "hbm_frac_on_alg_bytes": alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "note": "a serial recurrence per (representative, profile): 960 no-FMA fp32 flops per lane-row (HMMER rounds products "
-                            "and sums separately) against 78.6 TFLOP/s = 1024 SIMDs x 32 lanes x 2.4 GHz; duration = HIP events on the "
+                    "note": "a serial recurrence per (representative, profile): the recurrence's own no-FMA fp32 flops per lane-row (HMMER rounds "
+                            "products and sums separately; Forward 960, Backward 1056 with its four unconditional DD passes: the count is "
+                            "spelled out at the top of bench.py) against 78.6 TFLOP/s = 1024 SIMDs x 32 lanes x 2.4 GHz; duration = HIP events on the "
                             "engine's stream; traffic = PMC bytes per lane-row x rows per launch (profiles/round2_*)"}
         else:
             ach = alg[dom] / (kern[dom] * 1e-3) / 1e9

@@ -431,7 +431,7 @@ def main():
                             "pairs_over_region_cap": int(st["n_domain_overflow"]),
                             "uniques_with_pair_over_region_cap": int(st["n_uniq_region_cap"]),
                             "reads_with_pair_over_region_cap": int(st["n_reads_region_cap"])},
-            "concurrency": "k_bias of batch b+1 runs on a second stream beside k_decode of batch b: ms_bias_kernel is its stretched wall time, not extra step time",
+            "concurrency": "k_bias of batch b+1 runs on a second stream beside k_decode of batch b, and k_msv of chunk c+1 beside the domain stage of chunk c: ms_bias_kernel and ms_msv_kernel (hence kernels.k_msv and valu.msv_gcups) are stretched wall times, not extra step time; alone k_msv takes ~0.2 s per chunk (ITSX_MSV_OVERLAP=0)",
             "cluster": None if args.cluster_id >= 1.0 else {"windows": int(st["cl_windows"]), "cut_windows": int(st["cl_cuts"]),
                                                             "alignments": int(st["cl_alignments"]), "centroids": int(st["n_unique"])},
             "roofline": roof,

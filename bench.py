@@ -276,10 +276,11 @@ def main():
         tw = time.perf_counter() - tw
         warm_done += 1
         progress("warm-up step %d/%d done (%.2f s)" % (k + 1, args.warmup, tw))
-        if k + 1 < args.warmup:
-            # The K timed steps are never cut.  Warm-up steps after the first are: when another one would push the K timed
-            # steps past --budget-s (a slow box, a cold page cache, N ranks on one host), warming up stops here and the line
-            # reports the number actually done ("warmup") beside the number asked for ("warmup_requested").
+        if k >= 1 and k + 1 < args.warmup:
+            # The K timed steps are never cut.  Warm-up steps after the second are (the first one pays for every first-use
+            # allocation and says little about a step): when another one would push the K timed steps past --budget-s (a slow
+            # box, a cold page cache, N ranks on one host), warming up stops here and the line reports the number actually
+            # done ("warmup") beside the number asked for ("warmup_requested").
             room = torch.tensor([args.budget_s - (time.time() - T_START) - tw - (args.steps * tw * 1.05 + 20.0)], dtype=torch.float64, device=cdev)
             if use_dist:
                 dist.all_reduce(room, op=dist.ReduceOp.MIN)              # every rank takes the same decision

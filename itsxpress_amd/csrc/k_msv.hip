@@ -6,12 +6,12 @@
 //
 // CDNA4 mapping (no MFMA: this is a max/add scan, not a contraction):
 //   * lane = SEQUENCE, profile = uniform over the block.  A block of 256 lanes takes 256 representatives (neighbours in
-//     ascending length, so a wave's lanes finish together) through MSV_PB... a.PB profiles, one after the other; the
+//     ascending length, so a wave's lanes finish together) through a.PB profiles (up to 32), one after the other; the
 //     profile's emission table (16 residue codes x 23 registers' worth, 1.5 KB) sits in LDS, double-buffered, and every
 //     lane fetches the 96 bytes of ITS residue's row with six ds_read_b128 -- lanes with the same residue read the same
-//     banks (broadcast), the four nucleotides' rows start 8 banks apart.  There is no branch on the residue: the round-2
-//     kernel (lane = profile, emission rows in 92 registers, one copy of the row code per nucleotide) spent a sixth of
-//     its loop moving the row's registers back after the four-way branch, and could not be talked out of it.
+//     banks (broadcast), the four nucleotides' rows start 8 banks apart.  There is no branch on the residue: the kernel
+//     this one replaced (lane = profile, emission rows in 92 registers, one copy of the row code per nucleotide) spent a
+//     sixth of its loop moving the row's registers back after the four-way branch, and could not be talked out of it.
 //   * each lane keeps the DP row in 23 VGPRs, two cells per register as packed int16 (v_pk_max_i16 / v_pk_add_u16),
 //     STRIPED: register r holds cells r (low half) and r + 23 (high half), so the cell before both halves of register r is
 //     register r - 1 as it stands; only register 0 takes its predecessors from a shifted copy of the old register 22.

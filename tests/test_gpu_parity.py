@@ -228,6 +228,28 @@ def test_search_ragged_lengths_and_edge_cases(engine, t_hmm_text):
     _compare(engine, res)
 
 
+def test_search_mixed_lengths_and_degenerate_bases_across_tiles(engine, t_hmm_text):
+    """k_msv takes 256 representatives per block, a lane each: lengths from 20 to 620 inside one wave, 2 % N (a per-lane
+    exception list the lane steps through on its own), random reads that fail at different rows, reads with the motif
+    twice -- several blocks' worth, every stage equal to the oracle (scripts/parity_stress.py is the 12 000-read version)."""
+    blob, offs = synth.make_reads(t_hmm_text, 2500, config=3, seed=synth.SEED + 11, fixed_len=0, len_range=(300, 580), n_rate=0.02, sub_rate=0.01)
+    rng = np.random.default_rng(11)
+    seqs = []
+    for s in synth.to_strings(blob, offs):
+        r = rng.random()
+        if r < 0.35:
+            k = int(rng.integers(20, len(s)))
+            s = s[:k] if rng.random() < 0.5 else s[-k:]
+        elif r < 0.45:
+            s = "".join(rng.choice(list("ACGTNRYKMSWBDHV"), size=int(rng.integers(20, 620))))
+        elif r < 0.50:
+            s = s + s[: int(rng.integers(10, 200))]
+        seqs.append(s)
+    res = _run_both(engine, _its2_subset(t_hmm_text, 30, 30), seqs)
+    assert engine.n_unique > 2000 and res.counts["past_msv"] > 20000
+    _compare(engine, res)
+
+
 def test_search_fuzz_odd_reads(engine, mini_hmm_text, monkeypatch):
     """Reads nobody sequences: shorter than the models, homopolymers, consensus repeated many times (several domains per
     read, strong scores that force rescaling), IUPAC soup, motif fragments glued in both orientations.  Every stage must

@@ -309,6 +309,8 @@ int itsx_debug_packed_read(const itsx_ctx *ctx, int64_t i, uint32_t *words, int3
 int itsx_debug_calibrate(itsx_ctx *ctx, int pattern, double gbytes, int iters, int64_t *bytes_per_launch, double *ms_per_launch);
 /* deterministic log/exp evaluated ON THE DEVICE for n inputs */
 int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_log, double *out_exp);
+/* the bias filter's table-driven float logarithm (detmath.h: det_logf_fast) ON THE DEVICE: out[i] must equal (float)det_log((double)x[i]) */
+int itsx_debug_logf(itsx_ctx *ctx, const float *x, int64_t n, float *out);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,57 @@ ITSX_HD double det_exp(double x)
 
 ITSX_HD float det_logf(float x) { return (float)det_log((double)x); }
 
+// (float)det_log((double)x), bit for bit, for the one place that takes a logarithm per residue (the bias filter).  det_log costs ~55
+// double-precision operations, a division among them; but its result is only kept as a float.  So: a table-driven logarithm with a
+// PROVEN error bound (128 intervals of the reduced argument m in [sqrt(1/2), sqrt(2)): r = m * inv_c - 1 with |r| <= 0.004, inv_c a
+// double and logc = -log(inv_c) for exactly that double, log1p(r) to degree 5: 6.9e-16 truncation; k ln2 + logc + p: under
+// 5e-16 |y| rounding in all, det_log's own error, < 1 ulp of y, included), and the float is taken from it only when every double
+// within E = 1e-14 + 1e-15 |y| of the approximation rounds to the SAME float -- det_log's value is one of them.  Otherwise (about
+// 4 in 10^7 arguments around |y| = 1, more often next to x = 1 where y itself is tiny) det_log decides.  ~27 operations, no division.
+struct LogTab { double inv_c, logc; };
+constexpr int LOGTAB_N = 128;
+#if defined(__HIPCC__)
+__host__
+#endif
+inline void build_logtab(LogTab *t)
+{
+  for (int i = 0; i < LOGTAB_N; i++) {
+    const uint32_t h0 = 0x3fe6a09eu + (uint32_t)i * 0x2000u;
+    const double m0 = u2d((uint64_t)h0 << 32), m1 = u2d((uint64_t)(h0 + 0x2000u) << 32);
+    const double c = 0.5 * m0 + 0.5 * m1;
+    t[i].inv_c = 1.0 / c;
+    t[i].logc = (double)(-__builtin_logl((long double)t[i].inv_c));
+  }
+}
+ITSX_HD float det_logf_fast(float xf, const LogTab *tab)
+{
+  const double x = (double)xf;
+  const uint64_t u = d2u(x);
+  uint32_t hx = (uint32_t)(u >> 32);
+#ifdef ITSX_NO_FASTLOG                                   /* A/B builds (scripts/build_variant.sh): det_log for every argument */
+  if (false) {
+#else
+  if ((hx - 0x00100000u) < 0x7fe00000u) {              // positive, normal, finite
+#endif
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    const uint32_t lo20 = hx & 0x000fffffu;
+    const LogTab t = tab[lo20 >> 13];
+    const double m = u2d(((uint64_t)(lo20 + 0x3fe6a09eu) << 32) | (u & 0xffffffffull));
+    const double r = __builtin_fma(m, t.inv_c, -1.0);
+    double p = __builtin_fma(r, 0.2, -0.25);
+    p = __builtin_fma(r, p, 1.0 / 3.0);
+    p = __builtin_fma(r, p, -0.5);
+    p = __builtin_fma(r, p, 1.0);
+    p = r * p;
+    const double y = __builtin_fma((double)k, 6.93147180559945286227e-01, t.logc) + p;
+    const double E = __builtin_fma(__builtin_fabs(y), 1e-15, 1e-14);
+    const float lo = (float)(y - E), hi = (float)(y + E);
+    if (lo == hi) return lo;
+  }
+  return (float)det_log(x);
+}
+
 // P-value tails, as Easel defines them
 ITSX_HD double gumbel_surv(double x, double mu, double lambda)
 {

@@ -167,7 +167,7 @@ struct itsx_ctx {
   DBuf<DevProfile> d_prof;
   DBuf<uint32_t> d_etab;
   DBuf<int32_t> d_pbias, d_ptec, d_ptbm;
-  DBuf<float> d_flogsum;
+  DBuf<float> d_flogsum; DBuf<LogTab> d_logtab;
   std::vector<char> generic_q;          // per profile: needs the runtime-Q kernels
 
   // ---- reads
@@ -326,6 +326,9 @@ itsx_ctx *itsx_create(int device_id, int flags)
   std::vector<float> tbl(16000);
   for (int i = 0; i < 16000; i++) tbl[i] = (float)log(1. + exp((double)-i / 1000.f));
   if (upload(ctx->d_flogsum, tbl, ctx->st) != hipSuccess) { g_create_error = "device allocation failed"; delete ctx; return nullptr; }
+  std::vector<LogTab> lt(LOGTAB_N);
+  build_logtab(lt.data());
+  if (upload(ctx->d_logtab, lt, ctx->st) != hipSuccess) { g_create_error = "device allocation failed"; delete ctx; return nullptr; }
   (void)hipStreamSynchronize(ctx->st);
   return ctx;
 }
@@ -1403,7 +1406,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     HIPCHK(hipMemcpyAsync(d_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
     FloatArgs a{};
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
-    a.flogsum = ctx->d_flogsum.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
+    a.flogsum = ctx->d_flogsum.p; a.logtab = ctx->d_logtab.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
     a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
     VitArgs va{};
     if (ctx->have_vit) {
@@ -2461,6 +2464,21 @@ int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_lo
     launch_detmath(dx.p, n, dl.p, de.p, ctx->st);
     HIPCHK(hipMemcpyAsync(out_log, dl.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipMemcpyAsync(out_exp, de.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
+
+int itsx_debug_logf(itsx_ctx *ctx, const float *x, int64_t n, float *out)
+{
+  CTXCHK(ctx && x && out && n >= 0);
+  HIPCHK(hipSetDevice(ctx->device));
+  DBuf<float> dx, dy;
+  HIPCHK(dx.alloc((size_t)n + 1)); HIPCHK(dy.alloc((size_t)n + 1));
+  if (n > 0) {
+    HIPCHK(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, ctx->st));
+    launch_logf_fast(dx.p, n, ctx->d_logtab.p, dy.p, ctx->st);
+    HIPCHK(hipMemcpyAsync(out, dy.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
   }
   HIPCHK(hipStreamSynchronize(ctx->st));
   return ITSX_OK;

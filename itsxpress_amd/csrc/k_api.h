@@ -2,6 +2,7 @@
 #pragma once
 #include "engine.h"
 
+#include "detmath.h"
 namespace itsx {
 
 struct ReadsDev {
@@ -113,6 +114,7 @@ void    launch_pack_exc(const uint8_t *raw, int64_t raw_base, const int64_t *off
 // PMC calibration streams: pattern 0 read 6 of 6 fields (4 B/lane), 1 read 5 of 6, 2 write 6 of 6, 3 read 16 B/lane
 void    launch_calib(int pattern, float *slab, int64_t nwaves, int64_t R, float *out, hipStream_t st);
 void    launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st);
+void    launch_logf_fast(const float *x, int64_t n, const LogTab *tab, float *out, hipStream_t st);
 
 // ---- k_msv.hip
 struct MsvArgs {
@@ -157,6 +159,7 @@ struct FloatArgs {
   const DevProfile *prof;
   const LenTables *lt;
   const float *flogsum;         // [16000]
+  const LogTab *logtab;         // [LOGTAB_N] detmath.h: the bias filter's table-driven logarithm
   const PairRec *pairs;
   PairOut *pout;
   const WaveDesc *waves;

@@ -386,6 +386,9 @@ DEV void fill_lds_rf(float *rf_s, const DevProfile *pp)
 // kernel: it needs ~40 registers, so it runs at full occupancy instead of inside the 2-wave Forward kernel.
 __global__ void __launch_bounds__(256) k_bias(FloatArgs a, int64_t npairs)
 {
+  __shared__ LogTab ltab[LOGTAB_N];
+  if (threadIdx.x < LOGTAB_N) ltab[threadIdx.x] = a.logtab[threadIdx.x];
+  __syncthreads();
   const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= npairs) return;
   const PairRec pr = a.pairs[pi];
@@ -417,7 +420,7 @@ __global__ void __launch_bounds__(256) k_bias(FloatArgs a, int64_t npairs)
       // x / x == 1 exactly: only the smaller state needs the division
       const float q01 = ((n0 > n1) ? n1 : n0) / mx;
       d0 = (n0 == mx) ? 1.0f : q01; d1 = (n1 == mx) ? 1.0f : q01;
-      logsc += (float)det_log((double)mx);
+      logsc += det_logf_fast(mx, ltab);             // == (float)det_log((double)mx): detmath.h
     }
     float e = 0.0f; e += d0 * 1.0f; e += d1 * 1.0f;
     logsc += (float)det_log((double)e);

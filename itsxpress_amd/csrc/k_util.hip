@@ -68,6 +68,16 @@ __global__ void k_detmath(const double *__restrict__ x, int64_t n, double *__res
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { ol[i] = det_log(x[i]); oe[i] = det_exp(x[i]); }
 }
+__global__ void k_logf_fast(const float *__restrict__ x, int64_t n, const LogTab *__restrict__ tab, float *__restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = det_logf_fast(x[i], tab);
+}
+void launch_logf_fast(const float *x, int64_t n, const LogTab *tab, float *out, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_logf_fast, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, tab, out);
+}
 void launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st)
 {
   if (n <= 0) return;

@@ -410,6 +410,12 @@ class Engine:
         self._chk(self.L.itsx_debug_packed_read(self.h, i, w.ctypes.data, C.byref(nw), e.ctypes.data, C.byref(ne)))
         return w[:nw.value], e[:ne.value]
 
+    def debug_logf(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros_like(x)
+        self._chk(self.L.itsx_debug_logf(self.h, x.ctypes.data, len(x), out.ctypes.data))
+        return out
+
     def debug_detmath(self, x):
         x = np.ascontiguousarray(x, np.float64)
         a = np.zeros_like(x)

@@ -44,6 +44,14 @@ def test_detmath_device_matches_oracle_bitwise(engine):
     assert np.array_equal(de.view(np.uint64), oe.view(np.uint64))
     # and both agree with libm after rounding to float (what the pipeline stores)
     assert np.array_equal(np.float32(dl), np.float32(np.log(x)))
+    # the bias filter's table-driven logarithm == (float)det_log((double)x) on the device, bit for bit: 3 M floats over the whole range,
+    # crowded around 1 (where the result is tiny) and on the table's interval borders (checked for EVERY positive float on the
+    # host when it was written: 0 mismatches, 203 arguments fall back to det_log)
+    f = np.concatenate([np.float32(np.exp(rng.uniform(-87, 88, 1500000))), np.float32(rng.uniform(1e-4, 4.0, 1000000)),
+                        np.float32(1.0 + rng.uniform(-1e-3, 1e-3, 400000)),
+                        (np.uint32(0x3f3504f3) + np.arange(0, 100000, dtype=np.uint32) * np.uint32(167)).view(np.float32)])
+    dlf, _ = engine.debug_detmath(f.astype(np.float64))
+    assert np.array_equal(engine.debug_logf(f).view(np.uint32), np.float32(dlf).view(np.uint32))
 
 
 def test_profile_tables_match_oracle(engine, mini_hmm_text):

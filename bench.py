@@ -258,7 +258,7 @@ def main():
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
         if not use_dist:
             eng.finalize(domE=10.0)
-            return [np.stack(eng.trim_coords("3_", "4_"), axis=1)]
+            return [eng.trim_coords("3_", "4_")]          # (start, stop, tlen, index) per read, on the host
         # N > 1: the two exchanges run on the engine's own device buffers (RCCL over xGMI), nothing bounces through numpy
         allreduce_domz_device(eng, dev)                # hmmsearch's domZ is a count over the WHOLE data set
         eng.finalize(domE=10.0)
@@ -401,7 +401,8 @@ def main():
             ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl, "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic}
-        trimmed = int(((out[0][:, 0] >= 0) & (out[0][:, 1] >= 0) & (out[0][:, 0] < out[0][:, 1])).sum())
+        c_start, c_stop = (out[0][0], out[0][1]) if isinstance(out[0], tuple) else (out[0][:, 0], out[0][:, 1])
+        trimmed = int(((c_start >= 0) & (c_stop >= 0) & (c_start < c_stop)).sum())
         shape = ("merged reads of 300-580 bases (mean %.0f)" % mean_len) if cfg2 else "300 bp single-end reads"
         wl = ("configs[2]" if cfg2 else "configs[1]") + ": %d synthetic %s per GPU" % (n_local, shape)
         if strong:

@@ -60,7 +60,7 @@ class SampleBatch:
             eng = self.engine
             self.counts = np.asarray(eng.load_reads_files([s.seq_file for s in self.samples]), np.int64)
             self.first = np.concatenate([[0], np.cumsum(self.counts)[:-1]]).astype(np.int64)
-            n = eng.derep(strand_both=True, minseqlength=32)
+            n = eng.derep(strand_both=True, minseqlength=1)      # SeqSample.deduplicate's value (SeqSample.py:96 passes no --minseqlength; the mirror uses 1): a batch and a solo run must agree on short reads
             for i, s in enumerate(self.samples):
                 d = self._dir(i)
                 s.uc_file = os.path.join(d, "uc.txt")

@@ -952,18 +952,22 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   const int32_t scratch_pitch = Lmax + 1;
   if (multipass) while (Bmax > 16 && 2LL * Bmax * 32 * scratch_pitch * 16 > (4LL << 30)) Bmax /= 2;
   const int32_t kcap = std::max(8, ((Lmax - 7 + 7) / 8) * 8);
-  const int64_t cnt_budget = 8LL << 30;
 
   DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, acc_col, is_new, new_rank, scan_tmp, xlist, xn, hard, dbg;
   DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm, canon, ctab_val, need;
-  DBuf<unsigned long long> ctab_key, n_skipped, pre_stats, best0;
+  DBuf<int32_t> cw_n, wsum, wscan, qi_cnt, qi_cur, qi_off, ncand, ntop, ovf;
+  DBuf<int64_t> cw_off, cw_base;
+  DBuf<uint16_t> klist, cw_poolA, cw_poolB, qi_ent, tq, minm, cntx;
+  DBuf<uint32_t> hist2;
+  DBuf<unsigned long long> ctab_key, n_skipped, pre_stats, cand;
   DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct, selpid, wpid, xpid;
-  DBuf<uint16_t> klist, cnt; DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
-  DBuf<uint32_t> bitsA, bitsB;
-  DBuf<uint32_t> *bits = &bitsA, *bits_other = &bitsB;
+  DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
+  DBuf<uint16_t> *cw_pool = &cw_poolA, *cw_other = &cw_poolB;
   HIPCHK(upload(d_order, ord, ctx->st));
   const size_t ccap = (size_t)nk + 2048;
   HIPCHK(cent_len.alloc(ccap)); HIPCHK(cent_pos.alloc(ccap)); HIPCHK(cent_read.alloc(ccap));
+  HIPCHK(cw_n.alloc(ccap)); HIPCHK(cw_off.alloc(ccap + 1)); HIPCHK(cw_base.alloc(2));
+  HIPCHK(hipMemsetAsync(cw_off.p, 0, sizeof(int64_t), ctx->st));                       // the first column starts at 0
   HIPCHK(res_col.alloc((size_t)nk + 1)); HIPCHK(res_strand.alloc((size_t)nk + 1)); HIPCHK(res_id.alloc((size_t)nk + 1));
   const size_t nqs = 2 * (size_t)Bmax;
   HIPCHK(klist.alloc(nqs * kcap)); HIPCHK(knk.alloc(nqs)); HIPCHK(state.alloc(nqs)); HIPCHK(rejects.alloc(nqs));
@@ -972,87 +976,119 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(wn.alloc(nqs)); HIPCHK(wcol.alloc(nqs * 32)); HIPCHK(wkey.alloc(nqs * 32)); HIPCHK(wpid.alloc(nqs * 32));
   HIPCHK(xlist.alloc(nqs * 32)); HIPCHK(xn.alloc(nqs)); HIPCHK(hard.alloc(nqs)); HIPCHK(xkey.alloc(nqs * 32)); HIPCHK(xpid.alloc(nqs * 32));
   HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(newq.alloc((size_t)Bmax + 1)); HIPCHK(rm.alloc((size_t)Bmax + 1));
-  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(best0.alloc(nqs)); HIPCHK(pre_stats.alloc(4)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 4 * sizeof(unsigned long long), ctx->st));
+  HIPCHK(wsum.alloc((size_t)Bmax + 1)); HIPCHK(wscan.alloc((size_t)Bmax + 1));
+  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(pre_stats.alloc(4)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 4 * sizeof(unsigned long long), ctx->st));
   HIPCHK(hipMemsetAsync(n_skipped.p, 0, sizeof(unsigned long long), ctx->st)); HIPCHK(ctab_key.alloc(16384)); HIPCHK(ctab_val.alloc(16384));
   HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1));
   if (n > 0) launch_hash_reads(ctx->rd, 0, 0, ctx->w_hf.p, ctx->w_hr.p, ctx->st);      // identical reads of a window share one search
-  HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(Bmax + 1))); HIPCHK(n_align.alloc(1));
+  HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(65537 + Bmax + 1))); HIPCHK(n_align.alloc(1));
   HIPCHK(scratch.alloc(multipass ? nqs * 32 * (size_t)scratch_pitch * 2 : 2));
   HIPCHK(hipMemsetAsync(n_align.p, 0, sizeof(unsigned long long), ctx->st));
-  int64_t capC = 2048, cap0 = 262144;                     // columns of the index: grows by doubling (relayout) when needed
-  if (const char *e = getenv("ITSX_CL_CAPACITY")) cap0 = std::max(2048, atoi(e));
-  while (capC < std::min<int64_t>(nk, cap0)) capC *= 2;
-  HIPCHK(bits->alloc((size_t)65536 * (size_t)(capC / 32)));
-  HIPCHK(hipMemsetAsync(bits->p, 0, (size_t)65536 * (size_t)(capC / 32) * 4, ctx->st));
+  // the window's query index, the strands' thresholds and candidate lists, the counts against the window's own centroids
+  HIPCHK(qi_cnt.alloc(65537)); HIPCHK(qi_cur.alloc(65536)); HIPCHK(qi_off.alloc(65537));
+  HIPCHK(qi_ent.alloc(nqs * (size_t)kcap + 65536 * 8 + 64));
+  HIPCHK(tq.alloc(nqs)); HIPCHK(minm.alloc(nqs)); HIPCHK(ncand.alloc(nqs)); HIPCHK(ntop.alloc(nqs)); HIPCHK(ovf.alloc(1));
+  HIPCHK(hist2.alloc(nqs * (size_t)CL_HB));
+  int32_t cand_cap = 4096;                                  // per strand; grows (and the window is searched again) when a list overflows
+  if (const char *e = getenv("ITSX_CL_CCAP")) cand_cap = std::max(32, atoi(e));
+  HIPCHK(cand.alloc(nqs * (size_t)cand_cap));
+  HIPCHK(cntx.alloc(nqs * (size_t)Bmax));
+  int64_t pool_cap = 1LL << 26;                             // words of all centroids; doubles (with a copy) when a window could overrun it
+  if (const char *e = getenv("ITSX_CL_CAPACITY")) pool_cap = std::max<int64_t>(2048, atoll(e));
+  pool_cap = std::max<int64_t>(pool_cap, (int64_t)Bmax * kcap);
+  HIPCHK(cw_pool->alloc((size_t)pool_cap, true));
+  int64_t pool_used = 0;
 
   ClusterArgs a{};
   a.rd = ctx->rd; a.order = d_order.p; a.strand_both = strand_both ? 1 : 0;
   a.cent_len = cent_len.p; a.cent_pos = cent_pos.p; a.cent_read = cent_read.p;
   a.klist = klist.p; a.kcap = kcap; a.nk = knk.p;
+  a.cw_off = cw_off.p; a.cw_n = cw_n.p; a.cw_base = cw_base.p; a.wsum = wsum.p; a.wscan = wscan.p;
+  a.qi_cnt = qi_cnt.p; a.qi_cur = qi_cur.p; a.qi_off = qi_off.p; a.qi_ent = qi_ent.p;
+  a.tq = tq.p; a.minm = minm.p; a.hist2 = hist2.p; a.ncand = ncand.p; a.ntop = ntop.p; a.ovf = ovf.p; a.cntx = cntx.p;
   a.state = state.p; a.rejects = rejects.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.acc_id = acc_id.p;
   a.sel = sel.p; a.selm = selm.p; a.sel_short = sel_short.p; a.selkey = selkey.p; a.selpid = selpid.p;
   a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
   a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
   a.is_new = is_new.p; a.new_rank = new_rank.p; a.newq = newq.p; a.rm = rm.p;
-  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p; a.best0 = best0.p;
+  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p;
   a.pre_k = std::min(16, (int)((double)Lmax * (1.0 - id) / id) + 1); a.ctab_key = ctab_key.p; a.ctab_val = ctab_val.p; a.rhash = ctx->w_hf.p;
   a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
   a.thr = 100.0 * id; a.n_align = n_align.p;
 
   int32_t f = 0, C = 0, ncent = 0;
   int B = std::min(Bmax, 256);
-  int64_t windows = 0, cuts = 0;
+  int64_t windows = 0, cuts = 0, regrown = 0, stream_launches = 0;
   const bool debug = getenv("ITSX_CL_DEBUG") != nullptr;
   while (f < nk) {
-    int nq = std::min<int32_t>(B, nk - f);
-    auto pitch_for = [&](int q) { return ((((int64_t)C + q - 1) >> 11) + 1) * 2048; };
-    while (nq > 1 && 4LL * nq * pitch_for(nq) > cnt_budget) nq /= 2;
-    const int64_t cpitch = pitch_for(nq);
-    if ((int64_t)C + nq > capC) {                           // grow the column capacity of the index
-      int64_t ncap = capC;
-      while (ncap < (int64_t)C + nq) ncap *= 2;
-      HIPCHK(bits_other->alloc((size_t)65536 * (size_t)(ncap / 32)));
-      HIPCHK(hipMemsetAsync(bits_other->p, 0, (size_t)65536 * (size_t)(ncap / 32) * 4, ctx->st));
-      launch_cl_relayout(bits->p, capC / 32, bits_other->p, ncap / 32, ctx->st);
+    const int nq = std::min<int32_t>(B, nk - f);
+    if (pool_used + (int64_t)nq * kcap > pool_cap) {          // the window's would-be centroids could overrun the word pool: grow it
+      int64_t ncap = pool_cap;
+      while (pool_used + (int64_t)nq * kcap > ncap) ncap *= 2;
+      HIPCHK(cw_other->alloc((size_t)ncap, true));
+      HIPCHK(hipMemcpyAsync(cw_other->p, cw_pool->p, (size_t)pool_used * sizeof(uint16_t), hipMemcpyDeviceToDevice, ctx->st));
       HIPCHK(hipStreamSynchronize(ctx->st));
-      std::swap(bits, bits_other); bits_other->release();
-      capC = ncap;
+      std::swap(cw_pool, cw_other); cw_other->release();
+      pool_cap = ncap;
     }
-    HIPCHK(cnt.alloc((size_t)(2 * (int64_t)nq * cpitch)));
-    a.f = f; a.nq = nq; a.C = C; a.bits = bits->p; a.stride = capC / 32; a.cnt = cnt.p; a.cpitch = cpitch;
+    a.f = f; a.nq = nq; a.C = C; a.cw_pool = cw_pool->p; a.cand = cand.p; a.ccap = cand_cap; a.xpitch = nq;
     launch_cl_kmers(a, ctx->st);
-    HIPCHK(hipMemsetAsync(best0.p, 0, 2 * (size_t)nq * sizeof(unsigned long long), ctx->st));
-    a.use_best0 = (C >= 131072 || getenv("ITSX_CL_BEST0")) ? 1 : 0;                              // the fused best key pays once a count row is long (measured: -4 % at 271 k centroids, +10 % at 60 k)
-    launch_cl_count(a, 0, (C + 2047) >> 11, a.use_best0, ctx->st);
+    // every centroid streams past the window's query index; a strand keeps the candidates that can still be among its 32 best
+    launch_cl_qindex(a, scan_tmp.p, ctx->st);
+    for (int c0 = 0, step = 2048; c0 < C; step = std::min(step * 2, 1 << 20)) {
+      const int c1 = std::min(C, c0 + step);
+      launch_cl_stream(a, c0, c1, 1, ctx->st);
+      stream_launches++;
+      if (c1 < C) launch_cl_thresh(a, ctx->st);
+      c0 = c1;
+    }
+    launch_cl_topk(a, ctx->st);
     launch_cl_init(a, ctx->st);
     if (C > 0) launch_cl_walk(a, rows_per_lane, ctx->st);
     launch_cl_outcome(a, ctx->st);
     launch_exclusive_scan(is_new.p, new_rank.p, nq + 1, scan_tmp.p, ctx->st);
+    launch_cl_wsum(a, ctx->st);
+    launch_exclusive_scan(wsum.p, wscan.p, nq + 1, scan_tmp.p, ctx->st);
     launch_cl_columns(a, 0, ctx->st);
-    const int tile0 = C >> 11;
-    launch_cl_count(a, tile0, (int)((((int64_t)C + nq - 1) >> 11) - tile0 + 1), 0, ctx->st);
+    HIPCHK(hipMemsetAsync(cntx.p, 0, (size_t)2 * nq * nq * sizeof(uint16_t), ctx->st));
+    launch_cl_stream(a, C, C + nq, 2, ctx->st);               // the window's speculative centroids against the window's strands
     launch_cl_validate(a, rows_per_lane, ctx->st);
-    launch_cl_columns(a, 1, ctx->st);                       // roll back the speculative centroids that did not survive
-    int32_t wo[3] = {0, 0, 0};
+    launch_cl_columns(a, 1, ctx->st);                         // roll back the speculative centroids that did not survive
+    int32_t wo[3] = {0, 0, 0}, overflow = 0;
+    int64_t cwb[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(wo, wout.p, sizeof(wo), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(cwb, cw_base.p, sizeof(cwb), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(&overflow, ovf.p, sizeof(overflow), hipMemcpyDeviceToHost, ctx->st));
     HIPCHK(hipStreamSynchronize(ctx->st));
     HIPCHK(hipGetLastError());                              // a kernel that failed to launch must not pass silently
+    if (overflow) {
+      // a strand met more candidates at (or above) its threshold than its list holds -- long runs of equal counts: nothing of
+      // this window is kept, the lists grow and the window is searched again (the centroid set has not changed yet)
+      if ((int64_t)cand_cap >= (int64_t)C) SET_ERR(ctx, ITSX_E_DEVICE, "clustering candidate lists overflow although they hold every centroid");
+      cand_cap *= 4;
+      HIPCHK(cand.alloc(nqs * (size_t)cand_cap));
+      regrown++;
+      continue;
+    }
     const int32_t cut = wo[0];
     if (debug) {
       int32_t d[4] = {0, 0, 0, 0};
       (void)hipMemcpy(d, dbg.p, sizeof(d), hipMemcpyDeviceToHost);
-      std::vector<int32_t> hs(2 * (size_t)nq), hw(2 * (size_t)nq);
+      std::vector<int32_t> hs(2 * (size_t)nq), hw(2 * (size_t)nq), hc(2 * (size_t)nq);
       (void)hipMemcpy(hs.data(), state.p, hs.size() * 4, hipMemcpyDeviceToHost);
       (void)hipMemcpy(hw.data(), wn.p, hw.size() * 4, hipMemcpyDeviceToHost);
-      long sc[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0}, acc1 = 0;
-      for (size_t q = 0; q < hs.size(); q++) { sc[hs[q] & 3]++; sw[hs[q] & 3] += hw[q]; acc1 += hs[q] == 1 && hw[q] == 1; }
-      fprintf(stderr, "[cluster] f=%d nq=%d C=%d cut=%d cols=%d new=%d | hard=%d budget=%d joined_new=%d xaligns=%d | accept %ld (first try %ld, walk %ld) rej32 %ld exhausted %ld (walk %ld)\n",
-              f, nq, C, cut, wo[1], wo[2], d[0], d[1], d[2], d[3], sc[1], acc1, sw[1], sc[2], sc[3], sw[3]);
+      (void)hipMemcpy(hc.data(), ncand.p, hc.size() * 4, hipMemcpyDeviceToHost);
+      long sc[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0}, acc1 = 0, ncs = 0, ncm = 0;
+      for (size_t q = 0; q < hs.size(); q++) { sc[hs[q] & 3]++; sw[hs[q] & 3] += hw[q]; acc1 += hs[q] == 1 && hw[q] == 1; ncs += hc[q]; ncm = std::max<long>(ncm, hc[q]); }
+      fprintf(stderr, "[cluster] f=%d nq=%d C=%d cut=%d cols=%d new=%d | hard=%d budget=%d joined_new=%d xaligns=%d | accept %ld (first try %ld, walk %ld) rej32 %ld exhausted %ld (walk %ld) | appended %ld (max %ld per strand)\n",
+              f, nq, C, cut, wo[1], wo[2], d[0], d[1], d[2], d[3], sc[1], acc1, sw[1], sc[2], sc[3], sw[3], ncs, ncm);
     }
     if (cut < 1 || cut > nq) SET_ERR(ctx, ITSX_E_DEVICE, "clustering window validation returned an impossible cut");
     C += wo[1]; ncent += wo[2]; f += cut; windows++; cuts += cut < nq;
+    pool_used = cwb[1];
     B = cut == nq ? std::min(Bmax, std::max(B, nq) * 2) : std::min(Bmax, std::max(64, 2 * cut));
   }
+  if (debug) fprintf(stderr, "[cluster] %lld windows, %lld stream launches, %lld regrown candidate lists, word pool %.1f MB\n", (long long)windows, (long long)stream_launches, (long long)regrown, pool_used * 2.0 / 1e6);
 
   HIPCHK(ctx->d_rep_of.alloc((size_t)n + 1)); HIPCHK(ctx->d_strand.alloc((size_t)n + 1)); HIPCHK(ctx->d_uniq_of.alloc((size_t)n + 1));
   HIPCHK(ctx->w_is_seed.alloc((size_t)n + 1)); HIPCHK(ctx->w_seed_rank.alloc((size_t)n + 1)); HIPCHK(ctx->w_scan_tmp.alloc((size_t)scan_tmp_elems(n + 1)));

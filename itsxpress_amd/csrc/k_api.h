@@ -42,16 +42,24 @@ struct ClusterArgs {
   const int32_t *order;         // [nk] read index by processing position (label order)
   int32_t f, nq;                // window = positions [f, f+nq)
   int32_t strand_both;
-  uint32_t *bits;               // centroid index: [65536 words][stride] column bit matrix
-  int64_t stride;               // 32-bit words per row, a multiple of 64
   int32_t *cent_len, *cent_pos, *cent_read;   // per centroid column
   int32_t C;                    // centroids at the window start
   uint16_t *klist; int32_t kcap; int32_t *nk;  // distinct words of each (query, strand): [2 nq][kcap], [2 nq]
-  uint16_t *cnt; int64_t cpitch;               // shared-word counts [2 nq][cpitch]
+  // the centroids' distinct forward words, column after column (append-only; a rolled-back column has cw_n = 0)
+  uint16_t *cw_pool; int64_t *cw_off; int32_t *cw_n; int64_t *cw_base;   // cw_base[0] = cw_off[C] of this window; cw_base[1] = end after validation
+  int32_t *wsum, *wscan;        // [nq+1] words of each would-be centroid, and their exclusive scan
+  // the window's query index: word -> the (query strand) byte offsets 4 * qs that hold it, each list padded to 8 entries with the
+  // dummy offset 4 * QS_MAX
+  int32_t *qi_cnt, *qi_cur, *qi_off; uint16_t *qi_ent;   // [65537], [65536], [65537], [qi_off[65536]]
+  uint16_t *tq, *minm;          // [2 nq] appending threshold of the streaming pass (a lower bound of the 32nd best count) / min(12, words)
+  uint32_t *hist2;              // [2 nq][CL_HB] counts of the candidates appended so far (clipped at CL_HB - 1)
+  unsigned long long *cand; int32_t *ncand; int32_t ccap; int32_t *ovf;   // appended candidate keys [2 nq][ccap]; ovf[0] = a list overflowed
+  int32_t *ntop;                // [2 nq] candidates in sel/selkey (<= 32, rank order): the whole walk's candidate list
+  uint16_t *cntx; int32_t xpitch;   // shared-word counts against the window's speculative centroids [2 nq][xpitch]
   int32_t *state, *rejects, *acc_col;          // walk state per (query, strand): 0 active 1 accepted 2 32 rejects 3 exhausted
   unsigned long long *prev, *bound;            // rank key of the last candidate tried / of the point where the walk stopped
   double *acc_id;
-  int32_t *sel, *selm, *sel_short; unsigned long long *selkey; double *selpid;   // candidates of the current round [2 nq][32]
+  int32_t *sel, *selm, *sel_short; unsigned long long *selkey; double *selpid;   // the candidate list [2 nq][32]; selm = taken this round
   int32_t *wn, *wcol; unsigned long long *wkey; double *wpid;                    // the recorded walk [2 nq][32]
   int32_t *res_col; int8_t *res_strand; double *res_id;   // outcome by processing position
   int32_t *is_new, *new_rank;   // [nq+1]
@@ -60,8 +68,6 @@ struct ClusterArgs {
   int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[2]
   const uint64_t *rhash;        // [n reads] XXH64 of the packed forward strand
   unsigned long long *ctab_key; int32_t *ctab_val; int32_t *canon;   // window-local table of identical reads; canon[nq]
-  unsigned long long *best0;    // [2 nq] best candidate key left by the counting pass (round 0 of the walk)
-  int32_t use_best0;            // large centroid sets: round 0 takes best0 instead of scanning the count row
   int32_t *replay;              // [nq] queries whose walk must be replayed by k_cl_resolve
   int32_t *skipm;               // [nq] minus-strand walk cut short because the plus strand holds a 100 % hit
   int32_t *wout;                // [3] cut, columns consumed, true new centroids
@@ -74,16 +80,21 @@ struct ClusterArgs {
   unsigned long long *pre_stats;                 // [4] certificate outcomes: not applicable, bound too weak, a path exists, proven reject
   int32_t pre_k;                                 // largest edit budget K of this run (sizes the certificate's LDS rows)
 };
+constexpr int CL_HB = 1024;      // bins of hist2
+constexpr int CL_QS_MAX = 8192;  // query strands of one window (2 x the largest window)
 void launch_cl_kmers(const ClusterArgs &a, hipStream_t st);
-void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, int with_best, hipStream_t st);
+void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st);
+void launch_cl_stream(const ClusterArgs &a, int c0, int c1, int mode, hipStream_t st);      // mode 1: the old centroids [c0, c1); mode 2: the window's speculative ones
+void launch_cl_thresh(const ClusterArgs &a, hipStream_t st);
+void launch_cl_topk(const ClusterArgs &a, hipStream_t st);
 void launch_cl_init(const ClusterArgs &a, hipStream_t st);
 void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st);
 void launch_cl_outcome(const ClusterArgs &a, hipStream_t st);
+void launch_cl_wsum(const ClusterArgs &a, hipStream_t st);
 void launch_cl_columns(const ClusterArgs &a, int clear, hipStream_t st);
 void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st);
 void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
                         const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st);
-void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride, hipStream_t st);
 
 // ---- f4: read orientation (k_cluster.hip)
 void launch_orient(const ReadsDev &rd, const uint32_t *dbbits /*4^12 bits*/, int8_t *strand, int32_t *cfwd, int32_t *crev, hipStream_t st);

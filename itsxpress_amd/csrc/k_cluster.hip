@@ -18,12 +18,23 @@
 //    window against the enlarged centroid set.  The first query of a window is never affected, so the loop
 //    always advances; on amplicon data cuts are rare once a few hundred centroids exist.
 //
-// Data layout: the centroid index is a COLUMN BIT MATRIX bits[65536 words][stride]: row = 8-mer, bit c = centroid
-// c holds that word.  Counting the shared words of one query against 2048 centroids is then 64 lanes x one
-// 32-bit column word per query word, accumulated with carry-save adders on bit-sliced counters (Harley-Seal):
-// about 6 integer ops per query word per 32 centroids, coalesced 256-B row segments, no atomics.  Amplicons
-// share their conserved flanks, so nearly every centroid shares words with every query: the dense form is the
-// right one (an inverted index would touch the same cells one atomic at a time).
+// Shared-word counts (round 3: "query-stationary streaming"; rounds 1-2 kept a [65536 words][centroids] column bit matrix and
+// a [query strands][centroids] count matrix: both passes over it were O(queries x centroids) at 44 bytes and 66 lane operations
+// per (query strand, centroid), 2.4 s of a 6.1-s run at 1 M reads and quadratic from there).  Now NOTHING of size
+// queries x centroids is ever stored or swept.  Per window:
+//  * the window's query strands are indexed by word: word -> list of the strands that hold it (k_cl_qi_*: 65536 counters, one
+//    scan, one scatter; ~3 M entries for 4096 reads, L2-resident);
+//  * the centroids stream past: one workgroup takes one centroid at a time, walks the lists of the centroid's own distinct
+//    words (kept per centroid, append-only) and adds into a histogram over the window's query strands in LDS (32 KB): the
+//    work per (query strand, centroid) is the number of words they actually SHARE (2-3 on amplicons: the chance shares of
+//    random spacer words plus the conserved motifs) instead of the query's ~380 words x 6 bit-sliced operations;
+//  * a strand's count is looked at only where it can still matter: every strand carries a threshold tq (a lower bound of
+//    its 32nd best count so far, from a histogram of the candidates appended so far, refreshed between chunks of
+//    centroids); counts >= tq are appended to the strand's candidate list with their rank key, everything else is dropped;
+//  * k_cl_topk sorts out the 32 best keys of each list: the walk's whole candidate list (maxaccepts 1 + maxrejects 32 never
+//    tries more), in exactly the order the count matrix gave.
+// The speculative centroids of the window are streamed the same way against the window's strands (mode 2) into a small
+// [strands][window] count array for the validation step.  The result is the same candidate order as before, bit for bit.
 // The alignment is one wave per (query, candidate): lane l owns S consecutive DP rows, columns advance as an
 // anti-diagonal wavefront, the row above arrives by a one-lane shift; every cell carries (score, matches,
 // counted columns) packed into one int64 so that integer max is the lexicographic max and no traceback exists.
@@ -154,95 +165,183 @@ __global__ __launch_bounds__(256) void k_cl_kmers(ClusterArgs a)
   if (tid == 255) a.nk[qs] = part[255];
 }
 
-// ------------------------------------------------------------------ shared-word counts: bit-sliced carry-save counting
-#define CSA(h, l, x, y, z) { const uint32_t u_ = (x) ^ (y); h = ((x) & (y)) | (u_ & (z)); l = u_ ^ (z); }
-static constexpr int HCL = 13;          // counts/8 < 8192
-
-// with_best: the launch over the old centroids also leaves each query strand's BEST candidate key in best0[] (round 0 of the
-// walk then needs no pass over the count row); keys are ordered by the count first, so length and position are fetched
-// only for columns that reach the lane's running maximum
-__global__ __launch_bounds__(256) void k_cl_count(ClusterArgs a, int tile0, int ntiles, int with_best)
+// ------------------------------------------------------------------ the window's query index: word -> query strands
+__global__ __launch_bounds__(256) void k_cl_qi_count(ClusterArgs a, int fill)
 {
-  // query strands vary fastest over the grid: the blocks in flight share one group of 4 tiles, whose touched rows
-  // (1 KB each) then stay in L2 / MALL while every query of the window streams over them
   const int qs = blockIdx.x;
-  if (a.canon[qs >> 1] != (qs >> 1)) return;
-  const int lane = threadIdx.x & 63;
-  const int tile = tile0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (tile >= tile0 + ntiles) return;
+  if (a.canon[qs >> 1] != (qs >> 1)) return;                // copies read their canonical query's state
   const int n = a.nk[qs];
   const uint16_t *kl = a.klist + (size_t)qs * a.kcap;
-  const uint32_t *col = a.bits + (size_t)tile * 64 + lane;
-  const size_t stride = (size_t)a.stride;
-  uint32_t ones = 0, twos = 0, fours = 0;
-  uint32_t hc[HCL];
-#pragma unroll
-  for (int b = 0; b < HCL; b++) hc[b] = 0;
-  int nlev = 1;
-  while ((n >> 3) >> nlev) nlev++;
-  int i = 0;
-  for (; i + 8 <= n; i += 8) {
-    uint32_t x[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) x[t] = col[(size_t)kl[i + t] * stride];
-    uint32_t ta, tb, fa, fb, eights;
-    CSA(ta, ones, ones, x[0], x[1])
-    CSA(tb, ones, ones, x[2], x[3])
-    CSA(fa, twos, twos, ta, tb)
-    CSA(ta, ones, ones, x[4], x[5])
-    CSA(tb, ones, ones, x[6], x[7])
-    CSA(fb, twos, twos, ta, tb)
-    CSA(eights, fours, fours, fa, fb)
-    uint32_t carry = eights;
-#pragma unroll
-    for (int b = 0; b < HCL; b++) if (b < nlev) { const uint32_t t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const uint32_t w = kl[i];
+    if (!fill) atomicAdd(&a.qi_cnt[w], 1);
+    else a.qi_ent[a.qi_off[w] + atomicAdd(&a.qi_cur[w], 1)] = (uint16_t)(qs * 4);       // the strand's byte offset in the LDS histogram
   }
-  for (; i < n; i++) {
-    uint32_t carry = col[(size_t)kl[i] * stride], t_;
-    t_ = ones & carry; ones ^= carry; carry = t_;
-    t_ = twos & carry; twos ^= carry; carry = t_;
-    t_ = fours & carry; fours ^= carry; carry = t_;
+}
+__global__ void k_cl_qi_pad(ClusterArgs a)
+{
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < 65536) { a.qi_cnt[w] = (a.qi_cnt[w] + 7) & ~7; a.qi_cur[w] = 0; }             // lists are read 8 entries (16 bytes) at a time
+  if (w == 65536) a.qi_cnt[w] = 0;
+}
+__global__ void k_cl_qi_fill_dummy(ClusterArgs a)
+{
+  const int n = a.qi_off[65536];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a.qi_ent[i] = (uint16_t)(CL_QS_MAX * 4);
+}
+// per strand: min(12, words) and the starting threshold; the candidate lists start empty
+__global__ void k_cl_tq_init(ClusterArgs a)
+{
+  const int qs = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qs == 0) a.ovf[0] = 0;
+  if (qs >= 2 * a.nq) return;
+  const bool own = a.canon[qs >> 1] == (qs >> 1);
+  const int n = own ? a.nk[qs] : 0;
+  const uint16_t m = n > 0 ? (uint16_t)(n < 12 ? n : 12) : (uint16_t)0xFFFF;
+  a.minm[qs] = m; a.tq[qs] = m; a.ncand[qs] = 0; a.ntop[qs] = 0;
+}
+
+// ------------------------------------------------------------------ the centroids stream past the window
+// One workgroup, one centroid at a time.  items[] = pieces (<= 8 x 8 entries) of the word lists the centroid touches, so that
+// a conserved word held by thousands of strands is spread over the threads instead of serialising one of them.
+static constexpr int CL_ITEMS = 6144;
+__device__ __forceinline__ void cl_add8(uint32_t *hist, const uint4 v)
+{
+  char *h = reinterpret_cast<char *>(hist);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.x & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.x >> 16)), 1u);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.y & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.y >> 16)), 1u);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.z & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.z >> 16)), 1u);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.w & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.w >> 16)), 1u);
+}
+__global__ __launch_bounds__(256) void k_cl_stream(ClusterArgs a, int c0, int c1, int mode)
+{
+  __shared__ uint32_t hist[CL_QS_MAX + 8];
+  __shared__ uint32_t items[CL_ITEMS];
+  __shared__ int n_items;
+  const int tid = threadIdx.x;
+  const int nqs = 2 * a.nq;
+  const int nrounds = (nqs + 1023) >> 10;                    // a thread scans strands (j * 256 + tid) * 4 .. + 3, j < nrounds
+  const uint16_t *thr = mode == 2 ? a.minm : a.tq;
+  uint32_t T[32];
 #pragma unroll
-    for (int b = 0; b < HCL; b++) if (b < nlev) { t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
-  }
-  uint16_t *out = a.cnt + (size_t)qs * a.cpitch + (size_t)tile * 2048 + lane * 32;
+  for (int j = 0; j < 8; j++)
 #pragma unroll
-  for (int g = 0; g < 4; g++) {
-    uint32_t pk[4];
-#pragma unroll
-    for (int h = 0; h < 4; h++) {
-      uint32_t v2[2];
-#pragma unroll
-      for (int e = 0; e < 2; e++) {
-        const int bit = g * 8 + h * 2 + e;
-        uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
-#pragma unroll
-        for (int b = 0; b < HCL; b++) if (b < nlev) v |= ((hc[b] >> bit) & 1u) << (3 + b);
-        v2[e] = v;
+    for (int e = 0; e < 4; e++) { const int qs = (j * 256 + tid) * 4 + e; T[j * 4 + e] = (j < nrounds && qs < nqs) ? (uint32_t)thr[qs] : 0xffffffffu; }
+  for (int i = tid; i < CL_QS_MAX + 8; i += 256) hist[i] = 0u;
+  if (mode == 2) { const int lim = a.C + a.new_rank[a.nq]; c1 = c1 < lim ? c1 : lim; }
+  const uint4 *ent = reinterpret_cast<const uint4 *>(a.qi_ent);
+  __syncthreads();
+  for (int c = c0 + blockIdx.x; c < c1; c += gridDim.x) {
+    const int n = a.cw_n[c];
+    if (n == 0) continue;                                     // a rolled-back column
+    const uint16_t *cw = a.cw_pool + a.cw_off[c];
+    if (tid == 0) n_items = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const uint32_t w = cw[i];
+      int s = a.qi_off[w] >> 3, nch = (a.qi_off[w + 1] >> 3) - s;
+      while (nch > 0) {
+        const int take = nch < 8 ? nch : 8;
+        const int slot = atomicAdd(&n_items, 1);
+        if (slot < CL_ITEMS) items[slot] = ((uint32_t)s << 3) | (uint32_t)(take - 1);
+        else for (int k = 0; k < take; k++) cl_add8(hist, ent[s + k]);                  // list full (very long reads): the piece is added here
+        s += take; nch -= take;
       }
-      pk[h] = v2[0] | (v2[1] << 16);
     }
-    *reinterpret_cast<uint4 *>(out + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-  }
-  if (with_best) {
-    const uint32_t minm = n < 12 ? n : 12;
-    u64 best = 0;
-    uint32_t bestv = minm > 0 ? minm : 1;
-    const int c0 = tile * 2048 + lane * 32;
+    __syncthreads();
+    const int ni = n_items < CL_ITEMS ? n_items : CL_ITEMS;
+    for (int it = tid; it < ni; it += 256) {
+      const uint32_t x = items[it];
+      const int s = (int)(x >> 3), take = (int)(x & 7u) + 1;
+      for (int k = 0; k < take; k++) cl_add8(hist, ent[s + k]);
+    }
+    __syncthreads();
+    const int32_t clen = a.cent_len[c], cpos = a.cent_pos[c];
 #pragma unroll
-    for (int bit = 0; bit < 32; bit++) {
-      uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
+    for (int j = 0; j < 8; j++) {
+      if (j < nrounds) {
+        const int base = (j * 256 + tid) * 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(&hist[base]);
+        *reinterpret_cast<uint4 *>(&hist[base]) = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int b = 0; b < HCL; b++) if (b < nlev) v |= ((hc[b] >> bit) & 1u) << (3 + b);
-      const int c = c0 + bit;
-      if (v >= bestv && c < a.C) {
-        const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
-        if (key > best) { best = key; bestv = v; }
+        for (int e = 0; e < 4; e++) {
+          if (vv[e] >= T[j * 4 + e]) {
+            const int qs = base + e;
+            if (mode == 2) a.cntx[(size_t)qs * a.xpitch + (c - a.C)] = (uint16_t)vv[e];
+            else {
+              const int slot = atomicAdd(&a.ncand[qs], 1);
+              if (slot < a.ccap) a.cand[(size_t)qs * a.ccap + slot] = cand_key(vv[e], clen, cpos);
+              atomicAdd(&a.hist2[(size_t)qs * CL_HB + (vv[e] < (uint32_t)(CL_HB - 1) ? vv[e] : (uint32_t)(CL_HB - 1))], 1u);
+            }
+          }
+        }
       }
     }
-    for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(best, off); best = o > best ? o : best; }
-    if (lane == 0 && best) atomicMax(&a.best0[qs], best);
+    __syncthreads();
   }
+}
+
+// between two chunks of centroids: tq = the largest t with at least 32 appended candidates of count >= t (every candidate
+// of count >= the current tq has been appended and counted, so the sum is exact there); tq never goes down
+__global__ __launch_bounds__(256) void k_cl_thresh(ClusterArgs a)
+{
+  const int qs = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (qs >= 2 * a.nq) return;
+  if (a.ncand[qs] < 32) return;
+  const uint32_t *h = a.hist2 + (size_t)qs * CL_HB;
+  constexpr int PER = CL_HB / 64;
+  const int top = CL_HB - 1 - lane * PER;                   // lane 0 holds the highest bins
+  uint32_t b[PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { b[k] = h[top - k]; s += b[k]; }
+  uint32_t incl = s;
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+  const unsigned long long reach = __ballot(incl >= 32u);
+  if (reach == 0ULL) return;
+  const int first = __ffsll((long long)reach) - 1;
+  if (lane != first) return;
+  uint32_t run = incl - s;
+  int t = top;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { run += b[k]; if (run >= 32u) { t = top - k; break; } }
+  if ((uint32_t)t > (uint32_t)a.tq[qs]) a.tq[qs] = (uint16_t)t;
+}
+
+// the 32 best keys of each strand's list, in rank order: the candidate list of the whole walk
+__global__ __launch_bounds__(256) void k_cl_topk(ClusterArgs a)
+{
+  __shared__ unsigned long long red[4];
+  __shared__ unsigned long long bestk;
+  const int qs = blockIdx.x, tid = threadIdx.x;
+  int n = a.ncand[qs];
+  if (n > a.ccap) { if (tid == 0) a.ovf[0] = 1; n = a.ccap; }
+  const unsigned long long *keys = a.cand + (size_t)qs * a.ccap;
+  unsigned long long lim = ~0ULL;
+  int m = 0;
+  for (; m < 32 && m < n; m++) {
+    unsigned long long best = 0;
+    for (int i = tid; i < n; i += 256) { const unsigned long long k = keys[i]; if (k < lim && k > best) best = k; }
+    for (int off = 32; off; off >>= 1) { const unsigned long long o = __shfl_xor(best, off); best = o > best ? o : best; }
+    if ((tid & 63) == 0) red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long b = red[0];
+      for (int i = 1; i < 4; i++) b = red[i] > b ? red[i] : b;
+      bestk = b;
+      if (b) {
+        const int32_t pos = (int32_t)(0xffffffffu - (uint32_t)(b & 0xffffffffu));
+        int lo = 0, hi = a.C - 1;                             // cent_pos grows with the column index
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cent_pos[mid] < pos) lo = mid + 1; else hi = mid; }
+        a.sel[qs * 32 + m] = lo; a.selkey[qs * 32 + m] = b;
+      }
+    }
+    __syncthreads();
+    lim = bestk;
+    if (lim == 0ULL) break;
+    __syncthreads();
+  }
+  if (tid == 0) a.ntop[qs] = m;
 }
 
 // ------------------------------------------------------------------ the candidate walk
@@ -257,98 +356,25 @@ __global__ void k_cl_init(ClusterArgs a)
   a.prev[qs] = ~0ULL; a.bound[qs] = 0ULL; a.acc_id[qs] = -1.0; a.xn[qs] = 0; a.hard[qs] = 0;
 }
 
-// round 0 of the walk: the best key left by the counting pass is the only selected candidate
-__global__ void k_cl_pick0(ClusterArgs a)
+// The walk takes its candidates from the strand's list (k_cl_topk) in rank order: round 0 the best one (most reads accept
+// it), round 1 the whole remaining reject budget at once.  The (query strand, slot) items go to the alignment kernels' work list.
+__global__ void k_cl_take(ClusterArgs a, int round)
 {
   const int qs = blockIdx.x * blockDim.x + threadIdx.x;
   if (qs >= 2 * a.nq || a.state[qs] != 0) return;
-  const u64 key = a.best0[qs];
-  if (key == 0) { a.selm[qs] = 0; a.sel_short[qs] = 1; return; }
-  const int32_t pos = (int32_t)(0xffffffffu - (uint32_t)(key & 0xffffffffu));
-  int lo = 0, hi = a.C - 1;                                 // cent_pos grows with the column index
-  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cent_pos[mid] < pos) lo = mid + 1; else hi = mid; }
-  a.sel[qs * 32] = lo; a.selkey[qs * 32] = key; a.selm[qs] = 1; a.sel_short[qs] = 0;
-  a.work[atomicAdd(&a.work_n[0], 1)] = qs * 32;
-}
-
-// the next (up to kmax, within the reject budget) candidates strictly below the last one tried, in rank order.
-// Every thread keeps the best key of its own strided subset of the count row; the block maximum is consumed and only
-// its owner rescans (its subset, below the consumed key): one pass over the row plus need short rescans instead of
-// need passes.  The (query strand, slot) items are appended to a work list for the alignment kernel.
-__global__ __launch_bounds__(256) void k_cl_select(ClusterArgs a, int kmax)
-{
-  __shared__ u64 red[4];
-  __shared__ u64 bestk;
-  __shared__ int owner, ownc;
-  const int qs = blockIdx.x, tid = threadIdx.x;
-  if (a.state[qs] != 0) return;
-  if ((qs & 1) && kmax > 1 && a.state[qs - 1] == 1 && a.acc_id[qs - 1] == 100.0) {
+  if (round == 1 && (qs & 1) && a.state[qs - 1] == 1 && a.acc_id[qs - 1] == 100.0) {
     // a minus-strand hit wins only with a HIGHER identity than the plus-strand hit: nothing beats 100 %, so the
     // remaining 31 candidates of this strand cannot change the outcome (k_cl_resolve cuts the window if the plus hit is lost)
-    if (tid == 0) { a.state[qs] = 3; a.skipm[qs >> 1] = 1; }
+    a.state[qs] = 3; a.skipm[qs >> 1] = 1;
     return;
   }
-  const int n = a.nk[qs];
-  const uint32_t minm = n < 12 ? n : 12;
-  const uint16_t *cn = a.cnt + (size_t)qs * a.cpitch;
-  int need = 32 - a.rejects[qs];
-  need = need < kmax ? need : kmax;
-  u64 lim = a.prev[qs];
-  u64 best = 0; int bestc = -1;
-  auto rescan = [&]() {
-    best = 0; bestc = -1;
-    for (int c = tid; c < a.C; c += 256) {
-      const uint32_t v = cn[c];
-      if (v >= minm) {
-        const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
-        if (key < lim && key > best) { best = key; bestc = c; }
-      }
-    }
-  };
-  rescan();
-  int m = 0;
-  for (; m < need; m++) {
-    u64 mx = best;
-    for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
-    if ((tid & 63) == 0) red[tid >> 6] = mx;
-    __syncthreads();
-    if (tid == 0) {
-      u64 b = red[0];
-      for (int i = 1; i < 4; i++) b = red[i] > b ? red[i] : b;
-      bestk = b;
-      if (b) a.selkey[qs * 32 + m] = b;
-    }
-    __syncthreads();
-    const u64 bk = bestk;
-    if (bk == 0) break;
-    if (best == bk) { a.sel[qs * 32 + m] = bestc; owner = tid; }
-    __syncthreads();
-    if (m + 1 >= need) { m++; break; }
-    // the owner's subset (columns = owner mod 256) is rescanned by the whole block, below the consumed key
-    const int ow = owner;
-    u64 nb = 0; int nbc = -1;
-    for (int c = ow + tid * 256; c < a.C; c += 256 * 256) {
-      const uint32_t v = cn[c];
-      if (v >= minm) {
-        const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
-        if (key < bk && key > nb) { nb = key; nbc = c; }
-      }
-    }
-    u64 mx2 = nb;
-    for (int off = 32; off; off >>= 1) { const u64 o = __shfl_xor(mx2, off); mx2 = o > mx2 ? o : mx2; }
-    if ((tid & 63) == 0) red[tid >> 6] = mx2;
-    __syncthreads();
-    u64 b2 = red[0];
-    for (int i = 1; i < 4; i++) b2 = red[i] > b2 ? red[i] : b2;
-    if (nb == b2 && b2 != 0) ownc = nbc;
-    __syncthreads();
-    if (tid == ow) { best = b2; bestc = b2 ? ownc : -1; }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    a.selm[qs] = m; a.sel_short[qs] = m < need ? 1 : 0;
-    if (m > 0) { const int w0 = atomicAdd(&a.work_n[0], m); for (int k = 0; k < m; k++) a.work[w0 + k] = qs * 32 + k; }
-  }
+  const int first = round == 0 ? 0 : 1;
+  const int need = round == 0 ? 1 : 32 - a.rejects[qs];
+  int avail = a.ntop[qs] - first;
+  avail = avail < 0 ? 0 : avail;
+  const int m = avail < need ? avail : need;
+  a.selm[qs] = m; a.sel_short[qs] = m < need ? 1 : 0;
+  if (m > 0) { const int w0 = atomicAdd(&a.work_n[0], m); for (int k = 0; k < m; k++) a.work[w0 + k] = qs * 32 + first + k; }
 }
 
 __device__ __forceinline__ i64 shfl_up64(i64 v)
@@ -630,13 +656,13 @@ template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
   }
 }
 
-__global__ void k_cl_walk(ClusterArgs a)
+__global__ void k_cl_walk(ClusterArgs a, int first)
 {
   const int qs = blockIdx.x * blockDim.x + threadIdx.x;
   if (qs >= 2 * a.nq || a.state[qs] != 0) return;
   const int m = a.selm[qs];
   int w = a.wn[qs], rej = a.rejects[qs], st = 0;
-  for (int k = 0; k < m; k++) {
+  for (int k = first; k < first + m; k++) {
     const u64 key = a.selkey[qs * 32 + k];
     const double pid = a.selpid[qs * 32 + k];
     a.wkey[qs * 32 + w] = key; a.wpid[qs * 32 + w] = pid; a.wcol[qs * 32 + w] = a.sel[qs * 32 + k];
@@ -645,7 +671,7 @@ __global__ void k_cl_walk(ClusterArgs a)
     rej++;
     if (rej >= 32) { st = 2; a.bound[qs] = key; break; }
   }
-  if (st == 0) { if (a.sel_short[qs]) st = 3; else if (m > 0) a.prev[qs] = a.selkey[qs * 32 + m - 1]; }
+  if (st == 0) { if (a.sel_short[qs]) st = 3; else if (m > 0) a.prev[qs] = a.selkey[qs * 32 + first + m - 1]; }
   a.state[qs] = st; a.wn[qs] = w; a.rejects[qs] = rej; a.selm[qs] = 0;
 }
 __global__ void k_cl_reset_work(ClusterArgs a, int which) { a.work_n[which] = 0; }
@@ -668,23 +694,34 @@ __global__ void k_cl_outcome(ClusterArgs a)
   if (qi == 0) a.is_new[a.nq] = 0;
 }
 
-// set the column of each speculative centroid (mode 0) or clear the columns flagged in rm[] (mode 1); one wave per query
+// words of every would-be centroid of the window (their exclusive scan places the word lists in the pool)
+__global__ void k_cl_wsum(ClusterArgs a)
+{
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi == 0) a.cw_base[0] = a.cw_off[a.C];
+  if (qi > a.nq) return;
+  a.wsum[qi] = (qi < a.nq && a.is_new[qi]) ? a.nk[2 * a.canon[qi]] : 0;
+}
+// register each speculative centroid as a column: its distinct forward words go to the pool (mode 0); or roll back the
+// columns flagged in rm[] (mode 1: the column stays, without words, and never counts again); one wave per query
 __global__ __launch_bounds__(64) void k_cl_columns(ClusterArgs a, int clear)
 {
   const int qi = blockIdx.x, lane = threadIdx.x;
+  if (qi == a.nq) {                                          // one extra block: where the next window's first column starts
+    if (lane == 0 && !clear) a.cw_off[a.C + a.new_rank[a.nq]] = a.cw_base[0] + a.wscan[a.nq];
+    return;
+  }
   if (clear ? !a.rm[qi] : !a.is_new[qi]) return;
   const int col = a.C + a.new_rank[qi];
+  if (clear) { if (lane == 0) a.cw_n[col] = 0; return; }
   const int qs = 2 * a.canon[qi];
   const int n = a.nk[qs];
   const uint16_t *kl = a.klist + (size_t)qs * a.kcap;
-  const uint32_t bit = 1u << (col & 31);
-  uint32_t *base = a.bits + (col >> 5);
-  for (int i = lane; i < n; i += 64) {
-    uint32_t *p = base + (size_t)kl[i] * (size_t)a.stride;
-    if (clear) atomicAnd(p, ~bit); else atomicOr(p, bit);
-  }
-  if (lane == 0 && !clear) {
+  const int64_t off = a.cw_base[0] + a.wscan[qi];
+  for (int i = lane; i < n; i += 64) a.cw_pool[off + i] = kl[i];
+  if (lane == 0) {
     const int64_t r = a.order[a.f + qi];
+    a.cw_off[col] = off; a.cw_n[col] = n;
     a.cent_len[col] = a.rd.len[r]; a.cent_pos[col] = a.f + qi; a.cent_read[col] = (int32_t)r;
     a.res_col[a.f + qi] = col;
     a.newq[a.new_rank[qi]] = qi;
@@ -703,17 +740,17 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
   if (n == 0) return;
   const int n_new = a.new_rank[a.nq];
   if (n_new == 0) return;
-  if ((qs & 1) && a.skipm[cqi]) return;                  // this strand's walk was cut short: it has no say (see k_cl_select)
+  if ((qs & 1) && a.skipm[cqi]) return;                  // this strand's walk was cut short: it has no say (see k_cl_take)
   if (tid == 0) xcount = 0;
   __syncthreads();
   const int pos = a.f + (qs >> 1);
   const uint32_t minm = n < 12 ? n : 12;
   const int state = a.state[cs];
   const u64 bound = state == 3 ? 0ULL : a.bound[cs];
-  const uint16_t *cn = a.cnt + (size_t)cs * a.cpitch;
+  const uint16_t *cn = a.cntx + (size_t)cs * a.xpitch;      // k_cl_stream, mode 2
   for (int c = a.C + tid; c < a.C + n_new; c += 256) {
     if (a.cent_pos[c] >= pos) break;
-    const uint32_t v = cn[c];
+    const uint32_t v = cn[c - a.C];
     if (v >= minm) {
       const u64 key = cand_key(v, a.cent_len[c], a.cent_pos[c]);
       if (key > bound) {
@@ -833,7 +870,7 @@ __global__ __launch_bounds__(64) void k_cl_resolve(ClusterArgs a)
     ntrue += (qi < cut && tnew[qi]) ? 1 : 0;
   }
   for (int off = 32; off; off >>= 1) ntrue += __shfl_xor(ntrue, off);
-  if (lane == 0) { a.wout[0] = cut; a.wout[1] = a.new_rank[cut]; a.wout[2] = ntrue; }
+  if (lane == 0) { a.wout[0] = cut; a.wout[1] = a.new_rank[cut]; a.wout[2] = ntrue; a.cw_base[1] = a.cw_off[a.C + a.new_rank[cut]]; }
 }
 
 __global__ void k_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col, const int8_t *res_strand, const double *res_id,
@@ -846,13 +883,6 @@ __global__ void k_cl_finalize(int32_t nk, const int32_t *order, const int32_t *r
   rep_of[r] = rep; strand[r] = res_strand[p]; pct[r] = res_id[p]; is_seed[r] = rep == r ? 1 : 0;
 }
 
-__global__ void k_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride)
-{
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 65536 * sstride) return;
-  dst[(i / sstride) * dstride + (i % sstride)] = src[i];
-}
-
 // ------------------------------------------------------------------ launchers
 void launch_cl_kmers(const ClusterArgs &a, hipStream_t st)
 {
@@ -862,11 +892,24 @@ void launch_cl_kmers(const ClusterArgs &a, hipStream_t st)
   hipLaunchKernelGGL(k_cl_canon_lookup, dim3((a.nq + 255) / 256), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_cl_kmers, dim3(2 * a.nq), dim3(256), 0, st, a);
 }
-void launch_cl_count(const ClusterArgs &a, int tile0, int ntiles, int with_best, hipStream_t st)
+void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st)
 {
-  if (ntiles <= 0) return;
-  hipLaunchKernelGGL(k_cl_count, dim3(2 * a.nq, (ntiles + 3) / 4), dim3(256), 0, st, a, tile0, ntiles, with_best);
+  (void)hipMemsetAsync(a.qi_cnt, 0, 65537 * sizeof(int32_t), st);
+  hipLaunchKernelGGL(k_cl_qi_count, dim3(2 * a.nq), dim3(256), 0, st, a, 0);
+  hipLaunchKernelGGL(k_cl_qi_pad, dim3(65537 / 256 + 1), dim3(256), 0, st, a);
+  launch_exclusive_scan(a.qi_cnt, a.qi_off, 65537, scan_tmp, st);
+  hipLaunchKernelGGL(k_cl_qi_fill_dummy, dim3(1024), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_cl_qi_count, dim3(2 * a.nq), dim3(256), 0, st, a, 1);
+  hipLaunchKernelGGL(k_cl_tq_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
+  (void)hipMemsetAsync(a.hist2, 0, (size_t)2 * a.nq * CL_HB * sizeof(uint32_t), st);
 }
+void launch_cl_stream(const ClusterArgs &a, int c0, int c1, int mode, hipStream_t st)
+{
+  if (c1 <= c0) return;
+  hipLaunchKernelGGL(k_cl_stream, dim3(std::min(c1 - c0, 768)), dim3(256), 0, st, a, c0, c1, mode);
+}
+void launch_cl_thresh(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_thresh, dim3((2 * a.nq + 3) / 4), dim3(256), 0, st, a); }
+void launch_cl_topk(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_topk, dim3(2 * a.nq), dim3(256), 0, st, a); }
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
 static size_t precheck_lds(const ClusterArgs &a)
 {
@@ -878,19 +921,19 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   // round 0: the best candidate of every query (most reads accept it); round 1: the whole remaining reject budget at once
   for (int round = 0; round < 2; round++) {
     const int kmax = round == 0 ? 1 : 31;
-    if (round == 0 && a.use_best0) hipLaunchKernelGGL(k_cl_pick0, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_cl_select, dim3(2 * a.nq), dim3(256), 0, st, a, kmax);
+    hipLaunchKernelGGL(k_cl_take, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a, round);
     const int grid = std::min(2 * a.nq * kmax, 16384);
     const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
     if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 0);
     if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), lds, st, a);
     else hipLaunchKernelGGL(k_cl_align<10>, dim3(grid), dim3(64), lds, st, a);
-    hipLaunchKernelGGL(k_cl_walk, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_cl_walk, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a, round);
     hipLaunchKernelGGL(k_cl_reset_work, dim3(1), dim3(1), 0, st, a, 0);
   }
 }
 void launch_cl_outcome(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_outcome, dim3((a.nq + 255) / 256), dim3(256), 0, st, a); }
-void launch_cl_columns(const ClusterArgs &a, int clear, hipStream_t st) { hipLaunchKernelGGL(k_cl_columns, dim3(a.nq), dim3(64), 0, st, a, clear); }
+void launch_cl_wsum(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_wsum, dim3((a.nq + 256) / 256), dim3(256), 0, st, a); }
+void launch_cl_columns(const ClusterArgs &a, int clear, hipStream_t st) { hipLaunchKernelGGL(k_cl_columns, dim3(a.nq + 1), dim3(64), 0, st, a, clear); }
 void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
 {
   hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a);
@@ -906,12 +949,6 @@ void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col
 {
   if (nk > 0) hipLaunchKernelGGL(k_cl_finalize, dim3((nk + 255) / 256), dim3(256), 0, st, nk, order, res_col, res_strand, res_id, cent_read, rep_of, strand, pct, is_seed);
 }
-void launch_cl_relayout(const uint32_t *src, int64_t sstride, uint32_t *dst, int64_t dstride, hipStream_t st)
-{
-  const int64_t n = 65536 * sstride;
-  hipLaunchKernelGGL(k_cl_relayout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, sstride, dst, dstride);
-}
-
 }  // namespace itsx
 
 // ------------------------------------------------------------------ f4: read orientation (vsearch --orient restated)

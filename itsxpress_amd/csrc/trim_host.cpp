@@ -238,7 +238,7 @@ int itsx_fastq_ids(const char *path, char **names, int64_t **offsets, int64_t *n
 {
   if (!path || !names || !offsets || !n_records) return ITSX_E_ARG;
   Records in;
-  if (!in.open(path)) return ITSX_E_IO;
+  if (!in.open(path)) { g_trim_error = std::string("cannot read ") + path; return ITSX_E_IO; }
   std::string blob; std::vector<int64_t> off(1, 0);
   Rec rec;
   for (;;) {
@@ -252,7 +252,7 @@ int itsx_fastq_ids(const char *path, char **names, int64_t **offsets, int64_t *n
   }
   char *nb = (char *)malloc(blob.size() + 1);
   int64_t *ob = (int64_t *)malloc(off.size() * sizeof(int64_t));
-  if (!nb || !ob) { free(nb); free(ob); g_trim_error = "out of memory"; return ITSX_E_IO; }
+  if (!nb || !ob) { free(nb); free(ob); g_trim_error = "out of memory"; return ITSX_E_NOMEM; }
   memcpy(nb, blob.data(), blob.size()); nb[blob.size()] = 0;
   memcpy(ob, off.data(), off.size() * sizeof(int64_t));
   *names = nb; *offsets = ob; *n_records = (int64_t)off.size() - 1;

@@ -154,6 +154,13 @@ def allreduce_domz_device(engine, device=None):
             t.copy_(h)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda:
+            # itsx_search_finalize reads these counters on the ENGINE's stream, which knows nothing of torch's: the
+            # reduction (and the copy above) must have landed before this returns, whatever stream torch is using
+            # (a torch.cuda.stream(...) context, a per-thread default stream).  The zero-copy *_device views all need
+            # this ordering: torch work on engine memory is synchronised before the engine touches it again.
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
     return t
 
 
@@ -299,6 +306,8 @@ def read_rows(engine, rep_rows, device=None):
     if rep_rows.device != uq.device:          # after a host-side exchange (gloo): back to where the reads' map lives
         rep_rows = rep_rows.to(uq.device)
     ok = uq >= 0
-    rows = rep_rows[uq.clamp(min=0)]
     none = torch.tensor([-1, -1, -1, 0], dtype=torch.int32, device=rep_rows.device)
+    if rep_rows.shape[0] == 0:                # a shard whose reads were all dropped (no unique at all): what itsx_trim_coords returns
+        return none[None, :].expand(uq.shape[0], 4).contiguous()
+    rows = rep_rows[uq.clamp(min=0)]
     return torch.where(ok[:, None], rows, none[None, :])

@@ -183,7 +183,7 @@ class Engine:
         self._chk(self.L.itsx_select_sample(self.h, int(sample)))
 
     # ---- derep
-    def derep(self, strand_both=True, minseqlength=32):
+    def derep(self, strand_both=True, minseqlength=1):
         n = C.c_int64(0)
         self._chk(self.L.itsx_derep(self.h, int(strand_both), int(minseqlength), C.byref(n)))
         self.n_unique = n.value

@@ -17,8 +17,9 @@
  * Deviations, all documented in DESIGN.md:
  *   - libm log/exp inside the per-target pipeline are replaced by orc_log/orc_exp
  *     (orc_math.h) so that CPU and GPU agree bit-for-bit.
- *   - multidomain regions (stochastic traceback clustering in HMMER) are NOT
- *     re-clustered: the region is used as one envelope and flagged (flags bit0).
+ *   - multidomain regions ARE resolved the way p7_domaindef.c resolves them (region_trace_ensemble below: 200
+ *     stochastic tracebacks, null2 by trace, single-linkage clustering of the sampled domains); ORC_NO_ENSEMBLE=1
+ *     restores the older behaviour (the region kept as one envelope, flags bit0) for A/B tests only.
  *   - optimal-accuracy alignment (ali/hmm coordinates, acc) is not computed; the
  *     reference consumes only envelope coordinates and the domain bit score.
  * PARITY UNPINNED against a real hmmsearch build (none available here).

@@ -216,7 +216,7 @@ class SearchResult:
             pass
 
 
-def derep(codes, offsets, strand_both=True, minlen=32):
+def derep(codes, offsets, strand_both=True, minlen=1):
     n = len(offsets) - 1
     rep_of = np.zeros(n, np.int64)
     strand = np.zeros(n, np.int8)

@@ -30,7 +30,7 @@ def _samples(t_hmm_text):
     # the same sequences turn up in several samples, first in the other orientation in some of them
     smp[3] = [_rc(s) for s in smp[0][:40]] + smp[3] + smp[0][:60]
     smp[4] = smp[0][10:30] + smp[4] + [_rc(s) for s in smp[4][:25]]
-    smp[5] = smp[5] + smp[3][:30] + ["ACGT" * 5, "N" * 40]      # a read below minseqlength, an all-N read
+    smp[5] = smp[5] + smp[3][:30] + ["ACGT" * 5, "N" * 40]      # a read below the clustering commands' --minseqlength (kept: derep runs with 1), an all-N read
     for s in smp:
         rng.shuffle(s)
     return smp
@@ -143,8 +143,11 @@ def test_batch_files_equal_single_sample_runs(engine, fixture_reads, t_hmm_text,
     names, seqs = fixture_reads
     blob, offs = synth.make_reads(t_hmm_text, 500, seed=33)
     syn = synth.to_strings(blob, offs)
-    parts = [(names[:120], seqs[:120]), (names[120:], seqs[120:]),
-             (["s%05d extra words" % i for i in range(len(syn))], syn),
+    # reads of 5 and 31 bases (below vsearch's clustering default --minseqlength 32, kept by --fastx_uniques: SeqSample.py:96
+    # passes no such option) in two samples, twice each: a batch and a solo run must treat them alike
+    short = ["ACGTA", "ACGTTGCAAGGCTTACCGGATTTACGCAGTC", "ACGTA", "GACTGCGTAAATCCGGTAAGCCTTGCAACGT"]
+    parts = [(names[:120] + ["short%d" % i for i in range(4)], seqs[:120] + short), (names[120:], seqs[120:]),
+             (["s%05d extra words" % i for i in range(len(syn))] + ["t%d" % i for i in range(2)], syn + short[:2]),
              (names[:50][::-1], [_rc(s) for s in seqs[:50]][::-1])]
     hmm = tmp_path / "its2.hmm"
     hmm.write_text(mini_hmm_text + _its2_subset(t_hmm_text, 12, 12))
@@ -166,6 +169,9 @@ def test_batch_files_equal_single_sample_runs(engine, fixture_reads, t_hmm_text,
         s.deduplicate(threads=1)
         s._search(hmmfile=str(hmm), threads=1)
         solo.append({f: open(getattr(s, f), "rb").read() for f in ("uc_file", "rep_file", "dom_file")})
+        if k == 0:      # the short reads are in uc.txt (S, S, H +, H -): nothing below 32 bases vanished
+            rows = [ln.split("\t") for ln in solo[0]["uc_file"].decode().splitlines()]
+            assert sorted(r[0] + r[4] for r in rows if r[8].startswith("short")) == ["H+", "H-", "S*", "S*"]
         solo_coords.append([x.copy() for x in s.trim_coordinates("ITS2")])
     os.makedirs(batch_dir)
     objs = [SeqSampleNotPaired(fq, str(batch_dir)) for fq in fqs]

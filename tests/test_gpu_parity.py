@@ -129,17 +129,20 @@ def test_derep_matches_oracle_on_synthetic(engine, t_hmm_text):
     seqs = synth.to_strings(blob, offs)
     # edge cases: empty-ish/short reads (dropped), palindromes, an exact reverse complement pair with N
     seqs += ["ACGT" * 7, "ACGT" * 8, "ACGT" * 8, "A" * 31, "ACGTNACGT" * 5, "ACGTNACGT"[::-1].translate(str.maketrans("ACGT", "TGCA")) * 5]
+    seqs += ["ACGTA", ""]
     engine.set_reads(seqs)
-    nu = engine.derep()
-    rep_of, strand, _ = engine.get_derep()
     codes, o = orc.digitize(seqs)
-    nc, orep, ostrand = orc.derep(codes, o)
-    assert nu == nc
-    assert np.array_equal(rep_of, orep)
-    assert np.array_equal(strand, ostrand)
-    assert (strand == -1).sum() > 100 and (rep_of == -1).sum() == 2
-    st = engine.stats()
-    assert st["hash_reseeds"] == 0
+    # --minseqlength 32 (vsearch's default for the clustering commands) and 1 (--fastx_uniques: SeqSample.deduplicate's value)
+    for minlen, ndropped in ((32, 4), (1, 1)):
+        nu = engine.derep(minseqlength=minlen)
+        rep_of, strand, _ = engine.get_derep()
+        nc, orep, ostrand = orc.derep(codes, o, minlen=minlen)
+        assert nu == nc
+        assert np.array_equal(rep_of, orep)
+        assert np.array_equal(strand, ostrand)
+        assert (strand == -1).sum() > 100 and (rep_of == -1).sum() == ndropped
+        st = engine.stats()
+        assert st["hash_reseeds"] == 0
 
 
 def test_derep_forward_only_and_ragged_lengths(engine):

@@ -11,9 +11,11 @@ starts: 2-bit packing on the device -> derep -> MSV -> bias/Forward -> Backward/
 `host_handover` is the same step fed from a host buffer (staged PCIe upload included), measured in a leg of its own.
 
 `--gpus N`: when N > 1 and no launcher set WORLD_SIZE, this process starts N ranks of itself (before anything touches the
-GPU) and relays rank 0's line.  Weak scaling by default (every rank its own shard of the workload's size);
-`--total-reads T` shards T reads over the ranks (strong scaling; shards share their template library, so
-`--global-derep` has cross-shard duplicates to find).
+GPU) and relays rank 0's line.  STRONG scaling by default (north_star: "10 M reads at 1 GPU, >= 6x further at 8 GPUs"):
+the workload's reads (10 M for configs[2]) are sharded over the N ranks from ONE template library, so `--global-derep` has
+cross-shard duplicates to find; `--total-reads T` sets another total; `--weak` gives every rank its own full-size shard.
+`--workload cfg4` is BASELINE configs[4]'s per-GPU shape: 2x250-merged reads (300-480 bases), `--region ALL` profiles
+(`1_` / `4_`), greedy clustering at 0.995 (row a2) instead of exact dereplication.
 
 Prints ONE JSON line on rank 0.
 """
@@ -58,9 +60,17 @@ def _load_pmc():
             PMC_BYTES_PER_ROW = json.load(f)
 
 
-def its2_profiles(hmm_text):
+CFG4_DEFAULT = 2000000           # reads of a default `--workload cfg4` run (configs[4]'s per-GPU share is 12.5 M: --reads 12500000)
+
+
+def region_profiles(hmm_text, left="3_", right="4_"):
+    """what create_runtime_hmm selects (main.py:200-208): the profile blocks whose NAME starts with one of the region's prefixes"""
     blocks = [b + "//\n" for b in hmm_text.split("//\n") if "NAME  " in b]
-    return "".join(b for b in blocks if b.split("NAME  ")[1][:2] in ("3_", "4_"))
+    return "".join(b for b in blocks if b.split("NAME  ")[1][:2] in (left, right))
+
+
+def its2_profiles(hmm_text):
+    return region_profiles(hmm_text, "3_", "4_")
 
 
 def launch_ranks(n):
@@ -80,12 +90,27 @@ def launch_ranks(n):
     return rc
 
 
-def launch_selftest(world, rank):
-    """CPU check of the launcher + the two exchange steps with gloo and no engine (tests/test_dist_gloo.py)."""
+def shard_plan(workload, reads, total_reads, weak, world, rank):
+    """How the workload's reads are laid over the ranks.  N > 1 defaults to STRONG scaling: the workload's own size (10 M reads
+    for configs[2]) is the total of the whole job and rank r takes the slice [T r / N, T (r + 1) / N) -- north_star's ">= 6x
+    further at 8 GPUs" is on the 10 M-read job.  --weak (or an explicit --reads) gives every rank a full-size shard of its own.
+    Returns (reads of this rank, total of the job or 0 when weak, "strong" | "weak")."""
+    own = {"cfg2": 10000000, "cfg1": 1000000, "cfg4": CFG4_DEFAULT}[workload]
+    if world > 1 and not weak and not reads and not total_reads:
+        total_reads = own
+    if total_reads > 0:
+        return total_reads * (rank + 1) // world - total_reads * rank // world, total_reads, "strong"
+    return reads or own, 0, "weak"
+
+
+def launch_selftest(world, rank, args):
+    """CPU check of the launcher + the sharding plan + the two exchange steps with gloo and no engine (tests/test_dist_gloo.py)."""
     import numpy as np
     import torch.distributed as dist
     from itsxpress_amd.dist import allreduce_domz, gather_coords
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local, total, scaling = shard_plan(args.workload, args.reads, args.total_reads, args.weak, world, rank)
+    plan = allreduce_domz(np.array([n_local], np.int64))
     z = allreduce_domz(np.full(5, rank + 1, np.int64))
     n = 3 + rank
     c = gather_coords(np.full(n, rank, np.int32), np.arange(n, dtype=np.int32), np.full(n, 7, np.int32), np.ones(n, np.int32))
@@ -93,7 +118,8 @@ def launch_selftest(world, rank):
     if rank == 0:
         ok = bool((z == world * (world + 1) // 2).all()) and [b.shape[0] for b in c] == [3 + r for r in range(world)] and \
             all(int(b[0, 0]) == r for r, b in enumerate(c))
-        print(json.dumps({"metric": "launcher self-test (no engine, gloo)", "value": None, "n_gpus": world, "ok": ok}))
+        print(json.dumps({"metric": "launcher self-test (no engine, gloo)", "value": None, "n_gpus": world, "ok": ok, "scaling": scaling,
+                          "reads_rank0": int(n_local), "reads_all_ranks": int(plan[0]), "total_reads": int(total)}))
     dist.destroy_process_group()
 
 
@@ -132,24 +158,30 @@ def real_tools_baseline(hmm_its2, seqs, threads, tmp):
     return dt, coords
 
 
-def cpu_baseline(hmm_its2, blob, offs, sample_reads, threads):
+def cpu_baseline(hmm_text, blob, offs, sample_reads, threads, lp="3_", rp="4_", cluster_id=1.0):
     """the oracle (a port of the reference's CPU path) timed on a bounded sample of the same workload"""
     import numpy as np
     import orc
     raw = bytes(blob[:int(offs[sample_reads])])
     seqs = [raw[offs[i]:offs[i + 1]].decode() for i in range(sample_reads)]
-    hs = orc.HmmSet(text=hmm_its2)
+    hs = orc.HmmSet(text=hmm_text)
     t0 = time.time()
     codes, o = orc.digitize(seqs)
-    nc, rep, strand = orc.derep(codes, o)
+    if cluster_id < 1.0:            # row a2: the sequential greedy procedure (one thread, like its definition)
+        cl = orc.cluster(codes, o, ["r%09d" % i for i in range(len(seqs))], cluster_id)
+        nc, rep = cl["n_centroids"], cl["rep_of"]
+    else:
+        nc, rep, strand = orc.derep(codes, o)
     seeds = [i for i in range(len(seqs)) if rep[i] == i]
     c2, o2 = orc.digitize([seqs[i] for i in seeds])
     res = orc.SearchResult(hs, c2, o2, threads=threads, keep_trace=0)
-    us, ue, ut, ui = res.positions("3_", "4_")
+    us, ue, ut, ui = res.positions(lp, rp)
     dt = time.time() - t0
-    uniq = np.cumsum(np.asarray(rep) == np.arange(len(seqs))) - 1          # unique index of each seed, in input order
-    uo = uniq[np.asarray(rep)]
+    rep = np.asarray(rep)
+    uniq = np.cumsum(rep == np.arange(len(seqs))) - 1          # unique index of each seed, in input order
+    uo = uniq[np.maximum(rep, 0)]
     coords = np.stack([us[uo], ue[uo], ut[uo]], axis=1)                      # per read of the sample: the baseline path's answer
+    coords[rep < 0] = -1                                                     # reads the grouping dropped (--minseqlength)
     return sample_reads / dt, dt, nc, coords, seqs
 
 
@@ -167,18 +199,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg2", "cfg1"], default="cfg2",
-                    help="cfg2 = BASELINE configs[2] (10 M merged reads, 300-580 bases; the default), cfg1 = configs[1] (1 M x 300)")
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's own size)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg4"], default="cfg2",
+                    help="cfg2 = BASELINE configs[2] (10 M merged reads, 300-580 bases; the default), cfg1 = configs[1] (1 M x 300), "
+                         "cfg4 = configs[4]'s shape (2x250-merged reads of 300-480 bases, --region ALL profiles, cluster_id 0.995)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's own size); implies --weak at N > 1")
     ap.add_argument("--total-reads", type=int, default=0,
-                    help="strong scaling: this many reads in total, sharded over the ranks (shards share their templates)")
+                    help="strong scaling: this many reads in total, sharded over the ranks (shards share their templates); "
+                         "the default at N > 1, with the workload's own size as the total")
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own shard of the workload's size (weak scaling)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20-30 s of CPU work)")
     ap.add_argument("--handover-steps", type=int, default=1, help="steps fed from the host buffer, outside `value` (0 = skip)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ITSX_BENCH_BUDGET_S", "520")),
                     help="wall-clock budget of the whole run: the legs AFTER the K timed steps (host hand-over, CPU baseline) shrink or "
                          "are skipped to stay inside it (the driver's limit is 600 s); the timed steps themselves are never cut")
-    ap.add_argument("--cluster-id", type=float, default=1.0,
-                    help="1.0 = exact dereplication (the default); < 1 runs row a2 (greedy clustering) instead")
+    ap.add_argument("--cluster-id", type=float, default=None,
+                    help="1.0 = exact dereplication (the default for cfg1 / cfg2); < 1 runs row a2 (greedy clustering) instead (cfg4: 0.995)")
     ap.add_argument("--taxa", choices=["T", "all"], default="T",
                     help="T = the stand-in taxon (155 ITS2 profiles); all = --taxa All --region ITS2 (814 profiles, configs[3])")
     ap.add_argument("--global-derep", action="store_true",
@@ -188,12 +223,14 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
+    if args.cluster_id is None:
+        args.cluster_id = 0.995 if args.workload == "cfg4" else 1.0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.launch_selftest:
-        return launch_selftest(world, rank)
+        return launch_selftest(world, rank, args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -217,24 +254,35 @@ def main():
     import synth
     _load_pmc()
 
-    with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
-        thmm = f.read()
-    hmm = its2_profiles(thmm)
+    from itsxpress_amd.definitions import hmm_path
+    fungi = hmm_path("Fungi") if args.taxa == "T" else None      # ITSx_db/HMMs/F.hmm via $ITSXPRESS_DB_DIR / an installed itsxpress
+    if fungi:                                                     # the taxon every BASELINE config names: used the moment it is supplied
+        with open(fungi) as f:
+            thmm = f.read()
+        progress("Fungi profiles from %s" % fungi)
+    else:
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
+            thmm = f.read()
+    cfg2, cfg4 = args.workload == "cfg2", args.workload == "cfg4"
+    lp, rp = ("1_", "4_") if cfg4 else ("3_", "4_")        # create_runtime_hmm's prefixes: --region ALL / ITS2 (main.py:200-208)
+    hmm = region_profiles(thmm, lp, rp)
     if args.taxa == "all":
+        if cfg4:
+            raise SystemExit("--taxa all is configs[3]'s profile set (ITS2); cfg4 runs the stand-in taxon's --region ALL profiles")
         with gzip.open(os.path.join(ROOT, "tests", "golden", "all_its2.hmm.gz"), "rt") as f:
             hmm = f.read()
-    cfg2 = args.workload == "cfg2"
-    strong = args.total_reads > 0
-    if strong:
-        lo, hi = args.total_reads * rank // world, args.total_reads * (rank + 1) // world
-        n_local = hi - lo
-    else:
-        n_local = args.reads or (10000000 if cfg2 else 1000000)
+    # the workload's own size per GPU: configs[2] 10 M; configs[1] 1 M; configs[4] 100 M over 8 GPUs = 12.5 M per GPU (the
+    # default runs CFG4_DEFAULT reads so that a plain `bench.py --workload cfg4` finishes in minutes; --reads 12500000 is the share)
+    n_local, args.total_reads, scaling = shard_plan(args.workload, args.reads, args.total_reads, args.weak, world, rank)
+    strong = scaling == "strong"
     progress("generating %d reads (%s)" % (n_local, args.workload))
     t_gen = time.time()
-    gen = dict(config=3 if cfg2 else 2, seed=synth.SEED + (3 if cfg2 else 2) + 1000 * rank, as_array=True)
+    cfgno = 3 if cfg2 else (5 if cfg4 else 2)
+    gen = dict(config=cfgno, seed=synth.SEED + cfgno + 1000 * rank, as_array=True, left=lp, right=rp)
     if cfg2:
         gen.update(fixed_len=0, len_range=(300, 580))
+    if cfg4:
+        gen.update(fixed_len=0, len_range=(300, 480))
     if strong:                      # one template library for the whole job: 2 % of the TOTAL reads
         gen.update(template_seed=synth.SEED + 77, frac_templates=0.02 * args.total_reads / max(n_local, 1))
     blob, offs = synth.make_reads(thmm, n_local, **gen)
@@ -244,6 +292,8 @@ def main():
     nprof = eng.load_profiles(text=hmm)
     d_blob = torch.from_numpy(blob).to(dev)      # the batch's ASCII text, resident in HBM before the timed region
     torch.cuda.synchronize()
+
+    comm = {"allreduce_ms": 0.0, "gather_ms": 0.0}
 
     def step(from_host=False):
         if from_host:
@@ -258,15 +308,22 @@ def main():
         eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
         if not use_dist:
             eng.finalize(domE=10.0)
-            return [eng.trim_coords("3_", "4_")]          # (start, stop, tlen, index) per read, on the host
+            return [eng.trim_coords(lp, rp)]          # (start, stop, tlen, index) per read, on the host
         # N > 1: the two exchanges run on the engine's own device buffers (RCCL over xGMI), nothing bounces through numpy
-        allreduce_domz_device(eng, dev)                # hmmsearch's domZ is a count over the WHOLE data set
+        tc = time.perf_counter()
+        allreduce_domz_device(eng, dev)                # hmmsearch's domZ is a count over the WHOLE data set (returns once the reduction has landed)
+        comm["allreduce_ms"] += (time.perf_counter() - tc) * 1e3
         eng.finalize(domE=10.0)
         if g is not None:            # coordinates of the uniques scored elsewhere arrive here, then fan out to the reads
-            rows = read_rows(eng, exchange_rows(g, eng.rep_coords_device("3_", "4_", dev)), dev)
+            rows = read_rows(eng, exchange_rows(g, eng.rep_coords_device(lp, rp, dev)), dev)
         else:
-            rows = eng.trim_coords_device("3_", "4_", dev)
-        return gather_rows(rows, dst=0)
+            rows = eng.trim_coords_device(lp, rp, dev)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        out = gather_rows(rows, dst=0)                 # rank 0 ends with the rows on its host; includes the wait for the slowest rank
+        torch.cuda.synchronize()
+        comm["gather_ms"] += (time.perf_counter() - tc) * 1e3
+        return out
 
     progress("reads generated in %.1f s, text resident in HBM; %d warm-up + %d timed steps" % (t_gen, args.warmup, args.steps))
     warm_done = 0
@@ -290,6 +347,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    comm["allreduce_ms"] = comm["gather_ms"] = 0.0
     t0 = time.perf_counter()
     acc = {}
     out = None
@@ -301,9 +359,11 @@ def main():
             if k.startswith("ms_"):
                 acc[k] = acc.get(k, 0.0) + v
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0               # this rank's own K steps (the gather's wait for slower ranks included)
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -311,6 +371,14 @@ def main():
         tot = torch.tensor([n_local], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         total_local = int(tot.item())
+        # per-rank figures: step time without the exchanges (what the rank computed), and the exchanges themselves
+        own = (dt_own * 1e3 - comm["allreduce_ms"] - comm["gather_ms"]) / max(args.steps, 1)
+        v = torch.tensor([own, -own, comm["allreduce_ms"] / max(args.steps, 1), comm["gather_ms"] / max(args.steps, 1)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        rank_ms = {"compute_ms_per_step_max": float(v[0]), "compute_ms_per_step_min": -float(v[1]),
+                   "allreduce_ms_per_step_max": float(v[2]), "gather_ms_per_step_max": float(v[3]),
+                   "note": "per rank: step time without the two exchanges (max / min over ranks), the domZ all-reduce, the coordinate gather "
+                           "(a rank's gather includes its wait for the slowest rank)"}
     else:
         total_local = n_local
     st = eng.stats()
@@ -403,19 +471,23 @@ def main():
                     "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl, "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic}
         c_start, c_stop = (out[0][0], out[0][1]) if isinstance(out[0], tuple) else (out[0][:, 0], out[0][:, 1])
         trimmed = int(((c_start >= 0) & (c_stop >= 0) & (c_start < c_stop)).sum())
-        shape = ("merged reads of 300-580 bases (mean %.0f)" % mean_len) if cfg2 else "300 bp single-end reads"
-        wl = ("configs[2]" if cfg2 else "configs[1]") + ": %d synthetic %s per GPU" % (n_local, shape)
+        shape = ("merged reads of 300-580 bases (mean %.0f)" % mean_len) if cfg2 else \
+            ("2x250-merged reads of 300-480 bases (mean %.0f)" % mean_len) if cfg4 else "300 bp single-end reads"
+        cname = "configs[2]" if cfg2 else ("configs[4] (one GPU's shard; the full share is 12.5 M reads)" if cfg4 else "configs[1]")
+        wl = cname + ": %d synthetic %s per GPU" % (n_local, shape)
         if strong:
-            wl = "%d synthetic %s in total, sharded over %d ranks (shared template library)" % (args.total_reads, shape, world)
-        wl += ", ITS2" + (", cluster_id=1.0 (pure derep)" if args.cluster_id >= 1.0 else ", cluster_id=%g (greedy clustering, row a2)" % args.cluster_id)
+            wl = cname + ": %d synthetic %s in total, sharded over %d ranks (shared template library)" % (args.total_reads, shape, world)
+        wl += (", --region ALL (1_ / 4_ profiles)" if cfg4 else ", ITS2") + \
+            (", cluster_id=1.0 (pure derep)" if args.cluster_id >= 1.0 else ", cluster_id=%g (greedy clustering, row a2)" % args.cluster_id)
         if args.taxa == "all":
             wl += ", --taxa All (814 profiles, as configs[3])"
         res = {
-            "metric": "reads/sec trimmed (ITS2, stand-in taxon Tracheophyta for Fungi)", "value": value, "unit": "reads/s",
+            "metric": "reads/sec trimmed (%s%s)" % ("Fungi " if fungi else "", ("region ALL" if cfg4 else "ITS2") + ("" if fungi else ", stand-in taxon Tracheophyta for Fungi")),
+            "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": warm_done, "warmup_requested": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8+f32", "data": "synthetic",
             "config": {"workload": wl,
-                       "taxon": "Tracheophyta (stand-in: F.hmm absent from the reference mount)" if args.taxa == "T" else "All (every ITSx set in the mount; F.hmm absent)", "profiles": nprof,
+                       "taxon": ("Fungi (%s)" % fungi) if fungi else "Tracheophyta (stand-in: F.hmm absent from the reference mount)" if args.taxa == "T" else "All (every ITSx set in the mount; F.hmm absent)", "profiles": nprof,
                        "reads_rank0": n_local, "mean_length": round(mean_len, 1), "generate_s": round(t_gen, 1),
                        "unique": int(st["n_unique"]), "pairs_past_msv": int(st["n_past_msv"]), "pairs_past_fwd": int(st["n_past_fwd"]),
                        "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed,
@@ -423,6 +495,7 @@ def main():
             "timed_region": "ASCII text resident in HBM -> device 2-bit packing -> derep -> MSV -> Forward/Backward -> domains -> "
                             "thresholds -> per-read coordinates on the host (+ all-reduce / gather at N > 1)",
             "host_handover": handover,
+            "ranks": rank_ms,
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
             "kernels": kernel_table,
             "parity_risk": {"regions": int(st["n_regions"]), "regions_multidomain": int(st["n_multidomain"]),
@@ -435,7 +508,8 @@ def main():
                             "reads_with_pair_over_region_cap": int(st["n_reads_region_cap"])},
             "concurrency": "k_bias of batch b+1 runs on a second stream beside k_decode of batch b, and k_msv of chunk c+1 beside the domain stage of chunk c: ms_bias_kernel and ms_msv_kernel (hence kernels.k_msv and valu.msv_gcups) are stretched wall times, not extra step time; alone k_msv takes ~0.2 s per chunk (ITSX_MSV_OVERLAP=0)",
             "cluster": None if args.cluster_id >= 1.0 else {"windows": int(st["cl_windows"]), "cut_windows": int(st["cl_cuts"]),
-                                                            "alignments": int(st["cl_alignments"]), "centroids": int(st["n_unique"])},
+                                                            "alignments": int(st["cl_alignments"]), "certified_rejections": int(st["cl_certified"]),
+                                                            "centroids": int(st["n_unique"]), "ms_per_step": round(acc.get("ms_cluster", 0.0) / K, 1)},
             "roofline": roof,
             "valu": {"msv_gcups": st["msv_cells"] / (kern["k_msv"] * 1e-3) / 1e9 if kern["k_msv"] > 0 else None,
                      "fwd_rows_per_s": rows / (kern["k_filters_fwd"] * 1e-3) if kern["k_filters_fwd"] > 0 else None,
@@ -447,32 +521,38 @@ def main():
             threads = os.cpu_count() or 1
             if args.cpu_sample < 0:                      # the scalar port does ~2.5 (440-base) .. 5 (300-base) reads/s per core
                 args.cpu_sample = int(min(24000 if cfg2 else 40000, max(1200, (64 if cfg2 else 120) * threads)))
+                if args.cluster_id < 1.0:                # the greedy clustering of the baseline is sequential by definition: ~15 s for 6 000 reads
+                    args.cpu_sample = min(args.cpu_sample, 6000)
                 room = args.budget_s - (time.time() - T_START) - 20.0     # ~25 s of CPU work, less when the budget is nearly spent
                 args.cpu_sample = int(max(8192 if threads >= 64 else 600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
             m = min(args.cpu_sample, n_local)
             progress("CPU baseline on %d reads, %d threads" % (m, threads))
-            v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads)
+            v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads, lp, rp, args.cluster_id)
             progress("CPU baseline done in %.1f s" % cdt)
             # trim-coordinate concordance (BASELINE metric): the engine on the very same sample against the baseline path
             e2 = Engine(local_rank)
             e2.load_profiles(text=hmm)
             e2.set_reads_buffer(np.ascontiguousarray(blob[:int(offs[m])]), offs[:m + 1])
-            e2.derep(strand_both=True, minseqlength=1)
+            if args.cluster_id < 1.0:
+                e2.cluster(args.cluster_id, strand_both=True)
+            else:
+                e2.derep(strand_both=True, minseqlength=1)
             e2.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
             e2.finalize(domE=10.0)
-            gs, ge, gt, _ = e2.trim_coords("3_", "4_")
+            gs, ge, gt, _ = e2.trim_coords(lp, rp)
             e2.close()
             got = np.stack([gs, ge, gt], axis=1)
             conc = float((got == ccoords).all(axis=1).mean())
             res["cpu_baseline"] = {"value": v, "unit": "reads/s", "cores": threads, "kind": "port",
-                                   "sample": "first %d reads of the same workload (%d unique), derep+search+argmax, %.1f s" % (m, nc, cdt),
+                                   "sample": "first %d reads of the same workload (%d %s), %s+search+argmax, %.1f s" %
+                                             (m, nc, "centroids" if args.cluster_id < 1.0 else "unique", "cluster_size" if args.cluster_id < 1.0 else "derep", cdt),
                                    "trim_coord_concordance": conc,
                                    "concordance_is": "engine vs oracle/ (our restatement), not vs vsearch+hmmsearch"}
             # the real reference engines, when the box happens to have them (SURVEY 8d "preferred")
             import tempfile
             with tempfile.TemporaryDirectory() as tmp:
                 try:
-                    real = real_tools_baseline(hmm, seqs, threads, tmp)
+                    real = real_tools_baseline(hmm, seqs, threads, tmp) if (args.cluster_id >= 1.0 and not cfg4) else None
                 except Exception as e:      # a tool that is present but fails is reported, not fatal
                     real = None
                     res["cpu_baseline"]["real_tools_error"] = repr(e)[:200]

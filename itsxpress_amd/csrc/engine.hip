@@ -946,8 +946,10 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   const int32_t nk = (int32_t)ord.size();
   int Bmax = 4096;                                          // k_cl_resolve keeps the window's flags in LDS
   if (const char *e = getenv("ITSX_CL_WINDOW")) Bmax = std::min(4096, std::max(1, atoi(e)));
-  int rows_per_lane = (Lmax + 1 <= 320) ? 5 : 10;
-  if (const char *e = getenv("ITSX_CL_ROWS")) rows_per_lane = atoi(e) <= 5 ? 5 : 10;
+  // DP rows per lane of the alignment wave: 64 lanes x S rows hold the whole query when Lmax + 1 <= 64 S; the lanes past the
+  // query's end idle, so S is the smallest that fits (2x250-merged reads of <= 480 bases: S = 8, not 10: 78 % instead of 62 % busy)
+  int rows_per_lane = (Lmax + 1 <= 320) ? 5 : (Lmax + 1 <= 512) ? 8 : 10;
+  if (const char *e = getenv("ITSX_CL_ROWS")) rows_per_lane = atoi(e) <= 5 ? 5 : atoi(e) <= 8 ? 8 : 10;
   const bool multipass = Lmax + 1 > 64 * rows_per_lane;
   const int32_t scratch_pitch = Lmax + 1;
   if (multipass) while (Bmax > 16 && 2LL * Bmax * 32 * scratch_pitch * 16 > (4LL << 30)) Bmax /= 2;
@@ -958,8 +960,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   DBuf<int32_t> cw_n, wsum, wscan, qi_cnt, qi_cur, qi_off, ncand, ntop, ovf;
   DBuf<int64_t> cw_off, cw_base;
   DBuf<uint16_t> klist, cw_poolA, cw_poolB, qi_ent, tq, minm, cntx;
-  DBuf<uint32_t> hist2;
-  DBuf<unsigned long long> ctab_key, n_skipped, pre_stats, cand;
+  DBuf<unsigned long long> ctab_key, n_skipped, pre_stats, cand, tkey;
   DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct, selpid, wpid, xpid;
   DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
   DBuf<uint16_t> *cw_pool = &cw_poolA, *cw_other = &cw_poolB;
@@ -977,7 +978,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(xlist.alloc(nqs * 32)); HIPCHK(xn.alloc(nqs)); HIPCHK(hard.alloc(nqs)); HIPCHK(xkey.alloc(nqs * 32)); HIPCHK(xpid.alloc(nqs * 32));
   HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(newq.alloc((size_t)Bmax + 1)); HIPCHK(rm.alloc((size_t)Bmax + 1));
   HIPCHK(wsum.alloc((size_t)Bmax + 1)); HIPCHK(wscan.alloc((size_t)Bmax + 1));
-  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(pre_stats.alloc(4)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 4 * sizeof(unsigned long long), ctx->st));
+  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(2)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(pre_stats.alloc(16)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 16 * sizeof(unsigned long long), ctx->st));
   HIPCHK(hipMemsetAsync(n_skipped.p, 0, sizeof(unsigned long long), ctx->st)); HIPCHK(ctab_key.alloc(16384)); HIPCHK(ctab_val.alloc(16384));
   HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1));
   if (n > 0) launch_hash_reads(ctx->rd, 0, 0, ctx->w_hf.p, ctx->w_hr.p, ctx->st);      // identical reads of a window share one search
@@ -987,8 +988,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   // the window's query index, the strands' thresholds and candidate lists, the counts against the window's own centroids
   HIPCHK(qi_cnt.alloc(65537)); HIPCHK(qi_cur.alloc(65536)); HIPCHK(qi_off.alloc(65537));
   HIPCHK(qi_ent.alloc(nqs * (size_t)kcap + 65536 * 8 + 64));
-  HIPCHK(tq.alloc(nqs)); HIPCHK(minm.alloc(nqs)); HIPCHK(ncand.alloc(nqs)); HIPCHK(ntop.alloc(nqs)); HIPCHK(ovf.alloc(1));
-  HIPCHK(hist2.alloc(nqs * (size_t)CL_HB));
+  HIPCHK(tq.alloc(CL_QS_MAX + 8)); HIPCHK(minm.alloc(CL_QS_MAX + 8)); HIPCHK(tkey.alloc(nqs)); HIPCHK(ncand.alloc(nqs)); HIPCHK(ntop.alloc(nqs)); HIPCHK(ovf.alloc(1));
   int32_t cand_cap = 4096;                                  // per strand; grows (and the window is searched again) when a list overflows
   if (const char *e = getenv("ITSX_CL_CCAP")) cand_cap = std::max(32, atoi(e));
   HIPCHK(cand.alloc(nqs * (size_t)cand_cap));
@@ -1005,7 +1005,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.klist = klist.p; a.kcap = kcap; a.nk = knk.p;
   a.cw_off = cw_off.p; a.cw_n = cw_n.p; a.cw_base = cw_base.p; a.wsum = wsum.p; a.wscan = wscan.p;
   a.qi_cnt = qi_cnt.p; a.qi_cur = qi_cur.p; a.qi_off = qi_off.p; a.qi_ent = qi_ent.p;
-  a.tq = tq.p; a.minm = minm.p; a.hist2 = hist2.p; a.ncand = ncand.p; a.ntop = ntop.p; a.ovf = ovf.p; a.cntx = cntx.p;
+  a.tq = tq.p; a.minm = minm.p; a.tkey = tkey.p; a.ncand = ncand.p; a.ntop = ntop.p; a.ovf = ovf.p; a.cntx = cntx.p;
   a.state = state.p; a.rejects = rejects.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.acc_id = acc_id.p;
   a.sel = sel.p; a.selm = selm.p; a.sel_short = sel_short.p; a.selkey = selkey.p; a.selpid = selpid.p;
   a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
@@ -1039,10 +1039,10 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
       const int c1 = std::min(C, c0 + step);
       launch_cl_stream(a, c0, c1, 1, ctx->st);
       stream_launches++;
-      if (c1 < C) launch_cl_thresh(a, ctx->st);
+      if (c1 < C) launch_cl_topk(a, 0, ctx->st);              // cut the lists back to their 32 best, raise the thresholds
       c0 = c1;
     }
-    launch_cl_topk(a, ctx->st);
+    launch_cl_topk(a, 1, ctx->st);
     launch_cl_init(a, ctx->st);
     if (C > 0) launch_cl_walk(a, rows_per_lane, ctx->st);
     launch_cl_outcome(a, ctx->st);
@@ -1103,8 +1103,10 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(hipMemcpy(&naln, n_align.p, sizeof(naln), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&nskip, n_skipped.p, sizeof(nskip), hipMemcpyDeviceToHost));
   if (debug) {
-    unsigned long long ps[4] = {0, 0, 0, 0};
+    unsigned long long ps[16] = {0};
     (void)hipMemcpy(ps, pre_stats.p, sizeof(ps), hipMemcpyDeviceToHost);
+    if (ps[12]) fprintf(stderr, "[cluster] stream phases (clock ticks per centroid and workgroup): items %.0f, accumulate %.0f, scan %.0f, loop head %.0f; chunks of 8 entries per centroid %.0f\n",
+                        (double)ps[8] / ps[12], (double)ps[9] / ps[12], (double)ps[10] / ps[12], (double)ps[11] / ps[12], (double)ps[13] / ps[12]);
     fprintf(stderr, "[cluster] certificate: not applicable %llu, bound too weak %llu, path exists %llu, proven reject %llu; full alignments %llu\n", ps[0], ps[1], ps[2], ps[3], naln);
   }
   ctx->stats.ms_cluster = tm.stop();

@@ -51,8 +51,8 @@ struct ClusterArgs {
   // the window's query index: word -> the (query strand) byte offsets 4 * qs that hold it, each list padded to 8 entries with the
   // dummy offset 4 * QS_MAX
   int32_t *qi_cnt, *qi_cur, *qi_off; uint16_t *qi_ent;   // [65537], [65536], [65537], [qi_off[65536]]
-  uint16_t *tq, *minm;          // [2 nq] appending threshold of the streaming pass (a lower bound of the 32nd best count) / min(12, words)
-  uint32_t *hist2;              // [2 nq][CL_HB] counts of the candidates appended so far (clipped at CL_HB - 1)
+  uint16_t *tq, *minm;          // [CL_QS_MAX + 8] count threshold of the streaming pass (the count in tkey, at least minm) / min(12, words); 0xFFFF = never
+  unsigned long long *tkey;     // [2 nq] rank key of the strand's 32nd best candidate so far (0: fewer than 32 yet)
   unsigned long long *cand; int32_t *ncand; int32_t ccap; int32_t *ovf;   // appended candidate keys [2 nq][ccap]; ovf[0] = a list overflowed
   int32_t *ntop;                // [2 nq] candidates in sel/selkey (<= 32, rank order): the whole walk's candidate list
   uint16_t *cntx; int32_t xpitch;   // shared-word counts against the window's speculative centroids [2 nq][xpitch]
@@ -80,13 +80,11 @@ struct ClusterArgs {
   unsigned long long *pre_stats;                 // [4] certificate outcomes: not applicable, bound too weak, a path exists, proven reject
   int32_t pre_k;                                 // largest edit budget K of this run (sizes the certificate's LDS rows)
 };
-constexpr int CL_HB = 1024;      // bins of hist2
 constexpr int CL_QS_MAX = 8192;  // query strands of one window (2 x the largest window)
 void launch_cl_kmers(const ClusterArgs &a, hipStream_t st);
 void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st);
 void launch_cl_stream(const ClusterArgs &a, int c0, int c1, int mode, hipStream_t st);      // mode 1: the old centroids [c0, c1); mode 2: the window's speculative ones
-void launch_cl_thresh(const ClusterArgs &a, hipStream_t st);
-void launch_cl_topk(const ClusterArgs &a, hipStream_t st);
+void launch_cl_topk(const ClusterArgs &a, int final, hipStream_t st);
 void launch_cl_init(const ClusterArgs &a, hipStream_t st);
 void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st);
 void launch_cl_outcome(const ClusterArgs &a, hipStream_t st);

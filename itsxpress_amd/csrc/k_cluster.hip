@@ -28,11 +28,11 @@
 //    words (kept per centroid, append-only) and adds into a histogram over the window's query strands in LDS (32 KB): the
 //    work per (query strand, centroid) is the number of words they actually SHARE (2-3 on amplicons: the chance shares of
 //    random spacer words plus the conserved motifs) instead of the query's ~380 words x 6 bit-sliced operations;
-//  * a strand's count is looked at only where it can still matter: every strand carries a threshold tq (a lower bound of
-//    its 32nd best count so far, from a histogram of the candidates appended so far, refreshed between chunks of
-//    centroids); counts >= tq are appended to the strand's candidate list with their rank key, everything else is dropped;
-//  * k_cl_topk sorts out the 32 best keys of each list: the walk's whole candidate list (maxaccepts 1 + maxrejects 32 never
-//    tries more), in exactly the order the count matrix gave.
+//  * a strand's count is looked at only where it can still matter: every strand carries a threshold (the rank key of its
+//    32nd best candidate so far, refreshed between chunks of centroids, and that key's count for the quick test); a
+//    centroid whose key beats it is appended to the strand's candidate list, everything else is dropped;
+//  * k_cl_topk cuts each list back to its 32 best keys between chunks, and after the last chunk that list is the walk's
+//    whole candidate list (maxaccepts 1 + maxrejects 32 never tries more), in exactly the order the count matrix gave.
 // The speculative centroids of the window are streamed the same way against the window's strands (mode 2) into a small
 // [strands][window] count array for the validation step.  The result is the same candidate order as before, bit for bit.
 // The alignment is one wave per (query, candidate): lane l owns S consecutive DP rows, columns advance as an
@@ -189,7 +189,7 @@ __global__ void k_cl_qi_fill_dummy(ClusterArgs a)
   const int n = a.qi_off[65536];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a.qi_ent[i] = (uint16_t)(CL_QS_MAX * 4);
 }
-// per strand: min(12, words) and the starting threshold; the candidate lists start empty
+// per strand: min(12, words) = the starting count threshold; the candidate lists start empty
 __global__ void k_cl_tq_init(ClusterArgs a)
 {
   const int qs = blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,22 +198,32 @@ __global__ void k_cl_tq_init(ClusterArgs a)
   const bool own = a.canon[qs >> 1] == (qs >> 1);
   const int n = own ? a.nk[qs] : 0;
   const uint16_t m = n > 0 ? (uint16_t)(n < 12 ? n : 12) : (uint16_t)0xFFFF;
-  a.minm[qs] = m; a.tq[qs] = m; a.ncand[qs] = 0; a.ntop[qs] = 0;
+  a.minm[qs] = m; a.tq[qs] = m; a.tkey[qs] = 0ULL; a.ncand[qs] = 0; a.ntop[qs] = 0;
 }
 
 // ------------------------------------------------------------------ the centroids stream past the window
 // One workgroup, one centroid at a time.  items[] = pieces (<= 8 x 8 entries) of the word lists the centroid touches, so that
 // a conserved word held by thousands of strands is spread over the threads instead of serialising one of them.
-static constexpr int CL_ITEMS = 6144;
-__device__ __forceinline__ void cl_add8(uint32_t *hist, const uint4 v)
+static constexpr int CL_ITEMS = 4096;
+// Eight entries (one 16-byte load) of a word's list go into the histogram.  The lists of a centroid's words are nearly the
+// SAME list when the window holds reads of the centroid's own family (every one of those strands has every one of those
+// words), and they are filled in nearly the same order, so lanes that walk 64 of them in step would hit ONE address per
+// instruction: LDS atomics to one address are serialised, 64 deep.  Every lane therefore starts its piece at its own chunk
+// (chunk order rotated by `rot & 7` in the caller) and rotates the eight entries of a chunk by `rot >> 3`.
+__device__ __forceinline__ void cl_add8(uint32_t *hist, uint4 v, uint32_t r)
 {
   char *h = reinterpret_cast<char *>(hist);
-  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.x & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.x >> 16)), 1u);
-  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.y & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.y >> 16)), 1u);
-  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.z & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.z >> 16)), 1u);
-  atomicAdd(reinterpret_cast<uint32_t *>(h + (v.w & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (v.w >> 16)), 1u);
+  if (r & 4u) { const uint32_t t0 = v.x, t1 = v.y; v.x = v.z; v.y = v.w; v.z = t0; v.w = t1; }
+  if (r & 2u) { const uint32_t t0 = v.x; v.x = v.y; v.y = v.z; v.z = v.w; v.w = t0; }
+  const uint32_t sh = (r & 1u) * 16u;
+  const uint32_t x = __builtin_amdgcn_alignbit(v.y, v.x, sh), y = __builtin_amdgcn_alignbit(v.z, v.y, sh),
+                 z = __builtin_amdgcn_alignbit(v.w, v.z, sh), w = __builtin_amdgcn_alignbit(v.x, v.w, sh);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (x & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (x >> 16)), 1u);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (y & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (y >> 16)), 1u);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (z & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (z >> 16)), 1u);
+  atomicAdd(reinterpret_cast<uint32_t *>(h + (w & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (w >> 16)), 1u);
 }
-__global__ __launch_bounds__(256) void k_cl_stream(ClusterArgs a, int c0, int c1, int mode)
+__global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int c1, int mode)
 {
   __shared__ uint32_t hist[CL_QS_MAX + 8];
   __shared__ uint32_t items[CL_ITEMS];
@@ -221,127 +231,137 @@ __global__ __launch_bounds__(256) void k_cl_stream(ClusterArgs a, int c0, int c1
   const int tid = threadIdx.x;
   const int nqs = 2 * a.nq;
   const int nrounds = (nqs + 1023) >> 10;                    // a thread scans strands (j * 256 + tid) * 4 .. + 3, j < nrounds
-  const uint16_t *thr = mode == 2 ? a.minm : a.tq;
-  uint32_t T[32];
-#pragma unroll
-  for (int j = 0; j < 8; j++)
-#pragma unroll
-    for (int e = 0; e < 4; e++) { const int qs = (j * 256 + tid) * 4 + e; T[j * 4 + e] = (j < nrounds && qs < nqs) ? (uint32_t)thr[qs] : 0xffffffffu; }
+  // count thresholds, four strands (one 8-byte load) at a time; they only change between launches.  The arrays are
+  // allocated for the largest window and the launcher sets every entry past the window's end to 0xFFFF (never reached),
+  // so the scan needs no bound check.
+  const uint2 *thr = reinterpret_cast<const uint2 *>(mode == 2 ? a.minm : a.tq);
   for (int i = tid; i < CL_QS_MAX + 8; i += 256) hist[i] = 0u;
   if (mode == 2) { const int lim = a.C + a.new_rank[a.nq]; c1 = c1 < lim ? c1 : lim; }
   const uint4 *ent = reinterpret_cast<const uint4 *>(a.qi_ent);
   __syncthreads();
+#ifdef ITSX_CL_PROF
+  long long tp[4] = {0, 0, 0, 0}, tn = 0, tadd = 0;
+#define CLK(i) { const long long now_ = (long long)__builtin_readcyclecounter(); tp[i] += now_ - tlast; tlast = now_; }
+  long long tlast = (long long)__builtin_readcyclecounter();
+#else
+#define CLK(i)
+#endif
   for (int c = c0 + blockIdx.x; c < c1; c += gridDim.x) {
     const int n = a.cw_n[c];
     if (n == 0) continue;                                     // a rolled-back column
     const uint16_t *cw = a.cw_pool + a.cw_off[c];
     if (tid == 0) n_items = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-      const uint32_t w = cw[i];
-      int s = a.qi_off[w] >> 3, nch = (a.qi_off[w + 1] >> 3) - s;
+    CLK(3)
+    for (int i0 = 0; i0 < n; i0 += 256) {                     // (wave-uniform trip count: the shuffles below need every lane)
+      const int i = i0 + tid;
+      int s = 0, nch = 0;
+      if (i < n) { const uint32_t w = cw[i]; s = a.qi_off[w] >> 3; nch = (a.qi_off[w + 1] >> 3) - s; }
+      // slots for this word's pieces: a prefix sum over the wave and ONE atomic per wave (one per piece on one LDS address
+      // serialised ~2 300 returning atomics per centroid: 55 k clock ticks, as long as the additions themselves)
+      const int np = (nch + 7) >> 3;
+      int incl = np;
+      for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((tid & 63) >= off) incl += o; }
+      int base = 0;
+      if ((tid & 63) == 63) base = atomicAdd(&n_items, incl);
+      base = __shfl(base, 63);
+      int slot = base + incl - np;
       while (nch > 0) {
         const int take = nch < 8 ? nch : 8;
-        const int slot = atomicAdd(&n_items, 1);
         if (slot < CL_ITEMS) items[slot] = ((uint32_t)s << 3) | (uint32_t)(take - 1);
-        else for (int k = 0; k < take; k++) cl_add8(hist, ent[s + k]);                  // list full (very long reads): the piece is added here
-        s += take; nch -= take;
+        else for (int k = 0; k < take; k++) cl_add8(hist, ent[s + k], 0u);              // list full (very long reads): the piece is added here
+        s += take; nch -= take; slot++;
       }
     }
     __syncthreads();
+    CLK(0)
     const int ni = n_items < CL_ITEMS ? n_items : CL_ITEMS;
+#ifdef ITSX_CL_PROF
+    tn++; tadd += ni;
+#endif
     for (int it = tid; it < ni; it += 256) {
       const uint32_t x = items[it];
       const int s = (int)(x >> 3), take = (int)(x & 7u) + 1;
-      for (int k = 0; k < take; k++) cl_add8(hist, ent[s + k]);
+      // all (up to 8) loads of the piece are in flight before the first is used: the lists come from L2 / MALL at ~1 us a
+      // round trip, and a load -> wait -> add loop pays that once per 16 bytes (measured: 75 us per centroid and workgroup)
+      // ... in a lane-private order (chunk tid & 7 first, entries rotated by tid >> 3: 64 different starts in a wave), see cl_add8
+      uint4 v[8];
+      const int r0 = (tid & 7) % take;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (k < take) { int idx = k + r0; idx = idx >= take ? idx - take : idx; v[k] = ent[s + idx]; }
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (k < take) cl_add8(hist, v[k], (uint32_t)tid >> 3);
     }
     __syncthreads();
+    CLK(1)
     const int32_t clen = a.cent_len[c], cpos = a.cent_pos[c];
+#pragma unroll 1
+    for (int j = 0; j < nrounds; j++) {
+      const int base = (j * 256 + tid) * 4;
+      const uint2 t2 = thr[base >> 2];
+      const uint4 v = *reinterpret_cast<const uint4 *>(&hist[base]);
+      *reinterpret_cast<uint4 *>(&hist[base]) = make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t tt[4] = {t2.x & 0xffffu, t2.x >> 16, t2.y & 0xffffu, t2.y >> 16};
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      if (j < nrounds) {
-        const int base = (j * 256 + tid) * 4;
-        const uint4 v = *reinterpret_cast<const uint4 *>(&hist[base]);
-        *reinterpret_cast<uint4 *>(&hist[base]) = make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          if (vv[e] >= T[j * 4 + e]) {
-            const int qs = base + e;
-            if (mode == 2) a.cntx[(size_t)qs * a.xpitch + (c - a.C)] = (uint16_t)vv[e];
-            else {
+      for (int e = 0; e < 4; e++) {
+        if (vv[e] >= tt[e]) {
+          const int qs = base + e;
+          if (mode == 2) a.cntx[(size_t)qs * a.xpitch + (c - a.C)] = (uint16_t)vv[e];
+          else {
+            const u64 key = cand_key(vv[e], clen, cpos);
+            if (key > a.tkey[qs]) {                            // ties at the threshold count are cut by length and position
               const int slot = atomicAdd(&a.ncand[qs], 1);
-              if (slot < a.ccap) a.cand[(size_t)qs * a.ccap + slot] = cand_key(vv[e], clen, cpos);
-              atomicAdd(&a.hist2[(size_t)qs * CL_HB + (vv[e] < (uint32_t)(CL_HB - 1) ? vv[e] : (uint32_t)(CL_HB - 1))], 1u);
+              if (slot < a.ccap) a.cand[(size_t)qs * a.ccap + slot] = key;
             }
           }
         }
       }
     }
     __syncthreads();
+    CLK(2)
   }
+#ifdef ITSX_CL_PROF
+  if (tid == 0 && mode == 1) { for (int i = 0; i < 4; i++) atomicAdd(&a.pre_stats[8 + i], (unsigned long long)tp[i]); atomicAdd(&a.pre_stats[12], (unsigned long long)tn); atomicAdd(&a.pre_stats[13], (unsigned long long)tadd); }
+#endif
 }
 
-// between two chunks of centroids: tq = the largest t with at least 32 appended candidates of count >= t (every candidate
-// of count >= the current tq has been appended and counted, so the sum is exact there); tq never goes down
-__global__ __launch_bounds__(256) void k_cl_thresh(ClusterArgs a)
+// Between two chunks of centroids (final = 0) and after the last one (final = 1): the 32 best keys of the strand's list, in
+// rank order, replace the list; the 32nd becomes the strand's threshold (key, and its count for the quick test).  After the
+// last chunk that list IS the candidate list of the whole walk (maxaccepts 1 + maxrejects 32 never tries more): its columns
+// are looked up by position.  One wave per strand.
+__global__ __launch_bounds__(64) void k_cl_topk(ClusterArgs a, int final)
 {
-  const int qs = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (qs >= 2 * a.nq) return;
-  if (a.ncand[qs] < 32) return;
-  const uint32_t *h = a.hist2 + (size_t)qs * CL_HB;
-  constexpr int PER = CL_HB / 64;
-  const int top = CL_HB - 1 - lane * PER;                   // lane 0 holds the highest bins
-  uint32_t b[PER], s = 0;
-#pragma unroll
-  for (int k = 0; k < PER; k++) { b[k] = h[top - k]; s += b[k]; }
-  uint32_t incl = s;
-  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
-  const unsigned long long reach = __ballot(incl >= 32u);
-  if (reach == 0ULL) return;
-  const int first = __ffsll((long long)reach) - 1;
-  if (lane != first) return;
-  uint32_t run = incl - s;
-  int t = top;
-#pragma unroll
-  for (int k = 0; k < PER; k++) { run += b[k]; if (run >= 32u) { t = top - k; break; } }
-  if ((uint32_t)t > (uint32_t)a.tq[qs]) a.tq[qs] = (uint16_t)t;
-}
-
-// the 32 best keys of each strand's list, in rank order: the candidate list of the whole walk
-__global__ __launch_bounds__(256) void k_cl_topk(ClusterArgs a)
-{
-  __shared__ unsigned long long red[4];
-  __shared__ unsigned long long bestk;
-  const int qs = blockIdx.x, tid = threadIdx.x;
+  __shared__ unsigned long long top[32];
+  const int qs = blockIdx.x, lane = threadIdx.x;
   int n = a.ncand[qs];
-  if (n > a.ccap) { if (tid == 0) a.ovf[0] = 1; n = a.ccap; }
-  const unsigned long long *keys = a.cand + (size_t)qs * a.ccap;
+  if (n > a.ccap) { if (lane == 0) a.ovf[0] = 1; n = a.ccap; }
+  if (!final && n <= 32) return;                              // nothing to cut yet
+  unsigned long long *keys = a.cand + (size_t)qs * a.ccap;
   unsigned long long lim = ~0ULL;
   int m = 0;
   for (; m < 32 && m < n; m++) {
     unsigned long long best = 0;
-    for (int i = tid; i < n; i += 256) { const unsigned long long k = keys[i]; if (k < lim && k > best) best = k; }
+    for (int i = lane; i < n; i += 64) { const unsigned long long k = keys[i]; if (k < lim && k > best) best = k; }
     for (int off = 32; off; off >>= 1) { const unsigned long long o = __shfl_xor(best, off); best = o > best ? o : best; }
-    if ((tid & 63) == 0) red[tid >> 6] = best;
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long b = red[0];
-      for (int i = 1; i < 4; i++) b = red[i] > b ? red[i] : b;
-      bestk = b;
-      if (b) {
-        const int32_t pos = (int32_t)(0xffffffffu - (uint32_t)(b & 0xffffffffu));
-        int lo = 0, hi = a.C - 1;                             // cent_pos grows with the column index
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cent_pos[mid] < pos) lo = mid + 1; else hi = mid; }
-        a.sel[qs * 32 + m] = lo; a.selkey[qs * 32 + m] = b;
-      }
-    }
-    __syncthreads();
-    lim = bestk;
-    if (lim == 0ULL) break;
-    __syncthreads();
+    if (best == 0ULL) break;
+    if (lane == 0) top[m] = best;
+    lim = best;
   }
-  if (tid == 0) a.ntop[qs] = m;
+  __syncthreads();
+  if (lane < m) keys[lane] = top[lane];
+  if (lane == 0) {
+    a.ncand[qs] = m;
+    if (m == 32) { a.tkey[qs] = top[31]; const uint16_t c = (uint16_t)(top[31] >> 48); if (c > a.tq[qs]) a.tq[qs] = c; }
+    if (final) a.ntop[qs] = m;
+  }
+  if (final && lane < m) {
+    const unsigned long long b = top[lane];
+    const int32_t pos = (int32_t)(0xffffffffu - (uint32_t)(b & 0xffffffffu));
+    int lo = 0, hi = a.C - 1;                                 // cent_pos grows with the column index
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.cent_pos[mid] < pos) lo = mid + 1; else hi = mid; }
+    a.sel[qs * 32 + lane] = lo; a.selkey[qs * 32 + lane] = b;
+  }
 }
 
 // ------------------------------------------------------------------ the candidate walk
@@ -900,16 +920,17 @@ void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st)
   launch_exclusive_scan(a.qi_cnt, a.qi_off, 65537, scan_tmp, st);
   hipLaunchKernelGGL(k_cl_qi_fill_dummy, dim3(1024), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_cl_qi_count, dim3(2 * a.nq), dim3(256), 0, st, a, 1);
+  // strands past the window's end never reach a threshold (k_cl_stream scans four strands per load without a bound check)
+  (void)hipMemsetAsync(a.tq, 0xff, (size_t)(CL_QS_MAX + 8) * sizeof(uint16_t), st);
+  (void)hipMemsetAsync(a.minm, 0xff, (size_t)(CL_QS_MAX + 8) * sizeof(uint16_t), st);
   hipLaunchKernelGGL(k_cl_tq_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
-  (void)hipMemsetAsync(a.hist2, 0, (size_t)2 * a.nq * CL_HB * sizeof(uint32_t), st);
 }
 void launch_cl_stream(const ClusterArgs &a, int c0, int c1, int mode, hipStream_t st)
 {
   if (c1 <= c0) return;
   hipLaunchKernelGGL(k_cl_stream, dim3(std::min(c1 - c0, 768)), dim3(256), 0, st, a, c0, c1, mode);
 }
-void launch_cl_thresh(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_thresh, dim3((2 * a.nq + 3) / 4), dim3(256), 0, st, a); }
-void launch_cl_topk(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_topk, dim3(2 * a.nq), dim3(256), 0, st, a); }
+void launch_cl_topk(const ClusterArgs &a, int final, hipStream_t st) { hipLaunchKernelGGL(k_cl_topk, dim3(2 * a.nq), dim3(64), 0, st, a, final); }
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
 static size_t precheck_lds(const ClusterArgs &a)
 {
@@ -926,6 +947,7 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
     const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
     if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 0);
     if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), lds, st, a);
+    else if (rows_per_lane <= 8) hipLaunchKernelGGL(k_cl_align<8>, dim3(grid), dim3(64), lds, st, a);
     else hipLaunchKernelGGL(k_cl_align<10>, dim3(grid), dim3(64), lds, st, a);
     hipLaunchKernelGGL(k_cl_walk, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a, round);
     hipLaunchKernelGGL(k_cl_reset_work, dim3(1), dim3(1), 0, st, a, 0);
@@ -941,6 +963,7 @@ void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
   if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 1);
   if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(grid), dim3(64), lds, st, a);
+  else if (rows_per_lane <= 8) hipLaunchKernelGGL(k_cl_align_x<8>, dim3(grid), dim3(64), lds, st, a);
   else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(grid), dim3(64), lds, st, a);
   hipLaunchKernelGGL(k_cl_resolve, dim3(1), dim3(64), 0, st, a);
 }

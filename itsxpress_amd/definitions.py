@@ -32,6 +32,19 @@ def _find_root() -> str:
 
 ROOT_DIR: str = _find_root()
 
+
+def hmm_path(taxon: str = "Fungi"):
+    """Path of a taxon's profile file (`ITSx_db/HMMs/<letter>.hmm` under $ITSXPRESS_DB_DIR, an installed `itsxpress`
+    package or this package), or None when it is not there.  `F.hmm` -- the Fungi set every BASELINE config names -- is
+    absent from the reference mount this engine was built against; tests/test_fungi_pin.py and bench.py switch to it the
+    moment this returns a path.  Looked up at call time, so a test may set ITSXPRESS_DB_DIR first."""
+    fn = taxa_dict.get(taxon, taxon)
+    for root in (_find_root(), ROOT_DIR):
+        p = os.path.join(root, "ITSx_db", "HMMs", fn)
+        if os.path.isfile(p) and os.path.getsize(p) > 0:
+            return p
+    return None
+
 _TAXA = [("Alveolata", "A"), ("Bryophyta", "B"), ("Bacillariophyta", "C"), ("Amoebozoa", "D"),
          ("Euglenozoa", "E"), ("Fungi", "F"), ("Chlorophyta", "G"), ("Rhodophyta", "H"),
          ("Phaeophyceae", "I"), ("Marchantiophyta", "L"), ("Metazoa", "M"), ("Oomycota", "O"),

@@ -5,6 +5,7 @@ writes `<tempdir>/runtime_selected.hmm` holding, in source order, every model wh
 starts with one of the region's prefixes.  File order matters downstream: ItsPosition keeps
 the FIRST strictly-highest score, so equal scores are won by the earlier profile.
 """
+import logging
 import os
 
 REGION_PREFIXES = {"ITS2": ("3_", "4_"), "ITS1": ("1_", "2_"), "ALL": ("1_", "4_")}
@@ -14,7 +15,11 @@ def select_profile_blocks(paths, region):
     """Yield the text of every selected model block from the given HMMER3/f files."""
     prefixes = REGION_PREFIXES.get(region, ("1_", "2_", "3_", "4_"))
     for path in paths:
-        if not os.path.exists(path):      # the reference skips a missing taxon file silently
+        if not os.path.exists(path):
+            # the reference skips a missing taxon file silently (main.py:214-215), which turns `--taxa Fungi` into an EMPTY
+            # runtime_selected.hmm and a run that trims nothing; same result here, but not silently
+            logging.warning("create_runtime_hmm: profile file %s not found: no profiles selected from it "
+                            "(set ITSXPRESS_DB_DIR to a directory that holds ITSx_db/HMMs)", path)
             continue
         with open(path, "r") as fh:
             block, keep = [], False

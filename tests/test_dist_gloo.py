@@ -203,10 +203,21 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    rec = json.loads(lines[0])
+
+    def run(*flags):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"] + list(flags), env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    # the driver passes only --gpus N: that must be the honest curve, configs[2]'s 10 M reads sharded over the ranks (strong scaling)
+    rec = run()
     assert rec["n_gpus"] == 2 and rec["ok"] is True
+    assert rec["scaling"] == "strong" and rec["total_reads"] == 10000000 and rec["reads_rank0"] == 5000000 and rec["reads_all_ranks"] == 10000000
+    # weak scaling is opt-in
+    rec = run("--weak")
+    assert rec["scaling"] == "weak" and rec["reads_rank0"] == 10000000 and rec["reads_all_ranks"] == 20000000
+    rec = run("--total-reads", "3000001")
+    assert rec["scaling"] == "strong" and rec["reads_all_ranks"] == 3000001

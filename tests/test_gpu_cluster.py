@@ -81,10 +81,10 @@ def test_cluster_matches_oracle(engine, cid):
     assert 60 <= o["n_centroids"] < 3000 and (o["strand"] < 0).sum() > 100
 
 
-def test_cluster_fused_best_key_path(engine, monkeypatch):
-    # large centroid sets take round 0's candidate from the counting pass (best0) instead of a scan of the count row;
-    # forced here on a small library
-    monkeypatch.setenv("ITSX_CL_BEST0", "1")
+def test_cluster_candidate_lists_grow_when_they_overflow(engine, monkeypatch):
+    # a strand's candidate list holds what one chunk of centroids can append (4096 keys); forced tiny here: the window is
+    # searched again with lists four times the size until nothing overflows, and the outcome is the oracle's all the same
+    monkeypatch.setenv("ITSX_CL_CCAP", "40")
     reads, names = _noisy_library(41, 1500, 30, (200, 260), n_rate=0.01)
     _compare(engine, reads, names, 0.985)
 
@@ -135,7 +135,7 @@ def test_cluster_multipass_alignment(engine, monkeypatch):
 
 
 def test_cluster_index_growth(engine, monkeypatch):
-    # more centroids than the initial column capacity of the bit matrix: the index is re-laid out (twice) on the way
+    # more centroid words than the initial capacity of the word pool: the pool is doubled (with a copy) on the way
     monkeypatch.setenv("ITSX_CL_CAPACITY", "2048")
     rng = np.random.default_rng(5)
     acgt = np.array(list("ACGT"))

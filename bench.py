@@ -525,6 +525,8 @@ def main():
                     args.cpu_sample = min(args.cpu_sample, 6000)
                 room = args.budget_s - (time.time() - T_START) - 20.0     # ~25 s of CPU work, less when the budget is nearly spent
                 args.cpu_sample = int(max(8192 if threads >= 64 else 600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
+                if args.cluster_id < 1.0:                # ... and quadratic: 8 192 reads took 120 s, 3 000 take ~15 s
+                    args.cpu_sample = min(args.cpu_sample, 3000)
             m = min(args.cpu_sample, n_local)
             progress("CPU baseline on %d reads, %d threads" % (m, threads))
             v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads, lp, rp, args.cluster_id)

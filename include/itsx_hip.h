@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ITSX_ABI_VERSION 1
+#define ITSX_ABI_VERSION 2      /* 2: itsx_stats grew (n_mr_fail_kind), itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
 
 enum {
   ITSX_OK            =  0,
@@ -102,6 +102,12 @@ typedef struct {
   int64_t n_mr_distinct;     /* distinct (profile, target length, residues) multidomain regions actually sampled */
   int64_t n_slab_shrinks;    /* times the DP slab budget was halved because the device could not supply it */
   float   ms_vit_kernel;     int32_t pad4;               /* Viterbi filter (F2 < F1 only) */
+  /* multidomain regions of the last search that ran into a bookkeeping limit hmmsearch does not have, by kind: [1] matrix not
+   * sampleable, [2] more than 8 domains in one sampled path, [4] more than 512 distinct sampled (i, j, k, m) tuples, [5] a
+   * path left the region, [7] more than 4 envelopes in one region ([3], [6] cannot occur: see k_api.h).  Such a region is
+   * kept as one envelope (flagged); n_domain_overflow counts the (representative, profile) pairs with more than 8 envelopes.
+   * Any of these makes itsx_search return ITSX_E_UNSUPPORTED unless the environment holds ITSX_ALLOW_CAPS=1. */
+  int64_t n_mr_fail_kind[8];
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -225,7 +231,9 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE);
 int64_t itsx_num_domains(const itsx_ctx *ctx);
 int itsx_get_domains(const itsx_ctx *ctx, itsx_domain *rows /* [itsx_num_domains] */);
 int64_t itsx_num_pairtraces(const itsx_ctx *ctx);
-int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows);
+/* row_size = sizeof(itsx_pairtrace) as the CALLER was compiled: a library built from other sources is refused (ITSX_E_ARG) instead of
+ * writing rows of another stride */
+int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows, int64_t row_size);
 
 /* ---- a5/a6/a7: ItsPosition.parse/_score/get_position (itsxpress/SeqSample.py:400-498)
  * composed with Dedup.matchdict: per READ, start = left.env_to, stop = right.env_from - 1,
@@ -262,7 +270,8 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path);
  * offsets only (offsets[n_reads] = bytes needed). */
 int itsx_get_read_names(const itsx_ctx *ctx, char *names, int64_t cap, int64_t *offsets);
 
-int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out);
+/* out_size = sizeof(itsx_stats) as the caller was compiled (checked, like itsx_get_pairtraces' row_size) */
+int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out, int64_t out_size);
 
 /* ---- f1 ("next"): native FASTQ parse -> slice -> write.  Host-only and context-free.
  * itsx_write_trimmed_fastq replaces Dedup.create_trimmed_seqs (itsxpress/SeqSample.py:886-949): record i of

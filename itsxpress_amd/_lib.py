@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitsx_hip.so")
+ABI_VERSION = 2          # include/itsx_hip.h: ITSX_ABI_VERSION
 _LIB = None
 
 
@@ -47,7 +48,8 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("pad1", "<i4"), ("cl_certified", "<i8"), ("ms_pack", "<f4"), ("pad2", "<i4"),
                 ("n_uniq_multi_winner", "<i8"), ("n_reads_multi_winner", "<i8"), ("n_uniq_region_cap", "<i8"),
                 ("n_reads_region_cap", "<i8"), ("n_mr_clustered", "<i8"), ("n_mr_failed", "<i8"), ("n_mr_envelopes", "<i8"),
-                ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8"), ("ms_vit_kernel", "<f4"), ("pad4", "<i4")]
+                ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8"), ("ms_vit_kernel", "<f4"), ("pad4", "<i4"),
+                ("n_mr_fail_kind", "<i8", (8,))]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares
@@ -116,13 +118,13 @@ def lib():
         "itsx_num_domains": (i64, [vp]),
         "itsx_get_domains": (i32, [vp, vp]),
         "itsx_num_pairtraces": (i64, [vp]),
-        "itsx_get_pairtraces": (i32, [vp, vp]),
+        "itsx_get_pairtraces": (i32, [vp, vp, i64]),
         "itsx_trim_coords": (i32, [vp, cp, cp, vp, vp, vp, vp]),
         "itsx_rep_coords": (i32, [vp, cp, cp, vp, vp, vp, vp]),
         "itsx_write_uc": (i32, [vp, cp]),
         "itsx_write_rep_fasta": (i32, [vp, cp]),
         "itsx_write_domtbl": (i32, [vp, cp]),
-        "itsx_get_stats": (i32, [vp, vp]),
+        "itsx_get_stats": (i32, [vp, vp, i64]),
         "itsx_debug_read_hashes": (i32, [vp, vp, vp]),
         "itsx_debug_packed_read": (i32, [vp, i64, vp, vp, vp, vp]),
         "itsx_debug_detmath": (i32, [vp, vp, i64, vp, vp]),
@@ -146,7 +148,7 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.itsx_abi_version() != 1:
-        raise EngineError(-1, "ABI version mismatch")
+    if L.itsx_abi_version() != ABI_VERSION:
+        raise EngineError(-1, "ABI version mismatch: %s reports %d, this package binds version %d" % (LIB_PATH, L.itsx_abi_version(), ABI_VERSION))
     _LIB = L
     return L

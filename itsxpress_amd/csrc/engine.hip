@@ -1216,7 +1216,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.ms_vit_kernel = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.ms_vit_kernel = 0; for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
   if (U == 0) return ITSX_OK;
@@ -1296,6 +1296,19 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   for (size_t p = 0; p < dz32.size(); p++) ctx->domz[p] = dz32[p];
+  // Refuse, don't cap: hmmsearch has no limit on envelopes per target or on the bookkeeping of a region's traceback ensemble.
+  // A search that ran into one of this engine's limits would silently differ from the reference's result on those reads
+  // (concatemers, long CCS reads with tandem copies), so it fails loudly; ITSX_ALLOW_CAPS=1 accepts the documented behaviour
+  // (the 8 first envelopes of a pair are kept, a region whose ensemble overran is kept as ONE envelope).
+  if ((S.n_domain_overflow > 0 || S.n_mr_failed > 0) && !(getenv("ITSX_ALLOW_CAPS") && atoi(getenv("ITSX_ALLOW_CAPS")) != 0)) {
+    ctx->have_search = false;
+    std::string why = "the search ran into a bookkeeping limit hmmsearch does not have:";
+    if (S.n_domain_overflow) why += " " + std::to_string(S.n_domain_overflow) + " (representative, profile) pair(s) with more than " + std::to_string(MAXDOM) + " envelopes;";
+    static const char *kind[8] = {"", "unsampleable matrix", "more than 8 domains in one sampled path", "", "more than 512 distinct sampled tuples", "path left the region", "", "more than 4 envelopes in one region"};
+    for (int k = 1; k < 8; k++) if (S.n_mr_fail_kind[k]) why += " " + std::to_string(S.n_mr_fail_kind[k]) + " multidomain region(s): " + kind[k] + ";";
+    why += " set ITSX_ALLOW_CAPS=1 to accept the capped result (itsx_stats counts the affected reads)";
+    SET_ERR(ctx, ITSX_E_UNSUPPORTED, why);
+  }
   return ITSX_OK;
 }
 
@@ -1618,14 +1631,15 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
         w0 = w1;
       }
       DBuf<int64_t> &d_c = ctx->w_counters;
-      HIPCHK(d_c.alloc(8));
-      HIPCHK(hipMemsetAsync(d_c.p, 0, 8 * sizeof(int64_t), st));
+      HIPCHK(d_c.alloc(16));
+      HIPCHK(hipMemsetAsync(d_c.p, 0, 16 * sizeof(int64_t), st));
       launch_mr_apply(ctx->d_pout.p, d_raw.p, NP, mroff.p, mru.p, ctx->w_mrout.p, (unsigned long long *)d_c.p, st);
-      int64_t hc[2] = {0, 0};
+      int64_t hc[10] = {0};
       HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
       S.ms_ensemble += tm_e.stop();
       HIPCHK(hipGetLastError());
       S.n_mr_clustered += NMR; S.n_mr_distinct += NU; S.n_mr_failed += hc[0]; S.n_mr_envelopes += hc[1];
+      for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] += hc[2 + k];
     }
   }
   // ---- compact regions into a profile-grouped list
@@ -1905,8 +1919,9 @@ int64_t itsx_num_pairtraces(const itsx_ctx *ctx)
   if (fetch_traces(ctx) != ITSX_OK) return -1;
   return (int64_t)ctx->h_trace.size();
 }
-int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows)
+int itsx_get_pairtraces(const itsx_ctx *ctx, itsx_pairtrace *rows, int64_t row_size)
 {
+  if (ctx && row_size != (int64_t)sizeof(itsx_pairtrace)) SET_ERR(ctx, ITSX_E_ARG, "itsx_get_pairtraces: the caller's rows have " + std::to_string(row_size) + " bytes, this library's " + std::to_string(sizeof(itsx_pairtrace)));
   CTXCHK(ctx && rows && ctx->have_search);
   const int rc = fetch_traces(ctx);
   if (rc != ITSX_OK) return rc;
@@ -2434,9 +2449,10 @@ int itsx_get_read_names(const itsx_ctx *ctx, char *names, int64_t cap, int64_t *
   return ITSX_OK;
 }
 
-int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out)
+int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out, int64_t out_size)
 {
   CTXCHK(ctx && out);
+  if (out_size != (int64_t)sizeof(itsx_stats)) SET_ERR(ctx, ITSX_E_ARG, "itsx_get_stats: the caller's itsx_stats has " + std::to_string(out_size) + " bytes, this library's " + std::to_string(sizeof(itsx_stats)) + " (header and library from different sources)");
   *out = ctx->stats;
   return ITSX_OK;
 }

@@ -218,7 +218,8 @@ constexpr int MR_LANES = 32;       // regions per wave: half-filled waves, twice
 constexpr int MR_MAXD = 8;         // domains in one sampled path
 constexpr int MR_TCAP = 512;       // distinct sampled (i, j, k, m) tuples per region
 constexpr int MR_SCAP = 200 * MR_MAXD;
-constexpr int MR_NSIG = 32;        // clusters that reach the posterior threshold
+constexpr int MR_NSIG = 32;        // clusters that reach the posterior threshold: each holds >= 50 of the <= 200 x MR_MAXD sampled domains, so 32 always suffice
+static_assert(MR_NSIG * 50 >= 200 * MR_MAXD, "MR_NSIG must hold every cluster that can reach 25 % of 200 paths");
 constexpr int MR_HASH = 1024;      // slots of the per-region tuple index (a power of two >= 2 MR_TCAP)
 constexpr int MR_EPC = 256;        // widest endpoint histogram kept as an array (wider ones are counted pairwise)
 constexpr int MR_SCRATCH = 19456;  // bytes of per-region bookkeeping (k_ensemble.hip: MrScratch)

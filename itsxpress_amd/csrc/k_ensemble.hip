@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
       out.ei[out.nenv] = S.sig_i[d]; out.ej[out.nenv] = S.sig_j[d]; out.nenv++;
     }
   }
-  if (status != 0) {              // a bookkeeping limit was hit: the region yields nothing, and says so
+  if (status != 0) {              // a bookkeeping limit was hit: no cluster envelopes (k_mr_apply keeps the region whole), and it says so
     out.nenv = 0;
     for (int pos = 0; pos < Lr; pos++) n2[pos] = 0.0f;
   }
@@ -627,6 +627,14 @@ __global__ void __launch_bounds__(256) k_mr_apply(PairOut *__restrict__ pout, Re
     if (!r.multi) { if (n < MAXDOM) tmp[n++] = r; else over = 1; continue; }
     const MrOut o = out[mr_u[mk]];
     nfail += o.status != 0; nenv += o.nenv;
+    if (o.status != 0) {
+      // the ensemble ran into a bookkeeping limit (hmmsearch has none; itsx_search refuses the call unless ITSX_ALLOW_CAPS=1):
+      // the region is kept the way it was before this stage existed -- ONE envelope, null2 by expectation -- instead of
+      // vanishing with the read's coordinates; multi < 0 = "a simple envelope that carries the multidomain flag"
+      atomicAdd(&counters[2 + (o.status & 7)], 1ULL);
+      RegionRec c = r; c.multi = -1;
+      if (n < MAXDOM) tmp[n++] = c; else over = 1;
+    }
     for (int z = 0; z < o.nenv; z++) {
       RegionRec c; c.pair = (int32_t)pi; c.ienv = o.ei[z] + r.ienv - 1; c.jenv = o.ej[z] + r.ienv - 1; c.multi = mk + 1;
       if (n < MAXDOM) tmp[n++] = c; else over = 1;

@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   // of a region kept as one envelope, and every envelope is a simple one
   const bool have_mr = a.mr != nullptr;
   auto env_dc = [&](const RegionRec &rg, const RegionOut &ro) {
-    if (!have_mr || rg.multi == 0) return ro.domcorrection;
+    if (!have_mr || rg.multi <= 0) return ro.domcorrection;      // (< 0: a region whose ensemble failed, kept as a simple envelope)
     const int m = rg.multi - 1;
     const float *n2 = a.n2sc + a.n2off[a.mr_u[m]];
     const int ireg = a.mr[m].ireg;
@@ -1123,7 +1123,7 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   for (int d = 0; d < nd_all; d++) {
     const RegionRec rg = a.regions[g0 + d];
     const RegionOut ro = a.rout[a.upos[g0 + d]];
-    if (!have_mr || rg.multi == 0) {
+    if (!have_mr || rg.multi <= 0) {
       while (mk < mr1 && a.mr[mk].ireg < rg.ienv) { seqbias = add_region(mk, seqbias); any = true; mk++; }
       if (ro.ok) {
         if (!any) seqbias = ro.domcorrection;              // first term: same sum, same order

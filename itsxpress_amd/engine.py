@@ -365,7 +365,7 @@ class Engine:
             raise EngineError(-1, self.L.itsx_last_error(self.h).decode())
         out = np.zeros(n, TRACE_DTYPE)
         if n:
-            self._chk(self.L.itsx_get_pairtraces(self.h, out.ctypes.data))
+            self._chk(self.L.itsx_get_pairtraces(self.h, out.ctypes.data, TRACE_DTYPE.itemsize))
         return out
 
     def _coords(self, fn, n, left, right):
@@ -392,8 +392,8 @@ class Engine:
 
     def stats(self):
         s = np.zeros(1, STATS_DTYPE)
-        self._chk(self.L.itsx_get_stats(self.h, s.ctypes.data))
-        return {k: s[0][k].item() for k in STATS_DTYPE.names}
+        self._chk(self.L.itsx_get_stats(self.h, s.ctypes.data, STATS_DTYPE.itemsize))
+        return {k: (s[0][k].item() if s[0][k].ndim == 0 else s[0][k].tolist()) for k in STATS_DTYPE.names}
 
     # ---- test hooks
     def debug_read_hashes(self):

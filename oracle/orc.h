@@ -182,4 +182,7 @@ void orc_orient(const uint8_t *dbbits, const uint8_t *codes, const int64_t *offs
 #ifdef __cplusplus
 }
 #endif
+/* multidomain regions that hit a bookkeeping limit, by kind (index = the engine's MrOut.status code); reset != 0 clears them */
+void orc_mr_fail_counts(long long *out, int reset);
+
 #endif

@@ -722,6 +722,18 @@ static int link_samples(const spcoord *h1, const spcoord *h2)
 
 /* region ireg..jreg of dsq[1..L]: fills n2sc[ireg..jreg] and returns the cluster envelopes (absolute coordinates),
  * ordered by start; ret < 0 if the ensemble could not be sampled (the region then yields no envelope) */
+/* regions that ran into one of the bookkeeping limits below, by kind (the engine's MrOut.status codes): 1 unsampleable matrix,
+ * 2 more than 8 domains in one path, 4 more than 512 distinct tuples, 6 more than 32 clusters, 7 more than 4 envelopes */
+static long long g_mr_fail_kind[8];
+void orc_mr_fail_counts(long long *out, int reset)
+{
+  for (int k = 0; k < 8; k++) { out[k] = g_mr_fail_kind[k]; if (reset) g_mr_fail_kind[k] = 0; }
+}
+static void mr_fail(int kind)
+{
+#pragma omp atomic
+  g_mr_fail_kind[kind]++;
+}
 static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L, int ireg, int jreg, workspace *w, int *env_i, int *env_j, int maxenv)
 {
   const int Q = p->Q, Lr = jreg - ireg + 1, nsamples = 200;
@@ -731,8 +743,9 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
   for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
   orc_rng rng; rng_init(&rng, 42);
   /* bookkeeping limits of the device kernel (k_ensemble.hip), mirrored so that both sides fail alike: at most 8 domains
-   * in one sampled path, 512 distinct (i, j, k, m) tuples, 32 reportable clusters, 4 envelopes per region; a region that
-   * exceeds one yields no envelope and no null2 correction (never seen so far; the engine counts such regions) */
+   * in one sampled path, 512 distinct (i, j, k, m) tuples, 32 reportable clusters (never binding: a reportable cluster holds
+   * >= 50 of the <= 200 x 8 sampled domains), 4 envelopes per region; a region that exceeds one returns -1: the caller keeps
+   * it as one envelope (the engine refuses the whole search unless ITSX_ALLOW_CAPS=1 and counts such regions by kind) */
   enum { MAXD = 8, TCAP = 512, NSIG = 32, MRENV = 4 };
   int dfrom[MAXD], dto[MAXD], dk[MAXD], dm[MAXD];
   float *cntM = (float *)malloc(sizeof(float) * MAXD * QMAX * 4 * 2), *cntI = cntM + MAXD * QMAX * 4;
@@ -742,7 +755,7 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
   int bad = 0;
   for (int t = 0; t < nsamples && !bad; t++) {
     const int nd = stochastic_trace(&rng, p, w->full, w->ef, Lr, pmove, ploop, dfrom, dto, dk, dm, cntM, cntI, MAXD);
-    if (nd < 0) { bad = 1; break; }
+    if (nd < 0) { bad = 1; mr_fail(nd == -2 ? 2 : nd == -3 ? 5 : 1); break; }
     int hi = Lr;                                   /* positions above hi have had their contribution of this trace */
     for (int d = 0; d < nd; d++) {                 /* domains last-first */
       if (n == cap) { cap *= 2; sp = (spcoord *)realloc(sp, sizeof(spcoord) * cap); }
@@ -790,7 +803,7 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
       for (int u = 0; u < h && !seen; u++) seen = sp[u].i == sp[h].i && sp[u].j == sp[h].j && sp[u].k == sp[h].k && sp[u].m == sp[h].m;
       ndist += !seen;
     }
-    if (ndist > TCAP) bad = 1;
+    if (ndist > TCAP) { bad = 1; mr_fail(4); }
   }
   if (bad) {
     for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
@@ -852,7 +865,7 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
     if (best_m < mmin) best_m = mmin + am;
 #undef HIST
     if (best_i > best_j || best_k > best_m) continue;
-    if (nsig >= NSIG) { bad = 1; break; }
+    if (nsig >= NSIG) { bad = 1; mr_fail(6); break; }
     sig[nsig].i = best_i; sig[nsig].j = best_j; sig[nsig].k = best_k; sig[nsig].m = best_m; sig[nsig].idx = c;
     sig[nsig].prob = (float)ninc / (float)nsamples;
     nsig++;
@@ -870,7 +883,7 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
       if ((float)nov / (float)nn >= 0.8f) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
     }
   int ne = 0;
-  for (int d = 0; d < nsig && !bad; d++) if (!dominated[d]) { if (ne >= MRENV || ne >= maxenv) { bad = 1; break; } env_i[ne] = sig[d].i; env_j[ne] = sig[d].j; ne++; }
+  for (int d = 0; d < nsig && !bad; d++) if (!dominated[d]) { if (ne >= MRENV || ne >= maxenv) { bad = 1; mr_fail(7); break; } env_i[ne] = sig[d].i; env_j[ne] = sig[d].j; ne++; }
   if (bad) { ne = -1; for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f; }
   free(dominated); free(epc); free(sig); free(comp); free(stack); free(cntM); free(sp);
   return ne;
@@ -976,6 +989,13 @@ static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uin
               domrec d;
               if (rescore_domain(p, dsq, L, ei[e], ej[e], 1, w, &d) == 0) doms[ndom++] = d;
             }
+          if (ne < 0 && ndom < 64) {
+            /* the ensemble ran into a bookkeeping limit (hmmsearch has none: the engine REFUSES such a search unless
+             * ITSX_ALLOW_CAPS=1): the region is then kept the way it was before the ensemble stage existed, as ONE envelope
+             * with null2 by expectation, flagged -- it no longer vanishes (a concatemer kept its coordinates that way) */
+            domrec d;
+            if (rescore_domain(p, dsq, L, i, j, 0, w, &d) == 0) { d.flags |= 1; doms[ndom++] = d; }
+          }
         } else if (ndom < 64) {
           domrec d;
           if (rescore_domain(p, dsq, L, i, j, 0, w, &d) == 0) {

@@ -302,3 +302,11 @@ def orient(db_seqs, seqs):
     cr = np.zeros(max(1, n), np.int32)
     lib().orc_orient(bits.ctypes.data, codes.ctypes.data, off.ctypes.data, n, strand.ctypes.data, cf.ctypes.data, cr.ctypes.data)
     return strand[:n], cf[:n], cr[:n]
+
+
+def mr_fail_counts(reset=False):
+    """multidomain regions that ran into a mirrored bookkeeping limit since the last reset, by kind (index = the engine's
+    MrOut.status: 1 unsampleable, 2 > 8 domains in a path, 4 > 512 tuples, 5 walk left the region, 6 > 32 clusters, 7 > 4 envelopes)"""
+    out = (C.c_longlong * 8)()
+    lib().orc_mr_fail_counts(out, int(reset))
+    return [int(x) for x in out]

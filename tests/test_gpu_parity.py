@@ -27,7 +27,7 @@ def _its2_subset(hmm_text, n3=None, n4=None):
 
 # --------------------------------------------------------------------------------------------
 def test_library_loads_and_reports_device(engine):
-    assert engine.L.itsx_abi_version() == 1
+    assert engine.L.itsx_abi_version() == 2
 
 
 def test_detmath_device_matches_oracle_bitwise(engine):
@@ -294,13 +294,7 @@ def test_search_fuzz_odd_reads(engine, mini_hmm_text, monkeypatch):
     _compare(engine, res)
     _compare(engine, res, "1_", "2_")
     assert engine.stats()["n_domain_overflow"] == 0
-    # the documented limit: at most 8 regions per (representative, profile) are kept, the rest are counted
-    engine.set_reads([cons3[0] * 12 + rnd(40)])
-    engine.derep()
-    engine.search()
-    engine.finalize()
-    st = engine.stats()
-    assert st["n_domain_overflow"] >= 1 and engine.domains()["ndom"].max() == 8
+    # (the limits -- 8 envelopes per (representative, profile), the ensemble's bookkeeping -- are refused, not capped: tests/test_gpu_caps.py)
 
 
 def test_trim_coords_per_read_follow_matchdict(engine, fixture_reads, mini_hmm_text):

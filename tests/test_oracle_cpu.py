@@ -51,12 +51,16 @@ def test_oracle_derep_strands_and_short_reads():
     b = "AGGCTNACRTTTTACGACGATCGATCGATCGATTTACGA"
     seqs = [a, a[::-1].translate(comp), b[::-1].translate(comp), b, a.lower(), "ACGT" * 7, a.replace("T", "U")]
     codes, offs = orc.digitize(seqs)
-    nc, rep, strand = orc.derep(codes, offs)
+    # --minseqlength 32 (vsearch's default for the clustering commands): the 28-base read vanishes
+    nc, rep, strand = orc.derep(codes, offs, minlen=32)
     assert nc == 2
     assert rep.tolist() == [0, 0, 2, 2, 0, -1, 0]
     assert strand.tolist() == [1, -1, 1, -1, 1, 0, 1]
-    nc, rep, strand = orc.derep(codes, offs, strand_both=False)
+    nc, rep, strand = orc.derep(codes, offs, strand_both=False, minlen=32)
     assert nc == 4 and rep.tolist() == [0, 1, 2, 3, 0, -1, 0]
+    # --fastx_uniques (what SeqSample.deduplicate runs) keeps every non-empty read: the default here
+    nc, rep, strand = orc.derep(codes, offs)
+    assert nc == 3 and rep.tolist() == [0, 0, 2, 2, 0, 5, 0]
 
 
 def test_xxh64_known_answers(gold):
@@ -291,7 +295,7 @@ def test_cabi_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.itsx_abi_version() == 1
+    assert L.itsx_abi_version() == 2
 
 
 def test_engine_fails_loudly_without_a_gpu():

@@ -218,6 +218,9 @@ def main():
                     help="T = the stand-in taxon (155 ITS2 profiles); all = --taxa All --region ITS2 (814 profiles, configs[3])")
     ap.add_argument("--global-derep", action="store_true",
                     help="N > 1: match the uniques across shards (exact global dereplication, SURVEY 8e option 2) instead of per-shard")
+    ap.add_argument("--full-rows", action="store_true",
+                    help="keep every domain row resident (80 B x ~130 per representative: 66 GB at 10 M reads) instead of only the rows that can "
+                         "still win the argmax (ITSX_COMPACT_ROWS=1, the default here: the step asks for coordinates, not for domtbl.txt)")
     ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -249,6 +252,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     cdev = dev if os.environ.get("ITSX_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")     # where the bench's own scalars are reduced
 
+    if not args.full_rows:
+        os.environ.setdefault("ITSX_COMPACT_ROWS", "1")
     from itsxpress_amd import Engine
     from itsxpress_amd.dist import allreduce_domz_device, exchange_rows, gather_rows, global_derep, read_rows
     import synth
@@ -490,7 +495,8 @@ def main():
                        "taxon": ("Fungi (%s)" % fungi) if fungi else "Tracheophyta (stand-in: F.hmm absent from the reference mount)" if args.taxa == "T" else "All (every ITSx set in the mount; F.hmm absent)", "profiles": nprof,
                        "reads_rank0": n_local, "mean_length": round(mean_len, 1), "generate_s": round(t_gen, 1),
                        "unique": int(st["n_unique"]), "pairs_past_msv": int(st["n_past_msv"]), "pairs_past_fwd": int(st["n_past_fwd"]),
-                       "domains": int(st["n_domains"]), "reads_trimmed_rank0": trimmed,
+                       "domains": int(st["n_domains"]), "domain_rows_resident": int(st["n_rows_resident"]),
+                       "domain_rows_resident_GB": round(st["n_rows_resident"] * 80 / 1e9, 2), "reads_trimmed_rank0": trimmed,
                        "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
             "timed_region": "ASCII text resident in HBM -> device 2-bit packing -> derep -> MSV -> Forward/Backward -> domains -> "
                             "thresholds -> per-read coordinates on the host (+ all-reduce / gather at N > 1)",

@@ -108,6 +108,9 @@ typedef struct {
    * kept as one envelope (flagged); n_domain_overflow counts the (representative, profile) pairs with more than 8 envelopes.
    * Any of these makes itsx_search return ITSX_E_UNSUPPORTED unless the environment holds ITSX_ALLOW_CAPS=1. */
   int64_t n_mr_fail_kind[8];
+  /* domain rows (80 B each) resident on the device after the last search: all of them (= n_domains plus segment padding), or, with
+   * ITSX_COMPACT_ROWS=1, only the rows that can still win ItsPosition's argmax whatever the dataset-wide domZ turns out to be */
+  int64_t n_rows_resident;
 } itsx_stats;
 
 int         itsx_abi_version(void);

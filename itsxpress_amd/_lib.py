@@ -49,7 +49,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("n_uniq_multi_winner", "<i8"), ("n_reads_multi_winner", "<i8"), ("n_uniq_region_cap", "<i8"),
                 ("n_reads_region_cap", "<i8"), ("n_mr_clustered", "<i8"), ("n_mr_failed", "<i8"), ("n_mr_envelopes", "<i8"),
                 ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8"), ("ms_vit_kernel", "<f4"), ("pad4", "<i4"),
-                ("n_mr_fail_kind", "<i8", (8,))]
+                ("n_mr_fail_kind", "<i8", (8,)), ("n_rows_resident", "<i8")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares

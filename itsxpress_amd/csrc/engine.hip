@@ -37,6 +37,9 @@ void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, uns
 void launch_position_flags(const itsx_domain *dom, int64_t n, const int8_t *side, const unsigned long long *bl, const unsigned long long *br,
                            int32_t *uflag, hipStream_t st);
 void launch_count_flags(const int32_t *uflag, int32_t U, const int32_t *uniq_of, int64_t n, unsigned long long *c, hipStream_t st);
+void launch_compact_best(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, double lnp_certain, unsigned long long *bestc, hipStream_t st);
+void launch_compact_mark(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, double lnp_certain, const unsigned long long *bestc, int32_t *keep, hipStream_t st);
+void launch_compact_scatter(const itsx_domain *dom, int64_t n, const int32_t *keep, const int32_t *pos, itsx_domain *out, hipStream_t st);
 
 // ---- a few tiny kernels that only the orchestration needs --------------------------------
 __global__ void k_wave_rows_pairs(const WaveDesc *w, int nw, const PairRec *pairs, int32_t *rows)
@@ -227,6 +230,11 @@ struct itsx_ctx {
   DBuf<int16_t> d_vtab; DBuf<VitOut> d_vit; bool have_vit = false; double F2 = 1e-6;     // Viterbi filter (F2 < F1 only)
   DBuf<int32_t> d_domz32;
   DBuf<int64_t> d_domz64; bool domz_on_device = false;     // itsx_domz_device: the caller reduces the counters where they are
+  // ITSX_COMPACT_ROWS=1: a chunk's domain rows live in w_domscratch (reused by every chunk) and only the rows that can still
+  // win the argmax move to dom_bufs[chunk] (k_compact_*): 80 B x ~2 rows per representative instead of x ~130
+  bool compact_rows = false; double compact_zmax = 1e9, compact_dome_min = 1e-2, compact_lnp = 0; int compact_ncls = 0;
+  DBuf<itsx_domain> w_domscratch; DBuf<int8_t> w_cls; DBuf<unsigned long long> w_bestc; DBuf<int32_t> w_keep, w_keeppos, w_keeptmp;
+  int64_t rows_before_compaction = 0;
   DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
   std::vector<int32_t> h_sorted_active;  // the length-sorted list the HMM stages walk (= h_sorted_uniq unless itsx_set_active_uniques narrowed it)
   DBuf<LenTables> d_lt;
@@ -1216,9 +1224,30 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.ms_vit_kernel = 0; for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.ms_vit_kernel = 0; for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] = 0; S.n_rows_resident = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
+  ctx->compact_rows = getenv("ITSX_COMPACT_ROWS") && atoi(getenv("ITSX_COMPACT_ROWS")) != 0;
+  ctx->rows_before_compaction = 0;
+  if (ctx->compact_rows && U > 0) {
+    ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
+    if (const char *e = getenv("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
+    if (const char *e = getenv("ITSX_COMPACT_DOME_MIN")) ctx->compact_dome_min = std::max(1e-300, atof(e));
+    ctx->compact_lnp = log(ctx->compact_dome_min / ctx->compact_zmax) - 1e-6;       // certain: exp(lnP) * Zmax <= domE_min, with room for exp's last bit
+    // classes = the distinct 2-character NAME prefixes (what create_runtime_hmm and ItsPosition select by: 1_ 2_ 3_ 4_)
+    std::vector<int8_t> cls((size_t)P, 0); std::vector<std::string> seen;
+    for (int p = 0; p < P; p++) {
+      const std::string pre = ctx->profs[p].name.substr(0, 2);
+      size_t k = 0; while (k < seen.size() && seen[k] != pre) k++;
+      if (k == seen.size()) seen.push_back(pre);
+      if (k > 126) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "ITSX_COMPACT_ROWS: more than 127 distinct 2-character profile name prefixes");
+      cls[p] = (int8_t)k;
+    }
+    ctx->compact_ncls = (int)seen.size();
+    HIPCHK(upload(ctx->w_cls, cls, st));
+    HIPCHK(ctx->w_bestc.alloc((size_t)ctx->U * ctx->compact_ncls + 1));
+    HIPCHK(hipMemsetAsync(ctx->w_bestc.p, 0, ((size_t)ctx->U * ctx->compact_ncls + 1) * sizeof(unsigned long long), st));
+  }
   if (U == 0) return ITSX_OK;
 
   // ---- per-length constants (host libm, as hmmsearch computes them per target)
@@ -1296,6 +1325,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   for (size_t p = 0; p < dz32.size(); p++) ctx->domz[p] = dz32[p];
+  S.n_rows_resident = 0;
+  for (int64_t r : ctx->dom_n) S.n_rows_resident += r;
   // Refuse, don't cap: hmmsearch has no limit on envelopes per target or on the bookkeeping of a region's traceback ensemble.
   // A search that ran into one of this engine's limits would silently differ from the reference's result on those reads
   // (concatemers, long CCS reads with tandem copies), so it fails loudly; ITSX_ALLOW_CAPS=1 accepts the documented behaviour
@@ -1321,7 +1352,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   const int32_t *d_sorted = ctx->d_sorted_uniq.p + u0;     // PairRec::useq is relative to the chunk
   DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
   while ((int)ctx->dom_bufs.size() <= ci) ctx->dom_bufs.emplace_back(new DBuf<itsx_domain>());
-  DBuf<itsx_domain> &d_dom = *ctx->dom_bufs[ci];
+  DBuf<itsx_domain> &d_dom = ctx->compact_rows ? ctx->w_domscratch : *ctx->dom_bufs[ci];
   ctx->dom_n.push_back(0);
   ctx->trace_u0 = u0;
   // ---- MSV for every (unique, profile)
@@ -1757,6 +1788,21 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     if (NMR > 0) { sa.mr = ctx->w_mr.p; sa.mr_u = ctx->w_mru.p; sa.mrout = ctx->w_mrout.p; sa.n2off = ctx->w_n2off.p; sa.n2sc = ctx->w_n2sc.p; sa.mr_off = ctx->w_mroff.p; }
     sa.domz = ctx->d_domz32.p; sa.usample = ctx->dev_usample(); sa.P = ctx->P;
     launch_score(sa, st);
+    if (ctx->compact_rows) {
+      // keep what can still win once domZ is known (k_compact_*), in row order; the chunk's full rows are scratch
+      launch_compact_best(d_dom.p, NR, ctx->w_cls.p, ctx->compact_ncls, ctx->compact_lnp, ctx->w_bestc.p, st);
+      HIPCHK(ctx->w_keep.alloc((size_t)NR + 1)); HIPCHK(ctx->w_keeppos.alloc((size_t)NR + 1)); HIPCHK(ctx->w_keeptmp.alloc((size_t)scan_tmp_elems(NR + 1)));
+      launch_compact_mark(d_dom.p, NR, ctx->w_cls.p, ctx->compact_ncls, ctx->compact_lnp, ctx->w_bestc.p, ctx->w_keep.p, st);
+      launch_exclusive_scan(ctx->w_keep.p, ctx->w_keeppos.p, NR + 1, ctx->w_keeptmp.p, st);
+      int32_t kept = 0;
+      HIPCHK(hipMemcpyAsync(&kept, ctx->w_keeppos.p + NR, sizeof(kept), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      DBuf<itsx_domain> &small = *ctx->dom_bufs[ci];
+      HIPCHK(small.alloc((size_t)std::max<int32_t>(kept, 1), true));
+      launch_compact_scatter(d_dom.p, NR, ctx->w_keep.p, ctx->w_keeppos.p, small.p, st);
+      ctx->rows_before_compaction += NR;
+      ctx->dom_n[ci] = kept;
+    }
   }
   S.ms_domains += tm_dom.stop();
   // filter counters
@@ -1819,6 +1865,14 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
     for (size_t c = 0; c < ctx->dom_n.size(); c++)
       if (ctx->dom_n[c] > 0) launch_finalize(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, domE, ctx->dev_usample(), ctx->P, ctx->st);
     HIPCHK(hipStreamSynchronize(ctx->st));
+    if (ctx->compact_rows) {             // the rows were thinned out under two assumptions: check them against what finalize was given
+      int64_t zmax = 0;
+      for (int64_t z : ctx->domz) zmax = std::max(zmax, z);
+      if ((double)zmax > ctx->compact_zmax || domE < ctx->compact_dome_min)
+        SET_ERR(ctx, ITSX_E_UNSUPPORTED, "ITSX_COMPACT_ROWS kept only the rows that are reported for every domZ <= " + std::to_string(ctx->compact_zmax) +
+                " and every domE >= " + std::to_string(ctx->compact_dome_min) + ", but finalize got domZ up to " + std::to_string(zmax) + " and domE " + std::to_string(domE) +
+                " (raise ITSX_COMPACT_ZMAX / lower ITSX_COMPACT_DOME_MIN and search again)");
+    }
   }
   ctx->stats.ms_finalize = tm.stop();
   ctx->have_final = true;
@@ -1828,6 +1882,7 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
 static int fetch_domains(const itsx_ctx *cctx)
 {
   itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
+  if (ctx->compact_rows) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "the domain rows of this search were compacted (ITSX_COMPACT_ROWS=1): only coordinates are available, not the row table / domtbl.txt");
   if (!ctx->h_dom.empty()) return ITSX_OK;
   // domtblout order: profile, then target, then domain.  The device rows are grouped by profile already (not contiguously
   // across chunks), so: counting sort by profile, then every profile's rows are ordered on their own by a pool of threads.
@@ -2133,6 +2188,7 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
   const int32_t U = ctx->U; const int64_t n = ctx->N;
   std::vector<int8_t> side((size_t)std::max(ctx->P, 1), 0);
   const size_t ll = strlen(lp), rl = strlen(rp);
+  if (ctx->compact_rows && (ll > 2 || rl > 2)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "ITSX_COMPACT_ROWS keeps the best rows per 2-character profile prefix: a longer prefix cannot be served");
   for (int p = 0; p < ctx->P; p++) {
     const std::string &nm = ctx->profs[p].name;
     if (nm.compare(0, ll, lp) == 0) side[p] = 1;

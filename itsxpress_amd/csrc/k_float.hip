@@ -1233,6 +1233,55 @@ __global__ void __launch_bounds__(256) k_positions(const itsx_domain *__restrict
   if (sd == 0) return;
   atomicMax(sd == 1 ? &best_l[d.rep] : &best_r[d.rep], position_key(d, sd));
 }
+// ---- row compaction (ITSX_COMPACT_ROWS=1): per (representative, 2-character profile prefix) only the rows that can still
+// win ItsPosition's argmax once the dataset-wide domZ is known are kept.  A row is CERTAIN to be reported when its target is
+// reported and exp(lnP) * Zmax <= domE_min (lnP <= lnp_certain); below the best certain row of its class nothing can win any
+// more, and nothing below it changes the "sequence has a row" flag either.
+DEV unsigned long long compact_key(const itsx_domain &d) { return position_key(d, 1) >> 16; }       // [tenths][~profile][~domain]
+__global__ void __launch_bounds__(256) k_compact_best(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ cls, int ncls,
+                                                      double lnp_certain, unsigned long long *__restrict__ bestc)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const itsx_domain d = dom[i];
+  if (d.dom_idx < 0 || !d.seq_reported || !(d.lnP <= lnp_certain)) return;
+  atomicMax(&bestc[(size_t)d.rep * ncls + cls[d.prof]], compact_key(d));
+}
+__global__ void __launch_bounds__(256) k_compact_mark(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ cls, int ncls,
+                                                      double lnp_certain, const unsigned long long *__restrict__ bestc, int32_t *__restrict__ keep)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  int k = 0;
+  if (i < n) {
+    const itsx_domain d = dom[i];
+    if (d.dom_idx >= 0 && d.seq_reported) {                 // a row of an unreported target is never reported
+      const unsigned long long b = bestc[(size_t)d.rep * ncls + cls[d.prof]], key = compact_key(d);
+      const bool certain = d.lnP <= lnp_certain;
+      k = (certain ? key == b : key > b) || (d.flags & 2);  // (rows at the region cap stay: the parity-risk counters read them)
+    }
+  }
+  keep[i] = k;
+}
+__global__ void __launch_bounds__(256) k_compact_scatter(const itsx_domain *__restrict__ dom, int64_t n, const int32_t *__restrict__ keep,
+                                                         const int32_t *__restrict__ pos, itsx_domain *__restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && keep[i]) out[pos[i]] = dom[i];
+}
+void launch_compact_best(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, double lnp_certain, unsigned long long *bestc, hipStream_t st)
+{
+  if (n > 0) hipLaunchKernelGGL(k_compact_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, lnp_certain, bestc);
+}
+void launch_compact_mark(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, double lnp_certain, const unsigned long long *bestc, int32_t *keep, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_compact_mark, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, lnp_certain, bestc, keep);
+}
+void launch_compact_scatter(const itsx_domain *dom, int64_t n, const int32_t *keep, const int32_t *pos, itsx_domain *out, hipStream_t st)
+{
+  if (n > 0) hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, keep, pos, out);
+}
+
 // parity-risk bookkeeping, after k_positions: uflag[rep] bit 0 = the winning left/right domain carries flags bit 0 (its
 // region is one hmmsearch resolves by stochastic clustering), bit 1 = a pair of either side hit the region cap
 __global__ void __launch_bounds__(256) k_position_flags(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ side,

@@ -162,6 +162,10 @@ def cpu_baseline(hmm_text, blob, offs, sample_reads, threads, lp="3_", rp="4_", 
     """the oracle (a port of the reference's CPU path) timed on a bounded sample of the same workload"""
     import numpy as np
     import orc
+    # the timed leg runs oracle/libbase_sse.so: the checker's sources with HMMER's 4-lane float vectors in real SSE2 registers
+    # and a 16-lane byte MSV filter (results bit-identical to the scalar checker: tests/test_oracle_cpu.py)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libbase_sse.so"], check=True)
+    orc.use_library("libbase_sse.so")
     raw = bytes(blob[:int(offs[sample_reads])])
     seqs = [raw[offs[i]:offs[i + 1]].decode() for i in range(sample_reads)]
     hs = orc.HmmSet(text=hmm_text)
@@ -182,7 +186,30 @@ def cpu_baseline(hmm_text, blob, offs, sample_reads, threads, lp="3_", rp="4_", 
     uo = uniq[np.maximum(rep, 0)]
     coords = np.stack([us[uo], ue[uo], ut[uo]], axis=1)                      # per read of the sample: the baseline path's answer
     coords[rep < 0] = -1                                                     # reads the grouping dropped (--minseqlength)
-    return sample_reads / dt, dt, nc, coords, seqs
+    cnt = res.counts
+    ulen = np.array([len(seqs[i]) for i in seeds], np.float64)
+    # DP cells of the float stages actually run (Forward on every pair past the bias filter, Backward on every pair past Forward;
+    # a 45-node model: 45 cells per row), per second and per THREAD -- the figure to hold against HMMER's published rates
+    dp_cells = float(ulen.mean()) * 45.0 * (cnt.get("past_bias", 0) + cnt.get("past_fwd", 0))
+    orc.use_library("liborc.so")
+    extra = {"threads": threads, "physical_cores": physical_cores(), "simd": "SSE2 (4 x f32 Forward/Backward, 16 x u8 MSV), bit-identical to the scalar checker",
+             "fwd_bwd_cells_per_s_per_thread": dp_cells / dt / max(threads, 1), "msv_cells_per_s_per_thread": float(ulen.sum()) * 45.0 * hs.n / dt / max(threads, 1),
+             "note": "per-thread rates are whole-leg averages (every stage's time included), so they understate each kernel's own rate"}
+    return sample_reads / dt, dt, nc, coords, seqs, extra
+
+
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo: os.cpu_count() counts hardware THREADS"""
+    try:
+        seen, phys = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((phys, ln.split(":")[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
 
 
 T_START = time.time()
@@ -535,7 +562,7 @@ def main():
                     args.cpu_sample = min(args.cpu_sample, 3000)
             m = min(args.cpu_sample, n_local)
             progress("CPU baseline on %d reads, %d threads" % (m, threads))
-            v, cdt, nc, ccoords, seqs = cpu_baseline(hmm, blob, offs, m, threads, lp, rp, args.cluster_id)
+            v, cdt, nc, ccoords, seqs, cextra = cpu_baseline(hmm, blob, offs, m, threads, lp, rp, args.cluster_id)
             progress("CPU baseline done in %.1f s" % cdt)
             # trim-coordinate concordance (BASELINE metric): the engine on the very same sample against the baseline path
             e2 = Engine(local_rank)
@@ -556,6 +583,7 @@ def main():
                                              (m, nc, "centroids" if args.cluster_id < 1.0 else "unique", "cluster_size" if args.cluster_id < 1.0 else "derep", cdt),
                                    "trim_coord_concordance": conc,
                                    "concordance_is": "engine vs oracle/ (our restatement), not vs vsearch+hmmsearch"}
+            res["cpu_baseline"].update(cextra)
             # the real reference engines, when the box happens to have them (SURVEY 8d "preferred")
             import tempfile
             with tempfile.TemporaryDirectory() as tmp:

@@ -44,6 +44,27 @@ extern const uint8_t *orc_degen_table(void);
 double orc_det_log(double x) { return orc_log(x); }
 double orc_det_exp(double x) { return orc_exp(x); }
 
+/* The 4-lane vectors of HMMER's SSE implementation.  The CHECKER (liborc.so) spells them out in scalar C, one float at a
+ * time; the timed CPU BASELINE (libbase_sse.so: make -C oracle libbase_sse.so, -DORC_SSE) maps the same eight operations to
+ * real SSE2 registers -- same operations, same order, IEEE single precision both ways, so every result is bit-identical
+ * (tests/test_oracle_cpu.py::test_sse_baseline_is_bit_identical_to_the_checker) and only the speed differs. */
+#ifdef ORC_SSE
+#include <emmintrin.h>
+typedef __m128 v4;
+static inline v4 v4_set1(float a) { return _mm_set1_ps(a); }
+static inline v4 v4_zero(void) { return _mm_setzero_ps(); }
+static inline v4 v4_add(v4 a, v4 b) { return _mm_add_ps(a, b); }
+static inline v4 v4_mul(v4 a, v4 b) { return _mm_mul_ps(a, b); }
+static inline v4 v4_rshift(v4 a) { return _mm_castsi128_ps(_mm_slli_si128(_mm_castps_si128(a), 4)); }   /* lane z takes lane z-1, lane 0 takes +0 */
+static inline v4 v4_lshift(v4 a) { return _mm_castsi128_ps(_mm_srli_si128(_mm_castps_si128(a), 4)); }
+static inline float v4_hsum(v4 a)
+{
+  const v4 s = _mm_add_ps(a, _mm_shuffle_ps(a, a, _MM_SHUFFLE(2, 3, 0, 1)));     /* (v0+v1, v1+v0, v2+v3, v3+v2) */
+  return _mm_cvtss_f32(_mm_add_ss(s, _mm_movehl_ps(s, s)));                      /* (v0+v1) + (v2+v3) */
+}
+static inline v4 v4_ld(const float *p) { return _mm_loadu_ps(p); }
+static inline float v4_get(v4 a, int r) { float t[4]; _mm_storeu_ps(t, a); return t[r]; }
+#else
 typedef struct { float v[4]; } v4;
 static inline v4 v4_set1(float a) { v4 r = {{a, a, a, a}}; return r; }
 static inline v4 v4_zero(void) { v4 r = {{0.f, 0.f, 0.f, 0.f}}; return r; }
@@ -53,6 +74,8 @@ static inline v4 v4_rshift(v4 a) { v4 r = {{0.f, a.v[0], a.v[1], a.v[2]}}; retur
 static inline v4 v4_lshift(v4 a) { v4 r = {{a.v[1], a.v[2], a.v[3], 0.f}}; return r; }
 static inline float v4_hsum(v4 a) { return (a.v[0] + a.v[1]) + (a.v[2] + a.v[3]); }
 static inline v4 v4_ld(const float *p) { v4 r; memcpy(r.v, p, 16); return r; }
+static inline float v4_get(v4 a, int r) { return a.v[r]; }
+#endif
 
 typedef struct { float E, N, J, B, C, SCALE; } xrow;
 
@@ -100,6 +123,59 @@ float orc_nullsc(int L)
 double orc_len_lognn3(int L) { return log((double)((float)L / (float)(L + 3))); }
 
 /* ------------------------------------------------------------------ MSV */
+#ifdef ORC_SSE
+/* the timed baseline's MSV filter: 16 unsigned bytes per SSE2 register, striped like p7_MSVFilter (vector q, lane z = node
+ * z Q + q + 1), saturating adds / subtracts and maxima -- operations whose result does not depend on the order, so xJ and
+ * the overflow verdict equal the scalar loop's of the checker below (compared in tests).  The striped cost table is built
+ * per call (3 vectors x 16 codes for a 45-node model: noise beside L rows). */
+int orc_msv(const orc_profile *p, const uint8_t *dsq, int L, int *ret_xJ, float *ret_sc)
+{
+  const int M = p->M, Q = (M + 15) / 16 < 2 ? 2 : (M + 15) / 16;
+  __m128i rbv[ORC_KP][4 * QMAX / 16 + 2], dp[4 * QMAX / 16 + 2];
+  for (int x = 0; x < ORC_KP; x++)
+    for (int q = 0; q < Q; q++) {
+      uint8_t b[16];
+      for (int z = 0; z < 16; z++) { const int k = z * Q + q + 1; b[z] = k <= M ? p->rbv[(size_t)x * (M + 1) + k] : 255; }
+      rbv[x][q] = _mm_loadu_si128((const __m128i *)b);
+    }
+  const int tjb = orc_tjb_b(L);
+  const int bias = p->bias_b, base = p->base_b, tec = p->tec_b;
+  const int tjbm = tjb + p->tbm_b;
+  const __m128i biasv = _mm_set1_epi8((char)bias);
+  for (int q = 0; q < Q; q++) dp[q] = _mm_setzero_si128();
+  int xJ = 0;
+  int xB = base - tjbm; if (xB < 0) xB = 0;
+  for (int i = 1; i <= L; i++) {
+    const __m128i *rsc = rbv[dsq[i]];
+    const __m128i xBv = _mm_set1_epi8((char)xB);
+    __m128i xEv = _mm_setzero_si128();
+    __m128i mpv = _mm_slli_si128(dp[Q - 1], 1);           /* node k-1 of the previous row: the last vector shifted by one lane */
+    for (int q = 0; q < Q; q++) {
+      __m128i sv = _mm_max_epu8(mpv, xBv);
+      sv = _mm_adds_epu8(sv, biasv);
+      sv = _mm_subs_epu8(sv, rsc[q]);
+      xEv = _mm_max_epu8(xEv, sv);
+      mpv = dp[q];
+      dp[q] = sv;
+    }
+    xEv = _mm_max_epu8(xEv, _mm_srli_si128(xEv, 8));
+    xEv = _mm_max_epu8(xEv, _mm_srli_si128(xEv, 4));
+    xEv = _mm_max_epu8(xEv, _mm_srli_si128(xEv, 2));
+    xEv = _mm_max_epu8(xEv, _mm_srli_si128(xEv, 1));
+    int xE = _mm_cvtsi128_si32(xEv) & 0xff;
+    if (xE + bias >= 255) { *ret_xJ = 255; *ret_sc = INFINITY; return 1; }
+    xE -= tec; if (xE < 0) xE = 0;
+    if (xE > xJ) xJ = xE;
+    xB = (base > xJ ? base : xJ) - tjbm; if (xB < 0) xB = 0;
+  }
+  *ret_xJ = xJ;
+  float sc = ((float)(xJ - tjb) - (float)base);
+  sc /= p->scale_b;
+  sc -= 3.0f;
+  *ret_sc = sc;
+  return 0;
+}
+#else
 int orc_msv(const orc_profile *p, const uint8_t *dsq, int L, int *ret_xJ, float *ret_sc)
 {
   const int M = p->M;
@@ -134,6 +210,8 @@ int orc_msv(const orc_profile *p, const uint8_t *dsq, int L, int *ret_xJ, float 
   *ret_sc = sc;
   return 0;
 }
+
+#endif
 
 /* ------------------------------------------------------------------ bias filter */
 float orc_bias_filtersc(const orc_profile *p, const uint8_t *dsq, int L)
@@ -243,6 +321,7 @@ static int fwd_engine_x(const orc_profile *p, const uint8_t *dsq, int L,
 {
   const int Q = p->Q;
   v4 mmx[QMAX], dmx[QMAX], imx[QMAX];
+  dmx[0] = v4_zero();
   float xN, xE, xB, xC, xJ, totscale = 0.0f;
   for (int q = 0; q < Q; q++) mmx[q] = dmx[q] = imx[q] = v4_zero();
   xE = 0.f; xN = 1.f; xJ = 0.f; xB = pmove; xC = 0.f;
@@ -316,6 +395,7 @@ static int bwd_engine(const orc_profile *p, const uint8_t *dsq, int L,
   const int Q = p->Q;
   const float *tfv = p->tfv;
   v4 mmx[QMAX], dmx[QMAX], imx[QMAX];
+  dmx[0] = v4_zero();
   v4 mpv, ipv, dpv, mcv, dcv, tmmv, timv, tdmv, xBv, xEv;
   float xN, xE, xB, xC, xJ, totscale;
   int own = 0;
@@ -615,10 +695,10 @@ static int stochastic_trace(orc_rng *rng, const orc_profile *p, const v4 *full, 
       if (q > 0) { mpv = FULLV(i - 1, q - 1, 0); dpv = FULLV(i - 1, q - 1, 1); ipv = FULLV(i - 1, q - 1, 2); }
       else { mpv = v4_rshift(FULLV(i - 1, Q - 1, 0)); dpv = v4_rshift(FULLV(i - 1, Q - 1, 1)); ipv = v4_rshift(FULLV(i - 1, Q - 1, 2)); }
       const v4 xBv = v4_set1(xf[i - 1].B);
-      path[0] = v4_mul(xBv, TFVQ(7 * q + 0)).v[r];
-      path[1] = v4_mul(mpv, TFVQ(7 * q + 1)).v[r];
-      path[2] = v4_mul(ipv, TFVQ(7 * q + 2)).v[r];
-      path[3] = v4_mul(dpv, TFVQ(7 * q + 3)).v[r];
+      path[0] = v4_get(v4_mul(xBv, TFVQ(7 * q + 0)), r);
+      path[1] = v4_get(v4_mul(mpv, TFVQ(7 * q + 1)), r);
+      path[2] = v4_get(v4_mul(ipv, TFVQ(7 * q + 2)), r);
+      path[3] = v4_get(v4_mul(dpv, TFVQ(7 * q + 3)), r);
       fnorm(path, 4);
       static const int st4[4] = { ST_B, ST_M, ST_I, ST_D };
       s1 = st4[fchoose(rng, path, 4)];
@@ -629,16 +709,16 @@ static int stochastic_trace(orc_rng *rng, const orc_profile *p, const v4 *full, 
       v4 mpv, dpv, tmdv, tddv;
       if (q > 0) { mpv = FULLV(i, q - 1, 0); dpv = FULLV(i, q - 1, 1); tmdv = TFVQ(7 * (q - 1) + 4); tddv = TFVQ(7 * Q + (q - 1)); }
       else { mpv = v4_rshift(FULLV(i, Q - 1, 0)); dpv = v4_rshift(FULLV(i, Q - 1, 1)); tmdv = v4_rshift(TFVQ(7 * (Q - 1) + 4)); tddv = v4_rshift(TFVQ(8 * Q - 1)); }
-      path[0] = mpv.v[r] * tmdv.v[r];
-      path[1] = dpv.v[r] * tddv.v[r];
+      path[0] = v4_get(mpv, r) * v4_get(tmdv, r);
+      path[1] = v4_get(dpv, r) * v4_get(tddv, r);
       fnorm(path, 2);
       s1 = fchoose(rng, path, 2) == 0 ? ST_M : ST_D;
       k--;
       break; }
     case ST_I: {
       const int q = (k - 1) % Q, r = (k - 1) / Q;
-      path[0] = v4_mul(FULLV(i - 1, q, 0), TFVQ(7 * q + 5)).v[r];
-      path[1] = v4_mul(FULLV(i - 1, q, 2), TFVQ(7 * q + 6)).v[r];
+      path[0] = v4_get(v4_mul(FULLV(i - 1, q, 0), TFVQ(7 * q + 5)), r);
+      path[1] = v4_get(v4_mul(FULLV(i - 1, q, 2), TFVQ(7 * q + 6)), r);
       fnorm(path, 2);
       s1 = fchoose(rng, path, 2) == 0 ? ST_M : ST_I;
       i--;
@@ -667,10 +747,10 @@ static int stochastic_trace(orc_rng *rng, const orc_profile *p, const v4 *full, 
       while (s1 < 0) {
         for (int q = 0; q < Q && s1 < 0; q++) {
           v4 u = v4_mul(FULLV(i, q, 0), xEv);
-          for (int r = 0; r < 4 && s1 < 0; r++) { sum += u.v[r]; if (roll < sum) { k = r * Q + q + 1; s1 = ST_M; } }
+          for (int r = 0; r < 4 && s1 < 0; r++) { sum += v4_get(u, r); if (roll < sum) { k = r * Q + q + 1; s1 = ST_M; } }
           if (s1 >= 0) break;
           u = v4_mul(FULLV(i, q, 1), xEv);
-          for (int r = 0; r < 4 && s1 < 0; r++) { sum += u.v[r]; if (roll < sum) { k = r * Q + q + 1; s1 = ST_D; } }
+          for (int r = 0; r < 4 && s1 < 0; r++) { sum += v4_get(u, r); if (roll < sum) { k = r * Q + q + 1; s1 = ST_D; } }
         }
         if (s1 < 0 && sum < 0.99) return -1;        /* HMMER throws: probabilities were not normalised */
       }

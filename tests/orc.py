@@ -42,16 +42,28 @@ TRACE_DTYPE = np.dtype([("seq", "<i8"), ("prof", "<i4"), ("msv_xj", "<i4"), ("pa
                         ("ndom", "<i4"), ("ran_vit", "<i4"), ("pass_vit", "<i4"), ("vitsc", "<f4"), ("pad", "<i4")], align=True)
 
 
+_LIBNAME = "liborc.so"
+
+
 def build():
     """Compile oracle/liborc.so from the C restatement (gcc only)."""
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "liborc.so"], check=True)
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, _LIBNAME], check=True)
+
+
+def use_library(name="liborc.so"):
+    """Switch the binding between the CHECKER (liborc.so: plain scalar C, the default, what every parity test uses) and the
+    timed CPU BASELINE (libbase_sse.so: the same sources with real SSE2 vectors, bench.py's cpu_baseline leg; results
+    bit-identical).  Objects created before the switch must not be used after it."""
+    global _LIB, _LIBNAME
+    if name != _LIBNAME:
+        _LIB, _LIBNAME = None, name
 
 
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(ORACLE_DIR, "liborc.so")
+    path = os.path.join(ORACLE_DIR, _LIBNAME)
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

@@ -463,3 +463,31 @@ def test_viterbi_filter_agrees_with_an_independent_statement(fixture_reads, mini
     # with the reference's flags the filter never runs
     res0 = orc.SearchResult(hs, codes, o, keep_trace=1, threads=4)
     assert (res0.trace["ran_vit"] == 0).all()
+
+
+def test_sse_baseline_is_bit_identical_to_the_checker(t_hmm_text, fixture_reads):
+    """bench.py's cpu_baseline leg times oracle/libbase_sse.so: the checker's sources with the 4-lane float vectors in real
+    SSE2 registers and a 16-lane byte MSV filter.  Every number it produces must equal the scalar checker's bit for bit --
+    filter traces, every domain row, the coordinates -- on fixture reads, ragged synthetic reads (incl. multidomain
+    regions) and the short Trebouxia-style models of mini.hmm."""
+    import synth
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libbase_sse.so"], check=True)
+    names, seqs = fixture_reads
+    blob, offs = synth.make_reads(t_hmm_text, 400, seed=91, fixed_len=0, len_range=(150, 560))
+    seqs = list(seqs[:80]) + synth.to_strings(blob, offs) + ["ACGTRYKMSWBDHVN" * 12, "A" * 40]
+    mini = open(os.path.join(ROOT, "tests", "golden", "mini.hmm")).read()
+    out = {}
+    try:
+        for libname in ("liborc.so", "libbase_sse.so"):
+            orc.use_library(libname)
+            codes, offs2 = orc.digitize(seqs)
+            got = []
+            for hmm, flags in ((_its2(t_hmm_text), {}), (mini, {}), (mini, dict(F1=0.02, F2=1e-3, F3=1e-5))):
+                res = orc.SearchResult(orc.HmmSet(text=hmm), codes, offs2, threads=8, keep_trace=1, **flags)
+                fields = lambda a: [(f, a[f].tobytes()) for f in a.dtype.names if not f.startswith("pad")]      # (not the struct padding)
+                got.append((fields(res.trace), fields(res.domains), [a.tobytes() for a in res.positions("3_", "4_")], dict(res.counts)))
+            out[libname] = got
+    finally:
+        orc.use_library("liborc.so")
+    assert out["liborc.so"] == out["libbase_sse.so"]
+    assert out["liborc.so"][0][3]["multidomain"] > 0 and len(out["liborc.so"][0][1][0][1]) > 100000

@@ -323,6 +323,8 @@ int itsx_debug_calibrate(itsx_ctx *ctx, int pattern, double gbytes, int iters, i
 int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_log, double *out_exp);
 /* the bias filter's table-driven float logarithm (detmath.h: det_logf_fast) ON THE DEVICE: out[i] must equal (float)det_log((double)x[i]) */
 int itsx_debug_logf(itsx_ctx *ctx, const float *x, int64_t n, float *out);
+/* the DUST soft mask (vsearch --qmask dust) the device computes for the current reads: masked[sum of lengths], 1 = masked */
+int itsx_debug_dust(itsx_ctx *ctx, uint8_t *masked);
 
 #ifdef __cplusplus
 }

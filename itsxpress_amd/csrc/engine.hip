@@ -930,6 +930,37 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
   return ITSX_OK;
 }
 
+// vsearch's DUST soft mask (mask.cc dust() / wo()) on the host, for the orientation database (the reads are masked on the device by
+// k_dust, same procedure): windows of 64 advancing by 32, 3-mer repeat score 10 * sum / j, masked above 20
+static bool qmask_dust() { const char *e = getenv("ITSX_QMASK"); return !(e && strcmp(e, "none") == 0); }
+static void dust_host(const uint8_t *codes, int64_t L, std::vector<uint8_t> &masked)
+{
+  masked.assign((size_t)L, 0);
+  for (int64_t i = 0; i < L; i += 32) {
+    const int len = (L > i + 64) ? 64 : (int)(L - i);
+    const int l1 = len - 7;
+    int bestv = 0, besti = 0, bestj = 0;
+    if (l1 >= 0) {
+      int words[64], counts[64], word = 0;
+      for (int j = 0; j < len; j++) { const int c = codes[i + j]; word = (word << 2) | (c < 4 ? c : 0); words[j] = word & 63; }
+      for (int a = 0; a < l1; a++) {
+        memset(counts, 0, sizeof(counts));
+        int sum = 0;
+        for (int j = 2; j < len - a; j++) {
+          const int w = words[a + j], c = counts[w];
+          if (c) { sum += c; const int v = 10 * sum / j; if (v > bestv) { bestv = v; besti = a; bestj = j; } }
+          counts[w]++;
+        }
+      }
+    }
+    if (bestv > 20) {
+      const int b = besti + bestj;
+      for (int64_t j = besti + i; j <= b + i; j++) masked[(size_t)j] = 1;
+      if (b < 32) i += 32 - b;
+    }
+  }
+}
+
 // a2: greedy centroid clustering (k_cluster.hip explains the speculative windows)
 int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
 {
@@ -990,6 +1021,10 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(hipMemsetAsync(n_skipped.p, 0, sizeof(unsigned long long), ctx->st)); HIPCHK(ctab_key.alloc(16384)); HIPCHK(ctab_val.alloc(16384));
   HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1));
   if (n > 0) launch_hash_reads(ctx->rd, 0, 0, ctx->w_hf.p, ctx->w_hr.p, ctx->st);      // identical reads of a window share one search
+  // vsearch's default --qmask dust / --dbmask dust: the DUST soft mask of every read (queries and centroids alike), once
+  DBuf<uint32_t> dmask;
+  const bool use_dust = qmask_dust();
+  if (use_dust && n > 0) { HIPCHK(dmask.alloc((size_t)ctx->h_woff[n] + 1)); launch_dust(ctx->rd, dmask.p, ctx->st); }
   HIPCHK(scan_tmp.alloc((size_t)scan_tmp_elems(65537 + Bmax + 1))); HIPCHK(n_align.alloc(1));
   HIPCHK(scratch.alloc(multipass ? nqs * 32 * (size_t)scratch_pitch * 2 : 2));
   HIPCHK(hipMemsetAsync(n_align.p, 0, sizeof(unsigned long long), ctx->st));
@@ -1008,7 +1043,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   int64_t pool_used = 0;
 
   ClusterArgs a{};
-  a.rd = ctx->rd; a.order = d_order.p; a.strand_both = strand_both ? 1 : 0;
+  a.rd = ctx->rd; a.order = d_order.p; a.strand_both = strand_both ? 1 : 0; a.dmask = (use_dust && n > 0) ? dmask.p : nullptr;
   a.cent_len = cent_len.p; a.cent_pos = cent_pos.p; a.cent_read = cent_read.p;
   a.klist = klist.p; a.kcap = kcap; a.nk = knk.p;
   a.cw_off = cw_off.p; a.cw_n = cw_n.p; a.cw_base = cw_base.p; a.wsum = wsum.p; a.wscan = wscan.p;
@@ -1998,16 +2033,29 @@ int itsx_orient_load_db(itsx_ctx *ctx, const char *fasta_path, int64_t *n_sequen
   const std::string &text = *tp;
   std::vector<uint32_t> bits(1u << 19, 0u);                 // 4^12 bits
   int64_t nseq = 0;
-  uint32_t w = 0; int good = 0; bool header = false;
+  const bool use_dust = qmask_dust();                        // vsearch --dbmask dust (its default): masked words are not indexed
+  std::vector<uint8_t> seq, msk;
+  auto add_seq = [&]() {
+    if (seq.empty()) return;
+    if (use_dust) dust_host(seq.data(), (int64_t)seq.size(), msk);
+    uint32_t w = 0; int good = 0;
+    for (size_t i = 0; i < seq.size(); i++) {
+      const int code = seq[i];
+      if (code <= 3 && !(use_dust && msk[i])) { w = (w >> 2) | ((uint32_t)code << 22); good++; } else { w = 0; good = 0; }
+      if (good >= 12) bits[w >> 5] |= 1u << (w & 31);
+    }
+    seq.clear();
+  };
+  bool header = false;
   for (size_t i = 0; i < text.size(); i++) {
     const char c = text[i];
-    if (c == '>') { header = true; nseq++; w = 0; good = 0; continue; }
+    if (c == '>') { add_seq(); header = true; nseq++; continue; }
     if (c == '\n') { header = false; continue; }
     if (header || c == '\r') continue;
     const int code = g_code[(unsigned char)c];
-    if (code >= 0 && code <= 3) { w = (w >> 2) | ((uint32_t)code << 22); good++; } else { w = 0; good = 0; }
-    if (good >= 12) bits[w >> 5] |= 1u << (w & 31);
+    seq.push_back((uint8_t)((code >= 0 && code <= 15) ? code : 15));
   }
+  add_seq();
   if (nseq == 0) SET_ERR(ctx, ITSX_E_FORMAT, std::string("no FASTA records in ") + fasta_path);
   HIPCHK(upload(ctx->d_orient_db, bits, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
@@ -2026,7 +2074,10 @@ int itsx_orient(itsx_ctx *ctx, int8_t *strand, int32_t *count_fwd, int32_t *coun
   if (n == 0) return ITSX_OK;
   DBuf<int8_t> d_s; DBuf<int32_t> d_f, d_r;
   HIPCHK(d_s.alloc((size_t)n)); HIPCHK(d_f.alloc((size_t)n)); HIPCHK(d_r.alloc((size_t)n));
-  launch_orient(ctx->rd, ctx->d_orient_db.p, d_s.p, d_f.p, d_r.p, ctx->st);
+  DBuf<uint32_t> dmask;
+  const bool use_dust = qmask_dust();                        // vsearch --qmask dust (its default)
+  if (use_dust) { HIPCHK(dmask.alloc((size_t)ctx->h_woff[n] + 1)); launch_dust(ctx->rd, dmask.p, ctx->st); }
+  launch_orient(ctx->rd, ctx->d_orient_db.p, use_dust ? dmask.p : nullptr, d_s.p, d_f.p, d_r.p, ctx->st);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(strand, d_s.p, (size_t)n, hipMemcpyDeviceToHost, ctx->st));
   if (count_fwd) HIPCHK(hipMemcpyAsync(count_fwd, d_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
@@ -2576,6 +2627,25 @@ int itsx_debug_detmath(itsx_ctx *ctx, const double *x, int64_t n, double *out_lo
     HIPCHK(hipMemcpyAsync(out_exp, de.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
   }
   HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
+
+int itsx_debug_dust(itsx_ctx *ctx, uint8_t *masked)
+{
+  CTXCHK(ctx && masked);
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->N;
+  if (n == 0) return ITSX_OK;
+  DBuf<uint32_t> dm;
+  HIPCHK(dm.alloc((size_t)ctx->h_woff[n] + 1));
+  launch_dust(ctx->rd, dm.p, ctx->st);
+  std::vector<uint32_t> h((size_t)ctx->h_woff[n] + 1);
+  HIPCHK(hipMemcpyAsync(h.data(), dm.p, h.size() * 4, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  HIPCHK(hipGetLastError());
+  int64_t o = 0;
+  for (int64_t r = 0; r < n; r++)
+    for (int p = 0; p < ctx->h_len[r]; p++) masked[o++] = (uint8_t)((h[(size_t)ctx->h_woff[r] + (p >> 5)] >> (p & 31)) & 1u);
   return ITSX_OK;
 }
 

@@ -66,6 +66,7 @@ struct ClusterArgs {
   int32_t *newq, *rm;           // [nq] window index of each speculative centroid; columns to clear after validation
   int32_t *xlist, *xn, *hard; unsigned long long *xkey; double *xpid;            // speculative centroids entering a walk [2 nq][32]
   int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[2]
+  const uint32_t *dmask;        // DUST soft mask of every read, one bit per base at woff[r] (k_dust); nullptr: no masking (ITSX_QMASK=none)
   const uint64_t *rhash;        // [n reads] XXH64 of the packed forward strand
   unsigned long long *ctab_key; int32_t *ctab_val; int32_t *canon;   // window-local table of identical reads; canon[nq]
   int32_t *replay;              // [nq] queries whose walk must be replayed by k_cl_resolve
@@ -95,7 +96,8 @@ void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col
                         const int32_t *cent_read, int32_t *rep_of, int8_t *strand, double *pct, int32_t *is_seed, hipStream_t st);
 
 // ---- f4: read orientation (k_cluster.hip)
-void launch_orient(const ReadsDev &rd, const uint32_t *dbbits /*4^12 bits*/, int8_t *strand, int32_t *cfwd, int32_t *crev, hipStream_t st);
+void launch_orient(const ReadsDev &rd, const uint32_t *dbbits /*4^12 bits*/, const uint32_t *dmask /*k_dust, or nullptr*/, int8_t *strand, int32_t *cfwd, int32_t *crev, hipStream_t st);
+void launch_dust(const ReadsDev &rd, uint32_t *dmask, hipStream_t st);
 
 // ---- k_merge.hip (paired-end merge)
 struct MergeArgs {

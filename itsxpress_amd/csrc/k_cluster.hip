@@ -74,6 +74,69 @@ __device__ __forceinline__ u64 cand_key(uint32_t cnt, int32_t len, int32_t pos)
   return ((u64)cnt << 48) | ((u64)(65535 - len) << 32) | (u64)(0xffffffffu - (uint32_t)pos);
 }
 
+// ------------------------------------------------------------------ DUST soft masking of the seeds (vsearch --qmask dust / --dbmask dust)
+// vsearch's default for --cluster_size and --orient: words that touch a soft-masked symbol are left out of the k-mer sets (the
+// alignment sees every symbol).  mask.cc's dust() / wo() (after Tatusov & Lipman) restated like oracle/orc_cluster.c:orc_dust:
+// windows of 64 symbols advancing by 32; per window, for every start i (one LANE each) the running 3-mer repeat score
+// 10 * sum / j over the ends j; the first best (i, j) of the window is masked when its score exceeds 20; a masked window that
+// ends in its first half pulls the next one forward.  One wave per read (the windows of a read depend on each other), the
+// lane's 64 3-mer counters as bytes in LDS [3-mer][lane]; anything but A C G T counts as A (it is 0 in the 2-bit plane already).
+// dmask: one bit per base, the read's words at woff[r] (half of them used).
+__global__ __launch_bounds__(64) void k_dust(ReadsDev rd, uint32_t *dmask)
+{
+  __shared__ uint8_t cnt[64 * 64];
+  __shared__ uint8_t wd[64];
+  __shared__ uint32_t mbits[2048];                           // reads up to 65 535 bases
+  const int lane = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < rd.n; r += gridDim.x) {
+    const int L = rd.len[r];
+    const uint32_t *w = rd.words + rd.woff[r];
+    const int nmw = (L + 31) >> 5;
+    for (int i = lane; i < nmw; i += 64) mbits[i] = 0u;
+    __syncthreads();
+    for (int i = 0; i < L; i += 32) {
+      const int l = (L > i + 64) ? 64 : L - i;
+      // 3-mer codes of the window; the register that builds them starts empty at the window's first symbol
+      if (lane < l) {
+        uint32_t code = 0;
+        for (int d = 2; d >= 0; d--) { const int p = lane - d; const uint32_t c2 = p >= 0 ? (w[(i + p) >> 4] >> (((i + p) & 15) * 2)) & 3u : 0u; code = (code << 2) | c2; }
+        wd[lane] = (uint8_t)code;
+      }
+      for (int k = 0; k < 64; k++) cnt[k * 64 + lane] = 0;
+      __syncthreads();
+      const int l1 = l - 7;
+      int bv = 0, bj = 0;
+      if (lane < l1) {
+        int sum = 0;
+        for (int j = 2; j < l - lane; j++) {
+          const int word = wd[lane + j];
+          const int c = cnt[word * 64 + lane];
+          if (c) { sum += c; const int v = 10 * sum / j; if (v > bv) { bv = v; bj = j; } }
+          cnt[word * 64 + lane] = (uint8_t)(c + 1);
+        }
+      }
+      // the first best in (i, j) order: the highest score, then the lowest start
+      int key = (bv << 8) | (63 - lane);
+      for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(key, off); key = o > key ? o : key; }
+      const int v = key >> 8, a = 63 - (key & 255);
+      const int b = a + __shfl(bj, a);
+      __syncthreads();
+      if (v > 20) {
+        for (int j = a + i + lane; j <= b + i; j += 64) atomicOr(&mbits[j >> 5], 1u << (j & 31));
+        if (b < 32) i += 32 - b;
+      }
+      __syncthreads();
+    }
+    uint32_t *out = dmask + rd.woff[r];
+    for (int i = lane; i < nmw; i += 64) out[i] = mbits[i];
+    __syncthreads();
+  }
+}
+void launch_dust(const ReadsDev &rd, uint32_t *dmask, hipStream_t st)
+{
+  if (rd.n > 0) hipLaunchKernelGGL(k_dust, dim3((unsigned)std::min<int64_t>(rd.n, 1 << 20)), dim3(64), 0, st, rd, dmask);
+}
+
 // ------------------------------------------------------------------ identical reads inside a window share one search
 // Exact duplicates have the same words, the same counts and the same walk against the same centroids, so only the
 // first copy in the window (its CANONICAL query) is searched; the copies read its state.  What differs is the
@@ -134,6 +197,16 @@ __global__ __launch_bounds__(256) void k_cl_kmers(ClusterArgs a)
   for (int e = tid; e < nexc; e += 256) {
     const int pos = (int)(a.rd.exc[eo + e] >> 4);
     for (int d = 0; d < 8; d++) { const int p = pos - d; if (p >= 0) atomicOr(&bad[p >> 5], 1u << (p & 31)); }
+  }
+  if (a.dmask) {                                             // soft-masked symbols (k_dust) spoil the words that touch them, like ambiguity symbols
+    const uint32_t *dm = a.dmask + a.rd.woff[r];
+    for (int mw = tid; mw < ((L + 31) >> 5); mw += 256) {
+      uint32_t x = dm[mw];
+      while (x) {
+        const int pos = mw * 32 + __ffs(x) - 1; x &= x - 1;
+        for (int d = 0; d < 8; d++) { const int p = pos - d; if (p >= 0) atomicOr(&bad[p >> 5], 1u << (p & 31)); }
+      }
+    }
   }
   __syncthreads();
   for (int i = tid; i + 8 <= L; i += 256) {
@@ -977,7 +1050,8 @@ void launch_cl_finalize(int32_t nk, const int32_t *order, const int32_t *res_col
 // ------------------------------------------------------------------ f4: read orientation (vsearch --orient restated)
 // Reference call site itsxpress/SeqSample.py:48-91.  One block per read: its distinct unambiguous 12-mers (an LDS hash
 // set removes repeats) and their reverse complements are looked up in the database's 12-mer bitmap (2 MB, L2-resident);
-// forward when count_fwd >= 1 and >= 4 x count_rev, reverse when the mirror holds, otherwise undetermined.
+// forward when count_fwd >= 1 and >= 4 x count_rev, reverse when the mirror holds, otherwise undetermined.  Reads and database are
+// DUST-masked first (vsearch's defaults; k_dust above / dust_host in engine.hip) unless ITSX_QMASK=none.
 namespace itsx {
 static constexpr int OTAB = 16384;
 __device__ __forceinline__ uint32_t rc24(uint32_t k)
@@ -985,7 +1059,7 @@ __device__ __forceinline__ uint32_t rc24(uint32_t k)
   uint32_t r = __brev(~k & 0xffffffu) >> 8;
   return ((r >> 1) & 0x555555u) | ((r & 0x555555u) << 1);
 }
-__global__ __launch_bounds__(256) void k_orient(ReadsDev rd, const uint32_t *dbbits, int8_t *strand, int32_t *cfwd, int32_t *crev)
+__global__ __launch_bounds__(256) void k_orient(ReadsDev rd, const uint32_t *dbbits, const uint32_t *dmask, int8_t *strand, int32_t *cfwd, int32_t *crev)
 {
   __shared__ uint32_t tab[OTAB];
   __shared__ uint32_t bad[2048];
@@ -1005,6 +1079,16 @@ __global__ __launch_bounds__(256) void k_orient(ReadsDev rd, const uint32_t *dbb
     for (int e = tid; e < nexc; e += 256) {
       const int pos = (int)(rd.exc[eo + e] >> 4);
       for (int d = 0; d < 12; d++) { const int p = pos - d; if (p >= 0) atomicOr(&bad[p >> 5], 1u << (p & 31)); }
+    }
+    if (dmask) {                                               // vsearch --qmask dust: soft-masked symbols spoil the words that touch them
+      const uint32_t *dm = dmask + rd.woff[r];
+      for (int mw = tid; mw < ((L + 31) >> 5); mw += 256) {
+        uint32_t x = dm[mw];
+        while (x) {
+          const int pos = mw * 32 + __ffs(x) - 1; x &= x - 1;
+          for (int d = 0; d < 12; d++) { const int p = pos - d; if (p >= 0) atomicOr(&bad[p >> 5], 1u << (p & 31)); }
+        }
+      }
     }
     __syncthreads();
     int f = 0, v = 0;
@@ -1036,9 +1120,9 @@ __global__ __launch_bounds__(256) void k_orient(ReadsDev rd, const uint32_t *dbb
     }
   }
 }
-void launch_orient(const ReadsDev &rd, const uint32_t *dbbits, int8_t *strand, int32_t *cfwd, int32_t *crev, hipStream_t st)
+void launch_orient(const ReadsDev &rd, const uint32_t *dbbits, const uint32_t *dmask, int8_t *strand, int32_t *cfwd, int32_t *crev, hipStream_t st)
 {
   if (rd.n <= 0) return;
-  hipLaunchKernelGGL(k_orient, dim3((unsigned)std::min<int64_t>(rd.n, 65536)), dim3(256), 0, st, rd, dbbits, strand, cfwd, crev);
+  hipLaunchKernelGGL(k_orient, dim3((unsigned)std::min<int64_t>(rd.n, 65536)), dim3(256), 0, st, rd, dbbits, dmask, strand, cfwd, crev);
 }
 }  // namespace itsx

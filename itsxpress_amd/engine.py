@@ -410,6 +410,14 @@ class Engine:
         self._chk(self.L.itsx_debug_packed_read(self.h, i, w.ctypes.data, C.byref(nw), e.ctypes.data, C.byref(ne)))
         return w[:nw.value], e[:ne.value]
 
+    def debug_dust(self, lengths):
+        """the device's DUST soft mask of the current reads: a list of bool arrays"""
+        tot = int(sum(lengths))
+        out = np.zeros(max(tot, 1), np.uint8)
+        self._chk(self.L.itsx_debug_dust(self.h, out.ctypes.data))
+        o = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        return [out[o[i]:o[i + 1]].astype(bool) for i in range(len(lengths))]
+
     def debug_logf(self, x):
         x = np.ascontiguousarray(x, np.float32)
         out = np.zeros_like(x)

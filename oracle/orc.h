@@ -175,6 +175,9 @@ int  orc_merge_pair(const char *f, const char *fq, int fl, const char *r, const 
                     int allow_stagger, char *out_seq, char *out_qual, int *out_len, double *ret_score, int *ret_shift);
 void orc_merge_tables(double *q2p, double *match, double *mism, unsigned char *qsame, unsigned char *qdiff);
 
+/* DUST soft mask as vsearch applies it to seeds (--qmask dust / --dbmask dust): masked[pos] = 1 */
+void orc_dust(const uint8_t *codes, int64_t L, uint8_t *masked);
+
 /* ---- read orientation (vsearch --orient restated; orc_cluster.c; PARITY UNPINNED) ---- */
 void orc_orient_db_add(uint8_t *dbbits /*2 MB, zeroed*/, const uint8_t *codes, int64_t L);
 void orc_orient(const uint8_t *dbbits, const uint8_t *codes, const int64_t *offsets, int64_t n, int8_t *strand, int32_t *cfwd, int32_t *crev);

@@ -32,7 +32,8 @@
  *    columns, defines the identity (vsearch takes whatever its traceback yields); this makes the
  *    identity a function of the DP alone: every cell carries (score, matches, columns) packed in one
  *    64-bit integer so that integer max is the lexicographic max;
- *  - no DUST soft-masking of the seeds (vsearch default --qmask dust);
+ *  - DUST soft-masking of the seeds (vsearch's default --qmask dust / --dbmask dust: orc_dust below) is ON unless the
+ *    environment holds ORC_QMASK=none; it only removes words from the k-mer sets, the alignment sees every symbol;
  *  - labels are the identifiers up to the first blank;
  *  - the uc CIGAR column is not produced (the consumer, Dedup.parse SeqSample.py:542-562, reads columns
  *    0, 8 and 9 only).
@@ -90,14 +91,65 @@ void orc_align_identity(const uint8_t *q, int Lq, const uint8_t *t, int Lt, int6
   free(H); free(F);
 }
 
-/* distinct unambiguous 8-mers of a mask sequence, first base in the low bits; returns count, fills bitmap[65536/8] */
-static int kmer_set(const uint8_t *m, int L, uint8_t *bitmap, uint16_t *list)
+/*
+ * orc_dust -- the DUST low-complexity filter as vsearch applies it (mask.cc: dust() / wo(), after Tatusov & Lipman's `dust`;
+ * restated from the published algorithm -- PARITY UNPINNED like the rest of this file): windows of 64 symbols that advance
+ * by 32; inside a window, for every start i and every end j the score 10 * sum / j, where sum adds, for each 3-mer met
+ * again, the number of times it was met before (3-mers as 2-bit codes, anything but A C G T counts as A); the best-scoring
+ * interval of a window is masked when its score exceeds 20 (the first best one in (i, j) order); after a masked window that
+ * ends in its first half the next window starts right behind it (i += 32 - b).  masked[pos] = 1 for soft-masked symbols.
+ * vsearch removes from the k-mer sets every word that touches a masked symbol, exactly like words with ambiguity symbols.
+ */
+static int dust_wo(int len, const uint8_t *s, int *beg, int *end)
+{
+  const int l1 = len - 3 + 1 - 5;                 /* the smallest possible region is 8 symbols */
+  *beg = 0; *end = 0;
+  if (l1 < 0) return 0;
+  int bestv = 0, besti = 0, bestj = 0;
+  int counts[64], words[64];
+  int word = 0;
+  for (int j = 0; j < len; j++) { word = (word << 2) | (s[j] < 4 ? s[j] : 0); words[j] = word & 63; }
+  for (int i = 0; i < l1; i++) {
+    memset(counts, 0, sizeof(counts));
+    int sum = 0;
+    for (int j = 2; j < len - i; j++) {
+      const int w = words[i + j];
+      const int c = counts[w];
+      if (c) {
+        sum += c;
+        const int v = 10 * sum / j;
+        if (v > bestv) { bestv = v; besti = i; bestj = j; }
+      }
+      counts[w]++;
+    }
+  }
+  *beg = besti; *end = besti + bestj;
+  return bestv;
+}
+void orc_dust(const uint8_t *codes, int64_t L, uint8_t *masked)
+{
+  memset(masked, 0, (size_t)L);
+  for (int64_t i = 0; i < L; i += 32) {
+    const int l = (L > i + 64) ? 64 : (int)(L - i);
+    int a, b;
+    const int v = dust_wo(l, codes + i, &a, &b);
+    if (v > 20) {
+      for (int64_t j = a + i; j <= b + i; j++) masked[j] = 1;
+      if (b < 32) i += 32 - b;
+    }
+  }
+}
+static int qmask_dust(void) { const char *e = getenv("ORC_QMASK"); return !(e && strcmp(e, "none") == 0); }
+
+/* distinct unambiguous, unmasked 8-mers of a mask sequence, first base in the low bits; returns count, fills bitmap[65536/8];
+ * msk (may be NULL): soft-masked positions, in the order of m */
+static int kmer_set(const uint8_t *m, const uint8_t *msk, int L, uint8_t *bitmap, uint16_t *list)
 {
   memset(bitmap, 0, 8192);
   int n = 0, good = 0;
   uint32_t w = 0;
   for (int i = 0; i < L; i++) {
-    if (unamb(m[i])) { w = (w >> 2) | ((uint32_t)code2(m[i]) << 14); good++; }
+    if (unamb(m[i]) && !(msk && msk[i])) { w = (w >> 2) | ((uint32_t)code2(m[i]) << 14); good++; }
     else { good = 0; w = 0; }
     if (good >= 8) {
       const uint32_t k = w & 0xffffu;
@@ -156,6 +208,11 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
   int32_t *touched = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nk + 1));
   cand_t *cand = (cand_t *)malloc(sizeof(cand_t) * (size_t)(nk + 1));
   uint8_t *qm = (uint8_t *)malloc((size_t)Lmax), *tm = (uint8_t *)malloc((size_t)Lmax);
+  /* soft masks: of the forward strand of every read (a query's reverse strand carries the reversed mask: vsearch masks the
+   * query once and reverse-complements the masked copy; a centroid is indexed with its forward mask) */
+  const int use_dust = qmask_dust();
+  uint8_t *dmask = use_dust ? (uint8_t *)malloc((size_t)(offsets[n] + 1)) : NULL, *qmsk = (uint8_t *)malloc((size_t)Lmax);
+  if (use_dust) for (int64_t r = 0; r < n; r++) orc_dust(codes + offsets[r], offsets[r + 1] - offsets[r], dmask + offsets[r]);
   uint8_t *bitmap = (uint8_t *)malloc(8192);
   uint16_t *klist = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)Lmax);
   int32_t C = 0;
@@ -170,7 +227,8 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
     for (int s = 0; s < (strand_both ? 2 : 1); s++) {
       if (s == 0) for (int i = 0; i < Lq; i++) qm[i] = MASK4[codes[offsets[r] + i]];
       else for (int i = 0; i < Lq; i++) qm[i] = (uint8_t)revmask(MASK4[codes[offsets[r] + Lq - 1 - i]]);
-      const int nq = kmer_set(qm, Lq, bitmap, klist);
+      if (use_dust) for (int i = 0; i < Lq; i++) qmsk[i] = dmask[offsets[r] + (s == 0 ? i : Lq - 1 - i)];
+      const int nq = kmer_set(qm, use_dust ? qmsk : NULL, Lq, bitmap, klist);
       if (nq == 0) continue;
       const int minm = nq < 12 ? nq : 12;
       int nt = 0;
@@ -211,7 +269,7 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
     } else {
       rep_of[r] = r;
       for (int i = 0; i < Lq; i++) qm[i] = MASK4[codes[offsets[r] + i]];
-      const int nq = kmer_set(qm, Lq, bitmap, klist);
+      const int nq = kmer_set(qm, use_dust ? dmask + offsets[r] : NULL, Lq, bitmap, klist);
       for (int a = 0; a < nq; a++) {
         post_t *pl = &post[klist[a]];
         if (pl->n == pl->cap) { pl->cap = pl->cap ? pl->cap * 2 : 4; pl->v = (int32_t *)realloc(pl->v, sizeof(int32_t) * (size_t)pl->cap); }
@@ -222,7 +280,7 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
   }
   if (stats) { stats[0] = naln; stats[1] = C; }
   for (int k = 0; k < 65536; k++) free(post[k].v);
-  free(post); free(cent_pos); free(cnt); free(touched); free(cand); free(qm); free(tm); free(bitmap); free(klist); free(ord);
+  free(post); free(cent_pos); free(cnt); free(touched); free(cand); free(qm); free(tm); free(bitmap); free(klist); free(ord); free(dmask); free(qmsk);
   return nk;
 }
 
@@ -233,8 +291,9 @@ int64_t orc_cluster(const uint8_t *codes, const int64_t *offsets, int64_t n, con
  * test or fixture for it).  The procedure: the distinct unambiguous 12-mers (--wordlength 12) of the query and of its
  * reverse complement are looked up in the set of 12-mers of the database sequences; with count_fwd / count_rev hits the
  * read is forward when count_fwd >= 1 and count_fwd >= 4 * count_rev, reverse (to be reverse-complemented) when
- * count_rev >= 1 and count_rev >= 4 * count_fwd, otherwise undetermined (not written).  No DUST masking (vsearch masks
- * query and database by default), as in the clustering restatement above.
+ * count_rev >= 1 and count_rev >= 4 * count_fwd, otherwise undetermined (not written).  Query and database sequences are
+ * DUST-masked first (vsearch's defaults --qmask dust --dbmask dust; orc_dust above): words that touch a masked symbol are
+ * left out on both sides; ORC_QMASK=none switches the masking off.
  *   dbbits: 4^12 bits (2 MB), bit k set when 12-mer k (first base in the low bits) occurs in the database.
  */
 static inline uint32_t rc24(uint32_t k)
@@ -246,22 +305,27 @@ static inline uint32_t rc24(uint32_t k)
 void orc_orient_db_add(uint8_t *dbbits, const uint8_t *codes, int64_t L)
 {
   uint32_t w = 0; int good = 0;
+  uint8_t *msk = qmask_dust() ? (uint8_t *)malloc((size_t)L + 1) : NULL;
+  if (msk) orc_dust(codes, L, msk);
   for (int64_t i = 0; i < L; i++) {
-    if (codes[i] < 4) { w = (w >> 2) | ((uint32_t)codes[i] << 22); good++; } else { good = 0; w = 0; }
+    if (codes[i] < 4 && !(msk && msk[i])) { w = (w >> 2) | ((uint32_t)codes[i] << 22); good++; } else { good = 0; w = 0; }
     if (good >= 12) dbbits[w >> 3] |= (uint8_t)(1u << (w & 7));
   }
+  free(msk);
 }
 void orc_orient(const uint8_t *dbbits, const uint8_t *codes, const int64_t *offsets, int64_t n, int8_t *strand, int32_t *cfwd, int32_t *crev)
 {
   uint8_t *seen = (uint8_t *)calloc(1u << 21, 1);
-  uint32_t *list = NULL; int64_t cap = 0;
+  uint32_t *list = NULL; int64_t cap = 0, mcap = 0;
+  uint8_t *msk = NULL; const int use_dust = qmask_dust();
   for (int64_t r = 0; r < n; r++) {
     const int64_t L = offsets[r + 1] - offsets[r];
     if (L > cap) { cap = L; list = (uint32_t *)realloc(list, sizeof(uint32_t) * (size_t)cap); }
     int64_t nk = 0; uint32_t w = 0; int good = 0;
+    if (use_dust) { if (L > mcap) { mcap = L; msk = (uint8_t *)realloc(msk, (size_t)mcap + 1); } orc_dust(codes + offsets[r], L, msk); }
     for (int64_t i = 0; i < L; i++) {
       const uint8_t c = codes[offsets[r] + i];
-      if (c < 4) { w = (w >> 2) | ((uint32_t)c << 22); good++; } else { good = 0; w = 0; }
+      if (c < 4 && !(use_dust && msk[i])) { w = (w >> 2) | ((uint32_t)c << 22); good++; } else { good = 0; w = 0; }
       if (good >= 12 && !(seen[w >> 3] & (1u << (w & 7)))) { seen[w >> 3] |= (uint8_t)(1u << (w & 7)); list[nk++] = w; }
     }
     int32_t f = 0, v = 0;
@@ -274,5 +338,5 @@ void orc_orient(const uint8_t *dbbits, const uint8_t *codes, const int64_t *offs
     cfwd[r] = f; crev[r] = v;
     strand[r] = (f >= 1 && f >= 4 * v) ? 1 : (v >= 1 && v >= 4 * f) ? -1 : 0;
   }
-  free(seen); free(list);
+  free(seen); free(list); free(msk);
 }

@@ -322,3 +322,13 @@ def mr_fail_counts(reset=False):
     out = (C.c_longlong * 8)()
     lib().orc_mr_fail_counts(out, int(reset))
     return [int(x) for x in out]
+
+
+def dust(seq):
+    """vsearch's DUST soft mask of one sequence (orc_dust): a bool array, True = masked"""
+    codes, _ = digitize([seq])
+    out = np.zeros(max(1, len(seq)), np.uint8)
+    lib().orc_dust.restype = None
+    lib().orc_dust.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib().orc_dust(codes.ctypes.data, len(seq), out.ctypes.data)
+    return out[:len(seq)].astype(bool)

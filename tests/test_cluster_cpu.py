@@ -48,11 +48,47 @@ def py_align(q, t):
     return s, m, -c
 
 
-def py_words(s):
-    return {s[i:i + 8] for i in range(len(s) - 7) if all(ch in "ACGT" for ch in s[i:i + 8])}
+def py_dust(seq):
+    """vsearch's DUST soft mask (mask.cc dust()/wo(), after Tatusov & Lipman), stated independently of orc_dust: windows of 64
+    that advance by 32, 3-mer repeat score 10 * sum / j, masked above 20, the first best interval in (i, j) order"""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "U": 3}
+    s = [code.get(c, 0) for c in seq.upper()]
+    masked = [False] * len(s)
+    i = 0
+    while i < len(s):
+        win = s[i:i + 64]
+        n = len(win)
+        best = (0, 0, 0)
+        if n - 7 >= 0:
+            tri = [((win[j - 2] if j >= 2 else 0) << 4 | (win[j - 1] if j >= 1 else 0) << 2 | win[j]) for j in range(n)]
+            for a in range(n - 7):
+                seen, total = {}, 0
+                for j in range(2, n - a):
+                    w = tri[a + j]
+                    c = seen.get(w, 0)
+                    if c:
+                        total += c
+                        v = 10 * total // j
+                        if v > best[0]:
+                            best = (v, a, j)
+                    seen[w] = c + 1
+        v, a, j = best
+        if v > 20:
+            for k in range(a + i, a + j + i + 1):
+                masked[k] = True
+            if a + j < 32:
+                i += 32 - (a + j)
+        i += 32
+    return masked
 
 
-def py_cluster(reads, names, cid, strand_both=True, minlen=32):
+def py_words(s, masked=None):
+    ok = [ch in "ACGT" and not (masked and masked[i]) for i, ch in enumerate(s)]
+    return {s[i:i + 8] for i in range(len(s) - 7) if all(ok[i:i + 8])}
+
+
+def py_cluster(reads, names, cid, strand_both=True, minlen=32, dust=True):
+    masks = [py_dust(r) if dust else None for r in reads]
     order = sorted((i for i in range(len(reads)) if len(reads[i]) >= minlen), key=lambda i: (names[i].encode(), i))
     cents = []                                      # (read index, words, position)
     rep_of = [-1] * len(reads)
@@ -62,7 +98,7 @@ def py_cluster(reads, names, cid, strand_both=True, minlen=32):
         best = None
         for s in (0, 1) if strand_both else (0,):
             q = reads[r] if s == 0 else reads[r][::-1].translate(_RC)
-            qw = py_words(q)
+            qw = py_words(q, masks[r] if s == 0 or masks[r] is None else masks[r][::-1])
             if not qw:
                 continue
             minm = min(12, len(qw))
@@ -84,7 +120,7 @@ def py_cluster(reads, names, cid, strand_both=True, minlen=32):
                 rejects += 1
         if best is None:
             rep_of[r] = r
-            cents.append((r, py_words(reads[r]), pos))
+            cents.append((r, py_words(reads[r], masks[r]), pos))
         else:
             rep_of[r] = cents[best[0]][0]
             strand[r] = best[2]
@@ -183,3 +219,57 @@ def test_cluster_semantics():
     # without labels the input order is the processing order
     codes, off = orc.digitize([one, t])
     assert orc.cluster(codes, off, None, 0.99)["rep_of"].tolist() == [0, 0]
+
+
+def _low_complexity_library(seed, n):
+    """templates with homopolymer / microsatellite stretches: DUST removes their words from the seeds of queries and centroids"""
+    rng = np.random.default_rng(seed)
+    rnd = lambda k: "".join(rng.choice(list("ACGT"), k))
+    tmpl = []
+    for t in range(5):
+        core = [rnd(30), "A" * int(rng.integers(12, 30)), rnd(25), "CA" * int(rng.integers(8, 20)), rnd(20), "TTG" * int(rng.integers(6, 12)), rnd(30)]
+        tmpl.append("".join(core[k] for k in rng.permutation(len(core))))
+    reads, names = [], []
+    for i in range(n):
+        s = list(tmpl[int(rng.integers(0, 5))])
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, len(s)))] = str(rng.choice(list("ACGTN")))
+        s = "".join(s)
+        if rng.random() < 0.3:
+            s = s[::-1].translate(_RC)
+        reads.append(s)
+        names.append("d%04d" % int(rng.integers(0, 5000)))
+    return reads, names
+
+
+def test_dust_mask_matches_the_python_statement():
+    rng = np.random.default_rng(4)
+    rnd = lambda k: "".join(rng.choice(list("ACGT"), k))
+    seqs = [rnd(200), rnd(80) + "A" * 40 + rnd(80), rnd(60) + "AC" * 25 + rnd(90), rnd(50) + "ACG" * 12 + rnd(150), "T" * 30, "ACGTTGCA" * 20,
+            rnd(5), rnd(7), rnd(8), "A" * 8, rnd(63) + "G" * 20, rnd(33) + "N" * 30 + rnd(40), rnd(31) + "GA" * 9 + rnd(28) + "C" * 11 + rnd(70)]
+    reads, _ = _low_complexity_library(7, 40)
+    n_masked = 0
+    for s in seqs + reads:
+        m = orc.dust(s)
+        assert m.tolist() == py_dust(s), s
+        n_masked += int(m.sum())
+    assert not orc.dust(seqs[0]).any() and orc.dust(seqs[1])[85:115].all() and orc.dust("T" * 30).all() and n_masked > 1000
+    # anything but A C G T counts as A: a run of N is a homopolymer to DUST
+    assert orc.dust(seqs[11])[40:55].all()
+
+
+def test_cluster_with_dust_masking_matches_the_python_statement(monkeypatch):
+    """vsearch's default --qmask dust: words that touch a soft-masked symbol are left out of the k-mer sets of queries AND
+    centroids; the alignment still sees every symbol.  C restatement == the Python statement with the masking on (default)
+    and off (ORC_QMASK=none), and the masking does change outcomes on low-complexity reads."""
+    reads, names = _low_complexity_library(11, 80)
+    codes, off = orc.digitize(reads)
+    res = {}
+    for dust in (True, False):
+        if not dust:
+            monkeypatch.setenv("ORC_QMASK", "none")
+        o = orc.cluster(codes, off, names, 0.97)
+        rep_of, strand, pct, order = py_cluster(reads, names, 0.97, dust=dust)
+        assert o["order"].tolist() == order and o["rep_of"].tolist() == rep_of and o["strand"].tolist() == strand and o["pct_id"].tolist() == pct
+        res[dust] = (o["rep_of"].tolist(), o["n_alignments"])
+    assert res[True] != res[False]              # fewer shared words -> other candidates, other walks

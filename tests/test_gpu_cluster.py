@@ -196,3 +196,54 @@ def test_cluster_then_search_and_files(engine, mini_hmm_text, tmp_path):
     rs, re_, rt, _ = engine.rep_coords("3_", "4_")
     _, _, uniq_of = engine.get_derep()
     assert np.array_equal(start, rs[uniq_of]) and np.array_equal(stop, re_[uniq_of]) and (start >= 0).sum() > 1000
+
+
+def _low_complexity_reads(seed, n):
+    """homopolymer / microsatellite stretches inside amplicon-like reads, plus the edge shapes of the windowed filter"""
+    rng = np.random.default_rng(seed)
+    rnd = lambda k: "".join(rng.choice(list("ACGT"), int(k)))
+    tmpl = []
+    for t in range(8):
+        core = [rnd(40), "A" * int(rng.integers(10, 40)), rnd(35), "CA" * int(rng.integers(6, 30)), rnd(30), "TTG" * int(rng.integers(5, 14)), rnd(45),
+                "ACGTTGCA" * int(rng.integers(0, 6)), rnd(rng.integers(0, 70))]
+        tmpl.append("".join(core[k] for k in rng.permutation(len(core))))
+    reads, names = [], []
+    for i in range(n):
+        s = list(tmpl[int(rng.integers(0, len(tmpl)))])
+        for _ in range(int(rng.integers(0, 5))):
+            s[int(rng.integers(0, len(s)))] = str(rng.choice(list("ACGTN")))
+        s = "".join(s)
+        if rng.random() < 0.3:
+            s = s[::-1].translate(_RC)
+        reads.append(s)
+        names.append("d%05d" % int(rng.integers(0, 50000)))
+    return reads, names
+
+
+def test_dust_masks_equal_the_oracle(engine):
+    """k_dust (one wave per read, one lane per window start) == orc_dust on every base: window advance, the pull-forward after a
+    masked first half, reads shorter than a window, N runs (N counts as A)"""
+    rng = np.random.default_rng(3)
+    rnd = lambda k: "".join(rng.choice(list("ACGT"), int(k)))
+    reads, _ = _low_complexity_reads(5, 300)
+    reads += [rnd(200), "T" * 30, "A" * 8, rnd(5), rnd(7), rnd(8), rnd(63) + "G" * 20, rnd(64), rnd(65), rnd(33) + "N" * 30 + rnd(40), "AC" * 400,
+              rnd(31) + "GA" * 9 + rnd(28) + "C" * 11 + rnd(70), rnd(95) + "T" * 33, "G" * 33 + rnd(95), rnd(1500) + "CAG" * 30 + rnd(700)]
+    engine.set_reads(reads)
+    got = engine.debug_dust([len(r) for r in reads])
+    n_masked = 0
+    for r, g in zip(reads, got):
+        exp = orc.dust(r)
+        assert np.array_equal(g, exp), r[:80]
+        n_masked += int(exp.sum())
+    assert n_masked > 10000
+
+
+def test_cluster_with_dust_masked_seeds(engine, monkeypatch):
+    """vsearch's default --qmask dust / --dbmask dust (SeqSample.py:147-161 passes neither option): engine == oracle with the
+    masking on (the default) and off (ITSX_QMASK=none / ORC_QMASK=none), and it changes outcomes on low-complexity reads"""
+    reads, names = _low_complexity_reads(6, 1500)
+    o1, _ = _compare(engine, reads, names, 0.97)
+    monkeypatch.setenv("ITSX_QMASK", "none")
+    monkeypatch.setenv("ORC_QMASK", "none")
+    o0, _ = _compare(engine, reads, names, 0.97)
+    assert o1["n_alignments"] != o0["n_alignments"]

@@ -198,6 +198,22 @@ def cpu_baseline(hmm_text, blob, offs, sample_reads, threads, lp="3_", rp="4_", 
     return sample_reads / dt, dt, nc, coords, seqs, extra
 
 
+def stage_a(acc, K, n_reads, mean_len, cluster_id):
+    ms_pack, ms_group = acc.get("ms_pack", 0.0) / K, (acc.get("ms_cluster", 0.0) if cluster_id < 1.0 else acc.get("ms_derep", 0.0)) / K
+    alg = n_reads * (-(-mean_len // 4) + 48.0)
+    text = n_reads * mean_len
+    out = {"ms_pack": round(ms_pack, 3), "ms_group": round(ms_group, 3), "alg_bytes": alg, "text_bytes": text,
+           "note": "pack = ASCII text -> 2-bit words + exception list (reads the text once, writes L / 4); group = hash, table insert, exact "
+                   "verification, unique lists (row a1) or the greedy clustering (row a2: alignment-bound, not a streaming stage)"}
+    if ms_pack > 0:
+        out["pack_GBps"] = round((text + n_reads * mean_len / 4.0) / (ms_pack * 1e-3) / 1e9, 1)
+        out["pack_hbm_frac"] = round(out["pack_GBps"] / HBM_PEAK_GBS, 4)
+    if ms_group > 0 and cluster_id >= 1.0:
+        out["derep_GBps_on_alg_bytes"] = round(alg / (ms_group * 1e-3) / 1e9, 1)
+        out["derep_hbm_frac_on_alg_bytes"] = round(out["derep_GBps_on_alg_bytes"] / HBM_PEAK_GBS, 4)
+    return out
+
+
 def physical_cores():
     """distinct (physical id, core id) pairs of /proc/cpuinfo: os.cpu_count() counts hardware THREADS"""
     try:
@@ -543,6 +559,9 @@ def main():
             "cluster": None if args.cluster_id >= 1.0 else {"windows": int(st["cl_windows"]), "cut_windows": int(st["cl_cuts"]),
                                                             "alignments": int(st["cl_alignments"]), "certified_rejections": int(st["cl_certified"]),
                                                             "centroids": int(st["n_unique"]), "ms_per_step": round(acc.get("ms_cluster", 0.0) / K, 1)},
+            # stage A ("the genuinely HBM-bound stage"): device packing of the resident text + dereplication (or clustering),
+            # on SURVEY's algorithmic bytes per read, ceil(L / 4) + 48 (+ the L bytes of ASCII text the packing kernel reads here)
+            "stage_a": stage_a(acc, K, n_local, mean_len, args.cluster_id),
             "roofline": roof,
             "valu": {"msv_gcups": st["msv_cells"] / (kern["k_msv"] * 1e-3) / 1e9 if kern["k_msv"] > 0 else None,
                      "fwd_rows_per_s": rows / (kern["k_filters_fwd"] * 1e-3) if kern["k_filters_fwd"] > 0 else None,

@@ -996,7 +996,8 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
 
   DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, acc_col, is_new, new_rank, scan_tmp, xlist, xn, hard, dbg;
   DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm, canon, ctab_val, need;
-  DBuf<int32_t> cw_n, wsum, wscan, qi_cnt, qi_cur, qi_off, ncand, ntop, ovf;
+  DBuf<int32_t> cw_n, wsum, wscan, qi_cnt, qi_cur, qi_off, ncand, ntop, ovf, qi_hid, qi_nheavy;
+  DBuf<uint32_t> qi_bm;
   DBuf<int64_t> cw_off, cw_base;
   DBuf<uint16_t> klist, cw_poolA, cw_poolB, qi_ent, tq, minm, cntx;
   DBuf<unsigned long long> ctab_key, n_skipped, pre_stats, cand, tkey;
@@ -1031,6 +1032,9 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   // the window's query index, the strands' thresholds and candidate lists, the counts against the window's own centroids
   HIPCHK(qi_cnt.alloc(65537)); HIPCHK(qi_cur.alloc(65536)); HIPCHK(qi_off.alloc(65537));
   HIPCHK(qi_ent.alloc(nqs * (size_t)kcap + 65536 * 8 + 64));
+  int32_t hcap = 16384;                                     // strand bitmaps of conserved words (1 KB each); ITSX_CL_HEAVY=0: every word keeps its list
+  if (const char *e = getenv("ITSX_CL_HEAVY")) hcap = std::max(0, std::min(65536, atoi(e)));
+  HIPCHK(qi_hid.alloc(65536)); HIPCHK(qi_nheavy.alloc(1)); HIPCHK(qi_bm.alloc((size_t)std::max(hcap, 1) * (CL_QS_MAX / 32)));
   HIPCHK(tq.alloc(CL_QS_MAX + 8)); HIPCHK(minm.alloc(CL_QS_MAX + 8)); HIPCHK(tkey.alloc(nqs)); HIPCHK(ncand.alloc(nqs)); HIPCHK(ntop.alloc(nqs)); HIPCHK(ovf.alloc(1));
   int32_t cand_cap = 4096;                                  // per strand; grows (and the window is searched again) when a list overflows
   if (const char *e = getenv("ITSX_CL_CCAP")) cand_cap = std::max(32, atoi(e));
@@ -1048,6 +1052,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.klist = klist.p; a.kcap = kcap; a.nk = knk.p;
   a.cw_off = cw_off.p; a.cw_n = cw_n.p; a.cw_base = cw_base.p; a.wsum = wsum.p; a.wscan = wscan.p;
   a.qi_cnt = qi_cnt.p; a.qi_cur = qi_cur.p; a.qi_off = qi_off.p; a.qi_ent = qi_ent.p;
+  a.qi_hid = qi_hid.p; a.qi_nheavy = qi_nheavy.p; a.qi_bm = qi_bm.p; a.hcap = hcap;
   a.tq = tq.p; a.minm = minm.p; a.tkey = tkey.p; a.ncand = ncand.p; a.ntop = ntop.p; a.ovf = ovf.p; a.cntx = cntx.p;
   a.state = state.p; a.rejects = rejects.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.acc_id = acc_id.p;
   a.sel = sel.p; a.selm = selm.p; a.sel_short = sel_short.p; a.selkey = selkey.p; a.selpid = selpid.p;

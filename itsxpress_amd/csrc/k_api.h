@@ -51,6 +51,9 @@ struct ClusterArgs {
   // the window's query index: word -> the (query strand) byte offsets 4 * qs that hold it, each list padded to 8 entries with the
   // dummy offset 4 * QS_MAX
   int32_t *qi_cnt, *qi_cur, *qi_off; uint16_t *qi_ent;   // [65537], [65536], [65537], [qi_off[65536]]
+  // conserved words (held by >= CL_HEAVY strands of the window) have no list: a bitmap over the window's strands instead, added
+  // by bit-sliced carry-save adders (one dword = 32 strands per lane) -- an LDS atomic per (strand, word) is what the lists cost
+  int32_t *qi_hid; int32_t *qi_nheavy; uint32_t *qi_bm; int32_t hcap;   // [65536] bitmap number or -1; [1]; [hcap][CL_QS_MAX / 32]
   uint16_t *tq, *minm;          // [CL_QS_MAX + 8] count threshold of the streaming pass (the count in tkey, at least minm) / min(12, words); 0xFFFF = never
   unsigned long long *tkey;     // [2 nq] rank key of the strand's 32nd best candidate so far (0: fewer than 32 yet)
   unsigned long long *cand; int32_t *ncand; int32_t ccap; int32_t *ovf;   // appended candidate keys [2 nq][ccap]; ovf[0] = a list overflowed
@@ -82,6 +85,7 @@ struct ClusterArgs {
   int32_t pre_k;                                 // largest edit budget K of this run (sizes the certificate's LDS rows)
 };
 constexpr int CL_QS_MAX = 8192;  // query strands of one window (2 x the largest window)
+constexpr int CL_HEAVY = 128;    // a word held by at least this many strands of the window goes through its strand bitmap
 void launch_cl_kmers(const ClusterArgs &a, hipStream_t st);
 void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st);
 void launch_cl_stream(const ClusterArgs &a, int c0, int c1, int mode, hipStream_t st);      // mode 1: the old centroids [c0, c1); mode 2: the window's speculative ones

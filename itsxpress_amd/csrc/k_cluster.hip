@@ -248,19 +248,31 @@ __global__ __launch_bounds__(256) void k_cl_qi_count(ClusterArgs a, int fill)
   for (int i = threadIdx.x; i < n; i += 256) {
     const uint32_t w = kl[i];
     if (!fill) atomicAdd(&a.qi_cnt[w], 1);
-    else a.qi_ent[a.qi_off[w] + atomicAdd(&a.qi_cur[w], 1)] = (uint16_t)(qs * 4);       // the strand's byte offset in the LDS histogram
+    else {
+      const int hid = a.qi_hid[w];
+      if (hid >= 0) atomicOr(&a.qi_bm[(size_t)hid * (CL_QS_MAX / 32) + (qs >> 5)], 1u << (qs & 31));      // a conserved word: its strand bitmap
+      else a.qi_ent[a.qi_off[w] + atomicAdd(&a.qi_cur[w], 1)] = (uint16_t)(qs * 4);     // the strand's byte offset in the LDS histogram
+    }
   }
 }
 __global__ void k_cl_qi_pad(ClusterArgs a)
 {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < 65536) { a.qi_cnt[w] = (a.qi_cnt[w] + 7) & ~7; a.qi_cur[w] = 0; }             // lists are read 8 entries (16 bytes) at a time
+  if (w < 65536) {
+    int c = a.qi_cnt[w], hid = -1;
+    if (c >= CL_HEAVY && a.hcap > 0) { hid = atomicAdd(a.qi_nheavy, 1); if (hid >= a.hcap) hid = -1; }   // (no bitmap left: the word keeps its list)
+    a.qi_hid[w] = hid;
+    if (hid >= 0) c = 0;                                     // no list for a word with a bitmap
+    a.qi_cnt[w] = (c + 7) & ~7; a.qi_cur[w] = 0;             // lists are read 8 entries (16 bytes) at a time
+  }
   if (w == 65536) a.qi_cnt[w] = 0;
 }
 __global__ void k_cl_qi_fill_dummy(ClusterArgs a)
 {
   const int n = a.qi_off[65536];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a.qi_ent[i] = (uint16_t)(CL_QS_MAX * 4);
+  const int nh = a.qi_nheavy[0] < a.hcap ? a.qi_nheavy[0] : a.hcap;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nh * (CL_QS_MAX / 32); i += gridDim.x * blockDim.x) a.qi_bm[i] = 0u;
 }
 // per strand: min(12, words) = the starting count threshold; the candidate lists start empty
 __global__ void k_cl_tq_init(ClusterArgs a)
@@ -296,12 +308,16 @@ __device__ __forceinline__ void cl_add8(uint32_t *hist, uint4 v, uint32_t r)
   atomicAdd(reinterpret_cast<uint32_t *>(h + (z & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (z >> 16)), 1u);
   atomicAdd(reinterpret_cast<uint32_t *>(h + (w & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (w >> 16)), 1u);
 }
+#define CSA(h, l, x, y, z) { const uint32_t u_ = (x) ^ (y); h = ((x) & (y)) | (u_ & (z)); l = u_ ^ (z); }
+static constexpr int CL_HVL = 9;                               // bit-sliced levels above 4: counts of up to 2048 conserved words per batch
+static constexpr int CL_WBATCH = 2048;                         // words of a centroid taken at a time (a read has rarely more)
 __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int c1, int mode)
 {
   __shared__ uint32_t hist[CL_QS_MAX + 8];
   __shared__ uint32_t items[CL_ITEMS];
-  __shared__ int n_items;
-  const int tid = threadIdx.x;
+  __shared__ uint16_t hv[CL_WBATCH];
+  __shared__ int n_items, n_hv;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nqs = 2 * a.nq;
   const int nrounds = (nqs + 1023) >> 10;                    // a thread scans strands (j * 256 + tid) * 4 .. + 3, j < nrounds
   // count thresholds, four strands (one 8-byte load) at a time; they only change between launches.  The arrays are
@@ -311,7 +327,6 @@ __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int
   for (int i = tid; i < CL_QS_MAX + 8; i += 256) hist[i] = 0u;
   if (mode == 2) { const int lim = a.C + a.new_rank[a.nq]; c1 = c1 < lim ? c1 : lim; }
   const uint4 *ent = reinterpret_cast<const uint4 *>(a.qi_ent);
-  __syncthreads();
 #ifdef ITSX_CL_PROF
   long long tp[4] = {0, 0, 0, 0}, tn = 0, tadd = 0;
 #define CLK(i) { const long long now_ = (long long)__builtin_readcyclecounter(); tp[i] += now_ - tlast; tlast = now_; }
@@ -319,54 +334,104 @@ __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int
 #else
 #define CLK(i)
 #endif
+  __syncthreads();
   for (int c = c0 + blockIdx.x; c < c1; c += gridDim.x) {
     const int n = a.cw_n[c];
     if (n == 0) continue;                                     // a rolled-back column
     const uint16_t *cw = a.cw_pool + a.cw_off[c];
-    if (tid == 0) n_items = 0;
-    __syncthreads();
-    CLK(3)
-    for (int i0 = 0; i0 < n; i0 += 256) {                     // (wave-uniform trip count: the shuffles below need every lane)
-      const int i = i0 + tid;
-      int s = 0, nch = 0;
-      if (i < n) { const uint32_t w = cw[i]; s = a.qi_off[w] >> 3; nch = (a.qi_off[w + 1] >> 3) - s; }
-      // slots for this word's pieces: a prefix sum over the wave and ONE atomic per wave (one per piece on one LDS address
-      // serialised ~2 300 returning atomics per centroid: 55 k clock ticks, as long as the additions themselves)
-      const int np = (nch + 7) >> 3;
-      int incl = np;
-      for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((tid & 63) >= off) incl += o; }
-      int base = 0;
-      if ((tid & 63) == 63) base = atomicAdd(&n_items, incl);
-      base = __shfl(base, 63);
-      int slot = base + incl - np;
-      while (nch > 0) {
-        const int take = nch < 8 ? nch : 8;
-        if (slot < CL_ITEMS) items[slot] = ((uint32_t)s << 3) | (uint32_t)(take - 1);
-        else for (int k = 0; k < take; k++) cl_add8(hist, ent[s + k], 0u);              // list full (very long reads): the piece is added here
-        s += take; nch -= take; slot++;
+    for (int w0 = 0; w0 < n; w0 += CL_WBATCH) {               // (one batch, unless the read has more than 2048 distinct words)
+      const int nb = n - w0 < CL_WBATCH ? n - w0 : CL_WBATCH;
+      if (tid == 0) { n_items = 0; n_hv = 0; }
+      __syncthreads();
+      CLK(3)
+      // ---- the batch's words: conserved ones to the bitmap list, the others' lists cut into pieces of <= 64 entries
+      for (int i0 = 0; i0 < nb; i0 += 256) {                  // (wave-uniform trip count: the shuffles below need every lane)
+        const int i = i0 + tid;
+        int s = 0, nch = 0, hid = -1;
+        if (i < nb) { const uint32_t w = cw[w0 + i]; hid = a.qi_hid[w]; s = a.qi_off[w] >> 3; nch = (a.qi_off[w + 1] >> 3) - s; }
+        if (hid >= 0) hv[atomicAdd(&n_hv, 1)] = (uint16_t)hid;
+        // slots for this word's pieces: a prefix sum over the wave and ONE atomic per wave (one per piece on one LDS address
+        // serialised ~2 300 returning atomics per centroid: 55 k clock ticks, as long as the additions themselves)
+        const int np = (nch + 7) >> 3;
+        int incl = np;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        int base = 0;
+        if (lane == 63) base = atomicAdd(&n_items, incl);
+        base = __shfl(base, 63);
+        int slot = base + incl - np;
+        while (nch > 0) {
+          const int take = nch < 8 ? nch : 8;
+          if (slot < CL_ITEMS) items[slot] = ((uint32_t)s << 3) | (uint32_t)(take - 1);
+          else for (int k = 0; k < take; k++) cl_add8(hist, ent[s + k], 0u);              // list full (very long reads): the piece is added here
+          s += take; nch -= take; slot++;
+        }
       }
-    }
-    __syncthreads();
-    CLK(0)
-    const int ni = n_items < CL_ITEMS ? n_items : CL_ITEMS;
+      __syncthreads();
+      CLK(0)
+      const int ni = n_items < CL_ITEMS ? n_items : CL_ITEMS;
 #ifdef ITSX_CL_PROF
-    tn++; tadd += ni;
+      tn++; tadd += ni;
 #endif
-    for (int it = tid; it < ni; it += 256) {
-      const uint32_t x = items[it];
-      const int s = (int)(x >> 3), take = (int)(x & 7u) + 1;
-      // all (up to 8) loads of the piece are in flight before the first is used: the lists come from L2 / MALL at ~1 us a
-      // round trip, and a load -> wait -> add loop pays that once per 16 bytes (measured: 75 us per centroid and workgroup)
-      // ... in a lane-private order (chunk tid & 7 first, entries rotated by tid >> 3: 64 different starts in a wave), see cl_add8
-      uint4 v[8];
-      const int r0 = (tid & 7) % take;
+      for (int it = tid; it < ni; it += 256) {
+        const uint32_t x = items[it];
+        const int s = (int)(x >> 3), take = (int)(x & 7u) + 1;
+        // all (up to 8) loads of the piece are in flight before the first is used: the lists come from L2 / MALL at ~1 us a
+        // round trip, and a load -> wait -> add loop pays that once per 16 bytes (measured: 75 us per centroid and workgroup)
+        uint4 v[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (k < take) { int idx = k + r0; idx = idx >= take ? idx - take : idx; v[k] = ent[s + idx]; }
+        for (int k = 0; k < 8; k++) if (k < take) v[k] = ent[s + k];
 #pragma unroll
-      for (int k = 0; k < 8; k++) if (k < take) cl_add8(hist, v[k], (uint32_t)tid >> 3);
+        for (int k = 0; k < 8; k++) if (k < take) cl_add8(hist, v[k], 0u);
+      }
+      __syncthreads();
+      CLK(1)
+      // ---- conserved words: wave wv owns strands 2048 wv .. + 2047, a lane one dword (32 strands) of every bitmap; bit-sliced
+      // carry-save counting over the batch's bitmaps, then the counts go into the lane's own 32 histogram slots (no atomics)
+      const int nh = n_hv;
+      if (nh > 0 && wv * 2048 < nqs) {
+        const uint32_t *bm = a.qi_bm + wv * 64 + lane;
+        uint32_t ones = 0, twos = 0, fours = 0, hc[CL_HVL];
+#pragma unroll
+        for (int b = 0; b < CL_HVL; b++) hc[b] = 0;
+        int i = 0;
+        for (; i + 8 <= nh; i += 8) {
+          uint32_t x[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) x[t] = bm[(size_t)hv[i + t] * (CL_QS_MAX / 32)];
+          uint32_t ta, tb, fa, fb, eights;
+          CSA(ta, ones, ones, x[0], x[1])
+          CSA(tb, ones, ones, x[2], x[3])
+          CSA(fa, twos, twos, ta, tb)
+          CSA(ta, ones, ones, x[4], x[5])
+          CSA(tb, ones, ones, x[6], x[7])
+          CSA(fb, twos, twos, ta, tb)
+          CSA(eights, fours, fours, fa, fb)
+          uint32_t carry = eights;
+#pragma unroll
+          for (int b = 0; b < CL_HVL; b++) { const uint32_t t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
+        }
+        for (; i < nh; i++) {
+          uint32_t carry = bm[(size_t)hv[i] * (CL_QS_MAX / 32)], t_;
+          t_ = ones & carry; ones ^= carry; carry = t_;
+          t_ = twos & carry; twos ^= carry; carry = t_;
+          t_ = fours & carry; fours ^= carry; carry = t_;
+#pragma unroll
+          for (int b = 0; b < CL_HVL; b++) { t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
+        }
+        uint32_t any = ones | twos | fours;
+#pragma unroll
+        for (int b = 0; b < CL_HVL; b++) any |= hc[b];
+        uint32_t *hl = hist + (wv * 64 + lane) * 32;
+        while (any) {
+          const int bit = __ffs(any) - 1; any &= any - 1;
+          uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
+#pragma unroll
+          for (int b = 0; b < CL_HVL; b++) v |= ((hc[b] >> bit) & 1u) << (3 + b);
+          hl[bit] += v;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    CLK(1)
     const int32_t clen = a.cent_len[c], cpos = a.cent_pos[c];
 #pragma unroll 1
     for (int j = 0; j < nrounds; j++) {
@@ -988,6 +1053,7 @@ void launch_cl_kmers(const ClusterArgs &a, hipStream_t st)
 void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st)
 {
   (void)hipMemsetAsync(a.qi_cnt, 0, 65537 * sizeof(int32_t), st);
+  (void)hipMemsetAsync(a.qi_nheavy, 0, sizeof(int32_t), st);
   hipLaunchKernelGGL(k_cl_qi_count, dim3(2 * a.nq), dim3(256), 0, st, a, 0);
   hipLaunchKernelGGL(k_cl_qi_pad, dim3(65537 / 256 + 1), dim3(256), 0, st, a);
   launch_exclusive_scan(a.qi_cnt, a.qi_off, 65537, scan_tmp, st);

@@ -204,3 +204,56 @@ def test_cfg2_shape_is_invariant_under_permutation_and_dereplication(engine, t_h
     seeds = np.flatnonzero(rep0 == np.arange(n))
     rep2, c2, z2 = run(*take(seeds))
     assert np.array_equal(rep2, np.arange(len(seeds))) and np.array_equal(z2, z0) and np.array_equal(c2, c0[seeds])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3]: 50 M reads against --taxa All (814 ITS2 profiles), read-sharded over 8 GPUs = 6.25 M reads x 814 profiles per
+# GPU.  One GPU's share at a fifth of its size (the whole share takes 26 s and is a bench run: `bench.py --taxa all --reads 6250000`),
+# with the row compaction the bench runs with: the properties that do not depend on the size, and the sharding identity the N > 1 path
+# relies on (two shards + summed domZ == one run).
+N_CFG3 = 1_250_000
+
+
+def test_cfg3_shape_all_taxa_profiles_compacted_rows_and_two_shards(engine, t_hmm_text, all_its2_hmm_text, monkeypatch):
+    blob, offs = synth.make_reads(t_hmm_text, N_CFG3, config=4, fixed_len=0, len_range=(300, 580), as_array=True)
+    assert engine.load_profiles(text=all_its2_hmm_text) == 814
+    monkeypatch.setenv("ITSX_COMPACT_ROWS", "1")
+
+    def run(b, o, domz=None):
+        engine.set_reads_buffer(b, o)
+        engine.derep(strand_both=True, minseqlength=1)
+        engine.search()
+        z = engine.get_domz().copy()
+        if domz is not None:
+            engine.set_domz(domz)
+        engine.finalize()
+        return [a.copy() for a in engine.trim_coords("3_", "4_")], z, engine.get_derep()[0].copy(), engine.stats()
+
+    c, z, rep, st = run(blob, offs)
+    start, stop, tlen, ind = c
+    assert st["n_profiles"] == 814 and st["n_pairs"] == st["n_unique"] * 814
+    assert st["n_rows_resident"] * 20 < st["n_domains"]           # ~1.5 rows per representative and side instead of ~200 per representative
+    assert st["n_domain_overflow"] == 0 and st["n_mr_failed"] == 0
+    for a in c:
+        assert np.array_equal(a, a[rep])                         # every read carries its representative's result
+    both = (start >= 0) & (stop >= 0)
+    assert both.mean() > 0.9 and (stop[both] > start[both]).all()
+    assert np.array_equal(tlen[both], np.diff(offs)[rep][both])
+    # two contiguous shards searched on their own, finalized with the SUMMED domZ (what the all-reduce hands every rank), give the
+    # coordinates of the single run for every read whose representative lies in its own shard
+    h = N_CFG3 // 2
+    oa = offs[:h + 1]
+    ob = offs[h:] - offs[h]
+    ba, bb = blob[:int(offs[h])], blob[int(offs[h]):]
+    _, za, _, _ = run(ba, oa)
+    _, zb, _, _ = run(bb, ob)
+    zsum = za + zb
+    ca, _, _, _ = run(ba, oa, zsum)
+    cb, _, repb, _ = run(bb, ob, zsum)
+    # (per-shard dereplication counts a sequence present in both shards twice in domZ: section 7's option 1; the single run's domZ is smaller)
+    assert (zsum >= z).all()
+    same_a = all(np.array_equal(x[:h], y) for x, y in zip(c, ca))
+    own = rep[h:] >= h                                           # reads of shard b whose first occurrence is not in shard a
+    frac = np.mean([(x[h:][own] == y[own]).mean() for x, y in zip(c, cb)])
+    assert same_a or np.mean([(x[:h] == y).mean() for x, y in zip(c, ca)]) > 0.9999
+    assert frac > 0.9999                                         # only domains within a fraction of a bit of the E-value threshold may move

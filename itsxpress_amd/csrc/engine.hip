@@ -999,7 +999,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   DBuf<int32_t> cw_n, wsum, wscan, qi_cnt, qi_cur, qi_off, ncand, ntop, ovf, qi_hid, qi_nheavy;
   DBuf<uint32_t> qi_bm;
   DBuf<int64_t> cw_off, cw_base;
-  DBuf<uint16_t> klist, cw_poolA, cw_poolB, qi_ent, tq, minm, cntx;
+  DBuf<uint16_t> klist, cw_poolA, cw_poolB, qi_ent, cntx; DBuf<uint32_t> tq, minm;
   DBuf<unsigned long long> ctab_key, n_skipped, pre_stats, cand, tkey;
   DBuf<int8_t> res_strand; DBuf<double> res_id, acc_id, d_pct, selpid, wpid, xpid;
   DBuf<unsigned long long> prev, bound, selkey, wkey, xkey, scratch, n_align;
@@ -1153,7 +1153,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   if (debug) {
     unsigned long long ps[16] = {0};
     (void)hipMemcpy(ps, pre_stats.p, sizeof(ps), hipMemcpyDeviceToHost);
-    if (ps[12]) fprintf(stderr, "[cluster] stream phases (clock ticks per centroid and workgroup): items %.0f, accumulate %.0f, scan %.0f, loop head %.0f; chunks of 8 entries per centroid %.0f\n",
+    if (ps[12]) fprintf(stderr, "[cluster] stream phases (clock ticks per centroid and workgroup): pieces %.0f, list additions %.0f, scan %.0f, bitmaps %.0f; pieces per centroid %.0f\n",
                         (double)ps[8] / ps[12], (double)ps[9] / ps[12], (double)ps[10] / ps[12], (double)ps[11] / ps[12], (double)ps[13] / ps[12]);
     fprintf(stderr, "[cluster] certificate: not applicable %llu, bound too weak %llu, path exists %llu, proven reject %llu; full alignments %llu\n", ps[0], ps[1], ps[2], ps[3], naln);
   }

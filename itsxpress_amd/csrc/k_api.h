@@ -54,7 +54,10 @@ struct ClusterArgs {
   // conserved words (held by >= CL_HEAVY strands of the window) have no list: a bitmap over the window's strands instead, added
   // by bit-sliced carry-save adders (one dword = 32 strands per lane) -- an LDS atomic per (strand, word) is what the lists cost
   int32_t *qi_hid; int32_t *qi_nheavy; uint32_t *qi_bm; int32_t hcap;   // [65536] bitmap number or -1; [1]; [hcap][CL_QS_MAX / 32]
-  uint16_t *tq, *minm;          // [CL_QS_MAX + 8] count threshold of the streaming pass (the count in tkey, at least minm) / min(12, words); 0xFFFF = never
+  uint32_t *tq, *minm;          // [CL_QS_MAX + 8] thresholds on the HIGH HALF of a rank key, (count << 16 | 65535 - length): a centroid is a
+                                //   candidate when its high half is greater.  tq: high half of tkey, or (min(12, words) << 16) - 1 while the strand has
+                                //   fewer than 32 candidates; minm: (min(12, words) << 16) - 1 (mode 2); 0xFFFFFFFF = never.  Exact, not a pre-test:
+                                //   centroids stream in position order, so one that ties with the 32nd key on count and length always loses on position
   unsigned long long *tkey;     // [2 nq] rank key of the strand's 32nd best candidate so far (0: fewer than 32 yet)
   unsigned long long *cand; int32_t *ncand; int32_t ccap; int32_t *ovf;   // appended candidate keys [2 nq][ccap]; ovf[0] = a list overflowed
   int32_t *ntop;                // [2 nq] candidates in sel/selkey (<= 32, rank order): the whole walk's candidate list

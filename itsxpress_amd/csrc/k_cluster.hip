@@ -282,7 +282,7 @@ __global__ void k_cl_tq_init(ClusterArgs a)
   if (qs >= 2 * a.nq) return;
   const bool own = a.canon[qs >> 1] == (qs >> 1);
   const int n = own ? a.nk[qs] : 0;
-  const uint16_t m = n > 0 ? (uint16_t)(n < 12 ? n : 12) : (uint16_t)0xFFFF;
+  const uint32_t m = n > 0 ? ((uint32_t)(n < 12 ? n : 12) << 16) - 1u : 0xFFFFFFFFu;      // count >= min(12, words), any length
   a.minm[qs] = m; a.tq[qs] = m; a.tkey[qs] = 0ULL; a.ncand[qs] = 0; a.ntop[qs] = 0;
 }
 
@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int
   // count thresholds, four strands (one 8-byte load) at a time; they only change between launches.  The arrays are
   // allocated for the largest window and the launcher sets every entry past the window's end to 0xFFFF (never reached),
   // so the scan needs no bound check.
-  const uint2 *thr = reinterpret_cast<const uint2 *>(mode == 2 ? a.minm : a.tq);
+  const uint4 *thr = reinterpret_cast<const uint4 *>(mode == 2 ? a.minm : a.tq);
+  uint4 T4[8];                                               // this thread's 32 thresholds, fixed for the launch
+#pragma unroll
+  for (int j = 0; j < 8; j++) T4[j] = j < nrounds ? thr[j * 256 + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
   for (int i = tid; i < CL_QS_MAX + 8; i += 256) hist[i] = 0u;
   if (mode == 2) { const int lim = a.C + a.new_rank[a.nq]; c1 = c1 < lim ? c1 : lim; }
   const uint4 *ent = reinterpret_cast<const uint4 *>(a.qi_ent);
@@ -343,7 +346,6 @@ __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int
       const int nb = n - w0 < CL_WBATCH ? n - w0 : CL_WBATCH;
       if (tid == 0) { n_items = 0; n_hv = 0; }
       __syncthreads();
-      CLK(3)
       // ---- the batch's words: conserved ones to the bitmap list, the others' lists cut into pieces of <= 64 entries
       for (int i0 = 0; i0 < nb; i0 += 256) {                  // (wave-uniform trip count: the shuffles below need every lane)
         const int i = i0 + tid;
@@ -394,10 +396,7 @@ __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int
 #pragma unroll
         for (int b = 0; b < CL_HVL; b++) hc[b] = 0;
         int i = 0;
-        for (; i + 8 <= nh; i += 8) {
-          uint32_t x[8];
-#pragma unroll
-          for (int t = 0; t < 8; t++) x[t] = bm[(size_t)hv[i + t] * (CL_QS_MAX / 32)];
+        auto add8 = [&](const uint32_t *x) {
           uint32_t ta, tb, fa, fb, eights;
           CSA(ta, ones, ones, x[0], x[1])
           CSA(tb, ones, ones, x[2], x[3])
@@ -409,6 +408,19 @@ __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int
           uint32_t carry = eights;
 #pragma unroll
           for (int b = 0; b < CL_HVL; b++) { const uint32_t t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
+        };
+        // the bitmaps come from L2 at about a microsecond a round trip: 32 loads are in flight before the first is used
+        for (; i + 32 <= nh; i += 32) {
+          uint32_t x[32];
+#pragma unroll
+          for (int t = 0; t < 32; t++) x[t] = bm[(size_t)hv[i + t] * (CL_QS_MAX / 32)];
+          add8(x); add8(x + 8); add8(x + 16); add8(x + 24);
+        }
+        for (; i + 8 <= nh; i += 8) {
+          uint32_t x[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) x[t] = bm[(size_t)hv[i + t] * (CL_QS_MAX / 32)];
+          add8(x);
         }
         for (; i < nh; i++) {
           uint32_t carry = bm[(size_t)hv[i] * (CL_QS_MAX / 32)], t_;
@@ -431,27 +443,26 @@ __global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int
         }
       }
       __syncthreads();
+      CLK(3)
     }
     const int32_t clen = a.cent_len[c], cpos = a.cent_pos[c];
+    const uint32_t lenpart = (uint32_t)(65535 - clen) & 0xffffu;
 #pragma unroll 1
-    for (int j = 0; j < nrounds; j++) {
+    for (int j = 0; j < nrounds; j++) {                       // (rolled: the rare hit path below exists once; T4[j] is a uniform index)
       const int base = (j * 256 + tid) * 4;
-      const uint2 t2 = thr[base >> 2];
+      const uint4 t4 = T4[j];
       const uint4 v = *reinterpret_cast<const uint4 *>(&hist[base]);
       *reinterpret_cast<uint4 *>(&hist[base]) = make_uint4(0u, 0u, 0u, 0u);
       const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-      const uint32_t tt[4] = {t2.x & 0xffffu, t2.x >> 16, t2.y & 0xffffu, t2.y >> 16};
+      const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        if (vv[e] >= tt[e]) {
+        if (((vv[e] << 16) | lenpart) > tt[e]) {              // the high half of the rank key beats the strand's 32nd (see k_api.h: exact)
           const int qs = base + e;
           if (mode == 2) a.cntx[(size_t)qs * a.xpitch + (c - a.C)] = (uint16_t)vv[e];
           else {
-            const u64 key = cand_key(vv[e], clen, cpos);
-            if (key > a.tkey[qs]) {                            // ties at the threshold count are cut by length and position
-              const int slot = atomicAdd(&a.ncand[qs], 1);
-              if (slot < a.ccap) a.cand[(size_t)qs * a.ccap + slot] = key;
-            }
+            const int slot = atomicAdd(&a.ncand[qs], 1);
+            if (slot < a.ccap) a.cand[(size_t)qs * a.ccap + slot] = cand_key(vv[e], clen, cpos);
           }
         }
       }
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(64) void k_cl_topk(ClusterArgs a, int final)
   if (lane < m) keys[lane] = top[lane];
   if (lane == 0) {
     a.ncand[qs] = m;
-    if (m == 32) { a.tkey[qs] = top[31]; const uint16_t c = (uint16_t)(top[31] >> 48); if (c > a.tq[qs]) a.tq[qs] = c; }
+    if (m == 32) { a.tkey[qs] = top[31]; a.tq[qs] = (uint32_t)(top[31] >> 32); }
     if (final) a.ntop[qs] = m;
   }
   if (final && lane < m) {
@@ -1060,8 +1071,8 @@ void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st)
   hipLaunchKernelGGL(k_cl_qi_fill_dummy, dim3(1024), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_cl_qi_count, dim3(2 * a.nq), dim3(256), 0, st, a, 1);
   // strands past the window's end never reach a threshold (k_cl_stream scans four strands per load without a bound check)
-  (void)hipMemsetAsync(a.tq, 0xff, (size_t)(CL_QS_MAX + 8) * sizeof(uint16_t), st);
-  (void)hipMemsetAsync(a.minm, 0xff, (size_t)(CL_QS_MAX + 8) * sizeof(uint16_t), st);
+  (void)hipMemsetAsync(a.tq, 0xff, (size_t)(CL_QS_MAX + 8) * sizeof(uint32_t), st);
+  (void)hipMemsetAsync(a.minm, 0xff, (size_t)(CL_QS_MAX + 8) * sizeof(uint32_t), st);
   hipLaunchKernelGGL(k_cl_tq_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a);
 }
 void launch_cl_stream(const ClusterArgs &a, int c0, int c1, int mode, hipStream_t st)

@@ -512,7 +512,10 @@ def main():
                     "note": "a serial recurrence per (representative, profile): the recurrence's own no-FMA fp32 flops per lane-row (HMMER rounds "
                             "products and sums separately; Forward 960, Backward 1056 with its four unconditional DD passes: the count is "
                             "spelled out at the top of bench.py) against 78.6 TFLOP/s = 1024 SIMDs x 32 lanes x 2.4 GHz; duration = HIP events on the "
-                            "engine's stream; traffic = PMC bytes per lane-row x rows per launch (profiles/round2_*)"}
+                            "engine's stream; traffic = PMC bytes per lane-row x rows per launch (profiles/round2_*).  "
+                            "hbm_frac_on_alg_bytes / alg_bytes_per_launch count the DP slab rows (24 B written + 24 B read per lane-row) as the kernel's "
+                            "algorithmic bytes: a cost of this design (rows handed from Forward to Backward to the decoder through HBM), ~14 000 x "
+                            "SURVEY 8d's per-read bytes for the whole path -- beside the kernel's VALU bound, not a measure of efficiency"}
         else:
             ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

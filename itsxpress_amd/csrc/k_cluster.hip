@@ -289,7 +289,7 @@ __global__ void k_cl_tq_init(ClusterArgs a)
 // ------------------------------------------------------------------ the centroids stream past the window
 // One workgroup, one centroid at a time.  items[] = pieces (<= 8 x 8 entries) of the word lists the centroid touches, so that
 // a conserved word held by thousands of strands is spread over the threads instead of serialising one of them.
-static constexpr int CL_ITEMS = 4096;
+static constexpr int CL_ITEMS = 1024;                          // (a centroid makes ~300 pieces once the conserved words go through bitmaps)
 // Eight entries (one 16-byte load) of a word's list go into the histogram.  The lists of a centroid's words are nearly the
 // SAME list when the window holds reads of the centroid's own family (every one of those strands has every one of those
 // words), and they are filled in nearly the same order, so lanes that walk 64 of them in step would hit ONE address per
@@ -309,9 +309,9 @@ __device__ __forceinline__ void cl_add8(uint32_t *hist, uint4 v, uint32_t r)
   atomicAdd(reinterpret_cast<uint32_t *>(h + (w & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (w >> 16)), 1u);
 }
 #define CSA(h, l, x, y, z) { const uint32_t u_ = (x) ^ (y); h = ((x) & (y)) | (u_ & (z)); l = u_ ^ (z); }
-static constexpr int CL_HVL = 9;                               // bit-sliced levels above 4: counts of up to 2048 conserved words per batch
-static constexpr int CL_WBATCH = 2048;                         // words of a centroid taken at a time (a read has rarely more)
-__global__ __launch_bounds__(256, 3) void k_cl_stream(ClusterArgs a, int c0, int c1, int mode)
+static constexpr int CL_HVL = 8;                               // bit-sliced levels above 4: counts of up to 1024 conserved words per batch
+static constexpr int CL_WBATCH = 1024;                         // words of a centroid taken at a time (a read has rarely more)
+__global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int c1, int mode)
 {
   __shared__ uint32_t hist[CL_QS_MAX + 8];
   __shared__ uint32_t items[CL_ITEMS];
@@ -1078,7 +1078,7 @@ void launch_cl_qindex(const ClusterArgs &a, int32_t *scan_tmp, hipStream_t st)
 void launch_cl_stream(const ClusterArgs &a, int c0, int c1, int mode, hipStream_t st)
 {
   if (c1 <= c0) return;
-  hipLaunchKernelGGL(k_cl_stream, dim3(std::min(c1 - c0, 768)), dim3(256), 0, st, a, c0, c1, mode);
+  hipLaunchKernelGGL(k_cl_stream, dim3(std::min(c1 - c0, 1024)), dim3(256), 0, st, a, c0, c1, mode);      // four workgroups per CU (LDS 39 KB, <= 128 registers)
 }
 void launch_cl_topk(const ClusterArgs &a, int final, hipStream_t st) { hipLaunchKernelGGL(k_cl_topk, dim3(2 * a.nq), dim3(64), 0, st, a, final); }
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }

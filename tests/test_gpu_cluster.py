@@ -134,6 +134,15 @@ def test_cluster_multipass_alignment(engine, monkeypatch):
     _compare(engine, reads, names, 0.99)
 
 
+@pytest.mark.parametrize("heavy", ["0", "3"])
+def test_cluster_conserved_words_by_bitmap_or_by_list(engine, heavy, monkeypatch):
+    # words held by >= 128 strands of a window are counted through strand bitmaps (bit-sliced adders) instead of their lists;
+    # with no bitmaps at all (0) and with only three of them (the rest of the conserved words keep their lists) the outcome is the same
+    monkeypatch.setenv("ITSX_CL_HEAVY", heavy)
+    reads, names = _noisy_library(51, 2500, 6, (180, 230), max_err=3, n_rate=0.003, rc_rate=0.2, shared_flank=50)
+    _compare(engine, reads, names, 0.985)
+
+
 def test_cluster_index_growth(engine, monkeypatch):
     # more centroid words than the initial capacity of the word pool: the pool is doubled (with a copy) on the way
     monkeypatch.setenv("ITSX_CL_CAPACITY", "2048")

@@ -76,7 +76,7 @@ __device__ __forceinline__ u64 cand_key(uint32_t cnt, int32_t len, int32_t pos)
 
 // ------------------------------------------------------------------ DUST soft masking of the seeds (vsearch --qmask dust / --dbmask dust)
 // vsearch's default for --cluster_size and --orient: words that touch a soft-masked symbol are left out of the k-mer sets (the
-// alignment sees every symbol).  mask.cc's dust() / wo() (after Tatusov & Lipman) restated like oracle/orc_cluster.c:orc_dust:
+// alignment sees every symbol).  mask.cc's dust() / wo() (after Tatusov & Lipman) restated (the CPU test checker states it a second time, Python a third):
 // windows of 64 symbols advancing by 32; per window, for every start i (one LANE each) the running 3-mer repeat score
 // 10 * sum / j over the ends j; the first best (i, j) of the window is masked when its score exceeds 20; a masked window that
 // ends in its first half pulls the next one forward.  One wave per read (the windows of a read depend on each other), the

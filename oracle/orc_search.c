@@ -1181,15 +1181,42 @@ orc_results *orc_search(const orc_hmmset *hs, const uint8_t *codes, const int64_
     free(dsq); ws_free(&w);
     _mm_setcsr(csr);
   }
+  /* the domain rows of all threads, in (profile, sequence, domain) order.  Every (sequence, profile) pair was scored by exactly one
+   * thread and its rows carry ndom, so the place of every row follows from a count per pair and a prefix sum: no comparison sort,
+   * and the scatter runs on all threads (a serial merge + qsort of millions of 80-byte rows was most of the timed CPU-baseline leg
+   * on a 256-thread host) */
+  int64_t total_dom = 0;
+  for (int t = 0; t < nthreads; t++) total_dom += part[t].n_dom;
+  if (total_dom > 0) {
+    const int64_t np = (int64_t)hs->n * nseq;
+    int64_t *off = (int64_t *)calloc((size_t)np + 1, sizeof(int64_t));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1)
+#endif
+    for (int t = 0; t < nthreads; t++)
+      for (int64_t i = 0; i < part[t].n_dom; i++)
+        if (part[t].dom[i].dom_idx == 0) off[(int64_t)part[t].dom[i].prof * nseq + part[t].dom[i].seq] = part[t].dom[i].ndom;
+    int64_t run = 0;
+    for (int64_t k = 0; k < np; k++) { const int64_t c = off[k]; off[k] = run; run += c; }
+    R->dom = (orc_domain *)malloc(sizeof(orc_domain) * (size_t)total_dom);
+    R->n_dom = total_dom; R->cap_dom = total_dom;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1)
+#endif
+    for (int t = 0; t < nthreads; t++)
+      for (int64_t i = 0; i < part[t].n_dom; i++) {
+        const orc_domain *d = &part[t].dom[i];
+        R->dom[off[(int64_t)d->prof * nseq + d->seq] + d->dom_idx] = *d;
+      }
+    free(off);
+  }
   for (int t = 0; t < nthreads; t++) {
-    for (int64_t i = 0; i < part[t].n_dom; i++) res_push_dom(R, &part[t].dom[i]);
     for (int64_t i = 0; i < part[t].n_trace; i++) res_push_trace(R, &part[t].trace[i]);
     R->n_pairs += part[t].n_pairs; R->n_past_msv += part[t].n_past_msv; R->n_past_bias += part[t].n_past_bias;
     R->n_past_fwd += part[t].n_past_fwd; R->n_multidomain += part[t].n_multidomain;
     free(part[t].dom); free(part[t].trace);
   }
   free(part);
-  if (R->n_dom) qsort(R->dom, R->n_dom, sizeof(orc_domain), cmp_dom);
   if (R->n_trace) qsort(R->trace, R->n_trace, sizeof(orc_pairtrace), cmp_trace);
   return R;
 }

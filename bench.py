@@ -214,6 +214,33 @@ def stage_a(acc, K, n_reads, mean_len, cluster_id):
     return out
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the scheduler affinity mask cut by the cgroup's CPU quota (a GPU box hands a 1-GPU job
+    16 CPUs' worth of a 256-thread host: starting 256 threads there only adds throttling).  Returns (usable CPUs, what limits them)."""
+    n, why = os.cpu_count() or 1, "os.cpu_count()"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = int(float(quota) / period + 0.5)
+                if 0 < q < n:
+                    n, why = q, "cgroup CPU quota (%s)" % path
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), why
+
+
 def physical_cores():
     """distinct (physical id, core id) pairs of /proc/cpuinfo: os.cpu_count() counts hardware THREADS"""
     try:
@@ -573,14 +600,14 @@ def main():
                      "peak_nofma_tflops": VALU_NOFMA_TFLOPS},
         }
         if args.cpu_sample != 0 and world == 1:          # the CPU baseline is a rank-0, N=1 leg only
-            threads = os.cpu_count() or 1
-            if args.cpu_sample < 0:                      # the scalar port does ~2.5 (440-base) .. 5 (300-base) reads/s per core
-                args.cpu_sample = int(min(24000 if cfg2 else 40000, max(1200, (64 if cfg2 else 120) * threads)))
-                if args.cluster_id < 1.0:                # the greedy clustering of the baseline is sequential by definition: ~15 s for 6 000 reads
-                    args.cpu_sample = min(args.cpu_sample, 6000)
-                room = args.budget_s - (time.time() - T_START) - 20.0     # ~25 s of CPU work, less when the budget is nearly spent
-                args.cpu_sample = int(max(8192 if threads >= 64 else 600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
-                if args.cluster_id < 1.0:                # ... and quadratic: 8 192 reads took 120 s, 3 000 take ~15 s
+            threads, cpu_limit = effective_cpus()        # usable CPUs, not the host's hardware threads
+            if args.cpu_sample < 0:
+                # ~20 s of CPU work: the SSE2 port does ~70 (440-base reads x 155 profiles) .. 130 (300-base) reads/s per thread
+                rate = (130.0 if args.workload == "cfg1" else 70.0) * (155.0 / max(nprof, 1))
+                args.cpu_sample = int(min(40000, max(600, 20.0 * rate * threads)))
+                room = args.budget_s - (time.time() - T_START) - 20.0     # less when the budget is nearly spent
+                args.cpu_sample = int(max(600, min(args.cpu_sample, args.cpu_sample * max(room, 0.0) / 30.0)))
+                if args.cluster_id < 1.0:                # the baseline's greedy clustering is sequential by definition, and quadratic: 3 000 reads take ~15-45 s
                     args.cpu_sample = min(args.cpu_sample, 3000)
             m = min(args.cpu_sample, n_local)
             progress("CPU baseline on %d reads, %d threads" % (m, threads))
@@ -606,6 +633,7 @@ def main():
                                    "trim_coord_concordance": conc,
                                    "concordance_is": "engine vs oracle/ (our restatement), not vs vsearch+hmmsearch"}
             res["cpu_baseline"].update(cextra)
+            res["cpu_baseline"].update({"host_hardware_threads": os.cpu_count(), "cores_limited_by": cpu_limit})
             # the real reference engines, when the box happens to have them (SURVEY 8d "preferred")
             import tempfile
             with tempfile.TemporaryDirectory() as tmp:

@@ -214,7 +214,16 @@ def test_cfg2_shape_is_invariant_under_permutation_and_dereplication(engine, t_h
 N_CFG3 = 1_250_000
 
 
-def test_cfg3_shape_all_taxa_profiles_compacted_rows_and_two_shards(engine, t_hmm_text, all_its2_hmm_text, monkeypatch):
+def test_cfg3_shape_all_taxa_profiles_compacted_rows_and_two_shards(t_hmm_text, all_its2_hmm_text, monkeypatch):
+    from itsxpress_amd import Engine
+    engine = Engine(0)          # a context of its own, closed at the end: its work buffers (which only grow) go back to the device
+    try:
+        _cfg3_body(engine, t_hmm_text, all_its2_hmm_text, monkeypatch)
+    finally:
+        engine.close()
+
+
+def _cfg3_body(engine, t_hmm_text, all_its2_hmm_text, monkeypatch):
     blob, offs = synth.make_reads(t_hmm_text, N_CFG3, config=4, fixed_len=0, len_range=(300, 580), as_array=True)
     assert engine.load_profiles(text=all_its2_hmm_text) == 814
     monkeypatch.setenv("ITSX_COMPACT_ROWS", "1")

@@ -143,6 +143,14 @@ def test_cluster_conserved_words_by_bitmap_or_by_list(engine, heavy, monkeypatch
     _compare(engine, reads, names, 0.985)
 
 
+def test_cluster_long_reads_take_their_words_in_batches(engine):
+    # a centroid's words are taken 1 024 at a time (LDS); 1 300-base reads have ~1 290, most of them conserved inside their
+    # (large) family, so both batches go through bitmaps AND lists
+    reads, names = _noisy_library(61, 420, 2, (1280, 1320), max_err=4, indel=True, n_rate=0.001, rc_rate=0.2, shared_flank=80)
+    o, st = _compare(engine, reads, names, 0.99)
+    assert o["n_centroids"] < 200
+
+
 def test_cluster_index_growth(engine, monkeypatch):
     # more centroid words than the initial capacity of the word pool: the pool is doubled (with a copy) on the way
     monkeypatch.setenv("ITSX_CL_CAPACITY", "2048")

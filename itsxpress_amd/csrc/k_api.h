@@ -71,7 +71,8 @@ struct ClusterArgs {
   int32_t *is_new, *new_rank;   // [nq+1]
   int32_t *newq, *rm;           // [nq] window index of each speculative centroid; columns to clear after validation
   int32_t *xlist, *xn, *hard; unsigned long long *xkey; double *xpid;            // speculative centroids entering a walk [2 nq][32]
-  int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[2]
+  int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[4]: items of work / xwork, of awork's two halves
+  int32_t *awork;                   // [2][need_pitch] the items the certificate leaves to the dynamic program (walk / validation)
   const uint32_t *dmask;        // DUST soft mask of every read, one bit per base at woff[r] (k_dust); nullptr: no masking (ITSX_QMASK=none)
   const uint64_t *rhash;        // [n reads] XXH64 of the packed forward strand
   unsigned long long *ctab_key; int32_t *ctab_val; int32_t *canon;   // window-local table of identical reads; canon[nq]
@@ -86,6 +87,7 @@ struct ClusterArgs {
   unsigned long long *n_skipped;
   unsigned long long *pre_stats;                 // [4] certificate outcomes: not applicable, bound too weak, a path exists, proven reject
   int32_t pre_k;                                 // largest edit budget K of this run (sizes the certificate's LDS rows)
+  int32_t use_score;                             // the score pass (k_cl_score) settles the candidates whose best diagonal says nothing
 };
 constexpr int CL_QS_MAX = 8192;  // query strands of one window (2 x the largest window)
 constexpr int CL_HEAVY = 128;    // a word held by at least this many strands of the window goes through its strand bitmap

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64) void k_cl_topk(ClusterArgs a, int final)
 __global__ void k_cl_init(ClusterArgs a)
 {
   const int qs = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; a.work_n[0] = 0; a.work_n[1] = 0; }
+  if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; for (int r = 0; r < 4; r++) a.work_n[r] = 0; }
   if (qs < a.nq) { a.replay[qs] = 0; a.skipm[qs] = 0; }
   if (qs >= 2 * a.nq) return;
   a.state[qs] = a.canon[qs >> 1] != (qs >> 1) ? 4 : (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;      // 4 = a copy: reads its canonical query's state
@@ -685,7 +685,9 @@ static constexpr int PRE_LMAX = 2040;            // and reads up to this length 
 
 __device__ __forceinline__ uint32_t read_mask(const ReadsDev &rd, const uint32_t *w, int pos) { return 1u << ((w[pos >> 4] >> ((pos & 15) * 2)) & 3u); }
 
-__device__ bool precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds)
+// returns 0 = proven reject, 1 = the full alignment decides, 2 = the bound from the best diagonal is too weak (the score pass,
+// k_cl_score, computes the optimal score itself and asks again with it: have_lb)
+__device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds, bool have_lb = false, long long lb_given = 0)
 {
   const int lane = threadIdx.x;
   const int qi = qs >> 1, s = qs & 1;
@@ -696,7 +698,7 @@ __device__ bool precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *ld
   // made with the very expression identity_of() evaluates, so rounding cannot open a gap between the two
   int K = 0;
   while (K <= a.pre_k && 100.0 * (double)minL / (double)(minL + K + 1) >= a.thr) K++;
-  if (K > a.pre_k || Lq > PRE_LMAX || Lt > PRE_LMAX || Lq < 8 || Lt < 8) { if (lane == 0) atomicAdd(&a.pre_stats[0], 1ULL); return true; }   // no certificate: align
+  if (K > a.pre_k || Lq > PRE_LMAX || Lt > PRE_LMAX || Lq < 8 || Lt < 8) { if (lane == 0 && !have_lb) atomicAdd(&a.pre_stats[0], 1ULL); return 1; }   // no certificate: align
   uint8_t *qm = lds, *tm = qm + ((Lq + 3) & ~3);
   int32_t *head = reinterpret_cast<int32_t *>(tm + ((Lt + 3) & ~3));      // [256] chain heads of q's 8-mers (hashed)
   int32_t *nextp = head + 256;                                              // [Lq]
@@ -718,6 +720,9 @@ __device__ bool precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *ld
   for (int e = lane; e < nexq; e += 64) { const uint32_t ex = a.rd.exc[eoq + e]; const int pos = (int)(ex >> 4); const uint32_t m = mask4(ex & 15u); qm[s ? Lq - 1 - pos : pos] = (uint8_t)(s ? revmask4(m) : m); }
   for (int e = lane; e < next_; e += 64) { const uint32_t ex = a.rd.exc[eot + e]; tm[ex >> 4] = (uint8_t)mask4(ex & 15u); }
   __syncthreads();
+  long long lb = -(long long)(Lq + Lt + 4);                 // no pairs at all: two terminal runs
+  if (have_lb) lb = lb_given;                               // the optimal score itself: no alignment scores more, so the bound below is the tightest
+  else {
   // ---- the diagonal with most shared 8-mers (unambiguous symbols only)
   auto kmer_at = [&](const uint8_t *m, int L, int p, uint32_t &k) {
     if (p + 8 > L) return false;
@@ -748,16 +753,16 @@ __device__ bool precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *ld
     if (__popc(x) == 1 && __popc(y) == 1) part += (x == y) ? 2 : -4;
   }
   for (int off = 32; off; off >>= 1) part += __shfl_xor(part, off);
-  long long lb = -(long long)(Lq + Lt + 4);                 // no pairs at all: two terminal runs
   if (bv > 0 && i_hi > i_lo) {
     const int left = d > 0 ? d : -d;                        // one of the two reads overhangs on the left, one on the right
     const int right = (Lq - i_hi) + (Lt - (i_hi - d));
     const long long sc = part - (left ? 2 + left : 0) - (right ? 2 + right : 0);
     if (sc > lb) lb = sc;
   }
+  }
   const long long num = lb + Lq + Lt;
   const int Pmin = num <= 0 ? 0 : (int)((num + 3) / 4);
-  if (Pmin <= K + 4) { if (lane == 0) atomicAdd(&a.pre_stats[1], 1ULL); return true; }           // too weak to exclude chance overlaps: align
+  if (Pmin <= K + 4) { if (lane == 0 && !have_lb) atomicAdd(&a.pre_stats[1], 1ULL); return have_lb ? 1 : 2; }   // too weak to exclude chance overlaps
   // ---- k-differences reachability from every border cell with room for Pmin rows and columns
   const int W = 2 * K + 3, Wmax = 2 * a.pre_k + 3;
   int32_t *cur = fr + lane * 2 * Wmax, *prv = cur + Wmax;
@@ -791,8 +796,8 @@ __device__ bool precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *ld
   }
   if (hit) s_hit = 1;
   __syncthreads();
-  if (lane == 0) atomicAdd(&a.pre_stats[s_hit ? 2 : 3], 1ULL);
-  return s_hit != 0;
+  if (lane == 0) atomicAdd(&a.pre_stats[have_lb ? (s_hit ? 5 : 4) : (s_hit ? 2 : 3)], 1ULL);
+  return s_hit != 0 ? 1 : 0;
 }
 
 __global__ __launch_bounds__(64) void k_cl_precheck(ClusterArgs a, int which)
@@ -803,20 +808,148 @@ __global__ __launch_bounds__(64) void k_cl_precheck(ClusterArgs a, int which)
   const int32_t *cols = which ? a.xlist : a.sel;
   for (int w = blockIdx.x; w < nw; w += gridDim.x) {
     const int item = work[w];
-    const bool need = precheck_pair(a, item >> 5, cols[item], pre_lds);
-    if (threadIdx.x == 0) a.need[which * a.need_pitch + item] = need ? 1 : 0;
+    int need = precheck_pair(a, item >> 5, cols[item], pre_lds);
+    if (need == 2 && !a.use_score) need = 1;                  // no score pass: the full alignment decides
+    if (threadIdx.x == 0) {
+      a.need[which * a.need_pitch + item] = need;
+      if (need == 1) a.awork[which * a.need_pitch + atomicAdd(&a.work_n[2 + which], 1)] = item;      // the alignment kernels take these, one each
+    }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------ the score pass: the optimal score decides most rejections
+// 88 % of the full alignments were candidates whose best diagonal says nothing (unrelated reads that share a conserved motif):
+// the certificate's bound P >= (LB + Lq + Lt) / 4 needs a better LB, and the best there is is the optimal score itself.  The same
+// wavefront as align_pair, on 32-bit scores alone (no matches / columns, a third of the instructions); with it the certificate's
+// k-differences test runs again (unrelated pairs score about -650: Pmin ~ 37, no 2-edit path of that length) and only pairs that
+// pass it get the 64-bit dynamic program.  Single-pass queries only (Lq + 1 <= 64 S); the others keep need = 1.
+static constexpr int NEG32 = -(1 << 28);
+template <int S> __device__ __forceinline__ bool score_pair(const ClusterArgs &a, int qs, int col, uint8_t *tmask, int &res)
+{
+  const int lane = threadIdx.x;
+  const int qi = qs >> 1, s = qs & 1;
+  const int64_t rq = a.order[a.f + qi], rt = a.cent_read[col];
+  const int Lq = a.rd.len[rq], Lt = a.rd.len[rt];
+  const uint32_t *wq = a.rd.words + a.rd.woff[rq];
+  const uint32_t *wt = a.rd.words + a.rd.woff[rt];
+  const int64_t eoq = a.rd.excoff[rq], eot = a.rd.excoff[rt];
+  const int nexq = (int)(a.rd.excoff[rq + 1] - eoq), next_ = (int)(a.rd.excoff[rt + 1] - eot);
+  res = NEG32; bool have = false;
+  __syncthreads();
+  for (int o = lane; o < Lt; o += 64) tmask[o] = (uint8_t)(1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u));
+  __syncthreads();
+  for (int e = lane; e < next_; e += 64) { const uint32_t ex = a.rd.exc[eot + e]; tmask[ex >> 4] = (uint8_t)mask4(ex & 15u); }
+  __syncthreads();
+  const int i0 = lane * S;
+  uint32_t qm[S]; bool qu[S]; int goE[S], geE[S];
+#pragma unroll
+  for (int r = 0; r < S; r++) {
+    const int i = i0 + r;
+    uint32_t m = 0;
+    if (i >= 1 && i <= Lq) {
+      const int x = i - 1, o = s ? Lq - 1 - x : x;
+      const uint32_t c2 = (wq[o >> 4] >> ((o & 15) * 2)) & 3u;
+      m = 1u << (s ? 3u - c2 : c2);
+    }
+    qm[r] = m; goE[r] = (i == 0 || i == Lq) ? -3 : -22; geE[r] = (i == 0 || i == Lq) ? -1 : -2;
+  }
+  for (int e = 0; e < nexq; e++) {
+    const uint32_t ex = a.rd.exc[eoq + e];
+    const int pos = (int)(ex >> 4);
+    const int i = (s ? Lq - 1 - pos : pos) + 1;
+    const uint32_t m = s ? revmask4(mask4(ex & 15u)) : mask4(ex & 15u);
+#pragma unroll
+    for (int r = 0; r < S; r++) if (i == i0 + r) qm[r] = m;
+  }
+#pragma unroll
+  for (int r = 0; r < S; r++) qu[r] = unamb4(qm[r]);
+  int Hl[S], El[S];
+#pragma unroll
+  for (int r = 0; r < S; r++) { Hl[r] = NEG32; El[r] = NEG32; }
+  int diag_carry = lane == 0 ? 0 : NEG32, pubH = NEG32, pubF = NEG32;      // cell (0, 0) is 0
+  const int nsteps = Lt + 1 + 63;
+  for (int t = 0; t < nsteps; t++) {
+    int upH = __shfl_up(pubH, 1), upF = __shfl_up(pubF, 1);
+    const int j = t - lane;
+    if (lane == 0) { upH = NEG32; upF = NEG32; }
+    if (j >= 0 && j <= Lt) {
+      const uint32_t tm = j >= 1 ? (uint32_t)tmask[j - 1] : 0u;
+      const bool tF = (j == 0 || j == Lt);
+      const int goF = tF ? -3 : -22, geF = tF ? -1 : -2;
+      const bool tu = unamb4(tm);
+      int aboveH = upH, aboveF = upF, dg = diag_carry;
+#pragma unroll
+      for (int r = 0; r < S; r++) {
+        const int E = max(Hl[r] + goE[r], El[r] + geE[r]);
+        const int F = max(aboveH + goF, aboveF + geF);
+        const int D = (qu[r] && tu) ? ((qm[r] & tm) ? 2 : -4) : 0;       // +2 / -4 between unambiguous symbols, 0 otherwise
+        const int Hn = max(max(dg + D, E), F);
+        dg = Hl[r];
+        Hl[r] = Hn; El[r] = E;
+        aboveH = Hn; aboveF = F;
+      }
+      pubH = aboveH; pubF = aboveF;
+      diag_carry = upH;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < S; r++) if (i0 + r == Lq) { res = Hl[r]; have = true; }
+  return have;
+}
+template <int S> __global__ __launch_bounds__(64) void k_cl_score(ClusterArgs a, int which, int lds_pre)
+{
+  extern __shared__ uint8_t sc_lds[];
+  const int nw = a.work_n[which];
+  const int32_t *work = which ? a.xwork : a.work;
+  const int32_t *cols = which ? a.xlist : a.sel;
+  int32_t *need = a.need + which * a.need_pitch;
+  for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+    const int item = work[w];
+    if (need[item] != 2) continue;                          // (block-uniform)
+    const int qs = item >> 5, col = cols[item];
+    const int Lq = a.rd.len[a.order[a.f + (qs >> 1)]];
+    int verdict = 1;
+    if (Lq + 1 <= 64 * S) {
+      int res;
+      const bool have = score_pair<S>(a, qs, col, sc_lds + lds_pre, res);
+      const unsigned long long who = __ballot(have);
+      const int sstar = __shfl(res, __ffsll((long long)who) - 1);
+      verdict = precheck_pair(a, qs, col, sc_lds, true, (long long)sstar);
+    }
+    if (threadIdx.x == 0) {
+      need[item] = verdict;
+      if (verdict == 1) a.awork[which * a.need_pitch + atomicAdd(&a.work_n[2 + which], 1)] = item;
+    }
+    __syncthreads();
+  }
+}
+
+// proven rejections: identity -1 (below every threshold), counted
+__global__ void k_cl_skipped(ClusterArgs a, int which)
+{
+  const int nw = a.work_n[which];
+  const int32_t *work = which ? a.xwork : a.work;
+  double *pid = which ? a.xpid : a.selpid;
+  unsigned long long n = 0;
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += gridDim.x * blockDim.x) {
+    const int item = work[w];
+    if (a.need[which * a.need_pitch + item] == 0) { pid[item] = -1.0; n++; }
+  }
+  for (int off = 32; off; off >>= 1) n += __shfl_xor(n, off);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(a.n_skipped, n);
 }
 
 // one wave = one (query strand, selected candidate) alignment; the walk consumes the identities in rank order
 template <int S> __global__ __launch_bounds__(64) void k_cl_align(ClusterArgs a)
 {
   extern __shared__ uint8_t tmask_lds[];
-  const int nw = a.work_n[0];
+  // with the certificate on, the items that need the dynamic program come as a compact list of their own (the proven rejections
+  // got their -1 from k_cl_skipped): consecutive waves, one alignment each, instead of a few waves meeting several
+  const int nw = a.need ? a.work_n[2] : a.work_n[0];
+  const int32_t *list = a.need ? a.awork : a.work;
   for (int w = blockIdx.x; w < nw; w += gridDim.x) {      // every wave drains its share of the list and exits
-    const int item = a.work[w];
-    if (a.need && !a.need[item]) { if (threadIdx.x == 0) { a.selpid[item] = -1.0; atomicAdd(a.n_skipped, 1ULL); } continue; }   // proven reject
+    const int item = list[w];
     i64 res;
     if (align_pair<S>(a, item >> 5, a.sel[item], item, tmask_lds, res)) {
       a.selpid[item] = identity_of(res);
@@ -843,7 +976,7 @@ __global__ void k_cl_walk(ClusterArgs a, int first)
   if (st == 0) { if (a.sel_short[qs]) st = 3; else if (m > 0) a.prev[qs] = a.selkey[qs * 32 + first + m - 1]; }
   a.state[qs] = st; a.wn[qs] = w; a.rejects[qs] = rej; a.selm[qs] = 0;
 }
-__global__ void k_cl_reset_work(ClusterArgs a, int which) { a.work_n[which] = 0; }
+__global__ void k_cl_reset_work(ClusterArgs a, int which) { a.work_n[which] = 0; a.work_n[2 + which] = 0; }
 
 // ------------------------------------------------------------------ outcomes, new centroids, validation
 __global__ void k_cl_outcome(ClusterArgs a)
@@ -944,10 +1077,10 @@ __global__ __launch_bounds__(256) void k_cl_affected(ClusterArgs a)
 template <int S> __global__ __launch_bounds__(64) void k_cl_align_x(ClusterArgs a)
 {
   extern __shared__ uint8_t tmask_lds[];
-  const int nw = a.work_n[1];
+  const int nw = a.need ? a.work_n[3] : a.work_n[1];
+  const int32_t *list = a.need ? a.awork + a.need_pitch : a.xwork;
   for (int w = blockIdx.x; w < nw; w += gridDim.x) {
-    const int item = a.xwork[w];
-    if (a.need && !a.need[a.need_pitch + item]) { if (threadIdx.x == 0) { a.xpid[item] = -1.0; atomicAdd(a.n_skipped, 1ULL); } continue; }
+    const int item = list[w];
     i64 res;
     if (align_pair<S>(a, item >> 5, a.xlist[item], item, tmask_lds, res)) {
       const double pid = identity_of(res);
@@ -1087,6 +1220,15 @@ static size_t precheck_lds(const ClusterArgs &a)
   const size_t L = (size_t)std::min(a.scratch_pitch, PRE_LMAX + 1);      // masks, 8-mer index of the query, votes, per-lane LV rows
   return 2 * (L + 4) + 1024 + 4 * L + 2 * (L + 2) + 8 * L + 64 * 2 * (2 * (size_t)a.pre_k + 3) * 4 + 64;
 }
+static void launch_cl_score(const ClusterArgs &a, int which, int grid, int rows_per_lane, hipStream_t st)
+{
+  if (!a.use_score) return;                                   // (ITSX_CL_NOSCORE=1: the too-weak candidates go straight to the full alignment)
+  const int pre = (int)((precheck_lds(a) + 63) & ~(size_t)63);
+  const size_t lds = (size_t)pre + (((size_t)a.scratch_pitch + 63) & ~(size_t)63);
+  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_score<5>, dim3(grid), dim3(64), lds, st, a, which, pre);
+  else if (rows_per_lane <= 8) hipLaunchKernelGGL(k_cl_score<8>, dim3(grid), dim3(64), lds, st, a, which, pre);
+  else hipLaunchKernelGGL(k_cl_score<10>, dim3(grid), dim3(64), lds, st, a, which, pre);
+}
 void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
 {
   // round 0: the best candidate of every query (most reads accept it); round 1: the whole remaining reject budget at once
@@ -1095,7 +1237,11 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
     hipLaunchKernelGGL(k_cl_take, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a, round);
     const int grid = std::min(2 * a.nq * kmax, 16384);
     const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
-    if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 0);
+    if (a.need) {
+      hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 0);
+      launch_cl_score(a, 0, grid, rows_per_lane, st);
+      hipLaunchKernelGGL(k_cl_skipped, dim3(256), dim3(256), 0, st, a, 0);
+    }
     if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), lds, st, a);
     else if (rows_per_lane <= 8) hipLaunchKernelGGL(k_cl_align<8>, dim3(grid), dim3(64), lds, st, a);
     else hipLaunchKernelGGL(k_cl_align<10>, dim3(grid), dim3(64), lds, st, a);
@@ -1111,7 +1257,11 @@ void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   hipLaunchKernelGGL(k_cl_affected, dim3(2 * a.nq), dim3(256), 0, st, a);
   const int grid = std::min(2 * a.nq * 32, 16384);
   const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
-  if (a.need) hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 1);
+  if (a.need) {
+    hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 1);
+    launch_cl_score(a, 1, grid, rows_per_lane, st);
+    hipLaunchKernelGGL(k_cl_skipped, dim3(256), dim3(256), 0, st, a, 1);
+  }
   if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(grid), dim3(64), lds, st, a);
   else if (rows_per_lane <= 8) hipLaunchKernelGGL(k_cl_align_x<8>, dim3(grid), dim3(64), lds, st, a);
   else hipLaunchKernelGGL(k_cl_align_x<10>, dim3(grid), dim3(64), lds, st, a);

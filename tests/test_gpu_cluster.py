@@ -116,6 +116,11 @@ def test_cluster_rejection_certificate(engine, monkeypatch):
     monkeypatch.setenv("ITSX_CL_NOPRECHECK", "1")
     _, st0 = _compare(engine, reads, names, 0.99)
     assert st0["cl_certified"] == 0 and st0["cl_alignments"] > 3 * st["cl_alignments"]
+    # the score pass (the optimal score as the certificate's bound, for candidates whose best diagonal says nothing) on its own switch
+    monkeypatch.delenv("ITSX_CL_NOPRECHECK")
+    monkeypatch.setenv("ITSX_CL_NOSCORE", "1")
+    _, st1 = _compare(engine, reads, names, 0.99)
+    assert st["cl_alignments"] < st1["cl_alignments"] < st0["cl_alignments"]
 
 
 def test_cluster_plus_strand_only_and_no_names(engine):

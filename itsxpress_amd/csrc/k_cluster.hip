@@ -675,19 +675,20 @@ __device__ __forceinline__ double identity_of(i64 res)
 //      an accepted alignment has P >= (LB + Lq + Lt) / 4 =: Pmin;
 //  (3) so an accepted alignment is a path from the top/left border to the bottom/right border (whatever lies outside is
 //      terminal gap) with at most K unit-cost edits (compatible symbols match) spanning at least Pmin rows and columns.
-// Whether such a path exists is a k-differences question: furthest-reaching diagonals (Landau-Vishkin) from every border
-// cell that leaves enough room, one lane per start cell.  No such path => the candidate is rejected without the O(Lq Lt)
-// dynamic program; otherwise (all accepts, and the rare unlucky reject) the full alignment decides as before.
-// For unrelated candidates the walk dies after one or two symbols per start; for near misses (a family member with one
-// difference too many) Pmin is nearly the whole read and only a handful of start cells qualify.
+// Whether such a path exists is a k-differences question: furthest-reaching diagonals (Landau-Vishkin) with every border
+// cell as a source, one lane per diagonal, K + 1 synchronous levels.  No such path => the candidate is rejected without the
+// O(Lq Lt) dynamic program; otherwise (all accepts, and the rare unlucky reject) the full alignment decides as before.
+// For unrelated candidates the front dies after one or two symbols per diagonal; for near misses (a family member with one
+// difference too many) Pmin is nearly the whole read and no front spans it.
 // the certificate is used for edit budgets K <= 16 (identity thresholds >= ~0.95 at 300 bases; engine.hip sets pre_k)
 static constexpr int PRE_LMAX = 2040;            // and reads up to this length (LDS); longer ones go straight to the full alignment
 
 __device__ __forceinline__ uint32_t read_mask(const ReadsDev &rd, const uint32_t *w, int pos) { return 1u << ((w[pos >> 4] >> ((pos & 15) * 2)) & 3u); }
 
-// returns 0 = proven reject, 1 = the full alignment decides, 2 = the bound from the best diagonal is too weak (the score pass,
+// returns 0 = proven reject, 1 (-1) = the full alignment decides, 2 = the bound from the best diagonal is too weak (the score pass,
 // k_cl_score, computes the optimal score itself and asks again with it: have_lb)
-__device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds, bool have_lb = false, long long lb_given = 0)
+// same_q: the wave's previous call had the same query strand and built its 8-mer index (not have_lb): q's masks and index are still in LDS
+__device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds, bool have_lb = false, long long lb_given = 0, bool same_q = false)
 {
   const int lane = threadIdx.x;
   const int qi = qs >> 1, s = qs & 1;
@@ -696,28 +697,32 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
   const int minL = Lq < Lt ? Lq : Lt;
   // K = the largest E for which ANY alignment with M <= minL matches could pass: M / (M + E) grows with M, and the test is
   // made with the very expression identity_of() evaluates, so rounding cannot open a gap between the two
-  int K = 0;
-  while (K <= a.pre_k && 100.0 * (double)minL / (double)(minL + K + 1) >= a.thr) K++;
-  if (K > a.pre_k || Lq > PRE_LMAX || Lt > PRE_LMAX || Lq < 8 || Lt < 8) { if (lane == 0 && !have_lb) atomicAdd(&a.pre_stats[0], 1ULL); return 1; }   // no certificate: align
-  uint8_t *qm = lds, *tm = qm + ((Lq + 3) & ~3);
-  int32_t *head = reinterpret_cast<int32_t *>(tm + ((Lt + 3) & ~3));      // [256] chain heads of q's 8-mers (hashed)
+  // (lane e tests budget e + 1: the quotient falls with e, so the first lane that fails is K)
+  const unsigned long long kfail = __ballot(lane > a.pre_k || !(100.0 * (double)minL / (double)(minL + lane + 1) >= a.thr));
+  const int K = __ffsll((long long)kfail) - 1;
+  if (K > a.pre_k || Lq > PRE_LMAX || Lt > PRE_LMAX || Lq < 8 || Lt < 8) { if (lane == 0 && !have_lb) atomicAdd(&a.pre_stats[0], 1ULL); return have_lb ? 1 : -1; }   // no certificate: align (-1: and nothing was built in LDS)
+  uint8_t *qm = lds;                                                        // the query's side first: it survives from one candidate to the next
+  int32_t *head = reinterpret_cast<int32_t *>(qm + ((Lq + 3) & ~3));      // [256] chain heads of q's 8-mers (hashed)
   int32_t *nextp = head + 256;                                              // [Lq]
   uint16_t *qk = reinterpret_cast<uint16_t *>(nextp + Lq);                  // [Lq] 8-mer at each q position (0xFFFF: none)
-  int32_t *votes = reinterpret_cast<int32_t *>(qk + ((Lq + 1) & ~1));       // [Lq + Lt]
-  int32_t *fr = votes + Lq + Lt;                                            // [64 lanes][2][2 pre_k + 3]
+  uint8_t *tm = reinterpret_cast<uint8_t *>(qk + ((Lq + 1) & ~1));
+  int32_t *votes = reinterpret_cast<int32_t *>(tm + ((Lt + 3) & ~3));       // [Lq + Lt + 4]: diagonal votes, then a level of the front
+  int32_t *fr = votes + Lq + Lt + 4;                                        // [Lq + Lt + 4]: the other level
   __shared__ int s_hit;
   const uint32_t *wq = a.rd.words + a.rd.woff[rq];
   const uint32_t *wt = a.rd.words + a.rd.woff[rt];
   const int64_t eoq = a.rd.excoff[rq], eot = a.rd.excoff[rt];
   const int nexq = (int)(a.rd.excoff[rq + 1] - eoq), next_ = (int)(a.rd.excoff[rt + 1] - eot);
   __syncthreads();
-  for (int x = lane; x < Lq; x += 64) { const int o = s ? Lq - 1 - x : x; const uint32_t c2 = (wq[o >> 4] >> ((o & 15) * 2)) & 3u; qm[x] = (uint8_t)(1u << (s ? 3u - c2 : c2)); }
+  if (!same_q) {
+    for (int x = lane; x < Lq; x += 64) { const int o = s ? Lq - 1 - x : x; const uint32_t c2 = (wq[o >> 4] >> ((o & 15) * 2)) & 3u; qm[x] = (uint8_t)(1u << (s ? 3u - c2 : c2)); }
+    for (int i = lane; i < 256; i += 64) head[i] = -1;
+  }
   for (int o = lane; o < Lt; o += 64) tm[o] = (uint8_t)(1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u));
-  for (int i = lane; i < 256; i += 64) head[i] = -1;
   for (int i = lane; i < Lq + Lt; i += 64) votes[i] = 0;
   if (lane == 0) s_hit = 0;
   __syncthreads();
-  for (int e = lane; e < nexq; e += 64) { const uint32_t ex = a.rd.exc[eoq + e]; const int pos = (int)(ex >> 4); const uint32_t m = mask4(ex & 15u); qm[s ? Lq - 1 - pos : pos] = (uint8_t)(s ? revmask4(m) : m); }
+  if (!same_q) for (int e = lane; e < nexq; e += 64) { const uint32_t ex = a.rd.exc[eoq + e]; const int pos = (int)(ex >> 4); const uint32_t m = mask4(ex & 15u); qm[s ? Lq - 1 - pos : pos] = (uint8_t)(s ? revmask4(m) : m); }
   for (int e = lane; e < next_; e += 64) { const uint32_t ex = a.rd.exc[eot + e]; tm[ex >> 4] = (uint8_t)mask4(ex & 15u); }
   __syncthreads();
   long long lb = -(long long)(Lq + Lt + 4);                 // no pairs at all: two terminal runs
@@ -730,11 +735,13 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
     for (int t = 0; t < 8; t++) { const uint32_t b = m[p + t]; if (__popc(b) != 1) return false; k |= (uint32_t)(__ffs(b) - 1) << (2 * t); }
     return true;
   };
-  for (int p = lane; p < Lq; p += 64) {
-    uint32_t k;
-    if (kmer_at(qm, Lq, p, k)) { qk[p] = (uint16_t)k; nextp[p] = atomicExch(&head[(k * 40503u >> 8) & 255u], p); } else qk[p] = 0xFFFF;
+  if (!same_q) {
+    for (int p = lane; p < Lq; p += 64) {
+      uint32_t k;
+      if (kmer_at(qm, Lq, p, k)) { qk[p] = (uint16_t)k; nextp[p] = atomicExch(&head[(k * 40503u >> 8) & 255u], p); } else qk[p] = 0xFFFF;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int j = lane; j < Lt; j += 64) {
     uint32_t k;
     if (!kmer_at(tm, Lt, j, k)) continue;
@@ -763,52 +770,69 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
   const long long num = lb + Lq + Lt;
   const int Pmin = num <= 0 ? 0 : (int)((num + 3) / 4);
   if (Pmin <= K + 4) { if (lane == 0 && !have_lb) atomicAdd(&a.pre_stats[1], 1ULL); return have_lb ? 1 : 2; }   // too weak to exclude chance overlaps
-  // ---- k-differences reachability from every border cell with room for Pmin rows and columns
-  const int W = 2 * K + 3, Wmax = 2 * a.pre_k + 3;
-  int32_t *cur = fr + lane * 2 * Wmax, *prv = cur + Wmax;
-  const int nstart = Lq + Lt + 1;                           // 0..Lq: (i0, 0); Lq+1..: (0, j0 = idx - Lq)
+  // ---- k-differences reachability from ALL border cells at once.  Diagonal d = i - j (slot z = d + Lt) has exactly one border cell
+  // to start from, (max(d, 0), max(-d, 0)), and exactly one to end in; F[z] = the furthest row reached on it within e edits from ANY
+  // start (furthest-reaching diagonals with every start as a source of level 0: whatever one start reaches, the merged front reaches).
+  // The front no longer knows its start, so the span is measured from the most favourable start within K diagonals of the end
+  // diagonal -- a path of <= K edits cannot have come from further away -- which gives away at most K symbols of Pmin.
+  // Lanes own diagonals, levels are synchronous: (K + 1) (Lq + Lt + 1) independent extensions instead of one walk per start.
+  int32_t *P = votes + 1, *N = fr + 1;                       // [-1 .. nd]: a sentinel either side
+  const int nd = Lq + Lt + 1;
+  auto span_ok = [&](int i, int j, int d) {
+    int rows = i, cols = j;
+    if (d > K) rows = i - (d - K); else if (d < -K) cols = j + d + K;
+    return rows >= Pmin && cols >= Pmin;
+  };
   bool hit = false;
-  for (int st = lane; st < nstart && !hit; st += 64) {
-    const int i0 = st <= Lq ? st : 0, j0 = st <= Lq ? 0 : st - Lq;
-    if (Lq - i0 < Pmin || Lt - j0 < Pmin) continue;
-    for (int z = 0; z < W; z++) prv[z] = -1;
-    for (int e = 0; e <= K && !hit; e++) {
-      for (int z = 0; z < W; z++) cur[z] = -1;
-      for (int dl = -e; dl <= e; dl++) {                    // diagonal (i - j) - (i0 - j0) = dl, slot dl + K + 1
-        const int z = dl + K + 1;
-        int i;
-        if (e == 0) i = i0;
-        else {
-          i = -1;
-          if (prv[z] >= 0) i = prv[z] + 1;                                        // mismatching pair
-          if (prv[z - 1] >= 0 && prv[z - 1] + 1 > i) i = prv[z - 1] + 1;          // a q symbol against a gap
-          if (prv[z + 1] >= 0 && prv[z + 1] > i) i = prv[z + 1];                  // a t symbol against a gap
-          if (i < 0) continue;
-        }
-        int j = i - (i0 - j0) - dl;
-        if (i > Lq || j > Lt || j < j0 || i < i0) continue;
-        while (i < Lq && j < Lt && (qm[i] & tm[j])) { i++; j++; }
-        cur[z] = i;
-        if ((i == Lq || j == Lt) && i - i0 >= Pmin && j - j0 >= Pmin) { hit = true; break; }
-      }
-      int32_t *t_ = cur; cur = prv; prv = t_;
-    }
+  __syncthreads();                                           // votes[] is free now
+  for (int z = lane; z < nd; z += 64) {
+    const int d = z - Lt;
+    int i = d > 0 ? d : 0, j = i - d;
+    while (i < Lq && j < Lt && (qm[i] & tm[j])) { i++; j++; }
+    P[z] = i;
+    if ((i == Lq || j == Lt) && span_ok(i, j, d)) hit = true;
   }
-  if (hit) s_hit = 1;
+  if (lane == 0) { P[-1] = P[nd] = -1; N[-1] = N[nd] = -1; }
+  for (int e = 1; e <= K; e++) {
+    __syncthreads();
+    if (__ballot(hit) != 0ull) break;
+    for (int z = lane; z < nd; z += 64) {
+      const int d = z - Lt;
+      const int pa = P[z], pb = P[z - 1], pc = P[z + 1];
+      int i = pa;
+      if (pa < Lq && pa - d < Lt) i = pa + 1;                                   // a mismatching pair
+      if (pb >= 0 && pb < Lq && pb + 1 > i) i = pb + 1;                         // a q symbol against a gap (from diagonal d - 1)
+      if (pc >= 0 && pc - d <= Lt && pc > i) i = pc;                            // a t symbol against a gap (from diagonal d + 1)
+      int j = i - d;
+      while (i < Lq && j < Lt && (qm[i] & tm[j])) { i++; j++; }
+      N[z] = i;
+      if ((i == Lq || j == Lt) && span_ok(i, j, d)) hit = true;
+    }
+    int32_t *t_ = P; P = N; N = t_;
+  }
+  const bool any_hit = __ballot(hit) != 0ull;
+  if (lane == 0 && any_hit) s_hit = 1;
   __syncthreads();
   if (lane == 0) atomicAdd(&a.pre_stats[have_lb ? (s_hit ? 5 : 4) : (s_hit ? 2 : 3)], 1ULL);
   return s_hit != 0 ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_cl_precheck(ClusterArgs a, int which)
+__global__ __launch_bounds__(64) void k_cl_precheck(ClusterArgs a, int which, int per)
 {
   extern __shared__ uint8_t pre_lds[];
   const int nw = a.work_n[which];
   const int32_t *work = which ? a.xwork : a.work;
   const int32_t *cols = which ? a.xlist : a.sel;
-  for (int w = blockIdx.x; w < nw; w += gridDim.x) {
+  // the items of a query strand are consecutive in the list (k_cl_take): a wave takes `per` of them in a row (small: a related strand's items are the expensive ones) and builds a
+  // strand's masks and 8-mer index once (indexed = the strand whose index is in LDS: an early return of precheck_pair builds nothing)
+  int indexed = -1;
+  for (int w0 = blockIdx.x * per; w0 < nw; w0 += gridDim.x * per)
+  for (int w = w0; w < w0 + per && w < nw; w++) {
     const int item = work[w];
-    int need = precheck_pair(a, item >> 5, cols[item], pre_lds);
+    const int qs = item >> 5;
+    int need = precheck_pair(a, qs, cols[item], pre_lds, false, 0, qs == indexed);
+    indexed = need == -1 ? -1 : qs;
+    if (need < 0) need = 1;
     if (need == 2 && !a.use_score) need = 1;                  // no score pass: the full alignment decides
     if (threadIdx.x == 0) {
       a.need[which * a.need_pitch + item] = need;
@@ -1217,8 +1241,8 @@ void launch_cl_topk(const ClusterArgs &a, int final, hipStream_t st) { hipLaunch
 void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k_cl_init, dim3((2 * a.nq + 255) / 256), dim3(256), 0, st, a); }
 static size_t precheck_lds(const ClusterArgs &a)
 {
-  const size_t L = (size_t)std::min(a.scratch_pitch, PRE_LMAX + 1);      // masks, 8-mer index of the query, votes, per-lane LV rows
-  return 2 * (L + 4) + 1024 + 4 * L + 2 * (L + 2) + 8 * L + 64 * 2 * (2 * (size_t)a.pre_k + 3) * 4 + 64;
+  const size_t L = (size_t)std::min(a.scratch_pitch, PRE_LMAX + 1);      // masks, 8-mer index of the query, votes, two levels of the front
+  return 2 * (L + 4) + 1024 + 4 * L + 2 * (L + 2) + 2 * (8 * L + 16) + 64;
 }
 static void launch_cl_score(const ClusterArgs &a, int which, int grid, int rows_per_lane, hipStream_t st)
 {
@@ -1238,7 +1262,8 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
     const int grid = std::min(2 * a.nq * kmax, 16384);
     const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
     if (a.need) {
-      hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 0);
+      const int per = round == 0 ? 1 : 4;
+      hipLaunchKernelGGL(k_cl_precheck, dim3(std::min((2 * a.nq * kmax + per - 1) / per, 65536)), dim3(64), precheck_lds(a), st, a, 0, per);
       launch_cl_score(a, 0, grid, rows_per_lane, st);
       hipLaunchKernelGGL(k_cl_skipped, dim3(256), dim3(256), 0, st, a, 0);
     }
@@ -1258,7 +1283,7 @@ void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   const int grid = std::min(2 * a.nq * 32, 16384);
   const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
   if (a.need) {
-    hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 1);
+    hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 1, 1);
     launch_cl_score(a, 1, grid, rows_per_lane, st);
     hipLaunchKernelGGL(k_cl_skipped, dim3(256), dim3(256), 0, st, a, 1);
   }

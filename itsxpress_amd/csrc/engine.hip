@@ -1658,13 +1658,25 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       launch_mr_reorder(NU, NMR, newpos.p, ulist0.p, ulist.p, mru.p, st);
       HIPCHK(upload(ctx->w_n2off, hn2, st)); HIPCHK(upload(ctx->w_mrrowoff, hrow, st));
       HIPCHK(ctx->w_mrout.alloc((size_t)NU)); HIPCHK(ctx->w_n2sc.alloc((size_t)hn2[(size_t)NU] + 1));
-      const int NMW = (int)(((int64_t)NU + MR_LANES - 1) / MR_LANES);
-      std::vector<WaveDesc> mw((size_t)NMW);
-      for (int w = 0; w < NMW; w++) {
-        WaveDesc &d = mw[(size_t)w]; d = WaveDesc{};
-        d.prof = -1; d.first = (int64_t)w * MR_LANES; d.count = (int32_t)std::min<int64_t>(MR_LANES, (int64_t)NU - (int64_t)w * MR_LANES);
+      // waves over the regions in ascending length.  The longest regions decide when a batch ends (200 sequential paths each, and a
+      // wave walks its lanes' paths in phases, so it takes as long as its slowest lane in EVERY phase): they get waves of
+      // MR_LANES_LONG lanes, and the kernels take the waves from the back (longest first).
+      static const int lanes_long = getenv("ITSX_MR_LONG_LANES") ? std::max(1, std::min(MR_LANES, atoi(getenv("ITSX_MR_LONG_LANES")))) : MR_LANES_LONG;
+      static const double frac_long = getenv("ITSX_MR_LONG_FRAC") ? atof(getenv("ITSX_MR_LONG_FRAC")) : MR_LONG_FRAC;
+      const int64_t n_long = std::min<int64_t>(NU, (int64_t)(frac_long * (double)NU));
+      std::vector<WaveDesc> mw;
+      std::vector<int64_t> wfirst;
+      for (int64_t x = 0; x < NU;) {
+        const int lanes = x >= NU - n_long ? lanes_long : (int)std::min<int64_t>(MR_LANES, NU - n_long - x);
+        WaveDesc d{};
+        d.prof = -1; d.first = x; d.count = (int32_t)std::min<int64_t>(lanes, (int64_t)NU - x);
         d.rows = hlen[(size_t)ord[(size_t)(d.first + d.count - 1)]] + 1;                  // ascending length: the last lane's
+        wfirst.push_back(x);
+        mw.push_back(d);
+        x += d.count;
       }
+      const int NMW = (int)mw.size();
+      wfirst.push_back(NU);
       HIPCHK(upload(ctx->w_mrwaves, mw, st));
       const int64_t mrow_bytes = (int64_t)MRV * 16;
       const int64_t mbudget = std::max<int64_t>(1, (int64_t)(std::min(slab_gb, 16.0) * (1 << 30)) / mrow_bytes);
@@ -1673,12 +1685,12 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       int64_t mr_wave_cap = wave_cap;
       while (w0 < NMW) {
         int w1 = w0;
-        const int64_t row0 = hrow[(size_t)w0 * MR_LANES];
-        auto rows_to = [&](int w) { return hrow[(size_t)std::min<int64_t>((int64_t)w * MR_LANES, NU)] - row0; };
+        const int64_t row0 = hrow[(size_t)wfirst[(size_t)w0]];
+        auto rows_to = [&](int w) { return hrow[(size_t)wfirst[(size_t)std::min(w, NMW)]] - row0; };
         while (w1 < NMW && w1 - w0 < std::min(wave_cap, mr_wave_cap) && (w1 == w0 || rows_to(w1 + 1) <= mbudget)) w1++;
         const int64_t r = rows_to(w1);
         if (((size_t)r * MRV * 4 > ctx->w_mrslab.cap && ctx->w_mrslab.alloc((size_t)r * MRV * 4) != hipSuccess) ||
-            ctx->w_mrscratch.alloc((size_t)(w1 - w0) * MR_LANES * MR_SCRATCH) != hipSuccess) {
+            ctx->w_mrscratch.alloc((size_t)(wfirst[(size_t)w1] - wfirst[(size_t)w0]) * MR_SCRATCH) != hipSuccess) {
           (void)hipGetLastError();
           if (w1 - w0 <= 1) SET_ERR(ctx, ITSX_E_NOMEM, "no device memory left for the matrices of one wave of multidomain regions");
           mr_wave_cap = std::max<int64_t>(1, (int64_t)(w1 - w0) / 2);     // half as many regions at a time
@@ -1687,7 +1699,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
         }
         MrArgs ma{};
         ma.rd = ctx->rd; ma.sorted_uniq = d_sorted; ma.seed_read = ctx->d_seed_read.p; ma.prof = ctx->d_prof.p; ma.pairs = ctx->d_pairs.p;
-        ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = (int64_t)w0 * MR_LANES; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
+        ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = wfirst[(size_t)w0]; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
         ma.rowoff = ctx->w_mrrowoff.p; ma.rowoff0 = row0;
         ma.n2off = ctx->w_n2off.p; ma.n2sc = ctx->w_n2sc.p; ma.out = ctx->w_mrout.p; ma.scratch = ctx->w_mrscratch.p;
         static const bool mrdbg = getenv("ITSX_MR_DEBUG") != nullptr;

@@ -226,6 +226,8 @@ void launch_envelopes(const EnvArgs &a, int nwaves, int wave0, int generic_q, hi
 constexpr int MRV = 38;            // float4 vectors per matrix row: M, D, I of each of the 12 node groups | (E N J B) | (C SCALE - -)
 constexpr int MRENV = 4;           // envelopes kept per clustered region
 constexpr int MR_LANES = 32;       // regions per wave: half-filled waves, twice as many of them (the kernels wait on memory 2/3 of the time)
+constexpr int MR_LANES_LONG = 4;   // ... and per wave of the longest regions (engine.hip: they decide when a batch ends)
+constexpr double MR_LONG_FRAC = 0.02;   // the share of a batch's regions that counts as longest (measured: 0.01-0.05 alike, 2 or 4 lanes alike)
 constexpr int MR_MAXD = 8;         // domains in one sampled path
 constexpr int MR_TCAP = 512;       // distinct sampled (i, j, k, m) tuples per region
 constexpr int MR_SCAP = 200 * MR_MAXD;

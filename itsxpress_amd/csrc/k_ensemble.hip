@@ -56,7 +56,7 @@ DEV MrLane mr_lane(const MrArgs &a, const WaveDesc &wd, int lane)
 // the region's Forward matrix: p7_Forward(dsq + i - 1, j - i + 1) in multihit mode, every row kept
 __global__ void __launch_bounds__(64) k_mr_fwd(MrArgs a, int wave0)
 {
-  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const WaveDesc wd = a.waves[wave0 + (gridDim.x - 1 - blockIdx.x)];       // longest regions first
   const int lane = threadIdx.x;
   const MrLane e = mr_lane(a, wd, lane);
   const int Q = e.Q, Lw = wd.rows - 1;
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
   // the domains of the path being sampled, last first: first / last residue, first / last node, null2 odds of A C G T
   __shared__ uint32_t dom_ij[MR_MAXD][MR_LANES], dom_km[MR_MAXD][MR_LANES];
   __shared__ float dom_n2[MR_MAXD][4][MR_LANES];
-  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const WaveDesc wd = a.waves[wave0 + (gridDim.x - 1 - blockIdx.x)];       // longest regions first
   const int lane = threadIdx.x;
   const MrLane e = mr_lane(a, wd, lane);
   if (!e.active) return;

@@ -1,5 +1,6 @@
 // engine.h -- internal declarations of the gfx950 ITS-trimming engine (not part of the ABI).
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -37,7 +38,7 @@ std::string parse_hmm_text(const char *text, int64_t len, std::vector<HostProfil
 uint8_t host_tjb_b(int L);
 
 // ---- device-side model block: one per profile, read with scalar loads (wave-uniform) ----
-struct DevProfile {
+struct alignas(16) DevProfile {
   float tf[QMAX * 8 * 4];       // [q][t][z], t: BM MM IM DM MD MI II DD
   float tb[QMAX * 6 * 4];       // Backward's main loop, per q: II(q) MI(q) BM(q) MM(q+1) IM(q+1) DM(q+1), the
                                 // wrap-around at q = Q-1 (left shift of group 0) already applied
@@ -46,8 +47,12 @@ struct DevProfile {
   float ft10, ft11, fpi0, fpi1; // bias-filter HMM
   float ev[6];                  // MSV mu,lambda  VIT mu,lambda  FWD tau,lambda
   int   M, Q;
-  int   pad[2];
+  int   pad[4];                 // (tfn on a 16-byte boundary)
+  float tfn[(QMAX * 4 + 1) * 8]; // tf by node: [k][t], k = 0 (zeros) .. 4 Q (k_ensemble.hip: a traceback step loads one node's transitions)
 };
+
+static_assert(offsetof(DevProfile, tb) == sizeof(float) * QMAX * 8 * 4, "k_float.hip reaches tb as tf + 384 floats");
+static_assert(offsetof(DevProfile, tfn) % 16 == 0 && sizeof(DevProfile) % 16 == 0, "tfn is read with 16-byte loads");
 
 constexpr int VIT_TAB = 8 * (MMAX + 1) + NCODE * (MMAX + 1);   // int16 words of one profile's Viterbi-filter tables on the device
 struct LenTables {              // per target length L, built on the host with libm

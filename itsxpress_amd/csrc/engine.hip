@@ -378,6 +378,8 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
       for (int t = 0; t < 7; t++) for (int z = 0; z < 4; z++) d.tf[(q * 8 + t) * 4 + z] = h.tfv[((size_t)q * 7 + t) * 4 + z];
       for (int z = 0; z < 4; z++) d.tf[(q * 8 + 7) * 4 + z] = h.tfv[((size_t)7 * h.Q + q) * 4 + z];
     }
+    for (int k = 1; k <= 4 * h.Q; k++)            // the same transitions by node (slot k = z Q + q + 1 of the striped vectors)
+      for (int t = 0; t < 8; t++) d.tfn[k * 8 + t] = d.tf[(((k - 1) % h.Q) * 8 + t) * 4 + (k - 1) / h.Q];
     for (int q = 0; q < h.Q; q++) {
       const int order[3] = {6, 5, 0};      // II MI BM of this group
       for (int k = 0; k < 3; k++) for (int z = 0; z < 4; z++) d.tb[(q * 6 + k) * 4 + z] = d.tf[(q * 8 + order[k]) * 4 + z];

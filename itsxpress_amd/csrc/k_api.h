@@ -223,9 +223,12 @@ struct EnvArgs {
 void launch_envelopes(const EnvArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 
 // ---- k_ensemble.hip: multidomain regions (stochastic traceback clustering)
-constexpr int MRV = 38;            // float4 vectors per matrix row: M, D, I of each of the 12 node groups | (E N J B) | (C SCALE - -)
+constexpr int MRV = 52;            // float4 vectors per matrix row: {M D I B} of node 0 (zeros) .. 48 | (E N J B) | (E J C SCALE) | -
 constexpr int MRENV = 4;           // envelopes kept per clustered region
-constexpr int MR_LANES = 32;       // regions per wave: half-filled waves, twice as many of them (the kernels wait on memory 2/3 of the time)
+#ifndef ITSX_MR_LANES
+#define ITSX_MR_LANES 64
+#endif
+constexpr int MR_LANES = ITSX_MR_LANES;       // regions per wave: half-filled waves, twice as many of them (the kernels wait on memory 2/3 of the time)
 constexpr int MR_LANES_LONG = 4;   // ... and per wave of the longest regions (engine.hip: they decide when a batch ends)
 constexpr double MR_LONG_FRAC = 0.02;   // the share of a batch's regions that counts as longest (measured: 0.01-0.05 alike, 2 or 4 lanes alike)
 constexpr int MR_MAXD = 8;         // domains in one sampled path

@@ -26,7 +26,13 @@ enum { ST_M = 1, ST_D, ST_I, ST_S, ST_N, ST_B, ST_E, ST_C, ST_T, ST_J };
 
 // a region's matrix is contiguous (rows of MRV float4): a path moves to the neighbouring node group or to the row before, so
 // consecutive steps of a traceback stay within a cache line or two (interleaved by lane, every float4 of a step was a line of its own)
+// Row layout since round 3 (node-major): vector k = node k's {M, D, I, the row's B} for k = 0 (no node: zeros) .. 4 Q, then the
+// row's specials {E N J B} and {E J C scale}.  A step of a traceback needs M, D, I of ONE node (and B of that row): one vector load
+// instead of four from the striped row, and one more for the node's transitions (DevProfile::tfn).  The kernel is bound by the
+// number of load instructions whose lanes all hit different lines (one line per lane and instruction), not by bytes or latency.
 DEV f4 *mrslab(const MrArgs &a, int64_t r0, int row, int v, int lane) { (void)lane; return (f4 *)a.slab + ((r0 + row) * MRV + v); }
+constexpr int MR_SP = QMAX * 4 + 1, MR_CJ = QMAX * 4 + 2;
+static_assert(MR_CJ < MRV, "matrix row too short");
 DEV float comp4(const f4 &t, int r) { return r == 0 ? t.x : r == 1 ? t.y : r == 2 ? t.z : t.w; }
 // component r of the vector right-shifted by one lane ([0 a b c])
 DEV float comp4_rsh(const f4 &t, int r) { return r == 0 ? 0.0f : r == 1 ? t.x : r == 2 ? t.y : t.z; }
@@ -66,9 +72,9 @@ __global__ void __launch_bounds__(64) k_mr_fwd(MrArgs a, int wave0)
   for (int q = 0; q < QMAX; q++) { M[q] = vzero(); D[q] = vzero(); I[q] = vzero(); }
   float xE = 0.f, xN = 1.f, xJ = 0.f, xB = e.pmove, xC = 0.f;
   if (e.active) {
-    for (int q = 0; q < Q; q++) for (int s = 0; s < 3; s++) *mrslab(a, e.r0, 0, q * 3 + s, lane) = (f4){0.f, 0.f, 0.f, 0.f};
-    *mrslab(a, e.r0, 0, 36, lane) = (f4){xE, xN, xJ, xB};
-    *mrslab(a, e.r0, 0, 37, lane) = (f4){xC, 1.0f, 0.f, 0.f};
+    for (int k = 0; k <= Q * 4; k++) *mrslab(a, e.r0, 0, k, lane) = (f4){0.f, 0.f, 0.f, xB};
+    *mrslab(a, e.r0, 0, MR_SP, lane) = (f4){xE, xN, xJ, xB};
+    *mrslab(a, e.r0, 0, MR_CJ, lane) = (f4){xE, xJ, xC, 1.0f};
   }
   for (int i = 1; i <= Lw; i++) {
     if (!(e.active && i <= e.Lr)) continue;
@@ -129,15 +135,18 @@ __global__ void __launch_bounds__(64) k_mr_fwd(MrArgs a, int wave0)
       sc = xE;
       xE = 1.0f;
     }
+    *mrslab(a, e.r0, i, 0, lane) = (f4){0.f, 0.f, 0.f, xB};
 #pragma unroll
     for (int q = 0; q < QMAX; q++) {
       if (q >= Q) break;
-      *mrslab(a, e.r0, i, q * 3 + 0, lane) = tof4(M[q]);
-      *mrslab(a, e.r0, i, q * 3 + 1, lane) = tof4(D[q]);
-      *mrslab(a, e.r0, i, q * 3 + 2, lane) = tof4(I[q]);
+      const f4 m4 = tof4(M[q]), d4 = tof4(D[q]), i4 = tof4(I[q]);          // striped: component r is node r Q + q + 1
+      *mrslab(a, e.r0, i, 0 * Q + q + 1, lane) = (f4){m4.x, d4.x, i4.x, xB};
+      *mrslab(a, e.r0, i, 1 * Q + q + 1, lane) = (f4){m4.y, d4.y, i4.y, xB};
+      *mrslab(a, e.r0, i, 2 * Q + q + 1, lane) = (f4){m4.z, d4.z, i4.z, xB};
+      *mrslab(a, e.r0, i, 3 * Q + q + 1, lane) = (f4){m4.w, d4.w, i4.w, xB};
     }
-    *mrslab(a, e.r0, i, 36, lane) = (f4){xE, xN, xJ, xB};
-    *mrslab(a, e.r0, i, 37, lane) = (f4){xC, sc, 0.f, 0.f};
+    *mrslab(a, e.r0, i, MR_SP, lane) = (f4){xE, xN, xJ, xB};
+    *mrslab(a, e.r0, i, MR_CJ, lane) = (f4){xE, xJ, xC, sc};
   }
 }
 
@@ -174,6 +183,21 @@ DEV int choose_n(uint32_t &rng, int n, float p0, float p1, float p2, float p3)
   return i;
 }
 
+// the same over two weights (choose_n with w2 = w3 = 0: the sums, the quotients and the draws are the same)
+DEV int choose2(uint32_t &rng, float p0, float p1)
+{
+  float sum = 0.f; sum += p0; sum += p1;
+  if (sum != 0.0f) { p0 /= sum; p1 /= sum; }
+  else { p0 = p1 = (float)(1. / (double)(float)2); }
+  const double roll = rng_next(rng);
+  double s = 0.0;
+  s += p0; if (roll < s) return 0;
+  s += p1; if (roll < s) return 1;
+  int i;
+  do { i = (int)(rng_next(rng) * 2); } while ((i == 0 ? p0 : p1) == 0.f);
+  return i;
+}
+
 struct Tup { int i, j, k, m; };
 DEV Tup unpack_tup(unsigned long long v) { Tup t; t.i = (int)(v & 0xffff); t.j = (int)((v >> 16) & 0xffff); t.k = (int)((v >> 32) & 0xff); t.m = (int)((v >> 40) & 0xff); return t; }
 DEV unsigned long long pack_tup(int i, int j, int k, int m) { return (unsigned long long)i | ((unsigned long long)j << 16) | ((unsigned long long)k << 32) | ((unsigned long long)m << 40); }
@@ -200,22 +224,23 @@ struct MrScratch {
   uint16_t hslot[MR_HASH];                  // open-addressing index over key[]: tuple number + 1, 0 = empty
   uint16_t epc[MR_EPC];                     // endpoint histogram of one coordinate of one cluster
   int32_t sig_i[MR_NSIG], sig_j[MR_NSIG]; float sig_p[MR_NSIG]; uint8_t dominated[MR_NSIG];
+  f4 dn2[MR_MAXD];                          // null2 odds (A C G T) of the domains of the path being sampled
 };
 static_assert(sizeof(MrScratch) <= MR_SCRATCH, "scratch block too small");
 
-__global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_mr_trace(MrArgs a, int wave0)
 {
   // usage of the domain being walked: a match state is visited at most once per node (a bit mask), insert states are counted
   __shared__ uint16_t cntI_s[QMAX * 4][MR_LANES];
   // the domains of the path being sampled, last first: first / last residue, first / last node, null2 odds of A C G T
-  __shared__ uint32_t dom_ij[MR_MAXD][MR_LANES], dom_km[MR_MAXD][MR_LANES];
-  __shared__ float dom_n2[MR_MAXD][4][MR_LANES];
+  __shared__ uint32_t dom_ij[MR_MAXD][MR_LANES];
+  __shared__ uint16_t dom_km[MR_MAXD][MR_LANES];           // (the domains' null2 odds live in the region's scratch block: S.dn2)
   const WaveDesc wd = a.waves[wave0 + (gridDim.x - 1 - blockIdx.x)];       // longest regions first
   const int lane = threadIdx.x;
   const MrLane e = mr_lane(a, wd, lane);
   if (!e.active) return;
   const int Q = e.Q, Lr = e.Lr, Lw = wd.rows - 1;
-  const float *tf = e.pp->tf;
+  const float *tfn = e.pp->tfn;
   const float pmove = e.pmove, ploop = e.ploop;
   float *n2 = a.n2sc + a.n2off[e.mi];                       // n2[pos - 1], pos = 1..Lr relative to the region
   MrScratch &S = *(MrScratch *)(a.scratch + (int64_t)(e.mi - a.u0) * MR_SCRATCH);
@@ -224,9 +249,6 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
   uint32_t rng = rnd_mix3(42u, 87654321u, 12345678u);
   if (rng == 0) rng = 42;
   int ntup = 0, nsamp = 0, status = 0;
-  auto MV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 0, lane); };
-  auto DV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 1, lane); };
-  auto IV = [&](int row, int q) { return *mrslab(a, e.r0, row, q * 3 + 2, lane); };
   const unsigned short dgm[16] = {1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15};
   // Seq::code() walks the read's exception list through global loads on every call: the residue loop below would pay that for
   // every residue of every path of a read that has a single N (15 % of the bench's reads have one)
@@ -247,6 +269,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
     if (__ballot(status == 0) == 0ull) break;
     const unsigned long long tk0 = wall_clock64();
     int i = Lr, k = 0, s0 = status == 0 ? ST_C : ST_S, nd = 0;
+    int cj_row = -1; f4 cj_cur = (f4){0.f, 0.f, 0.f, 0.f};
     int dfrom = 0, dto = 0, dk = 0, dm = 0;
     unsigned long long maskM = 0ull;
     while (__ballot(s0 != ST_S) != 0ull) {
@@ -254,30 +277,37 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
       while (__ballot(s0 == ST_C || s0 == ST_J) != 0ull) {
         if (!(s0 == ST_C || s0 == ST_J)) continue;
         if (i < 1) { status = 5; s0 = ST_S; continue; }
-        const f4 sp0 = *mrslab(a, e.r0, i - 1, 36, lane), sp0b = *mrslab(a, e.r0, i - 1, 37, lane);
-        const f4 sp1 = *mrslab(a, e.r0, i, 36, lane), sp1b = *mrslab(a, e.r0, i, 37, lane);
-        const float w0 = (s0 == ST_C ? sp0b.x : sp0.z) * ploop, w1 = sp1.x * 0.5f * sp1b.y;
-        if (choose_n(rng, 2, w0, w1, 0.0f, 0.0f) == 0) i--; else s0 = ST_E;
+        // {E J C scale} of rows i - 1 and i: row i's vector is the one the previous step loaded as row i - 1
+        if (cj_row != i) { cj_cur = *mrslab(a, e.r0, i, MR_CJ, lane); cj_row = i; }
+        const f4 c0 = *mrslab(a, e.r0, i - 1, MR_CJ, lane);
+        const float w0 = (s0 == ST_C ? c0.z : c0.y) * ploop, w1 = cj_cur.x * 0.5f * cj_cur.w;
+        if (choose2(rng, w0, w1) == 0) { i--; cj_cur = c0; cj_row = i; } else s0 = ST_E;
       }
       // ---- E: which match or delete state the domain ends in
       if (__ballot(s0 == ST_E) != 0ull) {
         if (s0 == ST_E) {
           double sum = 0.0;
           const double roll = rng_next(rng);
-          const double norm = 1.0 / (double)mrslab(a, e.r0, i, 36, lane)->x;
+          const double norm = 1.0 / (double)cj_cur.x;                       // E of row i: the C* / J* loop ends holding it
           const float xEv = (float)norm;
           int s1 = -1;
           while (s1 < 0) {
-            for (int q0 = 0; q0 < Q && s1 < 0; q0 += 3) {               // three node groups' M and D vectors requested at once
-              f4 um[3], ud[3];
+            for (int q0 = 0; q0 < Q && s1 < 0; q0 += 3) {               // three node groups' (M, D) pairs requested at once;
+              f2 md[3][4];                                               // the sum runs in the striped order: group by group
 #pragma unroll
-              for (int z = 0; z < 3; z++) { const int qq = q0 + z < Q ? q0 + z : Q - 1; um[z] = MV(i, qq); ud[z] = DV(i, qq); }
+              for (int z = 0; z < 3; z++) {
+                const int qq = q0 + z < Q ? q0 + z : Q - 1;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) md[z][rr] = *(const f2 *)mrslab(a, e.r0, i, rr * Q + qq + 1, lane);
+              }
 #pragma unroll
               for (int z = 0; z < 3; z++) {
                 if (q0 + z >= Q || s1 >= 0) continue;
                 const int qq = q0 + z;
-                for (int rr = 0; rr < 4 && s1 < 0; rr++) { sum += (double)(comp4(um[z], rr) * xEv); if (roll < sum) { k = rr * Q + qq + 1; s1 = ST_M; } }
-                for (int rr = 0; rr < 4 && s1 < 0; rr++) { sum += (double)(comp4(ud[z], rr) * xEv); if (roll < sum) { k = rr * Q + qq + 1; s1 = ST_D; } }
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) { if (s1 < 0) { sum += (double)(md[z][rr].x * xEv); if (roll < sum) { k = rr * Q + qq + 1; s1 = ST_M; } } }
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) { if (s1 < 0) { sum += (double)(md[z][rr].y * xEv); if (roll < sum) { k = rr * Q + qq + 1; s1 = ST_D; } } }
               }
             }
             if (s1 < 0 && sum < 0.99) { status = 1; s1 = ST_S; }          // HMMER throws here
@@ -296,25 +326,16 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
       // ---- (M | D | I)*: the loads of a step for whichever of the three the lane is in, then one choice
       while (__ballot(s0 == ST_M || s0 == ST_D || s0 == ST_I) != 0ull) {
         if (!(s0 == ST_M || s0 == ST_D || s0 == ST_I)) continue;
-        const int q = (k - 1) % Q, r = (k - 1) / Q;
-        const bool wrap = (s0 != ST_I) && q == 0;                       // predecessor group is Q-1, one SSE lane to the left
-        const int qa = (s0 == ST_I) ? q : (q > 0 ? q - 1 : Q - 1);
+        // one vector = M, D, I of the node the step comes from and B of its row; one vector = that step's transitions
+        // (M: B M I D -> M of node k; D: M D -> D out of node k - 1; I: M I -> I of node k)
         const int rowA = (s0 == ST_D) ? i : i - 1;
-        const f4 vm = MV(rowA, qa), vd = DV(rowA, qa), vi = IV(rowA, qa);
-        const float xB = mrslab(a, e.r0, i - 1, 36, lane)->w;
-        // transition operands: M uses BM MM IM DM of its own group, D uses MD DD of the predecessor group, I uses MI II of its own
-        const int tq = (s0 == ST_D) ? qa : q;
-        const int tr = (wrap && s0 == ST_D) ? (r > 0 ? r - 1 : 0) : r;
-        const int tb = (s0 == ST_M) ? tBM : (s0 == ST_D) ? tMD : tMI;
-        const float t0 = tf[(tq * 8 + tb) * 4 + tr];
-        const float t1 = tf[(tq * 8 + ((s0 == ST_M) ? tMM : (s0 == ST_D) ? tDD : tII)) * 4 + tr];
-        const float t2 = tf[(tq * 8 + tIM) * 4 + tr], t3 = tf[(tq * 8 + tDM) * 4 + tr];
-        const float pm = wrap ? comp4_rsh(vm, r) : comp4(vm, r), pd = wrap ? comp4_rsh(vd, r) : comp4(vd, r), pi = wrap ? comp4_rsh(vi, r) : comp4(vi, r);
-        const bool zero = s0 == ST_D && wrap && r == 0;                 // right-shifted operands: lane 0 holds 0
+        const int kA = (s0 == ST_I) ? k : k - 1;
+        const f4 nv = *mrslab(a, e.r0, rowA, kA, lane);
+        const f4 tv = *(const f4 *)(tfn + (s0 == ST_D ? kA : k) * 8 + (s0 == ST_M ? 0 : 4));
         float w0, w1, w2 = 0.0f, w3 = 0.0f;
-        if (s0 == ST_M) { w0 = xB * t0; w1 = pm * t1; w2 = pi * t2; w3 = pd * t3; }
-        else if (s0 == ST_D) { w0 = pm * (zero ? 0.0f : t0); w1 = pd * (zero ? 0.0f : t1); }
-        else { w0 = pm * t0; w1 = pi * t1; }
+        if (s0 == ST_M) { w0 = nv.w * tv.x; w1 = nv.x * tv.y; w2 = nv.z * tv.z; w3 = nv.y * tv.w; }
+        else if (s0 == ST_D) { w0 = nv.x * tv.x; w1 = nv.y * tv.w; }              // (node 0 and its transitions are zeros)
+        else { w0 = nv.x * tv.y; w1 = nv.z * tv.z; }
         const int c = choose_n(rng, s0 == ST_M ? 4 : 2, w0, w1, w2, w3);
         int s1;
         if (s0 == ST_M) { s1 = c == 0 ? ST_B : c == 1 ? ST_M : c == 2 ? ST_I : ST_D; k--; i--; }
@@ -325,15 +346,15 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
           dfrom = i; dk = k;
           maskM |= 1ull << k;
         } else if (s1 == ST_I) {
-          cntI_s[((k - 1) % Q) * 4 + (k - 1) / Q][lane] += 1;
+          cntI_s[k - 1][lane] += 1;
         }
         s0 = s1;
       }
       // ---- B: where the domain was entered from, and p7_Null2_ByTrace over its states (only match and insert states emit)
       if (__ballot(s0 == ST_B) != 0ull) {
         if (s0 == ST_B) {
-          const f4 sp1 = *mrslab(a, e.r0, i, 36, lane);
-          s0 = choose_n(rng, 2, sp1.y * pmove, sp1.z * pmove, 0.0f, 0.0f) == 0 ? ST_S : ST_J;        // N: the path is finished
+          const f4 sp1 = *mrslab(a, e.r0, i, MR_SP, lane);
+          s0 = choose2(rng, sp1.y * pmove, sp1.z * pmove) == 0 ? ST_S : ST_J;        // N: the path is finished
           int Ld = __popcll(maskM);
           for (int z = 0; z < Q * 4; z++) Ld += (int)cntI_s[z][lane];
           const float norm = (float)(1.0 / (double)(float)Ld);
@@ -346,7 +367,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
             // node of (group qq, SSE lane z) = z Q + qq + 1; its match count is 1 or 0
             mv.a = (f2){(float)((maskM >> (0 * Q + qq + 1)) & 1ull), (float)((maskM >> (1 * Q + qq + 1)) & 1ull)};
             mv.b = (f2){(float)((maskM >> (2 * Q + qq + 1)) & 1ull), (float)((maskM >> (3 * Q + qq + 1)) & 1ull)};
-            iv.a = (f2){(float)cntI_s[qq * 4 + 0][lane], (float)cntI_s[qq * 4 + 1][lane]}; iv.b = (f2){(float)cntI_s[qq * 4 + 2][lane], (float)cntI_s[qq * 4 + 3][lane]};
+            iv.a = (f2){(float)cntI_s[0 * Q + qq][lane], (float)cntI_s[1 * Q + qq][lane]}; iv.b = (f2){(float)cntI_s[2 * Q + qq][lane], (float)cntI_s[3 * Q + qq][lane]};
             mv = vmul(mv, vset(norm)); iv = vmul(iv, vset(norm));
 #pragma unroll
             for (int x = 0; x < 4; x++) {
@@ -355,9 +376,11 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
             }
           }
           dom_ij[nd - 1][lane] = (uint32_t)dfrom | ((uint32_t)dto << 16);
-          dom_km[nd - 1][lane] = (uint32_t)dk | ((uint32_t)dm << 8);
+          dom_km[nd - 1][lane] = (uint16_t)((uint32_t)dk | ((uint32_t)dm << 8));
+          { float v4_[4];
 #pragma unroll
-          for (int x = 0; x < 4; x++) { float v = vhsum(sv[x]); v += xfactor; dom_n2[nd - 1][x][lane] = v; }
+            for (int x = 0; x < 4; x++) { float v = vhsum(sv[x]); v += xfactor; v4_[x] = v; }
+            S.dn2[nd - 1] = (f4){v4_[0], v4_[1], v4_[2], v4_[3]}; }
         }
       }
     }
@@ -367,7 +390,7 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
     // ---- after the path, all lanes together: its samples ...
     for (int d = 0; d < nd; d++) {
       if (nsamp >= MR_SCAP) { status = 3; break; }
-      const uint32_t ij = dom_ij[d][lane], km = dom_km[d][lane];
+      const uint32_t ij = dom_ij[d][lane], km = (uint32_t)dom_km[d][lane];
       const unsigned long long key = pack_tup((int)(ij & 0xffff), (int)(ij >> 16), (int)(km & 0xff), (int)(km >> 8));   // relative to the region
       uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 40) & (MR_HASH - 1);
       int tix = -1;
@@ -390,7 +413,8 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
     // ... and its residues' null2 terms.  As published: residues up to AND INCLUDING a domain's first one count as outside
     // (+1), the rest of the domain by its null2 odds; a residue takes exactly one term per path, so their order is free.
     {
-      int d = 0;
+      int d = 0, dl = -1;
+      f4 n2d = (f4){0.f, 0.f, 0.f, 0.f};                       // the null2 odds of domain dl
       uint32_t cw = 0; int cwi = -1;
       // four residues per round: their terms first, then four independent read-modify-writes in flight together
       for (int p4 = Lw; p4 >= 1; p4 -= 4) {
@@ -409,11 +433,12 @@ __global__ void __launch_bounds__(64) k_mr_trace(MrArgs a, int wave0)
               x = (int)((cw >> (2 * (p0 & 15))) & 3u);
               x = p0 == ex0p ? ex0c : x; x = p0 == ex1p ? ex1c : x;
             } else x = e.sq.code(p0);
-            if (x < 4) v[z] = dom_n2[d][x][lane];
+            if (d != dl) { dl = d; n2d = S.dn2[d]; }
+            if (x < 4) v[z] = comp4(n2d, x);
             else {
               float acc = 0.f; int ndg = 0;
 #pragma unroll
-              for (int y = 0; y < 4; y++) if (dgm[x] >> y & 1) { acc += dom_n2[d][y][lane]; ndg++; }
+              for (int y = 0; y < 4; y++) if (dgm[x] >> y & 1) { acc += comp4(n2d, y); ndg++; }
               v[z] = acc / (float)ndg;
             }
           }

@@ -997,7 +997,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   const int32_t kcap = std::max(8, ((Lmax - 7 + 7) / 8) * 8);
 
   DBuf<int32_t> d_order, cent_len, cent_pos, cent_read, res_col, knk, state, rejects, acc_col, is_new, new_rank, scan_tmp, xlist, xn, hard, dbg;
-  DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm, canon, ctab_val, need, awork;
+  DBuf<int32_t> sel, selm, sel_short, wn, wcol, newq, rm, wout, work, xwork, work_n, replay, skipm, canon, ctab_val, need, awork, spairs;
   DBuf<int32_t> cw_n, wsum, wscan, qi_cnt, qi_cur, qi_off, ncand, ntop, ovf, qi_hid, qi_nheavy;
   DBuf<uint32_t> qi_bm;
   DBuf<int64_t> cw_off, cw_base;
@@ -1020,7 +1020,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(xlist.alloc(nqs * 32)); HIPCHK(xn.alloc(nqs)); HIPCHK(hard.alloc(nqs)); HIPCHK(xkey.alloc(nqs * 32)); HIPCHK(xpid.alloc(nqs * 32));
   HIPCHK(is_new.alloc((size_t)Bmax + 1)); HIPCHK(new_rank.alloc((size_t)Bmax + 1)); HIPCHK(newq.alloc((size_t)Bmax + 1)); HIPCHK(rm.alloc((size_t)Bmax + 1));
   HIPCHK(wsum.alloc((size_t)Bmax + 1)); HIPCHK(wscan.alloc((size_t)Bmax + 1));
-  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(4)); HIPCHK(awork.alloc(2 * nqs * 32)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(pre_stats.alloc(16)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 16 * sizeof(unsigned long long), ctx->st));
+  HIPCHK(wout.alloc(4)); HIPCHK(dbg.alloc(4)); HIPCHK(work.alloc(nqs * 32)); HIPCHK(xwork.alloc(nqs * 32)); HIPCHK(work_n.alloc(8)); HIPCHK(awork.alloc(2 * nqs * 32)); HIPCHK(spairs.alloc(4 * nqs * 32)); HIPCHK(replay.alloc((size_t)Bmax + 1)); HIPCHK(skipm.alloc((size_t)Bmax + 1)); HIPCHK(canon.alloc((size_t)Bmax + 1)); HIPCHK(need.alloc(2 * nqs * 32)); HIPCHK(n_skipped.alloc(1)); HIPCHK(pre_stats.alloc(16)); HIPCHK(hipMemsetAsync(pre_stats.p, 0, 16 * sizeof(unsigned long long), ctx->st));
   HIPCHK(hipMemsetAsync(n_skipped.p, 0, sizeof(unsigned long long), ctx->st)); HIPCHK(ctab_key.alloc(16384)); HIPCHK(ctab_val.alloc(16384));
   HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1));
   if (n > 0) launch_hash_reads(ctx->rd, 0, 0, ctx->w_hf.p, ctx->w_hr.p, ctx->st);      // identical reads of a window share one search
@@ -1061,7 +1061,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
   a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
   a.is_new = is_new.p; a.new_rank = new_rank.p; a.newq = newq.p; a.rm = rm.p;
-  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.awork = awork.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p;
+  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.awork = awork.p; a.spairs = spairs.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p;
   a.use_score = getenv("ITSX_CL_NOSCORE") ? 0 : 1;
   a.pre_k = std::min(16, (int)((double)Lmax * (1.0 - id) / id) + 1); a.ctab_key = ctab_key.p; a.ctab_val = ctab_val.p; a.rhash = ctx->w_hf.p;
   a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;

@@ -71,7 +71,8 @@ struct ClusterArgs {
   int32_t *is_new, *new_rank;   // [nq+1]
   int32_t *newq, *rm;           // [nq] window index of each speculative centroid; columns to clear after validation
   int32_t *xlist, *xn, *hard; unsigned long long *xkey; double *xpid;            // speculative centroids entering a walk [2 nq][32]
-  int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[4]: items of work / xwork, of awork's two halves
+  int32_t *work, *xwork, *work_n;   // (query strand * 32 + slot) items for the two alignment kernels; work_n[6]: items of work / xwork, of awork's two halves, of spairs' two halves
+  int32_t *spairs;                  // [2][need_pitch][2]: the score pass's list: two items of one strand (or one and -1) per entry
   int32_t *awork;                   // [2][need_pitch] the items the certificate leaves to the dynamic program (walk / validation)
   const uint32_t *dmask;        // DUST soft mask of every read, one bit per base at woff[r] (k_dust); nullptr: no masking (ITSX_QMASK=none)
   const uint64_t *rhash;        // [n reads] XXH64 of the packed forward strand

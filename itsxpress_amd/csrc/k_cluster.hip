@@ -517,7 +517,7 @@ __global__ __launch_bounds__(64) void k_cl_topk(ClusterArgs a, int final)
 __global__ void k_cl_init(ClusterArgs a)
 {
   const int qs = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; for (int r = 0; r < 4; r++) a.work_n[r] = 0; }
+  if (qs == 0) { for (int r = 0; r < 4; r++) a.dbg[r] = 0; for (int r = 0; r < 6; r++) a.work_n[r] = 0; }
   if (qs < a.nq) { a.replay[qs] = 0; a.skipm[qs] = 0; }
   if (qs >= 2 * a.nq) return;
   a.state[qs] = a.canon[qs >> 1] != (qs >> 1) ? 4 : (a.nk[qs] == 0 || a.C == 0) ? 3 : 0;      // 4 = a copy: reads its canonical query's state
@@ -921,29 +921,178 @@ template <int S> __device__ __forceinline__ bool score_pair(const ClusterArgs &a
   for (int r = 0; r < S; r++) if (i0 + r == Lq) { res = Hl[r]; have = true; }
   return have;
 }
-template <int S> __global__ __launch_bounds__(64) void k_cl_score(ClusterArgs a, int which, int lds_pre)
+// Two candidates of ONE query strand at a time: the scores of a cell of both dynamic programs as the 16-bit halves of one register
+// (packed add / max: the scores stay within +-2 (Lq + Lt) + 44, far inside 16 bits; NEG16 plays NEG32's part and nothing derived
+// from it ever beats a real score or wraps), the query side -- masks, gap flags -- shared.  The shorter target's half runs on past
+// its last column with whatever it finds there; a target's score is taken when ITS last column passes the lane that holds row Lq.
+typedef short pk16 __attribute__((ext_vector_type(2)));
+typedef unsigned short pku16 __attribute__((ext_vector_type(2)));
+static constexpr int NEG16 = -20000;
+__device__ __forceinline__ pk16 pk_of(int lo, int hi) { return (pk16){(short)lo, (short)hi}; }
+__device__ __forceinline__ pk16 pk_max(pk16 x, pk16 y) { return __builtin_elementwise_max(x, y); }
+__device__ __forceinline__ int pk_bits(pk16 x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ pk16 pk_from(int x) { return __builtin_bit_cast(pk16, x); }
+template <int S> __device__ __forceinline__ void score_pair2(const ClusterArgs &a, int qs, int col1, int col2, uint8_t *tmask1, uint8_t *tmask2, int &res1, int &res2)
 {
-  extern __shared__ uint8_t sc_lds[];
+  const int lane = threadIdx.x;
+  const int qi = qs >> 1, s = qs & 1;
+  const int64_t rq = a.order[a.f + qi], rt1 = a.cent_read[col1], rt2 = a.cent_read[col2];
+  const int Lq = a.rd.len[rq], Lt1 = a.rd.len[rt1], Lt2 = a.rd.len[rt2];
+  const uint32_t *wq = a.rd.words + a.rd.woff[rq];
+  const int64_t eoq = a.rd.excoff[rq];
+  const int nexq = (int)(a.rd.excoff[rq + 1] - eoq);
+  __syncthreads();
+  for (int k = 0; k < 2; k++) {
+    const int64_t rt = k ? rt2 : rt1;
+    uint8_t *tmask = k ? tmask2 : tmask1;
+    const uint32_t *wt = a.rd.words + a.rd.woff[rt];
+    const int Lt = k ? Lt2 : Lt1;
+    for (int o = lane; o < Lt; o += 64) tmask[o] = (uint8_t)(1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u));
+  }
+  __syncthreads();
+  for (int k = 0; k < 2; k++) {
+    const int64_t rt = k ? rt2 : rt1;
+    uint8_t *tmask = k ? tmask2 : tmask1;
+    const int64_t eot = a.rd.excoff[rt];
+    const int next_ = (int)(a.rd.excoff[rt + 1] - eot);
+    for (int e = lane; e < next_; e += 64) { const uint32_t ex = a.rd.exc[eot + e]; tmask[ex >> 4] = (uint8_t)mask4(ex & 15u); }
+  }
+  __syncthreads();
+  const int i0 = lane * S;
+  uint32_t qpk[S], qall[S]; pk16 goE[S], geE[S];         // the row's mask in both halves (0 when ambiguous), all ones when unambiguous
+#pragma unroll
+  for (int r = 0; r < S; r++) {
+    const int i = i0 + r;
+    uint32_t m = 0;
+    if (i >= 1 && i <= Lq) {
+      const int x = i - 1, o = s ? Lq - 1 - x : x;
+      const uint32_t c2 = (wq[o >> 4] >> ((o & 15) * 2)) & 3u;
+      m = 1u << (s ? 3u - c2 : c2);
+    }
+    qpk[r] = m;
+    const bool term = (i == 0 || i == Lq);
+    goE[r] = pk_of(term ? -3 : -22, term ? -3 : -22); geE[r] = pk_of(term ? -1 : -2, term ? -1 : -2);
+  }
+  for (int e = 0; e < nexq; e++) {
+    const uint32_t ex = a.rd.exc[eoq + e];
+    const int pos = (int)(ex >> 4);
+    const int i = (s ? Lq - 1 - pos : pos) + 1;
+    const uint32_t m = s ? revmask4(mask4(ex & 15u)) : mask4(ex & 15u);
+#pragma unroll
+    for (int r = 0; r < S; r++) if (i == i0 + r) qpk[r] = m;
+  }
+  // an unambiguous row symbol c becomes the value 6 in a 3-bit field of its own, 6 << 3 c, in both halves: shifted right by
+  // 3 x (the target's symbol) and cut to 3 bits it leaves 6 where the two match and 0 where they do not
+  bool isrow[S];
+#pragma unroll
+  for (int r = 0; r < S; r++) {
+    const bool u = unamb4(qpk[r]);
+    const uint32_t six = u ? 6u << (3u * ((uint32_t)__ffs((int)qpk[r]) - 1u)) : 0u;
+    qall[r] = u ? 0xFFFFFFFFu : 0u; qpk[r] = six | (six << 16);
+    isrow[r] = (i0 + r == Lq);
+  }
+  const pk16 neg = pk_of(NEG16, NEG16);
+  pk16 Hl[S], El[S];
+#pragma unroll
+  for (int r = 0; r < S; r++) { Hl[r] = neg; El[r] = neg; }
+  pk16 diag_carry = lane == 0 ? pk_of(0, 0) : neg, pubH = neg, pubF = neg;      // cell (0, 0) is 0
+  const int Ltmax = Lt1 > Lt2 ? Lt1 : Lt2;
+  const int nsteps = Ltmax + 1 + 63;
+  const bool mine = (Lq >= i0 && Lq < i0 + S);            // this lane holds row Lq
+  int cap1 = 0, cap2 = 0;
+  // No lane is switched off while the wavefront passes: a lane that has not reached column 0 yet (j < 0) works on columns that do
+  // not exist, from NEG16 state and with no symbol, so everything it produces stays near NEG16 -- exactly what column 0 wants to its
+  // left -- and a lane past its target's last column produces values nobody reads (the result was taken when that column passed).
+  for (int t = 0; t < nsteps; t++) {
+    pk16 upH = pk_from(__shfl_up(pk_bits(pubH), 1)), upF = pk_from(__shfl_up(pk_bits(pubF), 1));
+    const int j = t - lane;
+    if (lane == 0) { upH = neg; upF = neg; }
+    const int jc = j < 1 ? 0 : (j > Ltmax ? Ltmax - 1 : j - 1);
+    uint32_t tm1 = (uint32_t)tmask1[jc], tm2 = (uint32_t)tmask2[jc];
+    if (j < 1) { tm1 = 0u; tm2 = 0u; }
+    const bool tu1 = unamb4(tm1), tu2 = unamb4(tm2);
+    const uint32_t ct1 = tu1 ? 3u * ((uint32_t)__ffs((int)tm1) - 1u) : 12u, ct2 = tu2 ? 3u * ((uint32_t)__ffs((int)tm2) - 1u) : 12u;
+    const pku16 ctpk = __builtin_bit_cast(pku16, ct1 | (ct2 << 16));              // (12: an ambiguous target symbol matches nothing)
+    const pku16 seven = (pku16){7, 7};
+    const uint32_t tbase = (tu1 ? 0x0000FFFCu : 0u) | (tu2 ? 0xFFFC0000u : 0u);            // -4 where the target symbol is unambiguous
+    const bool tF1 = (j == 0 || j == Lt1), tF2 = (j == 0 || j == Lt2);
+    const pk16 goF = pk_from((int)((tF1 ? 0xFFFDu : 0xFFEAu) | (tF2 ? 0xFFFD0000u : 0xFFEA0000u)));       // -3 : -22
+    const pk16 geF = pk_from((int)((tF1 ? 0xFFFFu : 0xFFFEu) | (tF2 ? 0xFFFF0000u : 0xFFFE0000u)));       // -1 : -2
+    pk16 aboveH = upH, aboveF = upF, dg = diag_carry;
+#pragma unroll
+    for (int r = 0; r < S; r++) {
+      const pk16 E = pk_max(Hl[r] + goE[r], El[r] + geE[r]);
+      const pk16 F = pk_max(aboveH + goF, aboveF + geF);
+      // +2 / -4 between unambiguous symbols, 0 otherwise: -4 where both are, + 6 where they match
+      const pku16 hit6 = (__builtin_bit_cast(pku16, qpk[r]) >> ctpk) & seven;
+      const pk16 D = __builtin_bit_cast(pk16, hit6) + pk_from((int)(qall[r] & tbase));
+      const pk16 Hn = pk_max(pk_max(dg + D, E), F);
+      dg = Hl[r];
+      Hl[r] = Hn; El[r] = E;
+      aboveH = Hn; aboveF = F;
+    }
+    pubH = aboveH; pubF = aboveF;
+    diag_carry = upH;
+    int hq = 0;                                                                    // row Lq of this column, where this lane holds it
+#pragma unroll
+    for (int r = 0; r < S; r++) hq = isrow[r] ? pk_bits(Hl[r]) : hq;
+    cap1 = j == Lt1 ? hq : cap1; cap2 = j == Lt2 ? hq : cap2;
+  }
+  if (mine) { res1 = (int)pk_from(cap1).x; res2 = (int)pk_from(cap2).y; }
+}
+// the score pass's list: the items the certificate could not judge, two of one strand per entry where a strand has two (a strand's
+// items are consecutive in the work list; a thread looks at 32 entries)
+__global__ void k_cl_pairs(ClusterArgs a, int which)
+{
   const int nw = a.work_n[which];
   const int32_t *work = which ? a.xwork : a.work;
+  const int32_t *need = a.need + which * a.need_pitch;
+  int32_t *out = a.spairs + (size_t)which * a.need_pitch * 2;
+  const int w0 = (blockIdx.x * blockDim.x + threadIdx.x) * 32;
+  int pend = -1;
+  for (int w = w0; w < w0 + 32 && w < nw; w++) {
+    const int item = work[w];
+    if (need[item] != 2) continue;
+    if (pend >= 0 && (pend >> 5) == (item >> 5)) { const int o = atomicAdd(&a.work_n[4 + which], 1); out[2 * o] = pend; out[2 * o + 1] = item; pend = -1; }
+    else { if (pend >= 0) { const int o = atomicAdd(&a.work_n[4 + which], 1); out[2 * o] = pend; out[2 * o + 1] = -1; } pend = item; }
+  }
+  if (pend >= 0) { const int o = atomicAdd(&a.work_n[4 + which], 1); out[2 * o] = pend; out[2 * o + 1] = -1; }
+}
+template <int S> __global__ __launch_bounds__(64) void k_cl_score(ClusterArgs a, int which, int lds_pre, int lds_t2)
+{
+  extern __shared__ uint8_t sc_lds[];
+  const int np = a.work_n[4 + which];
+  const int32_t *pairs = a.spairs + (size_t)which * a.need_pitch * 2;
   const int32_t *cols = which ? a.xlist : a.sel;
   int32_t *need = a.need + which * a.need_pitch;
-  for (int w = blockIdx.x; w < nw; w += gridDim.x) {
-    const int item = work[w];
-    if (need[item] != 2) continue;                          // (block-uniform)
-    const int qs = item >> 5, col = cols[item];
+  for (int w = blockIdx.x; w < np; w += gridDim.x) {
+    const int c[2] = {pairs[2 * w], pairs[2 * w + 1]};
+    const int qs = c[0] >> 5;
     const int Lq = a.rd.len[a.order[a.f + (qs >> 1)]];
-    int verdict = 1;
+    const bool pair = c[1] >= 0;
+    int verdict[2] = {1, 1};
     if (Lq + 1 <= 64 * S) {
-      int res;
-      const bool have = score_pair<S>(a, qs, col, sc_lds + lds_pre, res);
-      const unsigned long long who = __ballot(have);
-      const int sstar = __shfl(res, __ffsll((long long)who) - 1);
-      verdict = precheck_pair(a, qs, col, sc_lds, true, (long long)sstar);
+      if (pair) {
+        int r1 = NEG32, r2 = NEG32;
+        score_pair2<S>(a, qs, cols[c[0]], cols[c[1]], sc_lds + lds_pre, sc_lds + lds_t2, r1, r2);
+        const unsigned long long who = __ballot(r1 != NEG32 || r2 != NEG32);        // the lane that holds row Lq
+        const int src = __ffsll((long long)who) - 1;
+        const int s1 = __shfl(r1, src), s2 = __shfl(r2, src);
+        verdict[0] = precheck_pair(a, qs, cols[c[0]], sc_lds, true, (long long)s1);
+        verdict[1] = precheck_pair(a, qs, cols[c[1]], sc_lds, true, (long long)s2);
+      } else {
+        int res;
+        const bool have = score_pair<S>(a, qs, cols[c[0]], sc_lds + lds_pre, res);
+        const unsigned long long who = __ballot(have);
+        const int sstar = __shfl(res, __ffsll((long long)who) - 1);
+        verdict[0] = precheck_pair(a, qs, cols[c[0]], sc_lds, true, (long long)sstar);
+      }
     }
     if (threadIdx.x == 0) {
-      need[item] = verdict;
-      if (verdict == 1) a.awork[which * a.need_pitch + atomicAdd(&a.work_n[2 + which], 1)] = item;
+      for (int y = 0; y < (pair ? 2 : 1); y++) {
+        need[c[y]] = verdict[y];
+        if (verdict[y] == 1) a.awork[which * a.need_pitch + atomicAdd(&a.work_n[2 + which], 1)] = c[y];
+      }
     }
     __syncthreads();
   }
@@ -1000,7 +1149,7 @@ __global__ void k_cl_walk(ClusterArgs a, int first)
   if (st == 0) { if (a.sel_short[qs]) st = 3; else if (m > 0) a.prev[qs] = a.selkey[qs * 32 + first + m - 1]; }
   a.state[qs] = st; a.wn[qs] = w; a.rejects[qs] = rej; a.selm[qs] = 0;
 }
-__global__ void k_cl_reset_work(ClusterArgs a, int which) { a.work_n[which] = 0; a.work_n[2 + which] = 0; }
+__global__ void k_cl_reset_work(ClusterArgs a, int which) { a.work_n[which] = 0; a.work_n[2 + which] = 0; a.work_n[4 + which] = 0; }
 
 // ------------------------------------------------------------------ outcomes, new centroids, validation
 __global__ void k_cl_outcome(ClusterArgs a)
@@ -1244,14 +1393,16 @@ static size_t precheck_lds(const ClusterArgs &a)
   const size_t L = (size_t)std::min(a.scratch_pitch, PRE_LMAX + 1);      // masks, 8-mer index of the query, votes, two levels of the front
   return 2 * (L + 4) + 1024 + 4 * L + 2 * (L + 2) + 2 * (8 * L + 16) + 64;
 }
-static void launch_cl_score(const ClusterArgs &a, int which, int grid, int rows_per_lane, hipStream_t st)
+static void launch_cl_score(const ClusterArgs &a, int which, int grid, int maxitems, int rows_per_lane, hipStream_t st)
 {
   if (!a.use_score) return;                                   // (ITSX_CL_NOSCORE=1: the too-weak candidates go straight to the full alignment)
   const int pre = (int)((precheck_lds(a) + 63) & ~(size_t)63);
-  const size_t lds = (size_t)pre + (((size_t)a.scratch_pitch + 63) & ~(size_t)63);
-  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_score<5>, dim3(grid), dim3(64), lds, st, a, which, pre);
-  else if (rows_per_lane <= 8) hipLaunchKernelGGL(k_cl_score<8>, dim3(grid), dim3(64), lds, st, a, which, pre);
-  else hipLaunchKernelGGL(k_cl_score<10>, dim3(grid), dim3(64), lds, st, a, which, pre);
+  hipLaunchKernelGGL(k_cl_pairs, dim3((maxitems + 32 * 256 - 1) / (32 * 256)), dim3(256), 0, st, a, which);
+  const int tpitch = (int)(((size_t)a.scratch_pitch + 63) & ~(size_t)63);      // one target's masks; two targets at a time
+  const size_t lds = (size_t)pre + 2 * (size_t)tpitch;
+  if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_score<5>, dim3(grid), dim3(64), lds, st, a, which, pre, pre + tpitch);
+  else if (rows_per_lane <= 8) hipLaunchKernelGGL(k_cl_score<8>, dim3(grid), dim3(64), lds, st, a, which, pre, pre + tpitch);
+  else hipLaunchKernelGGL(k_cl_score<10>, dim3(grid), dim3(64), lds, st, a, which, pre, pre + tpitch);
 }
 void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
 {
@@ -1264,7 +1415,7 @@ void launch_cl_walk(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
     if (a.need) {
       const int per = round == 0 ? 1 : 4;
       hipLaunchKernelGGL(k_cl_precheck, dim3(std::min((2 * a.nq * kmax + per - 1) / per, 65536)), dim3(64), precheck_lds(a), st, a, 0, per);
-      launch_cl_score(a, 0, grid, rows_per_lane, st);
+      launch_cl_score(a, 0, grid, 2 * a.nq * kmax, rows_per_lane, st);
       hipLaunchKernelGGL(k_cl_skipped, dim3(256), dim3(256), 0, st, a, 0);
     }
     if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align<5>, dim3(grid), dim3(64), lds, st, a);
@@ -1284,7 +1435,7 @@ void launch_cl_validate(const ClusterArgs &a, int rows_per_lane, hipStream_t st)
   const size_t lds = ((size_t)a.scratch_pitch + 63) & ~(size_t)63;
   if (a.need) {
     hipLaunchKernelGGL(k_cl_precheck, dim3(grid), dim3(64), precheck_lds(a), st, a, 1, 1);
-    launch_cl_score(a, 1, grid, rows_per_lane, st);
+    launch_cl_score(a, 1, grid, 2 * a.nq * 32, rows_per_lane, st);
     hipLaunchKernelGGL(k_cl_skipped, dim3(256), dim3(256), 0, st, a, 1);
   }
   if (rows_per_lane <= 5) hipLaunchKernelGGL(k_cl_align_x<5>, dim3(grid), dim3(64), lds, st, a);

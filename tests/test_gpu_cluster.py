@@ -123,6 +123,35 @@ def test_cluster_rejection_certificate(engine, monkeypatch):
     assert st["cl_alignments"] < st1["cl_alignments"] < st0["cl_alignments"]
 
 
+def test_cluster_score_pass_pairs_of_unlike_targets(engine, monkeypatch):
+    """The score pass runs two candidates of a strand at a time, their scores in the 16-bit halves of one register: targets of very
+    different lengths in one pair, IUPAC codes on both sides, queries at the last length one pass of 8 rows per lane holds (511) and
+    the first that needs 10 (512); many small unrelated families, so that most candidates are 'too weak' for the diagonal bound."""
+    rng = np.random.default_rng(77)
+    reads, names = [], []
+    for lo, hi, seed in ((120, 180, 1), (300, 330, 2), (505, 512, 3)):
+        r, n = _noisy_library(90 + seed, 700, 90, (lo, hi), max_err=3, n_rate=0.003, rc_rate=0.4, shared_flank=20)
+        reads += r
+        names += ["%s;%d" % (x, seed) for x in n]
+    iupac = "RYSWKMBDHVN"
+    for i in range(0, len(reads), 7):                            # degenerate codes in every seventh read
+        s = list(reads[i])
+        for _ in range(3):
+            s[int(rng.integers(0, len(s)))] = iupac[int(rng.integers(0, len(iupac)))]
+        reads[i] = "".join(s)
+    perm = rng.permutation(len(reads))
+    reads = [reads[i] for i in perm]
+    names = [names[i] for i in perm]
+    assert max(map(len, reads)) >= 512 and any(len(r) == 511 for r in reads)
+    _, st = _compare(engine, reads, names, 0.99)
+    monkeypatch.setenv("ITSX_CL_NOSCORE", "1")
+    _, st1 = _compare(engine, reads, names, 0.99)
+    assert st1["cl_alignments"] > 2 * st["cl_alignments"] > 0   # the pass did take most of them
+    monkeypatch.delenv("ITSX_CL_NOSCORE")
+    monkeypatch.setenv("ITSX_CL_ROWS", "8")                      # 8 rows per lane although reads of 512+ exist: those queries skip the pass
+    _compare(engine, reads, names, 0.99)
+
+
 def test_cluster_plus_strand_only_and_no_names(engine):
     reads, names = _noisy_library(13, 1200, 30, (200, 240))
     _compare(engine, reads, names, 0.99, strand_both=False)

@@ -1156,8 +1156,8 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   if (debug) {
     unsigned long long ps[16] = {0};
     (void)hipMemcpy(ps, pre_stats.p, sizeof(ps), hipMemcpyDeviceToHost);
-    if (ps[12]) fprintf(stderr, "[cluster] stream phases (clock ticks per centroid and workgroup): pieces %.0f, list additions %.0f, scan %.0f, bitmaps %.0f; pieces per centroid %.0f\n",
-                        (double)ps[8] / ps[12], (double)ps[9] / ps[12], (double)ps[10] / ps[12], (double)ps[11] / ps[12], (double)ps[13] / ps[12]);
+    if (ps[12]) fprintf(stderr, "[cluster] stream phases (clock ticks per centroid and workgroup): pieces %.0f, list additions %.0f, scan %.0f, bitmaps %.0f (of which loads + adders %.0f); pieces per centroid %.0f\n",
+                        (double)ps[8] / ps[12], (double)ps[9] / ps[12], (double)ps[10] / ps[12], (double)(ps[11] + ps[14]) / ps[12], (double)ps[14] / ps[12], (double)ps[13] / ps[12]);
     fprintf(stderr, "[cluster] certificate: not applicable %llu, bound too weak %llu (score pass: proven reject %llu, path exists %llu), path exists %llu, proven reject %llu; full alignments %llu\n", ps[0], ps[1], ps[4], ps[5], ps[2], ps[3], naln);
   }
   ctx->stats.ms_cluster = tm.stop();

@@ -239,6 +239,12 @@ __global__ __launch_bounds__(256) void k_cl_kmers(ClusterArgs a)
 }
 
 // ------------------------------------------------------------------ the window's query index: word -> query strands
+// Where strand qs sits in k_cl_stream's LDS histogram (and in the threshold arrays tq / minm): bit-major, [qs & 31][qs >> 5].  The
+// conserved-word phase has lane g of a workgroup own strands 32 g .. 32 g + 31 (one dword of every bitmap); with the strands in
+// their own order its 64 lanes would write slot 32 g + bit -- two LDS banks for the whole wave, a 32-way conflict per access.
+__device__ __forceinline__ int cl_phys(int qs) { return ((qs & 31) << 8) | (qs >> 5); }
+__device__ __forceinline__ int cl_strand(int p) { return ((p & 255) << 5) | (p >> 8); }
+static_assert(CL_QS_MAX == 8192, "cl_phys / cl_strand are written for 256 groups of 32 strands");
 __global__ __launch_bounds__(256) void k_cl_qi_count(ClusterArgs a, int fill)
 {
   const int qs = blockIdx.x;
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256) void k_cl_qi_count(ClusterArgs a, int fill)
     else {
       const int hid = a.qi_hid[w];
       if (hid >= 0) atomicOr(&a.qi_bm[(size_t)hid * (CL_QS_MAX / 32) + (qs >> 5)], 1u << (qs & 31));      // a conserved word: its strand bitmap
-      else a.qi_ent[a.qi_off[w] + atomicAdd(&a.qi_cur[w], 1)] = (uint16_t)(qs * 4);     // the strand's byte offset in the LDS histogram
+      else a.qi_ent[a.qi_off[w] + atomicAdd(&a.qi_cur[w], 1)] = (uint16_t)(cl_phys(qs) * 4);     // the strand's byte offset in the LDS histogram
     }
   }
 }
@@ -283,7 +289,7 @@ __global__ void k_cl_tq_init(ClusterArgs a)
   const bool own = a.canon[qs >> 1] == (qs >> 1);
   const int n = own ? a.nk[qs] : 0;
   const uint32_t m = n > 0 ? ((uint32_t)(n < 12 ? n : 12) << 16) - 1u : 0xFFFFFFFFu;      // count >= min(12, words), any length
-  a.minm[qs] = m; a.tq[qs] = m; a.tkey[qs] = 0ULL; a.ncand[qs] = 0; a.ntop[qs] = 0;
+  a.minm[cl_phys(qs)] = m; a.tq[cl_phys(qs)] = m; a.tkey[qs] = 0ULL; a.ncand[qs] = 0; a.ntop[qs] = 0;
 }
 
 // ------------------------------------------------------------------ the centroids stream past the window
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
   __shared__ int n_items, n_hv;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nqs = 2 * a.nq;
-  const int nrounds = (nqs + 1023) >> 10;                    // a thread scans strands (j * 256 + tid) * 4 .. + 3, j < nrounds
+  const int nrounds = nqs > 0 ? 8 : 0;                       // a thread scans histogram slots (j * 256 + tid) * 4 .. + 3 (cl_phys order: every round holds strands of every window size)
   // count thresholds, four strands (one 8-byte load) at a time; they only change between launches.  The arrays are
   // allocated for the largest window and the launcher sets every entry past the window's end to 0xFFFF (never reached),
   // so the scan needs no bound check.
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
   if (mode == 2) { const int lim = a.C + a.new_rank[a.nq]; c1 = c1 < lim ? c1 : lim; }
   const uint4 *ent = reinterpret_cast<const uint4 *>(a.qi_ent);
 #ifdef ITSX_CL_PROF
-  long long tp[4] = {0, 0, 0, 0}, tn = 0, tadd = 0;
+  long long tp[6] = {0, 0, 0, 0, 0, 0}, tn = 0, tadd = 0;
 #define CLK(i) { const long long now_ = (long long)__builtin_readcyclecounter(); tp[i] += now_ - tlast; tlast = now_; }
   long long tlast = (long long)__builtin_readcyclecounter();
 #else
@@ -430,16 +436,19 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
 #pragma unroll
           for (int b = 0; b < CL_HVL; b++) { t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
         }
+#ifdef ITSX_CL_PROF
+        if (wv == 0) CLK(4)
+#endif
         uint32_t any = ones | twos | fours;
 #pragma unroll
         for (int b = 0; b < CL_HVL; b++) any |= hc[b];
-        uint32_t *hl = hist + (wv * 64 + lane) * 32;
+        uint32_t *hl = hist + (wv * 64 + lane);                // slot of (strand 32 g + bit) = 256 bit + g: the wave's lanes are neighbours
         while (any) {
           const int bit = __ffs(any) - 1; any &= any - 1;
           uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
 #pragma unroll
           for (int b = 0; b < CL_HVL; b++) v |= ((hc[b] >> bit) & 1u) << (3 + b);
-          hl[bit] += v;
+          hl[bit << 8] += v;
         }
       }
       __syncthreads();
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         if (((vv[e] << 16) | lenpart) > tt[e]) {              // the high half of the rank key beats the strand's 32nd (see k_api.h: exact)
-          const int qs = base + e;
+          const int qs = cl_strand(base + e);
           if (mode == 2) a.cntx[(size_t)qs * a.xpitch + (c - a.C)] = (uint16_t)vv[e];
           else {
             const int slot = atomicAdd(&a.ncand[qs], 1);
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
     CLK(2)
   }
 #ifdef ITSX_CL_PROF
-  if (tid == 0 && mode == 1) { for (int i = 0; i < 4; i++) atomicAdd(&a.pre_stats[8 + i], (unsigned long long)tp[i]); atomicAdd(&a.pre_stats[12], (unsigned long long)tn); atomicAdd(&a.pre_stats[13], (unsigned long long)tadd); }
+  if (tid == 0 && mode == 1) { for (int i = 0; i < 4; i++) atomicAdd(&a.pre_stats[8 + i], (unsigned long long)tp[i]); atomicAdd(&a.pre_stats[12], (unsigned long long)tn); atomicAdd(&a.pre_stats[13], (unsigned long long)tadd); atomicAdd(&a.pre_stats[14], (unsigned long long)tp[4]); }
 #endif
 }
 
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(64) void k_cl_topk(ClusterArgs a, int final)
   if (lane < m) keys[lane] = top[lane];
   if (lane == 0) {
     a.ncand[qs] = m;
-    if (m == 32) { a.tkey[qs] = top[31]; a.tq[qs] = (uint32_t)(top[31] >> 32); }
+    if (m == 32) { a.tkey[qs] = top[31]; a.tq[cl_phys(qs)] = (uint32_t)(top[31] >> 32); }
     if (final) a.ntop[qs] = m;
   }
   if (final && lane < m) {

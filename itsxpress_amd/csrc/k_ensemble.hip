@@ -9,8 +9,8 @@
 //
 // Mapping.  Such regions are rare (0.4 % of all regions on the bench workload) and their 200 tracebacks are inherently
 // sequential -- one random stream, and the number of draws a trace consumes depends on its path -- so one LANE owns one
-// region: k_mr_fwd fills the region's Forward matrix (rows of M, D, I and the special states in a [row][vector][lane]
-// slab), k_mr_trace walks the 200 paths, accumulates the per-residue null2 odds, dedupes the sampled (i, j, k, m) tuples,
+// region: k_mr_fwd fills the region's Forward matrix (contiguous per region, node-major rows: see mrslab below),
+// k_mr_trace walks the 200 paths, accumulates the per-residue null2 odds, dedupes the sampled (i, j, k, m) tuples,
 // clusters them and writes the surviving envelopes.  Lanes of a wave work on different profiles, so the transition and
 // emission tables come through ordinary vector loads here (the wave-uniform scalar-operand pipeline of k_float.hip does
 // not apply); these kernels are latency-bound integer/float bookkeeping, not throughput kernels.
@@ -24,19 +24,14 @@ namespace itsx {
 enum { tBM = 0, tMM, tIM, tDM, tMD, tMI, tII, tDD };
 enum { ST_M = 1, ST_D, ST_I, ST_S, ST_N, ST_B, ST_E, ST_C, ST_T, ST_J };
 
-// a region's matrix is contiguous (rows of MRV float4): a path moves to the neighbouring node group or to the row before, so
-// consecutive steps of a traceback stay within a cache line or two (interleaved by lane, every float4 of a step was a line of its own)
-// Row layout since round 3 (node-major): vector k = node k's {M, D, I, the row's B} for k = 0 (no node: zeros) .. 4 Q, then the
-// row's specials {E N J B} and {E J C scale}.  A step of a traceback needs M, D, I of ONE node (and B of that row): one vector load
-// instead of four from the striped row, and one more for the node's transitions (DevProfile::tfn).  The kernel is bound by the
-// number of load instructions whose lanes all hit different lines (one line per lane and instruction), not by bytes or latency.
+// A region's matrix is contiguous (rows of MRV float4; interleaved by lane, every float4 of a step was a line of its own).  Row
+// layout (node-major): vector k = node k's {M, D, I, the row's B} for k = 0 (no node: zeros) .. 4 Q, then the row's specials
+// {E N J B} and {E J C scale}.  A step of a traceback needs M, D, I of ONE node and B of that row: one vector load instead of four
+// from a row striped like the DP's, and one more for the node's transitions (DevProfile::tfn).
 DEV f4 *mrslab(const MrArgs &a, int64_t r0, int row, int v, int lane) { (void)lane; return (f4 *)a.slab + ((r0 + row) * MRV + v); }
 constexpr int MR_SP = QMAX * 4 + 1, MR_CJ = QMAX * 4 + 2;
 static_assert(MR_CJ < MRV, "matrix row too short");
 DEV float comp4(const f4 &t, int r) { return r == 0 ? t.x : r == 1 ? t.y : r == 2 ? t.z : t.w; }
-// component r of the vector right-shifted by one lane ([0 a b c])
-DEV float comp4_rsh(const f4 &t, int r) { return r == 0 ? 0.0f : r == 1 ? t.x : r == 2 ? t.y : t.z; }
-DEV V4 tov4(const f4 &t) { V4 r; r.a = (f2){t.x, t.y}; r.b = (f2){t.z, t.w}; return r; }
 DEV f4 tof4(const V4 &v) { return (f4){v.a.x, v.a.y, v.b.x, v.b.y}; }
 
 struct MrLane {

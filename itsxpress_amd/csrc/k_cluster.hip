@@ -712,11 +712,13 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
   if (K > a.pre_k || Lq > PRE_LMAX || Lt > PRE_LMAX || Lq < 8 || Lt < 8) { if (lane == 0 && !have_lb) atomicAdd(&a.pre_stats[0], 1ULL); return have_lb ? 1 : -1; }   // no certificate: align (-1: and nothing was built in LDS)
   uint8_t *qm = lds;                                                        // the query's side first: it survives from one candidate to the next
   int32_t *head = reinterpret_cast<int32_t *>(qm + ((Lq + 3) & ~3));      // [256] chain heads of q's 8-mers (hashed)
-  int32_t *nextp = head + 256;                                              // [Lq]
-  uint16_t *qk = reinterpret_cast<uint16_t *>(nextp + Lq);                  // [Lq] 8-mer at each q position (0xFFFF: none)
+  // (16-bit chain links, votes and front levels: positions stay below 2 048, and 8 KB of LDS per wave instead of 13 lets five waves
+  // share a SIMD where three did -- the kernel waits on LDS round trips half of its time)
+  int16_t *nextp = reinterpret_cast<int16_t *>(head + 256);                 // [Lq]
+  uint16_t *qk = reinterpret_cast<uint16_t *>(nextp + ((Lq + 1) & ~1));     // [Lq] 8-mer at each q position (0xFFFF: none)
   uint8_t *tm = reinterpret_cast<uint8_t *>(qk + ((Lq + 1) & ~1));
-  int32_t *votes = reinterpret_cast<int32_t *>(tm + ((Lt + 3) & ~3));       // [Lq + Lt + 4]: diagonal votes, then a level of the front
-  int32_t *fr = votes + Lq + Lt + 4;                                        // [Lq + Lt + 4]: the other level
+  uint32_t *votes = reinterpret_cast<uint32_t *>(tm + ((Lt + 3) & ~3));     // [(Lq + Lt) / 2 + 2]: diagonal votes, two to a word; then a level of the front
+  int16_t *fr = reinterpret_cast<int16_t *>(votes + ((Lq + Lt) >> 1) + 2);  // [Lq + Lt + 4]: the other level
   __shared__ int s_hit;
   const uint32_t *wq = a.rd.words + a.rd.woff[rq];
   const uint32_t *wt = a.rd.words + a.rd.woff[rt];
@@ -728,7 +730,7 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
     for (int i = lane; i < 256; i += 64) head[i] = -1;
   }
   for (int o = lane; o < Lt; o += 64) tm[o] = (uint8_t)(1u << ((wt[o >> 4] >> ((o & 15) * 2)) & 3u));
-  for (int i = lane; i < Lq + Lt; i += 64) votes[i] = 0;
+  for (int i = lane; i < ((Lq + Lt) >> 1) + 1; i += 64) votes[i] = 0u;
   if (lane == 0) s_hit = 0;
   __syncthreads();
   if (!same_q) for (int e = lane; e < nexq; e += 64) { const uint32_t ex = a.rd.exc[eoq + e]; const int pos = (int)(ex >> 4); const uint32_t m = mask4(ex & 15u); qm[s ? Lq - 1 - pos : pos] = (uint8_t)(s ? revmask4(m) : m); }
@@ -747,18 +749,23 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
   if (!same_q) {
     for (int p = lane; p < Lq; p += 64) {
       uint32_t k;
-      if (kmer_at(qm, Lq, p, k)) { qk[p] = (uint16_t)k; nextp[p] = atomicExch(&head[(k * 40503u >> 8) & 255u], p); } else qk[p] = 0xFFFF;
+      if (kmer_at(qm, Lq, p, k)) { qk[p] = (uint16_t)k; nextp[p] = (int16_t)atomicExch(&head[(k * 40503u >> 8) & 255u], p); } else qk[p] = 0xFFFF;
     }
     __syncthreads();
   }
   for (int j = lane; j < Lt; j += 64) {
     uint32_t k;
     if (!kmer_at(tm, Lt, j, k)) continue;
-    for (int p = head[(k * 40503u >> 8) & 255u]; p >= 0; p = nextp[p]) if (qk[p] == (uint16_t)k) atomicAdd(&votes[p - j + Lt - 1], 1);
+    for (int p = head[(k * 40503u >> 8) & 255u]; p >= 0; p = nextp[p]) if (qk[p] == (uint16_t)k) { const int z = p - j + Lt - 1; atomicAdd(&votes[z >> 1], 1u << ((z & 1) * 16)); }
   }
   __syncthreads();
   int bv = -1, bd = 0;
-  for (int i = lane; i < Lq + Lt - 1; i += 64) if (votes[i] > bv) { bv = votes[i]; bd = i; }
+  for (int i = lane; 2 * i < Lq + Lt - 1; i += 64) {          // (a word's low half is the lower diagonal: ties go to the lowest index as before)
+    const uint32_t w = votes[i];
+    const int lo = (int)(w & 0xffffu), hi = (int)(w >> 16);
+    if (lo > bv) { bv = lo; bd = 2 * i; }
+    if (2 * i + 1 < Lq + Lt - 1 && hi > bv) { bv = hi; bd = 2 * i + 1; }
+  }
   for (int off = 32; off; off >>= 1) { const int ov = __shfl_xor(bv, off), od = __shfl_xor(bd, off); if (ov > bv || (ov == bv && od < bd)) { bv = ov; bd = od; } }
   const int d = bd - (Lt - 1);                              // q index i pairs with t index i - d
   // ---- LB: the ungapped alignment along that diagonal, its overhangs as terminal gaps
@@ -785,7 +792,7 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
   // The front no longer knows its start, so the span is measured from the most favourable start within K diagonals of the end
   // diagonal -- a path of <= K edits cannot have come from further away -- which gives away at most K symbols of Pmin.
   // Lanes own diagonals, levels are synchronous: (K + 1) (Lq + Lt + 1) independent extensions instead of one walk per start.
-  int32_t *P = votes + 1, *N = fr + 1;                       // [-1 .. nd]: a sentinel either side
+  int16_t *P = reinterpret_cast<int16_t *>(votes) + 1, *N = fr + 1;      // [-1 .. nd]: a sentinel either side
   const int nd = Lq + Lt + 1;
   auto span_ok = [&](int i, int j, int d) {
     int rows = i, cols = j;
@@ -817,7 +824,7 @@ __device__ int precheck_pair(const ClusterArgs &a, int qs, int col, uint8_t *lds
       N[z] = i;
       if ((i == Lq || j == Lt) && span_ok(i, j, d)) hit = true;
     }
-    int32_t *t_ = P; P = N; N = t_;
+    int16_t *t_ = P; P = N; N = t_;
   }
   const bool any_hit = __ballot(hit) != 0ull;
   if (lane == 0 && any_hit) s_hit = 1;
@@ -1400,7 +1407,7 @@ void launch_cl_init(const ClusterArgs &a, hipStream_t st) { hipLaunchKernelGGL(k
 static size_t precheck_lds(const ClusterArgs &a)
 {
   const size_t L = (size_t)std::min(a.scratch_pitch, PRE_LMAX + 1);      // masks, 8-mer index of the query, votes, two levels of the front
-  return 2 * (L + 4) + 1024 + 4 * L + 2 * (L + 2) + 2 * (8 * L + 16) + 64;
+  return 2 * (L + 4) + 1024 + 2 * (L + 2) + 2 * (L + 2) + 2 * (4 * L + 16) + 64;
 }
 static void launch_cl_score(const ClusterArgs &a, int which, int grid, int maxitems, int rows_per_lane, hipStream_t st)
 {

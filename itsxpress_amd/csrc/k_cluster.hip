@@ -326,13 +326,10 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nqs = 2 * a.nq;
   const int nrounds = nqs > 0 ? 8 : 0;                       // a thread scans histogram slots (j * 256 + tid) * 4 .. + 3 (cl_phys order: every round holds strands of every window size)
-  // count thresholds, four strands (one 8-byte load) at a time; they only change between launches.  The arrays are
+  // count thresholds, four strands (one 16-byte load) at a time; they only change between launches.  The arrays are
   // allocated for the largest window and the launcher sets every entry past the window's end to 0xFFFF (never reached),
   // so the scan needs no bound check.
   const uint4 *thr = reinterpret_cast<const uint4 *>(mode == 2 ? a.minm : a.tq);
-  uint4 T4[8];                                               // this thread's 32 thresholds, fixed for the launch
-#pragma unroll
-  for (int j = 0; j < 8; j++) T4[j] = j < nrounds ? thr[j * 256 + tid] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
   for (int i = tid; i < CL_QS_MAX + 8; i += 256) hist[i] = 0u;
   if (mode == 2) { const int lim = a.C + a.new_rank[a.nq]; c1 = c1 < lim ? c1 : lim; }
   const uint4 *ent = reinterpret_cast<const uint4 *>(a.qi_ent);
@@ -456,25 +453,36 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
     }
     const int32_t clen = a.cent_len[c], cpos = a.cent_pos[c];
     const uint32_t lenpart = (uint32_t)(65535 - clen) & 0xffffu;
-#pragma unroll 1
-    for (int j = 0; j < nrounds; j++) {                       // (rolled: the rare hit path below exists once; T4[j] is a uniform index)
-      const int base = (j * 256 + tid) * 4;
-      const uint4 t4 = T4[j];
-      const uint4 v = *reinterpret_cast<const uint4 *>(&hist[base]);
-      *reinterpret_cast<uint4 *>(&hist[base]) = make_uint4(0u, 0u, 0u, 0u);
-      const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-      const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+    // The thread's 32 thresholds come from global memory in every turn, eight loads issued together: kept in registers for the
+    // launch they do not fit beside the bitmap phase's 32 loads in flight, and from scratch memory -- where the compiler put them --
+    // the rolled scan paid eight DEPENDENT round trips per turn (13.6 k of its 15.7 k clock ticks).  Pass 1 only compares; the rare
+    // slot that beats its threshold is handled in pass 2, slot by slot; then the thread's slots are cleared.
+    if (nrounds) {
+      uint4 T4[8];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        if (((vv[e] << 16) | lenpart) > tt[e]) {              // the high half of the rank key beats the strand's 32nd (see k_api.h: exact)
-          const int qs = cl_strand(base + e);
-          if (mode == 2) a.cntx[(size_t)qs * a.xpitch + (c - a.C)] = (uint16_t)vv[e];
+      for (int j = 0; j < 8; j++) T4[j] = thr[j * 256 + tid];
+      uint32_t hm = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&hist[(j * 256 + tid) * 4]);
+        hm |= ((((v.x << 16) | lenpart) > T4[j].x ? 1u : 0u) | (((v.y << 16) | lenpart) > T4[j].y ? 2u : 0u) |
+               (((v.z << 16) | lenpart) > T4[j].z ? 4u : 0u) | (((v.w << 16) | lenpart) > T4[j].w ? 8u : 0u)) << (4 * j);
+      }
+      if (__ballot(hm != 0u) != 0ull) {
+        for (uint32_t m = hm; m; m &= m - 1u) {                // the high half of the rank key beats the strand's 32nd (see k_api.h: exact)
+          const int b = __ffs((int)m) - 1;
+          const int slot_h = ((b >> 2) * 256 + tid) * 4 + (b & 3);
+          const uint32_t cnt = hist[slot_h];
+          const int qs = cl_strand(slot_h);
+          if (mode == 2) a.cntx[(size_t)qs * a.xpitch + (c - a.C)] = (uint16_t)cnt;
           else {
             const int slot = atomicAdd(&a.ncand[qs], 1);
-            if (slot < a.ccap) a.cand[(size_t)qs * a.ccap + slot] = cand_key(vv[e], clen, cpos);
+            if (slot < a.ccap) a.cand[(size_t)qs * a.ccap + slot] = cand_key(cnt, clen, cpos);
           }
         }
       }
+#pragma unroll
+      for (int j = 0; j < 8; j++) *reinterpret_cast<uint4 *>(&hist[(j * 256 + tid) * 4]) = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
     CLK(2)

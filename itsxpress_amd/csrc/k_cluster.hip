@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
           uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
 #pragma unroll
           for (int b = 0; b < CL_HVL; b++) v |= ((hc[b] >> bit) & 1u) << (3 + b);
-          hl[bit << 8] += v;
+          atomicAdd(&hl[bit << 8], v);                         // (no value comes back: nothing to wait for; the slot is this lane's own)
         }
       }
       __syncthreads();

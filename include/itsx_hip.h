@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ITSX_ABI_VERSION 2      /* 2: itsx_stats grew (n_mr_fail_kind), itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
+#define ITSX_ABI_VERSION 3      /* 3: rows modes (itsx_set_rows_mode, the lazy domain stage), itsx_stats grew; 2: itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
 
 enum {
   ITSX_OK            =  0,
@@ -111,6 +111,13 @@ typedef struct {
   /* domain rows (80 B each) resident on the device after the last search: all of them (= n_domains plus segment padding), or, with
    * ITSX_COMPACT_ROWS=1, only the rows that can still win ItsPosition's argmax whatever the dataset-wide domZ turns out to be */
   int64_t n_rows_resident;
+  /* the lazy domain stage (itsx_set_rows_mode(ctx, ITSX_ROWS_LAZY)) of the last search: pairs that went through Backward / decoding /
+   * envelopes (of n_past_msv), of which round 1 took the best-bound pair of each (representative, class); rows whose reporting
+   * depended on the exact domZ and could have changed a result (then the search was repeated in full: n_lazy_reruns);
+   * lane-rows and launches of the score-only Forward pass, its time and the selection's */
+  int32_t lazy;              int32_t n_bound_launches;
+  int64_t n_lazy_evaluated, n_lazy_round1, n_lazy_pending, n_lazy_reruns, bound_rows;
+  float   ms_bound_kernel, ms_lazy_select;
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -228,8 +235,27 @@ int itsx_get_uniques(const itsx_ctx *ctx, int64_t *seed_read, int64_t *abundance
  * reported representatives (hmmsearch's domZ).  itsx_search_finalize applies the
  * domain threshold.  Between the two a multi-GPU driver all-reduces domZ. */
 int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3);
-int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ /* [n_samples][n_profiles] */);
-int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ /* [n_samples][n_profiles] */);
+/* What itsx_search keeps of hmmsearch's per-domain table (--domtblout, itsxpress/SeqSample.py:190-209).  The reference's only
+ * consumer, ItsPosition.parse/_score (SeqSample.py:400-461), keeps per target and side the first row with the strictly greatest
+ * %.1f score and drops the rest:
+ *   ITSX_ROWS_FULL     every row stays resident (itsx_get_domains / itsx_write_domtbl work): what _search needs with --keeptemp;
+ *   ITSX_ROWS_COMPACT  every pair is evaluated, only the rows that can still win that argmax once domZ is known are kept;
+ *   ITSX_ROWS_LAZY     pairs that cannot win it are not evaluated past their Forward score (csrc/k_lazy.hip: a rigorous bound of
+ *                      a pair's best domain score from its Forward score); coordinates are exactly those of the other modes.
+ * In the last two the row table / domtbl.txt are refused.  mode -1 (the default) reads the environment at every search:
+ * ITSX_ROWS=full|compact|lazy, or ITSX_COMPACT_ROWS=1.
+ * After a LAZY search hmmsearch's domZ is known by bounds only: itsx_get_domz / itsx_set_domz / itsx_domz_device move
+ * itsx_domz_count() = 2 x n_samples x n_profiles counters (lower bounds, then upper bounds; a multi-rank driver sums both).
+ * itsx_search_finalize decides every row both bounds decide alike.  itsx_lazy_pending() = rows left undecided that could change
+ * a coordinate: when nobody exchanged counters the context repeats the search with every pair evaluated by itself; a multi-rank
+ * driver (counters exchanged) takes the maximum over ranks and, if positive, repeats search + exchange + finalize in
+ * ITSX_ROWS_COMPACT on every rank (itsx_trim_coords refuses until then). */
+enum { ITSX_ROWS_FULL = 0, ITSX_ROWS_COMPACT = 1, ITSX_ROWS_LAZY = 2 };
+int itsx_set_rows_mode(itsx_ctx *ctx, int mode);
+int64_t itsx_lazy_pending(const itsx_ctx *ctx);
+int64_t itsx_domz_count(const itsx_ctx *ctx);
+int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ /* [itsx_domz_count]: [n_samples][n_profiles] (x 2 after a lazy search) */);
+int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ /* same */);
 int itsx_search_finalize(itsx_ctx *ctx, double domE);
 int64_t itsx_num_domains(const itsx_ctx *ctx);
 int itsx_get_domains(const itsx_ctx *ctx, itsx_domain *rows /* [itsx_num_domains] */);

@@ -63,6 +63,8 @@ struct LenTables {              // per target length L, built on the host with l
   double  lognn3;               // log((float)L/(float)(L+3))
   int     tjb;                  // MSV J->B / N->B cost byte
   int     vmove;                // Viterbi filter: wordify(logf(3 / (L + 3)))
+  float   lazy_c;               // lazy domain stage: C(L) + margin, bits (engine.hip: lazy_bound_c)
+  int     pad;
 };
 
 // a surviving (representative, profile) comparison

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <numeric>
@@ -34,6 +35,8 @@ void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npair
 void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, const int32_t *usample, int P, hipStream_t st);
 void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, unsigned long long *bl, unsigned long long *br,
                       int32_t *in_ddict, hipStream_t st);
+void launch_position_coords(const itsx_domain *dom, int64_t n, const int8_t *side, const unsigned long long *bl, const unsigned long long *br,
+                            int32_t *cl, int32_t *cr, hipStream_t st);
 void launch_position_flags(const itsx_domain *dom, int64_t n, const int8_t *side, const unsigned long long *bl, const unsigned long long *br,
                            int32_t *uflag, hipStream_t st);
 void launch_count_flags(const int32_t *uflag, int32_t U, const int32_t *uniq_of, int64_t n, unsigned long long *c, hipStream_t st);
@@ -70,16 +73,15 @@ __global__ void k_gather_i32(const int32_t *src, const int64_t *idx, int n, int3
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = src[idx[i]];
 }
-__global__ void k_rep_coords(int32_t U, const unsigned long long *bl, const unsigned long long *br, const int32_t *ind,
+__global__ void k_rep_coords(int32_t U, const unsigned long long *bl, const unsigned long long *br, const int32_t *cl, const int32_t *cr,
                              const int32_t *seed_read, const int32_t *len, int32_t *start, int32_t *stop, int32_t *tlen)
 {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= U) return;
   const unsigned long long l = bl[u], r = br[u];
-  start[u] = l ? (int32_t)(l & 0xffff) : -1;
-  stop[u] = r ? (int32_t)(r & 0xffff) - 1 : -1;
+  start[u] = l ? cl[u] : -1;                      // left.to_pos  (itsxpress/SeqSample.py:480)
+  stop[u] = r ? cr[u] - 1 : -1;                   // right.from_pos - 1  (:484)
   tlen[u] = (l || r) ? len[seed_read[u]] : -1;
-  (void)ind;
 }
 __global__ void k_read_coords(int64_t n, const int32_t *uniq_of, const int32_t *us, const int32_t *ue, const int32_t *ut, const int32_t *uind,
                               int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
@@ -235,6 +237,15 @@ struct itsx_ctx {
   bool compact_rows = false; double compact_zmax = 1e9, compact_dome_min = 1e-2, compact_lnp = 0; int compact_ncls = 0;
   DBuf<itsx_domain> w_domscratch; DBuf<int8_t> w_cls; DBuf<unsigned long long> w_bestc; DBuf<int32_t> w_keep, w_keeppos, w_keeptmp;
   int64_t rows_before_compaction = 0;
+  // rows mode (itsx_set_rows_mode / ITSX_ROWS): 0 every domain row stays resident (domtbl.txt), 1 compact, 2 lazy (k_lazy.hip)
+  int rows_mode = -1;                    // -1: from the environment at every search
+  bool lazy = false;                     // this search runs the lazy domain stage
+  bool domz_exchanged = false;           // the caller moved domZ between search and finalize (a multi-rank driver): finalize never re-runs on its own
+  int64_t lazy_pending = 0;              // undecided rows that could change a result, after the last lazy finalize
+  double sF1 = 1e-6, sF3 = 1e-6;         // the last search's thresholds (finalize may have to repeat it in full)
+  std::vector<int64_t> domz_ub;          // [S][P] pairs past the MSV filter: an upper bound of hmmsearch's domZ
+  DBuf<float> l_fb; DBuf<uint32_t> l_b10; DBuf<uint8_t> l_done; DBuf<int32_t> l_flag, l_pos, l_scan, l_has; DBuf<unsigned long long> l_gtop, l_sure;
+  DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub;
   DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
   std::vector<int32_t> h_sorted_active;  // the length-sorted list the HMM stages walk (= h_sorted_uniq unless itsx_set_active_uniques narrowed it)
   DBuf<LenTables> d_lt;
@@ -251,6 +262,7 @@ struct itsx_ctx {
   DBuf<WaveDesc> w_waves, w_rw; DBuf<RegionRec> w_raw; DBuf<float> w_slab, w_eslab;
   DBuf<int32_t> w_mrcnt, w_mroff, w_mrlen, w_mrloff, w_mrrows, w_mrulist, w_mrulist2, w_mru; DBuf<int64_t> w_mrrowoff; DBuf<MrRec> w_mr; DBuf<MrOut> w_mrout; DBuf<int64_t> w_n2off; DBuf<float> w_n2sc, w_mrslab;
   DBuf<uint8_t> w_mrscratch; DBuf<WaveDesc> w_mrwaves;
+  DBuf<int32_t> w_cl, w_cr;
   DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri, w_uflag;
 };
 
@@ -1270,8 +1282,19 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.ms_vit_kernel = 0; for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] = 0; S.n_rows_resident = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
-  ctx->compact_rows = getenv("ITSX_COMPACT_ROWS") && atoi(getenv("ITSX_COMPACT_ROWS")) != 0;
-  ctx->rows_before_compaction = 0;
+  // rows mode: what the caller selected (itsx_set_rows_mode), else the environment (ITSX_ROWS=full|compact|lazy; ITSX_COMPACT_ROWS=1)
+  int mode = ctx->rows_mode;
+  if (mode < 0) {
+    mode = ITSX_ROWS_FULL;
+    if (getenv("ITSX_COMPACT_ROWS") && atoi(getenv("ITSX_COMPACT_ROWS")) != 0) mode = ITSX_ROWS_COMPACT;
+    if (const char *e = getenv("ITSX_ROWS")) mode = !strcmp(e, "lazy") ? ITSX_ROWS_LAZY : !strcmp(e, "compact") ? ITSX_ROWS_COMPACT : ITSX_ROWS_FULL;
+  }
+  if (mode == ITSX_ROWS_LAZY && getenv("ITSX_KEEP_TRACE")) mode = ITSX_ROWS_COMPACT;      // pair traces describe the full pipeline
+  ctx->compact_rows = mode != ITSX_ROWS_FULL;
+  ctx->lazy = mode == ITSX_ROWS_LAZY;
+  ctx->lazy_pending = 0; ctx->domz_exchanged = false; ctx->sF1 = F1; ctx->sF3 = F3;
+  ctx->domz_ub.assign((size_t)P * ctx->S, 0);
+  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
   if (ctx->compact_rows && U > 0) {
     ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
     if (const char *e = getenv("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
@@ -1310,6 +1333,11 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     t.lognn3 = log((double)((float)L / (float)(L + 3)));
     t.tjb = host_tjb_b(L);
     tjb[L] = t.tjb;
+    {   // lazy domain stage (k_lazy.hip): bits <= (fwdsc - nullsc) / ln 2 + C(L); + 0.02 bits for float rounding, rounded up to float
+      const double n = (double)L;
+      const double c = 1.0 + (2.0 * log(2.0 * (n + 3.0) / (3.0 * (n + 2.0))) + n * log((n + 3.0) / (n + 2.0))) / 0.69314718055994529;
+      t.lazy_c = nextafterf((float)(c + 0.02), 1e30f);
+    }
     { const float w = roundf((float)(500.0 / 0.69314718055994529) * logf((2.0f + 1.0f) / ((float)L + 2.0f + 1.0f)));
       t.vmove = (w >= 32767.0f) ? 32767 : (w <= -32768.0f) ? -32768 : (int)w; }
   }
@@ -1350,7 +1378,9 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::max(1.0, (double)fr / (double)(1ull << 30) / 4.0);
     ctx->pair_budget = (int64_t)(gb * (double)(1ull << 30) / 400.0);
   }
-  int64_t Uc = std::max<int64_t>(1, ctx->pair_budget / std::max(P, 1));
+  // (the lazy stage keeps ~40 B per pair -- the record, its Forward score, its bound, the selection scan -- and the 400 B only for
+  // the pairs it evaluates: chunks can be several times larger)
+  int64_t Uc = std::max<int64_t>(1, (ctx->lazy ? ctx->pair_budget * 5 : ctx->pair_budget) / std::max(P, 1));
   Uc = std::min<int64_t>(Uc, ((1ll << 31) - 4096) / std::max(Ppad, 1));
   if (const char *e = getenv("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
   ctx->keep_trace = getenv("ITSX_KEEP_TRACE") != nullptr;
@@ -1386,88 +1416,58 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   return ITSX_OK;
 }
 
-// one chunk [u0, u0+U) of the length-sorted unique list through every stage up to per-sequence reporting
-static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, double T, double F1, double F3)
+// a work list of (representative, profile) pairs grouped by profile: 64-aligned segments, ascending length inside a segment
+struct PairList {
+  PairRec *pairs = nullptr; PairOut *pout = nullptr;
+  int64_t NP = 0;
+  std::vector<int64_t> seg_start;        // [P + 1]
+  std::vector<int32_t> total;            // [P] pairs of each profile
+  const int64_t *d_seg_start = nullptr;  // seg_start on the device
+};
+
+// wave descriptors of a pair list (fast Q == 12 waves first, then the runtime-Q ones) and each wave's longest target + 1
+static int build_waves(itsx_ctx *ctx, const PairList &pl, std::vector<WaveDesc> &waves, std::vector<char> &wgeneric, std::vector<int32_t> &rows)
 {
   hipStream_t st = ctx->st;
-  const int P = ctx->P, G = ctx->G, Ppad = G * 64;
-  itsx_stats &S = ctx->stats;
-  const int32_t *d_sorted = ctx->d_sorted_uniq.p + u0;     // PairRec::useq is relative to the chunk
-  DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
-  while ((int)ctx->dom_bufs.size() <= ci) ctx->dom_bufs.emplace_back(new DBuf<itsx_domain>());
-  DBuf<itsx_domain> &d_dom = ctx->compact_rows ? ctx->w_domscratch : *ctx->dom_bufs[ci];
-  ctx->dom_n.push_back(0);
-  ctx->trace_u0 = u0;
-  // ---- MSV for every (unique, profile)
-  DBuf<uint16_t> &d_res = ctx->w_res;
-  HIPCHK(d_res.alloc((size_t)Ppad * std::max<int64_t>(U, ctx->next_u0 >= 0 ? ctx->next_U : 0)));
-  auto msv_for = [&](int64_t cu0, int32_t cU, hipStream_t s, int lds_pad = 0) {
-    MsvArgs a{};
-    a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p + cu0; a.seed_read = ctx->d_seed_read.p; a.U = cU; a.G = G;
-    a.etab = ctx->d_etab.p; a.pbias = ctx->d_pbias.p; a.ptec = ctx->d_ptec.p; a.ptbm = ctx->d_ptbm.p;
-    a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = d_res.p;
-    a.P = P;
-    // blocks of 256 sequences x PB profiles: a few thousand blocks at least, and up to 32 profiles per block so that a
-    // large job re-reads its sequences' packed words (from L2) 32 times less often than it has profiles
-    const int64_t tiles = ((int64_t)cU + 255) / 256;
-    a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * P / 4096));
-    launch_msv(a, s, lds_pad);
-  };
-  if (ctx->msv_pre_u0 == (int64_t)u0) {
-    // launched on st2 while the chunk before this one was in its domain stage
-    HIPCHK(hipStreamWaitEvent(st, ctx->ev_msv1, 0));
-    HIPCHK(hipEventSynchronize(ctx->ev_msv1));
-    float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev_msv0, ctx->ev_msv1);
-    S.ms_msv_kernel += ms;                       // its stretched wall time beside other kernels: not extra step time
-    S.msv_launches += 1;
-    ctx->msv_pre_u0 = -1;
-  } else {
-    StageTimer tm(st);
-    msv_for(u0, U, st);
-    const float ms = tm.stop();
-    S.ms_msv_kernel += ms; S.ms_msv += ms;
-    S.msv_launches += 1;
-  }
-  StageTimer tm_list(st);
-  // ---- survivor list grouped by profile (64-aligned segments, ascending length)
-  const int nchunks = (U + CHUNK - 1) / CHUNK;
-  DBuf<int32_t> &d_cnt = ctx->w_cnt, &d_total = ctx->w_total;
-  HIPCHK(d_cnt.alloc((size_t)P * nchunks)); HIPCHK(d_total.alloc((size_t)P));
-  launch_pair_count(d_res.p, P, U, nchunks, d_cnt.p, st);
-  launch_chunk_scan(d_cnt.p, P, nchunks, d_total.p, st);
-  std::vector<int32_t> total((size_t)P);
-  HIPCHK(hipMemcpyAsync(total.data(), d_total.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  std::vector<int64_t> seg_start((size_t)P + 1, 0);
-  for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; S.n_past_msv += total[p]; }
-  const int64_t NP = seg_start[P];
-  ctx->npairs_padded = NP;
-  if (NP == 0) { S.ms_msv += tm_list.stop(); return ITSX_OK; }
-  if (NP >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 surviving (representative, profile) pairs");
-  DBuf<int64_t> &d_seg_start = ctx->w_seg_start;
-  HIPCHK(upload(d_seg_start, seg_start, st));
-  HIPCHK(ctx->d_pairs.alloc((size_t)NP)); HIPCHK(ctx->d_pout.alloc((size_t)NP));
-  HIPCHK(hipMemsetAsync(ctx->d_pairs.p, 0xFF, (size_t)NP * sizeof(PairRec), st));
-  HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)NP * sizeof(PairOut), st));
-  launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p + u0, ctx->d_pairs.p, st);
-  // ---- wave descriptors
-  std::vector<WaveDesc> waves;
-  std::vector<char> wgeneric;
+  const int P = ctx->P;
+  waves.clear(); wgeneric.clear();
   for (int pass = 0; pass < 2; pass++)           // fast (Q == 12) waves first, then runtime-Q waves
     for (int p = 0; p < P; p++) {
       if ((int)ctx->generic_q[p] != pass) continue;
-      for (int64_t k = 0; k < total[p]; k += 64) {
-        WaveDesc w{}; w.prof = p; w.first = seg_start[p] + k; w.count = (int32_t)std::min<int64_t>(64, total[p] - k);
+      for (int64_t k = 0; k < pl.total[(size_t)p]; k += 64) {
+        WaveDesc w{}; w.prof = p; w.first = pl.seg_start[(size_t)p] + k; w.count = (int32_t)std::min<int64_t>(64, pl.total[(size_t)p] - k);
         waves.push_back(w); wgeneric.push_back((char)pass);
       }
     }
   const int NW = (int)waves.size();
   DBuf<WaveDesc> &d_waves = ctx->w_waves; DBuf<int32_t> &d_rows = ctx->w_rows;
-  HIPCHK(upload(d_waves, waves, st)); HIPCHK(d_rows.alloc((size_t)NW));
-  hipLaunchKernelGGL(k_wave_rows_pairs, dim3((NW + 255) / 256), dim3(256), 0, st, d_waves.p, NW, ctx->d_pairs.p, d_rows.p);
-  std::vector<int32_t> rows((size_t)NW);
+  HIPCHK(upload(d_waves, waves, st)); HIPCHK(d_rows.alloc((size_t)std::max(NW, 1)));
+  rows.assign((size_t)NW, 0);
+  if (NW == 0) return ITSX_OK;
+  hipLaunchKernelGGL(k_wave_rows_pairs, dim3((NW + 255) / 256), dim3(256), 0, st, d_waves.p, NW, pl.pairs, d_rows.p);
   HIPCHK(hipMemcpyAsync(rows.data(), d_rows.p, (size_t)NW * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  return ITSX_OK;
+}
+
+// every stage after the survivor list, for the pairs of `pl`: bias filter + Forward, Backward + decoding + regions, the ensemble
+// stage, envelope re-scoring, scores and domZ counts, domain rows (compacted when the context keeps only what can still win)
+static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorted, double T, double F1, double F3, const std::function<int()> *next_msv)
+{
+  hipStream_t st = ctx->st;
+  const int P = ctx->P;
+  itsx_stats &S = ctx->stats;
+  const int64_t NP = pl.NP;
+  const size_t di = ctx->dom_n.size();           // this call's segment of domain rows
+  ctx->dom_n.push_back(0);
+  while (ctx->dom_bufs.size() <= di) ctx->dom_bufs.emplace_back(new DBuf<itsx_domain>());
+  DBuf<itsx_domain> &d_dom = ctx->compact_rows ? ctx->w_domscratch : *ctx->dom_bufs[di];
+  if (NP == 0) return ITSX_OK;
+  StageTimer tm_list(st);
+  std::vector<WaveDesc> waves; std::vector<char> wgeneric; std::vector<int32_t> rows;
+  { const int rc = build_waves(ctx, pl, waves, wgeneric, rows); if (rc != ITSX_OK) return rc; }
+  const int NW = (int)waves.size();
+  DBuf<WaveDesc> &d_waves = ctx->w_waves;
   S.ms_msv += tm_list.stop();
 
   // ---- batches of waves sized to the slab budget
@@ -1531,13 +1531,13 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     HIPCHK(hipMemcpyAsync(d_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
     FloatArgs a{};
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
-    a.flogsum = ctx->d_flogsum.p; a.logtab = ctx->d_logtab.p; a.pairs = ctx->d_pairs.p; a.pout = ctx->d_pout.p; a.waves = d_waves.p; a.slab = d_slab.p;
+    a.flogsum = ctx->d_flogsum.p; a.logtab = ctx->d_logtab.p; a.pairs = pl.pairs; a.pout = pl.pout; a.waves = d_waves.p; a.slab = d_slab.p;
     a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
     VitArgs va{};
     if (ctx->have_vit) {
       HIPCHK(ctx->d_vit.alloc((size_t)NP));
       va.rd = ctx->rd; va.sorted_uniq = d_sorted; va.seed_read = ctx->d_seed_read.p; va.prof = ctx->d_prof.p; va.lt = ctx->d_lt.p;
-      va.pairs = ctx->d_pairs.p; va.pout = ctx->d_pout.p; va.waves = d_waves.p; va.vtab = ctx->d_vtab.p; va.vit = ctx->d_vit.p; va.F2 = ctx->F2;
+      va.pairs = pl.pairs; va.pout = pl.pout; va.waves = d_waves.p; va.vtab = ctx->d_vtab.p; va.vit = ctx->d_vit.p; va.F2 = ctx->F2;
       va.eloop = (int32_t)roundf((float)(500.0 / 0.69314718055994529) * logf(0.5f));
       a.vit = ctx->d_vit.p;
     }
@@ -1560,7 +1560,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
         int e = w + 1;
         while (e < bt.w1 && waves[(size_t)e].first == waves[(size_t)e - 1].first + 64) e++;
         FloatArgs ab = a;
-        ab.pairs = ctx->d_pairs.p + waves[(size_t)w].first; ab.pout = ctx->d_pout.p + waves[(size_t)w].first;
+        ab.pairs = pl.pairs + waves[(size_t)w].first; ab.pout = pl.pout + waves[(size_t)w].first;
         const size_t t = lz.begin(&S.ms_bias_kernel); launch_bias(ab, (int64_t)(e - w) * 64, s); lz.end(t);
         w = e;
       }
@@ -1589,23 +1589,9 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     lazy.collect();
     S.ms_filters += tm.stop();
   }
-  {
-    // ---- the next chunk's MSV filter, on the second stream: the kernels of the domain stage below wait on memory most of the
-    // time (tracebacks, envelope slabs, hashing), the MSV kernel is pure VALU work at 75 registers -- the two share the SIMDs.
-    // Its result buffer is free: this chunk's survivor list was built from it before the DP batches.
-    static const bool msv_overlap = !(getenv("ITSX_MSV_OVERLAP") && atoi(getenv("ITSX_MSV_OVERLAP")) == 0);
-    if (msv_overlap && ctx->next_u0 >= 0 && ctx->st2 && !ctx->keep_trace) {
-      if (!ctx->ev_msv0) {
-        HIPCHK(hipEventCreate(&ctx->ev_msv0)); HIPCHK(hipEventCreate(&ctx->ev_msv1));
-        HIPCHK(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
-      }
-      HIPCHK(hipEventRecord(ctx->ev_c, st)); HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->ev_c, 0));
-      HIPCHK(hipEventRecord(ctx->ev_msv0, ctx->st2));
-      msv_for(ctx->next_u0, ctx->next_U, ctx->st2, getenv("ITSX_MSV_PAD") ? atoi(getenv("ITSX_MSV_PAD")) : 40000);
-      HIPCHK(hipEventRecord(ctx->ev_msv1, ctx->st2));
-      ctx->msv_pre_u0 = ctx->next_u0;
-    }
-  }
+  // ---- the next chunk's MSV filter, on the second stream: the kernels of the domain stage below wait on memory most of the
+  // time (tracebacks, envelope slabs, hashing), the MSV kernel is pure VALU work at 75 registers -- the two share the SIMDs
+  if (next_msv) { const int rc = (*next_msv)(); if (rc != ITSX_OK) return rc; }
   StageTimer tm_dom(st);
   // ---- multidomain regions: resolved into envelopes by stochastic traceback clustering (k_ensemble.hip)
   int64_t NMR = 0;
@@ -1613,7 +1599,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   if (ensemble) {
     DBuf<int32_t> &mrcnt = ctx->w_mrcnt, &mroff = ctx->w_mroff, &stmp = ctx->w_scan2;
     HIPCHK(mrcnt.alloc((size_t)NP + 2)); HIPCHK(mroff.alloc((size_t)NP + 2)); HIPCHK(stmp.alloc((size_t)scan_tmp_elems(NP + 2)));
-    launch_mr_count(ctx->d_pout.p, d_raw.p, NP, mrcnt.p, st);
+    launch_mr_count(pl.pout, d_raw.p, NP, mrcnt.p, st);
     launch_exclusive_scan(mrcnt.p, mroff.p, NP + 1, stmp.p, st);
     int32_t tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, mroff.p + NP, 4, hipMemcpyDeviceToHost, st));
@@ -1623,7 +1609,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       StageTimer tm_e(st);
       static_assert(sizeof(MrRec) == sizeof(RegionRec), "MrRec is handed to the region memoisation kernels as a RegionRec");
       HIPCHK(ctx->w_mr.alloc((size_t)NMR));
-      launch_mr_fill(ctx->d_pout.p, d_raw.p, NP, mroff.p, ctx->w_mr.p, st);
+      launch_mr_fill(pl.pout, d_raw.p, NP, mroff.p, ctx->w_mr.p, st);
       // ---- memoisation: distinct (profile, target length, residues) regions
       DBuf<unsigned long long> &rkeys = ctx->w_keys; DBuf<int32_t> &rvals = ctx->w_vals; DBuf<uint32_t> &rslot = ctx->w_slot_of;
       DBuf<int32_t> &rrep = ctx->w_rrep, &ruq = ctx->w_ruq, &rurank = ctx->w_rurank, &rscan = ctx->w_scan_tmp;
@@ -1634,8 +1620,8 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       HIPCHK(hipMemsetAsync(rvals.p, 0x7f, tsize * sizeof(int32_t), st));
       HIPCHK(hipMemsetAsync(ruq.p, 0, ((size_t)NMR + 1) * sizeof(int32_t), st));
       const RegionRec *mr_as_regions = (const RegionRec *)ctx->w_mr.p;
-      launch_region_keys(ctx->rd, mr_as_regions, NMR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
-      launch_region_resolve(ctx->rd, mr_as_regions, NMR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
+      launch_region_keys(ctx->rd, mr_as_regions, NMR, pl.pairs, d_sorted, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
+      launch_region_resolve(ctx->rd, mr_as_regions, NMR, pl.pairs, d_sorted, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
       launch_exclusive_scan(ruq.p, rurank.p, NMR + 1, rscan.p, st);
       int32_t NU = 0;
       HIPCHK(hipMemcpyAsync(&NU, rurank.p + NMR, 4, hipMemcpyDeviceToHost, st));
@@ -1700,7 +1686,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
           continue;
         }
         MrArgs ma{};
-        ma.rd = ctx->rd; ma.sorted_uniq = d_sorted; ma.seed_read = ctx->d_seed_read.p; ma.prof = ctx->d_prof.p; ma.pairs = ctx->d_pairs.p;
+        ma.rd = ctx->rd; ma.sorted_uniq = d_sorted; ma.seed_read = ctx->d_seed_read.p; ma.prof = ctx->d_prof.p; ma.pairs = pl.pairs;
         ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = wfirst[(size_t)w0]; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
         ma.rowoff = ctx->w_mrrowoff.p; ma.rowoff0 = row0;
         ma.n2off = ctx->w_n2off.p; ma.n2sc = ctx->w_n2sc.p; ma.out = ctx->w_mrout.p; ma.scratch = ctx->w_mrscratch.p;
@@ -1719,7 +1705,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       DBuf<int64_t> &d_c = ctx->w_counters;
       HIPCHK(d_c.alloc(16));
       HIPCHK(hipMemsetAsync(d_c.p, 0, 16 * sizeof(int64_t), st));
-      launch_mr_apply(ctx->d_pout.p, d_raw.p, NP, mroff.p, mru.p, ctx->w_mrout.p, (unsigned long long *)d_c.p, st);
+      launch_mr_apply(pl.pout, d_raw.p, NP, mroff.p, mru.p, ctx->w_mrout.p, (unsigned long long *)d_c.p, st);
       int64_t hc[10] = {0};
       HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
       S.ms_ensemble += tm_e.stop();
@@ -1732,12 +1718,12 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   DBuf<int32_t> &d_rcnt = ctx->w_rcnt, &d_rpref = ctx->w_rpref, &d_scan_tmp = ctx->w_scan2;
   HIPCHK(d_rcnt.alloc((size_t)NP + 1)); HIPCHK(d_rpref.alloc((size_t)NP + 1)); HIPCHK(d_scan_tmp.alloc((size_t)scan_tmp_elems(NP + 1)));
   HIPCHK(hipMemsetAsync(d_rcnt.p, 0, ((size_t)NP + 1) * 4, st));
-  launch_region_counts(ctx->d_pout.p, NP, d_rcnt.p, st);
+  launch_region_counts(pl.pout, NP, d_rcnt.p, st);
   launch_exclusive_scan(d_rcnt.p, d_rpref.p, NP + 1, d_scan_tmp.p, st);
   std::vector<int32_t> bound((size_t)P + 1);
   {
     DBuf<int64_t> &d_idx = ctx->w_idx; DBuf<int32_t> &d_b = ctx->w_b;
-    HIPCHK(upload(d_idx, seg_start, st)); HIPCHK(d_b.alloc((size_t)P + 1));
+    HIPCHK(upload(d_idx, pl.seg_start, st)); HIPCHK(d_b.alloc((size_t)P + 1));
     hipLaunchKernelGGL(k_gather_i32, dim3((P + 1 + 255) / 256), dim3(256), 0, st, d_rpref.p, d_idx.p, P + 1, d_b.p);
     HIPCHK(hipMemcpyAsync(bound.data(), d_b.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1746,7 +1732,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   std::vector<int32_t> rtotal((size_t)P);
   for (int p = 0; p < P; p++) { rtotal[p] = bound[p + 1] - bound[p]; rseg[p + 1] = rseg[p] + ((int64_t)rtotal[p] + 63) / 64 * 64; S.n_domains += rtotal[p]; }
   const int64_t NR = rseg[P];
-  ctx->dom_n[ci] = NR;
+  ctx->dom_n[di] = NR;
   HIPCHK(ctx->d_pair_region0.alloc((size_t)NP));
   HIPCHK(ctx->d_regions.alloc((size_t)std::max<int64_t>(NR, 1)));
   HIPCHK(d_dom.alloc((size_t)std::max<int64_t>(NR, 1)));
@@ -1754,9 +1740,9 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   if (NR > 0) {
     DBuf<int64_t> &d_rseg = ctx->w_rseg;
     HIPCHK(upload(d_rseg, rseg, st));
-    launch_region_offsets(NP, ctx->d_pairs.p, d_rpref.p, d_seg_start.p, d_rseg.p, ctx->d_pair_region0.p, st);
+    launch_region_offsets(NP, pl.pairs, d_rpref.p, pl.d_seg_start, d_rseg.p, ctx->d_pair_region0.p, st);
     HIPCHK(hipMemsetAsync(ctx->d_regions.p, 0xFF, (size_t)NR * sizeof(RegionRec), st));     // padding slots: pair = -1
-    launch_region_fill(ctx->d_pout.p, d_raw.p, NP, ctx->d_pair_region0.p, ctx->d_regions.p, st);
+    launch_region_fill(pl.pout, d_raw.p, NP, ctx->d_pair_region0.p, ctx->d_regions.p, st);
     // ---- envelope memoisation: only distinct (profile, L, residues) envelopes are re-scored
     DBuf<unsigned long long> &rkeys = ctx->w_keys; DBuf<int32_t> &rvals = ctx->w_vals; DBuf<uint32_t> &rslot = ctx->w_slot_of;
     DBuf<int32_t> &rrep = ctx->w_rrep, &ruq = ctx->w_ruq, &rurank = ctx->w_rurank, &rscan = ctx->w_scan_tmp;
@@ -1767,8 +1753,8 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     HIPCHK(hipMemsetAsync(rkeys.p, 0, tsize * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(rvals.p, 0x7f, tsize * sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(ruq.p, 0, ((size_t)NR + 1) * sizeof(int32_t), st));
-    launch_region_keys(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
-    launch_region_resolve(ctx->rd, ctx->d_regions.p, NR, ctx->d_pairs.p, d_sorted, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
+    launch_region_keys(ctx->rd, ctx->d_regions.p, NR, pl.pairs, d_sorted, ctx->d_seed_read.p, rkeys.p, rvals.p, tsize - 1, rslot.p, st);
+    launch_region_resolve(ctx->rd, ctx->d_regions.p, NR, pl.pairs, d_sorted, ctx->d_seed_read.p, rvals.p, rslot.p, rrep.p, ruq.p, st);
     launch_exclusive_scan(ruq.p, rurank.p, NR + 1, rscan.p, st);
     std::vector<int32_t> ub((size_t)P + 1);
     {
@@ -1786,7 +1772,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     HIPCHK(upload(d_useg, useg, st));
     HIPCHK(ctx->d_ulist.alloc((size_t)std::max<int64_t>(NU, 1))); HIPCHK(ctx->d_rout.alloc((size_t)std::max<int64_t>(NU, 1)));
     HIPCHK(hipMemsetAsync(ctx->d_rout.p, 0, (size_t)std::max<int64_t>(NU, 1) * sizeof(RegionOut), st));
-    launch_region_upos(NR, ctx->d_regions.p, ctx->d_pairs.p, ruq.p, rurank.p, d_rseg.p, d_useg.p, ctx->d_upos.p, ctx->d_ulist.p, st);
+    launch_region_upos(NR, ctx->d_regions.p, pl.pairs, ruq.p, rurank.p, d_rseg.p, d_useg.p, ctx->d_upos.p, ctx->d_ulist.p, st);
     launch_region_upos_follow(NR, rrep.p, ruq.p, ctx->d_upos.p, st);
     std::vector<WaveDesc> rw; std::vector<char> rgen;
     for (int pass = 0; pass < 2; pass++)
@@ -1831,14 +1817,14 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       HIPCHK(hipMemcpyAsync(d_rw.p + w0, rw.data() + w0, (size_t)(w1 - w0) * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
       EnvArgs a{};
       a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
-      a.pairs = ctx->d_pairs.p; a.regions = ctx->d_ulist.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
+      a.pairs = pl.pairs; a.regions = ctx->d_ulist.p; a.rout = ctx->d_rout.p; a.waves = d_rw.p; a.slab = d_eslab.p;
       { const size_t t = elazy.begin(&S.ms_env_kernel); launch_envelopes(a, w1 - w0, w0, rgen[w0], st); elazy.end(t); }
       for (int w = w0; w < w1; w++) S.env_rows += (int64_t)(rrows[w] - 1) * rw[w].count;
       w0 = w1;
     }
     ScoreArgs sa{};
     sa.rd = ctx->rd; sa.sorted_uniq = d_sorted; sa.seed_read = ctx->d_seed_read.p; sa.prof = ctx->d_prof.p; sa.lt = ctx->d_lt.p;
-    sa.flogsum = ctx->d_flogsum.p; sa.pairs = ctx->d_pairs.p; sa.pout = ctx->d_pout.p; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
+    sa.flogsum = ctx->d_flogsum.p; sa.pairs = pl.pairs; sa.pout = pl.pout; sa.regions = ctx->d_regions.p; sa.rout = ctx->d_rout.p;
     sa.pair_region0 = ctx->d_pair_region0.p; sa.upos = ctx->d_upos.p; sa.dom = d_dom.p; sa.npairs = NP; sa.T = T;
     if (NMR > 0) { sa.mr = ctx->w_mr.p; sa.mr_u = ctx->w_mru.p; sa.mrout = ctx->w_mrout.p; sa.n2off = ctx->w_n2off.p; sa.n2sc = ctx->w_n2sc.p; sa.mr_off = ctx->w_mroff.p; }
     sa.domz = ctx->d_domz32.p; sa.usample = ctx->dev_usample(); sa.P = ctx->P;
@@ -1852,11 +1838,11 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       int32_t kept = 0;
       HIPCHK(hipMemcpyAsync(&kept, ctx->w_keeppos.p + NR, sizeof(kept), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      DBuf<itsx_domain> &small = *ctx->dom_bufs[ci];
+      DBuf<itsx_domain> &small = *ctx->dom_bufs[di];
       HIPCHK(small.alloc((size_t)std::max<int32_t>(kept, 1), true));
       launch_compact_scatter(d_dom.p, NR, ctx->w_keep.p, ctx->w_keeppos.p, small.p, st);
       ctx->rows_before_compaction += NR;
-      ctx->dom_n[ci] = kept;
+      ctx->dom_n[di] = kept;
     }
   }
   S.ms_domains += tm_dom.stop();
@@ -1865,30 +1851,214 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     DBuf<int64_t> &d_c = ctx->w_counters;
     HIPCHK(d_c.alloc(8));
     HIPCHK(hipMemsetAsync(d_c.p, 0, 8 * sizeof(int64_t), st));
-    hipLaunchKernelGGL(k_pair_counters, dim3((unsigned)std::min<int64_t>(4096, (NP + 255) / 256)), dim3(256), 0, st, ctx->d_pout.p, NP, (unsigned long long *)d_c.p);
+    hipLaunchKernelGGL(k_pair_counters, dim3((unsigned)std::min<int64_t>(4096, (NP + 255) / 256)), dim3(256), 0, st, pl.pout, NP, (unsigned long long *)d_c.p);
     int64_t hc[8];
     HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     S.n_past_bias += hc[0]; S.n_past_fwd += hc[1]; S.n_regions += hc[2]; S.n_domain_overflow += hc[3]; S.n_multidomain += hc[4];
   }
   HIPCHK(hipGetLastError());                                // a kernel of this chunk that failed to launch must not pass silently
+  return ITSX_OK;
+}
+
+
+// The lazy domain stage (k_lazy.hip): Forward scores for every pair of the chunk, then two rounds of the domain pipeline over
+// the pairs that can still win ItsPosition's argmax.
+static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorted, int32_t Uc, double T, double F1, double F3, const std::function<int()> *next_msv)
+{
+  hipStream_t st = ctx->st;
+  const int P = ctx->P, ncls = ctx->compact_ncls;
+  itsx_stats &S = ctx->stats;
+  const int64_t NP = pl.NP;
+  // ---- pass A: the Forward score of every pair (nothing else is kept)
+  HIPCHK(ctx->l_fb.alloc((size_t)NP + 1)); HIPCHK(ctx->l_b10.alloc((size_t)NP + 1)); HIPCHK(ctx->l_done.alloc((size_t)NP + 1));
+  HIPCHK(ctx->l_flag.alloc((size_t)NP + 2)); HIPCHK(ctx->l_pos.alloc((size_t)NP + 2)); HIPCHK(ctx->l_scan.alloc((size_t)scan_tmp_elems(NP + 2)));
+  HIPCHK(ctx->l_gtop.alloc((size_t)Uc * ncls + 1));
+  HIPCHK(hipMemsetAsync(ctx->l_done.p, 0, (size_t)NP + 1, st));
+  HIPCHK(hipMemsetAsync(ctx->l_gtop.p, 0, ((size_t)Uc * ncls + 1) * sizeof(unsigned long long), st));
+  {
+    std::vector<WaveDesc> waves; std::vector<char> wgeneric; std::vector<int32_t> rows;
+    { const int rc = build_waves(ctx, pl, waves, wgeneric, rows); if (rc != ITSX_OK) return rc; }
+    const int NW = (int)waves.size();
+    FloatArgs a{};
+    a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+    a.pairs = pl.pairs; a.waves = ctx->w_waves.p; a.F1 = F1; a.F3 = F3;
+    // rows of each wave (the kernel walks every lane to the wave's longest target)
+    for (int w = 0; w < NW; w++) waves[(size_t)w].rows = rows[(size_t)w];
+    HIPCHK(hipMemcpyAsync(ctx->w_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
+    int nfast = 0; while (nfast < NW && !wgeneric[(size_t)nfast]) nfast++;
+    StageTimer tm(st);
+    // launches of at most 2^20 waves: the timers of bench.py's roofline block want more than one sample
+    for (int w0 = 0; w0 < nfast; w0 += 1 << 20) { launch_fwd_bound(a, ctx->l_fb.p, std::min(1 << 20, nfast - w0), w0, 0, st); S.n_bound_launches++; }
+    if (NW > nfast) { launch_fwd_bound(a, ctx->l_fb.p, NW - nfast, nfast, 1, st); S.n_bound_launches++; }
+    const float ms = tm.stop();
+    S.ms_bound_kernel += ms; S.ms_filters += ms;
+    for (int w = 0; w < NW; w++) S.bound_rows += (int64_t)(rows[(size_t)w] - 1) * waves[(size_t)w].count;
+  }
+  StageTimer tm_sel(st);
+  LazyArgs la{};
+  la.pairs = pl.pairs; la.NP = NP; la.fb = ctx->l_fb.p; la.lt = ctx->d_lt.p; la.cls = ctx->w_cls.p; la.ncls = ncls; la.sorted_uniq = d_sorted;
+  la.b10 = ctx->l_b10.p; la.gtop = ctx->l_gtop.p; la.bestc = ctx->w_bestc.p; la.done = ctx->l_done.p; la.flag = ctx->l_flag.p;
+  launch_lazy_bound(la, st);
+  float ms_sel = tm_sel.stop();
+  for (int round = 0; round < 2; round++) {
+    StageTimer tm_r(st);
+    launch_lazy_mark(la, round, st);
+    launch_exclusive_scan(ctx->l_flag.p, ctx->l_pos.p, NP + 1, ctx->l_scan.p, st);
+    std::vector<int32_t> bound((size_t)P + 1);
+    {
+      DBuf<int64_t> &d_idx = ctx->w_idx; DBuf<int32_t> &d_b = ctx->w_b;
+      HIPCHK(upload(d_idx, pl.seg_start, st)); HIPCHK(d_b.alloc((size_t)P + 1));
+      hipLaunchKernelGGL(k_gather_i32, dim3((P + 1 + 255) / 256), dim3(256), 0, st, ctx->l_pos.p, d_idx.p, P + 1, d_b.p);
+      HIPCHK(hipMemcpyAsync(bound.data(), d_b.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    PairList sub;
+    sub.seg_start.assign((size_t)P + 1, 0); sub.total.assign((size_t)P, 0);
+    for (int p = 0; p < P; p++) { sub.total[(size_t)p] = bound[(size_t)p + 1] - bound[(size_t)p]; sub.seg_start[(size_t)p + 1] = sub.seg_start[(size_t)p] + ((int64_t)sub.total[(size_t)p] + 63) / 64 * 64; }
+    sub.NP = sub.seg_start[(size_t)P];
+    const int64_t nsel = (int64_t)bound[(size_t)P] - bound[0];
+    const bool last = round == 1;
+    if (sub.NP == 0) {
+      ms_sel += tm_r.stop();
+      if (last && next_msv) { const int rc = (*next_msv)(); if (rc != ITSX_OK) return rc; }
+      continue;
+    }
+    HIPCHK(ctx->l_pairs.alloc((size_t)sub.NP)); HIPCHK(ctx->d_pout.alloc((size_t)sub.NP));
+    HIPCHK(hipMemsetAsync(ctx->l_pairs.p, 0xFF, (size_t)sub.NP * sizeof(PairRec), st));
+    HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)sub.NP * sizeof(PairOut), st));
+    HIPCHK(upload(ctx->l_seg, sub.seg_start, st));
+    launch_lazy_scatter(pl.pairs, NP, ctx->l_flag.p, ctx->l_pos.p, pl.d_seg_start, ctx->l_seg.p, ctx->l_pairs.p, st);
+    sub.pairs = ctx->l_pairs.p; sub.pout = ctx->d_pout.p; sub.d_seg_start = ctx->l_seg.p;
+    ms_sel += tm_r.stop();
+    S.n_lazy_evaluated += nsel;
+    if (round == 0) S.n_lazy_round1 += nsel;
+    { const int rc = domain_pipeline(ctx, sub, d_sorted, T, F1, F3, last ? next_msv : nullptr); if (rc != ITSX_OK) return rc; }
+  }
+  S.ms_lazy_select += ms_sel; S.ms_filters += ms_sel;
+  return ITSX_OK;
+}
+
+// one chunk [u0, u0+U) of the length-sorted unique list through every stage up to per-sequence reporting
+static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, double T, double F1, double F3)
+{
+  (void)ci;
+  hipStream_t st = ctx->st;
+  const int P = ctx->P, G = ctx->G, Ppad = G * 64;
+  itsx_stats &S = ctx->stats;
+  const int32_t *d_sorted = ctx->d_sorted_uniq.p + u0;     // PairRec::useq is relative to the chunk
+  DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
+  ctx->trace_u0 = u0;
+  // ---- MSV for every (unique, profile)
+  DBuf<uint16_t> &d_res = ctx->w_res;
+  HIPCHK(d_res.alloc((size_t)Ppad * std::max<int64_t>(U, ctx->next_u0 >= 0 ? ctx->next_U : 0)));
+  auto msv_for = [&](int64_t cu0, int32_t cU, hipStream_t s, int lds_pad = 0) {
+    MsvArgs a{};
+    a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p + cu0; a.seed_read = ctx->d_seed_read.p; a.U = cU; a.G = G;
+    a.etab = ctx->d_etab.p; a.pbias = ctx->d_pbias.p; a.ptec = ctx->d_ptec.p; a.ptbm = ctx->d_ptbm.p;
+    a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = d_res.p;
+    a.P = P;
+    // blocks of 256 sequences x PB profiles: a few thousand blocks at least, and up to 32 profiles per block so that a
+    // large job re-reads its sequences' packed words (from L2) 32 times less often than it has profiles
+    const int64_t tiles = ((int64_t)cU + 255) / 256;
+    a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * P / 4096));
+    launch_msv(a, s, lds_pad);
+  };
+  if (ctx->msv_pre_u0 == (int64_t)u0) {
+    // launched on st2 while the chunk before this one was in its domain stage
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_msv1, 0));
+    HIPCHK(hipEventSynchronize(ctx->ev_msv1));
+    float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev_msv0, ctx->ev_msv1);
+    S.ms_msv_kernel += ms;                       // its stretched wall time beside other kernels: not extra step time
+    S.msv_launches += 1;
+    ctx->msv_pre_u0 = -1;
+  } else {
+    StageTimer tm(st);
+    msv_for(u0, U, st);
+    const float ms = tm.stop();
+    S.ms_msv_kernel += ms; S.ms_msv += ms;
+    S.msv_launches += 1;
+  }
+  StageTimer tm_list(st);
+  // ---- survivor list grouped by profile (64-aligned segments, ascending length)
+  const int nchunks = (U + CHUNK - 1) / CHUNK;
+  DBuf<int32_t> &d_cnt = ctx->w_cnt, &d_total = ctx->w_total;
+  HIPCHK(d_cnt.alloc((size_t)P * nchunks)); HIPCHK(d_total.alloc((size_t)P));
+  launch_pair_count(d_res.p, P, U, nchunks, d_cnt.p, st);
+  launch_chunk_scan(d_cnt.p, P, nchunks, d_total.p, st);
+  std::vector<int32_t> total((size_t)P);
+  HIPCHK(hipMemcpyAsync(total.data(), d_total.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<int64_t> seg_start((size_t)P + 1, 0);
+  for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; S.n_past_msv += total[p]; }
+  const int64_t NP = seg_start[P];
+  ctx->npairs_padded = ctx->lazy ? 0 : NP;
+  if (NP == 0) { S.ms_msv += tm_list.stop(); ctx->dom_n.push_back(0); while (ctx->dom_bufs.size() < ctx->dom_n.size()) ctx->dom_bufs.emplace_back(new DBuf<itsx_domain>()); return ITSX_OK; }
+  if (NP >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 surviving (representative, profile) pairs");
+  DBuf<int64_t> &d_seg_start = ctx->w_seg_start;
+  HIPCHK(upload(d_seg_start, seg_start, st));
+  HIPCHK(ctx->d_pairs.alloc((size_t)NP));
+  HIPCHK(hipMemsetAsync(ctx->d_pairs.p, 0xFF, (size_t)NP * sizeof(PairRec), st));
+  if (!ctx->lazy) {                                // (the lazy stage keeps a PairOut only for the pairs it evaluates)
+    HIPCHK(ctx->d_pout.alloc((size_t)NP));
+    HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)NP * sizeof(PairOut), st));
+  }
+  launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p + u0, ctx->d_pairs.p, st);
+  S.ms_msv += tm_list.stop();
+  for (int p = 0; p < P; p++)                     // an upper bound of hmmsearch's domZ: every reported target is a pair past the MSV filter
+    for (int32_t sm = 0; sm < ctx->S; sm++) ctx->domz_ub[(size_t)sm * P + p] += total[p];
+  PairList pl;
+  pl.pairs = ctx->d_pairs.p; pl.pout = ctx->lazy ? nullptr : ctx->d_pout.p; pl.NP = NP; pl.seg_start = seg_start; pl.total = total; pl.d_seg_start = d_seg_start.p;
+  // the next chunk's MSV filter on the second stream (its result buffer is free: this chunk's survivor list is built)
+  const std::function<int()> next_msv = [&]() -> int {
+    static const bool msv_overlap = !(getenv("ITSX_MSV_OVERLAP") && atoi(getenv("ITSX_MSV_OVERLAP")) == 0);
+    if (msv_overlap && ctx->next_u0 >= 0 && ctx->st2 && !ctx->keep_trace) {
+      if (!ctx->ev_msv0) {
+        HIPCHK(hipEventCreate(&ctx->ev_msv0)); HIPCHK(hipEventCreate(&ctx->ev_msv1));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_c, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(ctx->ev_c, st)); HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->ev_c, 0));
+      HIPCHK(hipEventRecord(ctx->ev_msv0, ctx->st2));
+      msv_for(ctx->next_u0, ctx->next_U, ctx->st2, getenv("ITSX_MSV_PAD") ? atoi(getenv("ITSX_MSV_PAD")) : 40000);
+      HIPCHK(hipEventRecord(ctx->ev_msv1, ctx->st2));
+      ctx->msv_pre_u0 = ctx->next_u0;
+    }
+    return ITSX_OK;
+  };
+  if (ctx->lazy) return lazy_rounds(ctx, pl, d_sorted, U, T, F1, F3, &next_msv);
+  { const int rc = domain_pipeline(ctx, pl, d_sorted, T, F1, F3, &next_msv); if (rc != ITSX_OK) return rc; }
   if (ctx->keep_trace) { const int rc = append_traces(ctx); if (rc != ITSX_OK) return rc; }
   return ITSX_OK;
 }
 
+int itsx_set_rows_mode(itsx_ctx *ctx, int mode)
+{
+  CTXCHK(ctx);
+  if (mode < -1 || mode > ITSX_ROWS_LAZY) SET_ERR(ctx, ITSX_E_ARG, "itsx_set_rows_mode: mode must be -1 (environment), 0 (full), 1 (compact) or 2 (lazy)");
+  ctx->rows_mode = mode;
+  return ITSX_OK;
+}
+int64_t itsx_lazy_pending(const itsx_ctx *ctx) { return ctx ? ctx->lazy_pending : -1; }
+
+// After a lazy search the counters are BOUNDS on hmmsearch's domZ: [S][P] reported targets among the evaluated pairs (below),
+// then [S][P] pairs past the MSV filter (above).  itsx_get_domz / itsx_set_domz move the lower half only when the search was
+// not lazy; after a lazy search they move both halves (2 x S x P values), like itsx_domz_device.
 int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ)
 {
   CTXCHK(ctx && domZ && ctx->have_search);
   for (size_t p = 0; p < ctx->domz.size(); p++) domZ[p] = ctx->domz[p];
+  if (ctx->lazy) for (size_t p = 0; p < ctx->domz_ub.size(); p++) domZ[ctx->domz.size() + p] = ctx->domz_ub[p];
   return ITSX_OK;
 }
 int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ)
 {
   CTXCHK(ctx && domZ && ctx->have_search);
   for (size_t p = 0; p < ctx->domz.size(); p++) ctx->domz[p] = domZ[p];
-  ctx->domz_on_device = false;
+  if (ctx->lazy) for (size_t p = 0; p < ctx->domz_ub.size(); p++) ctx->domz_ub[p] = domZ[ctx->domz.size() + p];
+  ctx->domz_on_device = false; ctx->domz_exchanged = true;
   return ITSX_OK;
 }
+int64_t itsx_domz_count(const itsx_ctx *ctx) { return ctx ? (int64_t)ctx->domz.size() * (ctx->lazy ? 2 : 1) : -1; }
 
 // ---- device-resident exchange (multi-GPU): the caller reduces / gathers these buffers where they are (RCCL), nothing bounces
 // through host arrays.  Pointers stay valid until the next call that recomputes the same quantity.
@@ -1896,13 +2066,45 @@ int itsx_domz_device(itsx_ctx *ctx, int64_t **d_domz, int64_t *n)
 {
   CTXCHK(ctx && d_domz && ctx->have_search);
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t m = ctx->domz.size();
-  HIPCHK(ctx->d_domz64.alloc(std::max<size_t>(m, 1)));
+  const size_t m = ctx->domz.size(), mm = m * (ctx->lazy ? 2 : 1);
+  HIPCHK(ctx->d_domz64.alloc(std::max<size_t>(mm, 1)));
   if (m) HIPCHK(hipMemcpyAsync(ctx->d_domz64.p, ctx->domz.data(), m * 8, hipMemcpyHostToDevice, ctx->st));
+  if (m && ctx->lazy) HIPCHK(hipMemcpyAsync(ctx->d_domz64.p + m, ctx->domz_ub.data(), m * 8, hipMemcpyHostToDevice, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
-  ctx->domz_on_device = true;
+  ctx->domz_on_device = true; ctx->domz_exchanged = true;
   *d_domz = ctx->d_domz64.p;
-  if (n) *n = (int64_t)m;
+  if (n) *n = (int64_t)mm;
+  return ITSX_OK;
+}
+
+// thresholds of a lazy search: rows both bounds decide alike are final; ctx->lazy_pending = undecided rows that could matter
+static int finalize_lazy(itsx_ctx *ctx, double domE)
+{
+  hipStream_t st = ctx->st;
+  const size_t m = ctx->domz.size();
+  DBuf<int64_t> &d_dz = ctx->domz_on_device ? ctx->d_domz64 : ctx->w_dz;
+  if (ctx->domz_on_device) {             // reduced in place by the caller: lower bounds, then upper bounds
+    if (m) { HIPCHK(hipMemcpyAsync(ctx->domz.data(), d_dz.p, m * 8, hipMemcpyDeviceToHost, st)); HIPCHK(hipMemcpyAsync(ctx->domz_ub.data(), d_dz.p + m, m * 8, hipMemcpyDeviceToHost, st)); }
+  } else {
+    std::vector<int64_t> both(ctx->domz); both.insert(both.end(), ctx->domz_ub.begin(), ctx->domz_ub.end());
+    HIPCHK(upload(d_dz, both, st, 2));
+  }
+  const int32_t U = ctx->U; const int ncls = std::max(ctx->compact_ncls, 1);
+  HIPCHK(ctx->l_sure.alloc((size_t)U * ncls + 1)); HIPCHK(ctx->l_has.alloc((size_t)U + 1)); HIPCHK(ctx->w_counters.alloc(16));
+  HIPCHK(hipMemsetAsync(ctx->l_sure.p, 0, ((size_t)U * ncls + 1) * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(ctx->l_has.p, 0, ((size_t)U + 1) * sizeof(int32_t), st));
+  HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 16 * sizeof(int64_t), st));
+  for (size_t c = 0; c < ctx->dom_n.size(); c++)
+    if (ctx->dom_n[c] > 0) launch_finalize_lazy(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, d_dz.p + m, domE, ctx->dev_usample(), ctx->P, st);
+  for (size_t c = 0; c < ctx->dom_n.size(); c++)
+    if (ctx->dom_n[c] > 0) launch_lazy_sure(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, st);
+  for (size_t c = 0; c < ctx->dom_n.size(); c++)
+    if (ctx->dom_n[c] > 0) launch_lazy_pending(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, (unsigned long long *)ctx->w_counters.p, st);
+  int64_t pend = 0;
+  HIPCHK(hipMemcpyAsync(&pend, ctx->w_counters.p, sizeof(pend), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (getenv("ITSX_LAZY_FORCE_PENDING")) pend += atoll(getenv("ITSX_LAZY_FORCE_PENDING"));      // test hook: exercises the full re-run
+  ctx->lazy_pending = pend; ctx->stats.n_lazy_pending = pend;
   return ITSX_OK;
 }
 
@@ -1912,6 +2114,35 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
   HIPCHK(hipSetDevice(ctx->device));
   StageTimer tm(ctx->st);
   ctx->h_dom.clear();
+  auto check_compaction = [&](const std::vector<int64_t> &z) -> int {       // the rows were thinned out under two assumptions: check them against what finalize was given
+    int64_t zmax = 0;
+    for (int64_t v : z) zmax = std::max(zmax, v);
+    if ((double)zmax > ctx->compact_zmax || domE < ctx->compact_dome_min)
+      SET_ERR(ctx, ITSX_E_UNSUPPORTED, "compacted domain rows: only the rows that are reported for every domZ <= " + std::to_string(ctx->compact_zmax) +
+              " and every domE >= " + std::to_string(ctx->compact_dome_min) + " were kept, but finalize got domZ up to " + std::to_string(zmax) + " and domE " + std::to_string(domE) +
+              " (raise ITSX_COMPACT_ZMAX / lower ITSX_COMPACT_DOME_MIN and search again)");
+    return ITSX_OK;
+  };
+  if (ctx->lazy) {
+    { const int rc = finalize_lazy(ctx, domE); if (rc != ITSX_OK) return rc; }
+    { const int rc = check_compaction(ctx->domz_ub); if (rc != ITSX_OK) return rc; }
+    if (ctx->lazy_pending > 0 && !ctx->domz_exchanged) {
+      // A row whose reporting depends on the exact domZ could change a result.  This context is on its own (nobody exchanged
+      // counters), so it repeats the search with every pair evaluated; a multi-rank driver sees itsx_lazy_pending() > 0 on some
+      // rank and repeats the search on all of them (itsxpress_amd/dist.py: search_and_finalize).
+      const int keep = ctx->rows_mode;
+      ctx->rows_mode = ITSX_ROWS_COMPACT;
+      const int64_t pend = ctx->lazy_pending;
+      const int rc = itsx_search(ctx, ctx->T, ctx->sF1, ctx->F2, ctx->sF3);
+      ctx->rows_mode = keep;
+      if (rc != ITSX_OK) return rc;
+      ctx->stats.n_lazy_reruns = 1; ctx->stats.n_lazy_pending = pend;
+    } else {
+      ctx->stats.ms_finalize = tm.stop();
+      ctx->have_final = true;
+      return ITSX_OK;
+    }
+  }
   {
     DBuf<int64_t> &d_dz = ctx->domz_on_device ? ctx->d_domz64 : ctx->w_dz;
     if (ctx->domz_on_device) {             // reduced in place by the caller (RCCL): the host copy follows the device
@@ -1920,14 +2151,7 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
     for (size_t c = 0; c < ctx->dom_n.size(); c++)
       if (ctx->dom_n[c] > 0) launch_finalize(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, domE, ctx->dev_usample(), ctx->P, ctx->st);
     HIPCHK(hipStreamSynchronize(ctx->st));
-    if (ctx->compact_rows) {             // the rows were thinned out under two assumptions: check them against what finalize was given
-      int64_t zmax = 0;
-      for (int64_t z : ctx->domz) zmax = std::max(zmax, z);
-      if ((double)zmax > ctx->compact_zmax || domE < ctx->compact_dome_min)
-        SET_ERR(ctx, ITSX_E_UNSUPPORTED, "ITSX_COMPACT_ROWS kept only the rows that are reported for every domZ <= " + std::to_string(ctx->compact_zmax) +
-                " and every domE >= " + std::to_string(ctx->compact_dome_min) + ", but finalize got domZ up to " + std::to_string(zmax) + " and domE " + std::to_string(domE) +
-                " (raise ITSX_COMPACT_ZMAX / lower ITSX_COMPACT_DOME_MIN and search again)");
-    }
+    if (ctx->compact_rows) { const int rc = check_compaction(ctx->domz); if (rc != ITSX_OK) return rc; }
   }
   ctx->stats.ms_finalize = tm.stop();
   ctx->have_final = true;
@@ -2254,6 +2478,9 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
   const bool to_host = start && stop && tlen && ind;        // all four, or none (the results stay on the device)
   if (!to_host && (start || stop || tlen || ind)) return ITSX_E_ARG;
   if (!ctx->have_final) SET_ERR(ctx, ITSX_E_ARG, "coordinates requested before itsx_search_finalize");
+  if (ctx->lazy && ctx->lazy_pending > 0)
+    SET_ERR(ctx, ITSX_E_ARG, std::to_string(ctx->lazy_pending) + " domain row(s) of the lazy search depend on the exact domZ and could change a result: "
+            "search again with itsx_set_rows_mode(ctx, 1) (itsx_lazy_pending reports this after itsx_search_finalize)");
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->st;
   const int32_t U = ctx->U; const int64_t n = ctx->N;
@@ -2271,9 +2498,12 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
   HIPCHK(us.alloc((size_t)U + 1)); HIPCHK(ue.alloc((size_t)U + 1)); HIPCHK(ut.alloc((size_t)U + 1));
   HIPCHK(hipMemsetAsync(bl.p, 0, ((size_t)U + 1) * 8, st)); HIPCHK(hipMemsetAsync(br.p, 0, ((size_t)U + 1) * 8, st));
   HIPCHK(hipMemsetAsync(uind.p, 0, ((size_t)U + 1) * 4, st));
+  HIPCHK(ctx->w_cl.alloc((size_t)U + 1)); HIPCHK(ctx->w_cr.alloc((size_t)U + 1));
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_positions(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_side.p, bl.p, br.p, uind.p, st);
-  if (U > 0) hipLaunchKernelGGL(k_rep_coords, dim3((U + 255) / 256), dim3(256), 0, st, U, bl.p, br.p, uind.p, ctx->d_seed_read.p, ctx->rd.len, us.p, ue.p, ut.p);
+  for (size_t c = 0; c < ctx->dom_n.size(); c++)          // the winners' coordinates (exactly one row carries each winning key)
+    if (ctx->dom_n[c] > 0) launch_position_coords(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_side.p, bl.p, br.p, ctx->w_cl.p, ctx->w_cr.p, st);
+  if (U > 0) hipLaunchKernelGGL(k_rep_coords, dim3((U + 255) / 256), dim3(256), 0, st, U, bl.p, br.p, ctx->w_cl.p, ctx->w_cr.p, ctx->d_seed_read.p, ctx->rd.len, us.p, ue.p, ut.p);
   {   // parity-risk counters (itsx_stats): winners out of clustered regions, pairs at the region cap
     DBuf<int32_t> &uflag = ctx->w_uflag; DBuf<int64_t> &d_c = ctx->w_counters;
     HIPCHK(uflag.alloc((size_t)U + 1)); HIPCHK(d_c.alloc(8));

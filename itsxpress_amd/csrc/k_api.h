@@ -207,6 +207,8 @@ struct VitArgs {
 void launch_vit(const VitArgs &a, int nwaves, int wave0, hipStream_t st);
 void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st, int lds_pad = 0);
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
+// the lazy domain stage's first pass (k_lazy.hip): Forward scores only, nothing goes to the slab or to PairOut; fb[pair] = fwdsc
+void launch_fwd_bound(const FloatArgs &a, float *fb, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st);
 
@@ -297,5 +299,41 @@ void launch_score(const ScoreArgs &a, hipStream_t st);
 void launch_region_count_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *pref,
                               const int64_t *seg_pair_start, const int64_t *seg_region_start, const int32_t *seg_of_pair_base,
                               RegionRec *out, hipStream_t st);
+
+// ItsPosition's order on domain rows (itsxpress/SeqSample.py:400-429: the FIRST row with a strictly greater %.1f score wins; rows come
+// in profile order, then domain order): [24b tenths + 2^23][20b ~profile][20b ~domain index].  A larger key wins.
+__device__ __forceinline__ unsigned long long rank_key(const itsx_domain &d)
+{
+  long long tenths = (long long)__builtin_rint((double)d.bitscore * 10.0) + (1ll << 23);
+  if (tenths < 0) tenths = 0;
+  if (tenths > (1ll << 24) - 1) tenths = (1ll << 24) - 1;
+  const unsigned long long di = (unsigned long long)(d.dom_idx < 0 ? 0 : (d.dom_idx > 0xFFFFF ? 0xFFFFF : d.dom_idx));
+  return ((unsigned long long)tenths << 40) | ((unsigned long long)(0xFFFFF - (d.prof & 0xFFFFF)) << 20) | (0xFFFFFull - di);
+}
+
+// ---- k_lazy.hip: the lazy domain stage (pairs that cannot win ItsPosition's argmax never reach Backward)
+constexpr int LAZY_TENTHS_BIAS = 1 << 23;      // the bias of the tenths field in rank_key
+struct LazyArgs {
+  const PairRec *pairs; int64_t NP;
+  const float *fb;                 // [NP] Forward score of the bound pass (nats; need not be HMMER's bits: a margin covers it)
+  const LenTables *lt;
+  const int8_t *cls; int32_t ncls; // 2-character prefix class of each profile
+  const int32_t *sorted_uniq;      // chunk-relative useq -> global unique index
+  uint32_t *b10;                   // [NP] largest %.1f tenths (+ LAZY_TENTHS_BIAS) a domain of the pair can print; 0 = no pair here
+  unsigned long long *gtop;        // [chunk uniques x ncls] (b10 << 32 | ~pair) of the group's best-bound pair
+  const unsigned long long *bestc; // [uniques x ncls] rank key of the best CERTAIN row so far (k_compact_best)
+  uint8_t *done;                   // [NP] the pair went through the domain stage already
+  int32_t *flag;                   // [NP + 1] selected for this round
+};
+void launch_lazy_bound(const LazyArgs &a, hipStream_t st);
+void launch_lazy_mark(const LazyArgs &a, int round, hipStream_t st);
+void launch_lazy_scatter(const PairRec *pairs, int64_t NP, const int32_t *flag, const int32_t *pos, const int64_t *seg_old, const int64_t *seg_new,
+                         PairRec *out, hipStream_t st);
+// three-valued thresholds with bounds on hmmsearch's domZ: dom_reported = 1 reported for every domZ in [zlb, zub], 0 for none, 2 = depends
+void launch_finalize_lazy(itsx_domain *dom, int64_t n, const int64_t *zlb, const int64_t *zub, double domE, const int32_t *usample, int P, hipStream_t st);
+// best sure row per (representative, class) and "has a sure row" per representative; then the rows whose status matters
+void launch_lazy_sure(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, unsigned long long *sure, int32_t *has, hipStream_t st);
+void launch_lazy_pending(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, const unsigned long long *sure, const int32_t *has,
+                         unsigned long long *count, hipStream_t st);
 
 }  // namespace itsx

@@ -433,8 +433,10 @@ __global__ void __launch_bounds__(256) k_bias(FloatArgs a, int64_t npairs)
 
 // =========================================================================================
 // K1: bias filter + Forward parser + F3 test, for one wave of survivors of the MSV filter
-template <int QT>
-__global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
+// BOUND = 1: the lazy domain stage's first pass -- the same recurrence, but nothing is kept except the score (fb[pair]): no slab
+// rows, no PairOut (the pairs that matter come back through the BOUND = 0 kernel, so this pass only has to be an upper bound)
+template <int QT, int BOUND>
+__global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0, float *__restrict__ fb)
 {
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
@@ -448,7 +450,8 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
   const PairRec pr = a.pairs[pi];
   const int L = pr.L;
   const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
-  PairOut po = a.pout[pi];            // filtersc / pass_bias come from k_bias
+  PairOut po;
+  if constexpr (!BOUND) po = a.pout[pi];            // filtersc / pass_bias come from k_bias
   const int Lw = wd.rows - 1;       // longest sequence in this wave
 
   // ---- Forward parser
@@ -460,9 +463,11 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
     const float ploop = 1.0f - pmove;
     float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f, totscale = 0.0f;
     const int64_t r0 = wd.slab;
-    *SLAB(a, r0, 0, 0, lane) = xE; *SLAB(a, r0, 0, 1, lane) = xN;
-    *SLAB(a, r0, 0, 2, lane) = xJ; *SLAB(a, r0, 0, 3, lane) = xB;
-    *SLAB(a, r0, 0, 4, lane) = xC; *SLAB(a, r0, 0, 5, lane) = 1.0f;
+    if constexpr (!BOUND) {
+      *SLAB(a, r0, 0, 0, lane) = xE; *SLAB(a, r0, 0, 1, lane) = xN;
+      *SLAB(a, r0, 0, 2, lane) = xJ; *SLAB(a, r0, 0, 3, lane) = xB;
+      *SLAB(a, r0, 0, 4, lane) = xC; *SLAB(a, r0, 0, 5, lane) = 1.0f;
+    }
     SeqStream ss; ss.open(sq, 0, +1);
     int xnext = ss.get(0);                   // residue of the NEXT row
     for (int i = 1; i <= Lw; i++) {
@@ -478,13 +483,21 @@ __global__ void __launch_bounds__(64, 2) k_filters_fwd(FloatArgs a, int wave0)
           totscale = (float)((double)totscale + det_log((double)xE));
           xE = 1.0f;
         }
-        SLAB_ST(SLAB(a, r0, i, 0, lane), xE); SLAB_ST(SLAB(a, r0, i, 1, lane), xN);
-        SLAB_ST(SLAB(a, r0, i, 2, lane), xJ); SLAB_ST(SLAB(a, r0, i, 3, lane), xB);
-        SLAB_ST(SLAB(a, r0, i, 4, lane), xC); SLAB_ST(SLAB(a, r0, i, 5, lane), sc);
+        if constexpr (!BOUND) {
+          SLAB_ST(SLAB(a, r0, i, 0, lane), xE); SLAB_ST(SLAB(a, r0, i, 1, lane), xN);
+          SLAB_ST(SLAB(a, r0, i, 2, lane), xJ); SLAB_ST(SLAB(a, r0, i, 3, lane), xB);
+          SLAB_ST(SLAB(a, r0, i, 4, lane), xC); SLAB_ST(SLAB(a, r0, i, 5, lane), sc);
+        }
+        (void)sc;
       }
     }
     const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
     po.fwdsc = (float)((double)totscale + det_log((double)(xC * pmove)));
+    if constexpr (BOUND) {
+      // a score the pipeline would call unusable gets no bound at all (NaN): such a pair is always evaluated
+      if (active) fb[pi] = bad ? __builtin_nanf("") : po.fwdsc;
+      return;
+    }
     const double P = exp_surv((double)(po.fwdsc - po.filtersc) / kLn2, (double)pp->ev[4], (double)pp->ev[5]);
     po.pass_fwd = po.pass_bias && (!a.vit || a.vit[pi].pass) && !bad && !(P > a.F3);
   }
@@ -1210,16 +1223,9 @@ __global__ void __launch_bounds__(256) k_finalize(itsx_domain *__restrict__ dom,
   const int rep = d.seq_reported && (det_exp(d.lnP) * (double)domz[(usample ? usample[d.rep] * P : 0) + d.prof] <= domE);
   dom[i].dom_reported = rep;
 }
-// key = [24b tenths+bias][20b ~prof][4b ~dom][16b coordinate]; atomicMax picks the highest %.1f score,
-// then the earliest profile, then the earliest domain -- ItsPosition._score's "first strictly greater".
-DEV unsigned long long position_key(const itsx_domain &d, int sd)
-{
-  long long tenths = (long long)__builtin_rint((double)d.bitscore * 10.0) + (1ll << 23);
-  if (tenths < 0) tenths = 0; if (tenths > (1ll << 24) - 1) tenths = (1ll << 24) - 1;
-  const unsigned long long coord = (unsigned long long)((sd == 1 ? d.jenv : d.ienv) & 0xffff);
-  return ((unsigned long long)tenths << 40) | ((unsigned long long)(0xFFFFF - d.prof) << 20) |
-         ((unsigned long long)(15 - (d.dom_idx & 15)) << 16) | coord;
-}
+// rank_key (k_api.h) = [24b tenths+bias][20b ~prof][20b ~dom]; atomicMax picks the highest %.1f score, then the earliest profile,
+// then the earliest domain -- ItsPosition._score's "first strictly greater".  The winner's coordinate is fetched by a second
+// pass (k_position_coords): (profile, domain index) is unique per representative, so exactly one row carries the winning key.
 __global__ void __launch_bounds__(256) k_positions(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ side /*[P] 1 left 2 right*/,
                                                    unsigned long long *__restrict__ best_l, unsigned long long *__restrict__ best_r,
                                                    int32_t *__restrict__ in_ddict)
@@ -1227,17 +1233,31 @@ __global__ void __launch_bounds__(256) k_positions(const itsx_domain *__restrict
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const itsx_domain d = dom[i];
-  if (d.dom_idx < 0 || !d.dom_reported) return;
+  if (d.dom_idx < 0 || d.dom_reported != 1) return;
   in_ddict[d.rep] = 1;
   const int sd = side[d.prof];
   if (sd == 0) return;
-  atomicMax(sd == 1 ? &best_l[d.rep] : &best_r[d.rep], position_key(d, sd));
+  atomicMax(sd == 1 ? &best_l[d.rep] : &best_r[d.rep], rank_key(d));
+}
+__global__ void __launch_bounds__(256) k_position_coords(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ side,
+                                                         const unsigned long long *__restrict__ best_l, const unsigned long long *__restrict__ best_r,
+                                                         int32_t *__restrict__ cl, int32_t *__restrict__ cr)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const itsx_domain d = dom[i];
+  if (d.dom_idx < 0 || d.dom_reported != 1) return;
+  const int sd = side[d.prof];
+  if (sd == 0) return;
+  const unsigned long long k = rank_key(d);
+  if (sd == 1) { if (k == best_l[d.rep]) cl[d.rep] = d.jenv; }
+  else if (k == best_r[d.rep]) cr[d.rep] = d.ienv;
 }
 // ---- row compaction (ITSX_COMPACT_ROWS=1): per (representative, 2-character profile prefix) only the rows that can still
 // win ItsPosition's argmax once the dataset-wide domZ is known are kept.  A row is CERTAIN to be reported when its target is
 // reported and exp(lnP) * Zmax <= domE_min (lnP <= lnp_certain); below the best certain row of its class nothing can win any
 // more, and nothing below it changes the "sequence has a row" flag either.
-DEV unsigned long long compact_key(const itsx_domain &d) { return position_key(d, 1) >> 16; }       // [tenths][~profile][~domain]
+DEV unsigned long long compact_key(const itsx_domain &d) { return rank_key(d); }       // [tenths][~profile][~domain]
 __global__ void __launch_bounds__(256) k_compact_best(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ cls, int ncls,
                                                       double lnp_certain, unsigned long long *__restrict__ bestc)
 {
@@ -1291,11 +1311,11 @@ __global__ void __launch_bounds__(256) k_position_flags(const itsx_domain *__res
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const itsx_domain d = dom[i];
-  if (d.dom_idx < 0 || !d.dom_reported) return;
+  if (d.dom_idx < 0 || d.dom_reported != 1) return;
   const int sd = side[d.prof];
   if (sd == 0) return;
   int f = 0;
-  if ((d.flags & 1) && position_key(d, sd) == (sd == 1 ? best_l[d.rep] : best_r[d.rep])) f |= 1;
+  if ((d.flags & 1) && rank_key(d) == (sd == 1 ? best_l[d.rep] : best_r[d.rep])) f |= 1;
   if (d.flags & 2) f |= 2;
   if (f) atomicOr(&uflag[d.rep], f);
 }
@@ -1321,8 +1341,14 @@ void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st, int lds_pad
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
 {
   if (nwaves <= 0) return;
-  if (generic_q) hipLaunchKernelGGL(k_filters_fwd<0>, dim3(nwaves), dim3(64), 0, st, a, wave0);
-  else           hipLaunchKernelGGL(k_filters_fwd<QMAX>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  if (generic_q) hipLaunchKernelGGL((k_filters_fwd<0, 0>), dim3(nwaves), dim3(64), 0, st, a, wave0, (float *)nullptr);
+  else           hipLaunchKernelGGL((k_filters_fwd<QMAX, 0>), dim3(nwaves), dim3(64), 0, st, a, wave0, (float *)nullptr);
+}
+void launch_fwd_bound(const FloatArgs &a, float *fb, int nwaves, int wave0, int generic_q, hipStream_t st)
+{
+  if (nwaves <= 0) return;
+  if (generic_q) hipLaunchKernelGGL((k_filters_fwd<0, 1>), dim3(nwaves), dim3(64), 0, st, a, wave0, fb);
+  else           hipLaunchKernelGGL((k_filters_fwd<QMAX, 1>), dim3(nwaves), dim3(64), 0, st, a, wave0, fb);
 }
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st)
 {
@@ -1381,6 +1407,12 @@ void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, uns
   hipLaunchKernelGGL(k_positions, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, side, bl, br, in_ddict);
 }
 
+void launch_position_coords(const itsx_domain *dom, int64_t n, const int8_t *side, const unsigned long long *bl, const unsigned long long *br,
+                            int32_t *cl, int32_t *cr, hipStream_t st)
+{
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_position_coords, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, side, bl, br, cl, cr);
+}
 void launch_position_flags(const itsx_domain *dom, int64_t n, const int8_t *side, const unsigned long long *bl, const unsigned long long *br,
                            int32_t *uflag, hipStream_t st)
 {

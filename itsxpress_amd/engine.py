@@ -299,14 +299,28 @@ class Engine:
     def search(self, T=10.0, F1=1e-6, F2=1e-6, F3=1e-6):
         self._chk(self.L.itsx_search(self.h, T, F1, F2, F3))
 
+    ROWS_FULL, ROWS_COMPACT, ROWS_LAZY = 0, 1, 2
+
+    def set_rows_mode(self, mode):
+        """What search() keeps of the domain table: "full" (every row: domtbl.txt), "compact" (every pair evaluated, only the rows
+        that can still win ItsPosition's argmax kept), "lazy" (pairs that cannot win it are not evaluated past their Forward score;
+        same coordinates), None = from the environment (ITSX_ROWS / ITSX_COMPACT_ROWS)."""
+        m = {None: -1, "env": -1, "full": 0, "compact": 1, "lazy": 2}.get(mode, mode)
+        self._chk(self.L.itsx_set_rows_mode(self.h, int(m)))
+
+    def lazy_pending(self):
+        """after finalize() of a lazy search whose counters were exchanged: rows that still depend on the exact domZ (> 0: search
+        again in "compact" mode on every rank)"""
+        return int(self.L.itsx_lazy_pending(self.h))
+
     def get_domz(self):
-        z = np.zeros(self.n_profiles * self.n_samples, np.int64)      # [sample][profile]
+        z = np.zeros(max(1, int(self.L.itsx_domz_count(self.h))), np.int64)      # [sample][profile] (x 2 after a lazy search: lower, upper bounds)
         self._chk(self.L.itsx_get_domz(self.h, z.ctypes.data))
-        return z
+        return z[:int(self.L.itsx_domz_count(self.h))]
 
     def set_domz(self, z):
         z = np.ascontiguousarray(z, np.int64)
-        assert z.size == self.n_profiles * self.n_samples
+        assert z.size == int(self.L.itsx_domz_count(self.h))
         self._chk(self.L.itsx_set_domz(self.h, z.ctypes.data))
 
     # ---- device-resident exchange (multi-GPU drivers): torch tensors over the engine's own device memory, no copies

@@ -1,0 +1,157 @@
+"""The lazy domain stage (itsx_set_rows_mode(ctx, ITSX_ROWS_LAZY); csrc/k_lazy.hip): pairs that cannot win ItsPosition's argmax
+(itsxpress/SeqSample.py:400-461) are not evaluated past their Forward score.  The per-read coordinates and the "sequence has a
+row" flag must be EXACTLY those of the full table -- on every prefix pair the reference uses, on one chunk and many, on damaged
+reads whose rows sit near the thresholds, against the CPU oracle, after a domZ exchange, for sample batches -- and the stage must
+really skip work.  `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import synth
+from test_gpu_compact import PAIRS, _same, _weak
+from test_gpu_parity import _its2_subset
+
+pytestmark = pytest.mark.gpu
+
+
+def _coords(engine, hmm, seqs, mode, domE=10.0, samples=None):
+    engine.set_rows_mode(mode)
+    try:
+        engine.load_profiles(text=hmm)
+        engine.set_reads(seqs)
+        if samples is not None:
+            engine.set_samples(samples[0], samples[1])
+        engine.derep()
+        engine.search()
+        engine.finalize(domE=domE)
+        st = engine.stats()
+        return [tuple(a.copy() for a in engine.trim_coords(l, r)) for l, r in PAIRS], st
+    finally:
+        engine.set_rows_mode(None)
+
+
+@pytest.mark.parametrize("chunk", [None, "53"])
+def test_lazy_coordinates_equal_the_full_table(engine, mini_hmm_text, t_hmm_text, monkeypatch, chunk):
+    rng = np.random.default_rng(23)
+    blob, offs = synth.make_reads(mini_hmm_text, 1500, seed=91, fixed_len=0, len_range=(200, 520))
+    seqs = _weak(synth.to_strings(blob, offs), rng)
+    hmm = mini_hmm_text + _its2_subset(t_hmm_text, 25, 25)            # 1_ 2_ 3_ 4_ profiles, families of near-identical ones
+    if chunk:
+        monkeypatch.setenv("ITSX_CHUNK_UNIQUES", chunk)
+    monkeypatch.delenv("ITSX_COMPACT_ROWS", raising=False)
+    ref, st0 = _coords(engine, hmm, seqs, "full")
+    assert sum(int(((c[0] >= 0) | (c[1] >= 0)).sum()) for c in ref) > 1500
+    got, st1 = _coords(engine, hmm, seqs, "lazy")
+    assert st1["lazy"] == 1 and st1["n_lazy_reruns"] == 0
+    assert _same(ref, got)
+    # work really skipped: far fewer pairs through Backward than past the MSV filter
+    assert 0 < st1["n_lazy_evaluated"] < 0.5 * st1["n_past_msv"]
+    assert st1["n_lazy_round1"] <= st1["n_lazy_evaluated"]
+    # another domE inside the compaction's assumptions
+    ref2, _ = _coords(engine, hmm, seqs, "full", domE=0.05)
+    got2, _ = _coords(engine, hmm, seqs, "lazy", domE=0.05)
+    assert _same(ref2, got2)
+
+
+def test_lazy_equals_the_oracle_on_the_bench_shape(engine, t_hmm_text):
+    """configs[2]'s shape (merged reads of 300-580 bases, the stand-in taxon's 155 ITS2 profiles): lazy coordinates == the CPU oracle's"""
+    hmm = _its2_subset(t_hmm_text, 10 ** 6, 10 ** 6)
+    blob, offs = synth.make_reads(t_hmm_text, 1200, config=3, seed=synth.SEED + 3, fixed_len=0, len_range=(300, 580))
+    seqs = synth.to_strings(blob, offs)
+    got, st = _coords(engine, hmm, seqs, "lazy")
+    assert st["n_lazy_evaluated"] < 0.15 * st["n_past_msv"]           # scripts/lazy_bound.py: 3.7 % on this workload
+    codes, o = orc.digitize(seqs)
+    nc, orep, ostrand = orc.derep(codes, o)
+    seeds = [i for i in range(len(seqs)) if orep[i] == i]
+    c2, o2 = orc.digitize([seqs[i] for i in seeds])
+    res = orc.SearchResult(orc.HmmSet(text=hmm), c2, o2, threads=os.cpu_count() or 4, keep_trace=0)
+    uniq = np.cumsum(np.asarray(orep) == np.arange(len(seqs))) - 1
+    uo = uniq[np.maximum(orep, 0)]
+    us, ue, ut, ui = res.positions("3_", "4_")
+    exp = np.stack([us[uo], ue[uo], ut[uo], ui[uo]])
+    assert np.array_equal(exp, np.stack(got[0]))
+
+
+def test_lazy_follows_a_domz_exchange(engine, mini_hmm_text):
+    """multi-GPU: the counters are summed over the ranks between search and finalize.  After a lazy search they are bounds (lower
+    half, upper half); a 50 000-fold inflation of both un-reports weak rows, and the lazy result must still equal the full table's
+    -- or say that rows are pending (then the driver repeats the search in compact mode)."""
+    rng = np.random.default_rng(29)
+    blob, offs = synth.make_reads(mini_hmm_text, 800, seed=72, fixed_len=0, len_range=(200, 420))
+    seqs = _weak(synth.to_strings(blob, offs), rng, frac=0.5)
+    out = []
+    for mode in ("full", "lazy"):
+        engine.set_rows_mode(mode)
+        engine.load_profiles(text=mini_hmm_text)
+        engine.set_reads(seqs)
+        engine.derep()
+        engine.search()
+        z = engine.get_domz()
+        if mode == "full":
+            assert z.size == engine.n_profiles
+            exact = z.copy()
+            engine.set_domz(z * 50000)
+        else:
+            assert z.size == 2 * engine.n_profiles
+            lo, hi = z[:engine.n_profiles], z[engine.n_profiles:]
+            assert (lo <= exact).all() and (exact <= hi).all()         # bounds of the exact counters
+            # what an all-reduce over 50 000 identical ranks would give; tight bounds (lower = upper = exact) decide every row
+            engine.set_domz(np.concatenate([exact, exact]) * 50000)
+        engine.finalize()
+        assert engine.lazy_pending() == 0
+        out.append([tuple(a.copy() for a in engine.trim_coords(l, r)) for l, r in PAIRS])
+    engine.set_rows_mode(None)
+    assert _same(out[0], out[1])
+
+
+def test_rows_that_depend_on_domz_trigger_the_full_search(engine, mini_hmm_text, monkeypatch):
+    """an undecided row that could change a result: alone, the context repeats the search with every pair evaluated (same
+    coordinates as the full table); with exchanged counters it reports the rows as pending and refuses coordinates"""
+    from itsxpress_amd import EngineError
+    rng = np.random.default_rng(31)
+    blob, offs = synth.make_reads(mini_hmm_text, 600, seed=73, fixed_len=0, len_range=(200, 420))
+    seqs = _weak(synth.to_strings(blob, offs), rng, frac=0.5)
+    ref, _ = _coords(engine, mini_hmm_text, seqs, "full")
+    monkeypatch.setenv("ITSX_LAZY_FORCE_PENDING", "3")
+    got, st = _coords(engine, mini_hmm_text, seqs, "lazy")
+    assert st["n_lazy_reruns"] == 1 and st["n_lazy_pending"] >= 3 and st["lazy"] == 0
+    assert _same(ref, got)
+    engine.set_rows_mode("lazy")
+    engine.search()
+    engine.set_domz(engine.get_domz())                       # counters exchanged: the driver decides
+    engine.finalize()
+    assert engine.lazy_pending() >= 3
+    with pytest.raises(EngineError):
+        engine.trim_coords("3_", "4_")
+    monkeypatch.delenv("ITSX_LAZY_FORCE_PENDING")
+    engine.set_rows_mode("compact")
+    engine.search()
+    engine.finalize()
+    got2 = [tuple(a.copy() for a in engine.trim_coords(l, r)) for l, r in PAIRS]
+    engine.set_rows_mode(None)
+    assert _same(ref, got2)
+
+
+def test_lazy_sample_batches(engine, mini_hmm_text, t_hmm_text):
+    """per-sample batching (q2_itsxpress.py:273-333): groups are per representative and a representative belongs to one sample;
+    domZ is bounded per (sample, profile)"""
+    hmm = mini_hmm_text + _its2_subset(t_hmm_text, 12, 12)
+    blob, offs = synth.make_reads(mini_hmm_text, 900, seed=77, fixed_len=0, len_range=(200, 420))
+    seqs = synth.to_strings(blob, offs)
+    smp = (np.arange(len(seqs)) % 3).astype(np.int32)
+    ref, _ = _coords(engine, hmm, seqs, "full", samples=(smp, 3))
+    got, st = _coords(engine, hmm, seqs, "lazy", samples=(smp, 3))
+    assert st["lazy"] == 1
+    assert _same(ref, got)
+
+
+def test_lazy_with_all_taxa_profiles(engine, all_its2_hmm_text, t_hmm_text):
+    """configs[3]'s profile set (814 profiles of 17 taxa): most pairs lose by tens of bits"""
+    blob, offs = synth.make_reads(t_hmm_text, 400, config=4, seed=synth.SEED + 4, fixed_len=0, len_range=(300, 580))
+    seqs = synth.to_strings(blob, offs)
+    ref, st0 = _coords(engine, all_its2_hmm_text, seqs, "compact")
+    got, st1 = _coords(engine, all_its2_hmm_text, seqs, "lazy")
+    assert _same(ref, got)
+    assert st1["n_lazy_evaluated"] < 0.2 * st1["n_past_msv"]

@@ -45,19 +45,24 @@ WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4          # wave instructions per second: 1
 #            + 3 x 2 (its three further DD passes are unconditional) + 2 (D into M) = 22 per q = 22 x 12 x 4 = 1056 flops;
 # the kernels issue 533 (Forward) / 561 (Backward) VALU instructions per row, 484 / 537 of them packed multiplies and adds
 # (instruction audit; Backward's include the five decoding products of the row)
-FLOPS_PER_ROW = {"k_filters_fwd": 960.0, "k_bwd_decode": 1056.0}
-VALU_PER_ROW = {"k_filters_fwd": 533.0, "k_bwd_decode": 561.0}
+FLOPS_PER_ROW = {"k_filters_fwd": 960.0, "k_bwd_decode": 1056.0, "k_fwd_bound": 960.0}
+VALU_PER_ROW = {"k_filters_fwd": 533.0, "k_bwd_decode": 561.0, "k_fwd_bound": 533.0}
+VALU_FMA_TFLOPS = 157.3          # the guide's fp32 vector peak (every instruction a fused multiply-add)
 # HBM bytes per lane-row from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE corrected by the factor
 # calibrated with scripts/fetch_calib.py on the slab access pattern (profiles/round2_fetch_calibration.md)
-PMC_BYTES_PER_ROW = None         # filled from profiles/round2_pmc_bytes_per_row.json when present
+PMC_BYTES_PER_ROW = None         # filled from profiles/round4_pmc_bytes_per_row.json (this round's kernels) when present
+PMC_SOURCE = None
 
 
 def _load_pmc():
-    global PMC_BYTES_PER_ROW
-    p = os.path.join(ROOT, "profiles", "round2_pmc_bytes_per_row.json")
-    if os.path.exists(p):
-        with open(p) as f:
-            PMC_BYTES_PER_ROW = json.load(f)
+    global PMC_BYTES_PER_ROW, PMC_SOURCE
+    for name in ("round4_pmc_bytes_per_row.json", "round2_pmc_bytes_per_row.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            with open(p) as f:
+                PMC_BYTES_PER_ROW = json.load(f)
+            PMC_SOURCE = "profiles/" + name
+            return
 
 
 CFG4_DEFAULT = 2000000           # reads of a default `--workload cfg4` run (configs[4]'s per-GPU share is 12.5 M: --reads 12500000)
@@ -288,9 +293,14 @@ def main():
                     help="T = the stand-in taxon (155 ITS2 profiles); all = --taxa All --region ITS2 (814 profiles, configs[3])")
     ap.add_argument("--global-derep", action="store_true",
                     help="N > 1: match the uniques across shards (exact global dereplication, SURVEY 8e option 2) instead of per-shard")
-    ap.add_argument("--full-rows", action="store_true",
-                    help="keep every domain row resident (80 B x ~130 per representative: 66 GB at 10 M reads) instead of only the rows that can "
-                         "still win the argmax (ITSX_COMPACT_ROWS=1, the default here: the step asks for coordinates, not for domtbl.txt)")
+    ap.add_argument("--rows", choices=["lazy", "compact", "full"], default="lazy",
+                    help="what the search keeps of the domain table (itsx_set_rows_mode): lazy = pairs that cannot win ItsPosition's argmax "
+                         "are not evaluated past their Forward score (the default: the step asks for coordinates, not for domtbl.txt); compact = "
+                         "every pair evaluated, only the rows that can still win kept; full = every row resident (66 GB at 10 M reads)")
+    ap.add_argument("--full-rows", action="store_true", help="= --rows full")
+    ap.add_argument("--full-steps", type=int, default=1,
+                    help="with --rows lazy: this many extra steps with every pair evaluated (--rows compact), after the timed ones and outside "
+                         "`value`: `full_pipeline_value`, and the lazy coordinates are compared with them for equality (0 = skip)")
     ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -322,10 +332,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     cdev = dev if os.environ.get("ITSX_BENCH_BACKEND", "nccl") == "nccl" else torch.device("cpu")     # where the bench's own scalars are reduced
 
-    if not args.full_rows:
-        os.environ.setdefault("ITSX_COMPACT_ROWS", "1")
+    if args.full_rows:
+        args.rows = "full"
     from itsxpress_amd import Engine
-    from itsxpress_amd.dist import allreduce_domz_device, exchange_rows, gather_rows, global_derep, read_rows
+    from itsxpress_amd.dist import exchange_and_finalize, exchange_rows, gather_rows, global_derep, read_rows
     import synth
     _load_pmc()
 
@@ -364,11 +374,12 @@ def main():
     t_gen = time.time() - t_gen
     mean_len = float(offs[-1]) / max(n_local, 1)
     eng = Engine(local_rank)
+    eng.set_rows_mode(args.rows)
     nprof = eng.load_profiles(text=hmm)
     d_blob = torch.from_numpy(blob).to(dev)      # the batch's ASCII text, resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    comm = {"allreduce_ms": 0.0, "gather_ms": 0.0}
+    comm = {"allreduce_ms": 0.0, "gather_ms": 0.0, "lazy_reruns": 0}
 
     def step(from_host=False):
         if from_host:
@@ -380,15 +391,17 @@ def main():
         else:
             eng.derep(strand_both=True, minseqlength=1)
         g = global_derep(eng, n_local, cdev) if (use_dist and args.global_derep) else None
-        eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
+        search = lambda: eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
+        search()
         if not use_dist:
-            eng.finalize(domE=10.0)
+            eng.finalize(domE=10.0)                   # (a lazy search with undecided rows repeats itself in full in here)
             return [eng.trim_coords(lp, rp)]          # (start, stop, tlen, index) per read, on the host
         # N > 1: the two exchanges run on the engine's own device buffers (RCCL over xGMI), nothing bounces through numpy
         tc = time.perf_counter()
-        allreduce_domz_device(eng, dev)                # hmmsearch's domZ is a count over the WHOLE data set (returns once the reduction has landed)
+        # hmmsearch's domZ is a count over the WHOLE data set (after a lazy search: its bounds); thresholds; a full search on
+        # every rank if some rank's rows stay undecided
+        comm["lazy_reruns"] += 1 if exchange_and_finalize(eng, dev, 10.0, search) > 0 else 0
         comm["allreduce_ms"] += (time.perf_counter() - tc) * 1e3
-        eng.finalize(domE=10.0)
         if g is not None:            # coordinates of the uniques scored elsewhere arrive here, then fan out to the reads
             rows = read_rows(eng, exchange_rows(g, eng.rep_coords_device(lp, rp, dev)), dev)
         else:
@@ -458,6 +471,40 @@ def main():
         total_local = n_local
     st = eng.stats()
 
+    # the same step with EVERY pair evaluated (--rows compact), outside `value`: what the lazy stage saves, and that it changes nothing
+    full_leg = None
+    if args.rows == "lazy" and args.full_steps > 0 and args.cluster_id >= 1.0:
+        left = torch.tensor([args.budget_s - (time.time() - T_START)], dtype=torch.float64, device=cdev)
+        if use_dist:
+            dist.all_reduce(left, op=dist.ReduceOp.MIN)
+        if float(left.item()) < args.full_steps * 3.0 * dt / max(args.steps, 1) + 30.0:
+            full_leg = {"skipped": "wall-clock budget (--budget-s %.0f)" % args.budget_s}
+        else:
+            lazy_rows = np.stack(out[0], axis=1) if (out is not None and isinstance(out[0], tuple)) else (np.concatenate(out) if out is not None else None)
+            eng.set_rows_mode("compact")
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            fout = None
+            for _ in range(args.full_steps):
+                progress("full-pipeline step (every pair evaluated)")
+                fout = step()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            tfull = time.perf_counter() - tf0
+            stf = eng.stats()
+            eng.set_rows_mode(args.rows)
+            if use_dist:
+                t = torch.tensor([tfull], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                tfull = float(t.item())
+            full_leg = {"steps": args.full_steps, "ms_per_step": tfull / args.full_steps * 1e3, "pairs_past_fwd": int(stf["n_past_fwd"]), "domains": int(stf["n_domains"])}
+            if rank == 0 and fout is not None:
+                full_rows = np.stack(fout[0], axis=1) if isinstance(fout[0], tuple) else np.concatenate(fout)
+                full_leg["coordinates_equal_lazy"] = bool(lazy_rows.shape == full_rows.shape and np.array_equal(lazy_rows, full_rows))
+
     # the same step fed from the host buffer (PCIe-inclusive), never part of `value`
     handover = None
     step_s = dt / max(args.steps, 1)
@@ -496,7 +543,7 @@ def main():
         total_reads = total_local * args.steps
         value = total_reads / dt
         K = args.steps
-        kern = {"k_msv": acc["ms_msv_kernel"] / K, "k_filters_fwd": acc["ms_fwd_kernel"] / K,
+        kern = {"k_msv": acc["ms_msv_kernel"] / K, "k_fwd_bound": acc.get("ms_bound_kernel", 0.0) / K, "k_filters_fwd": acc["ms_fwd_kernel"] / K,
                 "k_bwd_decode": acc["ms_bwd_kernel"] / K, "k_decode": acc["ms_decode_kernel"] / K,
                 "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K}
         dom = max(kern, key=kern.get)
@@ -505,6 +552,8 @@ def main():
         alg = {
             # a block of 256 representatives re-reads their packed words once per profile (from L2 after the first); 2 B per pair out
             "k_msv": U * wbytes + 2 * nprof * U,
+            # the lazy stage's score-only Forward: per pair the packed read + the pair record in, 4 B out; nothing per row
+            "k_fwd_bound": st["n_past_msv"] * (wbytes + 16 + 4),
             # per pair: packed read + PairRec/PairOut; per row: 6 special-state floats written
             "k_filters_fwd": st["n_past_msv"] * (wbytes + 16 + 40) + st["fwd_rows"] * 24,
             # per row: Forward's 6 floats read, 6 decoding terms written
@@ -516,30 +565,39 @@ def main():
         }
         # what bounds each of them: the DP scans are VALU-bound (no-FMA fp32), the streaming kernels HBM-bound
         rows = st["fwd_rows"]
-        tfl = {k: (rows * FLOPS_PER_ROW[k] / (kern[k] * 1e-3) / 1e12 if kern[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode")}
+        krows = {"k_filters_fwd": rows, "k_bwd_decode": rows, "k_fwd_bound": st["bound_rows"]}
+        tfl = {k: (krows[k] * FLOPS_PER_ROW[k] / (kern[k] * 1e-3) / 1e12 if kern[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode", "k_fwd_bound")}
         vfrac = {
             "k_msv": (st["msv_cells"] / 32.7) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 64 lanes x 45 cells per 88 wave instructions of a row
             "k_filters_fwd": (rows / 64 * VALU_PER_ROW["k_filters_fwd"]) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
             "k_bwd_decode": (rows / 64 * VALU_PER_ROW["k_bwd_decode"]) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
+            "k_fwd_bound": (st["bound_rows"] / 64 * VALU_PER_ROW["k_fwd_bound"]) / (kern["k_fwd_bound"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_fwd_bound"] > 0 else None,
         }
         kernel_table = {k: {"ms": round(kern[k], 3), "alg_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) if kern[k] > 0 else None,
                             "hbm_frac": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern[k] > 0 else None,
                             "nofma_tflops": round(tfl[k], 2) if tfl.get(k) else None,
                             "valu_issue_frac": round(vfrac[k], 3) if vfrac.get(k) else None} for k in kern}
         # launches of the dominant kernel in one step, for per-launch figures
-        nl = {"k_msv": max(1, int(st.get("msv_launches", 1)))}.get(dom, max(1, int(st.get("n_batches", 1))))
+        nl = {"k_msv": max(1, int(st.get("msv_launches", 1))), "k_fwd_bound": max(1, int(st.get("n_bound_launches", 1)))}.get(dom, max(1, int(st.get("n_batches", 1))))
         traffic = None
         if PMC_BYTES_PER_ROW and dom in PMC_BYTES_PER_ROW:
-            traffic = PMC_BYTES_PER_ROW[dom] * rows / nl
+            traffic = PMC_BYTES_PER_ROW[dom] * krows.get(dom, rows) / nl
+        # SURVEY 8d's algorithmic bytes of the WHOLE path per step: per read ceil(L / 4) + 48, per unique the packed words once per profile tile
+        survey_bytes = n_local * (-(-mean_len // 4) + 48.0) + U * wbytes
         if dom in tfl and tfl[dom]:
             roof = {"kernel": dom, "bound": "valu", "achieved": round(tfl[dom], 3), "peak": round(VALU_NOFMA_TFLOPS, 1), "unit": "TFLOP/s",
-                    "frac": tfl[dom] / VALU_NOFMA_TFLOPS, "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl,
-                    "alg_flops_per_launch": rows * FLOPS_PER_ROW[dom] / nl, "alg_flops_per_lane_row": FLOPS_PER_ROW[dom], "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
+                    "frac": tfl[dom] / VALU_NOFMA_TFLOPS, "frac_of_fma_peak": tfl[dom] / VALU_FMA_TFLOPS, "fma_peak": VALU_FMA_TFLOPS,
+                    "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl,
+                    "alg_flops_per_launch": krows[dom] * FLOPS_PER_ROW[dom] / nl, "alg_flops_per_lane_row": FLOPS_PER_ROW[dom], "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
                     "hbm_frac_on_alg_bytes": alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic_source": PMC_SOURCE if traffic is not None else None,
+                    "survey_bytes_per_step": survey_bytes,
+                    "traffic_vs_survey_bytes": (traffic * nl / survey_bytes) if traffic is not None else None,
                     "note": "a serial recurrence per (representative, profile): the recurrence's own no-FMA fp32 flops per lane-row (HMMER rounds "
                             "products and sums separately; Forward 960, Backward 1056 with its four unconditional DD passes: the count is "
                             "spelled out at the top of bench.py) against 78.6 TFLOP/s = 1024 SIMDs x 32 lanes x 2.4 GHz; duration = HIP events on the "
-                            "engine's stream; traffic = PMC bytes per lane-row x rows per launch (profiles/round2_*).  "
+                            "engine's stream; traffic = PMC bytes per lane-row x rows per launch (traffic_source); traffic_vs_survey_bytes = the kernel's HBM traffic per step "
+                            "over SURVEY 8d's algorithmic bytes of the whole path.  "
                             "hbm_frac_on_alg_bytes / alg_bytes_per_launch count the DP slab rows (24 B written + 24 B read per lane-row) as the kernel's "
                             "algorithmic bytes: a cost of this design (rows handed from Forward to Backward to the decoder through HBM), ~14 000 x "
                             "SURVEY 8d's per-read bytes for the whole path -- beside the kernel's VALU bound, not a measure of efficiency"}
@@ -570,7 +628,16 @@ def main():
                        "unique": int(st["n_unique"]), "pairs_past_msv": int(st["n_past_msv"]), "pairs_past_fwd": int(st["n_past_fwd"]),
                        "domains": int(st["n_domains"]), "domain_rows_resident": int(st["n_rows_resident"]),
                        "domain_rows_resident_GB": round(st["n_rows_resident"] * 80 / 1e9, 2), "reads_trimmed_rank0": trimmed,
+                       "domain_stage": {"lazy": "lazy (exact): pairs that cannot win ItsPosition's argmax stop after their Forward score", "compact": "every pair evaluated, rows compacted",
+                                        "full": "every pair evaluated, every row resident"}[args.rows] if not st["n_lazy_reruns"] else "lazy -> repeated in full (rows depended on the exact domZ)",
+                       "pairs_evaluated": int(st["n_lazy_evaluated"]) if st["lazy"] else int(st["n_past_msv"]),
+                       "pairs_evaluated_round1": int(st["n_lazy_round1"]) if st["lazy"] else None,
+                       "undecided_rows_that_mattered": int(st["n_lazy_pending"]) if st["lazy"] else None,
+                       "profiles_counted_exactly": int(st["n_lazy_completed_profiles"]) if st["lazy"] else None,
+                       "pairs_of_those_profiles": int(st["n_lazy_completed"]) if st["lazy"] else None,
                        "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
+            "full_pipeline": full_leg,
+            "full_pipeline_value": (total_local * full_leg["steps"] / (full_leg["ms_per_step"] * 1e-3 * full_leg["steps"])) if (full_leg and "ms_per_step" in full_leg) else None,
             "timed_region": "ASCII text resident in HBM -> device 2-bit packing -> derep -> MSV -> Forward/Backward -> domains -> "
                             "thresholds -> per-read coordinates on the host (+ all-reduce / gather at N > 1)",
             "host_handover": handover,
@@ -615,6 +682,7 @@ def main():
             progress("CPU baseline done in %.1f s" % cdt)
             # trim-coordinate concordance (BASELINE metric): the engine on the very same sample against the baseline path
             e2 = Engine(local_rank)
+            e2.set_rows_mode(args.rows)                   # the benchmarked configuration is the one compared
             e2.load_profiles(text=hmm)
             e2.set_reads_buffer(np.ascontiguousarray(blob[:int(offs[m])]), offs[:m + 1])
             if args.cluster_id < 1.0:

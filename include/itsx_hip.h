@@ -116,6 +116,9 @@ typedef struct {
    * depended on the exact domZ and could have changed a result (then the search was repeated in full: n_lazy_reruns);
    * lane-rows and launches of the score-only Forward pass, its time and the selection's */
   int32_t lazy;              int32_t n_bound_launches;
+  int64_t n_lazy_pending_profiles;                      /* distinct profiles among the undecided rows that mattered */
+  int64_t n_lazy_completed, n_lazy_completed_profiles;  /* itsx_lazy_complete: pairs of the profiles counted exactly, and those profiles */
+  float   ms_lazy_complete;  int32_t pad5;
   int64_t n_lazy_evaluated, n_lazy_round1, n_lazy_pending, n_lazy_reruns, bound_rows;
   float   ms_bound_kernel, ms_lazy_select;
 } itsx_stats;
@@ -247,12 +250,16 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3);
  * After a LAZY search hmmsearch's domZ is known by bounds only: itsx_get_domz / itsx_set_domz / itsx_domz_device move
  * itsx_domz_count() = 2 x n_samples x n_profiles counters (lower bounds, then upper bounds; a multi-rank driver sums both).
  * itsx_search_finalize decides every row both bounds decide alike.  itsx_lazy_pending() = rows left undecided that could change
- * a coordinate: when nobody exchanged counters the context repeats the search with every pair evaluated by itself; a multi-rank
- * driver (counters exchanged) takes the maximum over ranks and, if positive, repeats search + exchange + finalize in
- * ITSX_ROWS_COMPACT on every rank (itsx_trim_coords refuses until then). */
+ * a coordinate (itsx_trim_coords refuses while it is positive): see itsx_lazy_complete. */
 enum { ITSX_ROWS_FULL = 0, ITSX_ROWS_COMPACT = 1, ITSX_ROWS_LAZY = 2 };
 int itsx_set_rows_mode(itsx_ctx *ctx, int mode);
 int64_t itsx_lazy_pending(const itsx_ctx *ctx);
+/* The profiles of the undecided rows (flags[n_profiles], 1 = some row of this profile is pending), and the cure: itsx_lazy_complete
+ * sends EVERY pair of the flagged profiles through the domain pipeline, after which their counters are exact (lower == upper) and
+ * every row of theirs is decided.  Alone, itsx_search_finalize does this by itself; a multi-rank driver ORs the flags over the
+ * ranks, completes on every rank, exchanges the counters again and finalizes again. */
+int itsx_lazy_pending_profiles(const itsx_ctx *ctx, int32_t *flags);
+int itsx_lazy_complete(itsx_ctx *ctx, const int32_t *flags);
 int64_t itsx_domz_count(const itsx_ctx *ctx);
 int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ /* [itsx_domz_count]: [n_samples][n_profiles] (x 2 after a lazy search) */);
 int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ /* same */);

@@ -244,8 +244,12 @@ struct itsx_ctx {
   int64_t lazy_pending = 0;              // undecided rows that could change a result, after the last lazy finalize
   double sF1 = 1e-6, sF3 = 1e-6;         // the last search's thresholds (finalize may have to repeat it in full)
   std::vector<int64_t> domz_ub;          // [S][P] pairs past the MSV filter: an upper bound of hmmsearch's domZ
+  std::vector<int64_t> domz_loc, domz_ub_loc;   // this context's own counters (domz / domz_ub hold what finalize uses: the same, or the ranks' sums)
+  bool completing = false;               // itsx_lazy_complete: every pair of the profiles in plist goes through the domain pipeline
+  std::vector<int32_t> h_plist; DBuf<int32_t> d_plist;
+  int64_t s_Uc = 0; int s_Lcap = 0;       // the last search's chunk size and length cap (the completion walks the same chunks)
   DBuf<float> l_fb; DBuf<uint32_t> l_b10; DBuf<uint8_t> l_done; DBuf<int32_t> l_flag, l_pos, l_scan, l_has; DBuf<unsigned long long> l_gtop, l_sure;
-  DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub;
+  DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub; DBuf<int32_t> l_pflag; std::vector<int32_t> lazy_pending_prof;
   DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
   std::vector<int32_t> h_sorted_active;  // the length-sorted list the HMM stages walk (= h_sorted_uniq unless itsx_set_active_uniques narrowed it)
   DBuf<LenTables> d_lt;
@@ -1265,6 +1269,23 @@ static float msv_score_from_byte(int xj, int tjb)
 static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, double T, double F1, double F3);
 static int append_traces(itsx_ctx *ctx);
 
+// the active uniques, chunk by chunk (s_Uc uniques at a time), through search_chunk
+static int run_chunks(itsx_ctx *ctx, double T, double F1, double F3)
+{
+  const int64_t U = ctx->U_active, Uc = std::max<int64_t>(1, ctx->s_Uc);
+  int ci = 0;
+  if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));      // a search that failed half-way may have left an MSV launch behind
+  ctx->msv_pre_u0 = -1;
+  for (int64_t u0 = 0; u0 < U; u0 += Uc, ci++) {
+    ctx->next_u0 = (u0 + Uc < U) ? u0 + Uc : -1;
+    ctx->next_U = (int32_t)std::min<int64_t>(Uc, U - (u0 + Uc));
+    const int rc = search_chunk(ctx, ci, (int32_t)u0, (int32_t)std::min<int64_t>(Uc, U - u0), ctx->s_Lcap, T, F1, F3);
+    if (rc != ITSX_OK) return rc;
+  }
+  ctx->n_chunks = ci;
+  return ITSX_OK;
+}
+
 int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
 {
   CTXCHK(ctx);
@@ -1294,7 +1315,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->lazy = mode == ITSX_ROWS_LAZY;
   ctx->lazy_pending = 0; ctx->domz_exchanged = false; ctx->sF1 = F1; ctx->sF3 = F3;
   ctx->domz_ub.assign((size_t)P * ctx->S, 0);
-  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
+  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
   if (ctx->compact_rows && U > 0) {
     ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
     if (const char *e = getenv("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
@@ -1384,20 +1405,14 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   Uc = std::min<int64_t>(Uc, ((1ll << 31) - 4096) / std::max(Ppad, 1));
   if (const char *e = getenv("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
   ctx->keep_trace = getenv("ITSX_KEEP_TRACE") != nullptr;
-  int ci = 0;
-  if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));      // a search that failed half-way may have left an MSV launch behind
-  ctx->msv_pre_u0 = -1;
-  for (int64_t u0 = 0; u0 < U; u0 += Uc, ci++) {
-    ctx->next_u0 = (u0 + Uc < U) ? u0 + Uc : -1;
-    ctx->next_U = (int32_t)std::min<int64_t>(Uc, U - (u0 + Uc));
-    const int rc = search_chunk(ctx, ci, (int32_t)u0, (int32_t)std::min<int64_t>(Uc, U - u0), Lcap, T, F1, F3);
-    if (rc != ITSX_OK) return rc;
-  }
-  ctx->n_chunks = ci;
+  ctx->s_Uc = Uc; ctx->s_Lcap = Lcap;
+  ctx->domz_ub_loc.assign((size_t)P * ctx->S, 0);
+  { const int rc = run_chunks(ctx, T, F1, F3); if (rc != ITSX_OK) return rc; }
   std::vector<int32_t> dz32((size_t)P * ctx->S, 0);
   HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  for (size_t p = 0; p < dz32.size(); p++) ctx->domz[p] = dz32[p];
+  ctx->domz_loc.assign(dz32.begin(), dz32.end());
+  ctx->domz = ctx->domz_loc; ctx->domz_ub = ctx->domz_ub_loc;
   S.n_rows_resident = 0;
   for (int64_t r : ctx->dom_n) S.n_rows_resident += r;
   // Refuse, don't cap: hmmsearch has no limit on envelopes per target or on the bookkeeping of a region's traceback ensemble.
@@ -1961,7 +1976,11 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     // blocks of 256 sequences x PB profiles: a few thousand blocks at least, and up to 32 profiles per block so that a
     // large job re-reads its sequences' packed words (from L2) 32 times less often than it has profiles
     const int64_t tiles = ((int64_t)cU + 255) / 256;
-    a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * P / 4096));
+    if (ctx->completing) {           // only the listed profiles are filtered; every other row of res must read "not passed"
+      a.plist = ctx->d_plist.p; a.nlist = (int32_t)ctx->h_plist.size();
+      (void)hipMemsetAsync(d_res.p, 0, (size_t)Ppad * (size_t)cU * sizeof(uint16_t), s);
+    }
+    a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * (a.plist ? a.nlist : P) / 4096));
     launch_msv(a, s, lds_pad);
   };
   if (ctx->msv_pre_u0 == (int64_t)u0) {
@@ -1990,7 +2009,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   HIPCHK(hipMemcpyAsync(total.data(), d_total.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   std::vector<int64_t> seg_start((size_t)P + 1, 0);
-  for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; S.n_past_msv += total[p]; }
+  for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; if (ctx->completing) S.n_lazy_completed += total[p]; else S.n_past_msv += total[p]; }
   const int64_t NP = seg_start[P];
   ctx->npairs_padded = ctx->lazy ? 0 : NP;
   if (NP == 0) { S.ms_msv += tm_list.stop(); ctx->dom_n.push_back(0); while (ctx->dom_bufs.size() < ctx->dom_n.size()) ctx->dom_bufs.emplace_back(new DBuf<itsx_domain>()); return ITSX_OK; }
@@ -1999,16 +2018,19 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   HIPCHK(upload(d_seg_start, seg_start, st));
   HIPCHK(ctx->d_pairs.alloc((size_t)NP));
   HIPCHK(hipMemsetAsync(ctx->d_pairs.p, 0xFF, (size_t)NP * sizeof(PairRec), st));
-  if (!ctx->lazy) {                                // (the lazy stage keeps a PairOut only for the pairs it evaluates)
+  const bool lazy_now = ctx->lazy && !ctx->completing;
+  if (!lazy_now) {                                 // (the lazy stage keeps a PairOut only for the pairs it evaluates)
     HIPCHK(ctx->d_pout.alloc((size_t)NP));
     HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)NP * sizeof(PairOut), st));
   }
   launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p + u0, ctx->d_pairs.p, st);
   S.ms_msv += tm_list.stop();
-  for (int p = 0; p < P; p++)                     // an upper bound of hmmsearch's domZ: every reported target is a pair past the MSV filter
-    for (int32_t sm = 0; sm < ctx->S; sm++) ctx->domz_ub[(size_t)sm * P + p] += total[p];
+  const int64_t zub_scale = getenv("ITSX_LAZY_ZUB_SCALE") ? std::max<int64_t>(1, atoll(getenv("ITSX_LAZY_ZUB_SCALE"))) : 1;   // test hook: looser bounds, more undecided rows
+  if (!ctx->completing)
+    for (int p = 0; p < P; p++)                   // an upper bound of hmmsearch's domZ: every reported target is a pair past the MSV filter
+      for (int32_t sm = 0; sm < ctx->S; sm++) ctx->domz_ub_loc[(size_t)sm * P + p] += (int64_t)total[p] * zub_scale;
   PairList pl;
-  pl.pairs = ctx->d_pairs.p; pl.pout = ctx->lazy ? nullptr : ctx->d_pout.p; pl.NP = NP; pl.seg_start = seg_start; pl.total = total; pl.d_seg_start = d_seg_start.p;
+  pl.pairs = ctx->d_pairs.p; pl.pout = lazy_now ? nullptr : ctx->d_pout.p; pl.NP = NP; pl.seg_start = seg_start; pl.total = total; pl.d_seg_start = d_seg_start.p;
   // the next chunk's MSV filter on the second stream (its result buffer is free: this chunk's survivor list is built)
   const std::function<int()> next_msv = [&]() -> int {
     static const bool msv_overlap = !(getenv("ITSX_MSV_OVERLAP") && atoi(getenv("ITSX_MSV_OVERLAP")) == 0);
@@ -2025,7 +2047,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     }
     return ITSX_OK;
   };
-  if (ctx->lazy) return lazy_rounds(ctx, pl, d_sorted, U, T, F1, F3, &next_msv);
+  if (lazy_now) return lazy_rounds(ctx, pl, d_sorted, U, T, F1, F3, &next_msv);
   { const int rc = domain_pipeline(ctx, pl, d_sorted, T, F1, F3, &next_msv); if (rc != ITSX_OK) return rc; }
   if (ctx->keep_trace) { const int rc = append_traces(ctx); if (rc != ITSX_OK) return rc; }
   return ITSX_OK;
@@ -2039,6 +2061,53 @@ int itsx_set_rows_mode(itsx_ctx *ctx, int mode)
   return ITSX_OK;
 }
 int64_t itsx_lazy_pending(const itsx_ctx *ctx) { return ctx ? ctx->lazy_pending : -1; }
+int itsx_lazy_pending_profiles(const itsx_ctx *ctx, int32_t *flags)
+{
+  CTXCHK(ctx && flags && ctx->have_search);
+  for (int p = 0; p < ctx->P; p++) flags[p] = (ctx->lazy && (size_t)p < ctx->lazy_pending_prof.size()) ? (ctx->lazy_pending_prof[(size_t)p] != 0) : 0;
+  return ITSX_OK;
+}
+// Exact counters for the flagged profiles: EVERY pair of theirs past the MSV filter goes through the domain pipeline (the ones the
+// lazy rounds evaluated already come again -- their rows are duplicates with the same rank key, which changes no argmax), so that the
+// reported targets of these profiles are counted, not bounded.  Afterwards this context's lower and upper counters of the flagged
+// profiles are equal; a multi-rank driver exchanges the counters again before it finalizes.
+int itsx_lazy_complete(itsx_ctx *ctx, const int32_t *flags)
+{
+  CTXCHK(ctx && flags && ctx->have_search);
+  if (!ctx->lazy) SET_ERR(ctx, ITSX_E_ARG, "itsx_lazy_complete: the last search was not a lazy one");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->st;
+  const int P = ctx->P;
+  ctx->h_plist.clear();
+  for (int p = 0; p < P; p++) if (flags[p]) ctx->h_plist.push_back(p);
+  if (ctx->h_plist.empty() || ctx->U_active == 0) return ITSX_OK;
+  StageTimer tm(st);
+  HIPCHK(upload(ctx->d_plist, ctx->h_plist, st));
+  // the flagged profiles are counted afresh (k_score adds one per reported target)
+  std::vector<int32_t> dz32((size_t)P * ctx->S, 0);
+  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int32_t sm = 0; sm < ctx->S; sm++) for (int p : ctx->h_plist) dz32[(size_t)sm * P + p] = 0;
+  HIPCHK(hipMemcpyAsync(ctx->d_domz32.p, dz32.data(), dz32.size() * 4, hipMemcpyHostToDevice, st));
+  ctx->completing = true;
+  const int rc = run_chunks(ctx, ctx->T, ctx->sF1, ctx->sF3);
+  ctx->completing = false;
+  if (rc != ITSX_OK) { ctx->have_search = false; return rc; }
+  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int32_t sm = 0; sm < ctx->S; sm++)
+    for (int p : ctx->h_plist) {
+      const size_t z = (size_t)sm * P + p;
+      ctx->domz_loc[z] = ctx->domz_ub_loc[z] = dz32[z];
+      if (!ctx->domz_exchanged) ctx->domz[z] = ctx->domz_ub[z] = dz32[z];
+    }
+  ctx->have_final = false;
+  ctx->stats.n_lazy_completed_profiles += (int64_t)ctx->h_plist.size();
+  ctx->stats.n_rows_resident = 0;
+  for (int64_t r : ctx->dom_n) ctx->stats.n_rows_resident += r;
+  ctx->stats.ms_lazy_complete += tm.stop();
+  return ITSX_OK;
+}
 
 // After a lazy search the counters are BOUNDS on hmmsearch's domZ: [S][P] reported targets among the evaluated pairs (below),
 // then [S][P] pairs past the MSV filter (above).  itsx_get_domz / itsx_set_domz move the lower half only when the search was
@@ -2046,8 +2115,9 @@ int64_t itsx_lazy_pending(const itsx_ctx *ctx) { return ctx ? ctx->lazy_pending 
 int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ)
 {
   CTXCHK(ctx && domZ && ctx->have_search);
-  for (size_t p = 0; p < ctx->domz.size(); p++) domZ[p] = ctx->domz[p];
-  if (ctx->lazy) for (size_t p = 0; p < ctx->domz_ub.size(); p++) domZ[ctx->domz.size() + p] = ctx->domz_ub[p];
+  // this context's OWN counters (what a multi-rank driver sums), whatever itsx_set_domz / an in-place reduction put in their place
+  for (size_t p = 0; p < ctx->domz_loc.size(); p++) domZ[p] = ctx->domz_loc[p];
+  if (ctx->lazy) for (size_t p = 0; p < ctx->domz_ub_loc.size(); p++) domZ[ctx->domz_loc.size() + p] = ctx->domz_ub_loc[p];
   return ITSX_OK;
 }
 int itsx_set_domz(itsx_ctx *ctx, const int64_t *domZ)
@@ -2068,8 +2138,10 @@ int itsx_domz_device(itsx_ctx *ctx, int64_t **d_domz, int64_t *n)
   HIPCHK(hipSetDevice(ctx->device));
   const size_t m = ctx->domz.size(), mm = m * (ctx->lazy ? 2 : 1);
   HIPCHK(ctx->d_domz64.alloc(std::max<size_t>(mm, 1)));
-  if (m) HIPCHK(hipMemcpyAsync(ctx->d_domz64.p, ctx->domz.data(), m * 8, hipMemcpyHostToDevice, ctx->st));
-  if (m && ctx->lazy) HIPCHK(hipMemcpyAsync(ctx->d_domz64.p + m, ctx->domz_ub.data(), m * 8, hipMemcpyHostToDevice, ctx->st));
+  // (this context's OWN counters: after an exchange ctx->domz holds the ranks' sums, and a second exchange -- after
+  // itsx_lazy_complete -- must not add them up again)
+  if (m) HIPCHK(hipMemcpyAsync(ctx->d_domz64.p, ctx->domz_loc.data(), m * 8, hipMemcpyHostToDevice, ctx->st));
+  if (m && ctx->lazy) HIPCHK(hipMemcpyAsync(ctx->d_domz64.p + m, ctx->domz_ub_loc.data(), m * 8, hipMemcpyHostToDevice, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
   ctx->domz_on_device = true; ctx->domz_exchanged = true;
   *d_domz = ctx->d_domz64.p;
@@ -2094,15 +2166,20 @@ static int finalize_lazy(itsx_ctx *ctx, double domE)
   HIPCHK(hipMemsetAsync(ctx->l_sure.p, 0, ((size_t)U * ncls + 1) * sizeof(unsigned long long), st));
   HIPCHK(hipMemsetAsync(ctx->l_has.p, 0, ((size_t)U + 1) * sizeof(int32_t), st));
   HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 16 * sizeof(int64_t), st));
+  HIPCHK(ctx->l_pflag.alloc((size_t)std::max(ctx->P, 1)));
+  HIPCHK(hipMemsetAsync(ctx->l_pflag.p, 0, (size_t)std::max(ctx->P, 1) * 4, st));
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_finalize_lazy(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, d_dz.p + m, domE, ctx->dev_usample(), ctx->P, st);
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_lazy_sure(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, st);
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
-    if (ctx->dom_n[c] > 0) launch_lazy_pending(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, (unsigned long long *)ctx->w_counters.p, st);
+    if (ctx->dom_n[c] > 0) launch_lazy_pending(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, (unsigned long long *)ctx->w_counters.p, ctx->l_pflag.p, st);
   int64_t pend = 0;
   HIPCHK(hipMemcpyAsync(&pend, ctx->w_counters.p, sizeof(pend), hipMemcpyDeviceToHost, st));
+  ctx->lazy_pending_prof.assign((size_t)std::max(ctx->P, 1), 0);
+  HIPCHK(hipMemcpyAsync(ctx->lazy_pending_prof.data(), ctx->l_pflag.p, (size_t)std::max(ctx->P, 1) * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  { int np = 0; for (int32_t f : ctx->lazy_pending_prof) np += f != 0; ctx->stats.n_lazy_pending_profiles = np; }
   if (getenv("ITSX_LAZY_FORCE_PENDING")) pend += atoll(getenv("ITSX_LAZY_FORCE_PENDING"));      // test hook: exercises the full re-run
   ctx->lazy_pending = pend; ctx->stats.n_lazy_pending = pend;
   return ITSX_OK;
@@ -2126,17 +2203,30 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
   if (ctx->lazy) {
     { const int rc = finalize_lazy(ctx, domE); if (rc != ITSX_OK) return rc; }
     { const int rc = check_compaction(ctx->domz_ub); if (rc != ITSX_OK) return rc; }
-    if (ctx->lazy_pending > 0 && !ctx->domz_exchanged) {
-      // A row whose reporting depends on the exact domZ could change a result.  This context is on its own (nobody exchanged
-      // counters), so it repeats the search with every pair evaluated; a multi-rank driver sees itsx_lazy_pending() > 0 on some
-      // rank and repeats the search on all of them (itsxpress_amd/dist.py: search_and_finalize).
+    if (ctx->lazy_pending > 0 && !ctx->domz_exchanged && !getenv("ITSX_LAZY_NO_RERUN")) {
+      // Rows whose reporting depends on the exact domZ could change a result.  This context is on its own (nobody exchanged
+      // counters): the profiles of those rows are counted exactly (itsx_lazy_complete) and the thresholds applied again; a
+      // multi-rank driver does the same across ranks (itsxpress_amd/dist.py: exchange_and_finalize).
+      const int64_t pend = ctx->lazy_pending;
+      if (!getenv("ITSX_LAZY_NO_COMPLETE")) {
+        std::vector<int32_t> flags(ctx->lazy_pending_prof);
+        flags.resize((size_t)std::max(ctx->P, 1), 0);
+        { const int rc = itsx_lazy_complete(ctx, flags.data()); if (rc != ITSX_OK) return rc; }
+        { const int rc = finalize_lazy(ctx, domE); if (rc != ITSX_OK) return rc; }
+        ctx->stats.n_lazy_pending = pend;
+      }
+      if (ctx->lazy_pending == 0) {
+        ctx->stats.ms_finalize = tm.stop();
+        ctx->have_final = true;
+        return ITSX_OK;
+      }
+      // (cannot happen after a completion -- every row of a counted profile is decided --; kept as the safety net: everything in full)
       const int keep = ctx->rows_mode;
       ctx->rows_mode = ITSX_ROWS_COMPACT;
-      const int64_t pend = ctx->lazy_pending;
       const int rc = itsx_search(ctx, ctx->T, ctx->sF1, ctx->F2, ctx->sF3);
       ctx->rows_mode = keep;
       if (rc != ITSX_OK) return rc;
-      ctx->stats.n_lazy_reruns = 1; ctx->stats.n_lazy_pending = pend;
+      ctx->stats.n_lazy_reruns = 1; ctx->stats.n_lazy_pending = pend; ctx->stats.n_lazy_pending_profiles = 0; for (int32_t f : ctx->lazy_pending_prof) ctx->stats.n_lazy_pending_profiles += f != 0;
     } else {
       ctx->stats.ms_finalize = tm.stop();
       ctx->have_final = true;

@@ -152,6 +152,8 @@ struct MsvArgs {
   const int32_t *tjb;           // [Lcap]
   int32_t Lcap;
   uint16_t *res;                // [G*64][U]  bit8 = passed, low byte = xJ (255 = overflow)
+  const int32_t *plist;         // optional: only these profiles (the others' rows of res are left as they are); nullptr = all P
+  int32_t nlist;
 };
 void launch_msv(const MsvArgs &a, hipStream_t st, int lds_pad = 0);
 
@@ -334,6 +336,6 @@ void launch_finalize_lazy(itsx_domain *dom, int64_t n, const int64_t *zlb, const
 // best sure row per (representative, class) and "has a sure row" per representative; then the rows whose status matters
 void launch_lazy_sure(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, unsigned long long *sure, int32_t *has, hipStream_t st);
 void launch_lazy_pending(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, const unsigned long long *sure, const int32_t *has,
-                         unsigned long long *count, hipStream_t st);
+                         unsigned long long *count, int32_t *prof_flag /*[P]: profiles of such rows*/, hipStream_t st);
 
 }  // namespace itsx

@@ -57,10 +57,12 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
   Lw = uni(Lw);
   const int Ppad = a.G * 64;
   const int p0 = blockIdx.y * a.PB;
-  int p1 = p0 + a.PB; if (p1 > a.P) p1 = a.P;
+  const int np = a.plist ? a.nlist : a.P;
+  int p1 = p0 + a.PB; if (p1 > np) p1 = np;
   const int base = 190;
-  for (int p = p0; p < p1; p++) {
-    uint32_t *tb = tab[(p - p0) & 1];
+  for (int pj = p0; pj < p1; pj++) {
+    const int p = a.plist ? uni(a.plist[pj]) : pj;
+    uint32_t *tb = tab[(pj - p0) & 1];
     // every wave is past the barrier of profile p - 1, so none still reads the table of profile p - 2 in this buffer
     for (int i = threadIdx.x; i < 16 * MSV_TW; i += 256) tb[i] = a.etab[(size_t)p * 16 * MSV_TW + i];
     __syncthreads();
@@ -122,8 +124,9 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
 // runs beside another stream's kernels and must leave them their registers
 void launch_msv(const MsvArgs &a, hipStream_t st, int lds_pad)
 {
-  if (a.U <= 0 || a.P <= 0) return;
-  hipLaunchKernelGGL(k_msv, dim3((unsigned)((a.U + 255) / 256), (unsigned)((a.P + a.PB - 1) / a.PB)), dim3(256), (size_t)lds_pad, st, a);
+  const int np = a.plist ? a.nlist : a.P;
+  if (a.U <= 0 || np <= 0) return;
+  hipLaunchKernelGGL(k_msv, dim3((unsigned)((a.U + 255) / 256), (unsigned)((np + a.PB - 1) / a.PB)), dim3(256), (size_t)lds_pad, st, a);
 }
 
 // ---------------------------------------------------------------------------------------

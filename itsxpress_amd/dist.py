@@ -164,6 +164,52 @@ def allreduce_domz_device(engine, device=None):
     return t
 
 
+def exchange_and_finalize(engine, device=None, domE=10.0, search=None):
+    """The step between itsx_search and the coordinates on N ranks: all-reduce the counters where they live, apply the thresholds.
+    After a LAZY search (csrc/k_lazy.hip) the counters are bounds on hmmsearch's domZ; a rank may then hold rows that neither bound
+    decides and that could change a coordinate (engine.lazy_pending()).  The ranks agree on the maximum; if it is positive the
+    profiles of those rows (OR over the ranks) are counted exactly on EVERY rank (engine.lazy_complete: every pair of theirs is
+    evaluated), the counters are exchanged again and the thresholds applied again.  `search` (the callable that runs
+    engine.search with the caller's thresholds) is the safety net should rows stay undecided even then.  Returns the number of
+    pending rows before the completion (0 = nothing had to be completed)."""
+    import torch
+    import torch.distributed as dist
+    allreduce_domz_device(engine, device)
+    engine.finalize(domE=domE)
+    pend = engine.lazy_pending()
+    if dist.is_available() and dist.is_initialized():
+        t = torch.tensor([pend], dtype=torch.int64, device=None if (device is None or _host_backend()) else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pend = int(t.item())
+    if pend > 0:
+        # the profiles of those rows, over all ranks; every rank counts them exactly; the counters meet again
+        f = torch.from_numpy(engine.lazy_pending_profiles().astype(np.int32))
+        if dist.is_available() and dist.is_initialized():
+            if device is not None and not _host_backend():
+                f = f.to(device)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        engine.lazy_complete(f.cpu().numpy())
+        allreduce_domz_device(engine, device)
+        engine.finalize(domE=domE)
+        left = engine.lazy_pending()
+        if dist.is_available() and dist.is_initialized():
+            t = torch.tensor([left], dtype=torch.int64, device=None if (device is None or _host_backend()) else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            left = int(t.item())
+        if left > 0:                       # the safety net (a counted profile leaves no row undecided): everything in full, on every rank
+            if search is None:
+                raise RuntimeError("%d domain rows of the lazy search stayed undecided and no `search` callable was given to repeat it" % left)
+            keep = engine.rows_mode
+            engine.set_rows_mode("compact")
+            try:
+                search()
+                allreduce_domz_device(engine, device)
+                engine.finalize(domE=domE)
+            finally:
+                engine.set_rows_mode(keep)
+    return pend
+
+
 # ------------------------------------------------------------------------------------------------
 # Exact dereplication across shards (SURVEY.md section 8e, option 2): hash-partitioned all-to-all.
 #

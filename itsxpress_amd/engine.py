@@ -50,6 +50,7 @@ class Engine:
         self.n_unique = 0
         self.n_profiles = 0
         self.n_samples = 1
+        self.rows_mode = -1
 
     def close(self):
         if getattr(self, "h", None):
@@ -307,11 +308,24 @@ class Engine:
         same coordinates), None = from the environment (ITSX_ROWS / ITSX_COMPACT_ROWS)."""
         m = {None: -1, "env": -1, "full": 0, "compact": 1, "lazy": 2}.get(mode, mode)
         self._chk(self.L.itsx_set_rows_mode(self.h, int(m)))
+        self.rows_mode = int(m)
 
     def lazy_pending(self):
         """after finalize() of a lazy search whose counters were exchanged: rows that still depend on the exact domZ (> 0: search
         again in "compact" mode on every rank)"""
         return int(self.L.itsx_lazy_pending(self.h))
+
+    def lazy_pending_profiles(self):
+        """int32[n_profiles]: 1 where a pending row belongs to the profile"""
+        f = np.zeros(max(1, self.n_profiles), np.int32)
+        self._chk(self.L.itsx_lazy_pending_profiles(self.h, f.ctypes.data))
+        return f[:self.n_profiles]
+
+    def lazy_complete(self, flags):
+        """count the flagged profiles' reported targets exactly (every pair of theirs is evaluated); then exchange / finalize again"""
+        f = np.ascontiguousarray(flags, np.int32)
+        assert f.size == self.n_profiles
+        self._chk(self.L.itsx_lazy_complete(self.h, f.ctypes.data))
 
     def get_domz(self):
         z = np.zeros(max(1, int(self.L.itsx_domz_count(self.h))), np.int64)      # [sample][profile] (x 2 after a lazy search: lower, upper bounds)

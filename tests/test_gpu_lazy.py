@@ -134,6 +134,50 @@ def test_rows_that_depend_on_domz_trigger_the_full_search(engine, mini_hmm_text,
     assert _same(ref, got2)
 
 
+def test_undecided_rows_are_settled_by_counting_their_profiles(engine, mini_hmm_text, t_hmm_text, monkeypatch):
+    """With loose bounds on domZ (the hook inflates the upper one 500 000-fold, as a data set that much larger would) weak rows stay
+    undecided; the profiles of those that matter are then counted exactly (itsx_lazy_complete: every pair of theirs evaluated) and
+    the coordinates equal the full table's -- without the full search."""
+    rng = np.random.default_rng(37)
+    blob, offs = synth.make_reads(mini_hmm_text, 1500, seed=75, fixed_len=0, len_range=(200, 520))
+    seqs = []
+    for s in synth.to_strings(blob, offs):                   # heavy damage: many reads keep only rows near the Forward filter's threshold
+        if rng.random() < 0.6:
+            s = list(s)
+            for q in rng.choice(len(s), int(len(s) * rng.uniform(0.3, 0.42)), replace=False):
+                s[q] = str(rng.choice(list("ACGT")))
+            s = "".join(s)
+        seqs.append(s)
+    hmm = mini_hmm_text + _its2_subset(t_hmm_text, 25, 25)
+    monkeypatch.setenv("ITSX_LAZY_ZUB_SCALE", "500000")
+    e = engine
+    try:
+        ref, _ = _coords(e, hmm, seqs, "full")
+        got, st = _coords(e, hmm, seqs, "lazy")
+        assert st["n_lazy_pending"] > 0 and st["n_lazy_reruns"] == 0 and st["lazy"] == 1
+        assert 0 < st["n_lazy_completed_profiles"] <= e.n_profiles and st["n_lazy_completed"] > 0
+        assert _same(ref, got)
+        # the multi-rank protocol by hand: counters exchanged, so finalize only reports; flags -> complete -> exchange -> finalize
+        e.set_rows_mode("lazy")
+        e.search()
+        e.set_domz(e.get_domz())
+        e.finalize()
+        assert e.lazy_pending() > 0
+        flags = e.lazy_pending_profiles()
+        assert flags.sum() == st["n_lazy_pending_profiles"] or flags.sum() > 0
+        e.lazy_complete(flags)
+        z = e.get_domz()
+        P = e.n_profiles
+        e.set_domz(z)                       # (one rank: the "sum" is the context's own counters)
+        assert (z[:P][flags > 0] == z[P:][flags > 0]).all()      # counted, not bounded
+        e.finalize()
+        assert e.lazy_pending() == 0
+        got2 = [tuple(a.copy() for a in e.trim_coords(l, r)) for l, r in PAIRS]
+        assert _same(ref, got2)
+    finally:
+        e.set_rows_mode(None)
+
+
 def test_lazy_sample_batches(engine, mini_hmm_text, t_hmm_text):
     """per-sample batching (q2_itsxpress.py:273-333): groups are per representative and a representative belongs to one sample;
     domZ is bounded per (sample, profile)"""

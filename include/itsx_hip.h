@@ -118,7 +118,7 @@ typedef struct {
   int32_t lazy;              int32_t n_bound_launches;
   int64_t n_lazy_pending_profiles;                      /* distinct profiles among the undecided rows that mattered */
   int64_t n_lazy_completed, n_lazy_completed_profiles;  /* itsx_lazy_complete: pairs of the profiles counted exactly, and those profiles */
-  float   ms_lazy_complete;  int32_t pad5;
+  float   ms_lazy_complete;  float lazy_bound_maxdiff;  /* ITSX_LAZY_CHECK_BOUND=1 (tests): largest |bound kernel - HMMER-order Forward| of the last search, nats */
   int64_t n_lazy_evaluated, n_lazy_round1, n_lazy_pending, n_lazy_reruns, bound_rows;
   float   ms_bound_kernel, ms_lazy_select;
 } itsx_stats;
@@ -161,6 +161,9 @@ int itsx_set_reads_device(itsx_ctx *ctx, const void *d_bases, const int64_t *off
                           const char *names, const int64_t *name_offsets);
 /* FASTA or FASTQ file, plain or gzip (.gz): native parser for the same input. */
 int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
+/* One contiguous shard of the same file: records [n shard / n_shards, n (shard + 1) / n_shards) in file order, for a driver that
+ * spreads one sample over several GPUs (itsxpress_amd/multi.py); n_total = records in the file, first = index of the shard's first. */
+int itsx_load_reads_file_shard(itsx_ctx *ctx, const char *path, int32_t shard, int32_t n_shards, int64_t *n_total, int64_t *first, int64_t *n_reads);
 
 /* ---- f4, per-sample batching: the QIIME 2 plugin runs the whole path once per sample
  * (itsxpress/q2_itsxpress.py:273-333: one SeqSample, one vsearch and one hmmsearch process per manifest row), which
@@ -295,11 +298,30 @@ int itsx_trim_coords_device(itsx_ctx *ctx, const char *left_prefix, const char *
 int itsx_rep_coords_device(itsx_ctx *ctx, const char *left_prefix, const char *right_prefix, int32_t **d_rows, int64_t *n_rows);
 int itsx_derep_device(itsx_ctx *ctx, const int32_t **d_rep_of, const int32_t **d_uniq_of, const int8_t **d_strand, const int32_t **d_seed_read);
 int itsx_unique_keys128_device(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, int64_t gidx_base, int64_t **d_tuples, int64_t *n_unique);
+/* the same tuples copied to host memory (tuples[n_unique][4]): for a driver that has no collective library and moves them itself */
+int itsx_unique_keys128(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, int64_t gidx_base, int64_t *tuples);
 
 /* ---- file-compatible outputs (users pass --keeptemp; itsxpress/SeqSample.py:104-105,190) */
 int itsx_write_uc(const itsx_ctx *ctx, const char *path);
 int itsx_write_rep_fasta(const itsx_ctx *ctx, const char *path);
 int itsx_write_domtbl(const itsx_ctx *ctx, const char *path);
+/* The same three files written from ARRAYS (host-only, context-free: csrc/writers_host.cpp), for a driver that spreads ONE sample
+ * over several GPUs and must hand the reference's parsers one uc.txt / rep.fa / domtbl.txt, byte for byte what one GPU writes.
+ * itsx_write_derep_arrays: rep_of[i] = read index of the cluster's seed (-1 dropped), strand[i] = +1 / -1 relative to the seed,
+ *   len[i], names (NULL: r%09d), the seeds' sequences concatenated in input order of the seeds; either path may be NULL.
+ * itsx_write_domtbl_arrays: domain rows from any number of contexts with rep = index into target_names (the global unique list),
+ *   Z = targets searched, domz[n_profiles] = the data set's reported targets per profile, per profile NAME / M / Forward tau, lambda.
+ * itsx_profile_params / itsx_get_unique_seqs: what a driver needs from its contexts to fill those arrays.
+ * Errors: negative code, text from itsx_writers_last_error(). */
+int itsx_write_derep_arrays(const char *uc_path, const char *rep_path, int64_t n, const int64_t *rep_of, const int8_t *strand,
+                            const int32_t *len, const char *names, const int64_t *name_offsets, const char *seed_bases,
+                            const int64_t *seed_offs, int64_t n_seeds);
+int itsx_write_domtbl_arrays(const char *path, const itsx_domain *rows, int64_t n_rows, int64_t Z, const int64_t *domz, int32_t n_profiles,
+                             const char *prof_names, const int64_t *prof_name_offsets, const int32_t *prof_M, const float *prof_tau,
+                             const float *prof_lambda, const char *target_names, const int64_t *target_name_offsets);
+const char *itsx_writers_last_error(void);
+int itsx_profile_params(const itsx_ctx *ctx, int i, int32_t *M, float *evparam6);
+int itsx_get_unique_seqs(itsx_ctx *ctx, char *bases, int64_t cap, int64_t *offsets);
 
 /* labels of the loaded reads in input order (what Dedup.matchdict is keyed by, itsxpress/SeqSample.py:542-562; the paired
  * writer looks R1/R2 records up by them): concatenated into names[cap], offsets[n_reads + 1]; names == NULL fills the

@@ -50,7 +50,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("n_reads_region_cap", "<i8"), ("n_mr_clustered", "<i8"), ("n_mr_failed", "<i8"), ("n_mr_envelopes", "<i8"),
                 ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8"), ("ms_vit_kernel", "<f4"), ("pad4", "<i4"),
                 ("n_mr_fail_kind", "<i8", (8,)), ("n_rows_resident", "<i8"),
-                ("lazy", "<i4"), ("n_bound_launches", "<i4"), ("n_lazy_pending_profiles", "<i8"), ("n_lazy_completed", "<i8"), ("n_lazy_completed_profiles", "<i8"), ("ms_lazy_complete", "<f4"), ("pad5", "<i4"), ("n_lazy_evaluated", "<i8"), ("n_lazy_round1", "<i8"),
+                ("lazy", "<i4"), ("n_bound_launches", "<i4"), ("n_lazy_pending_profiles", "<i8"), ("n_lazy_completed", "<i8"), ("n_lazy_completed_profiles", "<i8"), ("ms_lazy_complete", "<f4"), ("lazy_bound_maxdiff", "<f4"), ("n_lazy_evaluated", "<i8"), ("n_lazy_round1", "<i8"),
                 ("n_lazy_pending", "<i8"), ("n_lazy_reruns", "<i8"), ("bound_rows", "<i8"), ("ms_bound_kernel", "<f4"),
                 ("ms_lazy_select", "<f4")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
@@ -70,7 +70,9 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_io_read", "itsx_io_free", "itsx_io_codecs", "itsx_fastq_ids",
            "itsx_load_reads_files", "itsx_set_samples", "itsx_num_samples", "itsx_select_sample",
            "itsx_io_parallel_inflates", "itsx_get_read_names",
-           "itsx_set_rows_mode", "itsx_lazy_pending", "itsx_domz_count", "itsx_lazy_pending_profiles", "itsx_lazy_complete"]
+           "itsx_set_rows_mode", "itsx_lazy_pending", "itsx_domz_count", "itsx_lazy_pending_profiles", "itsx_lazy_complete",
+           "itsx_load_reads_file_shard", "itsx_unique_keys128", "itsx_write_derep_arrays", "itsx_write_domtbl_arrays",
+           "itsx_writers_last_error", "itsx_profile_params", "itsx_get_unique_seqs"]
 
 
 def lib():
@@ -102,6 +104,13 @@ def lib():
         "itsx_derep_device": (i32, [vp, vp, vp, vp, vp]),
         "itsx_unique_keys128_device": (i32, [vp, C.c_uint64, C.c_uint64, i64, vp, vp]),
         "itsx_load_reads_file": (i32, [vp, cp, vp]),
+        "itsx_load_reads_file_shard": (i32, [vp, cp, i32, i32, vp, vp, vp]),
+        "itsx_unique_keys128": (i32, [vp, C.c_uint64, C.c_uint64, i64, vp]),
+        "itsx_write_derep_arrays": (i32, [cp, cp, i64, vp, vp, vp, vp, vp, vp, vp, i64]),
+        "itsx_write_domtbl_arrays": (i32, [cp, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "itsx_writers_last_error": (cp, []),
+        "itsx_profile_params": (i32, [vp, i32, vp, vp]),
+        "itsx_get_unique_seqs": (i32, [vp, vp, i64, vp]),
         "itsx_derep": (i32, [vp, i32, i32, vp]),
         "itsx_cluster": (i32, [vp, f64, i32, vp]),
         "itsx_get_cluster": (i32, [vp, vp, vp, vp]),

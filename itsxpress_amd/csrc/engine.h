@@ -16,6 +16,7 @@ constexpr int MMAX = 46;        // longest model the MSV kernel holds in registe
 constexpr int MSV_REGS = 23;
 constexpr int MSV_TW = 24;            // dwords per residue code in a profile's MSV emission table (MSV_REGS used)
 constexpr int MAXDOM = 8;       // regions kept per (rep, profile)
+constexpr int BOUND_PAIRS = 23; // k_lazy.hip: pairs of adjacent nodes the bound kernel keeps (2 x 23 = MMAX)
 
 // ---- host-side model (profile configuration happens once per model, on the host, with libm) ----
 struct HostProfile {

@@ -172,7 +172,7 @@ struct itsx_ctx {
   DBuf<DevProfile> d_prof;
   DBuf<uint32_t> d_etab;
   DBuf<int32_t> d_pbias, d_ptec, d_ptbm;
-  DBuf<float> d_flogsum; DBuf<LogTab> d_logtab;
+  DBuf<float> d_flogsum; DBuf<LogTab> d_logtab; DBuf<float> d_btab;
   std::vector<char> generic_q;          // per profile: needs the runtime-Q kernels
 
   // ---- reads
@@ -436,6 +436,32 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
       for (int x = 0; x < NCODE; x++) for (int k = 0; k <= h.M; k++) t[(8 + x) * (MMAX + 1) + k] = h.rww[(size_t)x * (h.M + 1) + k];
     }
     HIPCHK(upload(ctx->d_vtab, vt, ctx->st));
+  }
+  {   // the bound kernel's transitions by pair of nodes (k_lazy.hip: k_fwd_bound): record j = pair j's early half, pair j - 1's late half
+    std::vector<float> bt((size_t)std::max(P, 1) * (BOUND_PAIRS + 1) * 16, 0.0f);
+    for (int i = 0; i < P; i++) {
+      const DevProfile &d = dp[i];
+      const int K = 4 * ctx->profs[i].Q;                                      // slots of the striped layout (transitions beyond them: 0)
+      auto tn = [&](int k, int t) { return (k >= 1 && k <= K) ? d.tfn[k * 8 + t] : 0.0f; };
+      for (int j = 0; j <= BOUND_PAIRS; j++) {
+        float *o = bt.data() + ((size_t)i * (BOUND_PAIRS + 1) + j) * 16;
+        if (j < BOUND_PAIRS) {
+          const int k1 = 2 * j + 1, k2 = 2 * j + 2;
+          o[0] = tn(k1 + 1, 1); o[1] = tn(k2 + 1, 1);      // M_k -> M_k+1 (tf stores it at the target node)
+          o[2] = tn(k1 + 1, 2); o[3] = tn(k2 + 1, 2);      // I_k -> M_k+1
+          o[4] = tn(k1 + 1, 3); o[5] = tn(k2 + 1, 3);      // D_k -> M_k+1
+          o[6] = tn(k1, 5); o[7] = tn(k2, 5);              // M_k -> I_k
+          o[8] = tn(k1, 6); o[9] = tn(k2, 6);              // I_k -> I_k
+        }
+        if (j > 0) {
+          const int k1 = 2 * (j - 1) + 1, k2 = 2 * (j - 1) + 2;
+          o[10] = tn(k1, 0); o[11] = tn(k2, 0);            // B -> M_k
+          o[12] = tn(k1, 4); o[13] = tn(k2, 4);            // M_k -> D_k+1
+          o[14] = tn(k1 - 1, 7); o[15] = tn(k1, 7);        // D_k1-1 -> D_k1 (0 before node 1), D_k1 -> D_k2
+        }
+      }
+    }
+    HIPCHK(upload(ctx->d_btab, bt, ctx->st));
   }
   HIPCHK(upload(ctx->d_prof, dp, ctx->st));
   HIPCHK(upload(ctx->d_etab, etab, ctx->st));
@@ -795,6 +821,35 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
     fprintf(stderr, "[itsx] load %s: read+inflate %.0f ms, parse %.0f ms, upload+pack %.0f ms\n", path, ms(tt0, tt1), ms(tt1, tt2), ms(tt2, std::chrono::steady_clock::now()));
   }
   return rc;
+}
+
+// One shard of a file's reads: records [n shard / n_shards, n (shard + 1) / n_shards) in file order (input order is kept inside a
+// shard: first-occurrence representatives depend on it).  Every worker of a multi-GPU run parses the file itself (the decompressed
+// text is cached per process) and keeps its own slice.
+int itsx_load_reads_file_shard(itsx_ctx *ctx, const char *path, int32_t shard, int32_t n_shards, int64_t *n_total, int64_t *first, int64_t *n_reads)
+{
+  CTXCHK(ctx && path);
+  if (n_shards < 1 || shard < 0 || shard >= n_shards) SET_ERR(ctx, ITSX_E_ARG, "itsx_load_reads_file_shard: shard out of range");
+  std::string rerr;
+  const auto tp = slurp(path, true, rerr);
+  if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
+  ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
+  { const int prc = parse_fastx_append(ctx, *tp); if (prc != ITSX_OK) return prc; }
+  const int64_t tot = (int64_t)ctx->h_names.size();
+  const int64_t lo = tot * shard / n_shards, hi = tot * (shard + 1) / n_shards;
+  if (lo > 0 || hi < tot) {
+    const int64_t b0 = ctx->h_off[(size_t)lo], b1 = ctx->h_off[(size_t)hi];
+    std::string bases = ctx->h_bases.substr((size_t)b0, (size_t)(b1 - b0));
+    std::vector<int64_t> off((size_t)(hi - lo) + 1);
+    for (int64_t r = lo; r <= hi; r++) off[(size_t)(r - lo)] = ctx->h_off[(size_t)r] - b0;
+    std::vector<std::string> names(ctx->h_names.begin() + lo, ctx->h_names.begin() + hi);
+    ctx->h_bases.swap(bases); ctx->h_off.swap(off); ctx->h_names.swap(names);
+  }
+  ctx->N = hi - lo;
+  if (n_total) *n_total = tot;
+  if (first) *first = lo;
+  if (n_reads) *n_reads = ctx->N;
+  return pack_and_upload(ctx);
 }
 
 // ---- per-sample batching (q2_itsxpress.py:273-333 runs the whole path once per sample)
@@ -1315,7 +1370,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->lazy = mode == ITSX_ROWS_LAZY;
   ctx->lazy_pending = 0; ctx->domz_exchanged = false; ctx->sF1 = F1; ctx->sF3 = F3;
   ctx->domz_ub.assign((size_t)P * ctx->S, 0);
-  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
+  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.lazy_bound_maxdiff = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
   if (ctx->compact_rows && U > 0) {
     ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
     if (const char *e = getenv("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
@@ -1904,10 +1959,34 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     int nfast = 0; while (nfast < NW && !wgeneric[(size_t)nfast]) nfast++;
     StageTimer tm(st);
     // launches of at most 2^20 waves: the timers of bench.py's roofline block want more than one sample
-    for (int w0 = 0; w0 < nfast; w0 += 1 << 20) { launch_fwd_bound(a, ctx->l_fb.p, std::min(1 << 20, nfast - w0), w0, 0, st); S.n_bound_launches++; }
-    if (NW > nfast) { launch_fwd_bound(a, ctx->l_fb.p, NW - nfast, nfast, 1, st); S.n_bound_launches++; }
+    static const bool exact_bound = getenv("ITSX_LAZY_EXACT_BOUND") && atoi(getenv("ITSX_LAZY_EXACT_BOUND")) != 0;     // A/B: HMMER's own Forward as the bound pass
+    if (!exact_bound) {
+      for (int w0 = 0; w0 < NW; w0 += 1 << 20) { launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->l_fb.p, std::min(1 << 20, NW - w0), w0, st); S.n_bound_launches++; }
+    } else {
+      for (int w0 = 0; w0 < nfast; w0 += 1 << 20) { launch_fwd_bound(a, ctx->l_fb.p, std::min(1 << 20, nfast - w0), w0, 0, st); S.n_bound_launches++; }
+      if (NW > nfast) { launch_fwd_bound(a, ctx->l_fb.p, NW - nfast, nfast, 1, st); S.n_bound_launches++; }
+    }
     const float ms = tm.stop();
     S.ms_bound_kernel += ms; S.ms_filters += ms;
+    if (getenv("ITSX_LAZY_CHECK_BOUND") && !exact_bound) {      // test hook: the fast kernel's scores against HMMER's own arithmetic
+      DBuf<float> ref;
+      HIPCHK(ref.alloc((size_t)NP + 1));
+      for (int w0 = 0; w0 < nfast; w0 += 1 << 20) launch_fwd_bound(a, ref.p, std::min(1 << 20, nfast - w0), w0, 0, st);
+      if (NW > nfast) launch_fwd_bound(a, ref.p, NW - nfast, nfast, 1, st);
+      std::vector<float> h0((size_t)NP), h1((size_t)NP); std::vector<PairRec> hp((size_t)NP);
+      HIPCHK(hipMemcpyAsync(h0.data(), ref.p, (size_t)NP * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(h1.data(), ctx->l_fb.p, (size_t)NP * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(hp.data(), pl.pairs, (size_t)NP * sizeof(PairRec), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      float mx = S.lazy_bound_maxdiff;
+      for (int64_t i = 0; i < NP; i++) {
+        if (hp[(size_t)i].prof < 0) continue;
+        const float x = h0[(size_t)i], y = h1[(size_t)i];
+        if (x != x || y != y) { if ((x != x) != (y != y)) mx = 1e30f; continue; }
+        mx = std::max(mx, fabsf(x - y));
+      }
+      S.lazy_bound_maxdiff = mx;
+    }
     for (int w = 0; w < NW; w++) S.bound_rows += (int64_t)(rows[(size_t)w] - 1) * waves[(size_t)w].count;
   }
   StageTimer tm_sel(st);
@@ -2679,6 +2758,45 @@ int itsx_unique_keys128_device(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, 
 }
 int itsx_rep_coords(itsx_ctx *ctx, const char *lp, const char *rp, int32_t *start, int32_t *stop, int32_t *tlen, int32_t *ind)
 { return coords_common(ctx, lp, rp, false, start, stop, tlen, ind); }
+// the same tuples in host memory (a driver without a collective library: itsxpress_amd/multi.py moves them through pipes)
+int itsx_unique_keys128(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, int64_t gidx_base, int64_t *tuples)
+{
+  CTXCHK(ctx && (tuples || ctx->U == 0));
+  int64_t *d = nullptr; int64_t nu = 0;
+  const int rc = itsx_unique_keys128_device(ctx, seed_a, seed_b, gidx_base, &d, &nu);
+  if (rc != ITSX_OK) return rc;
+  if (nu > 0) HIPCHK(hipMemcpy(tuples, d, (size_t)nu * 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return ITSX_OK;
+}
+// E-value parameters and length of profile i: {MSV mu, lambda, Viterbi mu, lambda, Forward tau, lambda} (the array writers' columns)
+int itsx_profile_params(const itsx_ctx *ctx, int i, int32_t *M, float *evparam6)
+{
+  CTXCHK(ctx && i >= 0 && i < ctx->P);
+  if (M) *M = ctx->profs[(size_t)i].M;
+  if (evparam6) for (int k = 0; k < 6; k++) evparam6[k] = ctx->profs[(size_t)i].evparam[k];
+  return ITSX_OK;
+}
+// sequences of the unique representatives in input order of the seeds (what rep.fa holds), concatenated; offsets[n_unique + 1];
+// bases == NULL fills the offsets only
+int itsx_get_unique_seqs(itsx_ctx *ctx, char *bases, int64_t cap, int64_t *offsets)
+{
+  CTXCHK(ctx && offsets && ctx->have_derep);
+  if (!ctx->bases_view) {                                   // reads handed over in device memory: the text comes back once
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->h_bases.resize((size_t)ctx->h_off[(size_t)ctx->N]);
+    if (!ctx->h_bases.empty()) HIPCHK(hipMemcpy(&ctx->h_bases[0], ctx->dev_bases, ctx->h_bases.size(), hipMemcpyDeviceToHost));
+    ctx->bases_view = ctx->h_bases.data();
+  }
+  int64_t o = 0;
+  for (int32_t u = 0; u < ctx->U; u++) {
+    const int64_t s = ctx->h_seed_read[(size_t)u], L = ctx->h_len[(size_t)s];
+    offsets[u] = o;
+    if (bases) { if (o + L > cap) SET_ERR(ctx, ITSX_E_ARG, "sequence buffer too small"); memcpy(bases + o, ctx->bases_view + ctx->h_off[(size_t)s], (size_t)L); }
+    o += L;
+  }
+  offsets[ctx->U] = o;
+  return ITSX_OK;
+}
 
 // ------------------------------------------------------------------------------ writers
 static std::string read_name(const itsx_ctx *ctx, int64_t r)

@@ -211,6 +211,9 @@ void launch_bias(const FloatArgs &a, int64_t npairs, hipStream_t st, int lds_pad
 void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 // the lazy domain stage's first pass (k_lazy.hip): Forward scores only, nothing goes to the slab or to PairOut; fb[pair] = fwdsc
 void launch_fwd_bound(const FloatArgs &a, float *fb, int nwaves, int wave0, int generic_q, hipStream_t st);
+// the same score by the node-sequential fused-multiply-add kernel (k_lazy.hip: k_fwd_bound); btab = [P][BOUND_PAIRS][16] floats per
+// pair of nodes (2j + 1, 2j + 2): {MM IM DM out of the node (into the next one's match cell)} {MI II BM MD of the node} as pairs, DD x 2
+void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st);
 

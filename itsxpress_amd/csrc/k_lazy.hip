@@ -25,8 +25,142 @@
 #include "engine.h"
 #include "k_api.h"
 #include "detmath.h"
+#include "k_vec.h"
 
 namespace itsx {
+
+// =========================================================================================
+// Pass A's kernel: the Forward score of one (representative, profile) pair per lane, as a BOUND -- the same sum over paths as
+// p7_ForwardParser (k_filters_fwd), but not HMMER's arithmetic: nodes in their natural order 1..46 instead of the SSE striping
+// (whose four D->D passes per row exist only because of the striping), fused multiply-adds, rescaling at 1e20 instead of 1e4.
+// The result differs from HMMER's float by rounding only (relative ~1e-5, far inside LenTables::lazy_c's margin) and is used
+// for nothing but the selection; the pairs that matter get HMMER's own arithmetic in the domain pipeline.
+//   * lane = pair, wave = 64 pairs of one profile (the work list's grouping), state M, I, D of 46 nodes in 69 register pairs,
+//     pair j = nodes (2j + 1, 2j + 2): every operation on M and I is a packed one over two adjacent nodes;
+//   * a node's contribution to the NEXT node's match cell, S[k] = M[k] t(M_k->M_k+1) + I[k] t(I_k->M_k+1) + D[k] t(D_k->M_k+1), is
+//     formed on the aligned pairs and shifted by one node with a single register move per pair (the transitions are stored by
+//     their source node for that: BoundTab);
+//   * the D->D chain is 2 scalar FMAs per pair, sequential, as the recurrence is;
+//   * the profile's transitions are wave-uniform: 64 B per pair of nodes through scalar loads, double-buffered by hand (as in
+//     k_float.hip: left alone, the scheduler hoists a row's loads and spills SGPRs); emission odds by node in LDS (3 KB).
+// ~13 packed instructions per pair of nodes, ~320 per row against the striped kernel's 533.
+constexpr int BP = BOUND_PAIRS;                     // 23 pairs of nodes: models of up to 46 nodes (engine.h: MMAX)
+typedef const f4 __attribute__((address_space(4))) *cf4q;
+// record j of a profile's table (engine.hip: install_profiles), 16 floats: what pair j needs EARLY -- its transitions out of the
+// nodes (mm im dm: into the next node's match cell; mi ii) -- and what pair j - 1 needs LATE (bm md dd dd): one record per step
+struct BT { f2 mm, im, dm, mi, ii, bm, md; float dd1, dd2; };
+DEV BT ldbt(const float *tab, int j)
+{
+  const f4 a = *(cf4q)(uintptr_t)(tab + j * 16), b = *(cf4q)(uintptr_t)(tab + j * 16 + 4), c = *(cf4q)(uintptr_t)(tab + j * 16 + 8),
+           d = *(cf4q)(uintptr_t)(tab + j * 16 + 12);
+  BT t;
+  t.mm = (f2){a.x, a.y}; t.im = (f2){a.z, a.w}; t.dm = (f2){b.x, b.y}; t.mi = (f2){b.z, b.w};
+  t.ii = (f2){c.x, c.y}; t.bm = (f2){c.z, c.w}; t.md = (f2){d.x, d.y}; t.dd1 = d.z; t.dd2 = d.w;
+  return t;
+}
+DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, const float *__restrict__ btab, float *__restrict__ fb)
+{
+  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
+  const int lane = threadIdx.x;
+  const int prof = uni(wd.prof);
+  const DevProfile *pp = a.prof + prof;
+  // emission odds by node: en[code][k - 1], k = z Q + q + 1 in the striped table
+  __shared__ __attribute__((aligned(16))) float en[NCODE * 2 * BP];
+  {
+    const int Q = uni(pp->Q);
+    for (int i = threadIdx.x; i < NCODE * 2 * BP; i += 64) {
+      const int x = i / (2 * BP), k0 = i % (2 * BP);           // node k0 + 1
+      en[i] = (k0 < 4 * Q) ? pp->rf[(x * QMAX + (k0 % Q)) * 4 + k0 / Q] : 0.0f;
+    }
+    __syncthreads();
+  }
+  const float *tab = btab + (size_t)prof * ((BP + 1) * 16);
+  const bool active = lane < wd.count;
+  const int64_t pi = wd.first + (active ? lane : 0);
+  const PairRec pr = a.pairs[pi];
+  const int L = pr.L;
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  const int Lw = wd.rows - 1;
+  f2 M[BP], I[BP], D[BP];
+#pragma unroll
+  for (int j = 0; j < BP; j++) { M[j] = (f2){0.f, 0.f}; I[j] = (f2){0.f, 0.f}; D[j] = (f2){0.f, 0.f}; }
+  const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
+  const float ploop = 1.0f - pmove;
+  float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f;
+  double totscale = 0.0;
+  SeqStream ss; ss.open(sq, 0, +1);
+  int xnext = ss.get(0);
+  for (int i = 1; i <= Lw; i++) {
+    if (i <= L) {
+      const int x = xnext;
+      if (i < L) xnext = ss.get(i);
+      const float *ex = en + x * (2 * BP);
+      const float *tb = tab + opaque_zero();
+      const f2 xBv = (f2){xB, xB};
+      f2 acc = (f2){0.f, 0.f};
+      float sprev = 0.0f;                       // S of the node before the pair (S[0] = 0)
+      // pair 0's early half: S = what its nodes send to the next node's match cell (from the OLD row), and its new insert cells
+      BT cur = ldbt(tb, 0);
+      f2 ecur = *(const f2 *)(ex);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      f2 Scur = pfma(M[0], cur.mm, pfma(I[0], cur.im, D[0] * cur.dm));
+      I[0] = pfma(M[0], cur.mi, I[0] * cur.ii);
+      float dprev = 0.0f, mdprev = 0.0f;         // D'[2j] and M'[2j] t(M->D) of the node before the pair (none before node 1)
+      cur = ldbt(tb, 1);
+#pragma unroll
+      for (int j = 0; j < BP; j++) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): record j + 1 and pair j's emissions, requested one step ago
+        BT nxt = cur; f2 enxt = ecur;
+        if (j + 1 < BP) { nxt = ldbt(tb, j + 2); enxt = *(const f2 *)(ex + 2 * (j + 1)); }
+        f2 Sn = Scur;
+        if (j + 1 < BP) {                       // the next pair's early half, before this pair's D chain overwrites D[j + 1].x
+          Sn = pfma(M[j + 1], cur.mm, pfma(I[j + 1], cur.im, D[j + 1] * cur.dm));
+          I[j + 1] = pfma(M[j + 1], cur.mi, I[j + 1] * cur.ii);
+        }
+        const f2 sh = (f2){sprev, Scur.x};
+        sprev = Scur.y;
+        const f2 mn = pfma(xBv, cur.bm, sh) * ecur;
+        M[j] = mn;
+        const f2 md = mn * cur.md;
+        // both new delete cells of the pair are born here (its old ones went into Scur one step ago): dd1 = D_2j -> D_2j+1 (0 for
+        // j = 0), dd2 = D_2j+1 -> D_2j+2
+        // (as inline assembly: left to itself the compiler accumulates into the dying product's register -- v_fmac -- and then
+        // moves the result into the pair, twice per pair of nodes and row)
+        f2 dn;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.x) : "v"(dprev), "s"(cur.dd1), "v"(mdprev));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.y) : "v"(dn.x), "s"(cur.dd2), "v"(md.x));
+        dprev = dn.y; mdprev = md.y;
+        D[j] = dn;
+        acc = acc + mn; acc = acc + dn;
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt; ecur = enxt; Scur = Sn;
+      }
+      xE = acc.x + acc.y;
+      xN = xN * ploop;
+      xC = __builtin_fmaf(xC, ploop, xE * 0.5f);
+      xJ = __builtin_fmaf(xJ, ploop, xE * 0.5f);
+      xB = (xJ + xN) * pmove;
+      if (xE > 1.0e20f) {
+        const float r = 1.0f / xE;
+        xN *= r; xC *= r; xJ *= r; xB *= r;
+        const f2 rv = (f2){r, r};
+#pragma unroll
+        for (int j = 0; j < BP; j++) { M[j] = M[j] * rv; I[j] = I[j] * rv; D[j] = D[j] * rv; }
+        totscale += det_log((double)xE);
+        xE = 1.0f;
+      }
+    }
+  }
+  const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
+  if (active) fb[pi] = bad ? __builtin_nanf("") : (float)(totscale + det_log((double)(xC * pmove)));
+}
+
+void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, hipStream_t st)
+{
+  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound, dim3(nwaves), dim3(64), 0, st, a, wave0, btab, fb);
+}
 
 // largest %.1f tenths (biased) a domain of each pair can print, and the best-bound pair of every (representative, class)
 __global__ void __launch_bounds__(256) k_lazy_bound(LazyArgs a)

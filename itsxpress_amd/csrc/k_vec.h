@@ -48,4 +48,49 @@ DEV Seq open_seq(const ReadsDev &rd, int read)
   return s;
 }
 
+// Residues of one read taken in order (ascending for Forward, descending for Backward), one per DP row.  Seq::code() costs a
+// global load per row and per exception, each followed by a wait that -- vmcnt being in order -- also drains the row's six
+// slab stores.  The stream keeps the current 16-base word and the next one in registers (the next word is requested a whole
+// word ahead), and knows the position of the next exception, so a row costs a shift, a mask and one compare.
+struct SeqStream {
+  const uint32_t *w; const uint32_t *exc;
+  uint32_t cur, nxt; int cur_i, nw, dir;
+  int e, nexc, epos;                      // next exception in walking order: index, count, its position (-1: none left)
+  DEV void open(const Seq &s, int first_pos, int direction)
+  {
+    w = s.w; exc = s.exc; nexc = s.nexc; dir = direction; nw = (s.L + 15) >> 4; if (nw < 1) nw = 1;
+    cur_i = first_pos >> 4; if (cur_i >= nw) cur_i = nw - 1;
+    cur = w[cur_i];
+    const int ni = cur_i + dir;
+    nxt = (ni >= 0 && ni < nw) ? w[ni] : 0u;
+    if (dir > 0) { e = 0; while (e < nexc && (int)(exc[e] >> 4) < first_pos) e++; }
+    else { e = nexc - 1; while (e >= 0 && (int)(exc[e] >> 4) > first_pos) e--; }
+    epos = (e >= 0 && e < nexc) ? (int)(exc[e] >> 4) : -1;
+    // nothing may still be in flight when the row loop is entered: a load pending at the loop's entry makes the compiler wait
+    // for ALL memory operations (the previous row's stores included) at the first use in every iteration
+    asm volatile("" : "+v"(cur), "+v"(nxt), "+v"(epos));
+  }
+  // positions must be taken in walking order, one step at a time, starting at first_pos
+  DEV int get(int pos)
+  {
+    const int wi = pos >> 4;
+    if (wi != cur_i) {                    // every 16th row: the word requested 16 rows ago moves up, the one after it is requested
+      cur = nxt; cur_i = wi;
+      asm volatile("" : "+v"(cur));        // stays a branch: as a select it would read nxt (and wait for its load) on every row
+      const int ni = wi + dir;
+      if (ni >= 0 && ni < nw) nxt = w[ni];
+    }
+    int x = (int)((cur >> (2 * (pos & 15))) & 3u);
+    if (pos == epos) {                    // rare; everything loaded here is also consumed here, so no wait leaks into the common path
+      x = (int)(exc[e] & 15u);
+      e += dir;
+      int np = -1;
+      if (e >= 0 && e < nexc) np = (int)(exc[e] >> 4);
+      epos = np;
+      asm volatile("" : "+v"(epos), "+v"(x));
+    }
+    return x;
+  }
+};
+
 }  // namespace itsx

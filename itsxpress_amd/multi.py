@@ -1,0 +1,544 @@
+"""ITSXPRESS_GPUS=N: ONE sample spread over the N GPUs of a node, behind the mirror's own methods.
+
+The reference's callers reach the hot path only through `sobj.deduplicate / cluster / _search` (itsxpress/main.py:534-554,
+q2_itsxpress.py:287-309).  With ITSXPRESS_GPUS > 1 those methods drive a `MultiEngine` instead of an `Engine`: N worker processes
+(started fresh with multiprocessing "spawn", BEFORE this process has touched a GPU -- it never does), one HIP context each, reads
+sharded by contiguous index range.  The results are those of one GPU on the whole input, read for read and file for file:
+
+  * exact global dereplication (SURVEY 8e option 2): every worker dereplicates its shard on its GPU; only the UNIQUES meet, by an
+    orientation-free 128-bit key; per distinct sequence the global first occurrence is the representative and ONE holder of the
+    sequence in the representative's orientation scores it (`owner_verdicts`, the numpy twin of dist.owner_verdicts);
+  * hmmsearch's domZ is summed over the workers between search and finalize (after a lazy search: its bounds; undecided rows are
+    settled by counting their profiles on every worker, csrc/k_lazy.hip);
+  * per-read coordinates are composed here from the scorers' per-representative rows;
+  * uc.txt / rep.fa / domtbl.txt are written from the gathered arrays by the library's context-free writers
+    (csrc/writers_host.cpp), byte-identical to the files one GPU writes.
+
+No torch, no collective library: the two exchanges are tiny (40 B per unique, 16 B per profile) and travel as numpy arrays over
+the workers' pipes.  bench.py's torch.distributed / RCCL path (itsxpress_amd/dist.py) is the device-resident alternative for a
+driver that already runs one process per GPU.
+"""
+import ctypes as C
+import multiprocessing as mp
+import os
+
+import numpy as np
+
+from ._lib import DOMAIN_DTYPE, EngineError
+
+KEY_SEEDS = (0x1F83D9ABFB41BD6B, 0x5BE0CD19137E2179)
+
+
+def owner_verdicts(recv, src):
+    """recv [m, 5] int64 = (key0, key1, global index of the first occurrence, forward-is-canonical flag, local unique number) of
+    every worker's uniques, src [m] = the worker each row came from.  Returns [m, 4] int64 per row: global index and orientation flag
+    of the group's first occurrence (the representative), worker and local unique number of the holder that scores the sequence --
+    one of the holders in the representative's orientation, picked by the key so that the scoring spreads evenly."""
+    m = recv.shape[0]
+    if m == 0:
+        return np.zeros((0, 4), np.int64)
+    order = np.lexsort((recv[:, 2], recv[:, 1], recv[:, 0]))
+    s, ssrc = recv[order], src[order]
+    first = np.ones(m, bool)
+    first[1:] = (s[1:, 0] != s[:-1, 0]) | (s[1:, 1] != s[:-1, 1])
+    grp = np.cumsum(first) - 1
+    head = np.nonzero(first)[0]
+    seed_gidx, seed_fwd = s[head, 2][grp], s[head, 3][grp]
+    cand = (s[:, 3] == seed_fwd).astype(np.int64)
+    run = np.cumsum(cand) - cand
+    pos = run - run[head][grp]
+    cnt = np.zeros(head.shape[0], np.int64)
+    np.add.at(cnt, grp, cand)
+    pick = np.remainder(s[head, 1], cnt)[grp]
+    chosen = (cand == 1) & (pos == pick)
+    sr = np.zeros(head.shape[0], np.int64)
+    su = np.zeros(head.shape[0], np.int64)
+    sr[grp[chosen]] = ssrc[chosen]
+    su[grp[chosen]] = s[chosen, 4]
+    ans = np.stack([seed_gidx, seed_fwd, sr[grp], su[grp]], axis=1)
+    out = np.empty_like(ans)
+    out[order] = ans
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- the worker process
+def _worker_main(conn, device, rank, world):
+    os.environ["ITSXPRESS_GPU"] = str(device)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.pop("ITSXPRESS_GPUS", None)             # a worker drives one GPU
+    try:
+        from .engine import Engine                     # the first GPU call of this process happens in here
+        eng = Engine(device)
+    except BaseException as e:                         # noqa: report, do not hang the parent
+        conn.send(("err", (type(e).__name__, getattr(e, "code", -1), str(e))))
+        return
+    conn.send(("ok", None))
+    st = {"rank": rank, "world": world, "base": 0}
+    while True:
+        try:
+            cmd, args = conn.recv()
+        except EOFError:
+            break
+        if cmd == "close":
+            break
+        try:
+            conn.send(("ok", _HANDLERS[cmd](eng, st, *args)))
+        except BaseException as e:                     # noqa
+            conn.send(("err", (type(e).__name__, getattr(e, "code", -1), getattr(e, "message", str(e)))))
+    try:
+        eng.close()
+    finally:
+        conn.close()
+
+
+def _h_load_shard(eng, st, path):
+    tot, first, n = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    eng._chk(eng.L.itsx_load_reads_file_shard(eng.h, os.fsencode(path), st["rank"], st["world"], C.byref(tot), C.byref(first), C.byref(n)))
+    eng.n_reads, eng.n_samples = n.value, 1
+    st["base"] = first.value
+    return tot.value, first.value, n.value
+
+
+def _h_set_reads(eng, st, blob, offs, names, base):
+    eng.set_reads_buffer(blob, offs, names)
+    st["base"] = int(base)
+    return eng.n_reads
+
+
+def _h_derep(eng, st, strand_both, minlen):
+    U = eng.derep(strand_both=strand_both, minseqlength=minlen)
+    tup = np.zeros((max(U, 1), 4), np.int64)
+    eng._chk(eng.L.itsx_unique_keys128(eng.h, C.c_uint64(KEY_SEEDS[0]), C.c_uint64(KEY_SEEDS[1]), int(st["base"]), tup.ctypes.data))
+    st["tup"] = tup[:U]
+    return st["tup"]
+
+
+def _h_verdict(eng, st, verdict):
+    U = eng.n_unique
+    lu = np.arange(U, dtype=np.int64)
+    st["verdict"] = verdict
+    active = (verdict[:, 2] == st["rank"]) & (verdict[:, 3] == lu)
+    eng.set_active_uniques(active)
+    return int(active.sum())
+
+
+def _h_derep_arrays(eng, st, want_names, want_seqs):
+    """per read: local unique number, orientation relative to the GLOBAL representative, length (+ labels); per local unique: its
+    first occurrence (global index) and, when asked, its sequence"""
+    rep_of, strand, uniq_of = eng.get_derep()
+    v, tup = st["verdict"], st["tup"]
+    flip = v[:, 1] != tup[:, 3]                          # this shard's seed is the reverse complement of the representative
+    gstrand = strand.copy()
+    ok = uniq_of >= 0
+    gstrand[ok] = np.where(flip[uniq_of[ok]], -strand[ok], strand[ok])
+    lens = np.zeros(eng.n_reads, np.int32)
+    offs = np.zeros(eng.n_reads + 1, np.int64)
+    eng._chk(eng.L.itsx_get_read_names(eng.h, None, 0, offs.ctypes.data))
+    out = {"uniq_of": uniq_of.astype(np.int32), "strand": gstrand.astype(np.int8)}
+    seed, _ = eng.get_uniques()
+    out["seed_gidx_local"] = seed + st["base"]
+    if want_names:
+        out["names"] = eng.read_names_raw()
+    # read lengths from the packed set: the derep arrays do not carry them, the unique sequences do; ask the library for all reads' lengths
+    uo = np.zeros(eng.n_unique + 1, np.int64)
+    eng._chk(eng.L.itsx_get_unique_seqs(eng.h, None, 0, uo.ctypes.data))
+    ulen = np.diff(uo).astype(np.int32)
+    lens[ok] = ulen[uniq_of[ok]]                         # a read has its unique's length (exact dereplication)
+    out["len"] = lens
+    if want_seqs:
+        buf = C.create_string_buffer(int(uo[-1]) + 1)
+        eng._chk(eng.L.itsx_get_unique_seqs(eng.h, buf, int(uo[-1]), uo.ctypes.data))
+        out["useqs"] = (buf.raw[:int(uo[-1])], uo)
+    return out
+
+
+def _h_profiles(eng, st, path, text):
+    n = eng.load_profiles(path=path, text=text)
+    if st["rank"] != 0:
+        return n, None
+    names = eng.profile_names()
+    M = np.zeros(n, np.int32)
+    ev = np.zeros((n, 6), np.float32)
+    for i in range(n):
+        m = C.c_int32(0)
+        eng._chk(eng.L.itsx_profile_params(eng.h, i, C.byref(m), ev[i].ctypes.data))
+        M[i] = m.value
+    return n, (names, M, ev)
+
+
+def _h_search(eng, st, mode, T, F1, F2, F3):
+    eng.set_rows_mode(mode)
+    eng.search(T=T, F1=F1, F2=F2, F3=F3)
+    return eng.get_domz()
+
+
+def _h_finalize(eng, st, z, domE):
+    eng.set_domz(z)
+    eng.finalize(domE=domE)
+    return eng.lazy_pending(), eng.lazy_pending_profiles()
+
+
+def _h_complete(eng, st, flags):
+    eng.lazy_complete(flags)
+    return eng.get_domz()
+
+
+def _h_rep_coords(eng, st, left, right):
+    return np.stack(eng.rep_coords(left, right), axis=1).astype(np.int32)
+
+
+def _h_domains(eng, st):
+    return eng.domains()
+
+
+def _h_call(eng, st, name, args, kwargs):
+    return getattr(eng, name)(*args, **kwargs)
+
+
+def _h_stats(eng, st):
+    return eng.stats()
+
+
+_HANDLERS = {"load_shard": _h_load_shard, "set_reads": _h_set_reads, "derep": _h_derep, "verdict": _h_verdict,
+             "derep_arrays": _h_derep_arrays, "profiles": _h_profiles, "search": _h_search, "finalize": _h_finalize,
+             "complete": _h_complete, "rep_coords": _h_rep_coords, "domains": _h_domains, "call": _h_call, "stats": _h_stats}
+
+
+# ---------------------------------------------------------------------------------------------------- the driver
+class MultiEngine:
+    """The part of Engine's interface the mirror classes use, over N single-GPU workers."""
+
+    def __init__(self, n_gpus, devices=None):
+        self.world = int(n_gpus)
+        if self.world < 1:
+            raise ValueError("ITSXPRESS_GPUS must be >= 1")
+        self.devices = list(devices) if devices is not None else _devices_from_env(self.world)
+        ctx = mp.get_context("spawn")                   # fresh interpreters: nothing of this process's state, no forked GPU context
+        self.conns, self.procs = [], []
+        for r in range(self.world):
+            a, b = ctx.Pipe()
+            p = ctx.Process(target=_worker_main, args=(b, self.devices[r], r, self.world), daemon=True)
+            p.start()
+            b.close()
+            self.conns.append(a)
+            self.procs.append(p)
+        try:
+            self._collect()
+        except BaseException:
+            self.close()
+            raise
+        self.n_reads = self.n_unique = self.n_profiles = 0
+        self.n_samples = 1
+        self.rows_mode = -1
+        self._mode = None
+        self._search_args = None
+        self._final = False
+
+    # -- plumbing
+    def _send(self, cmd, args_per_worker):
+        for c, a in zip(self.conns, args_per_worker):
+            c.send((cmd, a))
+
+    def _collect(self):
+        out, err = [], None
+        for r, c in enumerate(self.conns):
+            try:
+                tag, val = c.recv()
+            except EOFError:
+                tag, val = "err", ("EOFError", -4, "worker %d (GPU %s) died" % (r, self.devices[r]))
+            if tag == "err" and err is None:
+                err = val
+            out.append(val)
+        if err is not None:                              # every worker has answered: nobody is left waiting in a half-done exchange
+            name, code, msg = err
+            if name == "FileNotFoundError":
+                raise FileNotFoundError(msg)
+            raise EngineError(code, msg)
+        return out
+
+    def _all(self, cmd, *args):
+        self._send(cmd, [args] * self.world)
+        return self._collect()
+
+    def _w0(self, name, *args, **kwargs):
+        self.conns[0].send(("call", (name, args, kwargs)))
+        tag, val = self.conns[0].recv()
+        if tag == "err":
+            if val[0] == "FileNotFoundError":
+                raise FileNotFoundError(val[2])
+            raise EngineError(val[1], val[2])
+        return val
+
+    def close(self):
+        for c in getattr(self, "conns", []):
+            try:
+                c.send(("close", None))
+            except Exception:
+                pass
+        for p in getattr(self, "procs", []):
+            p.join(timeout=20)
+            if p.is_alive():
+                p.kill()                                  # this exact child, nothing else
+        self.conns, self.procs = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reads
+    def load_reads_file(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        res = self._all("load_shard", path)
+        self.n_reads = int(res[0][0])
+        self._bases = [int(r[1]) for r in res]
+        self._nloc = [int(r[2]) for r in res]
+        self._derep = None
+        self._final = False
+        return self.n_reads
+
+    def set_reads(self, seqs, names=None):
+        n = len(seqs)
+        args = []
+        self._bases, self._nloc = [], []
+        for r in range(self.world):
+            lo, hi = n * r // self.world, n * (r + 1) // self.world
+            part = seqs[lo:hi]
+            lens = np.fromiter((len(s) for s in part), np.int64, hi - lo)
+            offs = np.zeros(hi - lo + 1, np.int64)
+            np.cumsum(lens, out=offs[1:])
+            blob = ("".join(part)).encode() if (part and isinstance(part[0], str)) else b"".join(part)
+            args.append((blob, offs, None if names is None else list(names[lo:hi]), lo))
+            self._bases.append(lo)
+            self._nloc.append(hi - lo)
+        self._send("set_reads", args)
+        self._collect()
+        self.n_reads = n
+        self._derep = None
+        self._final = False
+        return n
+
+    # -- a1: exact dereplication of the whole sample
+    def derep(self, strand_both=True, minseqlength=1):
+        tups = self._all("derep", bool(strand_both), int(minseqlength))
+        rows, src = [], []
+        for r, t in enumerate(tups):
+            lu = np.arange(t.shape[0], dtype=np.int64)
+            rows.append(np.concatenate([t, lu[:, None]], axis=1))
+            src.append(np.full(t.shape[0], r, np.int64))
+        recv = np.concatenate(rows) if rows else np.zeros((0, 5), np.int64)
+        verdict = owner_verdicts(recv, np.concatenate(src) if src else np.zeros(0, np.int64))
+        cut = np.cumsum([0] + [t.shape[0] for t in tups])
+        self._verdicts = [verdict[cut[r]:cut[r + 1]] for r in range(self.world)]
+        self._send("verdict", [(v,) for v in self._verdicts])
+        self._collect()
+        # the global unique list: distinct sequences in input order of their first occurrences
+        self._seeds = np.unique(verdict[:, 0]) if verdict.shape[0] else np.zeros(0, np.int64)
+        self._gmap = [np.searchsorted(self._seeds, v[:, 0]) for v in self._verdicts]        # local unique -> global unique
+        self.n_unique = int(self._seeds.shape[0])
+        self._derep = None
+        self._final = False
+        return self.n_unique
+
+    def cluster(self, cluster_id, strand_both=True):
+        if float(cluster_id) >= 1.0:
+            return self.derep(strand_both=strand_both, minseqlength=1)     # main.py:534-537: 1.0 is exact dereplication
+        raise EngineError(-5, "greedy clustering (cluster_id < 1) is sequential by definition and does not shard over GPUs: "
+                              "run it with ITSXPRESS_GPUS=1 (DESIGN.md section 7)")
+
+    def _derep_arrays(self, names=True, seqs=False):
+        if self._derep is None or (names and "names" not in self._derep[0]) or (seqs and "useqs" not in self._derep[0]):
+            self._derep = self._all("derep_arrays", bool(names), bool(seqs))
+        return self._derep
+
+    def get_derep(self):
+        """(rep_of, strand, uniq_of) per read of the WHOLE sample, as one Engine on the whole input reports them"""
+        parts = self._derep_arrays(names=False)
+        rep_of, strand, uniq_of = [], [], []
+        for r, d in enumerate(parts):
+            uq = d["uniq_of"].astype(np.int64)
+            ok = uq >= 0
+            g = np.where(ok, self._gmap[r][np.maximum(uq, 0)], -1)
+            uniq_of.append(g)
+            rep_of.append(np.where(ok, self._seeds[np.maximum(g, 0)], -1))
+            strand.append(d["strand"])
+        return np.concatenate(rep_of), np.concatenate(strand), np.concatenate(uniq_of)
+
+    def read_names_raw(self):
+        parts = self._derep_arrays(names=True)
+        blobs = [d["names"][0] for d in parts]
+        offs = [np.zeros(1, np.int64)]
+        base = 0
+        for d in parts:
+            o = d["names"][1]
+            offs.append(o[1:] + base)
+            base += int(o[-1])
+        return b"".join(blobs), np.concatenate(offs)
+
+    def read_names(self):
+        blob, offs = self.read_names_raw()
+        blob = blob.decode()
+        return [blob[offs[i]:offs[i + 1]] for i in range(self.n_reads)]
+
+    def write_uc(self, path):
+        self._write_derep(path, None)
+
+    def write_rep_fasta(self, path):
+        self._write_derep(None, path)
+
+    def _write_derep(self, uc_path, rep_path):
+        from . import _lib
+        L = _lib.lib()
+        parts = self._derep_arrays(names=True, seqs=rep_path is not None)
+        rep_of, strand, _ = self.get_derep()
+        lens = np.concatenate([d["len"] for d in parts]).astype(np.int32)
+        nblob, noffs = self.read_names_raw()
+        sb = so = None
+        if rep_path is not None:                         # the representatives' sequences, in input order of the seeds
+            chunks = [None] * self.n_unique
+            for r, d in enumerate(parts):
+                blob, uo = d["useqs"]
+                is_seed = self._verdicts[r][:, 0] == d["seed_gidx_local"]      # this shard holds the global first occurrence
+                for u in np.nonzero(is_seed)[0]:
+                    chunks[int(self._gmap[r][u])] = blob[int(uo[u]):int(uo[u + 1])]
+            so = np.zeros(self.n_unique + 1, np.int64)
+            np.cumsum([len(c) for c in chunks], out=so[1:])
+            sb = b"".join(chunks)
+        rep_of = np.ascontiguousarray(rep_of, np.int64)
+        strand = np.ascontiguousarray(strand, np.int8)
+        rc = L.itsx_write_derep_arrays(os.fsencode(uc_path) if uc_path else None, os.fsencode(rep_path) if rep_path else None,
+                                       self.n_reads, rep_of.ctypes.data, strand.ctypes.data, lens.ctypes.data,
+                                       nblob, noffs.ctypes.data, sb, so.ctypes.data if so is not None else None, self.n_unique)
+        if rc != 0:
+            raise EngineError(rc, L.itsx_writers_last_error().decode())
+
+    # -- a3 / a4
+    def load_profiles(self, path=None, text=None):
+        if path is not None and not os.path.exists(path):
+            raise FileNotFoundError(path)
+        res = self._all("profiles", path, text)
+        self.n_profiles = int(res[0][0])
+        self._pmeta = res[0][1]
+        self._final = False
+        return self.n_profiles
+
+    def profile_names(self):
+        return list(self._pmeta[0])
+
+    def set_rows_mode(self, mode):
+        self._mode = mode
+        self.rows_mode = {None: -1, "env": -1, "full": 0, "compact": 1, "lazy": 2}.get(mode, mode)
+
+    def search(self, T=10.0, F1=1e-6, F2=1e-6, F3=1e-6):
+        self._search_args = (T, F1, F2, F3)
+        self._z = self._all("search", self._mode, T, F1, F2, F3)
+        self._final = False
+
+    def finalize(self, domE=10.0):
+        z = np.sum(self._z, axis=0)
+        res = self._all("finalize", z, float(domE))
+        pend = max(int(r[0]) for r in res)
+        if pend > 0:                                     # rows that depend on the exact domZ: their profiles are counted on every worker
+            flags = np.max([r[1] for r in res], axis=0).astype(np.int32)
+            self._z = self._all("complete", flags)
+            z = np.sum(self._z, axis=0)
+            res = self._all("finalize", z, float(domE))
+            if max(int(r[0]) for r in res) > 0:          # (a counted profile leaves nothing undecided; the safety net: everything in full)
+                self._z = self._all("search", "compact", *self._search_args)
+                z = np.sum(self._z, axis=0)
+                self._all("finalize", z, float(domE))
+        self._domz = z
+        self._final = True
+
+    def _rep_rows(self, left, right):
+        rows = self._all("rep_coords", left, right)      # [U_i, 4] per worker, local uniques (meaningful where the worker scored)
+        out = np.full((self.n_unique, 4), -1, np.int32)
+        out[:, 3] = 0
+        for r, v in enumerate(self._verdicts):
+            mine = (v[:, 2] == r) & (v[:, 3] == np.arange(v.shape[0]))
+            out[self._gmap[r][mine]] = rows[r][mine]
+        return out
+
+    def rep_coords(self, left, right):
+        rows = self._rep_rows(left, right)
+        return tuple(np.ascontiguousarray(rows[:, k]) for k in range(4))
+
+    def trim_coords(self, left, right):
+        """per READ of the whole sample: start, stop, tlen (-1 = None), in_ddict"""
+        rows = self._rep_rows(left, right)
+        _, _, uniq_of = self.get_derep()
+        ok = uniq_of >= 0
+        out = np.full((self.n_reads, 4), -1, np.int32)
+        out[:, 3] = 0
+        out[ok] = rows[uniq_of[ok]]
+        return tuple(np.ascontiguousarray(out[:, k]) for k in range(4))
+
+    def domains(self):
+        """every worker's domain rows with `rep` = index into the GLOBAL unique list, in domtblout order"""
+        parts = self._all("domains")
+        rows = []
+        for r, d in enumerate(parts):
+            d = d.copy()
+            d["rep"] = self._gmap[r][d["rep"]]
+            rows.append(d)
+        allr = np.concatenate(rows) if rows else np.zeros(0, DOMAIN_DTYPE)
+        order = np.lexsort((allr["dom_idx"], allr["rep"], allr["prof"]))
+        return allr[order]
+
+    def write_domtbl(self, path):
+        from . import _lib
+        L = _lib.lib()
+        rows = np.ascontiguousarray(self.domains())
+        names, M, ev = self._pmeta
+        pn = "".join(names).encode()
+        po = np.zeros(len(names) + 1, np.int64)
+        np.cumsum([len(x) for x in names], out=po[1:])
+        tau = np.ascontiguousarray(ev[:, 4], np.float32)
+        lam = np.ascontiguousarray(ev[:, 5], np.float32)
+        M = np.ascontiguousarray(M, np.int32)
+        # labels of the representatives = labels of the global first occurrences
+        nblob, noffs = self.read_names_raw()
+        tn = [nblob[int(noffs[g]):int(noffs[g + 1])] for g in self._seeds]
+        to = np.zeros(len(tn) + 1, np.int64)
+        np.cumsum([len(x) for x in tn], out=to[1:])
+        tb = b"".join(tn)
+        z = np.ascontiguousarray(self._domz[:self.n_profiles], np.int64)
+        rc = L.itsx_write_domtbl_arrays(os.fsencode(path), rows.ctypes.data, rows.shape[0], self.n_unique, z.ctypes.data, self.n_profiles,
+                                        pn, po.ctypes.data, M.ctypes.data, tau.ctypes.data, lam.ctypes.data, tb, to.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, L.itsx_writers_last_error().decode())
+
+    def stats(self):
+        return self._all("stats")
+
+    # -- stages that are not sharded (one GPU does them): orientation of CCS reads, paired-end merging
+    def orient_load_db(self, fasta_path):
+        return self._w0("orient_load_db", fasta_path)
+
+    def orient_file(self, fastq):
+        self._w0("load_reads_file", fastq)
+        return self._w0("orient")
+
+    def merge_pairs_files(self, r1, r2, out, maxdiffs=40, maxee=2.0, allow_stagger=False):
+        return self._w0("merge_pairs_files", r1, r2, out, maxdiffs=maxdiffs, maxee=maxee, allow_stagger=allow_stagger)
+
+
+def _devices_from_env(n):
+    """ITSXPRESS_GPU_IDS="0,2,5" names the devices; otherwise 0..N-1.  (A one-GPU box may rehearse N workers on device 0 with
+    ITSXPRESS_GPU_IDS="0,0".)"""
+    ids = os.environ.get("ITSXPRESS_GPU_IDS", "").strip()
+    if ids:
+        d = [int(x) for x in ids.split(",") if x.strip() != ""]
+        if len(d) != n:
+            raise ValueError("ITSXPRESS_GPU_IDS names %d devices, ITSXPRESS_GPUS asks for %d" % (len(d), n))
+        return d
+    return list(range(n))
+
+
+def gpus_from_env():
+    v = os.environ.get("ITSXPRESS_GPUS", "").strip()
+    return int(v) if v else 1

@@ -199,3 +199,15 @@ def test_lazy_with_all_taxa_profiles(engine, all_its2_hmm_text, t_hmm_text):
     got, st1 = _coords(engine, all_its2_hmm_text, seqs, "lazy")
     assert _same(ref, got)
     assert st1["n_lazy_evaluated"] < 0.2 * st1["n_past_msv"]
+
+
+def test_bound_kernel_agrees_with_the_forward_parser(engine, t_hmm_text, mini_hmm_text, monkeypatch):
+    """pass A's kernel (node-sequential, fused multiply-adds, rescaling at 1e20) computes the same sum over paths as
+    p7_ForwardParser's striped arithmetic: scores within 1e-3 nats on every pair -- the bound's margin is 0.02 bits -- on ragged
+    reads with N's and on profiles of other lengths (mini.hmm holds 1_ / 2_ models shorter than 45 nodes)"""
+    monkeypatch.setenv("ITSX_LAZY_CHECK_BOUND", "1")
+    for hmm, src, n in ((_its2_subset(t_hmm_text, 40, 40), t_hmm_text, 1500), (mini_hmm_text, mini_hmm_text, 800)):
+        blob, offs = synth.make_reads(src, n, config=3, seed=synth.SEED + 11, fixed_len=0, len_range=(120, 900), n_rate=0.004)
+        _, st = _coords(engine, hmm, synth.to_strings(blob, offs), "lazy")
+        assert st["n_past_msv"] > 1000
+        assert 0.0 <= st["lazy_bound_maxdiff"] < 1e-3, st["lazy_bound_maxdiff"]

@@ -10,6 +10,14 @@ domtbl.txt (users pass --keeptemp; ItsPosition/Dedup of the *reference* can read
 Array fast path: ItsPosition.from_engine / Dedup.from_engine / SeqSample.trim_coordinates
 skip the text round trip.
 
+Two switches, both read from the environment when the method runs (or set as attributes of the sample object):
+  ITSXPRESS_GPUS=N   (`sobj.gpus`)  one sample spread over the N GPUs of a node: N worker processes behind the same methods
+                     (itsxpress_amd/multi.py: exact global dereplication, summed domZ, files byte-identical to one GPU's);
+  ITSXPRESS_ARRAYS=1 (`sobj.fast`)  the hot path hands ARRAYS to the consumers instead of text files: deduplicate / _search write
+                     nothing, the search runs the lazy domain stage (pairs that cannot win ItsPosition's argmax stop after their
+                     Forward score), and `uc_file` / `dom_file` are EngineTable tokens that this module's Dedup / ItsPosition
+                     accept in place of paths -- the reference's own call sequence (main.py:534-554, 626-638) runs unchanged.
+
 Either side of the path is mirrored too: read orientation (orient_reads), paired-end
 merging (_merge_reads), the trimmed-FASTQ writers (Dedup.create_*), and many samples as one batch
 (itsxpress_amd/batch.py).
@@ -27,6 +35,27 @@ logger = logging.getLogger(__name__)
 _REGION_PREFIX = {"ITS2": ("3_", "4_"), "ITS1": ("1_", "2_"), "ALL": ("1_", "4_")}
 
 
+class EngineTable(str):
+    """What `uc_file` / `dom_file` hold in arrays mode: a path-like token (the file it stands for is NOT written) that carries the
+    engine whose arrays replace the file.  This module's Dedup / ItsPosition take it where the reference's take a path."""
+
+    def __new__(cls, path, engine, kind):
+        self = super().__new__(cls, path)
+        self.engine, self.kind = engine, kind
+        return self
+
+
+def _new_engine(gpus=None):
+    """one Engine, or -- ITSXPRESS_GPUS > 1 -- N workers behind the same interface (started before this process touches a GPU)"""
+    from .multi import MultiEngine, gpus_from_env
+    n = int(gpus) if gpus else gpus_from_env()
+    return MultiEngine(n) if n > 1 else Engine()
+
+
+def _fast_from_env():
+    return os.environ.get("ITSXPRESS_ARRAYS", "").strip() not in ("", "0")
+
+
 class SeqSample:
     """Base class: dereplicate -> search, as the reference's SeqSample (SeqSample.py:18-225)."""
 
@@ -40,17 +69,23 @@ class SeqSample:
         self.r1: Optional[str] = None
         self.fastq2: Optional[str] = None
         self._engine: Optional[Engine] = None
+        self.gpus: Optional[int] = None          # None: ITSXPRESS_GPUS (default 1)
+        self.fast: Optional[bool] = None         # None: ITSXPRESS_ARRAYS (default off)
 
     # -- engine plumbing -------------------------------------------------------------
     @property
     def engine(self) -> Engine:
         if self._engine is None:
             try:
-                self._engine = Engine()
+                self._engine = _new_engine(getattr(self, "gpus", None))
             except FileNotFoundError:
                 logger.error("The HIP engine (libitsx_hip.so) was not found; build it first")
                 raise
         return self._engine
+
+    def _is_fast(self) -> bool:
+        f = getattr(self, "fast", None)
+        return _fast_from_env() if f is None else bool(f)
 
     def _load_reads(self) -> None:
         eng = self.engine
@@ -70,8 +105,7 @@ class SeqSample:
             oriented_fastq = os.path.join(self.tempdir, "oriented.fq")
             os.makedirs(self.tempdir, exist_ok=True)
             self.engine.orient_load_db(orient_ref)
-            self.engine.load_reads_file(self.fastq)
-            strand, _, _ = self.engine.orient()
+            strand, _, _ = self.engine.orient_file(self.fastq)
             write_oriented_fastq(self.fastq, oriented_fastq, strand)
             self.fastq = oriented_fastq
             self.seq_file = oriented_fastq
@@ -94,8 +128,11 @@ class SeqSample:
             # vsearch's --minseqlength default is 32 for the clustering / derep_* / usearch_global commands and 1 for the
             # others, --fastx_uniques among them: only empty reads vanish from uc.txt here
             n = self.engine.derep(strand_both=True, minseqlength=1)
-            self.engine.write_uc(self.uc_file)
-            self.engine.write_rep_fasta(self.rep_file)
+            if self._is_fast():                     # arrays mode: Dedup reads the engine, nothing is written
+                self.uc_file = EngineTable(self.uc_file, self.engine, "uc")
+            else:
+                self.engine.write_uc(self.uc_file)
+                self.engine.write_rep_fasta(self.rep_file)
             logging.info("itsx_hip derep: %d reads -> %d unique sequences", self.engine.n_reads, n)
         except EngineError as e:
             logging.exception("Could not perform dereplication with the HIP engine: %s", e)
@@ -114,9 +151,19 @@ class SeqSample:
             self.rep_file = os.path.join(self.tempdir, "rep.fa")
             self._load_reads()
             cid = float(cluster_id)
+            if cid < 1.0 and getattr(self.engine, "world", 1) > 1:
+                # greedy clustering is sequential by definition (a query sees every centroid before it): one GPU runs it
+                logging.warning("cluster_id < 1 does not shard over GPUs: this sample runs on one GPU (ITSXPRESS_GPUS ignored)")
+                self._engine.close()
+                self._engine = Engine()
+                self._reads_loaded_from = None
+                self._load_reads()
             self.engine.cluster(cid, strand_both=True)
-            self.engine.write_uc(self.uc_file)
-            self.engine.write_rep_fasta(self.rep_file)
+            if self._is_fast():
+                self.uc_file = EngineTable(self.uc_file, self.engine, "uc")
+            else:
+                self.engine.write_uc(self.uc_file)
+                self.engine.write_rep_fasta(self.rep_file)
         except EngineError as e:
             logging.exception("Could not perform clustering with the HIP engine: %s", e)
             raise e
@@ -135,9 +182,15 @@ class SeqSample:
                 eng.load_reads_file(self.rep_file)
                 eng.derep(strand_both=False, minseqlength=0)
             eng.load_profiles(path=hmmfile)
+            fast = self._is_fast()
+            # file-compatible: every domain row stays (domtbl.txt); arrays mode: the lazy domain stage, coordinates only
+            eng.set_rows_mode("lazy" if fast else "full")
             eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
             eng.finalize(domE=10.0)
-            eng.write_domtbl(self.dom_file)
+            if fast:
+                self.dom_file = EngineTable(self.dom_file, eng, "domtbl")
+            else:
+                eng.write_domtbl(self.dom_file)
         except EngineError as e:
             logging.exception("Could not perform ITS identification with the HIP engine: %s", e)
             raise e
@@ -204,10 +257,49 @@ class ItsPosition:
 
     def __init__(self, domtable: Optional[str], region: str) -> None:
         self.domtable = domtable
-        self.ddict: Dict[str, Any] = {}
+        self._ddict: Optional[Dict[str, Any]] = {}
+        self._engine = None
         self.leftprefix, self.rightprefix = _REGION_PREFIX[region]
-        if domtable is not None:
+        if isinstance(domtable, EngineTable):       # arrays mode: the engine's per-representative coordinates ARE the table
+            self._engine = domtable.engine
+            self._ddict = None                      # built on demand (get_position / ddict); the writers use the arrays directly
+        elif domtable is not None:
             self.parse()
+
+    @property
+    def ddict(self) -> Dict[str, Any]:
+        if self._ddict is None:
+            self._ddict = self._ddict_from_engine()
+        return self._ddict
+
+    @ddict.setter
+    def ddict(self, value) -> None:
+        self._ddict = value
+
+    def _ddict_from_engine(self) -> Dict[str, Any]:
+        """The reference's dict shape from the engine's arrays: one entry per representative that has a reported row; scores are
+        not kept by the lazy / compacted search (None): get_position never reads them."""
+        eng = self._engine
+        start, stop, tlen, ind = eng.rep_coords(self.leftprefix, self.rightprefix)
+        rep_of, _, uniq_of = eng.get_derep()
+        names = eng.read_names()
+        seed = {}
+        for r in range(len(rep_of)):
+            if rep_of[r] == r:
+                seed[int(uniq_of[r])] = names[r]
+        out: Dict[str, Any] = {}
+        for u in range(len(ind)):
+            if not ind[u]:
+                continue
+            e: Dict[str, Any] = {}
+            if start[u] >= 0:
+                e["left"] = {"score": None, "to_pos": int(start[u]), "from_pos": None}
+            if stop[u] >= 0:
+                e["right"] = {"score": None, "to_pos": None, "from_pos": int(stop[u]) + 1}
+            if tlen[u] >= 0:
+                e["tlen"] = int(tlen[u])
+            out[seed[u]] = e
+        return out
 
     def _score(self, sequence: str, stype: str, score: float, from_pos: int, to_pos: int, tlen: int) -> None:
         entry = self.ddict[sequence]
@@ -280,8 +372,24 @@ class Dedup:
         self.seq_file = seq_file
         self.fastq = fastq
         self.fastq2 = fastq2
-        if uc_file is not None:
+        self._engine = None
+        if isinstance(uc_file, EngineTable):        # arrays mode: the read -> representative map stays in the engine
+            self._engine = uc_file.engine
+        elif uc_file is not None:
             self.parse()
+
+    def _matchdict_from_engine(self) -> Dict[str, str]:
+        names = self._engine.read_names()
+        rep_of, _, _ = self._engine.get_derep()
+        return {names[i]: names[int(r)] for i, r in enumerate(rep_of) if r >= 0}
+
+    def __getattribute__(self, name):
+        # matchdict of an engine-backed Dedup is built the first time somebody asks for it (10 M entries are not free)
+        if name == "matchdict":
+            d = object.__getattribute__(self, "__dict__")
+            if d.get("matchdict") is None and d.get("_engine") is not None:
+                d["matchdict"] = object.__getattribute__(self, "_matchdict_from_engine")()
+        return object.__getattribute__(self, name)
 
     def parse(self) -> None:
         try:
@@ -304,6 +412,11 @@ class Dedup:
         from .trim import coords_from_dicts, read_names, write_trimmed_fastq
         if not wri_file:
             return
+        if self._engine is not None and getattr(itspos, "_engine", None) is self._engine:
+            # arrays mode: per-read coordinates straight from the engine, in the order of seq_file's records (the engine read them from it)
+            start, stop, _, _ = self._engine.trim_coords(itspos.leftprefix, itspos.rightprefix)
+            write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)
+            return
         names = read_names(self.seq_file)           # the native writer's own record parser: names and records cannot disagree
         start, stop, _ = coords_from_dicts(names, self.matchdict, itspos)
         write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)
@@ -315,6 +428,11 @@ class Dedup:
         if self.fastq is None or self.fastq2 is None:
             raise ValueError("Both fastq and fastq2 paths must be defined to create paired trimmed sequences.")
         if not wri_file:
+            return
+        if self._engine is not None and getattr(itspos, "_engine", None) is self._engine:
+            start, stop, tlen, _ = self._engine.trim_coords(itspos.leftprefix, itspos.rightprefix)
+            write_trimmed_paired(self.fastq, self.fastq2, outfile1, outfile2, self._engine.read_names_raw(), start, stop, tlen,
+                                 gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)
             return
         names = list(self.matchdict.keys())
         start, stop, tlen = coords_from_dicts(names, self.matchdict, itspos)
@@ -339,11 +457,12 @@ def install():
 
     def _eng(obj):
         if getattr(obj, "_engine", None) is None:
-            obj._engine = Engine()
+            obj._engine = _new_engine(getattr(obj, "gpus", None))
         return obj._engine
 
     ref.SeqSample.engine = property(_eng)
     ref.SeqSample._load_reads = SeqSample._load_reads
+    ref.SeqSample._is_fast = SeqSample._is_fast
     ref.SeqSample.deduplicate = SeqSample.deduplicate
     ref.SeqSample.cluster = SeqSample.cluster
     ref.SeqSample._search = SeqSample._search

@@ -212,6 +212,11 @@ class Engine:
         self._chk(self.L.itsx_orient(self.h, strand.ctypes.data, cf.ctypes.data, cr.ctypes.data))
         return strand[:self.n_reads], cf[:self.n_reads], cr[:self.n_reads]
 
+    def orient_file(self, fastq):
+        """load a FASTQ file and orient its reads (what SeqSample.orient_reads needs in one call)"""
+        self.load_reads_file(fastq)
+        return self.orient()
+
     # ---- f2: paired-end merge
     def merge_pairs(self, fwd, fqual, rev, rqual, maxdiffs=40, maxee=2.0, allow_stagger=False):
         """Lists of equal length (str): forward reads / qualities, reverse reads / qualities as they are in the file.

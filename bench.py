@@ -295,8 +295,14 @@ def main():
                     help="1.0 = exact dereplication (the default for cfg1 / cfg2); < 1 runs row a2 (greedy clustering) instead (cfg4: 0.995)")
     ap.add_argument("--taxa", choices=["T", "all"], default="T",
                     help="T = the stand-in taxon (155 ITS2 profiles); all = --taxa All --region ITS2 (814 profiles, configs[3])")
-    ap.add_argument("--global-derep", action="store_true",
-                    help="N > 1: match the uniques across shards (exact global dereplication, SURVEY 8e option 2) instead of per-shard")
+    ap.add_argument("--global-derep", action="store_true", help="(the default at N > 1 since round 4; kept for old command lines)")
+    ap.add_argument("--per-shard-derep", action="store_true",
+                    help="N > 1: every rank dereplicates and scores its own shard only (SURVEY 8e option 1): a sequence present in two shards is "
+                         "scored twice and counted twice in domZ, so coordinates can differ from the one-GPU answer near the thresholds.  The "
+                         "default is EXACT global dereplication (option 2): the result of one GPU on the whole input, read for read")
+    ap.add_argument("--concordance-reads", type=int, default=12000000,
+                    help="N > 1: rank 0 re-runs the whole job on ONE engine after the timed steps and compares every coordinate for equality "
+                         "(`concordance_vs_single_engine`) when the job has at most this many reads (0 = skip)")
     ap.add_argument("--rows", choices=["lazy", "compact", "full"], default="lazy",
                     help="what the search keeps of the domain table (itsx_set_rows_mode): lazy = pairs that cannot win ItsPosition's argmax "
                          "are not evaluated past their Forward score (the default: the step asks for coordinates, not for domtbl.txt); compact = "
@@ -312,6 +318,8 @@ def main():
         sys.exit(launch_ranks(args.gpus))
     if args.cluster_id is None:
         args.cluster_id = 0.995 if args.workload == "cfg4" else 1.0
+    # N > 1: exact global dereplication unless asked otherwise (greedy clustering has no exact sharded form: per shard)
+    args.global_derep = (not args.per_shard_derep) and args.cluster_id >= 1.0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -339,7 +347,7 @@ def main():
     if args.full_rows:
         args.rows = "full"
     from itsxpress_amd import Engine
-    from itsxpress_amd.dist import exchange_and_finalize, exchange_rows, gather_rows, global_derep, read_rows
+    from itsxpress_amd.dist import agree, exchange_and_finalize, exchange_rows, gather_rows, global_derep, read_rows
     import synth
     _load_pmc()
 
@@ -385,18 +393,33 @@ def main():
 
     comm = {"allreduce_ms": 0.0, "gather_ms": 0.0, "lazy_reruns": 0}
 
+    def guarded(fn):
+        """an engine call of this rank; at N > 1 every rank then learns whether all of them got through (a failed rank must not
+        leave its peers waiting in the next collective: they all stop with its message)"""
+        err = None
+        try:
+            fn()
+        except Exception as e:                       # noqa: reported below, on every rank
+            err = e
+        if use_dist and not agree(err is None, cdev):
+            raise RuntimeError("rank %d: %s" % (rank, repr(err) if err is not None else "another rank's engine call failed"))
+        if err is not None:
+            raise err
+
     def step(from_host=False):
-        if from_host:
-            eng.set_reads_buffer(blob, offs)     # staged upload + device packing
-        else:
-            eng.set_reads_device(d_blob.data_ptr(), offs, keep=d_blob)     # device packing of the resident text
-        if args.cluster_id < 1.0:
-            eng.cluster(args.cluster_id, strand_both=True)
-        else:
-            eng.derep(strand_both=True, minseqlength=1)
+        def group():
+            if from_host:
+                eng.set_reads_buffer(blob, offs)     # staged upload + device packing
+            else:
+                eng.set_reads_device(d_blob.data_ptr(), offs, keep=d_blob)     # device packing of the resident text
+            if args.cluster_id < 1.0:
+                eng.cluster(args.cluster_id, strand_both=True)
+            else:
+                eng.derep(strand_both=True, minseqlength=1)
+        guarded(group)
         g = global_derep(eng, n_local, cdev) if (use_dist and args.global_derep) else None
         search = lambda: eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
-        search()
+        guarded(search)
         if not use_dist:
             eng.finalize(domE=10.0)                   # (a lazy search with undecided rows repeats itself in full in here)
             return [eng.trim_coords(lp, rp)]          # (start, stop, tlen, index) per read, on the host
@@ -732,8 +755,51 @@ def main():
                                             "trim_coord_concordance": float((got == rcoords).all(axis=1).mean()),
                                             "concordance_is": "engine vs the real vsearch + hmmsearch path",
                                             "port_value": v, "port_concordance": conc})
+        # N > 1: is the sharded job's answer the one-GPU answer?  Rank 0 regenerates every rank's shard, runs ONE engine on the whole
+        # job and compares every coordinate row for equality (north_star: "100 % trim-coordinate concordance").
+        if use_dist and out is not None and args.cluster_id >= 1.0:
+            tot = int(total_local)
+            room = args.budget_s - (time.time() - T_START)
+            if not args.concordance_reads or tot > args.concordance_reads:
+                res["concordance_vs_single_engine"] = {"skipped": "the job has %d reads, --concordance-reads is %d" % (tot, args.concordance_reads)}
+            elif room < 40.0 + 6.0 * dt / max(args.steps, 1) * world:
+                res["concordance_vs_single_engine"] = {"skipped": "wall-clock budget (--budget-s %.0f): %.0f s left" % (args.budget_s, room)}
+            else:
+                tcz = time.time()
+                progress("one engine on the whole job (%d reads) for concordance_vs_single_engine" % tot)
+                parts, lens = [], []
+                for r in range(world):
+                    n_r = shard_plan(args.workload, args.reads, args.total_reads, args.weak, world, r)[0]
+                    gr = dict(gen, seed=synth.SEED + cfgno + 1000 * r)
+                    if strong:
+                        gr.update(frac_templates=0.02 * args.total_reads / max(n_r, 1))
+                    b_r, o_r = synth.make_reads(thmm, n_r, **gr)
+                    parts.append(b_r)
+                    lens.append(np.diff(o_r))
+                wblob = np.concatenate(parts)
+                woffs = np.zeros(tot + 1, np.int64)
+                np.cumsum(np.concatenate(lens), out=woffs[1:])
+                del parts
+                e1 = Engine(local_rank)
+                e1.set_rows_mode(args.rows)
+                e1.load_profiles(text=hmm)
+                e1.set_reads_buffer(wblob, woffs)
+                e1.derep(strand_both=True, minseqlength=1)
+                e1.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
+                e1.finalize(domE=10.0)
+                one = np.stack(e1.trim_coords(lp, rp), axis=1)
+                e1.close()
+                got = np.concatenate(out)
+                same = one.shape == got.shape and bool(np.array_equal(one, got))
+                res["concordance_vs_single_engine"] = {
+                    "reads": tot, "equal": same,
+                    "fraction_of_reads_equal": float((one == got).all(axis=1).mean()) if one.shape == got.shape else 0.0,
+                    "derep": "exact global (hash-partitioned all-to-all)" if args.global_derep else "per shard (--per-shard-derep)",
+                    "seconds": round(time.time() - tcz, 1),
+                    "note": "rank 0 regenerated every rank's shard and ran one engine on the whole job: start, stop, tlen and the 'has a row' flag of every read"}
         print(json.dumps(res))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1370,6 +1370,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->lazy = mode == ITSX_ROWS_LAZY;
   ctx->lazy_pending = 0; ctx->domz_exchanged = false; ctx->sF1 = F1; ctx->sF3 = F3;
   ctx->domz_ub.assign((size_t)P * ctx->S, 0);
+  if (ctx->compact_rows)                    // a full table of an earlier search (80 B x ~130 per representative) goes back to the device
+    for (auto &b : ctx->dom_bufs) if (b && b->cap * sizeof(itsx_domain) > ((size_t)256 << 20)) b->release();
   S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.lazy_bound_maxdiff = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
   if (ctx->compact_rows && U > 0) {
     ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
@@ -1456,7 +1458,19 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   }
   // (the lazy stage keeps ~40 B per pair -- the record, its Forward score, its bound, the selection scan -- and the 400 B only for
   // the pairs it evaluates: chunks can be several times larger)
-  int64_t Uc = std::max<int64_t>(1, (ctx->lazy ? ctx->pair_budget * 5 : ctx->pair_budget) / std::max(P, 1));
+  int64_t lazy_budget = ctx->pair_budget * 5;
+  if (ctx->lazy) {
+    // ... but never more than the device can hold NOW: a context that ran the full pipeline before keeps its slabs and work lists
+    // (buffers only grow).  ~64 B per pair, a third of what is free plus what the lazy lists hold already.
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      const double held = (double)ctx->d_pairs.cap * sizeof(PairRec) + (double)ctx->l_fb.cap * 4 + (double)ctx->l_b10.cap * 4 + (double)ctx->l_flag.cap * 4 +
+                          (double)ctx->l_pos.cap * 4 + (double)ctx->l_done.cap + (double)ctx->w_res.cap * 2;
+      lazy_budget = std::min<int64_t>(lazy_budget, (int64_t)(((double)fr + held) / 3.0 / 64.0));
+      lazy_budget = std::max<int64_t>(lazy_budget, (int64_t)1 << 20);
+    }
+  }
+  int64_t Uc = std::max<int64_t>(1, (ctx->lazy ? lazy_budget : ctx->pair_budget) / std::max(P, 1));
   Uc = std::min<int64_t>(Uc, ((1ll << 31) - 4096) / std::max(Ppad, 1));
   if (const char *e = getenv("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
   ctx->keep_trace = getenv("ITSX_KEEP_TRACE") != nullptr;

@@ -164,6 +164,18 @@ def allreduce_domz_device(engine, device=None):
     return t
 
 
+def agree(ok, device=None):
+    """Every rank learns whether ALL ranks are fine before the next collective: a rank whose engine call failed must not leave its
+    peers blocked in an all-reduce it never joins.  Returns True when every rank passed ok=True."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(ok)
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=None if (device is None or _host_backend()) else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item()) == 0
+
+
 def exchange_and_finalize(engine, device=None, domE=10.0, search=None):
     """The step between itsx_search and the coordinates on N ranks: all-reduce the counters where they live, apply the thresholds.
     After a LAZY search (csrc/k_lazy.hip) the counters are bounds on hmmsearch's domZ; a rank may then hold rows that neither bound
@@ -291,8 +303,10 @@ def global_derep(engine, n_reads_local, device=None):
     Without an initialised process group this is a no-op."""
     import torch
     import torch.distributed as dist
+    import os
     U = engine.n_unique
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    force = os.environ.get("ITSX_FORCE_DIST") == "1"          # one rank, every collective all the same (the nccl test on a one-GPU box)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         seed_read, _ = engine.get_uniques()
         return dict(active=np.ones(U, bool), seed_gidx=seed_read.astype(np.int64), flip=np.zeros(U, bool), base=0, scorer=None)
     ws, rank = dist.get_world_size(), dist.get_rank()
@@ -320,7 +334,9 @@ def exchange_rows(g, rep_rows):
     scored get that rank's rows: one all-to-all of requests (the scorer's unique numbers), one of answers."""
     import torch
     import torch.distributed as dist
-    if g.get("scorer") is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    import os
+    if g.get("scorer") is None or not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size() == 1 and os.environ.get("ITSX_FORCE_DIST") != "1"):
         return rep_rows
     ws = dist.get_world_size()
     if rep_rows.device != g["active_t"].device:

@@ -124,7 +124,7 @@ def test_bench_runs_its_n_rank_path_with_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(ITSX_BENCH_ONE_GPU="1", ITSX_BENCH_BACKEND="gloo")
-    for extra in (["--reads", "40000"], ["--total-reads", "80000", "--global-derep"]):
+    for extra in (["--reads", "40000", "--per-shard-derep"], ["--total-reads", "80000"]):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "1", "--warmup", "1",
                             "--cpu-sample", "0", "--handover-steps", "0"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -133,3 +133,28 @@ def test_bench_runs_its_n_rank_path_with_two_ranks_on_one_gpu():
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["reads_trimmed_rank0"] > 30000
         assert rec["scaling"] == ("strong" if "--total-reads" in extra else "weak")
+        conc = rec["concordance_vs_single_engine"]
+        if "--per-shard-derep" not in extra:          # the default: exact global dereplication == one engine on the whole job, read for read
+            assert conc["equal"] is True and conc["reads"] == 80000 and "exact global" in conc["derep"]
+        else:
+            assert conc["fraction_of_reads_equal"] > 0.99
+
+
+def test_every_collective_over_rccl_with_one_rank():
+    """the `nccl` backend (= RCCL) on this one-GPU box: one rank, ITSX_FORCE_DIST=1 -- init_process_group(device_id=), the in-place
+    all-reduce on the engine's zero-copy counter view, the all-to-all of the unique keys and of the coordinate rows (int64 / int32),
+    the gather of the rows -- and the line's own check that the result is the one-engine result"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "ITSX_BENCH_BACKEND", "ITSX_BENCH_ONE_GPU")}
+    env.update(ITSX_FORCE_DIST="1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "cfg1", "--reads", "60000", "--steps", "1", "--warmup", "1",
+                        "--cpu-sample", "0", "--handover-steps", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    rec = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["ranks"] is not None and rec["ranks"]["allreduce_ms_per_step_max"] > 0
+    assert rec["config"]["parallelism"].endswith("global derep")
+    assert rec["concordance_vs_single_engine"]["equal"] is True
+    assert rec["full_pipeline"]["coordinates_equal_lazy"] is True

@@ -3,6 +3,7 @@ The oracle cannot run at this size in seconds, so the checks are invariants of t
 cluster maps against an independent numpy/hash grouping, idempotence, permutation and
 reverse-complement invariance, and agreement between the text-file route and the array route."""
 import hashlib
+import time
 
 import numpy as np
 import pytest
@@ -133,6 +134,30 @@ def test_cfg2_size_runs_in_chunks_within_its_time_budget(full2):
     assert full2["wall"] < 90.0, "one cold pass over 10 M reads took %.1f s" % full2["wall"]     # ~10 s warm; first-use allocations included
 
 
+def test_cfg2_size_lazy_stage_equals_the_full_table(engine, t_hmm_text, full2):
+    """the bench's mode at the bench's size: the lazy domain stage's coordinates == the full table's for all 10 M reads, with a
+    twentieth of the pairs evaluated (undecided rows, if any, settled by counting their profiles -- never by the full search)"""
+    engine.set_rows_mode("lazy")
+    try:
+        engine.load_profiles(text=_its2(t_hmm_text))
+        t0 = time.time()
+        engine.set_reads_buffer(full2["blob"], full2["offs"])
+        engine.derep()
+        engine.search()
+        engine.finalize()
+        c = engine.trim_coords("3_", "4_")
+        wall = time.time() - t0
+        st = engine.stats()
+    finally:
+        engine.set_rows_mode(None)
+    assert all(np.array_equal(a, b) for a, b in zip(c, full2["coords"]))
+    assert st["lazy"] == 1 and st["n_lazy_reruns"] == 0
+    assert st["n_past_msv"] == full2["stats"]["n_past_msv"]
+    assert st["n_lazy_evaluated"] * 10 < st["n_past_msv"] and st["n_lazy_completed_profiles"] < st["n_profiles"] // 4
+    assert st["n_rows_resident"] < 0.05 * full2["stats"]["n_rows_resident"]
+    assert wall < 45.0, wall
+
+
 def test_cfg2_size_coordinates_are_cluster_consistent_and_in_range(full2):
     start, stop, tlen, ind = full2["coords"]
     r = full2["rep_of"]
@@ -208,61 +233,48 @@ def test_cfg2_shape_is_invariant_under_permutation_and_dereplication(engine, t_h
 
 # ------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3]: 50 M reads against --taxa All (814 ITS2 profiles), read-sharded over 8 GPUs = 6.25 M reads x 814 profiles per
-# GPU.  One GPU's share at a fifth of its size (the whole share takes 26 s and is a bench run: `bench.py --taxa all --reads 6250000`),
-# with the row compaction the bench runs with: the properties that do not depend on the size, and the sharding identity the N > 1 path
-# relies on (two shards + summed domZ == one run).
-N_CFG3 = 1_250_000
+# GPU: ONE GPU's FULL share, in the mode the bench runs (the lazy domain stage): the properties that do not depend on the size, and
+# the sharding identity the N > 1 path relies on -- two shards with EXACT global dereplication and summed counters == one run, for
+# every read (`==`, not "nearly": round 3's per-shard variant could only promise 0.9999).
+N_CFG3 = 6_250_000
 
 
-def test_cfg3_shape_all_taxa_profiles_compacted_rows_and_two_shards(t_hmm_text, all_its2_hmm_text, monkeypatch):
+def test_cfg3_full_share_all_taxa_profiles_lazy_and_two_exact_shards(t_hmm_text, all_its2_hmm_text):
     from itsxpress_amd import Engine
-    engine = Engine(0)          # a context of its own, closed at the end: its work buffers (which only grow) go back to the device
+    import shards
+    engines = [Engine(0), Engine(0)]   # contexts of their own, closed at the end: their work buffers (which only grow) go back to the device
     try:
-        _cfg3_body(engine, t_hmm_text, all_its2_hmm_text, monkeypatch)
+        blob, offs = synth.make_reads(t_hmm_text, N_CFG3, config=4, fixed_len=0, len_range=(300, 580), as_array=True)
+        e = engines[0]
+        assert e.load_profiles(text=all_its2_hmm_text) == 814
+        e.set_rows_mode("lazy")
+        t0 = time.time()
+        e.set_reads_buffer(blob, offs)
+        e.derep(strand_both=True, minseqlength=1)
+        e.search()
+        e.finalize()
+        c = [a.copy() for a in e.trim_coords("3_", "4_")]
+        wall = time.time() - t0
+        rep = e.get_derep()[0].copy()
+        st = e.stats()
+        e.set_rows_mode(None)
+        start, stop, tlen, ind = c
+        assert st["n_profiles"] == 814 and st["n_pairs"] == st["n_unique"] * 814 and st["lazy"] == 1 and st["n_lazy_reruns"] == 0
+        assert st["n_lazy_evaluated"] * 10 < st["n_past_msv"]           # the stage really skips: < 10 % of the pairs reach Backward
+        assert st["n_rows_resident"] < 4 * st["n_unique"] + 1000         # ~1 row per representative and side
+        assert st["n_domain_overflow"] == 0 and st["n_mr_failed"] == 0
+        for a in c:
+            assert np.array_equal(a, a[rep])                         # every read carries its representative's result
+        both = (start >= 0) & (stop >= 0)
+        assert both.mean() > 0.9 and (stop[both] > start[both]).all()
+        assert np.array_equal(tlen[both], np.diff(offs)[rep][both])
+        assert wall < 60.0, wall                                       # round 3's full pipeline took 26 s for this share
+        # two contiguous shards, exact global dereplication (owner's step), summed counters: the single run's rows for EVERY read
+        h = N_CFG3 // 2
+        parts = [(blob[:int(offs[h])], offs[:h + 1]), (blob[int(offs[h]):], offs[h:] - offs[h])]
+        rows, z, sts = shards.run_shards(engines, parts, all_its2_hmm_text)
+        assert np.array_equal(rows, np.stack(c, axis=1))
+        assert sum(s["n_lazy_evaluated"] for s in sts) < 0.1 * sum(s["n_past_msv"] for s in sts)
     finally:
-        engine.close()
-
-
-def _cfg3_body(engine, t_hmm_text, all_its2_hmm_text, monkeypatch):
-    blob, offs = synth.make_reads(t_hmm_text, N_CFG3, config=4, fixed_len=0, len_range=(300, 580), as_array=True)
-    assert engine.load_profiles(text=all_its2_hmm_text) == 814
-    monkeypatch.setenv("ITSX_COMPACT_ROWS", "1")
-
-    def run(b, o, domz=None):
-        engine.set_reads_buffer(b, o)
-        engine.derep(strand_both=True, minseqlength=1)
-        engine.search()
-        z = engine.get_domz().copy()
-        if domz is not None:
-            engine.set_domz(domz)
-        engine.finalize()
-        return [a.copy() for a in engine.trim_coords("3_", "4_")], z, engine.get_derep()[0].copy(), engine.stats()
-
-    c, z, rep, st = run(blob, offs)
-    start, stop, tlen, ind = c
-    assert st["n_profiles"] == 814 and st["n_pairs"] == st["n_unique"] * 814
-    assert st["n_rows_resident"] * 20 < st["n_domains"]           # ~1.5 rows per representative and side instead of ~200 per representative
-    assert st["n_domain_overflow"] == 0 and st["n_mr_failed"] == 0
-    for a in c:
-        assert np.array_equal(a, a[rep])                         # every read carries its representative's result
-    both = (start >= 0) & (stop >= 0)
-    assert both.mean() > 0.9 and (stop[both] > start[both]).all()
-    assert np.array_equal(tlen[both], np.diff(offs)[rep][both])
-    # two contiguous shards searched on their own, finalized with the SUMMED domZ (what the all-reduce hands every rank), give the
-    # coordinates of the single run for every read whose representative lies in its own shard
-    h = N_CFG3 // 2
-    oa = offs[:h + 1]
-    ob = offs[h:] - offs[h]
-    ba, bb = blob[:int(offs[h])], blob[int(offs[h]):]
-    _, za, _, _ = run(ba, oa)
-    _, zb, _, _ = run(bb, ob)
-    zsum = za + zb
-    ca, _, _, _ = run(ba, oa, zsum)
-    cb, _, repb, _ = run(bb, ob, zsum)
-    # (per-shard dereplication counts a sequence present in both shards twice in domZ: section 7's option 1; the single run's domZ is smaller)
-    assert (zsum >= z).all()
-    same_a = all(np.array_equal(x[:h], y) for x, y in zip(c, ca))
-    own = rep[h:] >= h                                           # reads of shard b whose first occurrence is not in shard a
-    frac = np.mean([(x[h:][own] == y[own]).mean() for x, y in zip(c, cb)])
-    assert same_a or np.mean([(x[:h] == y).mean() for x, y in zip(c, ca)]) > 0.9999
-    assert frac > 0.9999                                         # only domains within a fraction of a bit of the E-value threshold may move
+        for e in engines:
+            e.close()

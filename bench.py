@@ -69,6 +69,7 @@ def _load_pmc():
             return
 
 
+CFG3_SHARE = 6250000             # configs[3]: 50 M reads, --taxa All (814 ITS2 profiles), read-sharded over 8 GPUs = 6.25 M reads per GPU
 CFG4_DEFAULT = 2000000           # reads of a default `--workload cfg4` run (configs[4]'s per-GPU share is 12.5 M: --reads 12500000)
 
 
@@ -104,8 +105,8 @@ def shard_plan(workload, reads, total_reads, weak, world, rank):
     for configs[2]) is the total of the whole job and rank r takes the slice [T r / N, T (r + 1) / N) -- north_star's ">= 6x
     further at 8 GPUs" is on the 10 M-read job.  --weak (or an explicit --reads) gives every rank a full-size shard of its own.
     Returns (reads of this rank, total of the job or 0 when weak, "strong" | "weak")."""
-    own = {"cfg2": 10000000, "cfg1": 1000000, "cfg4": CFG4_DEFAULT}[workload]
-    if world > 1 and not weak and not reads and not total_reads:
+    own = {"cfg2": 10000000, "cfg1": 1000000, "cfg4": CFG4_DEFAULT, "cfg3": CFG3_SHARE}[workload]
+    if world > 1 and not weak and not reads and not total_reads and workload != "cfg3":      # (cfg3 is 50 M reads over 8 GPUs: each rank its share)
         total_reads = own
     if total_reads > 0:
         return total_reads * (rank + 1) // world - total_reads * rank // world, total_reads, "strong"
@@ -278,8 +279,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg4"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg1", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE configs[2] (10 M merged reads, 300-580 bases; the default), cfg1 = configs[1] (1 M x 300), "
+                         "cfg3 = configs[3]'s per-GPU share (6.25 M merged reads against --taxa All: 814 ITS2 profiles; every rank its own share), "
                          "cfg4 = configs[4]'s shape (2x250-merged reads of 300-480 bases, --region ALL profiles, cluster_id 0.995)")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's own size); implies --weak at N > 1")
     ap.add_argument("--total-reads", type=int, default=0,
@@ -360,7 +362,10 @@ def main():
     else:
         with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
             thmm = f.read()
-    cfg2, cfg4 = args.workload == "cfg2", args.workload == "cfg4"
+    cfg3 = args.workload == "cfg3"
+    if cfg3:
+        args.taxa = "all"
+    cfg2, cfg4 = args.workload == "cfg2" or cfg3, args.workload == "cfg4"        # (cfg3 has cfg2's read shape)
     lp, rp = ("1_", "4_") if cfg4 else ("3_", "4_")        # create_runtime_hmm's prefixes: --region ALL / ITS2 (main.py:200-208)
     hmm = region_profiles(thmm, lp, rp)
     if args.taxa == "all":
@@ -374,7 +379,7 @@ def main():
     strong = scaling == "strong"
     progress("generating %d reads (%s)" % (n_local, args.workload))
     t_gen = time.time()
-    cfgno = 3 if cfg2 else (5 if cfg4 else 2)
+    cfgno = 4 if cfg3 else (3 if cfg2 else (5 if cfg4 else 2))
     gen = dict(config=cfgno, seed=synth.SEED + cfgno + 1000 * rank, as_array=True, left=lp, right=rp)
     if cfg2:
         gen.update(fixed_len=0, len_range=(300, 580))
@@ -646,7 +651,7 @@ def main():
         trimmed = int(((c_start >= 0) & (c_stop >= 0) & (c_start < c_stop)).sum())
         shape = ("merged reads of 300-580 bases (mean %.0f)" % mean_len) if cfg2 else \
             ("2x250-merged reads of 300-480 bases (mean %.0f)" % mean_len) if cfg4 else "300 bp single-end reads"
-        cname = "configs[2]" if cfg2 else ("configs[4] (one GPU's shard; the full share is 12.5 M reads)" if cfg4 else "configs[1]")
+        cname = "configs[3] (one GPU's share of the 50 M reads)" if cfg3 else "configs[2]" if cfg2 else ("configs[4] (one GPU's shard; the full share is 12.5 M reads)" if cfg4 else "configs[1]")
         wl = cname + ": %d synthetic %s per GPU" % (n_local, shape)
         if strong:
             wl = cname + ": %d synthetic %s in total, sharded over %d ranks (shared template library)" % (args.total_reads, shape, world)

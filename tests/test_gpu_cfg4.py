@@ -17,7 +17,7 @@ import synth
 pytestmark = pytest.mark.gpu
 
 CID = 0.995
-N_FULL = 1_500_000
+N_FULL = 6_000_000          # about half of one GPU's share of configs[4] (12.5 M): 43 s of clustering on an MI355X (profiles/round3_cluster_curve.jsonl)
 
 
 def _region_all(hmm_text):
@@ -74,10 +74,14 @@ def full4(engine, t_hmm_text):
     rep_of, strand, uniq_of = engine.get_derep()
     pct, order = engine.get_cluster()
     st = engine.stats()
-    engine.search()
-    engine.finalize()
-    coords = engine.trim_coords("1_", "4_")
-    rcoords = engine.rep_coords("1_", "4_")
+    engine.set_rows_mode("lazy")                 # (the centroids' full table would hold ~100 rows each; the coordinates are what is checked)
+    try:
+        engine.search()
+        engine.finalize()
+        coords = engine.trim_coords("1_", "4_")
+        rcoords = engine.rep_coords("1_", "4_")
+    finally:
+        engine.set_rows_mode(None)
     return dict(blob=blob, offs=offs, ncl=ncl, rep_of=rep_of, strand=strand, uniq_of=uniq_of, pct=pct, order=order, stats=st,
                 coords=coords, rcoords=rcoords)
 
@@ -100,7 +104,7 @@ def test_full_size_cluster_structure(full4):
     members = r != np.arange(n)
     assert (full4["pct"][members] >= 100.0 * CID).all() and (full4["pct"][~members] == -1.0).all()
     assert (full4["strand"][~members] == 1).all() and 0.02 < (full4["strand"][members] < 0).mean() < 0.2
-    assert full4["stats"]["ms_cluster"] < 60000.0                 # wall-time guard: ~15 s on an MI355X
+    assert full4["stats"]["ms_cluster"] < 80000.0                 # wall-time guard: 43 s on an MI355X in round 3
 
 
 def test_full_size_members_meet_the_threshold_by_the_oracles_aligner(full4):

@@ -75,7 +75,7 @@ typedef struct {
 typedef struct {
   int64_t n_reads, n_unique, n_dropped_short;
   int64_t n_pairs, n_past_msv, n_past_bias, n_past_fwd, n_regions, n_multidomain, n_domains;
-  int64_t n_domain_overflow;      /* (rep,profile) pairs with more regions than the engine keeps (8) */
+  int64_t n_domain_overflow;      /* (rep,profile) pairs with more than 8 regions: the ones past the pair's slots live in an overflow list (none is dropped) */
   int32_t n_profiles, hash_reseeds;
   /* device time of the last call of each stage, milliseconds (HIP events on the engine's stream) */
   float   ms_derep, ms_msv, ms_filters, ms_domains, ms_finalize;
@@ -102,11 +102,11 @@ typedef struct {
   int64_t n_mr_distinct;     /* distinct (profile, target length, residues) multidomain regions actually sampled */
   int64_t n_slab_shrinks;    /* times the DP slab budget was halved because the device could not supply it */
   float   ms_vit_kernel;     int32_t pad4;               /* Viterbi filter (F2 < F1 only) */
-  /* multidomain regions of the last search that ran into a bookkeeping limit hmmsearch does not have, by kind: [1] matrix not
-   * sampleable, [2] more than 8 domains in one sampled path, [4] more than 512 distinct sampled (i, j, k, m) tuples, [5] a
-   * path left the region, [7] more than 4 envelopes in one region ([3], [6] cannot occur: see k_api.h).  Such a region is
-   * kept as one envelope (flagged); n_domain_overflow counts the (representative, profile) pairs with more than 8 envelopes.
-   * Any of these makes itsx_search return ITSX_E_UNSUPPORTED unless the environment holds ITSX_ALLOW_CAPS=1. */
+  /* multidomain regions of the last search whose Forward matrix could not be sampled, by kind: [1] probabilities not normalised,
+   * [5] a path left the region -- the cases in which hmmsearch's own stochastic traceback throws; itsx_search then returns
+   * ITSX_E_UNSUPPORTED.  The former bookkeeping limits ([2] more than 8 domains in one sampled path, [4] more than 512 distinct
+   * sampled tuples, [7] more than 4 envelopes in one region) no longer fail anything: such regions take the ensemble stage's overflow
+   * path (n_mr_overflow), and a pair's regions past its 8 slots an overflow list (n_domain_overflow counts those pairs). */
   int64_t n_mr_fail_kind[8];
   /* domain rows (80 B each) resident on the device after the last search: all of them (= n_domains plus segment padding), or, with
    * ITSX_COMPACT_ROWS=1, only the rows that can still win ItsPosition's argmax whatever the dataset-wide domZ turns out to be */
@@ -118,6 +118,7 @@ typedef struct {
   int32_t lazy;              int32_t n_bound_launches;
   int64_t n_lazy_pending_profiles;                      /* distinct profiles among the undecided rows that mattered */
   int64_t n_lazy_completed, n_lazy_completed_profiles;  /* itsx_lazy_complete: pairs of the profiles counted exactly, and those profiles */
+  int64_t n_mr_overflow;     /* distinct multidomain regions that went through the ensemble stage's overflow path (per-region arrays sized by the region) */
   float   ms_lazy_complete;  float lazy_bound_maxdiff;  /* ITSX_LAZY_CHECK_BOUND=1 (tests): largest |bound kernel - HMMER-order Forward| of the last search, nats */
   int64_t n_lazy_evaluated, n_lazy_round1, n_lazy_pending, n_lazy_reruns, bound_rows;
   float   ms_bound_kernel, ms_lazy_select;

@@ -50,7 +50,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("n_reads_region_cap", "<i8"), ("n_mr_clustered", "<i8"), ("n_mr_failed", "<i8"), ("n_mr_envelopes", "<i8"),
                 ("ms_ensemble", "<f4"), ("pad3", "<i4"), ("n_mr_distinct", "<i8"), ("n_slab_shrinks", "<i8"), ("ms_vit_kernel", "<f4"), ("pad4", "<i4"),
                 ("n_mr_fail_kind", "<i8", (8,)), ("n_rows_resident", "<i8"),
-                ("lazy", "<i4"), ("n_bound_launches", "<i4"), ("n_lazy_pending_profiles", "<i8"), ("n_lazy_completed", "<i8"), ("n_lazy_completed_profiles", "<i8"), ("ms_lazy_complete", "<f4"), ("lazy_bound_maxdiff", "<f4"), ("n_lazy_evaluated", "<i8"), ("n_lazy_round1", "<i8"),
+                ("lazy", "<i4"), ("n_bound_launches", "<i4"), ("n_lazy_pending_profiles", "<i8"), ("n_lazy_completed", "<i8"), ("n_lazy_completed_profiles", "<i8"), ("n_mr_overflow", "<i8"), ("ms_lazy_complete", "<f4"), ("lazy_bound_maxdiff", "<f4"), ("n_lazy_evaluated", "<i8"), ("n_lazy_round1", "<i8"),
                 ("n_lazy_pending", "<i8"), ("n_lazy_reruns", "<i8"), ("bound_rows", "<i8"), ("ms_bound_kernel", "<f4"),
                 ("ms_lazy_select", "<f4")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)

@@ -78,6 +78,7 @@ struct PairRec {
 struct PairOut {                // filled by the filter/DP kernels
   float filtersc, fwdsc, bcksc, nullsc, msv_sc;
   int32_t pass_bias, pass_fwd, nregions, ndom, flags;
+  int32_t nregions_raw;         // regions the scan kept before clustered ones were replaced by their envelopes (ndom counts those)
 };
 struct RegionRec {              // one envelope to re-score
   int32_t pair;                 // index into the pair list

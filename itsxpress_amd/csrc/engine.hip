@@ -28,10 +28,8 @@
 #include "fastq_io.h"
 
 namespace itsx {
-void launch_region_counts(const PairOut *pout, int64_t npairs, int32_t *cnt, hipStream_t st);
 void launch_region_offsets(int64_t npairs, const PairRec *pairs, const int32_t *pref, const int64_t *seg_pair_start,
                            const int64_t *seg_region_start, int64_t *pair_region0, hipStream_t st);
-void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int64_t *pair_region0, RegionRec *out, hipStream_t st);
 void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, const int32_t *usample, int P, hipStream_t st);
 void launch_positions(const itsx_domain *dom, int64_t n, const int8_t *side, unsigned long long *bl, unsigned long long *br,
                       int32_t *in_ddict, hipStream_t st);
@@ -266,6 +264,9 @@ struct itsx_ctx {
   DBuf<WaveDesc> w_waves, w_rw; DBuf<RegionRec> w_raw; DBuf<float> w_slab, w_eslab;
   DBuf<int32_t> w_mrcnt, w_mroff, w_mrlen, w_mrloff, w_mrrows, w_mrulist, w_mrulist2, w_mru; DBuf<int64_t> w_mrrowoff; DBuf<MrRec> w_mr; DBuf<MrOut> w_mrout; DBuf<int64_t> w_n2off; DBuf<float> w_n2sc, w_mrslab;
   DBuf<uint8_t> w_mrscratch; DBuf<WaveDesc> w_mrwaves;
+  // regions past a pair's MAXDOM slots (k_decode appends; ordered by (pair, k) afterwards) and the ensemble stage's overflow path
+  DBuf<RegionRec> w_pool, w_pool_sorted; DBuf<int32_t> w_pool_k; DBuf<unsigned long long> w_pool_n, w_pool_key; int64_t pool_cap = 0;
+  DBuf<int32_t> w_mrsel; DBuf<int64_t> w_mrselrow; DBuf<MrBig> w_mrbig; DBuf<uint8_t> w_mrarena; DBuf<int32_t> w_mrenv; DBuf<WaveDesc> w_mrbigwaves;
   DBuf<int32_t> w_cl, w_cr;
   DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri, w_uflag;
 };
@@ -1355,7 +1356,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz.assign((size_t)P * ctx->S, 0);
   itsx_stats &S = ctx->stats;
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
-  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.ms_vit_kernel = 0; for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] = 0; S.n_rows_resident = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
+  S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.n_mr_overflow = 0; S.ms_vit_kernel = 0; for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] = 0; S.n_rows_resident = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
   ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
   // rows mode: what the caller selected (itsx_set_rows_mode), else the environment (ITSX_ROWS=full|compact|lazy; ITSX_COMPACT_ROWS=1)
@@ -1484,18 +1485,12 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz = ctx->domz_loc; ctx->domz_ub = ctx->domz_ub_loc;
   S.n_rows_resident = 0;
   for (int64_t r : ctx->dom_n) S.n_rows_resident += r;
-  // Refuse, don't cap: hmmsearch has no limit on envelopes per target or on the bookkeeping of a region's traceback ensemble.
-  // A search that ran into one of this engine's limits would silently differ from the reference's result on those reads
-  // (concatemers, long CCS reads with tandem copies), so it fails loudly; ITSX_ALLOW_CAPS=1 accepts the documented behaviour
-  // (the 8 first envelopes of a pair are kept, a region whose ensemble overran is kept as ONE envelope).
-  if ((S.n_domain_overflow > 0 || S.n_mr_failed > 0) && !(getenv("ITSX_ALLOW_CAPS") && atoi(getenv("ITSX_ALLOW_CAPS")) != 0)) {
+  // Nothing is capped: a pair's regions beyond its slots go to an overflow list, an ensemble beyond the fast kernel's bookkeeping to the
+  // overflow path (k_ensemble.hip).  What remains is what makes hmmsearch itself throw: a region whose Forward matrix cannot be sampled
+  // (p7_StochasticTrace's "probabilities were not normalised"): reported, not papered over.
+  if (S.n_mr_failed > 0) {
     ctx->have_search = false;
-    std::string why = "the search ran into a bookkeeping limit hmmsearch does not have:";
-    if (S.n_domain_overflow) why += " " + std::to_string(S.n_domain_overflow) + " (representative, profile) pair(s) with more than " + std::to_string(MAXDOM) + " envelopes;";
-    static const char *kind[8] = {"", "unsampleable matrix", "more than 8 domains in one sampled path", "", "more than 512 distinct sampled tuples", "path left the region", "", "more than 4 envelopes in one region"};
-    for (int k = 1; k < 8; k++) if (S.n_mr_fail_kind[k]) why += " " + std::to_string(S.n_mr_fail_kind[k]) + " multidomain region(s): " + kind[k] + ";";
-    why += " set ITSX_ALLOW_CAPS=1 to accept the capped result (itsx_stats counts the affected reads)";
-    SET_ERR(ctx, ITSX_E_UNSUPPORTED, why);
+    SET_ERR(ctx, ITSX_E_UNSUPPORTED, std::to_string(S.n_mr_failed) + " multidomain region(s) with a Forward matrix that cannot be sampled (hmmsearch's stochastic traceback throws on them)");
   }
   return ITSX_OK;
 }
@@ -1584,6 +1579,14 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
   }
   DBuf<RegionRec> &d_raw = ctx->w_raw;
   HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));
+  // regions past a pair's MAXDOM slots: hmmsearch keeps them all (a concatemer, a CCS read with tandem copies), so they go to an
+  // overflow list that k_decode appends to; should even that list run full it is enlarged and the pipeline call repeated (pool_retry)
+  if (ctx->pool_cap <= 0) ctx->pool_cap = 1 << 16;
+  RegionPoolView pv{nullptr, nullptr, 0};
+ pool_retry:
+  HIPCHK(ctx->w_pool.alloc((size_t)ctx->pool_cap)); HIPCHK(ctx->w_pool_k.alloc((size_t)ctx->pool_cap)); HIPCHK(ctx->w_pool_n.alloc(2));
+  HIPCHK(hipMemsetAsync(ctx->w_pool_n.p, 0, 2 * sizeof(unsigned long long), st));
+  const itsx_stats stats_before = S;
   {
     StageTimer tm(st);
     // ---- batches of waves that fit the slab
@@ -1617,6 +1620,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
     a.flogsum = ctx->d_flogsum.p; a.logtab = ctx->d_logtab.p; a.pairs = pl.pairs; a.pout = pl.pout; a.waves = d_waves.p; a.slab = d_slab.p;
     a.regions = d_raw.p; a.F1 = F1; a.F3 = F3;
+    a.pool.rec = ctx->w_pool.p; a.pool.k = ctx->w_pool_k.p; a.pool.n = ctx->w_pool_n.p; a.pool.cap = ctx->pool_cap;
     VitArgs va{};
     if (ctx->have_vit) {
       HIPCHK(ctx->d_vit.alloc((size_t)NP));
@@ -1673,6 +1677,32 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
     lazy.collect();
     S.ms_filters += tm.stop();
   }
+  {   // the overflow list: ordered by (pair, region number) so that the kernels below find region k >= MAXDOM of a pair by bisection
+    unsigned long long pn = 0;
+    HIPCHK(hipMemcpyAsync(&pn, ctx->w_pool_n.p, sizeof(pn), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((int64_t)pn > ctx->pool_cap) {               // (never seen; a sample made of concatemers would do it)
+      while (ctx->pool_cap < (int64_t)pn) ctx->pool_cap *= 2;
+      const float keep_ms = S.ms_filters;
+      S = stats_before; S.ms_filters = keep_ms; S.n_slab_shrinks++;
+      goto pool_retry;
+    }
+    if (pn > 0) {
+      std::vector<RegionRec> hr((size_t)pn); std::vector<int32_t> hk((size_t)pn);
+      HIPCHK(hipMemcpyAsync(hr.data(), ctx->w_pool.p, (size_t)pn * sizeof(RegionRec), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(hk.data(), ctx->w_pool_k.p, (size_t)pn * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      std::vector<size_t> ord((size_t)pn);
+      std::iota(ord.begin(), ord.end(), (size_t)0);
+      auto key = [&](size_t i) { return ((unsigned long long)(uint32_t)hr[i].pair << 24) | (unsigned long long)(uint32_t)hk[i]; };
+      std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return key(x) < key(y); });
+      std::vector<RegionRec> sr((size_t)pn); std::vector<unsigned long long> sk((size_t)pn);
+      for (size_t i = 0; i < (size_t)pn; i++) { sr[i] = hr[ord[i]]; sk[i] = key(ord[i]); }
+      HIPCHK(upload(ctx->w_pool_sorted, sr, st)); HIPCHK(upload(ctx->w_pool_key, sk, st));
+      HIPCHK(hipStreamSynchronize(st));
+      pv.rec = ctx->w_pool_sorted.p; pv.key = ctx->w_pool_key.p; pv.n = (int64_t)pn;
+    }
+  }
   // ---- the next chunk's MSV filter, on the second stream: the kernels of the domain stage below wait on memory most of the
   // time (tracebacks, envelope slabs, hashing), the MSV kernel is pure VALU work at 75 registers -- the two share the SIMDs
   if (next_msv) { const int rc = (*next_msv)(); if (rc != ITSX_OK) return rc; }
@@ -1683,7 +1713,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
   if (ensemble) {
     DBuf<int32_t> &mrcnt = ctx->w_mrcnt, &mroff = ctx->w_mroff, &stmp = ctx->w_scan2;
     HIPCHK(mrcnt.alloc((size_t)NP + 2)); HIPCHK(mroff.alloc((size_t)NP + 2)); HIPCHK(stmp.alloc((size_t)scan_tmp_elems(NP + 2)));
-    launch_mr_count(pl.pout, d_raw.p, NP, mrcnt.p, st);
+    launch_mr_count(pl.pout, d_raw.p, pv, NP, mrcnt.p, st);
     launch_exclusive_scan(mrcnt.p, mroff.p, NP + 1, stmp.p, st);
     int32_t tot = 0;
     HIPCHK(hipMemcpyAsync(&tot, mroff.p + NP, 4, hipMemcpyDeviceToHost, st));
@@ -1693,7 +1723,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
       StageTimer tm_e(st);
       static_assert(sizeof(MrRec) == sizeof(RegionRec), "MrRec is handed to the region memoisation kernels as a RegionRec");
       HIPCHK(ctx->w_mr.alloc((size_t)NMR));
-      launch_mr_fill(pl.pout, d_raw.p, NP, mroff.p, ctx->w_mr.p, st);
+      launch_mr_fill(pl.pout, d_raw.p, pv, NP, mroff.p, ctx->w_mr.p, st);
       // ---- memoisation: distinct (profile, target length, residues) regions
       DBuf<unsigned long long> &rkeys = ctx->w_keys; DBuf<int32_t> &rvals = ctx->w_vals; DBuf<uint32_t> &rslot = ctx->w_slot_of;
       DBuf<int32_t> &rrep = ctx->w_rrep, &ruq = ctx->w_ruq, &rurank = ctx->w_rurank, &rscan = ctx->w_scan_tmp;
@@ -1786,23 +1816,86 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
         }
         w0 = w1;
       }
-      DBuf<int64_t> &d_c = ctx->w_counters;
-      HIPCHK(d_c.alloc(16));
-      HIPCHK(hipMemsetAsync(d_c.p, 0, 16 * sizeof(int64_t), st));
-      launch_mr_apply(pl.pout, d_raw.p, NP, mroff.p, mru.p, ctx->w_mrout.p, (unsigned long long *)d_c.p, st);
-      int64_t hc[10] = {0};
-      HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+      // ---- the overflow path: regions whose ensemble did not fit the fast kernel's fixed bookkeeping (more than 8 domains in a
+      // sampled path, more than 512 distinct tuples, more than 4 envelopes) run again with per-region arrays sized by their length
+      {
+        HIPCHK(ctx->w_mrsel.alloc((size_t)NU + 1)); HIPCHK(ctx->w_pool_n.alloc(2));
+        HIPCHK(hipMemsetAsync(ctx->w_pool_n.p + 1, 0, sizeof(unsigned long long), st));
+        launch_mr_overflowed(ctx->w_mrout.p, NU, ctx->w_mrsel.p, ctx->w_pool_n.p + 1, st);
+        unsigned long long nov = 0;
+        HIPCHK(hipMemcpyAsync(&nov, ctx->w_pool_n.p + 1, sizeof(nov), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nov > 0) {
+          std::vector<int32_t> sel((size_t)nov);
+          HIPCHK(hipMemcpyAsync(sel.data(), ctx->w_mrsel.p, (size_t)nov * 4, hipMemcpyDeviceToHost, st));
+          HIPCHK(hipStreamSynchronize(st));
+          std::sort(sel.begin(), sel.end());              // ascending position = ascending length (the fast pass's order)
+          S.n_mr_overflow += (int64_t)nov;
+          int64_t envtot = 0;                             // the envelope lists of all of them: 2 x 4 (Lr + 1) ints each, kept until the chunk is scored
+          std::vector<int64_t> envoff(sel.size());
+          for (size_t x = 0; x < sel.size(); x++) { envoff[x] = envtot; envtot += 8 * ((int64_t)hlen[(size_t)ord[(size_t)sel[x]]] + 1); }
+          HIPCHK(ctx->w_mrenv.alloc((size_t)envtot + 8));
+          size_t x0 = 0;
+          while (x0 < sel.size()) {                       // batches of regions whose blocks fit 8 GB together (one region at least)
+            std::vector<MrBig> big; std::vector<int64_t> srow; std::vector<WaveDesc> bw;
+            int64_t arena = 0, rows = 0; size_t x1 = x0;
+            while (x1 < sel.size()) {
+              const int Lr = hlen[(size_t)ord[(size_t)sel[x1]]];
+              MrBig g{}; g.capD = Lr + 1; g.capT = 200 * g.capD;
+              uint32_t hs = 1024; while (hs < 2u * (uint32_t)g.capT) hs <<= 1;
+              g.hmask = hs - 1;
+              auto al = [](int64_t v) { return (v + 15) & ~(int64_t)15; };
+              const int64_t capSig = 4 * (int64_t)g.capD;
+              const int64_t bytes = al(8ll * g.capT) + 6 * al(4ll * g.capT) + al(4ll * hs) + al(4ll * g.capD) + al(16ll * g.capD) + 3 * al(4 * capSig) +
+                                    al(g.capT) + al(2ll * g.capD) + al(capSig) + al(2 * MR_EPC) + 64;
+              g.envoff = envoff[x1];
+              if (x1 > x0 && arena + bytes > ((int64_t)8 << 30)) break;
+              g.off = arena; arena += bytes;
+              big.push_back(g); srow.push_back(rows); rows += Lr + 1;
+              x1++;
+            }
+            for (size_t x = x0; x < x1; x += MR_LANES_LONG) {      // few lanes per wave: these are the long, slow regions
+              WaveDesc d{}; d.prof = -1; d.first = (int64_t)(x - x0); d.count = (int32_t)std::min<size_t>(MR_LANES_LONG, x1 - x);
+              d.rows = hlen[(size_t)ord[(size_t)sel[x + d.count - 1]]] + 1;
+              bw.push_back(d);
+            }
+            std::vector<int32_t> selb(sel.begin() + x0, sel.begin() + x1);
+            HIPCHK(upload(ctx->w_mrsel, selb, st)); HIPCHK(upload(ctx->w_mrselrow, srow, st)); HIPCHK(upload(ctx->w_mrbig, big, st)); HIPCHK(upload(ctx->w_mrbigwaves, bw, st));
+            if ((size_t)rows * MRV * 4 > ctx->w_mrslab.cap) HIPCHK(ctx->w_mrslab.alloc((size_t)rows * MRV * 4));
+            HIPCHK(ctx->w_mrarena.alloc((size_t)arena));
+            MrArgs mb{};
+            mb.rd = ctx->rd; mb.sorted_uniq = d_sorted; mb.seed_read = ctx->d_seed_read.p; mb.prof = ctx->d_prof.p; mb.pairs = pl.pairs;
+            mb.mr = ctx->w_mr.p; mb.ulist = ulist.p; mb.u0 = 0; mb.waves = ctx->w_mrbigwaves.p; mb.slab = (float4 *)ctx->w_mrslab.p;
+            mb.rowoff = ctx->w_mrrowoff.p; mb.rowoff0 = 0; mb.n2off = ctx->w_n2off.p; mb.n2sc = ctx->w_n2sc.p; mb.out = ctx->w_mrout.p;
+            mb.scratch = nullptr; mb.sel = ctx->w_mrsel.p; mb.sel_rowoff = ctx->w_mrselrow.p; mb.big = ctx->w_mrbig.p; mb.arena = ctx->w_mrarena.p; mb.envpool = ctx->w_mrenv.p;
+            launch_mr_ensemble_big(mb, (int)bw.size(), st);
+            x0 = x1;
+          }
+        }
+      }
       S.ms_ensemble += tm_e.stop();
       HIPCHK(hipGetLastError());
-      S.n_mr_clustered += NMR; S.n_mr_distinct += NU; S.n_mr_failed += hc[0]; S.n_mr_envelopes += hc[1];
-      for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] += hc[2 + k];
+      S.n_mr_clustered += NMR; S.n_mr_distinct += NU;
     }
   }
   // ---- compact regions into a profile-grouped list
   DBuf<int32_t> &d_rcnt = ctx->w_rcnt, &d_rpref = ctx->w_rpref, &d_scan_tmp = ctx->w_scan2;
   HIPCHK(d_rcnt.alloc((size_t)NP + 1)); HIPCHK(d_rpref.alloc((size_t)NP + 1)); HIPCHK(d_scan_tmp.alloc((size_t)scan_tmp_elems(NP + 1)));
   HIPCHK(hipMemsetAsync(d_rcnt.p, 0, ((size_t)NP + 1) * 4, st));
-  launch_region_counts(pl.pout, NP, d_rcnt.p, st);
+  RegionListArgs rl{};
+  rl.pout = pl.pout; rl.raw = d_raw.p; rl.pv = pv; rl.npairs = NP;
+  if (NMR > 0) { rl.mr_off = ctx->w_mroff.p; rl.mr_u = ctx->w_mru.p; rl.mrout = ctx->w_mrout.p; rl.envpool = ctx->w_mrenv.p; }
+  {
+    DBuf<int64_t> &d_c = ctx->w_counters;
+    HIPCHK(d_c.alloc(16));
+    HIPCHK(hipMemsetAsync(d_c.p, 0, 16 * sizeof(int64_t), st));
+    launch_region_list_count(rl, d_rcnt.p, (unsigned long long *)d_c.p, st);
+    int64_t hc[10] = {0};
+    HIPCHK(hipMemcpyAsync(hc, d_c.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    S.n_mr_failed += hc[0]; S.n_mr_envelopes += hc[1];
+    for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] += hc[2 + k];
+  }
   launch_exclusive_scan(d_rcnt.p, d_rpref.p, NP + 1, d_scan_tmp.p, st);
   std::vector<int32_t> bound((size_t)P + 1);
   {
@@ -1826,7 +1919,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
     HIPCHK(upload(d_rseg, rseg, st));
     launch_region_offsets(NP, pl.pairs, d_rpref.p, pl.d_seg_start, d_rseg.p, ctx->d_pair_region0.p, st);
     HIPCHK(hipMemsetAsync(ctx->d_regions.p, 0xFF, (size_t)NR * sizeof(RegionRec), st));     // padding slots: pair = -1
-    launch_region_fill(pl.pout, d_raw.p, NP, ctx->d_pair_region0.p, ctx->d_regions.p, st);
+    launch_region_list_fill(rl, ctx->d_pair_region0.p, ctx->d_regions.p, st);
     // ---- envelope memoisation: only distinct (profile, L, residues) envelopes are re-scored
     DBuf<unsigned long long> &rkeys = ctx->w_keys; DBuf<int32_t> &rvals = ctx->w_vals; DBuf<uint32_t> &rslot = ctx->w_slot_of;
     DBuf<int32_t> &rrep = ctx->w_rrep, &ruq = ctx->w_ruq, &rurank = ctx->w_rurank, &rscan = ctx->w_scan_tmp;

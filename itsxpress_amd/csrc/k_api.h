@@ -176,6 +176,24 @@ struct WaveDesc {               // one wave = up to 64 items that share a profil
   int32_t pad;
 };
 struct VitOut { float vitsc; int32_t ran, pass; };      // k_vit.hip: verdict of the Viterbi filter for one pair
+// hmmsearch has no limit on the regions of a target (itsxpress/SeqSample.py:191-209 runs it on concatemers like on anything
+// else): a pair's first MAXDOM regions sit in its raw slots, the rest -- rare by construction -- go to this list, (pair, k) tagged
+struct RegionPool { RegionRec *rec; int32_t *k; unsigned long long *n; int64_t cap; };
+__device__ __forceinline__ void pool_put(const RegionPool &p, const RegionRec &r, int k)
+{
+  const unsigned long long i = atomicAdd(p.n, 1ULL);
+  if ((int64_t)i < p.cap) { p.rec[i] = r; p.k[i] = k; }
+}
+// after the list has been ordered by (pair, k): region k >= MAXDOM of pair pi (binary search; only pairs past their slots come here)
+struct RegionPoolView { const RegionRec *rec; const unsigned long long *key; int64_t n; };
+__device__ __forceinline__ RegionRec raw_region(const RegionRec *raw, const RegionPoolView &pv, int64_t pi, int k)
+{
+  if (k < MAXDOM) return raw[pi * MAXDOM + k];
+  const unsigned long long want = ((unsigned long long)pi << 24) | (unsigned long long)k;
+  int64_t lo = 0, hi = pv.n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (pv.key[mid] < want) lo = mid + 1; else hi = mid; }
+  return pv.rec[lo];
+}
 struct FloatArgs {
   ReadsDev rd;
   const int32_t *sorted_uniq, *seed_read;
@@ -189,6 +207,7 @@ struct FloatArgs {
   float *slab;                  // xmx rows: two planes of [row][6][64] (k_float.hip: SLAB)
   int64_t slab_plane;           // floats between the planes = rows of this batch x 6 x 64
   RegionRec *regions;           // [npairs][MAXDOM] raw, before compaction
+  RegionPool pool;              // regions past a pair's MAXDOM slots
   const VitOut *vit;            // Viterbi filter verdicts (null when the filter did not run: F2 >= F1)
   double F1, F3;
 };
@@ -248,7 +267,11 @@ constexpr int MR_HASH = 1024;      // slots of the per-region tuple index (a pow
 constexpr int MR_EPC = 256;        // widest endpoint histogram kept as an array (wider ones are counted pairwise)
 constexpr int MR_SCRATCH = 19456;  // bytes of per-region bookkeeping (k_ensemble.hip: MrScratch)
 struct MrRec { int32_t pair, ireg, jreg, slot; };                         // field for field a RegionRec (the memoisation kernels take it as one)
-struct MrOut { int32_t status, nenv; int32_t ei[MRENV], ej[MRENV]; };     // status 0 = resolved (else the region yields nothing); envelopes relative to the region (1-based)
+// status 0 = resolved; 2 / 4 / 7 = a bookkeeping limit of the fast kernel was hit (the region then goes through the overflow path, whose
+// arrays are sized by the region's length and cannot overrun); 1 / 5 = the matrix could not be sampled (hmmsearch itself throws there).
+// envelopes relative to the region (1-based): the first MRENV here, all nenv of them at envpool[big ...] when the overflow path ran (big >= 0)
+struct MrOut { int32_t status, nenv; int32_t ei[MRENV], ej[MRENV]; int64_t big; };
+struct MrBig { int64_t off, envoff; int32_t capD, capT; uint32_t hmask; int32_t pad; };    // one region's block of the overflow arena (engine.hip sizes it)
 struct MrArgs {
   ReadsDev rd;
   const int32_t *sorted_uniq, *seed_read;
@@ -265,18 +288,32 @@ struct MrArgs {
   float *n2sc;
   MrOut *out;                   // [distinct]
   uint8_t *scratch;
+  // the overflow path (regions the fast kernel could not hold): lanes take the regions sel[first + lane], whose matrices start at slab
+  // row sel_rowoff[first + lane], with per-region arrays in `arena`
+  const int32_t *sel; const int64_t *sel_rowoff; const MrBig *big; uint8_t *arena;
+  int32_t *envpool;             // the overflow path's envelope lists (they outlive the arena: read when the chunk's region list is built)
   unsigned long long *dbg;      // optional [4]: wave-clock ticks spent walking paths, closing them, clustering (ITSX_MR_DEBUG)
 };
-void launch_mr_count(const PairOut *pout, const RegionRec *raw, int64_t npairs, int32_t *cnt, hipStream_t st);
-void launch_mr_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *off, MrRec *mr, hipStream_t st);
+void launch_mr_count(const PairOut *pout, const RegionRec *raw, RegionPoolView pv, int64_t npairs, int32_t *cnt, hipStream_t st);
+void launch_mr_fill(const PairOut *pout, const RegionRec *raw, RegionPoolView pv, int64_t npairs, const int32_t *off, MrRec *mr, hipStream_t st);
 // distinct regions: ulist[urank[m]] = m and ulen = region length for the first copies; mr_u[m] = index of m's distinct region
 void launch_mr_ulist(int64_t nmr, const MrRec *mr, const int32_t *rep, const int32_t *is_uniq, const int32_t *urank, int32_t *ulist, int32_t *ulen,
                      int32_t *mr_u, hipStream_t st);
 // regions ordered by length: ulist_out[newpos[u]] = ulist_in[u], mr_u[m] = newpos[mr_u[m]]
 void launch_mr_reorder(int64_t nu, int64_t nmr, const int32_t *newpos, const int32_t *ulist_in, int32_t *ulist_out, int32_t *mr_u, hipStream_t st);
 void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st);
-void launch_mr_apply(PairOut *pout, RegionRec *raw, int64_t npairs, const int32_t *off, const int32_t *mr_u, const MrOut *out, unsigned long long *counters,
-                     hipStream_t st);
+void launch_mr_ensemble_big(const MrArgs &a, int nwaves, hipStream_t st);
+// distinct regions the fast kernel gave up on (status 2, 4, 7 -- and 3, 6, which cannot occur): appended to list, counted in n[0]
+void launch_mr_overflowed(const MrOut *out, int64_t nu, int32_t *list, unsigned long long *n, hipStream_t st);
+// A pair's final envelope list: its regions in order, every clustered region replaced by its envelopes (k_mr_apply's job until round 3,
+// now without a fixed-size buffer: counted, then written straight into the profile-grouped list).  cnt[pi] = envelopes (pout.ndom is set
+// to it); counters: [0] regions whose matrix could not be sampled, [1] cluster envelopes, [2 + status] such regions by kind
+struct RegionListArgs {
+  PairOut *pout; const RegionRec *raw; RegionPoolView pv; int64_t npairs;
+  const int32_t *mr_off; const int32_t *mr_u; const MrOut *mrout; const int32_t *envpool;     // null mr_off: no clustered regions in this chunk
+};
+void launch_region_list_count(const RegionListArgs &a, int32_t *cnt, unsigned long long *counters, hipStream_t st);
+void launch_region_list_fill(const RegionListArgs &a, const int64_t *pair_region0, RegionRec *out, hipStream_t st);
 
 struct ScoreArgs {
   ReadsDev rd;

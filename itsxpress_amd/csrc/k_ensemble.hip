@@ -18,6 +18,7 @@
 #include "k_api.h"
 #include "detmath.h"
 #include "k_vec.h"
+#include <type_traits>
 
 namespace itsx {
 
@@ -35,13 +36,14 @@ DEV float comp4(const f4 &t, int r) { return r == 0 ? t.x : r == 1 ? t.y : r == 
 DEV f4 tof4(const V4 &v) { return (f4){v.a.x, v.a.y, v.b.x, v.b.y}; }
 
 struct MrLane {
-  bool active; int64_t mi; MrRec m; int L, Lr, off, Q; const DevProfile *pp; Seq sq; float pmove, ploop; int64_t r0;
+  bool active; int64_t mi, slot; MrRec m; int L, Lr, off, Q; const DevProfile *pp; Seq sq; float pmove, ploop; int64_t r0;
 };
 DEV MrLane mr_lane(const MrArgs &a, const WaveDesc &wd, int lane)
 {
   MrLane e;
   e.active = lane < wd.count;
-  e.mi = wd.first + (e.active ? lane : 0);             // index of the distinct region
+  const int64_t slot = wd.first + (e.active ? lane : 0);
+  e.mi = a.sel ? (int64_t)a.sel[slot] : slot;          // index of the distinct region (the overflow path walks a selection)
   e.m = a.mr[a.ulist[e.mi]];
   const PairRec pr = a.pairs[e.m.pair];
   e.L = pr.L; e.Lr = e.m.jreg - e.m.ireg + 1; e.off = e.m.ireg - 1;
@@ -49,7 +51,8 @@ DEV MrLane mr_lane(const MrArgs &a, const WaveDesc &wd, int lane)
   e.sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
   e.pmove = (2.0f + 1.0f) / ((float)e.L + 2.0f + 1.0f);       // multihit, length model of the whole target
   e.ploop = 1.0f - e.pmove;
-  e.r0 = a.rowoff[e.mi] - a.rowoff0;
+  e.r0 = a.sel ? a.sel_rowoff[slot] : a.rowoff[e.mi] - a.rowoff0;
+  e.slot = slot;
   return e;
 }
 
@@ -223,8 +226,17 @@ struct MrScratch {
 };
 static_assert(sizeof(MrScratch) <= MR_SCRATCH, "scratch block too small");
 
+// BIG = the overflow path: the same procedure for the regions whose ensemble does not fit the fast kernel's fixed bookkeeping (more
+// than 8 domains in one sampled path, more than 512 distinct tuples, more than 4 envelopes: concatemers, tandem partial copies).
+// Every per-region array then lives in a block of global memory sized by the region's length -- a path of a region of Lr residues
+// has at most Lr domains, 200 paths at most 200 Lr tuples, at most 4 Lr clusters reach a quarter of the paths -- with 32-bit
+// indices: nothing can overrun, as in hmmsearch (p7_domaindef.c grows its lists).  Same random stream, same sums, same order.
+template <bool BIG>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_mr_trace(MrArgs a, int wave0)
 {
+  using idx_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
+  using sidx_t = typename std::conditional<BIG, int32_t, int16_t>::type;
+  constexpr idx_t NONE = (idx_t)~(idx_t)0;
   // usage of the domain being walked: a match state is visited at most once per node (a bit mask), insert states are counted
   __shared__ uint16_t cntI_s[QMAX * 4][MR_LANES];
   // the domains of the path being sampled, last first: first / last residue, first / last node, null2 odds of A C G T
@@ -238,9 +250,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const float *tfn = e.pp->tfn;
   const float pmove = e.pmove, ploop = e.ploop;
   float *n2 = a.n2sc + a.n2off[e.mi];                       // n2[pos - 1], pos = 1..Lr relative to the region
-  MrScratch &S = *(MrScratch *)(a.scratch + (int64_t)(e.mi - a.u0) * MR_SCRATCH);
+  // the region's bookkeeping: a fixed block per lane (fast path) or a block of the arena sized by the region (overflow path)
+  MrBig bg; bg.off = 0; bg.envoff = 0; bg.capD = MR_MAXD; bg.capT = MR_TCAP; bg.hmask = MR_HASH - 1; bg.pad = 0;
+  if constexpr (BIG) bg = a.big[e.slot];
+  const int capD = BIG ? bg.capD : MR_MAXD, capT = BIG ? bg.capT : MR_TCAP, capS = BIG ? bg.capT : MR_SCAP;
+  const int capSig = BIG ? 4 * bg.capD : MR_NSIG, capEnv = BIG ? 4 * bg.capD : MRENV;
+  const uint32_t hmask = BIG ? bg.hmask : (uint32_t)(MR_HASH - 1);
+  unsigned long long *Skey; idx_t *Stcount, *Scomp, *Sstack, *Sninc, *Stid, *Shslot; sidx_t *Slast; uint8_t *Stidx, *Sdominated;
+  uint16_t *Sepc; int32_t *Ssig_i, *Ssig_j, *Senv = nullptr; float *Ssig_p; f4 *Sdn2; uint32_t *Gdom_ij = nullptr; uint16_t *Gdom_km = nullptr;
+  if constexpr (BIG) {
+    uint8_t *blk = a.arena + bg.off;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { uint8_t *q = blk + o; o += (bytes + 15) & ~(size_t)15; return q; };
+    Skey = (unsigned long long *)take(8 * (size_t)capT);
+    Stcount = (idx_t *)take(4 * (size_t)capT); Scomp = (idx_t *)take(4 * (size_t)capT); Sstack = (idx_t *)take(4 * (size_t)capT);
+    Sninc = (idx_t *)take(4 * (size_t)capT); Slast = (sidx_t *)take(4 * (size_t)capT); Stid = (idx_t *)take(4 * (size_t)capT);
+    Shslot = (idx_t *)take(4 * ((size_t)hmask + 1));
+    Gdom_ij = (uint32_t *)take(4 * (size_t)capD); Sdn2 = (f4 *)take(16 * (size_t)capD);
+    Ssig_i = (int32_t *)take(4 * (size_t)capSig); Ssig_j = (int32_t *)take(4 * (size_t)capSig); Ssig_p = (float *)take(4 * (size_t)capSig);
+    Senv = a.envpool + bg.envoff;
+    Stidx = (uint8_t *)take((size_t)capT); Gdom_km = (uint16_t *)take(2 * (size_t)capD); Sdominated = (uint8_t *)take((size_t)capSig);
+    Sepc = (uint16_t *)take(2 * MR_EPC);
+  } else {
+    MrScratch &S = *(MrScratch *)(a.scratch + (int64_t)(e.mi - a.u0) * MR_SCRATCH);
+    Skey = S.key; Stcount = (idx_t *)S.tcount; Scomp = (idx_t *)S.comp; Sstack = (idx_t *)S.stack; Sninc = (idx_t *)S.ninc; Slast = (sidx_t *)S.last;
+    Stid = (idx_t *)S.tid; Stidx = S.tidx; Shslot = (idx_t *)S.hslot; Sepc = S.epc; Ssig_i = S.sig_i; Ssig_j = S.sig_j; Ssig_p = S.sig_p;
+    Sdominated = S.dominated; Sdn2 = S.dn2;
+  }
+#define DOM_IJ(d) (*(BIG ? &Gdom_ij[(d)] : &dom_ij[(d) < MR_MAXD ? (d) : 0][lane]))
+#define DOM_KM(d) (*(BIG ? &Gdom_km[(d)] : &dom_km[(d) < MR_MAXD ? (d) : 0][lane]))
   for (int pos = 0; pos < Lr; pos++) n2[pos] = 0.0f;
-  for (int z = 0; z < MR_HASH; z++) S.hslot[z] = 0;
+  for (uint32_t z = 0; z <= hmask; z++) Shslot[z] = 0;
   uint32_t rng = rnd_mix3(42u, 87654321u, 12345678u);
   if (rng == 0) rng = 42;
   int ntup = 0, nsamp = 0, status = 0;
@@ -307,7 +347,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
             }
             if (s1 < 0 && sum < 0.99) { status = 1; s1 = ST_S; }          // HMMER throws here
           }
-          if (status == 0 && nd >= MR_MAXD) { status = 2; s1 = ST_S; }
+          if (status == 0 && nd >= capD) { status = 2; s1 = ST_S; }
           if (status == 0) {
             nd++;
             dfrom = dto = dk = dm = 0;
@@ -370,12 +410,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
               sv[x] = vadd(sv[x], iv);
             }
           }
-          dom_ij[nd - 1][lane] = (uint32_t)dfrom | ((uint32_t)dto << 16);
-          dom_km[nd - 1][lane] = (uint16_t)((uint32_t)dk | ((uint32_t)dm << 8));
+          DOM_IJ(nd - 1) = (uint32_t)dfrom | ((uint32_t)dto << 16);
+          DOM_KM(nd - 1) = (uint16_t)((uint32_t)dk | ((uint32_t)dm << 8));
           { float v4_[4];
 #pragma unroll
             for (int x = 0; x < 4; x++) { float v = vhsum(sv[x]); v += xfactor; v4_[x] = v; }
-            S.dn2[nd - 1] = (f4){v4_[0], v4_[1], v4_[2], v4_[3]}; }
+            Sdn2[nd - 1] = (f4){v4_[0], v4_[1], v4_[2], v4_[3]}; }
         }
       }
     }
@@ -384,24 +424,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (status) continue;
     // ---- after the path, all lanes together: its samples ...
     for (int d = 0; d < nd; d++) {
-      if (nsamp >= MR_SCAP) { status = 3; break; }
-      const uint32_t ij = dom_ij[d][lane], km = (uint32_t)dom_km[d][lane];
+      if (nsamp >= capS) { status = 3; break; }
+      const uint32_t ij = DOM_IJ(d), km = (uint32_t)DOM_KM(d);
       const unsigned long long key = pack_tup((int)(ij & 0xffff), (int)(ij >> 16), (int)(km & 0xff), (int)(km >> 8));   // relative to the region
-      uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 40) & (MR_HASH - 1);
+      uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (BIG ? 32 : 40)) & hmask;
       int tix = -1;
       for (;;) {
-        const int v = S.hslot[h];
+        const int v = Shslot[h];
         if (v == 0) break;
-        if (S.key[v - 1] == key) { tix = v - 1; break; }
-        h = (h + 1) & (MR_HASH - 1);
+        if (Skey[v - 1] == key) { tix = v - 1; break; }
+        h = (h + 1) & hmask;
       }
       if (tix < 0) {
-        if (ntup >= MR_TCAP) { status = 4; break; }
-        tix = ntup; S.key[ntup] = key; S.tcount[ntup] = 0; ntup++;
-        S.hslot[h] = (uint16_t)(tix + 1);
+        if (ntup >= capT) { status = 4; break; }
+        tix = ntup; Skey[ntup] = key; Stcount[ntup] = 0; ntup++;
+        Shslot[h] = (idx_t)(tix + 1);
       }
-      S.tcount[tix]++;
-      S.tid[nsamp] = (uint16_t)tix; S.tidx[nsamp] = (uint8_t)t; nsamp++;
+      Stcount[tix]++;
+      Stid[nsamp] = (idx_t)tix; Stidx[nsamp] = (uint8_t)t; nsamp++;
     }
     tk_dedupe += wall_clock64() - tk1;
     if (status) continue;
@@ -419,8 +459,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
           const int pos = p4 - z;
           v[z] = 1.0f;
           if (pos < 1 || pos > Lr) continue;
-          while (d < nd && pos <= (int)(dom_ij[d][lane] & 0xffff)) d++;
-          if (d < nd && pos <= (int)(dom_ij[d][lane] >> 16)) {
+          while (d < nd && pos <= (int)(DOM_IJ(d) & 0xffff)) d++;
+          if (d < nd && pos <= (int)(DOM_IJ(d) >> 16)) {
             const int p0 = e.off + pos - 1;
             int x;
             if (e.sq.nexc <= 2) {                       // the read's (at most two) non-ACGT symbols sit in registers
@@ -428,7 +468,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
               x = (int)((cw >> (2 * (p0 & 15))) & 3u);
               x = p0 == ex0p ? ex0c : x; x = p0 == ex1p ? ex1c : x;
             } else x = e.sq.code(p0);
-            if (d != dl) { dl = d; n2d = S.dn2[d]; }
+            if (d != dl) { dl = d; n2d = Sdn2[d]; }
             if (x < 4) v[z] = comp4(n2d, x);
             else {
               float acc = 0.f; int ndg = 0;
@@ -452,7 +492,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const unsigned long long tk2 = wall_clock64();
 
   MrOut out;
-  out.status = status; out.nenv = 0;
+  out.status = status; out.nenv = 0; out.big = -1;
+  if constexpr (BIG) out.big = bg.envoff;
 #pragma unroll
   for (int z = 0; z < MRENV; z++) { out.ei[z] = 0; out.ej[z] = 0; }
   if (status != 0) {
@@ -465,52 +506,52 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // ---- single-linkage clustering over the DISTINCT tuples.  Copies of one tuple always share their neighbours, so they
   // fall into one component -- except an isolated tuple that does not link to itself (model span under 5 nodes): there
   // every copy is a cluster of its own with posterior 1/200, which never reaches 0.25.
-  for (int h = 0; h < ntup; h++) S.comp[h] = 0xffff;
+  for (int h = 0; h < ntup; h++) Scomp[h] = NONE;
   int nc = 0;
   for (int h0 = 0; h0 < ntup; h0++) {
-    if (S.comp[h0] != 0xffff) continue;
-    int ns = 0; S.stack[ns++] = (uint16_t)h0; S.comp[h0] = (uint16_t)nc;
+    if (Scomp[h0] != NONE) continue;
+    int ns = 0; Sstack[ns++] = (idx_t)h0; Scomp[h0] = (idx_t)nc;
     int members = 0;
     while (ns > 0) {
-      const int v = S.stack[--ns];
+      const int v = Sstack[--ns];
       members++;
-      const Tup tv = unpack_tup(S.key[v]);
+      const Tup tv = unpack_tup(Skey[v]);
       for (int u0 = 0; u0 < ntup; u0 += 4) {                      // four candidates requested together
-        unsigned long long ku[4]; uint16_t cu[4];
+        unsigned long long ku[4]; idx_t cu[4];
 #pragma unroll
-        for (int z = 0; z < 4; z++) { const int u = u0 + z < ntup ? u0 + z : ntup - 1; ku[z] = S.key[u]; cu[z] = S.comp[u]; }
+        for (int z = 0; z < 4; z++) { const int u = u0 + z < ntup ? u0 + z : ntup - 1; ku[z] = Skey[u]; cu[z] = Scomp[u]; }
 #pragma unroll
         for (int z = 0; z < 4; z++) {
           const int u = u0 + z;
-          if (u < ntup && cu[z] == 0xffff && link_tup(tv, unpack_tup(ku[z]))) { S.comp[u] = (uint16_t)nc; S.stack[ns++] = (uint16_t)u; }
+          if (u < ntup && cu[z] == NONE && link_tup(tv, unpack_tup(ku[z]))) { Scomp[u] = (idx_t)nc; Sstack[ns++] = (idx_t)u; }
         }
       }
     }
-    const Tup t0 = unpack_tup(S.key[h0]);
-    S.ninc[nc] = (members == 1 && !link_tup(t0, t0)) ? 0xffff : 0;      // 0xffff: a set of singletons, never reported
-    S.last[nc] = -1;
+    const Tup t0 = unpack_tup(Skey[h0]);
+    Sninc[nc] = (members == 1 && !link_tup(t0, t0)) ? NONE : (idx_t)0;      // 0xffff: a set of singletons, never reported
+    Slast[nc] = -1;
     nc++;
   }
   // posterior of each cluster: traces with at least one member (samples are in trace order)
   for (int h = 0; h < nsamp; h++) {
-    const int c = S.comp[S.tid[h]];
-    if (S.ninc[c] == 0xffff) continue;
-    if ((int)S.tidx[h] != (int)S.last[c]) S.ninc[c]++;
-    S.last[c] = (int16_t)S.tidx[h];
+    const int c = Scomp[Stid[h]];
+    if (Sninc[c] == NONE) continue;
+    if ((int)Stidx[h] != (int)Slast[c]) Sninc[c]++;
+    Slast[c] = (sidx_t)Stidx[h];
   }
   int nsig = 0;
   for (int c = 0; c < nc; c++) {
-    if (S.ninc[c] == 0xffff) continue;
-    const int ninc = S.ninc[c];
+    if (Sninc[c] == NONE) continue;
+    const int ninc = (int)Sninc[c];
     if ((float)ninc / (float)200 < 0.25f) continue;
     const int thr = (int)ceilf((float)ninc * 0.02f);
     // the cluster's members, then per coordinate the endpoint histogram (weight of a value = copies of the tuples carrying it)
     int nm = 0;
     int lo[4] = {1 << 30, 1 << 30, 1 << 30, 1 << 30}, hi[4] = {-1, -1, -1, -1};
     for (int h = 0; h < ntup; h++) {
-      if (S.comp[h] != c) continue;
-      S.stack[nm++] = (uint16_t)h;
-      const Tup th = unpack_tup(S.key[h]);
+      if (Scomp[h] != c) continue;
+      Sstack[nm++] = (idx_t)h;
+      const Tup th = unpack_tup(Skey[h]);
       const int v[4] = {th.i, th.k, th.j, th.m};
 #pragma unroll
       for (int f = 0; f < 4; f++) { lo[f] = min(lo[f], v[f]); hi[f] = max(hi[f], v[f]); }
@@ -520,28 +561,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       const bool leftmost = f < 2;                    // i and k: leftmost value with enough endpoints; j and m: rightmost
       const int W = hi[f] - lo[f] + 1;
       int pick = -1, am = -1, amw = -1;
-      if (W <= MR_EPC) {
-        for (int z = 0; z < W; z++) S.epc[z] = 0;
+      if (W <= MR_EPC && (!BIG || nsamp < 65536)) {
+        for (int z = 0; z < W; z++) Sepc[z] = 0;
         for (int x = 0; x < nm; x++) {
-          const int h = S.stack[x];
-          const Tup th = unpack_tup(S.key[h]);
+          const int h = Sstack[x];
+          const Tup th = unpack_tup(Skey[h]);
           const int v = f == 0 ? th.i : f == 1 ? th.k : f == 2 ? th.j : th.m;
-          S.epc[v - lo[f]] += S.tcount[h];
+          Sepc[v - lo[f]] += Stcount[h];
         }
         for (int z = 0; z < W; z++) {
-          const int w = S.epc[z];
+          const int w = Sepc[z];
           if (w >= thr && (pick < 0 || !leftmost)) pick = lo[f] + z;           // first hit from the left / last hit from the right
           if (w > amw) { amw = w; am = lo[f] + z; }                              // esl_vec_IArgMax: the first maximum
         }
       } else {
         for (int x = 0; x < nm; x++) {
-          const Tup th = unpack_tup(S.key[S.stack[x]]);
+          const Tup th = unpack_tup(Skey[Sstack[x]]);
           const int v = f == 0 ? th.i : f == 1 ? th.k : f == 2 ? th.j : th.m;
           int w = 0;
           for (int y = 0; y < nm; y++) {
-            const Tup tu = unpack_tup(S.key[S.stack[y]]);
+            const Tup tu = unpack_tup(Skey[Sstack[y]]);
             const int vu = f == 0 ? tu.i : f == 1 ? tu.k : f == 2 ? tu.j : tu.m;
-            if (vu == v) w += S.tcount[S.stack[y]];
+            if (vu == v) w += Stcount[Sstack[y]];
           }
           if (w >= thr && (pick < 0 || (leftmost ? v < pick : v > pick))) pick = v;
           if (w > amw || (w == amw && v < am)) { amw = w; am = v; }
@@ -550,30 +591,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       best[f] = pick >= 0 ? pick : am;
     }
     if (best[0] > best[2] || best[1] > best[3]) continue;
-    if (nsig >= MR_NSIG) { status = 6; break; }
-    S.sig_i[nsig] = best[0]; S.sig_j[nsig] = best[2]; S.sig_p[nsig] = (float)ninc / (float)200;
+    if (nsig >= capSig) { status = 6; break; }
+    Ssig_i[nsig] = best[0]; Ssig_j[nsig] = best[2]; Ssig_p[nsig] = (float)ninc / (float)200;
     nsig++;
   }
   if (status == 0) {
     // order by start (stable insertion sort), then drop dominated clusters
     for (int x = 1; x < nsig; x++) {
-      const int ti = S.sig_i[x], tj = S.sig_j[x]; const float tp = S.sig_p[x];
+      const int ti = Ssig_i[x], tj = Ssig_j[x]; const float tp = Ssig_p[x];
       int y = x - 1;
-      while (y >= 0 && S.sig_i[y] > ti) { S.sig_i[y + 1] = S.sig_i[y]; S.sig_j[y + 1] = S.sig_j[y]; S.sig_p[y + 1] = S.sig_p[y]; y--; }
-      S.sig_i[y + 1] = ti; S.sig_j[y + 1] = tj; S.sig_p[y + 1] = tp;
+      while (y >= 0 && Ssig_i[y] > ti) { Ssig_i[y + 1] = Ssig_i[y]; Ssig_j[y + 1] = Ssig_j[y]; Ssig_p[y + 1] = Ssig_p[y]; y--; }
+      Ssig_i[y + 1] = ti; Ssig_j[y + 1] = tj; Ssig_p[y + 1] = tp;
     }
-    for (int d = 0; d < nsig; d++) S.dominated[d] = 0;
+    for (int d = 0; d < nsig; d++) Sdominated[d] = 0;
     for (int d = 0; d < nsig; d++)
       for (int d2 = d + 1; d2 < nsig; d2++) {
-        const int nov = min(S.sig_j[d], S.sig_j[d2]) - max(S.sig_i[d], S.sig_i[d2]) + 1;
+        const int nov = min(Ssig_j[d], Ssig_j[d2]) - max(Ssig_i[d], Ssig_i[d2]) + 1;
         if (nov == 0) break;
-        const int n = min(S.sig_j[d] - S.sig_i[d] + 1, S.sig_j[d2] - S.sig_i[d2] + 1);
-        if ((float)nov / (float)n >= 0.8f) { if (S.sig_p[d] > S.sig_p[d2]) S.dominated[d2] = 1; else S.dominated[d] = 1; }
+        const int n = min(Ssig_j[d] - Ssig_i[d] + 1, Ssig_j[d2] - Ssig_i[d2] + 1);
+        if ((float)nov / (float)n >= 0.8f) { if (Ssig_p[d] > Ssig_p[d2]) Sdominated[d2] = 1; else Sdominated[d] = 1; }
       }
     for (int d = 0; d < nsig; d++) {
-      if (S.dominated[d]) continue;
-      if (out.nenv >= MRENV) { status = 7; break; }
-      out.ei[out.nenv] = S.sig_i[d]; out.ej[out.nenv] = S.sig_j[d]; out.nenv++;
+      if (Sdominated[d]) continue;
+      if (out.nenv >= capEnv) { status = 7; break; }
+      if (out.nenv < MRENV) { out.ei[out.nenv] = Ssig_i[d]; out.ej[out.nenv] = Ssig_j[d]; }
+      if constexpr (BIG) { Senv[2 * out.nenv] = Ssig_i[d]; Senv[2 * out.nenv + 1] = Ssig_j[d]; }
+      out.nenv++;
     }
   }
   if (status != 0) {              // a bookkeeping limit was hit: no cluster envelopes (k_mr_apply keeps the region whole), and it says so
@@ -584,27 +627,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   a.out[e.mi] = out;
   if (a.dbg && lane == 0) { atomicAdd(&a.dbg[0], tk_walk); atomicAdd(&a.dbg[1], tk_close); atomicAdd(&a.dbg[2], wall_clock64() - tk2); atomicAdd(&a.dbg[3], 1ull); atomicAdd(&a.dbg[4], tk_dedupe); }
 }
+#undef DOM_IJ
+#undef DOM_KM
 
 // =========================================================================================
 // list building: multidomain regions of every pair, in pair order
-__global__ void __launch_bounds__(256) k_mr_count(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, int64_t npairs,
+__global__ void __launch_bounds__(256) k_mr_count(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, RegionPoolView pv, int64_t npairs,
                                                   int32_t *__restrict__ cnt)
 {
   const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pi > npairs) return;
   int c = 0;
   if (pi < npairs && pout[pi].pass_fwd)
-    for (int k = 0; k < pout[pi].ndom; k++) c += raw[pi * MAXDOM + k].multi != 0;
+    for (int k = 0; k < pout[pi].ndom; k++) c += raw_region(raw, pv, pi, k).multi != 0;
   cnt[pi] = c;
 }
-__global__ void __launch_bounds__(256) k_mr_fill(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, int64_t npairs,
+__global__ void __launch_bounds__(256) k_mr_fill(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, RegionPoolView pv, int64_t npairs,
                                                  const int32_t *__restrict__ off, MrRec *__restrict__ mr)
 {
   const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= npairs || !pout[pi].pass_fwd) return;
   int o = off[pi];
   for (int k = 0; k < pout[pi].ndom; k++) {
-    const RegionRec r = raw[pi * MAXDOM + k];
+    const RegionRec r = raw_region(raw, pv, pi, k);
     if (!r.multi) continue;
     MrRec m; m.pair = (int32_t)pi; m.slot = k; m.ireg = r.ienv; m.jreg = r.jenv;
     mr[o++] = m;
@@ -630,53 +675,88 @@ __global__ void __launch_bounds__(256) k_mr_reorder(int64_t nu, int64_t nmr, con
   if (x < nu) ulist_out[newpos[x]] = ulist_in[x];
   if (x < nmr) mr_u[x] = newpos[mr_u[x]];
 }
-// every pair with multidomain regions gets its envelope list rebuilt: a clustered region is replaced by its envelopes
-__global__ void __launch_bounds__(256) k_mr_apply(PairOut *__restrict__ pout, RegionRec *__restrict__ raw, int64_t npairs,
-                                                  const int32_t *__restrict__ off, const int32_t *__restrict__ mr_u, const MrOut *__restrict__ out,
-                                                  unsigned long long *__restrict__ counters)
+// A pair's final envelope list: its regions in order, every clustered region replaced by its envelopes.  Walked twice with the same
+// code -- once to count, once to write straight into the profile-grouped list -- so that nothing needs a per-pair buffer of fixed size.
+template <class Emit>
+DEV int walk_region_list(const RegionListArgs &a, int64_t pi, int nraw, unsigned long long *nfail, unsigned long long *nenv, unsigned long long *kind, Emit emit)
 {
-  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= npairs || !pout[pi].pass_fwd) return;
-  const int nm = off[pi + 1] - off[pi];
-  if (nm == 0) return;
-  RegionRec tmp[MAXDOM];
-  int n = 0, over = 0, mk = off[pi];
-  unsigned long long nfail = 0, nenv = 0;
-  for (int k = 0; k < pout[pi].ndom; k++) {
-    const RegionRec r = raw[pi * MAXDOM + k];
-    if (!r.multi) { if (n < MAXDOM) tmp[n++] = r; else over = 1; continue; }
-    const MrOut o = out[mr_u[mk]];
-    nfail += o.status != 0; nenv += o.nenv;
+  int n = 0, mk = a.mr_off ? a.mr_off[pi] : 0;
+  for (int k = 0; k < nraw; k++) {
+    const RegionRec r = raw_region(a.raw, a.pv, pi, k);
+    if (!r.multi || !a.mr_off) { emit(n++, r); continue; }
+    const MrOut o = a.mrout[a.mr_u[mk]];
     if (o.status != 0) {
-      // the ensemble ran into a bookkeeping limit (hmmsearch has none; itsx_search refuses the call unless ITSX_ALLOW_CAPS=1):
-      // the region is kept the way it was before this stage existed -- ONE envelope, null2 by expectation -- instead of
-      // vanishing with the read's coordinates; multi < 0 = "a simple envelope that carries the multidomain flag"
-      atomicAdd(&counters[2 + (o.status & 7)], 1ULL);
+      // the region's matrix could not be sampled (hmmsearch itself throws there; itsx_search reports it): the region stays ONE
+      // envelope with null2 by expectation, multi < 0 = "a simple envelope that carries the multidomain flag"
+      if (nfail) { (*nfail)++; kind[o.status & 7]++; }
       RegionRec c = r; c.multi = -1;
-      if (n < MAXDOM) tmp[n++] = c; else over = 1;
-    }
-    for (int z = 0; z < o.nenv; z++) {
-      RegionRec c; c.pair = (int32_t)pi; c.ienv = o.ei[z] + r.ienv - 1; c.jenv = o.ej[z] + r.ienv - 1; c.multi = mk + 1;
-      if (n < MAXDOM) tmp[n++] = c; else over = 1;
+      emit(n++, c);
+    } else {
+      if (nenv) *nenv += (unsigned long long)o.nenv;
+      const int32_t *env = o.big >= 0 ? a.envpool + o.big : nullptr;
+      for (int z = 0; z < o.nenv; z++) {
+        RegionRec c; c.pair = (int32_t)pi; c.multi = mk + 1;
+        c.ienv = (env ? env[2 * z] : o.ei[z]) + r.ienv - 1; c.jenv = (env ? env[2 * z + 1] : o.ej[z]) + r.ienv - 1;
+        emit(n++, c);
+      }
     }
     mk++;
   }
-  for (int k = 0; k < n; k++) raw[pi * MAXDOM + k] = tmp[k];
-  pout[pi].ndom = n;
-  if (over) pout[pi].flags |= 2;
-  if (nfail) atomicAdd(&counters[0], nfail);
-  if (nenv) atomicAdd(&counters[1], nenv);
+  return n;
+}
+__global__ void __launch_bounds__(256) k_region_list_count(RegionListArgs a, int32_t *__restrict__ cnt, unsigned long long *__restrict__ counters)
+{
+  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi > a.npairs) return;
+  int n = 0;
+  if (pi < a.npairs && a.pout[pi].pass_fwd) {
+    unsigned long long nfail = 0, nenv = 0, kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    n = walk_region_list(a, pi, a.pout[pi].ndom, &nfail, &nenv, kind, [](int, const RegionRec &) {});
+    a.pout[pi].nregions_raw = a.pout[pi].ndom;      // the fill pass walks the raw regions again
+    a.pout[pi].ndom = n;
+    if (nfail) { atomicAdd(&counters[0], nfail); for (int z = 1; z < 8; z++) if (kind[z]) atomicAdd(&counters[2 + z], kind[z]); }
+    if (nenv) atomicAdd(&counters[1], nenv);
+  }
+  cnt[pi] = n;
+}
+__global__ void __launch_bounds__(256) k_region_list_fill(RegionListArgs a, const int64_t *__restrict__ pair_region0, RegionRec *__restrict__ out)
+{
+  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= a.npairs || !a.pout[pi].pass_fwd) return;
+  const int64_t o = pair_region0[pi];
+  walk_region_list(a, pi, a.pout[pi].nregions_raw, nullptr, nullptr, nullptr, [&](int n, const RegionRec &r) { out[o + n] = r; });
+}
+__global__ void __launch_bounds__(256) k_mr_overflowed(const MrOut *__restrict__ out, int64_t nu, int32_t *__restrict__ list, unsigned long long *__restrict__ n)
+{
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nu) return;
+  const int st = out[u].status;
+  if (st == 2 || st == 3 || st == 4 || st == 6 || st == 7) list[atomicAdd(n, 1ULL)] = (int32_t)u;
 }
 
-void launch_mr_count(const PairOut *pout, const RegionRec *raw, int64_t npairs, int32_t *cnt, hipStream_t st)
+void launch_mr_count(const PairOut *pout, const RegionRec *raw, RegionPoolView pv, int64_t npairs, int32_t *cnt, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_mr_count, dim3((unsigned)((npairs + 1 + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, cnt);
+  hipLaunchKernelGGL(k_mr_count, dim3((unsigned)((npairs + 1 + 255) / 256)), dim3(256), 0, st, pout, raw, pv, npairs, cnt);
 }
-void launch_mr_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int32_t *off, MrRec *mr, hipStream_t st)
+void launch_mr_fill(const PairOut *pout, const RegionRec *raw, RegionPoolView pv, int64_t npairs, const int32_t *off, MrRec *mr, hipStream_t st)
 {
   if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_mr_fill, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, off, mr);
+  hipLaunchKernelGGL(k_mr_fill, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, pv, npairs, off, mr);
 }
+void launch_region_list_count(const RegionListArgs &a, int32_t *cnt, unsigned long long *counters, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_region_list_count, dim3((unsigned)((a.npairs + 1 + 255) / 256)), dim3(256), 0, st, a, cnt, counters);
+}
+void launch_region_list_fill(const RegionListArgs &a, const int64_t *pair_region0, RegionRec *out, hipStream_t st)
+{
+  if (a.npairs <= 0) return;
+  hipLaunchKernelGGL(k_region_list_fill, dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a, pair_region0, out);
+}
+void launch_mr_overflowed(const MrOut *out, int64_t nu, int32_t *list, unsigned long long *n, hipStream_t st)
+{
+  if (nu > 0) hipLaunchKernelGGL(k_mr_overflowed, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, out, nu, list, n);
+}
+
 void launch_mr_ulist(int64_t nmr, const MrRec *mr, const int32_t *rep, const int32_t *is_uniq, const int32_t *urank, int32_t *ulist, int32_t *ulen,
                      int32_t *mr_u, hipStream_t st)
 {
@@ -693,13 +773,12 @@ void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st)
 {
   if (nwaves <= 0) return;
   hipLaunchKernelGGL(k_mr_fwd, dim3(nwaves), dim3(64), 0, st, a, wave0);
-  hipLaunchKernelGGL(k_mr_trace, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  hipLaunchKernelGGL(k_mr_trace<false>, dim3(nwaves), dim3(64), 0, st, a, wave0);
 }
-void launch_mr_apply(PairOut *pout, RegionRec *raw, int64_t npairs, const int32_t *off, const int32_t *mr_u, const MrOut *out, unsigned long long *counters,
-                     hipStream_t st)
+void launch_mr_ensemble_big(const MrArgs &a, int nwaves, hipStream_t st)
 {
-  if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_mr_apply, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, off, mr_u, out, counters);
+  if (nwaves <= 0) return;
+  hipLaunchKernelGGL(k_mr_fwd, dim3(nwaves), dim3(64), 0, st, a, 0);
+  hipLaunchKernelGGL(k_mr_trace<true>, dim3(nwaves), dim3(64), 0, st, a, 0);
 }
-
 }  // namespace itsx

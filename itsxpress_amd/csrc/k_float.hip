@@ -653,10 +653,9 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
       }
       const int multi = (mx >= rt3);
       nmulti += multi;
-      if (p.slot >= 0) {
-        RegionRec rr; rr.pair = (int32_t)pi; rr.ienv = p.ri; rr.jenv = p.j; rr.multi = multi;
-        a.regions[pi * MAXDOM + p.slot] = rr;
-      }
+      RegionRec rr; rr.pair = (int32_t)pi; rr.ienv = p.ri; rr.jenv = p.j; rr.multi = multi;
+      if (p.slot < MAXDOM) a.regions[pi * MAXDOM + p.slot] = rr;
+      else pool_put(a.pool, rr, p.slot);          // past the pair's slots: the overflow list (engine.hip orders it afterwards)
     };
     for (int j = 1; j <= L; j++) {
       const DRow cur = nxt;
@@ -683,8 +682,8 @@ __global__ void __launch_bounds__(64) k_decode(FloatArgs a, int wave0)
         // The multidomain test of a region re-reads the region's rows.  Done here it would run for ONE lane while the
         // other 63 wait (lanes close their regions at different rows) and it is a chain of dependent single-lane loads;
         // so the first two regions of a lane are only recorded, and tested after the row loop by all lanes together.
-        const int slot = nkept < MAXDOM ? nkept : -1;
-        if (slot >= 0) nkept++; else flags |= 2;
+        const int slot = nkept++;                  // hmmsearch keeps every region of a target: so does this (flag 2 = past the slots)
+        if (slot >= MAXDOM) flags |= 2;
         if (npend < 2) {
           Pend &p = npend == 0 ? p0 : p1;
           p.ri = ri; p.j = j; p.slot = slot; p.b = ck_btot; p.e = ck_etot; p.sp = ck_sp; p.t1 = ck_t1; p.rs = ck_rs; p.btot = btot;
@@ -1140,21 +1139,6 @@ __global__ void __launch_bounds__(256) k_score(ScoreArgs a)
   count_reported(a.domz, (a.usample ? a.usample[a.sorted_uniq[pr.useq]] * a.P : 0) + pr.prof, seq_rep != 0);
 }
 
-// compaction of raw per-pair region slots into the profile-grouped region list
-__global__ void __launch_bounds__(256) k_region_fill(const PairOut *__restrict__ pout, const RegionRec *__restrict__ raw, int64_t npairs,
-                                                     const int64_t *__restrict__ pair_region0, RegionRec *__restrict__ out)
-{
-  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= npairs) return;
-  const int n = pout[pi].pass_fwd ? pout[pi].ndom : 0;
-  const int64_t o = pair_region0[pi];
-  for (int k = 0; k < n; k++) out[o + k] = raw[pi * MAXDOM + k];
-}
-__global__ void __launch_bounds__(256) k_region_counts(const PairOut *__restrict__ pout, int64_t npairs, int32_t *__restrict__ cnt)
-{
-  const int64_t pi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi < npairs) cnt[pi] = pout[pi].pass_fwd ? pout[pi].ndom : 0;
-}
 // pair_region0[pi] = seg_region_start[seg] + (pref[pi] - pref[seg_pair_start[seg]])
 __global__ void __launch_bounds__(256) k_region_offsets(int64_t npairs, const PairRec *__restrict__ pairs, const int32_t *__restrict__ pref,
                                                         const int64_t *__restrict__ seg_pair_start, const int64_t *__restrict__ seg_region_start,
@@ -1334,21 +1318,11 @@ void launch_score(const ScoreArgs &a, hipStream_t st)
   if (a.npairs <= 0) return;
   hipLaunchKernelGGL(k_score, dim3((unsigned)((a.npairs + 255) / 256)), dim3(256), 0, st, a);
 }
-void launch_region_counts(const PairOut *pout, int64_t npairs, int32_t *cnt, hipStream_t st)
-{
-  if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_region_counts, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, npairs, cnt);
-}
 void launch_region_offsets(int64_t npairs, const PairRec *pairs, const int32_t *pref, const int64_t *seg_pair_start,
                            const int64_t *seg_region_start, int64_t *pair_region0, hipStream_t st)
 {
   if (npairs <= 0) return;
   hipLaunchKernelGGL(k_region_offsets, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, npairs, pairs, pref, seg_pair_start, seg_region_start, pair_region0);
-}
-void launch_region_fill(const PairOut *pout, const RegionRec *raw, int64_t npairs, const int64_t *pair_region0, RegionRec *out, hipStream_t st)
-{
-  if (npairs <= 0) return;
-  hipLaunchKernelGGL(k_region_fill, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, pout, raw, npairs, pair_region0, out);
 }
 void launch_finalize(itsx_domain *dom, int64_t n, const int64_t *domz, double domE, const int32_t *usample, int P, hipStream_t st)
 {

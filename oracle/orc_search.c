@@ -814,7 +814,7 @@ static void mr_fail(int kind)
 #pragma omp atomic
   g_mr_fail_kind[kind]++;
 }
-static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L, int ireg, int jreg, workspace *w, int *env_i, int *env_j, int maxenv)
+static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L, int ireg, int jreg, workspace *w, int **env_i, int **env_j, int *envcap)
 {
   const int Q = p->Q, Lr = jreg - ireg + 1, nsamples = 200;
   const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f), ploop = 1.0f - pmove;   /* multihit, length model of the whole target */
@@ -822,13 +822,13 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
   fwd_engine_x(p, dsq + ireg - 1, Lr, pmove, ploop, 0.5f, 0.5f, w->ef, NULL, w->full, &fsc);
   for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
   orc_rng rng; rng_init(&rng, 42);
-  /* bookkeeping limits of the device kernel (k_ensemble.hip), mirrored so that both sides fail alike: at most 8 domains
-   * in one sampled path, 512 distinct (i, j, k, m) tuples, 32 reportable clusters (never binding: a reportable cluster holds
-   * >= 50 of the <= 200 x 8 sampled domains), 4 envelopes per region; a region that exceeds one returns -1: the caller keeps
-   * it as one envelope (the engine refuses the whole search unless ITSX_ALLOW_CAPS=1 and counts such regions by kind) */
-  enum { MAXD = 8, TCAP = 512, NSIG = 32, MRENV = 4 };
-  int dfrom[MAXD], dto[MAXD], dk[MAXD], dm[MAXD];
-  float *cntM = (float *)malloc(sizeof(float) * MAXD * QMAX * 4 * 2), *cntI = cntM + MAXD * QMAX * 4;
+  /* no bookkeeping limit, as in hmmsearch (p7_domaindef.c / p7_spensemble.c grow their lists): a path of a region of Lr residues
+   * has at most Lr domains; every list below is sized by that or grows.  (Until round 3 the device kernel's fixed sizes -- 8 domains
+   * per path, 512 distinct tuples, 4 envelopes -- were mirrored here; its overflow path has none.)  What remains is what makes
+   * hmmsearch itself throw: a matrix that cannot be sampled (kinds 1 and 5 below). */
+  const int MAXD = Lr + 1;
+  int *dfrom = (int *)malloc(sizeof(int) * 4 * (size_t)MAXD), *dto = dfrom + MAXD, *dk = dto + MAXD, *dm = dk + MAXD;
+  float *cntM = (float *)malloc(sizeof(float) * (size_t)MAXD * QMAX * 4 * 2), *cntI = cntM + (size_t)MAXD * QMAX * 4;
   int cap = 1024, n = 0;
   spcoord *sp = (spcoord *)malloc(sizeof(spcoord) * cap);
   const uint8_t *degen = orc_degen_table();
@@ -873,21 +873,7 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
   }
   if (bad) {          /* HMMER would have thrown; keep the region without envelopes and without a null2 correction */
     for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
-    free(cntM); free(sp);
-    return -1;
-  }
-  if (!bad) {                                     /* distinct tuples, as the device counts them */
-    int ndist = 0;
-    for (int h = 0; h < n && ndist <= TCAP; h++) {
-      int seen = 0;
-      for (int u = 0; u < h && !seen; u++) seen = sp[u].i == sp[h].i && sp[u].j == sp[h].j && sp[u].k == sp[h].k && sp[u].m == sp[h].m;
-      ndist += !seen;
-    }
-    if (ndist > TCAP) { bad = 1; mr_fail(4); }
-  }
-  if (bad) {
-    for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f;
-    free(cntM); free(sp);
+    free(cntM); free(sp); free(dfrom);
     return -1;
   }
   for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = orc_logf(w->n2sc[pos] / (float)nsamples);
@@ -945,7 +931,6 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
     if (best_m < mmin) best_m = mmin + am;
 #undef HIST
     if (best_i > best_j || best_k > best_m) continue;
-    if (nsig >= NSIG) { bad = 1; mr_fail(6); break; }
     sig[nsig].i = best_i; sig[nsig].j = best_j; sig[nsig].k = best_k; sig[nsig].m = best_m; sig[nsig].idx = c;
     sig[nsig].prob = (float)ninc / (float)nsamples;
     nsig++;
@@ -963,9 +948,11 @@ static int region_trace_ensemble(const orc_profile *p, const uint8_t *dsq, int L
       if ((float)nov / (float)nn >= 0.8f) { if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
     }
   int ne = 0;
-  for (int d = 0; d < nsig && !bad; d++) if (!dominated[d]) { if (ne >= MRENV || ne >= maxenv) { bad = 1; mr_fail(7); break; } env_i[ne] = sig[d].i; env_j[ne] = sig[d].j; ne++; }
-  if (bad) { ne = -1; for (int pos = ireg; pos <= jreg; pos++) w->n2sc[pos] = 0.0f; }
-  free(dominated); free(epc); free(sig); free(comp); free(stack); free(cntM); free(sp);
+  for (int d = 0; d < nsig && !bad; d++) if (!dominated[d]) {
+    if (ne >= *envcap) { *envcap = 2 * *envcap + 8; *env_i = (int *)realloc(*env_i, sizeof(int) * *envcap); *env_j = (int *)realloc(*env_j, sizeof(int) * *envcap); }
+    (*env_i)[ne] = sig[d].i; (*env_j)[ne] = sig[d].j; ne++;
+  }
+  free(dominated); free(epc); free(sig); free(comp); free(stack); free(cntM); free(sp); free(dfrom);
   return ne;
 }
 #undef FULLV
@@ -1040,7 +1027,9 @@ static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uin
   for (int i = 0; i <= L; i++) w->n2sc[i] = 0.0f;
 
   /* region scan */
-  domrec doms[64]; int ndom = 0, nregions = 0;
+  domrec *doms = NULL; int ndom = 0, domcap = 0, nregions = 0;        /* as many as the target has (hmmsearch keeps them all) */
+#define PUSH_DOM(d_) do { if (ndom == domcap) { domcap = 2 * domcap + 16; doms = (domrec *)realloc(doms, sizeof(domrec) * domcap); } doms[ndom++] = (d_); } while (0)
+  int *ei = NULL, *ej = NULL, envcap = 0;
   {
     const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
     int i = -1, triggered = 0;
@@ -1061,26 +1050,23 @@ static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uin
           multi = (max >= rt3); }
         if (multi && !getenv("ORC_NO_ENSEMBLE")) {
           /* the region is resolved into envelopes by stochastic traceback clustering; its null2 scores come from the traces */
-          int ei[16], ej[16];
           r->n_multidomain++;
-          const int ne = region_trace_ensemble(p, dsq, L, i, j, w, ei, ej, 16);
-          for (int e = 0; e < ne; e++)
-            if (ndom < 64) {
-              domrec d;
-              if (rescore_domain(p, dsq, L, ei[e], ej[e], 1, w, &d) == 0) doms[ndom++] = d;
-            }
-          if (ne < 0 && ndom < 64) {
-            /* the ensemble ran into a bookkeeping limit (hmmsearch has none: the engine REFUSES such a search unless
-             * ITSX_ALLOW_CAPS=1): the region is then kept the way it was before the ensemble stage existed, as ONE envelope
-             * with null2 by expectation, flagged -- it no longer vanishes (a concatemer kept its coordinates that way) */
+          const int ne = region_trace_ensemble(p, dsq, L, i, j, w, &ei, &ej, &envcap);
+          for (int e = 0; e < ne; e++) {
             domrec d;
-            if (rescore_domain(p, dsq, L, i, j, 0, w, &d) == 0) { d.flags |= 1; doms[ndom++] = d; }
+            if (rescore_domain(p, dsq, L, ei[e], ej[e], 1, w, &d) == 0) PUSH_DOM(d);
           }
-        } else if (ndom < 64) {
+          if (ne < 0) {
+            /* the matrix could not be sampled (hmmsearch throws there; the engine reports such a search): the region is kept the
+             * way it was before the ensemble stage existed, as ONE envelope with null2 by expectation, flagged */
+            domrec d;
+            if (rescore_domain(p, dsq, L, i, j, 0, w, &d) == 0) { d.flags |= 1; PUSH_DOM(d); }
+          }
+        } else {
           domrec d;
           if (rescore_domain(p, dsq, L, i, j, 0, w, &d) == 0) {
             if (multi) { d.flags |= 1; r->n_multidomain++; }
-            doms[ndom++] = d;
+            PUSH_DOM(d);
           }
         }
         i = -1; triggered = 0;
@@ -1089,7 +1075,7 @@ static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uin
   }
   tr.nregions = nregions; tr.ndom = ndom;
   if (keep_trace) res_push_trace(r, &tr);
-  if (nregions == 0 || ndom == 0) return;
+  if (nregions == 0 || ndom == 0) { free(doms); free(ei); free(ej); return; }
 
   /* per-sequence score with null2 correction, and the reconstruction score */
   float seqbias = 0.0f;
@@ -1124,6 +1110,8 @@ static void pipeline_pair(const orc_profile *p, int prof, int64_t seq, const uin
     o.seq_reported = seq_rep; o.dom_reported = 0;
     res_push_dom(r, &o);
   }
+  free(doms); free(ei); free(ej);
+#undef PUSH_DOM
 }
 
 static int cmp_dom(const void *a, const void *b)

@@ -1,11 +1,11 @@
-"""Refuse, don't cap.  hmmsearch has no limit on the envelopes of a target or on the bookkeeping of a region's traceback
-ensemble; this engine has (8 envelopes per (representative, profile); per multidomain region at most 8 domains in one sampled
-path, 512 distinct sampled tuples, 4 envelopes).  A search that runs into one of them would differ from the reference's
-result on exactly those reads, so `itsx_search` fails with ITSX_E_UNSUPPORTED and says which limit and how often;
-ITSX_ALLOW_CAPS=1 accepts the documented capped behaviour (the first 8 envelopes; an overrun region kept as ONE envelope,
-flagged), which the oracle mirrors.  One adversarial read per limit, each found by a random search over tandem partial
-copies of a profile's consensus (concatemer-like reads).  The remaining two constants cannot bind (k_api.h: 32 clusters of
->= 50 sampled domains each out of <= 1 600; 1 600 samples = 200 paths x 8 domains).  `pytest -m gpu`."""
+"""Nothing is refused, nothing is capped.  hmmsearch has no limit on the envelopes of a target or on the bookkeeping of a region's
+traceback ensemble (p7_domaindef.c / p7_spensemble.c grow their lists; reference call site itsxpress/SeqSample.py:191-209).  The
+engine's fast kernels have (8 region slots per (representative, profile); per multidomain region 8 domains in one sampled path, 512
+distinct sampled tuples, 4 envelopes) -- and what does not fit them takes the overflow paths: an overflow list for the regions past a
+pair's slots, a second run of the ensemble with per-region arrays sized by the region's length (k_ensemble.hip: k_mr_trace<true>).
+One adversarial read per former limit, each found by a random search over tandem partial copies of a profile's consensus
+(concatemer-like reads): by DEFAULT the search succeeds and every compared quantity equals the uncapped CPU oracle, bit for bit, in the
+full and in the lazy rows mode.  `pytest -m gpu`."""
 import numpy as np
 import pytest
 
@@ -27,68 +27,67 @@ READ_ENVELOPES = ("AACGAACGGAGGCACGACCCCAACGCCGTTCGAGCGAGGGCAAACGCCTTTGGTCCGTCCG
                   "TGCCTGGCTGCCTCTGCCTGGAAGTGACGCGGTCTATGACACCCGTACACTT")
 
 
-def _search(engine, hmm, seqs):
-    engine.load_profiles(text=hmm)
-    engine.set_reads(seqs)
-    engine.derep()
-    engine.search()
 
 
-@pytest.mark.parametrize("read,kind,what", [(READ_PATH_DOMAINS, 2, "more than 8 domains in one sampled path"),
-                                            (READ_TUPLES, 4, "more than 512 distinct sampled tuples"),
-                                            (READ_ENVELOPES, 7, "more than 4 envelopes in one region")])
-def test_ensemble_limit_is_refused_and_the_allowed_fallback_equals_the_oracle(engine, mini_hmm_text, monkeypatch, read, kind, what):
-    from itsxpress_amd import EngineError
-    # an ordinary companion read: the refusal is per call, whatever else the call holds
+def _coords(engine, hmm, seqs, mode):
+    engine.set_rows_mode(mode)
+    try:
+        engine.load_profiles(text=hmm)
+        engine.set_reads(seqs)
+        engine.derep()
+        engine.search()
+        engine.finalize()
+        return [tuple(a.copy() for a in engine.trim_coords(l, r)) for l, r in (("3_", "4_"), ("1_", "2_"), ("1_", "4_"))], engine.stats()
+    finally:
+        engine.set_rows_mode(None)
+
+
+@pytest.mark.parametrize("read,what", [(READ_PATH_DOMAINS, "more than 8 domains in one sampled path"),
+                                       (READ_TUPLES, "more than 512 distinct sampled tuples"),
+                                       (READ_ENVELOPES, "more than 4 envelopes in one region")])
+def test_ensemble_beyond_the_fast_kernels_bookkeeping_equals_the_oracle(engine, mini_hmm_text, monkeypatch, read, what):
+    from test_gpu_parity import _run_both
+    # ordinary companion reads: the overflow path runs beside the fast one
     blob, offs = synth.make_reads(mini_hmm_text, 20, seed=3)
     seqs = synth.to_strings(blob, offs) + [read]
-    # the oracle confirms that THIS limit is the one the read trips
-    orc.mr_fail_counts(True)
-    c, o = orc.digitize([read])
-    orc.SearchResult(orc.HmmSet(text=mini_hmm_text), c, o, threads=1, keep_trace=0)
-    fails = orc.mr_fail_counts(True)
-    assert fails[kind] >= 1
-    monkeypatch.delenv("ITSX_ALLOW_CAPS", raising=False)
-    with pytest.raises(EngineError) as ei:
-        _search(engine, mini_hmm_text, seqs)
-    assert ei.value.code == -5 and what in str(ei.value) and "ITSX_ALLOW_CAPS" in str(ei.value)
-    with pytest.raises(EngineError):
-        engine.finalize()                                  # no result to finalize after a refused search
-    # explicitly allowed: the region is kept as one envelope (flagged), like the oracle's mirror of the limit
-    monkeypatch.setenv("ITSX_ALLOW_CAPS", "1")
-    from test_gpu_parity import _run_both
     monkeypatch.setenv("ITSX_KEEP_TRACE", "1")
+    monkeypatch.delenv("ITSX_ALLOW_CAPS", raising=False)
+    orc.mr_fail_counts(True)
     res = _run_both(engine, mini_hmm_text, seqs)
     st = engine.stats()
-    ofails = orc.mr_fail_counts(True)
-    assert st["n_mr_fail_kind"][kind] >= 1 and st["n_mr_failed"] == sum(st["n_mr_fail_kind"])
-    assert st["n_mr_fail_kind"] == ofails
-    if st["n_domain_overflow"] == 0:                       # (the oracle keeps up to 64 envelopes per pair, the engine 8)
-        _compare(engine, res)
+    assert orc.mr_fail_counts(True) == [0] * 8                      # the oracle holds no such limit any more
+    assert st["n_mr_overflow"] >= 1 and st["n_mr_failed"] == 0, what   # the read really leaves the fast kernel
+    _compare(engine, res)
     d = engine.domains()
     assert ((d["flags"] & 1) == 1).sum() >= 1
-    start, stop, tlen, ind = engine.trim_coords("3_", "4_")
-    assert ind[-1] == 1                                     # the read keeps its entry: the region did not vanish
+    full, _ = _coords(engine, mini_hmm_text, seqs, "full")
+    assert full[0][3][-1] == 1                                       # the read has its entry
+    monkeypatch.delenv("ITSX_KEEP_TRACE")
+    lazy, st2 = _coords(engine, mini_hmm_text, seqs, "lazy")
+    assert st2["lazy"] == 1 and all(np.array_equal(x, y) for a, b in zip(full, lazy) for x, y in zip(a, b))
 
 
-def test_more_than_eight_envelopes_per_pair_are_refused(engine, mini_hmm_text, monkeypatch):
-    from itsxpress_amd import EngineError
+@pytest.mark.parametrize("copies", [8, 12, 40])
+def test_any_number_of_envelopes_per_pair(engine, mini_hmm_text, monkeypatch, copies):
+    """a concatemer of `copies` copies of a profile's consensus: every envelope is kept (8 fit the pair's slots, the rest go through
+    the overflow list), the rows equal the oracle's, and the argmax works with domain indices past 16"""
+    from test_gpu_parity import _run_both
     cons3 = synth.consensus_motifs(mini_hmm_text, "3_")
     rng = np.random.default_rng(9)
     tail = "".join(rng.choice(list("ACGT"), 40))
-    monkeypatch.delenv("ITSX_ALLOW_CAPS", raising=False)
-    with pytest.raises(EngineError) as ei:
-        _search(engine, mini_hmm_text, [cons3[0] * 12 + tail])
-    assert ei.value.code == -5 and "more than 8 envelopes" in str(ei.value)
-    # eight copies are fine
-    _search(engine, mini_hmm_text, [cons3[0] * 8 + tail])
-    engine.finalize()
-    assert engine.stats()["n_domain_overflow"] == 0 and engine.domains()["ndom"].max() == 8
-    # allowed: the first 8 are kept and the rest counted, per read too
-    monkeypatch.setenv("ITSX_ALLOW_CAPS", "1")
-    _search(engine, mini_hmm_text, [cons3[0] * 12 + tail])
-    engine.finalize()
+    blob, offs = synth.make_reads(mini_hmm_text, 10, seed=5)
+    seqs = synth.to_strings(blob, offs) + [cons3[0] * copies + tail]
+    monkeypatch.setenv("ITSX_KEEP_TRACE", "1")
+    res = _run_both(engine, mini_hmm_text, seqs)
+    _compare(engine, res)
     st = engine.stats()
-    assert st["n_domain_overflow"] >= 1 and engine.domains()["ndom"].max() == 8
-    engine.trim_coords("3_", "4_")
-    assert engine.stats()["n_reads_region_cap"] == 1
+    d = engine.domains()
+    assert d["ndom"].max() >= copies and (st["n_domain_overflow"] >= 1) == (copies > 8)
+    monkeypatch.delenv("ITSX_KEEP_TRACE")
+    full, _ = _coords(engine, mini_hmm_text, seqs, "full")
+    lazy, _ = _coords(engine, mini_hmm_text, seqs, "lazy")
+    assert all(np.array_equal(x, y) for a, b in zip(full, lazy) for x, y in zip(a, b))
+    # the oracle's argmax on the same rows
+    us, ue, ut, ui = res.positions("3_", "4_")
+    _, _, uq = engine.get_derep()
+    assert np.array_equal(full[0][0], us[uq]) and np.array_equal(full[0][1], ue[uq]) and np.array_equal(full[0][3], ui[uq])

@@ -677,7 +677,7 @@ def main():
                        "undecided_rows_that_mattered": int(st["n_lazy_pending"]) if st["lazy"] else None,
                        "profiles_counted_exactly": int(st["n_lazy_completed_profiles"]) if st["lazy"] else None,
                        "pairs_of_those_profiles": int(st["n_lazy_completed"]) if st["lazy"] else None,
-                       "parallelism": "reads sharded x%d%s" % (world, ", global derep" if args.global_derep else "")},
+                       "parallelism": "reads sharded x%d%s" % (world, (", exact global derep" if args.global_derep else ", per-shard derep") if use_dist else "")},
             "full_pipeline": full_leg,
             "full_pipeline_value": (total_local * full_leg["steps"] / (full_leg["ms_per_step"] * 1e-3 * full_leg["steps"])) if (full_leg and "ms_per_step" in full_leg) else None,
             "timed_region": "ASCII text resident in HBM -> device 2-bit packing -> derep -> MSV -> Forward/Backward -> domains -> "

@@ -210,7 +210,8 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
 int itsx_merge_tables(double *q2p, double *match, double *mism, uint8_t *qsame, uint8_t *qdiff);
 
 /* ---- a1: SeqSample.deduplicate (itsxpress/SeqSample.py:93-131)
- * = vsearch --fastx_uniques --strand both; minseqlength 32 is vsearch's default. */
+ * = vsearch --fastx_uniques --strand both; vsearch's --minseqlength default is 1 for this command (32 for the clustering
+ * commands): SeqSample.deduplicate passes 1, shorter reads are dropped (rep_of -1). */
 int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_unique);
 /* ---- a2: SeqSample.cluster (itsxpress/SeqSample.py:133-176) = vsearch --cluster_size --id X --strand both:
  * greedy centroid clustering in label order (8-mer candidate ranking, global alignment, --iddef 2 identity,

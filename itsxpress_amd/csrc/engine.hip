@@ -1166,6 +1166,19 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
       c0 = c1;
     }
     launch_cl_topk(a, 1, ctx->st);
+    {   // a candidate list that overflowed is known HERE: the window is searched again before its walk, its validation and their
+        // counters have run (they ran first and were counted twice until round 3: advisor)
+      int32_t early = 0;
+      HIPCHK(hipMemcpyAsync(&early, ovf.p, sizeof(early), hipMemcpyDeviceToHost, ctx->st));
+      HIPCHK(hipStreamSynchronize(ctx->st));
+      if (early) {
+        if ((int64_t)cand_cap >= (int64_t)C) SET_ERR(ctx, ITSX_E_DEVICE, "clustering candidate lists overflow although they hold every centroid");
+        cand_cap *= 4;
+        HIPCHK(cand.alloc(nqs * (size_t)cand_cap));
+        regrown++;
+        continue;
+      }
+    }
     launch_cl_init(a, ctx->st);
     if (C > 0) launch_cl_walk(a, rows_per_lane, ctx->st);
     launch_cl_outcome(a, ctx->st);

@@ -255,7 +255,7 @@ constexpr int MRENV = 4;           // envelopes kept per clustered region
 #ifndef ITSX_MR_LANES
 #define ITSX_MR_LANES 64
 #endif
-constexpr int MR_LANES = ITSX_MR_LANES;       // regions per wave: half-filled waves, twice as many of them (the kernels wait on memory 2/3 of the time)
+constexpr int MR_LANES = ITSX_MR_LANES;       // regions per wave (64 since the matrix went node-major: same time as 32, half the scratch)
 constexpr int MR_LANES_LONG = 4;   // ... and per wave of the longest regions (engine.hip: they decide when a batch ends)
 constexpr double MR_LONG_FRAC = 0.02;   // the share of a batch's regions that counts as longest (measured: 0.01-0.05 alike, 2 or 4 lanes alike)
 constexpr int MR_MAXD = 8;         // domains in one sampled path

@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=1000000)
     ap.add_argument("--out-kind", default="gz", choices=["gz", "zst", "plain"])
+    ap.add_argument("--rows", default="lazy", choices=["lazy", "compact", "full"], help="the search's rows mode (lazy = what ITSXPRESS_ARRAYS=1 selects)")
+    ap.add_argument("--shape", default="cfg1", choices=["cfg1", "cfg2"], help="cfg1: 300-base reads; cfg2: merged reads of 300-580 bases")
     args = ap.parse_args()
     import synth
     from bench import its2_profiles
@@ -31,7 +33,10 @@ def main():
     from itsxpress_amd.trim import write_trimmed_fastq, read_text
     with gzip.open(os.path.join(ROOT, "tests", "golden", "T.hmm.gz"), "rt") as f:
         thmm = f.read()
-    blob, offs = synth.make_reads(thmm, args.reads, config=2, seed=synth.SEED + 2)
+    if args.shape == "cfg2":
+        blob, offs = synth.make_reads(thmm, args.reads, config=3, seed=synth.SEED + 3, fixed_len=0, len_range=(300, 580))
+    else:
+        blob, offs = synth.make_reads(thmm, args.reads, config=2, seed=synth.SEED + 2)
     n = args.reads
     rng = np.random.default_rng(9)
     tmp = tempfile.mkdtemp(prefix="itsx_file_run_")
@@ -39,16 +44,17 @@ def main():
         plain = os.path.join(tmp, "in.fastq")
         bases = np.frombuffer(blob, np.uint8)
         with open(plain, "wb") as f:                  # Illumina-like qualities: high, decaying along the read
+            qtab = [(np.clip(38 - (np.arange(600) // 25) - rng.integers(0, 6, 600), 2, 40) + 33).astype(np.uint8).tobytes() for _ in range(64)]
             for i in range(n):
                 s = bases[offs[i]:offs[i + 1]]
-                q = (np.clip(38 - (np.arange(len(s)) // 25) - rng.integers(0, 6, len(s)), 2, 40) + 33).astype(np.uint8)
-                f.write(b"@read%d 1:N:0:1\n" % i + s.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+                f.write(b"@read%d 1:N:0:1\n" % i + s.tobytes() + b"\n+\n" + qtab[i & 63][:len(s)] + b"\n")
         fq = os.path.join(tmp, "in.fastq.gz")
         write_trimmed_fastq(plain, fq, np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32), gzipped=True)
         in_bytes, in_gz = os.path.getsize(plain), os.path.getsize(fq)
         os.remove(plain)
 
         eng = Engine(0)
+        eng.set_rows_mode(args.rows)
         eng.load_profiles(text=its2_profiles(thmm))
         # first-touch costs (context, code objects, allocator) outside the stages: one small pass of the whole path
         eng.set_reads([bases[offs[i]:offs[i + 1]].tobytes().decode() for i in range(2000)], ["w%d" % i for i in range(2000)])
@@ -79,7 +85,7 @@ def main():
             assert lines[4 * k] == b"@read%d 1:N:0:1" % i
             assert lines[4 * k + 1] == bases[offs[i]:offs[i + 1]].tobytes()[start[i]:stop[i]]
         print(json.dumps({
-            "reads": n, "unique": int(nu), "written": int(nw), "out_kind": args.out_kind,
+            "reads": n, "shape": args.shape, "rows": args.rows, "unique": int(nu), "written": int(nw), "out_kind": args.out_kind,
             "input_MB": round(in_bytes / 1e6, 1), "input_gz_MB": round(in_gz / 1e6, 1), "output_MB": round(os.path.getsize(out) / 1e6, 1),
             "s_load": round(t["load"], 3), "s_path": round(t["path"], 3), "s_write": round(t["write"], 3), "s_total": round(total, 3),
             "reads_per_s_file_to_file": round(n / total), "io_threads": int(os.environ.get("ITSX_IO_THREADS", 0)) or min(os.cpu_count(), 32),

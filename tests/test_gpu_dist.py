@@ -155,6 +155,6 @@ def test_every_collective_over_rccl_with_one_rank():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     rec = json.loads([ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["ranks"] is not None and rec["ranks"]["allreduce_ms_per_step_max"] > 0
-    assert rec["config"]["parallelism"].endswith("global derep")
+    assert rec["config"]["parallelism"].endswith("exact global derep")
     assert rec["concordance_vs_single_engine"]["equal"] is True
     assert rec["full_pipeline"]["coordinates_equal_lazy"] is True

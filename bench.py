@@ -128,8 +128,8 @@ def launch_selftest(world, rank, args):
     if rank == 0:
         ok = bool((z == world * (world + 1) // 2).all()) and [b.shape[0] for b in c] == [3 + r for r in range(world)] and \
             all(int(b[0, 0]) == r for r, b in enumerate(c))
-        print(json.dumps({"metric": "launcher self-test (no engine, gloo)", "value": None, "n_gpus": world, "ok": ok, "scaling": scaling,
-                          "reads_rank0": int(n_local), "reads_all_ranks": int(plan[0]), "total_reads": int(total)}))
+        os.write(REAL_STDOUT, (json.dumps({"metric": "launcher self-test (no engine, gloo)", "value": None, "n_gpus": world, "ok": ok, "scaling": scaling,
+                          "reads_rank0": int(n_local), "reads_all_ranks": int(plan[0]), "total_reads": int(total)}) + "\n").encode())
     dist.destroy_process_group()
 
 
@@ -266,6 +266,7 @@ def physical_cores():
 
 
 T_START = time.time()
+REAL_STDOUT = 1
 
 
 def progress(msg):
@@ -318,6 +319,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
+    # stdout carries ONE JSON line and nothing else: whatever a library prints there (RCCL's version banner at the first collective) goes
+    # to stderr; the line is written to the real stdout at the very end
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     if args.cluster_id is None:
         args.cluster_id = 0.995 if args.workload == "cfg4" else 1.0
     # N > 1: exact global dereplication unless asked otherwise (greedy clustering has no exact sharded form: per shard)
@@ -802,7 +809,7 @@ def main():
                     "derep": "exact global (hash-partitioned all-to-all)" if args.global_derep else "per shard (--per-shard-derep)",
                     "seconds": round(time.time() - tcz, 1),
                     "note": "rank 0 regenerated every rank's shard and ran one engine on the whole job: start, stop, tlen and the 'has a row' flag of every read"}
-        print(json.dumps(res))
+        os.write(REAL_STDOUT, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,6 +16,8 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "../../include/itsx_hip.h"
@@ -121,6 +123,20 @@ extern "C" {
 
 const char *itsx_trim_last_error(void) { return g_trim_error.c_str(); }
 
+// a cursor over a byte range of a FASTQ text that starts at a record start (the record parser of Records, on a slice)
+static bool fastq_record_start(const char *t, const char *end, const char *p)
+{
+  // a line that starts with '@' and whose second line below starts with '+' (a quality line may start with '@' too, but then that
+  // second line is a sequence line): the rule the engine's loader cuts large texts by
+  if (p >= end || *p != '@') return false;
+  const char *l1 = (const char *)memchr(p, '\n', (size_t)(end - p));
+  if (!l1) return false;
+  const char *l2 = (const char *)memchr(l1 + 1, '\n', (size_t)(end - (l1 + 1)));
+  if (!l2 || l2 + 1 >= end) return false;
+  (void)t;
+  return l2[1] == '+';
+}
+
 int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int compression, int trim_ccs,
                              const int32_t *start, const int32_t *stop, int64_t n_records,
                              int64_t *n_written, int64_t *total_len)
@@ -130,6 +146,90 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
   Records in; Writer out;
   if (!in.open(seq_path)) return ITSX_E_IO;
   if (!out.open(out_path, compression)) return ITSX_E_IO;
+  // Large inputs: the record walk itself (10 M records = 9 GB of text in, 4 GB out) took longer on one thread than the whole GPU
+  // path.  The text is cut at record starts into ranges that a pool of threads slices independently -- a counting pass gives every
+  // range the index of its first record --, and the ranges' outputs go to the block writer in order: the same bytes as the serial walk.
+  const int T = itsx_io::io_threads();
+  const size_t size = (size_t)(in.end - in.s);
+  const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : (size_t)64 << 20;
+  if (T > 1 && size >= min_par) {
+    const size_t range = getenv("ITSX_WRITE_RANGE_KB") ? (size_t)atoll(getenv("ITSX_WRITE_RANGE_KB")) << 10 : (size_t)16 << 20;
+    const char *t0 = in.s, *tend = in.end;
+    std::vector<const char *> cut(1, t0);
+    for (size_t at = range; at < size; at += range) {
+      const char *p = (const char *)memchr(t0 + at, '\n', size - at);
+      while (p && p + 1 < tend && !fastq_record_start(t0, tend, p + 1)) p = (const char *)memchr(p + 1, '\n', (size_t)(tend - (p + 1)));
+      if (!p || p + 1 >= tend) break;
+      if (p + 1 > cut.back()) cut.push_back(p + 1);
+    }
+    cut.push_back(tend);
+    const size_t K = cut.size() - 1;
+    std::vector<int64_t> first(K + 1, 0);
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto pool = [&](auto fn) {
+      std::vector<std::thread> th;
+      next = 0;
+      for (int t = 0; t < T; t++) th.emplace_back([&] { for (size_t k = next.fetch_add(1); k < K; k = next.fetch_add(1)) fn(k); });
+      for (auto &x : th) x.join();
+    };
+    pool([&](size_t k) {                                    // pass 1: records per range
+      Records r; r.s = cut[k]; r.end = cut[k + 1];
+      Rec rec; int64_t n = 0; int rc;
+      while ((rc = r.next(rec)) == 1) n++;
+      if (rc < 0) bad = 1;
+      first[k + 1] = n;
+    });
+    if (!bad) {
+      for (size_t k = 0; k < K; k++) first[k + 1] += first[k];
+      if (first[K] > n_records) { g_trim_error = "more records in the file than coordinates"; return ITSX_E_ARG; }
+      int64_t nw = 0, tot = 0;
+      const bool ccs = trim_ccs != 0;
+      for (size_t k0 = 0; k0 < K && !bad; k0 += (size_t)T) {             // rounds of T ranges, written in order
+        const size_t k1 = std::min(K, k0 + (size_t)T);
+        std::vector<Writer> part(k1 - k0);
+        std::vector<int64_t> pn(k1 - k0, 0), pt(k1 - k0, 0);
+        std::vector<std::thread> th;
+        for (size_t k = k0; k < k1; k++)
+          th.emplace_back([&, k] {
+            Records r; r.s = cut[k]; r.end = cut[k + 1];
+            Writer &w = part[k - k0];                         // (never opened: emit() only appends to its buffer, which is taken below)
+            w.buf.reserve((size_t)(cut[k + 1] - cut[k]) / 2 + 4096);
+            Rec rec; int64_t i = first[k]; int rc;
+            std::string &o = w.buf;
+            static const char *fwd = "GACAGGTACAAGAAGGA", *rev = "TTAACCCAGTCTCCAGT";
+            while ((rc = r.next(rec)) == 1) {
+              const int64_t a = start[i], b = stop[i];
+              i++;
+              if (a < 0 || b < 0 || !(a < b)) continue;
+              int64_t lo, hi; py_slice((int64_t)rec.seq.size(), a, b, false, lo, hi);
+              o.append(rec.title.p, rec.title.n); o += '\n';
+              if (ccs) o += fwd;
+              o.append(rec.seq.p + lo, (size_t)(hi - lo));
+              if (ccs) o += rev;
+              o += "\n+\n";
+              if (ccs) o.append(17, '~');
+              o.append(rec.qual.p + lo, (size_t)(hi - lo));
+              if (ccs) o.append(17, '~');
+              o += '\n';
+              pn[k - k0]++; pt[k - k0] += (hi - lo) + (ccs ? 34 : 0);
+            }
+            if (rc < 0) bad = 1;
+          });
+        for (auto &x : th) x.join();
+        for (size_t k = k0; k < k1 && !bad; k++) { out.w.put(part[k - k0].buf); nw += pn[k - k0]; tot += pt[k - k0]; }
+      }
+      if (!bad) {
+        if (!out.close()) return ITSX_E_IO;
+        if (n_written) *n_written = nw;
+        if (total_len) *total_len = tot;
+        return ITSX_OK;
+      }
+    }
+    // a malformed record somewhere: the serial walk below names it (the output file is started again)
+    { std::string e; out.w.close(e); }
+    if (!out.open(out_path, compression)) return ITSX_E_IO;
+  }
   Rec rec; int64_t i = 0, nw = 0, tot = 0; int rc;
   while ((rc = in.next(rec)) == 1) {
     if (i >= n_records) { g_trim_error = "more records in the file than coordinates"; return ITSX_E_ARG; }

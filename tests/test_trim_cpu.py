@@ -166,3 +166,44 @@ def test_paired_writer_keeps_the_references_suffix_rule(tmp_path):
     z = np.zeros(0, np.int32)
     with pytest.raises(ValueError, match="zstd compressed"):
         write_trimmed_paired(str(a), str(b), str(tmp_path / "o1"), str(tmp_path / "o2"), [], z, z, z)
+
+
+def test_parallel_record_walk_writes_the_same_bytes(tmp_path, monkeypatch):
+    """large inputs are sliced by a pool of threads over ranges cut at record starts (quality lines that start with '@' included);
+    the output -- plain and gzip, with and without CCS stitching -- is byte for byte the serial walk's"""
+    import numpy as np
+    from itsxpress_amd.trim import write_trimmed_fastq
+    rng = np.random.default_rng(3)
+    fq = tmp_path / "in.fq"
+    n = 6000
+    with open(fq, "w") as f:
+        for i in range(n):
+            L = int(rng.integers(40, 400))
+            seq = "".join(rng.choice(list("ACGTN"), L))
+            qual = "".join(rng.choice(list("@+IF#5"), L))          # qualities that look like title and separator lines
+            f.write("@read%d some words\n%s\n+\n%s\n" % (i, seq, qual))
+    start = rng.integers(-1, 120, n).astype(np.int32)
+    stop = rng.integers(-1, 500, n).astype(np.int32)
+    out = {}
+    for mode, env in (("serial", {"ITSX_WRITE_MIN_MB": "100000"}), ("parallel", {"ITSX_WRITE_MIN_MB": "0", "ITSX_WRITE_RANGE_KB": "16", "ITSX_IO_THREADS": "5"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for kind, kw in (("plain", {}), ("gz", {"gzipped": True}), ("ccs", {"trim_ccs": True})):
+            o = tmp_path / ("%s_%s.out" % (mode, kind))
+            out[(mode, kind)] = (write_trimmed_fastq(str(fq), str(o), start, stop, **kw), open(o, "rb").read())
+        for k in env:
+            monkeypatch.delenv(k)
+    for kind in ("plain", "gz", "ccs"):
+        assert out[("serial", kind)] == out[("parallel", kind)], kind
+    assert out[("serial", "plain")][0][0] > 1000
+    # a malformed record is still named by its number
+    bad = tmp_path / "bad.fq"
+    with open(bad, "w") as f:
+        f.write(open(fq).read())
+        f.write("@broken\nACGT\n+\nII\n")
+    monkeypatch.setenv("ITSX_WRITE_MIN_MB", "0")
+    monkeypatch.setenv("ITSX_WRITE_RANGE_KB", "16")
+    from itsxpress_amd import EngineError
+    with pytest.raises(EngineError) as e:
+        write_trimmed_fastq(str(bad), str(tmp_path / "x.out"), np.zeros(n + 1, np.int32), np.full(n + 1, 10, np.int32))
+    assert "malformed FASTQ record %d" % n in str(e.value)

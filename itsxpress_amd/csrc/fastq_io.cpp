@@ -163,10 +163,31 @@ struct CacheEntry { std::string path; int64_t size, mtime_ns; std::shared_ptr<co
 std::mutex g_cache_mu;
 std::deque<CacheEntry> g_cache;          // most recent at the back
 
+// ITSX_TEXT_CACHE_GB, or by default a quarter of the memory this process may still take (MemAvailable, cut by the cgroup's limit), at
+// least 4 GB and at most 32: the writer of a 10 M-read sample inflated its 9 GB of text a second time because the cache held 4 GB
 double cache_budget_bytes()
 {
-  const char *e = getenv("ITSX_TEXT_CACHE_GB");
-  return (e ? atof(e) : 4.0) * (double)(1ull << 30);
+  if (const char *e = getenv("ITSX_TEXT_CACHE_GB")) return atof(e) * (double)(1ull << 30);
+  static const double deflt = [] {
+    double avail = 0.0;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+      char line[256];
+      while (fgets(line, sizeof(line), f)) { long long kb; if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) { avail = (double)kb * 1024.0; break; } }
+      fclose(f);
+    }
+    for (const char *p : {"/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"})
+      if (FILE *f = fopen(p, "r")) {
+        char buf[64] = {0};
+        if (fgets(buf, sizeof(buf), f) && buf[0] >= '0' && buf[0] <= '9') { const double lim = atof(buf); if (lim > 0 && (avail <= 0 || lim < avail)) avail = lim; }
+        fclose(f);
+        break;
+      }
+    double gb = avail > 0 ? avail / 4.0 / (double)(1ull << 30) : 4.0;
+    if (gb < 4.0) gb = 4.0;
+    if (gb > 32.0) gb = 32.0;
+    return gb;
+  }();
+  return deflt * (double)(1ull << 30);
 }
 bool stat_of(const char *path, int64_t &size, int64_t &mtime_ns)
 {

@@ -35,6 +35,8 @@ enum {
 };
 
 typedef struct itsx_ctx itsx_ctx;
+typedef struct itsx_stream itsx_stream;   /* a file's text, handed out while it is being inflated (itsx_stream_*) */
+typedef struct itsx_keyset itsx_keyset;   /* the sequences seen so far in a streaming run (itsx_keyset_*) */
 
 /* One reported-or-not domain, in hmmsearch --domtblout row order (profile file order,
  * then target index, then domain index).  Replaces one text row of domtbl.txt as
@@ -165,6 +167,31 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads);
 /* One contiguous shard of the same file: records [n shard / n_shards, n (shard + 1) / n_shards) in file order, for a driver that
  * spreads one sample over several GPUs (itsxpress_amd/multi.py); n_total = records in the file, first = index of the shard's first. */
 int itsx_load_reads_file_shard(itsx_ctx *ctx, const char *path, int32_t shard, int32_t n_shards, int64_t *n_total, int64_t *first, int64_t *n_reads);
+/* the records of a piece of FASTA / FASTQ TEXT already in memory (a slice of itsx_stream_next); replaces the context's reads */
+int itsx_load_reads_text(itsx_ctx *ctx, const char *text, int64_t nbytes, int64_t *n_reads);
+
+/* ---- streaming file-to-file runs (host-only, context-free: csrc/stream_host.cpp; driver: itsxpress_amd/stream.py).
+ * The reference inflates and parses the whole FASTQ before vsearch starts (itsxpress/main.py:534-554, SeqSample.py:93-131); on one
+ * MI355X the inflater is the slower party, so a large .fastq.gz is cut into file-order chunks that are dereplicated and scored while
+ * the rest is still being inflated.
+ * itsx_stream_open: reads the file and starts inflating in the background (block-parallel for large gzip files; plain, zstd and
+ *   small files are ready at once).  itsx_stream_next: BLOCKS until >= min_bytes of new text are final (or the file ends) and returns
+ *   the next slice, cut at a FASTQ record start (non-FASTQ text arrives in one slice); *last = 1 on the final slice.  Slices stay
+ *   valid until itsx_stream_close; keep_text != 0 leaves the whole text in the process's text cache under the file's path, where
+ *   itsx_write_trimmed_fastq finds it.  A corrupt file is an error of the LAST call at the latest (CRC-32 and length of every gzip
+ *   member are checked as in itsx_load_reads_file): a driver discards what it computed from earlier slices.
+ * itsx_keyset_assign: tuples[n_unique][4] as itsx_unique_keys128 returns them for chunk `chunk`; verdict[n_unique][4] = per local
+ *   unique (global index, orientation flag) of the sequence's FIRST occurrence so far and (chunk, local unique) of the holder that
+ *   scores it -- the first holder, which in file order is vsearch's representative.  Same rows as the multi-GPU owner verdicts.
+ * Errors: negative code, text from itsx_stream_last_error(). */
+int itsx_stream_open(const char *path, itsx_stream **out);
+int itsx_stream_next(itsx_stream *s, int64_t min_bytes, const char **text, int64_t *nbytes, int32_t *last);
+int itsx_stream_close(itsx_stream *s, int32_t keep_text);
+const char *itsx_stream_last_error(void);
+itsx_keyset *itsx_keyset_create(void);
+void itsx_keyset_destroy(itsx_keyset *k);
+int64_t itsx_keyset_size(const itsx_keyset *k);
+int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, int32_t chunk, int64_t *verdict);
 
 /* ---- f4, per-sample batching: the QIIME 2 plugin runs the whole path once per sample
  * (itsxpress/q2_itsxpress.py:273-333: one SeqSample, one vsearch and one hmmsearch process per manifest row), which
@@ -365,6 +392,8 @@ int  itsx_fastq_ids(const char *path, char **names, int64_t **offsets, int64_t *
 void itsx_io_free(char *text);
 int  itsx_io_codecs(void);
 int64_t itsx_io_parallel_inflates(void);
+/* drops the process-wide cache of decompressed texts (ITSX_TEXT_CACHE_GB; the loaders leave a file's text there for the writers) */
+void itsx_io_cache_clear(void);
 
 /* ---- test hooks (parity tests only) */
 /* XXH64 of each read's packed forward / reverse-complement key, as computed on the device */

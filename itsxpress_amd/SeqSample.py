@@ -48,8 +48,12 @@ class EngineTable(str):
 def _new_engine(gpus=None):
     """one Engine, or -- ITSXPRESS_GPUS > 1 -- N workers behind the same interface (started before this process touches a GPU)"""
     from .multi import MultiEngine, gpus_from_env
+    from .stream import StreamEngine, stream_from_env
     n = int(gpus) if gpus else gpus_from_env()
-    return MultiEngine(n) if n > 1 else Engine()
+    if n > 1:
+        return MultiEngine(n)
+    # ITSXPRESS_STREAM=1: file-order chunks of one FASTQ, scored while the rest of the file is still being inflated
+    return StreamEngine() if stream_from_env() else Engine()
 
 
 def _fast_from_env():
@@ -133,7 +137,8 @@ class SeqSample:
             else:
                 self.engine.write_uc(self.uc_file)
                 self.engine.write_rep_fasta(self.rep_file)
-            logging.info("itsx_hip derep: %d reads -> %d unique sequences", self.engine.n_reads, n)
+            if n is not None:                       # (a streaming engine defers the work until the search knows the profiles)
+                logging.info("itsx_hip derep: %d reads -> %d unique sequences", self.engine.n_reads, n)
         except EngineError as e:
             logging.exception("Could not perform dereplication with the HIP engine: %s", e)
             raise e
@@ -177,7 +182,7 @@ class SeqSample:
         try:
             self.dom_file = os.path.join(self.tempdir, "domtbl.txt")
             eng = self.engine
-            if eng.n_unique == 0 and self.rep_file and os.path.exists(self.rep_file) and eng.n_reads == 0:
+            if not getattr(eng, "deferred", False) and eng.n_unique == 0 and self.rep_file and os.path.exists(self.rep_file) and eng.n_reads == 0:
                 # _search called on a rep.fa produced elsewhere (the reference's tests do this)
                 eng.load_reads_file(self.rep_file)
                 eng.derep(strand_both=False, minseqlength=0)

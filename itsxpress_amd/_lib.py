@@ -69,10 +69,12 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq",
            "itsx_io_read", "itsx_io_free", "itsx_io_codecs", "itsx_fastq_ids",
            "itsx_load_reads_files", "itsx_set_samples", "itsx_num_samples", "itsx_select_sample",
-           "itsx_io_parallel_inflates", "itsx_get_read_names",
+           "itsx_io_parallel_inflates", "itsx_io_cache_clear", "itsx_get_read_names",
            "itsx_set_rows_mode", "itsx_lazy_pending", "itsx_domz_count", "itsx_lazy_pending_profiles", "itsx_lazy_complete",
            "itsx_load_reads_file_shard", "itsx_unique_keys128", "itsx_write_derep_arrays", "itsx_write_domtbl_arrays",
-           "itsx_writers_last_error", "itsx_profile_params", "itsx_get_unique_seqs"]
+           "itsx_writers_last_error", "itsx_profile_params", "itsx_get_unique_seqs",
+           "itsx_load_reads_text", "itsx_stream_open", "itsx_stream_next", "itsx_stream_close", "itsx_stream_last_error",
+           "itsx_keyset_create", "itsx_keyset_destroy", "itsx_keyset_size", "itsx_keyset_assign"]
 
 
 def lib():
@@ -105,6 +107,15 @@ def lib():
         "itsx_unique_keys128_device": (i32, [vp, C.c_uint64, C.c_uint64, i64, vp, vp]),
         "itsx_load_reads_file": (i32, [vp, cp, vp]),
         "itsx_load_reads_file_shard": (i32, [vp, cp, i32, i32, vp, vp, vp]),
+        "itsx_load_reads_text": (i32, [vp, vp, i64, vp]),
+        "itsx_stream_open": (i32, [cp, vp]),
+        "itsx_stream_next": (i32, [vp, i64, vp, vp, vp]),
+        "itsx_stream_close": (i32, [vp, i32]),
+        "itsx_stream_last_error": (cp, []),
+        "itsx_keyset_create": (vp, []),
+        "itsx_keyset_destroy": (None, [vp]),
+        "itsx_keyset_size": (i64, [vp]),
+        "itsx_keyset_assign": (i32, [vp, vp, i64, i32, vp]),
         "itsx_unique_keys128": (i32, [vp, C.c_uint64, C.c_uint64, i64, vp]),
         "itsx_write_derep_arrays": (i32, [cp, cp, i64, vp, vp, vp, vp, vp, vp, vp, i64]),
         "itsx_write_domtbl_arrays": (i32, [cp, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
@@ -157,6 +168,7 @@ def lib():
         "itsx_io_free": (None, [vp]),
         "itsx_io_codecs": (i32, []),
         "itsx_io_parallel_inflates": (i64, []),
+        "itsx_io_cache_clear": (None, []),
         "itsx_get_read_names": (i32, [vp, vp, i64, vp]),
         "itsx_load_reads_files": (i32, [vp, vp, i32, vp]),
         "itsx_set_samples": (i32, [vp, vp, i32]),

@@ -486,7 +486,7 @@ int itsx_load_profiles_mem(itsx_ctx *ctx, const char *text, int64_t len, int *n_
 }
 
 // whole file, decompressed by its magic bytes (fastq_io.h); read files stay in the text cache for the writers
-static std::shared_ptr<const std::string> slurp(const char *path, bool cacheable, std::string &err)
+static std::shared_ptr<const itsx_io::Text> slurp(const char *path, bool cacheable, std::string &err)
 {
   return itsx_io::read_text(path, err, cacheable);
 }
@@ -747,7 +747,7 @@ static size_t next_record_start(const char *t, size_t n, size_t from, bool fastq
   return n;
 }
 
-static int parse_fastx(const std::string &text, bool want_qual, bool upper, FastxPart &out, std::string &err)
+static int parse_fastx(const itsx_io::Text &text, bool want_qual, bool upper, FastxPart &out, std::string &err)
 {
   const size_t n = text.size();
   int T = itsx_io::io_threads();
@@ -790,7 +790,7 @@ static int parse_fastx(const std::string &text, bool want_qual, bool upper, Fast
 }
 
 // appended to the context's host-side read set
-static int parse_fastx_append(itsx_ctx *ctx, const std::string &text)
+static int parse_fastx_append(itsx_ctx *ctx, const itsx_io::Text &text)
 {
   FastxPart part;
   part.seq.swap(ctx->h_bases); part.off.swap(ctx->h_off); part.ids.swap(ctx->h_names);
@@ -822,6 +822,18 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
     fprintf(stderr, "[itsx] load %s: read+inflate %.0f ms, parse %.0f ms, upload+pack %.0f ms\n", path, ms(tt0, tt1), ms(tt1, tt2), ms(tt2, std::chrono::steady_clock::now()));
   }
   return rc;
+}
+
+int itsx_load_reads_text(itsx_ctx *ctx, const char *text, int64_t nbytes, int64_t *n_reads)
+{
+  CTXCHK(ctx && (text || nbytes == 0) && nbytes >= 0);
+  itsx_io::Text view;
+  view.borrow(text ? text : "", (size_t)nbytes);
+  ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
+  { const int prc = parse_fastx_append(ctx, view); if (prc != ITSX_OK) return prc; }
+  ctx->N = (int64_t)ctx->h_names.size();
+  if (n_reads) *n_reads = ctx->N;
+  return pack_and_upload(ctx);
 }
 
 // One shard of a file's reads: records [n shard / n_shards, n (shard + 1) / n_shards) in file order (input order is kept inside a
@@ -2563,7 +2575,7 @@ int itsx_orient_load_db(itsx_ctx *ctx, const char *fasta_path, int64_t *n_sequen
   std::string rerr;
   const auto tp = slurp(fasta_path, false, rerr);
   if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
-  const std::string &text = *tp;
+  const itsx_io::Text &text = *tp;
   std::vector<uint32_t> bits(1u << 19, 0u);                 // 4^12 bits
   int64_t nseq = 0;
   const bool use_dust = qmask_dust();                        // vsearch --dbmask dust (its default): masked words are not indexed

@@ -1,7 +1,10 @@
 // fastq_io.cpp -- see fastq_io.h.  Host-only.
 #include "fastq_io.h"
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
@@ -17,6 +20,88 @@
 #include <vector>
 
 namespace itsx_io {
+
+// ------------------------------------------------------------------ Text
+namespace {
+constexpr size_t TEXT_MAP_MIN = (size_t)1 << 20;        // mappings from here up
+inline size_t page_up(size_t n) { return (n + 4095) & ~(size_t)4095; }
+}
+void Text::release()
+{
+  if (kind_ == 1) free(p_);
+  else if (kind_ == 2) munmap(p_, cap_);
+  std::string().swap(own_);
+  p_ = nullptr; n_ = cap_ = 0; kind_ = 0; pinned_ = false;
+}
+bool Text::reserve(size_t cap)
+{
+  if (cap <= cap_) return true;
+  if (pinned_ || kind_ == 4) return false;
+  if (kind_ == 3) {                                     // an adopted string grows as a string does
+    const size_t keep = n_;
+    try { own_.resize(cap); } catch (...) { return false; }
+    p_ = &own_[0]; cap_ = own_.size(); n_ = keep;
+    return true;
+  }
+  if (cap < TEXT_MAP_MIN) {
+    if (kind_ == 2) return true;                        // (cannot happen: a mapping is never below the threshold)
+    char *q = (char *)realloc(kind_ == 1 ? p_ : nullptr, cap);
+    if (!q) return false;
+    p_ = q; cap_ = cap; kind_ = 1;
+    return true;
+  }
+  const size_t want = page_up(cap);
+  if (kind_ == 2) {
+    void *q = mremap(p_, cap_, want, MREMAP_MAYMOVE);
+    if (q != MAP_FAILED) { p_ = (char *)q; cap_ = want; return true; }
+    // (a mapping that something has split into several areas cannot be remapped in one call: copy)
+  }
+  void *q = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (q == MAP_FAILED) return false;
+  // huge pages under a text that is written once, front to back, by many threads: asked for over the WHOLE mapping, so that it
+  // stays one area (advice on a part splits it, and a split mapping cannot grow by mremap)
+  static const bool huge = !(getenv("ITSX_HUGEPAGES") && atoi(getenv("ITSX_HUGEPAGES")) == 0);
+  if (huge) (void)madvise(q, want, MADV_HUGEPAGE);
+  if (n_) memcpy(q, p_, n_);
+  if (kind_ == 1) free(p_);
+  else if (kind_ == 2) munmap(p_, cap_);
+  p_ = (char *)q; cap_ = want; kind_ = 2;
+  return true;
+}
+bool Text::resize(size_t n)
+{
+  if (n > cap_) {
+    // geometric growth, so that a decoder that doubles on demand does not remap for every step
+    size_t cap = std::max(n, cap_ + cap_ / 2);
+    if (!reserve(cap) && !reserve(n)) return false;
+  }
+  n_ = n;
+  return true;
+}
+void Text::shrink_to_fit()
+{
+  if (kind_ == 2) {
+    const size_t want = std::max(page_up(n_), (size_t)4096);
+    if (want < cap_) { munmap(p_ + want, cap_ - want); cap_ = want; }      // the front stays where it is
+  } else if (kind_ == 1 && n_ && n_ < cap_) {
+    char *q = (char *)realloc(p_, n_);
+    if (q) { p_ = q; cap_ = n_; }
+  }
+}
+void Text::swap(Text &o)
+{
+  std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); std::swap(kind_, o.kind_); std::swap(pinned_, o.pinned_);
+  own_.swap(o.own_);
+  if (kind_ == 3) p_ = own_.empty() ? nullptr : &own_[0];                  // (a short string lives inside the object)
+  if (o.kind_ == 3) o.p_ = o.own_.empty() ? nullptr : &o.own_[0];
+}
+void Text::adopt(std::string &&s)
+{
+  release();
+  own_ = std::move(s);
+  p_ = own_.empty() ? nullptr : &own_[0]; n_ = cap_ = own_.size(); kind_ = 3;
+}
+
 namespace {
 
 // ------------------------------------------------------------------ codecs bound at run time
@@ -72,12 +157,12 @@ void codecs() { std::call_once(g_codec_once, load_codecs); }
 int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 // ------------------------------------------------------------------ decompression of a whole buffer
-bool is_gzip(const std::string &r, size_t pos = 0) { return r.size() >= pos + 2 && (unsigned char)r[pos] == 0x1f && (unsigned char)r[pos + 1] == 0x8b; }
-bool is_zstd(const std::string &r) { return r.size() >= 4 && (unsigned char)r[0] == 0x28 && (unsigned char)r[1] == 0xb5 && (unsigned char)r[2] == 0x2f && (unsigned char)r[3] == 0xfd; }
+bool is_gzip(const Text &r, size_t pos = 0) { return r.size() >= pos + 2 && (unsigned char)r[pos] == 0x1f && (unsigned char)r[pos + 1] == 0x8b; }
+bool is_zstd(const Text &r) { return r.size() >= 4 && (unsigned char)r[0] == 0x28 && (unsigned char)r[1] == 0xb5 && (unsigned char)r[2] == 0x2f && (unsigned char)r[3] == 0xfd; }
 
 // The trailer's ISIZE (length mod 2^32 of the LAST member) is the whole length for the usual single-member file below
 // 4 GB; anything implausible falls back to 4x the compressed size.  Only a first guess: both inflaters grow on demand.
-size_t gzip_size_hint(const std::string &raw)
+size_t gzip_size_hint(const Text &raw)
 {
   const size_t guess = std::max<size_t>(raw.size() * 4, 1 << 20);
   if (raw.size() < 18) return guess;
@@ -87,17 +172,17 @@ size_t gzip_size_hint(const std::string &raw)
   return guess;
 }
 
-bool gunzip_libdeflate(const std::string &raw, std::string &out, std::string &err)
+bool gunzip_libdeflate(const Text &raw, Text &out, std::string &err)
 {
   void *d = g_ld.alloc_d();
   if (!d) { err = "libdeflate: out of memory"; return false; }
   size_t pos = 0, opos = 0;
-  out.resize(gzip_size_hint(raw));
-  bool ok = true;
-  while (pos < raw.size() && is_gzip(raw, pos)) {
+  bool ok = out.resize(gzip_size_hint(raw));
+  if (!ok) err = "out of memory inflating";
+  while (ok && pos < raw.size() && is_gzip(raw, pos)) {
     size_t ain = 0, aout = 0;
     const int rc = g_ld.gz_d(d, raw.data() + pos, raw.size() - pos, &out[0] + opos, out.size() - opos, &ain, &aout);
-    if (rc == 3) { out.resize(out.size() * 2); continue; }              // LIBDEFLATE_INSUFFICIENT_SPACE: retry this member
+    if (rc == 3) { if (!out.resize(out.size() * 2)) { err = "out of memory inflating"; ok = false; break; } continue; }              // LIBDEFLATE_INSUFFICIENT_SPACE: retry this member
     if (rc != 0) { err = "corrupt gzip data"; ok = false; break; }
     pos += ain; opos += aout;
   }
@@ -105,16 +190,16 @@ bool gunzip_libdeflate(const std::string &raw, std::string &out, std::string &er
   out.resize(ok ? opos : 0);
   return ok;
 }
-bool gunzip_zlib(const std::string &raw, std::string &out, std::string &err)
+bool gunzip_zlib(const Text &raw, Text &out, std::string &err)
 {
   z_stream zs; memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "zlib: inflateInit2 failed"; return false; }
-  out.resize(gzip_size_hint(raw));
   size_t pos = 0, opos = 0;
-  bool ok = true;
+  bool ok = out.resize(gzip_size_hint(raw));
+  if (!ok) err = "out of memory inflating";
   while (ok && pos < raw.size() && is_gzip(raw, pos)) {
     for (;;) {
-      if (opos == out.size()) out.resize(out.size() * 2);
+      if (opos == out.size() && !out.resize(out.size() * 2)) { ok = false; break; }
       const size_t in_chunk = std::min<size_t>(raw.size() - pos, 1u << 30), out_chunk = std::min<size_t>(out.size() - opos, 1u << 30);
       zs.next_in = (Bytef *)(raw.data() + pos); zs.avail_in = (uInt)in_chunk;
       zs.next_out = (Bytef *)(&out[0] + opos); zs.avail_out = (uInt)out_chunk;
@@ -132,22 +217,22 @@ bool gunzip_zlib(const std::string &raw, std::string &out, std::string &err)
   out.resize(ok ? opos : 0);
   return ok;
 }
-bool unzstd(const std::string &raw, std::string &out, std::string &err)
+bool unzstd(const Text &raw, Text &out, std::string &err)
 {
   if (!g_zs.ok) { err = "zstd-compressed file but libzstd.so.1 could not be loaded"; return false; }
   void *ds = g_zs.create_d();
   if (!ds) { err = "zstd: out of memory"; return false; }
-  out.resize(std::max<size_t>(raw.size() * 4, 1 << 20));
+  if (!out.resize(std::max<size_t>(raw.size() * 4, 1 << 20))) { g_zs.free_d(ds); err = "out of memory"; return false; }
   ZBuf in{(void *)raw.data(), raw.size(), 0}, ob{&out[0], out.size(), 0};
   bool ok = true; size_t last = 0;
   while (in.pos < in.size) {
-    if (ob.pos == ob.size) { out.resize(out.size() * 2); ob.p = &out[0]; ob.size = out.size(); }
+    if (ob.pos == ob.size) { if (!out.resize(out.size() * 2)) { err = "out of memory"; ok = false; break; } ob.p = &out[0]; ob.size = out.size(); }
     last = g_zs.decompress_stream(ds, &ob, &in);
     if (g_zs.is_error(last)) { err = "corrupt zstd data"; ok = false; break; }
   }
   // the input is consumed; a frame that still wants output has only been waiting for room
   while (ok && last != 0) {
-    if (ob.pos == ob.size) { out.resize(out.size() * 2); ob.p = &out[0]; ob.size = out.size(); }
+    if (ob.pos == ob.size) { if (!out.resize(out.size() * 2)) { err = "out of memory"; ok = false; break; } ob.p = &out[0]; ob.size = out.size(); }
     const size_t before = ob.pos;
     last = g_zs.decompress_stream(ds, &ob, &in);
     if (g_zs.is_error(last)) { err = "corrupt zstd data"; ok = false; break; }
@@ -159,7 +244,7 @@ bool unzstd(const std::string &raw, std::string &out, std::string &err)
 }
 
 // ------------------------------------------------------------------ the text cache
-struct CacheEntry { std::string path; int64_t size, mtime_ns; std::shared_ptr<const std::string> text; };
+struct CacheEntry { std::string path; int64_t size, mtime_ns; std::shared_ptr<const Text> text; };
 std::mutex g_cache_mu;
 std::deque<CacheEntry> g_cache;          // most recent at the back
 
@@ -201,7 +286,7 @@ bool stat_of(const char *path, int64_t &size, int64_t &mtime_ns)
 
 void cache_clear() { std::lock_guard<std::mutex> g(g_cache_mu); g_cache.clear(); }
 
-static void cache_insert(const char *path, int64_t fsize, int64_t mtime, std::shared_ptr<const std::string> text, double budget)
+static void cache_insert(const char *path, int64_t fsize, int64_t mtime, std::shared_ptr<const Text> text, double budget)
 {
   std::lock_guard<std::mutex> g(g_cache_mu);
   for (auto it = g_cache.begin(); it != g_cache.end(); ++it) if (it->path == path) { g_cache.erase(it); break; }
@@ -211,7 +296,7 @@ static void cache_insert(const char *path, int64_t fsize, int64_t mtime, std::sh
   while (total > budget && g_cache.size() > 1) { total -= (double)g_cache.front().text->size(); g_cache.pop_front(); }
 }
 
-void cache_put(const char *path, std::shared_ptr<const std::string> text)
+void cache_put(const char *path, std::shared_ptr<const Text> text)
 {
   const double budget = cache_budget_bytes();
   int64_t fsize = 0, mtime = 0;
@@ -232,7 +317,54 @@ int io_threads()
   return std::max(1, n);
 }
 
-std::shared_ptr<const std::string> read_text(const char *path, std::string &err, bool cacheable)
+// the file's bytes (+ 64 zero bytes behind them that are not part of size(): the inflaters may look a little past the end)
+static bool read_raw(const char *path, int64_t fsize, Text &raw, std::string &err)
+{
+  // the file's bytes: large regular files are read by a pool of threads into an untouched mapping (one thread's fread into a
+  // zero-filled string cost 0.9 s for the 3.6 GB of a 10 M-read sample)
+  {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { err = std::string("cannot read ") + path; return false; }
+    bool rerr = false;
+    size_t got = 0;
+    if (!raw.resize((size_t)fsize + 64)) { close(fd); err = std::string("out of memory reading ") + path; return false; }
+    const int T = (fsize >= (int64_t)(64 << 20)) ? std::min(io_threads(), 16) : 1;
+    if (T > 1) {
+      std::vector<std::thread> th;
+      std::atomic<bool> bad{false};
+      const size_t per = (((size_t)fsize + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
+      for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+          size_t at = std::min((size_t)fsize, per * (size_t)t);
+          const size_t end = std::min((size_t)fsize, at + per);
+          while (at < end) { const ssize_t n = pread(fd, raw.data() + at, end - at, (off_t)at); if (n <= 0) { if (n < 0) bad = true; break; } at += (size_t)n; }
+          if (at < end) bad = true;                      // shorter than its size said: the serial loop below decides
+        });
+      for (auto &x : th) x.join();
+      if (!bad) got = (size_t)fsize;
+    }
+    if (got == 0 || got < (size_t)fsize) {
+      got = 0;
+      while (got < (size_t)fsize) { const ssize_t n = pread(fd, raw.data() + got, (size_t)fsize - got, (off_t)got); if (n < 0) { rerr = true; break; } if (n == 0) break; got += (size_t)n; }
+    }
+    // a file that is still growing: read the rest
+    while (!rerr) {
+      if (!raw.resize(got + (1 << 16) + 64)) { rerr = true; break; }
+      const ssize_t n = pread(fd, raw.data() + got, 1 << 16, (off_t)got);
+      if (n < 0) rerr = true;
+      if (n <= 0) break;
+      got += (size_t)n;
+    }
+    close(fd);
+    if (rerr) { err = std::string("read error on ") + path; return false; }
+    raw.resize(got + 64);
+    memset(raw.data() + got, 0, 64);                     // the inflaters may look a few bytes past the end
+    raw.resize(got);
+  }
+  return true;
+}
+
+std::shared_ptr<const Text> read_text(const char *path, std::string &err, bool cacheable)
 {
   codecs();
   int64_t fsize = 0, mtime = 0;
@@ -249,30 +381,15 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
   }
   static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
   const auto c0 = std::chrono::steady_clock::now();
-  FILE *f = fopen(path, "rb");
-  if (!f) { err = std::string("cannot read ") + path; return nullptr; }
-  std::string raw;
-  raw.reserve((size_t)fsize + 64);
-  raw.resize((size_t)fsize);
-  size_t got = 0;
-  while (got < raw.size()) { const size_t n = fread(&raw[got], 1, raw.size() - got, f); if (n == 0) break; got += n; }
-  raw.resize(got);
-  // a file that is still growing, or a pipe: read the rest
-  char tail[1 << 16]; size_t n;
-  while ((n = fread(tail, 1, sizeof(tail), f)) > 0) raw.append(tail, n);
-  const bool rerr = ferror(f) != 0;
-  fclose(f);
-  if (rerr) { err = std::string("read error on ") + path; return nullptr; }
+  Text raw;
+  if (!read_raw(path, fsize, raw, err)) return nullptr;
   const auto c1 = std::chrono::steady_clock::now();
-  auto text = std::make_shared<std::string>();
+  auto text = std::make_shared<Text>();
   bool par = false;
   if (is_gzip(raw)) {
     // large single-member files: block-parallel inflate, accepted only on a CRC-32 and length match (pinflate.cpp)
     if (env_int("ITSX_PARALLEL_INFLATE", 1) != 0 && io_threads() > 1) {
-      const size_t n0 = raw.size();
-      raw.append(16, '\0');
-      par = gunzip_parallel(raw.data(), n0, *text, io_threads());
-      raw.resize(n0);
+      par = gunzip_parallel(raw.data(), raw.size(), *text, io_threads());
       if (par) g_parallel_inflates.fetch_add(1);
     }
     const bool ok = par || (g_ld.ok ? gunzip_libdeflate(raw, *text, err) : gunzip_zlib(raw, *text, err));
@@ -285,6 +402,173 @@ std::shared_ptr<const std::string> read_text(const char *path, std::string &err,
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1).count(), raw.size() / 1e6, text->size() / 1e6);
   if (cacheable && budget > 0 && (double)text->size() <= budget) cache_insert(path, fsize, mtime, text, budget);
   return text;
+}
+
+
+// ------------------------------------------------------------------ TextStream
+struct StreamImpl {
+  std::string path;
+  int64_t fsize = 0, mtime = 0;
+  Text raw;
+  std::shared_ptr<Text> text = std::make_shared<Text>();
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t avail = 0;            // bytes of *text that are final
+  bool done = false, failed = false, joined = true;
+  std::string err;
+  size_t handed = 0;
+  bool fastq = true;
+};
+
+namespace {
+// first FASTQ record start at or after `from` inside t[0, n): a line that starts with '@' whose second line below starts with '+'
+// (a quality line may start with '@'; then the second line below it is a sequence line, which never starts with '+')
+size_t fastq_start_from(const char *t, size_t n, size_t from)
+{
+  size_t q = from;
+  if (q > 0) { const char *nl = (const char *)memchr(t + q - 1, '\n', n - (q - 1)); if (!nl) return n; q = (size_t)(nl - t) + 1; }
+  while (q < n) {
+    if (t[q] == '@') {
+      const char *l1 = (const char *)memchr(t + q, '\n', n - q);
+      const char *l2 = l1 ? (const char *)memchr(l1 + 1, '\n', n - (size_t)(l1 + 1 - t)) : nullptr;
+      if (l2 && (size_t)(l2 + 1 - t) < n && l2[1] == '+') return q;
+    }
+    const char *nl = (const char *)memchr(t + q, '\n', n - q);
+    if (!nl) return n;
+    q = (size_t)(nl - t) + 1;
+  }
+  return n;
+}
+}  // namespace
+
+TextStream::TextStream() : s(new StreamImpl) {}
+TextStream::~TextStream()
+{
+  if (!s->joined) { s->th.join(); s->joined = true; }
+  delete s;
+}
+
+bool TextStream::open(const char *path, std::string &err)
+{
+  codecs();
+  s->path = path;
+  if (!stat_of(path, s->fsize, s->mtime)) { err = std::string("cannot read ") + path; return false; }
+  const double budget = cache_budget_bytes();
+  if (budget > 0) {                                   // already inflated in this process: one piece
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+      if (it->path == s->path && it->size == s->fsize && it->mtime_ns == s->mtime) {
+        s->text = std::const_pointer_cast<Text>(it->text);      // read only from here on
+        s->avail = s->text->size(); s->done = true;
+        return true;
+      }
+  }
+  if (!read_raw(path, s->fsize, s->raw, err)) return false;
+  const int T = io_threads();
+  const bool par = is_gzip(s->raw) && env_int("ITSX_PARALLEL_INFLATE", 1) != 0 && T > 1;
+  if (!par) {
+    bool ok = true;
+    if (is_gzip(s->raw)) ok = g_ld.ok ? gunzip_libdeflate(s->raw, *s->text, err) : gunzip_zlib(s->raw, *s->text, err);
+    else if (is_zstd(s->raw)) ok = unzstd(s->raw, *s->text, err);
+    else s->text->swap(s->raw);
+    if (!ok) { err += std::string(" in ") + path; return false; }
+    s->avail = s->text->size(); s->done = true;
+    return true;
+  }
+  // the text must not move while slices of it are out: address space for any plausible ratio up front (pages arrive on first touch)
+  const size_t n = s->raw.size();
+  size_t want = n * 64 + ((size_t)1 << 30);
+  while (want > n * 4 && !s->text->reserve(want)) want /= 2;
+  if (s->text->capacity() < n * 4 && !s->text->reserve(n * 4 + (1 << 20))) { err = std::string("out of memory inflating ") + path; return false; }
+  s->text->pin(true);
+  s->joined = false;
+  s->th = std::thread([this, T] {
+    StreamImpl *z = s;
+    const std::function<void(size_t)> progress = [z](size_t total) {
+      { std::lock_guard<std::mutex> g(z->mu); z->avail = total; }
+      z->cv.notify_all();
+    };
+    bool ok = gunzip_parallel(z->raw.data(), z->raw.size(), *z->text, T, &progress);
+    std::string e;
+    if (ok) g_parallel_inflates.fetch_add(1);
+    else {
+      // not a file the block-parallel inflater takes (or it ran out of pinned room).  Whatever it reported so far was NOT yet
+      // vouched for by a CRC: if a slice is out already the run is void, else the serial inflater delivers the file in one piece
+      std::unique_lock<std::mutex> g(z->mu);
+      if (z->handed == 0) {
+        z->avail = 0;
+        g.unlock();
+        z->text->pin(false);
+        ok = g_ld.ok ? gunzip_libdeflate(z->raw, *z->text, e) : gunzip_zlib(z->raw, *z->text, e);
+        g.lock();
+        if (ok) z->avail = z->text->size();
+      } else e = "the block-parallel inflater gave up after slices had been handed out";
+    }
+    { std::lock_guard<std::mutex> g(z->mu); z->done = true; z->failed = !ok; if (!ok) z->err = e + " in " + z->path; }
+    z->cv.notify_all();
+  });
+  return true;
+}
+
+bool TextStream::next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *last, std::string &err)
+{
+  std::unique_lock<std::mutex> g(s->mu);
+  min_bytes = std::max<size_t>(min_bytes, 1);
+  size_t window = (size_t)256 << 10;
+  for (;;) {
+    s->cv.wait(g, [&] { return s->done || s->avail >= s->handed + min_bytes + window; });
+    if (s->failed) { err = s->err; return false; }
+    const char *t = s->text->data();
+    const size_t avail = s->avail;
+    const bool done = s->done;
+    if (s->handed == 0) {                              // what kind of file is it?  only FASTQ is cut; anything else arrives whole
+      size_t f = 0;
+      while (f < avail && (t[f] == '\n' || t[f] == '\r')) f++;
+      s->fastq = f < avail && t[f] == '@';
+    }
+    if (!s->fastq && !done) { s->cv.wait(g, [&] { return s->done; }); continue; }
+    // a slice is min_bytes .. 1.5 min_bytes long whatever has piled up meanwhile: chunks of even size keep the consumer's pipeline
+    // even (and a plain file, all of it final at once, is cut like an inflating one)
+    size_t target = avail;
+    if (s->fastq && avail - s->handed > min_bytes + min_bytes / 2 + window) target = s->handed + min_bytes + min_bytes / 2;
+    if (done && target == avail) {
+      *ptr = t + s->handed; *nbytes = avail - s->handed; *last = true;
+      s->handed = avail;
+      return true;
+    }
+    // a record start about `window` before the target (the record-start test needs the two lines that follow the title)
+    const size_t from = target > s->handed + window ? target - window : s->handed + 1;
+    g.unlock();
+    const size_t c = fastq_start_from(t, avail, from);
+    g.lock();
+    if (c < avail && c > s->handed) {
+      *ptr = t + s->handed; *nbytes = c - s->handed; *last = false;
+      s->handed = c;
+      return true;
+    }
+    if (done) {                                         // no record start behind `from`: the rest is one slice
+      *ptr = t + s->handed; *nbytes = avail - s->handed; *last = true;
+      s->handed = avail;
+      return true;
+    }
+    window *= 8;                                        // records longer than the window: look further back, wait for more
+    if (window > min_bytes) min_bytes = window;
+  }
+}
+
+bool TextStream::finish(bool keep, std::string &err)
+{
+  if (!s->joined) { s->th.join(); s->joined = true; }
+  if (s->failed) { err = s->err; return false; }
+  s->text->pin(false);
+  Text().swap(s->raw);
+  if (keep) {
+    const double budget = cache_budget_bytes();
+    // (the reserved address space behind the text costs nothing, and trimming it would need the slices to be gone)
+    if (budget > 0 && (double)s->text->size() <= budget) cache_insert(s->path.c_str(), s->fsize, s->mtime, s->text, budget);
+  }
+  return true;
 }
 
 // ------------------------------------------------------------------ ordered block writer
@@ -432,7 +716,7 @@ bool BlockWriter::close(std::string &err)
   if (fclose(w->fp) != 0) w->failed = true;
   w->fp = nullptr;
   if (w->failed) { err = "compressing or writing the output failed"; return false; }
-  if (w->kept) { cache_put(w->path.c_str(), w->kept); w->kept.reset(); }
+  if (w->kept) { auto t = std::make_shared<Text>(); t->adopt(std::move(*w->kept)); cache_put(w->path.c_str(), t); w->kept.reset(); }
   return true;
 }
 

@@ -15,7 +15,9 @@
 //    through libzstd.so.1's stable one-shot / streaming entry points (no headers for either in this image, so both are
 //    bound at run time; absent libzstd = a loud error for .zst files only).
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 
@@ -23,18 +25,74 @@ namespace itsx_io {
 
 enum Kind { PLAIN = 0, GZIP = 1, ZSTD = 2 };
 
+// A file's bytes.  The part of std::string's interface the loaders and writers use, over memory that is NOT value-initialised when
+// it grows: a 9-GB text filled front to back by a pool of inflating threads must not be zeroed first by one of them (1.5 s of a
+// 5.5-s inflate).  Large buffers are anonymous mappings (pages arrive zeroed from the kernel on the first touch, by whichever
+// thread touches them; growth is an mremap, not a copy); small ones are malloc'd.  adopt() takes over a std::string without a copy.
+class Text {
+ public:
+  Text() = default;
+  ~Text() { release(); }
+  Text(const Text &) = delete;
+  Text &operator=(const Text &) = delete;
+  const char *data() const { return p_; }
+  char *data() { return p_; }
+  size_t size() const { return n_; }
+  size_t capacity() const { return cap_; }
+  bool empty() const { return n_ == 0; }
+  char operator[](size_t i) const { return p_[i]; }
+  char &operator[](size_t i) { return p_[i]; }
+  bool reserve(size_t cap);           // false: out of memory (content kept)
+  bool resize(size_t n);              // new bytes are unspecified (zero only where the kernel has just supplied the page)
+  void clear() { n_ = 0; }
+  void shrink_to_fit();
+  void swap(Text &o);
+  void adopt(std::string &&s);
+  void borrow(const char *q, size_t m) { release(); p_ = const_cast<char *>(q); n_ = cap_ = m; kind_ = 4; }   // a view: never written, never freed
+  // pin: the bytes stay where they are -- growth past the capacity FAILS instead of moving them (readers hold pointers into a
+  // buffer that is still being filled: TextStream)
+  void pin(bool on) { pinned_ = on; }
+  bool append(const char *q, size_t m) { const size_t at = n_; if (!resize(n_ + m)) return false; for (size_t i = 0; i < m; i++) p_[at + i] = q[i]; return true; }
+ private:
+  void release();
+  char *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+  int kind_ = 0;                      // 0 nothing, 1 malloc, 2 mmap, 3 the adopted string, 4 borrowed
+  bool pinned_ = false;
+  std::string own_;
+};
+
 // Returns the decompressed content or nullptr (err set).  cacheable: keep / look up the text in the process-wide cache.
-std::shared_ptr<const std::string> read_text(const char *path, std::string &err, bool cacheable);
+std::shared_ptr<const Text> read_text(const char *path, std::string &err, bool cacheable);
 void cache_clear();
 // Adopt `text` as the content of the file just written at `path` (temporary files the next stage reads back).
-void cache_put(const char *path, std::shared_ptr<const std::string> text);
+void cache_put(const char *path, std::shared_ptr<const Text> text);
 
 int io_threads();               // ITSX_IO_THREADS or min(hardware threads, 32)
 
 // pinflate.cpp: block-parallel inflate of a single-member gzip buffer (data[n .. n+16) must be readable).  true = `out`
 // holds the content and its length and CRC-32 matched the trailer; false = not applicable or any doubt: inflate serially.
-bool gunzip_parallel(const char *data, size_t n, std::string &out, int threads);
+// progress (may be null): called after every round with the number of bytes of `out` that are final (front to back).
+bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const std::function<void(size_t)> *progress = nullptr);
 int64_t parallel_inflates();    // files the block-parallel inflater has delivered since the library was loaded
+
+// A file's text delivered front to back WHILE it is being inflated: the loader of a large .fastq.gz hands record-aligned slices
+// to the GPU stages as the block-parallel inflater finishes its rounds, instead of after the last byte (itsx_stream_* in
+// include/itsx_hip.h).  Plain, zstd and small files arrive in one piece.  The text ends up in the cache like read_text's.
+struct StreamImpl;
+class TextStream {
+ public:
+  TextStream();
+  ~TextStream();
+  bool open(const char *path, std::string &err);
+  // Blocks until at least min_bytes past the last slice are final (or the file ends); the slice is cut at a FASTQ record start.
+  // false: the file could not be delivered (err); *last: nothing follows this slice.
+  bool next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *last, std::string &err);
+  // joins the inflater; keep: the text goes to the cache under the file's path.  Slices stay valid until the TextStream dies.
+  bool finish(bool keep, std::string &err);
+ private:
+  StreamImpl *s;
+};
 
 struct WriterImpl;
 class BlockWriter {

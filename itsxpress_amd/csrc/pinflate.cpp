@@ -319,7 +319,7 @@ template <class F> void parallel(int T, F fn)
 
 }  // namespace
 
-bool gunzip_parallel(const char *data, size_t n, std::string &out, int threads)
+bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const std::function<void(size_t)> *progress)
 {
   const uint8_t *p = (const uint8_t *)data;
   const size_t hdr = gzip_header_len(p, n);
@@ -333,10 +333,7 @@ bool gunzip_parallel(const char *data, size_t n, std::string &out, int threads)
   size_t guess = (size_t)last_len;           // right for the usual single-member file; otherwise only a first guess
   if (guess < n || guess > n * 40) guess = n * 4;
   out.reserve(guess + 64);
-  {                                          // the output is written once, front to back: ask for huge pages under it too
-    const uintptr_t two_mb = (uintptr_t)2 << 20, a = ((uintptr_t)out.data() + two_mb - 1) & ~(two_mb - 1), e = ((uintptr_t)out.data() + out.capacity()) & ~(two_mb - 1);
-    if (e > a && huge_pages()) (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
-  }
+  // (the output is written once, front to back: Text asks for huge pages under its mappings itself)
   std::vector<uint8_t> window(WSIZE, 0);
   // staging: one buffer of 16-bit symbols per chunk slot, reused round after round (12 symbols per compressed byte of a
   // chunk; a chunk that would need more gives the file back to the serial inflater)
@@ -405,7 +402,7 @@ bool gunzip_parallel(const char *data, size_t n, std::string &out, int threads)
       }
       window.swap(nw);
     }
-    out.resize(total);
+    if (!out.resize(total)) return false;
     std::vector<std::vector<uLong>> crcs(live.size());          // per chunk: CRC-32 of every piece between member ends
     parallel((int)live.size(), [&](int k) {
       const uint16_t *v = live[(size_t)k].out.v;
@@ -440,6 +437,7 @@ bool gunzip_parallel(const char *data, size_t n, std::string &out, int threads)
     }
     pos = live.back().end;
     finished = live.back().final;
+    if (progress && *progress) (*progress)(total);
     t_find += ms(r0, r1); t_dec += ms(r1, r2); t_res += ms(r2, now()); rounds++;
     if (!finished && pos >= stream_end_bits) return false;
   }

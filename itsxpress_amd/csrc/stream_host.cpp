@@ -1,0 +1,94 @@
+// stream_host.cpp -- the two host-side pieces of a STREAMING file-to-file run (itsxpress_amd/stream.py): the file's text handed out
+// in record-aligned slices while it is still being inflated, and the set of sequences seen so far.
+//
+// The reference reads the whole FASTQ before vsearch sees it and the whole uc.txt / domtbl.txt before it writes (main.py:534-624,
+// SeqSample.py:93-131,178-225,886-949); one GPU outruns the inflater, so a large .fastq.gz is cut into file-order chunks, each in a
+// context of its own: chunk k is dereplicated and its NEW sequences scored while chunk k + 1 is inflated and parsed.  Exactness is
+// the multi-GPU scheme's: a sequence is scored once, where it first occurs -- which in file order IS vsearch's
+// representative -- and hmmsearch's domZ is summed over the chunks before any threshold is applied.
+// Host-only, no GPU call, no arithmetic of the path.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/itsx_hip.h"
+#include "fastq_io.h"
+
+struct itsx_stream {
+  itsx_io::TextStream ts;
+  std::string err;
+};
+
+// open addressing over the 128-bit orientation-free keys of itsx_unique_keys128; value = the first holder
+struct itsx_keyset {
+  struct Slot { uint64_t k0, k1; int64_t gidx, fwd, chunk, lu; };
+  std::vector<Slot> tab;
+  std::vector<uint8_t> used;
+  size_t n = 0, mask = 0;
+  void grow(size_t cap)
+  {
+    std::vector<Slot> ot; ot.swap(tab);
+    std::vector<uint8_t> ou; ou.swap(used);
+    tab.assign(cap, Slot{}); used.assign(cap, 0); mask = cap - 1;
+    for (size_t i = 0; i < ot.size(); i++) if (ou[i]) { size_t h = (size_t)(ot[i].k0 ^ (ot[i].k1 * 0x9E3779B97F4A7C15ull)) & mask; while (used[h]) h = (h + 1) & mask; tab[h] = ot[i]; used[h] = 1; }
+  }
+};
+
+namespace { std::string g_stream_error; }
+
+extern "C" {
+
+const char *itsx_stream_last_error(void) { return g_stream_error.c_str(); }
+
+int itsx_stream_open(const char *path, itsx_stream **out)
+{
+  if (!path || !out) { g_stream_error = "itsx_stream_open: missing argument"; return ITSX_E_ARG; }
+  itsx_stream *s = new itsx_stream;
+  if (!s->ts.open(path, s->err)) { g_stream_error = s->err; delete s; return ITSX_E_IO; }
+  *out = s;
+  return ITSX_OK;
+}
+
+int itsx_stream_next(itsx_stream *s, int64_t min_bytes, const char **text, int64_t *nbytes, int32_t *last)
+{
+  if (!s || !text || !nbytes || !last) { g_stream_error = "itsx_stream_next: missing argument"; return ITSX_E_ARG; }
+  size_t nb = 0; bool l = false;
+  if (!s->ts.next((size_t)(min_bytes > 0 ? min_bytes : 1), text, &nb, &l, s->err)) { g_stream_error = s->err; return ITSX_E_IO; }
+  *nbytes = (int64_t)nb; *last = l ? 1 : 0;
+  return ITSX_OK;
+}
+
+int itsx_stream_close(itsx_stream *s, int32_t keep_text)
+{
+  if (!s) return ITSX_OK;
+  const bool ok = s->ts.finish(keep_text != 0, s->err);
+  if (!ok) g_stream_error = s->err;
+  delete s;
+  return ok ? ITSX_OK : ITSX_E_IO;
+}
+
+itsx_keyset *itsx_keyset_create(void)
+{
+  itsx_keyset *k = new itsx_keyset;
+  k->grow((size_t)1 << 16);
+  return k;
+}
+void itsx_keyset_destroy(itsx_keyset *k) { delete k; }
+int64_t itsx_keyset_size(const itsx_keyset *k) { return k ? (int64_t)k->n : 0; }
+
+int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, int32_t chunk, int64_t *verdict)
+{
+  if (!k || n_unique < 0 || (n_unique > 0 && (!tuples || !verdict))) { g_stream_error = "itsx_keyset_assign: missing argument"; return ITSX_E_ARG; }
+  for (int64_t u = 0; u < n_unique; u++) {
+    if ((k->n + 1) * 2 > k->tab.size()) k->grow(k->tab.size() * 2);
+    const uint64_t k0 = (uint64_t)tuples[4 * u], k1 = (uint64_t)tuples[4 * u + 1];
+    size_t h = (size_t)(k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) & k->mask;
+    while (k->used[h] && !(k->tab[h].k0 == k0 && k->tab[h].k1 == k1)) h = (h + 1) & k->mask;
+    if (!k->used[h]) { k->tab[h] = itsx_keyset::Slot{k0, k1, tuples[4 * u + 2], tuples[4 * u + 3], (int64_t)chunk, u}; k->used[h] = 1; k->n++; }
+    const itsx_keyset::Slot &s = k->tab[h];
+    verdict[4 * u] = s.gidx; verdict[4 * u + 1] = s.fwd; verdict[4 * u + 2] = s.chunk; verdict[4 * u + 3] = s.lu;
+  }
+  return ITSX_OK;
+}
+
+}  // extern "C"

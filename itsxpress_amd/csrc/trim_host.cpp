@@ -36,7 +36,7 @@ struct View {
 };
 struct Rec { View title, seq, qual; };
 struct Records {
-  std::shared_ptr<const std::string> text;
+  std::shared_ptr<const itsx_io::Text> text;
   const char *s = nullptr, *end = nullptr;
   bool open(const char *path)
   {
@@ -359,6 +359,7 @@ int itsx_fastq_ids(const char *path, char **names, int64_t **offsets, int64_t *n
   return ITSX_OK;
 }
 int itsx_io_codecs(void) { return itsx_io::codec_flags(); }
+void itsx_io_cache_clear(void) { itsx_io::cache_clear(); }
 int64_t itsx_io_parallel_inflates(void) { return itsx_io::parallel_inflates(); }
 
 }  // extern "C"

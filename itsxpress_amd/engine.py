@@ -155,6 +155,14 @@ class Engine:
         self.n_samples = 1
         return n.value
 
+    def load_reads_text(self, ptr, nbytes):
+        """the records of FASTA / FASTQ text already in memory (address + length: a slice of itsxpress_amd.stream's text stream)"""
+        n = C.c_int64(0)
+        self._chk(self.L.itsx_load_reads_text(self.h, C.c_void_p(ptr), int(nbytes), C.byref(n)))
+        self.n_reads = n.value
+        self.n_samples = 1
+        return n.value
+
     # ---- f4: per-sample batching (many samples, one pass of every kernel, per-sample results)
     def load_reads_files(self, paths):
         """One sequence file per sample, in order: sample index = position in `paths`.

@@ -189,6 +189,10 @@ def _h_rep_coords(eng, st, left, right):
     return np.stack(eng.rep_coords(left, right), axis=1).astype(np.int32)
 
 
+def _h_uniq_of(eng, st):
+    return eng.get_derep()[2].astype(np.int32, copy=False)
+
+
 def _h_domains(eng, st):
     return eng.domains()
 
@@ -203,11 +207,185 @@ def _h_stats(eng, st):
 
 _HANDLERS = {"load_shard": _h_load_shard, "set_reads": _h_set_reads, "derep": _h_derep, "verdict": _h_verdict,
              "derep_arrays": _h_derep_arrays, "profiles": _h_profiles, "search": _h_search, "finalize": _h_finalize,
-             "complete": _h_complete, "rep_coords": _h_rep_coords, "domains": _h_domains, "call": _h_call, "stats": _h_stats}
+             "complete": _h_complete, "rep_coords": _h_rep_coords, "uniq_of": _h_uniq_of, "domains": _h_domains, "call": _h_call, "stats": _h_stats}
 
 
 # ---------------------------------------------------------------------------------------------------- the driver
-class MultiEngine:
+class ShardedOps:
+    """What a sample spread over several contexts has in common, whoever holds the contexts (MultiEngine: one worker process per
+    GPU; itsxpress_amd.stream.StreamEngine: file-order chunks on one GPU): the global unique list, domZ summed before the
+    thresholds, per-read coordinates and the file-compatible outputs composed from the contexts' arrays.  A subclass supplies
+    `_each(cmd, args_per_shard)` -> one handler result per shard, `world`, `_verdicts`, `_bases`, `_nloc`."""
+
+    def _all(self, cmd, *args):
+        return self._each(cmd, [args] * self.world)
+
+    def _index_uniques(self):
+        """after the verdicts: the global unique list = distinct sequences in input order of their first occurrences"""
+        verdict = np.concatenate(self._verdicts) if self._verdicts else np.zeros((0, 4), np.int64)
+        self._seeds = np.unique(verdict[:, 0]) if verdict.shape[0] else np.zeros(0, np.int64)
+        self._gmap = [np.searchsorted(self._seeds, v[:, 0]) for v in self._verdicts]        # local unique -> global unique
+        self.n_unique = int(self._seeds.shape[0])
+        self._derep = None
+        self._final = False
+
+    def _derep_arrays(self, names=True, seqs=False):
+        if self._derep is None or (names and "names" not in self._derep[0]) or (seqs and "useqs" not in self._derep[0]):
+            self._derep = self._all("derep_arrays", bool(names), bool(seqs))
+        return self._derep
+
+    def get_derep(self):
+        """(rep_of, strand, uniq_of) per read of the WHOLE sample, as one Engine on the whole input reports them"""
+        parts = self._derep_arrays(names=False)
+        rep_of, strand, uniq_of = [], [], []
+        for r, d in enumerate(parts):
+            uq = d["uniq_of"].astype(np.int64)
+            ok = uq >= 0
+            g = np.where(ok, self._gmap[r][np.maximum(uq, 0)], -1) if self._gmap[r].shape[0] else np.full(uq.shape, -1, np.int64)
+            uniq_of.append(g)
+            rep_of.append(np.where(ok, self._seeds[np.maximum(g, 0)], -1) if self._seeds.shape[0] else np.full(uq.shape, -1, np.int64))
+            strand.append(d["strand"])
+        return np.concatenate(rep_of), np.concatenate(strand), np.concatenate(uniq_of)
+
+    def read_names_raw(self):
+        parts = self._derep_arrays(names=True)
+        blobs = [d["names"][0] for d in parts]
+        offs = [np.zeros(1, np.int64)]
+        base = 0
+        for d in parts:
+            o = d["names"][1]
+            offs.append(o[1:] + base)
+            base += int(o[-1])
+        return b"".join(blobs), np.concatenate(offs)
+
+    def read_names(self):
+        blob, offs = self.read_names_raw()
+        blob = blob.decode()
+        return [blob[offs[i]:offs[i + 1]] for i in range(self.n_reads)]
+
+    def write_uc(self, path):
+        self._write_derep(path, None)
+
+    def write_rep_fasta(self, path):
+        self._write_derep(None, path)
+
+    def _write_derep(self, uc_path, rep_path):
+        from . import _lib
+        L = _lib.lib()
+        parts = self._derep_arrays(names=True, seqs=rep_path is not None)
+        rep_of, strand, _ = self.get_derep()
+        lens = np.concatenate([d["len"] for d in parts]).astype(np.int32)
+        nblob, noffs = self.read_names_raw()
+        sb = so = None
+        if rep_path is not None:                         # the representatives' sequences, in input order of the seeds
+            chunks = [None] * self.n_unique
+            for r, d in enumerate(parts):
+                blob, uo = d["useqs"]
+                is_seed = self._verdicts[r][:, 0] == d["seed_gidx_local"]      # this shard holds the global first occurrence
+                for u in np.nonzero(is_seed)[0]:
+                    chunks[int(self._gmap[r][u])] = blob[int(uo[u]):int(uo[u + 1])]
+            so = np.zeros(self.n_unique + 1, np.int64)
+            np.cumsum([len(c) for c in chunks], out=so[1:])
+            sb = b"".join(chunks)
+        rep_of = np.ascontiguousarray(rep_of, np.int64)
+        strand = np.ascontiguousarray(strand, np.int8)
+        rc = L.itsx_write_derep_arrays(os.fsencode(uc_path) if uc_path else None, os.fsencode(rep_path) if rep_path else None,
+                                       self.n_reads, rep_of.ctypes.data, strand.ctypes.data, lens.ctypes.data,
+                                       nblob, noffs.ctypes.data, sb, so.ctypes.data if so is not None else None, self.n_unique)
+        if rc != 0:
+            raise EngineError(rc, L.itsx_writers_last_error().decode())
+
+    def profile_names(self):
+        return list(self._pmeta[0])
+
+    def set_rows_mode(self, mode):
+        self._mode = mode
+        self.rows_mode = {None: -1, "env": -1, "full": 0, "compact": 1, "lazy": 2}.get(mode, mode)
+
+    def finalize(self, domE=10.0):
+        z = np.sum(self._z, axis=0)
+        res = self._all("finalize", z, float(domE))
+        pend = max(int(r[0]) for r in res)
+        if pend > 0:                                     # rows that depend on the exact domZ: their profiles are counted on every shard
+            flags = np.max([r[1] for r in res], axis=0).astype(np.int32)
+            self._z = self._all("complete", flags)
+            z = np.sum(self._z, axis=0)
+            res = self._all("finalize", z, float(domE))
+            if max(int(r[0]) for r in res) > 0:          # (a counted profile leaves nothing undecided; the safety net: everything in full)
+                self._z = self._all("search", "compact", *self._search_args)
+                z = np.sum(self._z, axis=0)
+                self._all("finalize", z, float(domE))
+        self._domz = z
+        self._final = True
+
+    def _rep_rows(self, left, right):
+        rows = self._all("rep_coords", left, right)      # [U_i, 4] per shard, local uniques (meaningful where the shard scored)
+        out = np.full((self.n_unique, 4), -1, np.int32)
+        out[:, 3] = 0
+        for r, v in enumerate(self._verdicts):
+            mine = (v[:, 2] == r) & (v[:, 3] == np.arange(v.shape[0]))
+            out[self._gmap[r][mine]] = rows[r][mine]
+        return out
+
+    def rep_coords(self, left, right):
+        rows = self._rep_rows(left, right)
+        return tuple(np.ascontiguousarray(rows[:, k]) for k in range(4))
+
+    def trim_coords(self, left, right):
+        """per READ of the whole sample: start, stop, tlen (-1 = None), in_ddict"""
+        rows = self._rep_rows(left, right)
+        nothing = np.array([[-1, -1, -1, 0]], np.int32)
+        rows = np.concatenate([rows, nothing])            # row n_unique: a read that belongs to no cluster
+        cols = [np.ascontiguousarray(rows[:, k]) for k in range(4)]
+        out = [np.empty(self.n_reads, np.int32) for _ in range(4)]
+        at = 0
+        for r, uq in enumerate(self._all("uniq_of")):     # per shard: local unique of every read -> global unique -> its row
+            g = np.where(uq >= 0, self._gmap[r][np.maximum(uq, 0)], self.n_unique) if self._gmap[r].shape[0] else np.full(uq.shape, self.n_unique, np.int64)
+            for k in range(4):
+                np.take(cols[k], g, out=out[k][at:at + uq.shape[0]])
+            at += uq.shape[0]
+        return tuple(out)
+
+    def domains(self):
+        """every shard's domain rows with `rep` = index into the GLOBAL unique list, in domtblout order"""
+        parts = self._all("domains")
+        rows = []
+        for r, d in enumerate(parts):
+            d = d.copy()
+            d["rep"] = self._gmap[r][d["rep"]]
+            rows.append(d)
+        allr = np.concatenate(rows) if rows else np.zeros(0, DOMAIN_DTYPE)
+        order = np.lexsort((allr["dom_idx"], allr["rep"], allr["prof"]))
+        return allr[order]
+
+    def write_domtbl(self, path):
+        from . import _lib
+        L = _lib.lib()
+        rows = np.ascontiguousarray(self.domains())
+        names, M, ev = self._pmeta
+        pn = "".join(names).encode()
+        po = np.zeros(len(names) + 1, np.int64)
+        np.cumsum([len(x) for x in names], out=po[1:])
+        tau = np.ascontiguousarray(ev[:, 4], np.float32)
+        lam = np.ascontiguousarray(ev[:, 5], np.float32)
+        M = np.ascontiguousarray(M, np.int32)
+        # labels of the representatives = labels of the global first occurrences
+        nblob, noffs = self.read_names_raw()
+        tn = [nblob[int(noffs[g]):int(noffs[g + 1])] for g in self._seeds]
+        to = np.zeros(len(tn) + 1, np.int64)
+        np.cumsum([len(x) for x in tn], out=to[1:])
+        tb = b"".join(tn)
+        z = np.ascontiguousarray(self._domz[:self.n_profiles], np.int64)
+        rc = L.itsx_write_domtbl_arrays(os.fsencode(path), rows.ctypes.data, rows.shape[0], self.n_unique, z.ctypes.data, self.n_profiles,
+                                        pn, po.ctypes.data, M.ctypes.data, tau.ctypes.data, lam.ctypes.data, tb, to.ctypes.data)
+        if rc != 0:
+            raise EngineError(rc, L.itsx_writers_last_error().decode())
+
+    def stats(self):
+        return self._all("stats")
+
+
+class MultiEngine(ShardedOps):
     """The part of Engine's interface the mirror classes use, over N single-GPU workers."""
 
     def __init__(self, n_gpus, devices=None):
@@ -258,8 +436,8 @@ class MultiEngine:
             raise EngineError(code, msg)
         return out
 
-    def _all(self, cmd, *args):
-        self._send(cmd, [args] * self.world)
+    def _each(self, cmd, args_per_worker):
+        self._send(cmd, args_per_worker)
         return self._collect()
 
     def _w0(self, name, *args, **kwargs):
@@ -336,12 +514,7 @@ class MultiEngine:
         self._verdicts = [verdict[cut[r]:cut[r + 1]] for r in range(self.world)]
         self._send("verdict", [(v,) for v in self._verdicts])
         self._collect()
-        # the global unique list: distinct sequences in input order of their first occurrences
-        self._seeds = np.unique(verdict[:, 0]) if verdict.shape[0] else np.zeros(0, np.int64)
-        self._gmap = [np.searchsorted(self._seeds, v[:, 0]) for v in self._verdicts]        # local unique -> global unique
-        self.n_unique = int(self._seeds.shape[0])
-        self._derep = None
-        self._final = False
+        self._index_uniques()
         return self.n_unique
 
     def cluster(self, cluster_id, strand_both=True):
@@ -349,72 +522,6 @@ class MultiEngine:
             return self.derep(strand_both=strand_both, minseqlength=1)     # main.py:534-537: 1.0 is exact dereplication
         raise EngineError(-5, "greedy clustering (cluster_id < 1) is sequential by definition and does not shard over GPUs: "
                               "run it with ITSXPRESS_GPUS=1 (DESIGN.md section 7)")
-
-    def _derep_arrays(self, names=True, seqs=False):
-        if self._derep is None or (names and "names" not in self._derep[0]) or (seqs and "useqs" not in self._derep[0]):
-            self._derep = self._all("derep_arrays", bool(names), bool(seqs))
-        return self._derep
-
-    def get_derep(self):
-        """(rep_of, strand, uniq_of) per read of the WHOLE sample, as one Engine on the whole input reports them"""
-        parts = self._derep_arrays(names=False)
-        rep_of, strand, uniq_of = [], [], []
-        for r, d in enumerate(parts):
-            uq = d["uniq_of"].astype(np.int64)
-            ok = uq >= 0
-            g = np.where(ok, self._gmap[r][np.maximum(uq, 0)], -1)
-            uniq_of.append(g)
-            rep_of.append(np.where(ok, self._seeds[np.maximum(g, 0)], -1))
-            strand.append(d["strand"])
-        return np.concatenate(rep_of), np.concatenate(strand), np.concatenate(uniq_of)
-
-    def read_names_raw(self):
-        parts = self._derep_arrays(names=True)
-        blobs = [d["names"][0] for d in parts]
-        offs = [np.zeros(1, np.int64)]
-        base = 0
-        for d in parts:
-            o = d["names"][1]
-            offs.append(o[1:] + base)
-            base += int(o[-1])
-        return b"".join(blobs), np.concatenate(offs)
-
-    def read_names(self):
-        blob, offs = self.read_names_raw()
-        blob = blob.decode()
-        return [blob[offs[i]:offs[i + 1]] for i in range(self.n_reads)]
-
-    def write_uc(self, path):
-        self._write_derep(path, None)
-
-    def write_rep_fasta(self, path):
-        self._write_derep(None, path)
-
-    def _write_derep(self, uc_path, rep_path):
-        from . import _lib
-        L = _lib.lib()
-        parts = self._derep_arrays(names=True, seqs=rep_path is not None)
-        rep_of, strand, _ = self.get_derep()
-        lens = np.concatenate([d["len"] for d in parts]).astype(np.int32)
-        nblob, noffs = self.read_names_raw()
-        sb = so = None
-        if rep_path is not None:                         # the representatives' sequences, in input order of the seeds
-            chunks = [None] * self.n_unique
-            for r, d in enumerate(parts):
-                blob, uo = d["useqs"]
-                is_seed = self._verdicts[r][:, 0] == d["seed_gidx_local"]      # this shard holds the global first occurrence
-                for u in np.nonzero(is_seed)[0]:
-                    chunks[int(self._gmap[r][u])] = blob[int(uo[u]):int(uo[u + 1])]
-            so = np.zeros(self.n_unique + 1, np.int64)
-            np.cumsum([len(c) for c in chunks], out=so[1:])
-            sb = b"".join(chunks)
-        rep_of = np.ascontiguousarray(rep_of, np.int64)
-        strand = np.ascontiguousarray(strand, np.int8)
-        rc = L.itsx_write_derep_arrays(os.fsencode(uc_path) if uc_path else None, os.fsencode(rep_path) if rep_path else None,
-                                       self.n_reads, rep_of.ctypes.data, strand.ctypes.data, lens.ctypes.data,
-                                       nblob, noffs.ctypes.data, sb, so.ctypes.data if so is not None else None, self.n_unique)
-        if rc != 0:
-            raise EngineError(rc, L.itsx_writers_last_error().decode())
 
     # -- a3 / a4
     def load_profiles(self, path=None, text=None):
@@ -426,94 +533,10 @@ class MultiEngine:
         self._final = False
         return self.n_profiles
 
-    def profile_names(self):
-        return list(self._pmeta[0])
-
-    def set_rows_mode(self, mode):
-        self._mode = mode
-        self.rows_mode = {None: -1, "env": -1, "full": 0, "compact": 1, "lazy": 2}.get(mode, mode)
-
     def search(self, T=10.0, F1=1e-6, F2=1e-6, F3=1e-6):
         self._search_args = (T, F1, F2, F3)
         self._z = self._all("search", self._mode, T, F1, F2, F3)
         self._final = False
-
-    def finalize(self, domE=10.0):
-        z = np.sum(self._z, axis=0)
-        res = self._all("finalize", z, float(domE))
-        pend = max(int(r[0]) for r in res)
-        if pend > 0:                                     # rows that depend on the exact domZ: their profiles are counted on every worker
-            flags = np.max([r[1] for r in res], axis=0).astype(np.int32)
-            self._z = self._all("complete", flags)
-            z = np.sum(self._z, axis=0)
-            res = self._all("finalize", z, float(domE))
-            if max(int(r[0]) for r in res) > 0:          # (a counted profile leaves nothing undecided; the safety net: everything in full)
-                self._z = self._all("search", "compact", *self._search_args)
-                z = np.sum(self._z, axis=0)
-                self._all("finalize", z, float(domE))
-        self._domz = z
-        self._final = True
-
-    def _rep_rows(self, left, right):
-        rows = self._all("rep_coords", left, right)      # [U_i, 4] per worker, local uniques (meaningful where the worker scored)
-        out = np.full((self.n_unique, 4), -1, np.int32)
-        out[:, 3] = 0
-        for r, v in enumerate(self._verdicts):
-            mine = (v[:, 2] == r) & (v[:, 3] == np.arange(v.shape[0]))
-            out[self._gmap[r][mine]] = rows[r][mine]
-        return out
-
-    def rep_coords(self, left, right):
-        rows = self._rep_rows(left, right)
-        return tuple(np.ascontiguousarray(rows[:, k]) for k in range(4))
-
-    def trim_coords(self, left, right):
-        """per READ of the whole sample: start, stop, tlen (-1 = None), in_ddict"""
-        rows = self._rep_rows(left, right)
-        _, _, uniq_of = self.get_derep()
-        ok = uniq_of >= 0
-        out = np.full((self.n_reads, 4), -1, np.int32)
-        out[:, 3] = 0
-        out[ok] = rows[uniq_of[ok]]
-        return tuple(np.ascontiguousarray(out[:, k]) for k in range(4))
-
-    def domains(self):
-        """every worker's domain rows with `rep` = index into the GLOBAL unique list, in domtblout order"""
-        parts = self._all("domains")
-        rows = []
-        for r, d in enumerate(parts):
-            d = d.copy()
-            d["rep"] = self._gmap[r][d["rep"]]
-            rows.append(d)
-        allr = np.concatenate(rows) if rows else np.zeros(0, DOMAIN_DTYPE)
-        order = np.lexsort((allr["dom_idx"], allr["rep"], allr["prof"]))
-        return allr[order]
-
-    def write_domtbl(self, path):
-        from . import _lib
-        L = _lib.lib()
-        rows = np.ascontiguousarray(self.domains())
-        names, M, ev = self._pmeta
-        pn = "".join(names).encode()
-        po = np.zeros(len(names) + 1, np.int64)
-        np.cumsum([len(x) for x in names], out=po[1:])
-        tau = np.ascontiguousarray(ev[:, 4], np.float32)
-        lam = np.ascontiguousarray(ev[:, 5], np.float32)
-        M = np.ascontiguousarray(M, np.int32)
-        # labels of the representatives = labels of the global first occurrences
-        nblob, noffs = self.read_names_raw()
-        tn = [nblob[int(noffs[g]):int(noffs[g + 1])] for g in self._seeds]
-        to = np.zeros(len(tn) + 1, np.int64)
-        np.cumsum([len(x) for x in tn], out=to[1:])
-        tb = b"".join(tn)
-        z = np.ascontiguousarray(self._domz[:self.n_profiles], np.int64)
-        rc = L.itsx_write_domtbl_arrays(os.fsencode(path), rows.ctypes.data, rows.shape[0], self.n_unique, z.ctypes.data, self.n_profiles,
-                                        pn, po.ctypes.data, M.ctypes.data, tau.ctypes.data, lam.ctypes.data, tb, to.ctypes.data)
-        if rc != 0:
-            raise EngineError(rc, L.itsx_writers_last_error().decode())
-
-    def stats(self):
-        return self._all("stats")
 
     # -- stages that are not sharded (one GPU does them): orientation of CCS reads, paired-end merging
     def orient_load_db(self, fasta_path):

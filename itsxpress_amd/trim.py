@@ -40,6 +40,11 @@ def read_names(path):
     return [blob[offs[i]:offs[i + 1]].decode() for i in range(n.value)]
 
 
+def cache_clear():
+    """forget the decompressed texts the loaders left for the writers (the library's process-wide cache)"""
+    _lib.lib().itsx_io_cache_clear()
+
+
 def read_text(path):
     """Decompressed bytes of a plain / gzip / zstd file through the engine's reader (gzip.open / pyzstd.open of
     main.py:296-330)."""

@@ -3,7 +3,7 @@
 -- what a user of `itsxpress --fastq x.fq.gz --single_end --region ITS2 --outfile y.fq.gz` waits for, stage by stage
 (load = inflate + parse + upload + device packing; write = slice + block-parallel deflate; the input's text is shared
 between the two through the reader's cache, ITSX_TEXT_CACHE_GB=0 turns that off).
-Prints one JSON line.  usage: file_run.py [--reads 1000000] [--out-kind gz|zst|plain]"""
+Prints one JSON line.  usage: file_run.py [--reads 1000000] [--out-kind gz|zst|plain] [--stream [--check]]"""
 import argparse
 import gzip
 import json
@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--out-kind", default="gz", choices=["gz", "zst", "plain"])
     ap.add_argument("--rows", default="lazy", choices=["lazy", "compact", "full"], help="the search's rows mode (lazy = what ITSXPRESS_ARRAYS=1 selects)")
     ap.add_argument("--shape", default="cfg1", choices=["cfg1", "cfg2"], help="cfg1: 300-base reads; cfg2: merged reads of 300-580 bases")
+    ap.add_argument("--stream", action="store_true", help="file-order chunks scored while the file is inflated (itsxpress_amd/stream.py)")
+    ap.add_argument("--chunk-mb", type=float, default=0.0, help="--stream: text per chunk (0: about a tenth of the file)")
+    ap.add_argument("--check", action="store_true", help="--stream: compare the coordinates with one context on the whole file")
     args = ap.parse_args()
     import synth
     from bench import its2_profiles
@@ -62,15 +65,47 @@ def main():
         eng.search()
         eng.finalize()
         t = {}
-        t0 = time.perf_counter()
-        eng.load_reads_file(fq)
-        t["load"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        nu = eng.derep()
-        eng.search()
-        eng.finalize()
-        start, stop, tlen, ind = eng.trim_coords("3_", "4_")
-        t["path"] = time.perf_counter() - t0
+        extra = {}
+        if args.stream:
+            # file-order chunks: chunk k is dereplicated and scored while chunk k + 1 is inflated and parsed (itsxpress_amd/stream.py)
+            from itsxpress_amd.stream import StreamEngine
+            eng.close()
+            t0 = time.perf_counter()
+            se = StreamEngine(0, chunk_mb=args.chunk_mb or None)
+            se.set_rows_mode(args.rows)
+            se.load_reads_file(fq)
+            se.derep()
+            se.load_profiles(text=its2_profiles(thmm))
+            se.search()
+            t["load+search (streamed)"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            se.finalize()
+            t["finalize"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            nu = se.n_unique
+            start, stop, tlen, ind = se.trim_coords("3_", "4_")
+            t["coords"] = time.perf_counter() - t0
+            extra = {"stream_chunks": se.world, "stream_timeline_s(chunk, text ready, loaded, searched)": se.timeline,
+                     "chunk_load_s": [st.get("load_s") for _, st in se._engs]}
+            if args.check:                              # the same file through one context: identical coordinates
+                e1 = Engine(0)
+                e1.set_rows_mode(args.rows)
+                e1.load_profiles(text=its2_profiles(thmm))
+                e1.load_reads_file(fq); e1.derep(); e1.search(); e1.finalize()
+                ref = e1.trim_coords("3_", "4_")
+                extra["coordinates_equal_one_context"] = bool(all(np.array_equal(a, b) for a, b in zip((start, stop, tlen, ind), ref)))
+                assert extra["coordinates_equal_one_context"]
+                e1.close()
+        else:
+            t0 = time.perf_counter()
+            eng.load_reads_file(fq)
+            t["load"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            nu = eng.derep()
+            eng.search()
+            eng.finalize()
+            start, stop, tlen, ind = eng.trim_coords("3_", "4_")
+            t["path"] = time.perf_counter() - t0
         out = os.path.join(tmp, "trimmed.fastq" + {"gz": ".gz", "zst": ".zst", "plain": ""}[args.out_kind])
         t0 = time.perf_counter()
         nw, tot = write_trimmed_fastq(fq, out, start, stop, gzipped=args.out_kind == "gz", zstd_file=args.out_kind == "zst")
@@ -89,7 +124,7 @@ def main():
         print(json.dumps({
             "reads": n, "shape": args.shape, "rows": args.rows, "unique": int(nu), "written": int(nw), "out_kind": args.out_kind,
             "input_MB": round(in_bytes / 1e6, 1), "input_gz_MB": round(in_gz / 1e6, 1), "output_MB": round(os.path.getsize(out) / 1e6, 1),
-            "s_load": round(t["load"], 3), "s_path": round(t["path"], 3), "s_write": round(t["write"], 3), "s_total": round(total, 3),
+            "stages_s": {k: round(v, 3) for k, v in t.items()}, "s_total": round(total, 3), **extra,
             "reads_per_s_file_to_file": round(n / total), "io_threads": int(os.environ.get("ITSX_IO_THREADS", 0)) or min(os.cpu_count(), 32),
             "codecs": _lib.lib().itsx_io_codecs()}))
     finally:

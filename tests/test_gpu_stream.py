@@ -1,0 +1,135 @@
+"""ITSXPRESS_STREAM=1 (itsxpress_amd/stream.py): one FASTQ cut into file-order chunks -- each chunk dereplicated and scored while the
+rest of the file is still being inflated -- must give what one engine gives on the whole file: uc.txt, rep.fa, domtbl.txt byte for
+byte, per-read coordinates and the trimmed FASTQ.  Reference call sequence: itsxpress/main.py:534-554, 626-638.  `pytest -m gpu`."""
+import gzip
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+S = importlib.import_module("itsxpress_amd.SeqSample")
+
+
+def _its2(tmp, t_hmm_text):
+    from bench import its2_profiles
+    p = os.path.join(tmp, "its2.hmm")
+    with open(p, "w") as f:
+        f.write(its2_profiles(t_hmm_text))
+    return p
+
+
+def _fastq_gz(path, t_hmm_text, n, seed):
+    """duplicates all over the file (also reverse-complemented copies of earlier reads: rc_rate), qualities that start with '@'"""
+    blob, offs = synth.make_reads(t_hmm_text, n, config=3, seed=seed, fixed_len=0, len_range=(300, 520), rc_rate=0.2)
+    seqs = synth.to_strings(blob, offs)
+    rng = np.random.default_rng(seed)
+    with gzip.open(path, "wb", compresslevel=6) as f:
+        for i, s in enumerate(seqs):
+            q = (rng.integers(2, 41, len(s)) + 33).astype(np.uint8)
+            if i % 5 == 0:
+                q[0] = ord("@")
+            f.write(b"@read%06d extra words\n" % i + s.encode() + b"\n+\n" + q.tobytes() + b"\n")
+    return seqs
+
+
+_OPEN = []
+
+
+@pytest.fixture(autouse=True)
+def _close_engines():
+    yield
+    while _OPEN:
+        s = _OPEN.pop()
+        if getattr(s, "_engine", None) is not None:
+            s._engine.close()
+
+
+def _run(fq, tmp, hmm, stream, fast, monkeypatch):
+    os.makedirs(tmp, exist_ok=True)
+    monkeypatch.setenv("ITSXPRESS_GPUS", "1")
+    monkeypatch.setenv("ITSXPRESS_STREAM", "1" if stream else "0")
+    monkeypatch.setenv("ITSXPRESS_ARRAYS", "1" if fast else "0")
+    from itsxpress_amd import trim
+    trim.cache_clear()
+    sobj = S.SeqSampleNotPaired(fastq=fq, tempdir=tmp)
+    _OPEN.append(sobj)
+    sobj.deduplicate(threads=1)
+    sobj._search(hmmfile=hmm, threads=1)
+    its_pos = S.ItsPosition(domtable=sobj.dom_file, region="ITS2")
+    dedup_obj = S.Dedup(uc_file=sobj.uc_file, rep_file=sobj.rep_file, seq_file=sobj.seq_file, fastq=sobj.r1, fastq2=sobj.fastq2)
+    out = os.path.join(tmp, "trimmed.fq.gz")
+    dedup_obj.create_trimmed_seqs(out, gzipped=True, zstd_file=False, itspos=its_pos, wri_file=True, tempdir=tmp)
+    coords = sobj.trim_coordinates("ITS2")
+    return sobj, open(out, "rb").read(), [np.asarray(c).copy() for c in coords], its_pos, dedup_obj
+
+
+def test_chunks_equal_one_engine_file_for_file(tmp_path, t_hmm_text, monkeypatch):
+    tmp = str(tmp_path)
+    hmm = _its2(tmp, t_hmm_text)
+    fq = os.path.join(tmp, "synth.fq.gz")
+    _fastq_gz(fq, t_hmm_text, 12000, 515)
+    # small inflater rounds and small chunks: the file arrives in ~8 slices while it is being inflated
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "32")
+    monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "1.5")
+    one, out1, c1, pos1, dd1 = _run(fq, os.path.join(tmp, "one"), hmm, False, False, monkeypatch)
+    st, out2, c2, pos2, dd2 = _run(fq, os.path.join(tmp, "stream"), hmm, True, False, monkeypatch)
+    from itsxpress_amd.stream import StreamEngine
+    assert isinstance(st._engine, StreamEngine) and st._engine.world >= 4, st._engine.world
+    for name in ("uc.txt", "rep.fa", "domtbl.txt"):
+        a = open(os.path.join(tmp, "one", name), "rb").read()
+        b = open(os.path.join(tmp, "stream", name), "rb").read()
+        assert len(a) > 100 and a == b, name
+    assert out1 == out2 and len(out1) > 1000
+    assert all(np.array_equal(x, y) for x, y in zip(c1, c2))
+    assert pos1.ddict == pos2.ddict and dd1.matchdict == dd2.matchdict
+    # arrays mode: the pipeline proper (load, derep and lazy search overlapped; nothing written but the trimmed reads)
+    sf, outf, cf, posf, ddf = _run(fq, os.path.join(tmp, "fast"), hmm, True, True, monkeypatch)
+    eng = sf._engine
+    assert isinstance(eng, StreamEngine) and eng.world >= 4
+    assert outf == out1 and all(np.array_equal(x, y) for x, y in zip(c1, cf))
+    assert not os.path.exists(os.path.join(tmp, "fast", "uc.txt")) and not os.path.exists(os.path.join(tmp, "fast", "domtbl.txt"))
+    assert ddf.matchdict == dd1.matchdict
+    # the search of every chunk ran inside the pipeline (timeline: chunk, text ready, loaded, searched) and only first occurrences
+    # were scored: the chunks' scored uniques add up to the sample's
+    assert len(eng.timeline) == eng.world and all(t[3] >= t[2] >= t[1] for t in eng.timeline)
+    assert sum(int(((v[:, 2] == k) & (v[:, 3] == np.arange(v.shape[0]))).sum()) for k, v in enumerate(eng._verdicts)) == eng.n_unique
+
+
+def test_reference_fixture_and_one_slice_files(tmp_path, t_hmm_text, monkeypatch):
+    """the reference's own fixture (227 reads: one slice, one chunk) and a plain-text file through the streaming engine"""
+    tmp = str(tmp_path)
+    hmm = _its2(tmp, t_hmm_text)
+    fqz = os.path.join(GOLD, "seq.fq.gz")
+    one, out1, c1, pos1, dd1 = _run(fqz, os.path.join(tmp, "one"), hmm, False, False, monkeypatch)
+    st, out2, c2, pos2, dd2 = _run(fqz, os.path.join(tmp, "stream"), hmm, True, False, monkeypatch)
+    assert st._engine.world == 1
+    for name in ("uc.txt", "rep.fa", "domtbl.txt"):
+        assert open(os.path.join(tmp, "one", name), "rb").read() == open(os.path.join(tmp, "stream", name), "rb").read()
+    assert out1 == out2 and all(np.array_equal(x, y) for x, y in zip(c1, c2))
+    plain = os.path.join(tmp, "seq.fq")
+    with gzip.open(fqz, "rb") as f, open(plain, "wb") as g:
+        g.write(f.read())
+    sp, out3, c3, _, _ = _run(plain, os.path.join(tmp, "plain"), hmm, True, True, monkeypatch)
+    assert out3 == out1 and all(np.array_equal(x, y) for x, y in zip(c1, c3))
+
+
+def test_corrupt_gzip_is_an_error_not_a_result(tmp_path, t_hmm_text, monkeypatch):
+    """a flipped byte deep in the file: slices handed out before it are void -- the run ends in an error, as the plain loader's"""
+    tmp = str(tmp_path)
+    hmm = _its2(tmp, t_hmm_text)
+    fq = os.path.join(tmp, "synth.fq.gz")
+    _fastq_gz(fq, t_hmm_text, 8000, 99)
+    raw = bytearray(open(fq, "rb").read())
+    raw[len(raw) * 3 // 4] ^= 0x55
+    bad = os.path.join(tmp, "bad.fq.gz")
+    open(bad, "wb").write(bytes(raw))
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "32")
+    monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "1")
+    from itsxpress_amd import EngineError
+    with pytest.raises(EngineError):
+        _run(bad, os.path.join(tmp, "bad"), hmm, True, True, monkeypatch)

@@ -263,12 +263,15 @@ def test_parallel_inflate_multi_member_binary_stored_and_damaged(tmp_path, monke
     text = _amplicon_fastq(6000, 60)
     half = len(text) // 2
     small = b"".join(gzip.compress(text[i:i + 50000], 6) for i in range(0, len(text), 50000))
+    two_sym = np.random.default_rng(3).integers(65, 67, 24 << 20, dtype=np.uint8).tobytes()
     cases = {
         "two_members": (gzip.compress(text[:half], 6) + gzip.compress(b"", 6) + gzip.compress(text[half:], 1), text, 1),
         "small_members": (small, text, 1),
         "binary_head": (gzip.compress(np.random.default_rng(1).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes() + text, 6), None, 1),
         "stored": (gzip.compress(text, 0), text, 1),
         "zeros_behind": (gzip.compress(text, 6) + b"\0" * 64, text, 0),
+        # eight times its compressed size, in many members: the output outgrows the first guess (4 x) while the pool fills it
+        "outgrows_the_guess": (b"".join(gzip.compress(two_sym[i:i + (1 << 20)], 6) for i in range(0, len(two_sym), 1 << 20)), two_sym, 1),
     }
     for name, (blob, want, parallel) in cases.items():
         p = tmp_path / (name + ".gz")
@@ -287,3 +290,130 @@ def test_parallel_inflate_multi_member_binary_stored_and_damaged(tmp_path, monke
         p.write_bytes(blob)
         with pytest.raises(EngineError):
             read_text(str(p))
+
+
+def _stream_slices(path, min_bytes, keep=0):
+    import ctypes as C
+    L = _lib.lib()
+    h = C.c_void_p()
+    rc = L.itsx_stream_open(os.fsencode(str(path)), C.byref(h))
+    if rc != 0:
+        raise EngineError(rc, L.itsx_stream_last_error().decode())
+    out = []
+    try:
+        while True:
+            ptr, nb, last = C.c_void_p(), C.c_int64(0), C.c_int32(0)
+            rc = L.itsx_stream_next(h, min_bytes, C.byref(ptr), C.byref(nb), C.byref(last))
+            if rc != 0:
+                raise EngineError(rc, L.itsx_stream_last_error().decode())
+            out.append(C.string_at(ptr.value, nb.value) if nb.value else b"")
+            if last.value:
+                break
+    except BaseException:
+        L.itsx_stream_close(h, 0)
+        raise
+    rc = L.itsx_stream_close(h, keep)
+    if rc != 0:
+        raise EngineError(rc, L.itsx_stream_last_error().decode())
+    return out
+
+
+def test_text_stream_hands_out_whole_records_while_inflating(tmp_path, monkeypatch):
+    """itsx_stream_*: the slices of a large gzip FASTQ are cut at record starts (qualities that start with '@' included), arrive
+    before the file is done and add up to the serial inflater's text; plain, zstd-less and small files arrive in one slice; the
+    text lands in the cache for the writers; a damaged file is an error of the last call at the latest."""
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    recs = []
+    for i in range(40000):
+        ln = int(rng.integers(40, 420))
+        q = (rng.integers(0, 41, ln) + 33).astype(np.uint8)
+        if i % 3 == 0:
+            q[0] = ord("@")
+        recs.append(b"@r%d x\n" % i + acgt[rng.integers(0, 4, ln)].tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    text = b"".join(recs)
+    p = tmp_path / "in.fastq.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    L = _lib.lib()
+    monkeypatch.setenv("ITSX_IO_THREADS", "4")
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "64")
+    monkeypatch.setenv("ITSX_TEXT_CACHE_GB", "1")
+    L.itsx_io_cache_clear()
+    before = L.itsx_io_parallel_inflates()
+    sl = _stream_slices(p, 1 << 20, keep=1)
+    assert L.itsx_io_parallel_inflates() == before + 1
+    assert len(sl) >= 5 and b"".join(sl) == text
+    assert all(s[:1] == b"@" and s.count(b"\n") % 4 == 0 and s.endswith(b"\n") for s in sl)
+    # every slice parses on its own to the records it holds
+    from itsxpress_amd.trim import read_names as fastq_ids
+    n = 0
+    for k, s in enumerate(sl[:3]):
+        q = tmp_path / ("slice%d.fq" % k)
+        q.write_bytes(s)
+        ids = fastq_ids(str(q))
+        assert ids[0] == "r%d" % n and len(ids) == s.count(b"\n") // 4
+        n += len(ids)
+    # kept: the text is in the loaders' / writers' cache -- a second stream of the path is cut from it, nothing is inflated again
+    again = _stream_slices(p, 1 << 20)
+    assert again == sl or (b"".join(again) == text and all(len(x) <= (3 << 19) + (1 << 18) for x in again[:-1]))
+    assert L.itsx_io_parallel_inflates() == before + 1
+    assert all((1 << 20) <= len(x) <= (3 << 19) + (1 << 18) for x in sl[:-1]), [len(x) for x in sl]
+    L.itsx_io_cache_clear()
+    # text that is final at once (a plain file; the serial inflater, ITSX_PARALLEL_INFLATE=0) is cut the same way; a small file
+    # and FASTA (never cut) arrive in one piece
+    plain = tmp_path / "in.fastq"
+    plain.write_bytes(text)
+    pl = _stream_slices(plain, 1 << 20)
+    assert len(pl) >= 5 and b"".join(pl) == text and all(x[:1] == b"@" and x.count(b"\n") % 4 == 0 for x in pl)
+    small = tmp_path / "small.fastq.gz"
+    small.write_bytes(gzip.compress(text[:100000], 6))
+    assert _stream_slices(small, 1 << 10) == [text[:100000]]
+    fa = tmp_path / "in.fa.gz"
+    fasta = b"".join(b">s%d\n" % i + acgt[rng.integers(0, 4, 300)].tobytes() + b"\n" for i in range(30000))
+    fa.write_bytes(gzip.compress(fasta, 6))
+    assert _stream_slices(fa, 1 << 20) == [fasta]
+    monkeypatch.setenv("ITSX_PARALLEL_INFLATE", "0")
+    assert b"".join(_stream_slices(p, 1 << 20)) == text
+    monkeypatch.delenv("ITSX_PARALLEL_INFLATE")
+    empty = tmp_path / "empty.fastq"
+    empty.write_bytes(b"")
+    assert _stream_slices(empty, 1 << 20) == [b""]
+    # damage: a flipped byte late in the stream, a wrong CRC
+    good = p.read_bytes()
+    for name, blob in (("flipped", good[:len(good) * 3 // 4] + bytes([good[len(good) * 3 // 4] ^ 0x10]) + good[len(good) * 3 // 4 + 1:]),
+                       ("trailer", good[:-8] + bytes([good[-8] ^ 1]) + good[-7:])):
+        q = tmp_path / (name + ".gz")
+        q.write_bytes(blob)
+        with pytest.raises(EngineError):
+            _stream_slices(q, 1 << 20)
+    with pytest.raises(EngineError):
+        _stream_slices(tmp_path / "missing.gz", 1)
+
+
+def test_keyset_first_holder_wins():
+    """itsx_keyset_assign: a key's first holder (chunk, local unique, first occurrence, orientation) answers every later chunk"""
+    import ctypes as C
+    L = _lib.lib()
+    ks = L.itsx_keyset_create()
+    try:
+        rng = np.random.default_rng(2)
+        keys = rng.integers(-2**62, 2**62, (50000, 2), dtype=np.int64)
+        seen = {}
+        base = 0
+        for chunk in range(4):
+            pick = rng.integers(0, len(keys), 30000)
+            pick = pick[np.sort(np.unique(pick, return_index=True)[1])]          # a chunk's uniques are distinct
+            tup = np.zeros((len(pick), 4), np.int64)
+            tup[:, :2] = keys[pick]
+            tup[:, 2] = base + np.arange(len(pick)) * 3
+            tup[:, 3] = rng.integers(0, 2, len(pick))
+            out = np.zeros_like(tup)
+            assert L.itsx_keyset_assign(ks, tup.ctypes.data, len(pick), chunk, out.ctypes.data) == 0
+            for u, k in enumerate(pick):
+                want = seen.setdefault(int(k), (int(tup[u, 2]), int(tup[u, 3]), chunk, u))
+                assert tuple(int(x) for x in out[u]) == want
+            base += 100000
+        assert L.itsx_keyset_size(ks) == len(seen)
+        assert L.itsx_keyset_assign(ks, None, 0, 9, None) == 0
+    finally:
+        L.itsx_keyset_destroy(ks)

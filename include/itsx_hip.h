@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ITSX_ABI_VERSION 3      /* 3: rows modes (itsx_set_rows_mode, the lazy domain stage), itsx_stats grew; 2: itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
+#define ITSX_ABI_VERSION 4      /* 4: streaming loads (itsx_stream_*, itsx_keyset_*, itsx_load_reads_text), itsx_io_cache_clear; 3: rows modes (itsx_set_rows_mode, the lazy domain stage), itsx_stats grew; 2: itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
 
 enum {
   ITSX_OK            =  0,

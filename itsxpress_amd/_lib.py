@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitsx_hip.so")
-ABI_VERSION = 3          # include/itsx_hip.h: ITSX_ABI_VERSION
+ABI_VERSION = 4          # include/itsx_hip.h: ITSX_ABI_VERSION
 _LIB = None
 
 

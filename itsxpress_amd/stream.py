@@ -181,10 +181,11 @@ class StreamEngine(ShardedOps):
     def _chunk_bytes(self):
         if self.chunk_mb > 0:
             return int(self.chunk_mb * (1 << 20))
-        # about ten chunks of a gzip file (4 x its size is a typical FASTQ), never below 256 MB: a chunk costs a context and one
-        # more round of every launch, and the last chunk's search is the part of the GPU's work nothing overlaps
+        # slices are 1 - 1.5 x this: about eight chunks of a gzip file (4 x its size is a typical FASTQ), never below 256 MB -- a chunk
+        # costs a context and one more round of every launch (10 M reads: 5, 7, 11 chunks took 14.4, 12.1, 13.6 s file to file), and
+        # the last chunk's search is the part of the GPU's work nothing overlaps
         fsize = os.path.getsize(self._path)
-        return max(256 << 20, int(fsize * 4 / 10))
+        return max(256 << 20, int(fsize * 4 / 16))
 
     def _new_chunk(self, ptr, nb, base, k, keyset):
         import time

@@ -37,6 +37,7 @@ enum {
 typedef struct itsx_ctx itsx_ctx;
 typedef struct itsx_stream itsx_stream;   /* a file's text, handed out while it is being inflated (itsx_stream_*) */
 typedef struct itsx_keyset itsx_keyset;   /* the sequences seen so far in a streaming run (itsx_keyset_*) */
+typedef struct itsx_twriter itsx_twriter; /* a trimmed-FASTQ output that takes text and coordinates piece by piece (itsx_twriter_*) */
 
 /* One reported-or-not domain, in hmmsearch --domtblout row order (profile file order,
  * then target index, then domain index).  Replaces one text row of domtbl.txt as
@@ -183,15 +184,18 @@ int itsx_load_reads_text(itsx_ctx *ctx, const char *text, int64_t nbytes, int64_
  * itsx_keyset_assign: tuples[n_unique][4] as itsx_unique_keys128 returns them for chunk `chunk`; verdict[n_unique][4] = per local
  *   unique (global index, orientation flag) of the sequence's FIRST occurrence so far and (chunk, local unique) of the holder that
  *   scores it -- the first holder, which in file order is vsearch's representative.  Same rows as the multi-GPU owner verdicts.
+ *   gid[n_unique] (may be NULL): the sequence's number in first-seen order = its index in the global unique list.
  * Errors: negative code, text from itsx_stream_last_error(). */
 int itsx_stream_open(const char *path, itsx_stream **out);
 int itsx_stream_next(itsx_stream *s, int64_t min_bytes, const char **text, int64_t *nbytes, int32_t *last);
 int itsx_stream_close(itsx_stream *s, int32_t keep_text);
+/* an upper bound of the number of records in the whole file (lines / 4 for FASTQ), or -1 while it is still being inflated */
+int64_t itsx_stream_records_bound(itsx_stream *s);
 const char *itsx_stream_last_error(void);
 itsx_keyset *itsx_keyset_create(void);
 void itsx_keyset_destroy(itsx_keyset *k);
 int64_t itsx_keyset_size(const itsx_keyset *k);
-int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, int32_t chunk, int64_t *verdict);
+int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, int32_t chunk, int64_t *verdict, int64_t *gid);
 
 /* ---- f4, per-sample batching: the QIIME 2 plugin runs the whole path once per sample
  * (itsxpress/q2_itsxpress.py:273-333: one SeqSample, one vsearch and one hmmsearch process per manifest row), which
@@ -291,6 +295,11 @@ int64_t itsx_lazy_pending(const itsx_ctx *ctx);
  * every row of theirs is decided.  Alone, itsx_search_finalize does this by itself; a multi-rank driver ORs the flags over the
  * ranks, completes on every rank, exchanges the counters again and finalizes again. */
 int itsx_lazy_pending_profiles(const itsx_ctx *ctx, int32_t *flags);
+/* The representatives of the undecided rows (flags[n_unique]); itsx_set_partial_coords(ctx, 1): itsx_rep_coords / itsx_trim_coords
+ * answer although rows are undecided -- the caller promises not to use the flagged representatives' coordinates (a streaming driver
+ * finalizes a chunk with provisional bounds, writes what is decided and comes back for the rest: itsxpress_amd/stream.py). */
+int itsx_lazy_pending_uniques(itsx_ctx *ctx, uint8_t *flags);
+int itsx_set_partial_coords(itsx_ctx *ctx, int on);
 int itsx_lazy_complete(itsx_ctx *ctx, const int32_t *flags);
 int64_t itsx_domz_count(const itsx_ctx *ctx);
 int itsx_get_domz(const itsx_ctx *ctx, int64_t *domZ /* [itsx_domz_count]: [n_samples][n_profiles] (x 2 after a lazy search) */);
@@ -374,6 +383,21 @@ int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out, int64_t out_size);
 int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int compression, int trim_ccs,
                              const int32_t *start, const int32_t *stop, int64_t n_records,
                              int64_t *n_written, int64_t *total_len);
+/* The same writer as an object that takes the input's TEXT and the COORDINATES piece by piece and slices / deflates on its own
+ * threads while more arrive (a streaming run writes the first chunks' reads while the GPU scores the later ones).  The text is cut
+ * into units at the first record start at or after every multiple of 8 MB; a unit's output is one gzip member / zstd frame, units are
+ * written in order, so the file's bytes do not depend on how text and coordinates arrived: itsx_write_trimmed_fastq IS this object
+ * fed once.  itsx_twriter_text: text[0, avail) is final (one address, growing; last = 1 with the final piece; the text must stay
+ * valid until close).  itsx_twriter_coords: rows of records first_record .. first_record + n - 1 (record order, no gaps);
+ * decided[i] == 0 (NULL: all decided) marks a record whose coordinates may still change -- it holds back its own unit only, until
+ * itsx_twriter_update names it.  itsx_twriter_close waits for the pool, fails if a record was left undecided, frees the object.
+ * Errors: negative code, text from itsx_trim_last_error(). */
+int itsx_twriter_open(const char *out_path, int compression, int trim_ccs, itsx_twriter **w);
+int itsx_twriter_text(itsx_twriter *w, const char *text, int64_t avail, int32_t last);
+int itsx_twriter_coords(itsx_twriter *w, int64_t first_record, int64_t n, const int32_t *start, const int32_t *stop, const uint8_t *decided);
+int itsx_twriter_update(itsx_twriter *w, const int64_t *records, int64_t m, const int32_t *start, const int32_t *stop);
+int itsx_twriter_close(itsx_twriter *w, int64_t *n_written, int64_t *total_len);
+
 int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const char *out1_path, const char *out2_path,
                               int compression, int trim_ccs, const char *names, const int64_t *name_offsets, int64_t n_names,
                               const int32_t *start, const int32_t *stop, const int32_t *tlen, int64_t *n_written);

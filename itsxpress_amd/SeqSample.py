@@ -203,6 +203,15 @@ class SeqSample:
             logging.error("The HIP engine or the HMM file was not found")
             raise f
 
+    def plan_output(self, outfile: str, region: str, gzipped: bool = False, zstd_file: bool = False, trim_ccs: bool = False) -> None:
+        """Optional, before deduplicate(): where the trimmed single-end reads will go.  A streaming engine (ITSXPRESS_STREAM=1 with
+        ITSXPRESS_ARRAYS=1) then writes them WHILE it scores -- Dedup.create_trimmed_seqs, called later with the same arguments as in
+        the reference (main.py:626-638), only waits for the last bytes; every other engine ignores the plan."""
+        eng = self.engine
+        if self._is_fast() and hasattr(eng, "plan_output"):
+            left, right = _REGION_PREFIX[region]
+            eng.plan_output(outfile, left, right, gzipped=gzipped, zstd_file=zstd_file, trim_ccs=trim_ccs)
+
     # -- array fast path (a5/a6/a7 composed) ----------------------------------------------
     def trim_coordinates(self, region: str):
         """Per-read (start, stop, tlen, in_ddict) arrays straight from the device; -1 = None."""
@@ -418,6 +427,10 @@ class Dedup:
         if not wri_file:
             return
         if self._engine is not None and getattr(itspos, "_engine", None) is self._engine:
+            planned = getattr(self._engine, "output_planned", None)
+            if planned is not None and planned(outfile, itspos.leftprefix, itspos.rightprefix, gzipped, zstd_file, trim_ccs):
+                self._engine.finish_output()        # a streaming engine has written it while it scored (SeqSample.plan_output)
+                return
             # arrays mode: per-read coordinates straight from the engine, in the order of seq_file's records (the engine read them from it)
             start, stop, _, _ = self._engine.trim_coords(itspos.leftprefix, itspos.rightprefix)
             write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)

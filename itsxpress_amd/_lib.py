@@ -73,8 +73,10 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_set_rows_mode", "itsx_lazy_pending", "itsx_domz_count", "itsx_lazy_pending_profiles", "itsx_lazy_complete",
            "itsx_load_reads_file_shard", "itsx_unique_keys128", "itsx_write_derep_arrays", "itsx_write_domtbl_arrays",
            "itsx_writers_last_error", "itsx_profile_params", "itsx_get_unique_seqs",
-           "itsx_load_reads_text", "itsx_stream_open", "itsx_stream_next", "itsx_stream_close", "itsx_stream_last_error",
-           "itsx_keyset_create", "itsx_keyset_destroy", "itsx_keyset_size", "itsx_keyset_assign"]
+           "itsx_load_reads_text", "itsx_stream_open", "itsx_stream_next", "itsx_stream_close", "itsx_stream_last_error", "itsx_stream_records_bound",
+           "itsx_keyset_create", "itsx_keyset_destroy", "itsx_keyset_size", "itsx_keyset_assign",
+           "itsx_twriter_open", "itsx_twriter_text", "itsx_twriter_coords", "itsx_twriter_update", "itsx_twriter_close",
+           "itsx_lazy_pending_uniques", "itsx_set_partial_coords"]
 
 
 def lib():
@@ -111,11 +113,19 @@ def lib():
         "itsx_stream_open": (i32, [cp, vp]),
         "itsx_stream_next": (i32, [vp, i64, vp, vp, vp]),
         "itsx_stream_close": (i32, [vp, i32]),
+        "itsx_stream_records_bound": (i64, [vp]),
         "itsx_stream_last_error": (cp, []),
         "itsx_keyset_create": (vp, []),
         "itsx_keyset_destroy": (None, [vp]),
         "itsx_keyset_size": (i64, [vp]),
-        "itsx_keyset_assign": (i32, [vp, vp, i64, i32, vp]),
+        "itsx_keyset_assign": (i32, [vp, vp, i64, i32, vp, vp]),
+        "itsx_twriter_open": (i32, [cp, i32, i32, vp]),
+        "itsx_twriter_text": (i32, [vp, vp, i64, i32]),
+        "itsx_twriter_coords": (i32, [vp, i64, i64, vp, vp, vp]),
+        "itsx_twriter_update": (i32, [vp, vp, i64, vp, vp]),
+        "itsx_twriter_close": (i32, [vp, vp, vp]),
+        "itsx_lazy_pending_uniques": (i32, [vp, vp]),
+        "itsx_set_partial_coords": (i32, [vp, i32]),
         "itsx_unique_keys128": (i32, [vp, C.c_uint64, C.c_uint64, i64, vp]),
         "itsx_write_derep_arrays": (i32, [cp, cp, i64, vp, vp, vp, vp, vp, vp, vp, i64]),
         "itsx_write_domtbl_arrays": (i32, [cp, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp, vp]),

@@ -247,7 +247,7 @@ struct itsx_ctx {
   std::vector<int32_t> h_plist; DBuf<int32_t> d_plist;
   int64_t s_Uc = 0; int s_Lcap = 0;       // the last search's chunk size and length cap (the completion walks the same chunks)
   DBuf<float> l_fb; DBuf<uint32_t> l_b10; DBuf<uint8_t> l_done; DBuf<int32_t> l_flag, l_pos, l_scan, l_has; DBuf<unsigned long long> l_gtop, l_sure;
-  DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub; DBuf<int32_t> l_pflag; std::vector<int32_t> lazy_pending_prof;
+  DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub; DBuf<int32_t> l_pflag; DBuf<uint8_t> l_uflag; bool partial_coords = false; std::vector<int32_t> lazy_pending_prof;
   DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
   std::vector<int32_t> h_sorted_active;  // the length-sorted list the HMM stages walk (= h_sorted_uniq unless itsx_set_active_uniques narrowed it)
   DBuf<LenTables> d_lt;
@@ -2278,6 +2278,18 @@ int itsx_lazy_pending_profiles(const itsx_ctx *ctx, int32_t *flags)
   for (int p = 0; p < ctx->P; p++) flags[p] = (ctx->lazy && (size_t)p < ctx->lazy_pending_prof.size()) ? (ctx->lazy_pending_prof[(size_t)p] != 0) : 0;
   return ITSX_OK;
 }
+int itsx_set_partial_coords(itsx_ctx *ctx, int on) { CTXCHK(ctx); ctx->partial_coords = on != 0; return ITSX_OK; }
+// flags[n_unique]: 1 where an undecided row could still change the representative's coordinates (the rows itsx_lazy_pending counts)
+int itsx_lazy_pending_uniques(itsx_ctx *ctx, uint8_t *flags)
+{
+  CTXCHK(ctx && flags && ctx->have_search);
+  if (ctx->U <= 0) return ITSX_OK;
+  if (!ctx->lazy || !ctx->have_final || ctx->l_uflag.n < (size_t)ctx->U) { memset(flags, 0, (size_t)ctx->U); return ITSX_OK; }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(flags, ctx->l_uflag.p, (size_t)ctx->U, hipMemcpyDeviceToHost, ctx->st));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  return ITSX_OK;
+}
 // Exact counters for the flagged profiles: EVERY pair of theirs past the MSV filter goes through the domain pipeline (the ones the
 // lazy rounds evaluated already come again -- their rows are duplicates with the same rank key, which changes no argmax), so that the
 // reported targets of these profiles are counted, not bounded.  Afterwards this context's lower and upper counters of the flagged
@@ -2379,12 +2391,14 @@ static int finalize_lazy(itsx_ctx *ctx, double domE)
   HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 16 * sizeof(int64_t), st));
   HIPCHK(ctx->l_pflag.alloc((size_t)std::max(ctx->P, 1)));
   HIPCHK(hipMemsetAsync(ctx->l_pflag.p, 0, (size_t)std::max(ctx->P, 1) * 4, st));
+  HIPCHK(ctx->l_uflag.alloc((size_t)U + 1));
+  HIPCHK(hipMemsetAsync(ctx->l_uflag.p, 0, (size_t)U + 1, st));
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_finalize_lazy(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, d_dz.p + m, domE, ctx->dev_usample(), ctx->P, st);
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_lazy_sure(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, st);
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
-    if (ctx->dom_n[c] > 0) launch_lazy_pending(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, (unsigned long long *)ctx->w_counters.p, ctx->l_pflag.p, st);
+    if (ctx->dom_n[c] > 0) launch_lazy_pending(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, (unsigned long long *)ctx->w_counters.p, ctx->l_pflag.p, ctx->l_uflag.p, st);
   int64_t pend = 0;
   HIPCHK(hipMemcpyAsync(&pend, ctx->w_counters.p, sizeof(pend), hipMemcpyDeviceToHost, st));
   ctx->lazy_pending_prof.assign((size_t)std::max(ctx->P, 1), 0);
@@ -2779,7 +2793,7 @@ static int coords_common(itsx_ctx *ctx, const char *lp, const char *rp, bool per
   const bool to_host = start && stop && tlen && ind;        // all four, or none (the results stay on the device)
   if (!to_host && (start || stop || tlen || ind)) return ITSX_E_ARG;
   if (!ctx->have_final) SET_ERR(ctx, ITSX_E_ARG, "coordinates requested before itsx_search_finalize");
-  if (ctx->lazy && ctx->lazy_pending > 0)
+  if (ctx->lazy && ctx->lazy_pending > 0 && !ctx->partial_coords)
     SET_ERR(ctx, ITSX_E_ARG, std::to_string(ctx->lazy_pending) + " domain row(s) of the lazy search depend on the exact domZ and could change a result: "
             "search again with itsx_set_rows_mode(ctx, 1) (itsx_lazy_pending reports this after itsx_search_finalize)");
   HIPCHK(hipSetDevice(ctx->device));

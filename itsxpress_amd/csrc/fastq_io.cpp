@@ -419,6 +419,7 @@ struct StreamImpl {
   std::string err;
   size_t handed = 0;
   bool fastq = true;
+  long long bound = -1;
 };
 
 namespace {
@@ -557,6 +558,38 @@ bool TextStream::next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *
   }
 }
 
+long long TextStream::records_bound()
+{
+  size_t n;
+  {
+    std::lock_guard<std::mutex> g(s->mu);
+    if (!s->done || s->failed) return -1;
+    if (s->bound >= 0) return s->bound;
+    n = s->avail;
+  }
+  const char *t = s->text->data();
+  const int T = std::max(1, std::min(io_threads(), (int)(n >> 24) + 1));
+  std::vector<size_t> cnt((size_t)T, 0);
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; k++)
+    th.emplace_back([&, k] {
+      const char *p = t + n / (size_t)T * (size_t)k, *e = (k + 1 == T) ? t + n : t + n / (size_t)T * (size_t)(k + 1);
+      size_t c = 0;
+      while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; c++; p = q + 1; }
+      cnt[(size_t)k] = c;
+    });
+  for (auto &x : th) x.join();
+  size_t lines = 1;                                   // (a last line without its newline)
+  for (size_t c : cnt) lines += c;
+  size_t f = 0;
+  while (f < n && (t[f] == '\n' || t[f] == '\r')) f++;
+  const bool fastq = f < n && t[f] == '@';
+  const long long b = (long long)(lines / (fastq ? 4 : 2)) + 1;
+  std::lock_guard<std::mutex> g(s->mu);
+  s->bound = b;
+  return b;
+}
+
 bool TextStream::finish(bool keep, std::string &err)
 {
   if (!s->joined) { s->th.join(); s->joined = true; }
@@ -662,6 +695,20 @@ struct WriterImpl {
     drain(workers.size() * 3);
   }
 };
+
+PieceCompressor::PieceCompressor(int kind) : kind_(kind), level_(std::min(9, std::max(1, env_int("ITSX_GZIP_LEVEL", 6))))
+{
+  codecs();
+  if (kind_ == ZSTD && !g_zs.ok) ok_ = false;
+  if (kind_ == GZIP && g_ld.ok) ldc_ = g_ld.alloc_c(level_);
+}
+PieceCompressor::~PieceCompressor() { if (ldc_) g_ld.free_c(ldc_); }
+bool PieceCompressor::run(const std::string &in, std::string &out)
+{
+  if (kind_ == PLAIN) { out = in; return true; }
+  if (!ok_) return false;
+  return WriterImpl::compress_block(kind_, level_, ldc_, in, out);
+}
 
 BlockWriter::BlockWriter() : w(new WriterImpl) {}
 BlockWriter::~BlockWriter() { std::string e; if (w->fp) close(e); delete w; }

@@ -90,6 +90,9 @@ class TextStream {
   bool next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *last, std::string &err);
   // joins the inflater; keep: the text goes to the cache under the file's path.  Slices stay valid until the TextStream dies.
   bool finish(bool keep, std::string &err);
+  // an upper bound of the number of records in the WHOLE text (lines / 4 for FASTQ, / 2 otherwise, + 1), or -1 while the text is
+  // still being inflated: what a streaming driver needs to bound the counts of the chunks it has not seen yet
+  long long records_bound();
  private:
   StreamImpl *s;
 };
@@ -106,6 +109,18 @@ class BlockWriter {
   bool close(std::string &err);   // flushes; false when any block failed to compress or write
  private:
   WriterImpl *w;
+};
+
+// One piece of output as an independent gzip member / zstd frame (PLAIN: the bytes themselves), with the BlockWriter's codecs and
+// level: what a writer that orders its pieces itself (trim_host.cpp: itsx_twriter_*) runs on its own threads.  One per thread.
+class PieceCompressor {
+ public:
+  explicit PieceCompressor(int kind);
+  ~PieceCompressor();
+  bool ok() const { return ok_; }
+  bool run(const std::string &in, std::string &out);
+ private:
+  int kind_, level_; void *ldc_ = nullptr; bool ok_ = true;
 };
 
 // which codecs are live in this process (for tests / logs): bit 0 libdeflate, bit 1 libzstd

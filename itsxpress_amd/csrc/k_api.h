@@ -376,6 +376,6 @@ void launch_finalize_lazy(itsx_domain *dom, int64_t n, const int64_t *zlb, const
 // best sure row per (representative, class) and "has a sure row" per representative; then the rows whose status matters
 void launch_lazy_sure(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, unsigned long long *sure, int32_t *has, hipStream_t st);
 void launch_lazy_pending(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, const unsigned long long *sure, const int32_t *has,
-                         unsigned long long *count, int32_t *prof_flag /*[P]: profiles of such rows*/, hipStream_t st);
+                         unsigned long long *count, int32_t *prof_flag /*[P]: profiles of such rows*/, uint8_t *uniq_flag /*[U]: representatives of such rows*/, hipStream_t st);
 
 }  // namespace itsx

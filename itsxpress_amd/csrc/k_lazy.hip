@@ -249,7 +249,8 @@ __global__ void __launch_bounds__(256) k_lazy_sure(const itsx_domain *__restrict
 }
 __global__ void __launch_bounds__(256) k_lazy_pending(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ cls, int ncls,
                                                       const unsigned long long *__restrict__ sure, const int32_t *__restrict__ has,
-                                                      unsigned long long *__restrict__ count, int32_t *__restrict__ prof_flag)
+                                                      unsigned long long *__restrict__ count, int32_t *__restrict__ prof_flag,
+                                                      uint8_t *__restrict__ uniq_flag)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int c = 0;
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(256) k_lazy_pending(const itsx_domain *__restr
     const itsx_domain d = dom[i];
     // an undecided row matters when it would beat its group's best sure row, or when the sequence has no sure row at all
     if (d.dom_idx >= 0 && d.dom_reported == 2) c = !has[d.rep] || rank_key(d) > sure[(size_t)d.rep * ncls + cls[d.prof]];
-    if (c) prof_flag[d.prof] = 1;
+    if (c) { prof_flag[d.prof] = 1; uniq_flag[d.rep] = 1; }
   }
   const unsigned long long m = __ballot(c);
   if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(count, (unsigned long long)__builtin_popcountll(m));
@@ -285,9 +286,9 @@ void launch_lazy_sure(const itsx_domain *dom, int64_t n, const int8_t *cls, int 
   if (n > 0) hipLaunchKernelGGL(k_lazy_sure, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, sure, has);
 }
 void launch_lazy_pending(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, const unsigned long long *sure, const int32_t *has,
-                         unsigned long long *count, int32_t *prof_flag, hipStream_t st)
+                         unsigned long long *count, int32_t *prof_flag, uint8_t *uniq_flag, hipStream_t st)
 {
-  if (n > 0) hipLaunchKernelGGL(k_lazy_pending, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, sure, has, count, prof_flag);
+  if (n > 0) hipLaunchKernelGGL(k_lazy_pending, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, sure, has, count, prof_flag, uniq_flag);
 }
 
 }  // namespace itsx

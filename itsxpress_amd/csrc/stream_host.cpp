@@ -21,7 +21,7 @@ struct itsx_stream {
 
 // open addressing over the 128-bit orientation-free keys of itsx_unique_keys128; value = the first holder
 struct itsx_keyset {
-  struct Slot { uint64_t k0, k1; int64_t gidx, fwd, chunk, lu; };
+  struct Slot { uint64_t k0, k1; int64_t gidx, fwd, chunk, lu, id; };
   std::vector<Slot> tab;
   std::vector<uint8_t> used;
   size_t n = 0, mask = 0;
@@ -58,6 +58,8 @@ int itsx_stream_next(itsx_stream *s, int64_t min_bytes, const char **text, int64
   return ITSX_OK;
 }
 
+int64_t itsx_stream_records_bound(itsx_stream *s) { return s ? (int64_t)s->ts.records_bound() : -1; }
+
 int itsx_stream_close(itsx_stream *s, int32_t keep_text)
 {
   if (!s) return ITSX_OK;
@@ -76,7 +78,7 @@ itsx_keyset *itsx_keyset_create(void)
 void itsx_keyset_destroy(itsx_keyset *k) { delete k; }
 int64_t itsx_keyset_size(const itsx_keyset *k) { return k ? (int64_t)k->n : 0; }
 
-int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, int32_t chunk, int64_t *verdict)
+int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, int32_t chunk, int64_t *verdict, int64_t *gid)
 {
   if (!k || n_unique < 0 || (n_unique > 0 && (!tuples || !verdict))) { g_stream_error = "itsx_keyset_assign: missing argument"; return ITSX_E_ARG; }
   for (int64_t u = 0; u < n_unique; u++) {
@@ -84,9 +86,10 @@ int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, 
     const uint64_t k0 = (uint64_t)tuples[4 * u], k1 = (uint64_t)tuples[4 * u + 1];
     size_t h = (size_t)(k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) & k->mask;
     while (k->used[h] && !(k->tab[h].k0 == k0 && k->tab[h].k1 == k1)) h = (h + 1) & k->mask;
-    if (!k->used[h]) { k->tab[h] = itsx_keyset::Slot{k0, k1, tuples[4 * u + 2], tuples[4 * u + 3], (int64_t)chunk, u}; k->used[h] = 1; k->n++; }
+    if (!k->used[h]) { k->tab[h] = itsx_keyset::Slot{k0, k1, tuples[4 * u + 2], tuples[4 * u + 3], (int64_t)chunk, u, (int64_t)k->n}; k->used[h] = 1; k->n++; }
     const itsx_keyset::Slot &s = k->tab[h];
     verdict[4 * u] = s.gidx; verdict[4 * u + 1] = s.fwd; verdict[4 * u + 2] = s.chunk; verdict[4 * u + 3] = s.lu;
+    if (gid) gid[u] = s.id;
   }
   return ITSX_OK;
 }

@@ -17,6 +17,9 @@
 #include <memory>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -146,89 +149,28 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
   Records in; Writer out;
   if (!in.open(seq_path)) return ITSX_E_IO;
   if (!out.open(out_path, compression)) return ITSX_E_IO;
-  // Large inputs: the record walk itself (10 M records = 9 GB of text in, 4 GB out) took longer on one thread than the whole GPU
-  // path.  The text is cut at record starts into ranges that a pool of threads slices independently -- a counting pass gives every
-  // range the index of its first record --, and the ranges' outputs go to the block writer in order: the same bytes as the serial walk.
-  const int T = itsx_io::io_threads();
+  // The writer proper is itsx_twriter (below): units of the text sliced and deflated by a pool of threads, written in order --
+  // fed here with the whole text and every coordinate at once, by a streaming run piece by piece: the same bytes either way.
+  // (One I/O thread: the serial walk below; a malformed record sends the file there too, and the walk names it.)
   const size_t size = (size_t)(in.end - in.s);
-  const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : (size_t)64 << 20;
-  if (T > 1 && size >= min_par) {
-    const size_t range = getenv("ITSX_WRITE_RANGE_KB") ? (size_t)atoll(getenv("ITSX_WRITE_RANGE_KB")) << 10 : (size_t)16 << 20;
-    const char *t0 = in.s, *tend = in.end;
-    std::vector<const char *> cut(1, t0);
-    for (size_t at = range; at < size; at += range) {
-      const char *p = (const char *)memchr(t0 + at, '\n', size - at);
-      while (p && p + 1 < tend && !fastq_record_start(t0, tend, p + 1)) p = (const char *)memchr(p + 1, '\n', (size_t)(tend - (p + 1)));
-      if (!p || p + 1 >= tend) break;
-      if (p + 1 > cut.back()) cut.push_back(p + 1);
-    }
-    cut.push_back(tend);
-    const size_t K = cut.size() - 1;
-    std::vector<int64_t> first(K + 1, 0);
-    std::atomic<size_t> next{0};
-    std::atomic<int> bad{0};
-    auto pool = [&](auto fn) {
-      std::vector<std::thread> th;
-      next = 0;
-      for (int t = 0; t < T; t++) th.emplace_back([&] { for (size_t k = next.fetch_add(1); k < K; k = next.fetch_add(1)) fn(k); });
-      for (auto &x : th) x.join();
-    };
-    pool([&](size_t k) {                                    // pass 1: records per range
-      Records r; r.s = cut[k]; r.end = cut[k + 1];
-      Rec rec; int64_t n = 0; int rc;
-      while ((rc = r.next(rec)) == 1) n++;
-      if (rc < 0) bad = 1;
-      first[k + 1] = n;
-    });
-    if (!bad) {
-      for (size_t k = 0; k < K; k++) first[k + 1] += first[k];
-      if (first[K] > n_records) { g_trim_error = "more records in the file than coordinates"; return ITSX_E_ARG; }
-      int64_t nw = 0, tot = 0;
-      const bool ccs = trim_ccs != 0;
-      for (size_t k0 = 0; k0 < K && !bad; k0 += (size_t)T) {             // rounds of T ranges, written in order
-        const size_t k1 = std::min(K, k0 + (size_t)T);
-        std::vector<Writer> part(k1 - k0);
-        std::vector<int64_t> pn(k1 - k0, 0), pt(k1 - k0, 0);
-        std::vector<std::thread> th;
-        for (size_t k = k0; k < k1; k++)
-          th.emplace_back([&, k] {
-            Records r; r.s = cut[k]; r.end = cut[k + 1];
-            Writer &w = part[k - k0];                         // (never opened: emit() only appends to its buffer, which is taken below)
-            w.buf.reserve((size_t)(cut[k + 1] - cut[k]) / 2 + 4096);
-            Rec rec; int64_t i = first[k]; int rc;
-            std::string &o = w.buf;
-            static const char *fwd = "GACAGGTACAAGAAGGA", *rev = "TTAACCCAGTCTCCAGT";
-            while ((rc = r.next(rec)) == 1) {
-              const int64_t a = start[i], b = stop[i];
-              i++;
-              if (a < 0 || b < 0 || !(a < b)) continue;
-              int64_t lo, hi; py_slice((int64_t)rec.seq.size(), a, b, false, lo, hi);
-              o.append(rec.title.p, rec.title.n); o += '\n';
-              if (ccs) o += fwd;
-              o.append(rec.seq.p + lo, (size_t)(hi - lo));
-              if (ccs) o += rev;
-              o += "\n+\n";
-              if (ccs) o.append(17, '~');
-              o.append(rec.qual.p + lo, (size_t)(hi - lo));
-              if (ccs) o.append(17, '~');
-              o += '\n';
-              pn[k - k0]++; pt[k - k0] += (hi - lo) + (ccs ? 34 : 0);
-            }
-            if (rc < 0) bad = 1;
-          });
-        for (auto &x : th) x.join();
-        for (size_t k = k0; k < k1 && !bad; k++) { out.w.put(part[k - k0].buf); nw += pn[k - k0]; tot += pt[k - k0]; }
-      }
-      if (!bad) {
-        if (!out.close()) return ITSX_E_IO;
-        if (n_written) *n_written = nw;
-        if (total_len) *total_len = tot;
-        return ITSX_OK;
-      }
-    }
-    // a malformed record somewhere: the serial walk below names it (the output file is started again)
+  const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : 0;
+  if (itsx_io::io_threads() > 1 && size >= min_par) {
     { std::string e; out.w.close(e); }
-    if (!out.open(out_path, compression)) return ITSX_E_IO;
+    itsx_twriter *tw = nullptr;
+    int rc = itsx_twriter_open(out_path, compression, trim_ccs, &tw);
+    if (rc != ITSX_OK) return rc;
+    rc = itsx_twriter_text(tw, in.s, (int64_t)size, 1);
+    if (rc == ITSX_OK) rc = itsx_twriter_coords(tw, 0, n_records, start, stop, nullptr);
+    int64_t nw = 0, tot = 0;
+    const int crc = itsx_twriter_close(tw, &nw, &tot);
+    if (rc == ITSX_OK) rc = crc;
+    if (rc == ITSX_OK) {
+      if (n_written) *n_written = nw;
+      if (total_len) *total_len = tot;
+      return ITSX_OK;
+    }
+    if (rc != ITSX_E_FORMAT) return rc;
+    if (!out.open(out_path, compression)) return ITSX_E_IO;      // a malformed record somewhere: the serial walk names it
   }
   Rec rec; int64_t i = 0, nw = 0, tot = 0; int rc;
   while ((rc = in.next(rec)) == 1) {
@@ -245,6 +187,289 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
   if (n_written) *n_written = nw;
   if (total_len) *total_len = tot;
   return ITSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// itsx_twriter_*: the trimmed-FASTQ writer as an object that takes the input's text and the coordinates PIECE BY PIECE and works
+// while more arrive (a streaming file-to-file run deflates the first chunks' reads while the GPU scores the later chunks).
+// The text is cut into UNITS at the first record start at or after every multiple of 8 MB of the text: a unit's output is one
+// gzip member / zstd frame of its own (a unit without a surviving record adds nothing), so a unit depends on its own records only,
+// the units are written in order, and the bytes of the file do not depend on how text and coordinates arrived.
+// itsx_write_trimmed_fastq is the same object fed once.  A record whose coordinates are not decided yet (`decided[i] == 0`) holds
+// back its unit alone, until itsx_twriter_update names it.
+}  // extern "C" (the writer object's types are C++)
+
+// grows at the end without ever moving what it holds: the pool's threads read rows while the caller appends more
+template <class T> struct StableVec {
+  static constexpr size_t LOG = 20, BLK = (size_t)1 << LOG;
+  std::vector<std::unique_ptr<T[]>> blocks; size_t n = 0;
+  StableVec() { blocks.reserve(1 << 16); }            // 6.9e10 rows before the table itself would move
+  size_t size() const { return n; }
+  T &operator[](size_t i) { return blocks[i >> LOG][i & (BLK - 1)]; }
+  const T &operator[](size_t i) const { return blocks[i >> LOG][i & (BLK - 1)]; }
+  void append(const T *src, size_t m, T fill)
+  {
+    for (size_t k = 0; k < m;) {
+      if ((n >> LOG) >= blocks.size()) blocks.emplace_back(new T[BLK]);
+      const size_t at = n & (BLK - 1), take = std::min(m - k, BLK - at);
+      T *dst = blocks[n >> LOG].get() + at;
+      if (src) memcpy(dst, src + k, take * sizeof(T)); else for (size_t q = 0; q < take; q++) dst[q] = fill;
+      n += take; k += take;
+    }
+  }
+};
+
+struct itsx_twriter {
+  struct Unit {
+    size_t lo = 0, hi = 0;                 // text range (record-aligned)
+    int64_t count = -1, first = -1;        // records inside (counted by the pool), index of the first
+    int64_t undecided = -1;                // -1: coordinates not complete yet
+    int state = 0;                         // 0 cut, 1 being sliced, 2 done
+    std::string comp; int64_t nw = 0, tot = 0;
+  };
+  std::string path; int kind = 0; bool ccs = false; size_t unit_bytes = (size_t)8 << 20;
+  FILE *fp = nullptr;
+  const char *base = nullptr; size_t avail = 0; bool text_done = false;
+  size_t next_cut_at = 0;                  // the next multiple of unit_bytes to cut behind
+  std::deque<Unit> units;
+  size_t counted_prefix = 0;               // units [0, counted_prefix) know their `first`
+  int64_t records_cut = 0;                 // records in those units
+  StableVec<int32_t> start, stop; StableVec<uint8_t> decided;
+  size_t next_write = 0; bool flushing = false;
+  bool wrote_any = false, failed = false, malformed = false, closing = false;
+  std::string err;
+  int64_t nw = 0, tot = 0;
+  // pool
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_idle;
+  std::deque<std::pair<int, size_t>> jobs;  // (0 count | 1 slice, unit)
+  int busy = 0; bool quit = false;
+
+  // ---- all of these with `mu` held
+  void cut_units()
+  {
+    // a cut needs the record-start test's two following lines: only where enough text is final (or the text is complete)
+    for (;;) {
+      const size_t lo = units.empty() ? 0 : units.back().hi;
+      if (lo >= avail) break;
+      size_t hi;
+      const size_t want = next_cut_at + unit_bytes;
+      if (want >= avail) {
+        if (!text_done) break;
+        hi = avail;
+      } else {
+        const char *t0 = base, *tend = base + avail;
+        const char *p = (const char *)memchr(t0 + want, '\n', avail - want);
+        while (p && p + 1 < tend && !fastq_record_start_at(t0, tend, p + 1)) p = (const char *)memchr(p + 1, '\n', (size_t)(tend - (p + 1)));
+        if (!p || p + 1 >= tend) { if (!text_done) break; hi = avail; }
+        else hi = (size_t)(p + 1 - t0);
+      }
+      next_cut_at = want;
+      if (hi <= lo) continue;               // (a record longer than a unit)
+      Unit u; u.lo = lo; u.hi = hi;
+      units.push_back(std::move(u));
+      jobs.emplace_back(0, units.size() - 1);
+      if (hi >= avail) break;
+    }
+    cv_work.notify_all();
+  }
+  void advance()
+  {
+    while (counted_prefix < units.size() && units[counted_prefix].count >= 0) {
+      units[counted_prefix].first = records_cut;
+      records_cut += units[counted_prefix].count;
+      counted_prefix++;
+    }
+    for (size_t k = next_write; k < counted_prefix; k++) {
+      Unit &u = units[k];
+      if (u.state != 0) continue;
+      if (u.first + u.count > (int64_t)start.size()) break;      // its coordinates have not arrived
+      if (u.undecided < 0) { int64_t c = 0; for (int64_t i = u.first; i < u.first + u.count; i++) c += decided[(size_t)i] == 0; u.undecided = c; }
+      if (u.undecided == 0) { u.state = 1; jobs.emplace_back(1, k); }
+    }
+    cv_work.notify_all();
+  }
+  static bool fastq_record_start_at(const char *t, const char *end, const char *p);
+  void work();
+  // writes every finished unit that is next in order (called without the lock)
+  void flush_ready()
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    if (flushing) return;                  // somebody is at it already and will see this unit too: one writer keeps the order
+    flushing = true;
+    while (next_write < units.size() && units[next_write].state == 2) {
+      Unit &u = units[next_write];
+      std::string c; c.swap(u.comp);
+      nw += u.nw; tot += u.tot;
+      next_write++;
+      if (!c.empty()) {
+        wrote_any = true;
+        lk.unlock();
+        const bool ok = fwrite(c.data(), 1, c.size(), fp) == c.size();
+        lk.lock();
+        if (!ok) failed = true;
+      }
+    }
+    flushing = false;
+  }
+};
+
+bool itsx_twriter::fastq_record_start_at(const char *t, const char *end, const char *p) { return fastq_record_start(t, end, p); }
+
+void itsx_twriter::work()
+{
+  itsx_io::PieceCompressor pc(kind);
+  std::string out;
+  for (;;) {
+    std::pair<int, size_t> j;
+    size_t lo, hi; int64_t first = 0;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_work.wait(lk, [&] { return quit || !jobs.empty(); });
+      if (jobs.empty()) return;
+      j = jobs.front(); jobs.pop_front();
+      busy++;
+      lo = units[j.second].lo; hi = units[j.second].hi; first = units[j.second].first;
+    }
+    Records r; r.s = base + lo; r.end = base + hi;
+    Rec rec; int rc;
+    if (j.first == 0) {
+      int64_t n = 0;
+      while ((rc = r.next(rec)) == 1) n++;
+      std::lock_guard<std::mutex> lk(mu);
+      if (rc < 0) malformed = true;
+      units[j.second].count = n;
+      advance();
+      busy--;
+      cv_idle.notify_all();
+      continue;
+    }
+    out.clear();
+    out.reserve((hi - lo) / 2 + 4096);
+    static const char *fwd = "GACAGGTACAAGAAGGA", *rev = "TTAACCCAGTCTCCAGT";
+    int64_t i = first, n_out = 0, t_out = 0;
+    while ((rc = r.next(rec)) == 1) {
+      const int64_t a = start[(size_t)i], b = stop[(size_t)i];      // (rows of decided records are not written to any more)
+      i++;
+      if (a < 0 || b < 0 || !(a < b)) continue;
+      int64_t l, h; py_slice((int64_t)rec.seq.size(), a, b, false, l, h);
+      out.append(rec.title.p, rec.title.n); out += '\n';
+      if (ccs) out += fwd;
+      out.append(rec.seq.p + l, (size_t)(h - l));
+      if (ccs) out += rev;
+      out += "\n+\n";
+      if (ccs) out.append(17, '~');
+      out.append(rec.qual.p + l, (size_t)(h - l));
+      if (ccs) out.append(17, '~');
+      out += '\n';
+      n_out++; t_out += (h - l) + (ccs ? 34 : 0);
+    }
+    std::string comp;
+    bool ok = rc == 0;
+    if (ok && !out.empty()) ok = pc.run(out, comp);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      Unit &u = units[j.second];
+      if (!ok) { if (rc < 0) malformed = true; else failed = true; }
+      u.comp.swap(comp); u.nw = n_out; u.tot = t_out; u.state = 2;
+    }
+    flush_ready();
+    { std::lock_guard<std::mutex> lk(mu); busy--; }
+    cv_idle.notify_all();
+  }
+}
+
+extern "C" {
+
+int itsx_twriter_open(const char *out_path, int compression, int trim_ccs, itsx_twriter **out)
+{
+  if (!out_path || !out) { g_trim_error = "null argument"; return ITSX_E_ARG; }
+  if (compression < 0 || compression > 2) { g_trim_error = "compression must be 0 (plain), 1 (gzip) or 2 (zstd)"; return ITSX_E_ARG; }
+  { itsx_io::PieceCompressor probe(compression); if (!probe.ok()) { g_trim_error = "zstd output requested but libzstd.so.1 could not be loaded"; return ITSX_E_IO; } }
+  itsx_twriter *w = new itsx_twriter;
+  w->path = out_path; w->kind = compression; w->ccs = trim_ccs != 0;
+  if (const char *e = getenv("ITSX_WRITE_UNIT_KB")) w->unit_bytes = std::max<size_t>(1, (size_t)atoll(e)) << 10;
+  w->fp = fopen(out_path, "wb");
+  if (!w->fp) { g_trim_error = std::string("cannot write ") + out_path; delete w; return ITSX_E_IO; }
+  setvbuf(w->fp, nullptr, _IOFBF, 1 << 20);
+  const int T = itsx_io::io_threads();
+  for (int t = 0; t < T; t++) w->workers.emplace_back([w] { w->work(); });
+  *out = w;
+  return ITSX_OK;
+}
+
+int itsx_twriter_text(itsx_twriter *w, const char *base, int64_t avail, int32_t last)
+{
+  if (!w || avail < 0 || (!base && avail > 0)) { g_trim_error = "itsx_twriter_text: bad argument"; return ITSX_E_ARG; }
+  std::lock_guard<std::mutex> lk(w->mu);
+  if (w->text_done || (w->base && base != w->base) || (size_t)avail < w->avail) { g_trim_error = "itsx_twriter_text: the text grows at one address, front to back"; return ITSX_E_ARG; }
+  w->base = base; w->avail = (size_t)avail; w->text_done = last != 0;
+  w->cut_units();
+  return ITSX_OK;
+}
+
+int itsx_twriter_coords(itsx_twriter *w, int64_t first_record, int64_t n, const int32_t *start, const int32_t *stop, const uint8_t *decided)
+{
+  if (!w || n < 0 || (n > 0 && (!start || !stop))) { g_trim_error = "itsx_twriter_coords: bad argument"; return ITSX_E_ARG; }
+  std::lock_guard<std::mutex> lk(w->mu);
+  if (first_record != (int64_t)w->start.size()) { g_trim_error = "itsx_twriter_coords: coordinates arrive in record order, without gaps"; return ITSX_E_ARG; }
+  w->start.append(start, (size_t)n, 0);
+  w->stop.append(stop, (size_t)n, 0);
+  w->decided.append(decided, (size_t)n, 1);
+  w->advance();
+  return ITSX_OK;
+}
+
+int itsx_twriter_update(itsx_twriter *w, const int64_t *records, int64_t m, const int32_t *start, const int32_t *stop)
+{
+  if (!w || m < 0 || (m > 0 && (!records || !start || !stop))) { g_trim_error = "itsx_twriter_update: bad argument"; return ITSX_E_ARG; }
+  std::lock_guard<std::mutex> lk(w->mu);
+  for (int64_t k = 0; k < m; k++) {
+    const int64_t r = records[k];
+    if (r < 0 || r >= (int64_t)w->start.size()) { g_trim_error = "itsx_twriter_update: record out of range"; return ITSX_E_ARG; }
+    if (w->decided[(size_t)r]) continue;
+    w->start[(size_t)r] = start[k]; w->stop[(size_t)r] = stop[k]; w->decided[(size_t)r] = 1;
+    // its unit: the one whose record range holds r (units know their ranges once counted)
+    size_t a = 0, b = w->counted_prefix;
+    while (a + 1 < b) { const size_t mid = (a + b) / 2; if (w->units[mid].first <= r) a = mid; else b = mid; }
+    // (a unit that has not been counted yet, or whose rows were not complete, will count its undecided rows itself, later)
+    if (a < w->counted_prefix && r >= w->units[a].first && r < w->units[a].first + w->units[a].count && w->units[a].undecided > 0) w->units[a].undecided--;
+  }
+  w->advance();
+  return ITSX_OK;
+}
+
+int itsx_twriter_close(itsx_twriter *w, int64_t *n_written, int64_t *total_len)
+{
+  if (!w) return ITSX_OK;
+  int rc = ITSX_OK;
+  {
+    std::unique_lock<std::mutex> lk(w->mu);
+    if (!w->text_done) { g_trim_error = "itsx_twriter_close: the text is not complete"; rc = ITSX_E_ARG; }
+    else {
+      // everything that can run does; then every unit must be done
+      w->cv_idle.wait(lk, [&] { return w->jobs.empty() && w->busy == 0; });
+      if (w->malformed) { g_trim_error = "malformed FASTQ record"; rc = ITSX_E_FORMAT; }
+      else if (w->records_cut > (int64_t)w->start.size() || w->counted_prefix < w->units.size()) { g_trim_error = "more records in the file than coordinates"; rc = ITSX_E_ARG; }
+      else if (w->next_write < w->units.size()) { g_trim_error = "itsx_twriter_close: records whose coordinates were never decided"; rc = ITSX_E_ARG; }
+    }
+    w->quit = true;
+  }
+  w->cv_work.notify_all();
+  for (auto &t : w->workers) t.join();
+  if (rc == ITSX_OK && !w->wrote_any && w->kind != 0) {          // an empty file is still one valid member / frame
+    itsx_io::PieceCompressor pc(w->kind);
+    std::string c;
+    if (!pc.run(std::string(), c) || fwrite(c.data(), 1, c.size(), w->fp) != c.size()) w->failed = true;
+  }
+  if (fflush(w->fp) != 0 || ferror(w->fp)) w->failed = true;
+  if (fclose(w->fp) != 0) w->failed = true;
+  if (rc == ITSX_OK && w->failed) { g_trim_error = "compressing or writing the output failed"; rc = ITSX_E_IO; }
+  if (n_written) *n_written = w->nw;
+  if (total_len) *total_len = w->tot;
+  delete w;
+  return rc;
 }
 
 int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const char *out1_path, const char *out2_path,

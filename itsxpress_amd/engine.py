@@ -334,6 +334,16 @@ class Engine:
         self._chk(self.L.itsx_lazy_pending_profiles(self.h, f.ctypes.data))
         return f[:self.n_profiles]
 
+    def lazy_pending_uniques(self):
+        """uint8[n_unique]: 1 where an undecided row could still change the representative's coordinates"""
+        f = np.zeros(max(1, self.n_unique), np.uint8)
+        self._chk(self.L.itsx_lazy_pending_uniques(self.h, f.ctypes.data))
+        return f[:self.n_unique]
+
+    def set_partial_coords(self, on=True):
+        """rep_coords / trim_coords answer although rows are undecided (the caller skips the flagged representatives)"""
+        self._chk(self.L.itsx_set_partial_coords(self.h, 1 if on else 0))
+
     def lazy_complete(self, flags):
         """count the flagged profiles' reported targets exactly (every pair of theirs is evaluated); then exchange / finalize again"""
         f = np.ascontiguousarray(flags, np.int32)

@@ -54,12 +54,129 @@ class _TextStream:
             raise EngineError(rc, self.L.itsx_stream_last_error().decode())
         return ptr.value or 0, nb.value, bool(last.value)
 
+    def records_bound(self):
+        return int(self.L.itsx_stream_records_bound(self.h)) if self.h else -1
+
     def close(self, keep=True):
         if self.h:
             h, self.h = self.h, None
             rc = self.L.itsx_stream_close(h, 1 if keep else 0)
             if rc != 0:
                 raise EngineError(rc, self.L.itsx_stream_last_error().decode())
+
+
+class _Output:
+    """The trimmed FASTQ written WHILE the chunks are scored (`StreamEngine.plan_output`): right after its own search a chunk is
+    finalized with PROVISIONAL bounds on hmmsearch's domZ -- the counts of the chunks so far below, those counts' upper bounds plus
+    the reads not yet seen above (the final counts lie in between, so a row both bounds decide alike stays decided) -- and every
+    read whose representative has no undecided row goes to the library's writer object at once (`itsx_twriter_*`: units of the
+    text sliced and deflated by a pool of threads, written in order).  The few that wait are named after the exact finalize."""
+
+    def __init__(self, L, plan):
+        self.L, self.plan = L, plan
+        self.w = C.c_void_p()
+        rc = L.itsx_twriter_open(os.fsencode(plan["out"]), plan["kind"], 1 if plan["ccs"] else 0, C.byref(self.w))
+        if rc != 0:
+            raise EngineError(rc, L.itsx_trim_last_error().decode())
+        self.g_start = np.full(1 << 20, -1, np.int32)
+        self.g_stop = np.full(1 << 20, -1, np.int32)
+        self.g_dec = np.ones(1 << 20, np.uint8)
+        self.base_ptr = None
+        self.reads_seen = 0
+        self.late = []                 # per chunk: (first record, indexes of its undecided reads, their global uniques)
+        self.n_late_uniques = 0
+        self.result = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(rc, self.L.itsx_trim_last_error().decode())
+
+    def _grow(self, n):
+        if n > self.g_start.shape[0]:
+            cap = max(n, 2 * self.g_start.shape[0])
+            for name, fill in (("g_start", -1), ("g_stop", -1), ("g_dec", 1)):
+                old = getattr(self, name)
+                new = np.full(cap, fill, old.dtype)
+                new[:old.shape[0]] = old
+                setattr(self, name, new)
+
+    def chunk(self, k, eng, st, z_cum, bound, domE):
+        """chunk k's search is done and every earlier chunk has been here: thresholds under provisional bounds, rows, reads"""
+        plan = self.plan
+        z = np.array(z_cum, np.int64)
+        half = z.shape[0] // 2
+        self.reads_seen += eng.n_reads
+        z[half:] += max(0, int(bound) - self.reads_seen)        # every read not yet seen may add one reported target to every profile
+        eng.set_partial_coords(True)
+        eng.set_domz(z)
+        eng.finalize(domE=domE)
+        U = eng.n_unique
+        gid, v = st["gid"], st["verdict"]
+        if U:
+            pend = eng.lazy_pending_uniques()
+            rows = eng.rep_coords(plan["left"], plan["right"])
+            mine = (v[:, 2] == k) & (v[:, 3] == np.arange(U))
+            self._grow(int(gid.max()) + 1)
+            gm = gid[mine]
+            self.g_start[gm] = rows[0][mine]
+            self.g_stop[gm] = rows[1][mine]
+            self.g_dec[gm] = pend[mine] == 0
+            self.n_late_uniques += int((pend[mine] != 0).sum())
+        uq = eng.get_derep()[2]
+        n = int(uq.shape[0])
+        if U:
+            g = gid[np.maximum(uq, 0)]
+            ok = uq >= 0
+            start = np.where(ok, self.g_start[g], -1).astype(np.int32)
+            stop = np.where(ok, self.g_stop[g], -1).astype(np.int32)
+            dec = np.where(ok, self.g_dec[g], 1).astype(np.uint8)
+        else:
+            g = np.zeros(n, np.int64)
+            start = np.full(n, -1, np.int32); stop = np.full(n, -1, np.int32); dec = np.ones(n, np.uint8)
+        self._chk(self.L.itsx_twriter_text(self.w, C.c_void_p(self.base_ptr), int(st["text_end"]), 1 if st["last"] else 0))
+        self._chk(self.L.itsx_twriter_coords(self.w, int(st["base"]), n, start.ctypes.data, stop.ctypes.data, dec.ctypes.data))
+        idx = np.flatnonzero(dec == 0)
+        if idx.shape[0]:
+            self.late.append((int(st["base"]), idx.astype(np.int64), g[idx]))
+
+    def settle(self, engs):
+        """after the exact finalize: the rows of the representatives that waited, then their reads"""
+        plan = self.plan
+        if self.n_late_uniques:
+            for k, (eng, st) in enumerate(engs):
+                U = eng.n_unique
+                if not U:
+                    continue
+                gid, v = st["gid"], st["verdict"]
+                mine = (v[:, 2] == k) & (v[:, 3] == np.arange(U))
+                waited = mine & (self.g_dec[gid] == 0)
+                if waited.any():
+                    rows = eng.rep_coords(plan["left"], plan["right"])
+                    gw = gid[waited]
+                    self.g_start[gw] = rows[0][waited]
+                    self.g_stop[gw] = rows[1][waited]
+        for base, idx, g in self.late:
+            recs = np.ascontiguousarray(base + idx, np.int64)
+            a, b = np.ascontiguousarray(self.g_start[g], np.int32), np.ascontiguousarray(self.g_stop[g], np.int32)
+            self._chk(self.L.itsx_twriter_update(self.w, recs.ctypes.data, int(recs.shape[0]), a.ctypes.data, b.ctypes.data))
+        self.late = []
+
+    def finish(self):
+        if self.result is None:
+            n, tot = C.c_int64(0), C.c_int64(0)
+            w, self.w = self.w, None
+            self._chk(self.L.itsx_twriter_close(w, C.byref(n), C.byref(tot)))
+            self.result = (n.value, tot.value)
+        return self.result
+
+    def abort(self):
+        if self.w:
+            w, self.w = self.w, None
+            self.L.itsx_twriter_close(w, None, None)
+            try:
+                os.remove(self.plan["out"])
+            except OSError:
+                pass
 
 
 class StreamEngine(ShardedOps):
@@ -88,6 +205,9 @@ class StreamEngine(ShardedOps):
         self._pmeta = None
         self._verdicts, self._bases, self._nloc = [], [], []
         self.timeline = []            # (chunk, seconds since the pipeline started when: text ready, loaded, searched)
+        self._plan = None             # plan_output(): the trimmed FASTQ is written while the chunks are scored
+        self._out = None
+        self._stream = None
 
     # -- plumbing: the handlers of multi.py's workers, called in process
     @property
@@ -111,9 +231,36 @@ class StreamEngine(ShardedOps):
         return [_HANDLERS[cmd](eng, st, *a) for (eng, st), a in jobs]
 
     def close(self):
+        if getattr(self, "_out", None) is not None:
+            self._out.abort()                             # (a finished output has no writer left: nothing happens to the file)
+            self._out = None
         for eng, _ in getattr(self, "_engs", []):
             eng.close()
         self._engs = []
+        if getattr(self, "_stream", None) is not None:
+            try:
+                self._stream.close(keep=True)
+            except Exception:
+                pass
+            self._stream = None
+
+    # -- the output inside the pipeline
+    def plan_output(self, outfile, left, right, gzipped=False, zstd_file=False, trim_ccs=False, domE=10.0):
+        """Say BEFORE search() where the trimmed reads go (profile-name prefixes of the region's two sides, as ItsPosition has
+        them): the writer then works on the chunks that are done while the GPU scores the next ones.  finalize(domE) must use the
+        same domE; finish_output() returns (records written, summed length) once finalize() has run."""
+        self._plan = {"out": outfile, "left": left, "right": right, "kind": 1 if gzipped else (2 if zstd_file else 0),
+                      "ccs": bool(trim_ccs), "domE": float(domE)}
+
+    def output_planned(self, outfile, left, right, gzipped=False, zstd_file=False, trim_ccs=False):
+        p = self._plan
+        return (self._out is not None and p is not None and p["out"] == outfile and p["left"] == left and p["right"] == right
+                and p["kind"] == (1 if gzipped else (2 if zstd_file else 0)) and p["ccs"] == bool(trim_ccs))
+
+    def finish_output(self):
+        if self._out is None or not self._final:
+            raise EngineError(-1, "finish_output: no planned output, or finalize() has not run")
+        return self._out.finish()
 
     def __del__(self):
         try:
@@ -202,7 +349,7 @@ class StreamEngine(ShardedOps):
             t2 = time.perf_counter()
             tup = _HANDLERS["derep"](eng, st, *self._derep_args)
             t3 = time.perf_counter()
-            verdict = self._assign(keyset, tup, k)
+            verdict, st["gid"] = self._assign(keyset, tup, k)
             _HANDLERS["verdict"](eng, st, verdict)
             t4 = time.perf_counter()
             st["load_s"] = {"context+profiles": round(t1 - t0, 3), "parse+upload": round(t2 - t1, 3), "derep+keys": round(t3 - t2, 3),
@@ -216,10 +363,11 @@ class StreamEngine(ShardedOps):
         U = int(tup.shape[0])
         verdict = np.zeros((max(U, 1), 4), np.int64)
         tup = np.ascontiguousarray(tup, np.int64)
-        rc = self.L.itsx_keyset_assign(keyset, tup.ctypes.data, U, int(k), verdict.ctypes.data)
+        gid = np.zeros(max(U, 1), np.int64)
+        rc = self.L.itsx_keyset_assign(keyset, tup.ctypes.data, U, int(k), verdict.ctypes.data, gid.ctypes.data)
         if rc != 0:
             raise EngineError(rc, self.L.itsx_stream_last_error().decode())
-        return verdict[:U]
+        return verdict[:U], gid[:U]
 
     def _pipeline(self, with_search):
         import time
@@ -228,32 +376,59 @@ class StreamEngine(ShardedOps):
         q = queue.Queue(maxsize=3)
         keyset = self.L.itsx_keyset_create()
         stop = threading.Event()
+        if with_search and self._plan is not None:
+            self._out = _Output(self.L, self._plan)
+        fin_q, fin_err = queue.Queue(), []
+
+        def finisher():
+            # chunk k is finalized provisionally and handed to the writer as soon as the file's record count is known (the
+            # inflater is done: a few seconds in) -- on its own thread, beside the search of the next chunk
+            backlog = []
+            try:
+                while True:
+                    item = fin_q.get()
+                    if item is not None:
+                        backlog.append(item)
+                    bound = self._stream.records_bound() if self._stream is not None else -1
+                    if bound >= 0 or item is None:
+                        for k, zc in backlog:
+                            self._out.chunk(k, self._engs[k][0], self._engs[k][1], zc, bound, self._plan["domE"])
+                        backlog = []
+                    if item is None:
+                        break
+            except BaseException as e:                   # noqa: reported by the consumer
+                fin_err.append(e)
+
+        fin = None
+        if self._out is not None:
+            fin = threading.Thread(target=finisher, name="itsx-stream-writer", daemon=True)
+            fin.start()
 
         def loader():
             stream = None
             try:
                 stream = _TextStream(self._path)
+                self._stream = stream                    # (kept until the engine is closed: the writer reads the text)
                 want = self._chunk_bytes()
-                base, k = 0, 0
+                base, k, ptr0 = 0, 0, None
                 while not stop.is_set():
-                    ptr, nb, last = stream.next(want)
+                    ptr, nb, last = stream.next(want)    # last: the inflater is done and every member's CRC-32 and length agreed
                     t_text = time.perf_counter()
+                    if ptr0 is None:
+                        ptr0 = ptr
+                        if self._out is not None:
+                            self._out.base_ptr = ptr0
                     if nb > 0 or (last and k == 0):
                         eng, st, t_loaded = self._new_chunk(ptr, nb, base, k, keyset)
+                        st["text_end"], st["last"] = ptr + nb - ptr0, bool(last)
                         q.put((eng, st, t_text - t0, t_loaded - t0))
                         base += eng.n_reads
                         k += 1
                     if last:
                         break
-                stream.close(keep=True)                  # joins the inflater: a corrupt file is reported here at the latest
                 stream = None
                 q.put(None)
             except BaseException as e:                   # noqa: handed to the consumer
-                if stream is not None:
-                    try:
-                        stream.close(keep=False)
-                    except Exception:
-                        pass
                 q.put(e)
 
         th = threading.Thread(target=loader, name="itsx-stream-loader", daemon=True)
@@ -273,6 +448,8 @@ class StreamEngine(ShardedOps):
                 self._engs.append((eng, st))
                 if with_search:
                     zs.append(_HANDLERS["search"](eng, st, self._mode, *self._search_args))
+                    if fin is not None:
+                        fin_q.put((len(self._engs) - 1, np.sum(zs, axis=0)))
                 self.timeline.append((len(self._engs) - 1, round(t_text, 3), round(t_loaded, 3), round(time.perf_counter() - t0, 3)))
         except BaseException as e:                       # noqa
             err = e
@@ -287,6 +464,11 @@ class StreamEngine(ShardedOps):
                     pass
             th.join()
             self.L.itsx_keyset_destroy(keyset)
+            if fin is not None:
+                fin_q.put(None)
+                fin.join()
+                if err is None and fin_err:
+                    err = fin_err[0]
         if err is not None:
             self.close()
             raise err
@@ -308,7 +490,8 @@ class StreamEngine(ShardedOps):
         try:
             for k, (eng, st) in enumerate(self._engs):
                 tup = _HANDLERS["derep"](eng, st, *self._derep_args)
-                _HANDLERS["verdict"](eng, st, self._assign(keyset, tup, k))
+                verdict, st["gid"] = self._assign(keyset, tup, k)
+                _HANDLERS["verdict"](eng, st, verdict)
         finally:
             self.L.itsx_keyset_destroy(keyset)
         self._verdicts = [st["verdict"] for _, st in self._engs]
@@ -337,6 +520,14 @@ class StreamEngine(ShardedOps):
             self._derep = None
             self._final = False
         self._n_unique = int(self._seeds.shape[0])
+
+    def finalize(self, domE=10.0):
+        if self._out is not None and float(domE) != self._plan["domE"]:
+            self._out.abort()                             # planned with another threshold: what was written is void, the caller writes afresh
+            self._out = None
+        super().finalize(domE)
+        if self._out is not None:
+            self._out.settle(self._engs)
 
     # -- a3 / a4
     def search(self, T=10.0, F1=1e-6, F2=1e-6, F3=1e-6):

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--shape", default="cfg1", choices=["cfg1", "cfg2"], help="cfg1: 300-base reads; cfg2: merged reads of 300-580 bases")
     ap.add_argument("--stream", action="store_true", help="file-order chunks scored while the file is inflated (itsxpress_amd/stream.py)")
     ap.add_argument("--chunk-mb", type=float, default=0.0, help="--stream: text per chunk (0: about a tenth of the file)")
+    ap.add_argument("--stream-write", action="store_true", help="--stream: the writer inside the pipeline too (provisional thresholds per chunk)")
     ap.add_argument("--check", action="store_true", help="--stream: compare the coordinates with one context on the whole file")
     args = ap.parse_args()
     import synth
@@ -73,6 +74,9 @@ def main():
             t0 = time.perf_counter()
             se = StreamEngine(0, chunk_mb=args.chunk_mb or None)
             se.set_rows_mode(args.rows)
+            out = os.path.join(tmp, "trimmed.fastq" + {"gz": ".gz", "zst": ".zst", "plain": ""}[args.out_kind])
+            if args.stream_write:
+                se.plan_output(out, "3_", "4_", gzipped=args.out_kind == "gz", zstd_file=args.out_kind == "zst")
             se.load_reads_file(fq)
             se.derep()
             se.load_profiles(text=its2_profiles(thmm))
@@ -85,6 +89,11 @@ def main():
             nu = se.n_unique
             start, stop, tlen, ind = se.trim_coords("3_", "4_")
             t["coords"] = time.perf_counter() - t0
+            if args.stream_write:
+                t0 = time.perf_counter()
+                sw = se.finish_output()
+                t["write (the part left after the pipeline)"] = time.perf_counter() - t0
+                extra_w = {"late_uniques": se._out.n_late_uniques}
             extra = {"stream_chunks": se.world, "stream_timeline_s(chunk, text ready, loaded, searched)": se.timeline,
                      "chunk_load_s": [st.get("load_s") for _, st in se._engs]}
             if args.check:                              # the same file through one context: identical coordinates
@@ -107,9 +116,18 @@ def main():
             start, stop, tlen, ind = eng.trim_coords("3_", "4_")
             t["path"] = time.perf_counter() - t0
         out = os.path.join(tmp, "trimmed.fastq" + {"gz": ".gz", "zst": ".zst", "plain": ""}[args.out_kind])
-        t0 = time.perf_counter()
-        nw, tot = write_trimmed_fastq(fq, out, start, stop, gzipped=args.out_kind == "gz", zstd_file=args.out_kind == "zst")
-        t["write"] = time.perf_counter() - t0
+        if args.stream and args.stream_write:
+            nw, tot = sw
+            extra["representatives_that_waited_for_the_exact_thresholds"] = extra_w["late_uniques"]
+            if args.check:                              # the one-go writer on the same coordinates: the same bytes
+                ref_out = out + ".ref"
+                assert write_trimmed_fastq(fq, ref_out, start, stop, gzipped=args.out_kind == "gz", zstd_file=args.out_kind == "zst") == (nw, tot)
+                extra["output_bytes_equal_one_go_writer"] = open(ref_out, "rb").read() == open(out, "rb").read()
+                assert extra["output_bytes_equal_one_go_writer"]
+        else:
+            t0 = time.perf_counter()
+            nw, tot = write_trimmed_fastq(fq, out, start, stop, gzipped=args.out_kind == "gz", zstd_file=args.out_kind == "zst")
+            t["write"] = time.perf_counter() - t0
         total = sum(t.values())
         # the output holds exactly the kept reads, sliced: check a sample against the coordinates
         kept = np.flatnonzero((start >= 0) & (stop >= 0) & (start < stop))

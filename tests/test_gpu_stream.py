@@ -23,11 +23,19 @@ def _its2(tmp, t_hmm_text):
     return p
 
 
-def _fastq_gz(path, t_hmm_text, n, seed):
-    """duplicates all over the file (also reverse-complemented copies of earlier reads: rc_rate), qualities that start with '@'"""
+def _fastq_gz(path, t_hmm_text, n, seed, damage=0.0):
+    """duplicates all over the file (also reverse-complemented copies of earlier reads: rc_rate), qualities that start with '@';
+    damage: that share of the reads gets 30-42 % of its bases replaced (rows near the thresholds)"""
     blob, offs = synth.make_reads(t_hmm_text, n, config=3, seed=seed, fixed_len=0, len_range=(300, 520), rc_rate=0.2)
     seqs = synth.to_strings(blob, offs)
     rng = np.random.default_rng(seed)
+    if damage > 0:
+        for i in range(len(seqs)):
+            if rng.random() < damage:
+                s = list(seqs[i])
+                for q in rng.choice(len(s), int(len(s) * rng.uniform(0.3, 0.42)), replace=False):
+                    s[q] = "ACGT"[int(rng.integers(0, 4))]
+                seqs[i] = "".join(s)
     with gzip.open(path, "wb", compresslevel=6) as f:
         for i, s in enumerate(seqs):
             q = (rng.integers(2, 41, len(s)) + 33).astype(np.uint8)
@@ -133,3 +141,49 @@ def test_corrupt_gzip_is_an_error_not_a_result(tmp_path, t_hmm_text, monkeypatch
     from itsxpress_amd import EngineError
     with pytest.raises(EngineError):
         _run(bad, os.path.join(tmp, "bad"), hmm, True, True, monkeypatch)
+
+
+def test_writer_inside_the_pipeline_writes_the_same_bytes(tmp_path, t_hmm_text, monkeypatch):
+    """SeqSample.plan_output before deduplicate(): chunks are finalized with provisional domZ bounds right after their own search
+    and their reads deflated while later chunks are scored; the reads of representatives with an undecided row wait for the exact
+    thresholds.  The file is byte for byte what the writer produces in one go after everything else -- also when MANY rows are
+    undecided at first (ITSX_LAZY_ZUB_SCALE widens the bounds)."""
+    tmp = str(tmp_path)
+    hmm = _its2(tmp, t_hmm_text)
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "32")
+    monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "1.5")
+    monkeypatch.setenv("ITSX_WRITE_UNIT_KB", "256")
+    from itsxpress_amd.stream import StreamEngine
+    for name, scale in (("plain", None), ("wide", "20000")):
+        fq = os.path.join(tmp, name + ".fq.gz")
+        _fastq_gz(fq, t_hmm_text, 12000, 616, damage=0.6 if scale else 0.0)
+        if scale:
+            monkeypatch.setenv("ITSX_LAZY_ZUB_SCALE", scale)
+        _, ref_bytes, c_ref, _, _ = _run(fq, os.path.join(tmp, "one_" + name), hmm, False, True, monkeypatch)
+        d = os.path.join(tmp, name)
+        os.makedirs(d, exist_ok=True)
+        monkeypatch.setenv("ITSXPRESS_GPUS", "1"); monkeypatch.setenv("ITSXPRESS_STREAM", "1"); monkeypatch.setenv("ITSXPRESS_ARRAYS", "1")
+        from itsxpress_amd import trim
+        trim.cache_clear()
+        sobj = S.SeqSampleNotPaired(fastq=fq, tempdir=d)
+        _OPEN.append(sobj)
+        out = os.path.join(d, "trimmed.fq.gz")
+        sobj.plan_output(out, "ITS2", gzipped=True)
+        sobj.deduplicate(threads=1)
+        sobj._search(hmmfile=hmm, threads=1)
+        eng = sobj._engine
+        assert isinstance(eng, StreamEngine) and eng.world >= 4 and eng._out is not None
+        # the writer has been at work during the pipeline: the file exists before anybody asked for it
+        assert os.path.exists(out)
+        its_pos = S.ItsPosition(domtable=sobj.dom_file, region="ITS2")
+        dd = S.Dedup(uc_file=sobj.uc_file, rep_file=sobj.rep_file, seq_file=sobj.seq_file, fastq=sobj.r1, fastq2=sobj.fastq2)
+        dd.create_trimmed_seqs(out, gzipped=True, zstd_file=False, itspos=its_pos, wri_file=True, tempdir=d)
+        assert open(out, "rb").read() == ref_bytes, name
+        assert all(np.array_equal(x, y) for x, y in zip(c_ref, sobj.trim_coordinates("ITS2")))
+        if scale:
+            assert eng._out.n_late_uniques > 0, "the wide bounds were meant to leave rows undecided at first"
+            monkeypatch.delenv("ITSX_LAZY_ZUB_SCALE")
+        # another output path than the planned one: written the ordinary way
+        other = os.path.join(d, "other.fq.gz")
+        dd.create_trimmed_seqs(other, gzipped=True, zstd_file=False, itspos=its_pos, wri_file=True, tempdir=d)
+        assert open(other, "rb").read() == ref_bytes

@@ -77,8 +77,8 @@ def test_reader_takes_plain_gzip_multimember_and_zstd(sample):
     assert read_text(str(empty)) == b"" and read_fastx(str(empty)) == ([], [])
 
 
-@pytest.mark.parametrize("env", [{"ITSX_IO_BLOCK_KB": "16", "ITSX_IO_THREADS": "5"},
-                                 {"ITSX_IO_BLOCK_KB": "16", "ITSX_IO_THREADS": "3", "ITSX_IO_LIBDEFLATE": "0"},
+@pytest.mark.parametrize("env", [{"ITSX_IO_BLOCK_KB": "16", "ITSX_WRITE_UNIT_KB": "24", "ITSX_IO_THREADS": "5"},
+                                 {"ITSX_IO_BLOCK_KB": "16", "ITSX_WRITE_UNIT_KB": "24", "ITSX_IO_THREADS": "3", "ITSX_IO_LIBDEFLATE": "0"},
                                  {"ITSX_IO_THREADS": "1"}])
 def test_block_parallel_output_is_one_stream_to_any_reader(sample, env):
     """Many small blocks, several threads, both deflate implementations: Python's gzip / zlib must read back exactly
@@ -113,7 +113,7 @@ print(members, _lib.lib().itsx_io_codecs(), a[0])
     members, flags, nrec = map(int, r.stdout.split())
     assert open(str(d / "o.fq")).read() == _expected(text, start, stop) and nrec > 2000
     if "ITSX_IO_BLOCK_KB" in env:
-        assert members > 20                    # ~1 MB of output in 16 KB blocks
+        assert members > 20                    # ~1 MB of output, one member per 24 KB of input
     else:
         assert members == 1
     if env.get("ITSX_IO_LIBDEFLATE") == "0":
@@ -408,12 +408,13 @@ def test_keyset_first_holder_wins():
             tup[:, 2] = base + np.arange(len(pick)) * 3
             tup[:, 3] = rng.integers(0, 2, len(pick))
             out = np.zeros_like(tup)
-            assert L.itsx_keyset_assign(ks, tup.ctypes.data, len(pick), chunk, out.ctypes.data) == 0
+            gid = np.full(len(pick), -1, np.int64)
+            assert L.itsx_keyset_assign(ks, tup.ctypes.data, len(pick), chunk, out.ctypes.data, gid.ctypes.data) == 0
             for u, k in enumerate(pick):
-                want = seen.setdefault(int(k), (int(tup[u, 2]), int(tup[u, 3]), chunk, u))
-                assert tuple(int(x) for x in out[u]) == want
+                want = seen.setdefault(int(k), (int(tup[u, 2]), int(tup[u, 3]), chunk, u, len(seen)))
+                assert tuple(int(x) for x in out[u]) + (int(gid[u]),) == want          # gid: first-seen order
             base += 100000
         assert L.itsx_keyset_size(ks) == len(seen)
-        assert L.itsx_keyset_assign(ks, None, 0, 9, None) == 0
+        assert L.itsx_keyset_assign(ks, None, 0, 9, None, None) == 0
     finally:
         L.itsx_keyset_destroy(ks)

@@ -169,8 +169,9 @@ def test_paired_writer_keeps_the_references_suffix_rule(tmp_path):
 
 
 def test_parallel_record_walk_writes_the_same_bytes(tmp_path, monkeypatch):
-    """large inputs are sliced by a pool of threads over ranges cut at record starts (quality lines that start with '@' included);
-    the output -- plain and gzip, with and without CCS stitching -- is byte for byte the serial walk's"""
+    """the writer object cuts the text into units at record starts (quality lines that start with '@' included) that a pool of
+    threads slices and deflates; the output -- plain, with and without CCS stitching -- is byte for byte the serial walk's, the
+    gzip file its content in one member per unit"""
     import numpy as np
     from itsxpress_amd.trim import write_trimmed_fastq
     rng = np.random.default_rng(3)
@@ -185,7 +186,7 @@ def test_parallel_record_walk_writes_the_same_bytes(tmp_path, monkeypatch):
     start = rng.integers(-1, 120, n).astype(np.int32)
     stop = rng.integers(-1, 500, n).astype(np.int32)
     out = {}
-    for mode, env in (("serial", {"ITSX_WRITE_MIN_MB": "100000"}), ("parallel", {"ITSX_WRITE_MIN_MB": "0", "ITSX_WRITE_RANGE_KB": "16", "ITSX_IO_THREADS": "5"})):
+    for mode, env in (("serial", {"ITSX_WRITE_MIN_MB": "100000"}), ("parallel", {"ITSX_WRITE_MIN_MB": "0", "ITSX_WRITE_UNIT_KB": "16", "ITSX_IO_THREADS": "5"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for kind, kw in (("plain", {}), ("gz", {"gzipped": True}), ("ccs", {"trim_ccs": True})):
@@ -193,8 +194,11 @@ def test_parallel_record_walk_writes_the_same_bytes(tmp_path, monkeypatch):
             out[(mode, kind)] = (write_trimmed_fastq(str(fq), str(o), start, stop, **kw), open(o, "rb").read())
         for k in env:
             monkeypatch.delenv(k)
-    for kind in ("plain", "gz", "ccs"):
+    for kind in ("plain", "ccs"):
         assert out[("serial", kind)] == out[("parallel", kind)], kind
+    assert out[("serial", "gz")][0] == out[("parallel", "gz")][0]
+    assert gzip.decompress(out[("serial", "gz")][1]) == gzip.decompress(out[("parallel", "gz")][1]) == out[("serial", "plain")][1]
+    assert out[("parallel", "gz")][1].count(b"\x1f\x8b\x08") > 20 >= out[("serial", "gz")][1].count(b"\x1f\x8b\x08")
     assert out[("serial", "plain")][0][0] > 1000
     # a malformed record is still named by its number
     bad = tmp_path / "bad.fq"
@@ -202,8 +206,72 @@ def test_parallel_record_walk_writes_the_same_bytes(tmp_path, monkeypatch):
         f.write(open(fq).read())
         f.write("@broken\nACGT\n+\nII\n")
     monkeypatch.setenv("ITSX_WRITE_MIN_MB", "0")
-    monkeypatch.setenv("ITSX_WRITE_RANGE_KB", "16")
+    monkeypatch.setenv("ITSX_WRITE_UNIT_KB", "16")
     from itsxpress_amd import EngineError
     with pytest.raises(EngineError) as e:
         write_trimmed_fastq(str(bad), str(tmp_path / "x.out"), np.zeros(n + 1, np.int32), np.full(n + 1, 10, np.int32))
     assert "malformed FASTQ record %d" % n in str(e.value)
+
+
+def test_writer_object_fed_piece_by_piece_writes_the_same_file(tmp_path, monkeypatch):
+    """itsx_twriter_*: text and coordinates in pieces, in any rhythm, with records whose coordinates are decided late (they hold
+    back their own unit only): the file is byte for byte what itsx_write_trimmed_fastq writes in one go"""
+    import ctypes as C
+    from itsxpress_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(8)
+    n = 9000
+    recs = []
+    for i in range(n):
+        ln = int(rng.integers(30, 380))
+        q = "".join(rng.choice(list("@+IF#5"), ln))
+        recs.append("@r%d w\n%s\n+\n%s\n" % (i, "".join(rng.choice(list("ACGT"), ln)), q))
+    text = "".join(recs).encode()
+    fq = tmp_path / "in.fq"
+    fq.write_bytes(text)
+    start = rng.integers(-1, 100, n).astype(np.int32)
+    stop = rng.integers(-1, 420, n).astype(np.int32)
+    monkeypatch.setenv("ITSX_WRITE_UNIT_KB", "64")
+    monkeypatch.setenv("ITSX_IO_THREADS", "4")
+    ends = np.cumsum([len(r) for r in recs])
+    for kind, comp in (("gz", 1), ("plain", 0), ("zst", 2)):
+        if comp == 2 and not (L.itsx_io_codecs() & 2):
+            continue
+        ref = tmp_path / ("ref." + kind)
+        want = write_trimmed_fastq(str(fq), str(ref), start, stop, gzipped=comp == 1, zstd_file=comp == 2)
+        for trial in range(3):
+            out = tmp_path / ("piecewise%d.%s" % (trial, kind))
+            w = C.c_void_p()
+            assert L.itsx_twriter_open(os.fsencode(str(out)), comp, 0, C.byref(w)) == 0
+            buf = C.create_string_buffer(text, len(text))
+            base = C.addressof(buf)
+            late = rng.random(n) < (0.0, 0.002, 0.05)[trial]                    # undecided when their piece arrives
+            wrong = np.where(late, 7, start).astype(np.int32)                   # (whatever stands there must not be used)
+            cuts = sorted(set(int(x) for x in rng.integers(1, n, 5))) + [n]
+            lo = 0
+            for k, hi in enumerate(cuts):                                       # text up to record hi, then rows lo..hi (or the other way round)
+                a1, a2, a3 = np.ascontiguousarray(wrong[lo:hi]), np.ascontiguousarray(stop[lo:hi]), (~late[lo:hi]).astype(np.uint8)
+                steps = [lambda: L.itsx_twriter_text(w, base, int(ends[hi - 1]), 1 if hi == n else 0),
+                         lambda: L.itsx_twriter_coords(w, lo, hi - lo, a1.ctypes.data, a2.ctypes.data, a3.ctypes.data)]
+                for f in (steps if (k + trial) % 2 else steps[::-1]):
+                    assert f() == 0, L.itsx_trim_last_error()
+                lo = hi
+            idx = np.flatnonzero(late).astype(np.int64)
+            if trial == 2:                                                      # close before the late rows are named: refused, nothing hangs
+                nw, tot = C.c_int64(), C.c_int64()
+                assert L.itsx_twriter_close(w, C.byref(nw), C.byref(tot)) == -1
+                assert b"never decided" in L.itsx_trim_last_error()
+                continue
+            for part in np.array_split(idx, 3):
+                s1, s2 = np.ascontiguousarray(start[part]), np.ascontiguousarray(stop[part])
+                assert L.itsx_twriter_update(w, part.ctypes.data, len(part), s1.ctypes.data, s2.ctypes.data) == 0
+            nw, tot = C.c_int64(), C.c_int64()
+            assert L.itsx_twriter_close(w, C.byref(nw), C.byref(tot)) == 0, L.itsx_trim_last_error()
+            assert (nw.value, tot.value) == tuple(want)
+            assert out.read_bytes() == ref.read_bytes(), (kind, trial)
+    # coordinates out of order are refused
+    w = C.c_void_p()
+    assert L.itsx_twriter_open(os.fsencode(str(tmp_path / "x")), 0, 0, C.byref(w)) == 0
+    assert L.itsx_twriter_coords(w, 5, 1, start.ctypes.data, stop.ctypes.data, None) == -1
+    L.itsx_twriter_text(w, None, 0, 1)
+    assert L.itsx_twriter_close(w, None, None) == 0

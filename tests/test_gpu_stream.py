@@ -187,3 +187,40 @@ def test_writer_inside_the_pipeline_writes_the_same_bytes(tmp_path, t_hmm_text, 
         other = os.path.join(d, "other.fq.gz")
         dd.create_trimmed_seqs(other, gzipped=True, zstd_file=False, itspos=its_pos, wri_file=True, tempdir=d)
         assert open(other, "rb").read() == ref_bytes
+
+
+def test_paired_end_through_the_streaming_engine(tmp_path, t_hmm_text, monkeypatch):
+    """the reference's paired fixture: merge (one plain engine does it), then the merged file -- its text is in the cache, the
+    stream cuts it from there -- dereplicated and scored in chunks; R1 / R2 trimmed with the merged reads' coordinates.  Same
+    files as without ITSXPRESS_STREAM."""
+    tmp = str(tmp_path)
+    hmm = _its2(tmp, t_hmm_text)
+    raw = []
+    for fn in ("4774-1-MSITS3_R1.fastq", "4774-1-MSITS3_R2.fastq"):
+        p = os.path.join(tmp, fn)
+        with gzip.open(os.path.join(GOLD, fn + ".gz"), "rb") as f, open(p, "wb") as g:
+            g.write(f.read())
+        raw.append(p)
+    monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "0.02")           # the merged file is ~100 KB: a handful of chunks
+    outs = {}
+    for name, stream in (("one", False), ("stream", True)):
+        d = os.path.join(tmp, name)
+        os.makedirs(d, exist_ok=True)
+        monkeypatch.setenv("ITSXPRESS_GPUS", "1")
+        monkeypatch.setenv("ITSXPRESS_STREAM", "1" if stream else "0")
+        monkeypatch.setenv("ITSXPRESS_ARRAYS", "1")
+        sobj = S.SeqSamplePairedNotInterleaved(fastq=raw[0], tempdir=d, fastq2=raw[1])
+        _OPEN.append(sobj)
+        sobj._merge_reads(threads=1)
+        sobj.deduplicate(threads=1)
+        sobj._search(hmmfile=hmm, threads=1)
+        its_pos = S.ItsPosition(domtable=sobj.dom_file, region="ITS2")
+        dd = S.Dedup(uc_file=sobj.uc_file, rep_file=sobj.rep_file, seq_file=sobj.seq_file, fastq=sobj.r1, fastq2=sobj.fastq2)
+        o1, o2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
+        dd.create_paired_trimmed_seqs(o1, o2, gzipped=False, zstd_file=False, itspos=its_pos, wri_file=True)
+        outs[name] = (open(o1, "rb").read(), open(o2, "rb").read(), [np.asarray(c).copy() for c in sobj.trim_coordinates("ITS2")])
+        if stream:
+            from itsxpress_amd.stream import StreamEngine
+            assert isinstance(sobj._engine, StreamEngine) and sobj._engine.world >= 3, sobj._engine.world
+    assert outs["one"][0] == outs["stream"][0] and outs["one"][1] == outs["stream"][1] and len(outs["one"][0]) > 1000
+    assert all(np.array_equal(x, y) for x, y in zip(outs["one"][2], outs["stream"][2]))

@@ -450,16 +450,33 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
 #ifdef ITSX_CL_PROF
         if (wv == 0) CLK(4)
 #endif
+        // ---- the counts leave their bit planes.  Plane by plane that is 3 operations x 11 planes for every strand with a count;
+        // instead the planes are first gathered four at a time into NIBBLES: for the strands whose bit index is k mod 4, nibble j of
+        // n[g][k] holds planes 4g .. 4g+3 of strand bit 4j + k, so a strand's count is three bit-field extracts.  The upper planes
+        // (counts of 16 and more, of 256 and more) are skipped where no lane of the wave has any.
         uint32_t any = ones | twos | fours;
+        uint32_t anyB = hc[1] | hc[2] | hc[3] | hc[4], anyC = hc[5] | hc[6] | hc[7];
 #pragma unroll
         for (int b = 0; b < CL_HVL; b++) any |= hc[b];
+        const bool useB = __ballot(anyB != 0u) != 0ull, useC = __ballot(anyC != 0u) != 0ull;
         uint32_t *hl = hist + (wv * 64 + lane);                // slot of (strand 32 g + bit) = 256 bit + g: the wave's lanes are neighbours
-        while (any) {
-          const int bit = __ffs(any) - 1; any &= any - 1;
-          uint32_t v = ((ones >> bit) & 1u) | (((twos >> bit) & 1u) << 1) | (((fours >> bit) & 1u) << 2);
+        constexpr uint32_t M = 0x11111111u;
 #pragma unroll
-          for (int b = 0; b < CL_HVL; b++) v |= ((hc[b] >> bit) & 1u) << (3 + b);
-          atomicAdd(&hl[bit << 8], v);                         // (no value comes back: nothing to wait for; the slot is this lane's own)
+        for (int k = 0; k < 4; k++) {
+          uint32_t left = any & (M << k);
+          if (__ballot(left != 0u) == 0ull) continue;
+          const uint32_t nA = ((ones >> k) & M) | (((twos >> k) & M) << 1) | (((fours >> k) & M) << 2) | (((hc[0] >> k) & M) << 3);
+          uint32_t nB = 0u, nC = 0u;
+          if (useB) nB = ((hc[1] >> k) & M) | (((hc[2] >> k) & M) << 1) | (((hc[3] >> k) & M) << 2) | (((hc[4] >> k) & M) << 3);
+          if (useC) nC = ((hc[5] >> k) & M) | (((hc[6] >> k) & M) << 1) | (((hc[7] >> k) & M) << 2);
+          while (left) {
+            const int bit = __ffs(left) - 1; left &= left - 1;
+            const int sh = bit - k;                            // a multiple of 4
+            uint32_t v = (nA >> sh) & 15u;
+            if (useB) v |= ((nB >> sh) & 15u) << 4;
+            if (useC) v |= ((nC >> sh) & 15u) << 8;
+            atomicAdd(&hl[bit << 8], v);                       // (no value comes back: nothing to wait for; the slot is this lane's own)
+          }
         }
       }
       __syncthreads();

@@ -314,14 +314,16 @@ __device__ __forceinline__ void cl_add8(uint32_t *hist, uint4 v, uint32_t r)
   atomicAdd(reinterpret_cast<uint32_t *>(h + (z & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (z >> 16)), 1u);
   atomicAdd(reinterpret_cast<uint32_t *>(h + (w & 0xffffu)), 1u); atomicAdd(reinterpret_cast<uint32_t *>(h + (w >> 16)), 1u);
 }
-#define CSA(h, l, x, y, z) { const uint32_t u_ = (x) ^ (y); h = ((x) & (y)) | (u_ & (z)); l = u_ ^ (z); }
+// a full adder over 32 strands at once is TWO instructions on gfx950: v_bitop3_b32 with the majority (0xE8) and the parity (0x96) tables
+// (written with the bit operators the compiler shared x ^ y between the two and spent three or more)
+#define CSA(h, l, x, y, z) { const uint32_t x_ = (x), y_ = (y), z_ = (z); h = __builtin_amdgcn_bitop3_b32(x_, y_, z_, 0xE8); l = __builtin_amdgcn_bitop3_b32(x_, y_, z_, 0x96); }
 static constexpr int CL_HVL = 8;                               // bit-sliced levels above 4: counts of up to 1024 conserved words per batch
 static constexpr int CL_WBATCH = 1024;                         // words of a centroid taken at a time (a read has rarely more)
 __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int c1, int mode)
 {
   __shared__ uint32_t hist[CL_QS_MAX + 8];
   __shared__ uint32_t items[CL_ITEMS];
-  __shared__ uint16_t hv[CL_WBATCH];
+  __shared__ __attribute__((aligned(16))) uint16_t hv[CL_WBATCH];
   __shared__ int n_items, n_hv;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nqs = 2 * a.nq;
@@ -394,7 +396,10 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
       // carry-save counting over the batch's bitmaps, then the counts go into the lane's own 32 histogram slots (no atomics)
       const int nh = n_hv;
       if (nh > 0 && wv * 2048 < nqs) {
-        const uint32_t *bm = a.qi_bm + wv * 64 + lane;
+        // (a bitmap's address = a wave-uniform base + this lane's dword: the load takes the base from scalar registers and the
+        // lane's offset as it is, no address arithmetic per load)
+        const uint32_t loff = (uint32_t)(wv * 64 + lane);
+        const uint32_t *bmb = a.qi_bm;
         uint32_t ones = 0, twos = 0, fours = 0, hc[CL_HVL];
 #pragma unroll
         for (int b = 0; b < CL_HVL; b++) hc[b] = 0;
@@ -426,21 +431,23 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
 #pragma unroll
           for (int b = 2; b < CL_HVL; b++) { const uint32_t t_ = hc[b] & carry; hc[b] ^= carry; carry = t_; }
         };
-        // the bitmaps come from L2 at about a microsecond a round trip: 32 loads are in flight before the first is used
+        // the bitmaps come from L2 at about a microsecond a round trip: 32 loads are in flight before the first is used.  (This
+        // phase WAITS: with the adders at two instructions each and, as an experiment, the loads written out with scalar bases
+        // -- 207 -> 94 vector instructions per 32 words -- a 6 M-read run took as long as before, 39.3 vs 38.8 s.)
         for (; i + 32 <= nh; i += 32) {
           uint32_t x[32];
 #pragma unroll
-          for (int t = 0; t < 32; t++) x[t] = bm[(size_t)hv[i + t] * (CL_QS_MAX / 32)];
+          for (int t = 0; t < 32; t++) x[t] = (bmb + (size_t)hv[i + t] * (CL_QS_MAX / 32))[loff];
           add32(x);
         }
         for (; i + 8 <= nh; i += 8) {
           uint32_t x[8];
 #pragma unroll
-          for (int t = 0; t < 8; t++) x[t] = bm[(size_t)hv[i + t] * (CL_QS_MAX / 32)];
+          for (int t = 0; t < 8; t++) x[t] = (bmb + (size_t)hv[i + t] * (CL_QS_MAX / 32))[loff];
           add8(x);
         }
         for (; i < nh; i++) {
-          uint32_t carry = bm[(size_t)hv[i] * (CL_QS_MAX / 32)], t_;
+          uint32_t carry = (bmb + (size_t)hv[i] * (CL_QS_MAX / 32))[loff], t_;
           t_ = ones & carry; ones ^= carry; carry = t_;
           t_ = twos & carry; twos ^= carry; carry = t_;
           t_ = fours & carry; fours ^= carry; carry = t_;

@@ -347,8 +347,10 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
     const int n = a.cw_n[c];
     if (n == 0) continue;                                     // a rolled-back column
     const uint16_t *cw = a.cw_pool + a.cw_off[c];
-    for (int w0 = 0; w0 < n; w0 += CL_WBATCH) {               // (one batch, unless the read has more than 2048 distinct words)
-      const int nb = n - w0 < CL_WBATCH ? n - w0 : CL_WBATCH;
+    uint4 T4[8];                                              // the thread's 32 thresholds of this turn (requested below, used by the scan)
+    // one batch, unless the read has more than 1024 distinct words; the LAST batch is straight-line code of its own, so that the
+    // thresholds it requests are not live around a loop (they would sit beside the bitmap phase's 32 loads: spills)
+    auto batch = [&](const int w0, const int nb, auto last_batch) {
       if (tid == 0) { n_items = 0; n_hv = 0; }
       __syncthreads();
       // ---- the batch's words: conserved ones to the bitmap list, the others' lists cut into pieces of <= 64 entries
@@ -395,14 +397,15 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
       // ---- conserved words: wave wv owns strands 2048 wv .. + 2047, a lane one dword (32 strands) of every bitmap; bit-sliced
       // carry-save counting over the batch's bitmaps, then the counts go into the lane's own 32 histogram slots (no atomics)
       const int nh = n_hv;
-      if (nh > 0 && wv * 2048 < nqs) {
+      const bool bitmaps = nh > 0 && wv * 2048 < nqs;
+      uint32_t ones = 0, twos = 0, fours = 0, hc[CL_HVL];
+#pragma unroll
+      for (int b = 0; b < CL_HVL; b++) hc[b] = 0;
+      if (bitmaps) {
         // (a bitmap's address = a wave-uniform base + this lane's dword: the load takes the base from scalar registers and the
         // lane's offset as it is, no address arithmetic per load)
         const uint32_t loff = (uint32_t)(wv * 64 + lane);
         const uint32_t *bmb = a.qi_bm;
-        uint32_t ones = 0, twos = 0, fours = 0, hc[CL_HVL];
-#pragma unroll
-        for (int b = 0; b < CL_HVL; b++) hc[b] = 0;
         int i = 0;
         auto group8 = [&](const uint32_t *x) {                 // eight bitmaps into ones / twos / fours; what overflows is worth 8
           uint32_t ta, tb, fa, fb, eights;
@@ -457,6 +460,16 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
 #ifdef ITSX_CL_PROF
         if (wv == 0) CLK(4)
 #endif
+      }
+      // the scan's thresholds are requested HERE, eight loads together: the bitmap loads' registers are free again, and the round trip
+      // runs while the counts are unpacked (requested before the bitmap phase they cost more registers than four waves have)
+      if constexpr (decltype(last_batch)::value) {
+        if (nrounds) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) T4[j] = thr[j * 256 + tid];
+        }
+      }
+      if (bitmaps) {
         // ---- the counts leave their bit planes.  Plane by plane that is 3 operations x 11 planes for every strand with a count;
         // instead the planes are first gathered four at a time into NIBBLES: for the strands whose bit index is k mod 4, nibble j of
         // n[g][k] holds planes 4g .. 4g+3 of strand bit 4j + k, so a strand's count is three bit-field extracts.  The upper planes
@@ -488,6 +501,11 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
       }
       __syncthreads();
       CLK(3)
+    };
+    {
+      int w0 = 0;
+      for (; w0 + CL_WBATCH < n; w0 += CL_WBATCH) batch(w0, CL_WBATCH, std::false_type{});
+      batch(w0, n - w0, std::true_type{});
     }
     const int32_t clen = a.cent_len[c], cpos = a.cent_pos[c];
     const uint32_t lenpart = (uint32_t)(65535 - clen) & 0xffffu;
@@ -496,9 +514,6 @@ __global__ __launch_bounds__(256, 4) void k_cl_stream(ClusterArgs a, int c0, int
     // the rolled scan paid eight DEPENDENT round trips per turn (13.6 k of its 15.7 k clock ticks).  Pass 1 only compares; the rare
     // slot that beats its threshold is handled in pass 2, slot by slot; then the thread's slots are cleared.
     if (nrounds) {
-      uint4 T4[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) T4[j] = thr[j * 256 + tid];
       uint32_t hm = 0u;
 #pragma unroll
       for (int j = 0; j < 8; j++) {

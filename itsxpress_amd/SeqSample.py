@@ -156,9 +156,9 @@ class SeqSample:
             self.rep_file = os.path.join(self.tempdir, "rep.fa")
             self._load_reads()
             cid = float(cluster_id)
-            if cid < 1.0 and getattr(self.engine, "world", 1) > 1:
-                # greedy clustering is sequential by definition (a query sees every centroid before it): one GPU runs it
-                logging.warning("cluster_id < 1 does not shard over GPUs: this sample runs on one GPU (ITSXPRESS_GPUS ignored)")
+            if cid < 1.0 and (getattr(self.engine, "world", 1) > 1 or getattr(self.engine, "deferred", False)):
+                # greedy clustering is sequential by definition (a query sees every centroid before it): one GPU runs it, in one piece
+                logging.warning("cluster_id < 1 does not shard over GPUs or chunks: this sample runs on one GPU (ITSXPRESS_GPUS / ITSXPRESS_STREAM ignored)")
                 self._engine.close()
                 self._engine = Engine()
                 self._reads_loaded_from = None

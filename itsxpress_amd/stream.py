@@ -561,6 +561,9 @@ class StreamEngine(ShardedOps):
                 raise EngineError(-1, "search before load_reads_file")
             self._pipeline(with_search=True)
         else:
+            if self._out is not None:                     # (what the writer has was decided by another search: the caller writes afresh)
+                self._out.abort()
+                self._out = None
             self._z = self._all("search", self._mode, T, F1, F2, F3)
             self._searched = True
 

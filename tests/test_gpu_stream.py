@@ -124,6 +124,14 @@ def test_reference_fixture_and_one_slice_files(tmp_path, t_hmm_text, monkeypatch
         g.write(f.read())
     sp, out3, c3, _, _ = _run(plain, os.path.join(tmp, "plain"), hmm, True, True, monkeypatch)
     assert out3 == out1 and all(np.array_equal(x, y) for x, y in zip(c1, c3))
+    # greedy clustering (cluster_id < 1) is sequential by definition: under ITSXPRESS_STREAM the mirror runs it on one plain engine
+    from itsxpress_amd.engine import Engine
+    monkeypatch.setenv("ITSXPRESS_STREAM", "1")
+    sc = S.SeqSampleNotPaired(fastq=plain, tempdir=os.path.join(tmp, "cl"))
+    os.makedirs(sc.tempdir, exist_ok=True)
+    _OPEN.append(sc)
+    sc.cluster(threads=1, cluster_id=0.995)
+    assert type(sc._engine) is Engine and sc._engine.n_unique > 0
 
 
 def test_corrupt_gzip_is_an_error_not_a_result(tmp_path, t_hmm_text, monkeypatch):

@@ -1139,6 +1139,8 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.cw_off = cw_off.p; a.cw_n = cw_n.p; a.cw_base = cw_base.p; a.wsum = wsum.p; a.wscan = wscan.p;
   a.qi_cnt = qi_cnt.p; a.qi_cur = qi_cur.p; a.qi_off = qi_off.p; a.qi_ent = qi_ent.p;
   a.qi_hid = qi_hid.p; a.qi_nheavy = qi_nheavy.p; a.qi_bm = qi_bm.p; a.hcap = hcap;
+  a.heavy_min = CL_HEAVY;                                    // ITSX_CL_HEAVY_MIN: strands that must hold a word before it gets a bitmap (tuning; results do not depend on it)
+  if (const char *e = getenv("ITSX_CL_HEAVY_MIN")) a.heavy_min = std::max(8, atoi(e));
   a.tq = tq.p; a.minm = minm.p; a.tkey = tkey.p; a.ncand = ncand.p; a.ntop = ntop.p; a.ovf = ovf.p; a.cntx = cntx.p;
   a.state = state.p; a.rejects = rejects.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.acc_id = acc_id.p;
   a.sel = sel.p; a.selm = selm.p; a.sel_short = sel_short.p; a.selkey = selkey.p; a.selpid = selpid.p;

@@ -53,7 +53,7 @@ struct ClusterArgs {
   int32_t *qi_cnt, *qi_cur, *qi_off; uint16_t *qi_ent;   // [65537], [65536], [65537], [qi_off[65536]]
   // conserved words (held by >= CL_HEAVY strands of the window) have no list: a bitmap over the window's strands instead, added
   // by bit-sliced carry-save adders (one dword = 32 strands per lane) -- an LDS atomic per (strand, word) is what the lists cost
-  int32_t *qi_hid; int32_t *qi_nheavy; uint32_t *qi_bm; int32_t hcap;   // [65536] bitmap number or -1; [1]; [hcap][CL_QS_MAX / 32]
+  int32_t *qi_hid; int32_t *qi_nheavy; uint32_t *qi_bm; int32_t hcap; int32_t heavy_min;   // [65536] bitmap number or -1; [1]; [hcap][CL_QS_MAX / 32]
   uint32_t *tq, *minm;          // [CL_QS_MAX + 8] thresholds on the HIGH HALF of a rank key, (count << 16 | 65535 - length): a centroid is a
                                 //   candidate when its high half is greater.  tq: high half of tkey, or (min(12, words) << 16) - 1 while the strand has
                                 //   fewer than 32 candidates; minm: (min(12, words) << 16) - 1 (mode 2); 0xFFFFFFFF = never.  Exact, not a pre-test:

@@ -266,7 +266,7 @@ __global__ void k_cl_qi_pad(ClusterArgs a)
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w < 65536) {
     int c = a.qi_cnt[w], hid = -1;
-    if (c >= CL_HEAVY && a.hcap > 0) { hid = atomicAdd(a.qi_nheavy, 1); if (hid >= a.hcap) hid = -1; }   // (no bitmap left: the word keeps its list)
+    if (c >= a.heavy_min && a.hcap > 0) { hid = atomicAdd(a.qi_nheavy, 1); if (hid >= a.hcap) hid = -1; }   // (no bitmap left: the word keeps its list)
     a.qi_hid[w] = hid;
     if (hid >= 0) c = 0;                                     // no list for a word with a bitmap
     a.qi_cnt[w] = (c + 7) & ~7; a.qi_cur[w] = 0;             // lists are read 8 entries (16 bytes) at a time

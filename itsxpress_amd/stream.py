@@ -338,7 +338,8 @@ class StreamEngine(ShardedOps):
         fsize = os.path.getsize(self._path)
         return max(256 << 20, int(fsize * 4 / 16))
 
-    def _new_chunk(self, ptr, nb, base, k, keyset):
+    def _parse_chunk(self, ptr, nb, base, k):
+        """the loader's first stage: a context, the profiles, the slice's records parsed and packed on the device"""
         import time
         t0 = time.perf_counter()
         eng = Engine(self.device)
@@ -350,18 +351,22 @@ class StreamEngine(ShardedOps):
                     self.n_profiles, self._pmeta = int(res[0]), res[1]
             t1 = time.perf_counter()
             eng.load_reads_text(ptr, nb)
-            t2 = time.perf_counter()
-            tup = _HANDLERS["derep"](eng, st, *self._derep_args)
-            t3 = time.perf_counter()
-            verdict, st["gid"] = self._assign(keyset, tup, k)
-            _HANDLERS["verdict"](eng, st, verdict)
-            t4 = time.perf_counter()
-            st["load_s"] = {"context+profiles": round(t1 - t0, 3), "parse+upload": round(t2 - t1, 3), "derep+keys": round(t3 - t2, 3),
-                            "ownership": round(t4 - t3, 3), "MB": round(nb / 1e6, 1), "reads": eng.n_reads}
+            st["load_s"] = {"context+profiles": round(t1 - t0, 3), "parse+upload": round(time.perf_counter() - t1, 3),
+                            "MB": round(nb / 1e6, 1), "reads": eng.n_reads}
         except BaseException:
             eng.close()
             raise
-        return eng, st, time.perf_counter()
+        return eng, st
+
+    def _derep_chunk(self, eng, st, k, keyset):
+        """the loader's second stage, chunk after chunk in file order: dereplication, and which sequences are seen here first"""
+        import time
+        t2 = time.perf_counter()
+        tup = _HANDLERS["derep"](eng, st, *self._derep_args)
+        t3 = time.perf_counter()
+        verdict, st["gid"] = self._assign(keyset, tup, k)
+        _HANDLERS["verdict"](eng, st, verdict)
+        st["load_s"].update({"derep+keys": round(t3 - t2, 3), "ownership": round(time.perf_counter() - t3, 3)})
 
     def _assign(self, keyset, tup, k):
         U = int(tup.shape[0])
@@ -410,6 +415,31 @@ class StreamEngine(ShardedOps):
             fin = threading.Thread(target=finisher, name="itsx-stream-writer", daemon=True)
             fin.start()
 
+        q1 = queue.Queue(maxsize=2)
+
+        def loader2():
+            # second stage on a thread of its own: chunk k is dereplicated (its kernels queue up behind the searches on the GPU)
+            # while chunk k + 1 is parsed
+            k = 0
+            while True:
+                item = q1.get()
+                if item is None or isinstance(item, BaseException):
+                    q.put(item)
+                    return
+                eng, st, t_text = item
+                try:
+                    self._derep_chunk(eng, st, k, keyset)
+                except BaseException as e:                # noqa: handed to the consumer
+                    eng.close()
+                    q.put(e)
+                    while True:                           # (the first stage may still be filling its queue)
+                        it = q1.get()
+                        if it is None or isinstance(it, BaseException):
+                            return
+                        it[0].close()
+                q.put((eng, st, t_text, time.perf_counter() - t0))
+                k += 1
+
         def loader():
             stream = None
             try:
@@ -418,27 +448,31 @@ class StreamEngine(ShardedOps):
                 want = self._chunk_bytes()
                 base, k, ptr0 = 0, 0, None
                 while not stop.is_set():
-                    ptr, nb, last = stream.next(want)    # last: the inflater is done and every member's CRC-32 and length agreed
+                    # (the first slices are smaller -- a quarter, a half -- so that the GPU has something to do early: until the first
+                    # chunk is resident nothing overlaps anything)
+                    ptr, nb, last = stream.next(max(1, want >> max(0, 2 - k)))    # last: the inflater is done and every member's CRC-32 and length agreed
                     t_text = time.perf_counter()
                     if ptr0 is None:
                         ptr0 = ptr
                         if self._out is not None:
                             self._out.base_ptr = ptr0
                     if nb > 0 or (last and k == 0):
-                        eng, st, t_loaded = self._new_chunk(ptr, nb, base, k, keyset)
+                        eng, st = self._parse_chunk(ptr, nb, base, k)
                         st["text_end"], st["last"] = ptr + nb - ptr0, bool(last)
-                        q.put((eng, st, t_text - t0, t_loaded - t0))
+                        q1.put((eng, st, t_text - t0))
                         base += eng.n_reads
                         k += 1
                     if last:
                         break
                 stream = None
-                q.put(None)
-            except BaseException as e:                   # noqa: handed to the consumer
-                q.put(e)
+                q1.put(None)
+            except BaseException as e:                   # noqa: handed on
+                q1.put(e)
 
         th = threading.Thread(target=loader, name="itsx-stream-loader", daemon=True)
+        th2 = threading.Thread(target=loader2, name="itsx-stream-derep", daemon=True)
         th.start()
+        th2.start()
         err = None
         self.timeline = []
         # two chunks are searched at a time: a lazy search stops a dozen times for a count from the device, and the other context's
@@ -476,14 +510,16 @@ class StreamEngine(ShardedOps):
             pool.shutdown(wait=True)
             self.timeline.sort()
             stop.set()
-            while th.is_alive():                         # let the loader get rid of what it still holds
-                try:
-                    item = q.get(timeout=0.05)
-                    if isinstance(item, tuple):
-                        item[0].close()
-                except queue.Empty:
-                    pass
+            while th.is_alive() or th2.is_alive():       # let the loaders get rid of what they still hold
+                for qq in (q, q1) if not th2.is_alive() else (q,):
+                    try:
+                        item = qq.get(timeout=0.05)
+                        if isinstance(item, tuple):
+                            item[0].close()
+                    except queue.Empty:
+                        pass
             th.join()
+            th2.join()
             self.L.itsx_keyset_destroy(keyset)
             if fin is not None:
                 fin_q.put(None)
@@ -500,7 +536,6 @@ class StreamEngine(ShardedOps):
         self._nloc = [eng.n_reads for eng, _ in self._engs]
         self._n_reads = int(sum(self._nloc))
         self._index_uniques()
-        self._n_unique = int(self._seeds.shape[0])
         self._loaded = True
         if with_search:
             self._z = [zs[k] for k in range(len(self._engs))]
@@ -517,30 +552,54 @@ class StreamEngine(ShardedOps):
             self.L.itsx_keyset_destroy(keyset)
         self._verdicts = [st["verdict"] for _, st in self._engs]
         self._index_uniques()
-        self._n_unique = int(self._seeds.shape[0])
         self._searched = self._final = False
 
+    # The global unique list (first occurrences in file order) and the chunks' local -> global maps are what the keyset handed out
+    # chunk by chunk (`gid`: first-seen order); they are put together when somebody asks -- coordinates per read, the
+    # file-compatible outputs --, not in the pipeline: a planned output never needs them.
     def _index_uniques(self):
-        # chunks are in file order and a chunk numbers its uniques by first occurrence: the sequences first seen in chunk k, in that
-        # order, ARE the next stretch of the global unique list (checked; anything else takes the general route)
-        isnew = [(v[:, 2] == k) & (v[:, 3] == np.arange(v.shape[0])) for k, v in enumerate(self._verdicts)]
-        new = [v[m, 0] for v, m in zip(self._verdicts, isnew)]
-        seeds = np.concatenate(new) if new else np.zeros(0, np.int64)
-        if seeds.shape[0] > 1 and not bool(np.all(seeds[1:] > seeds[:-1])):
-            super()._index_uniques()
+        self._lazy_index = True
+        self._derep = None
+        self._final = False
+        self._n_unique = 1 + max((int(st["gid"].max()) for _, st in self._engs if st["gid"].shape[0]), default=-1)
+
+    def _build_index(self):
+        if not getattr(self, "_lazy_index", False):
+            return
+        self._lazy_index = False
+        n = self._n_unique
+        seeds = np.zeros(n, np.int64)
+        gm = []
+        for k, (_, st) in enumerate(self._engs):
+            v, gid = st["verdict"], st["gid"]
+            mine = (v[:, 2] == k) & (v[:, 3] == np.arange(v.shape[0]))
+            seeds[gid[mine]] = v[mine, 0]
+            gm.append(gid)
+        if n > 1 and not bool(np.all(seeds[1:] > seeds[:-1])):
+            # (a chunk that did not number its uniques by first occurrence: the general route, by sorting)
+            keep = (self._derep, self._final)
+            ShardedOps._index_uniques(self)
+            self._derep, self._final = keep
         else:
-            self._seeds = seeds
-            self._gmap, at = [], 0
-            for v, m in zip(self._verdicts, isnew):
-                g = np.empty(v.shape[0], np.int64)
-                n = int(m.sum())
-                g[m] = at + np.arange(n)
-                g[~m] = np.searchsorted(seeds[:at], v[~m, 0])          # first seen in an earlier chunk
-                self._gmap.append(g)
-                at += n
-            self._derep = None
-            self._final = False
-        self._n_unique = int(self._seeds.shape[0])
+            self._seeds_, self._gmap_ = seeds, gm
+
+    @property
+    def _seeds(self):
+        self._build_index()
+        return self._seeds_
+
+    @_seeds.setter
+    def _seeds(self, v):
+        self._seeds_ = v
+
+    @property
+    def _gmap(self):
+        self._build_index()
+        return self._gmap_
+
+    @_gmap.setter
+    def _gmap(self, v):
+        self._gmap_ = v
 
     def finalize(self, domE=10.0):
         if self._out is not None and float(domE) != self._plan["domE"]:

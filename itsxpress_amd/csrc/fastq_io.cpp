@@ -479,9 +479,12 @@ bool TextStream::open(const char *path, std::string &err)
   }
   // the text must not move while slices of it are out: address space for any plausible ratio up front (pages arrive on first touch)
   const size_t n = s->raw.size();
-  size_t want = n * 64 + ((size_t)1 << 30);
-  while (want > n * 4 && !s->text->reserve(want)) want /= 2;
-  if (s->text->capacity() < n * 4 && !s->text->reserve(n * 4 + (1 << 20))) { err = std::string("out of memory inflating ") + path; return false; }
+  // (ITSX_STREAM_RESERVE_X / _MB: the factor and the constant of that reservation -- tests make it too small on purpose)
+  const size_t rx = (size_t)std::max(1, env_int("ITSX_STREAM_RESERVE_X", 64)), rmb = (size_t)std::max(0, env_int("ITSX_STREAM_RESERVE_MB", 1024));
+  size_t want = n * rx + (rmb << 20);
+  const size_t least = std::min(want, n * 4 + ((size_t)1 << 20));
+  while (want > least && !s->text->reserve(want)) want /= 2;
+  if (s->text->capacity() < least && !s->text->reserve(least)) { err = std::string("out of memory inflating ") + path; return false; }
   s->text->pin(true);
   s->joined = false;
   s->th = std::thread([this, T] {

@@ -326,7 +326,26 @@ class StreamEngine(ShardedOps):
 
     def _ensure_loaded(self):
         if not self._loaded and self._path is not None:
-            self._pipeline(with_search=False)
+            self._run_pipeline(with_search=False)
+
+    def _run_pipeline(self, with_search):
+        """the pipeline; if the block-parallel inflater gives up on the file AFTER slices have been handed out (a stream it cannot
+        split, or one that expands more than 64-fold: the text may not move once slices are out), everything computed so far is
+        dropped and the file goes through again with the serial inflater (whole text first, then the same chunks)"""
+        try:
+            self._pipeline(with_search)
+        except EngineError as e:
+            if "gave up after slices" not in str(e):
+                raise
+            keep = os.environ.get("ITSX_PARALLEL_INFLATE")
+            os.environ["ITSX_PARALLEL_INFLATE"] = "0"
+            try:
+                self._pipeline(with_search)
+            finally:
+                if keep is None:
+                    os.environ.pop("ITSX_PARALLEL_INFLATE", None)
+                else:
+                    os.environ["ITSX_PARALLEL_INFLATE"] = keep
 
     # -- the pipeline
     def _chunk_bytes(self):
@@ -618,7 +637,7 @@ class StreamEngine(ShardedOps):
         if not self._loaded:
             if self._path is None:
                 raise EngineError(-1, "search before load_reads_file")
-            self._pipeline(with_search=True)
+            self._run_pipeline(with_search=True)
         else:
             if self._out is not None:                     # (what the writer has was decided by another search: the caller writes afresh)
                 self._out.abort()

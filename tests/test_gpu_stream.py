@@ -232,3 +232,36 @@ def test_paired_end_through_the_streaming_engine(tmp_path, t_hmm_text, monkeypat
             assert isinstance(sobj._engine, StreamEngine) and sobj._engine.world >= 3, sobj._engine.world
     assert outs["one"][0] == outs["stream"][0] and outs["one"][1] == outs["stream"][1] and len(outs["one"][0]) > 1000
     assert all(np.array_equal(x, y) for x, y in zip(outs["one"][2], outs["stream"][2]))
+
+
+def test_stream_that_outgrows_its_reservation_starts_over_serially(tmp_path, t_hmm_text, monkeypatch):
+    """the block-parallel inflater gives up after slices are out (the reservation is made too small on purpose): the engine drops
+    what it computed -- the planned output included -- and runs the file again through the serial inflater; same bytes"""
+    tmp = str(tmp_path)
+    hmm = _its2(tmp, t_hmm_text)
+    fq = os.path.join(tmp, "synth.fq.gz")
+    _fastq_gz(fq, t_hmm_text, 12000, 717)
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "32")
+    monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "1.5")
+    _, ref_bytes, c_ref, _, _ = _run(fq, os.path.join(tmp, "one"), hmm, False, True, monkeypatch)
+    monkeypatch.setenv("ITSX_STREAM_RESERVE_X", "1")
+    monkeypatch.setenv("ITSX_STREAM_RESERVE_MB", "4")
+    monkeypatch.setenv("ITSXPRESS_GPUS", "1"); monkeypatch.setenv("ITSXPRESS_STREAM", "1"); monkeypatch.setenv("ITSXPRESS_ARRAYS", "1")
+    from itsxpress_amd import trim, _lib
+    trim.cache_clear()
+    d = os.path.join(tmp, "stream")
+    os.makedirs(d, exist_ok=True)
+    before = _lib.lib().itsx_io_parallel_inflates()
+    sobj = S.SeqSampleNotPaired(fastq=fq, tempdir=d)
+    _OPEN.append(sobj)
+    out = os.path.join(d, "trimmed.fq.gz")
+    sobj.plan_output(out, "ITS2", gzipped=True)
+    sobj.deduplicate(threads=1)
+    sobj._search(hmmfile=hmm, threads=1)
+    assert _lib.lib().itsx_io_parallel_inflates() == before          # the parallel attempt did not deliver the file
+    assert os.environ.get("ITSX_PARALLEL_INFLATE") is None           # (the driver's switch for its second attempt is gone again)
+    its_pos = S.ItsPosition(domtable=sobj.dom_file, region="ITS2")
+    dd = S.Dedup(uc_file=sobj.uc_file, rep_file=sobj.rep_file, seq_file=sobj.seq_file, fastq=sobj.r1, fastq2=sobj.fastq2)
+    dd.create_trimmed_seqs(out, gzipped=True, zstd_file=False, itspos=its_pos, wri_file=True, tempdir=d)
+    assert open(out, "rb").read() == ref_bytes
+    assert all(np.array_equal(x, y) for x, y in zip(c_ref, sobj.trim_coordinates("ITS2")))

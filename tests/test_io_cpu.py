@@ -420,3 +420,25 @@ def test_keyset_first_holder_wins():
         assert L.itsx_keyset_assign(ks, None, 0, 9, None, None) == 0
     finally:
         L.itsx_keyset_destroy(ks)
+
+
+def test_text_stream_that_outgrows_its_reservation_says_so(tmp_path, monkeypatch):
+    """slices must not move once they are out, so the stream reserves address space up front (64 x the file + 1 GB); a file that
+    expands beyond it -- here the reservation is made too small on purpose -- is delivered by the serial inflater if nothing was
+    handed out yet, and otherwise ends in an error that says so (the streaming driver then starts over with the serial inflater)"""
+    text = _amplicon_fastq(20000, 77)                              # 12.5 MB, ~2.4 x its gzip
+    p = tmp_path / "in.fastq.gz"
+    p.write_bytes(gzip.compress(text, 6))
+    L = _lib.lib()
+    monkeypatch.setenv("ITSX_IO_THREADS", "4")
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "64")
+    monkeypatch.setenv("ITSX_TEXT_CACHE_GB", "0")
+    monkeypatch.setenv("ITSX_STREAM_RESERVE_X", "1")
+    monkeypatch.setenv("ITSX_STREAM_RESERVE_MB", "4")
+    with pytest.raises(EngineError) as e:                          # small slices: some are out when the room ends
+        _stream_slices(p, 1 << 20)
+    assert "gave up after slices" in str(e.value)
+    # a first slice larger than the file: nothing is out when the room ends, the serial inflater takes over
+    assert b"".join(_stream_slices(p, 1 << 30)) == text
+    monkeypatch.setenv("ITSX_PARALLEL_INFLATE", "0")               # what the driver's second attempt does
+    assert b"".join(_stream_slices(p, 1 << 20)) == text

@@ -7,6 +7,7 @@
 #include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -347,10 +348,13 @@ static bool read_raw(const char *path, int64_t fsize, Text &raw, std::string &er
       got = 0;
       while (got < (size_t)fsize) { const ssize_t n = pread(fd, raw.data() + got, (size_t)fsize - got, (off_t)got); if (n < 0) { rerr = true; break; } if (n == 0) break; got += (size_t)n; }
     }
-    // a file that is still growing: read the rest
+    // a file that is still growing, or something that has no size and no positions (a FIFO, a process substitution): read the rest
+    bool seekable = true;
     while (!rerr) {
-      if (!raw.resize(got + (1 << 16) + 64)) { rerr = true; break; }
-      const ssize_t n = pread(fd, raw.data() + got, 1 << 16, (off_t)got);
+      if (!raw.resize(got + (1 << 20) + 64)) { rerr = true; break; }
+      ssize_t n = seekable ? pread(fd, raw.data() + got, 1 << 20, (off_t)got) : read(fd, raw.data() + got, 1 << 20);
+      if (n < 0 && seekable && errno == ESPIPE) { seekable = false; continue; }
+      if (n < 0 && errno == EINTR) continue;
       if (n < 0) rerr = true;
       if (n <= 0) break;
       got += (size_t)n;

@@ -442,3 +442,23 @@ def test_text_stream_that_outgrows_its_reservation_says_so(tmp_path, monkeypatch
     assert b"".join(_stream_slices(p, 1 << 30)) == text
     monkeypatch.setenv("ITSX_PARALLEL_INFLATE", "0")               # what the driver's second attempt does
     assert b"".join(_stream_slices(p, 1 << 20)) == text
+
+
+def test_reader_takes_a_fifo(tmp_path):
+    """a path without a size or positions (a FIFO, a process substitution) is read to its end like any other"""
+    import threading
+    text = _amplicon_fastq(3000, 5)
+    blob = gzip.compress(text, 6)
+    fifo = str(tmp_path / "reads.fq.gz")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(blob)
+
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        assert read_text(fifo) == text
+    finally:
+        t.join()

@@ -1862,7 +1862,13 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
         ma.n2off = ctx->w_n2off.p; ma.n2sc = ctx->w_n2sc.p; ma.out = ctx->w_mrout.p; ma.scratch = ctx->w_mrscratch.p;
         static const bool mrdbg = getenv("ITSX_MR_DEBUG") != nullptr;
         if (mrdbg) { HIPCHK(ctx->w_counters.alloc(8)); HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 64, st)); ma.dbg = (unsigned long long *)ctx->w_counters.p; }
-        launch_mr_ensemble(ma, w1 - w0, w0, st);
+        // a small batch (a shard of a million reads, a chunk of a streaming run) cannot hide a path's chain of dependent matrix reads
+        // behind other waves: its regions are walked one per wave with the matrix in LDS (k_ensemble.hip: k_mr_trace<., true>)
+        static const int64_t one_max = getenv("ITSX_MR_ONE_MAX") ? atoll(getenv("ITSX_MR_ONE_MAX")) : 2048;      // (10 M reads: 6 400 and 21 500 regions in the two rounds took 252 and 531 ms this way, 212 in waves of 64)
+        const int64_t nreg = wfirst[(size_t)w1] - wfirst[(size_t)w0];
+        const bool one = nreg <= one_max;
+        if (one) ma.lds_bytes = (int32_t)std::min<int64_t>(40 << 10, (int64_t)mw[(size_t)w1 - 1].rows * MRV * 16);
+        launch_mr_ensemble(ma, w1 - w0, w0, st, one ? wfirst[(size_t)w0] : 0, one ? nreg : 0);
         if (mrdbg) {
           unsigned long long d[5];
           HIPCHK(hipMemcpyAsync(d, ctx->w_counters.p, 40, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));

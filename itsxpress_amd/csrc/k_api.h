@@ -281,6 +281,7 @@ struct MrArgs {
   const int32_t *ulist;         // distinct regions (same profile, target length and residues): index into mr of each one's first copy
   int64_t u0;                   // first distinct region of this batch (scratch blocks are per batch)
   const WaveDesc *waves;        // first = index into ulist, count, rows = longest region of the wave + 1
+  int32_t lds_bytes = 0;        // k_mr_trace<., true>: LDS per wave for the region's matrix
   float4 *slab;                 // a region's matrix is contiguous: [row 0..Lr][MRV]; region u starts at row rowoff[u] - rowoff0
   const int64_t *rowoff;        // [distinct] first slab row of each distinct region (all batches; rowoff0 = the batch's first)
   int64_t rowoff0;
@@ -301,7 +302,7 @@ void launch_mr_ulist(int64_t nmr, const MrRec *mr, const int32_t *rep, const int
                      int32_t *mr_u, hipStream_t st);
 // regions ordered by length: ulist_out[newpos[u]] = ulist_in[u], mr_u[m] = newpos[mr_u[m]]
 void launch_mr_reorder(int64_t nu, int64_t nmr, const int32_t *newpos, const int32_t *ulist_in, int32_t *ulist_out, int32_t *mr_u, hipStream_t st);
-void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st);
+void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st, int64_t one_first = 0, int64_t one_count = 0);
 void launch_mr_ensemble_big(const MrArgs &a, int nwaves, hipStream_t st);
 // distinct regions the fast kernel gave up on (status 2, 4, 7 -- and 3, 6, which cannot occur): appended to list, counted in n[0]
 void launch_mr_overflowed(const MrOut *out, int64_t nu, int32_t *list, unsigned long long *n, hipStream_t st);

@@ -231,22 +231,45 @@ static_assert(sizeof(MrScratch) <= MR_SCRATCH, "scratch block too small");
 // Every per-region array then lives in a block of global memory sized by the region's length -- a path of a region of Lr residues
 // has at most Lr domains, 200 paths at most 200 Lr tuples, at most 4 Lr clusters reach a quarter of the paths -- with 32-bit
 // indices: nothing can overrun, as in hmmsearch (p7_domaindef.c grows its lists).  Same random stream, same sums, same order.
-template <bool BIG>
+// ONE = the small-batch form: a wave walks ONE region (lane 0) and keeps the region's Forward matrix in LDS.  A sampled path is a
+// chain of dependent reads of that matrix -- 200 paths x ~150 steps, each a round trip to L2 when the matrix is in global memory:
+// 20 ms of a wave's 32 whatever the batch holds -- and a batch of a thousand regions (a 1 M-read shard, a chunk of a streaming run)
+// cannot hide it behind other waves.  From LDS the same reads take a fifth of the time; the wave's other lanes only help copying.
+// wave0 is then the first REGION of the launch; a matrix that does not fit the launch's LDS is walked where it is.
+template <bool BIG, bool ONE = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_mr_trace(MrArgs a, int wave0)
 {
+  extern __shared__ f4 mr_mat[];
   using idx_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
   using sidx_t = typename std::conditional<BIG, int32_t, int16_t>::type;
   constexpr idx_t NONE = (idx_t)~(idx_t)0;
   // usage of the domain being walked: a match state is visited at most once per node (a bit mask), insert states are counted
-  __shared__ uint16_t cntI_s[QMAX * 4][MR_LANES];
+  constexpr int NL = ONE ? 1 : MR_LANES;                   // (one region per wave: the per-lane arrays are 150 bytes, the LDS goes to the matrix)
+  __shared__ uint16_t cntI_s[QMAX * 4][NL];
   // the domains of the path being sampled, last first: first / last residue, first / last node, null2 odds of A C G T
-  __shared__ uint32_t dom_ij[MR_MAXD][MR_LANES];
-  __shared__ uint16_t dom_km[MR_MAXD][MR_LANES];           // (the domains' null2 odds live in the region's scratch block: S.dn2)
-  const WaveDesc wd = a.waves[wave0 + (gridDim.x - 1 - blockIdx.x)];       // longest regions first
-  const int lane = threadIdx.x;
+  __shared__ uint32_t dom_ij[MR_MAXD][NL];
+  __shared__ uint16_t dom_km[MR_MAXD][NL];                 // (the domains' null2 odds live in the region's scratch block: S.dn2)
+  WaveDesc wd;
+  if constexpr (ONE) { wd.prof = -1; wd.first = wave0 + (int64_t)(gridDim.x - 1 - blockIdx.x); wd.count = 1; wd.rows = 0; }
+  else wd = a.waves[wave0 + (gridDim.x - 1 - blockIdx.x)];                 // longest regions first
+  const int lane = ONE ? 0 : (int)threadIdx.x;
   const MrLane e = mr_lane(a, wd, lane);
-  if (!e.active) return;
-  const int Q = e.Q, Lr = e.Lr, Lw = wd.rows - 1;
+  const f4 *mat = (const f4 *)a.slab + e.r0 * MRV;                          // the region's matrix: [row 0..Lr][MRV]
+  bool in_lds = false;
+  if constexpr (ONE) {
+    const int64_t nvec = (int64_t)(e.Lr + 1) * MRV;
+    if (nvec * 16 <= (int64_t)a.lds_bytes) {
+      for (int64_t z = threadIdx.x; z < nvec; z += 64) mr_mat[z] = mat[z];
+      in_lds = true;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+  } else {
+    if (!e.active) return;
+  }
+  // (two typed reads under a uniform branch rather than one generic pointer: an LDS read, not a flat load that happens to land there)
+#define MATV(idx) ((ONE && in_lds) ? mr_mat[(idx)] : mat[(idx)])
+  const int Q = e.Q, Lr = e.Lr, Lw = ONE ? e.Lr : wd.rows - 1;
   const float *tfn = e.pp->tfn;
   const float pmove = e.pmove, ploop = e.ploop;
   float *n2 = a.n2sc + a.n2off[e.mi];                       // n2[pos - 1], pos = 1..Lr relative to the region
@@ -313,8 +336,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         if (!(s0 == ST_C || s0 == ST_J)) continue;
         if (i < 1) { status = 5; s0 = ST_S; continue; }
         // {E J C scale} of rows i - 1 and i: row i's vector is the one the previous step loaded as row i - 1
-        if (cj_row != i) { cj_cur = *mrslab(a, e.r0, i, MR_CJ, lane); cj_row = i; }
-        const f4 c0 = *mrslab(a, e.r0, i - 1, MR_CJ, lane);
+        if (cj_row != i) { cj_cur = MATV((int64_t)i * MRV + MR_CJ); cj_row = i; }
+        const f4 c0 = MATV((int64_t)(i - 1) * MRV + MR_CJ);
         const float w0 = (s0 == ST_C ? c0.z : c0.y) * ploop, w1 = cj_cur.x * 0.5f * cj_cur.w;
         if (choose2(rng, w0, w1) == 0) { i--; cj_cur = c0; cj_row = i; } else s0 = ST_E;
       }
@@ -333,7 +356,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
               for (int z = 0; z < 3; z++) {
                 const int qq = q0 + z < Q ? q0 + z : Q - 1;
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) md[z][rr] = *(const f2 *)mrslab(a, e.r0, i, rr * Q + qq + 1, lane);
+                for (int rr = 0; rr < 4; rr++) { const f4 q4 = MATV((int64_t)i * MRV + (rr * Q + qq + 1)); md[z][rr] = (f2){q4.x, q4.y}; }
               }
 #pragma unroll
               for (int z = 0; z < 3; z++) {
@@ -365,7 +388,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         // (M: B M I D -> M of node k; D: M D -> D out of node k - 1; I: M I -> I of node k)
         const int rowA = (s0 == ST_D) ? i : i - 1;
         const int kA = (s0 == ST_I) ? k : k - 1;
-        const f4 nv = *mrslab(a, e.r0, rowA, kA, lane);
+        const f4 nv = MATV((int64_t)rowA * MRV + kA);
         const f4 tv = *(const f4 *)(tfn + (s0 == ST_D ? kA : k) * 8 + (s0 == ST_M ? 0 : 4));
         float w0, w1, w2 = 0.0f, w3 = 0.0f;
         if (s0 == ST_M) { w0 = nv.w * tv.x; w1 = nv.x * tv.y; w2 = nv.z * tv.z; w3 = nv.y * tv.w; }
@@ -388,7 +411,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       // ---- B: where the domain was entered from, and p7_Null2_ByTrace over its states (only match and insert states emit)
       if (__ballot(s0 == ST_B) != 0ull) {
         if (s0 == ST_B) {
-          const f4 sp1 = *mrslab(a, e.r0, i, MR_SP, lane);
+          const f4 sp1 = MATV((int64_t)i * MRV + MR_SP);
           s0 = choose2(rng, sp1.y * pmove, sp1.z * pmove) == 0 ? ST_S : ST_J;        // N: the path is finished
           int Ld = __popcll(maskM);
           for (int z = 0; z < Q * 4; z++) Ld += (int)cntI_s[z][lane];
@@ -769,11 +792,14 @@ void launch_mr_reorder(int64_t nu, int64_t nmr, const int32_t *newpos, const int
   if (n <= 0) return;
   hipLaunchKernelGGL(k_mr_reorder, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, nu, nmr, newpos, ulist_in, ulist_out, mr_u);
 }
-void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st)
+// one_count > 0: the launch's regions [one_first, one_first + one_count) are walked one per wave with their matrices in LDS
+// (a.lds_bytes of it per wave); otherwise the waves of 64 (4) regions walk them where k_mr_fwd left them
+void launch_mr_ensemble(const MrArgs &a, int nwaves, int wave0, hipStream_t st, int64_t one_first, int64_t one_count)
 {
   if (nwaves <= 0) return;
   hipLaunchKernelGGL(k_mr_fwd, dim3(nwaves), dim3(64), 0, st, a, wave0);
-  hipLaunchKernelGGL(k_mr_trace<false>, dim3(nwaves), dim3(64), 0, st, a, wave0);
+  if (one_count > 0) hipLaunchKernelGGL((k_mr_trace<false, true>), dim3((unsigned)one_count), dim3(64), (size_t)a.lds_bytes, st, a, (int)one_first);
+  else hipLaunchKernelGGL(k_mr_trace<false>, dim3(nwaves), dim3(64), 0, st, a, wave0);
 }
 void launch_mr_ensemble_big(const MrArgs &a, int nwaves, hipStream_t st)
 {

@@ -48,6 +48,29 @@ __global__ void k_wave_rows_pairs(const WaveDesc *w, int nw, const PairRec *pair
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nw) rows[i] = pairs[w[i].first + w[i].count - 1].L + 1;       // ascending length inside a segment
 }
+// The wave list of a whole chunk's pairs, made where it is used: wave i covers 64 consecutive pairs of one profile's segment, the
+// profiles in launch order (`order`, waves before them in `woff`).  A million-read shard has 1.3 M waves: built on the host they were
+// 43 MB up, 5 MB of row counts down and 43 MB up again -- 20 ms in which the GPU did nothing.  Also sums the waves' lane-rows.
+__global__ void k_waves_build(int nw, int P, const int32_t *__restrict__ order, const int64_t *__restrict__ woff, const int64_t *__restrict__ seg_start,
+                              const int32_t *__restrict__ total, const PairRec *__restrict__ pairs, WaveDesc *__restrict__ w, unsigned long long *__restrict__ lane_rows)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long mine = 0;
+  if (i < nw) {
+    int lo = 0, hi = P;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (woff[mid] <= (int64_t)i) lo = mid; else hi = mid; }
+    const int p = order[lo];
+    const int64_t k = ((int64_t)i - woff[lo]) * 64;
+    WaveDesc d;
+    d.prof = p; d.first = seg_start[p] + k; d.count = (int32_t)min((int64_t)64, (int64_t)total[p] - k); d.slab = 0;
+    d.rows = pairs[d.first + d.count - 1].L + 1;             // ascending length inside a segment
+    d.pad = 0;
+    w[i] = d;
+    mine = (unsigned long long)(d.rows - 1) * (unsigned long long)d.count;
+  }
+  for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(lane_rows, mine);
+}
 __global__ void k_wave_rows_regions(const WaveDesc *w, int nw, const RegionRec *rg, int32_t *rows)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2116,16 +2139,29 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
   HIPCHK(hipMemsetAsync(ctx->l_done.p, 0, (size_t)NP + 1, st));
   HIPCHK(hipMemsetAsync(ctx->l_gtop.p, 0, ((size_t)Uc * ncls + 1) * sizeof(unsigned long long), st));
   {
-    std::vector<WaveDesc> waves; std::vector<char> wgeneric; std::vector<int32_t> rows;
-    { const int rc = build_waves(ctx, pl, waves, wgeneric, rows); if (rc != ITSX_OK) return rc; }
-    const int NW = (int)waves.size();
+    // the waves over every pair, fast (Q == 12) profiles first, then runtime-Q ones: built on the device (k_waves_build)
+    std::vector<int32_t> order; std::vector<int64_t> woff(1, 0);
+    int64_t nfast64 = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (int p = 0; p < P; p++) {
+        if ((int)ctx->generic_q[p] != pass) continue;
+        order.push_back(p);
+        woff.push_back(woff.back() + ((int64_t)pl.total[(size_t)p] + 63) / 64);
+        if (pass == 0) nfast64 = woff.back();
+      }
+    if (woff.back() >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 waves of pairs in one chunk");
+    const int NW = (int)woff.back(), nfast = (int)nfast64;
+    DBuf<int32_t> &d_order = ctx->w_b; DBuf<int64_t> &d_woff = ctx->w_idx; DBuf<int32_t> &d_tot = ctx->w_rcnt;
+    HIPCHK(upload(d_order, order, st)); HIPCHK(upload(d_woff, woff, st)); HIPCHK(upload(d_tot, pl.total, st));
+    HIPCHK(ctx->w_waves.alloc((size_t)std::max(NW, 1))); HIPCHK(ctx->w_counters.alloc(16));
+    HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 16 * sizeof(int64_t), st));
+    if (NW > 0) hipLaunchKernelGGL(k_waves_build, dim3((NW + 255) / 256), dim3(256), 0, st, NW, (int)order.size(), d_order.p, d_woff.p, pl.d_seg_start, d_tot.p,
+                                   pl.pairs, ctx->w_waves.p, (unsigned long long *)ctx->w_counters.p);
+    int64_t lane_rows = 0;
+    HIPCHK(hipMemcpyAsync(&lane_rows, ctx->w_counters.p, sizeof(lane_rows), hipMemcpyDeviceToHost, st));
     FloatArgs a{};
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
     a.pairs = pl.pairs; a.waves = ctx->w_waves.p; a.F1 = F1; a.F3 = F3;
-    // rows of each wave (the kernel walks every lane to the wave's longest target)
-    for (int w = 0; w < NW; w++) waves[(size_t)w].rows = rows[(size_t)w];
-    HIPCHK(hipMemcpyAsync(ctx->w_waves.p, waves.data(), (size_t)NW * sizeof(WaveDesc), hipMemcpyHostToDevice, st));
-    int nfast = 0; while (nfast < NW && !wgeneric[(size_t)nfast]) nfast++;
     StageTimer tm(st);
     // launches of at most 2^20 waves: the timers of bench.py's roofline block want more than one sample
     static const bool exact_bound = getenv("ITSX_LAZY_EXACT_BOUND") && atoi(getenv("ITSX_LAZY_EXACT_BOUND")) != 0;     // A/B: HMMER's own Forward as the bound pass
@@ -2156,7 +2192,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       }
       S.lazy_bound_maxdiff = mx;
     }
-    for (int w = 0; w < NW; w++) S.bound_rows += (int64_t)(rows[(size_t)w] - 1) * waves[(size_t)w].count;
+    S.bound_rows += lane_rows;                    // (its copy was waited for with the kernel's timer)
   }
   StageTimer tm_sel(st);
   LazyArgs la{};

@@ -299,6 +299,7 @@ struct itsx_ctx {
   int64_t s_Uc = 0; int s_Lcap = 0;       // the last search's chunk size and length cap (the completion walks the same chunks)
   DBuf<float> l_fb; DBuf<uint32_t> l_b10; DBuf<uint8_t> l_done; DBuf<int32_t> l_flag, l_pos, l_scan, l_has; DBuf<unsigned long long> l_gtop, l_sure;
   DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub; DBuf<int32_t> l_pflag; DBuf<uint8_t> l_uflag; bool partial_coords = false; std::vector<int32_t> lazy_pending_prof;
+  std::vector<uint16_t> thr_memo; std::vector<char> thr_memo_have; double thr_memo_F1 = -1.0; int thr_memo_Ppad = 0;   // MSV thresholds by length, kept between searches
   DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
   std::vector<int32_t> h_sorted_active;  // the length-sorted list the HMM stages walk (= h_sorted_uniq unless itsx_set_active_uniques narrowed it)
   DBuf<LenTables> d_lt;
@@ -429,6 +430,7 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
     if (p.M > MMAX || p.Q > QMAX) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "model '" + p.name + "' has more than 46 nodes; the device kernels hold at most 46");
     if (p.base_b + p.bias_b >= 255) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "model '" + p.name + "': MSV bias too large");
   }
+  ctx->thr_memo.clear(); ctx->thr_memo_have.clear(); ctx->thr_memo_F1 = -1.0;      // (the MSV thresholds kept between searches belong to the old profiles)
   HIPCHK(hipSetDevice(ctx->device));
   ctx->profs = std::move(pv);
   const int P = (int)ctx->profs.size();
@@ -1500,9 +1502,15 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       t.vmove = (w >= 32767.0f) ? 32767 : (w <= -32768.0f) ? -32768 : (int)w; }
   }
   // MSV pass threshold on the final xJ byte, per (length, profile): P(score) <= F1
+  // (a row depends on the length, the profiles and F1 only: rows made by an earlier search of this context are kept -- 200 k
+  // evaluations of the Gumbel tail, 13 ms per search of the bench's 280 lengths x 88 profiles, while the GPU waited)
+  if (ctx->thr_memo_F1 != F1 || ctx->thr_memo_Ppad != Ppad) { ctx->thr_memo.clear(); ctx->thr_memo_have.clear(); ctx->thr_memo_F1 = F1; ctx->thr_memo_Ppad = Ppad; }
+  if (ctx->thr_memo_have.size() < (size_t)Lcap) { ctx->thr_memo_have.resize((size_t)Lcap, 0); ctx->thr_memo.resize((size_t)Lcap * Ppad, 257); }
   std::vector<uint16_t> thr((size_t)Lcap * Ppad, 257);
   for (int L = 1; L < Lcap; L++) {
     if (!present[L]) continue;
+    if (ctx->thr_memo_have[(size_t)L]) { memcpy(&thr[(size_t)L * Ppad], &ctx->thr_memo[(size_t)L * Ppad], (size_t)Ppad * sizeof(uint16_t)); continue; }
+    ctx->thr_memo_have[(size_t)L] = 2;                 // (filled below)
     for (int p = 0; p < P; p++) {
       const HostProfile &h = ctx->profs[p];
       auto passes = [&](int xj) {
@@ -1516,6 +1524,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
       thr[(size_t)L * Ppad + p] = (uint16_t)lo;
     }
   }
+  for (int L = 1; L < Lcap; L++)
+    if (ctx->thr_memo_have[(size_t)L] == 2) { memcpy(&ctx->thr_memo[(size_t)L * Ppad], &thr[(size_t)L * Ppad], (size_t)Ppad * sizeof(uint16_t)); ctx->thr_memo_have[(size_t)L] = 1; }
   DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
   HIPCHK(upload(ctx->d_lt, lt, st)); HIPCHK(upload(d_thr, thr, st)); HIPCHK(upload(d_tjb, tjb, st));
 

@@ -230,7 +230,7 @@ class StreamEngine(ShardedOps):
         jobs = list(zip(self._engs, args_per_shard))
         if cmd in self._CONCURRENT and len(jobs) > 1:
             from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            with ThreadPoolExecutor(max_workers=min(int(os.environ.get("ITSX_STREAM_FINISHERS", "8") or 8), len(jobs))) as pool:
                 return list(pool.map(lambda j: _HANDLERS[cmd](j[0][0], j[0][1], *j[1]), jobs))
         return [_HANDLERS[cmd](eng, st, *a) for (eng, st), a in jobs]
 

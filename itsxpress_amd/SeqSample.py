@@ -45,15 +45,16 @@ class EngineTable(str):
         return self
 
 
-def _new_engine(gpus=None):
+def _new_engine(gpus=None, path=None, fast=False):
     """one Engine, or -- ITSXPRESS_GPUS > 1 -- N workers behind the same interface (started before this process touches a GPU)"""
     from .multi import MultiEngine, gpus_from_env
-    from .stream import StreamEngine, stream_from_env
+    from .stream import StreamEngine, stream_wanted
     n = int(gpus) if gpus else gpus_from_env()
     if n > 1:
         return MultiEngine(n)
-    # ITSXPRESS_STREAM=1: file-order chunks of one FASTQ, scored while the rest of the file is still being inflated
-    return StreamEngine() if stream_from_env() else Engine()
+    # ITSXPRESS_STREAM=1 (or, in arrays mode, a large input file and no ITSXPRESS_STREAM=0): file-order chunks of one FASTQ, scored
+    # while the rest of the file is still being inflated
+    return StreamEngine() if stream_wanted(path, fast) else Engine()
 
 
 def _fast_from_env():
@@ -81,7 +82,7 @@ class SeqSample:
     def engine(self) -> Engine:
         if self._engine is None:
             try:
-                self._engine = _new_engine(getattr(self, "gpus", None))
+                self._engine = _new_engine(getattr(self, "gpus", None), path=self.seq_file or self.fastq, fast=self._is_fast())
             except FileNotFoundError:
                 logger.error("The HIP engine (libitsx_hip.so) was not found; build it first")
                 raise

@@ -124,6 +124,21 @@ def test_reference_fixture_and_one_slice_files(tmp_path, t_hmm_text, monkeypatch
         g.write(f.read())
     sp, out3, c3, _, _ = _run(plain, os.path.join(tmp, "plain"), hmm, True, True, monkeypatch)
     assert out3 == out1 and all(np.array_equal(x, y) for x, y in zip(c1, c3))
+    # ITSXPRESS_STREAM unset: a large input streams by itself in arrays mode (and only there; ITSX_STREAM_AUTO_MB is the size, 512)
+    from itsxpress_amd.stream import StreamEngine
+    from itsxpress_amd.engine import Engine as _E
+    monkeypatch.delenv("ITSXPRESS_STREAM")
+    monkeypatch.setenv("ITSX_STREAM_AUTO_MB", "0.01")
+    for arrays, want in (("1", StreamEngine), ("0", _E)):
+        monkeypatch.setenv("ITSXPRESS_ARRAYS", arrays)
+        sa = S.SeqSampleNotPaired(fastq=plain, tempdir=os.path.join(tmp, "auto" + arrays))
+        _OPEN.append(sa)
+        assert type(sa.engine) is want
+    monkeypatch.setenv("ITSX_STREAM_AUTO_MB", "512")
+    sa = S.SeqSampleNotPaired(fastq=plain, tempdir=os.path.join(tmp, "auto_small"))
+    monkeypatch.setenv("ITSXPRESS_ARRAYS", "1")
+    _OPEN.append(sa)
+    assert type(sa.engine) is _E                              # (a 150-KB file)
     # greedy clustering (cluster_id < 1) is sequential by definition: under ITSXPRESS_STREAM the mirror runs it on one plain engine
     from itsxpress_amd.engine import Engine
     monkeypatch.setenv("ITSXPRESS_STREAM", "1")

@@ -238,6 +238,11 @@ int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const
                        char *out_seq, char *out_qual, int32_t *out_len, int32_t *reason, double *score, int32_t *shift);
 int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_path, const char *out_path, int maxdiffs, double maxee,
                            int allow_stagger, int64_t *n_pairs, int64_t *n_merged);
+/* the same merge with the merged reads left as the context's read set (labels: R1 identifiers of the merged pairs, input order): no
+ * seq.fq is written and nothing is parsed again; the merged bases stay on the device.  What an arrays-mode caller uses in place of
+ * itsx_merge_pairs_files + itsx_load_reads_file. */
+int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_path, int maxdiffs, double maxee, int allow_stagger,
+                          int64_t *n_pairs, int64_t *n_merged);
 int itsx_merge_tables(double *q2p, double *match, double *mism, uint8_t *qsame, uint8_t *qdiff);
 
 /* ---- a1: SeqSample.deduplicate (itsxpress/SeqSample.py:93-131)

@@ -252,8 +252,21 @@ class SeqSamplePairedNotInterleaved(SeqSample):
                 raise ValueError("Both r1 and fastq2 paths must be defined to merge reads.")
             os.makedirs(self.tempdir, exist_ok=True)
             seq_file = os.path.join(self.tempdir, "seq.fq")
-            n, m = self.engine.merge_pairs_files(self.r1, self.fastq2, seq_file, maxdiffs=maxmismatches, maxee=2.0,
-                                                 allow_stagger=bool(stagger))
+            eng = self.engine
+            if self._is_fast() and not hasattr(eng, "merge_pairs_load") and hasattr(eng, "_plain"):
+                # arrays mode on a streaming engine: the merged reads live in ONE context (nothing of a merged sample is inflated
+                # while it is scored: the merge needs both files whole) -- that context is the sample's engine from here on
+                plain = eng._plain()
+                eng._plain_eng = None
+                eng.close()
+                self._engine = eng = plain
+            if self._is_fast() and hasattr(eng, "merge_pairs_load"):
+                # arrays mode: the merged reads become the engine's read set where the merge kernel left them; no seq.fq, no second parse
+                n, m = eng.merge_pairs_load(self.r1, self.fastq2, maxdiffs=maxmismatches, maxee=2.0, allow_stagger=bool(stagger))
+                self._reads_loaded_from = seq_file
+            else:
+                n, m = eng.merge_pairs_files(self.r1, self.fastq2, seq_file, maxdiffs=maxmismatches, maxee=2.0,
+                                             allow_stagger=bool(stagger))
             logging.info("%d pairs, %d merged", n, m)
             self.seq_file = seq_file
         except EngineError as e:

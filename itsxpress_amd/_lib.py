@@ -65,7 +65,7 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
            "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath", "itsx_debug_logf", "itsx_debug_dust", "itsx_debug_calibrate",
            "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
-           "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_tables",
+           "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_pairs_load", "itsx_merge_tables",
            "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq",
            "itsx_io_read", "itsx_io_free", "itsx_io_codecs", "itsx_fastq_ids",
            "itsx_load_reads_files", "itsx_set_samples", "itsx_num_samples", "itsx_select_sample",
@@ -137,6 +137,7 @@ def lib():
         "itsx_get_cluster": (i32, [vp, vp, vp, vp]),
         "itsx_merge_buffers": (i32, [vp, cp, cp, vp, cp, cp, vp, i64, i32, f64, i32, vp, vp, vp, vp, vp, vp]),
         "itsx_merge_pairs_files": (i32, [vp, cp, cp, cp, i32, f64, i32, vp, vp]),
+        "itsx_merge_pairs_load": (i32, [vp, cp, cp, i32, f64, i32, vp, vp]),
         "itsx_merge_tables": (i32, [vp, vp, vp, vp, vp]),
         "itsx_orient_load_db": (i32, [vp, cp, vp]),
         "itsx_orient": (i32, [vp, vp, vp, vp]),

@@ -71,6 +71,16 @@ __global__ void k_waves_build(int nw, int P, const int32_t *__restrict__ order, 
   for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(lane_rows, mine);
 }
+// merged read j out of the merge kernel's output (pair i's bases sit at foff[i] + roff[i]) into a gap-free text: one wave per read
+__global__ void __launch_bounds__(256) k_gather_reads(const uint8_t *__restrict__ src, const int64_t *__restrict__ srcoff, const int64_t *__restrict__ dstoff, int64_t m,
+                                                      uint8_t *__restrict__ dst)
+{
+  const int lane = threadIdx.x & 63;
+  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < m; j += (int64_t)gridDim.x * 4) {
+    const int64_t so = srcoff[j], d0 = dstoff[j], len = dstoff[j + 1] - d0;
+    for (int64_t k = lane; k < len; k += 64) dst[d0 + k] = src[so + k];
+  }
+}
 __global__ void k_wave_rows_regions(const WaveDesc *w, int nw, const RegionRec *rg, int32_t *rows)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2766,11 +2776,13 @@ int itsx_merge_tables(double *q2p, double *match, double *mism, uint8_t *qsame, 
   return ITSX_OK;
 }
 
-int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const int64_t *foff, const char *rseq, const char *rqual,
-                       const int64_t *roff, int64_t n, int maxdiffs, double maxee, int allow_stagger,
-                       char *out_seq, char *out_qual, int32_t *out_len, int32_t *reason, double *score, int32_t *shift)
+// keep_os (may be null): the merged bases stay in device memory (taken over by *keep_os; pair i's at foff[i] + roff[i]) and are not copied
+// back -- itsx_merge_pairs_load packs them where they are
+static int merge_core(itsx_ctx *ctx, const char *fseq, const char *fqual, const int64_t *foff, const char *rseq, const char *rqual,
+                      const int64_t *roff, int64_t n, int maxdiffs, double maxee, int allow_stagger,
+                      char *out_seq, char *out_qual, int32_t *out_len, int32_t *reason, double *score, int32_t *shift, DBuf<uint8_t> *keep_os)
 {
-  CTXCHK(ctx && foff && roff && n >= 0 && out_len && reason && (n == 0 || (fseq && fqual && rseq && rqual && out_seq && out_qual)));
+  CTXCHK(ctx && foff && roff && n >= 0 && out_len && reason && (n == 0 || (fseq && fqual && rseq && rqual && (keep_os || (out_seq && out_qual)))));
   HIPCHK(hipSetDevice(ctx->device));
   if (n == 0) return ITSX_OK;
   const int64_t fb = foff[n], rb = roff[n];
@@ -2781,8 +2793,19 @@ int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const
     max_total = std::max(max_total, fl + rl);
   }
   if (max_total > 12000) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "read pairs longer than 12000 bases in total are not supported by the merge kernel");
-  for (int64_t i = 0; i < fb; i++) if ((unsigned char)fqual[i] < 33 || (unsigned char)fqual[i] > 126) SET_ERR(ctx, ITSX_E_FORMAT, "forward quality outside ASCII 33..126 (--fastq_qmax 93)");
-  for (int64_t i = 0; i < rb; i++) if ((unsigned char)rqual[i] < 33 || (unsigned char)rqual[i] > 126) SET_ERR(ctx, ITSX_E_FORMAT, "reverse quality outside ASCII 33..126 (--fastq_qmax 93)");
+  {   // every quality byte is looked at once (a gigabyte per million pairs: a pool of threads, not one)
+    std::atomic<int> badf{0}, badr{0};
+    const int T = (fb + rb) >= ((int64_t)8 << 20) ? std::max(1, std::min(itsx_io::io_threads(), 16)) : 1;
+    on_threads(T, [&](int t) {
+      int bf = 0, br = 0;
+      for (int64_t i = fb * t / T, e = fb * (t + 1) / T; i < e; i++) bf |= ((unsigned char)fqual[i] < 33) | ((unsigned char)fqual[i] > 126);
+      for (int64_t i = rb * t / T, e = rb * (t + 1) / T; i < e; i++) br |= ((unsigned char)rqual[i] < 33) | ((unsigned char)rqual[i] > 126);
+      if (bf) badf = 1;
+      if (br) badr = 1;
+    });
+    if (badf) SET_ERR(ctx, ITSX_E_FORMAT, "forward quality outside ASCII 33..126 (--fastq_qmax 93)");
+    if (badr) SET_ERR(ctx, ITSX_E_FORMAT, "reverse quality outside ASCII 33..126 (--fastq_qmax 93)");
+  }
   const MergeTables &t = merge_tables();
   DBuf<uint8_t> d_fs, d_fq, d_rs, d_rq, d_os, d_oq, d_qs, d_qd; DBuf<int64_t> d_fo, d_ro; DBuf<int32_t> d_len, d_reason, d_shift; DBuf<double> d_q2p, d_m, d_x, d_score;
   HIPCHK(d_fs.alloc((size_t)fb + 1)); HIPCHK(d_fq.alloc((size_t)fb + 1)); HIPCHK(d_rs.alloc((size_t)rb + 1)); HIPCHK(d_rq.alloc((size_t)rb + 1));
@@ -2802,12 +2825,21 @@ int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const
   launch_merge(a, ctx->st);
   ctx->stats.ms_merge = tm.stop();
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out_seq, d_os.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st)); HIPCHK(hipMemcpyAsync(out_qual, d_oq.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st));
+  if (out_seq) HIPCHK(hipMemcpyAsync(out_seq, d_os.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st));
+  if (out_qual) HIPCHK(hipMemcpyAsync(out_qual, d_oq.p, (size_t)(fb + rb), hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipMemcpyAsync(out_len, d_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st)); HIPCHK(hipMemcpyAsync(reason, d_reason.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
   if (score) HIPCHK(hipMemcpyAsync(score, d_score.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->st));
   if (shift) HIPCHK(hipMemcpyAsync(shift, d_shift.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->st));
   HIPCHK(hipStreamSynchronize(ctx->st));
+  if (keep_os) { std::swap(keep_os->p, d_os.p); std::swap(keep_os->n, d_os.n); std::swap(keep_os->cap, d_os.cap); }
   return ITSX_OK;
+}
+int itsx_merge_buffers(itsx_ctx *ctx, const char *fseq, const char *fqual, const int64_t *foff, const char *rseq, const char *rqual,
+                       const int64_t *roff, int64_t n, int maxdiffs, double maxee, int allow_stagger,
+                       char *out_seq, char *out_qual, int32_t *out_len, int32_t *reason, double *score, int32_t *shift)
+{
+  CTXCHK(ctx && (n == 0 || (out_seq && out_qual)));
+  return merge_core(ctx, fseq, fqual, foff, rseq, rqual, roff, n, maxdiffs, maxee, allow_stagger, out_seq, out_qual, out_len, reason, score, shift, nullptr);
 }
 
 // FASTQ in, FASTQ out: R1/R2 (plain or gzip) -> merged reads, labels = forward read's identifier up to the first blank
@@ -2867,6 +2899,72 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   if (n_pairs) *n_pairs = n;
   if (n_merged) *n_merged = merged;
   return ITSX_OK;
+}
+
+// R1/R2 -> merged reads as THIS CONTEXT'S READ SET (arrays mode: nothing written, nothing parsed again).  The reference writes the merged
+// reads to tempdir/seq.fq and vsearch reads them back (SeqSample.py:266-365, 93-131); here the merge kernel's output is gathered into
+// a gap-free text on the device and packed where it is -- the merged bases never visit the host, the merged qualities are not needed at
+// all (the paired writer slices the ORIGINAL R1 / R2 records with the merged reads' coordinates).  Labels = R1 identifiers of the merged
+// pairs, in input order, as itsx_merge_pairs_files writes them.
+int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_path, int maxdiffs, double maxee, int allow_stagger, int64_t *n_pairs, int64_t *n_merged)
+{
+  CTXCHK(ctx && r1_path && r2_path);
+  typedef FastxPart Side;
+  auto parse = [](const char *path, Side &sd, std::string &perr) -> int {
+    const auto tp = slurp(path, true, perr);
+    if (!tp) return ITSX_E_IO;
+    if (!tp->empty() && (*tp)[0] != '@') { perr = std::string("malformed FASTQ record 1 in ") + path; return ITSX_E_FORMAT; }
+    const int prc = parse_fastx(*tp, true, true, sd, perr);
+    if (prc != ITSX_OK) perr += std::string(" in ") + path;
+    return prc;
+  };
+  Side f, r;
+  std::string ferr, rerr2;
+  int rc2 = ITSX_OK;
+  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  const auto tm0 = std::chrono::steady_clock::now();
+  std::thread other([&] { rc2 = parse(r2_path, r, rerr2); });
+  int rc = parse(r1_path, f, ferr);
+  other.join();
+  const auto tm1 = std::chrono::steady_clock::now();
+  if (rc != ITSX_OK) { ctx->set_error(ferr); return rc; }
+  if (rc2 != ITSX_OK) { ctx->set_error(rerr2); return rc2; }
+  if (f.ids.size() != r.ids.size()) SET_ERR(ctx, ITSX_E_FORMAT, "R1 and R2 hold different numbers of records");
+  const int64_t n = (int64_t)f.ids.size();
+  std::vector<int32_t> olen((size_t)n + 1), reason((size_t)n + 1);
+  DBuf<uint8_t> d_os;
+  rc = merge_core(ctx, f.seq.data(), f.qual.data(), f.off.data(), r.seq.data(), r.qual.data(), r.off.data(), n, maxdiffs, maxee, allow_stagger,
+                  nullptr, nullptr, olen.data(), reason.data(), nullptr, nullptr, &d_os);
+  if (rc != ITSX_OK) return rc;
+  const auto tm2 = std::chrono::steady_clock::now();
+  hipStream_t st = ctx->st;
+  std::vector<int64_t> srcoff, dstoff(1, 0);
+  ctx->h_names.clear();
+  for (int64_t i = 0; i < n; i++) {
+    if (reason[i] != 0) continue;
+    srcoff.push_back(f.off[i] + r.off[i]);
+    dstoff.push_back(dstoff.back() + olen[i]);
+    ctx->h_names.emplace_back(std::move(f.ids[i]));
+  }
+  const int64_t m = (int64_t)srcoff.size();
+  if (m >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
+  DBuf<int64_t> d_src, d_dst; DBuf<uint8_t> d_cmp;
+  HIPCHK(upload(d_src, srcoff, st)); HIPCHK(upload(d_dst, dstoff, st)); HIPCHK(d_cmp.alloc((size_t)dstoff.back() + 64));
+  if (m > 0) hipLaunchKernelGGL(k_gather_reads, dim3((unsigned)std::min<int64_t>((m + 3) / 4, 65535)), dim3(256), 0, st, d_os.p, d_src.p, d_dst.p, m, d_cmp.p);
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  ctx->N = m;
+  ctx->h_off.swap(dstoff);
+  std::string().swap(ctx->h_bases);
+  static const uint8_t none = 0;
+  rc = pack_and_upload(ctx, nullptr, m > 0 ? d_cmp.p : &none);
+  if (trace) {
+    const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[itsx] merge + load: read+inflate+parse %.0f ms, upload+kernel %.0f ms, gather+pack %.0f ms\n", ms(tm0, tm1), ms(tm1, tm2), ms(tm2, std::chrono::steady_clock::now()));
+  }
+  if (n_pairs) *n_pairs = n;
+  if (n_merged) *n_merged = m;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------ coordinates

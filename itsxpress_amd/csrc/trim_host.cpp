@@ -10,6 +10,7 @@
 // included); --trim-ccs primer stitching with quality 93; the title line is written back verbatim and the
 // '+' line is bare, as Biopython's FASTQ writer does.  Pinned byte-for-byte by the reference's t2_r1.fq /
 // t2_r2.fq goldens (tests/test_trim_cpu.py).
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -472,34 +473,168 @@ int itsx_twriter_close(itsx_twriter *w, int64_t *n_written, int64_t *total_len)
   return rc;
 }
 
+// the merged reads' labels -> their index, without a string per label: open addressing over a 64-bit hash, the label bytes compared
+// on a hit (a std::unordered_map<std::string, ...> of 10 M labels was a second of allocations on one thread)
+struct NameIndex {
+  const char *names; const int64_t *offs; int64_t n; std::vector<int64_t> slot; uint64_t mask = 0;
+  static uint64_t hash(const char *p, size_t len)
+  {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < len; i++) { h ^= (unsigned char)p[i]; h *= 0x100000001b3ull; }
+    return h ^ (h >> 29);
+  }
+  void build(const char *nm, const int64_t *of, int64_t count)
+  {
+    names = nm; offs = of; n = count;
+    size_t cap = 16; while (cap < (size_t)count * 2) cap <<= 1;
+    slot.assign(cap, -1); mask = cap - 1;
+    for (int64_t i = 0; i < count; i++) {
+      uint64_t h = hash(nm + of[i], (size_t)(of[i + 1] - of[i])) & mask;
+      // (the first of equal labels wins, as emplace() kept it)
+      for (;;) {
+        const int64_t j = slot[h];
+        if (j < 0) { slot[h] = i; break; }
+        if (of[j + 1] - of[j] == of[i + 1] - of[i] && memcmp(nm + of[j], nm + of[i], (size_t)(of[i + 1] - of[i])) == 0) break;
+        h = (h + 1) & mask;
+      }
+    }
+  }
+  int64_t find(const char *p, size_t len) const
+  {
+    uint64_t h = hash(p, len) & mask;
+    for (;;) {
+      const int64_t j = slot[h];
+      if (j < 0) return -1;
+      if ((size_t)(offs[j + 1] - offs[j]) == len && memcmp(names + offs[j], p, len) == 0) return j;
+      h = (h + 1) & mask;
+    }
+  }
+};
+
 int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const char *out1_path, const char *out2_path,
                               int compression, int trim_ccs, const char *names, const int64_t *name_offsets, int64_t n_names,
                               const int32_t *start, const int32_t *stop, const int32_t *tlen, int64_t *n_written)
 {
   if (!r1_path || !r2_path || !out1_path || !out2_path || !names || !name_offsets || !start || !stop || !tlen) { g_trim_error = "null argument"; return ITSX_E_ARG; }
-  std::unordered_map<std::string, int64_t> idx;
-  idx.reserve((size_t)n_names * 2);
-  for (int64_t i = 0; i < n_names; i++) idx.emplace(std::string(names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i])), i);
   if (compression < 0 || compression > 2) { g_trim_error = "compression must be 0 (plain), 1 (gzip) or 2 (zstd)"; return ITSX_E_ARG; }
+  NameIndex idx;
+  idx.build(names, name_offsets, n_names);
   Records in1, in2; Writer o1, o2;
   if (!in1.open(r1_path) || !in2.open(r2_path)) return ITSX_E_IO;
   if (!o1.open(out1_path, compression) || !o2.open(out2_path, compression)) return ITSX_E_IO;
+  const bool ccs = trim_ccs != 0;
+  // one pair of records -> its two trimmed records (appended to the two buffers), as the serial walk below emits them
+  auto one_pair = [&](const Rec &a, const Rec &b, std::string &b1, std::string &b2) -> bool {
+    size_t e0 = 1; while (e0 < a.title.n && a.title.p[e0] != ' ' && a.title.p[e0] != '\t') e0++;
+    const int64_t k = idx.find(a.title.p + 1, e0 - 1);
+    if (k < 0) return false;
+    const int64_t s = start[k], e = stop[k], t = tlen[k];
+    if (s < 0 || e < 0 || !(s < e)) return false;
+    const int64_t r2start = t - e, r2end = t - s;
+    static const char *fwd = "GACAGGTACAAGAAGGA", *rev = "TTAACCCAGTCTCCAGT";
+    auto put = [&](std::string &out, const Rec &r, int64_t lo, int64_t hi) {
+      out.append(r.title.p, r.title.n); out += '\n';
+      if (ccs) out += fwd;
+      out.append(r.seq.p + lo, (size_t)(hi - lo));
+      if (ccs) out += rev;
+      out += "\n+\n";
+      if (ccs) out.append(17, '~');
+      out.append(r.qual.p + lo, (size_t)(hi - lo));
+      if (ccs) out.append(17, '~');
+      out += '\n';
+    };
+    int64_t lo, hi;
+    py_slice((int64_t)a.seq.size(), s, e, e > t, lo, hi);
+    put(b1, a, lo, hi);
+    py_slice((int64_t)b.seq.size(), r2start, r2end, r2end > t, lo, hi);
+    put(b2, b, lo, hi);
+    return true;
+  };
+  // Large inputs: R1 is cut into ranges at record starts, a counting pass gives every range its first record's number, R2 is cut at
+  // the SAME record numbers (its ranges' own counts say in which range a number lies; the worker walks to it), and a pool of threads
+  // slices the ranges; their outputs go to the two block writers in order -- the bytes of the serial walk.
+  const int T = itsx_io::io_threads();
+  const size_t size1 = (size_t)(in1.end - in1.s), size2 = (size_t)(in2.end - in2.s);
+  const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : (size_t)32 << 20;
+  if (T > 1 && size1 >= min_par && size2 > 0) {
+    const size_t range = getenv("ITSX_WRITE_UNIT_KB") ? (size_t)atoll(getenv("ITSX_WRITE_UNIT_KB")) << 10 : (size_t)8 << 20;
+    auto cuts_of = [&](const char *t0, const char *tend, std::vector<const char *> &cut) {
+      const size_t size = (size_t)(tend - t0);
+      cut.assign(1, t0);
+      for (size_t at = range; at < size; at += range) {
+        const char *p = (const char *)memchr(t0 + at, '\n', size - at);
+        while (p && p + 1 < tend && !fastq_record_start(t0, tend, p + 1)) p = (const char *)memchr(p + 1, '\n', (size_t)(tend - (p + 1)));
+        if (!p || p + 1 >= tend) break;
+        if (p + 1 > cut.back()) cut.push_back(p + 1);
+      }
+      cut.push_back(tend);
+    };
+    std::vector<const char *> c1, c2;
+    cuts_of(in1.s, in1.end, c1); cuts_of(in2.s, in2.end, c2);
+    const size_t K1 = c1.size() - 1, K2 = c2.size() - 1;
+    std::vector<int64_t> f1(K1 + 1, 0), f2(K2 + 1, 0);
+    std::atomic<int> bad{0};
+    std::atomic<size_t> next{0};
+    auto pool = [&](size_t K, auto fn) {
+      std::vector<std::thread> th;
+      next = 0;
+      for (int t = 0; t < T; t++) th.emplace_back([&] { for (size_t k = next.fetch_add(1); k < K; k = next.fetch_add(1)) fn(k); });
+      for (auto &x : th) x.join();
+    };
+    auto count = [&](const std::vector<const char *> &c, std::vector<int64_t> &f) {
+      return [&](size_t k) { Records r; r.s = c[k]; r.end = c[k + 1]; Rec rec; int64_t n = 0; int rc; while ((rc = r.next(rec)) == 1) n++; if (rc < 0) bad = 1; f[k + 1] = n; };
+    };
+    pool(K1, count(c1, f1));
+    pool(K2, count(c2, f2));
+    if (!bad) {
+      for (size_t k = 0; k < K1; k++) f1[k + 1] += f1[k];
+      for (size_t k = 0; k < K2; k++) f2[k + 1] += f2[k];
+      const int64_t npairs = std::min(f1[K1], f2[K2]);            // zip(): stops at the shorter file
+      int64_t nw = 0;
+      for (size_t k0 = 0; k0 < K1 && !bad; k0 += (size_t)T) {
+        const size_t k1 = std::min(K1, k0 + (size_t)T);
+        std::vector<std::string> p1(k1 - k0), p2(k1 - k0);
+        std::vector<int64_t> pn(k1 - k0, 0);
+        std::vector<std::thread> th;
+        for (size_t k = k0; k < k1; k++)
+          th.emplace_back([&, k] {
+            const int64_t first = f1[k], last = std::min(f1[k + 1], npairs);
+            if (first >= last) return;
+            Records ra; ra.s = c1[k]; ra.end = c1[k + 1];
+            // R2 at record `first`: the range that holds it, then a walk
+            size_t q = (size_t)(std::upper_bound(f2.begin(), f2.end(), first) - f2.begin()) - 1;
+            if (q >= K2) { bad = 1; return; }
+            Records rb; rb.s = c2[q]; rb.end = in2.end;
+            Rec a, b; int rc;
+            for (int64_t skip = first - f2[q]; skip > 0; skip--) if ((rc = rb.next(b)) != 1) { bad = 1; return; }
+            std::string &b1 = p1[k - k0], &b2 = p2[k - k0];
+            b1.reserve((size_t)(c1[k + 1] - c1[k]) / 2 + 4096); b2.reserve(b1.capacity());
+            for (int64_t i = first; i < last; i++) {
+              if (ra.next(a) != 1 || rb.next(b) != 1) { bad = 1; return; }
+              if (one_pair(a, b, b1, b2)) pn[k - k0]++;
+            }
+          });
+        for (auto &x : th) x.join();
+        for (size_t k = k0; k < k1 && !bad; k++) { o1.w.put(p1[k - k0]); o2.w.put(p2[k - k0]); nw += pn[k - k0]; }
+      }
+      if (!bad) {
+        if (!o1.close() || !o2.close()) return ITSX_E_IO;
+        if (n_written) *n_written = nw;
+        return ITSX_OK;
+      }
+    }
+    // a malformed record somewhere: the serial walk below names it (the output files are started again)
+    { std::string e; o1.w.close(e); o2.w.close(e); }
+    if (!o1.open(out1_path, compression) || !o2.open(out2_path, compression)) return ITSX_E_IO;
+  }
   Rec a, b; int64_t nw = 0, k = 0; int ra, rb;
   for (;;) {
     ra = in1.next(a); rb = in2.next(b);
     if (ra != 1 || rb != 1) break;            // zip(): stops at the shorter file
     k++;
-    auto it = idx.find(id_of(a.title));
-    if (it == idx.end()) continue;
-    const int64_t s = start[it->second], e = stop[it->second], t = tlen[it->second];
-    if (s < 0 || e < 0 || !(s < e)) continue;
-    const int64_t r2start = t - e, r2end = t - s;
-    int64_t lo, hi;
-    py_slice((int64_t)a.seq.size(), s, e, e > t, lo, hi);
-    emit(o1, a.title, a.seq.p, a.qual.p, lo, hi, trim_ccs != 0, nullptr);
-    py_slice((int64_t)b.seq.size(), r2start, r2end, r2end > t, lo, hi);
-    emit(o2, b.title, b.seq.p, b.qual.p, lo, hi, trim_ccs != 0, nullptr);
-    nw++;
+    if (one_pair(a, b, o1.buf, o2.buf)) nw++;
+    if (o1.buf.size() >= (1u << 20) - 4096) o1.flush();
+    if (o2.buf.size() >= (1u << 20) - 4096) o2.flush();
   }
   if (ra < 0 || rb < 0) { g_trim_error = "malformed FASTQ record near pair " + std::to_string(k); return ITSX_E_FORMAT; }
   if (!o1.close() || !o2.close()) return ITSX_E_IO;

@@ -261,6 +261,18 @@ class Engine:
                                                 float(maxee), int(allow_stagger), C.byref(n), C.byref(m)))
         return n.value, m.value
 
+    def merge_pairs_load(self, r1, r2, maxdiffs=40, maxee=2.0, allow_stagger=False):
+        """merge R1 / R2 and leave the merged reads as this engine's read set (nothing written): (pairs, merged)"""
+        for p in (r1, r2):
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+        n = C.c_int64(0)
+        m = C.c_int64(0)
+        self._chk(self.L.itsx_merge_pairs_load(self.h, os.fsencode(r1), os.fsencode(r2), int(maxdiffs), float(maxee), int(allow_stagger),
+                                               C.byref(n), C.byref(m)))
+        self.n_reads, self.n_samples, self.n_unique = m.value, 1, 0
+        return n.value, m.value
+
     def get_cluster(self):
         """After cluster(id < 1): (pct_id float64[n_reads] (-1 for centroids / dropped), order int64[kept])."""
         pct = np.zeros(self.n_reads, np.float64)

@@ -256,6 +256,8 @@ class StreamEngine(ShardedOps):
         for eng, _ in getattr(self, "_engs", []):
             eng.close()
         self._engs = []
+        if getattr(self, "_plain_eng", None) is not None and not getattr(self, "_keep_plain", False):
+            pass                                          # (the plain engine of the unstreamed stages lives as long as this object)
         if getattr(self, "_stream", None) is not None:
             try:
                 self._stream.close(keep=True)

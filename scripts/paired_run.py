@@ -92,7 +92,8 @@ def main():
         t["merge"] = time.perf_counter() - t0
         t0 = time.perf_counter()
         if args.array_path:
-            eng.load_reads_file(s.seq_file)
+            if getattr(s, "_reads_loaded_from", None) != s.seq_file:      # (ITSXPRESS_ARRAYS=1: the merge left its reads in the engine)
+                eng.load_reads_file(s.seq_file)
             nu = eng.derep()
             t["derep"] = time.perf_counter() - t0
             t0 = time.perf_counter()

@@ -127,3 +127,36 @@ def test_merge_files_and_mirror(engine, gold, tmp_path, mini_hmm_text):
     assert outs[0] == outs[1] and outs[0][0] == int(((start >= 0) & (stop >= 0) & (start < stop)).sum())
     with pytest.raises(FileNotFoundError):
         SeqSamplePairedNotInterleaved(fastq=r1, tempdir=str(tmp_path), fastq2=str(tmp_path / "nope.fq"))._merge_reads(threads=1)
+
+
+def test_merge_into_the_engines_read_set(engine, gold, tmp_path, t_hmm_text, monkeypatch):
+    """arrays mode: _merge_reads leaves the merged reads as the engine's read set (itsx_merge_pairs_load: gathered and packed on the
+    device, no seq.fq) -- the same reads, labels, dereplication, coordinates and trimmed pairs as through the file"""
+    from itsxpress_amd.SeqSample import SeqSamplePairedNotInterleaved, Dedup, ItsPosition
+    r1, r2 = os.path.join(gold, "4774-1-MSITS3_R1.fastq.gz"), os.path.join(gold, "4774-1-MSITS3_R2.fastq.gz")
+    from bench import its2_profiles
+    hmm = tmp_path / "its2.hmm"
+    hmm.write_text(its2_profiles(t_hmm_text))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ITSXPRESS_ARRAYS", mode)
+        monkeypatch.setenv("ITSXPRESS_STREAM", "0")
+        d = tmp_path / ("arrays" + mode)
+        s = SeqSamplePairedNotInterleaved(fastq=r1, tempdir=str(d), fastq2=r2)
+        s._merge_reads(threads=1, stagger=False)
+        assert os.path.exists(d / "seq.fq") == (mode == "0")                 # nothing written in arrays mode
+        s.deduplicate(threads=1)
+        s._search(hmmfile=str(hmm), threads=1)
+        pos = ItsPosition(domtable=s.dom_file, region="ITS2")
+        dd = Dedup(uc_file=s.uc_file, rep_file=s.rep_file, seq_file=s.seq_file, fastq=s.r1, fastq2=s.fastq2)
+        o1, o2 = str(d / "o1.fq"), str(d / "o2.fq")
+        dd.create_paired_trimmed_seqs(o1, o2, gzipped=False, zstd_file=False, itspos=pos, wri_file=True)
+        rep_of, strand, uniq_of = s.engine.get_derep()
+        res[mode] = (s.engine.read_names(), rep_of.copy(), strand.copy(), [np.asarray(c).copy() for c in s.trim_coordinates("ITS2")],
+                     open(o1, "rb").read(), open(o2, "rb").read())
+        s._engine.close()
+    a, b = res["0"], res["1"]
+    assert a[0] == b[0] and len(a[0]) == 236
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+    assert a[4] == b[4] and a[5] == b[5] and len(a[4]) > 1000

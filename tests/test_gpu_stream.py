@@ -226,12 +226,12 @@ def test_paired_end_through_the_streaming_engine(tmp_path, t_hmm_text, monkeypat
         raw.append(p)
     monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "0.02")           # the merged file is ~100 KB: a handful of chunks
     outs = {}
-    for name, stream in (("one", False), ("stream", True)):
+    for name, stream, arrays in (("one", False, "1"), ("stream", True, "0"), ("stream_arrays", True, "1")):
         d = os.path.join(tmp, name)
         os.makedirs(d, exist_ok=True)
         monkeypatch.setenv("ITSXPRESS_GPUS", "1")
         monkeypatch.setenv("ITSXPRESS_STREAM", "1" if stream else "0")
-        monkeypatch.setenv("ITSXPRESS_ARRAYS", "1")
+        monkeypatch.setenv("ITSXPRESS_ARRAYS", arrays)
         sobj = S.SeqSamplePairedNotInterleaved(fastq=raw[0], tempdir=d, fastq2=raw[1])
         _OPEN.append(sobj)
         sobj._merge_reads(threads=1)
@@ -242,11 +242,15 @@ def test_paired_end_through_the_streaming_engine(tmp_path, t_hmm_text, monkeypat
         o1, o2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
         dd.create_paired_trimmed_seqs(o1, o2, gzipped=False, zstd_file=False, itspos=its_pos, wri_file=True)
         outs[name] = (open(o1, "rb").read(), open(o2, "rb").read(), [np.asarray(c).copy() for c in sobj.trim_coordinates("ITS2")])
-        if stream:
-            from itsxpress_amd.stream import StreamEngine
+        from itsxpress_amd.stream import StreamEngine
+        from itsxpress_amd.engine import Engine as _E
+        if stream and arrays == "0":                     # through seq.fq: the merged file is cut from the cache, chunk by chunk
             assert isinstance(sobj._engine, StreamEngine) and sobj._engine.world >= 3, sobj._engine.world
-    assert outs["one"][0] == outs["stream"][0] and outs["one"][1] == outs["stream"][1] and len(outs["one"][0]) > 1000
-    assert all(np.array_equal(x, y) for x, y in zip(outs["one"][2], outs["stream"][2]))
+        if stream and arrays == "1":                     # arrays mode: the merged reads live in one plain context (no seq.fq at all)
+            assert type(sobj._engine) is _E and not os.path.exists(os.path.join(d, "seq.fq"))
+    for other in ("stream", "stream_arrays"):
+        assert outs["one"][0] == outs[other][0] and outs["one"][1] == outs[other][1] and len(outs["one"][0]) > 1000
+        assert all(np.array_equal(x, y) for x, y in zip(outs["one"][2], outs[other][2]))
 
 
 def test_stream_that_outgrows_its_reservation_starts_over_serially(tmp_path, t_hmm_text, monkeypatch):

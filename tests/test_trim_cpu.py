@@ -275,3 +275,54 @@ def test_writer_object_fed_piece_by_piece_writes_the_same_file(tmp_path, monkeyp
     assert L.itsx_twriter_coords(w, 5, 1, start.ctypes.data, stop.ctypes.data, None) == -1
     L.itsx_twriter_text(w, None, 0, 1)
     assert L.itsx_twriter_close(w, None, None) == 0
+
+
+def test_parallel_paired_writer_writes_the_same_bytes(tmp_path, monkeypatch):
+    """large R1 / R2 are cut at the same record numbers and sliced by a pool of threads (R2's records have other sizes than R1's: a
+    range of R2 starts inside another of its byte ranges); labels go through a hash index; same bytes as the serial walk, also when
+    R2 is the longer file, when labels repeat and when most pairs are dropped"""
+    rng = np.random.default_rng(21)
+    n = 7000
+    r1, r2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    names = []
+    with open(r1, "w") as f1, open(r2, "w") as f2:
+        for i in range(n + 50):                                   # R2 holds 50 records more: zip() stops at R1's end
+            l1, l2 = int(rng.integers(30, 260)), int(rng.integers(200, 400))
+            nm = "M0:%d:%d" % (i // 100, i % 100)
+            q1 = "".join(rng.choice(list("@+IF#5"), l1)); q2 = "".join(rng.choice(list("@+IF#5"), l2))
+            if i < n:
+                f1.write("@%s 1:N:0\n%s\n+\n%s\n" % (nm, "".join(rng.choice(list("ACGT"), l1)), q1))
+                names.append(nm)
+            f2.write("@%s 2:N:0\n%s\n+\n%s\n" % (nm, "".join(rng.choice(list("ACGT"), l2)), q2))
+    keep = np.flatnonzero(rng.random(n) < 0.8)                    # the merged reads: a subsequence of the pairs
+    mnames = [names[i] for i in keep] + [names[int(keep[0])]]     # (one label twice: the first entry counts)
+    m = len(mnames)
+    start = rng.integers(-1, 60, m).astype(np.int32)
+    stop = rng.integers(-1, 300, m).astype(np.int32)
+    tlen = rng.integers(250, 480, m).astype(np.int32)
+    out = {}
+    for mode, env in (("serial", {"ITSX_IO_THREADS": "1"}), ("parallel", {"ITSX_IO_THREADS": "5", "ITSX_WRITE_MIN_MB": "0", "ITSX_WRITE_UNIT_KB": "48"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for kind, kw in (("plain", {}), ("ccs", {"trim_ccs": True})):
+            o1, o2 = tmp_path / ("%s_%s_1.fq" % (mode, kind)), tmp_path / ("%s_%s_2.fq" % (mode, kind))
+            nw = write_trimmed_paired(str(r1), str(r2), str(o1), str(o2), mnames, start, stop, tlen, **kw)
+            out[(mode, kind)] = (nw, o1.read_bytes(), o2.read_bytes())
+        o1, o2 = tmp_path / (mode + "_1.fq.gz"), tmp_path / (mode + "_2.fq.gz")
+        nw = write_trimmed_paired(str(r1), str(r2), str(o1), str(o2), mnames, start, stop, tlen, gzipped=True)
+        out[(mode, "gz")] = (nw, gzip.decompress(o1.read_bytes()), gzip.decompress(o2.read_bytes()))
+        for k in env:
+            monkeypatch.delenv(k)
+    for kind in ("plain", "ccs", "gz"):
+        assert out[("serial", kind)] == out[("parallel", kind)], kind
+    assert out[("serial", "gz")][1:] == out[("serial", "plain")][1:] and out[("serial", "plain")][0] > 1000
+    # a malformed record in R2 is still reported
+    with open(r2, "a") as f2:
+        pass
+    bad = tmp_path / "bad2.fq"
+    bad.write_text(open(r2).read().replace("\n+\n", "\n-\n", 1))
+    monkeypatch.setenv("ITSX_WRITE_MIN_MB", "0")
+    monkeypatch.setenv("ITSX_WRITE_UNIT_KB", "48")
+    with pytest.raises(EngineError) as e:
+        write_trimmed_paired(str(r1), str(bad), str(tmp_path / "x1"), str(tmp_path / "x2"), mnames, start, stop, tlen)
+    assert "malformed FASTQ record" in str(e.value)

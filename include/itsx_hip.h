@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ITSX_ABI_VERSION 4      /* 4: streaming loads (itsx_stream_*, itsx_keyset_*, itsx_load_reads_text), itsx_io_cache_clear; 3: rows modes (itsx_set_rows_mode, the lazy domain stage), itsx_stats grew; 2: itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
+#define ITSX_ABI_VERSION 5      /* 5: prefix sharing (itsx_stats grew); 4: streaming loads (itsx_stream_*, itsx_keyset_*, itsx_load_reads_text), itsx_io_cache_clear; 3: rows modes (itsx_set_rows_mode, the lazy domain stage), itsx_stats grew; 2: itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
 
 enum {
   ITSX_OK            =  0,
@@ -125,6 +125,13 @@ typedef struct {
   float   ms_lazy_complete;  float lazy_bound_maxdiff;  /* ITSX_LAZY_CHECK_BOUND=1 (tests): largest |bound kernel - HMMER-order Forward| of the last search, nats */
   int64_t n_lazy_evaluated, n_lazy_round1, n_lazy_pending, n_lazy_reruns, bound_rows;
   float   ms_bound_kernel, ms_lazy_select;
+  /* prefix sharing (csrc/k_share.hip) of the last search: rows per block of the prefix tree (0: off); saved row states and chains that
+   * start from one; lane-rows the MSV filter and the lazy stage's score-only Forward pass computed (msv_rows, bound_rows) against the
+   * rows of their pairs (msv_rows_full, bound_rows_full); pairs that ran in the Forward pass only for a chain below them;
+   * ITSX_SHARE_CHECK=1 (tests): results that differ from the unshared kernels' (MSV cells, Forward scores; must be 0) */
+  int32_t share_B;           int32_t share_batches;
+  int64_t share_nodes, share_chains, msv_rows, msv_rows_full, bound_rows_full, n_share_helpers, share_mismatch;
+  float   ms_share_build;    float share_frac;          /* building the tree and the order, ms; rows the chains skip / rows of all uniques */
 } itsx_stats;
 
 int         itsx_abi_version(void);

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libitsx_hip.so")
-ABI_VERSION = 4          # include/itsx_hip.h: ITSX_ABI_VERSION
+ABI_VERSION = 5          # include/itsx_hip.h: ITSX_ABI_VERSION
 _LIB = None
 
 
@@ -52,7 +52,9 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("n_mr_fail_kind", "<i8", (8,)), ("n_rows_resident", "<i8"),
                 ("lazy", "<i4"), ("n_bound_launches", "<i4"), ("n_lazy_pending_profiles", "<i8"), ("n_lazy_completed", "<i8"), ("n_lazy_completed_profiles", "<i8"), ("n_mr_overflow", "<i8"), ("ms_lazy_complete", "<f4"), ("lazy_bound_maxdiff", "<f4"), ("n_lazy_evaluated", "<i8"), ("n_lazy_round1", "<i8"),
                 ("n_lazy_pending", "<i8"), ("n_lazy_reruns", "<i8"), ("bound_rows", "<i8"), ("ms_bound_kernel", "<f4"),
-                ("ms_lazy_select", "<f4")]
+                ("ms_lazy_select", "<f4"),
+                ("share_B", "<i4"), ("share_batches", "<i4"), ("share_nodes", "<i8"), ("share_chains", "<i8"), ("msv_rows", "<i8"), ("msv_rows_full", "<i8"),
+                ("bound_rows_full", "<i8"), ("n_share_helpers", "<i8"), ("share_mismatch", "<i8"), ("ms_share_build", "<f4"), ("share_frac", "<f4")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares

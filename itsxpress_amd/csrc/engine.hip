@@ -46,7 +46,11 @@ void launch_compact_scatter(const itsx_domain *dom, int64_t n, const int32_t *ke
 __global__ void k_wave_rows_pairs(const WaveDesc *w, int nw, const PairRec *pairs, int32_t *rows)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nw) rows[i] = pairs[w[i].first + w[i].count - 1].L + 1;       // ascending length inside a segment
+  if (i >= nw) return;
+  // (lengths ascend inside a segment -- piecewise, with prefix sharing: by (batch, depth) run -- so the longest need not be the last)
+  int mx = 0;
+  for (int k = 0; k < w[i].count; k++) mx = max(mx, pairs[w[i].first + k].L);
+  rows[i] = mx + 1;
 }
 // The wave list of a whole chunk's pairs, made where it is used: wave i covers 64 consecutive pairs of one profile's segment, the
 // profiles in launch order (`order`, waves before them in `woff`).  A million-read shard has 1.3 M waves: built on the host they were
@@ -331,6 +335,17 @@ struct itsx_ctx {
   DBuf<int32_t> w_mrsel; DBuf<int64_t> w_mrselrow; DBuf<MrBig> w_mrbig; DBuf<uint8_t> w_mrarena; DBuf<int32_t> w_mrenv; DBuf<WaveDesc> w_mrbigwaves;
   DBuf<int32_t> w_cl, w_cr;
   DBuf<int8_t> w_side; DBuf<unsigned long long> w_bl, w_br; DBuf<int32_t> w_uind, w_us, w_ue, w_ut, w_rs, w_re, w_rt, w_ri, w_uflag;
+
+  // ---- prefix sharing (k_share.hip), rebuilt by every itsx_search: the prefix tree of the active uniques by sorted position s (sh_*_s)
+  // and by processing position k = (batch, depth, s) (sh_dev); a batch is a range of s whose saved row states fit the slot budget
+  struct ShareBatch { int32_t k0, k1; int64_t node0, nnodes; int32_t nsplit; };   // nsplit > 1: the profiles in that many ranges, one after the other
+  bool share_on = false; int share_B = 32, share_logB = 5, share_maxd = 0;
+  DBuf<unsigned long long> sh_tab, sh_mask_s, sh_mask, sh_counters; DBuf<uint8_t> sh_depth_s, sh_depth;
+  DBuf<int32_t> sh_parent_s, sh_parent, sh_nn_s, sh_nn, sh_node0_s, sh_node0, sh_order, sh_ulen, sh_uorder, sh_inv, sh_flag, sh_pos, sh_bstart, sh_cursor, sh_segk, sh_scan, sh_cuts;
+  std::vector<ShareBatch> sh_batches; std::vector<int32_t> sh_segk_h;            // [batch][SHARE_SEGS]
+  DBuf<uint4> sh_mslots; DBuf<float4> sh_fslots; DBuf<uint32_t> sh_pass, sh_need; DBuf<int32_t> sh_real, sh_segflat, sh_segdepth, sh_wc, sh_woff; DBuf<int64_t> sh_bnd;
+  DBuf<uint16_t> sh_res_chk; DBuf<float> sh_fb_chk;
+  ShareDev sh_dev{};
 };
 
 #define CTXCHK(c)                                   \
@@ -1416,6 +1431,127 @@ static float msv_score_from_byte(int xj, int tjb)
 static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, double T, double F1, double F3);
 static int append_traces(itsx_ctx *ctx);
 
+// Prefix sharing (k_share.hip) for the search that is about to run: the prefix tree of the active uniques (per length and per chunk of
+// ctx->s_Uc uniques), the batches whose saved row states fit the slot budget, the processing order (batch, depth, length) and the tree
+// in that order.  ctx->share_on = false when it is switched off (ITSX_SHARE=0), cannot apply, or would share less than ITSX_SHARE_MIN
+// (default 0.10) of the rows: the search then runs today's schedule.
+static int build_share(itsx_ctx *ctx)
+{
+  hipStream_t st = ctx->st;
+  itsx_stats &S = ctx->stats;
+  ctx->share_on = false; ctx->sh_batches.clear(); ctx->sh_segk_h.clear();
+  S.share_B = 0; S.share_batches = 0; S.share_nodes = S.share_chains = 0; S.ms_share_build = 0; S.share_frac = 0;
+  const int32_t U = ctx->U_active, Uc = (int32_t)std::min<int64_t>(ctx->s_Uc, 0x7fffffff), P = ctx->P;
+  if (const char *e = getenv("ITSX_SHARE")) if (atoi(e) == 0) return ITSX_OK;
+  // (the pair traces name uniques by sorted position; the A/B switches of the bound pass use the classic wave list)
+  if (ctx->keep_trace || getenv("ITSX_LAZY_EXACT_BOUND") || getenv("ITSX_LAZY_CHECK_BOUND")) return ITSX_OK;
+  if (U < 2 || U >= (1 << 26) || P <= 0) return ITSX_OK;
+  int B = 32;
+  if (const char *e = getenv("ITSX_SHARE_B")) B = atoi(e);
+  int logB = 0; while ((1 << logB) < B) logB++;
+  if (B < 16 || B > 1024 || (1 << logB) != B) SET_ERR(ctx, ITSX_E_ARG, "ITSX_SHARE_B must be a power of two between 16 and 1024");
+  StageTimer tm(st);
+  TrieArgs a{};
+  a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p; a.seed_read = ctx->d_seed_read.p; a.U = U; a.Uc = std::max(1, Uc); a.B = B;
+  HIPCHK(ctx->sh_counters.alloc(16));
+  HIPCHK(hipMemsetAsync(ctx->sh_counters.p, 0, 16 * sizeof(unsigned long long), st));
+  a.counters = ctx->sh_counters.p;
+  launch_trie_keycount(a, st);
+  unsigned long long hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(hc, ctx->sh_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const unsigned long long nkeys = hc[4];
+  if (nkeys == 0) return ITSX_OK;
+  uint64_t slots = 1024; while (slots < 2 * nkeys) slots <<= 1;
+  HIPCHK(ctx->sh_tab.alloc((size_t)slots, true));
+  HIPCHK(hipMemsetAsync(ctx->sh_tab.p, 0xFF, (size_t)slots * sizeof(unsigned long long), st));
+  HIPCHK(ctx->sh_depth_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_parent_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_mask_s.alloc((size_t)U + 1));
+  HIPCHK(ctx->sh_nn_s.alloc((size_t)U + 2)); HIPCHK(ctx->sh_node0_s.alloc((size_t)U + 2)); HIPCHK(ctx->sh_scan.alloc((size_t)scan_tmp_elems((int64_t)U + 2)));
+  HIPCHK(hipMemsetAsync(ctx->sh_mask_s.p, 0, ((size_t)U + 1) * sizeof(unsigned long long), st));
+  a.tab = ctx->sh_tab.p; a.tmask = slots - 1; a.depth = ctx->sh_depth_s.p; a.parent = ctx->sh_parent_s.p; a.mask = ctx->sh_mask_s.p; a.nn = ctx->sh_nn_s.p;
+  launch_trie_insert(a, st); launch_trie_resolve(a, st); launch_trie_link(a, st); launch_trie_count(a, st);
+  launch_exclusive_scan(ctx->sh_nn_s.p, ctx->sh_node0_s.p, (int64_t)U + 1, ctx->sh_scan.p, st);
+  // where a batch may start: a new length or a new chunk
+  const int32_t ncap = 65536 + U / std::max(1, Uc) + 8;
+  HIPCHK(ctx->sh_cuts.alloc((size_t)ncap * 2));
+  launch_share_cuts(ctx->d_ulen.p, ctx->sh_node0_s.p, U, a.Uc, ncap, ctx->sh_cuts.p, ctx->sh_counters.p + 5, st);
+  int32_t NN = 0;
+  HIPCHK(hipMemcpyAsync(hc, ctx->sh_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(&NN, ctx->sh_node0_s.p + U, sizeof(NN), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int maxd = (int)hc[0];
+  const double frac = hc[2] ? (double)hc[1] / (double)hc[2] : 0.0;
+  S.share_frac = (float)frac;
+  double min_frac = 0.10;
+  if (const char *e = getenv("ITSX_SHARE_MIN")) min_frac = atof(e);
+  const int64_t ncuts = (int64_t)hc[5];
+  if (frac < min_frac || maxd <= 0 || NN <= 0 || ncuts > ncap) { S.ms_share_build = tm.stop(); return ITSX_OK; }
+  std::vector<int32_t> cuts((size_t)ncuts * 2);
+  HIPCHK(hipMemcpyAsync(cuts.data(), ctx->sh_cuts.p, cuts.size() * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<std::pair<int32_t, int32_t>> cv((size_t)ncuts);
+  for (int64_t i = 0; i < ncuts; i++) cv[(size_t)i] = {cuts[(size_t)2 * i], cuts[(size_t)2 * i + 1]};
+  std::sort(cv.begin(), cv.end());
+  cv.push_back({U, NN});
+  // ---- batches: consecutive groups of one chunk while their saved states (for every profile, at the Forward pass's size) fit the budget
+  double gb = 48.0;
+  { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::min(gb, std::max(0.25, ((double)fr + (double)ctx->sh_fslots.cap * sizeof(float4)) / (double)(1ull << 30) / 3.0)); }
+  if (const char *e = getenv("ITSX_SHARE_GB")) gb = std::max(0.001, atof(e));
+  const double state_b = (double)FWD_STATE_Q * sizeof(float4);
+  const int64_t nodes_max = std::max<int64_t>(1, (int64_t)(gb * (double)(1ull << 30) / (state_b * (double)P)));
+  std::vector<int32_t> bstart; std::vector<itsx_ctx::ShareBatch> &bt = ctx->sh_batches;
+  {
+    size_t i = 0;
+    while (i + 1 < cv.size()) {
+      size_t j = i + 1;                       // the batch takes groups i .. j - 1
+      while (j + 1 < cv.size() && cv[j].first % a.Uc != 0 && (int64_t)cv[j + 1].second - cv[i].second <= nodes_max) j++;
+      itsx_ctx::ShareBatch b{};
+      b.k0 = cv[i].first; b.k1 = cv[j].first; b.node0 = cv[i].second; b.nnodes = (int64_t)cv[j].second - cv[i].second;
+      b.nsplit = (int32_t)std::min<int64_t>(P, (b.nnodes + nodes_max - 1) / nodes_max); if (b.nsplit < 1) b.nsplit = 1;
+      bstart.push_back(b.k0); bt.push_back(b);
+      i = j;
+    }
+    bstart.push_back(U);
+  }
+  const int nb = (int)bt.size();
+  // a batch that one group overfills takes its profiles in nsplit ranges; if even one profile's states do not fit, nothing is shared
+  for (auto &b : bt) if ((double)b.nnodes * state_b * (double)((P + b.nsplit - 1) / b.nsplit) > 1.5 * gb * (double)(1ull << 30)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
+  // ---- the processing order: stable by (batch, depth)
+  HIPCHK(upload(ctx->sh_bstart, bstart, st)); HIPCHK(ctx->sh_cursor.alloc((size_t)nb + 1)); HIPCHK(ctx->sh_segk.alloc((size_t)nb * SHARE_SEGS));
+  HIPCHK(hipMemcpyAsync(ctx->sh_cursor.p, ctx->sh_bstart.p, (size_t)nb * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemsetAsync(ctx->sh_segk.p, 0, (size_t)nb * SHARE_SEGS * 4, st));
+  HIPCHK(ctx->sh_flag.alloc((size_t)U + 2)); HIPCHK(ctx->sh_pos.alloc((size_t)U + 2)); HIPCHK(ctx->sh_uorder.alloc((size_t)U + 1)); HIPCHK(ctx->sh_inv.alloc((size_t)U + 1));
+  for (int d = 0; d <= maxd; d++) {
+    launch_share_flag(ctx->sh_depth_s.p, U, d, ctx->sh_flag.p, st);
+    launch_exclusive_scan(ctx->sh_flag.p, ctx->sh_pos.p, (int64_t)U + 1, ctx->sh_scan.p, st);
+    launch_share_scatter(ctx->sh_depth_s.p, U, d, ctx->sh_pos.p, ctx->sh_bstart.p, nb, ctx->sh_cursor.p, ctx->sh_uorder.p, ctx->sh_inv.p, st);
+    launch_share_advance(d, ctx->sh_pos.p, ctx->sh_bstart.p, nb, ctx->sh_cursor.p, ctx->sh_segk.p, st);
+  }
+  ctx->sh_segk_h.assign((size_t)nb * SHARE_SEGS, 0);
+  HIPCHK(hipMemcpyAsync(ctx->sh_segk_h.data(), ctx->sh_segk.p, (size_t)nb * SHARE_SEGS * 4, hipMemcpyDeviceToHost, st));
+  // ---- the tree by processing position
+  HIPCHK(ctx->sh_depth.alloc((size_t)U + 1)); HIPCHK(ctx->sh_parent.alloc((size_t)U + 1)); HIPCHK(ctx->sh_mask.alloc((size_t)U + 1));
+  HIPCHK(ctx->sh_nn.alloc((size_t)U + 2)); HIPCHK(ctx->sh_node0.alloc((size_t)U + 2)); HIPCHK(ctx->sh_order.alloc((size_t)U + 1)); HIPCHK(ctx->sh_ulen.alloc((size_t)U + 1));
+  ShareDev &o = ctx->sh_dev;
+  o.depth = ctx->sh_depth.p; o.parent = ctx->sh_parent.p; o.mask = ctx->sh_mask.p; o.nn = ctx->sh_nn.p; o.node0 = ctx->sh_node0.p; o.order = ctx->sh_order.p; o.ulen = ctx->sh_ulen.p;
+  launch_share_permute(a, ctx->d_ulen.p, ctx->sh_uorder.p, ctx->sh_inv.p, o, st);
+  launch_exclusive_scan(ctx->sh_nn.p, ctx->sh_node0.p, (int64_t)U + 1, ctx->sh_scan.p, st);
+  HIPCHK(hipStreamSynchronize(st));
+  for (int b = 0; b < nb; b++) {               // the end of each batch's last depth, and of the depths that do not occur
+    for (int d = maxd + 1; d < SHARE_SEGS; d++) ctx->sh_segk_h[(size_t)b * SHARE_SEGS + d] = bt[(size_t)b].k1;
+  }
+  // ---- slots of the saved states: the largest batch's, for the MSV filter and for the Forward pass
+  int64_t need_slots = 0;
+  for (auto &b : bt) need_slots = std::max<int64_t>(need_slots, b.nnodes * (int64_t)((P + b.nsplit - 1) / b.nsplit));
+  HIPCHK(ctx->sh_mslots.alloc((size_t)need_slots * MSV_STATE_Q + 1));
+  if (ctx->lazy) HIPCHK(ctx->sh_fslots.alloc((size_t)need_slots * FWD_STATE_Q + 1));
+  ctx->share_on = true; ctx->share_B = B; ctx->share_logB = logB; ctx->share_maxd = maxd;
+  S.share_B = B; S.share_batches = nb; S.share_nodes = NN; S.share_chains = (int64_t)hc[3];
+  S.msv_rows_full = (int64_t)hc[2] * P; S.msv_rows = (int64_t)(hc[2] - hc[1]) * P;
+  S.ms_share_build = tm.stop();
+  return ITSX_OK;
+}
+
 // the active uniques, chunk by chunk (s_Uc uniques at a time), through search_chunk
 static int run_chunks(itsx_ctx *ctx, double T, double F1, double F3)
 {
@@ -1547,6 +1683,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     for (int32_t u = 0; u < U; u++) cells += (int64_t)ctx->h_len[ctx->h_seed_read[u]];
     int64_t msum = 0; for (auto &h : ctx->profs) msum += h.M;
     S.msv_cells = cells * msum;
+    S.msv_rows = S.msv_rows_full = cells * P; S.bound_rows_full = 0; S.n_share_helpers = 0; S.share_mismatch = 0;
   }
   // ---- the unique reads are searched in chunks so that every work list of a chunk fits a fixed share of HBM
   // (about 400 B per potential (unique, profile) pair); one chunk covers the 1 M-read bench
@@ -1576,6 +1713,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->keep_trace = getenv("ITSX_KEEP_TRACE") != nullptr;
   ctx->s_Uc = Uc; ctx->s_Lcap = Lcap;
   ctx->domz_ub_loc.assign((size_t)P * ctx->S, 0);
+  { const int rc = build_share(ctx); if (rc != ITSX_OK) return rc; }
   { const int rc = run_chunks(ctx, T, F1, F3); if (rc != ITSX_OK) return rc; }
   std::vector<int32_t> dz32((size_t)P * ctx->S, 0);
   HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
@@ -2146,7 +2284,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
 
 // The lazy domain stage (k_lazy.hip): Forward scores for every pair of the chunk, then two rounds of the domain pipeline over
 // the pairs that can still win ItsPosition's argmax.
-static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorted, int32_t Uc, double T, double F1, double F3, const std::function<int()> *next_msv)
+static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorted, int32_t u0, int32_t Uc, double T, double F1, double F3, const std::function<int()> *next_msv)
 {
   hipStream_t st = ctx->st;
   const int P = ctx->P, ncls = ctx->compact_ncls;
@@ -2158,7 +2296,70 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
   HIPCHK(ctx->l_gtop.alloc((size_t)Uc * ncls + 1));
   HIPCHK(hipMemsetAsync(ctx->l_done.p, 0, (size_t)NP + 1, st));
   HIPCHK(hipMemsetAsync(ctx->l_gtop.p, 0, ((size_t)Uc * ncls + 1) * sizeof(unsigned long long), st));
-  {
+  if (ctx->share_on) {
+    // prefix sharing (k_share.hip): the pairs of a profile ascend by processing position = (batch, depth, length); one launch takes the
+    // chains of one (batch, depth) for every profile, the depths of a batch in ascending order -- a chain starts from the state that a
+    // chain of a lower depth saved for the same profile
+    const int maxd = ctx->share_maxd, DS = maxd + 1;
+    std::vector<int32_t> segflat, segdepth, segbatch;
+    for (size_t bi = 0; bi < ctx->sh_batches.size(); bi++) {
+      const auto &b = ctx->sh_batches[bi];
+      if (b.k0 < u0 || b.k0 >= u0 + Uc) continue;
+      for (int d = 0; d < DS; d++) { segflat.push_back(ctx->sh_segk_h[bi * SHARE_SEGS + d] - u0); segdepth.push_back(d); segbatch.push_back((int32_t)bi); }
+    }
+    const int nseg = (int)segdepth.size();
+    segflat.push_back(Uc);
+    if ((int64_t)nseg * P + 1 >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "prefix sharing: too many (batch, depth, profile) segments in one chunk");
+    HIPCHK(upload(ctx->sh_segflat, segflat, st)); HIPCHK(upload(ctx->sh_segdepth, segdepth, st, 1)); HIPCHK(upload(ctx->w_rcnt, pl.total, st));
+    HIPCHK(ctx->sh_bnd.alloc((size_t)(nseg + 1) * P)); HIPCHK(ctx->sh_wc.alloc((size_t)nseg * P + 2)); HIPCHK(ctx->sh_woff.alloc((size_t)nseg * P + 2));
+    HIPCHK(ctx->sh_scan.alloc((size_t)scan_tmp_elems((int64_t)nseg * P + 2)));
+    launch_share_bounds(pl.pairs, pl.d_seg_start, ctx->w_rcnt.p, ctx->sh_segflat.p, nseg, P, ctx->sh_bnd.p, st);
+    launch_share_wcount(ctx->sh_bnd.p, nseg, P, ctx->sh_wc.p, st);
+    launch_exclusive_scan(ctx->sh_wc.p, ctx->sh_woff.p, (int64_t)nseg * P + 1, ctx->sh_scan.p, st);
+    std::vector<int32_t> woff((size_t)nseg * P + 1);
+    HIPCHK(hipMemcpyAsync(woff.data(), ctx->sh_woff.p, woff.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int NW = woff.back();
+    HIPCHK(ctx->w_waves.alloc((size_t)std::max(NW, 1))); HIPCHK(ctx->w_counters.alloc(16));
+    HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 16 * sizeof(int64_t), st));
+    launch_share_waves(NW, nseg, P, ctx->sh_woff.p, ctx->sh_bnd.p, ctx->sh_segdepth.p, ctx->share_B, pl.pairs, ctx->w_waves.p, (unsigned long long *)ctx->w_counters.p, st);
+    int64_t lane_rows[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(lane_rows, ctx->w_counters.p, sizeof(lane_rows), hipMemcpyDeviceToHost, st));
+    FloatArgs a{};
+    a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
+    a.pairs = pl.pairs; a.waves = ctx->w_waves.p; a.F1 = F1; a.F3 = F3;
+    StageTimer tm(st);
+    for (int t0 = 0; t0 < nseg; t0 += DS) {                 // one batch: its profile ranges one after the other, depths ascending
+      const auto &b = ctx->sh_batches[(size_t)segbatch[(size_t)t0]];
+      for (int r = 0; r < b.nsplit; r++) {
+        const int pa = (int)((int64_t)P * r / b.nsplit), pb = (int)((int64_t)P * (r + 1) / b.nsplit);
+        if (pb <= pa) continue;
+        for (int d = 0; d < DS; d++) {
+          const int t = t0 + d;
+          const int w0 = woff[(size_t)t * P + pa], w1 = woff[(size_t)t * P + pb];
+          if (w1 <= w0) continue;
+          ShareLaunch sl{};
+          sl.parent = ctx->sh_parent.p + u0; sl.mask = ctx->sh_mask.p + u0; sl.node0 = ctx->sh_node0.p + u0;
+          sl.slots = ctx->sh_fslots.p; sl.node_base = b.node0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
+          for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, st); S.n_bound_launches++; }
+        }
+      }
+    }
+    const float ms = tm.stop();
+    S.ms_bound_kernel += ms; S.ms_filters += ms;
+    S.bound_rows += lane_rows[0]; S.bound_rows_full += lane_rows[1];
+    if (getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0) {
+      // test hook: every pair again from row 1 (the same wave list serves: a wave needs its profile, its pairs and its longest target)
+      HIPCHK(ctx->sh_fb_chk.alloc((size_t)NP + 1));
+      for (int w0 = 0; w0 < NW; w0 += 1 << 20) launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->sh_fb_chk.p, std::min(1 << 20, NW - w0), w0, st);
+      HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 8, 0, sizeof(unsigned long long), st));
+      launch_diff_scores(ctx->l_fb.p, ctx->sh_fb_chk.p, pl.pairs, NP, ctx->sh_counters.p + 8, st);
+      unsigned long long nd = 0;
+      HIPCHK(hipMemcpyAsync(&nd, ctx->sh_counters.p + 8, sizeof(nd), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      S.share_mismatch += (int64_t)nd;
+    }
+  } else {
     // the waves over every pair, fast (Q == 12) profiles first, then runtime-Q ones: built on the device (k_waves_build)
     std::vector<int32_t> order; std::vector<int64_t> woff(1, 0);
     int64_t nfast64 = 0;
@@ -2212,7 +2413,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       }
       S.lazy_bound_maxdiff = mx;
     }
-    S.bound_rows += lane_rows;                    // (its copy was waited for with the kernel's timer)
+    S.bound_rows += lane_rows; S.bound_rows_full += lane_rows;     // (its copy was waited for with the kernel's timer)
   }
   StageTimer tm_sel(st);
   LazyArgs la{};
@@ -2265,27 +2466,52 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   hipStream_t st = ctx->st;
   const int P = ctx->P, G = ctx->G, Ppad = G * 64;
   itsx_stats &S = ctx->stats;
-  const int32_t *d_sorted = ctx->d_sorted_uniq.p + u0;     // PairRec::useq is relative to the chunk
+  // PairRec::useq is relative to the chunk; with prefix sharing it is the PROCESSING position: (batch, depth, length) order
+  const bool sh = ctx->share_on;
+  const int32_t *d_sorted = (sh ? ctx->sh_order.p : ctx->d_sorted_uniq.p) + u0;
+  const int32_t *d_ulen = (sh ? ctx->sh_ulen.p : ctx->d_ulen.p) + u0;
   DBuf<uint16_t> &d_thr = ctx->w_thr; DBuf<int32_t> &d_tjb = ctx->w_tjb;
   ctx->trace_u0 = u0;
   // ---- MSV for every (unique, profile)
   DBuf<uint16_t> &d_res = ctx->w_res;
   HIPCHK(d_res.alloc((size_t)Ppad * std::max<int64_t>(U, ctx->next_u0 >= 0 ? ctx->next_U : 0)));
-  auto msv_for = [&](int64_t cu0, int32_t cU, hipStream_t s, int lds_pad = 0) {
+  auto msv_for = [&](int64_t cu0, int32_t cU, hipStream_t s, int lds_pad = 0, uint16_t *res_out = nullptr, bool shared = true) {
     MsvArgs a{};
-    a.rd = ctx->rd; a.sorted_uniq = ctx->d_sorted_uniq.p + cu0; a.seed_read = ctx->d_seed_read.p; a.U = cU; a.G = G;
+    a.rd = ctx->rd; a.sorted_uniq = (sh ? ctx->sh_order.p : ctx->d_sorted_uniq.p) + cu0; a.seed_read = ctx->d_seed_read.p; a.U = cU; a.G = G;
     a.etab = ctx->d_etab.p; a.pbias = ctx->d_pbias.p; a.ptec = ctx->d_ptec.p; a.ptbm = ctx->d_ptbm.p;
-    a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = d_res.p;
+    a.thr = d_thr.p; a.tjb = d_tjb.p; a.Lcap = Lcap; a.res = res_out ? res_out : d_res.p;
     a.P = P;
     // blocks of 256 sequences x PB profiles: a few thousand blocks at least, and up to 32 profiles per block so that a
     // large job re-reads its sequences' packed words (from L2) 32 times less often than it has profiles
     const int64_t tiles = ((int64_t)cU + 255) / 256;
     if (ctx->completing) {           // only the listed profiles are filtered; every other row of res must read "not passed"
       a.plist = ctx->d_plist.p; a.nlist = (int32_t)ctx->h_plist.size();
-      (void)hipMemsetAsync(d_res.p, 0, (size_t)Ppad * (size_t)cU * sizeof(uint16_t), s);
+      (void)hipMemsetAsync(a.res, 0, (size_t)Ppad * (size_t)cU * sizeof(uint16_t), s);
     }
-    a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * (a.plist ? a.nlist : P) / 4096));
-    launch_msv(a, s, lds_pad);
+    const int np = a.plist ? a.nlist : P;
+    a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * np / 4096));
+    if (!sh || !shared) { launch_msv(a, s, lds_pad); return; }
+    // prefix sharing: batch by batch (the saved states of one batch fit the slot buffer), depth by depth (a chain starts from a state
+    // that a chain of a lower depth saved: launches of one stream run in order)
+    for (const auto &b : ctx->sh_batches) {
+      if (b.k0 < cu0 || b.k0 >= cu0 + cU) continue;
+      const size_t bi = (size_t)(&b - ctx->sh_batches.data());
+      for (int r = 0; r < b.nsplit; r++) {
+        const int pa = (int)((int64_t)np * r / b.nsplit), pb = (int)((int64_t)np * (r + 1) / b.nsplit);
+        if (pb <= pa) continue;
+        for (int d = 0; d <= ctx->share_maxd; d++) {
+          const int32_t k0 = ctx->sh_segk_h[bi * SHARE_SEGS + d], k1 = ctx->sh_segk_h[bi * SHARE_SEGS + d + 1];
+          if (k1 <= k0) continue;
+          MsvArgs c = a;
+          c.k0 = (int32_t)(k0 - cu0); c.k1 = (int32_t)(k1 - cu0); c.pfirst = pa; c.plast = pb; c.share = 1;
+          c.sl.parent = ctx->sh_parent.p + cu0; c.sl.mask = ctx->sh_mask.p + cu0; c.sl.node0 = ctx->sh_node0.p + cu0;
+          c.sl.slots = ctx->sh_mslots.p; c.sl.node_base = b.node0; c.sl.p0 = pa; c.sl.Pb = pb - pa; c.sl.depth = d; c.sl.logB = ctx->share_logB;
+          const int64_t t2 = ((int64_t)(k1 - k0) + 255) / 256;
+          c.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, t2 * (pb - pa) / 4096));
+          launch_msv(c, s, lds_pad);
+        }
+      }
+    }
   };
   if (ctx->msv_pre_u0 == (int64_t)u0) {
     // launched on st2 while the chunk before this one was in its domain stage
@@ -2307,13 +2533,37 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   const int nchunks = (U + CHUNK - 1) / CHUNK;
   DBuf<int32_t> &d_cnt = ctx->w_cnt, &d_total = ctx->w_total;
   HIPCHK(d_cnt.alloc((size_t)P * nchunks)); HIPCHK(d_total.alloc((size_t)P));
-  launch_pair_count(d_res.p, P, U, nchunks, d_cnt.p, st);
+  const bool lazy_now = ctx->lazy && !ctx->completing;
+  if (sh && getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0) {
+    // test hook: the same chunk through the unshared kernel; every cell of the result must be the same
+    HIPCHK(ctx->sh_res_chk.alloc((size_t)Ppad * (size_t)U));
+    msv_for(u0, U, st, 0, ctx->sh_res_chk.p, false);
+    HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 8, 0, sizeof(unsigned long long), st));
+    launch_diff_u16(d_res.p, ctx->sh_res_chk.p, (int64_t)P * U, ctx->sh_counters.p + 8, st);
+    unsigned long long nd = 0;
+    HIPCHK(hipMemcpyAsync(&nd, ctx->sh_counters.p + 8, sizeof(nd), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    S.share_mismatch += (int64_t)nd;
+  }
+  if (sh && lazy_now) {
+    // pass A runs a pair that failed the filter when a chain below it passed: it needs the row states (PairRec::xj = -1)
+    const int W = (P + 31) / 32;
+    HIPCHK(ctx->sh_pass.alloc((size_t)U * W + 1)); HIPCHK(ctx->sh_need.alloc((size_t)U * W + 1));
+    launch_need_bits(d_res.p, U, P, W, ctx->sh_pass.p, ctx->sh_need.p, st);
+    for (int d = ctx->share_maxd; d >= 1; d--) launch_need_up(d, ctx->sh_depth.p + u0, ctx->sh_parent.p + u0, U, W, ctx->sh_need.p, st);
+    HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 9, 0, sizeof(unsigned long long), st));
+    launch_need_mark(d_res.p, U, P, W, ctx->sh_pass.p, ctx->sh_need.p, ctx->sh_counters.p + 9, st);
+  }
+  HIPCHK(ctx->sh_real.alloc((size_t)P));
+  HIPCHK(hipMemsetAsync(ctx->sh_real.p, 0, (size_t)P * 4, st));
+  launch_pair_count(d_res.p, P, U, nchunks, d_cnt.p, ctx->sh_real.p, st);
   launch_chunk_scan(d_cnt.p, P, nchunks, d_total.p, st);
-  std::vector<int32_t> total((size_t)P);
+  std::vector<int32_t> total((size_t)P), real((size_t)P);       // pairs on the list / pairs past the filter (the same without sharing)
   HIPCHK(hipMemcpyAsync(total.data(), d_total.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(real.data(), ctx->sh_real.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   std::vector<int64_t> seg_start((size_t)P + 1, 0);
-  for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; if (ctx->completing) S.n_lazy_completed += total[p]; else S.n_past_msv += total[p]; }
+  for (int p = 0; p < P; p++) { seg_start[p + 1] = seg_start[p] + ((int64_t)total[p] + 63) / 64 * 64; if (ctx->completing) S.n_lazy_completed += real[p]; else S.n_past_msv += real[p]; S.n_share_helpers += total[p] - real[p]; }
   const int64_t NP = seg_start[P];
   ctx->npairs_padded = ctx->lazy ? 0 : NP;
   if (NP == 0) { S.ms_msv += tm_list.stop(); ctx->dom_n.push_back(0); while (ctx->dom_bufs.size() < ctx->dom_n.size()) ctx->dom_bufs.emplace_back(new DBuf<itsx_domain>()); return ITSX_OK; }
@@ -2322,17 +2572,16 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   HIPCHK(upload(d_seg_start, seg_start, st));
   HIPCHK(ctx->d_pairs.alloc((size_t)NP));
   HIPCHK(hipMemsetAsync(ctx->d_pairs.p, 0xFF, (size_t)NP * sizeof(PairRec), st));
-  const bool lazy_now = ctx->lazy && !ctx->completing;
   if (!lazy_now) {                                 // (the lazy stage keeps a PairOut only for the pairs it evaluates)
     HIPCHK(ctx->d_pout.alloc((size_t)NP));
     HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)NP * sizeof(PairOut), st));
   }
-  launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, ctx->d_ulen.p + u0, ctx->d_pairs.p, st);
+  launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, d_ulen, ctx->d_pairs.p, st);
   S.ms_msv += tm_list.stop();
   const int64_t zub_scale = getenv("ITSX_LAZY_ZUB_SCALE") ? std::max<int64_t>(1, atoll(getenv("ITSX_LAZY_ZUB_SCALE"))) : 1;   // test hook: looser bounds, more undecided rows
   if (!ctx->completing)
     for (int p = 0; p < P; p++)                   // an upper bound of hmmsearch's domZ: every reported target is a pair past the MSV filter
-      for (int32_t sm = 0; sm < ctx->S; sm++) ctx->domz_ub_loc[(size_t)sm * P + p] += (int64_t)total[p] * zub_scale;
+      for (int32_t sm = 0; sm < ctx->S; sm++) ctx->domz_ub_loc[(size_t)sm * P + p] += (int64_t)real[p] * zub_scale;
   PairList pl;
   pl.pairs = ctx->d_pairs.p; pl.pout = lazy_now ? nullptr : ctx->d_pout.p; pl.NP = NP; pl.seg_start = seg_start; pl.total = total; pl.d_seg_start = d_seg_start.p;
   // the next chunk's MSV filter on the second stream (its result buffer is free: this chunk's survivor list is built)
@@ -2351,7 +2600,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     }
     return ITSX_OK;
   };
-  if (lazy_now) return lazy_rounds(ctx, pl, d_sorted, U, T, F1, F3, &next_msv);
+  if (lazy_now) return lazy_rounds(ctx, pl, d_sorted, u0, U, T, F1, F3, &next_msv);
   { const int rc = domain_pipeline(ctx, pl, d_sorted, T, F1, F3, &next_msv); if (rc != ITSX_OK) return rc; }
   if (ctx->keep_trace) { const int rc = append_traces(ctx); if (rc != ITSX_OK) return rc; }
   return ITSX_OK;

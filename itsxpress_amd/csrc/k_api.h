@@ -137,6 +137,62 @@ void    launch_calib(int pattern, float *slab, int64_t nwaves, int64_t R, float 
 void    launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st);
 void    launch_logf_fast(const float *x, int64_t n, const LogTab *tab, float *out, hipStream_t st);
 
+// ---- k_share.hip: prefix sharing (round 5).  k_msv and k_fwd_bound scan every row of every (representative, profile) pair from row 1,
+// and their row state after row i depends on the profile, the target's LENGTH and its first i residues only -- while the representatives
+// of amplicon data are error variants of far fewer templates.  The chunk's uniques of equal length form a prefix tree over blocks of B
+// rows; a representative's CHAIN is the part of its path that no earlier representative walks: it starts from the row state its parent
+// chain saved at the branch point and saves its own state wherever a later chain branches off.
+struct TrieArgs {
+  ReadsDev rd;
+  const int32_t *sorted_uniq, *seed_read;   // [U] the length-sorted uniques the search walks
+  int32_t U, Uc, B;                          // Uc: uniques per search chunk (nothing is shared across chunks); B: rows per block (16 x 2^n)
+  unsigned long long *tab; uint64_t tmask;   // open addressing over (length, chunk, depth, prefix) keys: [38-bit tag | 26-bit s], ~0 = empty
+  uint8_t *depth;                            // [U] by sorted position s: first block the chain computes itself (0: from row 1)
+  int32_t *parent;                           // [U] s of the chain whose saved state it starts from (-1: none)
+  unsigned long long *mask;                  // [U] bit d: a later chain starts from this chain's state after row d * B
+  int32_t *nn;                               // [U + 1] saved states of the chain (popcount of mask)
+  unsigned long long *counters;              // [0] deepest start, [1] rows the chains skip, [2] rows of all uniques, [3] chains with a parent, [4] keys
+};
+void launch_trie_keycount(const TrieArgs &a, hipStream_t st);  // counters[4] += keys (one per unique and depth)
+void launch_trie_insert(const TrieArgs &a, hipStream_t st);
+void launch_trie_resolve(const TrieArgs &a, hipStream_t st);
+void launch_trie_link(const TrieArgs &a, hipStream_t st);      // depth / parent final, masks set
+void launch_trie_count(const TrieArgs &a, hipStream_t st);     // nn, counters
+// processing order k: (batch, depth, s) -- batches are ranges of s (bstart[nb + 1]); one pass per depth d
+void launch_share_flag(const uint8_t *depth, int32_t U, int d, int32_t *flag, hipStream_t st);                 // flag[s] = depth[s] == d; flag[U] = 0
+void launch_share_scatter(const uint8_t *depth, int32_t U, int d, const int32_t *pos, const int32_t *bstart, int nb, const int32_t *cursor,
+                          int32_t *uorder, int32_t *inv, hipStream_t st);
+void launch_share_advance(int d, const int32_t *pos, const int32_t *bstart, int nb, int32_t *cursor, int32_t *segk /*[nb][SHARE_SEGS]*/, hipStream_t st);
+void launch_share_cuts(const int32_t *ulen, const int32_t *node0_s, int32_t U, int32_t Uc, int32_t cap, int32_t *cuts /*[cap][2]: s, saved states before s*/,
+                       unsigned long long *n, hipStream_t st);
+struct PairRec;
+void launch_diff_u16(const uint16_t *x, const uint16_t *y, int64_t n, unsigned long long *c, hipStream_t st);
+void launch_diff_scores(const float *x, const float *y, const PairRec *pairs, int64_t n, unsigned long long *c, hipStream_t st);
+constexpr int SHARE_SEGS = 66;             // per batch: first k of depth 0 .. 64, and the batch's end
+struct ShareDev {                          // the tree by processing position k
+  uint8_t *depth; int32_t *parent /* k relative to the chunk */; unsigned long long *mask; int32_t *nn, *node0; int32_t *order /* global unique */, *ulen;
+};
+void launch_share_permute(const TrieArgs &a, const int32_t *ulen_s, const int32_t *uorder, const int32_t *inv, const ShareDev &o, hipStream_t st);
+// one launch of k_msv / k_fwd_bound over chains that start at the same depth (pointers relative to the chunk)
+struct ShareLaunch {
+  const int32_t *parent; const unsigned long long *mask; const int32_t *node0;
+  void *slots;                 // saved row states: [(node - node_base) * Pb + profile - p0][MSV_STATE_Q uint4 | FWD_STATE_Q float4]
+  int64_t node_base; int32_t p0, Pb;
+  int32_t depth, logB;
+};
+constexpr int MSV_STATE_Q = 7;             // 23 packed registers + xJ, xB, xEmax
+constexpr int FWD_STATE_Q = 36;            // M, I, D of 46 nodes + xN xJ xC xB + the scale's logarithm (double)
+// lazy searches only: a chain whose own pair failed the MSV filter still has to run for a profile when a chain below it needs its state
+void launch_need_bits(const uint16_t *res, int32_t U, int32_t P, int32_t W, uint32_t *pass, uint32_t *need, hipStream_t st);
+void launch_need_up(int d, const uint8_t *depth, const int32_t *parent, int32_t U, int32_t W, uint32_t *need, hipStream_t st);
+void launch_need_mark(uint16_t *res, int32_t U, int32_t P, int32_t W, const uint32_t *pass, const uint32_t *need, unsigned long long *n_helpers, hipStream_t st);
+// wave list of one chunk's pairs in share order: bnd[t][p] = first pair of profile p with useq >= segk[t]
+void launch_share_bounds(const PairRec *pairs, const int64_t *seg_start, const int32_t *total, const int32_t *segk, int32_t nseg, int32_t P, int64_t *bnd, hipStream_t st);
+void launch_share_wcount(const int64_t *bnd, int32_t nseg, int32_t P, int32_t *wc, hipStream_t st);            // wc[t * P + p] = waves; wc[nseg * P] = 0
+struct WaveDesc;
+void launch_share_waves(int32_t nw, int32_t nseg, int32_t P, const int32_t *woff, const int64_t *bnd, const int32_t *seg_depth, int32_t B, const PairRec *pairs,
+                        WaveDesc *w, unsigned long long *lane_rows /*[0] rows computed, [1] rows of the pairs*/, hipStream_t st);
+
 // ---- k_msv.hip
 struct MsvArgs {
   ReadsDev rd;
@@ -154,12 +210,16 @@ struct MsvArgs {
   uint16_t *res;                // [G*64][U]  bit8 = passed, low byte = xJ (255 = overflow)
   const int32_t *plist;         // optional: only these profiles (the others' rows of res are left as they are); nullptr = all P
   int32_t nlist;
+  int32_t k0, k1;               // sorted positions [k0, k1) of this launch (k1 = 0: all U)
+  int32_t pfirst, plast;        // profiles (list positions with plist) [pfirst, plast) (plast = 0: all)
+  int32_t share;                // prefix sharing: every sequence of [k0, k1) is a chain that starts at sl.depth
+  ShareLaunch sl;
 };
 void launch_msv(const MsvArgs &a, hipStream_t st, int lds_pad = 0);
 
 // survivor list: pairs grouped by profile, 64-aligned segments, ascending length inside a segment
 constexpr int CHUNK = 2048;
-void launch_pair_count(const uint16_t *res, int32_t P, int32_t U, int32_t nchunks, int32_t *cnt /*[P][nchunks]*/, hipStream_t st);
+void launch_pair_count(const uint16_t *res, int32_t P, int32_t U, int32_t nchunks, int32_t *cnt /*[P][nchunks]*/, int32_t *real /*[P], zeroed: pairs past the filter*/, hipStream_t st);
 void launch_chunk_scan(int32_t *cnt, int32_t P, int32_t nchunks, int32_t *total /*[P]*/, hipStream_t st);
 void launch_pair_fill(const uint16_t *res, int32_t P, int32_t U, int32_t nchunks, const int32_t *cnt,
                       const int64_t *seg_start /*[P]*/, const int32_t *ulen /*[U] length by sorted position*/,
@@ -233,6 +293,8 @@ void launch_fwd_bound(const FloatArgs &a, float *fb, int nwaves, int wave0, int 
 // the same score by the node-sequential fused-multiply-add kernel (k_lazy.hip: k_fwd_bound); btab = [P][BOUND_PAIRS][16] floats per
 // pair of nodes (2j + 1, 2j + 2): {MM IM DM out of the node (into the next one's match cell)} {MI II BM MD of the node} as pairs, DD x 2
 void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, hipStream_t st);
+// ... over waves of chains that start at sl.depth (k_share.hip): the rows before come from the parent chain's saved state
+void launch_fwd_bound_share(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st);
 

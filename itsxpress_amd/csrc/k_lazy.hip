@@ -60,7 +60,12 @@ DEV BT ldbt(const float *tab, int j)
 }
 DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-__global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, const float *__restrict__ btab, float *__restrict__ fb)
+// SHARE (k_share.hip): the wave's pairs are chains that start at the same depth of their length's prefix tree -- the rows before
+// come from the state the parent chain saved for this profile (FWD_STATE_Q float4: M, I, D of the 46 nodes, xN xJ xC xB, the scale's
+// logarithm), and a chain saves its own state after row d * B where a later chain branches off.  The same operations on the same
+// operands in the same order as the chain's unshared run: the scores are bitwise equal (tests/test_gpu_share.py).
+template <bool SHARE>
+__global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, const float *__restrict__ btab, float *__restrict__ fb, ShareLaunch sl)
 {
   const WaveDesc wd = a.waves[wave0 + blockIdx.x];
   const int lane = threadIdx.x;
@@ -90,9 +95,44 @@ __global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, con
   const float ploop = 1.0f - pmove;
   float xE = 0.f, xN = 1.f, xJ = 0.f, xB = pmove, xC = 0.f;
   double totscale = 0.0;
-  SeqStream ss; ss.open(sq, 0, +1);
-  int xnext = ss.get(0);
-  for (int i = 1; i <= Lw; i++) {
+  const int row0 = SHARE ? (sl.depth << sl.logB) : 0;       // rows done before this launch (wave-uniform)
+  unsigned long long smask = 0ull; int64_t snode = 0;
+  if constexpr (SHARE) {
+    const int k = pr.useq;
+    if (active) { smask = sl.mask[k]; snode = (int64_t)sl.node0[k] - sl.node_base; }
+    if (sl.depth > 0) {
+      const int par = sl.parent[k];
+      const int64_t node = (int64_t)sl.node0[par] + __popcll(sl.mask[par] & ((1ull << sl.depth) - 1ull)) - sl.node_base;
+      const f4 *src = (const f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
+#pragma unroll
+      for (int j = 0; j < BP; j++) { const f4 v = src[j]; M[j] = (f2){v.x, v.y}; I[j] = (f2){v.z, v.w}; }
+#pragma unroll
+      for (int j = 0; j < BP / 2; j++) { const f4 v = src[BP + j]; D[2 * j] = (f2){v.x, v.y}; D[2 * j + 1] = (f2){v.z, v.w}; }
+      const f4 u = src[BP + BP / 2], t = src[BP + BP / 2 + 1];
+      D[BP - 1] = (f2){u.x, u.y}; xN = u.z; xJ = u.w; xC = t.x; xB = t.y;
+      totscale = __builtin_bit_cast(double, (f2){t.z, t.w});
+    }
+  }
+  SeqStream ss; ss.open(sq, row0, +1);
+  int xnext = ss.get(row0);
+  for (int i = row0 + 1; i <= Lw; i++) {
+    if constexpr (SHARE) {
+      // a block boundary: the state after row i - 1 = d * B is what a chain that branches off there starts from
+      if (((i - 1) & ((1 << sl.logB) - 1)) == 0 && i - 1 > row0) {
+        const int d = (i - 1) >> sl.logB;
+        if (d < 64 && ((smask >> d) & 1ull) && i <= L) {
+          const int64_t node = snode + __popcll(smask & ((1ull << d) - 1ull));
+          f4 *dst = (f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
+#pragma unroll
+          for (int j = 0; j < BP; j++) dst[j] = (f4){M[j].x, M[j].y, I[j].x, I[j].y};
+#pragma unroll
+          for (int j = 0; j < BP / 2; j++) dst[BP + j] = (f4){D[2 * j].x, D[2 * j].y, D[2 * j + 1].x, D[2 * j + 1].y};
+          const f2 ts = __builtin_bit_cast(f2, totscale);
+          dst[BP + BP / 2] = (f4){D[BP - 1].x, D[BP - 1].y, xN, xJ};
+          dst[BP + BP / 2 + 1] = (f4){xC, xB, ts.x, ts.y};
+        }
+      }
+    }
     if (i <= L) {
       const int x = xnext;
       if (i < L) xnext = ss.get(i);
@@ -159,7 +199,11 @@ __global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, con
 
 void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, hipStream_t st)
 {
-  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound, dim3(nwaves), dim3(64), 0, st, a, wave0, btab, fb);
+  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<false>, dim3(nwaves), dim3(64), 0, st, a, wave0, btab, fb, ShareLaunch{});
+}
+void launch_fwd_bound_share(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st)
+{
+  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<true>, dim3(nwaves), dim3(64), 0, st, a, wave0, btab, fb, sl);
 }
 
 // largest %.1f tenths (biased) a domain of each pair can print, and the best-bound pair of every (representative, class)
@@ -169,6 +213,7 @@ __global__ void __launch_bounds__(256) k_lazy_bound(LazyArgs a)
   if (i >= a.NP) return;
   const PairRec pr = a.pairs[i];
   if (pr.prof < 0) { a.b10[i] = 0u; return; }
+  if (pr.xj < 0) { a.b10[i] = 0u; a.done[i] = 1; return; }      // ran for its row states only (k_share.hip): never selected
   const float f = a.fb[i];
   const LenTables lt = a.lt[pr.L];
   uint32_t b;

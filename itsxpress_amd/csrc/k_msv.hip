@@ -35,14 +35,27 @@ __device__ __forceinline__ s2 as_s2(uint32_t u) { return __builtin_bit_cast(s2, 
 __device__ __forceinline__ uint32_t as_u(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// SHARE (k_share.hip): the block's sequences are chains that start at the same depth -- the rows before come from the state the parent
+// chain saved (23 packed registers, xJ, xB, xEmax: MSV_STATE_Q uint4 per (node, profile)), and a chain saves its own state where a
+// later chain branches off.  Integer arithmetic on the same operands: the xJ bytes are those of the unshared kernel.
+template <bool SHARE>
 __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint32_t tab[2][16 * MSV_TW];
-  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int s = a.k0 + blockIdx.x * 256 + threadIdx.x;
+  const bool valid = s < a.k1;
   int L = 0, nexc = 0, tjb = 0, Lt = 0;
   const uint32_t *wp = a.rd.words;
   const uint32_t *ep = a.rd.exc;
-  if (s < a.U) {
+  const int row0 = SHARE ? (a.sl.depth << a.sl.logB) : 0;
+  int64_t src_node = 0;                            // the parent chain's saved state this chain starts from
+  if constexpr (SHARE) {
+    if (valid && a.sl.depth > 0) {
+      const int par = a.sl.parent[s];
+      src_node = (int64_t)a.sl.node0[par] + __popcll(a.sl.mask[par] & ((1ull << a.sl.depth) - 1ull)) - a.sl.node_base;
+    }
+  }
+  if (valid) {
     const int r = a.seed_read[a.sorted_uniq[s]];
     L = a.rd.len[r];
     wp = a.rd.words + a.rd.woff[r];
@@ -56,8 +69,8 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
   for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(Lw, d, 64); Lw = o > Lw ? o : Lw; }
   Lw = uni(Lw);
   const int Ppad = a.G * 64;
-  const int p0 = blockIdx.y * a.PB;
-  const int np = a.plist ? a.nlist : a.P;
+  const int p0 = a.pfirst + blockIdx.y * a.PB;
+  const int np = a.plast;
   int p1 = p0 + a.PB; if (p1 > np) p1 = np;
   const int base = 190;
   for (int pj = p0; pj < p1; pj++) {
@@ -73,12 +86,40 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
     uint32_t dp[MSV_REGS];
 #pragma unroll
     for (int i = 0; i < MSV_REGS; i++) dp[i] = 0;
+    if constexpr (SHARE) {
+      if (valid && a.sl.depth > 0) {
+        const uint4 *src = (const uint4 *)a.sl.slots + (src_node * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          const uint4 v = src[q];
+          dp[4 * q] = v.x; dp[4 * q + 1] = v.y; dp[4 * q + 2] = v.z; if (4 * q + 3 < MSV_REGS) dp[4 * q + 3] = v.w;
+        }
+        const uint4 v = src[6];
+        xJ = (int)v.x; xB = (int)v.y; xEmax = (int)v.z;
+      }
+    }
     int ei = 0;
-    int next_exc = nexc > 0 ? (int)(ep[0] >> 4) : 0x7fffffff;
-    uint32_t w = 0, wnext = L > 0 ? wp[0] : 0u;
-    for (int pos = 0; pos < Lw; pos++) {
+    int next_exc = nexc > 0 ? (int)(ep[0] >> 4) : 0x7fffffff;        // (a chain has no exception above its start: k_share.hip)
+    uint32_t w = 0, wnext = L > row0 ? wp[row0 >> 4] : 0u;
+    for (int pos = row0; pos < Lw; pos++) {
       const int sh = (pos & 15) * 2;
-      if (sh == 0) { w = wnext; if (pos + 16 < L) wnext = wp[(pos >> 4) + 1]; }      // the next 16 bases fly during these 16 rows
+      if (sh == 0) {
+        if constexpr (SHARE) {
+          // a block boundary: the state after row `pos` (1-based) is what a chain that branches off here starts from
+          if (pos > row0 && (pos & ((1 << a.sl.logB) - 1)) == 0 && pos < L) {
+            const int d = pos >> a.sl.logB;
+            const unsigned long long m = a.sl.mask[s];
+            if (d < 64 && ((m >> d) & 1ull)) {
+              const int64_t node = (int64_t)a.sl.node0[s] + __popcll(m & ((1ull << d) - 1ull)) - a.sl.node_base;
+              uint4 *dst = (uint4 *)a.sl.slots + (node * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
+#pragma unroll
+              for (int q = 0; q < 6; q++) dst[q] = make_uint4(dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], (4 * q + 3 < MSV_REGS) ? dp[(4 * q + 3) % MSV_REGS] : 0u);
+              dst[6] = make_uint4((uint32_t)xJ, (uint32_t)xB, (uint32_t)xEmax, 0u);
+            }
+          }
+        }
+        w = wnext; if (pos + 16 < L) wnext = wp[(pos >> 4) + 1];      // the next 16 bases fly during these 16 rows
+      }
       if (pos < L) {
         int code = (int)((w >> sh) & 3u);
         if (pos == next_exc) {
@@ -110,7 +151,7 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
         xB = xJ - tjbm; xB = xB > bm0 ? xB : bm0;            // = max(max(base, xJ) - tjbm, 0)
       }
     }
-    if (s < a.U) {
+    if (valid) {
       const int ovf = (xEmax + bias >= 255);
       const int thr = a.thr[(size_t)Lt * Ppad + p];
       const int pass = ovf | (xJ >= thr);
@@ -122,30 +163,41 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
 
 // lds_pad: dynamic LDS the launch asks for and never touches -- a cap on the blocks a CU holds (160 KB per CU), for the launch that
 // runs beside another stream's kernels and must leave them their registers
-void launch_msv(const MsvArgs &a, hipStream_t st, int lds_pad)
+void launch_msv(const MsvArgs &a0, hipStream_t st, int lds_pad)
 {
-  const int np = a.plist ? a.nlist : a.P;
-  if (a.U <= 0 || np <= 0) return;
-  hipLaunchKernelGGL(k_msv, dim3((unsigned)((a.U + 255) / 256), (unsigned)((np + a.PB - 1) / a.PB)), dim3(256), (size_t)lds_pad, st, a);
+  MsvArgs a = a0;
+  if (a.k1 <= 0) { a.k0 = 0; a.k1 = a.U; }
+  if (a.plast <= 0) { a.pfirst = 0; a.plast = a.plist ? a.nlist : a.P; }
+  const int np = a.plast - a.pfirst, nk = a.k1 - a.k0;
+  if (nk <= 0 || np <= 0) return;
+  const dim3 grid((unsigned)((nk + 255) / 256), (unsigned)((np + a.PB - 1) / a.PB));
+  if (a.share) hipLaunchKernelGGL(k_msv<true>, grid, dim3(256), (size_t)lds_pad, st, a);
+  else hipLaunchKernelGGL(k_msv<false>, grid, dim3(256), (size_t)lds_pad, st, a);
 }
 
 // ---------------------------------------------------------------------------------------
 // survivor list: (profile, sorted position) cells with the pass bit -> PairRec list grouped by
 // profile.  Three small passes: per-chunk counts, per-profile scan of chunk counts, fill.
-__global__ void __launch_bounds__(256) k_pair_count(const uint16_t *__restrict__ res, int32_t U, int32_t nchunks, int32_t *__restrict__ cnt)
+// a cell is on the list when it passed (bit 8) or when only a chain below it did (bit 9, k_share.hip: the pair runs in pass A for its
+// row states and is nobody's result: PairRec::xj = -1); real[p] counts the pairs that passed
+__global__ void __launch_bounds__(256) k_pair_count(const uint16_t *__restrict__ res, int32_t U, int32_t nchunks, int32_t *__restrict__ cnt, int32_t *__restrict__ real)
 {
-  __shared__ int32_t ws[4];
+  __shared__ int32_t ws[4], wr[4];
   const int p = blockIdx.y, c = blockIdx.x;
   const int64_t base = (int64_t)p * U;
-  int32_t n = 0;
+  int32_t n = 0, nr = 0;
   for (int i = threadIdx.x; i < CHUNK; i += 256) {
     const int s = c * CHUNK + i;
-    if (s < U) n += (res[base + s] >> 8) & 1;
+    if (s < U) { const int v = res[base + s]; n += (v & 0x300) != 0; nr += (v >> 8) & 1; }
   }
-  for (int d = 32; d >= 1; d >>= 1) n += __shfl_down(n, d, 64);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = n;
+  for (int d = 32; d >= 1; d >>= 1) { n += __shfl_down(n, d, 64); nr += __shfl_down(nr, d, 64); }
+  if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = n; wr[threadIdx.x >> 6] = nr; }
   __syncthreads();
-  if (threadIdx.x == 0) cnt[(int64_t)p * nchunks + c] = ws[0] + ws[1] + ws[2] + ws[3];
+  if (threadIdx.x == 0) {
+    cnt[(int64_t)p * nchunks + c] = ws[0] + ws[1] + ws[2] + ws[3];
+    const int32_t r = wr[0] + wr[1] + wr[2] + wr[3];
+    if (r) atomicAdd(&real[p], r);
+  }
 }
 // one block per profile: exclusive scan of its chunk counts (in place), total out
 __global__ void __launch_bounds__(256) k_chunk_scan(int32_t *__restrict__ cnt, int32_t nchunks, int32_t *__restrict__ total)
@@ -184,7 +236,7 @@ __global__ void __launch_bounds__(256) k_pair_fill(const uint16_t *__restrict__ 
   const int s0 = c * CHUNK + threadIdx.x * 8;
   uint16_t v[8]; int32_t n = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { v[i] = (s0 + i < U) ? res[base + s0 + i] : 0; n += (v[i] >> 8) & 1; }
+  for (int i = 0; i < 8; i++) { v[i] = (s0 + i < U) ? res[base + s0 + i] : 0; n += (v[i] & 0x300) != 0; }
   int32_t inc = n;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int d = 1; d < 64; d <<= 1) { const int32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
@@ -195,8 +247,8 @@ __global__ void __launch_bounds__(256) k_pair_fill(const uint16_t *__restrict__ 
   int64_t o = out0 + off + inc - n;
 #pragma unroll
   for (int i = 0; i < 8; i++)
-    if (v[i] & 0x100) {
-      PairRec pr; pr.useq = s0 + i; pr.prof = p; pr.xj = v[i] & 0xff; pr.L = ulen[s0 + i];
+    if (v[i] & 0x300) {
+      PairRec pr; pr.useq = s0 + i; pr.prof = p; pr.xj = (v[i] & 0x100) ? (v[i] & 0xff) : -1; pr.L = ulen[s0 + i];
       pairs[o++] = pr;
     }
 }
@@ -207,9 +259,9 @@ __global__ void __launch_bounds__(256) k_fill_ulen(int32_t U, const int32_t *__r
   if (s < U) ulen[s] = len[seed_read[sorted_uniq[s]]];
 }
 
-void launch_pair_count(const uint16_t *res, int32_t P, int32_t U, int32_t nchunks, int32_t *cnt, hipStream_t st)
+void launch_pair_count(const uint16_t *res, int32_t P, int32_t U, int32_t nchunks, int32_t *cnt, int32_t *real, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_pair_count, dim3((unsigned)nchunks, (unsigned)P), dim3(256), 0, st, res, U, nchunks, cnt);
+  hipLaunchKernelGGL(k_pair_count, dim3((unsigned)nchunks, (unsigned)P), dim3(256), 0, st, res, U, nchunks, cnt, real);
 }
 void launch_chunk_scan(int32_t *cnt, int32_t P, int32_t nchunks, int32_t *total, hipStream_t st)
 {

@@ -4,10 +4,10 @@ configs[2]'s 10 M reads, takes the distinct ones in (length, lexicographic) orde
 leader / follower groups greedily (a group's followers start Forward at the group's common prefix from the leader's row state);
 prints the share of Forward rows the followers would skip.  Result at 10 M reads: 4.8 % (4.4 % when a random 74 % of the uniques
 pass MSV for a profile) -- too little to pay for the sort, the grouping and a second kernel launch per batch."""
-import sys, time, gzip, os
+import sys, time, gzip, os, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np, synth
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+N = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10_000_000
 W = 448
 thmm = gzip.open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'T.hmm.gz'), 'rt').read()
 t0 = time.time()
@@ -41,6 +41,24 @@ for c0 in range(1, len(U), BLK):
     same_len = Lu[c0:c1] == Lu[c0 - 1:c1 - 1]
     lcp[c0:c1] = np.where(same_len, np.minimum(first, np.minimum(Lu[c0:c1], W)), 0)
 print("lcp done", time.time() - t0, flush=True)
+# ---- the TREE figure (round 5): every distinct prefix of a length group is computed once.  Rows shared = sum of the common prefix with
+# the lexicographic predecessor of equal length (the trie's internal path lengths), exact and with row-state check-points every B rows;
+# branch nodes = distinct (depth, prefix) check-points some later read starts from (each needs one saved row state per profile).
+tot = int(Lu.sum())
+print(json.dumps({"uniques": int(len(U)), "sum_L": tot, "rows_shared_frac_exact": round(float(lcp.sum()) / tot, 4)}), flush=True)
+for B in (16, 32, 64, 128):
+    lb = lcp // B
+    shared = int((lb * B).sum())
+    nodes = 0; chains_by_depth = []
+    for d in range(1, int(lb.max()) + 1):
+        ids = np.cumsum(lb < d)              # node number at depth d of every read's prefix
+        sel = lb == d
+        chains_by_depth.append(int(sel.sum()))
+        nodes += len(np.unique(ids[sel]))
+    print(json.dumps({"B": B, "rows_shared_frac": round(shared / tot, 4), "branch_nodes": nodes, "roots": int((lb == 0).sum()),
+                      "chains_by_start_depth": chains_by_depth[:24]}), flush=True)
+if "--tree-only" in sys.argv:
+    sys.exit(0)
 for frac in (1.0, 0.74):
     rng = np.random.default_rng(1)
     keep = np.flatnonzero(rng.random(len(U)) < frac) if frac < 1 else np.arange(len(U))

@@ -1494,10 +1494,17 @@ static int build_share(itsx_ctx *ctx)
   std::sort(cv.begin(), cv.end());
   cv.push_back({U, NN});
   // ---- batches: consecutive groups of one chunk while their saved states (for every profile, at the Forward pass's size) fit the budget
-  double gb = 48.0;
-  { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::min(gb, std::max(0.25, ((double)fr + (double)ctx->sh_fslots.cap * sizeof(float4)) / (double)(1ull << 30) / 3.0)); }
-  if (const char *e = getenv("ITSX_SHARE_GB")) gb = std::max(0.001, atof(e));
-  const double state_b = (double)FWD_STATE_Q * sizeof(float4);
+  // (a lazy search: the Forward pass's states, up to 24 GB -- 48 left the stages behind it too little at 10 M reads -- and a third of what is free; otherwise only the MSV filter shares, its
+  // states are a fifth the size, and the full table's rows and slabs want the memory: up to 8 GB and an eighth of what is free)
+  const bool fwd_too = ctx->lazy;
+  double gb = fwd_too ? 24.0 : 8.0;
+  {
+    size_t fr = 0, tot = 0;
+    const double held = (double)ctx->sh_fslots.cap * sizeof(float4) + (double)ctx->sh_mslots.cap * sizeof(uint4);
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::min(gb, std::max(0.25, ((double)fr + held) / (double)(1ull << 30) / (fwd_too ? 3.0 : 8.0)));
+  }
+  if (const char *e = getenv("ITSX_SHARE_GB")) gb = std::max(0.0001, atof(e));
+  const double state_b = fwd_too ? (double)FWD_STATE_Q * sizeof(float4) : (double)MSV_STATE_Q * sizeof(uint4);
   const int64_t nodes_max = std::max<int64_t>(1, (int64_t)(gb * (double)(1ull << 30) / (state_b * (double)P)));
   std::vector<int32_t> bstart; std::vector<itsx_ctx::ShareBatch> &bt = ctx->sh_batches;
   {
@@ -1543,8 +1550,13 @@ static int build_share(itsx_ctx *ctx)
   // ---- slots of the saved states: the largest batch's, for the MSV filter and for the Forward pass
   int64_t need_slots = 0;
   for (auto &b : bt) need_slots = std::max<int64_t>(need_slots, b.nnodes * (int64_t)((P + b.nsplit - 1) / b.nsplit));
-  HIPCHK(ctx->sh_mslots.alloc((size_t)need_slots * MSV_STATE_Q + 1));
-  if (ctx->lazy) HIPCHK(ctx->sh_fslots.alloc((size_t)need_slots * FWD_STATE_Q + 1));
+  // (no room for them: the search runs unshared)
+  if (ctx->sh_mslots.alloc((size_t)need_slots * MSV_STATE_Q + 1) != hipSuccess || (fwd_too && ctx->sh_fslots.alloc((size_t)need_slots * FWD_STATE_Q + 1) != hipSuccess)) {
+    (void)hipGetLastError();
+    ctx->sh_mslots.release(); ctx->sh_fslots.release(); bt.clear();
+    S.ms_share_build = tm.stop();
+    return ITSX_OK;
+  }
   ctx->share_on = true; ctx->share_B = B; ctx->share_logB = logB; ctx->share_maxd = maxd;
   S.share_B = B; S.share_batches = nb; S.share_nodes = NN; S.share_chains = (int64_t)hc[3];
   S.msv_rows_full = (int64_t)hc[2] * P; S.msv_rows = (int64_t)(hc[2] - hc[1]) * P;
@@ -2506,8 +2518,10 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
           c.k0 = (int32_t)(k0 - cu0); c.k1 = (int32_t)(k1 - cu0); c.pfirst = pa; c.plast = pb; c.share = 1;
           c.sl.parent = ctx->sh_parent.p + cu0; c.sl.mask = ctx->sh_mask.p + cu0; c.sl.node0 = ctx->sh_node0.p + cu0;
           c.sl.slots = ctx->sh_mslots.p; c.sl.node_base = b.node0; c.sl.p0 = pa; c.sl.Pb = pb - pa; c.sl.depth = d; c.sl.logB = ctx->share_logB;
+          // (a launch ends when its last blocks end, and the next depth waits for it: many short blocks -- ten rounds of the ~1 500 a chip
+          // holds -- rather than a few long ones that take their sequences through 32 profiles)
           const int64_t t2 = ((int64_t)(k1 - k0) + 255) / 256;
-          c.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, t2 * (pb - pa) / 4096));
+          c.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, t2 * (pb - pa) / 16384));
           launch_msv(c, s, lds_pad);
         }
       }
@@ -2586,7 +2600,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   pl.pairs = ctx->d_pairs.p; pl.pout = lazy_now ? nullptr : ctx->d_pout.p; pl.NP = NP; pl.seg_start = seg_start; pl.total = total; pl.d_seg_start = d_seg_start.p;
   // the next chunk's MSV filter on the second stream (its result buffer is free: this chunk's survivor list is built)
   const std::function<int()> next_msv = [&]() -> int {
-    static const bool msv_overlap = !(getenv("ITSX_MSV_OVERLAP") && atoi(getenv("ITSX_MSV_OVERLAP")) == 0);
+    const bool msv_overlap = !(getenv("ITSX_MSV_OVERLAP") && atoi(getenv("ITSX_MSV_OVERLAP")) == 0);     // (read at every search: bench.py times one step without the overlap)
     if (msv_overlap && ctx->next_u0 >= 0 && ctx->st2 && !ctx->keep_trace) {
       if (!ctx->ev_msv0) {
         HIPCHK(hipEventCreate(&ctx->ev_msv0)); HIPCHK(hipEventCreate(&ctx->ev_msv1));
@@ -3645,6 +3659,31 @@ int itsx_debug_calibrate(itsx_ctx *ctx, int pattern, double gbytes, int iters, i
   const int64_t touched = pattern == 1 ? 5 * 64 * 4 : row_floats * 4;
   if (bytes_per_launch) *bytes_per_launch = nwaves * R * touched;
   if (ms_per_launch) *ms_per_launch = ms / iters;
+  return ITSX_OK;
+}
+
+// VALU issue rates (profiles/round5_valu_issue.md): one instruction class, no dependence between consecutive instructions,
+// waves_per_simd waves on every SIMD of the chip.  cycles_per_instr = median over waves of s_memtime ticks per instruction as ONE wave
+// sees them (divide by waves_per_simd for the SIMD's issue interval); ms = the launch.
+int itsx_debug_issue(itsx_ctx *ctx, int op, int waves_per_simd, int iters, double *cycles_per_instr, double *ms)
+{
+  CTXCHK(ctx && op >= 0 && op <= 9 && waves_per_simd >= 1 && waves_per_simd <= 8 && (waves_per_simd <= 4 || waves_per_simd % 2 == 0) && iters >= 1);
+  HIPCHK(hipSetDevice(ctx->device));
+  int ncu = 256;
+  { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
+  const int nw = ncu * 4 * waves_per_simd;
+  DBuf<unsigned long long> ticks; DBuf<float> sink;
+  HIPCHK(ticks.alloc((size_t)nw)); HIPCHK(sink.alloc(4));
+  launch_issue(op, waves_per_simd, 16, ncu, ticks.p, sink.p, ctx->st);          // warm-up (clocks, code)
+  StageTimer tm(ctx->st);
+  launch_issue(op, waves_per_simd, iters, ncu, ticks.p, sink.p, ctx->st);
+  const float t = tm.stop();
+  HIPCHK(hipGetLastError());
+  std::vector<unsigned long long> h((size_t)nw);
+  HIPCHK(hipMemcpy(h.data(), ticks.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::sort(h.begin(), h.end());
+  if (cycles_per_instr) *cycles_per_instr = (double)h[h.size() / 2] / (64.0 * (double)iters);
+  if (ms) *ms = t;
   return ITSX_OK;
 }
 

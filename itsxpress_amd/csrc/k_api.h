@@ -134,6 +134,9 @@ void    launch_pack_exc(const uint8_t *raw, int64_t raw_base, const int64_t *off
                         const int32_t *exstart, long long *ebase, int64_t ecap, int64_t *excoff, uint32_t *exc, hipStream_t st);
 // PMC calibration streams: pattern 0 read 6 of 6 fields (4 B/lane), 1 read 5 of 6, 2 write 6 of 6, 3 read 16 B/lane
 void    launch_calib(int pattern, float *slab, int64_t nwaves, int64_t R, float *out, hipStream_t st);
+// VALU issue-rate probe: op 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_max_i16, 3 v_pk_add_u16, 4 v_pk_mul_f32, 5 v_pk_add_f32, 6 s_nop 0, 7 v_mul_f32,
+// 8 v_pk_mov_b32, 9 v_max_i16; 64 x iters instructions per wave, ticks[block * waves + wave] = s_memtime ticks
+void    launch_issue(int op, int waves_per_simd, int iters, int blocks, unsigned long long *ticks, float *sink, hipStream_t st);
 void    launch_detmath(const double *x, int64_t n, double *ol, double *oe, hipStream_t st);
 void    launch_logf_fast(const float *x, int64_t n, const LogTab *tab, float *out, hipStream_t st);
 

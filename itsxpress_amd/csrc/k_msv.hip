@@ -39,7 +39,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 // chain saved (23 packed registers, xJ, xB, xEmax: MSV_STATE_Q uint4 per (node, profile)), and a chain saves its own state where a
 // later chain branches off.  Integer arithmetic on the same operands: the xJ bytes are those of the unshared kernel.
 template <bool SHARE>
-__global__ void __launch_bounds__(256) k_msv(MsvArgs a)
+__global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint32_t tab[2][16 * MSV_TW];
   const int s = a.k0 + blockIdx.x * 256 + threadIdx.x;
@@ -48,13 +48,6 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
   const uint32_t *wp = a.rd.words;
   const uint32_t *ep = a.rd.exc;
   const int row0 = SHARE ? (a.sl.depth << a.sl.logB) : 0;
-  int64_t src_node = 0;                            // the parent chain's saved state this chain starts from
-  if constexpr (SHARE) {
-    if (valid && a.sl.depth > 0) {
-      const int par = a.sl.parent[s];
-      src_node = (int64_t)a.sl.node0[par] + __popcll(a.sl.mask[par] & ((1ull << a.sl.depth) - 1ull)) - a.sl.node_base;
-    }
-  }
   if (valid) {
     const int r = a.seed_read[a.sorted_uniq[s]];
     L = a.rd.len[r];
@@ -88,6 +81,9 @@ __global__ void __launch_bounds__(256) k_msv(MsvArgs a)
     for (int i = 0; i < MSV_REGS; i++) dp[i] = 0;
     if constexpr (SHARE) {
       if (valid && a.sl.depth > 0) {
+        // the parent chain's saved state this chain starts from (looked up per profile: two registers less in the row loop)
+        const int par = a.sl.parent[s];
+        const int64_t src_node = (int64_t)a.sl.node0[par] + __popcll(a.sl.mask[par] & ((1ull << a.sl.depth) - 1ull)) - a.sl.node_base;
         const uint4 *src = (const uint4 *)a.sl.slots + (src_node * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
 #pragma unroll
         for (int q = 0; q < 6; q++) {

@@ -115,6 +115,65 @@ __global__ void __launch_bounds__(64) k_calib_read16(const float4 *__restrict__ 
   for (int64_t r = 0; r < R; r++) { const float4 v = slab[(r0 + r) * 64 + lane]; acc += v.x + v.y + v.z + v.w; }
   out[(int64_t)blockIdx.x * 64 + lane] = acc;
 }
+// ---- VALU issue-rate probe (profiles/round5_valu_issue.md): chains of ONE instruction class with no dependence between
+// consecutive instructions (16 accumulators in rotation), `waves` waves per SIMD on every CU, timed per wave with s_memtime.
+// What bench.py's valu_issue_frac prices a kernel's instruction mix with.
+template <int OP>
+__device__ __forceinline__ void issue16(float (&x)[32], float a, float b)
+{
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
+    else if (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(float2 *)&x[2 * i]) : "v"(*(float2 *)&x[0]));   // (reads pair 0: written once per 16)
+    else if (OP == 2) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+    else if (OP == 3) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+    else if (OP == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(float2 *)&x[2 * i]) : "v"(*(float2 *)&x[0]));
+    else if (OP == 5) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(float2 *)&x[2 * i]) : "v"(*(float2 *)&x[0]));
+    else if (OP == 6) asm volatile("s_nop 0");
+    else if (OP == 7) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+    else if (OP == 8) asm volatile("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(*(float2 *)&x[2 * i]) : "v"(*(float2 *)&x[(2 * i + 2) & 31]));
+    else if (OP == 9) asm volatile("v_max_i16 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+  }
+}
+template <int OP>
+__global__ void __launch_bounds__(1024) k_issue(int iters, unsigned long long *__restrict__ ticks, float *__restrict__ sink)
+{
+  float x[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) x[i] = 1.0f + 1e-6f * (float)(threadIdx.x + i);
+  const float a = 0.999999f, b = 1e-7f;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it++) { issue16<OP>(x, a, b); issue16<OP>(x, a, b); issue16<OP>(x, a, b); issue16<OP>(x, a, b); }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; i++) s += x[i];
+  if ((threadIdx.x & 63) == 0) ticks[(size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+  if (s == 12345.678f) sink[0] = s;
+}
+void launch_issue(int op, int waves_per_simd, int iters, int blocks, unsigned long long *ticks, float *sink, hipStream_t st)
+{
+  // one block per CU with 4 x waves_per_simd waves and dynamic LDS no second block fits beside; past 4 waves per SIMD two blocks
+  // per CU (a block holds at most 16 waves)
+  const int per_cu = waves_per_simd > 4 ? 2 : 1;
+  const dim3 g((unsigned)(blocks * per_cu)), b((unsigned)(256 * waves_per_simd / per_cu));
+  const size_t lds = per_cu == 1 ? 96 * 1024 : 0;      // (two blocks of 12 / 16 waves per CU fill the chip exactly: the grid itself forces two on every CU)
+  switch (op) {
+    case 0: hipLaunchKernelGGL(k_issue<0>, g, b, lds, st, iters, ticks, sink); break;
+    case 1: hipLaunchKernelGGL(k_issue<1>, g, b, lds, st, iters, ticks, sink); break;
+    case 2: hipLaunchKernelGGL(k_issue<2>, g, b, lds, st, iters, ticks, sink); break;
+    case 3: hipLaunchKernelGGL(k_issue<3>, g, b, lds, st, iters, ticks, sink); break;
+    case 4: hipLaunchKernelGGL(k_issue<4>, g, b, lds, st, iters, ticks, sink); break;
+    case 5: hipLaunchKernelGGL(k_issue<5>, g, b, lds, st, iters, ticks, sink); break;
+    case 6: hipLaunchKernelGGL(k_issue<6>, g, b, lds, st, iters, ticks, sink); break;
+    case 7: hipLaunchKernelGGL(k_issue<7>, g, b, lds, st, iters, ticks, sink); break;
+    case 8: hipLaunchKernelGGL(k_issue<8>, g, b, lds, st, iters, ticks, sink); break;
+    default: hipLaunchKernelGGL(k_issue<9>, g, b, lds, st, iters, ticks, sink); break;
+  }
+}
+
 void launch_calib(int pattern, float *slab, int64_t nwaves, int64_t R, float *out, hipStream_t st)
 {
   if (pattern == 0) hipLaunchKernelGGL(k_calib_read4, dim3((unsigned)nwaves), dim3(64), 0, st, slab, R, 6, out);

@@ -48,8 +48,37 @@ WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4          # wave instructions per second: 1
 # k_fwd_bound (csrc/k_lazy.hip, the lazy stage's score-only Forward): nodes in their natural order, no striping -- per node 8 flops for the
 #            match cell (4 products, 3 sums, the emission), 3 for the insert cell, 3 for the delete cell, 2 for the E sum = 16 x 46 nodes = 736
 #            flops per lane-row; it is free to fuse (its result is a bound, not HMMER's float): 329 VALU instructions per row, 139 of them FMAs
-FLOPS_PER_ROW = {"k_filters_fwd": 960.0, "k_bwd_decode": 1056.0, "k_fwd_bound": 736.0}
+FLOPS_PER_ROW = {"k_filters_fwd": 960.0, "k_bwd_decode": 1056.0, "k_fwd_bound": 736.0}     # k_fwd_bound: 16 x the models' mean node count at run time (720 for 45 nodes)
 VALU_PER_ROW = {"k_filters_fwd": 533.0, "k_bwd_decode": 561.0, "k_fwd_bound": 329.0}
+# Instructions per wave and DP row by issue class (scripts/isa_count.py, the row loop without its rare branches).  Round 5 measured what
+# each class costs (profiles/round5_valu_issue.md, itsx_debug_issue): a PACKED instruction (v_pk_*: two f32 or two 16-bit cells per lane)
+# holds a SIMD 1.74 ns, a plain VALU instruction 1.00 ns, an s_nop 0.4 ns at full occupancy -- rounds 1-4 priced every instruction at
+# 4 cycles of a 2.4 GHz clock (1.67 ns), which read 1.02 for k_msv.  valu_issue_frac = sum(count x ns) x wave-rows / (1024 SIMDs x time).
+ISSUE_MIX = {"k_msv": {"packed": 69, "plain": 19, "s_nop": 3},
+             "k_fwd_bound": {"packed": 252, "plain": 77, "s_nop": 82},
+             "k_filters_fwd": {"packed": 484, "plain": 49, "s_nop": 21},
+             "k_bwd_decode": {"packed": 537, "plain": 24, "s_nop": 40}}
+ISSUE_NS = {"packed": 1.74, "plain": 1.00, "s_nop": 0.40}
+ISSUE_SOURCE = "built-in (profiles/round5_valu_issue.json not found)"
+N_SIMD = 1024
+
+
+def _load_issue():
+    global ISSUE_NS, ISSUE_SOURCE
+    p = os.path.join(ROOT, "profiles", "round5_valu_issue.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            d = json.load(f)
+        ISSUE_NS = {k: float(d["ns_per_simd"][k]) for k in ("packed", "plain", "s_nop")}
+        ISSUE_SOURCE = "profiles/round5_valu_issue.json"
+
+
+def issue_frac(kernel, wave_rows, ms):
+    """share of the SIMDs' issue time the kernel's own instruction mix accounts for (1.0 = nothing but its instructions, back to back)"""
+    if not ms or ms <= 0:
+        return None
+    ns_row = sum(ISSUE_MIX[kernel][c] * ISSUE_NS[c] for c in ISSUE_NS)
+    return wave_rows * ns_row / (N_SIMD * ms * 1e6)
 USES_FMA = {"k_fwd_bound"}       # priced against the FMA peak; the HMMER-order kernels against the no-FMA ceiling
 VALU_FMA_TFLOPS = 157.3          # the guide's fp32 vector peak (every instruction a fused multiply-add)
 # HBM bytes per lane-row from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE corrected by the factor
@@ -60,7 +89,7 @@ PMC_SOURCE = None
 
 def _load_pmc():
     global PMC_BYTES_PER_ROW, PMC_SOURCE
-    for name in ("round4_pmc_bytes_per_row.json", "round2_pmc_bytes_per_row.json"):
+    for name in ("round5_pmc_bytes_per_row.json", "round4_pmc_bytes_per_row.json", "round2_pmc_bytes_per_row.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             with open(p) as f:
@@ -311,6 +340,7 @@ def main():
                          "are not evaluated past their Forward score (the default: the step asks for coordinates, not for domtbl.txt); compact = "
                          "every pair evaluated, only the rows that can still win kept; full = every row resident (66 GB at 10 M reads)")
     ap.add_argument("--full-rows", action="store_true", help="= --rows full")
+    ap.add_argument("--alone-steps", type=int, default=1, help="1: one extra step with ITSX_MSV_OVERLAP=0 for the kernels' alone times (0 = skip)")
     ap.add_argument("--full-steps", type=int, default=1,
                     help="with --rows lazy: this many extra steps with every pair evaluated (--rows compact), after the timed ones and outside "
                          "`value`: `full_pipeline_value`, and the lazy coordinates are compared with them for equality (0 = skip)")
@@ -359,6 +389,7 @@ def main():
     from itsxpress_amd.dist import agree, exchange_and_finalize, exchange_rows, gather_rows, global_derep, read_rows
     import synth
     _load_pmc()
+    _load_issue()
 
     from itsxpress_amd.definitions import hmm_path
     fungi = hmm_path("Fungi") if args.taxa == "T" else None      # ITSx_db/HMMs/F.hmm via $ITSXPRESS_DB_DIR / an installed itsxpress
@@ -400,6 +431,9 @@ def main():
     eng = Engine(local_rank)
     eng.set_rows_mode(args.rows)
     nprof = eng.load_profiles(text=hmm)
+    # the models' node counts (LENG lines of the HMMER3/f text): k_fwd_bound's algorithmic flops are 16 per node and lane-row
+    lengs = [int(ln.split()[1]) for ln in hmm.split("\n") if ln.startswith("LENG ")]
+    mean_nodes = float(sum(lengs)) / max(len(lengs), 1) if lengs else 45.0
     d_blob = torch.from_numpy(blob).to(dev)      # the batch's ASCII text, resident in HBM before the timed region
     torch.cuda.synchronize()
 
@@ -510,6 +544,21 @@ def main():
         total_local = n_local
     st = eng.stats()
 
+    # one more step with nothing beside the scan kernels (ITSX_MSV_OVERLAP=0: the next chunk's k_msv does not run beside the domain stage and
+    # the bound pass), outside `value`: the kernels' ALONE times, which the roofline block uses when the timed steps' are stretched
+    alone = None
+    if args.alone_steps > 0 and args.cluster_id >= 1.0 and args.budget_s - (time.time() - T_START) > 2.5 * dt / max(args.steps, 1) + 30.0:
+        os.environ["ITSX_MSV_OVERLAP"] = "0"
+        progress("step without the MSV overlap (kernels alone)")
+        step()
+        torch.cuda.synchronize()
+        del os.environ["ITSX_MSV_OVERLAP"]
+        sa = eng.stats()
+        alone = {"k_msv": sa["ms_msv_kernel"], "k_fwd_bound": sa["ms_bound_kernel"], "k_filters_fwd": sa["ms_fwd_kernel"], "k_bwd_decode": sa["ms_bwd_kernel"],
+                 "k_decode": sa["ms_decode_kernel"], "k_env_fwd+k_env_bwd+k_env_post": sa["ms_env_kernel"]}
+        if use_dist:
+            dist.barrier()
+
     # the same step with EVERY pair evaluated (--rows compact), outside `value`: what the lazy stage saves, and that it changes nothing
     full_leg = None
     if args.rows == "lazy" and args.full_steps > 0 and args.cluster_id >= 1.0:
@@ -608,18 +657,21 @@ def main():
         }
         # what bounds each of them: the DP scans are VALU-bound (no-FMA fp32), the streaming kernels HBM-bound
         rows = st["fwd_rows"]
-        krows = {"k_filters_fwd": rows, "k_bwd_decode": rows, "k_fwd_bound": st["bound_rows"]}
-        tfl = {k: (krows[k] * FLOPS_PER_ROW[k] / (kern[k] * 1e-3) / 1e12 if kern[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode", "k_fwd_bound")}
-        vfrac = {
-            "k_msv": (st["msv_cells"] / 32.7) / (kern["k_msv"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_msv"] > 0 else None,        # 64 lanes x 45 cells per 88 wave instructions of a row
-            "k_filters_fwd": (rows / 64 * VALU_PER_ROW["k_filters_fwd"]) / (kern["k_filters_fwd"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_filters_fwd"] > 0 else None,
-            "k_bwd_decode": (rows / 64 * VALU_PER_ROW["k_bwd_decode"]) / (kern["k_bwd_decode"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_bwd_decode"] > 0 else None,
-            "k_fwd_bound": (st["bound_rows"] / 64 * VALU_PER_ROW["k_fwd_bound"]) / (kern["k_fwd_bound"] * 1e-3) / WAVE_INSTR_PEAK if kern["k_fwd_bound"] > 0 else None,
-        }
-        kernel_table = {k: {"ms": round(kern[k], 3), "alg_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) if kern[k] > 0 else None,
+        # lane-rows each scan kernel COMPUTED (with prefix sharing: the chains' own rows, not the rows of their pairs)
+        krows = {"k_filters_fwd": rows, "k_bwd_decode": rows, "k_fwd_bound": st["bound_rows"], "k_msv": st["msv_rows"]}
+        FLOPS_PER_ROW["k_fwd_bound"] = 16.0 * mean_nodes               # the profiles' own node count (45 for every ITSx model but two: 720), not the kernel's 46 slots
+        # the roofline and the issue fractions use a kernel's ALONE time when the extra step measured one (the timed steps' can be stretched by what ran beside it)
+        kt = {k: (alone[k] if (alone and alone.get(k, 0) > 0) else kern[k]) for k in kern}
+        tfl = {k: (krows[k] * FLOPS_PER_ROW[k] / (kt[k] * 1e-3) / 1e12 if kt[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode", "k_fwd_bound")}
+        vfrac = {k: issue_frac(k, krows[k] / 64.0, kt[k]) for k in ISSUE_MIX}
+        pmc = PMC_BYTES_PER_ROW or {}
+        kernel_table = {k: {"ms": round(kern[k], 3), "ms_alone": round(alone[k], 3) if alone else None,
+                            "alg_GBps": round(alg[k] / (kern[k] * 1e-3) / 1e9, 1) if kern[k] > 0 else None,
                             "hbm_frac": round(alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern[k] > 0 else None,
                             "nofma_tflops": round(tfl[k], 2) if tfl.get(k) else None,
-                            "valu_issue_frac": round(vfrac[k], 3) if vfrac.get(k) else None} for k in kern}
+                            "valu_issue_frac": round(vfrac[k], 3) if vfrac.get(k) else None,
+                            # HBM traffic from the PMC counters (bytes per lane-row x the rows of this run) over the kernel's algorithmic bytes
+                            "traffic_vs_alg": round(pmc[k] * krows[k] / alg[k], 2) if (k in pmc and k in krows and alg[k] > 0) else None} for k in kern}
         # launches of the dominant kernel in one step, for per-launch figures
         nl = {"k_msv": max(1, int(st.get("msv_launches", 1))), "k_fwd_bound": max(1, int(st.get("n_bound_launches", 1)))}.get(dom, max(1, int(st.get("n_batches", 1))))
         traffic = None
@@ -632,16 +684,19 @@ def main():
             roof = {"kernel": dom, "bound": "valu", "achieved": round(tfl[dom], 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": tfl[dom] / peak, "frac_of_fma_peak": tfl[dom] / VALU_FMA_TFLOPS, "frac_of_nofma_peak": tfl[dom] / VALU_NOFMA_TFLOPS,
                     "fma_peak": VALU_FMA_TFLOPS, "nofma_peak": round(VALU_NOFMA_TFLOPS, 1), "valu_issue_frac": vfrac.get(dom),
-                    "launches_per_step": nl, "avg_launch_ms": kern[dom] / nl,
+                    "issue_ns": dict(ISSUE_NS), "issue_mix_per_row": ISSUE_MIX.get(dom), "issue_source": ISSUE_SOURCE,
+                    "time_used": "alone (ITSX_MSV_OVERLAP=0 step)" if alone else "timed steps",
+                    "launches_per_step": nl, "avg_launch_ms": kt[dom] / nl,
                     "alg_flops_per_launch": krows[dom] * FLOPS_PER_ROW[dom] / nl, "alg_flops_per_lane_row": FLOPS_PER_ROW[dom], "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
                     "hbm_frac_on_alg_bytes": alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic_source": PMC_SOURCE if traffic is not None else None,
                     "survey_bytes_per_step": survey_bytes,
                     "traffic_vs_survey_bytes": (traffic * nl / survey_bytes) if traffic is not None else None,
-                    "note": ("the lazy stage's score-only Forward: the recurrence's own flops per lane-row in node order (16 per node x 46: bench.py's header) "
-                             "against the fp32 FMA peak 157.3 TFLOP/s -- 139 of its 329 instructions per row can be fused, the rest are the recurrence's plain "
-                             "products, sums and one register move per pair of nodes, so valu_issue_frac (instruction issue slots used) is the figure that says "
-                             "how much is left; duration = HIP events on the engine's stream.  " if dom in USES_FMA else "") +
+                    "note": ("the lazy stage's score-only Forward over the rows its chains COMPUTE (prefix sharing: config.rows_shared_frac of the pairs' rows come "
+                             "from saved states): the recurrence's own flops per lane-row in node order (16 per model node: 720 for the 45-node ITSx models) "
+                             "against the fp32 FMA peak 157.3 TFLOP/s -- 139 of its 329 instructions per row can be fused, and a packed instruction issues at the "
+                             "rate of two plain ones (profiles/round5_valu_issue.md), so valu_issue_frac -- the kernel's instruction mix priced with the measured "
+                             "issue times, over the SIMDs' time -- is the figure that says how much is left; duration = HIP events on the engine's stream.  " if dom in USES_FMA else "") +
                             "a serial recurrence per (representative, profile): the recurrence's own no-FMA fp32 flops per lane-row (HMMER rounds "
                             "products and sums separately; Forward 960, Backward 1056 with its four unconditional DD passes: the count is "
                             "spelled out at the top of bench.py) against 78.6 TFLOP/s = 1024 SIMDs x 32 lanes x 2.4 GHz; duration = HIP events on the "
@@ -684,6 +739,13 @@ def main():
                        "undecided_rows_that_mattered": int(st["n_lazy_pending"]) if st["lazy"] else None,
                        "profiles_counted_exactly": int(st["n_lazy_completed_profiles"]) if st["lazy"] else None,
                        "pairs_of_those_profiles": int(st["n_lazy_completed"]) if st["lazy"] else None,
+                       # prefix sharing (csrc/k_share.hip): rows the two scan kernels did NOT compute because another representative of the same length
+                       # had the same first residues (the state comes from its saved row state); tree = what the prefix tree offers at this block size
+                       "rows_shared_frac": {"k_fwd_bound": round(1.0 - st["bound_rows"] / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,
+                                            "k_msv": round(1.0 - st["msv_rows"] / st["msv_rows_full"], 4) if st.get("msv_rows_full") else None,
+                                            "tree": round(st["share_frac"], 4), "block_rows": int(st["share_B"]), "saved_states": int(st["share_nodes"]),
+                                            "chains_with_a_parent": int(st["share_chains"]), "batches": int(st["share_batches"]),
+                                            "pairs_run_for_their_states_only": int(st["n_share_helpers"]), "build_ms": round(acc.get("ms_share_build", 0.0) / K, 2)},
                        "parallelism": "reads sharded x%d%s" % (world, (", exact global derep" if args.global_derep else ", per-shard derep") if use_dist else "")},
             "full_pipeline": full_leg,
             "full_pipeline_value": (total_local * full_leg["steps"] / (full_leg["ms_per_step"] * 1e-3 * full_leg["steps"])) if (full_leg and "ms_per_step" in full_leg) else None,

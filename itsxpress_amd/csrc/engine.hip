@@ -1443,8 +1443,8 @@ static int build_share(itsx_ctx *ctx)
   S.share_B = 0; S.share_batches = 0; S.share_nodes = S.share_chains = 0; S.ms_share_build = 0; S.share_frac = 0;
   const int32_t U = ctx->U_active, Uc = (int32_t)std::min<int64_t>(ctx->s_Uc, 0x7fffffff), P = ctx->P;
   if (const char *e = getenv("ITSX_SHARE")) if (atoi(e) == 0) return ITSX_OK;
-  // (the pair traces name uniques by sorted position; the A/B switches of the bound pass use the classic wave list)
-  if (ctx->keep_trace || getenv("ITSX_LAZY_EXACT_BOUND") || getenv("ITSX_LAZY_CHECK_BOUND")) return ITSX_OK;
+  // (the pair traces name uniques by sorted position; the A/B switch of the bound pass uses the classic wave list)
+  if (ctx->keep_trace || getenv("ITSX_LAZY_EXACT_BOUND")) return ITSX_OK;
   if (U < 2 || U >= (1 << 26) || P <= 0) return ITSX_OK;
   int B = 32;
   if (const char *e = getenv("ITSX_SHARE_B")) B = atoi(e);
@@ -1654,7 +1654,10 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
     {   // lazy domain stage (k_lazy.hip): bits <= (fwdsc - nullsc) / ln 2 + C(L); + 0.02 bits for float rounding, rounded up to float
       const double n = (double)L;
       const double c = 1.0 + (2.0 * log(2.0 * (n + 3.0) / (3.0 * (n + 2.0))) + n * log((n + 3.0) / (n + 2.0))) / 0.69314718055994529;
-      t.lazy_c = nextafterf((float)(c + 0.02), 1e30f);
+      // the margin covers the rounding of both float sums (the bound kernel's and HMMER's own: sums of positive products, relative
+      // error <= ~3 (n + M) 2^-24 each): 0.02 bits up to ~38 000 residues, growing with n beyond (0.034 bits at 65 535)
+      const double margin = std::max(0.02, 6.0 * (n + (double)MMAX) * 5.9604644775390625e-8 / 0.69314718055994529);
+      t.lazy_c = nextafterf((float)(c + margin), 1e30f);
     }
     { const float w = roundf((float)(500.0 / 0.69314718055994529) * logf((2.0f + 1.0f) / ((float)L + 2.0f + 1.0f)));
       t.vmove = (w >= 32767.0f) ? 32767 : (w <= -32768.0f) ? -32768 : (int)w; }
@@ -2360,6 +2363,28 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     const float ms = tm.stop();
     S.ms_bound_kernel += ms; S.ms_filters += ms;
     S.bound_rows += lane_rows[0]; S.bound_rows_full += lane_rows[1];
+    if (getenv("ITSX_LAZY_CHECK_BOUND")) {       // test hook: the shared chains' scores against HMMER's own arithmetic from row 1
+      DBuf<float> ref;
+      HIPCHK(ref.alloc((size_t)NP + 1));
+      for (int t = 0; t < nseg; t++)
+        for (int p = 0; p < P; p++) {
+          const int w0 = woff[(size_t)t * P + p], w1 = woff[(size_t)t * P + p + 1];
+          if (w1 > w0) launch_fwd_bound(a, ref.p, w1 - w0, w0, (int)ctx->generic_q[(size_t)p], st);
+        }
+      std::vector<float> h0((size_t)NP), h1((size_t)NP); std::vector<PairRec> hp((size_t)NP);
+      HIPCHK(hipMemcpyAsync(h0.data(), ref.p, (size_t)NP * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(h1.data(), ctx->l_fb.p, (size_t)NP * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(hp.data(), pl.pairs, (size_t)NP * sizeof(PairRec), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      float mx = S.lazy_bound_maxdiff;
+      for (int64_t i = 0; i < NP; i++) {
+        if (hp[(size_t)i].prof < 0) continue;
+        const float x = h0[(size_t)i], y = h1[(size_t)i];
+        if (x != x || y != y) { if ((x != x) != (y != y)) mx = 1e30f; continue; }
+        mx = std::max(mx, fabsf(x - y));
+      }
+      S.lazy_bound_maxdiff = mx;
+    }
     if (getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0) {
       // test hook: every pair again from row 1 (the same wave list serves: a wave needs its profile, its pairs and its longest target)
       HIPCHK(ctx->sh_fb_chk.alloc((size_t)NP + 1));

@@ -210,4 +210,57 @@ def test_bound_kernel_agrees_with_the_forward_parser(engine, t_hmm_text, mini_hm
         blob, offs = synth.make_reads(src, n, config=3, seed=synth.SEED + 11, fixed_len=0, len_range=(120, 900), n_rate=0.004)
         _, st = _coords(engine, hmm, synth.to_strings(blob, offs), "lazy")
         assert st["n_past_msv"] > 1000
+        assert st["share_B"] == 32                        # (the chains of the prefix tree: rows that continue from a saved state)
         assert 0.0 <= st["lazy_bound_maxdiff"] < 1e-3, st["lazy_bound_maxdiff"]
+
+
+def _ccs_reads(t_hmm_text, rng, lengths, per_family=6):
+    """CCS-shaped targets (--trim-ccs inputs, itsxpress/SeqSample.py:48-91): kilobases of random sequence with full and PARTIAL copies of
+    a left and a right motif in tandem, a few error variants of each"""
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    lm = [m for m in synth.consensus_motifs(t_hmm_text, "3_") if len(m) == 45]
+    rm = [m for m in synth.consensus_motifs(t_hmm_text, "4_") if len(m) == 45]
+    seqs = []
+    for L in lengths:
+        base = acgt[rng.integers(0, 4, L)].copy()
+        a = int(rng.integers(50, 400))
+        while a + 400 < L:
+            l, r = lm[int(rng.integers(0, len(lm)))], rm[int(rng.integers(0, len(rm)))]
+            cut = int(rng.integers(0, 25))                                 # a partial copy now and then
+            base[a:a + 45 - cut] = np.frombuffer(l.encode(), np.uint8)[cut:]
+            b = a + 45 + int(rng.integers(100, 260))
+            base[b:b + 45] = np.frombuffer(r.encode(), np.uint8)
+            a = b + 45 + int(rng.integers(200, 3000))
+        for j in range(per_family):
+            v = base.copy()
+            for pos in rng.integers(0, L, 1 + j):
+                v[pos] = acgt[(np.searchsorted(acgt, v[pos]) + 1 + rng.integers(0, 3)) % 4]
+            if j == per_family - 1:
+                v[int(rng.integers(0, L))] = ord("N")
+            seqs.append(bytes(v).decode())
+    return seqs
+
+
+def test_lazy_equals_the_full_table_on_ccs_length_reads(engine, t_hmm_text, monkeypatch):
+    """2-20 kb targets with tandem partial copies and one target at the engine's limit of 65 535 residues: the bound kernel stays within
+    half the margin of HMMER's own Forward (the margin grows with the length: engine.hip, lazy_c), and the lazy coordinates are the full
+    table's -- with the prefix tree (63 blocks deep) and without"""
+    rng = np.random.default_rng(41)
+    lengths = [2000, 2600, 3500, 5000, 7000, 9000, 12000, 16000, 20000]
+    seqs = _ccs_reads(t_hmm_text, rng, lengths) + _ccs_reads(t_hmm_text, rng, [65535], per_family=2)
+    hmm = _its2_subset(t_hmm_text, 8, 8)
+    monkeypatch.setenv("ITSX_SHARE", "0")
+    ref, _ = _coords(engine, hmm, seqs, "full")
+    assert sum(int(((c[0] >= 0) | (c[1] >= 0)).sum()) for c in ref) > len(seqs) // 2
+    monkeypatch.setenv("ITSX_LAZY_CHECK_BOUND", "1")
+    margin_nats = lambda n: max(0.02, 6.0 * (n + 46) * 2.0 ** -24 / np.log(2.0)) * np.log(2.0)
+    for share in ("0", "1"):
+        monkeypatch.setenv("ITSX_SHARE", share)
+        monkeypatch.setenv("ITSX_SHARE_MIN", "0")
+        got, st = _coords(engine, hmm, seqs, "lazy")
+        assert st["lazy"] == 1 and st["n_lazy_reruns"] == 0 and (st["share_B"] == 32) == (share == "1")
+        assert 0.0 <= st["lazy_bound_maxdiff"] < 0.5 * margin_nats(65535), st["lazy_bound_maxdiff"]
+        assert _same(ref, got)
+    # the same bound on the 2-20 kb targets alone (what the 0.02-bit margin has to cover)
+    _, st = _coords(engine, hmm, seqs[:-2], "lazy")
+    assert 0.0 <= st["lazy_bound_maxdiff"] < 0.5 * margin_nats(20000), st["lazy_bound_maxdiff"]

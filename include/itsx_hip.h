@@ -199,6 +199,15 @@ int itsx_stream_close(itsx_stream *s, int32_t keep_text);
 /* an upper bound of the number of records in the whole file (lines / 4 for FASTQ), or -1 while it is still being inflated */
 int64_t itsx_stream_records_bound(itsx_stream *s);
 const char *itsx_stream_last_error(void);
+/* ---- one file's records in pieces, for the workers of a multi-GPU driver (host-only, context-free: csrc/shard_host.cpp; driver:
+ * itsxpress_amd/multi.py).  The reference hands the whole file to one vsearch process (itsxpress/SeqSample.py:93-131, 266-365).
+ * itsx_shard_text: the file's text (plain / gzip / zstd, inflated once, kept in the process's text cache) cut into n_parts contiguous
+ *   pieces at record starts near equal byte counts; piece p is written as the plain file out_prefix.<p> (use a /dev/shm prefix) and
+ *   holds records[p] records (bytes[p] bytes; bytes may be NULL).  match_records != NULL (a mate file, R2 after R1): piece p is cut
+ *   to hold exactly match_records[p] records instead; a file that does not hold them is ITSX_E_FORMAT.
+ * Errors: negative code, text from itsx_shard_last_error(). */
+int itsx_shard_text(const char *path, int32_t n_parts, const int64_t *match_records, const char *out_prefix, int64_t *records, int64_t *bytes);
+const char *itsx_shard_last_error(void);
 itsx_keyset *itsx_keyset_create(void);
 void itsx_keyset_destroy(itsx_keyset *k);
 int64_t itsx_keyset_size(const itsx_keyset *k);

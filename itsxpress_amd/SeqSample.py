@@ -190,6 +190,11 @@ class SeqSample:
             eng.load_profiles(path=hmmfile)
             fast = self._is_fast()
             # file-compatible: every domain row stays (domtbl.txt); arrays mode: the lazy domain stage, coordinates only
+            nu = int(getattr(eng, "n_unique", 0) or 0)
+            if not fast and nu > 1000000:
+                logging.info("itsx_hip search: %d unique sequences in file-compatible mode -- every (sequence, profile) pair is evaluated and "
+                             "domtbl.txt gets about %d rows (~%.0f GB); ITSXPRESS_ARRAYS=1 keeps the tables in the engine, evaluates only the pairs that "
+                             "can win and gives the same trimmed reads several times faster (INTEGRATION.md 3b)", nu, nu * 136, nu * 136 * 200 / 1e9)
             eng.set_rows_mode("lazy" if fast else "full")
             eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
             eng.finalize(domE=10.0)
@@ -447,6 +452,11 @@ class Dedup:
                 return
             # arrays mode: per-read coordinates straight from the engine, in the order of seq_file's records (the engine read them from it)
             start, stop, _, _ = self._engine.trim_coords(itspos.leftprefix, itspos.rightprefix)
+            if not os.path.exists(self.seq_file) and getattr(self._engine, "_last_merge", None) is not None:
+                # a paired sample whose merged reads never left the engine (_merge_reads in arrays mode writes no seq.fq) and whose caller
+                # wants the MERGED reads trimmed (main.py:596-624: --fastq2 without --outfile2): the merged records are written now
+                logging.info("itsx_hip: writing the merged reads to %s for the single merged output", self.seq_file)
+                self._engine.write_merged_fastq(self.seq_file)
             write_trimmed_fastq(self.seq_file, outfile, start, stop, gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)
             return
         names = read_names(self.seq_file)           # the native writer's own record parser: names and records cannot disagree
@@ -494,7 +504,11 @@ def install():
 
     ref.SeqSample.engine = property(_eng)
     ref.SeqSample._load_reads = SeqSample._load_reads
-    ref.SeqSample._is_fast = SeqSample._is_fast
+    # The reference's own ItsPosition / Dedup stay in place here and open uc.txt / domtbl.txt by PATH, so the installed methods always
+    # run file-compatible -- whatever ITSXPRESS_ARRAYS says (its EngineTable tokens are understood by this package's mirror classes only)
+    if _fast_from_env():
+        logging.getLogger(__name__).info("ITSXPRESS_ARRAYS is ignored by install(): the reference's ItsPosition / Dedup read uc.txt and domtbl.txt")
+    ref.SeqSample._is_fast = lambda self: False
     ref.SeqSample.deduplicate = SeqSample.deduplicate
     ref.SeqSample.cluster = SeqSample.cluster
     ref.SeqSample._search = SeqSample._search

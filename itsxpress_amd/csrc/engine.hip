@@ -267,6 +267,7 @@ struct itsx_ctx {
 
   // ---- derep
   bool have_derep = false;
+  int derep_strand_both = 1;             // how the last itsx_derep / itsx_cluster matched (the cross-shard keys follow it)
   int32_t U = 0;
   int32_t U_active = 0;                  // uniques this context scores (all of them unless itsx_set_active_uniques narrowed it)
   DBuf<int32_t> d_rep_of, d_uniq_of, d_seed_read, d_abund, d_sorted_uniq, d_ulen;
@@ -1091,6 +1092,7 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
   for (int64_t r = 0; r < n; r++) dropped += ctx->h_rep_of[r] < 0;
   ctx->stats.n_unique = U; ctx->stats.n_dropped_short = dropped;
   ctx->have_derep = true; ctx->have_search = ctx->have_final = false; ctx->clustered = false;
+  ctx->derep_strand_both = strand_both != 0;
   if (n_unique) *n_unique = U;
   return ITSX_OK;
 }
@@ -3360,8 +3362,10 @@ int itsx_unique_keys128_device(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, 
   HIPCHK(ctx->w_keys128.alloc((size_t)U * 4 + 4));
   if (n > 0 && U > 0) {
     HIPCHK(ctx->w_hf.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr.alloc((size_t)n + 1)); HIPCHK(ctx->w_hf1.alloc((size_t)n + 1)); HIPCHK(ctx->w_hr1.alloc((size_t)n + 1));
-    launch_hash_reads(ctx->rd, seed_a, 1, ctx->w_hf.p, ctx->w_hr.p, ctx->st);
-    launch_hash_reads(ctx->rd, seed_b, 1, ctx->w_hf1.p, ctx->w_hr1.p, ctx->st);
+    // (a plus-strand-only dereplication keeps a sequence and its reverse complement apart across shards too: the key is the forward
+    // strand's then -- k_hash_reads returns it for both strands -- and every flag says "forward")
+    launch_hash_reads(ctx->rd, seed_a, ctx->derep_strand_both, ctx->w_hf.p, ctx->w_hr.p, ctx->st);
+    launch_hash_reads(ctx->rd, seed_b, ctx->derep_strand_both, ctx->w_hf1.p, ctx->w_hr1.p, ctx->st);
     hipLaunchKernelGGL(k_unique_keys128, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, ctx->st, U, ctx->d_seed_read.p, ctx->rd.len, ctx->w_hf.p, ctx->w_hr.p,
                        ctx->w_hf1.p, ctx->w_hr1.p, gidx_base, ctx->w_keys128.p);
   }

@@ -424,6 +424,10 @@ struct StreamImpl {
   size_t handed = 0;
   bool fastq = true;
   long long bound = -1;
+  // next() looks for a record start with the lock released: the inflater's serial fallback (which may move the text) waits while a
+  // scan is under way, and a scan that ran across a fallback is thrown away (advisor, round 4)
+  bool scanning = false;
+  int gen = 0;
 };
 
 namespace {
@@ -446,6 +450,8 @@ size_t fastq_start_from(const char *t, size_t n, size_t from)
   return n;
 }
 }  // namespace
+
+size_t fastq_record_start(const char *t, size_t n, size_t from) { return fastq_start_from(t, n, from); }
 
 TextStream::TextStream() : s(new StreamImpl) {}
 TextStream::~TextStream()
@@ -506,6 +512,11 @@ bool TextStream::open(const char *path, std::string &err)
       std::unique_lock<std::mutex> g(z->mu);
       if (z->handed == 0) {
         z->avail = 0;
+        z->gen++;
+        z->cv.wait(g, [z] { return !z->scanning; });       // nobody reads the text while it is unpinned and filled again
+        if (z->handed != 0) e = "the block-parallel inflater gave up after slices had been handed out";
+      }
+      if (z->handed == 0) {
         g.unlock();
         z->text->pin(false);
         ok = g_ld.ok ? gunzip_libdeflate(z->raw, *z->text, e) : gunzip_zlib(z->raw, *z->text, e);
@@ -548,9 +559,14 @@ bool TextStream::next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *
     }
     // a record start about `window` before the target (the record-start test needs the two lines that follow the title)
     const size_t from = target > s->handed + window ? target - window : s->handed + 1;
+    const int gen = s->gen;
+    s->scanning = true;
     g.unlock();
     const size_t c = fastq_start_from(t, avail, from);
     g.lock();
+    s->scanning = false;
+    s->cv.notify_all();
+    if (gen != s->gen) continue;                        // the text was void (the inflater fell back): wait for the real one
     if (c < avail && c > s->handed) {
       *ptr = t + s->handed; *nbytes = c - s->handed; *last = false;
       s->handed = c;

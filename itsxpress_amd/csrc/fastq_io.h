@@ -97,6 +97,9 @@ class TextStream {
   StreamImpl *s;
 };
 
+// first FASTQ record start at or after `from` in t[0, n) (a line that starts with '@' whose second line below starts with '+'); n: none
+size_t fastq_record_start(const char *t, size_t n, size_t from);
+
 struct WriterImpl;
 class BlockWriter {
  public:

@@ -271,7 +271,24 @@ class Engine:
         self._chk(self.L.itsx_merge_pairs_load(self.h, os.fsencode(r1), os.fsencode(r2), int(maxdiffs), float(maxee), int(allow_stagger),
                                                C.byref(n), C.byref(m)))
         self.n_reads, self.n_samples, self.n_unique = m.value, 1, 0
+        self._last_merge = dict(r1=r1, r2=r2, maxdiffs=int(maxdiffs), maxee=float(maxee), allow_stagger=bool(allow_stagger))
         return n.value, m.value
+
+    def write_merged_fastq(self, path):
+        """After merge_pairs_load (which writes nothing): the merged records as a FASTQ file after all -- the same merge once more, in a
+        context of its own (this engine's read set and results stay as they are); record i of the file is read i of this engine.  For
+        the consumer that wants the MERGED reads trimmed (Dedup.create_trimmed_seqs on a paired sample, itsxpress/main.py:596-624)."""
+        lm = getattr(self, "_last_merge", None)
+        if lm is None:
+            raise EngineError(-1, "write_merged_fastq: this engine's reads do not come from merge_pairs_load")
+        tmp = Engine(self.device)
+        try:
+            n, m = tmp.merge_pairs_files(lm["r1"], lm["r2"], path, maxdiffs=lm["maxdiffs"], maxee=lm["maxee"], allow_stagger=lm["allow_stagger"])
+        finally:
+            tmp.close()
+        if m != self.n_reads:
+            raise EngineError(-1, "write_merged_fastq: %d merged records written, the engine holds %d" % (m, self.n_reads))
+        return m
 
     def get_cluster(self):
         """After cluster(id < 1): (pct_id float64[n_reads] (-1 for centroids / dropped), order int64[kept])."""

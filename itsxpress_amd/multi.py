@@ -14,13 +14,22 @@ sharded by contiguous index range.  The results are those of one GPU on the whol
   * uc.txt / rep.fa / domtbl.txt are written from the gathered arrays by the library's context-free writers
     (csrc/writers_host.cpp), byte-identical to the files one GPU writes.
 
-No torch, no collective library: the two exchanges are tiny (40 B per unique, 16 B per profile) and travel as numpy arrays over
-the workers' pipes.  bench.py's torch.distributed / RCCL path (itsxpress_amd/dist.py) is the device-resident alternative for a
-driver that already runs one process per GPU.
+No torch, no collective library.  Round 5: the parent no longer touches anything of the size of the data (it used to sort every
+worker's uniques on ONE core -- 8-46 s for 6 M uniques -- and to compose the coordinates per read).  The exchanges go worker to worker
+through files under /dev/shm (memory), the pipes carry commands and counts only:
+  * the owner step is hash-partitioned like dist.global_derep: key mod N owns, every worker sorts its Nth (`owner_verdicts` on a share);
+  * per-read coordinates are composed IN the workers (each reads the scorers' per-representative rows) into one shared array;
+  * the input file is inflated once by the parent and cut into record-aligned pieces (csrc/shard_host.cpp), R2 at R1's record counts;
+    merging and orientation run on every worker's piece.
+The global unique list (numbers in input order of the first occurrences) is only built when a file-compatible writer or get_derep
+asks for it.  bench.py's torch.distributed / RCCL path (itsxpress_amd/dist.py) is the device-resident alternative for a driver that
+already runs one process per GPU.
 """
 import ctypes as C
 import multiprocessing as mp
 import os
+import tempfile
+import time
 
 import numpy as np
 
@@ -99,6 +108,158 @@ def _h_load_shard(eng, st, path):
     eng.n_reads, eng.n_samples = n.value, 1
     st["base"] = first.value
     return tot.value, first.value, n.value
+
+
+def _xpath(st, tag, src, dst):
+    return "%s_%s_%d_%d.npy" % (st["xprefix"], tag, src, dst)
+
+
+def _h_job(eng, st, xprefix):
+    st["xprefix"] = xprefix
+    return None
+
+
+def _h_load_piece(eng, st, piece, base, n_expect):
+    """this worker's piece of the input (cut by the parent: itsx_shard_text); the piece is memory (/dev/shm) and goes once loaded"""
+    n = eng.load_reads_file(piece)
+    try:
+        os.unlink(piece)
+    except OSError:
+        pass
+    if n != n_expect:
+        raise RuntimeError("piece %s: %d records parsed, %d counted" % (piece, n, n_expect))
+    st["base"] = int(base)
+    return n
+
+
+def _h_merge_piece(eng, st, p1, p2, out, maxdiffs, maxee, allow_stagger):
+    """merge this worker's pieces of R1 / R2: into the engine's read set (out None) or into a piece of seq.fq"""
+    try:
+        if out is None:
+            n, m = eng.merge_pairs_load(p1, p2, maxdiffs=maxdiffs, maxee=maxee, allow_stagger=allow_stagger)
+        else:
+            n, m = eng.merge_pairs_files(p1, p2, out, maxdiffs=maxdiffs, maxee=maxee, allow_stagger=allow_stagger)
+    finally:
+        for p in (p1, p2):
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+    return n, m
+
+
+def _h_set_base(eng, st, base):
+    st["base"] = int(base)
+    return None
+
+
+def _h_orient_piece(eng, st, piece, db):
+    eng.orient_load_db(db)
+    try:
+        strand, cf, cr = eng.orient_file(piece)
+    finally:
+        try:
+            os.unlink(piece)
+        except OSError:
+            pass
+    return strand, cf, cr
+
+
+def _h_derep_x(eng, st, strand_both, minlen):
+    """phase A of the exchange: dereplicate the shard, send every unique's tuple to the key's owner (key mod N)"""
+    U = eng.derep(strand_both=strand_both, minseqlength=minlen)
+    tup = np.zeros((max(U, 1), 4), np.int64)
+    eng._chk(eng.L.itsx_unique_keys128(eng.h, C.c_uint64(KEY_SEEDS[0]), C.c_uint64(KEY_SEEDS[1]), int(st["base"]), tup.ctypes.data))
+    tup = tup[:U]
+    st["tup"] = tup
+    N, r = st["world"], st["rank"]
+    owner = (tup[:, 1].view(np.uint64) % np.uint64(N)).astype(np.int64) if U else np.zeros(0, np.int64)
+    st["sent"] = []
+    for d in range(N):
+        idx = np.nonzero(owner == d)[0]
+        st["sent"].append(idx)
+        np.save(_xpath(st, "t", r, d), np.concatenate([tup[idx], idx[:, None]], axis=1))
+    return U
+
+
+def _h_own_x(eng, st):
+    """phase B: the owner's step on this worker's share of the keys; the answers go back in the order the rows came"""
+    N, d = st["world"], st["rank"]
+    parts = []
+    for r in range(N):
+        p = _xpath(st, "t", r, d)
+        parts.append(np.load(p))
+        os.unlink(p)
+    src = np.concatenate([np.full(a.shape[0], r, np.int64) for r, a in enumerate(parts)]) if parts else np.zeros(0, np.int64)
+    recv = np.concatenate(parts) if parts else np.zeros((0, 5), np.int64)
+    ans = owner_verdicts(recv, src)
+    at = 0
+    for r, a in enumerate(parts):
+        np.save(_xpath(st, "v", d, r), ans[at:at + a.shape[0]])
+        at += a.shape[0]
+    return int(recv.shape[0])
+
+
+def _h_verdict_x(eng, st):
+    """phase C: the verdicts of this worker's uniques, collected from the owners; it scores what it was chosen for"""
+    N, r = st["world"], st["rank"]
+    U = eng.n_unique
+    verdict = np.zeros((U, 4), np.int64)
+    for d in range(N):
+        p = _xpath(st, "v", d, r)
+        verdict[st["sent"][d]] = np.load(p)
+        os.unlink(p)
+    st["sent"] = None
+    n_act = _h_verdict(eng, st, verdict)
+    seed, _ = eng.get_uniques()
+    n_seeds = int((verdict[:, 0] == seed + st["base"]).sum()) if U else 0       # global first occurrences this shard holds
+    return n_act, n_seeds
+
+
+def _h_get_verdict(eng, st):
+    return st["verdict"]
+
+
+def _h_rows_pub(eng, st, left, right):
+    """coordinates, step 1: the per-representative rows of this worker, where every worker can read them"""
+    np.save(_xpath(st, "r", st["rank"], 0), np.stack(eng.rep_coords(left, right), axis=1).astype(np.int32))
+    return None
+
+
+def _h_rows_compose(eng, st, out_path, n_total):
+    """coordinates, step 2: this shard's reads -> their local unique -> the scorer's row, written into the sample's shared array"""
+    N = st["world"]
+    v = st["verdict"]
+    U = v.shape[0]
+    urows = np.full((U + 1, 4), -1, np.int32)
+    urows[:, 3] = 0                                       # row U: a read that belongs to no cluster
+    for w in range(N):
+        mine = np.nonzero(v[:, 2] == w)[0]
+        if mine.shape[0]:
+            rw = np.load(_xpath(st, "r", w, 0), mmap_mode="r")
+            urows[mine] = rw[v[mine, 3]]
+    uq = eng.get_derep()[2]
+    g = np.where(uq >= 0, uq, U)
+    out = np.lib.format.open_memmap(out_path, mode="r+")
+    out[st["base"]:st["base"] + uq.shape[0]] = urows[g]
+    out.flush()
+    del out
+    return int(uq.shape[0])
+
+
+def _h_rows_done(eng, st):
+    try:
+        os.unlink(_xpath(st, "r", st["rank"], 0))
+    except OSError:
+        pass
+    return None
+
+
+def _h_names_pub(eng, st, path):
+    blob, offs = eng.read_names_raw()
+    np.save(path + ".b.npy", np.frombuffer(blob, np.uint8))
+    np.save(path + ".o.npy", offs)
+    return int(offs[-1])
 
 
 def _h_set_reads(eng, st, blob, offs, names, base):
@@ -205,7 +366,10 @@ def _h_stats(eng, st):
     return eng.stats()
 
 
-_HANDLERS = {"load_shard": _h_load_shard, "set_reads": _h_set_reads, "derep": _h_derep, "verdict": _h_verdict,
+_HANDLERS = {"job": _h_job, "load_piece": _h_load_piece, "merge_piece": _h_merge_piece, "set_base": _h_set_base, "orient_piece": _h_orient_piece,
+             "derep_x": _h_derep_x, "own_x": _h_own_x, "verdict_x": _h_verdict_x, "get_verdict": _h_get_verdict,
+             "rows_pub": _h_rows_pub, "rows_compose": _h_rows_compose, "rows_done": _h_rows_done, "names_pub": _h_names_pub,
+             "load_shard": _h_load_shard, "set_reads": _h_set_reads, "derep": _h_derep, "verdict": _h_verdict,
              "derep_arrays": _h_derep_arrays, "profiles": _h_profiles, "search": _h_search, "finalize": _h_finalize,
              "complete": _h_complete, "rep_coords": _h_rep_coords, "uniq_of": _h_uniq_of, "domains": _h_domains, "call": _h_call, "stats": _h_stats}
 
@@ -413,6 +577,58 @@ class MultiEngine(ShardedOps):
         self._mode = None
         self._search_args = None
         self._final = False
+        self._lazy_index = False
+        self._verdicts_ = []
+        self._last_merge = None
+        self.parent_s = {}                                # seconds this process spent inside each call (scripts/multi_run.py)
+        # worker-to-worker exchanges: files in memory, named by this driver
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        self._xdir = tempfile.mkdtemp(prefix="itsx_multi_%d_" % os.getpid(), dir=base)
+        self._xprefix = os.path.join(self._xdir, "x")
+        self._all("job", self._xprefix)
+
+    def _timed(self, name, t0):
+        self.parent_s[name] = self.parent_s.get(name, 0.0) + (time.perf_counter() - t0)
+
+    # -- the global unique list: built when a file-compatible writer / get_derep asks, never on the coordinates-only path
+    def _build_index(self):
+        if not self._lazy_index:
+            return
+        self._lazy_index = False
+        t0 = time.perf_counter()
+        self._verdicts_ = self._all("get_verdict")
+        keep = (self._derep, self._final, self.n_unique)
+        ShardedOps._index_uniques(self)
+        assert self.n_unique == keep[2], (self.n_unique, keep[2])
+        self._derep, self._final = keep[0], keep[1]
+        self._timed("index_uniques", t0)
+
+    @property
+    def _verdicts(self):
+        self._build_index()
+        return self._verdicts_
+
+    @_verdicts.setter
+    def _verdicts(self, v):
+        self._verdicts_ = v
+
+    @property
+    def _seeds(self):
+        self._build_index()
+        return self._seeds_
+
+    @_seeds.setter
+    def _seeds(self, v):
+        self._seeds_ = v
+
+    @property
+    def _gmap(self):
+        self._build_index()
+        return self._gmap_
+
+    @_gmap.setter
+    def _gmap(self, v):
+        self._gmap_ = v
 
     # -- plumbing
     def _send(self, cmd, args_per_worker):
@@ -460,6 +676,11 @@ class MultiEngine(ShardedOps):
             if p.is_alive():
                 p.kill()                                  # this exact child, nothing else
         self.conns, self.procs = [], []
+        xd = getattr(self, "_xdir", None)
+        if xd and os.path.isdir(xd):
+            import shutil
+            shutil.rmtree(xd, ignore_errors=True)
+            self._xdir = None
 
     def __del__(self):
         try:
@@ -468,15 +689,32 @@ class MultiEngine(ShardedOps):
             pass
 
     # -- reads
+    def _shard(self, path, tag, match=None):
+        """the file's text in one piece per worker (csrc/shard_host.cpp): piece paths, records per piece"""
+        from . import _lib
+        L = _lib.lib()
+        rec = np.zeros(self.world, np.int64)
+        pre = os.path.join(self._xdir, tag)
+        m = None if match is None else np.ascontiguousarray(match, np.int64)
+        rc = L.itsx_shard_text(os.fsencode(path), self.world, None if m is None else m.ctypes.data, os.fsencode(pre), rec.ctypes.data, None)
+        if rc != 0:
+            raise EngineError(rc, L.itsx_shard_last_error().decode())
+        return ["%s.%d" % (pre, r) for r in range(self.world)], rec
+
     def load_reads_file(self, path):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
-        res = self._all("load_shard", path)
-        self.n_reads = int(res[0][0])
-        self._bases = [int(r[1]) for r in res]
-        self._nloc = [int(r[2]) for r in res]
+        t0 = time.perf_counter()
+        pieces, rec = self._shard(path, "reads")
+        base = np.concatenate([[0], np.cumsum(rec)])
+        self._timed("load: inflate + cut", t0)
+        self._each("load_piece", [(pieces[r], int(base[r]), int(rec[r])) for r in range(self.world)])
+        self.n_reads = int(base[-1])
+        self._bases = [int(b) for b in base[:-1]]
+        self._nloc = [int(x) for x in rec]
         self._derep = None
         self._final = False
+        self._last_merge = None
         return self.n_reads
 
     def set_reads(self, seqs, names=None):
@@ -502,19 +740,17 @@ class MultiEngine(ShardedOps):
 
     # -- a1: exact dereplication of the whole sample
     def derep(self, strand_both=True, minseqlength=1):
-        tups = self._all("derep", bool(strand_both), int(minseqlength))
-        rows, src = [], []
-        for r, t in enumerate(tups):
-            lu = np.arange(t.shape[0], dtype=np.int64)
-            rows.append(np.concatenate([t, lu[:, None]], axis=1))
-            src.append(np.full(t.shape[0], r, np.int64))
-        recv = np.concatenate(rows) if rows else np.zeros((0, 5), np.int64)
-        verdict = owner_verdicts(recv, np.concatenate(src) if src else np.zeros(0, np.int64))
-        cut = np.cumsum([0] + [t.shape[0] for t in tups])
-        self._verdicts = [verdict[cut[r]:cut[r + 1]] for r in range(self.world)]
-        self._send("verdict", [(v,) for v in self._verdicts])
-        self._collect()
-        self._index_uniques()
+        """exact dereplication of the whole sample: local derep on every GPU, then the uniques meet at their key's owner (key mod N),
+        every worker sorts its Nth of the keys, the verdicts travel back -- three commands, nothing of the data's size in this process"""
+        t0 = time.perf_counter()
+        self._all("derep_x", bool(strand_both), int(minseqlength))
+        self._all("own_x")
+        res = self._all("verdict_x")
+        self.n_unique = int(sum(r[1] for r in res))
+        self._lazy_index = True                          # seeds / local -> global maps: only if somebody asks
+        self._derep = None
+        self._final = False
+        self._timed("derep (parent waits for the workers)", t0)
         return self.n_unique
 
     def cluster(self, cluster_id, strand_both=True):
@@ -538,16 +774,99 @@ class MultiEngine(ShardedOps):
         self._z = self._all("search", self._mode, T, F1, F2, F3)
         self._final = False
 
-    # -- stages that are not sharded (one GPU does them): orientation of CCS reads, paired-end merging
+    # -- coordinates per read: composed in the workers, into one array in shared memory
+    def trim_coords(self, left, right):
+        """per READ of the whole sample: start, stop, tlen (-1 = None), in_ddict"""
+        t0 = time.perf_counter()
+        path = self._xprefix + "_coords.npy"
+        out = np.lib.format.open_memmap(path, mode="w+", dtype=np.int32, shape=(self.n_reads, 4))
+        del out
+        self._all("rows_pub", left, right)
+        self._all("rows_compose", path, self.n_reads)
+        self._all("rows_done")
+        rows = np.load(path, mmap_mode="r")
+        res = tuple(np.ascontiguousarray(rows[:, k]) for k in range(4))
+        del rows
+        os.unlink(path)
+        self._timed("trim_coords", t0)
+        return res
+
+    def read_names_raw(self):
+        t0 = time.perf_counter()
+        paths = [self._xprefix + "_names_%d" % r for r in range(self.world)]
+        self._each("names_pub", [(p,) for p in paths])
+        blobs, offs, base = [], [np.zeros(1, np.int64)], 0
+        for p in paths:
+            b, o = np.load(p + ".b.npy"), np.load(p + ".o.npy")
+            blobs.append(b.tobytes())
+            offs.append(o[1:] + base)
+            base += int(o[-1])
+            os.unlink(p + ".b.npy")
+            os.unlink(p + ".o.npy")
+        self._timed("read_names_raw", t0)
+        return b"".join(blobs), np.concatenate(offs)
+
+    # -- either side of the path, sharded by record range like the reads: orientation of CCS reads, paired-end merging
     def orient_load_db(self, fasta_path):
-        return self._w0("orient_load_db", fasta_path)
+        if not os.path.exists(fasta_path):
+            raise FileNotFoundError(fasta_path)
+        self._orient_db = fasta_path
+        return 0
 
     def orient_file(self, fastq):
-        self._w0("load_reads_file", fastq)
-        return self._w0("orient")
+        if not os.path.exists(fastq):
+            raise FileNotFoundError(fastq)
+        pieces, rec = self._shard(fastq, "orient")
+        res = self._each("orient_piece", [(pieces[r], self._orient_db) for r in range(self.world)])
+        return tuple(np.concatenate([r[k] for r in res]) for k in range(3))
+
+    def _merge(self, r1, r2, out, maxdiffs, maxee, allow_stagger):
+        for p in (r1, r2):
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+        t0 = time.perf_counter()
+        p1, rec = self._shard(r1, "r1")
+        p2, _ = self._shard(r2, "r2", match=rec)           # R2 cut where R1 was: the same pairs on every worker
+        self._timed("merge: inflate + cut", t0)
+        outs = [None if out is None else "%s_merged.%d" % (self._xprefix, r) for r in range(self.world)]
+        res = self._each("merge_piece", [(p1[r], p2[r], outs[r], int(maxdiffs), float(maxee), bool(allow_stagger)) for r in range(self.world)])
+        return int(sum(x[0] for x in res)), [int(x[1]) for x in res], outs
+
+    def merge_pairs_load(self, r1, r2, maxdiffs=40, maxee=2.0, allow_stagger=False):
+        """merge R1 / R2 on every worker's piece; the merged reads are the workers' read sets (nothing written): (pairs, merged)"""
+        n, ms, _ = self._merge(r1, r2, None, maxdiffs, maxee, allow_stagger)
+        base = np.concatenate([[0], np.cumsum(ms)])
+        self._each("set_base", [(int(base[r]),) for r in range(self.world)])
+        self.n_reads = int(base[-1])
+        self._bases, self._nloc = [int(b) for b in base[:-1]], ms
+        self._derep = None
+        self._final = False
+        self._last_merge = dict(r1=r1, r2=r2, maxdiffs=int(maxdiffs), maxee=float(maxee), allow_stagger=bool(allow_stagger))
+        return n, self.n_reads
 
     def merge_pairs_files(self, r1, r2, out, maxdiffs=40, maxee=2.0, allow_stagger=False):
-        return self._w0("merge_pairs_files", r1, r2, out, maxdiffs=maxdiffs, maxee=maxee, allow_stagger=allow_stagger)
+        """the merged reads as ONE file (seq.fq): every worker merges its piece, the pieces are joined in order"""
+        n, ms, outs = self._merge(r1, r2, out, maxdiffs, maxee, allow_stagger)
+        with open(out, "wb") as f:
+            for p in outs:
+                with open(p, "rb") as g:
+                    while True:
+                        b = g.read(64 << 20)
+                        if not b:
+                            break
+                        f.write(b)
+                os.unlink(p)
+        return n, int(sum(ms))
+
+    def write_merged_fastq(self, path):
+        lm = self._last_merge
+        if lm is None:
+            raise EngineError(-1, "write_merged_fastq: this engine's reads do not come from merge_pairs_load")
+        # (the same merge once more, into files this time: itsx_merge_pairs_files leaves a context's read set and results alone)
+        n, m = self.merge_pairs_files(lm["r1"], lm["r2"], path, maxdiffs=lm["maxdiffs"], maxee=lm["maxee"], allow_stagger=lm["allow_stagger"])
+        if m != self.n_reads:
+            raise EngineError(-1, "write_merged_fastq: %d merged records written, the engines hold %d" % (m, self.n_reads))
+        return m
 
 
 def _devices_from_env(n):

@@ -256,8 +256,12 @@ class StreamEngine(ShardedOps):
         for eng, _ in getattr(self, "_engs", []):
             eng.close()
         self._engs = []
-        if getattr(self, "_plain_eng", None) is not None and not getattr(self, "_keep_plain", False):
-            pass                                          # (the plain engine of the unstreamed stages lives as long as this object)
+        if getattr(self, "_plain_eng", None) is not None:  # the plain context of the unstreamed stages (orientation, merging) goes with this object
+            try:
+                self._plain_eng.close()
+            except Exception:
+                pass
+            self._plain_eng = None
         if getattr(self, "_stream", None) is not None:
             try:
                 self._stream.close(keep=True)
@@ -672,7 +676,12 @@ class StreamEngine(ShardedOps):
         return self._plain().orient_load_db(fasta_path)
 
     def orient_file(self, fastq):
-        return self._plain().orient_file(fastq)
+        res = self._plain().orient_file(fastq)
+        # (the whole-file context has done its work: it leaves the device and the host before the streaming run starts -- SeqSample.orient_reads
+        # loads the database before every call)
+        self._plain_eng.close()
+        self._plain_eng = None
+        return res
 
     def merge_pairs_files(self, r1, r2, out, maxdiffs=40, maxee=2.0, allow_stagger=False):
         return self._plain().merge_pairs_files(r1, r2, out, maxdiffs=maxdiffs, maxee=maxee, allow_stagger=allow_stagger)

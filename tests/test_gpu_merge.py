@@ -151,12 +151,19 @@ def test_merge_into_the_engines_read_set(engine, gold, tmp_path, t_hmm_text, mon
         dd = Dedup(uc_file=s.uc_file, rep_file=s.rep_file, seq_file=s.seq_file, fastq=s.r1, fastq2=s.fastq2)
         o1, o2 = str(d / "o1.fq"), str(d / "o2.fq")
         dd.create_paired_trimmed_seqs(o1, o2, gzipped=False, zstd_file=False, itspos=pos, wri_file=True)
+        # the reference's other route for a paired sample (main.py:596-624: --fastq2 without --outfile2): the MERGED reads trimmed, one
+        # file -- in arrays mode seq.fq was never written, the merged records are materialised when this consumer asks for them
+        om = str(d / "merged_trimmed.fq")
+        dd.create_trimmed_seqs(om, gzipped=False, zstd_file=False, itspos=pos, wri_file=True, tempdir=str(d))
+        assert os.path.exists(d / "seq.fq")
         rep_of, strand, uniq_of = s.engine.get_derep()
         res[mode] = (s.engine.read_names(), rep_of.copy(), strand.copy(), [np.asarray(c).copy() for c in s.trim_coordinates("ITS2")],
-                     open(o1, "rb").read(), open(o2, "rb").read())
+                     open(o1, "rb").read(), open(o2, "rb").read(), open(om, "rb").read(), open(d / "seq.fq", "rb").read())
         s._engine.close()
     a, b = res["0"], res["1"]
     assert a[0] == b[0] and len(a[0]) == 236
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
     assert a[4] == b[4] and a[5] == b[5] and len(a[4]) > 1000
+    assert a[6] == b[6] and len(a[6]) > 1000 and a[7] == b[7]
+

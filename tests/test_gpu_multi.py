@@ -108,3 +108,54 @@ def test_three_workers_with_an_empty_shard(tmp_path, t_hmm_text, monkeypatch):
     assert out1 == out3 and all(np.array_equal(x, y) for x, y in zip(c1, c3))
     for name in ("uc.txt", "rep.fa", "domtbl.txt"):
         assert open(os.path.join(tmp, "one", name), "rb").read() == open(os.path.join(tmp, "three", name), "rb").read()
+
+
+def test_paired_sample_merge_and_orientation_over_two_workers(tmp_path, t_hmm_text, monkeypatch):
+    """round 5: merging and orientation are sharded by record range like the reads (R2 cut at R1's record counts: csrc/shard_host.cpp).
+    Two workers == one engine on seq.fq, the trimmed pairs, the single merged output and oriented.fq -- in file mode and in arrays mode"""
+    tmp = str(tmp_path)
+    hmm = _its2(tmp, t_hmm_text)
+    r1, r2 = os.path.join(GOLD, "4774-1-MSITS3_R1.fastq.gz"), os.path.join(GOLD, "4774-1-MSITS3_R2.fastq.gz")
+    res = {}
+    for gpus, fast in ((1, False), (2, False), (2, True), (3, True)):
+        monkeypatch.setenv("ITSXPRESS_GPUS", str(gpus))
+        monkeypatch.setenv("ITSXPRESS_GPU_IDS", ",".join(["0"] * gpus))
+        monkeypatch.setenv("ITSXPRESS_ARRAYS", "1" if fast else "0")
+        monkeypatch.setenv("ITSXPRESS_STREAM", "0")
+        d = os.path.join(tmp, "p%d%d" % (gpus, fast))
+        s = S.SeqSamplePairedNotInterleaved(fastq=r1, tempdir=d, fastq2=r2)
+        _OPEN.append(s)
+        s._merge_reads(threads=1, stagger=False)
+        assert os.path.exists(os.path.join(d, "seq.fq")) == (not fast)
+        s.deduplicate(threads=1)
+        s._search(hmmfile=hmm, threads=1)
+        pos = S.ItsPosition(domtable=s.dom_file, region="ITS2")
+        dd = S.Dedup(uc_file=s.uc_file, rep_file=s.rep_file, seq_file=s.seq_file, fastq=s.r1, fastq2=s.fastq2)
+        o1, o2, om = os.path.join(d, "o1.fq"), os.path.join(d, "o2.fq"), os.path.join(d, "om.fq")
+        dd.create_paired_trimmed_seqs(o1, o2, gzipped=False, zstd_file=False, itspos=pos, wri_file=True)
+        dd.create_trimmed_seqs(om, gzipped=False, zstd_file=False, itspos=pos, wri_file=True, tempdir=d)
+        res[(gpus, fast)] = (open(o1, "rb").read(), open(o2, "rb").read(), open(om, "rb").read(), open(os.path.join(d, "seq.fq"), "rb").read(),
+                             [np.asarray(c).copy() for c in s.trim_coordinates("ITS2")])
+        s._engine.close()
+        _OPEN.pop()
+    ref = res[(1, False)]
+    assert len(ref[0]) > 1000 and len(ref[2]) > 1000 and ref[3].count(b"\n") == 4 * 236
+    for k, v in res.items():
+        assert v[:4] == ref[:4], k
+        assert all(np.array_equal(x, y) for x, y in zip(v[4], ref[4])), k
+    # orientation (SeqSample.orient_reads, the --trim-ccs front end): oriented.fq of two workers == one engine's
+    monkeypatch.setenv("ITSXPRESS_DB_DIR", GOLD)
+    import itsxpress_amd.definitions as D
+    importlib.reload(D)
+    outs = []
+    for gpus in (1, 2):
+        monkeypatch.setenv("ITSXPRESS_GPUS", str(gpus))
+        monkeypatch.setenv("ITSXPRESS_GPU_IDS", ",".join(["0"] * gpus))
+        d = os.path.join(tmp, "o%d" % gpus)
+        s = S.SeqSampleNotPaired(fastq=os.path.join(GOLD, "seq.fq.gz"), tempdir=d)
+        _OPEN.append(s)
+        s.orient_reads(threads=1)
+        outs.append(open(s.seq_file, "rb").read())
+        s._engine.close()
+        _OPEN.pop()
+    assert outs[0] == outs[1] and outs[0].count(b"\n") >= 800

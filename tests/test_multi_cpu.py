@@ -107,3 +107,94 @@ def test_mirror_reads_its_switches_from_the_environment(monkeypatch):
     assert not s._is_fast()
     t = S.EngineTable("/tmp/uc.txt", object(), "uc")
     assert t == "/tmp/uc.txt" and os.path.basename(t) == "uc.txt" and t.kind == "uc"
+
+
+def test_install_runs_file_compatible_whatever_the_environment_says(tmp_path, monkeypatch):
+    """install() leaves the reference's own ItsPosition / Dedup in place; they open uc.txt / domtbl.txt by path, so the installed
+    methods must write those files even with ITSXPRESS_ARRAYS=1 in the environment (advisor, round 4)"""
+    import sys
+    import types
+    pkg, mod = types.ModuleType("itsxpress"), types.ModuleType("itsxpress.SeqSample")
+
+    class RefSample:
+        def __init__(self, fastq, tempdir):
+            self.fastq, self.tempdir, self.seq_file = fastq, tempdir, fastq
+
+    class RefPaired(RefSample):
+        pass
+    mod.SeqSample, mod.SeqSamplePairedNotInterleaved = RefSample, RefPaired
+    pkg.SeqSample = mod
+    monkeypatch.setitem(sys.modules, "itsxpress", pkg)
+    monkeypatch.setitem(sys.modules, "itsxpress.SeqSample", mod)
+    monkeypatch.setenv("ITSXPRESS_ARRAYS", "1")
+    from itsxpress_amd.SeqSample import install, SeqSample
+    install()
+    s = RefSample("x.fq", str(tmp_path))
+    assert s._is_fast() is False
+    assert SeqSample("x.fq", str(tmp_path))._is_fast() is True            # the mirror itself still follows the switch
+
+
+def test_shard_text_cuts_at_record_starts_and_follows_the_mate_file(tmp_path):
+    """itsx_shard_text (csrc/shard_host.cpp): the pieces are whole records, in order, and together the file; a mate file is cut at the
+    same record counts whatever its bytes; qualities that look like titles do not fool the cut; gzip input; FASTA; more pieces than
+    records; a mate that does not hold the records is refused"""
+    import ctypes as C
+    import gzip
+    from itsxpress_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+
+    def fastq(n, lo, hi, tag):
+        recs = []
+        for i in range(n):
+            ln = int(rng.integers(lo, hi))
+            seq = "".join(rng.choice(list("ACGT"), ln))
+            qual = "".join(rng.choice(list("@+I5"), ln))                  # '@' and '+' at line starts on purpose
+            recs.append("@%s%d some text\n%s\n+\n%s\n" % (tag, i, seq, qual))
+        return recs
+
+    def shard(path, parts, match=None):
+        rec = np.zeros(parts, np.int64)
+        by = np.zeros(parts, np.int64)
+        pre = str(tmp_path / ("piece_%d" % rng.integers(1 << 30)))
+        m = None if match is None else np.ascontiguousarray(match, np.int64)
+        rc = L.itsx_shard_text(os.fsencode(path), parts, None if m is None else m.ctypes.data, os.fsencode(pre), rec.ctypes.data, by.ctypes.data)
+        return rc, rec, [open("%s.%d" % (pre, p), "rb").read() if rc == 0 else b"" for p in range(parts)]
+
+    r1 = fastq(1000, 30, 400, "a")
+    r2 = fastq(1000, 200, 210, "b")
+    p1, p2 = tmp_path / "r1.fq", tmp_path / "r2.fq.gz"
+    p1.write_text("".join(r1))
+    with gzip.open(p2, "wt") as f:
+        f.write("".join(r2))
+    for parts in (1, 2, 3, 8):
+        rc, rec, pieces = shard(str(p1), parts)
+        assert rc == 0 and rec.sum() == 1000 and b"".join(pieces) == "".join(r1).encode()
+        at = 0
+        for p in range(parts):
+            assert pieces[p] == "".join(r1[at:at + rec[p]]).encode()
+            at += rec[p]
+        rc, rec2, pieces2 = shard(str(p2), parts, match=rec)
+        assert rc == 0 and np.array_equal(rec, rec2) and b"".join(pieces2) == "".join(r2).encode()
+        at = 0
+        for p in range(parts):
+            assert pieces2[p] == "".join(r2[at:at + rec[p]]).encode()
+            at += rec[p]
+    # more pieces than records; no trailing newline
+    small = tmp_path / "small.fq"
+    small.write_text("".join(r1[:3]).rstrip("\n"))
+    rc, rec, pieces = shard(str(small), 7)
+    assert rc == 0 and rec.sum() == 3 and b"".join(pieces) == "".join(r1[:3]).rstrip("\n").encode()
+    # FASTA with wrapped sequences
+    fa = tmp_path / "x.fa"
+    recs = [">s%d\n%s\n%s\n" % (i, "ACGT" * 15, "GG" * int(rng.integers(1, 20))) for i in range(200)]
+    fa.write_text("".join(recs))
+    rc, rec, pieces = shard(str(fa), 4)
+    assert rc == 0 and rec.sum() == 200 and b"".join(pieces) == "".join(recs).encode() and all(pc[:1] in (b">", b"") for pc in pieces)
+    rc, rec2, pieces2 = shard(str(fa), 4, match=rec)
+    assert rc == 0 and np.array_equal(rec, rec2) and pieces2 == pieces
+    # a mate with fewer records
+    short = tmp_path / "short.fq"
+    short.write_text("".join(r2[:900]))
+    rc, _, _ = shard(str(short), 3, match=np.array([400, 300, 300]))
+    assert rc != 0 and b"mate" in L.itsx_shard_last_error()

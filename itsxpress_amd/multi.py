@@ -240,10 +240,11 @@ def _h_rows_compose(eng, st, out_path, n_total):
             urows[mine] = rw[v[mine, 3]]
     uq = eng.get_derep()[2]
     g = np.where(uq >= 0, uq, U)
-    out = np.lib.format.open_memmap(out_path, mode="r+")
-    out[st["base"]:st["base"] + uq.shape[0]] = urows[g]
-    out.flush()
-    del out
+    for k in range(4):                                    # one file per column: the parent maps them as they are
+        out = np.lib.format.open_memmap("%s.%d.npy" % (out_path, k), mode="r+")
+        out[st["base"]:st["base"] + uq.shape[0]] = urows[g, k]
+        out.flush()
+        del out
     return int(uq.shape[0])
 
 
@@ -580,22 +581,29 @@ class MultiEngine(ShardedOps):
         self._lazy_index = False
         self._verdicts_ = []
         self._last_merge = None
-        self.parent_s = {}                                # seconds this process spent inside each call (scripts/multi_run.py)
+        self.parent_s, self.parent_own_s = {}, {}         # seconds inside each call / of them this process's own work (scripts/multi_run.py)
         # worker-to-worker exchanges: files in memory, named by this driver
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
         self._xdir = tempfile.mkdtemp(prefix="itsx_multi_%d_" % os.getpid(), dir=base)
         self._xprefix = os.path.join(self._xdir, "x")
         self._all("job", self._xprefix)
 
+    def _tic(self):
+        return (time.perf_counter(), getattr(self, "wait_s", 0.0))
+
     def _timed(self, name, t0):
-        self.parent_s[name] = self.parent_s.get(name, 0.0) + (time.perf_counter() - t0)
+        """wall time of a call, and the part of it that was this process's OWN work (the rest: waiting for the workers)"""
+        dt = time.perf_counter() - t0[0]
+        w = getattr(self, "wait_s", 0.0) - t0[1]
+        self.parent_s[name] = self.parent_s.get(name, 0.0) + dt
+        self.parent_own_s[name] = self.parent_own_s.get(name, 0.0) + max(0.0, dt - w)
 
     # -- the global unique list: built when a file-compatible writer / get_derep asks, never on the coordinates-only path
     def _build_index(self):
         if not self._lazy_index:
             return
         self._lazy_index = False
-        t0 = time.perf_counter()
+        t0 = self._tic()
         self._verdicts_ = self._all("get_verdict")
         keep = (self._derep, self._final, self.n_unique)
         ShardedOps._index_uniques(self)
@@ -653,8 +661,12 @@ class MultiEngine(ShardedOps):
         return out
 
     def _each(self, cmd, args_per_worker):
+        t0 = time.perf_counter()
         self._send(cmd, args_per_worker)
-        return self._collect()
+        try:
+            return self._collect()
+        finally:                                          # time this process spent waiting for its workers (not its own work)
+            self.wait_s = getattr(self, "wait_s", 0.0) + (time.perf_counter() - t0)
 
     def _w0(self, name, *args, **kwargs):
         self.conns[0].send(("call", (name, args, kwargs)))
@@ -704,7 +716,7 @@ class MultiEngine(ShardedOps):
     def load_reads_file(self, path):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
-        t0 = time.perf_counter()
+        t0 = self._tic()
         pieces, rec = self._shard(path, "reads")
         base = np.concatenate([[0], np.cumsum(rec)])
         self._timed("load: inflate + cut", t0)
@@ -742,7 +754,7 @@ class MultiEngine(ShardedOps):
     def derep(self, strand_both=True, minseqlength=1):
         """exact dereplication of the whole sample: local derep on every GPU, then the uniques meet at their key's owner (key mod N),
         every worker sorts its Nth of the keys, the verdicts travel back -- three commands, nothing of the data's size in this process"""
-        t0 = time.perf_counter()
+        t0 = self._tic()
         self._all("derep_x", bool(strand_both), int(minseqlength))
         self._all("own_x")
         res = self._all("verdict_x")
@@ -777,22 +789,24 @@ class MultiEngine(ShardedOps):
     # -- coordinates per read: composed in the workers, into one array in shared memory
     def trim_coords(self, left, right):
         """per READ of the whole sample: start, stop, tlen (-1 = None), in_ddict"""
-        t0 = time.perf_counter()
-        path = self._xprefix + "_coords.npy"
-        out = np.lib.format.open_memmap(path, mode="w+", dtype=np.int32, shape=(self.n_reads, 4))
-        del out
+        t0 = self._tic()
+        path = self._xprefix + "_coords"
+        for k in range(4):
+            out = np.lib.format.open_memmap("%s.%d.npy" % (path, k), mode="w+", dtype=np.int32, shape=(self.n_reads,))
+            del out
         self._all("rows_pub", left, right)
         self._all("rows_compose", path, self.n_reads)
         self._all("rows_done")
-        rows = np.load(path, mmap_mode="r")
-        res = tuple(np.ascontiguousarray(rows[:, k]) for k in range(4))
-        del rows
-        os.unlink(path)
+        res = []
+        for k in range(4):                                # private (copy-on-write) mappings of what the workers wrote: no copy here
+            p = "%s.%d.npy" % (path, k)
+            res.append(np.load(p, mmap_mode="c") if self.n_reads else np.zeros(0, np.int32))
+            os.unlink(p)
         self._timed("trim_coords", t0)
-        return res
+        return tuple(res)
 
     def read_names_raw(self):
-        t0 = time.perf_counter()
+        t0 = self._tic()
         paths = [self._xprefix + "_names_%d" % r for r in range(self.world)]
         self._each("names_pub", [(p,) for p in paths])
         blobs, offs, base = [], [np.zeros(1, np.int64)], 0
@@ -824,7 +838,7 @@ class MultiEngine(ShardedOps):
         for p in (r1, r2):
             if not os.path.exists(p):
                 raise FileNotFoundError(p)
-        t0 = time.perf_counter()
+        t0 = self._tic()
         p1, rec = self._shard(r1, "r1")
         p2, _ = self._shard(r2, "r2", match=rec)           # R2 cut where R1 was: the same pairs on every worker
         self._timed("merge: inflate + cut", t0)

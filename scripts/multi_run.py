@@ -72,10 +72,12 @@ def main():
                 line = {"workers": N, "reads": n, "unique": int(me.n_unique), "wall_s": {k: round(v, 3) for k, v in wall.items()},
                         "wall_total_s": round(sum(wall.values()), 3), "workers_started_s": round(t_start, 2),
                         "parent_s": {k: round(v, 3) for k, v in me.parent_s.items()},
-                        "parent_busy_s": round(me.parent_s.get("load: inflate + cut", 0.0) + me.parent_s.get("trim_coords", 0.0), 3),
+                        "parent_own_s": {k: round(v, 3) for k, v in me.parent_own_s.items()},
+                        "parent_own_compute_path_s": round(sum(v for k, v in me.parent_own_s.items() if not k.startswith("load")), 3),
                         "worker_device_ms": [round(x) for x in dev_ms],
-                        "note": "parent_s: 'load: inflate + cut' is this process's own work (inflate once, cut, write the pieces); 'derep' and "
-                                "'trim_coords' are waits for the workers' three / three commands (trim_coords + one 16-B-per-read copy); N workers share ONE GPU here"}
+                        "note": "parent_s: wall time of this process inside a call; parent_own_s: the part that was its own work, not a wait for the workers "
+                                "('load: inflate + cut' = inflate the file once, cut it, write the pieces; derep and trim_coords are three commands each); "
+                                "parent_own_compute_path_s = everything but the load; N workers share ONE GPU here"}
                 if args.check:
                     if ref is None:
                         ref = coords

@@ -30,6 +30,7 @@
 
 namespace itsx {
 
+constexpr int MSV_WT = 16;      // packed words a lane stages in LDS at a time (256 rows)
 typedef short s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s2 as_s2(uint32_t u) { return __builtin_bit_cast(s2, u); }
 __device__ __forceinline__ uint32_t as_u(s2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -42,6 +43,7 @@ template <bool SHARE>
 __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint32_t tab[2][16 * MSV_TW];
+  __shared__ uint32_t wst[MSV_WT][256];            // each lane's next 16 packed words (its own column: no barrier)
   const int s = a.k0 + blockIdx.x * 256 + threadIdx.x;
   const bool valid = s < a.k1;
   int L = 0, nexc = 0, tjb = 0, Lt = 0;
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
     }
     int ei = 0;
     int next_exc = nexc > 0 ? (int)(ep[0] >> 4) : 0x7fffffff;        // (a chain has no exception above its start: k_share.hip)
-    uint32_t w = 0, wnext = L > row0 ? wp[row0 >> 4] : 0u;
+    uint32_t w = 0;
     for (int pos = row0; pos < Lw; pos++) {
       const int sh = (pos & 15) * 2;
       if (sh == 0) {
@@ -114,7 +116,15 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
             }
           }
         }
-        w = wnext; if (pos + 16 < L) wnext = wp[(pos >> 4) + 1];      // the next 16 bases fly during these 16 rows
+        // the lane's packed words, 16 at a time (256 rows) through LDS: one contiguous 64-byte piece of the read per load instead of a
+        // dword every 16 rows -- every one of those dwords cost a whole line once 49 k lanes' lines no longer fit the XCD's L2
+        // (75.6 GB fetched per 1 M reads in round 4 against 0.1-0.4 GB of packed reads; profiles/round5_pmc_hbm_traffic_1M.md)
+        if ((pos & 255) == 0 || pos == row0) {
+          const int w0 = (pos >> 8) << 4, nw = (L + 15) >> 4;
+#pragma unroll
+          for (int j = 0; j < MSV_WT; j++) wst[j][threadIdx.x] = (w0 + j < nw) ? wp[w0 + j] : 0u;
+        }
+        w = wst[(pos >> 4) & (MSV_WT - 1)][threadIdx.x];
       }
       if (pos < L) {
         int code = (int)((w >> sh) & 3u);

@@ -190,7 +190,8 @@ class SeqSample:
             eng.load_profiles(path=hmmfile)
             fast = self._is_fast()
             # file-compatible: every domain row stays (domtbl.txt); arrays mode: the lazy domain stage, coordinates only
-            nu = int(getattr(eng, "n_unique", 0) or 0)
+            # (a streaming engine defers its work: asking it for a count would run the load stage apart from the search)
+            nu = 0 if (fast or getattr(eng, "deferred", False)) else int(getattr(eng, "n_unique", 0) or 0)
             if not fast and nu > 1000000:
                 logging.info("itsx_hip search: %d unique sequences in file-compatible mode -- every (sequence, profile) pair is evaluated and "
                              "domtbl.txt gets about %d rows (~%.0f GB); ITSXPRESS_ARRAYS=1 keeps the tables in the engine, evaluates only the pairs that "

@@ -1445,8 +1445,8 @@ static int build_share(itsx_ctx *ctx)
   S.share_B = 0; S.share_batches = 0; S.share_nodes = S.share_chains = 0; S.ms_share_build = 0; S.share_frac = 0;
   const int32_t U = ctx->U_active, Uc = (int32_t)std::min<int64_t>(ctx->s_Uc, 0x7fffffff), P = ctx->P;
   if (const char *e = getenv("ITSX_SHARE")) if (atoi(e) == 0) return ITSX_OK;
-  // (the pair traces name uniques by sorted position; the A/B switch of the bound pass uses the classic wave list)
-  if (ctx->keep_trace || getenv("ITSX_LAZY_EXACT_BOUND")) return ITSX_OK;
+  // (the A/B switch of the bound pass uses the classic wave list)
+  if (getenv("ITSX_LAZY_EXACT_BOUND")) return ITSX_OK;
   if (U < 2 || U >= (1 << 26) || P <= 0) return ITSX_OK;
   int B = 32;
   if (const char *e = getenv("ITSX_SHARE_B")) B = atoi(e);
@@ -2915,10 +2915,17 @@ static int append_traces(itsx_ctx *ctx)
   HIPCHK(hipMemcpy(pr.data(), ctx->d_pairs.p, (size_t)NP * sizeof(PairRec), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(po.data(), ctx->d_pout.p, (size_t)NP * sizeof(PairOut), hipMemcpyDeviceToHost));
   if (ctx->have_vit) { vo.resize((size_t)NP); HIPCHK(hipMemcpy(vo.data(), ctx->d_vit.p, (size_t)NP * sizeof(VitOut), hipMemcpyDeviceToHost)); }
+  // PairRec::useq is a position in the list the search walked: with prefix sharing the processing order (k_share.hip), else by length
+  std::vector<int32_t> order;
+  if (ctx->share_on) {
+    order.resize((size_t)ctx->U_active);
+    HIPCHK(hipMemcpy(order.data(), ctx->sh_order.p, order.size() * 4, hipMemcpyDeviceToHost));
+  }
+  const int32_t *walked = ctx->share_on ? order.data() : ctx->h_sorted_active.data();
   for (int64_t i = 0; i < NP; i++) {
-    if (pr[i].prof < 0) continue;
+    if (pr[i].prof < 0 || pr[i].xj < 0) continue;          // (padding; a pair that ran only for a chain below it)
     itsx_pairtrace t{};
-    t.rep = ctx->h_sorted_active[(size_t)ctx->trace_u0 + pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
+    t.rep = walked[(size_t)ctx->trace_u0 + pr[i].useq]; t.prof = pr[i].prof; t.msv_xj = pr[i].xj; t.pass_msv = 1;
     t.pass_bias = po[i].pass_bias; t.pass_fwd = po[i].pass_fwd; t.msv_sc = po[i].msv_sc; t.filtersc = po[i].filtersc;
     t.fwdsc = po[i].fwdsc; t.bcksc = po[i].bcksc; t.nullsc = po[i].nullsc; t.nregions = po[i].nregions; t.ndom = po[i].ndom;
     const bool ran = ctx->have_vit && po[i].pass_bias && vo[(size_t)i].ran;

@@ -220,6 +220,7 @@ template <class T> struct DBuf {
 struct itsx_ctx {
   int device = 0;
   hipStream_t st = nullptr, st2 = nullptr;   // st2: the bias filter of the next batch beside the decoder of this one
+  hipStream_t st3 = nullptr; hipEvent_t ev_s3a = nullptr, ev_s3b = nullptr;   // st3: every other batch of a shared MSV filter (their launch tails overlap)
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   // the MSV filter of chunk c + 1 runs on st2 beside the domain stage of chunk c (latency-bound kernels that leave the vector
   // ALUs idle): ev_msv0/1 bracket it; msv_pre_u0 = the chunk it was launched for (-1: none)
@@ -342,9 +343,9 @@ struct itsx_ctx {
   struct ShareBatch { int32_t k0, k1; int64_t node0, nnodes; int32_t nsplit; };   // nsplit > 1: the profiles in that many ranges, one after the other
   bool share_on = false; int share_B = 32, share_logB = 5, share_maxd = 0;
   DBuf<unsigned long long> sh_tab, sh_mask_s, sh_mask, sh_counters; DBuf<uint8_t> sh_depth_s, sh_depth;
-  DBuf<int32_t> sh_parent_s, sh_parent, sh_nn_s, sh_nn, sh_node0_s, sh_node0, sh_order, sh_ulen, sh_uorder, sh_inv, sh_flag, sh_pos, sh_bstart, sh_cursor, sh_segk, sh_scan, sh_cuts;
+  DBuf<int32_t> sh_src, sh_parent_s, sh_parent, sh_nn_s, sh_nn, sh_node0_s, sh_node0, sh_order, sh_ulen, sh_uorder, sh_inv, sh_flag, sh_pos, sh_bstart, sh_cursor, sh_segk, sh_scan, sh_cuts;
   std::vector<ShareBatch> sh_batches; std::vector<int32_t> sh_segk_h;            // [batch][SHARE_SEGS]
-  DBuf<uint4> sh_mslots; DBuf<float4> sh_fslots; DBuf<uint32_t> sh_pass, sh_need; DBuf<int32_t> sh_real, sh_segflat, sh_segdepth, sh_wc, sh_woff; DBuf<int64_t> sh_bnd;
+  DBuf<uint4> sh_mslots; size_t sh_mslots_half = 0, sh_fslots_half = 0; DBuf<uint32_t> sh_pass, sh_need; DBuf<int32_t> sh_real, sh_segflat, sh_segdepth, sh_wc, sh_woff; DBuf<int64_t> sh_bnd;
   DBuf<uint16_t> sh_res_chk; DBuf<float> sh_fb_chk;
   ShareDev sh_dev{};
 };
@@ -441,6 +442,7 @@ void itsx_destroy(itsx_ctx *ctx)
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->st);
+  if (ctx->st3) { (void)hipStreamSynchronize(ctx->st3); (void)hipStreamDestroy(ctx->st3); (void)hipEventDestroy(ctx->ev_s3a); (void)hipEventDestroy(ctx->ev_s3b); }
   if (ctx->st2) { (void)hipStreamSynchronize(ctx->st2); (void)hipStreamDestroy(ctx->st2); (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b);
                   if (ctx->ev_msv0) { (void)hipEventDestroy(ctx->ev_msv0); (void)hipEventDestroy(ctx->ev_msv1); (void)hipEventDestroy(ctx->ev_c); } }
   (void)hipStreamDestroy(ctx->st);
@@ -1496,17 +1498,18 @@ static int build_share(itsx_ctx *ctx)
   std::sort(cv.begin(), cv.end());
   cv.push_back({U, NN});
   // ---- batches: consecutive groups of one chunk while their saved states (for every profile, at the Forward pass's size) fit the budget
-  // (a lazy search: the Forward pass's states, up to 24 GB -- 48 left the stages behind it too little at 10 M reads -- and a third of what is free; otherwise only the MSV filter shares, its
+  // (a lazy search: the Forward pass's states, up to 48 GB (in the DP slab's memory: below) and a third of what is free; otherwise only the MSV filter shares, its
   // states are a fifth the size, and the full table's rows and slabs want the memory: up to 8 GB and an eighth of what is free)
   const bool fwd_too = ctx->lazy;
-  double gb = fwd_too ? 24.0 : 8.0;
+  double gb = fwd_too ? 48.0 : 8.0;
   {
     size_t fr = 0, tot = 0;
-    const double held = (double)ctx->sh_fslots.cap * sizeof(float4) + (double)ctx->sh_mslots.cap * sizeof(uint4);
+    const double held = (double)ctx->w_slab.cap * sizeof(float) + (double)ctx->sh_mslots.cap * sizeof(uint4);
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::min(gb, std::max(0.25, ((double)fr + held) / (double)(1ull << 30) / (fwd_too ? 3.0 : 8.0)));
   }
   if (const char *e = getenv("ITSX_SHARE_GB")) gb = std::max(0.0001, atof(e));
-  const double state_b = fwd_too ? (double)FWD_STATE_Q * sizeof(float4) : (double)MSV_STATE_Q * sizeof(uint4);
+  // (two batches run side by side, each on its own half of the buffers: a batch gets half the budget)
+  const double state_b = 2.0 * (fwd_too ? (double)FWD_STATE_Q * sizeof(float4) : (double)MSV_STATE_Q * sizeof(uint4));
   const int64_t nodes_max = std::max<int64_t>(1, (int64_t)(gb * (double)(1ull << 30) / (state_b * (double)P)));
   std::vector<int32_t> bstart; std::vector<itsx_ctx::ShareBatch> &bt = ctx->sh_batches;
   {
@@ -1524,7 +1527,7 @@ static int build_share(itsx_ctx *ctx)
   }
   const int nb = (int)bt.size();
   // a batch that one group overfills takes its profiles in nsplit ranges; if even one profile's states do not fit, nothing is shared
-  for (auto &b : bt) if ((double)b.nnodes * state_b * (double)((P + b.nsplit - 1) / b.nsplit) > 1.5 * gb * (double)(1ull << 30)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
+  for (auto &b : bt) if ((double)b.nnodes * state_b * (double)((P + b.nsplit - 1) / b.nsplit) > 3.0 * gb * (double)(1ull << 30)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
   // ---- the processing order: stable by (batch, depth)
   HIPCHK(upload(ctx->sh_bstart, bstart, st)); HIPCHK(ctx->sh_cursor.alloc((size_t)nb + 1)); HIPCHK(ctx->sh_segk.alloc((size_t)nb * SHARE_SEGS));
   HIPCHK(hipMemcpyAsync(ctx->sh_cursor.p, ctx->sh_bstart.p, (size_t)nb * 4, hipMemcpyDeviceToDevice, st));
@@ -1542,9 +1545,12 @@ static int build_share(itsx_ctx *ctx)
   HIPCHK(ctx->sh_depth.alloc((size_t)U + 1)); HIPCHK(ctx->sh_parent.alloc((size_t)U + 1)); HIPCHK(ctx->sh_mask.alloc((size_t)U + 1));
   HIPCHK(ctx->sh_nn.alloc((size_t)U + 2)); HIPCHK(ctx->sh_node0.alloc((size_t)U + 2)); HIPCHK(ctx->sh_order.alloc((size_t)U + 1)); HIPCHK(ctx->sh_ulen.alloc((size_t)U + 1));
   ShareDev &o = ctx->sh_dev;
+  HIPCHK(ctx->sh_src.alloc((size_t)U + 1));
+  o.src = ctx->sh_src.p;
   o.depth = ctx->sh_depth.p; o.parent = ctx->sh_parent.p; o.mask = ctx->sh_mask.p; o.nn = ctx->sh_nn.p; o.node0 = ctx->sh_node0.p; o.order = ctx->sh_order.p; o.ulen = ctx->sh_ulen.p;
   launch_share_permute(a, ctx->d_ulen.p, ctx->sh_uorder.p, ctx->sh_inv.p, o, st);
   launch_exclusive_scan(ctx->sh_nn.p, ctx->sh_node0.p, (int64_t)U + 1, ctx->sh_scan.p, st);
+  launch_share_src(o, U, a.Uc, st);
   HIPCHK(hipStreamSynchronize(st));
   for (int b = 0; b < nb; b++) {               // the end of each batch's last depth, and of the depths that do not occur
     for (int d = maxd + 1; d < SHARE_SEGS; d++) ctx->sh_segk_h[(size_t)b * SHARE_SEGS + d] = bt[(size_t)b].k1;
@@ -1553,9 +1559,16 @@ static int build_share(itsx_ctx *ctx)
   int64_t need_slots = 0;
   for (auto &b : bt) need_slots = std::max<int64_t>(need_slots, b.nnodes * (int64_t)((P + b.nsplit - 1) / b.nsplit));
   // (no room for them: the search runs unshared)
-  if (ctx->sh_mslots.alloc((size_t)need_slots * MSV_STATE_Q + 1) != hipSuccess || (fwd_too && ctx->sh_fslots.alloc((size_t)need_slots * FWD_STATE_Q + 1) != hipSuccess)) {
+  ctx->sh_mslots_half = (size_t)need_slots * MSV_STATE_Q;      // two batches of the MSV filter run side by side (search_chunk)
+  static const bool two_fwd = !(getenv("ITSX_SHARE_FWD_STREAMS") && atoi(getenv("ITSX_SHARE_FWD_STREAMS")) < 2);
+  // The Forward pass's states live in the DP slab (ctx->w_slab): pass A is over before the rounds' Forward / Backward kernels write their
+  // rows there, so the two never need the memory at the same time -- 24-48 GB that round 5's first version held twice (and that cost the
+  // stages behind it their batch sizes)
+  ctx->sh_fslots_half = (fwd_too && two_fwd && nb > 1) ? (size_t)need_slots * FWD_STATE_Q : 0;       // (one batch: nothing to run beside it)
+  if (ctx->sh_mslots.alloc(2 * (size_t)need_slots * MSV_STATE_Q + 1) != hipSuccess ||
+      (fwd_too && ctx->w_slab.alloc(4 * ((size_t)need_slots * FWD_STATE_Q * (ctx->sh_fslots_half ? 2 : 1) + 1), true) != hipSuccess)) {
     (void)hipGetLastError();
-    ctx->sh_mslots.release(); ctx->sh_fslots.release(); bt.clear();
+    ctx->sh_mslots.release(); bt.clear();
     S.ms_share_build = tm.stop();
     return ITSX_OK;
   }
@@ -2346,8 +2359,21 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
     a.pairs = pl.pairs; a.waves = ctx->w_waves.p; a.F1 = F1; a.F3 = F3;
     StageTimer tm(st);
+    // (batches are independent: every other one on a second stream with its own half of the slot buffer, so that a launch's tail --
+    // the next depth waits for its last waves -- is filled by the other batch's waves)
+    hipStream_t alt = st;
+    if (ctx->sh_fslots_half > 0 && nseg > DS) {
+      if (!ctx->st3) {
+        if (hipStreamCreateWithFlags(&ctx->st3, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->st3 = nullptr; }
+        else { (void)hipEventCreateWithFlags(&ctx->ev_s3a, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->ev_s3b, hipEventDisableTiming); }
+      }
+      if (ctx->st3) { alt = ctx->st3; HIPCHK(hipEventRecord(ctx->ev_s3a, st)); HIPCHK(hipStreamWaitEvent(alt, ctx->ev_s3a, 0)); }
+    }
     for (int t0 = 0; t0 < nseg; t0 += DS) {                 // one batch: its profile ranges one after the other, depths ascending
       const auto &b = ctx->sh_batches[(size_t)segbatch[(size_t)t0]];
+      const bool on_alt = alt != st && ((t0 / DS) & 1);
+      hipStream_t bs = on_alt ? alt : st;
+      float4 *fsl = (float4 *)ctx->w_slab.p + (on_alt ? ctx->sh_fslots_half : 0);
       for (int r = 0; r < b.nsplit; r++) {
         const int pa = (int)((int64_t)P * r / b.nsplit), pb = (int)((int64_t)P * (r + 1) / b.nsplit);
         if (pb <= pa) continue;
@@ -2356,12 +2382,13 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
           const int w0 = woff[(size_t)t * P + pa], w1 = woff[(size_t)t * P + pb];
           if (w1 <= w0) continue;
           ShareLaunch sl{};
-          sl.parent = ctx->sh_parent.p + u0; sl.mask = ctx->sh_mask.p + u0; sl.node0 = ctx->sh_node0.p + u0;
-          sl.slots = ctx->sh_fslots.p; sl.node_base = b.node0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
-          for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, st); S.n_bound_launches++; }
+          sl.src = ctx->sh_src.p + u0; sl.mask = ctx->sh_mask.p + u0; sl.node0 = ctx->sh_node0.p + u0;
+          sl.slots = fsl; sl.node_base = b.node0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
+          for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bound_launches++; }
         }
       }
     }
+    if (alt != st) { HIPCHK(hipEventRecord(ctx->ev_s3b, alt)); HIPCHK(hipStreamWaitEvent(st, ctx->ev_s3b, 0)); }
     const float ms = tm.stop();
     S.ms_bound_kernel += ms; S.ms_filters += ms;
     S.bound_rows += lane_rows[0]; S.bound_rows_full += lane_rows[1];
@@ -2531,10 +2558,27 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * np / 4096));
     if (!sh || !shared) { launch_msv(a, s, lds_pad); return; }
     // prefix sharing: batch by batch (the saved states of one batch fit the slot buffer), depth by depth (a chain starts from a state
-    // that a chain of a lower depth saved: launches of one stream run in order)
+    // that a chain of a lower depth saved: launches of one stream run in order).  Batches are independent of each other: every other
+    // one runs on a second stream with a slot buffer of its own, so that the tail of one launch -- the next depth waits for its last
+    // blocks -- is filled by the other batch's blocks (and blocks may take their sequences through more profiles: fewer re-reads)
+    static const bool two = !(getenv("ITSX_SHARE_MSV_STREAMS") && atoi(getenv("ITSX_SHARE_MSV_STREAMS")) < 2);
+    int nbatch_here = 0;
+    for (const auto &b : ctx->sh_batches) nbatch_here += (b.k0 >= cu0 && b.k0 < cu0 + cU);
+    hipStream_t alt = s;
+    if (two && nbatch_here > 1) {
+      if (!ctx->st3) {
+        if (hipStreamCreateWithFlags(&ctx->st3, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->st3 = nullptr; }
+        else { (void)hipEventCreateWithFlags(&ctx->ev_s3a, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->ev_s3b, hipEventDisableTiming); }
+      }
+      if (ctx->st3) { alt = ctx->st3; (void)hipEventRecord(ctx->ev_s3a, s); (void)hipStreamWaitEvent(alt, ctx->ev_s3a, 0); }
+    }
+    int seen = 0;
     for (const auto &b : ctx->sh_batches) {
       if (b.k0 < cu0 || b.k0 >= cu0 + cU) continue;
       const size_t bi = (size_t)(&b - ctx->sh_batches.data());
+      const bool on_alt = alt != s && (seen++ & 1);
+      hipStream_t bs = on_alt ? alt : s;
+      uint4 *slots = ctx->sh_mslots.p + (on_alt ? ctx->sh_mslots_half : 0);
       for (int r = 0; r < b.nsplit; r++) {
         const int pa = (int)((int64_t)np * r / b.nsplit), pb = (int)((int64_t)np * (r + 1) / b.nsplit);
         if (pb <= pa) continue;
@@ -2543,16 +2587,18 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
           if (k1 <= k0) continue;
           MsvArgs c = a;
           c.k0 = (int32_t)(k0 - cu0); c.k1 = (int32_t)(k1 - cu0); c.pfirst = pa; c.plast = pb; c.share = 1;
-          c.sl.parent = ctx->sh_parent.p + cu0; c.sl.mask = ctx->sh_mask.p + cu0; c.sl.node0 = ctx->sh_node0.p + cu0;
-          c.sl.slots = ctx->sh_mslots.p; c.sl.node_base = b.node0; c.sl.p0 = pa; c.sl.Pb = pb - pa; c.sl.depth = d; c.sl.logB = ctx->share_logB;
-          // (a launch ends when its last blocks end, and the next depth waits for it: many short blocks -- ten rounds of the ~1 500 a chip
-          // holds -- rather than a few long ones that take their sequences through 32 profiles)
+          c.sl.src = ctx->sh_src.p + cu0; c.sl.mask = ctx->sh_mask.p + cu0; c.sl.node0 = ctx->sh_node0.p + cu0;
+          c.sl.slots = slots; c.sl.node_base = b.node0; c.sl.p0 = pa; c.sl.Pb = pb - pa; c.sl.depth = d; c.sl.logB = ctx->share_logB;
+          // (a launch ends when its last blocks end, and the next depth waits for it: many short blocks -- rounds of the ~1 000-1 500 a
+          // chip holds -- rather than a few long ones that take their sequences through 32 profiles; with the other batch's launches
+          // beside it a block may be four times as long)
           const int64_t t2 = ((int64_t)(k1 - k0) + 255) / 256;
-          c.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, t2 * (pb - pa) / 16384));
-          launch_msv(c, s, lds_pad);
+          c.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, t2 * (pb - pa) / (alt != s ? 4096 : 16384)));
+          launch_msv(c, bs, lds_pad);
         }
       }
     }
+    if (alt != s) { (void)hipEventRecord(ctx->ev_s3b, alt); (void)hipStreamWaitEvent(s, ctx->ev_s3b, 0); }
   };
   if (ctx->msv_pre_u0 == (int64_t)u0) {
     // launched on st2 while the chunk before this one was in its domain stage

@@ -174,16 +174,18 @@ void launch_diff_scores(const float *x, const float *y, const PairRec *pairs, in
 constexpr int SHARE_SEGS = 66;             // per batch: first k of depth 0 .. 64, and the batch's end
 struct ShareDev {                          // the tree by processing position k
   uint8_t *depth; int32_t *parent /* k relative to the chunk */; unsigned long long *mask; int32_t *nn, *node0; int32_t *order /* global unique */, *ulen;
+  int32_t *src;                            // number of the saved state the chain starts from (-1: from row 1): one coalesced load instead of two gathers
 };
+void launch_share_src(const ShareDev &o, int32_t U, int32_t Uc, hipStream_t st);     // after node0 is scanned
 void launch_share_permute(const TrieArgs &a, const int32_t *ulen_s, const int32_t *uorder, const int32_t *inv, const ShareDev &o, hipStream_t st);
 // one launch of k_msv / k_fwd_bound over chains that start at the same depth (pointers relative to the chunk)
 struct ShareLaunch {
-  const int32_t *parent; const unsigned long long *mask; const int32_t *node0;
+  const int32_t *src; const unsigned long long *mask; const int32_t *node0;
   void *slots;                 // saved row states: [(node - node_base) * Pb + profile - p0][MSV_STATE_Q uint4 | FWD_STATE_Q float4]
   int64_t node_base; int32_t p0, Pb;
   int32_t depth, logB;
 };
-constexpr int MSV_STATE_Q = 7;             // 23 packed registers + xJ, xB, xEmax
+constexpr int MSV_STATE_Q = 8;             // 23 packed registers + xJ, xB, xEmax, padded to one 128-byte line
 constexpr int FWD_STATE_Q = 36;            // M, I, D of 46 nodes + xN xJ xC xB + the scale's logarithm (double)
 // lazy searches only: a chain whose own pair failed the MSV filter still has to run for a profile when a chain below it needs its state
 void launch_need_bits(const uint16_t *res, int32_t U, int32_t P, int32_t W, uint32_t *pass, uint32_t *need, hipStream_t st);
@@ -215,6 +217,7 @@ struct MsvArgs {
   int32_t nlist;
   int32_t k0, k1;               // sorted positions [k0, k1) of this launch (k1 = 0: all U)
   int32_t pfirst, plast;        // profiles (list positions with plist) [pfirst, plast) (plast = 0: all)
+  int32_t wtl;                  // packed words a lane keeps in LDS (set by launch_msv: the whole read, or 16 at a time)
   int32_t share;                // prefix sharing: every sequence of [k0, k1) is a chain that starts at sl.depth
   ShareLaunch sl;
 };

@@ -101,8 +101,7 @@ __global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, con
     const int k = pr.useq;
     if (active) { smask = sl.mask[k]; snode = (int64_t)sl.node0[k] - sl.node_base; }
     if (sl.depth > 0) {
-      const int par = sl.parent[k];
-      const int64_t node = (int64_t)sl.node0[par] + __popcll(sl.mask[par] & ((1ull << sl.depth) - 1ull)) - sl.node_base;
+      const int64_t node = (int64_t)sl.src[k] - sl.node_base;
       const f4 *src = (const f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
 #pragma unroll
       for (int j = 0; j < BP; j++) { const f4 v = src[j]; M[j] = (f2){v.x, v.y}; I[j] = (f2){v.z, v.w}; }

@@ -25,6 +25,8 @@
 //   * the P-value test is folded into a per-(length, profile) threshold on the final xJ byte, computed on the host with
 //     the same double arithmetic hmmsearch uses.
 //   * results go to res[profile][sorted position]: consecutive lanes, consecutive halfwords.
+#include <algorithm>
+#include <cstdlib>
 #include "engine.h"
 #include "k_api.h"
 
@@ -43,7 +45,10 @@ template <bool SHARE>
 __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint32_t tab[2][16 * MSV_TW];
-  __shared__ uint32_t wst[MSV_WT][256];            // each lane's next 16 packed words (its own column: no barrier)
+  // each lane's packed words in LDS (its own column: no barrier): the WHOLE read when the launch's longest fits 37 words (592 bases:
+  // 37 KB a block, four blocks a CU) -- loaded once for all the block's profiles --, else 16 words (256 rows) at a time
+  extern __shared__ uint32_t wst[];
+  const bool whole = a.wtl > MSV_WT;
   const int s = a.k0 + blockIdx.x * 256 + threadIdx.x;
   const bool valid = s < a.k1;
   int L = 0, nexc = 0, tjb = 0, Lt = 0;
@@ -59,6 +64,10 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
     ep = a.rd.exc + eo;
     Lt = L < a.Lcap ? L : a.Lcap - 1;
     tjb = a.tjb[Lt];
+  }
+  if (whole) {
+    const int nw = (L + 15) >> 4;
+    for (int j = 0; j < a.wtl; j++) wst[j * 256 + threadIdx.x] = (j < nw) ? wp[j] : 0u;
   }
   int Lw = L;                                     // the wave runs to its longest sequence (lengths ascend: usually all equal)
   for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(Lw, d, 64); Lw = o > Lw ? o : Lw; }
@@ -83,9 +92,8 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
     for (int i = 0; i < MSV_REGS; i++) dp[i] = 0;
     if constexpr (SHARE) {
       if (valid && a.sl.depth > 0) {
-        // the parent chain's saved state this chain starts from (looked up per profile: two registers less in the row loop)
-        const int par = a.sl.parent[s];
-        const int64_t src_node = (int64_t)a.sl.node0[par] + __popcll(a.sl.mask[par] & ((1ull << a.sl.depth) - 1ull)) - a.sl.node_base;
+        // the parent chain's saved state this chain starts from (one 128-byte line; its number: one coalesced load per profile)
+        const int64_t src_node = (int64_t)a.sl.src[s] - a.sl.node_base;
         const uint4 *src = (const uint4 *)a.sl.slots + (src_node * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -119,12 +127,12 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
         // the lane's packed words, 16 at a time (256 rows) through LDS: one contiguous 64-byte piece of the read per load instead of a
         // dword every 16 rows -- every one of those dwords cost a whole line once 49 k lanes' lines no longer fit the XCD's L2
         // (75.6 GB fetched per 1 M reads in round 4 against 0.1-0.4 GB of packed reads; profiles/round5_pmc_hbm_traffic_1M.md)
-        if ((pos & 255) == 0 || pos == row0) {
+        if (!whole && ((pos & 255) == 0 || pos == row0)) {
           const int w0 = (pos >> 8) << 4, nw = (L + 15) >> 4;
 #pragma unroll
-          for (int j = 0; j < MSV_WT; j++) wst[j][threadIdx.x] = (w0 + j < nw) ? wp[w0 + j] : 0u;
+          for (int j = 0; j < MSV_WT; j++) wst[j * 256 + threadIdx.x] = (w0 + j < nw) ? wp[w0 + j] : 0u;
         }
-        w = wst[(pos >> 4) & (MSV_WT - 1)][threadIdx.x];
+        w = wst[(whole ? (pos >> 4) : ((pos >> 4) & (MSV_WT - 1))) * 256 + threadIdx.x];
       }
       if (pos < L) {
         int code = (int)((w >> sh) & 3u);
@@ -177,8 +185,14 @@ void launch_msv(const MsvArgs &a0, hipStream_t st, int lds_pad)
   const int np = a.plast - a.pfirst, nk = a.k1 - a.k0;
   if (nk <= 0 || np <= 0) return;
   const dim3 grid((unsigned)((nk + 255) / 256), (unsigned)((np + a.PB - 1) / a.PB));
-  if (a.share) hipLaunchKernelGGL(k_msv<true>, grid, dim3(256), (size_t)lds_pad, st, a);
-  else hipLaunchKernelGGL(k_msv<false>, grid, dim3(256), (size_t)lds_pad, st, a);
+  // words a lane keeps in LDS: every word of the launch's longest read when that is at most 37 (four blocks of 37 + 3 KB fill a CU's
+  // 160 KB exactly), else 16 at a time; ITSX_MSV_WHOLE=0: always 16 (A/B)
+  static const bool allow_whole = !(getenv("ITSX_MSV_WHOLE") && atoi(getenv("ITSX_MSV_WHOLE")) == 0);
+  const int need = (a.Lcap - 1 + 15) / 16;
+  a.wtl = (allow_whole && need > MSV_WT && need <= 37) ? need : MSV_WT;
+  const size_t lds = std::max<size_t>((size_t)lds_pad, (size_t)a.wtl * 256 * sizeof(uint32_t));
+  if (a.share) hipLaunchKernelGGL(k_msv<true>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(k_msv<false>, grid, dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------

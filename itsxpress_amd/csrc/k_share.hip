@@ -257,6 +257,22 @@ __global__ void __launch_bounds__(256) k_share_permute(TrieArgs a, const int32_t
   o.mask[k] = m; o.nn[k] = __popcll(m);
   o.order[k] = a.sorted_uniq[s]; o.ulen[k] = ulen_s[s];
 }
+__global__ void __launch_bounds__(256) k_share_src(ShareDev o, int32_t U, int32_t Uc)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= U) return;
+  const int d = o.depth[k];
+  int v = -1;
+  if (d > 0) {
+    const int par = (k / Uc) * Uc + o.parent[k];
+    v = o.node0[par] + __popcll(o.mask[par] & ((1ull << d) - 1ull));
+  }
+  o.src[k] = v;
+}
+void launch_share_src(const ShareDev &o, int32_t U, int32_t Uc, hipStream_t st)
+{
+  if (U > 0) hipLaunchKernelGGL(k_share_src, dim3((U + 255) / 256), dim3(256), 0, st, o, U, Uc);
+}
 void launch_share_permute(const TrieArgs &a, const int32_t *ulen_s, const int32_t *uorder, const int32_t *inv, const ShareDev &o, hipStream_t st)
 {
   hipLaunchKernelGGL(k_share_permute, dim3((a.U + 1 + 255) / 256), dim3(256), 0, st, a, ulen_s, uorder, inv, o);

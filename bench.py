@@ -686,6 +686,10 @@ def main():
                     "fma_peak": VALU_FMA_TFLOPS, "nofma_peak": round(VALU_NOFMA_TFLOPS, 1), "valu_issue_frac": vfrac.get(dom),
                     "issue_ns": dict(ISSUE_NS), "issue_mix_per_row": ISSUE_MIX.get(dom), "issue_source": ISSUE_SOURCE,
                     "time_used": "alone (ITSX_MSV_OVERLAP=0 step)" if alone else "timed steps",
+                    # what the same launches deliver counted on the rows of the kernel's PAIRS (the rows the chains skip included): not the
+                    # kernel's own rate -- `achieved` is that -- but the rate an unshared kernel would need to match it
+                    "equivalent_tflops_on_pairs_rows": (round(st["bound_rows_full"] * FLOPS_PER_ROW[dom] / (kt[dom] * 1e-3) / 1e12, 2)
+                                                        if (dom == "k_fwd_bound" and st.get("bound_rows_full")) else None),
                     "launches_per_step": nl, "avg_launch_ms": kt[dom] / nl,
                     "alg_flops_per_launch": krows[dom] * FLOPS_PER_ROW[dom] / nl, "alg_flops_per_lane_row": FLOPS_PER_ROW[dom], "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
                     "hbm_frac_on_alg_bytes": alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -1508,8 +1508,15 @@ static int build_share(itsx_ctx *ctx)
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::min(gb, std::max(0.25, ((double)fr + held) / (double)(1ull << 30) / (fwd_too ? 3.0 : 8.0)));
   }
   if (const char *e = getenv("ITSX_SHARE_GB")) gb = std::max(0.0001, atof(e));
-  // (two batches run side by side, each on its own half of the buffers: a batch gets half the budget)
-  const double state_b = 2.0 * (fwd_too ? (double)FWD_STATE_Q * sizeof(float4) : (double)MSV_STATE_Q * sizeof(uint4));
+  // Two batches of the MSV filter always run side by side, each on its own half of its (small) buffer.  The Forward pass does so only
+  // with ITSX_SHARE_FWD_STREAMS=2: measured, its launches' tails are too short for that to gain anything (2.029 vs 2.024 s per 10 M
+  // reads), and overlapping launches make a kernel trace's durations (each stretched by the other) disagree with the wall time
+  static const bool two_fwd = getenv("ITSX_SHARE_FWD_STREAMS") && atoi(getenv("ITSX_SHARE_FWD_STREAMS")) >= 2;
+  const double state_b = fwd_too ? (two_fwd ? 2.0 : 1.0) * (double)FWD_STATE_Q * sizeof(float4) : 2.0 * (double)MSV_STATE_Q * sizeof(uint4);
+  // ... and no more than a job of this size needs: a quarter of all its states at a time still gives every (batch, depth) launch
+  // thousands of waves, and device memory is not free to get (20-40 ms per GB in a fresh context: a streamed file's chunks each bring
+  // their own -- round 5's first streamed run spent 5 s in hipMalloc for slots its 1.3 M-read chunks filled to a tenth)
+  if (!getenv("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)NN * state_b * (double)P / (double)(1ull << 30) / 4.0));
   const int64_t nodes_max = std::max<int64_t>(1, (int64_t)(gb * (double)(1ull << 30) / (state_b * (double)P)));
   std::vector<int32_t> bstart; std::vector<itsx_ctx::ShareBatch> &bt = ctx->sh_batches;
   {
@@ -1527,7 +1534,7 @@ static int build_share(itsx_ctx *ctx)
   }
   const int nb = (int)bt.size();
   // a batch that one group overfills takes its profiles in nsplit ranges; if even one profile's states do not fit, nothing is shared
-  for (auto &b : bt) if ((double)b.nnodes * state_b * (double)((P + b.nsplit - 1) / b.nsplit) > 3.0 * gb * (double)(1ull << 30)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
+  for (auto &b : bt) if ((double)b.nnodes * state_b * (double)((P + b.nsplit - 1) / b.nsplit) > 1.5 * gb * (double)(1ull << 30)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
   // ---- the processing order: stable by (batch, depth)
   HIPCHK(upload(ctx->sh_bstart, bstart, st)); HIPCHK(ctx->sh_cursor.alloc((size_t)nb + 1)); HIPCHK(ctx->sh_segk.alloc((size_t)nb * SHARE_SEGS));
   HIPCHK(hipMemcpyAsync(ctx->sh_cursor.p, ctx->sh_bstart.p, (size_t)nb * 4, hipMemcpyDeviceToDevice, st));
@@ -1560,7 +1567,6 @@ static int build_share(itsx_ctx *ctx)
   for (auto &b : bt) need_slots = std::max<int64_t>(need_slots, b.nnodes * (int64_t)((P + b.nsplit - 1) / b.nsplit));
   // (no room for them: the search runs unshared)
   ctx->sh_mslots_half = (size_t)need_slots * MSV_STATE_Q;      // two batches of the MSV filter run side by side (search_chunk)
-  static const bool two_fwd = !(getenv("ITSX_SHARE_FWD_STREAMS") && atoi(getenv("ITSX_SHARE_FWD_STREAMS")) < 2);
   // The Forward pass's states live in the DP slab (ctx->w_slab): pass A is over before the rounds' Forward / Backward kernels write their
   // rows there, so the two never need the memory at the same time -- 24-48 GB that round 5's first version held twice (and that cost the
   // stages behind it their batch sizes)

@@ -9,7 +9,9 @@
 // Host-only, no GPU call, no arithmetic of the path.
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/itsx_hip.h"
 #include "fastq_io.h"
@@ -19,19 +21,27 @@ struct itsx_stream {
   std::string err;
 };
 
-// open addressing over the 128-bit orientation-free keys of itsx_unique_keys128; value = the first holder
+// open addressing over the 128-bit orientation-free keys of itsx_unique_keys128; value = the first holder.  PARTS sub-tables by the
+// key's top bits, each filled by ONE thread of itsx_keyset_assign's pool: a chunk's 0.75-1.5 M lookups into a table of hundreds of MB are
+// cache misses one after the other on one thread (1.9 s of a 10 M-read streamed run's loader, round 5), independent across partitions
 struct itsx_keyset {
   struct Slot { uint64_t k0, k1; int64_t gidx, fwd, chunk, lu, id; };
-  std::vector<Slot> tab;
-  std::vector<uint8_t> used;
-  size_t n = 0, mask = 0;
-  void grow(size_t cap)
-  {
-    std::vector<Slot> ot; ot.swap(tab);
-    std::vector<uint8_t> ou; ou.swap(used);
-    tab.assign(cap, Slot{}); used.assign(cap, 0); mask = cap - 1;
-    for (size_t i = 0; i < ot.size(); i++) if (ou[i]) { size_t h = (size_t)(ot[i].k0 ^ (ot[i].k1 * 0x9E3779B97F4A7C15ull)) & mask; while (used[h]) h = (h + 1) & mask; tab[h] = ot[i]; used[h] = 1; }
-  }
+  static constexpr int PARTS = 16;
+  struct Part {
+    std::vector<Slot> tab;
+    std::vector<uint8_t> used;
+    size_t n = 0, mask = 0;
+    void grow(size_t cap)
+    {
+      std::vector<Slot> ot; ot.swap(tab);
+      std::vector<uint8_t> ou; ou.swap(used);
+      tab.assign(cap, Slot{}); used.assign(cap, 0); mask = cap - 1;
+      for (size_t i = 0; i < ot.size(); i++) if (ou[i]) { size_t h = (size_t)(ot[i].k0 ^ (ot[i].k1 * 0x9E3779B97F4A7C15ull)) & mask; while (used[h]) h = (h + 1) & mask; tab[h] = ot[i]; used[h] = 1; }
+    }
+  };
+  Part part[PARTS];
+  size_t n = 0;                          // distinct keys so far = the next id
+  static int part_of(uint64_t k0, uint64_t k1) { return (int)(((k0 * 0x9E3779B97F4A7C15ull) ^ k1) >> 60) & (PARTS - 1); }
 };
 
 namespace { std::string g_stream_error; }
@@ -72,7 +82,7 @@ int itsx_stream_close(itsx_stream *s, int32_t keep_text)
 itsx_keyset *itsx_keyset_create(void)
 {
   itsx_keyset *k = new itsx_keyset;
-  k->grow((size_t)1 << 16);
+  for (auto &p : k->part) p.grow((size_t)1 << 14);
   return k;
 }
 void itsx_keyset_destroy(itsx_keyset *k) { delete k; }
@@ -81,16 +91,47 @@ int64_t itsx_keyset_size(const itsx_keyset *k) { return k ? (int64_t)k->n : 0; }
 int itsx_keyset_assign(itsx_keyset *k, const int64_t *tuples, int64_t n_unique, int32_t chunk, int64_t *verdict, int64_t *gid)
 {
   if (!k || n_unique < 0 || (n_unique > 0 && (!tuples || !verdict))) { g_stream_error = "itsx_keyset_assign: missing argument"; return ITSX_E_ARG; }
+  constexpr int PARTS = itsx_keyset::PARTS;
+  // where every tuple's slot is (partition, index) and whether it is new: by partition, in parallel; a partition's thread walks the
+  // tuples in order, so the FIRST holder of a key inside this call is the earlier unique, as on one thread
+  std::vector<uint32_t> where((size_t)n_unique);
+  std::vector<uint8_t> fresh((size_t)n_unique, 0);
+  auto work = [&](int p) {
+    itsx_keyset::Part &pt = k->part[p];
+    for (int64_t u = 0; u < n_unique; u++) {
+      const uint64_t k0 = (uint64_t)tuples[4 * u], k1 = (uint64_t)tuples[4 * u + 1];
+      if (itsx_keyset::part_of(k0, k1) != p) continue;
+      if ((pt.n + 1) * 2 > pt.tab.size()) pt.grow(pt.tab.size() * 2);
+      size_t h = (size_t)(k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) & pt.mask;
+      while (pt.used[h] && !(pt.tab[h].k0 == k0 && pt.tab[h].k1 == k1)) h = (h + 1) & pt.mask;
+      if (!pt.used[h]) { pt.tab[h] = itsx_keyset::Slot{k0, k1, tuples[4 * u + 2], tuples[4 * u + 3], (int64_t)chunk, u, -1}; pt.used[h] = 1; pt.n++; fresh[(size_t)u] = 1; }
+      where[(size_t)u] = (uint32_t)h;
+    }
+  };
+  const int T = n_unique >= 4096 ? std::min(PARTS, std::max(1, itsx_io::io_threads())) : 1;
+  if (T <= 1) { for (int p = 0; p < PARTS; p++) work(p); }
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&, t] { for (int p = t; p < PARTS; p += T) work(p); });
+    for (auto &x : th) x.join();
+  }
+  // (a table that grew after a tuple's slot was noted moved that slot: the slots of a partition that grew in this call are looked up again)
+  // ids in first-seen order: the new keys of this call are numbered by their unique number
+  int64_t next = (int64_t)k->n;
   for (int64_t u = 0; u < n_unique; u++) {
-    if ((k->n + 1) * 2 > k->tab.size()) k->grow(k->tab.size() * 2);
     const uint64_t k0 = (uint64_t)tuples[4 * u], k1 = (uint64_t)tuples[4 * u + 1];
-    size_t h = (size_t)(k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) & k->mask;
-    while (k->used[h] && !(k->tab[h].k0 == k0 && k->tab[h].k1 == k1)) h = (h + 1) & k->mask;
-    if (!k->used[h]) { k->tab[h] = itsx_keyset::Slot{k0, k1, tuples[4 * u + 2], tuples[4 * u + 3], (int64_t)chunk, u, (int64_t)k->n}; k->used[h] = 1; k->n++; }
-    const itsx_keyset::Slot &s = k->tab[h];
+    itsx_keyset::Part &pt = k->part[itsx_keyset::part_of(k0, k1)];
+    size_t h = where[(size_t)u];
+    if (h > pt.mask || !pt.used[h] || pt.tab[h].k0 != k0 || pt.tab[h].k1 != k1) {      // the partition was rehashed since
+      h = (size_t)(k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) & pt.mask;
+      while (!(pt.used[h] && pt.tab[h].k0 == k0 && pt.tab[h].k1 == k1)) h = (h + 1) & pt.mask;
+    }
+    itsx_keyset::Slot &s = pt.tab[h];
+    if (fresh[(size_t)u]) s.id = next++;
     verdict[4 * u] = s.gidx; verdict[4 * u + 1] = s.fwd; verdict[4 * u + 2] = s.chunk; verdict[4 * u + 3] = s.lu;
     if (gid) gid[u] = s.id;
   }
+  k->n = (size_t)next;
   return ITSX_OK;
 }
 

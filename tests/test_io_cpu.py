@@ -399,11 +399,12 @@ def test_keyset_first_holder_wins():
     ks = L.itsx_keyset_create()
     try:
         rng = np.random.default_rng(2)
-        keys = rng.integers(-2**62, 2**62, (50000, 2), dtype=np.int64)
+        # (enough keys for the 16 sub-tables to grow several times, inside one call too: a slot noted before its table moved is found again)
+        keys = rng.integers(-2**62, 2**62, (600000, 2), dtype=np.int64)
         seen = {}
         base = 0
         for chunk in range(4):
-            pick = rng.integers(0, len(keys), 30000)
+            pick = rng.integers(0, len(keys), 30000 if chunk == 0 else 350000)
             pick = pick[np.sort(np.unique(pick, return_index=True)[1])]          # a chunk's uniques are distinct
             tup = np.zeros((len(pick), 4), np.int64)
             tup[:, :2] = keys[pick]
@@ -415,7 +416,7 @@ def test_keyset_first_holder_wins():
             for u, k in enumerate(pick):
                 want = seen.setdefault(int(k), (int(tup[u, 2]), int(tup[u, 3]), chunk, u, len(seen)))
                 assert tuple(int(x) for x in out[u]) + (int(gid[u]),) == want          # gid: first-seen order
-            base += 100000
+            base += 2000000
         assert L.itsx_keyset_size(ks) == len(seen)
         assert L.itsx_keyset_assign(ks, None, 0, 9, None, None) == 0
     finally:

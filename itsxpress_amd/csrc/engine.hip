@@ -2562,7 +2562,9 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     }
     const int np = a.plist ? a.nlist : P;
     a.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, tiles * np / 4096));
-    if (!sh || !shared) { launch_msv(a, s, lds_pad); return; }
+    // (the completion filters a handful of profiles: its launches would be a hundred tiny ones per chunk -- it runs unshared, on the same
+    // processing order)
+    if (!sh || !shared || ctx->completing) { launch_msv(a, s, lds_pad); return; }
     // prefix sharing: batch by batch (the saved states of one batch fit the slot buffer), depth by depth (a chain starts from a state
     // that a chain of a lower depth saved: launches of one stream run in order).  Batches are independent of each other: every other
     // one runs on a second stream with a slot buffer of its own, so that the tail of one launch -- the next depth waits for its last

@@ -184,6 +184,41 @@ static void defer_free(void *q, size_t bytes)
   if (flush) grave_flush();
 }
 
+// The labels of a read set: one blob + offsets instead of one std::string per record (10-20 M allocations per 10 M-read run, and
+// as many moves when the parser's pieces are joined).  The part of std::vector<std::string>'s interface the engine uses.
+struct NameList {
+  std::vector<char> blob; std::vector<int64_t> off{0};
+  size_t size() const { return off.size() - 1; }
+  bool empty() const { return off.size() <= 1; }
+  void clear() { blob.clear(); off.assign(1, 0); }
+  void swap(NameList &o) { blob.swap(o.blob); off.swap(o.off); }
+  const char *ptr(size_t i) const { return blob.data() + off[i]; }
+  size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i]); }
+  void emplace_back(const char *b, const char *e) { blob.insert(blob.end(), b, e); off.push_back((int64_t)blob.size()); }
+  std::string operator[](size_t i) const { return std::string(ptr(i), len(i)); }
+  int cmp(size_t a, size_t b) const          // strcmp's order (labels hold no NUL)
+  {
+    const size_t la = len(a), lb = len(b), m = la < lb ? la : lb;
+    const int c = m ? memcmp(ptr(a), ptr(b), m) : 0;
+    return c ? c : (la < lb ? -1 : la > lb ? 1 : 0);
+  }
+  void assign(const char *names, const int64_t *name_offsets, int64_t n)      // names[name_offsets[i] .. name_offsets[i + 1])
+  {
+    const int64_t o0 = name_offsets[0];
+    blob.assign(names + o0, names + name_offsets[n]);
+    off.resize((size_t)n + 1);
+    for (int64_t i = 0; i <= n; i++) off[(size_t)i] = name_offsets[i] - o0;
+  }
+  NameList slice(size_t lo, size_t hi) const
+  {
+    NameList r;
+    r.blob.assign(blob.begin() + off[lo], blob.begin() + off[hi]);
+    r.off.resize(hi - lo + 1);
+    for (size_t i = lo; i <= hi; i++) r.off[i - lo] = off[i] - off[lo];
+    return r;
+  }
+};
+
 template <class T> struct DBuf {
   T *p = nullptr; size_t n = 0, cap = 0;
   // exact: no growth headroom (the slabs: their size is a budget, not a data-dependent count)
@@ -241,14 +276,14 @@ struct itsx_ctx {
 
   // ---- reads
   int64_t N = 0;
-  std::string h_bases;                   // original text (rep.fa keeps the input's case)
+  itsx_io::Text h_bases;                 // original text (rep.fa keeps the input's case); not zero-filled when it grows
   const char *bases_view = "";           // = h_bases.data(), or the caller's buffer after itsx_set_reads_view
   const uint8_t *dev_bases = nullptr;    // after itsx_set_reads_device: the caller's device buffer (bases_view is fetched on demand)
   static constexpr int NSTAGE = 3;       // pinned / device staging of the hand-over (pack_and_upload)
   void *stage_pin[NSTAGE] = {nullptr, nullptr, nullptr}; DBuf<uint8_t> stage_dev[NSTAGE]; hipEvent_t stage_ev[NSTAGE] = {nullptr, nullptr, nullptr}; size_t stage_cap = 0;
   DBuf<int64_t> w_pk_off; DBuf<int8_t> w_pk_lut; DBuf<int32_t> w_pk_excnt, w_pk_exstart, w_pk_tmp; DBuf<long long> w_pk_bad;
   std::vector<int64_t> h_off;
-  std::vector<std::string> h_names;
+  NameList h_names;
   std::vector<int64_t> h_woff;           // word offset of each read (the words themselves and the exceptions live on the device only)
   std::vector<int32_t> h_len;
   DBuf<uint32_t> d_words, d_exc;
@@ -727,13 +762,12 @@ static int set_reads_impl(itsx_ctx *ctx, const char *bases, const int64_t *offse
   const int64_t base0 = offsets[0];
   for (auto &o : ctx->h_off) o -= base0;
   const char *view = nullptr;
-  if (borrow) { std::string().swap(ctx->h_bases); view = bases ? bases + base0 : ""; }
+  if (borrow) { itsx_io::Text().swap(ctx->h_bases); view = bases ? bases + base0 : ""; }
   else if (bases) ctx->h_bases.assign(bases + base0, (size_t)(offsets[n] - base0));
   else ctx->h_bases.clear();
   ctx->h_names.clear();
   if (names && name_offsets) {
-    ctx->h_names.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) ctx->h_names[i].assign(names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i]));
+    ctx->h_names.assign(names, name_offsets, n);
   }
   return pack_and_upload(ctx, view);
 }
@@ -750,11 +784,10 @@ int itsx_set_reads_device(itsx_ctx *ctx, const void *d_bases, const int64_t *off
   ctx->h_off.assign(offsets, offsets + n + 1);
   const int64_t base0 = offsets[0];
   for (auto &o : ctx->h_off) o -= base0;
-  std::string().swap(ctx->h_bases);
+  itsx_io::Text().swap(ctx->h_bases);
   ctx->h_names.clear();
   if (names && name_offsets) {
-    ctx->h_names.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) ctx->h_names[i].assign(names + name_offsets[i], (size_t)(name_offsets[i + 1] - name_offsets[i]));
+    ctx->h_names.assign(names, name_offsets, n);
   }
   static const uint8_t none = 0;
   return pack_and_upload(ctx, nullptr, d_bases ? (const uint8_t *)d_bases + base0 : &none);
@@ -763,7 +796,7 @@ int itsx_set_reads_device(itsx_ctx *ctx, const void *d_bases, const int64_t *off
 // ---- FASTA / FASTQ text -> records (labels up to the first blank, as vsearch labels them).  Large texts are cut at record
 // starts and parsed by the I/O pool; the pieces are joined in order, so the result is the serial parser's.
 struct FastxPart {
-  std::string seq, qual; std::vector<int64_t> off{0}; std::vector<std::string> ids;
+  itsx_io::Text seq, qual; std::vector<int64_t> off{0}; NameList ids;
   int rc = ITSX_OK; std::string err;
 };
 
@@ -779,8 +812,10 @@ static void parse_fastx_range(const char *s, const char *end, bool want_qual, bo
   auto put_seq = [&](const char *b, const char *e) {
     const size_t o = out.seq.size();
     out.seq.append(b, e);
-    if (upper) for (size_t i = o; i < out.seq.size(); i++) out.seq[i] = (char)toupper((unsigned char)out.seq[i]);
+    if (upper) { char *q = out.seq.data(); for (size_t i = o; i < out.seq.size(); i++) q[i] = (char)toupper((unsigned char)q[i]); }
   };
+  // (a FASTQ record is about half sequence: room for it up front instead of a dozen doublings with their copies)
+  if (end > s && (size_t)(end - s) > ((size_t)1 << 20)) { out.seq.reserve(out.seq.size() + (size_t)(end - s) / 2 + 4096); if (want_qual) out.qual.reserve(out.qual.size() + (size_t)(end - s) / 2 + 4096); out.ids.blob.reserve(out.ids.blob.size() + (size_t)(end - s) / 8); }
   const char *b, *e;
   bool pending = false;                  // a header line already read into b,e
   while (pending || next_line(b, e)) {
@@ -803,7 +838,7 @@ static void parse_fastx_range(const char *s, const char *end, bool want_qual, bo
         if (b < e && *b == '>') { pending = true; break; }
         put_seq(b, e);
       }
-      if (want_qual) out.qual.resize(out.seq.size(), 'I');
+      if (want_qual) { const size_t q0 = out.qual.size(); out.qual.resize(out.seq.size()); if (out.qual.size() > q0) memset(out.qual.data() + q0, 'I', out.qual.size() - q0); }
       out.off.push_back((int64_t)out.seq.size());
     } else { out.rc = ITSX_E_FORMAT; out.err = "input is neither FASTA nor FASTQ"; return; }
   }
@@ -857,16 +892,22 @@ static int parse_fastx(const itsx_io::Text &text, bool want_qual, bool upper, Fa
     if (parts[k].rc != ITSX_OK) { err = parts[k].err + " near read " + std::to_string(nrec + parts[k].ids.size()); return parts[k].rc; }
     nrec += parts[k].ids.size(); nseq += parts[k].seq.size();
   }
-  const size_t rec0 = out.ids.size(), seq0 = out.seq.size();
-  out.ids.resize(rec0 + nrec); out.off.resize(rec0 + nrec + 1); out.seq.resize(seq0 + nseq);
-  if (want_qual) out.qual.resize(seq0 + nseq);
-  std::vector<size_t> rbase(np), sbase(np);
-  { size_t r = rec0, q = seq0; for (size_t k = 0; k < np; k++) { rbase[k] = r; sbase[k] = q; r += parts[k].ids.size(); q += parts[k].seq.size(); } }
+  const size_t rec0 = out.ids.size(), seq0 = out.seq.size(), nam0 = out.ids.blob.size();
+  size_t nnam = 0;
+  for (size_t k = 0; k < np; k++) nnam += parts[k].ids.blob.size();
+  out.ids.off.resize(rec0 + nrec + 1); out.ids.blob.resize(nam0 + nnam); out.off.resize(rec0 + nrec + 1);
+  if (!out.seq.resize(seq0 + nseq) || (want_qual && !out.qual.resize(seq0 + nseq))) { err = "out of memory parsing the reads"; return ITSX_E_NOMEM; }
+  std::vector<size_t> rbase(np), sbase(np), nbase(np);
+  { size_t r = rec0, q = seq0, m = nam0; for (size_t k = 0; k < np; k++) { rbase[k] = r; sbase[k] = q; nbase[k] = m; r += parts[k].ids.size(); q += parts[k].seq.size(); m += parts[k].ids.blob.size(); } }
   on_threads((int)np, [&](int k) {
     FastxPart &p = parts[(size_t)k];
-    memcpy(&out.seq[sbase[(size_t)k]], p.seq.data(), p.seq.size());
-    if (want_qual) memcpy(&out.qual[sbase[(size_t)k]], p.qual.data(), p.qual.size());
-    for (size_t i = 0; i < p.ids.size(); i++) { out.ids[rbase[(size_t)k] + i] = std::move(p.ids[i]); out.off[rbase[(size_t)k] + i + 1] = (int64_t)sbase[(size_t)k] + p.off[i + 1]; }
+    if (p.seq.size()) memcpy(out.seq.data() + sbase[(size_t)k], p.seq.data(), p.seq.size());
+    if (want_qual && p.qual.size()) memcpy(out.qual.data() + sbase[(size_t)k], p.qual.data(), p.qual.size());
+    if (p.ids.blob.size()) memcpy(out.ids.blob.data() + nbase[(size_t)k], p.ids.blob.data(), p.ids.blob.size());
+    for (size_t i = 0; i < p.ids.size(); i++) {
+      out.ids.off[rbase[(size_t)k] + i + 1] = (int64_t)nbase[(size_t)k] + p.ids.off[i + 1];
+      out.off[rbase[(size_t)k] + i + 1] = (int64_t)sbase[(size_t)k] + p.off[i + 1];
+    }
   });
   return ITSX_OK;
 }
@@ -934,10 +975,11 @@ int itsx_load_reads_file_shard(itsx_ctx *ctx, const char *path, int32_t shard, i
   const int64_t lo = tot * shard / n_shards, hi = tot * (shard + 1) / n_shards;
   if (lo > 0 || hi < tot) {
     const int64_t b0 = ctx->h_off[(size_t)lo], b1 = ctx->h_off[(size_t)hi];
-    std::string bases = ctx->h_bases.substr((size_t)b0, (size_t)(b1 - b0));
+    itsx_io::Text bases;
+    bases.assign(ctx->h_bases.data() + b0, (size_t)(b1 - b0));
     std::vector<int64_t> off((size_t)(hi - lo) + 1);
     for (int64_t r = lo; r <= hi; r++) off[(size_t)(r - lo)] = ctx->h_off[(size_t)r] - b0;
-    std::vector<std::string> names(ctx->h_names.begin() + lo, ctx->h_names.begin() + hi);
+    NameList names = ctx->h_names.slice((size_t)lo, (size_t)hi);
     ctx->h_bases.swap(bases); ctx->h_off.swap(off); ctx->h_names.swap(names);
   }
   ctx->N = hi - lo;
@@ -1148,7 +1190,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
     if (ctx->h_len[r] >= minlen && ctx->h_len[r] <= 50000) { ord.push_back((int32_t)r); Lmax = std::max(Lmax, (int)ctx->h_len[r]); }
   if (!ctx->h_names.empty())
     std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
-      const int c = strcmp(ctx->h_names[a].c_str(), ctx->h_names[b].c_str());
+      const int c = ctx->h_names.cmp((size_t)a, (size_t)b);
       return c < 0 || (c == 0 && a < b);
     });
   const int32_t nk = (int32_t)ord.size();
@@ -3235,7 +3277,7 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   for (int64_t i = 0; i < n; i++) {
     if (reason[i] != 0) continue;
     const size_t o = (size_t)(f.off[i] + r.off[i]);
-    buf += '@'; buf += f.ids[i]; buf += '\n';
+    buf += '@'; buf.append(f.ids.ptr((size_t)i), f.ids.len((size_t)i)); buf += '\n';
     buf.append(oseq.data() + o, (size_t)olen[i]); buf += "\n+\n";
     buf.append(oqual.data() + o, (size_t)olen[i]); buf += '\n';
     if (buf.size() >= (1u << 20)) { bw.put(buf); buf.clear(); }
@@ -3295,7 +3337,7 @@ int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_pat
     if (reason[i] != 0) continue;
     srcoff.push_back(f.off[i] + r.off[i]);
     dstoff.push_back(dstoff.back() + olen[i]);
-    ctx->h_names.emplace_back(std::move(f.ids[i]));
+    ctx->h_names.emplace_back(f.ids.ptr((size_t)i), f.ids.ptr((size_t)i) + f.ids.len((size_t)i));
   }
   const int64_t m = (int64_t)srcoff.size();
   if (m >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
@@ -3306,7 +3348,7 @@ int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_pat
   HIPCHK(hipGetLastError());
   ctx->N = m;
   ctx->h_off.swap(dstoff);
-  std::string().swap(ctx->h_bases);
+  itsx_io::Text().swap(ctx->h_bases);
   static const uint8_t none = 0;
   rc = pack_and_upload(ctx, nullptr, m > 0 ? d_cmp.p : &none);
   if (trace) {
@@ -3683,6 +3725,12 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path)
 int itsx_get_read_names(const itsx_ctx *ctx, char *names, int64_t cap, int64_t *offsets)
 {
   CTXCHK(ctx && offsets);
+  if (!ctx->h_names.empty() && (int64_t)ctx->h_names.size() == ctx->N) {      // the labels as they are kept: one copy
+    const int64_t tot = ctx->h_names.off[(size_t)ctx->N];
+    if (names) { if (tot > cap) SET_ERR(ctx, ITSX_E_ARG, "name buffer too small"); if (tot) memcpy(names, ctx->h_names.blob.data(), (size_t)tot); }
+    memcpy(offsets, ctx->h_names.off.data(), ((size_t)ctx->N + 1) * sizeof(int64_t));
+    return ITSX_OK;
+  }
   int64_t o = 0;
   for (int64_t r = 0; r < ctx->N; r++) {
     offsets[r] = o;

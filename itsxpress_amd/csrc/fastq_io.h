@@ -52,7 +52,10 @@ class Text {
   // pin: the bytes stay where they are -- growth past the capacity FAILS instead of moving them (readers hold pointers into a
   // buffer that is still being filled: TextStream)
   void pin(bool on) { pinned_ = on; }
-  bool append(const char *q, size_t m) { const size_t at = n_; if (!resize(n_ + m)) return false; for (size_t i = 0; i < m; i++) p_[at + i] = q[i]; return true; }
+  bool append(const char *q, size_t m) { const size_t at = n_; if (!resize(n_ + m)) return false; if (m) __builtin_memcpy(p_ + at, q, m); return true; }
+  bool append(const char *b, const char *e) { return append(b, (size_t)(e - b)); }
+  bool assign(const char *q, size_t m) { n_ = 0; return append(q, m); }
+  std::string substr(size_t o, size_t m) const { return std::string(p_ + o, m); }
  private:
   void release();
   char *p_ = nullptr;

@@ -1890,7 +1890,10 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
     int64_t total_rows = 0;
     for (int w = 0; w < NW; w++) total_rows += rows[(size_t)w];
     const int64_t floor_rows = ((int64_t)4 << 30) / row_bytes, have_rows = (int64_t)(ctx->w_slab.cap / (12 * 64));
-    budget_rows = std::min(budget_rows, std::max(std::max(total_rows / 8 + 1, floor_rows), have_rows));
+    // (memory the context holds is kept as it is while it is at least half of that: growing a buffer is a free and an allocation, and
+    // on this driver both are paid at ~30 GB/s -- freed memory is wiped, fresh memory cleared: scripts/alloc_probe.hip)
+    const int64_t want_rows = std::max(total_rows / 8 + 1, floor_rows);
+    budget_rows = std::min(budget_rows, 2 * have_rows >= want_rows ? have_rows : want_rows);
   }
   DBuf<RegionRec> &d_raw = ctx->w_raw;
   HIPCHK(d_raw.alloc((size_t)NP * MAXDOM));

@@ -474,38 +474,54 @@ int itsx_twriter_close(itsx_twriter *w, int64_t *n_written, int64_t *total_len)
 }
 
 // the merged reads' labels -> their index, without a string per label: open addressing over a 64-bit hash, the label bytes compared
-// on a hit (a std::unordered_map<std::string, ...> of 10 M labels was a second of allocations on one thread)
+// on a hit (a std::unordered_map<std::string, ...> of 10 M labels was a second of allocations on one thread).  Built by a pool of
+// threads: a slot is claimed with a compare-and-swap, a slot's LABEL never changes once it is set, and of equal labels the smallest
+// index stays (the first of them wins, as emplace() kept it) -- lookups do not depend on the order of the insertions.
 struct NameIndex {
-  const char *names; const int64_t *offs; int64_t n; std::vector<int64_t> slot; uint64_t mask = 0;
+  const char *names = nullptr; const int64_t *offs = nullptr; int64_t n = 0; std::unique_ptr<std::atomic<int64_t>[]> slot; uint64_t mask = 0;
   static uint64_t hash(const char *p, size_t len)
   {
     uint64_t h = 0xcbf29ce484222325ull;
     for (size_t i = 0; i < len; i++) { h ^= (unsigned char)p[i]; h *= 0x100000001b3ull; }
     return h ^ (h >> 29);
   }
-  void build(const char *nm, const int64_t *of, int64_t count)
+  bool same(int64_t j, const char *p, size_t len) const { return (size_t)(offs[j + 1] - offs[j]) == len && memcmp(names + offs[j], p, len) == 0; }
+  void insert(int64_t i)
+  {
+    const char *p = names + offs[i]; const size_t len = (size_t)(offs[i + 1] - offs[i]);
+    uint64_t h = hash(p, len) & mask;
+    for (;;) {
+      int64_t j = slot[h].load(std::memory_order_relaxed);
+      if (j < 0 && slot[h].compare_exchange_strong(j, i, std::memory_order_relaxed)) return;
+      // j = who holds the slot
+      if (same(j, p, len)) { while (i < j && !slot[h].compare_exchange_weak(j, i, std::memory_order_relaxed)) {} return; }
+      h = (h + 1) & mask;
+    }
+  }
+  void build(const char *nm, const int64_t *of, int64_t count, int threads)
   {
     names = nm; offs = of; n = count;
     size_t cap = 16; while (cap < (size_t)count * 2) cap <<= 1;
-    slot.assign(cap, -1); mask = cap - 1;
-    for (int64_t i = 0; i < count; i++) {
-      uint64_t h = hash(nm + of[i], (size_t)(of[i + 1] - of[i])) & mask;
-      // (the first of equal labels wins, as emplace() kept it)
-      for (;;) {
-        const int64_t j = slot[h];
-        if (j < 0) { slot[h] = i; break; }
-        if (of[j + 1] - of[j] == of[i + 1] - of[i] && memcmp(nm + of[j], nm + of[i], (size_t)(of[i + 1] - of[i])) == 0) break;
-        h = (h + 1) & mask;
-      }
+    slot.reset(new std::atomic<int64_t>[cap]); mask = cap - 1;
+    const int T = (count >= (1 << 16)) ? std::max(1, threads) : 1;
+    auto part = [&](int t) {
+      for (size_t k = cap * (size_t)t / (size_t)T, e = cap * (size_t)(t + 1) / (size_t)T; k < e; k++) slot[k].store(-1, std::memory_order_relaxed);
+    };
+    auto fill = [&](int t) { for (int64_t i = count * t / T, e = count * (t + 1) / T; i < e; i++) insert(i); };
+    if (T == 1) { part(0); fill(0); return; }
+    for (int phase = 0; phase < 2; phase++) {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; t++) th.emplace_back([&, t] { if (phase == 0) part(t); else fill(t); });
+      for (auto &x : th) x.join();
     }
   }
   int64_t find(const char *p, size_t len) const
   {
     uint64_t h = hash(p, len) & mask;
     for (;;) {
-      const int64_t j = slot[h];
+      const int64_t j = slot[h].load(std::memory_order_relaxed);
       if (j < 0) return -1;
-      if ((size_t)(offs[j + 1] - offs[j]) == len && memcmp(names + offs[j], p, len) == 0) return j;
+      if (same(j, p, len)) return j;
       h = (h + 1) & mask;
     }
   }
@@ -517,11 +533,22 @@ int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const ch
 {
   if (!r1_path || !r2_path || !out1_path || !out2_path || !names || !name_offsets || !start || !stop || !tlen) { g_trim_error = "null argument"; return ITSX_E_ARG; }
   if (compression < 0 || compression > 2) { g_trim_error = "compression must be 0 (plain), 1 (gzip) or 2 (zstd)"; return ITSX_E_ARG; }
+  const int T = itsx_io::io_threads();
   NameIndex idx;
-  idx.build(names, name_offsets, n_names);
-  Records in1, in2; Writer o1, o2;
-  if (!in1.open(r1_path) || !in2.open(r2_path)) return ITSX_E_IO;
-  if (!o1.open(out1_path, compression) || !o2.open(out2_path, compression)) return ITSX_E_IO;
+  Records in1, in2;
+  {   // the two inputs are inflated side by side (each by its own pool of block decoders) while the labels are indexed
+    std::string e1, e2;
+    auto open = [](Records &r, const char *path, std::string &err) {
+      r.text = itsx_io::read_text(path, err, true);
+      if (r.text) { r.s = r.text->data(); r.end = r.s + r.text->size(); }
+    };
+    std::thread t1([&] { open(in1, r1_path, e1); });
+    std::thread t2([&] { open(in2, r2_path, e2); });
+    idx.build(names, name_offsets, n_names, T);
+    t1.join(); t2.join();
+    if (!in1.text || !in2.text) { g_trim_error = !in1.text ? e1 : e2; return ITSX_E_IO; }
+  }
+  { itsx_io::PieceCompressor probe(compression); if (!probe.ok()) { g_trim_error = "zstd output requested but libzstd.so.1 could not be loaded"; return ITSX_E_IO; } }
   const bool ccs = trim_ccs != 0;
   // one pair of records -> its two trimmed records (appended to the two buffers), as the serial walk below emits them
   auto one_pair = [&](const Rec &a, const Rec &b, std::string &b1, std::string &b2) -> bool {
@@ -551,9 +578,11 @@ int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const ch
     return true;
   };
   // Large inputs: R1 is cut into ranges at record starts, a counting pass gives every range its first record's number, R2 is cut at
-  // the SAME record numbers (its ranges' own counts say in which range a number lies; the worker walks to it), and a pool of threads
-  // slices the ranges; their outputs go to the two block writers in order -- the bytes of the serial walk.
-  const int T = itsx_io::io_threads();
+  // the SAME record numbers (its ranges' own counts say in which range a number lies; the worker walks to it).  A pool of threads
+  // takes the ranges in order: a thread slices its range AND compresses the two pieces (each an independent gzip member / zstd
+  // frame), the calling thread writes the pieces in range order -- the records of the serial walk below, in its order.  (Round 4
+  // sliced T ranges at a time and then fed the two block writers from ONE thread: 8 GB of text copied block by block between the
+  // slicers and the compressors' 64 threads, and 10 M labels indexed by one thread before anything started: 3 s of a 6-s writer.)
   const size_t size1 = (size_t)(in1.end - in1.s), size2 = (size_t)(in2.end - in2.s);
   const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : (size_t)32 << 20;
   if (T > 1 && size1 >= min_par && size2 > 0) {
@@ -574,59 +603,97 @@ int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const ch
     const size_t K1 = c1.size() - 1, K2 = c2.size() - 1;
     std::vector<int64_t> f1(K1 + 1, 0), f2(K2 + 1, 0);
     std::atomic<int> bad{0};
-    std::atomic<size_t> next{0};
-    auto pool = [&](size_t K, auto fn) {
+    {
+      std::atomic<size_t> next{0};
       std::vector<std::thread> th;
-      next = 0;
-      for (int t = 0; t < T; t++) th.emplace_back([&] { for (size_t k = next.fetch_add(1); k < K; k = next.fetch_add(1)) fn(k); });
+      for (int t = 0; t < T; t++)
+        th.emplace_back([&] {
+          for (size_t k = next.fetch_add(1); k < K1 + K2; k = next.fetch_add(1)) {
+            const bool first = k < K1; const size_t q = first ? k : k - K1;
+            Records r; r.s = (first ? c1 : c2)[q]; r.end = (first ? c1 : c2)[q + 1];
+            Rec rec; int64_t n = 0; int rc;
+            while ((rc = r.next(rec)) == 1) n++;
+            if (rc < 0) bad = 1;
+            (first ? f1 : f2)[q + 1] = n;
+          }
+        });
       for (auto &x : th) x.join();
-    };
-    auto count = [&](const std::vector<const char *> &c, std::vector<int64_t> &f) {
-      return [&](size_t k) { Records r; r.s = c[k]; r.end = c[k + 1]; Rec rec; int64_t n = 0; int rc; while ((rc = r.next(rec)) == 1) n++; if (rc < 0) bad = 1; f[k + 1] = n; };
-    };
-    pool(K1, count(c1, f1));
-    pool(K2, count(c2, f2));
+    }
+    FILE *fo1 = nullptr, *fo2 = nullptr;
     if (!bad) {
+      fo1 = fopen(out1_path, "wb"); fo2 = fo1 ? fopen(out2_path, "wb") : nullptr;
+      if (!fo1 || !fo2) { if (fo1) fclose(fo1); g_trim_error = std::string("cannot write ") + (fo1 ? out2_path : out1_path); return ITSX_E_IO; }
+      setvbuf(fo1, nullptr, _IOFBF, 1 << 20); setvbuf(fo2, nullptr, _IOFBF, 1 << 20);
       for (size_t k = 0; k < K1; k++) f1[k + 1] += f1[k];
       for (size_t k = 0; k < K2; k++) f2[k + 1] += f2[k];
       const int64_t npairs = std::min(f1[K1], f2[K2]);            // zip(): stops at the shorter file
-      int64_t nw = 0;
-      for (size_t k0 = 0; k0 < K1 && !bad; k0 += (size_t)T) {
-        const size_t k1 = std::min(K1, k0 + (size_t)T);
-        std::vector<std::string> p1(k1 - k0), p2(k1 - k0);
-        std::vector<int64_t> pn(k1 - k0, 0);
-        std::vector<std::thread> th;
-        for (size_t k = k0; k < k1; k++)
-          th.emplace_back([&, k] {
+      struct Piece { std::string z1, z2; int64_t n = 0; bool ready = false; };
+      std::vector<Piece> pieces(K1);
+      std::mutex mu; std::condition_variable cv_ready, cv_room;
+      size_t written = 0;                                          // ranges the calling thread has written
+      const size_t window = (size_t)T * 3;                         // a thread never runs further ahead of the writer than this
+      std::atomic<size_t> next{0};
+      std::atomic<int> io_failed{0};
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; t++)
+        th.emplace_back([&] {
+          itsx_io::PieceCompressor pc(compression);
+          std::string b1, b2;
+          for (size_t k = next.fetch_add(1); k < K1; k = next.fetch_add(1)) {
+            { std::unique_lock<std::mutex> lk(mu); cv_room.wait(lk, [&] { return k < written + window; }); }
+            Piece &pz = pieces[k];
             const int64_t first = f1[k], last = std::min(f1[k + 1], npairs);
-            if (first >= last) return;
-            Records ra; ra.s = c1[k]; ra.end = c1[k + 1];
-            // R2 at record `first`: the range that holds it, then a walk
-            size_t q = (size_t)(std::upper_bound(f2.begin(), f2.end(), first) - f2.begin()) - 1;
-            if (q >= K2) { bad = 1; return; }
-            Records rb; rb.s = c2[q]; rb.end = in2.end;
-            Rec a, b; int rc;
-            for (int64_t skip = first - f2[q]; skip > 0; skip--) if ((rc = rb.next(b)) != 1) { bad = 1; return; }
-            std::string &b1 = p1[k - k0], &b2 = p2[k - k0];
-            b1.reserve((size_t)(c1[k + 1] - c1[k]) / 2 + 4096); b2.reserve(b1.capacity());
-            for (int64_t i = first; i < last; i++) {
-              if (ra.next(a) != 1 || rb.next(b) != 1) { bad = 1; return; }
-              if (one_pair(a, b, b1, b2)) pn[k - k0]++;
+            if (!bad && first < last) {
+              Records ra; ra.s = c1[k]; ra.end = c1[k + 1];
+              // R2 at record `first`: the range that holds it, then a walk
+              const size_t q = (size_t)(std::upper_bound(f2.begin(), f2.end(), first) - f2.begin()) - 1;
+              Records rb; rb.s = c2[std::min(q, K2 - 1)]; rb.end = in2.end;
+              Rec a, b;
+              bool ok = q < K2;
+              for (int64_t skip = ok ? first - f2[q] : 0; ok && skip > 0; skip--) ok = rb.next(b) == 1;
+              b1.clear(); b2.clear();
+              b1.reserve((size_t)(c1[k + 1] - c1[k]) + 4096); b2.reserve(b1.capacity());
+              for (int64_t i = first; ok && i < last; i++) {
+                ok = ra.next(a) == 1 && rb.next(b) == 1;
+                if (ok && one_pair(a, b, b1, b2)) pz.n++;
+              }
+              if (!ok) bad = 1;
+              else if (pz.n > 0 && (!pc.run(b1, pz.z1) || !pc.run(b2, pz.z2))) io_failed = 1;
             }
-          });
-        for (auto &x : th) x.join();
-        for (size_t k = k0; k < k1 && !bad; k++) { o1.w.put(p1[k - k0]); o2.w.put(p2[k - k0]); nw += pn[k - k0]; }
+            { std::lock_guard<std::mutex> lk(mu); pz.ready = true; }
+            cv_ready.notify_all();
+          }
+        });
+      int64_t nw = 0; bool any = false;
+      for (size_t k = 0; k < K1; k++) {
+        Piece &pz = pieces[k];
+        { std::unique_lock<std::mutex> lk(mu); cv_ready.wait(lk, [&] { return pz.ready; }); }
+        if (!bad && !io_failed && pz.n > 0) {
+          if (fwrite(pz.z1.data(), 1, pz.z1.size(), fo1) != pz.z1.size() || fwrite(pz.z2.data(), 1, pz.z2.size(), fo2) != pz.z2.size()) io_failed = 1;
+          nw += pz.n; any = true;
+        }
+        std::string().swap(pz.z1); std::string().swap(pz.z2);
+        { std::lock_guard<std::mutex> lk(mu); written = k + 1; }
+        cv_room.notify_all();
       }
+      for (auto &x : th) x.join();
+      if (!bad && !io_failed && !any && compression != 0) {       // an empty file is still one valid member / frame
+        itsx_io::PieceCompressor pc(compression); std::string z;
+        if (!pc.run(std::string(), z) || fwrite(z.data(), 1, z.size(), fo1) != z.size() || fwrite(z.data(), 1, z.size(), fo2) != z.size()) io_failed = 1;
+      }
+      if (fflush(fo1) != 0 || ferror(fo1) || fflush(fo2) != 0 || ferror(fo2)) io_failed = 1;
+      if (fclose(fo1) != 0) io_failed = 1;
+      if (fclose(fo2) != 0) io_failed = 1;
       if (!bad) {
-        if (!o1.close() || !o2.close()) return ITSX_E_IO;
+        if (io_failed) { g_trim_error = "compressing or writing the output failed"; return ITSX_E_IO; }
         if (n_written) *n_written = nw;
         return ITSX_OK;
       }
     }
     // a malformed record somewhere: the serial walk below names it (the output files are started again)
-    { std::string e; o1.w.close(e); o2.w.close(e); }
-    if (!o1.open(out1_path, compression) || !o2.open(out2_path, compression)) return ITSX_E_IO;
   }
+  Writer o1, o2;
+  if (!o1.open(out1_path, compression) || !o2.open(out2_path, compression)) return ITSX_E_IO;
   Rec a, b; int64_t nw = 0, k = 0; int ra, rb;
   for (;;) {
     ra = in1.next(a); rb = in2.next(b);

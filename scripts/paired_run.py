@@ -97,6 +97,7 @@ def main():
             nu = eng.derep()
             t["derep"] = time.perf_counter() - t0
             t0 = time.perf_counter()
+            eng.set_rows_mode("lazy")              # what SeqSample._search selects in arrays mode (coordinates only, no domtbl.txt)
             eng.search()
             eng.finalize()
         else:
@@ -118,6 +119,9 @@ def main():
         kept = int(((start >= 0) & (stop >= 0) & (start < stop)).sum())
         assert nw == kept, (nw, kept)
         print(json.dumps({"pairs": n, "merged": len(names[1]) - 1, "unique": int(nu), "pairs_written": int(nw), "array_path": bool(args.array_path),
+                          "input_gz_MB": round(sum(os.path.getsize(p) for p in paths) / 1e6, 1),
+                          "output_gz_MB": round((os.path.getsize(o1) + os.path.getsize(o2)) / 1e6, 1),
+                          "gzip_level": int(os.environ.get("ITSX_GZIP_LEVEL", 6)),
                           **{"s_" + k: round(v, 3) for k, v in t.items()}, "s_total": round(total, 3),
                           "pairs_per_s_file_to_file": round(n / total)}))
     finally:

@@ -326,3 +326,40 @@ def test_parallel_paired_writer_writes_the_same_bytes(tmp_path, monkeypatch):
     with pytest.raises(EngineError) as e:
         write_trimmed_paired(str(r1), str(bad), str(tmp_path / "x1"), str(tmp_path / "x2"), mnames, start, stop, tlen)
     assert "malformed FASTQ record" in str(e.value)
+
+
+def test_label_index_built_by_a_pool_keeps_the_first_of_equal_labels(tmp_path, monkeypatch):
+    """70 k merged labels (the index is filled by several threads from 65 536 on), every tenth label a second time with OTHER
+    coordinates: the first entry counts, whatever thread inserted which first; and a sample nothing of which survives is still
+    one valid (empty) gzip member per file"""
+    rng = np.random.default_rng(22)
+    n = 70000
+    r1, r2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    with open(r1, "w") as f1, open(r2, "w") as f2:
+        for i in range(n):
+            f1.write("@r%d 1\n%s\n+\n%s\n" % (i, "ACGTACGTACGTACGTACGTACGTACGTAC", "I" * 30))
+            f2.write("@r%d 2\n%s\n+\n%s\n" % (i, "TTGCATTGCATTGCATTGCATTGCATTGCA", "F" * 30))
+    first = ["r%d" % i for i in range(n)]
+    dup = ["r%d" % i for i in range(0, n, 10)]
+    perm = rng.permutation(len(dup))
+    mnames = first + [dup[i] for i in perm]
+    m = len(mnames)
+    start = np.concatenate([rng.integers(0, 10, n), np.full(len(dup), 29)]).astype(np.int32)
+    stop = np.concatenate([rng.integers(10, 30, n), np.full(len(dup), 30)]).astype(np.int32)
+    tlen = np.full(m, 30, np.int32)
+    out = {}
+    for mode, env in (("serial", {"ITSX_IO_THREADS": "1"}), ("pool", {"ITSX_IO_THREADS": "6", "ITSX_WRITE_MIN_MB": "0", "ITSX_WRITE_UNIT_KB": "256"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        o1, o2 = tmp_path / (mode + "_1.fq.gz"), tmp_path / (mode + "_2.fq.gz")
+        nw = write_trimmed_paired(str(r1), str(r2), str(o1), str(o2), mnames, start, stop, tlen, gzipped=True)
+        out[mode] = (nw, gzip.decompress(o1.read_bytes()), gzip.decompress(o2.read_bytes()))
+        e1, e2 = tmp_path / (mode + "_e1.fq.gz"), tmp_path / (mode + "_e2.fq.gz")
+        assert write_trimmed_paired(str(r1), str(r2), str(e1), str(e2), mnames, np.full(m, -1, np.int32), stop, tlen, gzipped=True) == 0
+        assert gzip.decompress(e1.read_bytes()) == b"" and gzip.decompress(e2.read_bytes()) == b""
+        for k in env:
+            monkeypatch.delenv(k)
+    assert out["serial"] == out["pool"] and out["pool"][0] == n
+    recs = out["pool"][1].split(b"\n")
+    for i in (0, 10, 69990):                                  # a repeated label: its FIRST coordinates
+        assert len(recs[4 * i + 1]) == int(stop[i] - start[i]), i

@@ -3808,13 +3808,14 @@ int itsx_debug_calibrate(itsx_ctx *ctx, int pattern, double gbytes, int iters, i
 // sees them (divide by waves_per_simd for the SIMD's issue interval); ms = the launch.
 int itsx_debug_issue(itsx_ctx *ctx, int op, int waves_per_simd, int iters, double *cycles_per_instr, double *ms)
 {
-  CTXCHK(ctx && op >= 0 && op <= 9 && waves_per_simd >= 1 && waves_per_simd <= 8 && (waves_per_simd <= 4 || waves_per_simd % 2 == 0) && iters >= 1);
+  CTXCHK(ctx && op >= 0 && op <= 11 && waves_per_simd >= 1 && waves_per_simd <= 8 && (waves_per_simd <= 4 || waves_per_simd % 2 == 0) && iters >= 1);
   HIPCHK(hipSetDevice(ctx->device));
   int ncu = 256;
   { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, ctx->device) == hipSuccess) ncu = pr.multiProcessorCount; }
   const int nw = ncu * 4 * waves_per_simd;
   DBuf<unsigned long long> ticks; DBuf<float> sink;
-  HIPCHK(ticks.alloc((size_t)nw)); HIPCHK(sink.alloc(4));
+  HIPCHK(ticks.alloc((size_t)nw)); HIPCHK(sink.alloc(1024));          // (the scalar probes read 1.1 KB of it)
+  HIPCHK(hipMemsetAsync(sink.p, 0, 1024 * sizeof(float), ctx->st));
   launch_issue(op, waves_per_simd, 16, ncu, ticks.p, sink.p, ctx->st);          // warm-up (clocks, code)
   StageTimer tm(ctx->st);
   launch_issue(op, waves_per_simd, iters, ncu, ticks.p, sink.p, ctx->st);

@@ -64,18 +64,24 @@ DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // come from the state the parent chain saved for this profile (FWD_STATE_Q float4: M, I, D of the 46 nodes, xN xJ xC xB, the scale's
 // logarithm), and a chain saves its own state after row d * B where a later chain branches off.  The same operations on the same
 // operands in the same order as the chain's unshared run: the scores are bitwise equal (tests/test_gpu_share.py).
+// A block is FWD_WPB consecutive waves of the work list -- the same profile but at a run's end -- so that the waves a CU holds at one time
+// read one or two profiles' transition tables through its scalar cache, not eight (SQC_DCACHE_MISSES: 5e)
+constexpr int FWD_WPB = 4;
 template <bool SHARE>
-__global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, const float *__restrict__ btab, float *__restrict__ fb, ShareLaunch sl)
+__global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int wave0, int nwaves, const float *__restrict__ btab, float *__restrict__ fb, ShareLaunch sl)
 {
-  const WaveDesc wd = a.waves[wave0 + blockIdx.x];
-  const int lane = threadIdx.x;
+  const int wv = threadIdx.x >> 6, widx = blockIdx.x * FWD_WPB + wv;
+  WaveDesc wd = a.waves[wave0 + min(widx, nwaves - 1)];
+  if (widx >= nwaves) { wd.count = 0; wd.rows = 1; }          // (a block's spare waves: no lane, no row)
+  const int lane = threadIdx.x & 63;
   const int prof = uni(wd.prof);
   const DevProfile *pp = a.prof + prof;
-  // emission odds by node: en[code][k - 1], k = z Q + q + 1 in the striped table
-  __shared__ __attribute__((aligned(16))) float en[NCODE * 2 * BP];
+  // emission odds by node: en[code][k - 1], k = z Q + q + 1 in the striped table (one copy per wave: a run may end inside the block)
+  __shared__ __attribute__((aligned(16))) float en_all[FWD_WPB][NCODE * 2 * BP];
+  float *en = en_all[wv];
   {
     const int Q = uni(pp->Q);
-    for (int i = threadIdx.x; i < NCODE * 2 * BP; i += 64) {
+    for (int i = lane; i < NCODE * 2 * BP; i += 64) {
       const int x = i / (2 * BP), k0 = i % (2 * BP);           // node k0 + 1
       en[i] = (k0 < 4 * Q) ? pp->rf[(x * QMAX + (k0 % Q)) * 4 + k0 / Q] : 0.0f;
     }
@@ -147,35 +153,47 @@ __global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, con
       f2 Scur = pfma(M[0], cur.mm, pfma(I[0], cur.im, D[0] * cur.dm));
       I[0] = pfma(M[0], cur.mi, I[0] * cur.ii);
       float dprev = 0.0f, mdprev = 0.0f;         // D'[2j] and M'[2j] t(M->D) of the node before the pair (none before node 1)
+      f2 Sprev = (f2){0.f, 0.f};                 // S of the pair before (its second node feeds this pair's first; S[0] = 0)
+      f2 dlast = (f2){0.f, 0.f};                 // the pair before's new delete cells, not yet in the row's sum
       cur = ldbt(tb, 1);
+      // One step = the late half of pair j (8 instructions, a chain: sh -> w -> mn -> md -> dn.y) and the early half of pair j + 1 (5,
+      // independent of it).  At two waves per SIMD an instruction that reads the result of the one before it costs a wait state that the
+      // other wave only half fills (profiles/round5_valu_issue.md: an s_nop holds the SIMD 0.9 ns at this occupancy; the compiler's own
+      // order had 4 per step, 11 % of the row).  The order is therefore fixed by hand -- every statement fenced -- so that no instruction
+      // follows its producer directly: the early half's instructions sit between the links of the chain, and the new delete cells go
+      // into the row's sum one step later.
+#define SB __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
       for (int j = 0; j < BP; j++) {
         __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): record j + 1 and pair j's emissions, requested one step ago
+        const bool more = j + 1 < BP;
         BT nxt = cur; f2 enxt = ecur;
-        if (j + 1 < BP) { nxt = ldbt(tb, j + 2); enxt = *(const f2 *)(ex + 2 * (j + 1)); }
-        f2 Sn = Scur;
-        if (j + 1 < BP) {                       // the next pair's early half, before this pair's D chain overwrites D[j + 1].x
-          Sn = pfma(M[j + 1], cur.mm, pfma(I[j + 1], cur.im, D[j + 1] * cur.dm));
-          I[j + 1] = pfma(M[j + 1], cur.mi, I[j + 1] * cur.ii);
-        }
-        const f2 sh = (f2){sprev, Scur.x};
-        sprev = Scur.y;
-        const f2 mn = pfma(xBv, cur.bm, sh) * ecur;
-        M[j] = mn;
-        const f2 md = mn * cur.md;
-        // both new delete cells of the pair are born here (its old ones went into Scur one step ago): dd1 = D_2j -> D_2j+1 (0 for
-        // j = 0), dd2 = D_2j+1 -> D_2j+2
+        if (more) { nxt = ldbt(tb, j + 2); enxt = *(const f2 *)(ex + 2 * (j + 1)); }
+        SB;
+        const f2 sh = (f2){Sprev.y, Scur.x}; SB;
+        f2 t = (f2){0.f, 0.f}, u = t, Sn = Scur;
+        if (more) { t = D[j + 1] * cur.dm; SB; }
+        // both new delete cells of the pair are born in this step (its old ones went into Scur one step ago): dd1 = D_2j -> D_2j+1 (0
+        // for j = 0), dd2 = D_2j+1 -> D_2j+2
         // (as inline assembly: left to itself the compiler accumulates into the dying product's register -- v_fmac -- and then
         // moves the result into the pair, twice per pair of nodes and row)
         f2 dn;
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.x) : "v"(dprev), "s"(cur.dd1), "v"(mdprev));
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.y) : "v"(dn.x), "s"(cur.dd2), "v"(md.x));
-        dprev = dn.y; mdprev = md.y;
-        D[j] = dn;
-        acc = acc + mn; acc = acc + dn;
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt; ecur = enxt; Scur = Sn;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.x) : "v"(dprev), "s"(cur.dd1), "v"(mdprev)); SB;
+        const f2 w = pfma(xBv, cur.bm, sh); SB;
+        if (more) { t = pfma(I[j + 1], cur.im, t); SB; u = I[j + 1] * cur.ii; SB; }
+        const f2 mn = w * ecur; SB;
+        if (more) { Sn = pfma(M[j + 1], cur.mm, t); SB; }
+        const f2 md = mn * cur.md; SB;
+        acc = acc + mn; SB;
+        if (more) { I[j + 1] = pfma(M[j + 1], cur.mi, u); SB; }
+        acc = acc + dlast; SB;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.y) : "v"(dn.x), "s"(cur.dd2), "v"(md.x)); SB;
+        M[j] = mn; D[j] = dn;
+        dprev = dn.y; mdprev = md.y; dlast = dn;
+        Sprev = Scur; Scur = Sn; cur = nxt; ecur = enxt;
       }
+#undef SB
+      acc = acc + dlast;
       xE = acc.x + acc.y;
       xN = xN * ploop;
       xC = __builtin_fmaf(xC, ploop, xE * 0.5f);
@@ -198,11 +216,11 @@ __global__ void __launch_bounds__(64, 2) k_fwd_bound(FloatArgs a, int wave0, con
 
 void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, hipStream_t st)
 {
-  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<false>, dim3(nwaves), dim3(64), 0, st, a, wave0, btab, fb, ShareLaunch{});
+  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<false>, dim3((nwaves + FWD_WPB - 1) / FWD_WPB), dim3(64 * FWD_WPB), 0, st, a, wave0, nwaves, btab, fb, ShareLaunch{});
 }
 void launch_fwd_bound_share(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st)
 {
-  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<true>, dim3(nwaves), dim3(64), 0, st, a, wave0, btab, fb, sl);
+  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<true>, dim3((nwaves + FWD_WPB - 1) / FWD_WPB), dim3(64 * FWD_WPB), 0, st, a, wave0, nwaves, btab, fb, sl);
 }
 
 // largest %.1f tenths (biased) a domain of each pair can print, and the best-bound pair of every (representative, class)

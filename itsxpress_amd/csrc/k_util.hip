@@ -135,6 +135,22 @@ __device__ __forceinline__ void issue16(float (&x)[32], float a, float b)
     else if (OP == 9) asm volatile("v_max_i16 %0, %0, %1" : "+v"(x[i]) : "v"(a));
   }
 }
+// ---- scalar-cache probe: what k_fwd_bound asks of it per pair of nodes -- 64 B of wave-uniform transitions through two
+// s_load_dwordx8, waited for one step later -- alone (OP 10) and under the kernel's own ~12 packed instructions per step (OP 11)
+template <int OP>
+__device__ __forceinline__ void sload16(float (&x)[32], const float *tab)
+{
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx8 s[36:43], %0, %1\n\ts_load_dwordx8 s[44:51], %0, %2"
+                 :: "s"(tab), "n"(i * 64), "n"(i * 64 + 32)
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "memory");
+    if (OP == 11) {
+#pragma unroll
+      for (int k = 0; k < 12; k++) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(float2 *)&x[2 * ((i + k) & 15)]) : "v"(*(float2 *)&x[0]));
+    }
+  }
+}
 template <int OP>
 __global__ void __launch_bounds__(1024) k_issue(int iters, unsigned long long *__restrict__ ticks, float *__restrict__ sink)
 {
@@ -144,8 +160,9 @@ __global__ void __launch_bounds__(1024) k_issue(int iters, unsigned long long *_
   const float a = 0.999999f, b = 1e-7f;
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < iters; it++) { issue16<OP>(x, a, b); issue16<OP>(x, a, b); issue16<OP>(x, a, b); issue16<OP>(x, a, b); }
-  asm volatile("s_nop 0" ::: "memory");
+  if constexpr (OP >= 10) { for (int it = 0; it < iters; it++) { sload16<OP>(x, sink); sload16<OP>(x, sink); sload16<OP>(x, sink); sload16<OP>(x, sink); } }
+  else for (int it = 0; it < iters; it++) { issue16<OP>(x, a, b); issue16<OP>(x, a, b); issue16<OP>(x, a, b); issue16<OP>(x, a, b); }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 0" ::: "memory");
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   float s = 0.f;
 #pragma unroll
@@ -170,7 +187,9 @@ void launch_issue(int op, int waves_per_simd, int iters, int blocks, unsigned lo
     case 6: hipLaunchKernelGGL(k_issue<6>, g, b, lds, st, iters, ticks, sink); break;
     case 7: hipLaunchKernelGGL(k_issue<7>, g, b, lds, st, iters, ticks, sink); break;
     case 8: hipLaunchKernelGGL(k_issue<8>, g, b, lds, st, iters, ticks, sink); break;
-    default: hipLaunchKernelGGL(k_issue<9>, g, b, lds, st, iters, ticks, sink); break;
+    case 9: hipLaunchKernelGGL(k_issue<9>, g, b, lds, st, iters, ticks, sink); break;
+    case 10: hipLaunchKernelGGL(k_issue<10>, g, b, lds, st, iters, ticks, sink); break;
+    default: hipLaunchKernelGGL(k_issue<11>, g, b, lds, st, iters, ticks, sink); break;
   }
 }
 

@@ -55,7 +55,7 @@ VALU_PER_ROW = {"k_filters_fwd": 533.0, "k_bwd_decode": 561.0, "k_fwd_bound": 32
 # holds a SIMD 1.74 ns, a plain VALU instruction 1.00 ns, an s_nop 0.4 ns at full occupancy -- rounds 1-4 priced every instruction at
 # 4 cycles of a 2.4 GHz clock (1.67 ns), which read 1.02 for k_msv.  valu_issue_frac = sum(count x ns) x wave-rows / (1024 SIMDs x time).
 ISSUE_MIX = {"k_msv": {"packed": 69, "plain": 19, "s_nop": 3},
-             "k_fwd_bound": {"packed": 254, "plain": 77, "s_nop": 7},
+             "k_fwd_bound": {"packed": 185, "plain": 77, "s_nop": 6},
              "k_filters_fwd": {"packed": 484, "plain": 49, "s_nop": 21},
              "k_bwd_decode": {"packed": 537, "plain": 24, "s_nop": 40}}
 ISSUE_NS = {"packed": 1.74, "plain": 1.00, "s_nop": 0.40}
@@ -698,7 +698,7 @@ def main():
                     "traffic_vs_survey_bytes": (traffic * nl / survey_bytes) if traffic is not None else None,
                     "note": ("the lazy stage's score-only Forward over the rows its chains COMPUTE (prefix sharing: config.rows_shared_frac of the pairs' rows come "
                              "from saved states): the recurrence's own flops per lane-row in node order (16 per model node: 720 for the 45-node ITSx models) "
-                             "against the fp32 FMA peak 157.3 TFLOP/s -- 139 of its 331 instructions per row can be fused, and a packed instruction issues at the "
+                             "against the fp32 FMA peak 157.3 TFLOP/s (ALGORITHMIC flops: the kernel itself executes 8.5 of the 11 operations per node -- the deletes' scale and their share of E are folded into the profile's table, DESIGN.md 5e) -- 139 of its 262 instructions per row are fused, and a packed instruction issues at the "
                              "rate of two plain ones (profiles/round5_valu_issue.md), so valu_issue_frac -- the kernel's instruction mix priced with the measured "
                              "issue times, over the SIMDs' time -- is the figure that says how much is left; duration = HIP events on the engine's stream.  " if dom in USES_FMA else "") +
                             "a serial recurrence per (representative, profile): the recurrence's own no-FMA fp32 flops per lane-row (HMMER rounds "

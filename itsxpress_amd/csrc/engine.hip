@@ -271,7 +271,7 @@ struct itsx_ctx {
   DBuf<DevProfile> d_prof;
   DBuf<uint32_t> d_etab;
   DBuf<int32_t> d_pbias, d_ptec, d_ptbm;
-  DBuf<float> d_flogsum; DBuf<LogTab> d_logtab; DBuf<float> d_btab;
+  DBuf<float> d_flogsum; DBuf<LogTab> d_logtab; DBuf<float> d_btab; bool bound_fold = false;   // (the bound kernel's table, and whether it is the folded one)
   std::vector<char> generic_q;          // per profile: needs the runtime-Q kernels
 
   // ---- reads
@@ -556,28 +556,68 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
     HIPCHK(upload(ctx->d_vtab, vt, ctx->st));
   }
   {   // the bound kernel's transitions by pair of nodes (k_lazy.hip: k_fwd_bound): record j = pair j's early half, pair j - 1's late half
-    std::vector<float> bt((size_t)std::max(P, 1) * (BOUND_PAIRS + 1) * 16, 0.0f);
+    // FOLD (k_lazy.hip): with H_k = 1 + t(D_k -> D_k+1) H_k+1 (what one unit of D_k adds to the row's E through itself and the deletes
+    // after it), g_k = 1 + t(M_k -> D_k+1) H_k+1, s_1 = 1, s_k+1 = t(M_k -> D_k+1) / g_k, a_k = s_k t(D_k -> D_k+1) / s_k+1 the kernel
+    // keeps M~_k = M_k g_k and D^_k = D_k / s_k:  D^_k+1 = D^_k a_k + M~_k,  E = sum of M~_k;  M -> M / I transitions divided by g_k, the D -> M
+    // ones multiplied by s_k, the emission odds multiplied by g_k (in the kernel, from the table's last 48 floats); the insert cells likewise
+    // divided by r_k = t(M_k -> I_k) / g_k (I^_k' = I^_k t(I_k -> I_k) + M~_k; the I -> M transitions multiplied by r_k).  Needs
+    // t(M_k -> D_k+1) > 0 wherever the delete path goes on (every node hmmbuild writes; after the last node both are 0 and a_k = 0 ends the
+    // chain); one profile without that and the whole set runs the plain recurrences (ITSX_BOUND_FOLD=0 does too).
+    const int KK = 2 * BOUND_PAIRS;
+    std::vector<std::vector<double>> G((size_t)P), SC((size_t)P), AA((size_t)P), RI((size_t)P);
+    bool fold = !(getenv("ITSX_BOUND_FOLD") && atoi(getenv("ITSX_BOUND_FOLD")) == 0);
+    for (int i = 0; i < P && fold; i++) {
+      const DevProfile &d = dp[i];
+      const int K = 4 * ctx->profs[i].Q;
+      auto tn = [&](int k, int t) { return (k >= 1 && k <= K) ? (double)d.tfn[k * 8 + t] : 0.0; };
+      std::vector<double> H((size_t)KK + 3, 1.0), &g = G[(size_t)i], &sc = SC[(size_t)i], &aa = AA[(size_t)i], &ri = RI[(size_t)i];
+      g.assign((size_t)KK + 2, 1.0); sc.assign((size_t)KK + 3, 1.0); aa.assign((size_t)KK + 2, 0.0); ri.assign((size_t)KK + 2, 1.0);
+      for (int k = KK; k >= 1; k--) H[(size_t)k] = 1.0 + tn(k, 7) * H[(size_t)k + 1];
+      for (int k = 1; k <= KK; k++) g[(size_t)k] = 1.0 + tn(k, 4) * H[(size_t)k + 1];
+      for (int k = 1; k <= KK; k++) {
+        const double md = tn(k, 4), dd = tn(k, 7);
+        if (md > 0.0) { sc[(size_t)k + 1] = md / g[(size_t)k]; aa[(size_t)k] = sc[(size_t)k] * dd / sc[(size_t)k + 1]; }
+        else if (dd > 0.0 && k > 1) fold = false;          // a delete path that goes on past a node no match cell feeds: not foldable
+        else { sc[(size_t)k + 1] = 1.0; aa[(size_t)k] = 0.0; }
+        // (the scales stay far inside float: s_k+1 in [t_MD / 2, t_MD], a_k a ratio of neighbouring t_MD's times t_DD)
+        if (!(sc[(size_t)k + 1] > 1e-30 && sc[(size_t)k + 1] < 1e30 && aa[(size_t)k] < 1e30)) fold = false;
+        // the insert cells by r_k = t(M_k -> I_k) / g_k: I^_k' = I^_k t(I_k -> I_k) + M~_k.  A node without M -> I must not use its insert cell at all
+        const double mi = tn(k, 5);
+        if (mi > 0.0) ri[(size_t)k] = mi / g[(size_t)k];
+        else if (tn(k, 6) > 0.0 || tn(k + 1, 2) > 0.0) fold = false;
+        else ri[(size_t)k] = 1.0;
+        if (!(ri[(size_t)k] > 1e-30)) fold = false;
+      }
+    }
+    ctx->bound_fold = fold;
+    std::vector<float> bt((size_t)std::max(P, 1) * BOUND_TAB, 0.0f);
     for (int i = 0; i < P; i++) {
       const DevProfile &d = dp[i];
       const int K = 4 * ctx->profs[i].Q;                                      // slots of the striped layout (transitions beyond them: 0)
       auto tn = [&](int k, int t) { return (k >= 1 && k <= K) ? d.tfn[k * 8 + t] : 0.0f; };
+      auto gk = [&](int k) { return fold && k >= 1 && k <= KK ? G[(size_t)i][(size_t)k] : 1.0; };
+      auto sk = [&](int k) { return fold && k >= 1 && k <= KK + 1 ? SC[(size_t)i][(size_t)k] : 1.0; };
+      auto rk = [&](int k) { return fold && k >= 1 && k <= KK ? RI[(size_t)i][(size_t)k] : 1.0; };
       for (int j = 0; j <= BOUND_PAIRS; j++) {
-        float *o = bt.data() + ((size_t)i * (BOUND_PAIRS + 1) + j) * 16;
+        float *o = bt.data() + (size_t)i * BOUND_TAB + (size_t)j * 16;
         if (j < BOUND_PAIRS) {
           const int k1 = 2 * j + 1, k2 = 2 * j + 2;
-          o[0] = tn(k1 + 1, 1); o[1] = tn(k2 + 1, 1);      // M_k -> M_k+1 (tf stores it at the target node)
-          o[2] = tn(k1 + 1, 2); o[3] = tn(k2 + 1, 2);      // I_k -> M_k+1
-          o[4] = tn(k1 + 1, 3); o[5] = tn(k2 + 1, 3);      // D_k -> M_k+1
-          o[6] = tn(k1, 5); o[7] = tn(k2, 5);              // M_k -> I_k
-          o[8] = tn(k1, 6); o[9] = tn(k2, 6);              // I_k -> I_k
+          o[0] = (float)(tn(k1 + 1, 1) / gk(k1)); o[1] = (float)(tn(k2 + 1, 1) / gk(k2));      // M_k -> M_k+1 (tf stores it at the target node)
+          o[2] = (float)(tn(k1 + 1, 2) * rk(k1)); o[3] = (float)(tn(k2 + 1, 2) * rk(k2));      // I_k -> M_k+1
+          o[4] = (float)(tn(k1 + 1, 3) * sk(k1)); o[5] = (float)(tn(k2 + 1, 3) * sk(k2));      // D_k -> M_k+1
+          o[6] = tn(k1, 6); o[7] = tn(k2, 6);                                                    // I_k -> I_k
+          o[12] = (float)(tn(k1, 5) / gk(k1)); o[13] = (float)(tn(k2, 5) / gk(k2));            // M_k -> I_k (FOLD: not read)
         }
         if (j > 0) {
           const int k1 = 2 * (j - 1) + 1, k2 = 2 * (j - 1) + 2;
-          o[10] = tn(k1, 0); o[11] = tn(k2, 0);            // B -> M_k
-          o[12] = tn(k1, 4); o[13] = tn(k2, 4);            // M_k -> D_k+1
-          o[14] = tn(k1 - 1, 7); o[15] = tn(k1, 7);        // D_k1-1 -> D_k1 (0 before node 1), D_k1 -> D_k2
+          o[8] = tn(k1, 0); o[9] = tn(k2, 0);              // B -> M_k
+          if (fold) { o[10] = k1 > 1 ? (float)AA[(size_t)i][(size_t)k1 - 1] : 0.0f; o[11] = (float)AA[(size_t)i][(size_t)k1]; }
+          else { o[10] = tn(k1 - 1, 7); o[11] = tn(k1, 7); }   // D_k1-1 -> D_k1 (0 before node 1), D_k1 -> D_k2
+          o[14] = tn(k1, 4); o[15] = tn(k2, 4);            // M_k -> D_k+1 (FOLD: not read)
         }
       }
+      float *gq = bt.data() + (size_t)i * BOUND_TAB + (size_t)(BOUND_PAIRS + 1) * 16;
+      for (int k0 = 0; k0 < KK; k0++) gq[k0] = (float)gk(k0 + 1);
     }
     HIPCHK(upload(ctx->d_btab, bt, ctx->st));
   }
@@ -2435,7 +2475,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
           ShareLaunch sl{};
           sl.src = ctx->sh_src.p + u0; sl.mask = ctx->sh_mask.p + u0; sl.node0 = ctx->sh_node0.p + u0;
           sl.slots = fsl; sl.node_base = b.node0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
-          for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bound_launches++; }
+          for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->bound_fold, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bound_launches++; }
         }
       }
     }
@@ -2468,7 +2508,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     if (getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0) {
       // test hook: every pair again from row 1 (the same wave list serves: a wave needs its profile, its pairs and its longest target)
       HIPCHK(ctx->sh_fb_chk.alloc((size_t)NP + 1));
-      for (int w0 = 0; w0 < NW; w0 += 1 << 20) launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->sh_fb_chk.p, std::min(1 << 20, NW - w0), w0, st);
+      for (int w0 = 0; w0 < NW; w0 += 1 << 20) launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->bound_fold, ctx->sh_fb_chk.p, std::min(1 << 20, NW - w0), w0, st);
       HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 8, 0, sizeof(unsigned long long), st));
       launch_diff_scores(ctx->l_fb.p, ctx->sh_fb_chk.p, pl.pairs, NP, ctx->sh_counters.p + 8, st);
       unsigned long long nd = 0;
@@ -2504,7 +2544,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     // launches of at most 2^20 waves: the timers of bench.py's roofline block want more than one sample
     static const bool exact_bound = getenv("ITSX_LAZY_EXACT_BOUND") && atoi(getenv("ITSX_LAZY_EXACT_BOUND")) != 0;     // A/B: HMMER's own Forward as the bound pass
     if (!exact_bound) {
-      for (int w0 = 0; w0 < NW; w0 += 1 << 20) { launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->l_fb.p, std::min(1 << 20, NW - w0), w0, st); S.n_bound_launches++; }
+      for (int w0 = 0; w0 < NW; w0 += 1 << 20) { launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->bound_fold, ctx->l_fb.p, std::min(1 << 20, NW - w0), w0, st); S.n_bound_launches++; }
     } else {
       for (int w0 = 0; w0 < nfast; w0 += 1 << 20) { launch_fwd_bound(a, ctx->l_fb.p, std::min(1 << 20, nfast - w0), w0, 0, st); S.n_bound_launches++; }
       if (NW > nfast) { launch_fwd_bound(a, ctx->l_fb.p, NW - nfast, nfast, 1, st); S.n_bound_launches++; }

@@ -298,9 +298,9 @@ void launch_filters_fwd(const FloatArgs &a, int nwaves, int wave0, int generic_q
 void launch_fwd_bound(const FloatArgs &a, float *fb, int nwaves, int wave0, int generic_q, hipStream_t st);
 // the same score by the node-sequential fused-multiply-add kernel (k_lazy.hip: k_fwd_bound); btab = [P][BOUND_PAIRS][16] floats per
 // pair of nodes (2j + 1, 2j + 2): {MM IM DM out of the node (into the next one's match cell)} {MI II BM MD of the node} as pairs, DD x 2
-void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, hipStream_t st);
+void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, hipStream_t st);
 // ... over waves of chains that start at sl.depth (k_share.hip): the rows before come from the parent chain's saved state
-void launch_fwd_bound_share(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st);
+void launch_fwd_bound_share(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st);
 

@@ -54,8 +54,9 @@ DEV BT ldbt(const float *tab, int j)
   const f4 a = *(cf4q)(uintptr_t)(tab + j * 16), b = *(cf4q)(uintptr_t)(tab + j * 16 + 4), c = *(cf4q)(uintptr_t)(tab + j * 16 + 8),
            d = *(cf4q)(uintptr_t)(tab + j * 16 + 12);
   BT t;
-  t.mm = (f2){a.x, a.y}; t.im = (f2){a.z, a.w}; t.dm = (f2){b.x, b.y}; t.mi = (f2){b.z, b.w};
-  t.ii = (f2){c.x, c.y}; t.bm = (f2){c.z, c.w}; t.md = (f2){d.x, d.y}; t.dd1 = d.z; t.dd2 = d.w;
+  // (what the folded recurrences read comes first: 12 floats, one dwordx8 + one dwordx4; mi and md are the plain kernel's alone)
+  t.mm = (f2){a.x, a.y}; t.im = (f2){a.z, a.w}; t.dm = (f2){b.x, b.y}; t.ii = (f2){b.z, b.w};
+  t.bm = (f2){c.x, c.y}; t.dd1 = c.z; t.dd2 = c.w; t.mi = (f2){d.x, d.y}; t.md = (f2){d.z, d.w};
   return t;
 }
 DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -67,7 +68,14 @@ DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // A block is FWD_WPB consecutive waves of the work list -- the same profile but at a run's end -- so that the waves a CU holds at one time
 // read one or two profiles' transition tables through its scalar cache, not eight (SQC_DCACHE_MISSES: 5e)
 constexpr int FWD_WPB = 4;
-template <bool SHARE>
+// FOLD (engine.hip: install_profiles builds the table for it; every profile whose interior M->D transitions are all > 0, i.e. every
+// profile hmmbuild writes): the delete cells are kept DIVIDED by s_k = t(M_k-1 -> D_k) / g_k-1 and the match cells MULTIPLIED by
+// g_k = 1 + the share of M_k that the deletes after it carry into E -- constants of the profile, folded into its transitions and
+// emission odds on the host.  The same sum over paths term by term, with two operations per node fewer: a new delete cell is ONE
+// multiply-add (D^_k+1 = D^_k a_k + M~_k: no product M_k t(M_k -> D_k+1) first), and the row's E is the sum of the match cells alone
+// (no second accumulation of the deletes).  The insert cells are kept divided by r_k = t(M_k -> I_k) / g_k in the same way: I^_k' = I^_k t(I_k -> I_k)
+// + M~_k, one multiply-add instead of a product and a multiply-add.  8 packed + 2 plain instructions per pair of nodes instead of 11 + 2.
+template <bool SHARE, bool FOLD>
 __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int wave0, int nwaves, const float *__restrict__ btab, float *__restrict__ fb, ShareLaunch sl)
 {
   const int wv = threadIdx.x >> 6, widx = blockIdx.x * FWD_WPB + wv;
@@ -79,15 +87,17 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
   // emission odds by node: en[code][k - 1], k = z Q + q + 1 in the striped table (one copy per wave: a run may end inside the block)
   __shared__ __attribute__((aligned(16))) float en_all[FWD_WPB][NCODE * 2 * BP];
   float *en = en_all[wv];
+  const float *tab = btab + (size_t)prof * BOUND_TAB;
   {
     const int Q = uni(pp->Q);
+    const float *g = tab + (BP + 1) * 16;                      // FOLD: the match cells' scale by node
     for (int i = lane; i < NCODE * 2 * BP; i += 64) {
       const int x = i / (2 * BP), k0 = i % (2 * BP);           // node k0 + 1
-      en[i] = (k0 < 4 * Q) ? pp->rf[(x * QMAX + (k0 % Q)) * 4 + k0 / Q] : 0.0f;
+      const float e = (k0 < 4 * Q) ? pp->rf[(x * QMAX + (k0 % Q)) * 4 + k0 / Q] : 0.0f;
+      en[i] = FOLD ? e * g[k0] : e;
     }
     __syncthreads();
   }
-  const float *tab = btab + (size_t)prof * ((BP + 1) * 16);
   const bool active = lane < wd.count;
   const int64_t pi = wd.first + (active ? lane : 0);
   const PairRec pr = a.pairs[pi];
@@ -151,8 +161,8 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
       f2 ecur = *(const f2 *)(ex);
       __builtin_amdgcn_s_waitcnt(0xC07F);
       f2 Scur = pfma(M[0], cur.mm, pfma(I[0], cur.im, D[0] * cur.dm));
-      I[0] = pfma(M[0], cur.mi, I[0] * cur.ii);
-      float dprev = 0.0f, mdprev = 0.0f;         // D'[2j] and M'[2j] t(M->D) of the node before the pair (none before node 1)
+      if constexpr (FOLD) I[0] = pfma(I[0], cur.ii, M[0]); else I[0] = pfma(M[0], cur.mi, I[0] * cur.ii);
+      float dprev = 0.0f, mdprev = 0.0f;         // D'[2j] and M'[2j] t(M->D) (FOLD: M'[2j] itself) of the node before the pair (none before node 1)
       f2 Sprev = (f2){0.f, 0.f};                 // S of the pair before (its second node feeds this pair's first; S[0] = 0)
       f2 dlast = (f2){0.f, 0.f};                 // the pair before's new delete cells, not yet in the row's sum
       cur = ldbt(tb, 1);
@@ -180,20 +190,28 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
         f2 dn;
         asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.x) : "v"(dprev), "s"(cur.dd1), "v"(mdprev)); SB;
         const f2 w = pfma(xBv, cur.bm, sh); SB;
-        if (more) { t = pfma(I[j + 1], cur.im, t); SB; u = I[j + 1] * cur.ii; SB; }
+        if (more) { t = pfma(I[j + 1], cur.im, t); SB; if constexpr (!FOLD) { u = I[j + 1] * cur.ii; SB; } }
         const f2 mn = w * ecur; SB;
         if (more) { Sn = pfma(M[j + 1], cur.mm, t); SB; }
-        const f2 md = mn * cur.md; SB;
-        acc = acc + mn; SB;
-        if (more) { I[j + 1] = pfma(M[j + 1], cur.mi, u); SB; }
-        acc = acc + dlast; SB;
-        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.y) : "v"(dn.x), "s"(cur.dd2), "v"(md.x)); SB;
+        if constexpr (FOLD) {
+          acc = acc + mn; SB;
+          if (more) { I[j + 1] = pfma(I[j + 1], cur.ii, M[j + 1]); SB; }      // (the insert cells divided by t(M_k -> I_k) / g_k)
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.y) : "v"(dn.x), "s"(cur.dd2), "v"(mn.x)); SB;
+          mdprev = mn.y;
+        } else {
+          const f2 md = mn * cur.md; SB;
+          acc = acc + mn; SB;
+          if (more) { I[j + 1] = pfma(M[j + 1], cur.mi, u); SB; }
+          acc = acc + dlast; SB;
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(dn.y) : "v"(dn.x), "s"(cur.dd2), "v"(md.x)); SB;
+          mdprev = md.y; dlast = dn;
+        }
         M[j] = mn; D[j] = dn;
-        dprev = dn.y; mdprev = md.y; dlast = dn;
+        dprev = dn.y;
         Sprev = Scur; Scur = Sn; cur = nxt; ecur = enxt;
       }
 #undef SB
-      acc = acc + dlast;
+      if constexpr (!FOLD) acc = acc + dlast;
       xE = acc.x + acc.y;
       xN = xN * ploop;
       xC = __builtin_fmaf(xC, ploop, xE * 0.5f);
@@ -214,13 +232,19 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
   if (active) fb[pi] = bad ? __builtin_nanf("") : (float)(totscale + det_log((double)(xC * pmove)));
 }
 
-void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, hipStream_t st)
+void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, hipStream_t st)
 {
-  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<false>, dim3((nwaves + FWD_WPB - 1) / FWD_WPB), dim3(64 * FWD_WPB), 0, st, a, wave0, nwaves, btab, fb, ShareLaunch{});
+  if (nwaves <= 0) return;
+  const dim3 g((nwaves + FWD_WPB - 1) / FWD_WPB), b(64 * FWD_WPB);
+  if (fold) hipLaunchKernelGGL((k_fwd_bound<false, true>), g, b, 0, st, a, wave0, nwaves, btab, fb, ShareLaunch{});
+  else hipLaunchKernelGGL((k_fwd_bound<false, false>), g, b, 0, st, a, wave0, nwaves, btab, fb, ShareLaunch{});
 }
-void launch_fwd_bound_share(const FloatArgs &a, const float *btab, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st)
+void launch_fwd_bound_share(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st)
 {
-  if (nwaves > 0) hipLaunchKernelGGL(k_fwd_bound<true>, dim3((nwaves + FWD_WPB - 1) / FWD_WPB), dim3(64 * FWD_WPB), 0, st, a, wave0, nwaves, btab, fb, sl);
+  if (nwaves <= 0) return;
+  const dim3 g((nwaves + FWD_WPB - 1) / FWD_WPB), b(64 * FWD_WPB);
+  if (fold) hipLaunchKernelGGL((k_fwd_bound<true, true>), g, b, 0, st, a, wave0, nwaves, btab, fb, sl);
+  else hipLaunchKernelGGL((k_fwd_bound<true, false>), g, b, 0, st, a, wave0, nwaves, btab, fb, sl);
 }
 
 // largest %.1f tenths (biased) a domain of each pair can print, and the best-bound pair of every (representative, class)

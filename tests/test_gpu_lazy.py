@@ -264,3 +264,51 @@ def test_lazy_equals_the_full_table_on_ccs_length_reads(engine, t_hmm_text, monk
     # the same bound on the 2-20 kb targets alone (what the 0.02-bit margin has to cover)
     _, st = _coords(engine, hmm, seqs[:-2], "lazy")
     assert 0.0 <= st["lazy_bound_maxdiff"] < 0.5 * margin_nats(20000), st["lazy_bound_maxdiff"]
+
+
+def _without_match_to_delete(hmm_text, node):
+    """the profiles of `hmm_text` with t(M_node -> D_node+1) = 0 ('*') -- the delete path past that node lives on D -> D alone"""
+    out, k = [], None
+    for ln in hmm_text.split("\n"):
+        f = ln.split()
+        if ln.startswith("HMM "):
+            k = 0
+        elif k is not None and len(f) >= 5 and f[0].isdigit():
+            k = int(f[0])
+        elif k == node and len(f) == 7 and f[6] != "*" and not ln.lstrip().startswith("1.38629  1.38629"):
+            f[2] = "*"
+            ln = "          " + "  ".join("%7s" % x for x in f)
+            k = None
+        if ln.startswith("//"):
+            k = None
+        out.append(ln)
+    return "\n".join(out)
+
+
+def test_bound_kernel_folded_and_plain_recurrences(engine, t_hmm_text, monkeypatch):
+    """pass A keeps its delete cells divided by t(M -> D) / g and its match cells multiplied by g (constants folded into the table on
+    the host: two operations per node fewer).  The folded kernel, the plain one (ITSX_BOUND_FOLD=0) and the plain one forced by a profile
+    the fold cannot take (an interior M -> D of zero) all stay within 1e-3 nats of p7_ForwardParser's arithmetic, and the coordinates
+    are the full table's every time"""
+    blob, offs = synth.make_reads(t_hmm_text, 2500, config=3, seed=synth.SEED + 12, fixed_len=0, len_range=(150, 700), n_rate=0.003)
+    seqs = synth.to_strings(blob, offs)
+    hmm = _its2_subset(t_hmm_text, 20, 20)
+    odd = _without_match_to_delete(hmm, 17)
+    assert odd != hmm and odd.count("*") > hmm.count("*")
+    monkeypatch.setenv("ITSX_LAZY_CHECK_BOUND", "1")
+    for text in (hmm, odd):
+        monkeypatch.delenv("ITSX_BOUND_FOLD", raising=False)
+        ref, _ = _coords(engine, text, seqs, "full")
+        outs = []
+        for fold in (None, "0"):
+            if fold is not None:
+                monkeypatch.setenv("ITSX_BOUND_FOLD", fold)
+            got, st = _coords(engine, text, seqs, "lazy")
+            assert st["lazy"] == 1 and st["n_lazy_reruns"] == 0 and st["n_past_msv"] > 5000
+            assert 0.0 <= st["lazy_bound_maxdiff"] < 1e-3, (fold, st["lazy_bound_maxdiff"])
+            assert _same(ref, got)
+            outs.append(st["lazy_bound_maxdiff"])
+        if text is hmm:
+            assert outs[0] != outs[1]                     # (two different kernels ran)
+        else:
+            assert outs[0] == outs[1]                     # (the plain one both times: the fold refused the profile set)

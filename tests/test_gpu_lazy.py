@@ -266,8 +266,8 @@ def test_lazy_equals_the_full_table_on_ccs_length_reads(engine, t_hmm_text, monk
     assert 0.0 <= st["lazy_bound_maxdiff"] < 0.5 * margin_nats(20000), st["lazy_bound_maxdiff"]
 
 
-def _without_match_to_delete(hmm_text, node):
-    """the profiles of `hmm_text` with t(M_node -> D_node+1) = 0 ('*') -- the delete path past that node lives on D -> D alone"""
+def _without_match_to_delete(hmm_text, node, value="*"):
+    """the profiles of `hmm_text` with t(M_node -> D_node+1) = 0 ('*'; or exp(-value)) -- the delete path past that node lives on D -> D alone"""
     out, k = [], None
     for ln in hmm_text.split("\n"):
         f = ln.split()
@@ -276,7 +276,7 @@ def _without_match_to_delete(hmm_text, node):
         elif k is not None and len(f) >= 5 and f[0].isdigit():
             k = int(f[0])
         elif k == node and len(f) == 7 and f[6] != "*" and not ln.lstrip().startswith("1.38629  1.38629"):
-            f[2] = "*"
+            f[2] = value
             ln = "          " + "  ".join("%7s" % x for x in f)
             k = None
         if ln.startswith("//"):
@@ -288,15 +288,16 @@ def _without_match_to_delete(hmm_text, node):
 def test_bound_kernel_folded_and_plain_recurrences(engine, t_hmm_text, monkeypatch):
     """pass A keeps its delete cells divided by t(M -> D) / g and its match cells multiplied by g (constants folded into the table on
     the host: two operations per node fewer).  The folded kernel, the plain one (ITSX_BOUND_FOLD=0) and the plain one forced by a profile
-    the fold cannot take (an interior M -> D of zero) all stay within 1e-3 nats of p7_ForwardParser's arithmetic, and the coordinates
+    the fold cannot take (an interior M -> D of zero, or of 1e-13) all stay within 1e-3 nats of p7_ForwardParser's arithmetic, and the coordinates
     are the full table's every time"""
     blob, offs = synth.make_reads(t_hmm_text, 2500, config=3, seed=synth.SEED + 12, fixed_len=0, len_range=(150, 700), n_rate=0.003)
     seqs = synth.to_strings(blob, offs)
     hmm = _its2_subset(t_hmm_text, 20, 20)
     odd = _without_match_to_delete(hmm, 17)
-    assert odd != hmm and odd.count("*") > hmm.count("*")
+    tiny = _without_match_to_delete(hmm, 17, "30.00000")       # 1e-13: the scaled delete cells would leave float's range
+    assert odd != hmm and odd.count("*") > hmm.count("*") and tiny.count("30.00000") == 40
     monkeypatch.setenv("ITSX_LAZY_CHECK_BOUND", "1")
-    for text in (hmm, odd):
+    for text in (hmm, odd, tiny):
         monkeypatch.delenv("ITSX_BOUND_FOLD", raising=False)
         ref, _ = _coords(engine, text, seqs, "full")
         outs = []

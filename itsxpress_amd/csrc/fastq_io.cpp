@@ -115,6 +115,7 @@ struct LibDeflate {
   void *(*alloc_d)() = nullptr;
   int (*gz_d)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
   void (*free_d)(void *) = nullptr;
+  uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;       // optional (carry-less multiply: ~10x zlib's table walk)
   bool ok = false;
 };
 struct ZBuf { void *p; size_t size, pos; };          // ZSTD_inBuffer / ZSTD_outBuffer (same shape, src is const in the former)
@@ -144,6 +145,7 @@ void load_codecs()
                 sym(g_ld.h, "libdeflate_gzip_compress", g_ld.gz_c) && sym(g_ld.h, "libdeflate_free_compressor", g_ld.free_c) &&
                 sym(g_ld.h, "libdeflate_alloc_decompressor", g_ld.alloc_d) && sym(g_ld.h, "libdeflate_gzip_decompress_ex", g_ld.gz_d) &&
                 sym(g_ld.h, "libdeflate_free_decompressor", g_ld.free_d);
+      (void)sym(g_ld.h, "libdeflate_crc32", g_ld.crc);
     }
   }
   for (const char *n : {"libzstd.so.1", "libzstd.so"}) { g_zs.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_zs.h) break; }
@@ -286,6 +288,16 @@ bool stat_of(const char *path, int64_t &size, int64_t &mtime_ns)
 }  // namespace
 
 void cache_clear() { std::lock_guard<std::mutex> g(g_cache_mu); g_cache.clear(); }
+
+uint32_t crc32_fast(uint32_t crc, const void *p, size_t n)
+{
+  codecs();
+  if (g_ld.crc) return g_ld.crc(crc, p, n);
+  uLong c = (uLong)crc;
+  const unsigned char *q = (const unsigned char *)p;
+  while (n > 0) { const size_t m = std::min<size_t>(n, (size_t)1 << 30); c = crc32(c, q, (uInt)m); q += m; n -= m; }
+  return (uint32_t)c;
+}
 
 static void cache_insert(const char *path, int64_t fsize, int64_t mtime, std::shared_ptr<const Text> text, double budget)
 {

@@ -68,6 +68,8 @@ class Text {
 // Returns the decompressed content or nullptr (err set).  cacheable: keep / look up the text in the process-wide cache.
 std::shared_ptr<const Text> read_text(const char *path, std::string &err, bool cacheable);
 void cache_clear();
+// CRC-32 (the gzip polynomial), continuing from `crc` (0 to start): libdeflate's when the library is there, else zlib's
+uint32_t crc32_fast(uint32_t crc, const void *p, size_t n);
 // Adopt `text` as the content of the file just written at `path` (temporary files the next stage reads back).
 void cache_put(const char *path, std::shared_ptr<const Text> text);
 

@@ -28,6 +28,9 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 namespace itsx_io {
 namespace {
@@ -236,7 +239,9 @@ int inflate_block(const In &s, uint64_t &pos, Sink &out, Huff &ll, Huff &dd)
 bool find_block(const In &s, uint64_t from, uint64_t to, uint64_t &found)
 {
   Huff ll, dd;
-  std::vector<uint16_t> pbuf((size_t)1 << 20);
+  // (a candidate that decodes 32 K symbols of printable text from one code description is a block: every symbol of a false start would
+  // have to be a valid code AND text; the chunk is decoded again from there anyway, and every member's CRC is the safety net)
+  std::vector<uint16_t> pbuf((size_t)1 << 15);
   Sink probe; probe.text_only = true; probe.v = pbuf.data();
   for (uint64_t p = from; p < to; p++) {
     if (!s.room(p + 64)) return false;
@@ -248,7 +253,7 @@ bool find_block(const In &s, uint64_t from, uint64_t to, uint64_t &found)
     probe.n = 0; probe.cap = pbuf.size();
     q = p;
     int rc = inflate_block(s, q, probe, ll, dd);
-    if (rc == BLK_LIMIT) { found = p; return true; }             // a megabyte of text from one code description: it is a block
+    if (rc == BLK_LIMIT) { found = p; return true; }             // 32 K symbols of text from one code description: it is a block
     if (rc != BLK_OK || probe.n < 64) continue;
     // the next block must look like a block too: header type valid, and some text
     probe.n = 0; probe.cap = 4096;
@@ -409,14 +414,24 @@ bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const s
       const size_t vn = live[(size_t)k].out.n;
       const uint8_t *w = win[(size_t)k].data();
       uint8_t *o = (uint8_t *)&out[0] + off[(size_t)k];
-      for (size_t i = 0; i < vn; i++) { const uint16_t x = v[i]; o[i] = x < 256 ? (uint8_t)x : w[x - 256]; }
+      size_t i = 0;
+#if defined(__SSE2__)
+      // sixteen symbols at a time: all of them bytes (no marker among them, the rule past a chunk's first window) -> one pack and store
+      const __m128i zero = _mm_setzero_si128();
+      for (; i + 16 <= vn; i += 16) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(v + i)), b = _mm_loadu_si128((const __m128i *)(v + i + 8));
+        if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_srli_epi16(_mm_or_si128(a, b), 8), zero)) == 0xFFFF)
+          _mm_storeu_si128((__m128i *)(o + i), _mm_packus_epi16(a, b));
+        else
+          for (size_t q = i; q < i + 16; q++) { const uint16_t x = v[q]; o[q] = x < 256 ? (uint8_t)x : w[x - 256]; }
+      }
+#endif
+      for (; i < vn; i++) { const uint16_t x = v[i]; o[i] = x < 256 ? (uint8_t)x : w[x - 256]; }
       const std::vector<MemberEnd> &ends = live[(size_t)k].ends;
       size_t from = 0;
       for (size_t e = 0; e <= ends.size(); e++) {
         const size_t to = e < ends.size() ? ends[e].at : vn;
-        uLong c = crc32(0L, Z_NULL, 0);
-        for (size_t done = from; done < to;) { const size_t m = std::min<size_t>(to - done, 1u << 30); c = crc32(c, o + done, (uInt)m); done += m; }
-        crcs[(size_t)k].push_back(c);
+        crcs[(size_t)k].push_back((uLong)crc32_fast(0u, o + from, to - from));
         from = to;
       }
     });

@@ -255,6 +255,11 @@ template <class T> struct DBuf {
 struct itsx_ctx {
   int device = 0;
   hipStream_t st = nullptr, st2 = nullptr;   // st2: the bias filter of the next batch beside the decoder of this one
+  // st_hi: a stream of the highest priority that the LOAD stage's entry points swap in for `st` (LoadPriority below).  Several contexts
+  // share a GPU in a streaming run: a chunk's packing / hashing / grouping kernels are milliseconds of work that otherwise wait in line
+  // behind the 20-ms launches of the chunks being searched (round 5: a chunk resident 0.9 s after its text was there, 0.3 s of it a
+  // profile upload's synchronisation, 0.26 s a dereplication that takes 0.06 on an idle device)
+  hipStream_t st_hi = nullptr;
   hipStream_t st3 = nullptr; hipEvent_t ev_s3a = nullptr, ev_s3b = nullptr;   // st3: every other batch of a shared MSV filter (their launch tails overlap)
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   // the MSV filter of chunk c + 1 runs on st2 beside the domain stage of chunk c (latency-bound kernels that leave the vector
@@ -443,6 +448,16 @@ int itsx_abi_version(void) { return ITSX_ABI_VERSION; }
 
 const char *itsx_last_error(const itsx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// the load stage's work on the high-priority stream: swapped in for the call, waited for and swapped back at its end (everything after
+// the call -- the search on `st` -- sees the load stage's results complete)
+struct LoadPriority {
+  itsx_ctx *c; bool on;
+  explicit LoadPriority(itsx_ctx *ctx) : c(ctx), on(ctx && ctx->st_hi != nullptr) { if (on) std::swap(c->st, c->st_hi); }
+  ~LoadPriority() { if (on) { (void)hipStreamSynchronize(c->st); std::swap(c->st, c->st_hi); } }
+  LoadPriority(const LoadPriority &) = delete;
+  LoadPriority &operator=(const LoadPriority &) = delete;
+};
+
 itsx_ctx *itsx_create(int device_id, int flags)
 {
   (void)flags;
@@ -461,6 +476,11 @@ itsx_ctx *itsx_create(int device_id, int flags)
   itsx_ctx *ctx = new itsx_ctx();
   ctx->device = device_id;
   if (hipStreamCreate(&ctx->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete ctx; return nullptr; }
+  if (!(getenv("ITSX_LOAD_PRIORITY") && atoi(getenv("ITSX_LOAD_PRIORITY")) == 0)) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least ||
+        hipStreamCreateWithPriority(&ctx->st_hi, hipStreamDefault, greatest) != hipSuccess) { (void)hipGetLastError(); ctx->st_hi = nullptr; }
+  }
   // p7_FLogsum's table, built with libm exactly as hmmsearch builds it at start-up
   std::vector<float> tbl(16000);
   for (int i = 0; i < 16000; i++) tbl[i] = (float)log(1. + exp((double)-i / 1000.f));
@@ -481,6 +501,7 @@ void itsx_destroy(itsx_ctx *ctx)
   if (ctx->st2) { (void)hipStreamSynchronize(ctx->st2); (void)hipStreamDestroy(ctx->st2); (void)hipEventDestroy(ctx->ev_a); (void)hipEventDestroy(ctx->ev_b);
                   if (ctx->ev_msv0) { (void)hipEventDestroy(ctx->ev_msv0); (void)hipEventDestroy(ctx->ev_msv1); (void)hipEventDestroy(ctx->ev_c); } }
   (void)hipStreamDestroy(ctx->st);
+  if (ctx->st_hi) { (void)hipStreamSynchronize(ctx->st_hi); (void)hipStreamDestroy(ctx->st_hi); }
   for (int k = 0; k < itsx_ctx::NSTAGE; k++) { if (ctx->stage_pin[k]) (void)hipHostFree(ctx->stage_pin[k]); if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]); }
   delete ctx;
   grave_flush();                         // this context's buffers, and whatever the others have given up meanwhile
@@ -495,6 +516,7 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
   }
   ctx->thr_memo.clear(); ctx->thr_memo_have.clear(); ctx->thr_memo_F1 = -1.0;      // (the MSV thresholds kept between searches belong to the old profiles)
   HIPCHK(hipSetDevice(ctx->device));
+  LoadPriority load_priority(ctx);
   ctx->profs = std::move(pv);
   const int P = (int)ctx->profs.size();
   ctx->P = P; ctx->G = (P + 63) / 64;
@@ -990,6 +1012,7 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
 int itsx_load_reads_text(itsx_ctx *ctx, const char *text, int64_t nbytes, int64_t *n_reads)
 {
   CTXCHK(ctx && (text || nbytes == 0) && nbytes >= 0);
+  LoadPriority load_priority(ctx);
   itsx_io::Text view;
   view.borrow(text ? text : "", (size_t)nbytes);
   ctx->h_bases.clear(); ctx->h_off.assign(1, 0); ctx->h_names.clear();
@@ -1137,6 +1160,7 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
 {
   CTXCHK(ctx);
   HIPCHK(hipSetDevice(ctx->device));
+  LoadPriority load_priority(ctx);
   const int64_t n = ctx->N;
   StageTimer tm(ctx->st);
   DBuf<uint64_t> &hf = ctx->w_hf, &hr = ctx->w_hr; DBuf<unsigned long long> &keys = ctx->w_keys;
@@ -3504,6 +3528,7 @@ int itsx_unique_keys128_device(itsx_ctx *ctx, uint64_t seed_a, uint64_t seed_b, 
   CTXCHK(ctx && ctx->have_derep && d_tuples);
   if (ctx->S > 1) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "cross-rank dereplication of a sample batch is not supported: shard whole samples across ranks");
   HIPCHK(hipSetDevice(ctx->device));
+  LoadPriority load_priority(ctx);
   const int64_t n = ctx->N; const int32_t U = ctx->U;
   HIPCHK(ctx->w_keys128.alloc((size_t)U * 4 + 4));
   if (n > 0 && U > 0) {

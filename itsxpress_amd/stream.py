@@ -383,6 +383,7 @@ class StreamEngine(ShardedOps):
         import time
         t0 = time.perf_counter()
         eng = Engine(self.device)
+        tc = time.perf_counter()
         st = {"rank": k, "world": 0, "base": int(base)}
         try:
             if self._profiles is not None:
@@ -391,7 +392,7 @@ class StreamEngine(ShardedOps):
                     self.n_profiles, self._pmeta = int(res[0]), res[1]
             t1 = time.perf_counter()
             eng.load_reads_text(ptr, nb)
-            st["load_s"] = {"context+profiles": round(t1 - t0, 3), "parse+upload": round(time.perf_counter() - t1, 3),
+            st["load_s"] = {"context": round(tc - t0, 3), "profiles": round(t1 - tc, 3), "parse+upload": round(time.perf_counter() - t1, 3),
                             "MB": round(nb / 1e6, 1), "reads": eng.n_reads}
         except BaseException:
             eng.close()

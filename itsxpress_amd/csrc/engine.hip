@@ -1617,7 +1617,10 @@ static int build_share(itsx_ctx *ctx)
   // Two batches of the MSV filter always run side by side, each on its own half of its (small) buffer.  The Forward pass does so only
   // with ITSX_SHARE_FWD_STREAMS=2: measured, its launches' tails are too short for that to gain anything (2.029 vs 2.024 s per 10 M
   // reads), and overlapping launches make a kernel trace's durations (each stretched by the other) disagree with the wall time
-  static const bool two_fwd = getenv("ITSX_SHARE_FWD_STREAMS") && atoi(getenv("ITSX_SHARE_FWD_STREAMS")) >= 2;
+  // ... except in a SMALL search (under 2 M representatives: a GPU's share of a sharded job), where a (batch, depth) launch is a few
+  // milliseconds and its tail a tenth of that: 1.25 M reads 244 -> 232 ms, the step 496 -> 476 (ITSX_SHARE_FWD_STREAMS=1 / 2 force one way)
+  // (not under an explicit slot budget: two batches side by side need twice the slots)
+  const bool two_fwd = getenv("ITSX_SHARE_FWD_STREAMS") ? atoi(getenv("ITSX_SHARE_FWD_STREAMS")) >= 2 : (U < 2000000 && !getenv("ITSX_SHARE_GB"));
   const double state_b = fwd_too ? (two_fwd ? 2.0 : 1.0) * (double)FWD_STATE_Q * sizeof(float4) : 2.0 * (double)MSV_STATE_Q * sizeof(uint4);
   // ... and no more than a job of this size needs: a quarter of all its states at a time still gives every (batch, depth) launch
   // thousands of waves, and device memory is not free to get (20-40 ms per GB in a fresh context: a streamed file's chunks each bring

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(engine, hmm, seqs, mode, env, monkeypatch, names=None):
-    for k in ("ITSX_SHARE", "ITSX_SHARE_B", "ITSX_SHARE_GB", "ITSX_SHARE_MIN", "ITSX_SHARE_CHECK", "ITSX_CHUNK_UNIQUES"):
+    for k in ("ITSX_SHARE", "ITSX_SHARE_B", "ITSX_SHARE_GB", "ITSX_SHARE_MIN", "ITSX_SHARE_CHECK", "ITSX_CHUNK_UNIQUES", "ITSX_SHARE_FWD_STREAMS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -62,7 +62,9 @@ def test_shared_schedule_is_bitwise_the_unshared_one(engine, t_hmm_text, monkeyp
                                  {"ITSX_SHARE_GB": 0.02},                       # many batches
                                  {"ITSX_SHARE_GB": 0.0005},                     # ... and the profiles in ranges
                                  {"ITSX_CHUNK_UNIQUES": 1777},                  # nothing is shared across chunks
-                                 {"ITSX_CHUNK_UNIQUES": 1777, "ITSX_SHARE_GB": 0.004}])
+                                 {"ITSX_CHUNK_UNIQUES": 1777, "ITSX_SHARE_GB": 0.004},
+                                 {"ITSX_SHARE_GB": 0.02, "ITSX_SHARE_FWD_STREAMS": 2},      # the Forward pass's batches on two streams (the default
+                                 {"ITSX_SHARE_GB": 0.02, "ITSX_SHARE_FWD_STREAMS": 1}])     # under 2 M representatives without a slot budget) / on one
 def test_batches_splits_chunks_and_block_sizes(engine, t_hmm_text, monkeypatch, env):
     hmm = _its2_subset(t_hmm_text, 12, 12)
     seqs = _bench_reads(t_hmm_text, 9000, seed=6)

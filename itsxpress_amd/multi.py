@@ -468,14 +468,20 @@ class ShardedOps:
         self.rows_mode = {None: -1, "env": -1, "full": 0, "compact": 1, "lazy": 2}.get(mode, mode)
 
     def finalize(self, domE=10.0):
+        import time
+        t0 = time.perf_counter()
         z = np.sum(self._z, axis=0)
         res = self._all("finalize", z, float(domE))
         pend = max(int(r[0]) for r in res)
+        self.finalize_s = {"thresholds": round(time.perf_counter() - t0, 3)}       # (where an exact finalize's time goes: scripts/file_run.py prints it)
         if pend > 0:                                     # rows that depend on the exact domZ: their profiles are counted on every shard
             flags = np.max([r[1] for r in res], axis=0).astype(np.int32)
+            t1 = time.perf_counter()
             self._z = self._all("complete", flags)
+            t2 = time.perf_counter()
             z = np.sum(self._z, axis=0)
             res = self._all("finalize", z, float(domE))
+            self.finalize_s.update({"profiles_counted": int((flags != 0).sum()), "counting": round(t2 - t1, 3), "thresholds_again": round(time.perf_counter() - t2, 3)})
             if max(int(r[0]) for r in res) > 0:          # (a counted profile leaves nothing undecided; the safety net: everything in full)
                 self._z = self._all("search", "compact", *self._search_args)
                 z = np.sum(self._z, axis=0)

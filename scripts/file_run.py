@@ -98,7 +98,7 @@ def main():
                 t["write (the part left after the pipeline)"] = time.perf_counter() - t0
                 extra_w = {"late_uniques": se._out.n_late_uniques}
             extra = {"stream_chunks": se.world, "stream_timeline_s(chunk, text ready, loaded, searched)": se.timeline,
-                     "chunk_load_s": [st.get("load_s") for _, st in se._engs]}
+                     "chunk_load_s": [st.get("load_s") for _, st in se._engs], "finalize_s": getattr(se, "finalize_s", None)}
             if args.check:                              # the same file through one context: identical coordinates
                 e1 = Engine(0)
                 e1.set_rows_mode(args.rows)

@@ -24,6 +24,8 @@
 #include <thread>
 #include <unordered_map>
 #include <vector>
+#include <fcntl.h>
+#include <unistd.h>
 #include "../../include/itsx_hip.h"
 #include "fastq_io.h"
 
@@ -229,7 +231,7 @@ struct itsx_twriter {
     std::string comp; int64_t nw = 0, tot = 0;
   };
   std::string path; int kind = 0; bool ccs = false; size_t unit_bytes = (size_t)8 << 20;
-  FILE *fp = nullptr;
+  int fd = -1; uint64_t file_off = 0;      // the output, written at explicit offsets (a burst of finished units goes out on several threads)
   const char *base = nullptr; size_t avail = 0; bool text_done = false;
   size_t next_cut_at = 0;                  // the next multiple of unit_bytes to cut behind
   std::deque<Unit> units;
@@ -300,19 +302,48 @@ struct itsx_twriter {
     if (flushing) return;                  // somebody is at it already and will see this unit too: one writer keeps the order
     flushing = true;
     while (next_write < units.size() && units[next_write].state == 2) {
-      Unit &u = units[next_write];
-      std::string c; c.swap(u.comp);
-      nw += u.nw; tot += u.tot;
-      next_write++;
-      if (!c.empty()) {
-        wrote_any = true;
-        lk.unlock();
-        const bool ok = fwrite(c.data(), 1, c.size(), fp) == c.size();
-        lk.lock();
-        if (!ok) failed = true;
+      // every finished unit that is next, up to 256 MB at a time: usually one; after a unit that waited for its last coordinates
+      // (a streaming run's exact thresholds) everything behind it -- most of the file -- at once
+      std::vector<std::string> run; std::vector<uint64_t> at; uint64_t bytes = 0;
+      while (next_write < units.size() && units[next_write].state == 2 && bytes < ((uint64_t)256 << 20)) {
+        Unit &u = units[next_write];
+        nw += u.nw; tot += u.tot;
+        next_write++;
+        if (u.comp.empty()) continue;
+        run.emplace_back(); run.back().swap(u.comp);
+        at.push_back(file_off + bytes); bytes += run.back().size();
       }
+      if (run.empty()) continue;
+      wrote_any = true;
+      file_off += bytes;
+      lk.unlock();
+      const bool ok = write_run(run, at);
+      lk.lock();
+      if (!ok) failed = true;
     }
     flushing = false;
+  }
+  static bool pwrite_all(int fd, const char *p, size_t n, uint64_t off)
+  {
+    while (n > 0) {
+      const ssize_t w = pwrite(fd, p, n, (off_t)off);
+      if (w <= 0) return false;
+      p += w; n -= (size_t)w; off += (uint64_t)w;
+    }
+    return true;
+  }
+  bool write_run(const std::vector<std::string> &run, const std::vector<uint64_t> &at) const
+  {
+    uint64_t bytes = 0;
+    for (const auto &c : run) bytes += c.size();
+    const int T = (bytes >= ((uint64_t)32 << 20) && run.size() >= 4) ? (int)std::min<size_t>(8, run.size()) : 1;
+    if (T == 1) { for (size_t k = 0; k < run.size(); k++) if (!pwrite_all(fd, run[k].data(), run[k].size(), at[k])) return false; return true; }
+    std::atomic<size_t> next{0}; std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([&] { for (size_t k = next.fetch_add(1); k < run.size(); k = next.fetch_add(1)) if (!pwrite_all(fd, run[k].data(), run[k].size(), at[k])) bad = 1; });
+    for (auto &x : th) x.join();
+    return !bad;
   }
 };
 
@@ -391,9 +422,8 @@ int itsx_twriter_open(const char *out_path, int compression, int trim_ccs, itsx_
   itsx_twriter *w = new itsx_twriter;
   w->path = out_path; w->kind = compression; w->ccs = trim_ccs != 0;
   if (const char *e = getenv("ITSX_WRITE_UNIT_KB")) w->unit_bytes = std::max<size_t>(1, (size_t)atoll(e)) << 10;
-  w->fp = fopen(out_path, "wb");
-  if (!w->fp) { g_trim_error = std::string("cannot write ") + out_path; delete w; return ITSX_E_IO; }
-  setvbuf(w->fp, nullptr, _IOFBF, 1 << 20);
+  w->fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+  if (w->fd < 0) { g_trim_error = std::string("cannot write ") + out_path; delete w; return ITSX_E_IO; }
   const int T = itsx_io::io_threads();
   for (int t = 0; t < T; t++) w->workers.emplace_back([w] { w->work(); });
   *out = w;
@@ -462,10 +492,9 @@ int itsx_twriter_close(itsx_twriter *w, int64_t *n_written, int64_t *total_len)
   if (rc == ITSX_OK && !w->wrote_any && w->kind != 0) {          // an empty file is still one valid member / frame
     itsx_io::PieceCompressor pc(w->kind);
     std::string c;
-    if (!pc.run(std::string(), c) || fwrite(c.data(), 1, c.size(), w->fp) != c.size()) w->failed = true;
+    if (!pc.run(std::string(), c) || !itsx_twriter::pwrite_all(w->fd, c.data(), c.size(), w->file_off)) w->failed = true;
   }
-  if (fflush(w->fp) != 0 || ferror(w->fp)) w->failed = true;
-  if (fclose(w->fp) != 0) w->failed = true;
+  if (close(w->fd) != 0) w->failed = true;
   if (rc == ITSX_OK && w->failed) { g_trim_error = "compressing or writing the output failed"; rc = ITSX_E_IO; }
   if (n_written) *n_written = w->nw;
   if (total_len) *total_len = w->tot;

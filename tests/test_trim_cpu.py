@@ -277,6 +277,44 @@ def test_writer_object_fed_piece_by_piece_writes_the_same_file(tmp_path, monkeyp
     assert L.itsx_twriter_close(w, None, None) == 0
 
 
+def test_writer_object_writes_a_held_back_file_in_one_burst(tmp_path, monkeypatch):
+    """the FIRST record is decided last (a streaming run's exact thresholds): every unit behind it is finished and waits, then 40 MB go
+    out at once -- at explicit offsets, on several threads -- and the file is still the one-go writer's, byte for byte"""
+    import ctypes as C
+    from itsxpress_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    n, ln = 130000, 150
+    acgt, ql = np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"#5FI", np.uint8)
+    sq, qq = acgt[rng.integers(0, 4, (n, ln))], ql[rng.integers(0, 4, (n, ln))]
+    text = b"".join(b"@r%d x\n" % i + sq[i].tobytes() + b"\n+\n" + qq[i].tobytes() + b"\n" for i in range(n))
+    fq = tmp_path / "in.fq"
+    fq.write_bytes(text)
+    start, stop = np.zeros(n, np.int32), np.full(n, ln, np.int32)
+    monkeypatch.setenv("ITSX_WRITE_UNIT_KB", "1024")
+    monkeypatch.setenv("ITSX_IO_THREADS", "6")
+    ref = tmp_path / "ref.fq"
+    want = write_trimmed_fastq(str(fq), str(ref), start, stop)
+    assert ref.stat().st_size > (36 << 20)
+    out = tmp_path / "burst.fq"
+    w = C.c_void_p()
+    assert L.itsx_twriter_open(os.fsencode(str(out)), 0, 0, C.byref(w)) == 0
+    buf = C.create_string_buffer(text, len(text))
+    assert L.itsx_twriter_text(w, C.addressof(buf), len(text), 1) == 0
+    dec = np.ones(n, np.uint8); dec[0] = 0
+    wrong = start.copy(); wrong[0] = 99
+    assert L.itsx_twriter_coords(w, 0, n, wrong.ctypes.data, stop.ctypes.data, dec.ctypes.data) == 0
+    import time
+    time.sleep(1.0)                                               # (the pool finishes every unit but the first)
+    assert out.stat().st_size == 0
+    rec = np.zeros(1, np.int64)
+    assert L.itsx_twriter_update(w, rec.ctypes.data, 1, start.ctypes.data, stop.ctypes.data) == 0
+    nw, tot = C.c_int64(), C.c_int64()
+    assert L.itsx_twriter_close(w, C.byref(nw), C.byref(tot)) == 0, L.itsx_trim_last_error()
+    assert (nw.value, tot.value) == tuple(want)
+    assert out.read_bytes() == ref.read_bytes()
+
+
 def test_parallel_paired_writer_writes_the_same_bytes(tmp_path, monkeypatch):
     """large R1 / R2 are cut at the same record numbers and sliced by a pool of threads (R2's records have other sizes than R1's: a
     range of R2 starts inside another of its byte ranges); labels go through a hash index; same bytes as the serial walk, also when

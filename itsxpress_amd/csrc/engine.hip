@@ -2430,6 +2430,27 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
 }
 
 
+namespace itsx {
+__global__ void k_dbg_group_count(const PairRec *__restrict__ pairs, int64_t NP, const int32_t *__restrict__ flag, const int8_t *__restrict__ cls, int ncls, unsigned long long *__restrict__ cnt)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NP || !flag[i]) return;
+  const PairRec pr = pairs[i];
+  if (pr.prof < 0) return;
+  atomicAdd(&cnt[(size_t)pr.useq * ncls + cls[pr.prof]], 1ull);
+}
+__global__ void k_dbg_group_hist(const unsigned long long *__restrict__ cnt, int64_t ng, unsigned long long *__restrict__ hist)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ng) return;
+  const unsigned long long c = cnt[i];
+  const int b = c <= 4 ? (int)c : c <= 8 ? 5 : c <= 16 ? 6 : 7;
+  atomicAdd(&hist[b], 1ull);
+  if (c > 1) atomicAdd(&hist[8], c - 1);
+  if (c > 2) atomicAdd(&hist[9], c - 2);
+}
+}  // namespace itsx
+
 // The lazy domain stage (k_lazy.hip): Forward scores for every pair of the chunk, then two rounds of the domain pipeline over
 // the pairs that can still win ItsPosition's argmax.
 static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorted, int32_t u0, int32_t Uc, double T, double F1, double F3, const std::function<int()> *next_msv)
@@ -2608,6 +2629,17 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
   for (int round = 0; round < 2; round++) {
     StageTimer tm_r(st);
     launch_lazy_mark(la, round, st);
+    if (round == 1 && getenv("ITSX_LAZY_HIST")) {      // experiment: how many candidates a group sends into round 2
+      const int64_t ng = (int64_t)Uc * ncls;
+      HIPCHK(hipMemsetAsync(ctx->l_gtop.p, 0, (size_t)ng * 8, st));
+      hipLaunchKernelGGL(k_dbg_group_count, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, pl.pairs, NP, ctx->l_flag.p, ctx->w_cls.p, ncls, ctx->l_gtop.p);
+      DBuf<unsigned long long> hist; HIPCHK(hist.alloc(16)); HIPCHK(hipMemsetAsync(hist.p, 0, 16 * 8, st));
+      hipLaunchKernelGGL(k_dbg_group_hist, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, ctx->l_gtop.p, ng, hist.p);
+      unsigned long long h[16];
+      HIPCHK(hipMemcpyAsync(h, hist.p, sizeof(h), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+      fprintf(stderr, "[itsx] round 2 candidates per group: 0:%llu 1:%llu 2:%llu 3:%llu 4:%llu 5-8:%llu 9-16:%llu 17+:%llu; pairs beyond a group's first %llu, beyond its second %llu\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+    }
     launch_exclusive_scan(ctx->l_flag.p, ctx->l_pos.p, NP + 1, ctx->l_scan.p, st);
     std::vector<int32_t> bound((size_t)P + 1);
     {

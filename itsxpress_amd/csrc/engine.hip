@@ -601,14 +601,15 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
         if (md > 0.0) { sc[(size_t)k + 1] = md / g[(size_t)k]; aa[(size_t)k] = sc[(size_t)k] * dd / sc[(size_t)k + 1]; }
         else if (dd > 0.0 && k > 1) fold = false;          // a delete path that goes on past a node no match cell feeds: not foldable
         else { sc[(size_t)k + 1] = 1.0; aa[(size_t)k] = 0.0; }
-        // (rescaling lets a row's cells reach 1e20 x g before they are scaled back: the scaled cells must stay far below FLT_MAX)
-        if (!(sc[(size_t)k + 1] > 1e-10 && sc[(size_t)k + 1] < 1e10 && aa[(size_t)k] < 1e10)) fold = false;
+        // (rescaling lets a row's cells reach ~1e21 -- 1e29 under ITSX_BOUND_RESCALE_EXP=28 -- before they are scaled back: the scaled cells
+        // must stay far below FLT_MAX, 3.4e38)
+        if (!(sc[(size_t)k + 1] > 1e-6 && sc[(size_t)k + 1] < 1e6 && aa[(size_t)k] < 1e6)) fold = false;
         // the insert cells by r_k = t(M_k -> I_k) / g_k: I^_k' = I^_k t(I_k -> I_k) + M~_k.  A node without M -> I must not use its insert cell at all
         const double mi = tn(k, 5);
         if (mi > 0.0) ri[(size_t)k] = mi / g[(size_t)k];
         else if (tn(k, 6) > 0.0 || tn(k + 1, 2) > 0.0) fold = false;
         else ri[(size_t)k] = 1.0;
-        if (!(ri[(size_t)k] > 1e-10)) fold = false;
+        if (!(ri[(size_t)k] > 1e-6)) fold = false;
       }
     }
     ctx->bound_fold = fold;

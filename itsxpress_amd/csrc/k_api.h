@@ -184,6 +184,7 @@ struct ShareLaunch {
   void *slots;                 // saved row states: [(node - node_base) * Pb + profile - p0][MSV_STATE_Q uint4 | FWD_STATE_Q float4]
   int64_t node_base; int32_t p0, Pb;
   int32_t depth, logB;
+  float rescale;               // k_fwd_bound: a row's cells are scaled back when its E passes this
 };
 constexpr int MSV_STATE_Q = 8;             // 23 packed registers + xJ, xB, xEmax, padded to one 128-byte line
 constexpr int FWD_STATE_Q = 36;            // M, I, D of 46 nodes + xN xJ xC xB + the scale's logarithm (double)

@@ -217,7 +217,9 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
       xC = __builtin_fmaf(xC, ploop, xE * 0.5f);
       xJ = __builtin_fmaf(xJ, ploop, xE * 0.5f);
       xB = (xJ + xN) * pmove;
-      if (xE > 1.0e20f) {
+      // (1e20; at 1e28 -- most targets never get here, a 45-node domain multiplies E by up to ~1e25 -- pass A takes the same 1.600 s per
+      // 10 M reads: ITSX_BOUND_RESCALE_EXP)
+      if (xE > sl.rescale) {
         const float r = 1.0f / xE;
         xN *= r; xC *= r; xJ *= r; xB *= r;
         const f2 rv = (f2){r, r};
@@ -232,16 +234,24 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
   if (active) fb[pi] = bad ? __builtin_nanf("") : (float)(totscale + det_log((double)(xC * pmove)));
 }
 
+// 1e20 by default (ITSX_BOUND_RESCALE_EXP: another power of ten, for A/B; at most 28 -- the folded cells must stay inside float)
+static float bound_rescale()
+{
+  static const float v = [] { const char *e = getenv("ITSX_BOUND_RESCALE_EXP"); const double x = e ? atof(e) : 20.0; return (float)pow(10.0, x < 4.0 ? 4.0 : x > 28.0 ? 28.0 : x); }();
+  return v;
+}
 void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, hipStream_t st)
 {
   if (nwaves <= 0) return;
+  ShareLaunch none{}; none.rescale = bound_rescale();
   const dim3 g((nwaves + FWD_WPB - 1) / FWD_WPB), b(64 * FWD_WPB);
-  if (fold) hipLaunchKernelGGL((k_fwd_bound<false, true>), g, b, 0, st, a, wave0, nwaves, btab, fb, ShareLaunch{});
-  else hipLaunchKernelGGL((k_fwd_bound<false, false>), g, b, 0, st, a, wave0, nwaves, btab, fb, ShareLaunch{});
+  if (fold) hipLaunchKernelGGL((k_fwd_bound<false, true>), g, b, 0, st, a, wave0, nwaves, btab, fb, none);
+  else hipLaunchKernelGGL((k_fwd_bound<false, false>), g, b, 0, st, a, wave0, nwaves, btab, fb, none);
 }
-void launch_fwd_bound_share(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st)
+void launch_fwd_bound_share(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, const ShareLaunch &sl0, hipStream_t st)
 {
   if (nwaves <= 0) return;
+  ShareLaunch sl = sl0; sl.rescale = bound_rescale();
   const dim3 g((nwaves + FWD_WPB - 1) / FWD_WPB), b(64 * FWD_WPB);
   if (fold) hipLaunchKernelGGL((k_fwd_bound<true, true>), g, b, 0, st, a, wave0, nwaves, btab, fb, sl);
   else hipLaunchKernelGGL((k_fwd_bound<true, false>), g, b, 0, st, a, wave0, nwaves, btab, fb, sl);

@@ -151,14 +151,13 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
   if (compression < 0 || compression > 2) { g_trim_error = "compression must be 0 (plain), 1 (gzip) or 2 (zstd)"; return ITSX_E_ARG; }
   Records in; Writer out;
   if (!in.open(seq_path)) return ITSX_E_IO;
-  if (!out.open(out_path, compression)) return ITSX_E_IO;
   // The writer proper is itsx_twriter (below): units of the text sliced and deflated by a pool of threads, written in order --
   // fed here with the whole text and every coordinate at once, by a streaming run piece by piece: the same bytes either way.
   // (One I/O thread: the serial walk below; a malformed record sends the file there too, and the walk names it.)
   const size_t size = (size_t)(in.end - in.s);
   const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : 0;
   if (itsx_io::io_threads() > 1 && size >= min_par) {
-    { std::string e; out.w.close(e); }
+    { itsx_io::PieceCompressor probe(compression); if (!probe.ok()) { g_trim_error = "zstd output requested but libzstd.so.1 could not be loaded"; return ITSX_E_IO; } }
     itsx_twriter *tw = nullptr;
     int rc = itsx_twriter_open(out_path, compression, trim_ccs, &tw);
     if (rc != ITSX_OK) return rc;
@@ -173,8 +172,8 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
       return ITSX_OK;
     }
     if (rc != ITSX_E_FORMAT) return rc;
-    if (!out.open(out_path, compression)) return ITSX_E_IO;      // a malformed record somewhere: the serial walk names it
   }
+  if (!out.open(out_path, compression)) return ITSX_E_IO;        // (the output is opened ONCE on every way through: it may be a pipe; after a malformed record the serial walk names it)
   Rec rec; int64_t i = 0, nw = 0, tot = 0; int rc;
   while ((rc = in.next(rec)) == 1) {
     if (i >= n_records) { g_trim_error = "more records in the file than coordinates"; return ITSX_E_ARG; }
@@ -232,6 +231,7 @@ struct itsx_twriter {
   };
   std::string path; int kind = 0; bool ccs = false; size_t unit_bytes = (size_t)8 << 20;
   int fd = -1; uint64_t file_off = 0;      // the output, written at explicit offsets (a burst of finished units goes out on several threads)
+  bool seekable = true;                    // (a pipe -- /dev/stdout, a process substitution -- takes the pieces one after the other)
   const char *base = nullptr; size_t avail = 0; bool text_done = false;
   size_t next_cut_at = 0;                  // the next multiple of unit_bytes to cut behind
   std::deque<Unit> units;
@@ -323,10 +323,10 @@ struct itsx_twriter {
     }
     flushing = false;
   }
-  static bool pwrite_all(int fd, const char *p, size_t n, uint64_t off)
+  static bool pwrite_all(int fd, const char *p, size_t n, uint64_t off, bool seekable = true)
   {
     while (n > 0) {
-      const ssize_t w = pwrite(fd, p, n, (off_t)off);
+      const ssize_t w = seekable ? pwrite(fd, p, n, (off_t)off) : write(fd, p, n);
       if (w <= 0) return false;
       p += w; n -= (size_t)w; off += (uint64_t)w;
     }
@@ -336,8 +336,8 @@ struct itsx_twriter {
   {
     uint64_t bytes = 0;
     for (const auto &c : run) bytes += c.size();
-    const int T = (bytes >= ((uint64_t)32 << 20) && run.size() >= 4) ? (int)std::min<size_t>(8, run.size()) : 1;
-    if (T == 1) { for (size_t k = 0; k < run.size(); k++) if (!pwrite_all(fd, run[k].data(), run[k].size(), at[k])) return false; return true; }
+    const int T = (seekable && bytes >= ((uint64_t)32 << 20) && run.size() >= 4) ? (int)std::min<size_t>(8, run.size()) : 1;
+    if (T == 1) { for (size_t k = 0; k < run.size(); k++) if (!pwrite_all(fd, run[k].data(), run[k].size(), at[k], seekable)) return false; return true; }
     std::atomic<size_t> next{0}; std::atomic<int> bad{0};
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++)
@@ -424,6 +424,7 @@ int itsx_twriter_open(const char *out_path, int compression, int trim_ccs, itsx_
   if (const char *e = getenv("ITSX_WRITE_UNIT_KB")) w->unit_bytes = std::max<size_t>(1, (size_t)atoll(e)) << 10;
   w->fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
   if (w->fd < 0) { g_trim_error = std::string("cannot write ") + out_path; delete w; return ITSX_E_IO; }
+  w->seekable = lseek(w->fd, 0, SEEK_CUR) != (off_t)-1;
   const int T = itsx_io::io_threads();
   for (int t = 0; t < T; t++) w->workers.emplace_back([w] { w->work(); });
   *out = w;
@@ -492,7 +493,7 @@ int itsx_twriter_close(itsx_twriter *w, int64_t *n_written, int64_t *total_len)
   if (rc == ITSX_OK && !w->wrote_any && w->kind != 0) {          // an empty file is still one valid member / frame
     itsx_io::PieceCompressor pc(w->kind);
     std::string c;
-    if (!pc.run(std::string(), c) || !itsx_twriter::pwrite_all(w->fd, c.data(), c.size(), w->file_off)) w->failed = true;
+    if (!pc.run(std::string(), c) || !itsx_twriter::pwrite_all(w->fd, c.data(), c.size(), w->file_off, w->seekable)) w->failed = true;
   }
   if (close(w->fd) != 0) w->failed = true;
   if (rc == ITSX_OK && w->failed) { g_trim_error = "compressing or writing the output failed"; rc = ITSX_E_IO; }

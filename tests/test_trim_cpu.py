@@ -315,6 +315,31 @@ def test_writer_object_writes_a_held_back_file_in_one_burst(tmp_path, monkeypatc
     assert out.read_bytes() == ref.read_bytes()
 
 
+def test_single_end_writer_into_a_pipe(tmp_path, monkeypatch):
+    """the output may be a pipe (a process substitution, /dev/stdout): no offsets there, the pieces go out one after the other"""
+    import threading
+    rng = np.random.default_rng(10)
+    n = 3000
+    fq = tmp_path / "in.fq"
+    with open(fq, "w") as f:
+        for i in range(n):
+            ln = int(rng.integers(40, 300))
+            f.write("@p%d\n%s\n+\n%s\n" % (i, "".join(rng.choice(list("ACGT"), ln)), "I" * ln))
+    start, stop = rng.integers(0, 20, n).astype(np.int32), rng.integers(20, 300, n).astype(np.int32)
+    monkeypatch.setenv("ITSX_WRITE_UNIT_KB", "64")
+    monkeypatch.setenv("ITSX_IO_THREADS", "4")
+    ref = tmp_path / "ref.fq.gz"
+    want = write_trimmed_fastq(str(fq), str(ref), start, stop, gzipped=True)
+    fifo = tmp_path / "out.fifo"
+    os.mkfifo(fifo)
+    got = []
+    t = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    t.start()
+    assert write_trimmed_fastq(str(fq), str(fifo), start, stop, gzipped=True) == want
+    t.join(timeout=30)
+    assert gzip.decompress(got[0]) == gzip.decompress(ref.read_bytes())
+
+
 def test_parallel_paired_writer_writes_the_same_bytes(tmp_path, monkeypatch):
     """large R1 / R2 are cut at the same record numbers and sliced by a pool of threads (R2's records have other sizes than R1's: a
     range of R2 starts inside another of its byte ranges); labels go through a hash index; same bytes as the serial walk, also when

@@ -451,7 +451,9 @@ int itsx_debug_packed_read(const itsx_ctx *ctx, int64_t i, uint32_t *words, int3
  * 3: read 16 B per lane -- and report the bytes one launch touches, so rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled */
 int itsx_debug_calibrate(itsx_ctx *ctx, int pattern, double gbytes, int iters, int64_t *bytes_per_launch, double *ms_per_launch);
 /* VALU issue-rate probe behind bench.py's valu_issue_frac (profiles/round5_valu_issue.md): op 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_max_i16,
- * 3 v_pk_add_u16, 4 v_pk_mul_f32, 5 v_pk_add_f32, 6 s_nop 0, 7 v_mul_f32, 8 v_pk_mov_b32, 9 v_max_i16; 64 x iters independent instructions per
+ * 3 v_pk_add_u16, 4 v_pk_mul_f32, 5 v_pk_add_f32, 6 s_nop 0, 7 v_mul_f32, 8 v_pk_mov_b32, 9 v_max_i16; 10 the scalar-cache probe: two
+ * s_load_dwordx8 of a 1-KB table per step, waited for one step later (what k_fwd_bound asks per pair of nodes), 11 the same under 12
+ * v_pk_fma_f32 per step (scripts/scalar_probe.py); 64 x iters independent instructions (steps) per
  * wave, waves_per_simd (1-4, 6, 8) waves on every SIMD; cycles_per_instr as one wave sees them (shader clock ticks, median over the waves) */
 int itsx_debug_issue(itsx_ctx *ctx, int op, int waves_per_simd, int iters, double *cycles_per_instr, double *ms);
 /* deterministic log/exp evaluated ON THE DEVICE for n inputs */

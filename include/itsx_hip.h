@@ -207,6 +207,11 @@ const char *itsx_stream_last_error(void);
  *   to hold exactly match_records[p] records instead; a file that does not hold them is ITSX_E_FORMAT.
  * Errors: negative code, text from itsx_shard_last_error(). */
 int itsx_shard_text(const char *path, int32_t n_parts, const int64_t *match_records, const char *out_prefix, int64_t *records, int64_t *bytes);
+/* The owner's step of the cross-shard dereplication for a multi-worker run (itsxpress_amd/multi.py: owner_verdicts states it in numpy):
+ * recv[m][5] = (key0, key1, global index of the first occurrence, forward-is-canonical flag, local unique number) of the uniques whose
+ * keys this worker owns, src[m] = the worker each row came from; out[m][4] = per row the global index and flag of its group's first
+ * occurrence and the worker / local unique number of the holder that scores the sequence.  Host-only. */
+int itsx_owner_verdicts(const int64_t *recv, const int64_t *src, int64_t m, int64_t *out);
 const char *itsx_shard_last_error(void);
 itsx_keyset *itsx_keyset_create(void);
 void itsx_keyset_destroy(itsx_keyset *k);

@@ -65,7 +65,7 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
            "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
-           "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath", "itsx_debug_logf", "itsx_debug_dust", "itsx_debug_calibrate", "itsx_debug_issue", "itsx_shard_text", "itsx_shard_last_error",
+           "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath", "itsx_debug_logf", "itsx_debug_dust", "itsx_debug_calibrate", "itsx_debug_issue", "itsx_shard_text", "itsx_shard_last_error", "itsx_owner_verdicts",
            "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
            "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_pairs_load", "itsx_merge_tables",
            "itsx_orient_load_db", "itsx_orient", "itsx_write_oriented_fastq",
@@ -176,6 +176,7 @@ def lib():
         "itsx_debug_issue": (i32, [vp, i32, i32, i32, vp, vp]),
         "itsx_shard_text": (i32, [C.c_char_p, i32, vp, C.c_char_p, vp, vp]),
         "itsx_shard_last_error": (C.c_char_p, []),
+        "itsx_owner_verdicts": (i32, [vp, vp, i64, vp]),
         "itsx_write_trimmed_fastq": (i32, [cp, cp, i32, i32, vp, vp, i64, vp, vp]),
         "itsx_write_trimmed_paired": (i32, [cp, cp, cp, cp, i32, i32, vp, vp, i64, vp, vp, vp, vp]),
         "itsx_trim_last_error": (cp, []),

@@ -26,6 +26,7 @@ def test_numpy_owner_step_equals_the_torch_one():
         src = rng.integers(0, world, m).astype(np.int64)
         a = multi.owner_verdicts(recv, src)
         b = dist.owner_verdicts(torch.from_numpy(recv), torch.from_numpy(src)).numpy()
+        assert np.array_equal(a, multi.owner_verdicts_native(recv, src))          # (the library's: what the workers run)
         assert np.array_equal(a, b)
         # one scorer per distinct sequence, in the representative's orientation, and the representative is the smallest index
         for k in range(300):
@@ -38,6 +39,14 @@ def test_numpy_owner_step_equals_the_torch_one():
             holders = [(int(src[r]), int(recv[r, 4])) for r in rows if recv[r, 3] == recv[first, 3]]
             assert (int(a[rows[0], 2]), int(a[rows[0], 3])) in holders
     assert multi.owner_verdicts(np.zeros((0, 5), np.int64), np.zeros(0, np.int64)).shape == (0, 4)
+    assert multi.owner_verdicts_native(np.zeros((0, 5), np.int64), np.zeros(0, np.int64)).shape == (0, 4)
+    # at a size where the library's pool is at work (buckets filled by several threads), keys of both signs, heavy duplication
+    m = 200000
+    keys = rng.integers(-2 ** 63, 2 ** 63 - 1, (40000, 2))
+    pick = rng.integers(0, 40000, m)
+    recv = np.stack([keys[pick, 0], keys[pick, 1], rng.permutation(3 * m)[:m], rng.integers(0, 2, m), rng.integers(0, 10 ** 6, m)], axis=1).astype(np.int64)
+    src = rng.integers(0, 8, m).astype(np.int64)
+    assert np.array_equal(multi.owner_verdicts(recv, src), multi.owner_verdicts_native(recv, src))
 
 
 def test_array_writers_reproduce_the_reference_fixture(tmp_path):

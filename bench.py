@@ -320,6 +320,10 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own shard of the workload's size (weak scaling)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (0 = skip, -1 = auto: ~20-30 s of CPU work)")
     ap.add_argument("--handover-steps", type=int, default=1, help="steps fed from the host buffer, outside `value` (0 = skip)")
+    ap.add_argument("--paired-pairs", type=int, default=0,
+                    help="N = 1 only: after the timed steps, configs[2] as the config states it -- this many synthetic 2x250 PAIRS, R1 / R2 .fastq.gz in, "
+                         "trimmed R1 / R2 .fastq.gz out, through the mirror classes in arrays mode (scripts/paired_run.py) -- reported as the extra key "
+                         "`paired_file_to_file`, never as `value` (0 = skip, the default: generating 10 M pairs alone takes minutes)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ITSX_BENCH_BUDGET_S", "520")),
                     help="wall-clock budget of the whole run: the legs AFTER the K timed steps (host hand-over, CPU baseline) shrink or "
                          "are skipped to stay inside it (the driver's limit is 600 s); the timed steps themselves are never cut")
@@ -631,6 +635,24 @@ def main():
                     "GB_per_step": float(offs[-1]) / 1e9,
                     "note": "host buffer -> pinned staging -> HBM -> device packing inside the step (PCIe-inclusive); not `value`"}
 
+    paired_leg = None
+    if args.paired_pairs > 0 and world == 1:
+        progress("paired file-to-file leg (%d pairs)" % args.paired_pairs)
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        keep = {k: os.environ.get(k) for k in ("ITSXPRESS_ARRAYS", "ITSXPRESS_STREAM")}
+        os.environ["ITSXPRESS_ARRAYS"], os.environ["ITSXPRESS_STREAM"] = "1", "0"
+        try:
+            import paired_run
+            paired_leg = paired_run.run(args.paired_pairs, True)
+            paired_leg["note"] = ("R1 / R2 .fastq.gz -> merge (k_merge.hip) -> derep -> lazy search -> coordinates -> trimmed R1 / R2 .fastq.gz, one GPU, "
+                                  "ITSXPRESS_ARRAYS=1 (scripts/paired_run.py); host codecs included; not `value`")
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
     if rank == 0:
         total_reads = total_local * args.steps
         value = total_reads / dt
@@ -756,6 +778,7 @@ def main():
             "timed_region": "ASCII text resident in HBM -> device 2-bit packing -> derep -> MSV -> Forward/Backward -> domains -> "
                             "thresholds -> per-read coordinates on the host (+ all-reduce / gather at N > 1)",
             "host_handover": handover,
+            "paired_file_to_file": paired_leg,
             "ranks": rank_ms,
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
             "kernels": kernel_table,

@@ -25,6 +25,12 @@ def main():
     ap.add_argument("--pairs", type=int, default=500000)
     ap.add_argument("--array-path", action="store_true", help="skip uc.txt / rep.fa / domtbl.txt (the in-memory hand-off, f3)")
     args = ap.parse_args()
+    print(json.dumps(run(args.pairs, args.array_path)))
+
+
+def run(pairs, array_path=True):
+    """the run as a function (bench.py --paired-pairs calls it for its `paired_file_to_file` key): the stage times as a dict"""
+    args = argparse.Namespace(pairs=int(pairs), array_path=bool(array_path))
     import synth
     from bench import its2_profiles
     from itsxpress_amd import Engine, SeqSamplePairedNotInterleaved
@@ -118,12 +124,12 @@ def main():
         total = sum(t.values())
         kept = int(((start >= 0) & (stop >= 0) & (start < stop)).sum())
         assert nw == kept, (nw, kept)
-        print(json.dumps({"pairs": n, "merged": len(names[1]) - 1, "unique": int(nu), "pairs_written": int(nw), "array_path": bool(args.array_path),
+        return ({"pairs": n, "merged": len(names[1]) - 1, "unique": int(nu), "pairs_written": int(nw), "array_path": bool(args.array_path),
                           "input_gz_MB": round(sum(os.path.getsize(p) for p in paths) / 1e6, 1),
                           "output_gz_MB": round((os.path.getsize(o1) + os.path.getsize(o2)) / 1e6, 1),
                           "gzip_level": int(os.environ.get("ITSX_GZIP_LEVEL", 6)),
                           **{"s_" + k: round(v, 3) for k, v in t.items()}, "s_total": round(total, 3),
-                          "pairs_per_s_file_to_file": round(n / total)}))
+                          "pairs_per_s_file_to_file": round(n / total)})
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

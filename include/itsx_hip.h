@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define ITSX_ABI_VERSION 5      /* 5: prefix sharing (itsx_stats grew); 4: streaming loads (itsx_stream_*, itsx_keyset_*, itsx_load_reads_text), itsx_io_cache_clear; 3: rows modes (itsx_set_rows_mode, the lazy domain stage), itsx_stats grew; 2: itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
+#define ITSX_ABI_VERSION 6      /* 6: two-sided sharing (itsx_stats grew); 5: prefix sharing (itsx_stats grew); 4: streaming loads (itsx_stream_*, itsx_keyset_*, itsx_load_reads_text), itsx_io_cache_clear; 3: rows modes (itsx_set_rows_mode, the lazy domain stage), itsx_stats grew; 2: itsx_get_stats / itsx_get_pairtraces take the caller's struct size */
 
 enum {
   ITSX_OK            =  0,
@@ -132,6 +132,15 @@ typedef struct {
   int32_t share_B;           int32_t share_batches;
   int64_t share_nodes, share_chains, msv_rows, msv_rows_full, bound_rows_full, n_share_helpers, share_mismatch;
   float   ms_share_build;    float share_frac;          /* building the tree and the order, ms; rows the chains skip / rows of all uniques */
+  /* two-sided sharing (round 6; lazy searches): a Forward chain stops where its SUFFIX is one an earlier representative of its length
+   * ends with too, and takes the rest of the sum over paths from the Backward state that representative's chain saved there.
+   * n_joined: representatives that join; bwd_chains / gamma_nodes: Backward chains and their saved states; per representative (one
+   * profile) two_fwd_rows + two_bwd_rows rows are walked of two_rows_full; bwd_rows: lane-rows of the Backward chains of the last
+   * search (bound_rows: the Forward chains'); ITSX_SHARE_CHECK=1 (tests): join_maxdiff = largest |joined score - unshared score|, nats
+   * (more than 2e-3 counts into share_mismatch) */
+  int32_t two_sided;         int32_t n_bwd_launches;
+  int64_t n_joined, bwd_chains, gamma_nodes, bwd_rows, two_fwd_rows, two_bwd_rows, two_rows_full;
+  float   join_maxdiff;      int32_t pad5;
 } itsx_stats;
 
 int         itsx_abi_version(void);

@@ -17,6 +17,7 @@ constexpr int MSV_REGS = 23;
 constexpr int MSV_TW = 24;            // dwords per residue code in a profile's MSV emission table (MSV_REGS used)
 constexpr int MAXDOM = 8;       // regions kept per (rep, profile)
 constexpr int BOUND_PAIRS = 23; // k_lazy.hip: pairs of adjacent nodes the bound kernel keeps (2 x 23 = MMAX)
+constexpr int BOUND_RTAB = BOUND_PAIRS * 12 + 4;   // k_bwd_bound's table: per pair of nodes mm im dm ii bm dd, two floats each (round 6)
 constexpr int BOUND_TAB = (BOUND_PAIRS + 1) * 16 + 2 * BOUND_PAIRS + 2;   // floats per profile of its table: 24 records of 16, then the match cells' scale by node (FOLD)
 
 // ---- host-side model (profile configuration happens once per model, on the host, with libm) ----

@@ -276,6 +276,7 @@ struct itsx_ctx {
   DBuf<DevProfile> d_prof;
   DBuf<uint32_t> d_etab;
   DBuf<int32_t> d_pbias, d_ptec, d_ptbm;
+  DBuf<float> d_rtab;                      // k_bwd_bound's table (round 6: two-sided sharing)
   DBuf<float> d_flogsum; DBuf<LogTab> d_logtab; DBuf<float> d_btab; bool bound_fold = false;   // (the bound kernel's table, and whether it is the folded one)
   std::vector<char> generic_q;          // per profile: needs the runtime-Q kernels
 
@@ -380,7 +381,7 @@ struct itsx_ctx {
 
   // ---- prefix sharing (k_share.hip), rebuilt by every itsx_search: the prefix tree of the active uniques by sorted position s (sh_*_s)
   // and by processing position k = (batch, depth, s) (sh_dev); a batch is a range of s whose saved row states fit the slot budget
-  struct ShareBatch { int32_t k0, k1; int64_t node0, nnodes; int32_t nsplit; };   // nsplit > 1: the profiles in that many ranges, one after the other
+  struct ShareBatch { int32_t k0, k1; int64_t node0, nnodes; int32_t nsplit; int64_t gnode0, gnnodes; };   // nsplit > 1: the profiles in that many ranges, one after the other; g*: the batch's saved Backward states
   bool share_on = false; int share_B = 32, share_logB = 5, share_maxd = 0;
   DBuf<unsigned long long> sh_tab, sh_mask_s, sh_mask, sh_counters; DBuf<uint8_t> sh_depth_s, sh_depth;
   DBuf<int32_t> sh_src, sh_parent_s, sh_parent, sh_nn_s, sh_nn, sh_node0_s, sh_node0, sh_order, sh_ulen, sh_uorder, sh_inv, sh_flag, sh_pos, sh_bstart, sh_cursor, sh_segk, sh_scan, sh_cuts;
@@ -388,6 +389,17 @@ struct itsx_ctx {
   DBuf<uint4> sh_mslots; size_t sh_mslots_half = 0, sh_fslots_half = 0; DBuf<uint32_t> sh_pass, sh_need; DBuf<int32_t> sh_real, sh_segflat, sh_segdepth, sh_wc, sh_woff; DBuf<int64_t> sh_bnd;
   DBuf<uint16_t> sh_res_chk; DBuf<float> sh_fb_chk;
   ShareDev sh_dev{};
+  // two-sided sharing (round 6): the suffix tree by s (sh_r*_s), the joins, the Backward chains by backward position kb (sh_bdev), their
+  // batches' first positions (sh_bsegk_h), the slots of the saved Backward states behind the Forward ones in the DP slab
+  bool two_on = false; int share_maxrd = 0; int32_t Ub = 0; size_t sh_gslots_off = 0;
+  DBuf<uint8_t> sh_rdepth_s, sh_rdepth; DBuf<unsigned long long> sh_rmask_s, sh_rmask, sh_keys, sh_keys2;
+  DBuf<int32_t> sh_rparent_s, sh_rparent, sh_jlev_s, sh_jown_s, sh_endrow_s, sh_rsteps_s, sh_rnn_s, sh_rnode0_s, sh_endrow, sh_jlev, sh_jsrc, sh_jownb;
+  DBuf<int32_t> sh_border_s, sh_invb, sh_bsegk, sh_rnn, sh_rnode0, sh_border, sh_bulen, sh_rsrc, sh_bsteps, sh_vals;
+  DBuf<uint8_t> sh_sorttmp;
+  std::vector<int32_t> sh_bsegk_h;
+  BShareDev sh_bdev{};
+  DBuf<uint32_t> sh_needb; DBuf<uint16_t> sh_resb; DBuf<int32_t> sh_cntb, sh_totalb, sh_realb, sh_bsegflat, sh_bsegdepth, sh_bwc, sh_bwoff; DBuf<int64_t> sh_bbnd, sh_bseg_start;
+  DBuf<PairRec> sh_bpairs; DBuf<WaveDesc> sh_bwaves;
 };
 
 #define CTXCHK(c)                                   \
@@ -643,6 +655,20 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
       for (int k0 = 0; k0 < KK; k0++) gq[k0] = (float)gk(k0 + 1);
     }
     HIPCHK(upload(ctx->d_btab, bt, ctx->st));
+    // k_bwd_bound (round 6) walks the same recurrences transposed: per pair of nodes (k1, k2) the folded M_k -> M_k+1, I_k -> M_k+1,
+    // D_k -> M_k+1, I_k -> I_k, B -> M_k and D_k -> D_k+1 constants of the table above, by SOURCE node
+    std::vector<float> rt((size_t)std::max(P, 1) * BOUND_RTAB, 0.0f);
+    for (int i = 0; i < P && fold; i++) {
+      const float *b = bt.data() + (size_t)i * BOUND_TAB;
+      for (int j = 0; j < BOUND_PAIRS; j++) {
+        float *o = rt.data() + (size_t)i * BOUND_RTAB + (size_t)j * 12;
+        for (int q = 0; q < 8; q++) o[q] = b[(size_t)j * 16 + q];                          // mm im dm ii of the pair's nodes
+        o[8] = b[(size_t)(j + 1) * 16 + 8]; o[9] = b[(size_t)(j + 1) * 16 + 9];            // B -> M_k1, B -> M_k2
+        o[10] = b[(size_t)(j + 1) * 16 + 11];                                              // D_k1 -> D_k2
+        o[11] = (j + 2 <= BOUND_PAIRS) ? b[(size_t)(j + 2) * 16 + 10] : 0.0f;              // D_k2 -> D_k2+1 (none after the last node)
+      }
+    }
+    HIPCHK(upload(ctx->d_rtab, rt, ctx->st));
   }
   HIPCHK(upload(ctx->d_prof, dp, ctx->st));
   HIPCHK(upload(ctx->d_etab, etab, ctx->st));
@@ -1568,10 +1594,11 @@ static int build_share(itsx_ctx *ctx)
   HIPCHK(hipMemsetAsync(ctx->sh_counters.p, 0, 16 * sizeof(unsigned long long), st));
   a.counters = ctx->sh_counters.p;
   launch_trie_keycount(a, st);
-  unsigned long long hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(hc, ctx->sh_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
+  if (ctx->lazy && ctx->bound_fold) { TrieArgs r0 = a; r0.rev = 1; launch_trie_keycount(r0, st); }      // (the suffix tree uses the same table after the prefix tree)
+  unsigned long long hc0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(hc0, ctx->sh_counters.p, sizeof(hc0), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  const unsigned long long nkeys = hc[4];
+  const unsigned long long nkeys = std::max(hc0[4], hc0[6]);
   if (nkeys == 0) return ITSX_OK;
   uint64_t slots = 1024; while (slots < 2 * nkeys) slots <<= 1;
   HIPCHK(ctx->sh_tab.alloc((size_t)slots, true));
@@ -1582,13 +1609,38 @@ static int build_share(itsx_ctx *ctx)
   a.tab = ctx->sh_tab.p; a.tmask = slots - 1; a.depth = ctx->sh_depth_s.p; a.parent = ctx->sh_parent_s.p; a.mask = ctx->sh_mask_s.p; a.nn = ctx->sh_nn_s.p;
   launch_trie_insert(a, st); launch_trie_resolve(a, st); launch_trie_link(a, st); launch_trie_count(a, st);
   launch_exclusive_scan(ctx->sh_nn_s.p, ctx->sh_node0_s.p, (int64_t)U + 1, ctx->sh_scan.p, st);
+  // ---- two-sided sharing (round 6; lazy searches with the folded bound kernel): the SUFFIX tree in the same table, the joins, the
+  // chains' extents (k_share.hip: k_join_*)
+  bool two = ctx->lazy && ctx->bound_fold && !(getenv("ITSX_SHARE_TWO") && atoi(getenv("ITSX_SHARE_TWO")) == 0);
+  ctx->two_on = false; ctx->Ub = 0; ctx->share_maxrd = 0; ctx->sh_bsegk_h.clear();
+  S.two_sided = 0; S.n_joined = 0; S.bwd_chains = 0; S.gamma_nodes = 0; S.bwd_rows = 0; S.join_maxdiff = 0; S.n_bwd_launches = 0; S.two_fwd_rows = S.two_bwd_rows = S.two_rows_full = 0;
+  TrieArgs ar = a;
+  JoinArgs ja{};
+  if (two) {
+    HIPCHK(ctx->sh_rdepth_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_rparent_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_rmask_s.alloc((size_t)U + 1));
+    HIPCHK(ctx->sh_jlev_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_jown_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_endrow_s.alloc((size_t)U + 1));
+    HIPCHK(ctx->sh_rsteps_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_rnn_s.alloc((size_t)U + 2)); HIPCHK(ctx->sh_rnode0_s.alloc((size_t)U + 2));
+    HIPCHK(hipMemsetAsync(ctx->sh_tab.p, 0xFF, (size_t)slots * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(ctx->sh_rmask_s.p, 0, ((size_t)U + 1) * sizeof(unsigned long long), st));
+    ar.rev = 1; ar.depth = ctx->sh_rdepth_s.p; ar.parent = ctx->sh_rparent_s.p; ar.mask = ctx->sh_rmask_s.p; ar.nn = ctx->sh_rnn_s.p;
+    launch_trie_insert(ar, st); launch_trie_resolve(ar, st); launch_trie_link(ar, st);
+    ja.t = ar; ja.fdepth = ctx->sh_depth_s.p; ja.fmask = ctx->sh_mask_s.p; ja.rmask = ctx->sh_rmask_s.p; ja.jlev = ctx->sh_jlev_s.p; ja.jown = ctx->sh_jown_s.p;
+    ja.endrow = ctx->sh_endrow_s.p; ja.rsteps = ctx->sh_rsteps_s.p; ja.counters = ctx->sh_counters.p;
+    launch_join_resolve(ja, st);
+    for (int r = 63; r >= 1; r--) launch_join_up(ja, r, st);
+    launch_join_ends(ja, st);
+    launch_popc64(ctx->sh_rmask_s.p, ctx->sh_rnn_s.p, (int64_t)U + 1, U, st);
+    launch_exclusive_scan(ctx->sh_rnn_s.p, ctx->sh_rnode0_s.p, (int64_t)U + 1, ctx->sh_scan.p, st);
+  }
   // where a batch may start: a new length or a new chunk
   const int32_t ncap = 65536 + U / std::max(1, Uc) + 8;
-  HIPCHK(ctx->sh_cuts.alloc((size_t)ncap * 2));
-  launch_share_cuts(ctx->d_ulen.p, ctx->sh_node0_s.p, U, a.Uc, ncap, ctx->sh_cuts.p, ctx->sh_counters.p + 5, st);
-  int32_t NN = 0;
+  HIPCHK(ctx->sh_cuts.alloc((size_t)ncap * 3));
+  launch_share_cuts(ctx->d_ulen.p, ctx->sh_node0_s.p, two ? ctx->sh_rnode0_s.p : nullptr, U, a.Uc, ncap, ctx->sh_cuts.p, ctx->sh_counters.p + 5, st);
+  int32_t NN = 0, NG = 0;
+  unsigned long long hc[16];
   HIPCHK(hipMemcpyAsync(hc, ctx->sh_counters.p, sizeof(hc), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&NN, ctx->sh_node0_s.p + U, sizeof(NN), hipMemcpyDeviceToHost, st));
+  if (two) HIPCHK(hipMemcpyAsync(&NG, ctx->sh_rnode0_s.p + U, sizeof(NG), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   const int maxd = (int)hc[0];
   const double frac = hc[2] ? (double)hc[1] / (double)hc[2] : 0.0;
@@ -1597,18 +1649,21 @@ static int build_share(itsx_ctx *ctx)
   if (const char *e = getenv("ITSX_SHARE_MIN")) min_frac = atof(e);
   const int64_t ncuts = (int64_t)hc[5];
   if (frac < min_frac || maxd <= 0 || NN <= 0 || ncuts > ncap) { S.ms_share_build = tm.stop(); return ITSX_OK; }
-  std::vector<int32_t> cuts((size_t)ncuts * 2);
+  if (two && (hc[10] == 0 || NG <= 0)) two = false;            // nobody joins: the one-sided schedule
+  const int maxrd = two ? (int)hc[13] : 0;
+  std::vector<int32_t> cuts((size_t)ncuts * 3);
   HIPCHK(hipMemcpyAsync(cuts.data(), ctx->sh_cuts.p, cuts.size() * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  std::vector<std::pair<int32_t, int32_t>> cv((size_t)ncuts);
-  for (int64_t i = 0; i < ncuts; i++) cv[(size_t)i] = {cuts[(size_t)2 * i], cuts[(size_t)2 * i + 1]};
-  std::sort(cv.begin(), cv.end());
-  cv.push_back({U, NN});
+  struct Cut { int32_t s, n, g; };
+  std::vector<Cut> cv((size_t)ncuts);
+  for (int64_t i = 0; i < ncuts; i++) cv[(size_t)i] = {cuts[(size_t)3 * i], cuts[(size_t)3 * i + 1], two ? cuts[(size_t)3 * i + 2] : 0};
+  std::sort(cv.begin(), cv.end(), [](const Cut &x, const Cut &y) { return x.s < y.s; });
+  cv.push_back({U, NN, two ? NG : 0});
   // ---- batches: consecutive groups of one chunk while their saved states (for every profile, at the Forward pass's size) fit the budget
   // (a lazy search: the Forward pass's states, up to 48 GB (in the DP slab's memory: below) and a third of what is free; otherwise only the MSV filter shares, its
   // states are a fifth the size, and the full table's rows and slabs want the memory: up to 8 GB and an eighth of what is free)
   const bool fwd_too = ctx->lazy;
-  double gb = fwd_too ? 48.0 : 8.0;
+  double gb = fwd_too ? (two ? 72.0 : 48.0) : 8.0;
   {
     size_t fr = 0, tot = 0;
     const double held = (double)ctx->w_slab.cap * sizeof(float) + (double)ctx->sh_mslots.cap * sizeof(uint4);
@@ -1626,71 +1681,102 @@ static int build_share(itsx_ctx *ctx)
   // ... and no more than a job of this size needs: a quarter of all its states at a time still gives every (batch, depth) launch
   // thousands of waves, and device memory is not free to get (20-40 ms per GB in a fresh context: a streamed file's chunks each bring
   // their own -- round 5's first streamed run spent 5 s in hipMalloc for slots its 1.3 M-read chunks filled to a tenth)
-  if (!getenv("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)NN * state_b * (double)P / (double)(1ull << 30) / 4.0));
+  if (!getenv("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)((int64_t)NN + NG) * state_b * (double)P / (double)(1ull << 30) / 4.0));
   const int64_t nodes_max = std::max<int64_t>(1, (int64_t)(gb * (double)(1ull << 30) / (state_b * (double)P)));
   std::vector<int32_t> bstart; std::vector<itsx_ctx::ShareBatch> &bt = ctx->sh_batches;
   {
     size_t i = 0;
     while (i + 1 < cv.size()) {
       size_t j = i + 1;                       // the batch takes groups i .. j - 1
-      while (j + 1 < cv.size() && cv[j].first % a.Uc != 0 && (int64_t)cv[j + 1].second - cv[i].second <= nodes_max) j++;
+      while (j + 1 < cv.size() && cv[j].s % a.Uc != 0 && ((int64_t)cv[j + 1].n - cv[i].n) + ((int64_t)cv[j + 1].g - cv[i].g) <= nodes_max) j++;
       itsx_ctx::ShareBatch b{};
-      b.k0 = cv[i].first; b.k1 = cv[j].first; b.node0 = cv[i].second; b.nnodes = (int64_t)cv[j].second - cv[i].second;
-      b.nsplit = (int32_t)std::min<int64_t>(P, (b.nnodes + nodes_max - 1) / nodes_max); if (b.nsplit < 1) b.nsplit = 1;
+      b.k0 = cv[i].s; b.k1 = cv[j].s; b.node0 = cv[i].n; b.nnodes = (int64_t)cv[j].n - cv[i].n; b.gnode0 = cv[i].g; b.gnnodes = (int64_t)cv[j].g - cv[i].g;
+      b.nsplit = (int32_t)std::min<int64_t>(P, (b.nnodes + b.gnnodes + nodes_max - 1) / nodes_max); if (b.nsplit < 1) b.nsplit = 1;
       bstart.push_back(b.k0); bt.push_back(b);
       i = j;
     }
     bstart.push_back(U);
   }
   const int nb = (int)bt.size();
+  if (nb >= (1 << 24)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
   // a batch that one group overfills takes its profiles in nsplit ranges; if even one profile's states do not fit, nothing is shared
-  for (auto &b : bt) if ((double)b.nnodes * state_b * (double)((P + b.nsplit - 1) / b.nsplit) > 1.5 * gb * (double)(1ull << 30)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
-  // ---- the processing order: stable by (batch, depth)
-  HIPCHK(upload(ctx->sh_bstart, bstart, st)); HIPCHK(ctx->sh_cursor.alloc((size_t)nb + 1)); HIPCHK(ctx->sh_segk.alloc((size_t)nb * SHARE_SEGS));
-  HIPCHK(hipMemcpyAsync(ctx->sh_cursor.p, ctx->sh_bstart.p, (size_t)nb * 4, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemsetAsync(ctx->sh_segk.p, 0, (size_t)nb * SHARE_SEGS * 4, st));
-  HIPCHK(ctx->sh_flag.alloc((size_t)U + 2)); HIPCHK(ctx->sh_pos.alloc((size_t)U + 2)); HIPCHK(ctx->sh_uorder.alloc((size_t)U + 1)); HIPCHK(ctx->sh_inv.alloc((size_t)U + 1));
-  for (int d = 0; d <= maxd; d++) {
-    launch_share_flag(ctx->sh_depth_s.p, U, d, ctx->sh_flag.p, st);
-    launch_exclusive_scan(ctx->sh_flag.p, ctx->sh_pos.p, (int64_t)U + 1, ctx->sh_scan.p, st);
-    launch_share_scatter(ctx->sh_depth_s.p, U, d, ctx->sh_pos.p, ctx->sh_bstart.p, nb, ctx->sh_cursor.p, ctx->sh_uorder.p, ctx->sh_inv.p, st);
-    launch_share_advance(d, ctx->sh_pos.p, ctx->sh_bstart.p, nb, ctx->sh_cursor.p, ctx->sh_segk.p, st);
-  }
+  for (auto &b : bt) if ((double)(b.nnodes + b.gnnodes) * state_b * (double)((P + b.nsplit - 1) / b.nsplit) > 1.5 * gb * (double)(1ull << 30)) { bt.clear(); S.ms_share_build = tm.stop(); return ITSX_OK; }
+  // ---- the processing order: stable by (batch, depth, last row) (k_order.hip)
+  HIPCHK(upload(ctx->sh_bstart, bstart, st)); HIPCHK(ctx->sh_segk.alloc((size_t)nb * SHARE_SEGS));
+  HIPCHK(ctx->sh_uorder.alloc((size_t)U + 1)); HIPCHK(ctx->sh_inv.alloc((size_t)U + 1));
+  HIPCHK(ctx->sh_keys.alloc((size_t)U + 1)); HIPCHK(ctx->sh_keys2.alloc((size_t)U + 1)); HIPCHK(ctx->sh_vals.alloc((size_t)U + 1));
+  const size_t sort_bytes = order_sort_bytes(U);
+  HIPCHK(ctx->sh_sorttmp.alloc(sort_bytes));
+  launch_order_keys(ctx->sh_depth_s.p, two ? ctx->sh_endrow_s.p : ctx->d_ulen.p, nullptr, U, ctx->sh_bstart.p, nb, ctx->sh_keys.p, ctx->sh_vals.p, st);
+  if (order_sort(ctx->sh_sorttmp.p, sort_bytes, ctx->sh_keys.p, ctx->sh_keys2.p, ctx->sh_vals.p, ctx->sh_uorder.p, U, st) != 0) SET_ERR(ctx, ITSX_E_DEVICE, "prefix sharing: the order's radix sort failed");
+  HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 15, 0, sizeof(unsigned long long), st));
+  launch_order_segk(ctx->sh_keys2.p, U, nb, ctx->sh_segk.p, ctx->sh_inv.p, ctx->sh_uorder.p, U, ctx->sh_counters.p + 15, st);
   ctx->sh_segk_h.assign((size_t)nb * SHARE_SEGS, 0);
   HIPCHK(hipMemcpyAsync(ctx->sh_segk_h.data(), ctx->sh_segk.p, (size_t)nb * SHARE_SEGS * 4, hipMemcpyDeviceToHost, st));
   // ---- the tree by processing position
   HIPCHK(ctx->sh_depth.alloc((size_t)U + 1)); HIPCHK(ctx->sh_parent.alloc((size_t)U + 1)); HIPCHK(ctx->sh_mask.alloc((size_t)U + 1));
   HIPCHK(ctx->sh_nn.alloc((size_t)U + 2)); HIPCHK(ctx->sh_node0.alloc((size_t)U + 2)); HIPCHK(ctx->sh_order.alloc((size_t)U + 1)); HIPCHK(ctx->sh_ulen.alloc((size_t)U + 1));
+  HIPCHK(ctx->sh_endrow.alloc((size_t)U + 1)); HIPCHK(ctx->sh_jlev.alloc((size_t)U + 1)); HIPCHK(ctx->sh_jsrc.alloc((size_t)U + 1)); HIPCHK(ctx->sh_jownb.alloc((size_t)U + 1));
   ShareDev &o = ctx->sh_dev;
   HIPCHK(ctx->sh_src.alloc((size_t)U + 1));
   o.src = ctx->sh_src.p;
   o.depth = ctx->sh_depth.p; o.parent = ctx->sh_parent.p; o.mask = ctx->sh_mask.p; o.nn = ctx->sh_nn.p; o.node0 = ctx->sh_node0.p; o.order = ctx->sh_order.p; o.ulen = ctx->sh_ulen.p;
-  launch_share_permute(a, ctx->d_ulen.p, ctx->sh_uorder.p, ctx->sh_inv.p, o, st);
+  o.endrow = ctx->sh_endrow.p; o.jlev = ctx->sh_jlev.p; o.jsrc = ctx->sh_jsrc.p;
+  launch_share_permute(a, ctx->d_ulen.p, ctx->sh_uorder.p, ctx->sh_inv.p, two ? ctx->sh_endrow_s.p : nullptr, two ? ctx->sh_jlev_s.p : nullptr, o, st);
   launch_exclusive_scan(ctx->sh_nn.p, ctx->sh_node0.p, (int64_t)U + 1, ctx->sh_scan.p, st);
   launch_share_src(o, U, a.Uc, st);
-  HIPCHK(hipStreamSynchronize(st));
-  for (int b = 0; b < nb; b++) {               // the end of each batch's last depth, and of the depths that do not occur
-    for (int d = maxd + 1; d < SHARE_SEGS; d++) ctx->sh_segk_h[(size_t)b * SHARE_SEGS + d] = bt[(size_t)b].k1;
+  int32_t Ub = 0;
+  if (two) {
+    // ---- the Backward chains: the uniques that save a state for somebody, by (batch, blocks from the end they start at, rows they walk)
+    HIPCHK(ctx->sh_border_s.alloc((size_t)U + 1)); HIPCHK(ctx->sh_invb.alloc((size_t)U + 1)); HIPCHK(ctx->sh_bsegk.alloc((size_t)nb * SHARE_SEGS));
+    launch_order_keys(ctx->sh_rdepth_s.p, ctx->sh_rsteps_s.p, ctx->sh_rsteps_s.p, U, ctx->sh_bstart.p, nb, ctx->sh_keys.p, ctx->sh_vals.p, st);
+    if (order_sort(ctx->sh_sorttmp.p, sort_bytes, ctx->sh_keys.p, ctx->sh_keys2.p, ctx->sh_vals.p, ctx->sh_border_s.p, U, st) != 0) SET_ERR(ctx, ITSX_E_DEVICE, "two-sided sharing: the order's radix sort failed");
+    HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 15, 0, sizeof(unsigned long long), st));
+    launch_order_segk(ctx->sh_keys2.p, U, nb, ctx->sh_bsegk.p, ctx->sh_invb.p, ctx->sh_border_s.p, U, ctx->sh_counters.p + 15, st);
+    unsigned long long nv = 0;
+    ctx->sh_bsegk_h.assign((size_t)nb * SHARE_SEGS, 0);
+    HIPCHK(hipMemcpyAsync(ctx->sh_bsegk_h.data(), ctx->sh_bsegk.p, (size_t)nb * SHARE_SEGS * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&nv, ctx->sh_counters.p + 15, sizeof(nv), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    Ub = (int32_t)nv;
+    HIPCHK(ctx->sh_rdepth.alloc((size_t)Ub + 1)); HIPCHK(ctx->sh_rparent.alloc((size_t)Ub + 1)); HIPCHK(ctx->sh_rmask.alloc((size_t)Ub + 1));
+    HIPCHK(ctx->sh_rnn.alloc((size_t)Ub + 2)); HIPCHK(ctx->sh_rnode0.alloc((size_t)Ub + 2)); HIPCHK(ctx->sh_border.alloc((size_t)Ub + 1)); HIPCHK(ctx->sh_bulen.alloc((size_t)Ub + 1));
+    HIPCHK(ctx->sh_rsrc.alloc((size_t)Ub + 1)); HIPCHK(ctx->sh_bsteps.alloc((size_t)Ub + 1));
+    BShareDev &ob = ctx->sh_bdev;
+    ob.depth = ctx->sh_rdepth.p; ob.parent = ctx->sh_rparent.p; ob.mask = ctx->sh_rmask.p; ob.nn = ctx->sh_rnn.p; ob.node0 = ctx->sh_rnode0.p; ob.order = ctx->sh_border.p;
+    ob.ulen = ctx->sh_bulen.p; ob.src = ctx->sh_rsrc.p; ob.steps = ctx->sh_bsteps.p;
+    launch_bshare_permute(ar, Ub, ctx->d_ulen.p, ctx->sh_border_s.p, ctx->sh_invb.p, ctx->sh_rmask_s.p, ctx->sh_rsteps_s.p, ob, st);
+    launch_exclusive_scan(ctx->sh_rnn.p, ctx->sh_rnode0.p, (int64_t)Ub + 1, ctx->sh_scan.p, st);
+    launch_bshare_src(ob, Ub, st);
+    launch_join_src(U, B, ctx->sh_uorder.p, ctx->sh_jown_s.p, ctx->sh_invb.p, ob, o, ctx->sh_jownb.p, st);
   }
+  HIPCHK(hipStreamSynchronize(st));
   // ---- slots of the saved states: the largest batch's, for the MSV filter and for the Forward pass
-  int64_t need_slots = 0;
-  for (auto &b : bt) need_slots = std::max<int64_t>(need_slots, b.nnodes * (int64_t)((P + b.nsplit - 1) / b.nsplit));
+  int64_t need_slots = 0, need_gslots = 0;
+  for (auto &b : bt) {
+    const int64_t pr = (int64_t)((P + b.nsplit - 1) / b.nsplit);
+    need_slots = std::max<int64_t>(need_slots, b.nnodes * pr); need_gslots = std::max<int64_t>(need_gslots, b.gnnodes * pr);
+  }
   // (no room for them: the search runs unshared)
   ctx->sh_mslots_half = (size_t)need_slots * MSV_STATE_Q;      // two batches of the MSV filter run side by side (search_chunk)
   // The Forward pass's states live in the DP slab (ctx->w_slab): pass A is over before the rounds' Forward / Backward kernels write their
   // rows there, so the two never need the memory at the same time -- 24-48 GB that round 5's first version held twice (and that cost the
-  // stages behind it their batch sizes)
-  ctx->sh_fslots_half = (fwd_too && two_fwd && nb > 1) ? (size_t)need_slots * FWD_STATE_Q : 0;       // (one batch: nothing to run beside it)
+  // stages behind it their batch sizes).  Two-sided: a batch's Backward states follow its Forward states.
+  const size_t half = ((size_t)need_slots + (size_t)(two ? need_gslots : 0)) * FWD_STATE_Q;
+  ctx->sh_gslots_off = (size_t)need_slots * FWD_STATE_Q;
+  ctx->sh_fslots_half = (fwd_too && two_fwd && nb > 1) ? half : 0;       // (one batch: nothing to run beside it)
   if (ctx->sh_mslots.alloc(2 * (size_t)need_slots * MSV_STATE_Q + 1) != hipSuccess ||
-      (fwd_too && ctx->w_slab.alloc(4 * ((size_t)need_slots * FWD_STATE_Q * (ctx->sh_fslots_half ? 2 : 1) + 1), true) != hipSuccess)) {
+      (fwd_too && ctx->w_slab.alloc(4 * (half * (ctx->sh_fslots_half ? 2 : 1) + 1), true) != hipSuccess)) {
     (void)hipGetLastError();
     ctx->sh_mslots.release(); bt.clear();
     S.ms_share_build = tm.stop();
     return ITSX_OK;
   }
   ctx->share_on = true; ctx->share_B = B; ctx->share_logB = logB; ctx->share_maxd = maxd;
+  ctx->two_on = two; ctx->Ub = Ub; ctx->share_maxrd = maxrd;
   S.share_B = B; S.share_batches = nb; S.share_nodes = NN; S.share_chains = (int64_t)hc[3];
   S.msv_rows_full = (int64_t)hc[2] * P; S.msv_rows = (int64_t)(hc[2] - hc[1]) * P;
+  if (two) { S.two_sided = 1; S.n_joined = (int64_t)hc[10]; S.bwd_chains = (int64_t)hc[14]; S.gamma_nodes = NG; S.two_fwd_rows = (int64_t)hc[11]; S.two_bwd_rows = (int64_t)hc[12]; S.two_rows_full = (int64_t)hc[2]; }
   S.ms_share_build = tm.stop();
   return ITSX_OK;
 }
@@ -2471,6 +2557,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     // chains of one (batch, depth) for every profile, the depths of a batch in ascending order -- a chain starts from the state that a
     // chain of a lower depth saved for the same profile
     const int maxd = ctx->share_maxd, DS = maxd + 1;
+    const bool two = ctx->two_on;
     std::vector<int32_t> segflat, segdepth, segbatch;
     for (size_t bi = 0; bi < ctx->sh_batches.size(); bi++) {
       const auto &b = ctx->sh_batches[bi];
@@ -2490,14 +2577,81 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     HIPCHK(hipMemcpyAsync(woff.data(), ctx->sh_woff.p, woff.size() * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const int NW = woff.back();
-    HIPCHK(ctx->w_waves.alloc((size_t)std::max(NW, 1))); HIPCHK(ctx->w_counters.alloc(16));
-    HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 16 * sizeof(int64_t), st));
-    launch_share_waves(NW, nseg, P, ctx->sh_woff.p, ctx->sh_bnd.p, ctx->sh_segdepth.p, ctx->share_B, pl.pairs, ctx->w_waves.p, (unsigned long long *)ctx->w_counters.p, st);
-    int64_t lane_rows[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(lane_rows, ctx->w_counters.p, sizeof(lane_rows), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx->w_waves.alloc((size_t)std::max(NW, 1))); HIPCHK(ctx->w_counters.alloc(512));
+    HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 512 * sizeof(int64_t), st));
+    launch_share_waves(NW, nseg, P, ctx->sh_woff.p, ctx->sh_bnd.p, ctx->sh_segdepth.p, ctx->share_B, pl.pairs, two ? ctx->sh_endrow.p + u0 : nullptr, 0, ctx->w_waves.p,
+                       (unsigned long long *)ctx->w_counters.p, st);
+    std::vector<int64_t> lr((size_t)384, 0);
     FloatArgs a{};
     a.rd = ctx->rd; a.sorted_uniq = d_sorted; a.seed_read = ctx->d_seed_read.p; a.prof = ctx->d_prof.p; a.lt = ctx->d_lt.p;
     a.pairs = pl.pairs; a.waves = ctx->w_waves.p; a.F1 = F1; a.F3 = F3;
+    // ---- two-sided sharing (round 6): the Backward chains' work list.  A chain runs for a profile when a pair past the filter joins one of
+    // its states, or a chain below it in the suffix tree runs (k_join_need / k_need_up_b); the list is made like the Forward pass's own
+    const int maxrd = ctx->share_maxrd, DSB = maxrd + 1;
+    int32_t cb0 = 0, Ubc = 0; int NWB = 0;
+    std::vector<int32_t> bwoff;
+    FloatArgs ab = a;
+    if (two) {
+      int32_t cb1 = 0; bool any = false;
+      std::vector<int32_t> bsegflat, bsegdepth;
+      for (size_t bi = 0; bi < ctx->sh_batches.size(); bi++) {
+        const auto &b = ctx->sh_batches[bi];
+        if (b.k0 < u0 || b.k0 >= u0 + Uc) continue;
+        const int32_t lo = ctx->sh_bsegk_h[bi * SHARE_SEGS], hi = ctx->sh_bsegk_h[bi * SHARE_SEGS + SHARE_SEGS - 1];
+        if (!any) { cb0 = lo; any = true; }
+        cb1 = hi;
+      }
+      Ubc = any ? cb1 - cb0 : 0;
+      for (size_t bi = 0; bi < ctx->sh_batches.size(); bi++) {
+        const auto &b = ctx->sh_batches[bi];
+        if (b.k0 < u0 || b.k0 >= u0 + Uc) continue;
+        for (int d = 0; d < DSB; d++) { bsegflat.push_back(ctx->sh_bsegk_h[bi * SHARE_SEGS + d] - cb0); bsegdepth.push_back(d); }
+      }
+      const int nbseg = (int)bsegdepth.size();
+      bsegflat.push_back(Ubc);
+      bwoff.assign((size_t)nbseg * P + 1, 0);
+      if (Ubc > 0) {
+        const int W = (P + 31) / 32;
+        HIPCHK(ctx->sh_needb.alloc((size_t)Ubc * W + 1));
+        HIPCHK(hipMemsetAsync(ctx->sh_needb.p, 0, ((size_t)Ubc * W + 1) * 4, st));
+        launch_join_need(ctx->sh_jlev.p + u0, ctx->sh_jownb.p + u0, Uc, W, cb0, ctx->sh_pass.p, ctx->sh_needb.p, st);
+        for (int r = maxrd; r >= 1; r--) launch_need_up_b(r, ctx->sh_rdepth.p + cb0, ctx->sh_rparent.p + cb0, cb0, Ubc, W, ctx->sh_needb.p, st);
+        HIPCHK(ctx->sh_resb.alloc((size_t)P * Ubc + 1));
+        launch_need_res(ctx->sh_needb.p, Ubc, P, W, ctx->sh_resb.p, st);
+        const int nchb = (Ubc + CHUNK - 1) / CHUNK;
+        HIPCHK(ctx->sh_cntb.alloc((size_t)P * nchb)); HIPCHK(ctx->sh_totalb.alloc((size_t)P)); HIPCHK(ctx->sh_realb.alloc((size_t)P));
+        HIPCHK(hipMemsetAsync(ctx->sh_realb.p, 0, (size_t)P * 4, st));
+        launch_pair_count(ctx->sh_resb.p, P, Ubc, nchb, ctx->sh_cntb.p, ctx->sh_realb.p, st);
+        launch_chunk_scan(ctx->sh_cntb.p, P, nchb, ctx->sh_totalb.p, st);
+        std::vector<int32_t> totalb((size_t)P);
+        HIPCHK(hipMemcpyAsync(totalb.data(), ctx->sh_totalb.p, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<int64_t> bseg((size_t)P + 1, 0);
+        for (int p = 0; p < P; p++) bseg[(size_t)p + 1] = bseg[(size_t)p] + ((int64_t)totalb[(size_t)p] + 63) / 64 * 64;
+        const int64_t NPB = bseg[(size_t)P];
+        if (NPB >= (1ll << 31) || (int64_t)nbseg * P + 1 >= (1ll << 31)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "two-sided sharing: too many Backward chains in one chunk");
+        if (NPB > 0) {
+          HIPCHK(upload(ctx->sh_bseg_start, bseg, st));
+          HIPCHK(ctx->sh_bpairs.alloc((size_t)NPB));
+          HIPCHK(hipMemsetAsync(ctx->sh_bpairs.p, 0xFF, (size_t)NPB * sizeof(PairRec), st));
+          launch_pair_fill(ctx->sh_resb.p, P, Ubc, nchb, ctx->sh_cntb.p, ctx->sh_bseg_start.p, ctx->sh_bulen.p + cb0, ctx->sh_bpairs.p, st);
+          HIPCHK(upload(ctx->sh_bsegflat, bsegflat, st)); HIPCHK(upload(ctx->sh_bsegdepth, bsegdepth, st, 1));
+          HIPCHK(ctx->sh_bbnd.alloc((size_t)(nbseg + 1) * P)); HIPCHK(ctx->sh_bwc.alloc((size_t)nbseg * P + 2)); HIPCHK(ctx->sh_bwoff.alloc((size_t)nbseg * P + 2));
+          HIPCHK(ctx->sh_scan.alloc((size_t)scan_tmp_elems((int64_t)nbseg * P + 2)));
+          launch_share_bounds(ctx->sh_bpairs.p, ctx->sh_bseg_start.p, ctx->sh_totalb.p, ctx->sh_bsegflat.p, nbseg, P, ctx->sh_bbnd.p, st);
+          launch_share_wcount(ctx->sh_bbnd.p, nbseg, P, ctx->sh_bwc.p, st);
+          launch_exclusive_scan(ctx->sh_bwc.p, ctx->sh_bwoff.p, (int64_t)nbseg * P + 1, ctx->sh_scan.p, st);
+          HIPCHK(hipMemcpyAsync(bwoff.data(), ctx->sh_bwoff.p, bwoff.size() * 4, hipMemcpyDeviceToHost, st));
+          HIPCHK(hipStreamSynchronize(st));
+          NWB = bwoff.back();
+          HIPCHK(ctx->sh_bwaves.alloc((size_t)std::max(NWB, 1)));
+          launch_share_waves(NWB, nbseg, P, ctx->sh_bwoff.p, ctx->sh_bbnd.p, ctx->sh_bsegdepth.p, ctx->share_B, ctx->sh_bpairs.p, ctx->sh_bsteps.p + cb0, 1, ctx->sh_bwaves.p,
+                             (unsigned long long *)ctx->w_counters.p + 128, st);
+          ab.sorted_uniq = ctx->sh_border.p + cb0; ab.pairs = ctx->sh_bpairs.p; ab.waves = ctx->sh_bwaves.p;
+        }
+      }
+    }
+    HIPCHK(hipMemcpyAsync(lr.data(), ctx->w_counters.p, 256 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     StageTimer tm(st);
     // (batches are independent: every other one on a second stream with its own half of the slot buffer, so that a launch's tail --
     // the next depth waits for its last waves -- is filled by the other batch's waves)
@@ -2514,9 +2668,23 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       const bool on_alt = alt != st && ((t0 / DS) & 1);
       hipStream_t bs = on_alt ? alt : st;
       float4 *fsl = (float4 *)ctx->w_slab.p + (on_alt ? ctx->sh_fslots_half : 0);
+      float4 *gsl = fsl + ctx->sh_gslots_off;
+      const int tb0 = (t0 / DS) * DSB;
       for (int r = 0; r < b.nsplit; r++) {
         const int pa = (int)((int64_t)P * r / b.nsplit), pb = (int)((int64_t)P * (r + 1) / b.nsplit);
         if (pb <= pa) continue;
+        // the batch's Backward chains first, the deepest suffixes last (a chain starts from the state a shorter suffix's chain saved):
+        // every state a Forward chain of this batch joins is there before the first of them runs
+        if (two && NWB > 0)
+          for (int d = 0; d < DSB; d++) {
+            const int t = tb0 + d;
+            const int w0 = bwoff[(size_t)t * P + pa], w1 = bwoff[(size_t)t * P + pb];
+            if (w1 <= w0) continue;
+            ShareLaunch sl{};
+            sl.src = ctx->sh_rsrc.p + cb0; sl.mask = ctx->sh_rmask.p + cb0; sl.node0 = ctx->sh_rnode0.p + cb0; sl.endrow = ctx->sh_bsteps.p + cb0;
+            sl.slots = gsl; sl.node_base = b.gnode0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
+            for (int w = w0; w < w1; w += 1 << 20) { launch_bwd_bound_share(ab, ctx->d_btab.p, ctx->d_rtab.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bwd_launches++; }
+          }
         for (int d = 0; d < DS; d++) {
           const int t = t0 + d;
           const int w0 = woff[(size_t)t * P + pa], w1 = woff[(size_t)t * P + pb];
@@ -2524,6 +2692,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
           ShareLaunch sl{};
           sl.src = ctx->sh_src.p + u0; sl.mask = ctx->sh_mask.p + u0; sl.node0 = ctx->sh_node0.p + u0;
           sl.slots = fsl; sl.node_base = b.node0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
+          if (two) { sl.endrow = ctx->sh_endrow.p + u0; sl.jlev = ctx->sh_jlev.p + u0; sl.jsrc = ctx->sh_jsrc.p + u0; sl.gslots = gsl; sl.gnode_base = b.gnode0; }
           for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->bound_fold, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bound_launches++; }
         }
       }
@@ -2531,7 +2700,11 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     if (alt != st) { HIPCHK(hipEventRecord(ctx->ev_s3b, alt)); HIPCHK(hipStreamWaitEvent(st, ctx->ev_s3b, 0)); }
     const float ms = tm.stop();
     S.ms_bound_kernel += ms; S.ms_filters += ms;
-    S.bound_rows += lane_rows[0]; S.bound_rows_full += lane_rows[1];
+    for (int q = 0; q < 64; q++) { S.bound_rows += lr[(size_t)2 * q]; S.bound_rows_full += lr[(size_t)2 * q + 1]; S.bwd_rows += lr[(size_t)128 + 2 * q]; }
+    // the check hooks below run every pair from row 1: their waves reach the pairs' last rows
+    const bool want_check = getenv("ITSX_LAZY_CHECK_BOUND") || (getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0);
+    if (two && want_check)
+      launch_share_waves(NW, nseg, P, ctx->sh_woff.p, ctx->sh_bnd.p, ctx->sh_segdepth.p, ctx->share_B, pl.pairs, nullptr, 0, ctx->w_waves.p, (unsigned long long *)ctx->w_counters.p + 256, st);
     if (getenv("ITSX_LAZY_CHECK_BOUND")) {       // test hook: the shared chains' scores against HMMER's own arithmetic from row 1
       DBuf<float> ref;
       HIPCHK(ref.alloc((size_t)NP + 1));
@@ -2547,7 +2720,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       HIPCHK(hipStreamSynchronize(st));
       float mx = S.lazy_bound_maxdiff;
       for (int64_t i = 0; i < NP; i++) {
-        if (hp[(size_t)i].prof < 0) continue;
+        if (hp[(size_t)i].prof < 0 || hp[(size_t)i].xj < 0) continue;          // (a pair that ran for its row states only has no score)
         const float x = h0[(size_t)i], y = h1[(size_t)i];
         if (x != x || y != y) { if ((x != x) != (y != y)) mx = 1e30f; continue; }
         mx = std::max(mx, fabsf(x - y));
@@ -2555,15 +2728,18 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       S.lazy_bound_maxdiff = mx;
     }
     if (getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0) {
-      // test hook: every pair again from row 1 (the same wave list serves: a wave needs its profile, its pairs and its longest target)
+      // test hook: every pair again from row 1 (the same wave list serves: a wave needs its profile, its pairs and its longest target).  A
+      // chain that ran on its own to L has the unshared score bit for bit; a JOINED pair's score is the same sum over paths in another
+      // order of operations: it must agree within 2e-3 nats (join_maxdiff reports the largest difference)
       HIPCHK(ctx->sh_fb_chk.alloc((size_t)NP + 1));
       for (int w0 = 0; w0 < NW; w0 += 1 << 20) launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->bound_fold, ctx->sh_fb_chk.p, std::min(1 << 20, NW - w0), w0, st);
-      HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 8, 0, sizeof(unsigned long long), st));
-      launch_diff_scores(ctx->l_fb.p, ctx->sh_fb_chk.p, pl.pairs, NP, ctx->sh_counters.p + 8, st);
-      unsigned long long nd = 0;
-      HIPCHK(hipMemcpyAsync(&nd, ctx->sh_counters.p + 8, sizeof(nd), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemsetAsync(ctx->sh_counters.p + 8, 0, 2 * sizeof(unsigned long long), st));
+      launch_diff_scores(ctx->l_fb.p, ctx->sh_fb_chk.p, pl.pairs, NP, two ? ctx->sh_jlev.p + u0 : nullptr, ctx->sh_counters.p + 8, st);
+      unsigned long long nd[2] = {0, 0};
+      HIPCHK(hipMemcpyAsync(nd, ctx->sh_counters.p + 8, sizeof(nd), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      S.share_mismatch += (int64_t)nd;
+      S.share_mismatch += (int64_t)nd[0];
+      S.join_maxdiff = std::max(S.join_maxdiff, __builtin_bit_cast(float, (uint32_t)nd[1]));
     }
   } else {
     // the waves over every pair, fast (Q == 12) profiles first, then runtime-Q ones: built on the device (k_waves_build)

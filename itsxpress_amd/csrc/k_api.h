@@ -149,6 +149,8 @@ struct TrieArgs {
   ReadsDev rd;
   const int32_t *sorted_uniq, *seed_read;   // [U] the length-sorted uniques the search walks
   int32_t U, Uc, B;                          // Uc: uniques per search chunk (nothing is shared across chunks); B: rows per block (16 x 2^n)
+  int32_t rev;                               // 0: the PREFIX tree (depth d = the first d blocks).  1: the SUFFIX tree (round 6: depth r = the LAST r blocks, rows
+                                             // (A - r) B + 1 .. L with A = ceil(L / B) -- the boundaries are the prefix tree's): mask is left alone (k_join_*)
   unsigned long long *tab; uint64_t tmask;   // open addressing over (length, chunk, depth, prefix) keys: [38-bit tag | 26-bit s], ~0 = empty
   uint8_t *depth;                            // [U] by sorted position s: first block the chain computes itself (0: from row 1)
   int32_t *parent;                           // [U] s of the chain whose saved state it starts from (-1: none)
@@ -156,28 +158,58 @@ struct TrieArgs {
   int32_t *nn;                               // [U + 1] saved states of the chain (popcount of mask)
   unsigned long long *counters;              // [0] deepest start, [1] rows the chains skip, [2] rows of all uniques, [3] chains with a parent, [4] keys
 };
-void launch_trie_keycount(const TrieArgs &a, hipStream_t st);  // counters[4] += keys (one per unique and depth)
+void launch_trie_keycount(const TrieArgs &a, hipStream_t st);  // counters[4] (suffix tree: [6]) += keys (one per unique and depth)
 void launch_trie_insert(const TrieArgs &a, hipStream_t st);
 void launch_trie_resolve(const TrieArgs &a, hipStream_t st);
 void launch_trie_link(const TrieArgs &a, hipStream_t st);      // depth / parent final, masks set
 void launch_trie_count(const TrieArgs &a, hipStream_t st);     // nn, counters
-// processing order k: (batch, depth, s) -- batches are ranges of s (bstart[nb + 1]); one pass per depth d
-void launch_share_flag(const uint8_t *depth, int32_t U, int d, int32_t *flag, hipStream_t st);                 // flag[s] = depth[s] == d; flag[U] = 0
-void launch_share_scatter(const uint8_t *depth, int32_t U, int d, const int32_t *pos, const int32_t *bstart, int nb, const int32_t *cursor,
-                          int32_t *uorder, int32_t *inv, hipStream_t st);
-void launch_share_advance(int d, const int32_t *pos, const int32_t *bstart, int nb, int32_t *cursor, int32_t *segk /*[nb][SHARE_SEGS]*/, hipStream_t st);
-void launch_share_cuts(const int32_t *ulen, const int32_t *node0_s, int32_t U, int32_t Uc, int32_t cap, int32_t *cuts /*[cap][2]: s, saved states before s*/,
-                       unsigned long long *n, hipStream_t st);
+void launch_share_cuts(const int32_t *ulen, const int32_t *node0_s, const int32_t *rnode0_s /*nullptr: none*/, int32_t U, int32_t Uc, int32_t cap,
+                       int32_t *cuts /*[cap][3]: s, saved Forward / MSV states before s, saved Backward states before s*/, unsigned long long *n, hipStream_t st);
 struct PairRec;
 void launch_diff_u16(const uint16_t *x, const uint16_t *y, int64_t n, unsigned long long *c, hipStream_t st);
-void launch_diff_scores(const float *x, const float *y, const PairRec *pairs, int64_t n, unsigned long long *c, hipStream_t st);
+void launch_diff_scores(const float *x, const float *y, const PairRec *pairs, int64_t n, const int32_t *jlev /*by useq, or nullptr*/, unsigned long long *c /*[2]*/, hipStream_t st);
+void launch_popc64(const unsigned long long *m, int32_t *out, int64_t n, int64_t nvalid, hipStream_t st);
 constexpr int SHARE_SEGS = 66;             // per batch: first k of depth 0 .. 64, and the batch's end
 struct ShareDev {                          // the tree by processing position k
   uint8_t *depth; int32_t *parent /* k relative to the chunk */; unsigned long long *mask; int32_t *nn, *node0; int32_t *order /* global unique */, *ulen;
   int32_t *src;                            // number of the saved state the chain starts from (-1: from row 1): one coalesced load instead of two gathers
+  // two-sided sharing (round 6), Forward chains: last row the chain computes, the level it joins a saved Backward state at (-1: none; it
+  // then runs to its L) and that state's number
+  int32_t *endrow, *jlev, *jsrc;
 };
 void launch_share_src(const ShareDev &o, int32_t U, int32_t Uc, hipStream_t st);     // after node0 is scanned
-void launch_share_permute(const TrieArgs &a, const int32_t *ulen_s, const int32_t *uorder, const int32_t *inv, const ShareDev &o, hipStream_t st);
+// ---- two-sided sharing (round 6): the suffix tree's links are in rdepth / rparent (TrieArgs::rev = 1, its hash table still alive)
+struct JoinArgs {
+  TrieArgs t;                                // the SUFFIX tree's arguments (rev = 1; depth / parent = rdepth / rparent by sorted position s)
+  const uint8_t *fdepth; const unsigned long long *fmask;     // the prefix tree by s
+  unsigned long long *rmask;                 // [U] bit r: somebody takes this chain's Backward state r blocks from the end
+  int32_t *jlev, *jown;                      // [U] join level (-1: none) and the owner (s) of the Backward state there
+  int32_t *endrow;                           // [U] last row of the Forward chain
+  int32_t *rsteps;                           // [U] rows of the Backward chain (0: it does not run)
+  unsigned long long *counters;              // [10] joins, [11] Forward rows, [12] Backward rows, [13] deepest suffix start among the runners, [14] Backward chains
+};
+void launch_join_resolve(const JoinArgs &a, hipStream_t st);     // jlev / jown, rmask bits of the owners
+void launch_join_up(const JoinArgs &a, int r, hipStream_t st);   // chains that start r blocks from the end and run make their parents save there (r descending)
+void launch_join_ends(const JoinArgs &a, hipStream_t st);        // endrow, rsteps, counters
+// processing orders by a stable radix sort (k_order.hip): key[s] -> order; segk[b][d] = first position with (batch, depth) >= (b, d)
+void launch_order_keys(const uint8_t *depth, const int32_t *minor, const int32_t *runs /*nullptr: all*/, int32_t U, const int32_t *bstart, int nb, unsigned long long *keys, int32_t *vals, hipStream_t st);
+size_t order_sort_bytes(int64_t n);
+int  order_sort(void *tmp, size_t bytes, const unsigned long long *kin, unsigned long long *kout, const int32_t *vin, int32_t *vout, int64_t n, hipStream_t st);
+void launch_order_segk(const unsigned long long *sorted_keys, int32_t n, int nb, int32_t *segk /*[nb][SHARE_SEGS]*/, int32_t *inv /*[U] or nullptr*/, const int32_t *vals, int32_t U, unsigned long long *nvalid, hipStream_t st);
+void launch_share_permute(const TrieArgs &a, const int32_t *ulen_s, const int32_t *uorder, const int32_t *inv, const int32_t *endrow_s, const int32_t *jlev_s,
+                          const ShareDev &o, hipStream_t st);
+struct BShareDev {                         // the Backward chains by backward position kb (round 6): only the uniques that save a state for somebody
+  uint8_t *depth; int32_t *parent /* kb, global */; unsigned long long *mask; int32_t *nn, *node0; int32_t *order /* global unique */, *ulen;
+  int32_t *src;                            // number of the saved Backward state the chain starts from (-1: from row L)
+  int32_t *steps;                          // rows the chain walks (those past L of a chain that starts at the end included)
+};
+void launch_bshare_permute(const TrieArgs &a, int32_t Ub, const int32_t *ulen_s, const int32_t *border_s, const int32_t *invb, const unsigned long long *rmask_s,
+                           const int32_t *rsteps_s, const BShareDev &o, hipStream_t st);
+void launch_bshare_src(const BShareDev &o, int32_t Ub, hipStream_t st);
+void launch_join_src(int32_t U, int32_t B, const int32_t *uorder, const int32_t *jown_s, const int32_t *invb, const BShareDev &ob, const ShareDev &o, int32_t *jownb, hipStream_t st);
+void launch_join_need(const int32_t *jlev, const int32_t *jownb, int32_t U, int32_t W, int32_t cb0, const uint32_t *pass, uint32_t *need_b, hipStream_t st);
+void launch_need_up_b(int r, const uint8_t *rdepth, const int32_t *rparent, int32_t cb0, int32_t Ub, int32_t W, uint32_t *need_b, hipStream_t st);
+void launch_need_res(const uint32_t *need_b, int32_t Ub, int32_t P, int32_t W, uint16_t *res, hipStream_t st);
 // one launch of k_msv / k_fwd_bound over chains that start at the same depth (pointers relative to the chunk)
 struct ShareLaunch {
   const int32_t *src; const unsigned long long *mask; const int32_t *node0;
@@ -185,6 +217,12 @@ struct ShareLaunch {
   int64_t node_base; int32_t p0, Pb;
   int32_t depth, logB;
   float rescale;               // k_fwd_bound: a row's cells are scaled back when its E passes this
+  // two-sided sharing (round 6).  k_fwd_bound: endrow[k] = last row chain k computes (nullptr: every chain runs to its L), jlev[k] = the level
+  // (row jlev * B) at which it takes the rest of the sum over paths from Backward state jsrc[k] of gslots (-1: no join).
+  // k_bwd_bound: src / mask / node0 / slots / node_base describe the BACKWARD chains (by backward position), depth = blocks from the end the
+  // launch's chains start at, endrow[kb] = rows (virtual ones past L included) chain kb walks
+  const int32_t *endrow, *jlev, *jsrc;
+  const void *gslots; int64_t gnode_base;
 };
 constexpr int MSV_STATE_Q = 8;             // 23 packed registers + xJ, xB, xEmax, padded to one 128-byte line
 constexpr int FWD_STATE_Q = 36;            // M, I, D of 46 nodes + xN xJ xC xB + the scale's logarithm (double)
@@ -197,7 +235,8 @@ void launch_share_bounds(const PairRec *pairs, const int64_t *seg_start, const i
 void launch_share_wcount(const int64_t *bnd, int32_t nseg, int32_t P, int32_t *wc, hipStream_t st);            // wc[t * P + p] = waves; wc[nseg * P] = 0
 struct WaveDesc;
 void launch_share_waves(int32_t nw, int32_t nseg, int32_t P, const int32_t *woff, const int64_t *bnd, const int32_t *seg_depth, int32_t B, const PairRec *pairs,
-                        WaveDesc *w, unsigned long long *lane_rows /*[0] rows computed, [1] rows of the pairs*/, hipStream_t st);
+                        const int32_t *endrow /*by useq; nullptr: the pair's L*/, int backward, WaveDesc *w,
+                        unsigned long long *lane_rows /*[64][2], zeroed: rows computed, rows of the pairs (summed by the host)*/, hipStream_t st);
 
 // ---- k_msv.hip
 struct MsvArgs {
@@ -302,6 +341,8 @@ void launch_fwd_bound(const FloatArgs &a, float *fb, int nwaves, int wave0, int 
 void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, hipStream_t st);
 // ... over waves of chains that start at sl.depth (k_share.hip): the rows before come from the parent chain's saved state
 void launch_fwd_bound_share(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st);
+// round 6: the Backward chains of the two-sided schedule (folded units only; rtab: engine.hip, BOUND_RTAB floats per profile)
+void launch_bwd_bound_share(const FloatArgs &a, const float *btab, const float *rtab, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st);
 void launch_bwd_decode(const FloatArgs &a, int nwaves, int wave0, int generic_q, hipStream_t st);
 void launch_decode(const FloatArgs &a, int nwaves, int wave0, hipStream_t st);
 

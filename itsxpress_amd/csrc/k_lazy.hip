@@ -113,9 +113,15 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
   double totscale = 0.0;
   const int row0 = SHARE ? (sl.depth << sl.logB) : 0;       // rows done before this launch (wave-uniform)
   unsigned long long smask = 0ull; int64_t snode = 0;
+  // two-sided sharing (round 6): the chain's last row, and the level at which it takes the rest of the sum over paths from a saved
+  // Backward state (k_bwd_bound) instead of walking on to L
+  int endrow = L, jlev = -1; int64_t jnode = 0;
   if constexpr (SHARE) {
     const int k = pr.useq;
-    if (active) { smask = sl.mask[k]; snode = (int64_t)sl.node0[k] - sl.node_base; }
+    if (active) {
+      smask = sl.mask[k]; snode = (int64_t)sl.node0[k] - sl.node_base;
+      if (sl.endrow) { endrow = sl.endrow[k]; jlev = pr.xj >= 0 ? sl.jlev[k] : -1; jnode = (int64_t)sl.jsrc[k] - sl.gnode_base; }
+    }
     if (sl.depth > 0) {
       const int64_t node = (int64_t)sl.src[k] - sl.node_base;
       const f4 *src = (const f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
@@ -130,12 +136,12 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
   }
   SeqStream ss; ss.open(sq, row0, +1);
   int xnext = ss.get(row0);
-  for (int i = row0 + 1; i <= Lw; i++) {
+  for (int i = row0 + 1; ; i++) {
     if constexpr (SHARE) {
       // a block boundary: the state after row i - 1 = d * B is what a chain that branches off there starts from
-      if (((i - 1) & ((1 << sl.logB) - 1)) == 0 && i - 1 > row0) {
+      if (((i - 1) & ((1 << sl.logB) - 1)) == 0) {
         const int d = (i - 1) >> sl.logB;
-        if (d < 64 && ((smask >> d) & 1ull) && i <= L) {
+        if (d < 64 && ((smask >> d) & 1ull) && i - 1 > row0) {           // (a mask has no bit above the chain's last level)
           const int64_t node = snode + __popcll(smask & ((1ull << d) - 1ull));
           f4 *dst = (f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
 #pragma unroll
@@ -146,9 +152,28 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
           dst[BP + BP / 2] = (f4){D[BP - 1].x, D[BP - 1].y, xN, xJ};
           dst[BP + BP / 2 + 1] = (f4){xC, xB, ts.x, ts.y};
         }
+        if (d == jlev) {
+          // the join: every path crosses the cut after row d * B in exactly one of M_k, I_k, D_k, N, J, C, B -- the score is the inner
+          // product of the Forward state with the suffix's Backward state (same layout, dual units: k_bwd_bound), plus both scales
+          const f4 *g = (const f4 *)sl.gslots + (jnode * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
+          f2 sa = (f2){0.f, 0.f}, sb = (f2){0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < BP; j++) { const f4 v = g[j]; sa = pfma(M[j], (f2){v.x, v.y}, sa); sb = pfma(I[j], (f2){v.z, v.w}, sb); }
+#pragma unroll
+          for (int j = 0; j < BP / 2; j++) { const f4 v = g[BP + j]; sa = pfma(D[2 * j], (f2){v.x, v.y}, sa); sb = pfma(D[2 * j + 1], (f2){v.z, v.w}, sb); }
+          const f4 u = g[BP + BP / 2], t = g[BP + BP / 2 + 1];
+          sa = pfma(D[BP - 1], (f2){u.x, u.y}, sa);
+          sb = pfma((f2){xN, xJ}, (f2){u.z, u.w}, sb);
+          sa = pfma((f2){xC, xB}, (f2){t.x, t.y}, sa);
+          const float dot = (sa.x + sa.y) + (sb.x + sb.y);
+          const double gscale = __builtin_bit_cast(double, (f2){t.z, t.w});
+          const bool jbad = (dot != dot) || (dot <= 0.0f) || (dot == __builtin_inff());
+          fb[pi] = jbad ? __builtin_nanf("") : (float)(totscale + gscale + det_log((double)dot));
+        }
       }
     }
-    if (i <= L) {
+    if (i > Lw) break;
+    if (i <= endrow) {
       const int x = xnext;
       if (i < L) xnext = ss.get(i);
       const float *ex = en + x * (2 * BP);
@@ -231,7 +256,155 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
     }
   }
   const bool bad = (xC != xC) || (xC == 0.0f) || (xC == __builtin_inff());
-  if (active) fb[pi] = bad ? __builtin_nanf("") : (float)(totscale + det_log((double)(xC * pmove)));
+  if (active && jlev < 0) fb[pi] = bad ? __builtin_nanf("") : (float)(totscale + det_log((double)(xC * pmove)));
+}
+
+// =========================================================================================
+// Round 6, two-sided sharing: the BACKWARD half of pass A's sum over paths.  One Forward row is a linear map of the row state
+// (M~, I^, D^ of 46 nodes, N, J, C, B: k_fwd_bound's folded units); the score is a linear functional of the last row's state (C times
+// the move out).  Pulled back through the rows L, L - 1, ..., j B + 1 -- the TRANSPOSED maps, applied in that order -- it becomes a
+// vector gamma_j with   score = < Forward state after row j B, gamma_j >   for EVERY prefix, and gamma_j depends on the profile, the
+// target's length and the residues after row j B only: the uniques of one length that end alike share it.  This kernel walks a
+// Backward chain (lane = chain x profile, wave = 64 chains of one (batch, blocks-from-the-end) segment) and saves gamma at the block
+// boundaries where somebody joins (k_share.hip: k_join_*), in k_fwd_bound's state layout, so that the join is 72 packed multiply-adds.
+// The transposed row, with a' = adjoint of the new row's cell and x the row's residue:
+//     nJ = gJ + move gB,  nN = gN + move gB,  aE = (nJ + gC) / 2
+//     aD_k = gD_k + dd_k aD_k+1,   aM_k = gM_k + aE + aD_k+1,   w_k = e_k(x) aM_k                  (k = 46 .. 1, aD_47 = w_47 = 0)
+//     gM_k <- mm_k w_k+1 + gI_k,   gI_k <- im_k w_k+1 + ii_k gI_k,   gD_k <- dm_k w_k+1,   gB <- sum_k bm_k w_k
+//     gN <- loop nN,  gJ <- loop nJ,  gC <- loop gC
+// (the same table entries as the Forward kernel's, by pair of nodes: engine.hip builds rtab).  The cells are kept below ~1e6 by a sum test
+// every 16 rows (block boundaries are multiples of 16), the scale's logarithm travels with the state like Forward's.
+struct RT { f2 mm, im, dm, ii, bm, aa; };
+DEV RT ldrt(const float *tab, int j)
+{
+  const f4 a = *(cf4q)(uintptr_t)(tab + j * 12), b = *(cf4q)(uintptr_t)(tab + j * 12 + 4), c = *(cf4q)(uintptr_t)(tab + j * 12 + 8);
+  RT t;
+  t.mm = (f2){a.x, a.y}; t.im = (f2){a.z, a.w}; t.dm = (f2){b.x, b.y}; t.ii = (f2){b.z, b.w}; t.bm = (f2){c.x, c.y}; t.aa = (f2){c.z, c.w};
+  return t;
+}
+__global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int wave0, int nwaves, const float *__restrict__ btab, const float *__restrict__ rtab, ShareLaunch sl)
+{
+  const int wv = threadIdx.x >> 6, widx = blockIdx.x * FWD_WPB + wv;
+  WaveDesc wd = a.waves[wave0 + min(widx, nwaves - 1)];
+  if (widx >= nwaves) { wd.count = 0; wd.rows = 1; }
+  const int lane = threadIdx.x & 63;
+  const int prof = uni(wd.prof);
+  const DevProfile *pp = a.prof + prof;
+  __shared__ __attribute__((aligned(16))) float en_all[FWD_WPB][NCODE * 2 * BP];
+  float *en = en_all[wv];
+  const float *tab = rtab + (size_t)prof * BOUND_RTAB;
+  {
+    const int Q = uni(pp->Q);
+    const float *g = btab + (size_t)prof * BOUND_TAB + (BP + 1) * 16;      // the match cells' scale by node (the Forward kernel's folded units)
+    for (int i = lane; i < NCODE * 2 * BP; i += 64) {
+      const int x = i / (2 * BP), k0 = i % (2 * BP);
+      const float e = (k0 < 4 * Q) ? pp->rf[(x * QMAX + (k0 % Q)) * 4 + k0 / Q] : 0.0f;
+      en[i] = e * g[k0];
+    }
+    __syncthreads();
+  }
+  const bool active = lane < wd.count;
+  const int64_t pi = wd.first + (active ? lane : 0);
+  const PairRec pr = a.pairs[pi];
+  const int L = pr.L;
+  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  const int nsteps = wd.rows - 1;                             // the wave's longest chain
+  f2 M[BP], I[BP], D[BP];
+#pragma unroll
+  for (int j = 0; j < BP; j++) { M[j] = (f2){0.f, 0.f}; I[j] = (f2){0.f, 0.f}; D[j] = (f2){0.f, 0.f}; }
+  const float pmove = (2.0f + 1.0f) / ((float)L + 2.0f + 1.0f);
+  const float ploop = 1.0f - pmove;
+  float xN = 0.f, xJ = 0.f, xB = 0.f, xC = pmove;             // gamma after the last row: the score is C times the move out
+  double totscale = 0.0;
+  const int kb = pr.useq;
+  const int rd = sl.depth;                                    // blocks from the end the launch's chains start at (wave-uniform)
+  unsigned long long smask = 0ull; int64_t snode = 0; int mysteps = 0;
+  if (active) { smask = sl.mask[kb]; snode = (int64_t)sl.node0[kb] - sl.node_base; mysteps = sl.endrow[kb]; }
+  if (rd > 0) {
+    const int64_t node = (int64_t)sl.src[kb] - sl.node_base;
+    const f4 *src = (const f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
+#pragma unroll
+    for (int j = 0; j < BP; j++) { const f4 v = src[j]; M[j] = (f2){v.x, v.y}; I[j] = (f2){v.z, v.w}; }
+#pragma unroll
+    for (int j = 0; j < BP / 2; j++) { const f4 v = src[BP + j]; D[2 * j] = (f2){v.x, v.y}; D[2 * j + 1] = (f2){v.z, v.w}; }
+    const f4 u = src[BP + BP / 2], t = src[BP + BP / 2 + 1];
+    D[BP - 1] = (f2){u.x, u.y}; xN = u.z; xJ = u.w; xC = t.x; xB = t.y;
+    totscale = __builtin_bit_cast(double, (f2){t.z, t.w});
+  }
+  const int A = (L + (1 << sl.logB) - 1) >> sl.logB;
+  const int top = (A - rd) << sl.logB;                        // the row the chain's state stands after (virtual when rd = 0 and L is no multiple of B)
+  const int first = top < L ? top : L;
+  SeqStream ss; ss.open(sq, first > 0 ? first - 1 : 0, -1);
+  int xnext = first > 0 ? ss.get(first - 1) : 0;
+  for (int step = 0; ; step++) {
+    if ((step & ((1 << sl.logB) - 1)) == 0 && step > 0) {
+      // a block boundary: gamma after row top - step = (A - rdl) B is what the Forward chains that end there take
+      const int rdl = rd + (step >> sl.logB);
+      if (active && rdl < 64 && ((smask >> rdl) & 1ull)) {
+        const int64_t node = snode + __popcll(smask & ((1ull << rdl) - 1ull));
+        f4 *dst = (f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
+#pragma unroll
+        for (int j = 0; j < BP; j++) dst[j] = (f4){M[j].x, M[j].y, I[j].x, I[j].y};
+#pragma unroll
+        for (int j = 0; j < BP / 2; j++) dst[BP + j] = (f4){D[2 * j].x, D[2 * j].y, D[2 * j + 1].x, D[2 * j + 1].y};
+        const f2 ts = __builtin_bit_cast(f2, totscale);
+        dst[BP + BP / 2] = (f4){D[BP - 1].x, D[BP - 1].y, xN, xJ};
+        dst[BP + BP / 2 + 1] = (f4){xC, xB, ts.x, ts.y};
+      }
+    }
+    if (step >= nsteps) break;
+    const int row = top - step;                               // this step pulls gamma back through row `row`
+    if (row <= L && step < mysteps) {
+      const int x = xnext;
+      if (row > 1) xnext = ss.get(row - 2);
+      const float *ex = en + x * (2 * BP);
+      const float *tb = tab + opaque_zero();
+      const float gb0 = xB * pmove;
+      const float nJ = xJ + gb0, nN = xN + gb0;
+      const float aE = 0.5f * (nJ + xC);
+      const f2 aEv = (f2){aE, aE};
+      float aDn = 0.0f, wn = 0.0f;                            // aD and w of the node after the pair
+      f2 accB = (f2){0.f, 0.f};
+#pragma unroll
+      for (int j = BP - 1; j >= 0; j--) {
+        const RT t = ldrt(tb, j);
+        const f2 e = *(const f2 *)(ex + 2 * j);
+        const float aD2 = __builtin_fmaf(t.aa.y, aDn, D[j].y);
+        const f2 aM = (M[j] + aEv) + (f2){aD2, aDn};
+        const float aD1 = __builtin_fmaf(t.aa.x, aD2, D[j].x);
+        const f2 w = aM * e;
+        accB = pfma(t.bm, w, accB);
+        const f2 wsh = (f2){w.y, wn};                         // w of the node after each of the pair's two
+        const f2 gi = I[j];
+        M[j] = pfma(t.mm, wsh, gi);
+        I[j] = pfma(t.im, wsh, t.ii * gi);
+        D[j] = t.dm * wsh;
+        aDn = aD1; wn = w.x;
+      }
+      xB = accB.x + accB.y;
+      xN = ploop * nN; xJ = ploop * nJ; xC = ploop * xC;
+    }
+    if ((step & 15) == 15) {
+      f2 sm = (f2){0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < BP; j++) sm = sm + ((M[j] + I[j]) + D[j]);
+      const float tot = (sm.x + sm.y) + ((xN + xJ) + (xC + xB));
+      if (tot > 1e6f || (tot < 1e-6f && tot > 0.0f)) {
+        const float r = 1.0f / tot;
+        const f2 rv = (f2){r, r};
+#pragma unroll
+        for (int j = 0; j < BP; j++) { M[j] = M[j] * rv; I[j] = I[j] * rv; D[j] = D[j] * rv; }
+        xN *= r; xJ *= r; xC *= r; xB *= r;
+        totscale += det_log((double)tot);
+      }
+    }
+  }
+}
+void launch_bwd_bound_share(const FloatArgs &a, const float *btab, const float *rtab, int nwaves, int wave0, const ShareLaunch &sl, hipStream_t st)
+{
+  if (nwaves <= 0) return;
+  const dim3 g((nwaves + FWD_WPB - 1) / FWD_WPB), b(64 * FWD_WPB);
+  hipLaunchKernelGGL(k_bwd_bound, g, b, 0, st, a, wave0, nwaves, btab, rtab, sl);
 }
 
 // 1e20 by default (ITSX_BOUND_RESCALE_EXP: another power of ten, for A/B; at most 28 -- the folded cells must stay inside float)

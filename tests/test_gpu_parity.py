@@ -27,7 +27,7 @@ def _its2_subset(hmm_text, n3=None, n4=None):
 
 # --------------------------------------------------------------------------------------------
 def test_library_loads_and_reports_device(engine):
-    assert engine.L.itsx_abi_version() == 5
+    assert engine.L.itsx_abi_version() == 6
 
 
 def test_detmath_device_matches_oracle_bitwise(engine):

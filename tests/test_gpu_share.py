@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(engine, hmm, seqs, mode, env, monkeypatch, names=None):
-    for k in ("ITSX_SHARE", "ITSX_SHARE_B", "ITSX_SHARE_GB", "ITSX_SHARE_MIN", "ITSX_SHARE_CHECK", "ITSX_CHUNK_UNIQUES", "ITSX_SHARE_FWD_STREAMS"):
+    for k in ("ITSX_SHARE", "ITSX_SHARE_B", "ITSX_SHARE_GB", "ITSX_SHARE_MIN", "ITSX_SHARE_CHECK", "ITSX_CHUNK_UNIQUES", "ITSX_SHARE_FWD_STREAMS", "ITSX_SHARE_TWO"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -54,7 +54,8 @@ def test_shared_schedule_is_bitwise_the_unshared_one(engine, t_hmm_text, monkeyp
     assert st["n_past_msv"] == st0["n_past_msv"] and st["n_pairs"] == st0["n_pairs"]
     if mode == "lazy":
         assert 0 < st["bound_rows"] < 0.85 * st["bound_rows_full"]
-        assert st["n_lazy_evaluated"] == st0["n_lazy_evaluated"]
+        # (a joined pair's bound is the same sum over paths in another order of operations: a tenth may round the other way for a few)
+        assert abs(st["n_lazy_evaluated"] - st0["n_lazy_evaluated"]) <= (0 if not st["two_sided"] else 1e-3 * st0["n_lazy_evaluated"] + 2)
     assert _same(ref, got)
 
 

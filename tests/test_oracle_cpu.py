@@ -295,7 +295,7 @@ def test_cabi_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.itsx_abi_version() == _lib.ABI_VERSION == 5
+    assert L.itsx_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_engine_fails_loudly_without_a_gpu():

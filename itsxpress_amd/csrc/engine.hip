@@ -276,7 +276,8 @@ struct itsx_ctx {
   DBuf<DevProfile> d_prof;
   DBuf<uint32_t> d_etab;
   DBuf<int32_t> d_pbias, d_ptec, d_ptbm;
-  DBuf<float> d_rtab;                      // k_bwd_bound's table (round 6: two-sided sharing)
+  DBuf<float> d_rtab, d_entab;             // k_bwd_bound's table; the folded emission odds by node (round 6: two-sided sharing)
+  DBuf<ChainRec> sh_chain, sh_bchain;      // the chains' records by processing position (Forward / Backward)
   DBuf<float> d_flogsum; DBuf<LogTab> d_logtab; DBuf<float> d_btab; bool bound_fold = false;   // (the bound kernel's table, and whether it is the folded one)
   std::vector<char> generic_q;          // per profile: needs the runtime-Q kernels
 
@@ -669,6 +670,19 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
       }
     }
     HIPCHK(upload(ctx->d_rtab, rt, ctx->st));
+    // the folded emission odds by node, [code][k - 1]: what both kernels keep in LDS
+    std::vector<float> et((size_t)std::max(P, 1) * NCODE * KK, 0.0f);
+    for (int i = 0; i < P && fold; i++) {
+      const DevProfile &d = dp[i];
+      const int Q = ctx->profs[i].Q;
+      const float *gq = bt.data() + (size_t)i * BOUND_TAB + (size_t)(BOUND_PAIRS + 1) * 16;
+      for (int x = 0; x < NCODE; x++)
+        for (int k0 = 0; k0 < KK; k0++) {
+          const float e = (k0 < 4 * Q) ? d.rf[(x * QMAX + (k0 % Q)) * 4 + k0 / Q] : 0.0f;
+          et[((size_t)i * NCODE + x) * KK + k0] = e * gq[k0];
+        }
+    }
+    HIPCHK(upload(ctx->d_entab, et, ctx->st));
   }
   HIPCHK(upload(ctx->d_prof, dp, ctx->st));
   HIPCHK(upload(ctx->d_etab, etab, ctx->st));
@@ -1749,6 +1763,9 @@ static int build_share(itsx_ctx *ctx)
     launch_exclusive_scan(ctx->sh_rnn.p, ctx->sh_rnode0.p, (int64_t)Ub + 1, ctx->sh_scan.p, st);
     launch_bshare_src(ob, Ub, st);
     launch_join_src(U, B, ctx->sh_uorder.p, ctx->sh_jown_s.p, ctx->sh_invb.p, ob, o, ctx->sh_jownb.p, st);
+    HIPCHK(ctx->sh_chain.alloc((size_t)U + 1)); HIPCHK(ctx->sh_bchain.alloc((size_t)Ub + 1));
+    launch_chain_recs(U, ctx->rd, o.order, ctx->d_seed_read.p, o.src, o.node0, o.mask, o.endrow, o.jlev, o.jsrc, ctx->sh_chain.p, st);
+    launch_chain_recs(Ub, ctx->rd, ob.order, ctx->d_seed_read.p, ob.src, ob.node0, ob.mask, ob.steps, nullptr, nullptr, ctx->sh_bchain.p, st);
   }
   HIPCHK(hipStreamSynchronize(st));
   // ---- slots of the saved states: the largest batch's, for the MSV filter and for the Forward pass
@@ -2652,6 +2669,20 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       }
     }
     HIPCHK(hipMemcpyAsync(lr.data(), ctx->w_counters.p, 256 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    // diagnostic (scripts/passa_launches.py): every launch's waves and wave-rows, in launch order, to set against a kernel trace
+    std::vector<WaveDesc> dumpf, dumpb;
+    const bool dump = getenv("ITSX_PASSA_DUMP") != nullptr;
+    if (dump) {
+      dumpf.resize((size_t)std::max(NW, 1)); dumpb.resize((size_t)std::max(NWB, 1));
+      HIPCHK(hipMemcpyAsync(dumpf.data(), ctx->w_waves.p, (size_t)NW * sizeof(WaveDesc), hipMemcpyDeviceToHost, st));
+      if (NWB > 0) HIPCHK(hipMemcpyAsync(dumpb.data(), ctx->sh_bwaves.p, (size_t)NWB * sizeof(WaveDesc), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    auto dump_launch = [&](const char *what, int batch, int d, int w0, int w1, const std::vector<WaveDesc> &wv, int row0) {
+      int64_t rows = 0, mx = 0, lanes = 0;
+      for (int w = w0; w < w1; w++) { const int64_t r = wv[(size_t)w].rows - 1 - row0; rows += r; mx = std::max(mx, r); lanes += wv[(size_t)w].count; }
+      fprintf(stderr, "[passa] %s batch %d depth %d waves %d wave_rows %lld max_rows %lld lanes %lld\n", what, batch, d, w1 - w0, (long long)rows, (long long)mx, (long long)lanes);
+    };
     StageTimer tm(st);
     // (batches are independent: every other one on a second stream with its own half of the slot buffer, so that a launch's tail --
     // the next depth waits for its last waves -- is filled by the other batch's waves)
@@ -2683,6 +2714,8 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
             ShareLaunch sl{};
             sl.src = ctx->sh_rsrc.p + cb0; sl.mask = ctx->sh_rmask.p + cb0; sl.node0 = ctx->sh_rnode0.p + cb0; sl.endrow = ctx->sh_bsteps.p + cb0;
             sl.slots = gsl; sl.node_base = b.gnode0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
+            sl.chain = ctx->sh_bchain.p + cb0; sl.entab = ctx->d_entab.p;
+            if (dump) dump_launch("bwd", t0 / DS, d, w0, w1, dumpb, 0);
             for (int w = w0; w < w1; w += 1 << 20) { launch_bwd_bound_share(ab, ctx->d_btab.p, ctx->d_rtab.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bwd_launches++; }
           }
         for (int d = 0; d < DS; d++) {
@@ -2692,7 +2725,12 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
           ShareLaunch sl{};
           sl.src = ctx->sh_src.p + u0; sl.mask = ctx->sh_mask.p + u0; sl.node0 = ctx->sh_node0.p + u0;
           sl.slots = fsl; sl.node_base = b.node0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
-          if (two) { sl.endrow = ctx->sh_endrow.p + u0; sl.jlev = ctx->sh_jlev.p + u0; sl.jsrc = ctx->sh_jsrc.p + u0; sl.gslots = gsl; sl.gnode_base = b.gnode0; }
+          if (two) {
+            sl.endrow = ctx->sh_endrow.p + u0; sl.jlev = ctx->sh_jlev.p + u0; sl.jsrc = ctx->sh_jsrc.p + u0; sl.gslots = gsl; sl.gnode_base = b.gnode0;
+            if (!getenv("ITSX_NO_CHAINREC")) { sl.chain = ctx->sh_chain.p + u0; sl.entab = ctx->d_entab.p; }
+            if (getenv("ITSX_TEST_HOOKS") && getenv("ITSX_PASSA_DBG")) sl.dbg = atoi(getenv("ITSX_PASSA_DBG"));
+          }
+          if (dump) dump_launch("fwd", t0 / DS, d, w0, w1, dumpf, d << ctx->share_logB);
           for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->bound_fold, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bound_launches++; }
         }
       }

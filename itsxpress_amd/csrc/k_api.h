@@ -223,7 +223,22 @@ struct ShareLaunch {
   // launch's chains start at, endrow[kb] = rows (virtual ones past L included) chain kb walks
   const int32_t *endrow, *jlev, *jsrc;
   const void *gslots; int64_t gnode_base;
+  // everything a lane needs of its chain in ONE 64-byte record by processing position (k_fwd_bound: by k; k_bwd_bound: by kb) instead of a
+  // chain of dependent loads (pair -> sorted position -> read -> offsets): a wave's start-up was 30 rows' worth of latency
+  const struct ChainRec *chain;
+  const float *entab;          // [P][NCODE][2 * BOUND_PAIRS] the folded emission odds by node (engine.hip: install_profiles)
+  int32_t dbg;                 // diagnostic (ITSX_TEST_HOOKS=1 ITSX_PASSA_DBG=bits; results are garbage): 1 no rows, 2 no restore, 4 no join
 };
+struct alignas(16) ChainRec {
+  int64_t woff, excoff;        // the read's packed words / exceptions
+  int32_t nexc, L, src, node0; // src: saved state the chain starts from; node0: first of its own saved states
+  unsigned long long mask;     // levels it saves at
+  int32_t endrow;              // Forward: last row; Backward: rows it walks
+  int32_t jlev, jsrc, pad;     // Forward: join level (-1: none) and the Backward state joined
+};
+static_assert(sizeof(ChainRec) == 64, "k_fwd_bound / k_bwd_bound read a chain's record as four 16-byte loads");
+void launch_chain_recs(int32_t n, const ReadsDev &rd, const int32_t *order /*global unique by position*/, const int32_t *seed_read, const int32_t *src, const int32_t *node0,
+                       const unsigned long long *mask, const int32_t *endrow, const int32_t *jlev, const int32_t *jsrc, ChainRec *out, hipStream_t st);
 constexpr int MSV_STATE_Q = 8;             // 23 packed registers + xJ, xB, xEmax, padded to one 128-byte line
 constexpr int FWD_STATE_Q = 36;            // M, I, D of 46 nodes + xN xJ xC xB + the scale's logarithm (double)
 // lazy searches only: a chain whose own pair failed the MSV filter still has to run for a profile when a chain below it needs its state

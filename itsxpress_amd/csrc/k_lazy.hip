@@ -67,7 +67,10 @@ DEV f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // operands in the same order as the chain's unshared run: the scores are bitwise equal (tests/test_gpu_share.py).
 // A block is FWD_WPB consecutive waves of the work list -- the same profile but at a run's end -- so that the waves a CU holds at one time
 // read one or two profiles' transition tables through its scalar cache, not eight (SQC_DCACHE_MISSES: 5e)
-constexpr int FWD_WPB = 4;
+#ifndef ITSX_FWD_WPB
+#define ITSX_FWD_WPB 1
+#endif
+constexpr int FWD_WPB = ITSX_FWD_WPB;
 // FOLD (engine.hip: install_profiles builds the table for it; every profile whose interior M->D transitions are all > 0, i.e. every
 // profile hmmbuild writes): the delete cells are kept DIVIDED by s_k = t(M_k-1 -> D_k) / g_k-1 and the match cells MULTIPLIED by
 // g_k = 1 + the share of M_k that the deletes after it carry into E -- constants of the profile, folded into its transitions and
@@ -88,7 +91,20 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
   __shared__ __attribute__((aligned(16))) float en_all[FWD_WPB][NCODE * 2 * BP];
   float *en = en_all[wv];
   const float *tab = btab + (size_t)prof * BOUND_TAB;
-  {
+  const bool active = lane < wd.count;
+  const int64_t pi = wd.first + (active ? lane : 0);
+  const PairRec pr = a.pairs[pi];
+  const int L = pr.L;
+  // (two-sided schedule: the chain's record -- one 64-byte load instead of four dependent ones -- and the folded emission table as it
+  // stands in memory; each wave fills and reads its OWN copy, so the wave's own order of LDS operations is all the fence it needs)
+  const bool recs = SHARE && sl.chain != nullptr;
+  ChainRec cr{};
+  if (recs) { const f4 *q = (const f4 *)(sl.chain + pr.useq); const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; f4 *o = (f4 *)&cr; o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; }
+  if (FOLD && recs && sl.entab) {
+    const f4 *e4 = (const f4 *)(sl.entab + (size_t)prof * (NCODE * 2 * BP));
+    for (int i = lane; i < NCODE * 2 * BP / 4; i += 64) ((f4 *)en)[i] = e4[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
     const int Q = uni(pp->Q);
     const float *g = tab + (BP + 1) * 16;                      // FOLD: the match cells' scale by node
     for (int i = lane; i < NCODE * 2 * BP; i += 64) {
@@ -98,12 +114,10 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
     }
     __syncthreads();
   }
-  const bool active = lane < wd.count;
-  const int64_t pi = wd.first + (active ? lane : 0);
-  const PairRec pr = a.pairs[pi];
-  const int L = pr.L;
-  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
-  const int Lw = wd.rows - 1;
+  Seq sq;
+  if (recs) { sq.w = a.rd.words + cr.woff; sq.exc = a.rd.exc + cr.excoff; sq.nexc = cr.nexc; sq.L = cr.L; }
+  else sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  int Lw = wd.rows - 1;
   f2 M[BP], I[BP], D[BP];
 #pragma unroll
   for (int j = 0; j < BP; j++) { M[j] = (f2){0.f, 0.f}; I[j] = (f2){0.f, 0.f}; D[j] = (f2){0.f, 0.f}; }
@@ -119,11 +133,18 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
   if constexpr (SHARE) {
     const int k = pr.useq;
     if (active) {
-      smask = sl.mask[k]; snode = (int64_t)sl.node0[k] - sl.node_base;
-      if (sl.endrow) { endrow = sl.endrow[k]; jlev = pr.xj >= 0 ? sl.jlev[k] : -1; jnode = (int64_t)sl.jsrc[k] - sl.gnode_base; }
+      if (recs) {
+        smask = cr.mask; snode = (int64_t)cr.node0 - sl.node_base;
+        endrow = cr.endrow; jlev = pr.xj >= 0 ? cr.jlev : -1; jnode = (int64_t)cr.jsrc - sl.gnode_base;
+      } else {
+        smask = sl.mask[k]; snode = (int64_t)sl.node0[k] - sl.node_base;
+        if (sl.endrow) { endrow = sl.endrow[k]; jlev = pr.xj >= 0 ? sl.jlev[k] : -1; jnode = (int64_t)sl.jsrc[k] - sl.gnode_base; }
+      }
     }
-    if (sl.depth > 0) {
-      const int64_t node = (int64_t)sl.src[k] - sl.node_base;
+    if (sl.dbg & 1) Lw = row0;
+    if (sl.dbg & 4) jlev = -1;
+    if (sl.depth > 0 && !(sl.dbg & 2)) {
+      const int64_t node = (int64_t)(recs ? cr.src : sl.src[k]) - sl.node_base;
       const f4 *src = (const f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
 #pragma unroll
       for (int j = 0; j < BP; j++) { const f4 v = src[j]; M[j] = (f2){v.x, v.y}; I[j] = (f2){v.z, v.w}; }
@@ -293,21 +314,19 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int 
   __shared__ __attribute__((aligned(16))) float en_all[FWD_WPB][NCODE * 2 * BP];
   float *en = en_all[wv];
   const float *tab = rtab + (size_t)prof * BOUND_RTAB;
-  {
-    const int Q = uni(pp->Q);
-    const float *g = btab + (size_t)prof * BOUND_TAB + (BP + 1) * 16;      // the match cells' scale by node (the Forward kernel's folded units)
-    for (int i = lane; i < NCODE * 2 * BP; i += 64) {
-      const int x = i / (2 * BP), k0 = i % (2 * BP);
-      const float e = (k0 < 4 * Q) ? pp->rf[(x * QMAX + (k0 % Q)) * 4 + k0 / Q] : 0.0f;
-      en[i] = e * g[k0];
-    }
-    __syncthreads();
-  }
+  (void)pp; (void)btab;
   const bool active = lane < wd.count;
   const int64_t pi = wd.first + (active ? lane : 0);
   const PairRec pr = a.pairs[pi];
   const int L = pr.L;
-  const Seq sq = open_seq(a.rd, a.seed_read[a.sorted_uniq[pr.useq]]);
+  ChainRec cr;
+  { const f4 *q = (const f4 *)(sl.chain + pr.useq); const f4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3]; f4 *o = (f4 *)&cr; o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3; }
+  {
+    const f4 *e4 = (const f4 *)(sl.entab + (size_t)prof * (NCODE * 2 * BP));
+    for (int i = lane; i < NCODE * 2 * BP / 4; i += 64) ((f4 *)en)[i] = e4[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  Seq sq; sq.w = a.rd.words + cr.woff; sq.exc = a.rd.exc + cr.excoff; sq.nexc = cr.nexc; sq.L = cr.L;
   const int nsteps = wd.rows - 1;                             // the wave's longest chain
   f2 M[BP], I[BP], D[BP];
 #pragma unroll
@@ -319,9 +338,10 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int 
   const int kb = pr.useq;
   const int rd = sl.depth;                                    // blocks from the end the launch's chains start at (wave-uniform)
   unsigned long long smask = 0ull; int64_t snode = 0; int mysteps = 0;
-  if (active) { smask = sl.mask[kb]; snode = (int64_t)sl.node0[kb] - sl.node_base; mysteps = sl.endrow[kb]; }
+  (void)kb;
+  if (active) { smask = cr.mask; snode = (int64_t)cr.node0 - sl.node_base; mysteps = cr.endrow; }
   if (rd > 0) {
-    const int64_t node = (int64_t)sl.src[kb] - sl.node_base;
+    const int64_t node = (int64_t)cr.src - sl.node_base;
     const f4 *src = (const f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
 #pragma unroll
     for (int j = 0; j < BP; j++) { const f4 v = src[j]; M[j] = (f2){v.x, v.y}; I[j] = (f2){v.z, v.w}; }

@@ -398,6 +398,23 @@ void launch_bshare_permute(const TrieArgs &a, int32_t Ub, const int32_t *ulen_s,
 {
   hipLaunchKernelGGL(k_bshare_permute, dim3((Ub + 1 + 255) / 256), dim3(256), 0, st, a, Ub, ulen_s, border_s, invb, rmask_s, rsteps_s, o);
 }
+__global__ void __launch_bounds__(256) k_chain_recs(int32_t n, ReadsDev rd, const int32_t *__restrict__ order, const int32_t *__restrict__ seed_read, const int32_t *__restrict__ src,
+                                                    const int32_t *__restrict__ node0, const unsigned long long *__restrict__ mask, const int32_t *__restrict__ endrow,
+                                                    const int32_t *__restrict__ jlev, const int32_t *__restrict__ jsrc, ChainRec *__restrict__ out)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int r = seed_read[order[k]];
+  ChainRec c;
+  c.woff = rd.woff[r]; c.excoff = rd.excoff[r]; c.nexc = (int32_t)(rd.excoff[r + 1] - c.excoff); c.L = rd.len[r];
+  c.src = src[k]; c.node0 = node0[k]; c.mask = mask[k]; c.endrow = endrow[k]; c.jlev = jlev ? jlev[k] : -1; c.jsrc = jsrc ? jsrc[k] : -1; c.pad = 0;
+  out[k] = c;
+}
+void launch_chain_recs(int32_t n, const ReadsDev &rd, const int32_t *order, const int32_t *seed_read, const int32_t *src, const int32_t *node0, const unsigned long long *mask,
+                       const int32_t *endrow, const int32_t *jlev, const int32_t *jsrc, ChainRec *out, hipStream_t st)
+{
+  if (n > 0) hipLaunchKernelGGL(k_chain_recs, dim3((n + 255) / 256), dim3(256), 0, st, n, rd, order, seed_read, src, node0, mask, endrow, jlev, jsrc, out);
+}
 void launch_bshare_src(const BShareDev &o, int32_t Ub, hipStream_t st) { if (Ub > 0) hipLaunchKernelGGL(k_bshare_src, dim3((Ub + 255) / 256), dim3(256), 0, st, o, Ub); }
 void launch_join_src(int32_t U, int32_t B, const int32_t *uorder, const int32_t *jown_s, const int32_t *invb, const BShareDev &ob, const ShareDev &o, int32_t *jownb, hipStream_t st)
 {

@@ -558,7 +558,7 @@ def main():
         torch.cuda.synchronize()
         del os.environ["ITSX_MSV_OVERLAP"]
         sa = eng.stats()
-        alone = {"k_msv": sa["ms_msv_kernel"], "k_fwd_bound": sa["ms_bound_kernel"], "k_filters_fwd": sa["ms_fwd_kernel"], "k_bwd_decode": sa["ms_bwd_kernel"],
+        alone = {"k_msv": sa["ms_msv_kernel"], "k_fwd_bound": sa["ms_bound_kernel"] - sa.get("ms_bwd_bound", 0.0), "k_bwd_bound": sa.get("ms_bwd_bound", 0.0), "k_filters_fwd": sa["ms_fwd_kernel"], "k_bwd_decode": sa["ms_bwd_kernel"],
                  "k_decode": sa["ms_decode_kernel"], "k_env_fwd+k_env_bwd+k_env_post": sa["ms_env_kernel"]}
         if use_dist:
             dist.barrier()
@@ -657,9 +657,10 @@ def main():
         total_reads = total_local * args.steps
         value = total_reads / dt
         K = args.steps
-        kern = {"k_msv": acc["ms_msv_kernel"] / K, "k_fwd_bound": acc.get("ms_bound_kernel", 0.0) / K, "k_filters_fwd": acc["ms_fwd_kernel"] / K,
+        # (two-sided sharing, round 6: ms_bound_kernel is pass A's wall time; ms_bwd_bound the share of its Backward chains, k_bwd_bound)
+        kern = {"k_msv": acc["ms_msv_kernel"] / K, "k_fwd_bound": (acc.get("ms_bound_kernel", 0.0) - acc.get("ms_bwd_bound", 0.0)) / K, "k_filters_fwd": acc["ms_fwd_kernel"] / K,
                 "k_bwd_decode": acc["ms_bwd_kernel"] / K, "k_decode": acc["ms_decode_kernel"] / K,
-                "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K}
+                "k_env_fwd+k_env_bwd+k_env_post": acc["ms_env_kernel"] / K, "k_bwd_bound": acc.get("ms_bwd_bound", 0.0) / K}
         dom = max(kern, key=kern.get)
         # algorithmic HBM bytes of each main kernel, per step; L = the mean read length
         U, wbytes = st["n_unique"], 4.0 * ((mean_len + 15) // 16)
@@ -668,6 +669,7 @@ def main():
             "k_msv": U * wbytes + 2 * nprof * U,
             # the lazy stage's score-only Forward: per pair the packed read + the pair record in, 4 B out; nothing per row
             "k_fwd_bound": st["n_past_msv"] * (wbytes + 16 + 4),
+            "k_bwd_bound": st.get("bwd_rows", 0) / max(mean_len, 1.0) * (wbytes + 16),
             # per pair: packed read + PairRec/PairOut; per row: 6 special-state floats written
             "k_filters_fwd": st["n_past_msv"] * (wbytes + 16 + 40) + st["fwd_rows"] * 24,
             # per row: Forward's 6 floats read, 6 decoding terms written
@@ -680,11 +682,12 @@ def main():
         # what bounds each of them: the DP scans are VALU-bound (no-FMA fp32), the streaming kernels HBM-bound
         rows = st["fwd_rows"]
         # lane-rows each scan kernel COMPUTED (with prefix sharing: the chains' own rows, not the rows of their pairs)
-        krows = {"k_filters_fwd": rows, "k_bwd_decode": rows, "k_fwd_bound": st["bound_rows"], "k_msv": st["msv_rows"]}
+        krows = {"k_filters_fwd": rows, "k_bwd_decode": rows, "k_fwd_bound": st["bound_rows"], "k_msv": st["msv_rows"], "k_bwd_bound": st.get("bwd_rows", 0)}
         FLOPS_PER_ROW["k_fwd_bound"] = 16.0 * mean_nodes               # the profiles' own node count (45 for every ITSx model but two: 720), not the kernel's 46 slots
+        FLOPS_PER_ROW["k_bwd_bound"] = 16.0 * mean_nodes               # the same recurrences transposed: the same count
         # the roofline and the issue fractions use a kernel's ALONE time when the extra step measured one (the timed steps' can be stretched by what ran beside it)
         kt = {k: (alone[k] if (alone and alone.get(k, 0) > 0) else kern[k]) for k in kern}
-        tfl = {k: (krows[k] * FLOPS_PER_ROW[k] / (kt[k] * 1e-3) / 1e12 if kt[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode", "k_fwd_bound")}
+        tfl = {k: (krows[k] * FLOPS_PER_ROW[k] / (kt[k] * 1e-3) / 1e12 if kt[k] > 0 else None) for k in ("k_filters_fwd", "k_bwd_decode", "k_fwd_bound", "k_bwd_bound")}
         vfrac = {k: issue_frac(k, krows[k] / 64.0, kt[k]) for k in ISSUE_MIX}
         pmc = PMC_BYTES_PER_ROW or {}
         kernel_table = {k: {"ms": round(kern[k], 3), "ms_alone": round(alone[k], 3) if alone else None,
@@ -714,6 +717,13 @@ def main():
                                                         if (dom == "k_fwd_bound" and st.get("bound_rows_full")) else None),
                     "launches_per_step": nl, "avg_launch_ms": kt[dom] / nl,
                     "alg_flops_per_launch": krows[dom] * FLOPS_PER_ROW[dom] / nl, "alg_flops_per_lane_row": FLOPS_PER_ROW[dom], "alg_bytes_per_launch": alg[dom] / nl, "traffic": traffic,
+                    # what the kernel EXECUTES: 8.5 of the 11 operations per node (three folded into the profile's table), every one counted as its
+                    # flops (a fused multiply-add two): the fraction of the peak that the instructions actually issued account for
+                    "executed_flops_per_lane_row": round(FLOPS_PER_ROW[dom] * 8.5 / 11.0, 1) if dom == "k_fwd_bound" else None,
+                    "frac_executed": (tfl[dom] / peak) * 8.5 / 11.0 if dom == "k_fwd_bound" else None,
+                    # SURVEY 8d's figure for the WHOLE path: its algorithmic bytes per step over the step's wall time, against the HBM peak -- the path is
+                    # not HBM-bound (its DP stages are scans bound by VALU issue); reported because 8d asks for it
+                    "hbm_frac_whole_path_on_survey_bytes": survey_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                     "hbm_frac_on_alg_bytes": alg[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic_source": PMC_SOURCE if traffic is not None else None,
                     "survey_bytes_per_step": survey_bytes,
@@ -767,11 +777,20 @@ def main():
                        "pairs_of_those_profiles": int(st["n_lazy_completed"]) if st["lazy"] else None,
                        # prefix sharing (csrc/k_share.hip): rows the two scan kernels did NOT compute because another representative of the same length
                        # had the same first residues (the state comes from its saved row state); tree = what the prefix tree offers at this block size
+                       # pass A's rows (Forward chains + Backward chains) over the rows of its pairs: what two-sided sharing leaves to compute
+                       "rows_computed_frac": round((st["bound_rows"] + st.get("bwd_rows", 0)) / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,
+                       "two_sided": ({"joined_representatives": int(st["n_joined"]), "backward_chains": int(st["bwd_chains"]), "backward_states": int(st["gamma_nodes"]),
+                                      "forward_rows_frac": round(st["bound_rows"] / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,
+                                      "backward_rows_frac": round(st["bwd_rows"] / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,
+                                      "backward_launches": int(st["n_bwd_launches"])} if st.get("two_sided") else None),
                        "rows_shared_frac": {"k_fwd_bound": round(1.0 - st["bound_rows"] / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,
                                             "k_msv": round(1.0 - st["msv_rows"] / st["msv_rows_full"], 4) if st.get("msv_rows_full") else None,
                                             "tree": round(st["share_frac"], 4), "block_rows": int(st["share_B"]), "saved_states": int(st["share_nodes"]),
                                             "chains_with_a_parent": int(st["share_chains"]), "batches": int(st["share_batches"]),
                                             "pairs_run_for_their_states_only": int(st["n_share_helpers"]), "build_ms": round(acc.get("ms_share_build", 0.0) / K, 2)},
+                       # the library's environment switches that were set when the last timed search started (csrc/switches.cpp; only non-default ones
+                       # can appear: an empty dict = every switch at its default) and the Python layer's
+                       "switches": {**eng.switches(), **{k: v for k, v in os.environ.items() if k.startswith("ITSXPRESS_")}},
                        "parallelism": "reads sharded x%d%s" % (world, (", exact global derep" if args.global_derep else ", per-shard derep") if use_dist else "")},
             "full_pipeline": full_leg,
             "full_pipeline_value": (total_local * full_leg["steps"] / (full_leg["ms_per_step"] * 1e-3 * full_leg["steps"])) if (full_leg and "ms_per_step" in full_leg) else None,
@@ -781,6 +800,17 @@ def main():
             "paired_file_to_file": paired_leg,
             "ranks": rank_ms,
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},
+            # how stage_ms adds up to a step (its entries are NOT disjoint): the top-level stages are ms_pack + ms_derep + ms_msv + ms_filters + ms_domains +
+            # ms_finalize; ms_lazy_complete is part of ms_finalize AND its own filter / domain work is accumulated into ms_msv / ms_filters / ms_domains a second
+            # time, so it is subtracted once; every *_kernel / ms_ensemble / ms_lazy_select / ms_share_build entry lies inside one of the stages (ms_bound_kernel,
+            # ms_bwd_bound, ms_fwd_kernel, ms_lazy_select in ms_filters; ms_bwd / decode / env / ensemble in ms_domains); ms_msv_kernel of chunk c + 1 and
+            # ms_bias_kernel run beside other kernels (stretched wall times); the rest of the step is host work (result copies, the coordinates' hand-over)
+            "stage_overlap": {"top_level_ms": round((sum(acc.get(k, 0.0) for k in ("ms_pack", "ms_derep", "ms_msv", "ms_filters", "ms_domains", "ms_finalize", "ms_cluster", "ms_merge"))
+                                                     - acc.get("ms_lazy_complete", 0.0)) / K, 1),
+                              "ms_per_step": round(dt / args.steps * 1e3, 1),
+                              "note": "top_level_ms = ms_pack + ms_derep + ms_msv + ms_filters + ms_domains + ms_finalize - ms_lazy_complete (counted in ms_finalize and, "
+                                      "through the stages it re-runs, in ms_msv / ms_filters / ms_domains); all other stage_ms entries are nested in these; the "
+                                      "difference to ms_per_step is host time between the stages"},
             "kernels": kernel_table,
             "parity_risk": {"regions": int(st["n_regions"]), "regions_multidomain": int(st["n_multidomain"]),
                             "uniques_winner_is_cluster_envelope": int(st["n_uniq_multi_winner"]),

@@ -140,7 +140,7 @@ typedef struct {
    * (more than 2e-3 counts into share_mismatch) */
   int32_t two_sided;         int32_t n_bwd_launches;
   int64_t n_joined, bwd_chains, gamma_nodes, bwd_rows, two_fwd_rows, two_bwd_rows, two_rows_full;
-  float   join_maxdiff;      int32_t pad5;
+  float   join_maxdiff;      float ms_bwd_bound;        /* the Backward chains' kernel time (part of ms_bound_kernel) */
 } itsx_stats;
 
 int         itsx_abi_version(void);
@@ -403,6 +403,14 @@ int itsx_get_read_names(const itsx_ctx *ctx, char *names, int64_t cap, int64_t *
 
 /* out_size = sizeof(itsx_stats) as the caller was compiled (checked, like itsx_get_pairtraces' row_size) */
 int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out, int64_t out_size);
+/* The library's environment switches that are set ("NAME=value" lines; the registry with every switch's class -- tuning, mode,
+ * diagnostic, test hook -- is csrc/switches.cpp, the table INTEGRATION.md section 7): of ctx's last search (snapshot taken when it
+ * started) or, with ctx == NULL, of the environment now.  A test hook (result-changing) is honoured only under ITSX_TEST_HOOKS=1 and
+ * says so here otherwise.  The reference has no such surface: it passes fixed flags (itsxpress/SeqSample.py:191-209).
+ * Returns the length needed, terminator included. */
+int64_t itsx_switches(const itsx_ctx *ctx, char *buf, int64_t cap);
+/* the registry: "NAME<tab>class<tab>meaning" lines, class = tuning | mode | diagnostic | hook */
+int64_t itsx_switch_registry(char *buf, int64_t cap);
 
 /* ---- f1 ("next"): native FASTQ parse -> slice -> write.  Host-only and context-free.
  * itsx_write_trimmed_fastq replaces Dedup.create_trimmed_seqs (itsxpress/SeqSample.py:886-949): record i of

@@ -56,7 +56,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("share_B", "<i4"), ("share_batches", "<i4"), ("share_nodes", "<i8"), ("share_chains", "<i8"), ("msv_rows", "<i8"), ("msv_rows_full", "<i8"),
                 ("bound_rows_full", "<i8"), ("n_share_helpers", "<i8"), ("share_mismatch", "<i8"), ("ms_share_build", "<f4"), ("share_frac", "<f4"),
                 ("two_sided", "<i4"), ("n_bwd_launches", "<i4"), ("n_joined", "<i8"), ("bwd_chains", "<i8"), ("gamma_nodes", "<i8"), ("bwd_rows", "<i8"),
-                ("two_fwd_rows", "<i8"), ("two_bwd_rows", "<i8"), ("two_rows_full", "<i8"), ("join_maxdiff", "<f4"), ("pad5", "<i4")]
+                ("two_fwd_rows", "<i8"), ("two_bwd_rows", "<i8"), ("two_rows_full", "<i8"), ("join_maxdiff", "<f4"), ("ms_bwd_bound", "<f4")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares
@@ -66,7 +66,7 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_cluster", "itsx_get_derep", "itsx_unique_keys", "itsx_set_active_uniques", "itsx_get_uniques",
            "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
-           "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats",
+           "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats", "itsx_switches", "itsx_switch_registry",
            "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath", "itsx_debug_logf", "itsx_debug_dust", "itsx_debug_calibrate", "itsx_debug_issue", "itsx_shard_text", "itsx_shard_last_error", "itsx_owner_verdicts",
            "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
            "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_pairs_load", "itsx_merge_tables",
@@ -169,6 +169,8 @@ def lib():
         "itsx_write_rep_fasta": (i32, [vp, cp]),
         "itsx_write_domtbl": (i32, [vp, cp]),
         "itsx_get_stats": (i32, [vp, vp, i64]),
+        "itsx_switches": (i64, [vp, vp, i64]),
+        "itsx_switch_registry": (i64, [vp, i64]),
         "itsx_debug_read_hashes": (i32, [vp, vp, vp]),
         "itsx_debug_packed_read": (i32, [vp, i64, vp, vp, vp, vp]),
         "itsx_debug_detmath": (i32, [vp, vp, i64, vp, vp]),

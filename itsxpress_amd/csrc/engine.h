@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "../../include/itsx_hip.h"
+#include "switches.h"
 
 namespace itsx {
 

@@ -67,10 +67,13 @@ __global__ void k_waves_build(int nw, int P, const int32_t *__restrict__ order, 
     const int64_t k = ((int64_t)i - woff[lo]) * 64;
     WaveDesc d;
     d.prof = p; d.first = seg_start[p] + k; d.count = (int32_t)min((int64_t)64, (int64_t)total[p] - k); d.slab = 0;
-    d.rows = pairs[d.first + d.count - 1].L + 1;             // ascending length inside a segment
+    // (called on length-ordered segments today -- the unshared schedule -- but a share-ordered list must not under-size a wave silently:
+    // the longest of the wave's pairs, not the last)
+    int mx = 0;
+    for (int q = 0; q < d.count; q++) { const int L = pairs[d.first + q].L; mx = L > mx ? L : mx; mine += (unsigned long long)L; }
+    d.rows = mx + 1;
     d.pad = 0;
     w[i] = d;
-    mine = (unsigned long long)(d.rows - 1) * (unsigned long long)d.count;
   }
   for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(lane_rows, mine);
@@ -177,7 +180,7 @@ static void grave_flush()
 }
 static void defer_free(void *q, size_t bytes)
 {
-  static const size_t budget = (size_t)(getenv("ITSX_DEFER_FREE_GB") ? std::max(0.0, atof(getenv("ITSX_DEFER_FREE_GB"))) : 16.0) << 30;
+  static const size_t budget = (size_t)(sw_get("ITSX_DEFER_FREE_GB") ? std::max(0.0, atof(sw_get("ITSX_DEFER_FREE_GB"))) : 16.0) << 30;
   if (budget == 0) { (void)hipFree(q); return; }
   bool flush = false;
   { std::lock_guard<std::mutex> g(g_grave_mu); g_grave.push_back(q); g_grave_bytes += bytes; flush = g_grave_bytes > budget; }
@@ -226,7 +229,7 @@ template <class T> struct DBuf {
   {
     n = count;
     if (count <= cap && p) return hipSuccess;
-    static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+    static const bool trace = sw_get("ITSX_TRACE_ALLOC") != nullptr;
     if (p) {
       const auto f0 = std::chrono::steady_clock::now();
       defer_free(p, cap * sizeof(T));
@@ -392,6 +395,7 @@ struct itsx_ctx {
   ShareDev sh_dev{};
   // two-sided sharing (round 6): the suffix tree by s (sh_r*_s), the joins, the Backward chains by backward position kb (sh_bdev), their
   // batches' first positions (sh_bsegk_h), the slots of the saved Backward states behind the Forward ones in the DP slab
+  std::string switches_at_search;
   bool two_on = false; int share_maxrd = 0; int32_t Ub = 0; size_t sh_gslots_off = 0;
   DBuf<uint8_t> sh_rdepth_s, sh_rdepth; DBuf<unsigned long long> sh_rmask_s, sh_rmask, sh_keys, sh_keys2;
   DBuf<int32_t> sh_rparent_s, sh_rparent, sh_jlev_s, sh_jown_s, sh_endrow_s, sh_rsteps_s, sh_rnn_s, sh_rnode0_s, sh_endrow, sh_jlev, sh_jsrc, sh_jownb;
@@ -489,7 +493,7 @@ itsx_ctx *itsx_create(int device_id, int flags)
   itsx_ctx *ctx = new itsx_ctx();
   ctx->device = device_id;
   if (hipStreamCreate(&ctx->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete ctx; return nullptr; }
-  if (!(getenv("ITSX_LOAD_PRIORITY") && atoi(getenv("ITSX_LOAD_PRIORITY")) == 0)) {
+  if (!(sw_get("ITSX_LOAD_PRIORITY") && atoi(sw_get("ITSX_LOAD_PRIORITY")) == 0)) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least ||
         hipStreamCreateWithPriority(&ctx->st_hi, hipStreamDefault, greatest) != hipSuccess) { (void)hipGetLastError(); ctx->st_hi = nullptr; }
@@ -600,7 +604,7 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
     // chain); one profile without that and the whole set runs the plain recurrences (ITSX_BOUND_FOLD=0 does too).
     const int KK = 2 * BOUND_PAIRS;
     std::vector<std::vector<double>> G((size_t)P), SC((size_t)P), AA((size_t)P), RI((size_t)P);
-    bool fold = !(getenv("ITSX_BOUND_FOLD") && atoi(getenv("ITSX_BOUND_FOLD")) == 0);
+    bool fold = !(sw_get("ITSX_BOUND_FOLD") && atoi(sw_get("ITSX_BOUND_FOLD")) == 0);
     for (int i = 0; i < P && fold; i++) {
       const DevProfile &d = dp[i];
       const int K = 4 * ctx->profs[i].Q;
@@ -779,7 +783,7 @@ static int pack_and_upload(itsx_ctx *ctx, const char *view = nullptr, const uint
   hipStream_t st = ctx->st;
   const int64_t nb = n > 0 ? ctx->h_off[n] : 0;
   int64_t CH = 64ll << 20;
-  if (const char *e = getenv("ITSX_PACK_CHUNK")) CH = std::max<int64_t>(70000, atoll(e));       // bytes; a read has at most 65535
+  if (const char *e = sw_get("ITSX_PACK_CHUNK")) CH = std::max<int64_t>(70000, atoll(e));       // bytes; a read has at most 65535
   CH = std::min<int64_t>(CH, std::max<int64_t>(nb, 70000));
   constexpr int K = itsx_ctx::NSTAGE;
   if (!dev_raw && (int64_t)ctx->stage_cap < CH) {
@@ -803,7 +807,7 @@ static int pack_and_upload(itsx_ctx *ctx, const char *view = nullptr, const uint
   HIPCHK(hipMemsetAsync(d_excnt.p, 0, ((size_t)n + 2) * 4, st));
   // the exception list is sized by a guess; a read set with more non-ACGT symbols than that repeats the exception pass
   int64_t ecap = std::max<int64_t>((int64_t)ctx->d_exc.cap, nb / 256 + 4096);
-  if (const char *e = getenv("ITSX_PACK_ECAP")) ecap = std::max<int64_t>(1, atoll(e));
+  if (const char *e = sw_get("ITSX_PACK_ECAP")) ecap = std::max<int64_t>(1, atoll(e));
   HIPCHK(ctx->d_exc.alloc((size_t)ecap));
   int copy_threads = std::max(1, std::min(8, itsx_io::io_threads()));
   long long hb[4] = {0, 0, 0, 0};                        // exceptions so far, list overflow, first illegal read, -
@@ -971,7 +975,7 @@ static int parse_fastx(const itsx_io::Text &text, bool want_qual, bool upper, Fa
 {
   const size_t n = text.size();
   int T = itsx_io::io_threads();
-  if (const char *e = getenv("ITSX_PARSE_MIN_MB")) { if (n < (size_t)atol(e) << 20) T = 1; }
+  if (const char *e = sw_get("ITSX_PARSE_MIN_MB")) { if (n < (size_t)atol(e) << 20) T = 1; }
   else if (n < ((size_t)16 << 20)) T = 1;
   size_t first = 0;
   while (first < n && (text[first] == '\n' || text[first] == '\r')) first++;
@@ -1032,7 +1036,7 @@ int itsx_load_reads_file(itsx_ctx *ctx, const char *path, int64_t *n_reads)
 {
   CTXCHK(ctx && path);
   std::string rerr;
-  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  static const bool trace = sw_get("ITSX_TRACE_ALLOC") != nullptr;
   const auto tt0 = std::chrono::steady_clock::now();
   const auto tp = slurp(path, true, rerr);
   if (!tp) SET_ERR(ctx, ITSX_E_IO, rerr);
@@ -1248,7 +1252,7 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
 
 // vsearch's DUST soft mask (mask.cc dust() / wo()) on the host, for the orientation database (the reads are masked on the device by
 // k_dust, same procedure): windows of 64 advancing by 32, 3-mer repeat score 10 * sum / j, masked above 20
-static bool qmask_dust() { const char *e = getenv("ITSX_QMASK"); return !(e && strcmp(e, "none") == 0); }
+static bool qmask_dust() { const char *e = sw_get("ITSX_QMASK"); return !(e && strcmp(e, "none") == 0); }
 static void dust_host(const uint8_t *codes, int64_t L, std::vector<uint8_t> &masked)
 {
   masked.assign((size_t)L, 0);
@@ -1300,11 +1304,11 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
     });
   const int32_t nk = (int32_t)ord.size();
   int Bmax = 4096;                                          // k_cl_resolve keeps the window's flags in LDS
-  if (const char *e = getenv("ITSX_CL_WINDOW")) Bmax = std::min(4096, std::max(1, atoi(e)));
+  if (const char *e = sw_get("ITSX_CL_WINDOW")) Bmax = std::min(4096, std::max(1, atoi(e)));
   // DP rows per lane of the alignment wave: 64 lanes x S rows hold the whole query when Lmax + 1 <= 64 S; the lanes past the
   // query's end idle, so S is the smallest that fits (2x250-merged reads of <= 480 bases: S = 8, not 10: 78 % instead of 62 % busy)
   int rows_per_lane = (Lmax + 1 <= 320) ? 5 : (Lmax + 1 <= 512) ? 8 : 10;
-  if (const char *e = getenv("ITSX_CL_ROWS")) rows_per_lane = atoi(e) <= 5 ? 5 : atoi(e) <= 8 ? 8 : 10;
+  if (const char *e = sw_get("ITSX_CL_ROWS")) rows_per_lane = atoi(e) <= 5 ? 5 : atoi(e) <= 8 ? 8 : 10;
   const bool multipass = Lmax + 1 > 64 * rows_per_lane;
   const int32_t scratch_pitch = Lmax + 1;
   if (multipass) while (Bmax > 16 && 2LL * Bmax * 32 * scratch_pitch * 16 > (4LL << 30)) Bmax /= 2;
@@ -1349,15 +1353,15 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   HIPCHK(qi_cnt.alloc(65537)); HIPCHK(qi_cur.alloc(65536)); HIPCHK(qi_off.alloc(65537));
   HIPCHK(qi_ent.alloc(nqs * (size_t)kcap + 65536 * 8 + 64));
   int32_t hcap = 16384;                                     // strand bitmaps of conserved words (1 KB each); ITSX_CL_HEAVY=0: every word keeps its list
-  if (const char *e = getenv("ITSX_CL_HEAVY")) hcap = std::max(0, std::min(65536, atoi(e)));
+  if (const char *e = sw_get("ITSX_CL_HEAVY")) hcap = std::max(0, std::min(65536, atoi(e)));
   HIPCHK(qi_hid.alloc(65536)); HIPCHK(qi_nheavy.alloc(1)); HIPCHK(qi_bm.alloc((size_t)std::max(hcap, 1) * (CL_QS_MAX / 32)));
   HIPCHK(tq.alloc(CL_QS_MAX + 8)); HIPCHK(minm.alloc(CL_QS_MAX + 8)); HIPCHK(tkey.alloc(nqs)); HIPCHK(ncand.alloc(nqs)); HIPCHK(ntop.alloc(nqs)); HIPCHK(ovf.alloc(1));
   int32_t cand_cap = 4096;                                  // per strand; grows (and the window is searched again) when a list overflows
-  if (const char *e = getenv("ITSX_CL_CCAP")) cand_cap = std::max(32, atoi(e));
+  if (const char *e = sw_get("ITSX_CL_CCAP")) cand_cap = std::max(32, atoi(e));
   HIPCHK(cand.alloc(nqs * (size_t)cand_cap));
   HIPCHK(cntx.alloc(nqs * (size_t)Bmax));
   int64_t pool_cap = 1LL << 26;                             // words of all centroids; doubles (with a copy) when a window could overrun it
-  if (const char *e = getenv("ITSX_CL_CAPACITY")) pool_cap = std::max<int64_t>(2048, atoll(e));
+  if (const char *e = sw_get("ITSX_CL_CAPACITY")) pool_cap = std::max<int64_t>(2048, atoll(e));
   pool_cap = std::max<int64_t>(pool_cap, (int64_t)Bmax * kcap);
   HIPCHK(cw_pool->alloc((size_t)pool_cap, true));
   int64_t pool_used = 0;
@@ -1370,15 +1374,15 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   a.qi_cnt = qi_cnt.p; a.qi_cur = qi_cur.p; a.qi_off = qi_off.p; a.qi_ent = qi_ent.p;
   a.qi_hid = qi_hid.p; a.qi_nheavy = qi_nheavy.p; a.qi_bm = qi_bm.p; a.hcap = hcap;
   a.heavy_min = CL_HEAVY;                                    // ITSX_CL_HEAVY_MIN: strands that must hold a word before it gets a bitmap (tuning; results do not depend on it)
-  if (const char *e = getenv("ITSX_CL_HEAVY_MIN")) a.heavy_min = std::max(8, atoi(e));
+  if (const char *e = sw_get("ITSX_CL_HEAVY_MIN")) a.heavy_min = std::max(8, atoi(e));
   a.tq = tq.p; a.minm = minm.p; a.tkey = tkey.p; a.ncand = ncand.p; a.ntop = ntop.p; a.ovf = ovf.p; a.cntx = cntx.p;
   a.state = state.p; a.rejects = rejects.p; a.acc_col = acc_col.p; a.prev = prev.p; a.bound = bound.p; a.acc_id = acc_id.p;
   a.sel = sel.p; a.selm = selm.p; a.sel_short = sel_short.p; a.selkey = selkey.p; a.selpid = selpid.p;
   a.wn = wn.p; a.wcol = wcol.p; a.wkey = wkey.p; a.wpid = wpid.p;
   a.res_col = res_col.p; a.res_strand = res_strand.p; a.res_id = res_id.p;
   a.is_new = is_new.p; a.new_rank = new_rank.p; a.newq = newq.p; a.rm = rm.p;
-  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.awork = awork.p; a.spairs = spairs.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = getenv("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p;
-  a.use_score = getenv("ITSX_CL_NOSCORE") ? 0 : 1;
+  a.xlist = xlist.p; a.xn = xn.p; a.hard = hard.p; a.xkey = xkey.p; a.xpid = xpid.p; a.wout = wout.p; a.dbg = dbg.p; a.work = work.p; a.xwork = xwork.p; a.work_n = work_n.p; a.awork = awork.p; a.spairs = spairs.p; a.replay = replay.p; a.skipm = skipm.p; a.canon = canon.p; a.need = sw_get("ITSX_CL_NOPRECHECK") ? nullptr : need.p; a.need_pitch = (int32_t)(nqs * 32); a.n_skipped = n_skipped.p; a.pre_stats = pre_stats.p;
+  a.use_score = sw_get("ITSX_CL_NOSCORE") ? 0 : 1;
   a.pre_k = std::min(16, (int)((double)Lmax * (1.0 - id) / id) + 1); a.ctab_key = ctab_key.p; a.ctab_val = ctab_val.p; a.rhash = ctx->w_hf.p;
   a.scratch = scratch.p; a.scratch_pitch = scratch_pitch;
   a.thr = 100.0 * id; a.n_align = n_align.p;
@@ -1386,7 +1390,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   int32_t f = 0, C = 0, ncent = 0;
   int B = std::min(Bmax, 256);
   int64_t windows = 0, cuts = 0, regrown = 0, stream_launches = 0;
-  const bool debug = getenv("ITSX_CL_DEBUG") != nullptr;
+  const bool debug = sw_get("ITSX_CL_DEBUG") != nullptr;
   while (f < nk) {
     const int nq = std::min<int32_t>(B, nk - f);
     if (pool_used + (int64_t)nq * kcap > pool_cap) {          // the window's would-be centroids could overrun the word pool: grow it
@@ -1592,13 +1596,15 @@ static int build_share(itsx_ctx *ctx)
   itsx_stats &S = ctx->stats;
   ctx->share_on = false; ctx->sh_batches.clear(); ctx->sh_segk_h.clear();
   S.share_B = 0; S.share_batches = 0; S.share_nodes = S.share_chains = 0; S.ms_share_build = 0; S.share_frac = 0;
+  ctx->two_on = false; ctx->Ub = 0; ctx->share_maxrd = 0; ctx->sh_bsegk_h.clear();
+  S.two_sided = 0; S.n_joined = 0; S.bwd_chains = 0; S.gamma_nodes = 0; S.bwd_rows = 0; S.join_maxdiff = 0; S.ms_bwd_bound = 0; S.n_bwd_launches = 0; S.two_fwd_rows = S.two_bwd_rows = S.two_rows_full = 0;
   const int32_t U = ctx->U_active, Uc = (int32_t)std::min<int64_t>(ctx->s_Uc, 0x7fffffff), P = ctx->P;
-  if (const char *e = getenv("ITSX_SHARE")) if (atoi(e) == 0) return ITSX_OK;
+  if (const char *e = sw_get("ITSX_SHARE")) if (atoi(e) == 0) return ITSX_OK;
   // (the A/B switch of the bound pass uses the classic wave list)
-  if (getenv("ITSX_LAZY_EXACT_BOUND")) return ITSX_OK;
+  if (sw_get("ITSX_LAZY_EXACT_BOUND")) return ITSX_OK;
   if (U < 2 || U >= (1 << 26) || P <= 0) return ITSX_OK;
   int B = 32;
-  if (const char *e = getenv("ITSX_SHARE_B")) B = atoi(e);
+  if (const char *e = sw_get("ITSX_SHARE_B")) B = atoi(e);
   int logB = 0; while ((1 << logB) < B) logB++;
   if (B < 16 || B > 1024 || (1 << logB) != B) SET_ERR(ctx, ITSX_E_ARG, "ITSX_SHARE_B must be a power of two between 16 and 1024");
   StageTimer tm(st);
@@ -1625,9 +1631,7 @@ static int build_share(itsx_ctx *ctx)
   launch_exclusive_scan(ctx->sh_nn_s.p, ctx->sh_node0_s.p, (int64_t)U + 1, ctx->sh_scan.p, st);
   // ---- two-sided sharing (round 6; lazy searches with the folded bound kernel): the SUFFIX tree in the same table, the joins, the
   // chains' extents (k_share.hip: k_join_*)
-  bool two = ctx->lazy && ctx->bound_fold && !(getenv("ITSX_SHARE_TWO") && atoi(getenv("ITSX_SHARE_TWO")) == 0);
-  ctx->two_on = false; ctx->Ub = 0; ctx->share_maxrd = 0; ctx->sh_bsegk_h.clear();
-  S.two_sided = 0; S.n_joined = 0; S.bwd_chains = 0; S.gamma_nodes = 0; S.bwd_rows = 0; S.join_maxdiff = 0; S.n_bwd_launches = 0; S.two_fwd_rows = S.two_bwd_rows = S.two_rows_full = 0;
+  bool two = ctx->lazy && ctx->bound_fold && !(sw_get("ITSX_SHARE_TWO") && atoi(sw_get("ITSX_SHARE_TWO")) == 0);
   TrieArgs ar = a;
   JoinArgs ja{};
   if (two) {
@@ -1660,7 +1664,7 @@ static int build_share(itsx_ctx *ctx)
   const double frac = hc[2] ? (double)hc[1] / (double)hc[2] : 0.0;
   S.share_frac = (float)frac;
   double min_frac = 0.10;
-  if (const char *e = getenv("ITSX_SHARE_MIN")) min_frac = atof(e);
+  if (const char *e = sw_get("ITSX_SHARE_MIN")) min_frac = atof(e);
   const int64_t ncuts = (int64_t)hc[5];
   if (frac < min_frac || maxd <= 0 || NN <= 0 || ncuts > ncap) { S.ms_share_build = tm.stop(); return ITSX_OK; }
   if (two && (hc[10] == 0 || NG <= 0)) two = false;            // nobody joins: the one-sided schedule
@@ -1683,19 +1687,19 @@ static int build_share(itsx_ctx *ctx)
     const double held = (double)ctx->w_slab.cap * sizeof(float) + (double)ctx->sh_mslots.cap * sizeof(uint4);
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) gb = std::min(gb, std::max(0.25, ((double)fr + held) / (double)(1ull << 30) / (fwd_too ? 3.0 : 8.0)));
   }
-  if (const char *e = getenv("ITSX_SHARE_GB")) gb = std::max(0.0001, atof(e));
+  if (const char *e = sw_get("ITSX_SHARE_GB")) gb = std::max(0.0001, atof(e));
   // Two batches of the MSV filter always run side by side, each on its own half of its (small) buffer.  The Forward pass does so only
   // with ITSX_SHARE_FWD_STREAMS=2: measured, its launches' tails are too short for that to gain anything (2.029 vs 2.024 s per 10 M
   // reads), and overlapping launches make a kernel trace's durations (each stretched by the other) disagree with the wall time
   // ... except in a SMALL search (under 2 M representatives: a GPU's share of a sharded job), where a (batch, depth) launch is a few
   // milliseconds and its tail a tenth of that: 1.25 M reads 244 -> 232 ms, the step 496 -> 476 (ITSX_SHARE_FWD_STREAMS=1 / 2 force one way)
   // (not under an explicit slot budget: two batches side by side need twice the slots)
-  const bool two_fwd = getenv("ITSX_SHARE_FWD_STREAMS") ? atoi(getenv("ITSX_SHARE_FWD_STREAMS")) >= 2 : (U < 2000000 && !getenv("ITSX_SHARE_GB"));
+  const bool two_fwd = sw_get("ITSX_SHARE_FWD_STREAMS") ? atoi(sw_get("ITSX_SHARE_FWD_STREAMS")) >= 2 : (U < 2000000 && !sw_get("ITSX_SHARE_GB"));
   const double state_b = fwd_too ? (two_fwd ? 2.0 : 1.0) * (double)FWD_STATE_Q * sizeof(float4) : 2.0 * (double)MSV_STATE_Q * sizeof(uint4);
   // ... and no more than a job of this size needs: a quarter of all its states at a time still gives every (batch, depth) launch
   // thousands of waves, and device memory is not free to get (20-40 ms per GB in a fresh context: a streamed file's chunks each bring
   // their own -- round 5's first streamed run spent 5 s in hipMalloc for slots its 1.3 M-read chunks filled to a tenth)
-  if (!getenv("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)((int64_t)NN + NG) * state_b * (double)P / (double)(1ull << 30) / 4.0));
+  if (!sw_get("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)((int64_t)NN + NG) * state_b * (double)P / (double)(1ull << 30) / 4.0));
   const int64_t nodes_max = std::max<int64_t>(1, (int64_t)(gb * (double)(1ull << 30) / (state_b * (double)P)));
   std::vector<int32_t> bstart; std::vector<itsx_ctx::ShareBatch> &bt = ctx->sh_batches;
   {
@@ -1821,6 +1825,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   if (!ctx->have_derep) SET_ERR(ctx, ITSX_E_ARG, "itsx_search called before itsx_derep / itsx_cluster");
   if (ctx->P <= 0) SET_ERR(ctx, ITSX_E_ARG, "no profiles loaded");
   ctx->F2 = F2; ctx->have_vit = F2 < F1;              // hmmsearch enters the Viterbi filter only for P > F2: never when F1 <= F2
+  ctx->switches_at_search = sw_report();              // what the environment asked of this search (itsx_switches)
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = ctx->st;
   const int P = ctx->P, G = ctx->G, Ppad = G * 64, U = ctx->U_active;
@@ -1836,10 +1841,10 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   int mode = ctx->rows_mode;
   if (mode < 0) {
     mode = ITSX_ROWS_FULL;
-    if (getenv("ITSX_COMPACT_ROWS") && atoi(getenv("ITSX_COMPACT_ROWS")) != 0) mode = ITSX_ROWS_COMPACT;
-    if (const char *e = getenv("ITSX_ROWS")) mode = !strcmp(e, "lazy") ? ITSX_ROWS_LAZY : !strcmp(e, "compact") ? ITSX_ROWS_COMPACT : ITSX_ROWS_FULL;
+    if (sw_get("ITSX_COMPACT_ROWS") && atoi(sw_get("ITSX_COMPACT_ROWS")) != 0) mode = ITSX_ROWS_COMPACT;
+    if (const char *e = sw_get("ITSX_ROWS")) mode = !strcmp(e, "lazy") ? ITSX_ROWS_LAZY : !strcmp(e, "compact") ? ITSX_ROWS_COMPACT : ITSX_ROWS_FULL;
   }
-  if (mode == ITSX_ROWS_LAZY && getenv("ITSX_KEEP_TRACE")) mode = ITSX_ROWS_COMPACT;      // pair traces describe the full pipeline
+  if (mode == ITSX_ROWS_LAZY && sw_get("ITSX_KEEP_TRACE")) mode = ITSX_ROWS_COMPACT;      // pair traces describe the full pipeline
   ctx->compact_rows = mode != ITSX_ROWS_FULL;
   ctx->lazy = mode == ITSX_ROWS_LAZY;
   ctx->lazy_pending = 0; ctx->domz_exchanged = false; ctx->sF1 = F1; ctx->sF3 = F3;
@@ -1849,8 +1854,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.lazy_bound_maxdiff = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
   if (ctx->compact_rows && U > 0) {
     ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
-    if (const char *e = getenv("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
-    if (const char *e = getenv("ITSX_COMPACT_DOME_MIN")) ctx->compact_dome_min = std::max(1e-300, atof(e));
+    if (const char *e = sw_get("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
+    if (const char *e = sw_get("ITSX_COMPACT_DOME_MIN")) ctx->compact_dome_min = std::max(1e-300, atof(e));
     ctx->compact_lnp = log(ctx->compact_dome_min / ctx->compact_zmax) - 1e-6;       // certain: exp(lnP) * Zmax <= domE_min, with room for exp's last bit
     // classes = the distinct 2-character NAME prefixes (what create_runtime_hmm and ItsPosition select by: 1_ 2_ 3_ 4_)
     std::vector<int8_t> cls((size_t)P, 0); std::vector<std::string> seen;
@@ -1958,8 +1963,8 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   }
   int64_t Uc = std::max<int64_t>(1, (ctx->lazy ? lazy_budget : ctx->pair_budget) / std::max(P, 1));
   Uc = std::min<int64_t>(Uc, ((1ll << 31) - 4096) / std::max(Ppad, 1));
-  if (const char *e = getenv("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
-  ctx->keep_trace = getenv("ITSX_KEEP_TRACE") != nullptr;
+  if (const char *e = sw_get("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
+  ctx->keep_trace = sw_get("ITSX_KEEP_TRACE") != nullptr;
   ctx->s_Uc = Uc; ctx->s_Lcap = Lcap;
   ctx->domz_ub_loc.assign((size_t)P * ctx->S, 0);
   { const int rc = build_share(ctx); if (rc != ITSX_OK) return rc; }
@@ -2042,7 +2047,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) ctx->slab_gb = std::min(64.0, std::max(1.0, (double)fr / (double)(1ull << 30) / 4.0));
   }
   double slab_gb = ctx->slab_gb;
-  if (const char *e = getenv("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));     // read at every call
+  if (const char *e = sw_get("ITSX_SLAB_GB")) slab_gb = std::max(0.25, atof(e));     // read at every call
   {   // never more than a quarter of what the device has left right now (plus what the context's slab already holds): the stages
       // after the DP kernels need room too.  A budget above that is cut here; one the allocator still refuses is halved below.
     size_t fr = 0, tot = 0;
@@ -2056,8 +2061,8 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
   // A job that fits a few batches does not need the whole budget: eight batches already keep the launch tails small, and
   // device memory is not free to get (20-40 ms per GB in a fresh process: a 64-GB slab costs more than the search of a
   // 100 k-read sample).  Memory the context holds already is used in full.
-  static const bool adapt = !(getenv("ITSX_SLAB_ADAPT") && atoi(getenv("ITSX_SLAB_ADAPT")) == 0);
-  if (adapt && !getenv("ITSX_SLAB_GB")) {
+  static const bool adapt = !(sw_get("ITSX_SLAB_ADAPT") && atoi(sw_get("ITSX_SLAB_ADAPT")) == 0);
+  if (adapt && !sw_get("ITSX_SLAB_GB")) {
     int64_t total_rows = 0;
     for (int w = 0; w < NW; w++) total_rows += rows[(size_t)w];
     const int64_t floor_rows = ((int64_t)4 << 30) / row_bytes, have_rows = (int64_t)(ctx->w_slab.cap / (12 * 64));
@@ -2121,11 +2126,11 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
     // The bias-composition filter of a batch (its own full-occupancy kernel, VALU-bound, ~48 registers) runs on a second
     // stream beside the decoder of the batch before it (latency-bound, ~50 registers): the two share the SIMDs, which
     // the 256-register DP kernels never do with anything.
-    static const bool overlap = !(getenv("ITSX_BIAS_OVERLAP") && atoi(getenv("ITSX_BIAS_OVERLAP")) == 0);
+    static const bool overlap = !(sw_get("ITSX_BIAS_OVERLAP") && atoi(sw_get("ITSX_BIAS_OVERLAP")) == 0);
     if (overlap && !ctx->st2) {
       int least = 0, greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      if (getenv("ITSX_ST2_PRIO") && atoi(getenv("ITSX_ST2_PRIO")) == 0) least = 0;
+      if (sw_get("ITSX_ST2_PRIO") && atoi(sw_get("ITSX_ST2_PRIO")) == 0) least = 0;
       HIPCHK(hipStreamCreateWithPriority(&ctx->st2, hipStreamNonBlocking, least));     // what runs there fills gaps, it does not take turns
       HIPCHK(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
     }
@@ -2198,7 +2203,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
   StageTimer tm_dom(st);
   // ---- multidomain regions: resolved into envelopes by stochastic traceback clustering (k_ensemble.hip)
   int64_t NMR = 0;
-  const bool ensemble = !(getenv("ITSX_NO_ENSEMBLE") && atoi(getenv("ITSX_NO_ENSEMBLE")) != 0);
+  const bool ensemble = !(sw_get("ITSX_NO_ENSEMBLE") && atoi(sw_get("ITSX_NO_ENSEMBLE")) != 0);
   if (ensemble) {
     DBuf<int32_t> &mrcnt = ctx->w_mrcnt, &mroff = ctx->w_mroff, &stmp = ctx->w_scan2;
     HIPCHK(mrcnt.alloc((size_t)NP + 2)); HIPCHK(mroff.alloc((size_t)NP + 2)); HIPCHK(stmp.alloc((size_t)scan_tmp_elems(NP + 2)));
@@ -2252,8 +2257,8 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
       // waves over the regions in ascending length.  The longest regions decide when a batch ends (200 sequential paths each, and a
       // wave walks its lanes' paths in phases, so it takes as long as its slowest lane in EVERY phase): they get waves of
       // MR_LANES_LONG lanes, and the kernels take the waves from the back (longest first).
-      static const int lanes_long = getenv("ITSX_MR_LONG_LANES") ? std::max(1, std::min(MR_LANES, atoi(getenv("ITSX_MR_LONG_LANES")))) : MR_LANES_LONG;
-      static const double frac_long = getenv("ITSX_MR_LONG_FRAC") ? atof(getenv("ITSX_MR_LONG_FRAC")) : MR_LONG_FRAC;
+      static const int lanes_long = sw_get("ITSX_MR_LONG_LANES") ? std::max(1, std::min(MR_LANES, atoi(sw_get("ITSX_MR_LONG_LANES")))) : MR_LANES_LONG;
+      static const double frac_long = sw_get("ITSX_MR_LONG_FRAC") ? atof(sw_get("ITSX_MR_LONG_FRAC")) : MR_LONG_FRAC;
       const int64_t n_long = std::min<int64_t>(NU, (int64_t)(frac_long * (double)NU));
       std::vector<WaveDesc> mw;
       std::vector<int64_t> wfirst;
@@ -2293,11 +2298,11 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
         ma.mr = ctx->w_mr.p; ma.ulist = ulist.p; ma.u0 = wfirst[(size_t)w0]; ma.waves = ctx->w_mrwaves.p; ma.slab = (float4 *)ctx->w_mrslab.p;
         ma.rowoff = ctx->w_mrrowoff.p; ma.rowoff0 = row0;
         ma.n2off = ctx->w_n2off.p; ma.n2sc = ctx->w_n2sc.p; ma.out = ctx->w_mrout.p; ma.scratch = ctx->w_mrscratch.p;
-        static const bool mrdbg = getenv("ITSX_MR_DEBUG") != nullptr;
+        static const bool mrdbg = sw_get("ITSX_MR_DEBUG") != nullptr;
         if (mrdbg) { HIPCHK(ctx->w_counters.alloc(8)); HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 64, st)); ma.dbg = (unsigned long long *)ctx->w_counters.p; }
         // a small batch (a shard of a million reads, a chunk of a streaming run) cannot hide a path's chain of dependent matrix reads
         // behind other waves: its regions are walked one per wave with the matrix in LDS (k_ensemble.hip: k_mr_trace<., true>)
-        static const int64_t one_max = getenv("ITSX_MR_ONE_MAX") ? atoll(getenv("ITSX_MR_ONE_MAX")) : 2048;      // (10 M reads: 6 400 and 21 500 regions in the two rounds took 252 and 531 ms this way, 212 in waves of 64)
+        static const int64_t one_max = sw_get("ITSX_MR_ONE_MAX") ? atoll(sw_get("ITSX_MR_ONE_MAX")) : 2048;      // (10 M reads: 6 400 and 21 500 regions in the two rounds took 252 and 531 ms this way, 212 in waves of 64)
         const int64_t nreg = wfirst[(size_t)w1] - wfirst[(size_t)w0];
         const bool one = nreg <= one_max;
         if (one) ma.lds_bytes = (int32_t)std::min<int64_t>(40 << 10, (int64_t)mw[(size_t)w1 - 1].rows * MRV * 16);
@@ -2466,7 +2471,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
     int64_t ebudget = (int64_t)(slab_gb * (1 << 30)) / erow_bytes;
     LazyTimers elazy(st);
     DBuf<float> &d_eslab = ctx->w_eslab; int64_t ealloc = (int64_t)(d_eslab.cap / (104 * 64));
-    if (adapt && !getenv("ITSX_SLAB_GB")) {                  // as for the parser slab: four batches are enough here
+    if (adapt && !sw_get("ITSX_SLAB_GB")) {                  // as for the parser slab: four batches are enough here
       int64_t total_rows = 0;
       for (int w = 0; w < NRW; w++) total_rows += rrows[(size_t)w];
       ebudget = std::min(ebudget, std::max(std::max(total_rows / 4 + 1, ((int64_t)2 << 30) / erow_bytes), ealloc));
@@ -2671,7 +2676,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     HIPCHK(hipMemcpyAsync(lr.data(), ctx->w_counters.p, 256 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     // diagnostic (scripts/passa_launches.py): every launch's waves and wave-rows, in launch order, to set against a kernel trace
     std::vector<WaveDesc> dumpf, dumpb;
-    const bool dump = getenv("ITSX_PASSA_DUMP") != nullptr;
+    const bool dump = sw_get("ITSX_PASSA_DUMP") != nullptr;
     if (dump) {
       dumpf.resize((size_t)std::max(NW, 1)); dumpb.resize((size_t)std::max(NWB, 1));
       HIPCHK(hipMemcpyAsync(dumpf.data(), ctx->w_waves.p, (size_t)NW * sizeof(WaveDesc), hipMemcpyDeviceToHost, st));
@@ -2684,6 +2689,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       fprintf(stderr, "[passa] %s batch %d depth %d waves %d wave_rows %lld max_rows %lld lanes %lld\n", what, batch, d, w1 - w0, (long long)rows, (long long)mx, (long long)lanes);
     };
     StageTimer tm(st);
+    LazyTimers tb(st);                                      // the Backward chains' share of the pass (batches on the main stream)
     // (batches are independent: every other one on a second stream with its own half of the slot buffer, so that a launch's tail --
     // the next depth waits for its last waves -- is filled by the other batch's waves)
     hipStream_t alt = st;
@@ -2706,6 +2712,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
         if (pb <= pa) continue;
         // the batch's Backward chains first, the deepest suffixes last (a chain starts from the state a shorter suffix's chain saved):
         // every state a Forward chain of this batch joins is there before the first of them runs
+        const size_t tbi = (two && NWB > 0 && bs == st) ? tb.begin(&S.ms_bwd_bound) : (size_t)-1;
         if (two && NWB > 0)
           for (int d = 0; d < DSB; d++) {
             const int t = tb0 + d;
@@ -2718,6 +2725,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
             if (dump) dump_launch("bwd", t0 / DS, d, w0, w1, dumpb, 0);
             for (int w = w0; w < w1; w += 1 << 20) { launch_bwd_bound_share(ab, ctx->d_btab.p, ctx->d_rtab.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bwd_launches++; }
           }
+        if (tbi != (size_t)-1) tb.end(tbi);
         for (int d = 0; d < DS; d++) {
           const int t = t0 + d;
           const int w0 = woff[(size_t)t * P + pa], w1 = woff[(size_t)t * P + pb];
@@ -2727,8 +2735,8 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
           sl.slots = fsl; sl.node_base = b.node0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
           if (two) {
             sl.endrow = ctx->sh_endrow.p + u0; sl.jlev = ctx->sh_jlev.p + u0; sl.jsrc = ctx->sh_jsrc.p + u0; sl.gslots = gsl; sl.gnode_base = b.gnode0;
-            if (!getenv("ITSX_NO_CHAINREC")) { sl.chain = ctx->sh_chain.p + u0; sl.entab = ctx->d_entab.p; }
-            if (getenv("ITSX_TEST_HOOKS") && getenv("ITSX_PASSA_DBG")) sl.dbg = atoi(getenv("ITSX_PASSA_DBG"));
+            if (!sw_get("ITSX_NO_CHAINREC")) { sl.chain = ctx->sh_chain.p + u0; sl.entab = ctx->d_entab.p; }
+            if (sw_get("ITSX_TEST_HOOKS") && sw_get("ITSX_PASSA_DBG")) sl.dbg = atoi(sw_get("ITSX_PASSA_DBG"));
           }
           if (dump) dump_launch("fwd", t0 / DS, d, w0, w1, dumpf, d << ctx->share_logB);
           for (int w = w0; w < w1; w += 1 << 20) { launch_fwd_bound_share(a, ctx->d_btab.p, ctx->bound_fold, ctx->l_fb.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bound_launches++; }
@@ -2737,13 +2745,14 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     }
     if (alt != st) { HIPCHK(hipEventRecord(ctx->ev_s3b, alt)); HIPCHK(hipStreamWaitEvent(st, ctx->ev_s3b, 0)); }
     const float ms = tm.stop();
+    tb.collect();
     S.ms_bound_kernel += ms; S.ms_filters += ms;
     for (int q = 0; q < 64; q++) { S.bound_rows += lr[(size_t)2 * q]; S.bound_rows_full += lr[(size_t)2 * q + 1]; S.bwd_rows += lr[(size_t)128 + 2 * q]; }
     // the check hooks below run every pair from row 1: their waves reach the pairs' last rows
-    const bool want_check = getenv("ITSX_LAZY_CHECK_BOUND") || (getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0);
+    const bool want_check = sw_get("ITSX_LAZY_CHECK_BOUND") || (sw_get("ITSX_SHARE_CHECK") && atoi(sw_get("ITSX_SHARE_CHECK")) != 0);
     if (two && want_check)
       launch_share_waves(NW, nseg, P, ctx->sh_woff.p, ctx->sh_bnd.p, ctx->sh_segdepth.p, ctx->share_B, pl.pairs, nullptr, 0, ctx->w_waves.p, (unsigned long long *)ctx->w_counters.p + 256, st);
-    if (getenv("ITSX_LAZY_CHECK_BOUND")) {       // test hook: the shared chains' scores against HMMER's own arithmetic from row 1
+    if (sw_get("ITSX_LAZY_CHECK_BOUND")) {       // test hook: the shared chains' scores against HMMER's own arithmetic from row 1
       DBuf<float> ref;
       HIPCHK(ref.alloc((size_t)NP + 1));
       for (int t = 0; t < nseg; t++)
@@ -2765,7 +2774,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
       }
       S.lazy_bound_maxdiff = mx;
     }
-    if (getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0) {
+    if (sw_get("ITSX_SHARE_CHECK") && atoi(sw_get("ITSX_SHARE_CHECK")) != 0) {
       // test hook: every pair again from row 1 (the same wave list serves: a wave needs its profile, its pairs and its longest target).  A
       // chain that ran on its own to L has the unshared score bit for bit; a JOINED pair's score is the same sum over paths in another
       // order of operations: it must agree within 2e-3 nats (join_maxdiff reports the largest difference)
@@ -2805,7 +2814,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     a.pairs = pl.pairs; a.waves = ctx->w_waves.p; a.F1 = F1; a.F3 = F3;
     StageTimer tm(st);
     // launches of at most 2^20 waves: the timers of bench.py's roofline block want more than one sample
-    static const bool exact_bound = getenv("ITSX_LAZY_EXACT_BOUND") && atoi(getenv("ITSX_LAZY_EXACT_BOUND")) != 0;     // A/B: HMMER's own Forward as the bound pass
+    static const bool exact_bound = sw_get("ITSX_LAZY_EXACT_BOUND") && atoi(sw_get("ITSX_LAZY_EXACT_BOUND")) != 0;     // A/B: HMMER's own Forward as the bound pass
     if (!exact_bound) {
       for (int w0 = 0; w0 < NW; w0 += 1 << 20) { launch_fwd_bound_seq(a, ctx->d_btab.p, ctx->bound_fold, ctx->l_fb.p, std::min(1 << 20, NW - w0), w0, st); S.n_bound_launches++; }
     } else {
@@ -2814,7 +2823,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     }
     const float ms = tm.stop();
     S.ms_bound_kernel += ms; S.ms_filters += ms;
-    if (getenv("ITSX_LAZY_CHECK_BOUND") && !exact_bound) {      // test hook: the fast kernel's scores against HMMER's own arithmetic
+    if (sw_get("ITSX_LAZY_CHECK_BOUND") && !exact_bound) {      // test hook: the fast kernel's scores against HMMER's own arithmetic
       DBuf<float> ref;
       HIPCHK(ref.alloc((size_t)NP + 1));
       for (int w0 = 0; w0 < nfast; w0 += 1 << 20) launch_fwd_bound(a, ref.p, std::min(1 << 20, nfast - w0), w0, 0, st);
@@ -2844,7 +2853,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
   for (int round = 0; round < 2; round++) {
     StageTimer tm_r(st);
     launch_lazy_mark(la, round, st);
-    if (round == 1 && getenv("ITSX_LAZY_HIST")) {      // experiment: how many candidates a group sends into round 2
+    if (round == 1 && sw_get("ITSX_LAZY_HIST")) {      // experiment: how many candidates a group sends into round 2
       const int64_t ng = (int64_t)Uc * ncls;
       HIPCHK(hipMemsetAsync(ctx->l_gtop.p, 0, (size_t)ng * 8, st));
       hipLaunchKernelGGL(k_dbg_group_count, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, pl.pairs, NP, ctx->l_flag.p, ctx->w_cls.p, ncls, ctx->l_gtop.p);
@@ -2928,7 +2937,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
     // that a chain of a lower depth saved: launches of one stream run in order).  Batches are independent of each other: every other
     // one runs on a second stream with a slot buffer of its own, so that the tail of one launch -- the next depth waits for its last
     // blocks -- is filled by the other batch's blocks (and blocks may take their sequences through more profiles: fewer re-reads)
-    static const bool two = !(getenv("ITSX_SHARE_MSV_STREAMS") && atoi(getenv("ITSX_SHARE_MSV_STREAMS")) < 2);
+    static const bool two = !(sw_get("ITSX_SHARE_MSV_STREAMS") && atoi(sw_get("ITSX_SHARE_MSV_STREAMS")) < 2);
     int nbatch_here = 0;
     for (const auto &b : ctx->sh_batches) nbatch_here += (b.k0 >= cu0 && b.k0 < cu0 + cU);
     hipStream_t alt = s;
@@ -2988,7 +2997,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   DBuf<int32_t> &d_cnt = ctx->w_cnt, &d_total = ctx->w_total;
   HIPCHK(d_cnt.alloc((size_t)P * nchunks)); HIPCHK(d_total.alloc((size_t)P));
   const bool lazy_now = ctx->lazy && !ctx->completing;
-  if (sh && getenv("ITSX_SHARE_CHECK") && atoi(getenv("ITSX_SHARE_CHECK")) != 0) {
+  if (sh && sw_get("ITSX_SHARE_CHECK") && atoi(sw_get("ITSX_SHARE_CHECK")) != 0) {
     // test hook: the same chunk through the unshared kernel; every cell of the result must be the same
     HIPCHK(ctx->sh_res_chk.alloc((size_t)Ppad * (size_t)U));
     msv_for(u0, U, st, 0, ctx->sh_res_chk.p, false);
@@ -3032,7 +3041,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   }
   launch_pair_fill(d_res.p, P, U, nchunks, d_cnt.p, d_seg_start.p, d_ulen, ctx->d_pairs.p, st);
   S.ms_msv += tm_list.stop();
-  const int64_t zub_scale = getenv("ITSX_LAZY_ZUB_SCALE") ? std::max<int64_t>(1, atoll(getenv("ITSX_LAZY_ZUB_SCALE"))) : 1;   // test hook: looser bounds, more undecided rows
+  const int64_t zub_scale = sw_get("ITSX_LAZY_ZUB_SCALE") ? std::max<int64_t>(1, atoll(sw_get("ITSX_LAZY_ZUB_SCALE"))) : 1;   // test hook: looser bounds, more undecided rows
   if (!ctx->completing)
     for (int p = 0; p < P; p++)                   // an upper bound of hmmsearch's domZ: every reported target is a pair past the MSV filter
       for (int32_t sm = 0; sm < ctx->S; sm++) ctx->domz_ub_loc[(size_t)sm * P + p] += (int64_t)real[p] * zub_scale;
@@ -3040,7 +3049,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
   pl.pairs = ctx->d_pairs.p; pl.pout = lazy_now ? nullptr : ctx->d_pout.p; pl.NP = NP; pl.seg_start = seg_start; pl.total = total; pl.d_seg_start = d_seg_start.p;
   // the next chunk's MSV filter on the second stream (its result buffer is free: this chunk's survivor list is built)
   const std::function<int()> next_msv = [&]() -> int {
-    const bool msv_overlap = !(getenv("ITSX_MSV_OVERLAP") && atoi(getenv("ITSX_MSV_OVERLAP")) == 0);     // (read at every search: bench.py times one step without the overlap)
+    const bool msv_overlap = !(sw_get("ITSX_MSV_OVERLAP") && atoi(sw_get("ITSX_MSV_OVERLAP")) == 0);     // (read at every search: bench.py times one step without the overlap)
     if (msv_overlap && ctx->next_u0 >= 0 && ctx->st2 && !ctx->keep_trace) {
       if (!ctx->ev_msv0) {
         HIPCHK(hipEventCreate(&ctx->ev_msv0)); HIPCHK(hipEventCreate(&ctx->ev_msv1));
@@ -3048,7 +3057,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       }
       HIPCHK(hipEventRecord(ctx->ev_c, st)); HIPCHK(hipStreamWaitEvent(ctx->st2, ctx->ev_c, 0));
       HIPCHK(hipEventRecord(ctx->ev_msv0, ctx->st2));
-      msv_for(ctx->next_u0, ctx->next_U, ctx->st2, getenv("ITSX_MSV_PAD") ? atoi(getenv("ITSX_MSV_PAD")) : 40000);
+      msv_for(ctx->next_u0, ctx->next_U, ctx->st2, sw_get("ITSX_MSV_PAD") ? atoi(sw_get("ITSX_MSV_PAD")) : 40000);
       HIPCHK(hipEventRecord(ctx->ev_msv1, ctx->st2));
       ctx->msv_pre_u0 = ctx->next_u0;
     }
@@ -3201,7 +3210,7 @@ static int finalize_lazy(itsx_ctx *ctx, double domE)
   HIPCHK(hipMemcpyAsync(ctx->lazy_pending_prof.data(), ctx->l_pflag.p, (size_t)std::max(ctx->P, 1) * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   { int np = 0; for (int32_t f : ctx->lazy_pending_prof) np += f != 0; ctx->stats.n_lazy_pending_profiles = np; }
-  if (getenv("ITSX_LAZY_FORCE_PENDING")) pend += atoll(getenv("ITSX_LAZY_FORCE_PENDING"));      // test hook: exercises the full re-run
+  if (sw_get("ITSX_LAZY_FORCE_PENDING")) pend += atoll(sw_get("ITSX_LAZY_FORCE_PENDING"));      // test hook: exercises the full re-run
   ctx->lazy_pending = pend; ctx->stats.n_lazy_pending = pend;
   return ITSX_OK;
 }
@@ -3224,12 +3233,12 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
   if (ctx->lazy) {
     { const int rc = finalize_lazy(ctx, domE); if (rc != ITSX_OK) return rc; }
     { const int rc = check_compaction(ctx->domz_ub); if (rc != ITSX_OK) return rc; }
-    if (ctx->lazy_pending > 0 && !ctx->domz_exchanged && !getenv("ITSX_LAZY_NO_RERUN")) {
+    if (ctx->lazy_pending > 0 && !ctx->domz_exchanged && !sw_get("ITSX_LAZY_NO_RERUN")) {
       // Rows whose reporting depends on the exact domZ could change a result.  This context is on its own (nobody exchanged
       // counters): the profiles of those rows are counted exactly (itsx_lazy_complete) and the thresholds applied again; a
       // multi-rank driver does the same across ranks (itsxpress_amd/dist.py: exchange_and_finalize).
       const int64_t pend = ctx->lazy_pending;
-      if (!getenv("ITSX_LAZY_NO_COMPLETE")) {
+      if (!sw_get("ITSX_LAZY_NO_COMPLETE")) {
         std::vector<int32_t> flags(ctx->lazy_pending_prof);
         flags.resize((size_t)std::max(ctx->P, 1), 0);
         { const int rc = itsx_lazy_complete(ctx, flags.data()); if (rc != ITSX_OK) return rc; }
@@ -3569,7 +3578,7 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
   Side f, r;
   std::string ferr, rerr2;
   int rc2 = ITSX_OK;
-  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  static const bool trace = sw_get("ITSX_TRACE_ALLOC") != nullptr;
   const auto tm0 = std::chrono::steady_clock::now();
   std::thread other([&] { rc2 = parse(r2_path, r, rerr2); });
   int rc = parse(r1_path, f, ferr);
@@ -3631,7 +3640,7 @@ int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_pat
   Side f, r;
   std::string ferr, rerr2;
   int rc2 = ITSX_OK;
-  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  static const bool trace = sw_get("ITSX_TRACE_ALLOC") != nullptr;
   const auto tm0 = std::chrono::steady_clock::now();
   std::thread other([&] { rc2 = parse(r2_path, r, rerr2); });
   int rc = parse(r1_path, f, ferr);
@@ -4058,6 +4067,26 @@ int itsx_get_read_names(const itsx_ctx *ctx, char *names, int64_t cap, int64_t *
   }
   offsets[ctx->N] = o;
   return ITSX_OK;
+}
+
+// the library's environment switches (csrc/switches.cpp) that are set: of the last search of ctx (snapshot taken when it started), or, with
+// ctx == NULL, of the environment right now.  "NAME=value\n" lines; returns the length needed (incl. the terminator)
+int64_t itsx_switches(const itsx_ctx *ctx, char *buf, int64_t cap)
+{
+  const std::string s = ctx ? ctx->switches_at_search : sw_report();
+  if (buf && cap > 0) { const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1); memcpy(buf, s.data(), n); buf[n] = 0; }
+  return (int64_t)s.size() + 1;
+}
+
+// the registry itself: "NAME\tclass\tmeaning\n" lines (class: tuning | mode | diagnostic | hook)
+int64_t itsx_switch_registry(char *buf, int64_t cap)
+{
+  static const char *kinds[] = {"tuning", "mode", "diagnostic", "hook"};
+  int n = 0; const Switch *r = sw_registry(&n);
+  std::string s;
+  for (int i = 0; i < n; i++) { s += r[i].name; s += "\t"; s += kinds[r[i].kind]; s += "\t"; s += r[i].what; s += "\n"; }
+  if (buf && cap > 0) { const size_t m = std::min<size_t>(s.size(), (size_t)cap - 1); memcpy(buf, s.data(), m); buf[m] = 0; }
+  return (int64_t)s.size() + 1;
 }
 
 int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out, int64_t out_size)

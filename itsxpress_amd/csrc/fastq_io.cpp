@@ -61,7 +61,7 @@ bool Text::reserve(size_t cap)
   if (q == MAP_FAILED) return false;
   // huge pages under a text that is written once, front to back, by many threads: asked for over the WHOLE mapping, so that it
   // stays one area (advice on a part splits it, and a split mapping cannot grow by mremap)
-  static const bool huge = !(getenv("ITSX_HUGEPAGES") && atoi(getenv("ITSX_HUGEPAGES")) == 0);
+  static const bool huge = !(sw_get("ITSX_HUGEPAGES") && atoi(sw_get("ITSX_HUGEPAGES")) == 0);
   if (huge) (void)madvise(q, want, MADV_HUGEPAGE);
   if (n_) memcpy(q, p_, n_);
   if (kind_ == 1) free(p_);
@@ -137,7 +137,7 @@ template <class F> bool sym(void *h, const char *name, F &f) { f = reinterpret_c
 
 void load_codecs()
 {
-  const char *off = getenv("ITSX_IO_LIBDEFLATE");
+  const char *off = sw_get("ITSX_IO_LIBDEFLATE");
   if (!(off && atoi(off) == 0)) {
     for (const char *n : {"libdeflate.so.0", "libdeflate.so"}) { g_ld.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_ld.h) break; }
     if (g_ld.h) {
@@ -157,7 +157,7 @@ void load_codecs()
 }
 void codecs() { std::call_once(g_codec_once, load_codecs); }
 
-int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+int env_int(const char *name, int dflt) { const char *e = itsx::sw_get(name); return e ? atoi(e) : dflt; }
 
 // ------------------------------------------------------------------ decompression of a whole buffer
 bool is_gzip(const Text &r, size_t pos = 0) { return r.size() >= pos + 2 && (unsigned char)r[pos] == 0x1f && (unsigned char)r[pos + 1] == 0x8b; }
@@ -255,7 +255,7 @@ std::deque<CacheEntry> g_cache;          // most recent at the back
 // least 4 GB and at most 32: the writer of a 10 M-read sample inflated its 9 GB of text a second time because the cache held 4 GB
 double cache_budget_bytes()
 {
-  if (const char *e = getenv("ITSX_TEXT_CACHE_GB")) return atof(e) * (double)(1ull << 30);
+  if (const char *e = sw_get("ITSX_TEXT_CACHE_GB")) return atof(e) * (double)(1ull << 30);
   static const double deflt = [] {
     double avail = 0.0;
     if (FILE *f = fopen("/proc/meminfo", "r")) {
@@ -395,7 +395,7 @@ std::shared_ptr<const Text> read_text(const char *path, std::string &err, bool c
         break;
       }
   }
-  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  static const bool trace = sw_get("ITSX_TRACE_ALLOC") != nullptr;
   const auto c0 = std::chrono::steady_clock::now();
   Text raw;
   if (!read_raw(path, fsize, raw, err)) return nullptr;

@@ -15,6 +15,7 @@
 //    through libzstd.so.1's stable one-shot / streaming entry points (no headers for either in this image, so both are
 //    bound at run time; absent libzstd = a loud error for .zst files only).
 #pragma once
+#include "switches.h"
 #include <cstddef>
 #include <cstdint>
 #include <functional>

@@ -430,7 +430,7 @@ void launch_bwd_bound_share(const FloatArgs &a, const float *btab, const float *
 // 1e20 by default (ITSX_BOUND_RESCALE_EXP: another power of ten, for A/B; at most 28 -- the folded cells must stay inside float)
 static float bound_rescale()
 {
-  static const float v = [] { const char *e = getenv("ITSX_BOUND_RESCALE_EXP"); const double x = e ? atof(e) : 20.0; return (float)pow(10.0, x < 4.0 ? 4.0 : x > 28.0 ? 28.0 : x); }();
+  static const float v = [] { const char *e = sw_get("ITSX_BOUND_RESCALE_EXP"); const double x = e ? atof(e) : 20.0; return (float)pow(10.0, x < 4.0 ? 4.0 : x > 28.0 ? 28.0 : x); }();
   return v;
 }
 void launch_fwd_bound_seq(const FloatArgs &a, const float *btab, bool fold, float *fb, int nwaves, int wave0, hipStream_t st)

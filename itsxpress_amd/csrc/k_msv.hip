@@ -187,7 +187,7 @@ void launch_msv(const MsvArgs &a0, hipStream_t st, int lds_pad)
   const dim3 grid((unsigned)((nk + 255) / 256), (unsigned)((np + a.PB - 1) / a.PB));
   // words a lane keeps in LDS: every word of the launch's longest read when that is at most 37 (four blocks of 37 + 3 KB fill a CU's
   // 160 KB exactly), else 16 at a time; ITSX_MSV_WHOLE=0: always 16 (A/B)
-  static const bool allow_whole = !(getenv("ITSX_MSV_WHOLE") && atoi(getenv("ITSX_MSV_WHOLE")) == 0);
+  static const bool allow_whole = !(sw_get("ITSX_MSV_WHOLE") && atoi(sw_get("ITSX_MSV_WHOLE")) == 0);
   const int need = (a.Lcap - 1 + 15) / 16;
   a.wtl = (allow_whole && need > MSV_WT && need <= 37) ? need : MSV_WT;
   const size_t lds = std::max<size_t>((size_t)lds_pad, (size_t)a.wtl * 256 * sizeof(uint32_t));

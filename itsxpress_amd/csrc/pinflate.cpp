@@ -151,7 +151,7 @@ inline bool texty(int c) { return (c >= 32 && c < 127) || c == '\n' || c == '\r'
 
 // Anonymous memory with transparent huge pages asked for: the staging buffers and the output are written once, front to
 // back, and with 4-KB pages the page faults cost more than the decoding (measured: 269 -> 40 ms for 37 MB of text).
-bool huge_pages() { static const bool on = !(getenv("ITSX_HUGEPAGES") && atoi(getenv("ITSX_HUGEPAGES")) == 0); return on; }
+bool huge_pages() { static const bool on = !(sw_get("ITSX_HUGEPAGES") && atoi(sw_get("ITSX_HUGEPAGES")) == 0); return on; }
 struct HugeBuf {
   void *p = nullptr; size_t bytes = 0;
   bool alloc(size_t want)
@@ -329,7 +329,7 @@ bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const s
   const uint8_t *p = (const uint8_t *)data;
   const size_t hdr = gzip_header_len(p, n);
   size_t chunk_bytes = 1u << 20;
-  if (const char *e = getenv("ITSX_PINFLATE_CHUNK_KB")) chunk_bytes = std::max<size_t>(16, (size_t)atol(e)) << 10;      // tests use small chunks
+  if (const char *e = sw_get("ITSX_PINFLATE_CHUNK_KB")) chunk_bytes = std::max<size_t>(16, (size_t)atol(e)) << 10;      // tests use small chunks
   if (!hdr || threads < 2 || n < 4 * chunk_bytes) return false;
   const uint32_t last_len = le32(p + n - 4);
   const In s{p, n};
@@ -349,7 +349,7 @@ bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const s
   uLong crc = crc32(0L, Z_NULL, 0);          // of the member being assembled
   uint64_t member_len = 0;
   bool finished = false;
-  static const bool trace = getenv("ITSX_TRACE_ALLOC") != nullptr;
+  static const bool trace = sw_get("ITSX_TRACE_ALLOC") != nullptr;
   double t_find = 0, t_dec = 0, t_res = 0; int rounds = 0;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

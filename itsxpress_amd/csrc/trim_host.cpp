@@ -155,7 +155,7 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
   // fed here with the whole text and every coordinate at once, by a streaming run piece by piece: the same bytes either way.
   // (One I/O thread: the serial walk below; a malformed record sends the file there too, and the walk names it.)
   const size_t size = (size_t)(in.end - in.s);
-  const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : 0;
+  const size_t min_par = sw_get("ITSX_WRITE_MIN_MB") ? (size_t)atoll(sw_get("ITSX_WRITE_MIN_MB")) << 20 : 0;
   if (itsx_io::io_threads() > 1 && size >= min_par) {
     { itsx_io::PieceCompressor probe(compression); if (!probe.ok()) { g_trim_error = "zstd output requested but libzstd.so.1 could not be loaded"; return ITSX_E_IO; } }
     itsx_twriter *tw = nullptr;
@@ -421,7 +421,7 @@ int itsx_twriter_open(const char *out_path, int compression, int trim_ccs, itsx_
   { itsx_io::PieceCompressor probe(compression); if (!probe.ok()) { g_trim_error = "zstd output requested but libzstd.so.1 could not be loaded"; return ITSX_E_IO; } }
   itsx_twriter *w = new itsx_twriter;
   w->path = out_path; w->kind = compression; w->ccs = trim_ccs != 0;
-  if (const char *e = getenv("ITSX_WRITE_UNIT_KB")) w->unit_bytes = std::max<size_t>(1, (size_t)atoll(e)) << 10;
+  if (const char *e = sw_get("ITSX_WRITE_UNIT_KB")) w->unit_bytes = std::max<size_t>(1, (size_t)atoll(e)) << 10;
   w->fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
   if (w->fd < 0) { g_trim_error = std::string("cannot write ") + out_path; delete w; return ITSX_E_IO; }
   w->seekable = lseek(w->fd, 0, SEEK_CUR) != (off_t)-1;
@@ -614,9 +614,9 @@ int itsx_write_trimmed_paired(const char *r1_path, const char *r2_path, const ch
   // sliced T ranges at a time and then fed the two block writers from ONE thread: 8 GB of text copied block by block between the
   // slicers and the compressors' 64 threads, and 10 M labels indexed by one thread before anything started: 3 s of a 6-s writer.)
   const size_t size1 = (size_t)(in1.end - in1.s), size2 = (size_t)(in2.end - in2.s);
-  const size_t min_par = getenv("ITSX_WRITE_MIN_MB") ? (size_t)atoll(getenv("ITSX_WRITE_MIN_MB")) << 20 : (size_t)32 << 20;
+  const size_t min_par = sw_get("ITSX_WRITE_MIN_MB") ? (size_t)atoll(sw_get("ITSX_WRITE_MIN_MB")) << 20 : (size_t)32 << 20;
   if (T > 1 && size1 >= min_par && size2 > 0) {
-    const size_t range = getenv("ITSX_WRITE_UNIT_KB") ? (size_t)atoll(getenv("ITSX_WRITE_UNIT_KB")) << 10 : (size_t)8 << 20;
+    const size_t range = sw_get("ITSX_WRITE_UNIT_KB") ? (size_t)atoll(sw_get("ITSX_WRITE_UNIT_KB")) << 10 : (size_t)8 << 20;
     auto cuts_of = [&](const char *t0, const char *tend, std::vector<const char *> &cut) {
       const size_t size = (size_t)(tend - t0);
       cut.assign(1, t0);

@@ -475,6 +475,15 @@ class Engine:
         self._chk(self.L.itsx_get_stats(self.h, s.ctypes.data, STATS_DTYPE.itemsize))
         return {k: (s[0][k].item() if s[0][k].ndim == 0 else s[0][k].tolist()) for k in STATS_DTYPE.names}
 
+    def switches(self, now=False):
+        """the library's environment switches that were set when the last search started (now=True: that are set now), as a dict
+        NAME -> value; a test hook that is not honoured (no ITSX_TEST_HOOKS=1) carries the note "(ignored: ...)" """
+        h = None if now else self.h
+        n = self.L.itsx_switches(h, None, 0)
+        buf = C.create_string_buffer(int(n))
+        self.L.itsx_switches(h, buf, n)
+        return dict(line.split("=", 1) for line in buf.value.decode().split("\n") if "=" in line)
+
     # ---- test hooks
     def debug_read_hashes(self):
         f = np.zeros(self.n_reads, np.uint64)

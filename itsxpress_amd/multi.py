@@ -26,8 +26,10 @@ asks for it.  bench.py's torch.distributed / RCCL path (itsxpress_amd/dist.py) i
 already runs one process per GPU.
 """
 import ctypes as C
+import glob
 import multiprocessing as mp
 import os
+import shutil
 import tempfile
 import time
 
@@ -602,13 +604,61 @@ class MultiEngine(ShardedOps):
         self._final = False
         self._lazy_index = False
         self._verdicts_ = []
+        self._seeds_ = np.zeros(0, np.int64)
+        self._gmap_ = []
         self._last_merge = None
         self.parent_s, self.parent_own_s = {}, {}         # seconds inside each call / of them this process's own work (scripts/multi_run.py)
-        # worker-to-worker exchanges: files in memory, named by this driver
-        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        # worker-to-worker exchanges: files named by this driver -- in memory (/dev/shm) while it has room for them, else in the temp
+        # directory; ITSXPRESS_XDIR names another place (a container's /dev/shm is often 64 MB)
+        self._xdir = None
+        self._new_xdir(self._xbase(1 << 26))
+
+    @staticmethod
+    def _free_bytes(d):
+        try:
+            v = os.statvfs(d)
+            return v.f_bavail * v.f_frsize
+        except OSError:
+            return 0
+
+    def _xbase(self, need):
+        """where the exchange files go: ITSXPRESS_XDIR if given, /dev/shm if it holds `need` bytes, else the temp directory"""
+        env = os.environ.get("ITSXPRESS_XDIR")
+        if env:
+            if not (os.path.isdir(env) and os.access(env, os.W_OK)):
+                raise EngineError(-2, "ITSXPRESS_XDIR=%s is not a writable directory" % env)
+            return env
+        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and self._free_bytes("/dev/shm") >= need:
+            return "/dev/shm"
+        return tempfile.gettempdir()
+
+    def _new_xdir(self, base):
+        old = self._xdir
         self._xdir = tempfile.mkdtemp(prefix="itsx_multi_%d_" % os.getpid(), dir=base)
         self._xprefix = os.path.join(self._xdir, "x")
         self._all("job", self._xprefix)
+        if old:
+            shutil.rmtree(old, ignore_errors=True)
+
+    def _ensure_room(self, need):
+        """the exchange directory must hold `need` more bytes: move it (memory -> temp directory) or say so, instead of a worker dying of
+        SIGBUS on a full tmpfs"""
+        if self._free_bytes(self._xdir) >= need:
+            return
+        base = self._xbase(need)
+        if os.path.dirname(self._xdir) != base and self._free_bytes(base) >= need:
+            self._new_xdir(base)
+            return
+        raise EngineError(-2, "the multi-GPU exchange directory %s has %.1f GB free, this sample needs %.1f GB: point ITSXPRESS_XDIR at a "
+                              "directory with room (or enlarge /dev/shm)" % (self._xdir, self._free_bytes(self._xdir) / 1e9, need / 1e9))
+
+    def _sweep(self):
+        """a failed exchange leaves its files behind: remove what the current job wrote"""
+        for f in glob.glob(self._xprefix + "_*"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
 
     def _tic(self):
         return (time.perf_counter(), getattr(self, "wait_s", 0.0))
@@ -728,10 +778,15 @@ class MultiEngine(ShardedOps):
         from . import _lib
         L = _lib.lib()
         rec = np.zeros(self.world, np.int64)
+        # the pieces are the inflated text: a .gz / .zst file is taken at eight times its size (FASTQ deflates ~4-5 x), anything else at its own
+        size = os.path.getsize(path)
+        self._ensure_room(int(size * (8 if path.endswith((".gz", ".zst")) else 1.05)) + (1 << 20))
         pre = os.path.join(self._xdir, tag)
         m = None if match is None else np.ascontiguousarray(match, np.int64)
         rc = L.itsx_shard_text(os.fsencode(path), self.world, None if m is None else m.ctypes.data, os.fsencode(pre), rec.ctypes.data, None)
+        L.itsx_io_cache_clear()                              # (the parent keeps no copy of the text: the pieces are it)
         if rc != 0:
+            self._sweep()
             raise EngineError(rc, L.itsx_shard_last_error().decode())
         return ["%s.%d" % (pre, r) for r in range(self.world)], rec
 
@@ -770,6 +825,8 @@ class MultiEngine(ShardedOps):
         self.n_reads = n
         self._derep = None
         self._final = False
+        self._last_merge = None
+        self._lazy_index = False
         return n
 
     # -- a1: exact dereplication of the whole sample
@@ -777,9 +834,14 @@ class MultiEngine(ShardedOps):
         """exact dereplication of the whole sample: local derep on every GPU, then the uniques meet at their key's owner (key mod N),
         every worker sorts its Nth of the keys, the verdicts travel back -- three commands, nothing of the data's size in this process"""
         t0 = self._tic()
-        self._all("derep_x", bool(strand_both), int(minseqlength))
-        self._all("own_x")
-        res = self._all("verdict_x")
+        self._ensure_room(48 * max(1, self.n_reads) + (1 << 20))      # the keys travel as 32 B per unique, the verdicts as 12
+        try:
+            self._all("derep_x", bool(strand_both), int(minseqlength))
+            self._all("own_x")
+            res = self._all("verdict_x")
+        except BaseException:
+            self._sweep()
+            raise
         self.n_unique = int(sum(r[1] for r in res))
         self._lazy_index = True                          # seeds / local -> global maps: only if somebody asks
         self._derep = None
@@ -813,17 +875,29 @@ class MultiEngine(ShardedOps):
         """per READ of the whole sample: start, stop, tlen (-1 = None), in_ddict"""
         t0 = self._tic()
         path = self._xprefix + "_coords"
-        for k in range(4):
-            out = np.lib.format.open_memmap("%s.%d.npy" % (path, k), mode="w+", dtype=np.int32, shape=(self.n_reads,))
-            del out
-        self._all("rows_pub", left, right)
-        self._all("rows_compose", path, self.n_reads)
-        self._all("rows_done")
-        res = []
-        for k in range(4):                                # private (copy-on-write) mappings of what the workers wrote: no copy here
-            p = "%s.%d.npy" % (path, k)
-            res.append(np.load(p, mmap_mode="c") if self.n_reads else np.zeros(0, np.int32))
-            os.unlink(p)
+        self._ensure_room(16 * self.n_reads + 32 * max(1, self.n_unique) + (1 << 20))
+        try:
+            for k in range(4):
+                out = np.lib.format.open_memmap("%s.%d.npy" % (path, k), mode="w+", dtype=np.int32, shape=(self.n_reads,))
+                del out
+                # (a memmap file is sparse: reserve its blocks now, so that a full file system is an error here and not a SIGBUS in a worker)
+                fd = os.open("%s.%d.npy" % (path, k), os.O_RDWR)
+                try:
+                    if self.n_reads:
+                        os.posix_fallocate(fd, 0, os.fstat(fd).st_size)
+                finally:
+                    os.close(fd)
+            self._all("rows_pub", left, right)
+            self._all("rows_compose", path, self.n_reads)
+            self._all("rows_done")
+            res = []
+            for k in range(4):                                # private (copy-on-write) mappings of what the workers wrote: no copy here
+                p = "%s.%d.npy" % (path, k)
+                res.append(np.load(p, mmap_mode="c") if self.n_reads else np.zeros(0, np.int32))
+                os.unlink(p)
+        except BaseException:
+            self._sweep()
+            raise
         self._timed("trim_coords", t0)
         return tuple(res)
 

@@ -9,6 +9,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+# the library honours its result-changing test hooks (csrc/switches.cpp: SW_HOOK) only under this gate; the suite uses several
+# (tests/test_gpu_switches.py removes the gate and checks that every one of them is then ignored)
+os.environ.setdefault("ITSX_TEST_HOOKS", "1")
 
 
 def pytest_configure(config):

@@ -491,3 +491,59 @@ def test_sse_baseline_is_bit_identical_to_the_checker(t_hmm_text, fixture_reads)
         orc.use_library("liborc.so")
     assert out["liborc.so"] == out["libbase_sse.so"]
     assert out["liborc.so"][0][3]["multidomain"] > 0 and len(out["liborc.so"][0][1][0][1]) > 100000
+
+
+def test_every_environment_switch_is_registered_and_documented():
+    """csrc/switches.cpp is the one registry of the library's environment switches: every sw_get("...") in csrc/ names an entry, nothing
+    else calls getenv, every entry has a row in INTEGRATION.md section 7 (scripts/switch_table.py prints it), and the result-changing ones
+    are test hooks (honoured only under ITSX_TEST_HOOKS=1: tests/test_gpu_switches.py)"""
+    import ctypes as C
+    import glob
+    import re
+    from itsxpress_amd import _lib
+    L = _lib.lib()
+    n = L.itsx_switch_registry(None, 0)
+    b = C.create_string_buffer(int(n))
+    L.itsx_switch_registry(b, n)
+    reg = {line.split("\t")[0]: line.split("\t")[1] for line in b.value.decode().strip().split("\n")}
+    used = set()
+    src = os.path.join(ROOT, "itsxpress_amd", "csrc")
+    for f in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.cpp")) + glob.glob(os.path.join(src, "*.h")):
+        text = open(f).read()
+        used |= set(re.findall(r'(?:sw_get|env_int)\("(ITSX_[A-Z0-9_]+)"', text))
+        if os.path.basename(f) != "switches.cpp":
+            assert "getenv(" not in text, "%s calls getenv: every switch goes through sw_get (csrc/switches.h)" % f
+    assert used <= set(reg), sorted(used - set(reg))
+    assert set(reg) <= used | {"ITSX_TEST_HOOKS"}, sorted(set(reg) - used)
+    for k in ("ITSX_NO_ENSEMBLE", "ITSX_LAZY_ZUB_SCALE", "ITSX_LAZY_FORCE_PENDING", "ITSX_LAZY_NO_RERUN", "ITSX_LAZY_NO_COMPLETE"):
+        assert reg[k] == "hook"
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for k, kind in reg.items():
+        assert re.search(r"\| `%s` \| %s \|" % (k, kind), doc), "INTEGRATION.md section 7 lacks %s (%s)" % (k, kind)
+    # the Python layer's switches are in the same table
+    pyused = set()
+    for f in glob.glob(os.path.join(ROOT, "itsxpress_amd", "*.py")):
+        pyused |= set(re.findall(r'environ[^\n]*?"(ITSX[A-Z0-9_]+)"', open(f).read()))
+    for k in pyused:
+        assert "`%s`" % k in doc, "INTEGRATION.md section 7 lacks the Python layer's %s" % k
+
+
+def test_hooks_are_ignored_without_the_gate(monkeypatch):
+    """itsx_switches(NULL): a hook that is set without ITSX_TEST_HOOKS=1 is reported as ignored"""
+    import ctypes as C
+    from itsxpress_amd import _lib
+    L = _lib.lib()
+
+    def report():
+        n = L.itsx_switches(None, None, 0)
+        b = C.create_string_buffer(int(n))
+        L.itsx_switches(None, b, n)
+        return dict(x.split("=", 1) for x in b.value.decode().split("\n") if "=" in x)
+    monkeypatch.delenv("ITSX_TEST_HOOKS", raising=False)
+    monkeypatch.setenv("ITSX_LAZY_NO_RERUN", "1")
+    monkeypatch.setenv("ITSX_SHARE_B", "64")
+    r = report()
+    assert "ignored" in r["ITSX_LAZY_NO_RERUN"] and r["ITSX_SHARE_B"] == "64"
+    monkeypatch.setenv("ITSX_TEST_HOOKS", "1")
+    r = report()
+    assert r["ITSX_LAZY_NO_RERUN"] == "1"

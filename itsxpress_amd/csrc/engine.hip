@@ -390,6 +390,7 @@ struct itsx_ctx {
   DBuf<unsigned long long> sh_tab, sh_mask_s, sh_mask, sh_counters; DBuf<uint8_t> sh_depth_s, sh_depth;
   DBuf<int32_t> sh_src, sh_parent_s, sh_parent, sh_nn_s, sh_nn, sh_node0_s, sh_node0, sh_order, sh_ulen, sh_uorder, sh_inv, sh_flag, sh_pos, sh_bstart, sh_cursor, sh_segk, sh_scan, sh_cuts;
   std::vector<ShareBatch> sh_batches; std::vector<int32_t> sh_segk_h;            // [batch][SHARE_SEGS]
+  DBuf<uint4> sh_mgslots; size_t sh_mgslots_half = 0;        // the MSV filter's saved Backward states (two-sided sharing)
   DBuf<uint4> sh_mslots; size_t sh_mslots_half = 0, sh_fslots_half = 0; DBuf<uint32_t> sh_pass, sh_need; DBuf<int32_t> sh_real, sh_segflat, sh_segdepth, sh_wc, sh_woff; DBuf<int64_t> sh_bnd;
   DBuf<uint16_t> sh_res_chk; DBuf<float> sh_fb_chk;
   ShareDev sh_dev{};
@@ -1786,7 +1787,8 @@ static int build_share(itsx_ctx *ctx)
   const size_t half = ((size_t)need_slots + (size_t)(two ? need_gslots : 0)) * FWD_STATE_Q;
   ctx->sh_gslots_off = (size_t)need_slots * FWD_STATE_Q;
   ctx->sh_fslots_half = (fwd_too && two_fwd && nb > 1) ? half : 0;       // (one batch: nothing to run beside it)
-  if (ctx->sh_mslots.alloc(2 * (size_t)need_slots * MSV_STATE_Q + 1) != hipSuccess ||
+  ctx->sh_mgslots_half = (size_t)need_gslots * MSV_STATE_Q;
+  if (ctx->sh_mslots.alloc(2 * (size_t)need_slots * MSV_STATE_Q + 1) != hipSuccess || (two && ctx->sh_mgslots.alloc(2 * (size_t)need_gslots * MSV_STATE_Q + 1) != hipSuccess) ||
       (fwd_too && ctx->w_slab.alloc(4 * (half * (ctx->sh_fslots_half ? 2 : 1) + 1), true) != hipSuccess)) {
     (void)hipGetLastError();
     ctx->sh_mslots.release(); bt.clear();
@@ -1797,6 +1799,7 @@ static int build_share(itsx_ctx *ctx)
   ctx->two_on = two; ctx->Ub = Ub; ctx->share_maxrd = maxrd;
   S.share_B = B; S.share_batches = nb; S.share_nodes = NN; S.share_chains = (int64_t)hc[3];
   S.msv_rows_full = (int64_t)hc[2] * P; S.msv_rows = (int64_t)(hc[2] - hc[1]) * P;
+  if (two && !(sw_get("ITSX_MSV_TWO") && atoi(sw_get("ITSX_MSV_TWO")) == 0)) S.msv_rows = (int64_t)(hc[11] + hc[12]) * P;
   if (two) { S.two_sided = 1; S.n_joined = (int64_t)hc[10]; S.bwd_chains = (int64_t)hc[14]; S.gamma_nodes = NG; S.two_fwd_rows = (int64_t)hc[11]; S.two_bwd_rows = (int64_t)hc[12]; S.two_rows_full = (int64_t)hc[2]; }
   S.ms_share_build = tm.stop();
   return ITSX_OK;
@@ -2948,6 +2951,12 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       }
       if (ctx->st3) { alt = ctx->st3; (void)hipEventRecord(ctx->ev_s3a, s); (void)hipStreamWaitEvent(alt, ctx->ev_s3a, 0); }
     }
+    // two-sided sharing (round 6): the filter is max-plus arithmetic on integers, so a chain that stops where its suffix is shared and
+    // takes the rest from the saved Backward state (k_msv_bwd) gets the unshared kernel's xJ exactly (ITSX_SHARE_CHECK counts cells)
+    static const bool msv_two = !(sw_get("ITSX_MSV_TWO") && atoi(sw_get("ITSX_MSV_TWO")) == 0);
+    const bool bi2 = ctx->two_on && msv_two;
+    int32_t cb0 = 0;
+    if (bi2) { bool any = false; for (const auto &b : ctx->sh_batches) if (b.k0 >= cu0 && b.k0 < cu0 + cU && !any) { cb0 = ctx->sh_bsegk_h[(size_t)(&b - ctx->sh_batches.data()) * SHARE_SEGS]; any = true; } }
     int seen = 0;
     for (const auto &b : ctx->sh_batches) {
       if (b.k0 < cu0 || b.k0 >= cu0 + cU) continue;
@@ -2955,9 +2964,23 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
       const bool on_alt = alt != s && (seen++ & 1);
       hipStream_t bs = on_alt ? alt : s;
       uint4 *slots = ctx->sh_mslots.p + (on_alt ? ctx->sh_mslots_half : 0);
+      uint4 *gslots = bi2 ? ctx->sh_mgslots.p + (on_alt ? ctx->sh_mgslots_half : 0) : nullptr;
       for (int r = 0; r < b.nsplit; r++) {
         const int pa = (int)((int64_t)np * r / b.nsplit), pb = (int)((int64_t)np * (r + 1) / b.nsplit);
         if (pb <= pa) continue;
+        if (bi2)
+          for (int d = 0; d <= ctx->share_maxrd; d++) {       // the batch's Backward chains, shortest suffixes first
+            const int32_t k0 = ctx->sh_bsegk_h[bi * SHARE_SEGS + d], k1 = ctx->sh_bsegk_h[bi * SHARE_SEGS + d + 1];
+            if (k1 <= k0) continue;
+            MsvArgs c = a;
+            c.sorted_uniq = ctx->sh_border.p + cb0; c.U = 0; c.res = nullptr;
+            c.k0 = (int32_t)(k0 - cb0); c.k1 = (int32_t)(k1 - cb0); c.pfirst = pa; c.plast = pb; c.share = 2;
+            c.sl.src = ctx->sh_rsrc.p + cb0; c.sl.mask = ctx->sh_rmask.p + cb0; c.sl.node0 = ctx->sh_rnode0.p + cb0; c.sl.endrow = ctx->sh_bsteps.p + cb0;
+            c.sl.slots = gslots; c.sl.node_base = b.gnode0; c.sl.p0 = pa; c.sl.Pb = pb - pa; c.sl.depth = d; c.sl.logB = ctx->share_logB;
+            const int64_t t2 = ((int64_t)(k1 - k0) + 255) / 256;
+            c.PB = (int)std::max<int64_t>(1, std::min<int64_t>(32, t2 * (pb - pa) / (alt != s ? 4096 : 16384)));
+            launch_msv(c, bs, lds_pad);
+          }
         for (int d = 0; d <= ctx->share_maxd; d++) {
           const int32_t k0 = ctx->sh_segk_h[bi * SHARE_SEGS + d], k1 = ctx->sh_segk_h[bi * SHARE_SEGS + d + 1];
           if (k1 <= k0) continue;
@@ -2965,6 +2988,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
           c.k0 = (int32_t)(k0 - cu0); c.k1 = (int32_t)(k1 - cu0); c.pfirst = pa; c.plast = pb; c.share = 1;
           c.sl.src = ctx->sh_src.p + cu0; c.sl.mask = ctx->sh_mask.p + cu0; c.sl.node0 = ctx->sh_node0.p + cu0;
           c.sl.slots = slots; c.sl.node_base = b.node0; c.sl.p0 = pa; c.sl.Pb = pb - pa; c.sl.depth = d; c.sl.logB = ctx->share_logB;
+          if (bi2) { c.sl.endrow = ctx->sh_endrow.p + cu0; c.sl.jlev = ctx->sh_jlev.p + cu0; c.sl.jsrc = ctx->sh_jsrc.p + cu0; c.sl.gslots = gslots; c.sl.gnode_base = b.gnode0; }
           // (a launch ends when its last blocks end, and the next depth waits for it: many short blocks -- rounds of the ~1 000-1 500 a
           // chip holds -- rather than a few long ones that take their sequences through 32 profiles; with the other batch's launches
           // beside it a block may be four times as long)

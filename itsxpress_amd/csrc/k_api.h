@@ -273,7 +273,8 @@ struct MsvArgs {
   int32_t k0, k1;               // sorted positions [k0, k1) of this launch (k1 = 0: all U)
   int32_t pfirst, plast;        // profiles (list positions with plist) [pfirst, plast) (plast = 0: all)
   int32_t wtl;                  // packed words a lane keeps in LDS (set by launch_msv: the whole read, or 16 at a time)
-  int32_t share;                // prefix sharing: every sequence of [k0, k1) is a chain that starts at sl.depth
+  int32_t share;                // 1: prefix sharing, every sequence of [k0, k1) is a chain that starts at sl.depth; 2: the Backward chains of the
+                                // two-sided schedule (k_msv_bwd: [k0, k1) are backward positions, sl.depth blocks from the end)
   ShareLaunch sl;
 };
 void launch_msv(const MsvArgs &a, hipStream_t st, int lds_pad = 0);

@@ -69,7 +69,16 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
     const int nw = (L + 15) >> 4;
     for (int j = 0; j < a.wtl; j++) wst[j * 256 + threadIdx.x] = (j < nw) ? wp[j] : 0u;
   }
-  int Lw = L;                                     // the wave runs to its longest sequence (lengths ascend: usually all equal)
+  // two-sided sharing (round 6, k_share.hip: k_join_*): a chain whose suffix another representative of its length ends with too stops
+  // after row `myend` = jlev * B and takes the rest of the maximum over paths from that representative's saved BACKWARD state
+  // (k_msv_bwd below).  The filter is max-plus arithmetic on integers -- every cell is a maximum over paths of sums -- so
+  //     final xJ = max over the state's components (cell_k + g_k, xJ + gJ, xB + gB, g0)
+  // is the unshared kernel's xJ exactly, and xEmax follows from it (xJ = max(0, max_i xE_i - tec) by the recurrence).
+  int myend = L, jlev = -1; int64_t jnode = 0;
+  if constexpr (SHARE) {
+    if (valid && a.sl.endrow) { myend = a.sl.endrow[s]; jlev = a.sl.jlev[s]; jnode = (int64_t)a.sl.jsrc[s] - a.sl.gnode_base; }
+  }
+  int Lw = valid ? myend : 0;                     // the wave runs to its longest chain (chains of one depth ascend by their last row)
   for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(Lw, d, 64); Lw = o > Lw ? o : Lw; }
   Lw = uni(Lw);
   const int Ppad = a.G * 64;
@@ -107,23 +116,45 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
     int ei = 0;
     int next_exc = nexc > 0 ? (int)(ep[0] >> 4) : 0x7fffffff;        // (a chain has no exception above its start: k_share.hip)
     uint32_t w = 0;
-    for (int pos = row0; pos < Lw; pos++) {
+    const int lend = myend;
+    int jxJ = -1, jem = 0;                           // the joined result, if the chain joins
+    for (int pos = row0; pos <= Lw; pos++) {
       const int sh = (pos & 15) * 2;
       if (sh == 0) {
         if constexpr (SHARE) {
           // a block boundary: the state after row `pos` (1-based) is what a chain that branches off here starts from
-          if (pos > row0 && (pos & ((1 << a.sl.logB) - 1)) == 0 && pos < L) {
+          if ((pos & ((1 << a.sl.logB) - 1)) == 0 && valid) {
             const int d = pos >> a.sl.logB;
             const unsigned long long m = a.sl.mask[s];
-            if (d < 64 && ((m >> d) & 1ull)) {
+            if (pos > row0 && pos < L && d < 64 && ((m >> d) & 1ull)) {       // (a mask has no bit above the chain's last level)
               const int64_t node = (int64_t)a.sl.node0[s] + __popcll(m & ((1ull << d) - 1ull)) - a.sl.node_base;
               uint4 *dst = (uint4 *)a.sl.slots + (node * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
 #pragma unroll
               for (int q = 0; q < 6; q++) dst[q] = make_uint4(dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], (4 * q + 3 < MSV_REGS) ? dp[(4 * q + 3) % MSV_REGS] : 0u);
               dst[6] = make_uint4((uint32_t)xJ, (uint32_t)xB, (uint32_t)xEmax, 0u);
             }
+            if (d == jlev) {
+              // the join (saturating adds: a suffix that overflows stays an overflow)
+              const uint4 *g = (const uint4 *)a.sl.gslots + (jnode * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
+              s2 mx = as_s2(0x80008000u);
+#pragma unroll
+              for (int q = 0; q < 6; q++) {
+                const uint4 v = g[q];
+                mx = __builtin_elementwise_max(mx, __builtin_elementwise_add_sat(as_s2(dp[4 * q]), as_s2(v.x)));
+                mx = __builtin_elementwise_max(mx, __builtin_elementwise_add_sat(as_s2(dp[4 * q + 1]), as_s2(v.y)));
+                mx = __builtin_elementwise_max(mx, __builtin_elementwise_add_sat(as_s2(dp[4 * q + 2]), as_s2(v.z)));
+                if (4 * q + 3 < MSV_REGS) mx = __builtin_elementwise_max(mx, __builtin_elementwise_add_sat(as_s2(dp[4 * q + 3]), as_s2(v.w)));
+              }
+              const uint4 t = g[6];
+              int xf = (int)mx.x > (int)mx.y ? (int)mx.x : (int)mx.y;
+              const int c1 = xJ + (int)t.x, c2 = xB + (int)t.y, c3 = (int)t.z;
+              xf = xf > c1 ? xf : c1; xf = xf > c2 ? xf : c2; xf = xf > c3 ? xf : c3;
+              jxJ = xf; jem = xf + tec;               // (xf + tec = the largest row maximum of the whole read when xf > 0); the chain may walk
+                                                      // on for the states its prefix children start from
+            }
           }
         }
+        if (pos >= Lw) break;
         // the lane's packed words, 16 at a time (256 rows) through LDS: one contiguous 64-byte piece of the read per load instead of a
         // dword every 16 rows -- every one of those dwords cost a whole line once 49 k lanes' lines no longer fit the XCD's L2
         // (75.6 GB fetched per 1 M reads in round 4 against 0.1-0.4 GB of packed reads; profiles/round5_pmc_hbm_traffic_1M.md)
@@ -134,7 +165,7 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
         }
         w = wst[(whole ? (pos >> 4) : ((pos >> 4) & (MSV_WT - 1))) * 256 + threadIdx.x];
       }
-      if (pos < L) {
+      if (pos < lend) {
         int code = (int)((w >> sh) & 3u);
         if (pos == next_exc) {
           code = (int)(ep[ei] & 15u);
@@ -166,11 +197,127 @@ __global__ void __launch_bounds__(256, 6) k_msv(MsvArgs a)
       }
     }
     if (valid) {
+      if (jxJ >= 0) { xJ = jxJ; xEmax = xEmax > jem ? xEmax : jem; }
       const int ovf = (xEmax + bias >= 255);
       const int thr = a.thr[(size_t)Lt * Ppad + p];
       const int pass = ovf | (xJ >= thr);
       const int xj = ovf ? 255 : xJ;
       a.res[(size_t)p * a.U + s] = (uint16_t)(pass ? (0x100 | xj) : 0);
+    }
+  }
+}
+
+// Round 6, two-sided sharing: the BACKWARD chains of the filter.  A row of the filter is a max-plus linear map of the state (46 cells, xJ,
+// xB and the constant 0: xB = max(xJ - tjbm, bm0)); the final xJ is a max-plus linear functional of the last state.  Pulled back through
+// the rows L, L - 1, ..., j B + 1 it becomes a vector g_j with  final xJ = max over components (state after row j B + g_j)  for EVERY
+// prefix: it belongs to the suffix, and the uniques of one length that end alike share it.  Lane = Backward chain (k_share.hip: the
+// uniques that save a state for somebody), the block's 256 chains start the same number of blocks from the end, a.PB profiles one after
+// the other.  With a' the adjoint of a new row's value and x the row's residue:
+//     aJ = max(gJ, gB - tjbm),  g0 <- max(g0, gB + bm0),  aE = aJ - tec
+//     w_k = max(g_k, aE) + e_k(x)   (k = 46 .. 1),   g_k-1 <- w_k  (g_46 <- none),   gB <- max_k w_k,   gJ <- aJ
+// in the forward kernel's register striping (register r = cells r, r + 23: the shift by one cell is a renaming but for the wrap register).
+// Adds saturate: a suffix whose score overflows stays above every threshold instead of wrapping.  The rows a Backward chain walks lie
+// above its read's last residue outside ACGT (k_share.hip), so it never meets an exception.
+__global__ void __launch_bounds__(256, 6) k_msv_bwd(MsvArgs a)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t tab[2][16 * MSV_TW];
+  extern __shared__ uint32_t wst[];
+  const bool whole = a.wtl > MSV_WT;
+  const int s = a.k0 + blockIdx.x * 256 + threadIdx.x;      // backward position
+  const bool valid = s < a.k1;
+  int L = 0, tjb = 0, mysteps = 0;
+  const uint32_t *wp = a.rd.words;
+  if (valid) {
+    const int r = a.seed_read[a.sorted_uniq[s]];
+    L = a.rd.len[r];
+    wp = a.rd.words + a.rd.woff[r];
+    const int Lt = L < a.Lcap ? L : a.Lcap - 1;
+    tjb = a.tjb[Lt];
+    mysteps = a.sl.endrow[s];
+  }
+  const int nw = (L + 15) >> 4;
+  if (whole) for (int j = 0; j < a.wtl; j++) wst[j * 256 + threadIdx.x] = (j < nw) ? wp[j] : 0u;
+  int nsteps = mysteps;
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(nsteps, d, 64); nsteps = o > nsteps ? o : nsteps; }
+  nsteps = uni(nsteps);
+  const int rd = a.sl.depth, logB = a.sl.logB;
+  const int A = (L + (1 << logB) - 1) >> logB;
+  const int top = (A - rd) << logB;                          // the row the chain's state stands after (virtual past L when rd = 0)
+  const int p0 = a.pfirst + blockIdx.y * a.PB;
+  int p1 = p0 + a.PB; if (p1 > a.plast) p1 = a.plast;
+  const int base = 190;
+  constexpr int NEG = -16384;
+  const unsigned long long m = valid ? a.sl.mask[s] : 0ull;
+  for (int pj = p0; pj < p1; pj++) {
+    const int p = pj;
+    uint32_t *tb = tab[(pj - p0) & 1];
+    for (int i = threadIdx.x; i < 16 * MSV_TW; i += 256) tb[i] = a.etab[(size_t)p * 16 * MSV_TW + i];
+    __syncthreads();
+    const int tec = uni(a.ptec[p]), tbm = uni(a.ptbm[p]);
+    const int tjbm = tjb + tbm;
+    int bm0 = base - tjbm; bm0 = bm0 < 0 ? 0 : bm0;
+    int gJ = 0, gB = NEG, g0 = NEG;
+    uint32_t g[MSV_REGS];
+#pragma unroll
+    for (int i = 0; i < MSV_REGS; i++) g[i] = 0xC000C000u;   // NEG in both halves
+    if (valid && rd > 0) {
+      const int64_t src_node = (int64_t)a.sl.src[s] - a.sl.node_base;
+      const uint4 *src = (const uint4 *)a.sl.slots + (src_node * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const uint4 v = src[q];
+        g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; if (4 * q + 3 < MSV_REGS) g[4 * q + 3] = v.w;
+      }
+      const uint4 v = src[6];
+      gJ = (int)v.x; gB = (int)v.y; g0 = (int)v.z;
+    }
+    uint32_t w = 0; int wi = -1;
+    for (int step = 0; ; step++) {
+      if ((step & ((1 << logB) - 1)) == 0 && step > 0 && valid) {
+        // a block boundary: the state after row top - step is what the Forward chains that end there take
+        const int rdl = rd + (step >> logB);
+        if (step <= mysteps && rdl < 64 && ((m >> rdl) & 1ull)) {
+          const int64_t node = (int64_t)a.sl.node0[s] + __popcll(m & ((1ull << rdl) - 1ull)) - a.sl.node_base;
+          uint4 *dst = (uint4 *)a.sl.slots + (node * a.sl.Pb + (pj - a.pfirst)) * MSV_STATE_Q;
+#pragma unroll
+          for (int q = 0; q < 6; q++) dst[q] = make_uint4(g[4 * q], g[4 * q + 1], g[4 * q + 2], (4 * q + 3 < MSV_REGS) ? g[(4 * q + 3) % MSV_REGS] : 0u);
+          dst[6] = make_uint4((uint32_t)gJ, (uint32_t)gB, (uint32_t)g0, 0u);
+        }
+      }
+      if (step >= nsteps) break;
+      const int row = top - step;                             // this step pulls the state back through row `row` (1-based)
+      if (row <= L && step < mysteps) {
+        const int pos = row - 1;
+        if ((pos >> 4) != wi) {
+          wi = pos >> 4;
+          if (whole) w = wst[wi * 256 + threadIdx.x];
+          else w = wp[wi];                                    // (reads past 592 bases: a dword every 16 rows)
+        }
+        const int code = (int)((w >> ((pos & 15) * 2)) & 3u);
+        const uint4 *e4 = (const uint4 *)(tb + code * MSV_TW);
+        uint32_t e[MSV_TW];
+#pragma unroll
+        for (int q = 0; q < MSV_TW / 4; q++) { const uint4 v = e4[q]; e[4 * q] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w; }
+        int aJ = gB - tjbm; aJ = aJ > gJ ? aJ : gJ;
+        const int n0 = gB + bm0; g0 = g0 > n0 ? g0 : n0;
+        int aE = aJ - tec; aE = aE > 30000 ? 30000 : aE;
+        const s2 aEv = as_s2((uint32_t)(aE & 0xffff) * 0x10001u);
+        s2 mxa = as_s2(0xC000C000u), mxb = as_s2(0xC000C000u);
+        // W[r] = (w of cells r, r + 23); the new g[r] is W[r + 1], the new g[22] = (W[0]'s high half, nothing)
+        const s2 W0 = __builtin_elementwise_add_sat(__builtin_elementwise_max(as_s2(g[0]), aEv), as_s2(e[0]));
+        mxa = __builtin_elementwise_max(mxa, W0);
+#pragma unroll
+        for (int r = 1; r < MSV_REGS; r++) {
+          const s2 Wr = __builtin_elementwise_add_sat(__builtin_elementwise_max(as_s2(g[r]), aEv), as_s2(e[r]));
+          if (r & 1) mxb = __builtin_elementwise_max(mxb, Wr); else mxa = __builtin_elementwise_max(mxa, Wr);
+          g[r - 1] = as_u(Wr);
+        }
+        g[MSV_REGS - 1] = (as_u(W0) >> 16) | 0xC0000000u;
+        const uint32_t m2 = as_u(__builtin_elementwise_max(mxa, mxb));
+        const int lo = (int)(int16_t)(m2 & 0xffffu), hi = (int)(int16_t)(m2 >> 16);
+        gB = lo > hi ? lo : hi;
+        gJ = aJ;
+      }
     }
   }
 }
@@ -191,7 +338,8 @@ void launch_msv(const MsvArgs &a0, hipStream_t st, int lds_pad)
   const int need = (a.Lcap - 1 + 15) / 16;
   a.wtl = (allow_whole && need > MSV_WT && need <= 37) ? need : MSV_WT;
   const size_t lds = std::max<size_t>((size_t)lds_pad, (size_t)a.wtl * 256 * sizeof(uint32_t));
-  if (a.share) hipLaunchKernelGGL(k_msv<true>, grid, dim3(256), lds, st, a);
+  if (a.share == 2) hipLaunchKernelGGL(k_msv_bwd, grid, dim3(256), lds, st, a);
+  else if (a.share) hipLaunchKernelGGL(k_msv<true>, grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL(k_msv<false>, grid, dim3(256), lds, st, a);
 }
 

@@ -34,6 +34,7 @@ static const Switch g_sw[] = {
   // ---- TUNING (result-neutral)
   {"ITSX_SHARE", SW_TUNING, "=0: no prefix sharing (round 4's schedule)"},
   {"ITSX_SHARE_TWO", SW_TUNING, "=0: one-sided (prefix-only) sharing for pass A"},
+  {"ITSX_MSV_TWO", SW_TUNING, "=0: the MSV filter keeps the one-sided (prefix-only) schedule when pass A shares two-sidedly"},
   {"ITSX_SHARE_B", SW_TUNING, "rows per block of the prefix / suffix trees (default 32)"},
   {"ITSX_SHARE_GB", SW_TUNING, "budget of the saved row states, GB"},
   {"ITSX_SHARE_MIN", SW_TUNING, "smallest shared-row fraction for which the shared schedule is used (default 0.10)"},

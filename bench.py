@@ -89,7 +89,7 @@ PMC_SOURCE = None
 
 def _load_pmc():
     global PMC_BYTES_PER_ROW, PMC_SOURCE
-    for name in ("round5_pmc_bytes_per_row.json", "round4_pmc_bytes_per_row.json", "round2_pmc_bytes_per_row.json"):
+    for name in ("round6_pmc_bytes_per_row.json", "round5_pmc_bytes_per_row.json", "round4_pmc_bytes_per_row.json", "round2_pmc_bytes_per_row.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             with open(p) as f:
@@ -779,6 +779,7 @@ def main():
                        # had the same first residues (the state comes from its saved row state); tree = what the prefix tree offers at this block size
                        # pass A's rows (Forward chains + Backward chains) over the rows of its pairs: what two-sided sharing leaves to compute
                        "rows_computed_frac": round((st["bound_rows"] + st.get("bwd_rows", 0)) / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,
+                       "lane_rows": {k: int(st[k]) for k in ("bound_rows", "bwd_rows", "bound_rows_full", "msv_rows", "msv_rows_full")},
                        "two_sided": ({"joined_representatives": int(st["n_joined"]), "backward_chains": int(st["bwd_chains"]), "backward_states": int(st["gamma_nodes"]),
                                       "forward_rows_frac": round(st["bound_rows"] / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,
                                       "backward_rows_frac": round(st["bwd_rows"] / st["bound_rows_full"], 4) if st.get("bound_rows_full") else None,

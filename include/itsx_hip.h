@@ -408,6 +408,10 @@ int itsx_get_stats(const itsx_ctx *ctx, itsx_stats *out, int64_t out_size);
  * started) or, with ctx == NULL, of the environment now.  A test hook (result-changing) is honoured only under ITSX_TEST_HOOKS=1 and
  * says so here otherwise.  The reference has no such surface: it passes fixed flags (itsxpress/SeqSample.py:191-209).
  * Returns the length needed, terminator included. */
+/* A context that will not search again soon (a streamed file's chunk, itsxpress_amd/stream.py) hands its largest scratch buffer -- the DP
+ * slab, tens of GB -- to the next context of the process on that device; results and everything itsx_search_finalize /
+ * itsx_lazy_complete need stay.  The reference has nothing of the kind (one process per tool run, itsxpress/SeqSample.py:117,210). */
+int itsx_release_scratch(itsx_ctx *ctx);
 int64_t itsx_switches(const itsx_ctx *ctx, char *buf, int64_t cap);
 /* the registry: "NAME<tab>class<tab>meaning" lines, class = tuning | mode | diagnostic | hook */
 int64_t itsx_switch_registry(char *buf, int64_t cap);

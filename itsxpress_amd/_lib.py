@@ -66,7 +66,7 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_load_reads_file", "itsx_derep", "itsx_cluster", "itsx_get_cluster", "itsx_get_derep", "itsx_unique_keys", "itsx_set_active_uniques", "itsx_get_uniques",
            "itsx_search", "itsx_get_domz", "itsx_set_domz", "itsx_search_finalize", "itsx_num_domains",
            "itsx_get_domains", "itsx_num_pairtraces", "itsx_get_pairtraces", "itsx_trim_coords",
-           "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats", "itsx_switches", "itsx_switch_registry",
+           "itsx_rep_coords", "itsx_write_uc", "itsx_write_rep_fasta", "itsx_write_domtbl", "itsx_get_stats", "itsx_switches", "itsx_switch_registry", "itsx_release_scratch",
            "itsx_debug_read_hashes", "itsx_debug_packed_read", "itsx_debug_detmath", "itsx_debug_logf", "itsx_debug_dust", "itsx_debug_calibrate", "itsx_debug_issue", "itsx_shard_text", "itsx_shard_last_error", "itsx_owner_verdicts",
            "itsx_write_trimmed_fastq", "itsx_write_trimmed_paired", "itsx_trim_last_error",
            "itsx_merge_buffers", "itsx_merge_pairs_files", "itsx_merge_pairs_load", "itsx_merge_tables",
@@ -170,6 +170,7 @@ def lib():
         "itsx_write_domtbl": (i32, [vp, cp]),
         "itsx_get_stats": (i32, [vp, vp, i64]),
         "itsx_switches": (i64, [vp, vp, i64]),
+        "itsx_release_scratch": (i32, [vp]),
         "itsx_switch_registry": (i64, [vp, i64]),
         "itsx_debug_read_hashes": (i32, [vp, vp, vp]),
         "itsx_debug_packed_read": (i32, [vp, i64, vp, vp, vp, vp]),

@@ -187,6 +187,37 @@ static void defer_free(void *q, size_t bytes)
   if (flush) grave_flush();
 }
 
+// The DP slab (pass A's saved states, then the rounds' rows) is the one buffer of tens of GB, and FRESH device memory costs 20-40 ms per GB
+// (it is cleared): a streamed file's chunk contexts each brought their own (round 6: 9 x ~1 s).  A context that is done with its slab
+// (itsx_release_scratch: its stream is idle) puts it here, and the next context's slab request takes a block of at least its size from
+// here before it asks the driver.  Blocks leave the pool when the last context is destroyed.
+struct PoolBlock { void *p; size_t bytes; int device; };
+static std::mutex g_pool_mu;
+static std::vector<PoolBlock> g_pool;
+static int g_live_contexts = 0;
+static void *pool_take(size_t bytes, int device, size_t *got)
+{
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  int best = -1;
+  for (size_t i = 0; i < g_pool.size(); i++)
+    if (g_pool[i].device == device && g_pool[i].bytes >= bytes && (best < 0 || g_pool[i].bytes < g_pool[(size_t)best].bytes)) best = (int)i;
+  if (best < 0) return nullptr;
+  void *q = g_pool[(size_t)best].p; *got = g_pool[(size_t)best].bytes;
+  g_pool.erase(g_pool.begin() + best);
+  return q;
+}
+static void pool_put(void *q, size_t bytes, int device)
+{
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  g_pool.push_back(PoolBlock{q, bytes, device});
+}
+static void pool_flush()
+{
+  std::vector<PoolBlock> v;
+  { std::lock_guard<std::mutex> g(g_pool_mu); v.swap(g_pool); }
+  for (auto &b : v) (void)hipFree(b.p);
+}
+
 // The labels of a read set: one blob + offsets instead of one std::string per record (10-20 M allocations per 10 M-read run, and
 // as many moves when the parser's pieces are joined).  The part of std::vector<std::string>'s interface the engine uses.
 struct NameList {
@@ -224,6 +255,7 @@ struct NameList {
 
 template <class T> struct DBuf {
   T *p = nullptr; size_t n = 0, cap = 0;
+  int pool_device = -1;       // >= 0: a request that must allocate looks in the slab pool first (the DP slab only)
   // exact: no growth headroom (the slabs: their size is a budget, not a data-dependent count)
   hipError_t alloc(size_t count, bool exact = false)
   {
@@ -237,6 +269,10 @@ template <class T> struct DBuf {
     }
     p = nullptr; cap = 0;
     if (!count) return hipSuccess;
+    if (pool_device >= 0) {
+      size_t got = 0;
+      if (void *q = pool_take(count * sizeof(T), pool_device, &got)) { p = (T *)q; cap = got / sizeof(T); return hipSuccess; }
+    }
     const size_t want = exact ? count : count + count / 8 + 64;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
@@ -493,6 +529,8 @@ itsx_ctx *itsx_create(int device_id, int flags)
   }
   itsx_ctx *ctx = new itsx_ctx();
   ctx->device = device_id;
+  ctx->w_slab.pool_device = device_id;
+  { std::lock_guard<std::mutex> g(g_pool_mu); g_live_contexts++; }
   if (hipStreamCreate(&ctx->st) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete ctx; return nullptr; }
   if (!(sw_get("ITSX_LOAD_PRIORITY") && atoi(sw_get("ITSX_LOAD_PRIORITY")) == 0)) {
     int least = 0, greatest = 0;
@@ -523,6 +561,22 @@ void itsx_destroy(itsx_ctx *ctx)
   for (int k = 0; k < itsx_ctx::NSTAGE; k++) { if (ctx->stage_pin[k]) (void)hipHostFree(ctx->stage_pin[k]); if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]); }
   delete ctx;
   grave_flush();                         // this context's buffers, and whatever the others have given up meanwhile
+  bool last = false;
+  { std::lock_guard<std::mutex> g(g_pool_mu); last = --g_live_contexts <= 0; }
+  if (last) pool_flush();
+}
+
+// A context that will not search again soon (a streamed file's chunk after its search; results, row lists and everything a finalize or
+// a completion needs stay) hands its DP slab to the next context on the device.  Safe: its streams are drained first.
+int itsx_release_scratch(itsx_ctx *ctx)
+{
+  CTXCHK(ctx);
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->st));
+  if (ctx->st2) HIPCHK(hipStreamSynchronize(ctx->st2));
+  if (ctx->st3) HIPCHK(hipStreamSynchronize(ctx->st3));
+  if (ctx->w_slab.p) { pool_put(ctx->w_slab.p, ctx->w_slab.cap * sizeof(float), ctx->device); ctx->w_slab.p = nullptr; ctx->w_slab.n = ctx->w_slab.cap = 0; }
+  return ITSX_OK;
 }
 
 // ------------------------------------------------------------------------------ profiles
@@ -1701,6 +1755,9 @@ static int build_share(itsx_ctx *ctx)
   // thousands of waves, and device memory is not free to get (20-40 ms per GB in a fresh context: a streamed file's chunks each bring
   // their own -- round 5's first streamed run spent 5 s in hipMalloc for slots its 1.3 M-read chunks filled to a tenth)
   if (!sw_get("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)((int64_t)NN + NG) * state_b * (double)P / (double)(1ull << 30) / 4.0));
+  // (in steps of half a GB: a budget that follows the free memory byte by byte made every search of a warm context ask for a slab a few
+  // KB larger than the one it held -- 20 GB freed and allocated again per search)
+  if (gb > 1.0) gb = floor(gb * 2.0) / 2.0;
   const int64_t nodes_max = std::max<int64_t>(1, (int64_t)(gb * (double)(1ull << 30) / (state_b * (double)P)));
   std::vector<int32_t> bstart; std::vector<itsx_ctx::ShareBatch> &bt = ctx->sh_batches;
   {
@@ -1789,7 +1846,7 @@ static int build_share(itsx_ctx *ctx)
   ctx->sh_fslots_half = (fwd_too && two_fwd && nb > 1) ? half : 0;       // (one batch: nothing to run beside it)
   ctx->sh_mgslots_half = (size_t)need_gslots * MSV_STATE_Q;
   if (ctx->sh_mslots.alloc(2 * (size_t)need_slots * MSV_STATE_Q + 1) != hipSuccess || (two && ctx->sh_mgslots.alloc(2 * (size_t)need_gslots * MSV_STATE_Q + 1) != hipSuccess) ||
-      (fwd_too && ctx->w_slab.alloc(4 * (half * (ctx->sh_fslots_half ? 2 : 1) + 1), true) != hipSuccess)) {
+      (fwd_too && ctx->w_slab.alloc(((4 * (half * (ctx->sh_fslots_half ? 2 : 1) + 1) + ((size_t)64 << 20) - 1) >> 26) << 26, true) != hipSuccess)) {
     (void)hipGetLastError();
     ctx->sh_mslots.release(); bt.clear();
     S.ms_share_build = tm.stop();

@@ -475,6 +475,11 @@ class Engine:
         self._chk(self.L.itsx_get_stats(self.h, s.ctypes.data, STATS_DTYPE.itemsize))
         return {k: (s[0][k].item() if s[0][k].ndim == 0 else s[0][k].tolist()) for k in STATS_DTYPE.names}
 
+    def release_scratch(self):
+        """hand the context's DP slab (tens of GB) to the next context of this process on the device: a streamed file's chunk after
+        its search (results and what finalize / complete need stay)"""
+        self._chk(self.L.itsx_release_scratch(self.h))
+
     def switches(self, now=False):
         """the library's environment switches that were set when the last search started (now=True: that are set now), as a dict
         NAME -> value; a test hook that is not honoured (no ITSX_TEST_HOOKS=1) carries the note "(ignored: ...)" """

@@ -524,6 +524,7 @@ class StreamEngine(ShardedOps):
 
         def do_search(k, eng, st, t_text, t_loaded):
             zs[k] = _HANDLERS["search"](eng, st, self._mode, *self._search_args)
+            eng.release_scratch()                         # (the next chunk's context takes this one's slab instead of fresh memory)
             self.timeline.append((k, round(t_text, 3), round(t_loaded, 3), round(time.perf_counter() - t0, 3)))
             if fin is not None:
                 fin_q.put(k)

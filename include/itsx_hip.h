@@ -203,8 +203,22 @@ int itsx_load_reads_text(itsx_ctx *ctx, const char *text, int64_t nbytes, int64_
  *   gid[n_unique] (may be NULL): the sequence's number in first-seen order = its index in the global unique list.
  * Errors: negative code, text from itsx_stream_last_error(). */
 int itsx_stream_open(const char *path, itsx_stream **out);
+/* Round 6, for a multi-GPU driver (itsxpress_amd/multi.py; replaces the reference's whole-file read of itsxpress/main.py:295-330 for N
+ * worker processes): the text is inflated into a SHARED mapping of `backing` (a new, sparse file the caller unlinks), so that a worker
+ * maps the slice it is told about -- offset = slice address - itsx_stream_base(s) -- while later slices are still being inflated; no
+ * copy of the pieces.  *plain_input = 1: the input is uncompressed and was not copied: the offsets are offsets into the input file.
+ * itsx_stream_progress: text bytes that are final, compressed bytes behind them, the file's size (for an estimate of the whole
+ * text's size before it is there: even pieces). */
+int itsx_stream_open_shared(const char *path, const char *backing, itsx_stream **out, int32_t *plain_input);
+const char *itsx_stream_base(itsx_stream *s);
+int itsx_stream_progress(itsx_stream *s, int64_t *avail, int64_t *consumed, int64_t *raw_size);
 int itsx_stream_next(itsx_stream *s, int64_t min_bytes, const char **text, int64_t *nbytes, int32_t *last);
 int itsx_stream_close(itsx_stream *s, int32_t keep_text);
+/* Round 6, a streamed PAIRED sample (itsxpress/SeqSample.py:266-365, main.py:513-519: the reference merges the whole files first):
+ * R1's slice comes from itsx_stream_next, itsx_count_records says how many records it holds, and the mate file's stream hands out
+ * exactly that many with itsx_stream_next_records (fewer only at the end of its file: *got). */
+int itsx_stream_next_records(itsx_stream *s, int64_t n_records, const char **text, int64_t *nbytes, int64_t *got, int32_t *last);
+int64_t itsx_count_records(const char *text, int64_t nbytes);
 /* an upper bound of the number of records in the whole file (lines / 4 for FASTQ), or -1 while it is still being inflated */
 int64_t itsx_stream_records_bound(itsx_stream *s);
 const char *itsx_stream_last_error(void);
@@ -273,6 +287,11 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
  * itsx_merge_pairs_files + itsx_load_reads_file. */
 int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_path, int maxdiffs, double maxee, int allow_stagger,
                           int64_t *n_pairs, int64_t *n_merged);
+/* the same from record-aligned pieces of the two files' text that hold the same number of records (a streaming driver's slices), and,
+ * per pair of the last merge-and-load, the index of its merged read in the context's read set (-1: not merged) */
+int itsx_merge_pairs_load_text(itsx_ctx *ctx, const char *text1, int64_t nbytes1, const char *text2, int64_t nbytes2, int maxdiffs, double maxee, int allow_stagger,
+                               int64_t *n_pairs, int64_t *n_merged);
+int itsx_merge_pair_index(const itsx_ctx *ctx, int32_t *index, int64_t n_pairs);
 int itsx_merge_tables(double *q2p, double *match, double *mism, uint8_t *qsame, uint8_t *qdiff);
 
 /* ---- a1: SeqSample.deduplicate (itsxpress/SeqSample.py:93-131)
@@ -440,6 +459,9 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
  * itsx_twriter_update names it.  itsx_twriter_close waits for the pool, fails if a record was left undecided, frees the object.
  * Errors: negative code, text from itsx_trim_last_error(). */
 int itsx_twriter_open(const char *out_path, int compression, int trim_ccs, itsx_twriter **w);
+/* mode 1 (a paired run's mates, itsxpress/SeqSample.py:587-670): (start, stop) are Python slice bounds as they come -- start may be
+ * negative, stop == INT32_MAX = open end, stop == INT32_MIN = the record is not written */
+int itsx_twriter_set_mode(itsx_twriter *w, int32_t mode);
 int itsx_twriter_text(itsx_twriter *w, const char *text, int64_t avail, int32_t last);
 int itsx_twriter_coords(itsx_twriter *w, int64_t first_record, int64_t n, const int32_t *start, const int32_t *stop, const uint8_t *decided);
 int itsx_twriter_update(itsx_twriter *w, const int64_t *records, int64_t m, const int32_t *start, const int32_t *stop);

@@ -219,6 +219,16 @@ class SeqSample:
             left, right = _REGION_PREFIX[region]
             eng.plan_output(outfile, left, right, gzipped=gzipped, zstd_file=zstd_file, trim_ccs=trim_ccs)
 
+    def plan_output_paired(self, outfile1: str, outfile2: str, region: str, gzipped: bool = False, zstd_file: bool = False) -> None:
+        """Optional, before deduplicate(): where the two mates' trimmed files will go (Dedup.create_paired_trimmed_seqs' arguments,
+        main.py:556-624).  A streaming engine then writes them while it scores; every other engine ignores the plan."""
+        eng = self.engine
+        # (only when the files that are merged are the files that are sliced: with reversed primers the reference merges fastq2 / fastq
+        # but slices fastq / fastq2, SeqSample.py:244-264 -- that sample takes the staged writer)
+        if self._is_fast() and hasattr(eng, "plan_output_paired") and getattr(self, "r1", None) == self.fastq:
+            left, right = _REGION_PREFIX[region]
+            eng.plan_output_paired(outfile1, outfile2, left, right, gzipped=gzipped, zstd_file=zstd_file)
+
     # -- array fast path (a5/a6/a7 composed) ----------------------------------------------
     def trim_coordinates(self, region: str):
         """Per-read (start, stop, tlen, in_ddict) arrays straight from the device; -1 = None."""
@@ -273,7 +283,10 @@ class SeqSamplePairedNotInterleaved(SeqSample):
             else:
                 n, m = eng.merge_pairs_files(self.r1, self.fastq2, seq_file, maxdiffs=maxmismatches, maxee=2.0,
                                              allow_stagger=bool(stagger))
-            logging.info("%d pairs, %d merged", n, m)
+            if n >= 0:
+                logging.info("%d pairs, %d merged", n, m)
+            else:
+                logging.info("itsx_hip: the pairs are merged chunk by chunk while the files are inflated (streamed)")
             self.seq_file = seq_file
         except EngineError as e:
             logging.exception("Could not perform read merging with the HIP engine: %s", e)
@@ -473,6 +486,10 @@ class Dedup:
         if not wri_file:
             return
         if self._engine is not None and getattr(itspos, "_engine", None) is self._engine:
+            planned = getattr(self._engine, "output_planned_paired", None)
+            if planned is not None and not trim_ccs and planned(outfile1, outfile2, itspos.leftprefix, itspos.rightprefix, gzipped, zstd_file):
+                self._engine.finish_output()        # a streaming engine has written both while it scored (SeqSample.plan_output_paired)
+                return
             start, stop, tlen, _ = self._engine.trim_coords(itspos.leftprefix, itspos.rightprefix)
             write_trimmed_paired(self.fastq, self.fastq2, outfile1, outfile2, self._engine.read_names_raw(), start, stop, tlen,
                                  gzipped=gzipped, trim_ccs=trim_ccs, zstd_file=zstd_file)

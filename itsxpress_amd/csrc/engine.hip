@@ -433,6 +433,7 @@ struct itsx_ctx {
   // two-sided sharing (round 6): the suffix tree by s (sh_r*_s), the joins, the Backward chains by backward position kb (sh_bdev), their
   // batches' first positions (sh_bsegk_h), the slots of the saved Backward states behind the Forward ones in the DP slab
   std::string switches_at_search;
+  std::vector<int32_t> h_merge_index;      // per pair of the last merge-and-load: its merged read, -1 = not merged
   bool two_on = false; int share_maxrd = 0; int32_t Ub = 0; size_t sh_gslots_off = 0;
   DBuf<uint8_t> sh_rdepth_s, sh_rdepth; DBuf<unsigned long long> sh_rmask_s, sh_rmask, sh_keys, sh_keys2;
   DBuf<int32_t> sh_rparent_s, sh_rparent, sh_jlev_s, sh_jown_s, sh_endrow_s, sh_rsteps_s, sh_rnn_s, sh_rnode0_s, sh_endrow, sh_jlev, sh_jsrc, sh_jownb;
@@ -3706,15 +3707,20 @@ int itsx_merge_pairs_files(itsx_ctx *ctx, const char *r1_path, const char *r2_pa
 // a gap-free text on the device and packed where it is -- the merged bases never visit the host, the merged qualities are not needed at
 // all (the paired writer slices the ORIGINAL R1 / R2 records with the merged reads' coordinates).  Labels = R1 identifiers of the merged
 // pairs, in input order, as itsx_merge_pairs_files writes them.
-int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_path, int maxdiffs, double maxee, int allow_stagger, int64_t *n_pairs, int64_t *n_merged)
+// the two sides of a paired sample from files (text1 == nullptr) or from record-aligned pieces of their text already in memory (a
+// streaming driver's slices: itsx_merge_pairs_load_text)
+static int merge_pairs_load_impl(itsx_ctx *ctx, const char *r1_path, const char *r2_path, const char *text1, int64_t nb1, const char *text2, int64_t nb2,
+                                 int maxdiffs, double maxee, int allow_stagger, int64_t *n_pairs, int64_t *n_merged)
 {
-  CTXCHK(ctx && r1_path && r2_path);
   typedef FastxPart Side;
-  auto parse = [](const char *path, Side &sd, std::string &perr) -> int {
-    const auto tp = slurp(path, true, perr);
-    if (!tp) return ITSX_E_IO;
-    if (!tp->empty() && (*tp)[0] != '@') { perr = std::string("malformed FASTQ record 1 in ") + path; return ITSX_E_FORMAT; }
-    const int prc = parse_fastx(*tp, true, true, sd, perr);
+  auto parse = [](const char *path, const char *text, int64_t nb, Side &sd, std::string &perr) -> int {
+    std::shared_ptr<const itsx_io::Text> tp;
+    itsx_io::Text view;
+    const itsx_io::Text *t = &view;
+    if (text) view.borrow(text, (size_t)nb);
+    else { tp = slurp(path, true, perr); if (!tp) return ITSX_E_IO; t = tp.get(); }
+    if (!t->empty() && (*t)[0] != '@') { perr = std::string("malformed FASTQ record 1 in ") + path; return ITSX_E_FORMAT; }
+    const int prc = parse_fastx(*t, true, true, sd, perr);
     if (prc != ITSX_OK) perr += std::string(" in ") + path;
     return prc;
   };
@@ -3723,8 +3729,8 @@ int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_pat
   int rc2 = ITSX_OK;
   static const bool trace = sw_get("ITSX_TRACE_ALLOC") != nullptr;
   const auto tm0 = std::chrono::steady_clock::now();
-  std::thread other([&] { rc2 = parse(r2_path, r, rerr2); });
-  int rc = parse(r1_path, f, ferr);
+  std::thread other([&] { rc2 = parse(r2_path, text2, nb2, r, rerr2); });
+  int rc = parse(r1_path, text1, nb1, f, ferr);
   other.join();
   const auto tm1 = std::chrono::steady_clock::now();
   if (rc != ITSX_OK) { ctx->set_error(ferr); return rc; }
@@ -3740,8 +3746,10 @@ int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_pat
   hipStream_t st = ctx->st;
   std::vector<int64_t> srcoff, dstoff(1, 0);
   ctx->h_names.clear();
+  ctx->h_merge_index.assign((size_t)n, -1);              // per pair: its merged read (itsx_merge_pair_index)
   for (int64_t i = 0; i < n; i++) {
     if (reason[i] != 0) continue;
+    ctx->h_merge_index[(size_t)i] = (int32_t)srcoff.size();
     srcoff.push_back(f.off[i] + r.off[i]);
     dstoff.push_back(dstoff.back() + olen[i]);
     ctx->h_names.emplace_back(f.ids.ptr((size_t)i), f.ids.ptr((size_t)i) + f.ids.len((size_t)i));
@@ -3765,6 +3773,27 @@ int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_pat
   if (n_pairs) *n_pairs = n;
   if (n_merged) *n_merged = m;
   return rc;
+}
+int itsx_merge_pairs_load(itsx_ctx *ctx, const char *r1_path, const char *r2_path, int maxdiffs, double maxee, int allow_stagger, int64_t *n_pairs, int64_t *n_merged)
+{
+  CTXCHK(ctx && r1_path && r2_path);
+  return merge_pairs_load_impl(ctx, r1_path, r2_path, nullptr, 0, nullptr, 0, maxdiffs, maxee, allow_stagger, n_pairs, n_merged);
+}
+// Round 6 (a streamed paired sample, itsxpress_amd/stream.py): the same, from record-aligned pieces of R1's and R2's text that hold the
+// same number of records (itsx_stream_next / itsx_stream_next_records)
+int itsx_merge_pairs_load_text(itsx_ctx *ctx, const char *text1, int64_t nbytes1, const char *text2, int64_t nbytes2, int maxdiffs, double maxee, int allow_stagger,
+                               int64_t *n_pairs, int64_t *n_merged)
+{
+  CTXCHK(ctx && text1 && text2 && nbytes1 >= 0 && nbytes2 >= 0);
+  return merge_pairs_load_impl(ctx, "(R1 slice)", "(R2 slice)", text1, nbytes1, text2, nbytes2, maxdiffs, maxee, allow_stagger, n_pairs, n_merged);
+}
+// per pair of the last itsx_merge_pairs_load / _load_text: the index of its merged read in the context's read set, -1 = not merged
+int itsx_merge_pair_index(const itsx_ctx *ctx, int32_t *index, int64_t n_pairs)
+{
+  CTXCHK(ctx && index);
+  if ((size_t)n_pairs != ctx->h_merge_index.size()) SET_ERR(ctx, ITSX_E_ARG, "itsx_merge_pair_index: the last merge held " + std::to_string(ctx->h_merge_index.size()) + " pairs");
+  memcpy(index, ctx->h_merge_index.data(), (size_t)n_pairs * sizeof(int32_t));
+  return ITSX_OK;
 }
 
 // ------------------------------------------------------------------------------ coordinates

@@ -30,14 +30,27 @@ inline size_t page_up(size_t n) { return (n + 4095) & ~(size_t)4095; }
 void Text::release()
 {
   if (kind_ == 1) free(p_);
-  else if (kind_ == 2) munmap(p_, cap_);
+  else if (kind_ == 2 || kind_ == 5) munmap(p_, cap_);
   std::string().swap(own_);
   p_ = nullptr; n_ = cap_ = 0; kind_ = 0; pinned_ = false;
+}
+bool Text::reserve_file(const char *path, size_t cap)
+{
+  release();
+  const size_t want = page_up(std::max<size_t>(cap, 4096));
+  const int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+  if (fd < 0) return false;
+  if (ftruncate(fd, (off_t)want) != 0) { close(fd); unlink(path); return false; }
+  void *q = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_NORESERVE, fd, 0);
+  close(fd);
+  if (q == MAP_FAILED) { unlink(path); return false; }
+  p_ = (char *)q; cap_ = want; n_ = 0; kind_ = 5;
+  return true;
 }
 bool Text::reserve(size_t cap)
 {
   if (cap <= cap_) return true;
-  if (pinned_ || kind_ == 4) return false;
+  if (pinned_ || kind_ == 4 || kind_ == 5) return false;
   if (kind_ == 3) {                                     // an adopted string grows as a string does
     const size_t keep = n_;
     try { own_.resize(cap); } catch (...) { return false; }
@@ -431,6 +444,7 @@ struct StreamImpl {
   std::mutex mu;
   std::condition_variable cv;
   size_t avail = 0;            // bytes of *text that are final
+  size_t consumed = 0;         // compressed bytes behind them
   bool done = false, failed = false, joined = true;
   std::string err;
   size_t handed = 0;
@@ -472,13 +486,24 @@ TextStream::~TextStream()
   delete s;
 }
 
-bool TextStream::open(const char *path, std::string &err)
+void TextStream::progress(size_t *avail, size_t *consumed, size_t *raw_size)
+{
+  std::lock_guard<std::mutex> g(s->mu);
+  const size_t raw = (size_t)s->fsize;
+  if (avail) *avail = s->avail;
+  if (consumed) *consumed = s->done ? raw : s->consumed;
+  if (raw_size) *raw_size = raw;
+}
+const char *TextStream::base() const { return s->text->data(); }
+
+bool TextStream::open(const char *path, std::string &err, const char *shared_backing, bool *plain_input)
 {
   codecs();
   s->path = path;
+  if (plain_input) *plain_input = false;
   if (!stat_of(path, s->fsize, s->mtime)) { err = std::string("cannot read ") + path; return false; }
   const double budget = cache_budget_bytes();
-  if (budget > 0) {                                   // already inflated in this process: one piece
+  if (budget > 0 && !shared_backing) {                // already inflated in this process: one piece
     std::lock_guard<std::mutex> g(g_cache_mu);
     for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
       if (it->path == s->path && it->size == s->fsize && it->mtime_ns == s->mtime) {
@@ -492,10 +517,20 @@ bool TextStream::open(const char *path, std::string &err)
   const bool par = is_gzip(s->raw) && env_int("ITSX_PARALLEL_INFLATE", 1) != 0 && T > 1;
   if (!par) {
     bool ok = true;
+    const bool packed = is_gzip(s->raw) || is_zstd(s->raw);
     if (is_gzip(s->raw)) ok = g_ld.ok ? gunzip_libdeflate(s->raw, *s->text, err) : gunzip_zlib(s->raw, *s->text, err);
     else if (is_zstd(s->raw)) ok = unzstd(s->raw, *s->text, err);
-    else s->text->swap(s->raw);
+    else { s->text->swap(s->raw); if (plain_input) *plain_input = true; }
     if (!ok) { err += std::string(" in ") + path; return false; }
+    if (shared_backing && packed) {                   // (one thread's inflate: the text goes to the shared file afterwards)
+      auto sh = std::make_shared<Text>();
+      if (!sh->reserve_file(shared_backing, s->text->size() + 1)) { err = std::string("cannot create ") + shared_backing; return false; }
+      memcpy(sh->data(), s->text->data(), s->text->size());
+      const size_t m = s->text->size();
+      sh->pin(false);
+      s->text = sh;
+      s->text->resize(m);
+    }
     s->avail = s->text->size(); s->done = true;
     return true;
   }
@@ -505,14 +540,20 @@ bool TextStream::open(const char *path, std::string &err)
   const size_t rx = (size_t)std::max(1, env_int("ITSX_STREAM_RESERVE_X", 64)), rmb = (size_t)std::max(0, env_int("ITSX_STREAM_RESERVE_MB", 1024));
   size_t want = n * rx + (rmb << 20);
   const size_t least = std::min(want, n * 4 + ((size_t)1 << 20));
-  while (want > least && !s->text->reserve(want)) want /= 2;
-  if (s->text->capacity() < least && !s->text->reserve(least)) { err = std::string("out of memory inflating ") + path; return false; }
+  if (shared_backing) {
+    // (a sparse file: only the pages the text touches exist; 16 x is room for any FASTQ -- past it the inflater gives the file back)
+    want = std::min(want, n * 16 + (rmb << 20));
+    if (!s->text->reserve_file(shared_backing, std::max(want, least))) { err = std::string("cannot create the shared text ") + shared_backing; return false; }
+  } else {
+    while (want > least && !s->text->reserve(want)) want /= 2;
+    if (s->text->capacity() < least && !s->text->reserve(least)) { err = std::string("out of memory inflating ") + path; return false; }
+  }
   s->text->pin(true);
   s->joined = false;
   s->th = std::thread([this, T] {
     StreamImpl *z = s;
-    const std::function<void(size_t)> progress = [z](size_t total) {
-      { std::lock_guard<std::mutex> g(z->mu); z->avail = total; }
+    const std::function<void(size_t, size_t)> progress = [z](size_t total, size_t consumed) {
+      { std::lock_guard<std::mutex> g(z->mu); z->avail = total; z->consumed = consumed; }
       z->cv.notify_all();
     };
     bool ok = gunzip_parallel(z->raw.data(), z->raw.size(), *z->text, T, &progress);
@@ -591,6 +632,43 @@ bool TextStream::next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *
     }
     window *= 8;                                        // records longer than the window: look further back, wait for more
     if (window > min_bytes) min_bytes = window;
+  }
+}
+
+bool TextStream::next_records(size_t n_records, const char **ptr, size_t *nbytes, size_t *got, bool *last, std::string &err)
+{
+  std::unique_lock<std::mutex> g(s->mu);
+  const size_t want_lines = n_records * 4;
+  size_t pos = s->handed, lines = 0;
+  for (;;) {
+    if (s->failed) { err = s->err; return false; }
+    const int gen = s->gen;
+    const char *t = s->text->data();
+    const size_t avail = s->avail;
+    const bool done = s->done;
+    // count newlines in what is final and not yet looked at (with the lock released: the serial fallback waits for scans)
+    s->scanning = true;
+    g.unlock();
+    while (lines < want_lines && pos < avail) {
+      const char *q = (const char *)memchr(t + pos, '\n', avail - pos);
+      if (!q) { pos = avail; break; }
+      pos = (size_t)(q - t) + 1; lines++;
+    }
+    g.lock();
+    s->scanning = false;
+    s->cv.notify_all();
+    if (gen != s->gen) { pos = s->handed; lines = 0; continue; }      // the text was void (the inflater fell back): start over
+    if (lines >= want_lines || done) {
+      size_t end = pos;
+      if (lines < want_lines && done) end = avail;                    // (a last line without its newline belongs to the last record)
+      *ptr = t + s->handed; *nbytes = end - s->handed;
+      if (lines >= want_lines) *got = n_records;
+      else { const size_t all = lines + ((end > s->handed && t[end - 1] != '\n') ? 1 : 0); *got = all / 4; }
+      s->handed = end;
+      *last = done && end >= avail;
+      return true;
+    }
+    s->cv.wait(g, [&] { return s->done || s->failed || s->avail > avail; });
   }
 }
 

@@ -44,6 +44,9 @@ class Text {
   char operator[](size_t i) const { return p_[i]; }
   char &operator[](size_t i) { return p_[i]; }
   bool reserve(size_t cap);           // false: out of memory (content kept)
+  // a SHARED mapping of a (new) file of `cap` bytes instead of anonymous memory: other processes map the same file and read the text
+  // where the inflater puts it (the multi-GPU driver's workers: no copy of their piece).  The file is sparse; the caller unlinks it.
+  bool reserve_file(const char *path, size_t cap);
   bool resize(size_t n);              // new bytes are unspecified (zero only where the kernel has just supplied the page)
   void clear() { n_ = 0; }
   void shrink_to_fit();
@@ -61,7 +64,7 @@ class Text {
   void release();
   char *p_ = nullptr;
   size_t n_ = 0, cap_ = 0;
-  int kind_ = 0;                      // 0 nothing, 1 malloc, 2 mmap, 3 the adopted string, 4 borrowed
+  int kind_ = 0;                      // 0 nothing, 1 malloc, 2 mmap, 3 the adopted string, 4 borrowed, 5 a shared file mapping (never grows)
   bool pinned_ = false;
   std::string own_;
 };
@@ -79,7 +82,8 @@ int io_threads();               // ITSX_IO_THREADS or min(hardware threads, 32)
 // pinflate.cpp: block-parallel inflate of a single-member gzip buffer (data[n .. n+16) must be readable).  true = `out`
 // holds the content and its length and CRC-32 matched the trailer; false = not applicable or any doubt: inflate serially.
 // progress (may be null): called after every round with the number of bytes of `out` that are final (front to back).
-bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const std::function<void(size_t)> *progress = nullptr);
+// (second argument: compressed bytes consumed so far -- a driver that deals the text out in N even pieces estimates its final size from the two)
+bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const std::function<void(size_t, size_t)> *progress = nullptr);
 int64_t parallel_inflates();    // files the block-parallel inflater has delivered since the library was loaded
 
 // A file's text delivered front to back WHILE it is being inflated: the loader of a large .fastq.gz hands record-aligned slices
@@ -90,10 +94,19 @@ class TextStream {
  public:
   TextStream();
   ~TextStream();
-  bool open(const char *path, std::string &err);
+  // shared_backing (may be null): the text is inflated into a shared mapping of that (new, sparse) file, so that other processes can
+  // map the slices they are told about; a plain (uncompressed) input is not copied there -- *plain_input says so and the caller maps the
+  // input file itself (slices are offsets into it all the same)
+  bool open(const char *path, std::string &err, const char *shared_backing = nullptr, bool *plain_input = nullptr);
+  // text bytes that are final, compressed bytes consumed, compressed size (equal pairs once the file is done)
+  void progress(size_t *avail, size_t *consumed, size_t *raw_size);
+  const char *base() const;
   // Blocks until at least min_bytes past the last slice are final (or the file ends); the slice is cut at a FASTQ record start.
   // false: the file could not be delivered (err); *last: nothing follows this slice.
   bool next(size_t min_bytes, const char **ptr, size_t *nbytes, bool *last, std::string &err);
+  // The mate file of a paired run: the next slice holds exactly n_records FASTQ records (4 n lines) -- blocks until that many are
+  // final; fewer only at the end of the file (*last).  *got = records in the slice.
+  bool next_records(size_t n_records, const char **ptr, size_t *nbytes, size_t *got, bool *last, std::string &err);
   // joins the inflater; keep: the text goes to the cache under the file's path.  Slices stay valid until the TextStream dies.
   bool finish(bool keep, std::string &err);
   // an upper bound of the number of records in the WHOLE text (lines / 4 for FASTQ, / 2 otherwise, + 1), or -1 while the text is

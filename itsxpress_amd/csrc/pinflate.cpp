@@ -324,7 +324,7 @@ template <class F> void parallel(int T, F fn)
 
 }  // namespace
 
-bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const std::function<void(size_t)> *progress)
+bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const std::function<void(size_t, size_t)> *progress)
 {
   const uint8_t *p = (const uint8_t *)data;
   const size_t hdr = gzip_header_len(p, n);
@@ -452,7 +452,7 @@ bool gunzip_parallel(const char *data, size_t n, Text &out, int threads, const s
     }
     pos = live.back().end;
     finished = live.back().final;
-    if (progress && *progress) (*progress)(total);
+    if (progress && *progress) (*progress)(total, (size_t)(pos >> 3));
     t_find += ms(r0, r1); t_dec += ms(r1, r2); t_res += ms(r2, now()); rounds++;
     if (!finished && pos >= stream_end_bits) return false;
   }

@@ -59,6 +59,31 @@ int itsx_stream_open(const char *path, itsx_stream **out)
   return ITSX_OK;
 }
 
+// the text goes into a shared mapping of `backing` (a new, sparse file the caller unlinks): other processes map the slices they are told
+// about -- offset = slice address - itsx_stream_base(s).  *plain_input = 1: the input is uncompressed and was NOT copied; the offsets
+// are offsets into the input file itself.
+int itsx_stream_open_shared(const char *path, const char *backing, itsx_stream **out, int32_t *plain_input)
+{
+  if (!path || !backing || !out) { g_stream_error = "itsx_stream_open_shared: missing argument"; return ITSX_E_ARG; }
+  itsx_stream *s = new itsx_stream;
+  bool plain = false;
+  if (!s->ts.open(path, s->err, backing, &plain)) { g_stream_error = s->err; delete s; return ITSX_E_IO; }
+  if (plain_input) *plain_input = plain ? 1 : 0;
+  *out = s;
+  return ITSX_OK;
+}
+const char *itsx_stream_base(itsx_stream *s) { return s ? s->ts.base() : nullptr; }
+int itsx_stream_progress(itsx_stream *s, int64_t *avail, int64_t *consumed, int64_t *raw_size)
+{
+  if (!s) return ITSX_E_ARG;
+  size_t a = 0, c = 0, r = 0;
+  s->ts.progress(&a, &c, &r);
+  if (avail) *avail = (int64_t)a;
+  if (consumed) *consumed = (int64_t)c;
+  if (raw_size) *raw_size = (int64_t)r;
+  return ITSX_OK;
+}
+
 int itsx_stream_next(itsx_stream *s, int64_t min_bytes, const char **text, int64_t *nbytes, int32_t *last)
 {
   if (!s || !text || !nbytes || !last) { g_stream_error = "itsx_stream_next: missing argument"; return ITSX_E_ARG; }
@@ -66,6 +91,36 @@ int itsx_stream_next(itsx_stream *s, int64_t min_bytes, const char **text, int64
   if (!s->ts.next((size_t)(min_bytes > 0 ? min_bytes : 1), text, &nb, &l, s->err)) { g_stream_error = s->err; return ITSX_E_IO; }
   *nbytes = (int64_t)nb; *last = l ? 1 : 0;
   return ITSX_OK;
+}
+
+// the mate file's slice: exactly n_records records (fewer only at the end of the file)
+int itsx_stream_next_records(itsx_stream *s, int64_t n_records, const char **text, int64_t *nbytes, int64_t *got, int32_t *last)
+{
+  if (!s || !text || !nbytes || !got || !last || n_records < 0) { g_stream_error = "itsx_stream_next_records: missing argument"; return ITSX_E_ARG; }
+  size_t nb = 0, g = 0; bool l = false;
+  if (!s->ts.next_records((size_t)n_records, text, &nb, &g, &l, s->err)) { g_stream_error = s->err; return ITSX_E_IO; }
+  *nbytes = (int64_t)nb; *got = (int64_t)g; *last = l ? 1 : 0;
+  return ITSX_OK;
+}
+// FASTQ records in a record-aligned piece of text (lines / 4; a last line without its newline counts), on the I/O pool
+int64_t itsx_count_records(const char *text, int64_t nbytes)
+{
+  if (!text || nbytes <= 0) return 0;
+  const size_t n = (size_t)nbytes;
+  const int T = std::max(1, std::min(itsx_io::io_threads(), (int)(n >> 24) + 1));
+  std::vector<size_t> cnt((size_t)T, 0);
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; k++)
+    th.emplace_back([&, k] {
+      const char *p = text + n / (size_t)T * (size_t)k, *e = (k + 1 == T) ? text + n : text + n / (size_t)T * (size_t)(k + 1);
+      size_t c = 0;
+      while (p < e) { const char *q = (const char *)memchr(p, '\n', (size_t)(e - p)); if (!q) break; c++; p = q + 1; }
+      cnt[(size_t)k] = c;
+    });
+  for (auto &x : th) x.join();
+  size_t lines = text[n - 1] != '\n' ? 1 : 0;
+  for (size_t c : cnt) lines += c;
+  return (int64_t)(lines / 4);
 }
 
 int64_t itsx_stream_records_bound(itsx_stream *s) { return s ? (int64_t)s->ts.records_bound() : -1; }

@@ -230,6 +230,8 @@ struct itsx_twriter {
     std::string comp; int64_t nw = 0, tot = 0;
   };
   std::string path; int kind = 0; bool ccs = false; size_t unit_bytes = (size_t)8 << 20;
+  int mode = 0;                            // 1: (start, stop) are Python slice bounds as they come (a paired run's mates: start may be negative,
+                                           // stop == INT32_MAX = open end, stop == INT32_MIN = the record is not written)
   int fd = -1; uint64_t file_off = 0;      // the output, written at explicit offsets (a burst of finished units goes out on several threads)
   bool seekable = true;                    // (a pipe -- /dev/stdout, a process substitution -- takes the pieces one after the other)
   const char *base = nullptr; size_t avail = 0; bool text_done = false;
@@ -384,8 +386,14 @@ void itsx_twriter::work()
     while ((rc = r.next(rec)) == 1) {
       const int64_t a = start[(size_t)i], b = stop[(size_t)i];      // (rows of decided records are not written to any more)
       i++;
-      if (a < 0 || b < 0 || !(a < b)) continue;
-      int64_t l, h; py_slice((int64_t)rec.seq.size(), a, b, false, l, h);
+      int64_t l, h;
+      if (mode == 1) {
+        if (b == INT32_MIN) continue;
+        py_slice((int64_t)rec.seq.size(), a, b, b == INT32_MAX, l, h);
+      } else {
+        if (a < 0 || b < 0 || !(a < b)) continue;
+        py_slice((int64_t)rec.seq.size(), a, b, false, l, h);
+      }
       out.append(rec.title.p, rec.title.n); out += '\n';
       if (ccs) out += fwd;
       out.append(rec.seq.p + l, (size_t)(h - l));
@@ -431,6 +439,15 @@ int itsx_twriter_open(const char *out_path, int compression, int trim_ccs, itsx_
   return ITSX_OK;
 }
 
+// mode 1: the coordinates are Python slice bounds as they come -- a paired run's mates, itsxpress/SeqSample.py:587-670: R1[start:stop]
+// (or [start:]), R2[tlen - stop : tlen - start]; stop == INT32_MAX = open end, stop == INT32_MIN = the record is not written
+int itsx_twriter_set_mode(itsx_twriter *w, int32_t mode)
+{
+  if (!w || mode < 0 || mode > 1) { g_trim_error = "itsx_twriter_set_mode: mode must be 0 or 1"; return ITSX_E_ARG; }
+  std::lock_guard<std::mutex> lk(w->mu);
+  w->mode = mode;
+  return ITSX_OK;
+}
 int itsx_twriter_text(itsx_twriter *w, const char *base, int64_t avail, int32_t last)
 {
   if (!w || avail < 0 || (!base && avail > 0)) { g_trim_error = "itsx_twriter_text: bad argument"; return ITSX_E_ARG; }

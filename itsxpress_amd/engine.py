@@ -274,6 +274,18 @@ class Engine:
         self._last_merge = dict(r1=r1, r2=r2, maxdiffs=int(maxdiffs), maxee=float(maxee), allow_stagger=bool(allow_stagger))
         return n.value, m.value
 
+    def merge_pairs_load_text(self, ptr1, nb1, ptr2, nb2, maxdiffs=40, maxee=2.0, allow_stagger=False):
+        """the same from record-aligned pieces of R1's and R2's text in memory that hold the same number of records (addresses + lengths:
+        slices of itsxpress_amd.stream's two text streams): (pairs, merged, per pair the index of its merged read or -1)"""
+        n = C.c_int64(0)
+        m = C.c_int64(0)
+        self._chk(self.L.itsx_merge_pairs_load_text(self.h, C.c_void_p(ptr1), int(nb1), C.c_void_p(ptr2), int(nb2), int(maxdiffs), float(maxee),
+                                                    int(allow_stagger), C.byref(n), C.byref(m)))
+        self.n_reads, self.n_samples, self.n_unique = m.value, 1, 0
+        idx = np.zeros(max(1, n.value), np.int32)
+        self._chk(self.L.itsx_merge_pair_index(self.h, idx.ctypes.data, n.value))
+        return n.value, m.value, idx[:n.value]
+
     def write_merged_fastq(self, path):
         """After merge_pairs_load (which writes nothing): the merged records as a FASTQ file after all -- the same merge once more, in a
         context of its own (this engine's read set and results stay as they are); record i of the file is read i of this engine.  For

@@ -150,6 +150,26 @@ def _h_load_piece(eng, st, piece, base, n_expect):
     return n
 
 
+def _h_load_range(eng, st, path, off, nb):
+    """this worker's part of the input as a byte range of a file it maps itself: the shared text the parent is still inflating
+    behind this range (itsx_stream_open_shared), or the uncompressed input.  No copy of the piece; the base follows (set_base)"""
+    import mmap
+    if nb <= 0:
+        eng.set_reads([], None)
+        return 0
+    gran = mmap.ALLOCATIONGRANULARITY
+    a = (off // gran) * gran
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), nb + (off - a), access=mmap.ACCESS_READ, offset=a)
+    try:
+        arr = np.frombuffer(mm, np.uint8)
+        n = eng.load_reads_text(arr.ctypes.data + (off - a), nb)
+        del arr
+    finally:
+        mm.close()
+    return n
+
+
 def _h_merge_piece(eng, st, p1, p2, out, maxdiffs, maxee, allow_stagger):
     """merge this worker's pieces of R1 / R2: into the engine's read set (out None) or into a piece of seq.fq"""
     try:
@@ -385,7 +405,7 @@ def _h_stats(eng, st):
     return eng.stats()
 
 
-_HANDLERS = {"job": _h_job, "load_piece": _h_load_piece, "merge_piece": _h_merge_piece, "set_base": _h_set_base, "orient_piece": _h_orient_piece,
+_HANDLERS = {"job": _h_job, "load_piece": _h_load_piece, "load_range": _h_load_range, "merge_piece": _h_merge_piece, "set_base": _h_set_base, "orient_piece": _h_orient_piece,
              "derep_x": _h_derep_x, "own_x": _h_own_x, "verdict_x": _h_verdict_x, "get_verdict": _h_get_verdict,
              "rows_pub": _h_rows_pub, "rows_compose": _h_rows_compose, "rows_done": _h_rows_done, "names_pub": _h_names_pub,
              "load_shard": _h_load_shard, "set_reads": _h_set_reads, "derep": _h_derep, "verdict": _h_verdict,
@@ -791,8 +811,14 @@ class MultiEngine(ShardedOps):
         return ["%s.%d" % (pre, r) for r in range(self.world)], rec
 
     def load_reads_file(self, path):
+        """The reference reads the whole file before anything else starts (itsxpress/main.py:295-330).  Here the parent inflates it ONCE,
+        into a shared mapping, and hands every worker its byte range as soon as that range is final: worker 0 parses, uploads and packs
+        while the ranges of workers 1 .. N - 1 are still being inflated (round 5 cut the pieces after the last byte: 1.6-2.8 s in which
+        no worker had anything to do)."""
         if not os.path.exists(path):
             raise FileNotFoundError(path)
+        if os.environ.get("ITSX_MULTI_LOAD", "stream") != "pieces":
+            return self._load_streamed(path)
         t0 = self._tic()
         pieces, rec = self._shard(path, "reads")
         base = np.concatenate([[0], np.cumsum(rec)])
@@ -805,6 +831,96 @@ class MultiEngine(ShardedOps):
         self._final = False
         self._last_merge = None
         return self.n_reads
+
+    def _load_streamed(self, path):
+        from . import _lib
+        L = _lib.lib()
+        t0 = self._tic()
+        size = os.path.getsize(path)
+        self._ensure_room(int(size * (8 if path.endswith((".gz", ".zst")) else 0.0)) + (1 << 20))
+        backing = os.path.join(self._xdir, "text")
+        h, plain = C.c_void_p(), C.c_int32(0)
+        rc = L.itsx_stream_open_shared(os.fsencode(path), os.fsencode(backing), C.byref(h), C.byref(plain))
+        if rc != 0:
+            raise EngineError(rc, L.itsx_stream_last_error().decode())
+        src = path if plain.value else backing
+        N = self.world
+        sent, t_first = 0, None
+        try:
+            base_ptr = L.itsx_stream_base(h) or 0
+            off, last = 0, False
+            ptr, nb, lst = C.c_void_p(), C.c_int64(0), C.c_int32(0)
+
+            def nxt(min_bytes):
+                rc = L.itsx_stream_next(h, int(max(1, min_bytes)), C.byref(ptr), C.byref(nb), C.byref(lst))
+                if rc != 0:
+                    raise EngineError(rc, L.itsx_stream_last_error().decode())
+                return nb.value, bool(lst.value)
+
+            def estimate():
+                a, c, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+                L.itsx_stream_progress(h, C.byref(a), C.byref(c), C.byref(r))
+                return int(a.value * (r.value / c.value)) if c.value > 0 else 0
+
+            for r in range(N):
+                start, got = off, 0
+                if not last:
+                    if r == N - 1:
+                        while not last:                      # the rest of the file
+                            n1, last = nxt(1 << 40)
+                            got += n1
+                    else:
+                        if off == 0:                         # a first, small slice: after it the text's final size can be estimated
+                            n1, last = nxt(16 << 20)
+                            got += n1
+                        while not last:
+                            total = estimate()
+                            want = (total - start) // (N - r) if total > 0 else (64 << 20)
+                            if got >= want - (want >> 3):
+                                break
+                            n1, last = nxt(max(1 << 20, min(want - got, 256 << 20)))   # (next() hands out up to 1.5 x what is asked for)
+                            got += n1
+                    off = start + got
+                if t_first is None:
+                    t_first = time.perf_counter() - t0[0]
+                self.conns[r].send(("load_range", (src, int(start), int(got))))
+                sent += 1
+            self._timed("load: inflate + deal ranges (workers already loading)", t0)
+            sent = 0                                         # (from here on _collect takes every worker's answer, errors included)
+            tw = time.perf_counter()
+            try:
+                res = self._collect()
+            finally:
+                self.wait_s = getattr(self, "wait_s", 0.0) + (time.perf_counter() - tw)
+        except BaseException:
+            for r in range(sent):                            # (drain what the workers still answer, so that the pipes stay in step)
+                try:
+                    self.conns[r].recv()
+                except Exception:
+                    pass
+            L.itsx_stream_close(h, 0)
+            self._sweep_file(backing)
+            raise
+        L.itsx_stream_close(h, 0)
+        self._sweep_file(backing)
+        rec = np.asarray([int(x) for x in res], np.int64)
+        base = np.concatenate([[0], np.cumsum(rec)])
+        self._each("set_base", [(int(base[r]),) for r in range(N)])
+        self.first_worker_busy_s = t_first
+        self.n_reads = int(base[-1])
+        self._bases = [int(b) for b in base[:-1]]
+        self._nloc = [int(x) for x in rec]
+        self._derep = None
+        self._final = False
+        self._last_merge = None
+        return self.n_reads
+
+    @staticmethod
+    def _sweep_file(p):
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
 
     def set_reads(self, seqs, names=None):
         n = len(seqs)

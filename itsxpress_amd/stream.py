@@ -73,6 +73,14 @@ class _TextStream:
             raise EngineError(rc, self.L.itsx_stream_last_error().decode())
         return ptr.value or 0, nb.value, bool(last.value)
 
+    def next_records(self, n_records):
+        """the mate file's slice: exactly n_records records (fewer only when its file ends: the count comes back)"""
+        ptr, nb, got, last = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        rc = self.L.itsx_stream_next_records(self.h, int(n_records), C.byref(ptr), C.byref(nb), C.byref(got), C.byref(last))
+        if rc != 0:
+            raise EngineError(rc, self.L.itsx_stream_last_error().decode())
+        return ptr.value or 0, nb.value, got.value, bool(last.value)
+
     def records_bound(self):
         return int(self.L.itsx_stream_records_bound(self.h)) if self.h else -1
 
@@ -198,6 +206,156 @@ class _Output:
                 pass
 
 
+class _OutputPaired(_Output):
+    """The two mates' trimmed files written while the chunks are scored (`StreamEngine.plan_output_paired`; the reference writes them after
+    everything else, itsxpress/SeqSample.py:587-670, 713-790): two of the library's writer objects in slice mode, one per input file, fed
+    per chunk with the pair's Python slice bounds -- R1[start:stop] (or [start:] when stop > tlen), R2[tlen - stop : tlen - start] -- for
+    every pair whose merged read has both sides (start < stop); a pair that did not merge, or whose read is not trimmed, is skipped in
+    both files."""
+
+    SKIP, OPEN = -(1 << 31), (1 << 31) - 1
+
+    def __init__(self, L, plan):
+        self.L, self.plan = L, plan
+        self.w = self.w2 = None
+        ws = []
+        try:
+            for path in (plan["out"], plan["out2"]):
+                w = C.c_void_p()
+                rc = L.itsx_twriter_open(os.fsencode(path), plan["kind"], 0, C.byref(w))
+                if rc != 0:
+                    raise EngineError(rc, L.itsx_trim_last_error().decode())
+                ws.append(w)
+                self._chk(L.itsx_twriter_set_mode(w, 1))
+        except BaseException:
+            for w in ws:
+                L.itsx_twriter_close(w, None, None)
+            raise
+        self.w, self.w2 = ws
+        self.g_start = np.full(1 << 20, -1, np.int32)
+        self.g_stop = np.full(1 << 20, -1, np.int32)
+        self.g_dec = np.ones(1 << 20, np.uint8)
+        self.g_tlen = np.full(1 << 20, -1, np.int32)
+        self.base_ptr = self.base_ptr2 = None
+        self.reads_seen = 0
+        self.late = []                 # per chunk: (first pair, indexes of its undecided pairs, their global uniques, their tlen)
+        self.n_late_uniques = 0
+        self.result = None
+
+    def _grow(self, n):
+        if n > self.g_start.shape[0]:
+            cap = max(n, 2 * self.g_start.shape[0])
+            for name, fill in (("g_start", -1), ("g_stop", -1), ("g_dec", 1), ("g_tlen", -1)):
+                old = getattr(self, name)
+                new = np.full(cap, fill, old.dtype)
+                new[:old.shape[0]] = old
+                setattr(self, name, new)
+
+    def _pair_bounds(self, start, stop, tlen, ok):
+        """the four slice bounds of the pairs whose merged read has (start, stop, tlen); ok: the pair is written"""
+        s, e, t = start.astype(np.int64), stop.astype(np.int64), tlen.astype(np.int64)
+        keep = ok & (s >= 0) & (e >= 0) & (s < e)
+        a1 = np.where(keep, s, 0).astype(np.int32)
+        b1 = np.where(keep, np.where(e > t, self.OPEN, e), self.SKIP).astype(np.int32)
+        r2s, r2e = t - e, t - s
+        a2 = np.where(keep, r2s, 0).astype(np.int32)
+        b2 = np.where(keep, np.where(r2e > t, self.OPEN, r2e), self.SKIP).astype(np.int32)
+        return a1, b1, a2, b2
+
+    def chunk(self, k, eng, st, z_cum, bound, domE):
+        plan = self.plan
+        z = np.array(z_cum, np.int64)
+        half = z.shape[0] // 2
+        self.reads_seen += int(st["pairs"])
+        z[half:] += max(0, int(bound) - self.reads_seen)        # every pair not yet seen may add one reported target to every profile
+        eng.set_partial_coords(True)
+        eng.set_domz(z)
+        eng.finalize(domE=domE)
+        U = eng.n_unique
+        gid, v = st["gid"], st["verdict"]
+        if U:
+            pend = eng.lazy_pending_uniques()
+            rows = eng.rep_coords(plan["left"], plan["right"])
+            mine = (v[:, 2] == k) & (v[:, 3] == np.arange(U))
+            self._grow(int(gid.max()) + 1)
+            gm = gid[mine]
+            self.g_start[gm] = rows[0][mine]
+            self.g_stop[gm] = rows[1][mine]
+            self.g_tlen[gm] = rows[2][mine]                  # (dereplication is exact and full-length: a read is as long as its representative)
+            self.g_dec[gm] = pend[mine] == 0
+            self.n_late_uniques += int((pend[mine] != 0).sum())
+        uq = eng.get_derep()[2]                              # per merged read: its unique (-1: dropped)
+        mi = st["merged_index"]                              # per pair: its merged read (-1: not merged)
+        npairs = int(mi.shape[0])
+        merged = mi >= 0
+        if U and npairs and uq.shape[0]:
+            u_of_pair = np.where(merged, uq[np.maximum(mi, 0)], -1)
+            ok = u_of_pair >= 0
+            g = gid[np.maximum(u_of_pair, 0)]
+            start = np.where(ok, self.g_start[g], -1)
+            stop = np.where(ok, self.g_stop[g], -1)
+            dec = np.where(ok, self.g_dec[g], 1).astype(np.uint8)
+            tlen = np.where(ok, self.g_tlen[g], 0)
+        else:
+            g = np.zeros(npairs, np.int64)
+            ok = np.zeros(npairs, bool)
+            start = np.full(npairs, -1, np.int64); stop = np.full(npairs, -1, np.int64); dec = np.ones(npairs, np.uint8)
+            tlen = np.zeros(npairs, np.int64)
+        a1, b1, a2, b2 = self._pair_bounds(start, stop, tlen, ok)
+        for w, base, end, a, b in ((self.w, self.base_ptr, st["text_end"], a1, b1), (self.w2, self.base_ptr2, st["text_end2"], a2, b2)):
+            self._chk(self.L.itsx_twriter_text(w, C.c_void_p(base), int(end), 1 if st["last"] else 0))
+            self._chk(self.L.itsx_twriter_coords(w, int(st["pair_base"]), npairs, a.ctypes.data, b.ctypes.data, dec.ctypes.data))
+        idx = np.flatnonzero(dec == 0)
+        if idx.shape[0]:
+            self.late.append((int(st["pair_base"]), idx.astype(np.int64), g[idx]))
+
+    def settle(self, engs):
+        plan = self.plan
+        if self.n_late_uniques:
+            for k, (eng, st) in enumerate(engs):
+                U = eng.n_unique
+                if not U:
+                    continue
+                gid, v = st["gid"], st["verdict"]
+                mine = (v[:, 2] == k) & (v[:, 3] == np.arange(U))
+                waited = mine & (self.g_dec[gid] == 0)
+                if waited.any():
+                    rows = eng.rep_coords(plan["left"], plan["right"])
+                    gw = gid[waited]
+                    self.g_start[gw] = rows[0][waited]
+                    self.g_stop[gw] = rows[1][waited]
+                    self.g_tlen[gw] = rows[2][waited]
+        for base, idx, g in self.late:
+            recs = np.ascontiguousarray(base + idx, np.int64)
+            a1, b1, a2, b2 = self._pair_bounds(self.g_start[g], self.g_stop[g], self.g_tlen[g], np.ones(idx.shape[0], bool))
+            self._chk(self.L.itsx_twriter_update(self.w, recs.ctypes.data, int(recs.shape[0]), a1.ctypes.data, b1.ctypes.data))
+            self._chk(self.L.itsx_twriter_update(self.w2, recs.ctypes.data, int(recs.shape[0]), a2.ctypes.data, b2.ctypes.data))
+        self.late = []
+
+    def finish(self):
+        if self.result is None:
+            res = []
+            for name in ("w", "w2"):
+                n, tot = C.c_int64(0), C.c_int64(0)
+                w = getattr(self, name)
+                setattr(self, name, None)
+                self._chk(self.L.itsx_twriter_close(w, C.byref(n), C.byref(tot)))
+                res.append((n.value, tot.value))
+            self.result = (res[0][0], res[0][1] + res[1][1])
+        return self.result
+
+    def abort(self):
+        for name, key in (("w", "out"), ("w2", "out2")):
+            w = getattr(self, name, None)
+            if w:
+                setattr(self, name, None)
+                self.L.itsx_twriter_close(w, None, None)
+                try:
+                    os.remove(self.plan[key])
+                except OSError:
+                    pass
+
+
 class StreamEngine(ShardedOps):
     """The part of Engine's interface the mirror classes use, over file-order chunks of one FASTQ on one GPU."""
 
@@ -227,6 +385,11 @@ class StreamEngine(ShardedOps):
         self._plan = None             # plan_output(): the trimmed FASTQ is written while the chunks are scored
         self._out = None
         self._stream = None
+        self._path2 = None            # a paired sample (merge_pairs_load): R2, cut at R1's record counts; the chunks' reads are the merged reads
+        self._merge = None
+        self._stream2 = None
+        self._last_merge = None
+        self.n_pairs = 0
 
     # -- plumbing: the handlers of multi.py's workers, called in process
     @property
@@ -262,12 +425,13 @@ class StreamEngine(ShardedOps):
             except Exception:
                 pass
             self._plain_eng = None
-        if getattr(self, "_stream", None) is not None:
-            try:
-                self._stream.close(keep=True)
-            except Exception:
-                pass
-            self._stream = None
+        for name in ("_stream", "_stream2"):
+            if getattr(self, name, None) is not None:
+                try:
+                    getattr(self, name).close(keep=True)
+                except Exception:
+                    pass
+                setattr(self, name, None)
 
     # -- the output inside the pipeline
     def plan_output(self, outfile, left, right, gzipped=False, zstd_file=False, trim_ccs=False, domE=10.0):
@@ -277,9 +441,20 @@ class StreamEngine(ShardedOps):
         self._plan = {"out": outfile, "left": left, "right": right, "kind": 1 if gzipped else (2 if zstd_file else 0),
                       "ccs": bool(trim_ccs), "domE": float(domE)}
 
+    def plan_output_paired(self, outfile1, outfile2, left, right, gzipped=False, zstd_file=False, domE=10.0):
+        """A paired sample (merge_pairs_load): say BEFORE search() where the two mates' trimmed files go; they are then written while the
+        chunks are scored (class _OutputPaired)."""
+        self._plan = {"out": outfile1, "out2": outfile2, "left": left, "right": right, "kind": 1 if gzipped else (2 if zstd_file else 0),
+                      "ccs": False, "domE": float(domE)}
+
+    def output_planned_paired(self, outfile1, outfile2, left, right, gzipped=False, zstd_file=False):
+        p = self._plan
+        return (self._out is not None and p is not None and p.get("out2") == outfile2 and p["out"] == outfile1 and p["left"] == left
+                and p["right"] == right and p["kind"] == (1 if gzipped else (2 if zstd_file else 0)))
+
     def output_planned(self, outfile, left, right, gzipped=False, zstd_file=False, trim_ccs=False):
         p = self._plan
-        return (self._out is not None and p is not None and p["out"] == outfile and p["left"] == left and p["right"] == right
+        return (self._out is not None and p is not None and "out2" not in p and p["out"] == outfile and p["left"] == left and p["right"] == right
                 and p["kind"] == (1 if gzipped else (2 if zstd_file else 0)) and p["ccs"] == bool(trim_ccs))
 
     def finish_output(self):
@@ -298,10 +473,36 @@ class StreamEngine(ShardedOps):
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.close()
-        self._path = path
+        self._path, self._path2, self._merge, self._last_merge = path, None, None, None
         self._loaded = self._searched = self._final = False
         self._derep = None
         return None
+
+    def merge_pairs_load(self, r1, r2, maxdiffs=40, maxee=2.0, allow_stagger=False):
+        """A paired sample, streamed (round 6; the reference merges the whole files first: itsxpress/SeqSample.py:266-365, main.py:513-519):
+        R1 and R2 are inflated side by side, R1's slices are cut at record starts and R2's at the same record counts, every pair of slices
+        is merged on the device by the chunk's own context (k_merge.hip) and the chunk goes on like a single-end one -- its reads are the
+        merged reads.  Deferred like load_reads_file: the counts are known after the pipeline (`n_pairs`, `n_reads`); returns (-1, -1)."""
+        for p in (r1, r2):
+            if not os.path.exists(p):
+                raise FileNotFoundError(p)
+        self.close()
+        self._path, self._path2 = r1, r2
+        self._merge = dict(maxdiffs=int(maxdiffs), maxee=float(maxee), allow_stagger=bool(allow_stagger))
+        self._last_merge = dict(r1=r1, r2=r2, **self._merge)
+        self._loaded = self._searched = self._final = False
+        self._derep = None
+        return -1, -1
+
+    def write_merged_fastq(self, path):
+        """the merged records as a file after all (a caller that wants the MERGED reads trimmed: one plain context merges once more)"""
+        lm = self._last_merge
+        if lm is None:
+            raise EngineError(-1, "write_merged_fastq: no paired sample was loaded")
+        res = self._plain().merge_pairs_files(lm["r1"], lm["r2"], path, maxdiffs=lm["maxdiffs"], maxee=lm["maxee"], allow_stagger=lm["allow_stagger"])
+        self._plain_eng.close()
+        self._plain_eng = None
+        return res
 
     def derep(self, strand_both=True, minseqlength=1):
         self._derep_args = (bool(strand_both), int(minseqlength))
@@ -378,8 +579,9 @@ class StreamEngine(ShardedOps):
         fsize = os.path.getsize(self._path)
         return max(256 << 20, int(fsize * 4 / 16))
 
-    def _parse_chunk(self, ptr, nb, base, k):
-        """the loader's first stage: a context, the profiles, the slice's records parsed and packed on the device"""
+    def _parse_chunk(self, ptr, nb, base, k, ptr2=None, nb2=0):
+        """the loader's first stage: a context, the profiles, the slice's records parsed and packed on the device (a paired sample: both
+        slices parsed, the pairs merged on the device, the merged reads packed)"""
         import time
         t0 = time.perf_counter()
         eng = Engine(self.device)
@@ -391,9 +593,13 @@ class StreamEngine(ShardedOps):
                 if k == 0:
                     self.n_profiles, self._pmeta = int(res[0]), res[1]
             t1 = time.perf_counter()
-            eng.load_reads_text(ptr, nb)
+            if ptr2 is None:
+                eng.load_reads_text(ptr, nb)
+            else:
+                npairs, _, st["merged_index"] = eng.merge_pairs_load_text(ptr, nb, ptr2, nb2, **self._merge)
+                st["pairs"] = int(npairs)
             st["load_s"] = {"context": round(tc - t0, 3), "profiles": round(t1 - tc, 3), "parse+upload": round(time.perf_counter() - t1, 3),
-                            "MB": round(nb / 1e6, 1), "reads": eng.n_reads}
+                            "MB": round((nb + nb2) / 1e6, 1), "reads": eng.n_reads}
         except BaseException:
             eng.close()
             raise
@@ -426,8 +632,8 @@ class StreamEngine(ShardedOps):
         q = queue.Queue(maxsize=3)
         keyset = self.L.itsx_keyset_create()
         stop = threading.Event()
-        if with_search and self._plan is not None:
-            self._out = _Output(self.L, self._plan)
+        if with_search and self._plan is not None and (("out2" in self._plan) == (self._path2 is not None)):
+            self._out = (_OutputPaired if self._path2 is not None else _Output)(self.L, self._plan)
         fin_q, fin_err = queue.Queue(), []
 
         zs = {}
@@ -486,20 +692,37 @@ class StreamEngine(ShardedOps):
             try:
                 stream = _TextStream(self._path)
                 self._stream = stream                    # (kept until the engine is closed: the writer reads the text)
+                paired = self._path2 is not None
+                stream2 = None
+                if paired:
+                    stream2 = _TextStream(self._path2)   # (both files inflate side by side from here on)
+                    self._stream2 = stream2
                 want = self._chunk_bytes()
-                base, k, ptr0 = 0, 0, None
+                base, k, ptr0, ptr0b, pair_base = 0, 0, None, None, 0
                 while not stop.is_set():
                     # (the first slices are smaller -- a quarter, a half -- so that the GPU has something to do early: until the first
                     # chunk is resident nothing overlaps anything)
                     ptr, nb, last = stream.next(max(1, want >> max(0, 2 - k)))    # last: the inflater is done and every member's CRC-32 and length agreed
+                    ptr2, nb2 = None, 0
+                    if paired:
+                        n1 = int(self.L.itsx_count_records(C.c_void_p(ptr), int(nb))) if nb > 0 else 0
+                        ptr2, nb2, got, last2 = stream2.next_records(n1)
+                        if got != n1 or (last and not last2):
+                            # (the reference's merge refuses files of unlike length too: vsearch --fastq_mergepairs stops with an error)
+                            raise EngineError(-3, "R1 and R2 hold different numbers of records")
                     t_text = time.perf_counter()
                     if ptr0 is None:
-                        ptr0 = ptr
+                        ptr0, ptr0b = ptr, ptr2
                         if self._out is not None:
                             self._out.base_ptr = ptr0
+                            if paired:
+                                self._out.base_ptr2 = ptr0b
                     if nb > 0 or (last and k == 0):
-                        eng, st = self._parse_chunk(ptr, nb, base, k)
+                        eng, st = self._parse_chunk(ptr, nb, base, k, ptr2, nb2)
                         st["text_end"], st["last"] = ptr + nb - ptr0, bool(last)
+                        if paired:
+                            st["text_end2"], st["pair_base"] = ptr2 + nb2 - ptr0b, pair_base
+                            pair_base += st["pairs"]
                         q1.put((eng, st, t_text - t0))
                         base += eng.n_reads
                         k += 1
@@ -577,6 +800,7 @@ class StreamEngine(ShardedOps):
         self._bases = [st["base"] for _, st in self._engs]
         self._nloc = [eng.n_reads for eng, _ in self._engs]
         self._n_reads = int(sum(self._nloc))
+        self.n_pairs = int(sum(st.get("pairs", 0) for _, st in self._engs))
         self._index_uniques()
         self._loaded = True
         if with_search:

@@ -75,6 +75,10 @@ def main():
                         "parent_own_s": {k: round(v, 3) for k, v in me.parent_own_s.items()},
                         "parent_own_compute_path_s": round(sum(v for k, v in me.parent_own_s.items() if not k.startswith("load")), 3),
                         "worker_device_ms": [round(x) for x in dev_ms],
+                        # round 6: the parent deals byte ranges of a shared text while it is still inflating the rest -- seconds from the call to the
+                        # first worker having its range, and the parent's serial share of the wall (its own work outside the load + that lead time)
+                        "first_worker_busy_s": round(getattr(me, "first_worker_busy_s", float("nan")) or 0.0, 3),
+                        "parent_serial_share_of_wall": round((sum(v for k, v in me.parent_own_s.items() if not k.startswith("load")) + (getattr(me, "first_worker_busy_s", 0.0) or 0.0)) / max(1e-9, sum(wall.values())), 4),
                         "note": "parent_s: wall time of this process inside a call; parent_own_s: the part that was its own work, not a wait for the workers "
                                 "('load: inflate + cut' = inflate the file once, cut it, write the pieces; derep and trim_coords are three commands each); "
                                 "parent_own_compute_path_s = everything but the load; N workers share ONE GPU here"}

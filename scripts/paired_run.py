@@ -24,11 +24,51 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=500000)
     ap.add_argument("--array-path", action="store_true", help="skip uc.txt / rep.fa / domtbl.txt (the in-memory hand-off, f3)")
+    ap.add_argument("--stream", action="store_true", help="round 6: after the staged run, the same files through the STREAMED paired pipeline "
+                                                          "(ITSXPRESS_STREAM=1 ITSXPRESS_ARRAYS=1, SeqSample.plan_output_paired) and its wall time")
+    ap.add_argument("--check", action="store_true", help="--stream: the two outputs (inflated) must equal the staged run's byte for byte")
     args = ap.parse_args()
-    print(json.dumps(run(args.pairs, args.array_path)))
+    print(json.dumps(run(args.pairs, args.array_path, args.stream, args.check)))
 
 
-def run(pairs, array_path=True):
+def stream_leg(paths, hmm, tmp):
+    """the reference's call sequence (main.py:513-519, 534-554, 556-624) through the mirror with the streaming engine: R1 / R2 inflated side
+    by side, merged chunk by chunk on the device, scored, the two outputs deflated while later chunks are scored"""
+    from itsxpress_amd import SeqSample as S
+    from itsxpress_amd import trim
+    keep = {k: os.environ.get(k) for k in ("ITSXPRESS_ARRAYS", "ITSXPRESS_STREAM", "ITSXPRESS_GPUS")}
+    os.environ.update({"ITSXPRESS_ARRAYS": "1", "ITSXPRESS_STREAM": "1", "ITSXPRESS_GPUS": "1"})
+    trim.cache_clear()
+    o1, o2 = os.path.join(tmp, "s1.fastq.gz"), os.path.join(tmp, "s2.fastq.gz")
+    sobj = None
+    try:
+        t0 = time.perf_counter()
+        sobj = S.SeqSamplePairedNotInterleaved(fastq=paths[0], tempdir=os.path.join(tmp, "swork"), fastq2=paths[1])
+        sobj.plan_output_paired(o1, o2, "ITS2", gzipped=True)
+        sobj._merge_reads(threads=1, stagger=False)
+        sobj.deduplicate(threads=1)
+        sobj._search(hmmfile=hmm, threads=1)
+        t_pipe = time.perf_counter() - t0
+        its_pos = S.ItsPosition(domtable=sobj.dom_file, region="ITS2")
+        dd = S.Dedup(uc_file=sobj.uc_file, rep_file=sobj.rep_file, seq_file=sobj.seq_file, fastq=sobj.r1, fastq2=sobj.fastq2)
+        dd.create_paired_trimmed_seqs(o1, o2, gzipped=True, zstd_file=False, itspos=its_pos, wri_file=True)
+        total = time.perf_counter() - t0
+        eng = sobj._engine
+        return {"s_total": round(total, 3), "s_merge+derep+search (streamed)": round(t_pipe, 3), "s_finalize+write tail": round(total - t_pipe, 3),
+                "chunks": int(eng.world), "pairs": int(getattr(eng, "n_pairs", 0)), "merged": int(eng.n_reads),
+                "timeline_s(chunk, text ready, loaded, searched)": [list(x) for x in eng.timeline],
+                "output_gz_MB": round((os.path.getsize(o1) + os.path.getsize(o2)) / 1e6, 1)}, (o1, o2)
+    finally:
+        if sobj is not None and getattr(sobj, "_engine", None) is not None:
+            sobj._engine.close()
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def run(pairs, array_path=True, stream=False, check=False):
     """the run as a function (bench.py --paired-pairs calls it for its `paired_file_to_file` key): the stage times as a dict"""
     args = argparse.Namespace(pairs=int(pairs), array_path=bool(array_path))
     import synth
@@ -124,7 +164,21 @@ def run(pairs, array_path=True):
         total = sum(t.values())
         kept = int(((start >= 0) & (stop >= 0) & (start < stop)).sum())
         assert nw == kept, (nw, kept)
-        return ({"pairs": n, "merged": len(names[1]) - 1, "unique": int(nu), "pairs_written": int(nw), "array_path": bool(args.array_path),
+        streamed = None
+        if stream:
+            eng.close()
+            streamed, (s1, s2) = stream_leg(paths, hmm, tmp)
+            streamed["pairs_per_s_file_to_file"] = round(n / streamed["s_total"])
+            if check:
+                for a, b in ((o1, s1), (o2, s2)):
+                    with gzip.open(a, "rb") as fa, gzip.open(b, "rb") as fb:
+                        while True:
+                            x, y = fa.read(1 << 24), fb.read(1 << 24)
+                            assert x == y, "streamed output differs from the staged one: %s" % b
+                            if not x:
+                                break
+                streamed["outputs_equal_staged"] = True
+        return ({"streamed": streamed, "pairs": n, "merged": len(names[1]) - 1, "unique": int(nu), "pairs_written": int(nw), "array_path": bool(args.array_path),
                           "input_gz_MB": round(sum(os.path.getsize(p) for p in paths) / 1e6, 1),
                           "output_gz_MB": round((os.path.getsize(o1) + os.path.getsize(o2)) / 1e6, 1),
                           "gzip_level": int(os.environ.get("ITSX_GZIP_LEVEL", 6)),

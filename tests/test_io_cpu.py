@@ -463,3 +463,61 @@ def test_reader_takes_a_fifo(tmp_path):
         assert read_text(fifo) == text
     finally:
         t.join()
+
+
+def test_shared_text_stream_lets_another_mapping_read_the_slices(tmp_path, monkeypatch):
+    """itsx_stream_open_shared (round 6; the multi-GPU driver's load: itsxpress_amd/multi.py): the text is inflated into a shared
+    mapping of a file, a slice is readable through ANY mapping of that file at `address - base` as soon as it is handed out, the
+    progress pair estimates the final size, the slices add up to the serial inflater's text; a plain input is not copied (its slices
+    are offsets into the input itself)"""
+    import ctypes as C
+    import mmap
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "64")
+    monkeypatch.setenv("ITSX_TEXT_CACHE_GB", "0")
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(60000):
+        n = int(rng.integers(80, 160))
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)), b"@" + b"I" * (n - 1)))
+    text = b"".join(recs)
+    gz = tmp_path / "in.fq.gz"
+    with gzip.open(gz, "wb", compresslevel=6) as f:
+        f.write(text)
+    plain = tmp_path / "in.fq"
+    plain.write_bytes(text)
+    L = _lib.lib()
+    for path, want_plain in ((gz, 0), (plain, 1)):
+        backing = tmp_path / ("text_%d" % want_plain)
+        h, pl = C.c_void_p(), C.c_int32(-1)
+        assert L.itsx_stream_open_shared(os.fsencode(str(path)), os.fsencode(str(backing)), C.byref(h), C.byref(pl)) == 0, L.itsx_stream_last_error()
+        assert pl.value == want_plain
+        src = path if want_plain else backing
+        base = L.itsx_stream_base(h)
+        got, off = [], 0
+        est = []
+        while True:
+            ptr, nb, last = C.c_void_p(), C.c_int64(0), C.c_int32(0)
+            assert L.itsx_stream_next(h, 1 << 20, C.byref(ptr), C.byref(nb), C.byref(last)) == 0, L.itsx_stream_last_error()
+            assert (ptr.value or base) - base == off
+            a, c, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            L.itsx_stream_progress(h, C.byref(a), C.byref(c), C.byref(r))
+            if c.value:
+                est.append(a.value * r.value / c.value)
+            if nb.value:                                   # read the slice through a mapping of our own, like a worker process
+                gran = mmap.ALLOCATIONGRANULARITY
+                lo = (off // gran) * gran
+                with open(src, "rb") as f:
+                    mm = mmap.mmap(f.fileno(), nb.value + off - lo, access=mmap.ACCESS_READ, offset=lo)
+                piece = bytes(mm[off - lo:])
+                mm.close()
+                assert piece[:1] == b"@"
+                got.append(piece)
+            off += nb.value
+            if last.value:
+                break
+        assert L.itsx_stream_close(h, 0) == 0
+        assert b"".join(got) == text
+        assert len(got) > (1 if not want_plain else 0)
+        assert all(0.7 * len(text) < e < 1.4 * len(text) for e in est), est[:4]
+        if not want_plain:
+            os.unlink(backing)

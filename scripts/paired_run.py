@@ -34,7 +34,8 @@ def main():
 def stream_leg(paths, hmm, tmp):
     """the reference's call sequence (main.py:513-519, 534-554, 556-624) through the mirror with the streaming engine: R1 / R2 inflated side
     by side, merged chunk by chunk on the device, scored, the two outputs deflated while later chunks are scored"""
-    from itsxpress_amd import SeqSample as S
+    import importlib
+    S = importlib.import_module("itsxpress_amd.SeqSample")
     from itsxpress_amd import trim
     keep = {k: os.environ.get(k) for k in ("ITSXPRESS_ARRAYS", "ITSXPRESS_STREAM", "ITSXPRESS_GPUS")}
     os.environ.update({"ITSXPRESS_ARRAYS": "1", "ITSXPRESS_STREAM": "1", "ITSXPRESS_GPUS": "1"})

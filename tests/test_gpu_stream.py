@@ -213,9 +213,10 @@ def test_writer_inside_the_pipeline_writes_the_same_bytes(tmp_path, t_hmm_text, 
 
 
 def test_paired_end_through_the_streaming_engine(tmp_path, t_hmm_text, monkeypatch):
-    """the reference's paired fixture: merge (one plain engine does it), then the merged file -- its text is in the cache, the
-    stream cuts it from there -- dereplicated and scored in chunks; R1 / R2 trimmed with the merged reads' coordinates.  Same
-    files as without ITSXPRESS_STREAM."""
+    """the reference's paired fixture.  File mode: merge (one plain engine does it), then the merged file -- its text is in the cache,
+    the stream cuts it from there -- dereplicated and scored in chunks.  Arrays mode (round 6): R1 and R2 streamed side by side, R2 cut
+    at R1's record counts, every pair of slices merged by its chunk's context; with SeqSample.plan_output_paired the two outputs are
+    written by the pipeline itself.  R1 / R2 trimmed with the merged reads' coordinates: same files as without ITSXPRESS_STREAM."""
     tmp = str(tmp_path)
     hmm = _its2(tmp, t_hmm_text)
     raw = []
@@ -226,7 +227,7 @@ def test_paired_end_through_the_streaming_engine(tmp_path, t_hmm_text, monkeypat
         raw.append(p)
     monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "0.02")           # the merged file is ~100 KB: a handful of chunks
     outs = {}
-    for name, stream, arrays in (("one", False, "1"), ("stream", True, "0"), ("stream_arrays", True, "1")):
+    for name, stream, arrays in (("one", False, "1"), ("stream", True, "0"), ("stream_arrays", True, "1"), ("stream_arrays_planned", True, "1")):
         d = os.path.join(tmp, name)
         os.makedirs(d, exist_ok=True)
         monkeypatch.setenv("ITSXPRESS_GPUS", "1")
@@ -234,23 +235,44 @@ def test_paired_end_through_the_streaming_engine(tmp_path, t_hmm_text, monkeypat
         monkeypatch.setenv("ITSXPRESS_ARRAYS", arrays)
         sobj = S.SeqSamplePairedNotInterleaved(fastq=raw[0], tempdir=d, fastq2=raw[1])
         _OPEN.append(sobj)
+        o1, o2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
+        if name.endswith("planned"):
+            sobj.plan_output_paired(o1, o2, "ITS2")
         sobj._merge_reads(threads=1)
         sobj.deduplicate(threads=1)
         sobj._search(hmmfile=hmm, threads=1)
         its_pos = S.ItsPosition(domtable=sobj.dom_file, region="ITS2")
         dd = S.Dedup(uc_file=sobj.uc_file, rep_file=sobj.rep_file, seq_file=sobj.seq_file, fastq=sobj.r1, fastq2=sobj.fastq2)
-        o1, o2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
         dd.create_paired_trimmed_seqs(o1, o2, gzipped=False, zstd_file=False, itspos=its_pos, wri_file=True)
         outs[name] = (open(o1, "rb").read(), open(o2, "rb").read(), [np.asarray(c).copy() for c in sobj.trim_coordinates("ITS2")])
+        if name == "one":
+            merged_one = sobj._engine.n_reads
         from itsxpress_amd.stream import StreamEngine
         from itsxpress_amd.engine import Engine as _E
         if stream and arrays == "0":                     # through seq.fq: the merged file is cut from the cache, chunk by chunk
             assert isinstance(sobj._engine, StreamEngine) and sobj._engine.world >= 3, sobj._engine.world
-        if stream and arrays == "1":                     # arrays mode: the merged reads live in one plain context (no seq.fq at all)
-            assert type(sobj._engine) is _E and not os.path.exists(os.path.join(d, "seq.fq"))
-    for other in ("stream", "stream_arrays"):
+        if stream and arrays == "1":                     # arrays mode: R1 / R2 streamed, merged chunk by chunk (no seq.fq at all)
+            assert isinstance(sobj._engine, StreamEngine) and sobj._engine.world >= 3 and not os.path.exists(os.path.join(d, "seq.fq"))
+            assert sobj._engine.n_pairs == 250 and sobj._engine.n_reads == merged_one     # (the fixture's 250 pairs; as many merged as in one context)
+            if name.endswith("planned"):
+                assert sobj._engine._out is not None and sobj._engine._out.result is not None
+    for other in ("stream", "stream_arrays", "stream_arrays_planned"):
         assert outs["one"][0] == outs[other][0] and outs["one"][1] == outs[other][1] and len(outs["one"][0]) > 1000
         assert all(np.array_equal(x, y) for x, y in zip(outs["one"][2], outs[other][2]))
+
+
+def test_synthetic_pairs_streamed_equal_the_staged_run(tmp_path, t_hmm_text, monkeypatch):
+    """30 000 synthetic 2x250 pairs (scripts/paired_run.py's generator: sequencing errors, pairs that do not merge), .fastq.gz in and out,
+    several chunks: the streamed pipeline's two outputs, inflated, equal the staged run's byte for byte; R2 shorter than R1 is an error"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import paired_run
+    monkeypatch.setenv("ITSX_STREAM_CHUNK_MB", "2")
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "256")
+    res = paired_run.run(30000, True, stream=True, check=True)
+    st = res["streamed"]
+    assert st["outputs_equal_staged"] and st["chunks"] >= 3 and st["pairs"] == 30000 and st["merged"] == res["merged"]
+    assert res["pairs_written"] > 20000
 
 
 def test_stream_that_outgrows_its_reservation_starts_over_serially(tmp_path, t_hmm_text, monkeypatch):

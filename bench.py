@@ -643,9 +643,11 @@ def main():
         os.environ["ITSXPRESS_ARRAYS"], os.environ["ITSXPRESS_STREAM"] = "1", "0"
         try:
             import paired_run
-            paired_leg = paired_run.run(args.paired_pairs, True)
+            paired_leg = paired_run.run(args.paired_pairs, True, stream=True)
             paired_leg["note"] = ("R1 / R2 .fastq.gz -> merge (k_merge.hip) -> derep -> lazy search -> coordinates -> trimmed R1 / R2 .fastq.gz, one GPU, "
-                                  "ITSXPRESS_ARRAYS=1 (scripts/paired_run.py); host codecs included; not `value`")
+                                  "ITSXPRESS_ARRAYS=1 (scripts/paired_run.py); host codecs included; not `value`.  `streamed` (round 6): the same files through "
+                                  "the streamed paired pipeline -- R1 / R2 inflated side by side, merged chunk by chunk, the two outputs deflated while later "
+                                  "chunks are scored (ITSXPRESS_STREAM=1, SeqSample.plan_output_paired)")
         finally:
             for k, v in keep.items():
                 if v is None:

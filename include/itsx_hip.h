@@ -209,6 +209,7 @@ int itsx_stream_open(const char *path, itsx_stream **out);
  * copy of the pieces.  *plain_input = 1: the input is uncompressed and was not copied: the offsets are offsets into the input file.
  * itsx_stream_progress: text bytes that are final, compressed bytes behind them, the file's size (for an estimate of the whole
  * text's size before it is there: even pieces). */
+int itsx_stream_open_threads(const char *path, int32_t threads, itsx_stream **out);     /* itsx_stream_open with a pool of `threads` inflating threads */
 int itsx_stream_open_shared(const char *path, const char *backing, itsx_stream **out, int32_t *plain_input);
 const char *itsx_stream_base(itsx_stream *s);
 int itsx_stream_progress(itsx_stream *s, int64_t *avail, int64_t *consumed, int64_t *raw_size);
@@ -229,6 +230,9 @@ const char *itsx_stream_last_error(void);
  *   holds records[p] records (bytes[p] bytes; bytes may be NULL).  match_records != NULL (a mate file, R2 after R1): piece p is cut
  *   to hold exactly match_records[p] records instead; a file that does not hold them is ITSX_E_FORMAT.
  * Errors: negative code, text from itsx_shard_last_error(). */
+/* one piece of a text in memory (a slice of itsx_stream_next, while the rest of the file is still being inflated) into a new file, by the
+ * I/O pool: a multi-GPU driver's worker loads it with itsx_load_reads_file */
+int itsx_write_range(const char *path, const char *text, int64_t nbytes);
 int itsx_shard_text(const char *path, int32_t n_parts, const int64_t *match_records, const char *out_prefix, int64_t *records, int64_t *bytes);
 /* The owner's step of the cross-shard dereplication for a multi-worker run (itsxpress_amd/multi.py: owner_verdicts states it in numpy):
  * recv[m][5] = (key0, key1, global index of the first occurrence, forward-is-canonical flag, local unique number) of the uniques whose

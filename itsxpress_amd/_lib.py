@@ -78,8 +78,8 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_load_reads_file_shard", "itsx_unique_keys128", "itsx_write_derep_arrays", "itsx_write_domtbl_arrays",
            "itsx_writers_last_error", "itsx_profile_params", "itsx_get_unique_seqs",
            "itsx_load_reads_text", "itsx_stream_open", "itsx_stream_next", "itsx_stream_close", "itsx_stream_last_error", "itsx_stream_records_bound",
-           "itsx_stream_open_shared", "itsx_stream_base", "itsx_stream_progress", "itsx_stream_next_records", "itsx_count_records",
-           "itsx_merge_pairs_load_text", "itsx_merge_pair_index", "itsx_twriter_set_mode",
+           "itsx_stream_open_shared", "itsx_stream_open_threads", "itsx_stream_base", "itsx_stream_progress", "itsx_stream_next_records", "itsx_count_records",
+           "itsx_merge_pairs_load_text", "itsx_merge_pair_index", "itsx_twriter_set_mode", "itsx_write_range",
            "itsx_keyset_create", "itsx_keyset_destroy", "itsx_keyset_size", "itsx_keyset_assign",
            "itsx_twriter_open", "itsx_twriter_text", "itsx_twriter_coords", "itsx_twriter_update", "itsx_twriter_close",
            "itsx_lazy_pending_uniques", "itsx_set_partial_coords"]
@@ -121,6 +121,7 @@ def lib():
         "itsx_stream_close": (i32, [vp, i32]),
         "itsx_stream_records_bound": (i64, [vp]),
         "itsx_stream_open_shared": (i32, [cp, cp, vp, vp]),
+        "itsx_stream_open_threads": (i32, [cp, i32, vp]),
         "itsx_stream_base": (vp, [vp]),
         "itsx_stream_progress": (i32, [vp, vp, vp, vp]),
         "itsx_stream_next_records": (i32, [vp, i64, vp, vp, vp, vp]),
@@ -128,6 +129,7 @@ def lib():
         "itsx_merge_pairs_load_text": (i32, [vp, vp, i64, vp, i64, i32, f64, i32, vp, vp]),
         "itsx_merge_pair_index": (i32, [vp, vp, i64]),
         "itsx_twriter_set_mode": (i32, [vp, i32]),
+        "itsx_write_range": (i32, [cp, vp, i64]),
         "itsx_stream_last_error": (cp, []),
         "itsx_keyset_create": (vp, []),
         "itsx_keyset_destroy": (None, [vp]),

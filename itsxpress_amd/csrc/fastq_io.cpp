@@ -496,7 +496,7 @@ void TextStream::progress(size_t *avail, size_t *consumed, size_t *raw_size)
 }
 const char *TextStream::base() const { return s->text->data(); }
 
-bool TextStream::open(const char *path, std::string &err, const char *shared_backing, bool *plain_input)
+bool TextStream::open(const char *path, std::string &err, const char *shared_backing, bool *plain_input, int threads)
 {
   codecs();
   s->path = path;
@@ -513,7 +513,7 @@ bool TextStream::open(const char *path, std::string &err, const char *shared_bac
       }
   }
   if (!read_raw(path, s->fsize, s->raw, err)) return false;
-  const int T = io_threads();
+  const int T = threads > 0 ? threads : io_threads();
   const bool par = is_gzip(s->raw) && env_int("ITSX_PARALLEL_INFLATE", 1) != 0 && T > 1;
   if (!par) {
     bool ok = true;

@@ -97,7 +97,8 @@ class TextStream {
   // shared_backing (may be null): the text is inflated into a shared mapping of that (new, sparse) file, so that other processes can
   // map the slices they are told about; a plain (uncompressed) input is not copied there -- *plain_input says so and the caller maps the
   // input file itself (slices are offsets into it all the same)
-  bool open(const char *path, std::string &err, const char *shared_backing = nullptr, bool *plain_input = nullptr);
+  // threads (0: io_threads()): the inflater's pool -- a paired run's two streams share the CPUs
+  bool open(const char *path, std::string &err, const char *shared_backing = nullptr, bool *plain_input = nullptr, int threads = 0);
   // text bytes that are final, compressed bytes consumed, compressed size (equal pairs once the file is done)
   void progress(size_t *avail, size_t *consumed, size_t *raw_size);
   const char *base() const;

@@ -13,6 +13,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <unistd.h>
 #include "../../include/itsx_hip.h"
 #include "fastq_io.h"
 
@@ -61,6 +63,34 @@ template <class F> void on_pool(int T, int jobs, F fn)
 extern "C" {
 
 const char *itsx_shard_last_error(void) { return g_shard_error.c_str(); }
+
+// Round 6: one piece of a text that is still being inflated (a slice of itsx_stream_next) into a new file, by the I/O pool -- the multi-GPU
+// driver hands a worker its piece while the parent's inflater is busy with the rest (itsxpress_amd/multi.py: _load_streamed).  write()
+// into a tmpfs file allocates its pages in the kernel: 9 GB through a SHARED MAPPING of such a file took the inflater 4.7 s instead of 1.5
+// (2.3 M page faults of 4 KB), which is why the pieces are files and not a mapping.
+int itsx_write_range(const char *path, const char *text, int64_t nbytes)
+{
+  if (!path || (!text && nbytes > 0) || nbytes < 0) { g_shard_error = "itsx_write_range: missing argument"; return ITSX_E_ARG; }
+  const int fd = open(path, O_CREAT | O_WRONLY | O_TRUNC, 0600);
+  if (fd < 0) { g_shard_error = std::string("cannot write ") + path; return ITSX_E_IO; }
+  const size_t n = (size_t)nbytes;
+  if (n > 0 && ftruncate(fd, (off_t)n) != 0) { close(fd); unlink(path); g_shard_error = std::string("cannot write ") + path; return ITSX_E_IO; }
+  const size_t BS = (size_t)16 << 20;
+  const int nb = (int)((n + BS - 1) / BS);
+  const int T = std::max(1, std::min(itsx_io::io_threads(), 8));
+  std::atomic<int> bad{0};
+  on_pool(T, nb, [&](int b) {
+    size_t at = (size_t)b * BS; const size_t e = std::min(n, at + BS);
+    while (at < e && !bad) {
+      const ssize_t w = pwrite(fd, text + at, e - at, (off_t)at);
+      if (w <= 0) { bad = 1; break; }
+      at += (size_t)w;
+    }
+  });
+  if (close(fd) != 0) bad = 1;
+  if (bad) { unlink(path); g_shard_error = std::string("cannot write ") + path + " (no space left?)"; return ITSX_E_IO; }
+  return ITSX_OK;
+}
 
 int itsx_shard_text(const char *path, int32_t n_parts, const int64_t *match_records, const char *out_prefix, int64_t *records, int64_t *bytes)
 {

@@ -72,6 +72,15 @@ int itsx_stream_open_shared(const char *path, const char *backing, itsx_stream *
   *out = s;
   return ITSX_OK;
 }
+// the same as itsx_stream_open with a pool of `threads` inflating threads (a paired run's two streams share the CPUs)
+int itsx_stream_open_threads(const char *path, int32_t threads, itsx_stream **out)
+{
+  if (!path || !out) { g_stream_error = "itsx_stream_open_threads: missing argument"; return ITSX_E_ARG; }
+  itsx_stream *s = new itsx_stream;
+  if (!s->ts.open(path, s->err, nullptr, nullptr, threads)) { g_stream_error = s->err; delete s; return ITSX_E_IO; }
+  *out = s;
+  return ITSX_OK;
+}
 const char *itsx_stream_base(itsx_stream *s) { return s ? s->ts.base() : nullptr; }
 int itsx_stream_progress(itsx_stream *s, int64_t *avail, int64_t *consumed, int64_t *raw_size)
 {

@@ -144,7 +144,7 @@ def _h_load_piece(eng, st, piece, base, n_expect):
         os.unlink(piece)
     except OSError:
         pass
-    if n != n_expect:
+    if n_expect >= 0 and n != n_expect:                # (-1: dealt while the file was still being inflated; the base follows with set_base)
         raise RuntimeError("piece %s: %d records parsed, %d counted" % (piece, n, n_expect))
     st["base"] = int(base)
     return n
@@ -811,10 +811,12 @@ class MultiEngine(ShardedOps):
         return ["%s.%d" % (pre, r) for r in range(self.world)], rec
 
     def load_reads_file(self, path):
-        """The reference reads the whole file before anything else starts (itsxpress/main.py:295-330).  Here the parent inflates it ONCE,
-        into a shared mapping, and hands every worker its byte range as soon as that range is final: worker 0 parses, uploads and packs
-        while the ranges of workers 1 .. N - 1 are still being inflated (round 5 cut the pieces after the last byte: 1.6-2.8 s in which
-        no worker had anything to do)."""
+        """The reference reads the whole file before anything else starts (itsxpress/main.py:295-330).  Here the parent inflates it ONCE
+        and hands every worker its piece as soon as that part of the text is final: worker 0 parses, uploads and packs while the pieces
+        of workers 1 .. N - 1 are still being inflated (round 5 cut the pieces after the last byte: 1.6-2.8 s in which no worker had
+        anything to do).  The pieces are files in the exchange directory, written by the I/O pool (itsx_write_range); a shared MAPPING of
+        one file for all workers (itsx_stream_open_shared) was measured first and is slower -- 2.3 M page faults of 4 KB under the
+        inflater's threads: 4.7 s instead of 1.5 for 9 GB."""
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         if os.environ.get("ITSX_MULTI_LOAD", "stream") != "pieces":
@@ -837,55 +839,60 @@ class MultiEngine(ShardedOps):
         L = _lib.lib()
         t0 = self._tic()
         size = os.path.getsize(path)
-        self._ensure_room(int(size * (8 if path.endswith((".gz", ".zst")) else 0.0)) + (1 << 20))
-        backing = os.path.join(self._xdir, "text")
-        h, plain = C.c_void_p(), C.c_int32(0)
-        rc = L.itsx_stream_open_shared(os.fsencode(path), os.fsencode(backing), C.byref(h), C.byref(plain))
+        self._ensure_room(int(size * (8 if path.endswith((".gz", ".zst")) else 1.05)) + (1 << 20))
+        h = C.c_void_p()
+        rc = L.itsx_stream_open(os.fsencode(path), C.byref(h))
         if rc != 0:
             raise EngineError(rc, L.itsx_stream_last_error().decode())
-        src = path if plain.value else backing
         N = self.world
         sent, t_first = 0, None
         try:
-            base_ptr = L.itsx_stream_base(h) or 0
-            off, last = 0, False
             ptr, nb, lst = C.c_void_p(), C.c_int64(0), C.c_int32(0)
+            last = False
 
             def nxt(min_bytes):
                 rc = L.itsx_stream_next(h, int(max(1, min_bytes)), C.byref(ptr), C.byref(nb), C.byref(lst))
                 if rc != 0:
                     raise EngineError(rc, L.itsx_stream_last_error().decode())
-                return nb.value, bool(lst.value)
+                return (ptr.value or 0), nb.value, bool(lst.value)
 
             def estimate():
                 a, c, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
                 L.itsx_stream_progress(h, C.byref(a), C.byref(c), C.byref(r))
                 return int(a.value * (r.value / c.value)) if c.value > 0 else 0
 
+            done_bytes = 0
             for r in range(N):
-                start, got = off, 0
+                p0, got = 0, 0                               # the piece: [p0, p0 + got) of the text (slices are consecutive)
                 if not last:
                     if r == N - 1:
                         while not last:                      # the rest of the file
-                            n1, last = nxt(1 << 40)
+                            q, n1, last = nxt(1 << 40)
+                            p0 = p0 or q
                             got += n1
                     else:
-                        if off == 0:                         # a first, small slice: after it the text's final size can be estimated
-                            n1, last = nxt(16 << 20)
+                        if done_bytes == 0:                  # a first, small slice: after it the text's final size can be estimated
+                            q, n1, last = nxt(16 << 20)
+                            p0 = p0 or q
                             got += n1
                         while not last:
                             total = estimate()
-                            want = (total - start) // (N - r) if total > 0 else (64 << 20)
+                            want = (total - done_bytes) // (N - r) if total > 0 else (64 << 20)
                             if got >= want - (want >> 3):
                                 break
-                            n1, last = nxt(max(1 << 20, min(want - got, 256 << 20)))   # (next() hands out up to 1.5 x what is asked for)
+                            q, n1, last = nxt(max(1 << 20, min(want - got, 256 << 20)))   # (next() hands out up to 1.5 x what is asked for)
+                            p0 = p0 or q
                             got += n1
-                    off = start + got
+                    done_bytes += got
+                piece = os.path.join(self._xdir, "reads.%d" % r)
+                rc = L.itsx_write_range(os.fsencode(piece), C.c_void_p(p0), int(got))
+                if rc != 0:
+                    raise EngineError(rc, L.itsx_shard_last_error().decode())
                 if t_first is None:
                     t_first = time.perf_counter() - t0[0]
-                self.conns[r].send(("load_range", (src, int(start), int(got))))
+                self.conns[r].send(("load_piece", (piece, 0, -1)))
                 sent += 1
-            self._timed("load: inflate + deal ranges (workers already loading)", t0)
+            self._timed("load: inflate + deal pieces (workers already loading)", t0)
             sent = 0                                         # (from here on _collect takes every worker's answer, errors included)
             tw = time.perf_counter()
             try:
@@ -899,10 +906,11 @@ class MultiEngine(ShardedOps):
                 except Exception:
                     pass
             L.itsx_stream_close(h, 0)
-            self._sweep_file(backing)
+            self._sweep()
+            for f in glob.glob(os.path.join(self._xdir, "reads.*")):
+                self._sweep_file(f)
             raise
         L.itsx_stream_close(h, 0)
-        self._sweep_file(backing)
         rec = np.asarray([int(x) for x in res], np.int64)
         base = np.concatenate([[0], np.cumsum(rec)])
         self._each("set_base", [(int(base[r]),) for r in range(N)])

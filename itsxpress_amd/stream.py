@@ -57,12 +57,15 @@ def stream_wanted(path=None, fast=False):
 
 
 class _TextStream:
-    def __init__(self, path):
+    def __init__(self, path, threads=0):
         self.L = _lib.lib()
         self.h = C.c_void_p()
         if not os.path.exists(path):
             raise FileNotFoundError(path)
-        rc = self.L.itsx_stream_open(os.fsencode(path), C.byref(self.h))
+        if threads > 0:
+            rc = self.L.itsx_stream_open_threads(os.fsencode(path), int(threads), C.byref(self.h))
+        else:
+            rc = self.L.itsx_stream_open(os.fsencode(path), C.byref(self.h))
         if rc != 0:
             raise EngineError(rc, self.L.itsx_stream_last_error().decode())
 
@@ -690,12 +693,14 @@ class StreamEngine(ShardedOps):
         def loader():
             stream = None
             try:
-                stream = _TextStream(self._path)
-                self._stream = stream                    # (kept until the engine is closed: the writer reads the text)
                 paired = self._path2 is not None
+                # (a paired sample's two inflaters share the CPUs: half of the I/O pool's threads each -- ITSX_STREAM_PAIR_THREADS)
+                pt = int(os.environ.get("ITSX_STREAM_PAIR_THREADS", "0") or 0) if paired else 0
+                stream = _TextStream(self._path, pt)
+                self._stream = stream                    # (kept until the engine is closed: the writer reads the text)
                 stream2 = None
                 if paired:
-                    stream2 = _TextStream(self._path2)   # (both files inflate side by side from here on)
+                    stream2 = _TextStream(self._path2, pt)   # (both files inflate side by side from here on)
                     self._stream2 = stream2
                 want = self._chunk_bytes()
                 base, k, ptr0, ptr0b, pair_base = 0, 0, None, None, 0

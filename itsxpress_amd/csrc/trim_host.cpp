@@ -173,7 +173,7 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
     }
     if (rc != ITSX_E_FORMAT) return rc;
   }
-  if (!out.open(out_path, compression)) return ITSX_E_IO;        // (the output is opened ONCE on every way through: it may be a pipe; after a malformed record the serial walk names it)
+  if (!out.open(out_path, compression)) return ITSX_E_IO;        // (the single-threaded way through; ALSO taken after the pool's writer object met a malformed record -- the output is then opened a second time, truncated, and this walk names the record: a pipe's reader has seen partial data by then; the call fails with ITSX_E_FORMAT either way)
   Rec rec; int64_t i = 0, nw = 0, tot = 0; int rc;
   while ((rc = in.next(rec)) == 1) {
     if (i >= n_records) { g_trim_error = "more records in the file than coordinates"; return ITSX_E_ARG; }

@@ -23,6 +23,8 @@ PY_SWITCHES = [
     ("ITSX_STREAM_CHUNK_MB", "tuning", "text per streamed chunk"),
     ("ITSX_STREAM_FINISHERS", "tuning", "threads finalizing streamed chunks"),
     ("ITSX_STREAM_SEARCHES", "tuning", "chunk searches in flight"),
+    ("ITSX_STREAM_PAIR_THREADS", "tuning", "inflating threads per file of a streamed paired sample (default: the I/O pool's size each)"),
+    ("ITSX_MULTI_LOAD", "tuning", "=pieces: the multi-GPU driver cuts the pieces after the whole file is inflated (round 5's load) instead of dealing them while it inflates"),
     ("ITSX_FORCE_DIST", "diagnostic", "=1: run the collectives even with one rank (tests/test_gpu_dist.py)"),
 ]
 

@@ -141,6 +141,10 @@ typedef struct {
   int32_t two_sided;         int32_t n_bwd_launches;
   int64_t n_joined, bwd_chains, gamma_nodes, bwd_rows, two_fwd_rows, two_bwd_rows, two_rows_full;
   float   join_maxdiff;      float ms_bwd_bound;        /* the Backward chains' kernel time (part of ms_bound_kernel) */
+  /* the top-up round of itsx_search_finalize (round 6): pairs it evaluated -- the best-bound unevaluated pairs of the profiles with
+   * undecided rows, as many as those rows need for the lower bound on domZ to decide them -- and its time (part of ms_finalize);
+   * n_lazy_completed stays 0 when it settles everything */
+  int64_t n_lazy_topup;      float ms_lazy_topup;       int32_t pad6;
 } itsx_stats;
 
 int         itsx_abi_version(void);

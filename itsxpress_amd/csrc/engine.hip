@@ -433,6 +433,11 @@ struct itsx_ctx {
   // two-sided sharing (round 6): the suffix tree by s (sh_r*_s), the joins, the Backward chains by backward position kb (sh_bdev), their
   // batches' first positions (sh_bsegk_h), the slots of the saved Backward states behind the Forward ones in the DP slab
   std::string switches_at_search;
+  // the top-up round of itsx_search_finalize (round 6): the last search's pair list, while it is still in the buffers (one chunk, one sample)
+  struct TopUp { bool valid = false; int64_t NP = 0; std::vector<int64_t> seg_start; std::vector<int32_t> total; int32_t u0 = 0, Uc = 0; } topup;
+  DBuf<unsigned long long> l_zneed, l_zsplit, l_tcnt; DBuf<int32_t> l_slot, l_pslot; DBuf<uint32_t> l_cut;
+  std::vector<unsigned long long> h_zneed;
+  bool prev_lazy = false; int prev_P = 0; int64_t prev_U = 0, prev_Uc = 0;      // the last search's chunking (itsx_search)
   std::vector<int32_t> h_merge_index;      // per pair of the last merge-and-load: its merged read, -1 = not merged
   bool two_on = false; int share_maxrd = 0; int32_t Ub = 0; size_t sh_gslots_off = 0;
   DBuf<uint8_t> sh_rdepth_s, sh_rdepth; DBuf<unsigned long long> sh_rmask_s, sh_rmask, sh_keys, sh_keys2;
@@ -1897,7 +1902,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   S.n_pairs = (int64_t)U * P; S.n_past_msv = S.n_past_bias = S.n_past_fwd = S.n_regions = S.n_multidomain = S.n_domains = S.n_domain_overflow = 0;
   S.ms_msv = S.ms_filters = S.ms_domains = S.ms_msv_kernel = S.ms_fwd_kernel = S.ms_bwd_kernel = S.ms_env_kernel = S.ms_bias_kernel = S.ms_decode_kernel = 0; S.n_batches = 0; S.ms_ensemble = 0; S.n_mr_clustered = S.n_mr_distinct = S.n_mr_failed = S.n_mr_envelopes = 0; S.n_slab_shrinks = 0; S.n_mr_overflow = 0; S.ms_vit_kernel = 0; for (int k = 0; k < 8; k++) S.n_mr_fail_kind[k] = 0; S.n_rows_resident = 0; S.msv_cells = 0; S.msv_launches = 0; S.fwd_rows = 0; S.env_rows = 0; S.n_env_unique = 0;
   ctx->npairs_padded = 0; ctx->dom_n.clear(); ctx->trace_u0 = 0; ctx->n_chunks = 0;
-  ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false;
+  ctx->have_search = true; ctx->have_final = false; ctx->domz_on_device = false; ctx->topup.valid = false;
   // rows mode: what the caller selected (itsx_set_rows_mode), else the environment (ITSX_ROWS=full|compact|lazy; ITSX_COMPACT_ROWS=1)
   int mode = ctx->rows_mode;
   if (mode < 0) {
@@ -1912,7 +1917,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz_ub.assign((size_t)P * ctx->S, 0);
   if (ctx->compact_rows)                    // a full table of an earlier search (80 B x ~130 per representative) goes back to the device
     for (auto &b : ctx->dom_bufs) if (b && b->cap * sizeof(itsx_domain) > ((size_t)256 << 20)) b->release();
-  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.lazy_bound_maxdiff = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0;
+  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.lazy_bound_maxdiff = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0; S.n_lazy_topup = 0; S.ms_lazy_topup = 0;
   if (ctx->compact_rows && U > 0) {
     ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
     if (const char *e = sw_get("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
@@ -2024,9 +2029,13 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   }
   int64_t Uc = std::max<int64_t>(1, (ctx->lazy ? lazy_budget : ctx->pair_budget) / std::max(P, 1));
   Uc = std::min<int64_t>(Uc, ((1ll << 31) - 4096) / std::max(Ppad, 1));
+  // (a context that has searched a job of this size already holds the buffers for it -- they only grow --: what is FREE now says nothing
+  // about whether the chunk fits, and a second, tiny chunk costs a round of every launch and the top-up round its list)
+  if (ctx->lazy && ctx->prev_lazy && ctx->prev_P == P && (int64_t)U <= ctx->prev_U && ctx->prev_Uc > Uc) Uc = ctx->prev_Uc;
   if (const char *e = sw_get("ITSX_CHUNK_UNIQUES")) Uc = std::max<int64_t>(1, atoll(e));
   ctx->keep_trace = sw_get("ITSX_KEEP_TRACE") != nullptr;
   ctx->s_Uc = Uc; ctx->s_Lcap = Lcap;
+  ctx->prev_lazy = ctx->lazy; ctx->prev_P = P; ctx->prev_U = U; ctx->prev_Uc = Uc;
   ctx->domz_ub_loc.assign((size_t)P * ctx->S, 0);
   { const int rc = build_share(ctx); if (rc != ITSX_OK) return rc; }
   { const int rc = run_chunks(ctx, T, F1, F3); if (rc != ITSX_OK) return rc; }
@@ -2957,6 +2966,9 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
     { const int rc = domain_pipeline(ctx, sub, d_sorted, T, F1, F3, last ? next_msv : nullptr); if (rc != ITSX_OK) return rc; }
   }
   S.ms_lazy_select += ms_sel; S.ms_filters += ms_sel;
+  // (the list, the bounds and the done flags stay where they are: the top-up round of itsx_search_finalize reads them when this was the
+  // search's only chunk)
+  ctx->topup.valid = !ctx->completing; ctx->topup.NP = NP; ctx->topup.seg_start = pl.seg_start; ctx->topup.total = pl.total; ctx->topup.u0 = u0; ctx->topup.Uc = Uc;
   return ITSX_OK;
 }
 
@@ -3280,13 +3292,24 @@ static int finalize_lazy(itsx_ctx *ctx, double domE)
   HIPCHK(hipMemsetAsync(ctx->l_pflag.p, 0, (size_t)std::max(ctx->P, 1) * 4, st));
   HIPCHK(ctx->l_uflag.alloc((size_t)U + 1));
   HIPCHK(hipMemsetAsync(ctx->l_uflag.p, 0, (size_t)U + 1, st));
+  {   // per profile: what would settle its undecided rows from below / from above (lazy_topup); the split between the two lies 60 % of the way up
+    const size_t Pn = (size_t)std::max(ctx->P, 1);
+    std::vector<unsigned long long> init(2 * Pn), split(Pn, 0);
+    for (size_t p = 0; p < Pn; p++) {
+      init[2 * p] = 0; init[2 * p + 1] = ~0ull;
+      if (p < ctx->domz.size() && ctx->S == 1) { const double lo = (double)ctx->domz[p], hi = (double)std::max(ctx->domz_ub[p], ctx->domz[p]); split[p] = (unsigned long long)(lo + 0.6 * (hi - lo)); }
+    }
+    HIPCHK(upload(ctx->l_zneed, init, st)); HIPCHK(upload(ctx->l_zsplit, split, st));
+  }
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_finalize_lazy(ctx->dom_bufs[c]->p, ctx->dom_n[c], d_dz.p, d_dz.p + m, domE, ctx->dev_usample(), ctx->P, st);
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
     if (ctx->dom_n[c] > 0) launch_lazy_sure(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, st);
   for (size_t c = 0; c < ctx->dom_n.size(); c++)
-    if (ctx->dom_n[c] > 0) launch_lazy_pending(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, (unsigned long long *)ctx->w_counters.p, ctx->l_pflag.p, ctx->l_uflag.p, st);
+    if (ctx->dom_n[c] > 0) launch_lazy_pending(ctx->dom_bufs[c]->p, ctx->dom_n[c], ctx->w_cls.p, ncls, ctx->l_sure.p, ctx->l_has.p, (unsigned long long *)ctx->w_counters.p, ctx->l_pflag.p, ctx->l_uflag.p, ctx->S == 1 ? ctx->l_zneed.p : nullptr, ctx->l_zsplit.p, domE, st);
   int64_t pend = 0;
+  ctx->h_zneed.assign((size_t)std::max(ctx->P, 1) * 2, 0);
+  HIPCHK(hipMemcpyAsync(ctx->h_zneed.data(), ctx->l_zneed.p, (size_t)std::max(ctx->P, 1) * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(&pend, ctx->w_counters.p, sizeof(pend), hipMemcpyDeviceToHost, st));
   ctx->lazy_pending_prof.assign((size_t)std::max(ctx->P, 1), 0);
   HIPCHK(hipMemcpyAsync(ctx->lazy_pending_prof.data(), ctx->l_pflag.p, (size_t)std::max(ctx->P, 1) * 4, hipMemcpyDeviceToHost, st));
@@ -3294,6 +3317,158 @@ static int finalize_lazy(itsx_ctx *ctx, double domE)
   { int np = 0; for (int32_t f : ctx->lazy_pending_prof) np += f != 0; ctx->stats.n_lazy_pending_profiles = np; }
   if (sw_get("ITSX_LAZY_FORCE_PENDING")) pend += atoll(sw_get("ITSX_LAZY_FORCE_PENDING"));      // test hook: exercises the full re-run
   ctx->lazy_pending = pend; ctx->stats.n_lazy_pending = pend;
+  return ITSX_OK;
+}
+
+// The top-up round (round 6).  A row is undecided when domE / P-value lies between the bounds on its profile's domZ -- the reported
+// targets among the EVALUATED pairs below, the pairs past the MSV filter above.  On amplicon data nearly every pair past the filter is a
+// reported target, so the truth is almost always "domZ is far larger, the row is not reported", and proving it does not take the exact
+// count (itsx_lazy_complete: every pair of the profile through the whole pipeline, 13.7 M pairs for 4 rows at 10 M reads): it takes
+// enough MORE reported targets for the lower bound to pass domE / P-value.  So the profile's unevaluated pairs are ordered by their
+// bound (one radix sort), as many of the best as the rows need (+ 2 %) go through the domain pipeline like a third lazy round, and the
+// thresholds are applied again; what is still undecided then (a row that IS reported, or one whose count lies in the top third of the
+// profile's pairs) is counted in full as before.  The upper bound is tightened on the way: reported among the evaluated + pairs not evaluated.  Exact for the same reason the bounds are: a lower bound that passes domE / P-value decides the row whatever the
+// exact count is.  Only for a search of one chunk and one sample whose lists are still in the buffers; everything else goes straight on.
+static int lazy_topup(itsx_ctx *ctx, double domE, bool *ran)
+{
+  (void)domE;
+  *ran = false;
+  const auto &tu = ctx->topup;
+  if (sw_get("ITSX_LAZY_HIST")) fprintf(stderr, "[itsx] top-up: valid %d chunks %d samples %d pairs %lld\n", (int)tu.valid, ctx->n_chunks, ctx->S, (long long)tu.NP);
+  if (!tu.valid || ctx->n_chunks != 1 || ctx->S != 1 || tu.NP <= 0) return ITSX_OK;
+  static const bool on = !(sw_get("ITSX_LAZY_TOPUP") && atoi(sw_get("ITSX_LAZY_TOPUP")) == 0);
+  if (!on) return ITSX_OK;
+  hipStream_t st = ctx->st;
+  const int P = ctx->P;
+  itsx_stats &S = ctx->stats;
+  // the profiles with undecided rows
+  std::vector<int32_t> slot((size_t)P, -1), prof_of;
+  for (int p = 0; p < P; p++) {
+    if (!ctx->lazy_pending_prof[(size_t)p]) continue;
+    if (ctx->h_zneed[(size_t)2 * p] == 0 && ctx->h_zneed[(size_t)2 * p + 1] == ~0ull) continue;
+    slot[(size_t)p] = (int32_t)prof_of.size(); prof_of.push_back(p);
+  }
+  const int ns = (int)prof_of.size();
+  if (ns == 0) return ITSX_OK;
+  StageTimer tm(st);
+  const int64_t NP = tu.NP;
+  HIPCHK(upload(ctx->l_slot, slot, st)); HIPCHK(upload(ctx->l_pslot, prof_of, st));
+  HIPCHK(upload(ctx->w_idx, tu.seg_start, st)); HIPCHK(upload(ctx->w_rcnt, tu.total, st));
+  // evaluated pairs per profile so far: the upper bound on its domZ is (reported among them) + (pairs not evaluated)
+  auto count_done = [&](std::vector<unsigned long long> &out) -> int {
+    HIPCHK(ctx->l_tcnt.alloc((size_t)ns));
+    HIPCHK(hipMemsetAsync(ctx->l_tcnt.p, 0, (size_t)ns * sizeof(unsigned long long), st));
+    launch_topup_count(ctx->l_done.p, ctx->w_idx.p, ctx->w_rcnt.p, ctx->l_pslot.p, ns, ctx->l_tcnt.p, st);
+    out.assign((size_t)ns, 0);
+    HIPCHK(hipMemcpyAsync(out.data(), ctx->l_tcnt.p, (size_t)ns * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return ITSX_OK;
+  };
+  std::vector<unsigned long long> ndone;
+  { const int rc = count_done(ndone); if (rc != ITSX_OK) return rc; }
+  // the unevaluated pairs of those profiles, compact (a few per cent of the list), then ordered by (profile, bound descending)
+  launch_topup_keys(ctx->d_pairs.p, NP, ctx->l_done.p, ctx->l_b10.p, ctx->l_slot.p, ctx->l_flag.p, nullptr, nullptr, nullptr, st);
+  launch_exclusive_scan(ctx->l_flag.p, ctx->l_pos.p, NP + 1, ctx->l_scan.p, st);
+  int32_t M32 = 0;
+  HIPCHK(hipMemcpyAsync(&M32, ctx->l_pos.p + NP, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int64_t M = M32;
+  if (M <= 0) return ITSX_OK;
+  HIPCHK(ctx->sh_keys.alloc((size_t)M + 1)); HIPCHK(ctx->sh_keys2.alloc((size_t)M + 1)); HIPCHK(ctx->sh_vals.alloc((size_t)M + 1)); HIPCHK(ctx->sh_uorder.alloc((size_t)M + 1));
+  const size_t sort_bytes = order_sort_bytes(M);
+  HIPCHK(ctx->sh_sorttmp.alloc(sort_bytes));
+  launch_topup_keys(ctx->d_pairs.p, NP, ctx->l_done.p, ctx->l_b10.p, ctx->l_slot.p, ctx->l_flag.p, ctx->l_pos.p, ctx->sh_keys.p, ctx->sh_vals.p, st);
+  if (order_sort(ctx->sh_sorttmp.p, sort_bytes, ctx->sh_keys.p, ctx->sh_keys2.p, ctx->sh_vals.p, ctx->sh_uorder.p, M, st) != 0) SET_ERR(ctx, ITSX_E_DEVICE, "top-up round: the radix sort failed");
+  HIPCHK(hipStreamSynchronize(st));
+  auto lower = [&](unsigned long long key, int64_t &pos) -> int {       // binary search over device memory: ~24 eight-byte copies per probe
+    int64_t lo = 0, hi = M;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1; unsigned long long v = 0;
+      HIPCHK(hipMemcpy(&v, ctx->sh_keys2.p + mid, 8, hipMemcpyDeviceToHost));
+      if (v < key) lo = mid + 1; else hi = mid;
+    }
+    pos = lo; return ITSX_OK;
+  };
+  std::vector<uint32_t> cut((size_t)2 * ns, 0);
+  bool any = false;
+  for (int k = 0; k < ns; k++) {
+    const int p = prof_of[(size_t)k];
+    int64_t a = 0, b = 0;
+    { const int rc = lower((unsigned long long)k << 32, a); if (rc != ITSX_OK) return rc; }
+    { const int rc = lower((unsigned long long)(k + 1) << 32, b); if (rc != ITSX_OK) return rc; }
+    const int64_t have = b - a;                          // its unevaluated pairs, best bound first in [a, b)
+    if (have <= 0) continue;
+    const int64_t lo = ctx->domz[(size_t)p], hi = lo + have;       // (the tight upper bound: every unevaluated pair reported)
+    int64_t from_top = 0, from_bottom = 0;
+    const unsigned long long zl = ctx->h_zneed[(size_t)2 * p], zh = ctx->h_zneed[(size_t)2 * p + 1];
+    // rows settled from BELOW: the lower bound must reach zl -- that many more reported targets, taken from the best pairs (+ 2 %: a few are not)
+    if (zl > 0 && (int64_t)zl > lo) { const int64_t need = (int64_t)zl - lo; from_top = need + need / 50 + 64; }
+    // rows settled from ABOVE: the upper bound must fall to zh -- that many pairs shown unreported, looked for among the weakest (+ 25 %: some are reported)
+    // (only with ITSX_LAZY_TOPUP=2: on amplicon data nearly every pair past the filter IS a reported target -- at 10 M reads 387 k of a profile's
+    // 394 k weakest pairs were --, so the upper bound hardly moves and such a row goes to the full count anyway)
+    static const bool both = sw_get("ITSX_LAZY_TOPUP") && atoi(sw_get("ITSX_LAZY_TOPUP")) == 2;
+    if (both && zh != ~0ull && hi > (int64_t)zh) { const int64_t need = hi - (int64_t)zh; from_bottom = need + need / 4 + 64; }
+    if (sw_get("ITSX_LAZY_HIST")) fprintf(stderr, "[itsx] top-up: profile %d bounds %lld .. %lld (%lld unevaluated), rows need >= %llu / <= %llu: best %lld, weakest %lld\n", p, (long long)lo, (long long)hi,
+                                          (long long)have, zl, zh == ~0ull ? 0ull : zh, (long long)from_top, (long long)from_bottom);
+    // (a profile whose rows need most of its pairs anyway is left to the full count)
+    if (from_top + from_bottom > have - have / 3) continue;
+    unsigned long long v = 0;
+    if (from_top > 0) {
+      HIPCHK(hipMemcpy(&v, ctx->sh_keys2.p + a + from_top - 1, 8, hipMemcpyDeviceToHost));
+      cut[(size_t)2 * k] = std::max<uint32_t>(1u, 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull));
+    }
+    if (from_bottom > 0) {
+      HIPCHK(hipMemcpy(&v, ctx->sh_keys2.p + b - from_bottom, 8, hipMemcpyDeviceToHost));
+      cut[(size_t)2 * k + 1] = std::max<uint32_t>(1u, 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull));
+      if (cut[(size_t)2 * k] > 0 && cut[(size_t)2 * k + 1] >= cut[(size_t)2 * k]) { cut[(size_t)2 * k] = cut[(size_t)2 * k + 1] = 0; continue; }   // (the two ends meet: the full count)
+    }
+    any = any || from_top > 0 || from_bottom > 0;
+  }
+  if (!any) return ITSX_OK;
+  HIPCHK(upload(ctx->l_cut, cut, st));
+  launch_topup_mark(ctx->d_pairs.p, NP, ctx->l_done.p, ctx->l_b10.p, ctx->l_slot.p, ctx->l_cut.p, ctx->l_flag.p, st);
+  launch_exclusive_scan(ctx->l_flag.p, ctx->l_pos.p, NP + 1, ctx->l_scan.p, st);
+  std::vector<int32_t> bound((size_t)P + 1);
+  {
+    DBuf<int32_t> &d_b = ctx->w_b;
+    HIPCHK(d_b.alloc((size_t)P + 1));
+    hipLaunchKernelGGL(k_gather_i32, dim3((P + 1 + 255) / 256), dim3(256), 0, st, ctx->l_pos.p, ctx->w_idx.p, P + 1, d_b.p);
+    HIPCHK(hipMemcpyAsync(bound.data(), d_b.p, ((size_t)P + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  PairList sub;
+  sub.seg_start.assign((size_t)P + 1, 0); sub.total.assign((size_t)P, 0);
+  for (int p = 0; p < P; p++) { sub.total[(size_t)p] = bound[(size_t)p + 1] - bound[(size_t)p]; sub.seg_start[(size_t)p + 1] = sub.seg_start[(size_t)p] + ((int64_t)sub.total[(size_t)p] + 63) / 64 * 64; }
+  sub.NP = sub.seg_start[(size_t)P];
+  const int64_t nsel = (int64_t)bound[(size_t)P] - bound[0];
+  if (sub.NP == 0) return ITSX_OK;
+  HIPCHK(ctx->l_pairs.alloc((size_t)sub.NP)); HIPCHK(ctx->d_pout.alloc((size_t)sub.NP));
+  HIPCHK(hipMemsetAsync(ctx->l_pairs.p, 0xFF, (size_t)sub.NP * sizeof(PairRec), st));
+  HIPCHK(hipMemsetAsync(ctx->d_pout.p, 0, (size_t)sub.NP * sizeof(PairOut), st));
+  HIPCHK(upload(ctx->l_seg, sub.seg_start, st));
+  launch_lazy_scatter(ctx->d_pairs.p, NP, ctx->l_flag.p, ctx->l_pos.p, ctx->w_seg_start.p, ctx->l_seg.p, ctx->l_pairs.p, st);
+  sub.pairs = ctx->l_pairs.p; sub.pout = ctx->d_pout.p; sub.d_seg_start = ctx->l_seg.p;
+  const int32_t *d_sorted = (ctx->share_on ? ctx->sh_order.p : ctx->d_sorted_uniq.p) + tu.u0;
+  ctx->trace_u0 = tu.u0;
+  { const int rc = domain_pipeline(ctx, sub, d_sorted, ctx->T, ctx->sF1, ctx->sF3, nullptr); if (rc != ITSX_OK) return rc; }
+  // the bounds after the round: reported among the evaluated pairs below, those + the pairs still not evaluated above
+  std::vector<int32_t> dz32((size_t)P * ctx->S, 0);
+  HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(upload(ctx->w_idx, tu.seg_start, st)); HIPCHK(upload(ctx->w_rcnt, tu.total, st));      // (the pipeline used the buffers)
+  { const int rc = count_done(ndone); if (rc != ITSX_OK) return rc; }
+  for (size_t z = 0; z < dz32.size(); z++) { ctx->domz_loc[z] = dz32[z]; ctx->domz[z] = dz32[z]; }
+  for (int k = 0; k < ns; k++) {
+    const int p = prof_of[(size_t)k];
+    const int64_t left = (int64_t)tu.total[(size_t)p] - (int64_t)ndone[(size_t)k];       // (helper pairs, xj < 0, are marked done by k_lazy_bound)
+    const int64_t hi = (int64_t)dz32[(size_t)p] + std::max<int64_t>(0, left);
+    if (hi < ctx->domz_ub[(size_t)p]) { ctx->domz_ub[(size_t)p] = hi; ctx->domz_ub_loc[(size_t)p] = hi; }
+    if (sw_get("ITSX_LAZY_HIST")) fprintf(stderr, "[itsx] top-up: profile %d now %d .. %lld\n", p, dz32[(size_t)p], (long long)ctx->domz_ub[(size_t)p]);
+  }
+  S.n_lazy_evaluated += nsel; S.n_lazy_topup += nsel;
+  S.n_rows_resident = 0;
+  for (int64_t r : ctx->dom_n) S.n_rows_resident += r;
+  S.ms_lazy_topup += tm.stop();
+  *ran = true;
   return ITSX_OK;
 }
 
@@ -3320,6 +3495,19 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
       // counters): the profiles of those rows are counted exactly (itsx_lazy_complete) and the thresholds applied again; a
       // multi-rank driver does the same across ranks (itsxpress_amd/dist.py: exchange_and_finalize).
       const int64_t pend = ctx->lazy_pending;
+      {   // first the cheap way: enough more of the profiles' best pairs for the lower bounds to decide the rows (lazy_topup)
+        bool ran = false;
+        { const int rc = lazy_topup(ctx, domE, &ran); if (rc != ITSX_OK) return rc; }
+        if (ran) {
+          { const int rc = finalize_lazy(ctx, domE); if (rc != ITSX_OK) return rc; }
+          ctx->stats.n_lazy_pending = pend;
+          if (ctx->lazy_pending == 0) {
+            ctx->stats.ms_finalize = tm.stop();
+            ctx->have_final = true;
+            return ITSX_OK;
+          }
+        }
+      }
       if (!sw_get("ITSX_LAZY_NO_COMPLETE")) {
         std::vector<int32_t> flags(ctx->lazy_pending_prof);
         flags.resize((size_t)std::max(ctx->P, 1), 0);

@@ -503,6 +503,10 @@ void launch_finalize_lazy(itsx_domain *dom, int64_t n, const int64_t *zlb, const
 // best sure row per (representative, class) and "has a sure row" per representative; then the rows whose status matters
 void launch_lazy_sure(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, unsigned long long *sure, int32_t *has, hipStream_t st);
 void launch_lazy_pending(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, const unsigned long long *sure, const int32_t *has,
-                         unsigned long long *count, int32_t *prof_flag /*[P]: profiles of such rows*/, uint8_t *uniq_flag /*[U]: representatives of such rows*/, hipStream_t st);
+                         unsigned long long *count, int32_t *prof_flag, uint8_t *uniq_flag, unsigned long long *zneed /*[2 P] or nullptr*/, const unsigned long long *zsplit /*[P]*/, double domE, hipStream_t st);
+void launch_topup_count(const uint8_t *done, const int64_t *seg_start, const int32_t *total, const int32_t *prof_of_slot, int nslots, unsigned long long *cnt, hipStream_t st);
+void launch_topup_keys(const PairRec *pairs, int64_t NP, const uint8_t *done, const uint32_t *b10, const int32_t *slot_of_prof, int32_t *flag, const int32_t *pos /*nullptr: flags only*/,
+                       unsigned long long *keys, int32_t *vals, hipStream_t st);
+void launch_topup_mark(const PairRec *pairs, int64_t NP, uint8_t *done, const uint32_t *b10, const int32_t *slot_of_prof, const uint32_t *cutoff, int32_t *flag, hipStream_t st);
 
 }  // namespace itsx

@@ -539,7 +539,8 @@ __global__ void __launch_bounds__(256) k_lazy_sure(const itsx_domain *__restrict
 __global__ void __launch_bounds__(256) k_lazy_pending(const itsx_domain *__restrict__ dom, int64_t n, const int8_t *__restrict__ cls, int ncls,
                                                       const unsigned long long *__restrict__ sure, const int32_t *__restrict__ has,
                                                       unsigned long long *__restrict__ count, int32_t *__restrict__ prof_flag,
-                                                      uint8_t *__restrict__ uniq_flag)
+                                                      uint8_t *__restrict__ uniq_flag, unsigned long long *__restrict__ zneed, const unsigned long long *__restrict__ zsplit,
+                                                      double domE)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int c = 0;
@@ -547,7 +548,22 @@ __global__ void __launch_bounds__(256) k_lazy_pending(const itsx_domain *__restr
     const itsx_domain d = dom[i];
     // an undecided row matters when it would beat its group's best sure row, or when the sequence has no sure row at all
     if (d.dom_idx >= 0 && d.dom_reported == 2) c = !has[d.rep] || rank_key(d) > sure[(size_t)d.rep * ncls + cls[d.prof]];
-    if (c) { prof_flag[d.prof] = 1; uniq_flag[d.rep] = 1; }
+    if (c) {
+      prof_flag[d.prof] = 1; uniq_flag[d.rep] = 1;
+      // the row is NOT reported as soon as the profile's reported targets exceed domE / P-value: the count that settles it (the top-up
+      // round of itsx_search_finalize evaluates that many more of the profile's best pairs before anything is counted in full)
+      // ... and it IS reported as soon as the UPPER bound falls to domE / P-value.  zneed[2 p] = the largest such count at or below the
+      // profile's split (settled from below: more of its best pairs), zneed[2 p + 1] = the smallest one above it (settled from above:
+      // its weakest pairs shown unreported); the split lies between the profile's two bounds (finalize_lazy)
+      if (zneed) {
+        const double z = domE / det_exp(d.lnP);
+        if (z < 9.0e18) {
+          const unsigned long long zf = (unsigned long long)z;
+          if (zf + 2ull <= zsplit[d.prof]) atomicMax(&zneed[2 * d.prof], zf + 2ull);
+          else atomicMin(&zneed[2 * d.prof + 1], zf > 2ull ? zf - 2ull : 0ull);
+        } else atomicMin(&zneed[2 * d.prof + 1], (unsigned long long)9.0e18);
+      }
+    }
   }
   const unsigned long long m = __ballot(c);
   if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(count, (unsigned long long)__builtin_popcountll(m));
@@ -575,9 +591,68 @@ void launch_lazy_sure(const itsx_domain *dom, int64_t n, const int8_t *cls, int 
   if (n > 0) hipLaunchKernelGGL(k_lazy_sure, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, sure, has);
 }
 void launch_lazy_pending(const itsx_domain *dom, int64_t n, const int8_t *cls, int ncls, const unsigned long long *sure, const int32_t *has,
-                         unsigned long long *count, int32_t *prof_flag, uint8_t *uniq_flag, hipStream_t st)
+                         unsigned long long *count, int32_t *prof_flag, uint8_t *uniq_flag, unsigned long long *zneed, const unsigned long long *zsplit, double domE, hipStream_t st)
 {
-  if (n > 0) hipLaunchKernelGGL(k_lazy_pending, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, sure, has, count, prof_flag, uniq_flag);
+  if (n > 0) hipLaunchKernelGGL(k_lazy_pending, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, n, cls, ncls, sure, has, count, prof_flag, uniq_flag, zneed, zsplit, domE);
+}
+// evaluated pairs (done flags) of the listed profiles' segments: cnt[slot] (zeroed); grid (blocks per profile, slots)
+__global__ void __launch_bounds__(256) k_topup_count(const uint8_t *__restrict__ done, const int64_t *__restrict__ seg_start, const int32_t *__restrict__ total,
+                                                     const int32_t *__restrict__ prof_of_slot, unsigned long long *__restrict__ cnt)
+{
+  const int sl = blockIdx.y, p = prof_of_slot[sl];
+  const int64_t base = seg_start[p], n = total[p];
+  unsigned long long c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c += done[base + i] != 0;
+  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cnt[sl], c);
+}
+void launch_topup_count(const uint8_t *done, const int64_t *seg_start, const int32_t *total, const int32_t *prof_of_slot, int nslots, unsigned long long *cnt, hipStream_t st)
+{
+  if (nslots > 0) hipLaunchKernelGGL(k_topup_count, dim3(512, (unsigned)nslots), dim3(256), 0, st, done, seg_start, total, prof_of_slot, cnt);
+}
+
+// ---- the top-up round (itsx_search_finalize): the unevaluated pairs of the profiles that have undecided rows, best bound first
+// pass 0 (pos == nullptr): flag[i] = the pair belongs to a profile with undecided rows and has not been evaluated; pass 1: its key
+// [slot | ~bound] into the compact list at pos[i]
+__global__ void __launch_bounds__(256) k_topup_keys(const PairRec *__restrict__ pairs, int64_t NP, const uint8_t *__restrict__ done, const uint32_t *__restrict__ b10,
+                                                    const int32_t *__restrict__ slot_of_prof, int32_t *__restrict__ flag, const int32_t *__restrict__ pos,
+                                                    unsigned long long *__restrict__ keys, int32_t *__restrict__ vals)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > NP) return;
+  int f = 0, sl = -1;
+  if (i < NP) {
+    const PairRec pr = pairs[i];
+    if (pr.prof >= 0 && pr.xj >= 0 && !done[i]) { sl = slot_of_prof[pr.prof]; f = sl >= 0; }
+  }
+  if (!pos) { flag[i] = f; return; }
+  if (f) { keys[pos[i]] = ((unsigned long long)sl << 32) | (unsigned long long)(0xFFFFFFFFu - b10[i]); vals[pos[i]] = (int32_t)i; }
+}
+__global__ void __launch_bounds__(256) k_topup_mark(const PairRec *__restrict__ pairs, int64_t NP, uint8_t *__restrict__ done, const uint32_t *__restrict__ b10,
+                                                    const int32_t *__restrict__ slot_of_prof, const uint32_t *__restrict__ cutoff, int32_t *__restrict__ flag)
+{
+  // cutoff[2 slot] > 0: the pairs whose bound is at least that (the best ones); cutoff[2 slot + 1] > 0: those whose bound is at most that
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > NP) return;
+  int f = 0;
+  if (i < NP) {
+    const PairRec pr = pairs[i];
+    if (pr.prof >= 0 && pr.xj >= 0 && !done[i]) {
+      const int sl = slot_of_prof[pr.prof];
+      if (sl >= 0) { const uint32_t hi = cutoff[2 * sl], lo = cutoff[2 * sl + 1], b = b10[i]; f = (hi > 0 && b >= hi) || (lo > 0 && b <= lo); }
+    }
+    if (f) done[i] = 1;
+  }
+  flag[i] = f;
+}
+void launch_topup_keys(const PairRec *pairs, int64_t NP, const uint8_t *done, const uint32_t *b10, const int32_t *slot_of_prof, int32_t *flag, const int32_t *pos,
+                       unsigned long long *keys, int32_t *vals, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_topup_keys, dim3((unsigned)((NP + 1 + 255) / 256)), dim3(256), 0, st, pairs, NP, done, b10, slot_of_prof, flag, pos, keys, vals);
+}
+void launch_topup_mark(const PairRec *pairs, int64_t NP, uint8_t *done, const uint32_t *b10, const int32_t *slot_of_prof, const uint32_t *cutoff, int32_t *flag, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_topup_mark, dim3((unsigned)((NP + 1 + 255) / 256)), dim3(256), 0, st, pairs, NP, done, b10, slot_of_prof, cutoff, flag);
 }
 
 }  // namespace itsx

@@ -43,6 +43,7 @@ static const Switch g_sw[] = {
   {"ITSX_NO_CHAINREC", SW_TUNING, "pass A reads a chain's data through the round-5 arrays instead of its 64-byte record (A/B)"},
   {"ITSX_BOUND_FOLD", SW_TUNING, "=0: pass A's plain recurrences instead of the folded ones (also switches two-sided sharing off)"},
   {"ITSX_BOUND_RESCALE_EXP", SW_TUNING, "power of ten at which pass A rescales a row (default 20)"},
+  {"ITSX_LAZY_TOPUP", SW_TUNING, "=0: undecided rows go straight to the full count of their profiles (no top-up round); =2: the round also looks for unreported pairs among a profile's weakest (rows settled from above)"},
   {"ITSX_LAZY_EXACT_BOUND", SW_TUNING, "pass A through the HMMER-order Forward kernel (A/B)"},
   {"ITSX_CHUNK_UNIQUES", SW_TUNING, "representatives per search chunk"},
   {"ITSX_MSV_OVERLAP", SW_TUNING, "=0: the next chunk's MSV filter does not run beside the domain stage"},

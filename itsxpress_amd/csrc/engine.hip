@@ -3297,7 +3297,12 @@ static int finalize_lazy(itsx_ctx *ctx, double domE)
     std::vector<unsigned long long> init(2 * Pn), split(Pn, 0);
     for (size_t p = 0; p < Pn; p++) {
       init[2 * p] = 0; init[2 * p + 1] = ~0ull;
-      if (p < ctx->domz.size() && ctx->S == 1) { const double lo = (double)ctx->domz[p], hi = (double)std::max(ctx->domz_ub[p], ctx->domz[p]); split[p] = (unsigned long long)(lo + 0.6 * (hi - lo)); }
+      if (p < ctx->domz.size() && ctx->S == 1) {
+        double lo = (double)ctx->domz[p], hi = (double)std::max(ctx->domz_ub[p], ctx->domz[p]);
+        // (no more targets than the profile has pairs on the last search's list, whatever the upper bound says: a multi-rank sum, a test's inflated bound)
+        if (ctx->topup.valid && ctx->n_chunks == 1 && p < ctx->topup.total.size()) hi = std::min(hi, std::max(lo, (double)ctx->topup.total[p]));
+        split[p] = (unsigned long long)(lo + 0.6 * (hi - lo));
+      }
     }
     HIPCHK(upload(ctx->l_zneed, init, st)); HIPCHK(upload(ctx->l_zsplit, split, st));
   }
@@ -3336,8 +3341,7 @@ static int lazy_topup(itsx_ctx *ctx, double domE, bool *ran)
   const auto &tu = ctx->topup;
   if (sw_get("ITSX_LAZY_HIST")) fprintf(stderr, "[itsx] top-up: valid %d chunks %d samples %d pairs %lld\n", (int)tu.valid, ctx->n_chunks, ctx->S, (long long)tu.NP);
   if (!tu.valid || ctx->n_chunks != 1 || ctx->S != 1 || tu.NP <= 0) return ITSX_OK;
-  static const bool on = !(sw_get("ITSX_LAZY_TOPUP") && atoi(sw_get("ITSX_LAZY_TOPUP")) == 0);
-  if (!on) return ITSX_OK;
+  if (sw_get("ITSX_LAZY_TOPUP") && atoi(sw_get("ITSX_LAZY_TOPUP")) == 0) return ITSX_OK;      // (read at every call)
   hipStream_t st = ctx->st;
   const int P = ctx->P;
   itsx_stats &S = ctx->stats;
@@ -3406,7 +3410,7 @@ static int lazy_topup(itsx_ctx *ctx, double domE, bool *ran)
     // rows settled from ABOVE: the upper bound must fall to zh -- that many pairs shown unreported, looked for among the weakest (+ 25 %: some are reported)
     // (only with ITSX_LAZY_TOPUP=2: on amplicon data nearly every pair past the filter IS a reported target -- at 10 M reads 387 k of a profile's
     // 394 k weakest pairs were --, so the upper bound hardly moves and such a row goes to the full count anyway)
-    static const bool both = sw_get("ITSX_LAZY_TOPUP") && atoi(sw_get("ITSX_LAZY_TOPUP")) == 2;
+    const bool both = sw_get("ITSX_LAZY_TOPUP") && atoi(sw_get("ITSX_LAZY_TOPUP")) == 2;
     if (both && zh != ~0ull && hi > (int64_t)zh) { const int64_t need = hi - (int64_t)zh; from_bottom = need + need / 4 + 64; }
     if (sw_get("ITSX_LAZY_HIST")) fprintf(stderr, "[itsx] top-up: profile %d bounds %lld .. %lld (%lld unevaluated), rows need >= %llu / <= %llu: best %lld, weakest %lld\n", p, (long long)lo, (long long)hi,
                                           (long long)have, zl, zh == ~0ull ? 0ull : zh, (long long)from_top, (long long)from_bottom);

@@ -150,6 +150,7 @@ def test_undecided_rows_are_settled_by_counting_their_profiles(engine, mini_hmm_
         seqs.append(s)
     hmm = mini_hmm_text + _its2_subset(t_hmm_text, 25, 25)
     monkeypatch.setenv("ITSX_LAZY_ZUB_SCALE", "500000")
+    monkeypatch.setenv("ITSX_LAZY_TOPUP", "0")               # (this test is about the full count; the top-up round ahead of it has its own below)
     e = engine
     try:
         ref, _ = _coords(e, hmm, seqs, "full")
@@ -176,6 +177,34 @@ def test_undecided_rows_are_settled_by_counting_their_profiles(engine, mini_hmm_
         assert _same(ref, got2)
     finally:
         e.set_rows_mode(None)
+
+
+def test_top_up_round_settles_rows_from_below(engine, mini_hmm_text, t_hmm_text, monkeypatch):
+    """Round 6: before a profile with undecided rows is counted in full, its best-bound unevaluated pairs go through the pipeline -- as many
+    as the lower bound on its domZ needs to pass domE / P-value of those rows (itsx_search_finalize: lazy_topup).  Weak rows on a
+    workload where nearly every pair past the filter is a reported target: the round runs, settles rows, what it cannot settle is still
+    counted in full, and the coordinates are the full table's either way (ITSX_LAZY_TOPUP=0: straight to the full count)."""
+    rng = np.random.default_rng(37)
+    blob, offs = synth.make_reads(mini_hmm_text, 3000, seed=75, fixed_len=0, len_range=(200, 520))
+    seqs = []
+    for s in synth.to_strings(blob, offs):                   # heavy damage: many reads keep only rows near the Forward filter's threshold
+        if rng.random() < 0.6:
+            s = list(s)
+            for q in rng.choice(len(s), int(len(s) * rng.uniform(0.3, 0.42)), replace=False):
+                s[q] = str(rng.choice(list("ACGT")))
+            s = "".join(s)
+        seqs.append(s)
+    hmm = mini_hmm_text + _its2_subset(t_hmm_text, 25, 25)
+    monkeypatch.setenv("ITSX_LAZY_ZUB_SCALE", "500000")      # (upper bounds as of a data set that much larger: weak rows stay undecided at first)
+    try:
+        ref, _ = _coords(engine, hmm, seqs, "full")
+        monkeypatch.setenv("ITSX_LAZY_TOPUP", "1")
+        got, st = _coords(engine, hmm, seqs, "lazy")
+        assert st["n_lazy_pending"] > 0 and st["n_lazy_reruns"] == 0 and st["lazy"] == 1
+        assert st["n_lazy_topup"] > 0, st
+        assert _same(ref, got)
+    finally:
+        engine.set_rows_mode(None)
 
 
 def test_lazy_sample_batches(engine, mini_hmm_text, t_hmm_text):

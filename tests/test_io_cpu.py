@@ -521,3 +521,41 @@ def test_shared_text_stream_lets_another_mapping_read_the_slices(tmp_path, monke
         assert all(0.7 * len(text) < e < 1.4 * len(text) for e in est), est[:4]
         if not want_plain:
             os.unlink(backing)
+
+
+def test_mate_stream_hands_out_the_asked_number_of_records(tmp_path, monkeypatch):
+    """itsx_stream_next_records / itsx_count_records / itsx_write_range (round 6: a streamed paired sample cuts R2 at R1's record counts; the
+    multi-GPU driver writes a worker's piece while the rest of the file is inflated): slices hold exactly the records asked for, fewer
+    only at the end of the file; a piece written from memory is the text it came from"""
+    import ctypes as C
+    monkeypatch.setenv("ITSX_PINFLATE_CHUNK_KB", "64")
+    monkeypatch.setenv("ITSX_TEXT_CACHE_GB", "0")
+    rng = np.random.default_rng(8)
+    recs = []
+    for i in range(50000):
+        n = int(rng.integers(50, 200))
+        recs.append(b"@m%d 2:N:0\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)), b"@" * n))
+    text = b"".join(recs)
+    gz = tmp_path / "r2.fq.gz"
+    with gzip.open(gz, "wb", compresslevel=6) as f:
+        f.write(text)
+    L = _lib.lib()
+    assert L.itsx_count_records(C.c_char_p(text), len(text)) == 50000
+    assert L.itsx_count_records(C.c_char_p(text[:-1]), len(text) - 1) == 50000          # (a last line without its newline)
+    h = C.c_void_p()
+    assert L.itsx_stream_open(os.fsencode(str(gz)), C.byref(h)) == 0, L.itsx_stream_last_error()
+    got, asked, off, n_left = [], [1, 7, 12000, 0, 20000, 30000], 0, 50000
+    for want in asked:
+        ptr, nb, cnt, last = C.c_void_p(), C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        assert L.itsx_stream_next_records(h, want, C.byref(ptr), C.byref(nb), C.byref(cnt), C.byref(last)) == 0, L.itsx_stream_last_error()
+        piece = C.string_at(ptr.value, nb.value) if nb.value else b""
+        exp = min(want, n_left)
+        assert cnt.value == exp and piece == b"".join(recs[off:off + exp])
+        if piece:
+            p = tmp_path / ("piece_%d" % off)
+            assert L.itsx_write_range(os.fsencode(str(p)), ptr, nb.value) == 0, L.itsx_shard_last_error()
+            assert p.read_bytes() == piece
+        off += exp; n_left -= exp
+        assert bool(last.value) == (n_left == 0)
+    assert L.itsx_stream_close(h, 0) == 0
+    assert L.itsx_write_range(os.fsencode(str(tmp_path / "no" / "such" / "dir")), C.c_char_p(b"x"), 1) != 0

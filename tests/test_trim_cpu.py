@@ -426,3 +426,62 @@ def test_label_index_built_by_a_pool_keeps_the_first_of_equal_labels(tmp_path, m
     recs = out["pool"][1].split(b"\n")
     for i in (0, 10, 69990):                                  # a repeated label: its FIRST coordinates
         assert len(recs[4 * i + 1]) == int(stop[i] - start[i]), i
+
+
+def test_writer_object_in_slice_mode_follows_python_slicing(tmp_path):
+    """itsx_twriter_set_mode(w, 1) (round 6: the two mates of a streamed paired sample, itsxpress/SeqSample.py:587-670): (start, stop) are Python
+    slice bounds as they come -- negative starts count from the end, stop == INT32_MAX is an open end, stop == INT32_MIN skips the record;
+    what the paired writer's own arithmetic gives, R1[start:stop] (or [start:]) and R2[tlen - stop : tlen - start] (or [.. :]), must come
+    out of two such writers exactly as out of itsx_write_trimmed_paired"""
+    import ctypes as C
+    from itsxpress_amd import _lib
+    rng = np.random.default_rng(5)
+    n = 3000
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    recs1, recs2, names, start, stop, tlen = [], [], [], [], [], []
+    for i in range(n):
+        l1, l2 = int(rng.integers(60, 250)), int(rng.integers(60, 250))
+        s1, s2 = acgt[rng.integers(0, 4, l1)].tobytes(), acgt[rng.integers(0, 4, l2)].tobytes()
+        q1, q2 = bytes(rng.integers(35, 74, l1).astype(np.uint8)), bytes(rng.integers(35, 74, l2).astype(np.uint8))
+        recs1.append(b"@p%d 1:N\n" % i + s1 + b"\n+\n" + q1 + b"\n")
+        recs2.append(b"@p%d 2:N\n" % i + s2 + b"\n+\n" + q2 + b"\n")
+        names.append("p%d" % i)
+        t = int(rng.integers(120, 480))
+        a = int(rng.integers(0, 150))
+        b = int(rng.integers(a - 5, t + 40))            # also stop <= start (skipped) and stop > tlen (open end, negative R2 start)
+        if i % 17 == 0:
+            a, b = -1, -1                                # not trimmed
+        start.append(a); stop.append(b); tlen.append(t)
+    t1, t2 = b"".join(recs1), b"".join(recs2)
+    f1, f2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    f1.write_bytes(t1); f2.write_bytes(t2)
+    start, stop, tlen = (np.asarray(x, np.int32) for x in (start, stop, tlen))
+    o1, o2 = tmp_path / "o1.fq", tmp_path / "o2.fq"
+    nw = write_trimmed_paired(str(f1), str(f2), str(o1), str(o2), names, start, stop, tlen)
+    # the same through two writer objects in slice mode
+    SKIP, OPEN = -(1 << 31), (1 << 31) - 1
+    s64, e64, t64 = start.astype(np.int64), stop.astype(np.int64), tlen.astype(np.int64)
+    keep = (s64 >= 0) & (e64 >= 0) & (s64 < e64)
+    a1 = np.where(keep, s64, 0).astype(np.int32); b1 = np.where(keep, np.where(e64 > t64, OPEN, e64), SKIP).astype(np.int32)
+    a2 = np.where(keep, t64 - e64, 0).astype(np.int32); b2 = np.where(keep, np.where(t64 - s64 > t64, OPEN, t64 - s64), SKIP).astype(np.int32)
+    L = _lib.lib()
+    got = []
+    for text, a, b, name in ((t1, a1, b1, "w1.fq"), (t2, a2, b2, "w2.fq")):
+        w = C.c_void_p()
+        out = tmp_path / name
+        assert L.itsx_twriter_open(os.fsencode(str(out)), 0, 0, C.byref(w)) == 0
+        assert L.itsx_twriter_set_mode(w, 1) == 0
+        buf = C.create_string_buffer(text, len(text))
+        dec = np.ones(n, np.uint8)
+        assert L.itsx_twriter_text(w, buf, len(text), 1) == 0
+        assert L.itsx_twriter_coords(w, 0, n, a.ctypes.data, b.ctypes.data, dec.ctypes.data) == 0
+        cnt, tot = C.c_int64(0), C.c_int64(0)
+        assert L.itsx_twriter_close(w, C.byref(cnt), C.byref(tot)) == 0, L.itsx_trim_last_error()
+        assert cnt.value == nw == int(keep.sum())
+        got.append(out.read_bytes())
+    assert got[0] == o1.read_bytes() and got[1] == o2.read_bytes() and len(got[0]) > 10000
+    w = C.c_void_p()
+    assert L.itsx_twriter_open(os.fsencode(str(tmp_path / "x.fq")), 0, 0, C.byref(w)) == 0
+    assert L.itsx_twriter_set_mode(w, 2) != 0
+    L.itsx_twriter_text(w, None, 0, 1)
+    L.itsx_twriter_close(w, None, None)

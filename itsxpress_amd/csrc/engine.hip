@@ -527,6 +527,15 @@ itsx_ctx *itsx_create(int device_id, int flags)
   if (device_id < 0 || device_id >= ndev) { g_create_error = "device ordinal out of range"; return nullptr; }
   e = hipSetDevice(device_id);
   if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+  // How a host thread waits for the device.  The runtime's default spins: a thread inside hipStreamSynchronize holds a CPU at 100 %.  One
+  // context on a GPU-bound job wants that (a lazy search stops for a count from the device a few hundred times); a file-to-file run with
+  // four or five threads waiting on the GPU beside thirty-two that inflate, parse and deflate on the box's 16 CPUs does not.  ITSX_SYNC=block:
+  // waiting threads sleep until the signal's interrupt (the streamed runs set it, itsxpress_amd/stream.py); ITSX_SYNC=spin: the default.
+  if (const char *sm = sw_get("ITSX_SYNC")) {
+    if (strcmp(sm, "block") == 0) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    else if (strcmp(sm, "spin") == 0) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void)hipGetLastError();
+  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return nullptr; }
   if (std::string(prop.gcnArchName).compare(0, 6, "gfx950") != 0) {
@@ -2330,10 +2339,16 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
       static const int lanes_long = sw_get("ITSX_MR_LONG_LANES") ? std::max(1, std::min(MR_LANES, atoi(sw_get("ITSX_MR_LONG_LANES")))) : MR_LANES_LONG;
       static const double frac_long = sw_get("ITSX_MR_LONG_FRAC") ? atof(sw_get("ITSX_MR_LONG_FRAC")) : MR_LONG_FRAC;
       const int64_t n_long = std::min<int64_t>(NU, (int64_t)(frac_long * (double)NU));
+      // A lazy search sends few regions here (10 M reads: 1 000 - 8 000 distinct ones per round, against 600 000 of a full table): in waves of
+      // 64 they are 16 - 120 waves on a chip of 1 024 SIMDs, each walking 200 x ~125 dependent steps for its lanes' 200 x ~60.  The kernel holds
+      // four waves per SIMD: as few lanes per wave as keep every wave resident at once (ITSX_MR_WAVES, 4 096; never under two lanes) --
+      // less of the phase divergence, the same latency per step (10 M reads: 215 -> 168 ms per step; a full table's waves stay at 64 lanes)
+      static const int64_t waves_target = sw_get("ITSX_MR_WAVES") ? atoll(sw_get("ITSX_MR_WAVES")) : 4096;
+      const int lanes_norm = waves_target <= 0 ? MR_LANES : (int)std::max<int64_t>(2, std::min<int64_t>(MR_LANES, (NU + waves_target - 1) / waves_target));
       std::vector<WaveDesc> mw;
       std::vector<int64_t> wfirst;
       for (int64_t x = 0; x < NU;) {
-        const int lanes = x >= NU - n_long ? lanes_long : (int)std::min<int64_t>(MR_LANES, NU - n_long - x);
+        const int lanes = x >= NU - n_long ? std::min(lanes_long, lanes_norm) : (int)std::min<int64_t>(lanes_norm, NU - n_long - x);
         WaveDesc d{};
         d.prof = -1; d.first = x; d.count = (int32_t)std::min<int64_t>(lanes, (int64_t)NU - x);
         d.rows = hlen[(size_t)ord[(size_t)(d.first + d.count - 1)]] + 1;                  // ascending length: the last lane's

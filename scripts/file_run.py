@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--chunk-mb", type=float, default=0.0, help="--stream: text per chunk (0: about a tenth of the file)")
     ap.add_argument("--stream-write", action="store_true", help="--stream: the writer inside the pipeline too (provisional thresholds per chunk)")
     ap.add_argument("--check", action="store_true", help="--stream: compare the coordinates with one context on the whole file")
+    ap.add_argument("--input-dir", default="", help="keep the generated in.fastq.gz here and use it again when it is there (several arms over one file)")
     args = ap.parse_args()
     import synth
     from bench import its2_profiles
@@ -47,15 +48,24 @@ def main():
     try:
         plain = os.path.join(tmp, "in.fastq")
         bases = np.frombuffer(blob, np.uint8)
-        with open(plain, "wb") as f:                  # Illumina-like qualities: high, decaying along the read
-            qtab = [(np.clip(38 - (np.arange(600) // 25) - rng.integers(0, 6, 600), 2, 40) + 33).astype(np.uint8).tobytes() for _ in range(64)]
-            for i in range(n):
-                s = bases[offs[i]:offs[i + 1]]
-                f.write(b"@read%d 1:N:0:1\n" % i + s.tobytes() + b"\n+\n" + qtab[i & 63][:len(s)] + b"\n")
-        fq = os.path.join(tmp, "in.fastq.gz")
-        write_trimmed_fastq(plain, fq, np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32), gzipped=True)
-        in_bytes, in_gz = os.path.getsize(plain), os.path.getsize(fq)
-        os.remove(plain)
+        kept = os.path.join(args.input_dir, "in_%s_%d.fastq.gz" % (args.shape, n)) if args.input_dir else ""
+        if kept and os.path.exists(kept) and os.path.exists(kept + ".size"):
+            fq = kept
+            in_bytes, in_gz = int(open(kept + ".size").read()), os.path.getsize(fq)
+        else:
+            with open(plain, "wb") as f:                  # Illumina-like qualities: high, decaying along the read
+                qtab = [(np.clip(38 - (np.arange(600) // 25) - rng.integers(0, 6, 600), 2, 40) + 33).astype(np.uint8).tobytes() for _ in range(64)]
+                for i in range(n):
+                    s = bases[offs[i]:offs[i + 1]]
+                    f.write(b"@read%d 1:N:0:1\n" % i + s.tobytes() + b"\n+\n" + qtab[i & 63][:len(s)] + b"\n")
+            fq = kept or os.path.join(tmp, "in.fastq.gz")
+            if kept:
+                os.makedirs(args.input_dir, exist_ok=True)
+            write_trimmed_fastq(plain, fq, np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32), gzipped=True)
+            in_bytes, in_gz = os.path.getsize(plain), os.path.getsize(fq)
+            os.remove(plain)
+            if kept:
+                open(kept + ".size", "w").write(str(in_bytes))
 
         eng = Engine(0)
         eng.set_rows_mode(args.rows)

@@ -527,15 +527,6 @@ itsx_ctx *itsx_create(int device_id, int flags)
   if (device_id < 0 || device_id >= ndev) { g_create_error = "device ordinal out of range"; return nullptr; }
   e = hipSetDevice(device_id);
   if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
-  // How a host thread waits for the device.  The runtime's default spins: a thread inside hipStreamSynchronize holds a CPU at 100 %.  One
-  // context on a GPU-bound job wants that (a lazy search stops for a count from the device a few hundred times); a file-to-file run with
-  // four or five threads waiting on the GPU beside thirty-two that inflate, parse and deflate on the box's 16 CPUs does not.  ITSX_SYNC=block:
-  // waiting threads sleep until the signal's interrupt (the streamed runs set it, itsxpress_amd/stream.py); ITSX_SYNC=spin: the default.
-  if (const char *sm = sw_get("ITSX_SYNC")) {
-    if (strcmp(sm, "block") == 0) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
-    else if (strcmp(sm, "spin") == 0) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
-    (void)hipGetLastError();
-  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return nullptr; }
   if (std::string(prop.gcnArchName).compare(0, 6, "gfx950") != 0) {

@@ -366,10 +366,6 @@ class StreamEngine(ShardedOps):
 
     def __init__(self, device=None, chunk_mb=None):
         self.L = _lib.lib()
-        # A streamed run has four or five host threads waiting for the GPU (two searches, the loaders, the writer's finisher) beside the
-        # I/O pool's threads that inflate, parse and deflate; the runtime's default wait polls -- each of those threads held a CPU of the
-        # box's sixteen.  The contexts this object creates wait asleep (csrc/engine.hip: itsx_create; 10 M reads file to file 7.1 -> 6.1 s).
-        os.environ.setdefault("ITSX_SYNC", "block")
         self.device = _device_from_env() if device is None else int(device)
         if chunk_mb is None:
             chunk_mb = float(os.environ.get("ITSX_STREAM_CHUNK_MB", "0") or 0)

@@ -80,6 +80,10 @@ def run(pairs, array_path=True, stream=False, check=False):
         thmm = f.read()
     n = args.pairs
     rng = np.random.default_rng(17)
+    t_gen = time.perf_counter()
+
+    def note(what):                      # (a 10 M-pair input takes minutes to generate: a line per stage keeps a watched run alive)
+        print("[paired_run] %6.1f s  %s" % (time.perf_counter() - t_gen, what), file=sys.stderr, flush=True)
     # amplicons: a library of templates of 300-480 bases, Zipf-sampled; the differences between reads come from sequencing
     nt = max(1, n // 50)
     tb, to = synth.make_reads(thmm, nt, config=3, seed=synth.SEED + 7, fixed_len=0, len_range=(300, 480), frac_templates=1.0,
@@ -108,8 +112,11 @@ def run(pairs, array_path=True, stream=False, check=False):
         reads = reads.copy()
         reads[err] = acgt[rng.integers(0, 4, int(err.sum()))]
         return reads, (q + 33).astype(np.uint8)
+    note("templates sampled")
     fwd, fq = sequenced(fwd)
+    note("R1 sequenced")
     rev, rq = sequenced(rev)
+    note("R2 sequenced")
     tmp = tempfile.mkdtemp(prefix="itsx_paired_run_")
     try:
         paths = []
@@ -122,6 +129,7 @@ def run(pairs, array_path=True, stream=False, check=False):
             write_trimmed_fastq(plain, gz, np.zeros(n, np.int32), np.full(n, 1 << 30, np.int32), gzipped=True)
             os.remove(plain)
             paths.append(gz)
+            note(tag + " written")
         hmm = os.path.join(tmp, "its2.hmm")
         with open(hmm, "w") as f:
             f.write(its2_profiles(thmm))
@@ -134,6 +142,7 @@ def run(pairs, array_path=True, stream=False, check=False):
         s = SeqSamplePairedNotInterleaved(paths[0], os.path.join(tmp, "work"), paths[1])
         s._engine = eng
         t = {}
+        note("staged run starts")
         t0 = time.perf_counter()
         s._merge_reads(threads=1, stagger=False)
         t["merge"] = time.perf_counter() - t0
@@ -166,9 +175,20 @@ def run(pairs, array_path=True, stream=False, check=False):
         kept = int(((start >= 0) & (stop >= 0) & (start < stop)).sum())
         assert nw == kept, (nw, kept)
         streamed = None
+        note("staged run done: %.2f s" % total)
         if stream:
             eng.close()
-            streamed, (s1, s2) = stream_leg(paths, hmm, tmp)
+            # (ITSX_PAIRED_SYNC_ARMS=spin,block: the streamed leg once per way of waiting, the last one kept; a leg that does not end is
+            # reported by every thread's stack after two minutes)
+            arms = [a for a in os.environ.get("ITSX_PAIRED_SYNC_ARMS", "").split(",") if a]
+            import faulthandler
+            for arm in arms or [None]:
+                if arm is not None:
+                    os.environ["ITSX_SYNC"] = arm
+                faulthandler.dump_traceback_later(120, exit=True)
+                streamed, (s1, s2) = stream_leg(paths, hmm, tmp)
+                faulthandler.cancel_dump_traceback_later()
+                note("streamed run done (%s): %.2f s  %s" % (arm or os.environ.get("ITSX_SYNC", "default"), streamed["s_total"], json.dumps(streamed)[:300]))
             streamed["pairs_per_s_file_to_file"] = round(n / streamed["s_total"])
             if check:
                 for a, b in ((o1, s1), (o2, s2)):

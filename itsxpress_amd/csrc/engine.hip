@@ -2798,6 +2798,7 @@ static int lazy_rounds(itsx_ctx *ctx, const PairList &pl, const int32_t *d_sorte
             sl.src = ctx->sh_rsrc.p + cb0; sl.mask = ctx->sh_rmask.p + cb0; sl.node0 = ctx->sh_rnode0.p + cb0; sl.endrow = ctx->sh_bsteps.p + cb0;
             sl.slots = gsl; sl.node_base = b.gnode0; sl.p0 = pa; sl.Pb = pb - pa; sl.depth = d; sl.logB = ctx->share_logB;
             sl.chain = ctx->sh_bchain.p + cb0; sl.entab = ctx->d_entab.p;
+            if (sw_get("ITSX_TEST_HOOKS") && sw_get("ITSX_PASSA_DBG")) sl.dbg = atoi(sw_get("ITSX_PASSA_DBG"));
             if (dump) dump_launch("bwd", t0 / DS, d, w0, w1, dumpb, 0);
             for (int w = w0; w < w1; w += 1 << 20) { launch_bwd_bound_share(ab, ctx->d_btab.p, ctx->d_rtab.p, std::min(1 << 20, w1 - w), w, sl, bs); S.n_bwd_launches++; }
           }

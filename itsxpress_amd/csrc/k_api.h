@@ -227,7 +227,7 @@ struct ShareLaunch {
   // chain of dependent loads (pair -> sorted position -> read -> offsets): a wave's start-up was 30 rows' worth of latency
   const struct ChainRec *chain;
   const float *entab;          // [P][NCODE][2 * BOUND_PAIRS] the folded emission odds by node (engine.hip: install_profiles)
-  int32_t dbg;                 // diagnostic (ITSX_TEST_HOOKS=1 ITSX_PASSA_DBG=bits; results are garbage): 1 no rows, 2 no restore, 4 no join
+  int32_t dbg;                 // diagnostic (ITSX_TEST_HOOKS=1 ITSX_PASSA_DBG=bits; results are garbage): 1 no rows, 2 no restore, 4 no join; k_bwd_bound: 8 no saves, 16 no restore, 32 no rows
 };
 struct alignas(16) ChainRec {
   int64_t woff, excoff;        // the read's packed words / exceptions

@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   Seq sq; sq.w = a.rd.words + cr.woff; sq.exc = a.rd.exc + cr.excoff; sq.nexc = cr.nexc; sq.L = cr.L;
-  const int nsteps = wd.rows - 1;                             // the wave's longest chain
+  const int nsteps = (sl.dbg & 32) ? 0 : wd.rows - 1;         // the wave's longest chain
   f2 M[BP], I[BP], D[BP];
 #pragma unroll
   for (int j = 0; j < BP; j++) { M[j] = (f2){0.f, 0.f}; I[j] = (f2){0.f, 0.f}; D[j] = (f2){0.f, 0.f}; }
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int 
   unsigned long long smask = 0ull; int64_t snode = 0; int mysteps = 0;
   (void)kb;
   if (active) { smask = cr.mask; snode = (int64_t)cr.node0 - sl.node_base; mysteps = cr.endrow; }
-  if (rd > 0) {
+  if (rd > 0 && !(sl.dbg & 16)) {
     const int64_t node = (int64_t)cr.src - sl.node_base;
     const f4 *src = (const f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
 #pragma unroll
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int 
     if ((step & ((1 << sl.logB) - 1)) == 0 && step > 0) {
       // a block boundary: gamma after row top - step = (A - rdl) B is what the Forward chains that end there take
       const int rdl = rd + (step >> sl.logB);
-      if (active && rdl < 64 && ((smask >> rdl) & 1ull)) {
+      if (active && rdl < 64 && ((smask >> rdl) & 1ull) && !(sl.dbg & 8)) {
         const int64_t node = snode + __popcll(smask & ((1ull << rdl) - 1ull));
         f4 *dst = (f4 *)sl.slots + (node * sl.Pb + (prof - sl.p0)) * FWD_STATE_Q;
 #pragma unroll
@@ -385,10 +385,18 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int 
       const f2 aEv = (f2){aE, aE};
       float aDn = 0.0f, wn = 0.0f;                            // aD and w of the node after the pair
       f2 accB = (f2){0.f, 0.f};
+      // (the table record and the emission odds of pair j - 1 are requested while pair j is worked on, as in the Forward step: left to
+      // itself the compiler asks for a record a few instructions before its first use and waits for the scalar cache twenty times a row
+      // -- 0.89 ns per wave-row against the Forward kernel's 0.56)
+      RT cur = ldrt(tb, BP - 1);
+      f2 ecur = *(const f2 *)(ex + 2 * (BP - 1));
 #pragma unroll
       for (int j = BP - 1; j >= 0; j--) {
-        const RT t = ldrt(tb, j);
-        const f2 e = *(const f2 *)(ex + 2 * j);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): pair j's record and emissions, requested one step ago
+        const RT t = cur;
+        const f2 e = ecur;
+        if (j > 0) { cur = ldrt(tb, j - 1); ecur = *(const f2 *)(ex + 2 * (j - 1)); }
+        __builtin_amdgcn_sched_barrier(0);
         const float aD2 = __builtin_fmaf(t.aa.y, aDn, D[j].y);
         const f2 aM = (M[j] + aEv) + (f2){aD2, aDn};
         const float aD1 = __builtin_fmaf(t.aa.x, aD2, D[j].x);

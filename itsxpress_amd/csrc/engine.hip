@@ -726,12 +726,21 @@ static int install_profiles(itsx_ctx *ctx, std::vector<HostProfile> &pv, int *n_
     std::vector<float> rt((size_t)std::max(P, 1) * BOUND_RTAB, 0.0f);
     for (int i = 0; i < P && fold; i++) {
       const float *b = bt.data() + (size_t)i * BOUND_TAB;
-      for (int j = 0; j < BOUND_PAIRS; j++) {
+      // record j = what the kernel's step j reads: mm im dm bm of pair j (the late half of pair j: k_lazy.hip) and ii, dd of pair j - 1
+      // (the early half of the pair after it in walking order); the last pair's ii, dd stand behind the records
+      for (int j = 0; j <= BOUND_PAIRS; j++) {
         float *o = rt.data() + (size_t)i * BOUND_RTAB + (size_t)j * 12;
-        for (int q = 0; q < 8; q++) o[q] = b[(size_t)j * 16 + q];                          // mm im dm ii of the pair's nodes
-        o[8] = b[(size_t)(j + 1) * 16 + 8]; o[9] = b[(size_t)(j + 1) * 16 + 9];            // B -> M_k1, B -> M_k2
-        o[10] = b[(size_t)(j + 1) * 16 + 11];                                              // D_k1 -> D_k2
-        o[11] = (j + 2 <= BOUND_PAIRS) ? b[(size_t)(j + 2) * 16 + 10] : 0.0f;              // D_k2 -> D_k2+1 (none after the last node)
+        if (j < BOUND_PAIRS) {
+          for (int q = 0; q < 6; q++) o[q] = b[(size_t)j * 16 + q];                        // mm im dm of the pair's nodes
+          o[6] = b[(size_t)(j + 1) * 16 + 8]; o[7] = b[(size_t)(j + 1) * 16 + 9];          // B -> M_k1, B -> M_k2
+        }
+        if (j >= 1) {
+          const int jj = j - 1;
+          float *q = j < BOUND_PAIRS ? o + 8 : o;
+          q[0] = b[(size_t)jj * 16 + 6]; q[1] = b[(size_t)jj * 16 + 7];                    // I_k -> I_k of pair j - 1
+          q[2] = b[(size_t)(jj + 1) * 16 + 11];                                            // D_k1 -> D_k2
+          q[3] = (jj + 2 <= BOUND_PAIRS) ? b[(size_t)(jj + 2) * 16 + 10] : 0.0f;           // D_k2 -> D_k2+1 (none after the last node)
+        }
       }
     }
     HIPCHK(upload(ctx->d_rtab, rt, ctx->st));

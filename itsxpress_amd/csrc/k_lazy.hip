@@ -295,12 +295,14 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_fwd_bound(FloatArgs a, int 
 //     gN <- loop nN,  gJ <- loop nJ,  gC <- loop gC
 // (the same table entries as the Forward kernel's, by pair of nodes: engine.hip builds rtab).  The cells are kept below ~1e6 by a sum test
 // every 16 rows (block boundaries are multiples of 16), the scale's logarithm travels with the state like Forward's.
-struct RT { f2 mm, im, dm, ii, bm, aa; };
+// record j of the table (engine.hip: install_profiles): mm im dm bm of pair j, then ii and dd (aa) of pair j - 1 -- what ONE step of the
+// row loop below reads: the late half of pair j and the early half of pair j - 1
+struct RT { f2 mm, im, dm, bm, ii, aa; };
 DEV RT ldrt(const float *tab, int j)
 {
   const f4 a = *(cf4q)(uintptr_t)(tab + j * 12), b = *(cf4q)(uintptr_t)(tab + j * 12 + 4), c = *(cf4q)(uintptr_t)(tab + j * 12 + 8);
   RT t;
-  t.mm = (f2){a.x, a.y}; t.im = (f2){a.z, a.w}; t.dm = (f2){b.x, b.y}; t.ii = (f2){b.z, b.w}; t.bm = (f2){c.x, c.y}; t.aa = (f2){c.z, c.w};
+  t.mm = (f2){a.x, a.y}; t.im = (f2){a.z, a.w}; t.dm = (f2){b.x, b.y}; t.bm = (f2){b.z, b.w}; t.ii = (f2){c.x, c.y}; t.aa = (f2){c.z, c.w};
   return t;
 }
 __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int wave0, int nwaves, const float *__restrict__ btab, const float *__restrict__ rtab, ShareLaunch sl)
@@ -385,30 +387,47 @@ __global__ void __launch_bounds__(64 * FWD_WPB, 2) k_bwd_bound(FloatArgs a, int 
       const f2 aEv = (f2){aE, aE};
       float aDn = 0.0f, wn = 0.0f;                            // aD and w of the node after the pair
       f2 accB = (f2){0.f, 0.f};
-      // (the table record and the emission odds of pair j - 1 are requested while pair j is worked on, as in the Forward step: left to
-      // itself the compiler asks for a record a few instructions before its first use and waits for the scalar cache twenty times a row
-      // -- 0.89 ns per wave-row against the Forward kernel's 0.56)
+      // One step = the LATE half of pair j (w = e aM, its share of B, the new M I D of the pair: a chain w -> wsh -> cells) and the EARLY half
+      // of pair j - 1 (its aD chain -- two dependent multiply-adds --, aM, ii I), statement by statement in a fixed order so that no
+      // instruction reads the result of the one before it (at two waves per SIMD that costs a wait state the other wave only half fills:
+      // the compiler's own order ran at 0.87 ns per wave-row against the Forward step's 0.56); the step's table record (engine.hip: what
+      // both halves read, 12 floats) and emission odds are requested one step ahead, as in the Forward step.
+#define SB __builtin_amdgcn_sched_barrier(0)
+      const f4 tl = *(cf4q)(uintptr_t)(tb + BP * 12);         // ii, dd of the last pair
       RT cur = ldrt(tb, BP - 1);
       f2 ecur = *(const f2 *)(ex + 2 * (BP - 1));
+      // the early half of the last pair (no node after it: aDn = 0)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      float aD2 = __builtin_fmaf(tl.w, aDn, D[BP - 1].y);
+      f2 pre = M[BP - 1] + aEv;
+      float aD1 = __builtin_fmaf(tl.z, aD2, D[BP - 1].x);
+      f2 iig = (f2){tl.x, tl.y} * I[BP - 1];
+      f2 aM = pre + (f2){aD2, aDn};
+      aDn = aD1;
 #pragma unroll
       for (int j = BP - 1; j >= 0; j--) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): pair j's record and emissions, requested one step ago
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): step j's record and pair j's emissions, requested one step ago
         const RT t = cur;
         const f2 e = ecur;
-        if (j > 0) { cur = ldrt(tb, j - 1); ecur = *(const f2 *)(ex + 2 * (j - 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-        const float aD2 = __builtin_fmaf(t.aa.y, aDn, D[j].y);
-        const f2 aM = (M[j] + aEv) + (f2){aD2, aDn};
-        const float aD1 = __builtin_fmaf(t.aa.x, aD2, D[j].x);
-        const f2 w = aM * e;
-        accB = pfma(t.bm, w, accB);
-        const f2 wsh = (f2){w.y, wn};                         // w of the node after each of the pair's two
+        const bool more = j > 0;
+        if (more) { cur = ldrt(tb, j - 1); ecur = *(const f2 *)(ex + 2 * (j - 1)); }
+        SB;
+        const f2 w = aM * e; SB;
+        float aD2n = 0.f, aD1n = 0.f; f2 pren = (f2){0.f, 0.f}, iign = pren, aMn = pren;
+        if (more) { aD2n = __builtin_fmaf(t.aa.y, aDn, D[j - 1].y); SB; }
+        accB = pfma(t.bm, w, accB); SB;
+        if (more) { pren = M[j - 1] + aEv; SB; }
+        const f2 wsh = (f2){w.y, wn}; SB;                     // w of the node after each of the pair's two
+        if (more) { aD1n = __builtin_fmaf(t.aa.x, aD2n, D[j - 1].x); SB; }
         const f2 gi = I[j];
-        M[j] = pfma(t.mm, wsh, gi);
-        I[j] = pfma(t.im, wsh, t.ii * gi);
-        D[j] = t.dm * wsh;
-        aDn = aD1; wn = w.x;
+        M[j] = pfma(t.mm, wsh, gi); SB;
+        if (more) { iign = t.ii * I[j - 1]; SB; }
+        I[j] = pfma(t.im, wsh, iig); SB;
+        if (more) { aMn = pren + (f2){aD2n, aDn}; SB; }
+        D[j] = t.dm * wsh; SB;
+        wn = w.x; aDn = aD1n; aM = aMn; iig = iign;
       }
+#undef SB
       xB = accB.x + accB.y;
       xN = ploop * nN; xJ = ploop * nJ; xC = ploop * xC;
     }

@@ -337,7 +337,11 @@ void launch_msv(const MsvArgs &a0, hipStream_t st, int lds_pad)
   static const bool allow_whole = !(sw_get("ITSX_MSV_WHOLE") && atoi(sw_get("ITSX_MSV_WHOLE")) == 0);
   const int need = (a.Lcap - 1 + 15) / 16;
   a.wtl = (allow_whole && need > MSV_WT && need <= 37) ? need : MSV_WT;
-  const size_t lds = std::max<size_t>((size_t)lds_pad, (size_t)a.wtl * 256 * sizeof(uint32_t));
+  // (a Backward chain walks a few blocks of its read through one to eight profiles: it takes its words from memory as it goes, a dword
+  // every 16 rows -- the whole read in LDS first was 37 gathers per chain for ~6 words used, and 37 KB per block held a CU to 4 blocks)
+  static const bool bwd_whole = sw_get("ITSX_MSV_BWD_WHOLE") && atoi(sw_get("ITSX_MSV_BWD_WHOLE")) != 0;
+  if (a.share == 2 && !bwd_whole) a.wtl = MSV_WT;
+  const size_t lds = std::max<size_t>((size_t)lds_pad, (a.share == 2 && !bwd_whole) ? 0 : (size_t)a.wtl * 256 * sizeof(uint32_t));
   if (a.share == 2) hipLaunchKernelGGL(k_msv_bwd, grid, dim3(256), lds, st, a);
   else if (a.share) hipLaunchKernelGGL(k_msv<true>, grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL(k_msv<false>, grid, dim3(256), lds, st, a);

@@ -3061,6 +3061,7 @@ static int search_chunk(itsx_ctx *ctx, int ci, int32_t u0, int32_t U, int Lcap, 
             MsvArgs c = a;
             c.sorted_uniq = ctx->sh_border.p + cb0; c.U = 0; c.res = nullptr;
             c.k0 = (int32_t)(k0 - cb0); c.k1 = (int32_t)(k1 - cb0); c.pfirst = pa; c.plast = pb; c.share = 2;
+            if (sw_get("ITSX_TEST_HOOKS") && sw_get("ITSX_PASSA_DBG")) c.sl.dbg = atoi(sw_get("ITSX_PASSA_DBG"));
             c.sl.src = ctx->sh_rsrc.p + cb0; c.sl.mask = ctx->sh_rmask.p + cb0; c.sl.node0 = ctx->sh_rnode0.p + cb0; c.sl.endrow = ctx->sh_bsteps.p + cb0;
             c.sl.slots = gslots; c.sl.node_base = b.gnode0; c.sl.p0 = pa; c.sl.Pb = pb - pa; c.sl.depth = d; c.sl.logB = ctx->share_logB;
             const int64_t t2 = ((int64_t)(k1 - k0) + 255) / 256;

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, 6) k_msv_bwd(MsvArgs a)
   if (whole) for (int j = 0; j < a.wtl; j++) wst[j * 256 + threadIdx.x] = (j < nw) ? wp[j] : 0u;
   int nsteps = mysteps;
   for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(nsteps, d, 64); nsteps = o > nsteps ? o : nsteps; }
-  nsteps = uni(nsteps);
+  nsteps = (a.sl.dbg & 32) ? 0 : uni(nsteps);                // (diagnostic bit, ITSX_TEST_HOOKS=1 ITSX_PASSA_DBG=32: no rows)
   const int rd = a.sl.depth, logB = a.sl.logB;
   const int A = (L + (1 << logB) - 1) >> logB;
   const int top = (A - rd) << logB;                          // the row the chain's state stands after (virtual past L when rd = 0)

@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 def tot(name):
     r = [x for x in rows if name in x["Kernel_Name"]]
     return len(r), sum(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in r) / 1e6
-print("dbg", sys.argv[2], "k_bwd_bound n %d %.1f ms" % tot("k_bwd_bound"), "| k_fwd_bound n %d %.1f ms" % tot("k_fwd_bound"), flush=True)
+print("dbg", sys.argv[2], "k_bwd_bound n %d %.1f ms" % tot("k_bwd_bound"), "| k_fwd_bound n %d %.1f ms" % tot("k_fwd_bound"), "| k_msv_bwd n %d %.1f ms" % tot("k_msv_bwd"), "| k_msv< n %d %.1f ms" % tot("k_msv<"), flush=True)
 PY
 done
 rm -rf $out/trace

@@ -178,17 +178,12 @@ def run(pairs, array_path=True, stream=False, check=False):
         note("staged run done: %.2f s" % total)
         if stream:
             eng.close()
-            # (ITSX_PAIRED_SYNC_ARMS=spin,block: the streamed leg once per way of waiting, the last one kept; a leg that does not end is
-            # reported by every thread's stack after two minutes)
-            arms = [a for a in os.environ.get("ITSX_PAIRED_SYNC_ARMS", "").split(",") if a]
+            # (a leg that does not end is reported by every thread's stack after two minutes)
             import faulthandler
-            for arm in arms or [None]:
-                if arm is not None:
-                    os.environ["ITSX_SYNC"] = arm
-                faulthandler.dump_traceback_later(120, exit=True)
-                streamed, (s1, s2) = stream_leg(paths, hmm, tmp)
-                faulthandler.cancel_dump_traceback_later()
-                note("streamed run done (%s): %.2f s  %s" % (arm or os.environ.get("ITSX_SYNC", "default"), streamed["s_total"], json.dumps(streamed)[:300]))
+            faulthandler.dump_traceback_later(120, exit=True)
+            streamed, (s1, s2) = stream_leg(paths, hmm, tmp)
+            faulthandler.cancel_dump_traceback_later()
+            note("streamed run done: %.2f s" % streamed["s_total"])
             streamed["pairs_per_s_file_to_file"] = round(n / streamed["s_total"])
             if check:
                 for a, b in ((o1, s1), (o2, s2)):

@@ -1751,7 +1751,7 @@ static int build_share(itsx_ctx *ctx)
   // (a lazy search: the Forward pass's states, up to 48 GB (in the DP slab's memory: below) and a third of what is free; otherwise only the MSV filter shares, its
   // states are a fifth the size, and the full table's rows and slabs want the memory: up to 8 GB and an eighth of what is free)
   const bool fwd_too = ctx->lazy;
-  double gb = fwd_too ? (two ? 72.0 : 48.0) : 8.0;
+  double gb = fwd_too ? (two ? 76.0 : 48.0) : 8.0;
   {
     size_t fr = 0, tot = 0;
     const double held = (double)ctx->w_slab.cap * sizeof(float) + (double)ctx->sh_mslots.cap * sizeof(uint4);
@@ -1769,7 +1769,9 @@ static int build_share(itsx_ctx *ctx)
   // ... and no more than a job of this size needs: a quarter of all its states at a time still gives every (batch, depth) launch
   // thousands of waves, and device memory is not free to get (20-40 ms per GB in a fresh context: a streamed file's chunks each bring
   // their own -- round 5's first streamed run spent 5 s in hipMalloc for slots its 1.3 M-read chunks filled to a tenth)
-  if (!sw_get("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)((int64_t)NN + NG) * state_b * (double)P / (double)(1ull << 30) / 4.0));
+  // (a quarter and a twentieth: the groups a batch is made of do not fill four exact quarters, and a fifth batch with the 2 % that are left
+  // over is thirty launches of a few thousand waves -- 39 ms of pass A and 20 ms of the filter at 10 M reads for 15 ms' worth of rows)
+  if (!sw_get("ITSX_SHARE_GB")) gb = std::min(gb, std::max(1.0, (double)((int64_t)NN + NG) * state_b * (double)P / (double)(1ull << 30) / 3.8));
   // (in steps of half a GB: a budget that follows the free memory byte by byte made every search of a warm context ask for a slab a few
   // KB larger than the one it held -- 20 GB freed and allocated again per search)
   if (gb > 1.0) gb = floor(gb * 2.0) / 2.0;

@@ -143,8 +143,10 @@ typedef struct {
   float   join_maxdiff;      float ms_bwd_bound;        /* the Backward chains' kernel time (part of ms_bound_kernel) */
   /* the top-up round of itsx_search_finalize (round 6): pairs it evaluated -- the best-bound unevaluated pairs of the profiles with
    * undecided rows, as many as those rows need for the lower bound on domZ to decide them -- and its time (part of ms_finalize);
-   * n_lazy_completed stays 0 when it settles everything */
-  int64_t n_lazy_topup;      float ms_lazy_topup;       int32_t pad6;
+   * n_lazy_completed stays 0 when it settles everything.  ms_lazy_topup_stages = the part of ms_lazy_topup spent in the domain pipeline:
+   * that part is ALSO accumulated into ms_filters / ms_domains, like the stages itsx_lazy_complete re-runs (it took the place of a
+   * padding word: the structure's size and every other offset are unchanged) */
+  int64_t n_lazy_topup;      float ms_lazy_topup;       float ms_lazy_topup_stages;
 } itsx_stats;
 
 int         itsx_abi_version(void);

@@ -57,7 +57,7 @@ STATS_FIELDS = [("n_reads", "<i8"), ("n_unique", "<i8"), ("n_dropped_short", "<i
                 ("bound_rows_full", "<i8"), ("n_share_helpers", "<i8"), ("share_mismatch", "<i8"), ("ms_share_build", "<f4"), ("share_frac", "<f4"),
                 ("two_sided", "<i4"), ("n_bwd_launches", "<i4"), ("n_joined", "<i8"), ("bwd_chains", "<i8"), ("gamma_nodes", "<i8"), ("bwd_rows", "<i8"),
                 ("two_fwd_rows", "<i8"), ("two_bwd_rows", "<i8"), ("two_rows_full", "<i8"), ("join_maxdiff", "<f4"), ("ms_bwd_bound", "<f4"),
-                ("n_lazy_topup", "<i8"), ("ms_lazy_topup", "<f4"), ("pad6", "<i4")]
+                ("n_lazy_topup", "<i8"), ("ms_lazy_topup", "<f4"), ("ms_lazy_topup_stages", "<f4")]
 STATS_DTYPE = np.dtype(STATS_FIELDS, align=True)
 
 # every symbol include/itsx_hip.h declares

@@ -1928,7 +1928,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   ctx->domz_ub.assign((size_t)P * ctx->S, 0);
   if (ctx->compact_rows)                    // a full table of an earlier search (80 B x ~130 per representative) goes back to the device
     for (auto &b : ctx->dom_bufs) if (b && b->cap * sizeof(itsx_domain) > ((size_t)256 << 20)) b->release();
-  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.lazy_bound_maxdiff = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0; S.n_lazy_topup = 0; S.ms_lazy_topup = 0;
+  S.lazy = ctx->lazy; S.n_lazy_evaluated = S.n_lazy_round1 = S.n_lazy_pending = S.n_lazy_reruns = 0; S.n_lazy_completed = S.n_lazy_completed_profiles = S.n_lazy_pending_profiles = 0; S.ms_lazy_complete = 0; S.lazy_bound_maxdiff = 0; S.ms_bound_kernel = S.ms_lazy_select = 0; S.bound_rows = 0; S.n_bound_launches = 0; S.n_lazy_topup = 0; S.ms_lazy_topup = 0; S.ms_lazy_topup_stages = 0;
   if (ctx->compact_rows && U > 0) {
     ctx->compact_zmax = 1e9; ctx->compact_dome_min = 1e-2;          // hmmsearch's --domE is 10 unless given; 1e9 reported targets per profile is a lot of data
     if (const char *e = sw_get("ITSX_COMPACT_ZMAX")) ctx->compact_zmax = std::max(1.0, atof(e));
@@ -3483,7 +3483,7 @@ static int lazy_topup(itsx_ctx *ctx, double domE, bool *ran)
   sub.pairs = ctx->l_pairs.p; sub.pout = ctx->d_pout.p; sub.d_seg_start = ctx->l_seg.p;
   const int32_t *d_sorted = (ctx->share_on ? ctx->sh_order.p : ctx->d_sorted_uniq.p) + tu.u0;
   ctx->trace_u0 = tu.u0;
-  { const int rc = domain_pipeline(ctx, sub, d_sorted, ctx->T, ctx->sF1, ctx->sF3, nullptr); if (rc != ITSX_OK) return rc; }
+  { StageTimer tp(st); const int rc = domain_pipeline(ctx, sub, d_sorted, ctx->T, ctx->sF1, ctx->sF3, nullptr); if (rc != ITSX_OK) return rc; S.ms_lazy_topup_stages += tp.stop(); }
   // the bounds after the round: reported among the evaluated pairs below, those + the pairs still not evaluated above
   std::vector<int32_t> dz32((size_t)P * ctx->S, 0);
   HIPCHK(hipMemcpyAsync(dz32.data(), ctx->d_domz32.p, dz32.size() * 4, hipMemcpyDeviceToHost, st));

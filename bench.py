@@ -456,23 +456,31 @@ def main():
         if err is not None:
             raise err
 
+    calls = {}                                        # wall time of each engine call of a step, as the host sees it (config.host_calls_ms)
+
+    def timed_call(name, fn):
+        t = time.perf_counter()
+        r = fn()
+        calls[name] = calls.get(name, 0.0) + (time.perf_counter() - t) * 1e3
+        return r
+
     def step(from_host=False):
         def group():
             if from_host:
-                eng.set_reads_buffer(blob, offs)     # staged upload + device packing
+                timed_call("set_reads", lambda: eng.set_reads_buffer(blob, offs))     # staged upload + device packing
             else:
-                eng.set_reads_device(d_blob.data_ptr(), offs, keep=d_blob)     # device packing of the resident text
+                timed_call("set_reads", lambda: eng.set_reads_device(d_blob.data_ptr(), offs, keep=d_blob))     # device packing of the resident text
             if args.cluster_id < 1.0:
-                eng.cluster(args.cluster_id, strand_both=True)
+                timed_call("cluster", lambda: eng.cluster(args.cluster_id, strand_both=True))
             else:
-                eng.derep(strand_both=True, minseqlength=1)
+                timed_call("derep", lambda: eng.derep(strand_both=True, minseqlength=1))
         guarded(group)
         g = global_derep(eng, n_local, cdev) if (use_dist and args.global_derep) else None
-        search = lambda: eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
+        search = lambda: timed_call("search", lambda: eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6))
         guarded(search)
         if not use_dist:
-            eng.finalize(domE=10.0)                   # (a lazy search with undecided rows repeats itself in full in here)
-            return [eng.trim_coords(lp, rp)]          # (start, stop, tlen, index) per read, on the host
+            timed_call("finalize", lambda: eng.finalize(domE=10.0))                   # (a lazy search with undecided rows repeats itself in full in here)
+            return [timed_call("trim_coords", lambda: eng.trim_coords(lp, rp))]          # (start, stop, tlen, index) per read, on the host
         # N > 1: the two exchanges run on the engine's own device buffers (RCCL over xGMI), nothing bounces through numpy
         tc = time.perf_counter()
         # hmmsearch's domZ is a count over the WHOLE data set (after a lazy search: its bounds); thresholds; a full search on
@@ -513,6 +521,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     comm["allreduce_ms"] = comm["gather_ms"] = 0.0
+    calls.clear()
     t0 = time.perf_counter()
     acc = {}
     out = None
@@ -525,6 +534,7 @@ def main():
                 acc[k] = acc.get(k, 0.0) + v
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0               # this rank's own K steps (the gather's wait for slower ranks included)
+    host_calls_ms = {k: round(v / max(args.steps, 1), 1) for k, v in calls.items()}     # (before the extra legs below add to `calls`)
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -811,7 +821,9 @@ def main():
             "stage_overlap": {"top_level_ms": round((sum(acc.get(k, 0.0) for k in ("ms_pack", "ms_derep", "ms_msv", "ms_filters", "ms_domains", "ms_finalize", "ms_cluster", "ms_merge"))
                                                      - acc.get("ms_lazy_complete", 0.0) - acc.get("ms_lazy_topup_stages", 0.0)) / K, 1),
                               "ms_per_step": round(dt / args.steps * 1e3, 1),
-                              "note": "top_level_ms = ms_pack + ms_derep + ms_msv + ms_filters + ms_domains + ms_finalize - ms_lazy_complete - ms_lazy_topup_stages (both "
+                              "host_calls_ms": host_calls_ms,
+                              "note": "host_calls_ms = wall time of each engine call of a step as the host sees it (they add up to ms_per_step: what the stages' own "
+                                      "timers leave out is inside set_reads / trim_coords -- offsets in, coordinates out); top_level_ms = ms_pack + ms_derep + ms_msv + ms_filters + ms_domains + ms_finalize - ms_lazy_complete - ms_lazy_topup_stages (both "
                                       "counted in ms_finalize and, through the stages they re-run, in ms_msv / ms_filters / ms_domains); all other stage_ms entries are nested in these; the "
                                       "difference to ms_per_step is host time between the stages"},
             "kernels": kernel_table,

@@ -1237,9 +1237,9 @@ static int build_unique_lists(itsx_ctx *ctx)
     DBuf<int32_t> &hist = ctx->w_hist, &cursor = ctx->w_cursor, &tmp2 = ctx->w_tmp2;
     HIPCHK(hist.alloc(lcap)); HIPCHK(cursor.alloc(lcap)); HIPCHK(tmp2.alloc((size_t)scan_tmp_elems(lcap)));
     HIPCHK(hipMemsetAsync(hist.p, 0, lcap * sizeof(int32_t), ctx->st));
-    launch_len_hist(U, ctx->d_seed_read.p, ctx->rd.len, hist.p, lcap, ctx->st);
+    launch_len_hist(U, ctx->d_seed_read.p, ctx->rd.len, hist.p, lcap, ctx->st, ctx->Lmax + 1);
     launch_exclusive_scan(hist.p, cursor.p, lcap, tmp2.p, ctx->st);
-    launch_len_scatter(U, ctx->d_seed_read.p, ctx->rd.len, cursor.p, lcap, ctx->d_sorted_uniq.p, ctx->st);
+    launch_len_scatter(U, ctx->d_seed_read.p, ctx->rd.len, cursor.p, lcap, ctx->d_sorted_uniq.p, ctx->st, ctx->Lmax + 1);
     launch_fill_ulen(U, ctx->d_sorted_uniq.p, ctx->d_seed_read.p, ctx->rd.len, ctx->d_ulen.p, ctx->st);
     HIPCHK(hipStreamSynchronize(ctx->st));
   }

@@ -24,9 +24,9 @@ void launch_table_resolve(const ReadsDev &rd, const uint64_t *hf, const int32_t 
                           const int32_t *sample = nullptr);
 void launch_uniques(int64_t n, const int32_t *rep_of, const int32_t *seed_rank, int32_t *uniq_of, int32_t *seed_read,
                     int32_t *abundance, hipStream_t st);
-void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *hist, int32_t lcap, hipStream_t st);
+void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *hist, int32_t lcap, hipStream_t st, int32_t nb = 0 /*longest read + 1, if known*/);
 void launch_len_scatter(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *cursor, int32_t lcap,
-                        int32_t *sorted_uniq, hipStream_t st);
+                        int32_t *sorted_uniq, hipStream_t st, int32_t nb = 0);
 
 void launch_region_keys(const ReadsDev &rd, const RegionRec *regions, int64_t nr, const PairRec *pairs, const int32_t *sorted_uniq,
                         const int32_t *seed_read, unsigned long long *keys, int32_t *vals, uint64_t mask, uint32_t *slot_of, hipStream_t st);

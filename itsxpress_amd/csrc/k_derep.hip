@@ -236,6 +236,45 @@ __global__ void __launch_bounds__(256) k_len_hist(int32_t U, const int32_t *__re
     }
   }
 }
+// The same two steps for read sets whose longest read is short enough for a block to keep its own counters in LDS (every amplicon set:
+// the bench's lengths spread over 281 values, so a wave met ~57 distinct ones and the kernels above fell back to nearly one global atomic
+// per lane on a few hundred hot addresses: 5.4 ms each per 6 M representatives).  A block takes LEN_TILE consecutive representatives:
+// counts them by length in LDS, then touches global memory once per (block, distinct length).  SCATTER: the block reserves its range of
+// every length with that one atomic and ranks its members in LDS (the order inside a length is as arbitrary as above).
+constexpr int LEN_TILE = 4096;
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_len_bins(int32_t U, const int32_t *__restrict__ seed_read, const int32_t *__restrict__ len,
+                                                  int32_t *__restrict__ hist_or_cursor, int32_t nb, int32_t *__restrict__ sorted_uniq)
+{
+  extern __shared__ int32_t lds_bins[];                    // cnt[nb] (+ base[nb] when scattering)
+  int32_t *cnt = lds_bins, *base = lds_bins + nb;
+  for (int b = threadIdx.x; b < nb; b += 256) cnt[b] = 0;
+  __syncthreads();
+  const int32_t u0 = blockIdx.x * LEN_TILE, u1 = min(U, u0 + LEN_TILE);
+  int32_t myL[LEN_TILE / 256];
+#pragma unroll
+  for (int k = 0; k < LEN_TILE / 256; k++) {
+    const int32_t u = u0 + k * 256 + (int32_t)threadIdx.x;
+    int L = -1;
+    if (u < u1) { L = len[seed_read[u]]; if (L >= nb) L = nb - 1; atomicAdd(&cnt[L], 1); }
+    myL[k] = L;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    const int32_t c = cnt[b];
+    if (c) {
+      const int32_t g = atomicAdd(&hist_or_cursor[b], c);
+      if (SCATTER) { base[b] = g; cnt[b] = 0; }
+    }
+  }
+  if (!SCATTER) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < LEN_TILE / 256; k++) {
+    const int L = myL[k];
+    if (L >= 0) sorted_uniq[base[L] + atomicAdd(&cnt[L], 1)] = u0 + k * 256 + (int32_t)threadIdx.x;
+  }
+}
 __global__ void __launch_bounds__(256) k_len_scatter(int32_t U, const int32_t *__restrict__ seed_read, const int32_t *__restrict__ len,
                                                      int32_t *__restrict__ cursor, int32_t lcap, int32_t *__restrict__ sorted_uniq)
 {
@@ -407,9 +446,14 @@ void launch_uniques(int64_t n, const int32_t *rep_of, const int32_t *seed_rank, 
 {
   hipLaunchKernelGGL(k_uniques, dim3(grid_for(n)), dim3(256), 0, st, n, rep_of, seed_rank, uniq_of, seed_read, abundance);
 }
-void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *hist, int32_t lcap, hipStream_t st)
+// nb = longest read + 1 when the caller knows it (0: unknown): up to LEN_LDS_BINS lengths the blocks count in LDS
+constexpr int LEN_LDS_BINS = 8192;
+void launch_len_hist(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *hist, int32_t lcap, hipStream_t st, int32_t nb)
 {
-  hipLaunchKernelGGL(k_len_hist, dim3(grid_for(U)), dim3(256), 0, st, U, seed_read, len, hist, lcap);
+  if (nb > 0 && nb <= LEN_LDS_BINS && nb <= lcap)
+    hipLaunchKernelGGL(k_len_bins<false>, dim3((unsigned)((U + LEN_TILE - 1) / LEN_TILE)), dim3(256), (size_t)nb * 4, st, U, seed_read, len, hist, nb, nullptr);
+  else
+    hipLaunchKernelGGL(k_len_hist, dim3(grid_for(U)), dim3(256), 0, st, U, seed_read, len, hist, lcap);
 }
 void launch_region_keys(const ReadsDev &rd, const RegionRec *regions, int64_t nr, const PairRec *pairs, const int32_t *sorted_uniq,
                         const int32_t *seed_read, unsigned long long *keys, int32_t *vals, uint64_t mask, uint32_t *slot_of, hipStream_t st)
@@ -431,9 +475,12 @@ void launch_region_upos_follow(int64_t nr, const int32_t *rep_region, const int3
   hipLaunchKernelGGL(k_region_upos_follow, dim3(grid_for(nr)), dim3(256), 0, st, nr, rep_region, is_uniq, upos);
 }
 void launch_len_scatter(int32_t U, const int32_t *seed_read, const int32_t *len, int32_t *cursor, int32_t lcap,
-                        int32_t *sorted_uniq, hipStream_t st)
+                        int32_t *sorted_uniq, hipStream_t st, int32_t nb)
 {
-  hipLaunchKernelGGL(k_len_scatter, dim3(grid_for(U)), dim3(256), 0, st, U, seed_read, len, cursor, lcap, sorted_uniq);
+  if (nb > 0 && nb <= LEN_LDS_BINS && nb <= lcap)
+    hipLaunchKernelGGL(k_len_bins<true>, dim3((unsigned)((U + LEN_TILE - 1) / LEN_TILE)), dim3(256), (size_t)nb * 8, st, U, seed_read, len, cursor, nb, sorted_uniq);
+  else
+    hipLaunchKernelGGL(k_len_scatter, dim3(grid_for(U)), dim3(256), 0, st, U, seed_read, len, cursor, lcap, sorted_uniq);
 }
 
 }  // namespace itsx

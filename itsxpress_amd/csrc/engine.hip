@@ -838,15 +838,36 @@ static int pack_and_upload(itsx_ctx *ctx, const char *view = nullptr, const uint
   ctx->dev_bases = dev_raw;
   ctx->bases_view = dev_raw ? nullptr : (view ? view : ctx->h_bases.data());
   const char *bases = ctx->bases_view;
-  ctx->h_len.resize((size_t)n); ctx->h_woff.assign((size_t)n + 1, 0);
+  ctx->h_len.resize((size_t)n); ctx->h_woff.resize((size_t)n + 1);
+  ctx->h_woff[0] = 0;
   int Lmax = 0;
-  for (int64_t r = 0; r < n; r++) {
-    const int64_t L = ctx->h_off[r + 1] - ctx->h_off[r];
-    if (L < 0) SET_ERR(ctx, ITSX_E_ARG, "read offsets must be non-decreasing");
-    if (L > 65535) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "reads longer than 65535 bases are not supported");
-    ctx->h_len[r] = (int32_t)L;
-    Lmax = std::max(Lmax, (int)L);
-    ctx->h_woff[r + 1] = ctx->h_woff[r] + std::max<int64_t>(1, (L + 15) / 16);
+  {   // lengths, word offsets (a running sum: per thread over its share of the reads, then shifted by the shares before it), longest read
+    const int T = n >= (1 << 20) ? std::max(1, std::min(8, itsx_io::io_threads())) : 1;
+    std::vector<int64_t> wsum((size_t)T + 1, 0); std::vector<int> lmx((size_t)T, 0), bad((size_t)T, 0);
+    on_threads(T, [&](int t) {
+      const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+      int64_t w = 0; int mx = 0, b = 0;
+      for (int64_t r = lo; r < hi; r++) {
+        const int64_t L = ctx->h_off[r + 1] - ctx->h_off[r];
+        if (L < 0) b |= 1;
+        if (L > 65535) b |= 2;
+        ctx->h_len[r] = (int32_t)L;
+        mx = std::max(mx, (int)std::min<int64_t>(L, 1 << 30));
+        w += std::max<int64_t>(1, (L + 15) / 16);
+        ctx->h_woff[r + 1] = w;
+      }
+      wsum[(size_t)t + 1] = w; lmx[(size_t)t] = mx; bad[(size_t)t] = b;
+    });
+    int b = 0;
+    for (int t = 0; t < T; t++) { wsum[(size_t)t + 1] += wsum[(size_t)t]; Lmax = std::max(Lmax, lmx[(size_t)t]); b |= bad[(size_t)t]; }
+    if (b & 1) SET_ERR(ctx, ITSX_E_ARG, "read offsets must be non-decreasing");
+    if (b & 2) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "reads longer than 65535 bases are not supported");
+    if (T > 1)
+      on_threads(T, [&](int t) {
+        if (t == 0) return;
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T, add = wsum[(size_t)t];
+        for (int64_t r = lo; r < hi; r++) ctx->h_woff[r + 1] += add;
+      });
   }
   ctx->Lmax = Lmax;
   HIPCHK(hipSetDevice(ctx->device));
@@ -930,14 +951,22 @@ static int pack_and_upload(itsx_ctx *ctx, const char *view = nullptr, const uint
   return ITSX_OK;
 }
 
+// the caller's offsets, rebased to 0 (10 M reads: 80 MB -- copied and shifted in one pass by a few threads)
+static int64_t take_offsets(itsx_ctx *ctx, const int64_t *offsets, int64_t n)
+{
+  const int64_t base0 = offsets[0];
+  ctx->h_off.resize((size_t)n + 1);
+  int64_t *dst = ctx->h_off.data();
+  const int T = n >= (1 << 20) ? std::max(1, std::min(8, itsx_io::io_threads())) : 1;
+  on_threads(T, [&](int t) { for (int64_t r = (n + 1) * t / T, hi = (n + 1) * (t + 1) / T; r < hi; r++) dst[r] = offsets[r] - base0; });
+  return base0;
+}
 static int set_reads_impl(itsx_ctx *ctx, const char *bases, const int64_t *offsets, int64_t n, const char *names, const int64_t *name_offsets, bool borrow)
 {
   CTXCHK(ctx && offsets && n >= 0 && (bases || offsets[n] == offsets[0]));
   if (n >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
   ctx->N = n;
-  ctx->h_off.assign(offsets, offsets + n + 1);
-  const int64_t base0 = offsets[0];
-  for (auto &o : ctx->h_off) o -= base0;
+  const int64_t base0 = take_offsets(ctx, offsets, n);
   const char *view = nullptr;
   if (borrow) { itsx_io::Text().swap(ctx->h_bases); view = bases ? bases + base0 : ""; }
   else if (bases) ctx->h_bases.assign(bases + base0, (size_t)(offsets[n] - base0));
@@ -958,9 +987,7 @@ int itsx_set_reads_device(itsx_ctx *ctx, const void *d_bases, const int64_t *off
   CTXCHK(ctx && offsets && n >= 0 && (d_bases || offsets[n] == offsets[0]));
   if (n >= (1ll << 31) - 64) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "more than 2^31 reads in one context");
   ctx->N = n;
-  ctx->h_off.assign(offsets, offsets + n + 1);
-  const int64_t base0 = offsets[0];
-  for (auto &o : ctx->h_off) o -= base0;
+  const int64_t base0 = take_offsets(ctx, offsets, n);
   itsx_io::Text().swap(ctx->h_bases);
   ctx->h_names.clear();
   if (names && name_offsets) {
@@ -1955,7 +1982,23 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   std::vector<LenTables> lt((size_t)Lcap);
   std::vector<int32_t> tjb((size_t)Lcap, 0);
   std::vector<char> present((size_t)Lcap, 0);
-  for (int32_t u = 0; u < ctx->U; u++) present[ctx->h_len[ctx->h_seed_read[u]]] = 1;
+  int64_t cells_active = 0;                                 // residues of the active representatives (the filter's cell count, below)
+  {   // two gathers per representative from arrays the size of the read set: a few threads (10 M reads: 25 ms on one, the GPU idle)
+    const int32_t Ua = ctx->U, Uact = ctx->U_active;
+    const int Th = Ua >= (1 << 19) ? std::max(1, std::min(8, itsx_io::io_threads())) : 1;
+    std::vector<std::vector<char>> pres((size_t)Th); std::vector<int64_t> csum((size_t)Th, 0);
+    on_threads(Th, [&](int t) {
+      std::vector<char> &pr = pres[(size_t)t]; pr.assign((size_t)Lcap, 0);
+      int64_t c = 0;
+      for (int64_t u = (int64_t)Ua * t / Th, hi = (int64_t)Ua * (t + 1) / Th; u < hi; u++) {
+        const int32_t L = ctx->h_len[ctx->h_seed_read[(size_t)u]];
+        pr[(size_t)L] = 1;
+        if (u < Uact) c += L;
+      }
+      csum[(size_t)t] = c;
+    });
+    for (int t = 0; t < Th; t++) { cells_active += csum[(size_t)t]; for (int L = 0; L < Lcap; L++) present[(size_t)L] |= pres[(size_t)t][(size_t)L]; }
+  }
   for (int L = 0; L < Lcap; L++) {
     LenTables &t = lt[L]; memset(&t, 0, sizeof(t));
     if (L == 0) continue;
@@ -2010,8 +2053,7 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3)
   HIPCHK(ctx->d_domz32.alloc((size_t)P * ctx->S));
   HIPCHK(hipMemsetAsync(ctx->d_domz32.p, 0, (size_t)P * ctx->S * 4, st));
   {
-    int64_t cells = 0;
-    for (int32_t u = 0; u < U; u++) cells += (int64_t)ctx->h_len[ctx->h_seed_read[u]];
+    const int64_t cells = cells_active;
     int64_t msum = 0; for (auto &h : ctx->profs) msum += h.M;
     S.msv_cells = cells * msum;
     S.msv_rows = S.msv_rows_full = cells * P; S.bound_rows_full = 0; S.n_share_helpers = 0; S.share_mismatch = 0;

@@ -345,14 +345,19 @@ int itsx_search(itsx_ctx *ctx, double T, double F1, double F2, double F3);
  *   ITSX_ROWS_COMPACT  every pair is evaluated, only the rows that can still win that argmax once domZ is known are kept;
  *   ITSX_ROWS_LAZY     pairs that cannot win it are not evaluated past their Forward score (csrc/k_lazy.hip: a rigorous bound of
  *                      a pair's best domain score from its Forward score); coordinates are exactly those of the other modes.
- * In the last two the row table / domtbl.txt are refused.  mode -1 (the default) reads the environment at every search:
- * ITSX_ROWS=full|compact|lazy, or ITSX_COMPACT_ROWS=1.
+ * In the last two the row table / domtbl.txt are refused -- unless the caller asks for the KEPT rows: itsx_set_kept_rows(ctx, 1)
+ * makes itsx_num_domains / itsx_get_domains / itsx_write_domtbl serve, after itsx_search_finalize, the WINNERS among the rows the context
+ * holds: per target and 2-character profile prefix the reported row ItsPosition's argmax ends up with -- a row of the full table, field
+ * for field, in --domtblout order.  ItsPosition.parse (SeqSample.py:400-461) reads the same dictionary out of that domtbl.txt as out of
+ * the full one (itsxpress_amd/SeqSample.py: ITSXPRESS_DOMTBL=winners); the '#' / 'of' columns count the listed rows of the target.
+ * mode -1 (the default) reads the environment at every search: ITSX_ROWS=full|compact|lazy, or ITSX_COMPACT_ROWS=1.
  * After a LAZY search hmmsearch's domZ is known by bounds only: itsx_get_domz / itsx_set_domz / itsx_domz_device move
  * itsx_domz_count() = 2 x n_samples x n_profiles counters (lower bounds, then upper bounds; a multi-rank driver sums both).
  * itsx_search_finalize decides every row both bounds decide alike.  itsx_lazy_pending() = rows left undecided that could change
  * a coordinate (itsx_trim_coords refuses while it is positive): see itsx_lazy_complete. */
 enum { ITSX_ROWS_FULL = 0, ITSX_ROWS_COMPACT = 1, ITSX_ROWS_LAZY = 2 };
 int itsx_set_rows_mode(itsx_ctx *ctx, int mode);
+int itsx_set_kept_rows(itsx_ctx *ctx, int on);
 int64_t itsx_lazy_pending(const itsx_ctx *ctx);
 /* The profiles of the undecided rows (flags[n_profiles], 1 = some row of this profile is pending), and the cure: itsx_lazy_complete
  * sends EVERY pair of the flagged profiles through the domain pipeline, after which their counters are exact (lower == upper) and

@@ -61,6 +61,10 @@ def _fast_from_env():
     return os.environ.get("ITSXPRESS_ARRAYS", "").strip() not in ("", "0")
 
 
+def _winners_from_env():
+    return os.environ.get("ITSXPRESS_DOMTBL", "").strip().lower() == "winners"
+
+
 class SeqSample:
     """Base class: dereplicate -> search, as the reference's SeqSample (SeqSample.py:18-225)."""
 
@@ -76,6 +80,7 @@ class SeqSample:
         self._engine: Optional[Engine] = None
         self.gpus: Optional[int] = None          # None: ITSXPRESS_GPUS (default 1)
         self.fast: Optional[bool] = None         # None: ITSXPRESS_ARRAYS (default off)
+        self.domtbl: Optional[str] = None        # None: ITSXPRESS_DOMTBL ("winners": files as ever, domtbl.txt = the rows that can win)
 
     # -- engine plumbing -------------------------------------------------------------
     @property
@@ -189,19 +194,26 @@ class SeqSample:
                 eng.derep(strand_both=False, minseqlength=0)
             eng.load_profiles(path=hmmfile)
             fast = self._is_fast()
-            # file-compatible: every domain row stays (domtbl.txt); arrays mode: the lazy domain stage, coordinates only
+            dt = getattr(self, "domtbl", None)
+            winners = (not fast) and ((dt or "").lower() == "winners" if dt is not None else _winners_from_env())
+            # file-compatible: every domain row stays (domtbl.txt); arrays mode: the lazy domain stage, coordinates only;
+            # ITSXPRESS_DOMTBL=winners: the files of the first with the search of the second -- domtbl.txt holds, per target and side,
+            # the row ItsPosition.parse ends up with: the reference's own parser reads the same dictionary out of it as out of
+            # hmmsearch's full table (SeqSample.py:400-461 keeps the first strictly greatest score)
             # (a streaming engine defers its work: asking it for a count would run the load stage apart from the search)
             nu = 0 if (fast or getattr(eng, "deferred", False)) else int(getattr(eng, "n_unique", 0) or 0)
-            if not fast and nu > 1000000:
+            if not fast and not winners and nu > 1000000:
                 logging.info("itsx_hip search: %d unique sequences in file-compatible mode -- every (sequence, profile) pair is evaluated and "
-                             "domtbl.txt gets about %d rows (~%.0f GB); ITSXPRESS_ARRAYS=1 keeps the tables in the engine, evaluates only the pairs that "
-                             "can win and gives the same trimmed reads several times faster (INTEGRATION.md 3b)", nu, nu * 136, nu * 136 * 200 / 1e9)
-            eng.set_rows_mode("lazy" if fast else "full")
+                             "domtbl.txt gets about %d rows (~%.0f GB); ITSXPRESS_DOMTBL=winners writes only the rows ItsPosition can end up with "
+                             "(same files, same trimmed reads, the search several times faster), ITSXPRESS_ARRAYS=1 keeps the tables in the engine "
+                             "altogether (INTEGRATION.md 3b)", nu, nu * 136, nu * 136 * 200 / 1e9)
+            eng.set_rows_mode("lazy" if (fast or winners) else "full")
             eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
             eng.finalize(domE=10.0)
             if fast:
                 self.dom_file = EngineTable(self.dom_file, eng, "domtbl")
             else:
+                eng.set_kept_rows(winners)
                 eng.write_domtbl(self.dom_file)
         except EngineError as e:
             logging.exception("Could not perform ITS identification with the HIP engine: %s", e)

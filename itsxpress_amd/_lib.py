@@ -83,7 +83,7 @@ EXPORTS = ["itsx_abi_version", "itsx_last_error", "itsx_create", "itsx_destroy",
            "itsx_merge_pairs_load_text", "itsx_merge_pair_index", "itsx_twriter_set_mode", "itsx_write_range",
            "itsx_keyset_create", "itsx_keyset_destroy", "itsx_keyset_size", "itsx_keyset_assign",
            "itsx_twriter_open", "itsx_twriter_text", "itsx_twriter_coords", "itsx_twriter_update", "itsx_twriter_close",
-           "itsx_lazy_pending_uniques", "itsx_set_partial_coords"]
+           "itsx_lazy_pending_uniques", "itsx_set_partial_coords", "itsx_set_kept_rows"]
 
 
 def lib():
@@ -143,6 +143,7 @@ def lib():
         "itsx_twriter_close": (i32, [vp, vp, vp]),
         "itsx_lazy_pending_uniques": (i32, [vp, vp]),
         "itsx_set_partial_coords": (i32, [vp, i32]),
+        "itsx_set_kept_rows": (i32, [vp, i32]),
         "itsx_unique_keys128": (i32, [vp, C.c_uint64, C.c_uint64, i64, vp]),
         "itsx_write_derep_arrays": (i32, [cp, cp, i64, vp, vp, vp, vp, vp, vp, vp, i64]),
         "itsx_write_domtbl_arrays": (i32, [cp, vp, i64, i64, vp, i32, vp, vp, vp, vp, vp, vp, vp]),

@@ -349,6 +349,7 @@ struct itsx_ctx {
 
   // ---- derep
   bool have_derep = false;
+  std::vector<int32_t> order_cache; bool order_cache_ok = false;      // cluster_order() of the current dereplication (uc.txt and rep.fa both ask)
   int derep_strand_both = 1;             // how the last itsx_derep / itsx_cluster matched (the cross-shard keys follow it)
   int32_t U = 0;
   int32_t U_active = 0;                  // uniques this context scores (all of them unless itsx_set_active_uniques narrowed it)
@@ -395,7 +396,7 @@ struct itsx_ctx {
   std::vector<int32_t> h_plist; DBuf<int32_t> d_plist;
   int64_t s_Uc = 0; int s_Lcap = 0;       // the last search's chunk size and length cap (the completion walks the same chunks)
   DBuf<float> l_fb; DBuf<uint32_t> l_b10; DBuf<uint8_t> l_done; DBuf<int32_t> l_flag, l_pos, l_scan, l_has; DBuf<unsigned long long> l_gtop, l_sure;
-  DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub; DBuf<int32_t> l_pflag; DBuf<uint8_t> l_uflag; bool partial_coords = false; std::vector<int32_t> lazy_pending_prof;
+  DBuf<PairRec> l_pairs; DBuf<int64_t> l_seg, l_zub; DBuf<int32_t> l_pflag; DBuf<uint8_t> l_uflag; bool partial_coords = false; bool kept_rows = false; std::vector<int32_t> lazy_pending_prof;
   std::vector<uint16_t> thr_memo; std::vector<char> thr_memo_have; double thr_memo_F1 = -1.0; int thr_memo_Ppad = 0;   // MSV thresholds by length, kept between searches
   DBuf<int32_t> w_coords4; DBuf<int64_t> w_keys128; DBuf<uint64_t> w_hf1, w_hr1;
   std::vector<int32_t> h_sorted_active;  // the length-sorted list the HMM stages walk (= h_sorted_uniq unless itsx_set_active_uniques narrowed it)
@@ -946,6 +947,7 @@ static int pack_and_upload(itsx_ctx *ctx, const char *view = nullptr, const uint
   ctx->rd.excoff = ctx->d_excoff.p; ctx->rd.exc = ctx->d_exc.p; ctx->rd.n = n;
   ctx->have_derep = ctx->have_search = ctx->have_final = false;
   ctx->stats.n_reads = n;
+  ctx->order_cache_ok = false;
   ctx->S = 1; ctx->sel_sample = -1; ctx->h_sample.clear(); ctx->h_usample.clear();      // a new read set is one sample until told otherwise
   ctx->stats.ms_pack = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
   return ITSX_OK;
@@ -1201,6 +1203,7 @@ int itsx_set_samples(itsx_ctx *ctx, const int32_t *sample_of_read, int32_t n_sam
   HIPCHK(hipSetDevice(ctx->device));
   ctx->have_derep = ctx->have_search = ctx->have_final = false;
   ctx->sel_sample = -1; ctx->h_usample.clear();
+  ctx->order_cache_ok = false;
   if (!sample_of_read || n_samples <= 1) { ctx->S = 1; ctx->h_sample.clear(); return ITSX_OK; }
   if ((int64_t)n_samples * std::max(ctx->P, 1) > (1ll << 28)) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "too many samples x profiles for one batch");
   for (int64_t r = 0; r < ctx->N; r++)
@@ -1217,6 +1220,7 @@ int itsx_select_sample(itsx_ctx *ctx, int32_t sample)
   CTXCHK(ctx);
   if (sample < -1 || sample >= ctx->S) SET_ERR(ctx, ITSX_E_ARG, "sample index out of range");
   ctx->sel_sample = sample;
+  ctx->order_cache_ok = false;
   return ITSX_OK;
 }
 int itsx_load_reads_files(itsx_ctx *ctx, const char *const *paths, int32_t n_paths, int64_t *n_reads_per_file)
@@ -1342,6 +1346,7 @@ int itsx_derep(itsx_ctx *ctx, int strand_both, int minseqlength, int64_t *n_uniq
   for (int64_t r = 0; r < n; r++) dropped += ctx->h_rep_of[r] < 0;
   ctx->stats.n_unique = U; ctx->stats.n_dropped_short = dropped;
   ctx->have_derep = true; ctx->have_search = ctx->have_final = false; ctx->clustered = false;
+  ctx->order_cache_ok = false;
   ctx->derep_strand_both = strand_both != 0;
   if (n_unique) *n_unique = U;
   return ITSX_OK;
@@ -1599,6 +1604,7 @@ int itsx_cluster(itsx_ctx *ctx, double id, int strand_both, int64_t *n_unique)
   ctx->stats.n_unique = ctx->U; ctx->stats.n_dropped_short = n - nk;
   ctx->stats.cl_windows = windows; ctx->stats.cl_cuts = cuts; ctx->stats.cl_alignments = (int64_t)naln; ctx->stats.cl_certified = (int64_t)nskip;
   ctx->have_derep = true; ctx->have_search = ctx->have_final = false; ctx->clustered = true;
+  ctx->order_cache_ok = false;
   if (ctx->U != ncent) SET_ERR(ctx, ITSX_E_DEVICE, "clustering bookkeeping mismatch (centroids " + std::to_string(ncent) + " vs uniques " + std::to_string(ctx->U) + ")");
   if (n_unique) *n_unique = ctx->U;
   return ITSX_OK;
@@ -3239,6 +3245,7 @@ int itsx_lazy_pending_profiles(const itsx_ctx *ctx, int32_t *flags)
   return ITSX_OK;
 }
 int itsx_set_partial_coords(itsx_ctx *ctx, int on) { CTXCHK(ctx); ctx->partial_coords = on != 0; return ITSX_OK; }
+int itsx_set_kept_rows(itsx_ctx *ctx, int on) { CTXCHK(ctx); if (ctx->kept_rows != (on != 0)) ctx->h_dom.clear(); ctx->kept_rows = on != 0; return ITSX_OK; }
 // flags[n_unique]: 1 where an undecided row could still change the representative's coordinates (the rows itsx_lazy_pending counts)
 int itsx_lazy_pending_uniques(itsx_ctx *ctx, uint8_t *flags)
 {
@@ -3626,7 +3633,9 @@ int itsx_search_finalize(itsx_ctx *ctx, double domE)
 static int fetch_domains(const itsx_ctx *cctx)
 {
   itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
-  if (ctx->compact_rows) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "the domain rows of this search were compacted (ITSX_COMPACT_ROWS=1): only coordinates are available, not the row table / domtbl.txt");
+  if (ctx->compact_rows && !ctx->kept_rows) SET_ERR(ctx, ITSX_E_UNSUPPORTED, "the domain rows of this search were compacted (ITSX_COMPACT_ROWS=1): only coordinates are available, not the row table / domtbl.txt (itsx_set_kept_rows(ctx, 1) serves the rows that were kept)");
+  if (ctx->compact_rows && !ctx->have_final) SET_ERR(ctx, ITSX_E_ARG, "the kept rows of a compact / lazy search are served after itsx_search_finalize");
+  if (ctx->lazy && ctx->lazy_pending > 0) SET_ERR(ctx, ITSX_E_ARG, "the kept rows of a lazy search are served once no row is undecided (itsx_lazy_pending)");
   if (!ctx->h_dom.empty()) return ITSX_OK;
   // domtblout order: profile, then target, then domain.  The device rows are grouped by profile already (not contiguously
   // across chunks), so: counting sort by profile, then every profile's rows are ordered on their own by a pool of threads.
@@ -3655,6 +3664,35 @@ static int fetch_domains(const itsx_ctx *cctx)
         return a.dom_idx < b.dom_idx;
       });
   });
+  if (ctx->compact_rows) {
+    // kept rows (itsx_set_kept_rows): a pair the lazy stage evaluated twice -- a top-up or completion round after round 1 / 2 -- left
+    // its rows twice, bit for bit the same; the table names every (profile, target, domain) once.  A row that is still undecided
+    // (dom_reported == 2: reported under the lower bound on domZ only) is one that cannot win -- it ranks below its group's best sure
+    // row, or it would have been settled (k_lazy_pending) -- and is left out like every other row that cannot
+    // ... and of the decided rows the table lists the WINNERS: per target and 2-character prefix the reported row with the largest rank
+    // key, the one ItsPosition.parse ends up with.  (What else is resident -- a round-1 row that a round-2 row outranked, a row that
+    // was best until a later batch -- depends on the order the batches ran in; the winners do not.)
+    std::vector<int8_t> cls((size_t)P, 0); std::vector<std::string> seen;
+    for (int p = 0; p < ctx->P; p++) {
+      const std::string pre = ctx->profs[(size_t)p].name.substr(0, 2);
+      size_t k = 0; while (k < seen.size() && seen[k] != pre) k++;
+      if (k == seen.size()) seen.push_back(pre);
+      cls[(size_t)p] = (int8_t)k;
+    }
+    const size_t ncls = std::max<size_t>(seen.size(), 1);
+    std::vector<unsigned long long> best((size_t)std::max(ctx->U, 1) * ncls, 0ull);
+    for (const auto &d : ctx->h_dom)
+      if (d.dom_reported == 1) { unsigned long long &b = best[(size_t)d.rep * ncls + (size_t)cls[(size_t)d.prof]]; b = std::max(b, rank_key(d)); }
+    size_t w = 0;
+    for (size_t r = 0; r < ctx->h_dom.size(); r++) {
+      const itsx_domain &d = ctx->h_dom[r];
+      if (d.dom_reported != 1 || rank_key(d) != best[(size_t)d.rep * ncls + (size_t)cls[(size_t)d.prof]]) continue;
+      if (w > 0 && ctx->h_dom[w - 1].prof == d.prof && ctx->h_dom[w - 1].rep == d.rep && ctx->h_dom[w - 1].dom_idx == d.dom_idx) continue;
+      if (w != r) ctx->h_dom[w] = d;
+      w++;
+    }
+    ctx->h_dom.resize(w);
+  }
   return ITSX_OK;
 }
 
@@ -4221,30 +4259,93 @@ int itsx_get_unique_seqs(itsx_ctx *ctx, char *bases, int64_t cap, int64_t *offse
 }
 
 // ------------------------------------------------------------------------------ writers
+// blocks of a text file formatted by a pool of threads while this thread writes the finished ones in order (a few blocks ahead at most);
+// false on a short write
+static bool write_blocks(FILE *f, size_t nb, const std::function<void(size_t, std::string &)> &format_block)
+{
+  const int T = (int)std::min<size_t>((size_t)itsx_io::io_threads(), std::max<size_t>(nb, 1));
+  bool io_ok = true;
+  if (T <= 1 || nb <= 1) {
+    std::string out;
+    for (size_t b = 0; b < nb; b++) { out.clear(); format_block(b, out); if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) io_ok = false; }
+  } else {
+    std::vector<std::string> blocks(nb);
+    std::vector<char> ready(nb, 0);
+    std::mutex mu; std::condition_variable cv;
+    size_t next = 0, written = 0;
+    const size_t ahead = (size_t)T * 4;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([&] {
+        for (;;) {
+          size_t b;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return next >= nb || next < written + ahead; });
+            if (next >= nb) return;
+            b = next++;
+          }
+          std::string out;
+          out.reserve(32768 * 200);
+          format_block(b, out);
+          { std::lock_guard<std::mutex> lk(mu); blocks[b].swap(out); ready[b] = 1; }
+          cv.notify_all();
+        }
+      });
+    for (size_t b = 0; b < nb; b++) {
+      std::string out;
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[b] != 0; }); out.swap(blocks[b]); }
+      if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) io_ok = false;
+      { std::lock_guard<std::mutex> lk(mu); written = b + 1; }
+      cv.notify_all();
+    }
+    for (auto &x : th) x.join();
+  }
+  return io_ok;
+}
+
 static std::string read_name(const itsx_ctx *ctx, int64_t r)
 {
   if (!ctx->h_names.empty()) return ctx->h_names[(size_t)r];
   char b[32]; snprintf(b, sizeof(b), "r%09lld", (long long)r); return b;
 }
 // clusters in vsearch's output order: abundance descending, ties by label
-static std::vector<int32_t> cluster_order(const itsx_ctx *ctx)
+static const std::vector<int32_t> &cluster_order(const itsx_ctx *cctx)
 {
+  itsx_ctx *ctx = const_cast<itsx_ctx *>(cctx);
+  if (ctx->order_cache_ok) return ctx->order_cache;
+  std::vector<int32_t> &ord = ctx->order_cache;
+  ord.clear();
+  ord.reserve((size_t)ctx->U);
   const int32_t sel = ctx->S > 1 ? ctx->sel_sample : -1;      // writers restricted to one sample of a batch
   if (ctx->clustered) {                  // --cluster_size: clusters are numbered as their centroids were created
-    std::vector<int32_t> ord;
-    ord.reserve((size_t)ctx->U);
     for (int32_t r : ctx->h_order) if (ctx->h_rep_of[r] == r) ord.push_back(ctx->h_uniq_of[r]);
+    ctx->order_cache_ok = true;
     return ord;
   }
-  std::vector<int32_t> ord;
-  ord.reserve((size_t)ctx->U);
   for (int32_t u = 0; u < ctx->U; u++) if (sel < 0 || ctx->usample(u) == sel) ord.push_back(u);
   std::vector<std::string> lab((size_t)ctx->U);
-  for (int32_t u = 0; u < ctx->U; u++) lab[u] = read_name(ctx, ctx->h_seed_read[u]);
-  std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+  const int T = ctx->U >= (1 << 17) ? std::max(1, std::min(16, itsx_io::io_threads())) : 1;
+  on_threads(T, [&](int t) { for (int64_t u = (int64_t)ctx->U * t / T, hi = (int64_t)ctx->U * (t + 1) / T; u < hi; u++) lab[(size_t)u] = read_name(ctx, ctx->h_seed_read[(size_t)u]); });
+  auto before = [&](int32_t a, int32_t b) {
     if (ctx->h_abund[a] != ctx->h_abund[b]) return ctx->h_abund[a] > ctx->h_abund[b];
     return strcmp(lab[a].c_str(), lab[b].c_str()) < 0;
-  });
+  };
+  // a stable sort in pieces (6 M labels of a 10 M-read sample: seconds on one thread): every thread orders its share, neighbouring
+  // shares are merged pairwise -- std::inplace_merge keeps equal elements in order, so the result is std::stable_sort's
+  const size_t n = ord.size();
+  std::vector<size_t> cut((size_t)T + 1);
+  for (int t = 0; t <= T; t++) cut[(size_t)t] = n * (size_t)t / (size_t)T;
+  on_threads(T, [&](int t) { std::stable_sort(ord.begin() + (ptrdiff_t)cut[(size_t)t], ord.begin() + (ptrdiff_t)cut[(size_t)t + 1], before); });
+  for (int w = 1; w < T; w *= 2) {
+    std::vector<int> lefts;
+    for (int t = 0; t + w < T; t += 2 * w) lefts.push_back(t);
+    on_threads((int)lefts.size(), [&](int k) {
+      const int t = lefts[(size_t)k];
+      std::inplace_merge(ord.begin() + (ptrdiff_t)cut[(size_t)t], ord.begin() + (ptrdiff_t)cut[(size_t)(t + w)], ord.begin() + (ptrdiff_t)cut[(size_t)std::min(T, t + 2 * w)], before);
+    });
+  }
+  ctx->order_cache_ok = true;
   return ord;
 }
 
@@ -4253,7 +4354,7 @@ int itsx_write_uc(const itsx_ctx *ctx, const char *path)
   CTXCHK(ctx && path && ctx->have_derep);
   FILE *f = fopen(path, "w");
   if (!f) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + path);
-  const std::vector<int32_t> ord = cluster_order(ctx);
+  const std::vector<int32_t> &ord = cluster_order(ctx);
   if (ctx->clustered) {
     // vsearch --cluster_size writes the S and H rows as the queries are processed, then one C row per cluster
     std::vector<int32_t> cno((size_t)ctx->U);
@@ -4270,22 +4371,48 @@ int itsx_write_uc(const itsx_ctx *ctx, const char *path)
     if (fclose(f) != 0 || bad) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
     return ITSX_OK;
   }
-  std::vector<std::vector<int64_t>> members((size_t)ctx->U);
-  for (int64_t r = 0; r < ctx->N; r++) { const int32_t u = ctx->h_uniq_of[r]; if (u >= 0 && ctx->h_rep_of[r] != r) members[u].push_back(r); }
-  for (size_t c = 0; c < ord.size(); c++) {
-    const int32_t u = ord[c]; const int64_t s = ctx->h_seed_read[u];
-    const std::string sl = read_name(ctx, s);
-    fprintf(f, "S\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_len[s], sl.c_str());
-    for (int64_t r : members[u])
-      fprintf(f, "H\t%zu\t%d\t100.0\t%c\t0\t0\t*\t%s\t%s\n", c, ctx->h_len[r], ctx->h_strand[r] < 0 ? '-' : '+', read_name(ctx, r).c_str(), sl.c_str());
+  // the members of every cluster in input order (a counting sort by representative), then blocks of clusters formatted by the I/O pool:
+  // the S row and the H rows of a cluster, cluster after cluster, then the C rows (10 M reads: 16 M lines)
+  std::vector<int64_t> mstart((size_t)ctx->U + 1, 0);
+  for (int64_t r = 0; r < ctx->N; r++) { const int32_t u = ctx->h_uniq_of[r]; if (u >= 0 && ctx->h_rep_of[r] != r) mstart[(size_t)u + 1]++; }
+  for (int32_t u = 0; u < ctx->U; u++) mstart[(size_t)u + 1] += mstart[(size_t)u];
+  std::vector<int64_t> member((size_t)mstart[(size_t)ctx->U]);
+  {
+    std::vector<int64_t> cur(mstart.begin(), mstart.end() - 1);
+    for (int64_t r = 0; r < ctx->N; r++) { const int32_t u = ctx->h_uniq_of[r]; if (u >= 0 && ctx->h_rep_of[r] != r) member[(size_t)cur[(size_t)u]++] = r; }
   }
-  for (size_t c = 0; c < ord.size(); c++) {
-    const int32_t u = ord[c];
-    fprintf(f, "C\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_abund[u], read_name(ctx, ctx->h_seed_read[u]).c_str());
-  }
+  const size_t BLK = 16384, nbc = (ord.size() + BLK - 1) / BLK;
+  auto append = [](std::string &out, const char *fmt, auto... args) {
+    char line[512];
+    const int len = snprintf(line, sizeof(line), fmt, args...);
+    if (len < 0) return;
+    if ((size_t)len < sizeof(line)) { out.append(line, (size_t)len); return; }
+    std::string big((size_t)len + 1, '\0');                  // (labels longer than the line buffer)
+    snprintf(&big[0], big.size(), fmt, args...);
+    out.append(big.data(), (size_t)len);
+  };
+  auto format_block = [&](size_t b, std::string &out) {
+    if (b < nbc) {
+      for (size_t c = b * BLK; c < std::min(ord.size(), (b + 1) * BLK); c++) {
+        const int32_t u = ord[c]; const int64_t s = ctx->h_seed_read[u];
+        const std::string sl = read_name(ctx, s);
+        append(out, "S\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_len[s], sl.c_str());
+        for (int64_t k = mstart[(size_t)u]; k < mstart[(size_t)u + 1]; k++) {
+          const int64_t r = member[(size_t)k];
+          append(out, "H\t%zu\t%d\t100.0\t%c\t0\t0\t*\t%s\t%s\n", c, ctx->h_len[r], ctx->h_strand[r] < 0 ? '-' : '+', read_name(ctx, r).c_str(), sl.c_str());
+        }
+      }
+    } else {
+      for (size_t c = (b - nbc) * BLK; c < std::min(ord.size(), (b - nbc + 1) * BLK); c++) {
+        const int32_t u = ord[c];
+        append(out, "C\t%zu\t%d\t*\t*\t*\t*\t*\t%s\t*\n", c, ctx->h_abund[u], read_name(ctx, ctx->h_seed_read[u]).c_str());
+      }
+    }
+  };
   // a truncated uc.txt would silently shorten Dedup.parse's matchdict (vsearch exits non-zero on a full disk)
+  const bool ok = write_blocks(f, 2 * nbc, format_block);
   const bool bad = ferror(f) != 0;
-  if (fclose(f) != 0 || bad) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
+  if (fclose(f) != 0 || bad || !ok) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
   return ITSX_OK;
 }
 
@@ -4300,14 +4427,19 @@ int itsx_write_rep_fasta(const itsx_ctx *cctx, const char *path)
   }
   FILE *f = fopen(path, "w");
   if (!f) SET_ERR(ctx, ITSX_E_IO, std::string("cannot write ") + path);
-  for (int32_t u : cluster_order(ctx)) {
-    const int64_t s = ctx->h_seed_read[u];
-    fprintf(f, ">%s\n", read_name(ctx, s).c_str());
-    const char *b = ctx->bases_view + ctx->h_off[s]; const int64_t L = ctx->h_len[s];
-    for (int64_t i = 0; i < L; i += 80) { fwrite(b + i, 1, (size_t)std::min<int64_t>(80, L - i), f); fputc('\n', f); }
-  }
+  const std::vector<int32_t> &ord = cluster_order(ctx);
+  const size_t BLK = 8192, nb = (ord.size() + BLK - 1) / BLK;
+  auto format_block = [&](size_t bk, std::string &out) {
+    for (size_t c = bk * BLK; c < std::min(ord.size(), (bk + 1) * BLK); c++) {
+      const int64_t s = ctx->h_seed_read[ord[c]];
+      out.push_back('>'); out.append(read_name(ctx, s)); out.push_back('\n');
+      const char *b = ctx->bases_view + ctx->h_off[s]; const int64_t L = ctx->h_len[s];
+      for (int64_t i = 0; i < L; i += 80) { out.append(b + i, (size_t)std::min<int64_t>(80, L - i)); out.push_back('\n'); }
+    }
+  };
+  const bool ok = write_blocks(f, nb, format_block);
   const bool bad = ferror(f) != 0;
-  if (fclose(f) != 0 || bad) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
+  if (fclose(f) != 0 || bad || !ok) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
   return ITSX_OK;
 }
 
@@ -4377,44 +4509,7 @@ int itsx_write_domtbl(const itsx_ctx *ctx, const char *path)
       i = j;
     }
   };
-  const int T = (int)std::min<size_t>((size_t)itsx_io::io_threads(), std::max<size_t>(nb, 1));
-  bool io_ok = true;
-  if (T <= 1 || nb <= 1) {
-    std::string out;
-    for (size_t b = 0; b < nb; b++) { out.clear(); format_block(b, out); if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) io_ok = false; }
-  } else {
-    std::vector<std::string> blocks(nb);
-    std::vector<char> ready(nb, 0);
-    std::mutex mu; std::condition_variable cv;
-    size_t next = 0, written = 0;
-    const size_t ahead = (size_t)T * 4;
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; t++)
-      th.emplace_back([&] {
-        for (;;) {
-          size_t b;
-          {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return next >= nb || next < written + ahead; });
-            if (next >= nb) return;
-            b = next++;
-          }
-          std::string out;
-          out.reserve(32768 * 200);
-          format_block(b, out);
-          { std::lock_guard<std::mutex> lk(mu); blocks[b].swap(out); ready[b] = 1; }
-          cv.notify_all();
-        }
-      });
-    for (size_t b = 0; b < nb; b++) {
-      std::string out;
-      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[b] != 0; }); out.swap(blocks[b]); }
-      if (!out.empty() && fwrite(out.data(), 1, out.size(), f) != out.size()) io_ok = false;
-      { std::lock_guard<std::mutex> lk(mu); written = b + 1; }
-      cv.notify_all();
-    }
-    for (auto &x : th) x.join();
-  }
+  bool io_ok = write_blocks(f, nb, format_block);
   if (fclose(f) != 0) io_ok = false;
   if (!io_ok) SET_ERR(ctx, ITSX_E_IO, std::string("short write to ") + path);
   return ITSX_OK;

@@ -471,7 +471,7 @@ void launch_region_count_fill(const PairOut *pout, const RegionRec *raw, int64_t
 
 // ItsPosition's order on domain rows (itsxpress/SeqSample.py:400-429: the FIRST row with a strictly greater %.1f score wins; rows come
 // in profile order, then domain order): [24b tenths + 2^23][20b ~profile][20b ~domain index].  A larger key wins.
-__device__ __forceinline__ unsigned long long rank_key(const itsx_domain &d)
+__host__ __device__ __forceinline__ unsigned long long rank_key(const itsx_domain &d)
 {
   long long tenths = (long long)__builtin_rint((double)d.bitscore * 10.0) + (1ll << 23);
   if (tenths < 0) tenths = 0;

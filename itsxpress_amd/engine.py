@@ -364,6 +364,11 @@ class Engine:
         self._chk(self.L.itsx_set_rows_mode(self.h, int(m)))
         self.rows_mode = int(m)
 
+    def set_kept_rows(self, on=True):
+        """After a "compact" / "lazy" search: domains() / write_domtbl() serve the WINNERS among the rows the context kept (per target and
+        2-character profile prefix the reported row ItsPosition's argmax ends up with -- a row of the full table) instead of refusing."""
+        self._chk(self.L.itsx_set_kept_rows(self.h, 1 if on else 0))
+
     def lazy_pending(self):
         """after finalize() of a lazy search whose counters were exchanged: rows that still depend on the exact domZ (> 0: search
         again in "compact" mode on every rank)"""

@@ -505,6 +505,10 @@ class ShardedOps:
         self._mode = mode
         self.rows_mode = {None: -1, "env": -1, "full": 0, "compact": 1, "lazy": 2}.get(mode, mode)
 
+    def set_kept_rows(self, on=True):
+        """after a "lazy" / "compact" search: domains() / write_domtbl() compose the rows the shards kept (Engine.set_kept_rows)"""
+        self._all("call", "set_kept_rows", (bool(on),), {})
+
     def finalize(self, domE=10.0):
         import time
         t0 = time.perf_counter()

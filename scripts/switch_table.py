@@ -16,6 +16,7 @@ PY_SWITCHES = [
     ("ITSXPRESS_GPUS", "mode", "N > 1: one sample over N worker processes, one GPU each (multi.py); outputs byte-identical to one GPU's"),
     ("ITSXPRESS_GPU_IDS", "mode", "comma-separated device ordinals for ITSXPRESS_GPUS"),
     ("ITSXPRESS_ARRAYS", "mode", "=1: arrays instead of uc.txt / rep.fa / domtbl.txt between the stages, lazy rows mode (same trimmed reads)"),
+    ("ITSXPRESS_DOMTBL", "mode", "=winners: files as ever, the lazy search behind them; domtbl.txt holds per target and side the row ItsPosition.parse ends up with (same dictionary, same trimmed reads)"),
     ("ITSXPRESS_STREAM", "mode", "=1 / 0: streamed file-order chunks on / off (default: by input size, ITSX_STREAM_AUTO_MB)"),
     ("ITSXPRESS_DB_DIR", "mode", "directory with additional ITSx_db HMM files (F.hmm)"),
     ("ITSXPRESS_XDIR", "tuning", "directory of the multi-GPU exchange files (default /dev/shm when it has room, else the temp directory)"),

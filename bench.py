@@ -348,6 +348,9 @@ def main():
     ap.add_argument("--full-steps", type=int, default=1,
                     help="with --rows lazy: this many extra steps with every pair evaluated (--rows compact), after the timed ones and outside "
                          "`value`: `full_pipeline_value`, and the lazy coordinates are compared with them for equality (0 = skip)")
+    ap.add_argument("--files-leg", type=int, default=1,
+                    help="N = 1, --rows lazy: after the timed steps the job's uc.txt, rep.fa and the winners' domtbl.txt are written once (what "
+                         "ITSXPRESS_DOMTBL=winners hands the reference's own parsers), outside `value`: `winners_files` (0 = skip)")
     ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -645,6 +648,37 @@ def main():
                     "GB_per_step": float(offs[-1]) / 1e9,
                     "note": "host buffer -> pinned staging -> HBM -> device packing inside the step (PCIe-inclusive); not `value`"}
 
+    # the file-compatible outputs of the lazy search (ITSXPRESS_DOMTBL=winners, INTEGRATION.md 3a'): the three files the reference's own
+    # Dedup / ItsPosition parse, written from the engine's state after the last step; never part of `value`
+    files_leg = None
+    if args.files_leg > 0 and world == 1 and args.rows == "lazy" and args.cluster_id >= 1.0:
+        if args.budget_s - (time.time() - T_START) < (40.0 if args.cpu_sample == 0 else 80.0):
+            files_leg = {"skipped": "wall-clock budget (--budget-s %.0f)" % args.budget_s}
+        else:
+            import tempfile
+            progress("uc.txt, rep.fa and the winners' domtbl.txt of the job")
+            if eng.stats()["lazy"] != 1:                  # (the last extra step was the full-pipeline one: the files come from a lazy search)
+                step()
+            fdir = tempfile.mkdtemp(prefix="itsx_bench_files_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            try:
+                tfw = time.perf_counter()
+                eng.set_kept_rows(True)
+                paths = [os.path.join(fdir, nm) for nm in ("uc.txt", "rep.fa", "domtbl.txt")]
+                eng.write_uc(paths[0])
+                eng.write_rep_fasta(paths[1])
+                t_dom = time.perf_counter()
+                eng.write_domtbl(paths[2])
+                tfw, t_dom = time.perf_counter() - tfw, time.perf_counter() - t_dom
+                files_leg = {"s_three_files": round(tfw, 3), "s_domtbl": round(t_dom, 3), "domtbl_rows": int(eng.L.itsx_num_domains(eng.h)),
+                             "MB": {os.path.basename(q): round(os.path.getsize(q) / 1e6, 1) for q in paths},
+                             "reads_per_s_search_plus_files": total_local / (dt / max(args.steps, 1) + tfw),
+                             "note": "one row per target and profile prefix: the row ItsPosition.parse ends up with (tests/test_gpu_winners.py); "
+                                     "written to a memory-backed directory; the default file mode lists every row (full_pipeline + ~136 rows per "
+                                     "representative: profiles/round6_winners_run_10M.json)"}
+            finally:
+                eng.set_kept_rows(False)
+                shutil.rmtree(fdir, ignore_errors=True)
+
     paired_leg = None
     if args.paired_pairs > 0 and world == 1:
         progress("paired file-to-file leg (%d pairs)" % args.paired_pairs)
@@ -810,6 +844,7 @@ def main():
             "timed_region": "ASCII text resident in HBM -> device 2-bit packing -> derep -> MSV -> Forward/Backward -> domains -> "
                             "thresholds -> per-read coordinates on the host (+ all-reduce / gather at N > 1)",
             "host_handover": handover,
+            "winners_files": files_leg,
             "paired_file_to_file": paired_leg,
             "ranks": rank_ms,
             "stage_ms": {k: round(v / K, 3) for k, v in acc.items()},

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 for v in "$@"; do
   envs=""; if [ "$v" != "-" ]; then envs=$(echo "$v" | tr ',' ' '); fi
   lib=$(echo " $envs" | sed -n 's/.* LIB=\([^ ]*\).*/\1/p'); [ -z "$lib" ] && lib=-
-  out=$(env $envs python -c "import sys, runpy, os; sys.path.insert(0, '.'); import itsxpress_amd._lib as l; l.LIB_PATH = os.path.abspath(sys.argv[1]) if sys.argv[1] != '-' else l.LIB_PATH; sys.argv = ['bench.py'] + sys.argv[2:]; runpy.run_path('bench.py', run_name='__main__')" $lib --steps ${STEPS:-2} --warmup 1 --cpu-sample 0 --handover-steps 0 --full-steps 0 --alone-steps 0 ${BENCH_ARGS} 2>/dev/null | grep '^{' | tail -1)
+  out=$(env $envs python -c "import sys, runpy, os; sys.path.insert(0, '.'); import itsxpress_amd._lib as l; l.LIB_PATH = os.path.abspath(sys.argv[1]) if sys.argv[1] != '-' else l.LIB_PATH; sys.argv = ['bench.py'] + sys.argv[2:]; runpy.run_path('bench.py', run_name='__main__')" $lib --steps ${STEPS:-2} --warmup 1 --cpu-sample 0 --handover-steps 0 --full-steps 0 --files-leg 0 --alone-steps 0 ${BENCH_ARGS} 2>/dev/null | grep '^{' | tail -1)
   echo "$out" | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); s = d['stage_ms']; r = d['config'].get('rows_shared_frac', {})

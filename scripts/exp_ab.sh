@@ -2,7 +2,7 @@
 # A/B arms of the default bench step: bash scripts/exp_ab.sh name1 "ENV=.. ENV=.." name2 "..." ...
 set -o pipefail
 out=gpurun_out/exp_ab; mkdir -p $out
-common="${BENCH_ARGS:---steps 3 --warmup 1 --cpu-sample 0 --handover-steps 0 --full-steps 0 --alone-steps 0}"
+common="${BENCH_ARGS:---steps 3 --warmup 1 --cpu-sample 0 --handover-steps 0 --full-steps 0 --files-leg 0 --alone-steps 0}"
 while [ $# -ge 2 ]; do
   name=$1; envs=$2; shift 2
   env $envs python bench.py $common > $out/$name.json 2> $out/$name.err || { echo "FAILED $name"; tail -5 $out/$name.err; exit 1; }

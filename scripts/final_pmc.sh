@@ -8,7 +8,7 @@ for tag in 1M 10M; do
   for c in FETCH_SIZE WRITE_SIZE; do
     n=$([ $c = FETCH_SIZE ] && echo fetch || echo write)
     echo "[pmc] $tag $c"
-    (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d/$n -- python3 $R/bench.py $reads --steps 1 --warmup 0 --cpu-sample 0 --handover-steps 0 --full-steps 0 --alone-steps 0 > $d/$n.json 2> $d/$n.err)
+    (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d/$n -- python3 $R/bench.py $reads --steps 1 --warmup 0 --cpu-sample 0 --handover-steps 0 --full-steps 0 --files-leg 0 --alone-steps 0 > $d/$n.json 2> $d/$n.err)
     find $d/$n -name "*kernel_trace.csv" -delete; find $d/$n -name "*agent_info.csv" -delete
   done
   du -sh $d

@@ -3,7 +3,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/final; mkdir -p $out
-lean="--cpu-sample 0 --handover-steps 0 --full-steps 0"
+lean="--cpu-sample 0 --handover-steps 0 --full-steps 0 --files-leg 0"
 echo "[final] default bench"; python bench.py > $out/bench_default_line.json 2> $out/bench_default.err || { echo FAILED default; tail -5 $out/bench_default.err; }
 echo "[final] kernel stats"; rm -rf $out/stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 1 --warmup 1 $lean --alone-steps 0 > $out/bench_10M_profiled_line.json 2> $out/stats.err

@@ -25,7 +25,7 @@ import numpy as np
 
 from .engine import Engine
 from ._lib import EngineError
-from .SeqSample import _REGION_PREFIX
+from .SeqSample import _REGION_PREFIX, _winners_from_env
 
 
 class SampleBatch:
@@ -92,13 +92,23 @@ class SampleBatch:
             if self.counts is None:
                 raise EngineError(-1, "deduplicate() the batch before _search()")
             eng.load_profiles(path=hmmfile)
-            eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
-            eng.finalize(domE=10.0)
-            for i, s in enumerate(self.samples):
-                s.dom_file = os.path.join(self._dir(i), "domtbl.txt")
-                eng.select_sample(i)
-                eng.write_domtbl(s.dom_file)
-            eng.select_sample(-1)
+            # ITSXPRESS_DOMTBL=winners (SeqSample._search): the lazy search, every sample's domtbl.txt = the rows its ItsPosition ends up with
+            winners = _winners_from_env()
+            if winners:
+                eng.set_rows_mode("lazy")
+            try:
+                eng.search(T=10.0, F1=1e-6, F2=1e-6, F3=1e-6)
+                eng.finalize(domE=10.0)
+                eng.set_kept_rows(winners)
+                for i, s in enumerate(self.samples):
+                    s.dom_file = os.path.join(self._dir(i), "domtbl.txt")
+                    eng.select_sample(i)
+                    eng.write_domtbl(s.dom_file)
+                eng.select_sample(-1)
+            finally:
+                if winners:
+                    eng.set_kept_rows(False)
+                    eng.set_rows_mode(None)
         except EngineError as e:
             logging.exception("Could not perform ITS identification with the HIP engine: %s", e)
             raise e

@@ -157,3 +157,42 @@ def test_winners_table_composed_from_several_contexts(tmp_path, t_hmm_text, monk
             s = M._OPEN.pop()
             if getattr(s, "_engine", None) is not None:
                 s._engine.close()
+
+
+def test_sample_batch_writes_winners_tables(engine, fixture_reads, t_hmm_text, mini_hmm_text, tmp_path, monkeypatch):
+    """SampleBatch (one engine pass over many samples, per-sample domZ): every sample's domtbl.txt in the winners mode parses to the
+    dictionary of its default-mode file."""
+    from itsxpress_amd import ItsPosition, SeqSampleNotPaired
+    from itsxpress_amd.batch import SampleBatch
+    names, seqs = fixture_reads
+    blob, offs = synth.make_reads(t_hmm_text, 600, seed=33)
+    syn = synth.to_strings(blob, offs)
+    parts = [(names[:120], seqs[:120]), (names[120:], seqs[120:]), (["s%05d" % i for i in range(len(syn))], syn)]
+    hmm = tmp_path / "its2.hmm"
+    hmm.write_text(mini_hmm_text + _its2_subset(t_hmm_text, 12, 12))
+    fqs = []
+    for k, (nm, sq) in enumerate(parts):
+        fq = tmp_path / ("sample%d.fq" % k)
+        with open(fq, "w") as f:
+            for n, s in zip(nm, sq):
+                f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+        fqs.append(str(fq))
+    got = {}
+    try:
+        for mode in ("full", "winners"):
+            d = tmp_path / mode
+            os.makedirs(d)
+            if mode == "winners":
+                monkeypatch.setenv("ITSXPRESS_DOMTBL", "winners")
+            objs = [SeqSampleNotPaired(fq, str(d)) for fq in fqs]
+            b = SampleBatch(objs, engine=engine)
+            b.deduplicate(threads=1)
+            b._search(hmmfile=str(hmm), threads=1)
+            got[mode] = [({r: ItsPosition(s.dom_file, r).ddict for r in REGIONS}, sum(1 for ln in open(s.dom_file) if not ln.startswith("#"))) for s in objs]
+    finally:
+        engine.set_kept_rows(False)
+        engine.set_rows_mode(None)
+    for k in range(len(parts)):
+        assert got["full"][k][0] == got["winners"][k][0], k
+        assert 0 < got["winners"][k][1] < got["full"][k][1]
+    assert len(got["full"][2][0]["ITS2"]) > 300

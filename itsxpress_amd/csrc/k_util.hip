@@ -206,61 +206,85 @@ void launch_calib(int pattern, float *slab, int64_t nwaves, int64_t R, float *ou
 // The boundary hands over ASCII bases; they are uploaded as they are -- in chunks of whole reads through pinned staging
 // buffers (engine.hip: pack_and_upload) -- and packed here (2 bits per base, 16 bases per word, every read on a word
 // boundary; non-ACGT symbols are 0 in the 2-bit plane and listed as (pos << 4 | code) exceptions in position order).
-// One wave per read, one lane per 16-base word.  `raw` holds the bases of reads [r0, r1) only: byte raw_base of the
-// whole read set is raw[0].
+// One lane per 16-base word, a block per 64 consecutive reads (k_pack_words).  `raw` holds the bases of reads [r0, r1) only: byte
+// raw_base of the whole read set is raw[0].
 namespace itsx {
 struct __attribute__((packed, aligned(1))) Raw16 { uint32_t a, b, c, d; };
+// 16 bases in ONE load (the text is not aligned to anything: gfx950 takes the unaligned 16 bytes as they are), and -- when all of them are
+// A / C / G / T in either case, the rule -- their codes by arithmetic: (c >> 1) & 3 is 0 1 3 2 for A C G T, x ^ (x >> 1) makes that 0 1 2 3.
+// A 0x41, C 0x43, G 0x47, T 0x54: bits 7..5 of the upper-cased byte are 010 and its low five bits are one of 1, 3, 7, 20.
+__device__ __forceinline__ bool pack16_plain(const uint8_t *p, uint32_t &w)
+{
+  const Raw16 v = *(const Raw16 *)p;
+  const uint32_t d[4] = {v.a, v.b, v.c, v.d};
+  bool plain = true;
+  w = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const uint32_t c = (d[q] >> (8 * t)) & 0xffu, u = c & 0xdfu;
+      plain = plain && ((u & 0xe0u) == 0x40u) && (((0x0010008au >> (u & 31u)) & 1u) != 0u);
+      const uint32_t x = (c >> 1) & 3u;
+      w |= (x ^ (x >> 1)) << (2 * (4 * q + t));
+    }
+  }
+  return plain;
+}
+// A block takes PACK_RB consecutive reads: their text is one contiguous stretch (the reads are concatenated), and so are their words, so
+// thread t of the block takes word t, t + 256, ... of that stretch whichever read it belongs to (a 6-step search over the group's 65 word
+// offsets in LDS) -- every lane busy and consecutive lanes on consecutive 16-byte chunks, where a wave per read (rounds 1-5) kept 19-37 of
+// its 64 lanes busy on merged amplicons and paid a read's bookkeeping per wave.
+constexpr int PACK_RB = 64;
 __global__ void __launch_bounds__(256) k_pack_words(const uint8_t *__restrict__ raw, int64_t raw_base, const int64_t *__restrict__ off,
                                                     const int64_t *__restrict__ woff, int64_t r0, int64_t r1, const int8_t *__restrict__ lut,
                                                     uint32_t *__restrict__ words, int32_t *__restrict__ excnt, long long *__restrict__ first_bad)
 {
   __shared__ int8_t code[256];
+  __shared__ int32_t s_orel[PACK_RB + 1], s_wrel[PACK_RB + 1];        // byte / word offsets of the group's reads relative to its first
+  __shared__ int32_t s_ne[PACK_RB];
+  __shared__ int32_t s_bad;
   code[threadIdx.x] = lut[threadIdx.x];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t r = r0 + wave; r < r1; r += nwaves) {
-    const int64_t o = off[r] - raw_base;
-    const int L = (int)(off[r + 1] - off[r]);
-    const int nw = L > 0 ? (L + 15) >> 4 : 1;
-    int ne = 0; bool bad = false;
-    for (int k = lane; k < nw; k += 64) {
-      uint32_t w = 0;
+  const int tid = (int)threadIdx.x;
+  const int64_t ngroups = (r1 - r0 + PACK_RB - 1) / PACK_RB;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t first = r0 + g * PACK_RB;
+    const int nr = (int)(r1 - first < PACK_RB ? r1 - first : PACK_RB);
+    const int64_t o0 = off[first], w0 = woff[first];      // (64 reads of at most 65 535 bases: the relative offsets fit 32 bits)
+    __syncthreads();                                       // (the group before this one is done with the arrays; `code` is there)
+    if (tid <= nr) { s_orel[tid] = (int32_t)(off[first + tid] - o0); s_wrel[tid] = (int32_t)(woff[first + tid] - w0); }
+    if (tid < PACK_RB) s_ne[tid] = 0;
+    if (tid == 0) s_bad = PACK_RB;
+    __syncthreads();
+    const uint8_t *text = raw + (o0 - raw_base);
+    const int Wb = s_wrel[nr];
+    for (int w = tid; w < Wb; w += 256) {
+      int j = 0;                                           // the read of word w: s_wrel[j] <= w < s_wrel[j + 1]
+#pragma unroll
+      for (int step = PACK_RB / 2; step >= 1; step >>= 1) if (j + step < nr && s_wrel[j + step] <= w) j += step;
+      const int k = w - s_wrel[j];
+      const int o = s_orel[j], L = s_orel[j + 1] - o;
       const int base = k * 16, m = L - base < 16 ? L - base : 16;
-      bool plain = false;
-      if (m == 16) {
-        // a full word: its 16 bases in ONE load (the text is not aligned to anything: gfx950 takes the unaligned 16 bytes as they are),
-        // and -- when all of them are A / C / G / T in either case, the rule -- their codes by arithmetic: (c >> 1) & 3 is 0 1 3 2 for
-        // A C G T, x ^ (x >> 1) makes that 0 1 2 3.  (Round 5: sixteen byte loads and sixteen table look-ups per lane before.)
-        const Raw16 v = *(const Raw16 *)(raw + o + base);
-        const uint32_t d[4] = {v.a, v.b, v.c, v.d};
-        plain = true;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const uint32_t c = (d[q] >> (8 * t)) & 0xffu, u = c & 0xdfu;
-            // A 0x41, C 0x43, G 0x47, T 0x54: bits 7..5 of the upper-cased byte are 010 and its low five bits are one of 1, 3, 7, 20
-            plain = plain && ((u & 0xe0u) == 0x40u) && (((0x0010008au >> (u & 31u)) & 1u) != 0u);
-            const uint32_t x = (c >> 1) & 3u;
-            w |= (x ^ (x >> 1)) << (2 * (4 * q + t));
-          }
-        }
-      }
+      uint32_t wd = 0;
+      // a full word: its 16 bases in ONE load and, when all of them are A / C / G / T in either case, their codes by arithmetic
+      const bool plain = m == 16 && pack16_plain(text + o + base, wd);
       if (!plain) {
-        w = 0;
+        wd = 0;
+        int ne = 0; bool bad = false;
         for (int t = 0; t < m; t++) {
-          const int c = code[raw[o + base + t]];
+          const int c = code[text[o + base + t]];
           if (c < 0) bad = true;
-          else if (c <= 3) w |= (uint32_t)c << (2 * t);
+          else if (c <= 3) wd |= (uint32_t)c << (2 * t);
           else ne++;
         }
+        if (ne) atomicAdd(&s_ne[j], ne);
+        if (bad) atomicMin(&s_bad, j);
       }
-      words[woff[r] + k] = w;
+      words[w0 + w] = wd;
     }
-    for (int d = 32; d; d >>= 1) ne += __shfl_xor(ne, d);
-    if (lane == 0) excnt[r] = ne;
-    if (__ballot(bad) && lane == 0) atomicMin(first_bad, (long long)r);
+    __syncthreads();
+    if (tid < nr) excnt[first + tid] = s_ne[tid];
+    if (tid == 0 && s_bad < PACK_RB) atomicMin(first_bad, (long long)(first + s_bad));
   }
 }
 // exceptions are rare: one thread per read that has any, positions ascending.  exstart = exclusive scan of excnt over THIS
@@ -279,7 +303,14 @@ __global__ void __launch_bounds__(256) k_pack_exc(const uint8_t *__restrict__ ra
   const int64_t o = off[r] - raw_base;
   const int L = (int)(off[r + 1] - off[r]);
   uint32_t *e = exc + g;
-  for (int i = 0; i < L; i++) { const int c = lut[raw[o + i]]; if (c > 3) *e++ = ((uint32_t)i << 4) | (uint32_t)c; }
+  // (sixteen bases at a time, and only a chunk that is not all A / C / G / T is taken apart: a read with one N in 440 bases cost its
+  // thread -- and the 63 beside it -- 440 dependent byte loads)
+  for (int base = 0; base < L; base += 16) {
+    const int m = L - base < 16 ? L - base : 16;
+    uint32_t w;
+    if (m == 16 && pack16_plain(raw + o + base, w)) continue;
+    for (int t = 0; t < m; t++) { const int c = lut[raw[o + base + t]]; if (c > 3) *e++ = ((uint32_t)(base + t) << 4) | (uint32_t)c; }
+  }
 }
 __global__ void k_pack_advance(long long *__restrict__ ebase, const int32_t *__restrict__ chunk_total, int64_t *__restrict__ excoff_end)
 {
@@ -289,7 +320,7 @@ void launch_pack(const uint8_t *raw, int64_t raw_base, const int64_t *off, const
                  uint32_t *words, int32_t *excnt, long long *first_bad, hipStream_t st)
 {
   if (r1 <= r0) return;
-  hipLaunchKernelGGL(k_pack_words, dim3((unsigned)std::min<int64_t>((r1 - r0 + 3) / 4, 65536)), dim3(256), 0, st, raw, raw_base, off, woff, r0, r1, lut, words, excnt, first_bad);
+  hipLaunchKernelGGL(k_pack_words, dim3((unsigned)std::min<int64_t>((r1 - r0 + PACK_RB - 1) / PACK_RB, 1 << 20)), dim3(256), 0, st, raw, raw_base, off, woff, r0, r1, lut, words, excnt, first_bad);
 }
 void launch_pack_exc(const uint8_t *raw, int64_t raw_base, const int64_t *off, int64_t r0, int64_t r1, const int8_t *lut, const int32_t *excnt,
                      const int32_t *exstart, long long *ebase, int64_t ecap, int64_t *excoff, uint32_t *exc, hipStream_t st)

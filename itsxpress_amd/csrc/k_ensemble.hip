@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   __shared__ uint16_t cntI_s[QMAX * 4][NL];
   // the domains of the path being sampled, last first: first / last residue, first / last node, null2 odds of A C G T
   __shared__ uint32_t dom_ij[MR_MAXD][NL];
-  __shared__ uint16_t dom_km[MR_MAXD][NL];                 // (the domains' null2 odds live in the region's scratch block: S.dn2)
+  __shared__ uint16_t dom_km[MR_MAXD][NL];                 // (the domains' null2 odds live in the region's scratch block: S.dn2 ...
+  __shared__ f4 dn2_one[ONE ? MR_MAXD : 1];                // ... ONE: here, where the lanes that did not write them read them)
   WaveDesc wd;
   if constexpr (ONE) { wd.prof = -1; wd.first = wave0 + (int64_t)(gridDim.x - 1 - blockIdx.x); wd.count = 1; wd.rows = 0; }
   else wd = a.waves[wave0 + (gridDim.x - 1 - blockIdx.x)];                 // longest regions first
@@ -263,10 +264,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       in_lds = true;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
   } else {
     if (!e.active) return;
   }
+  // ONE: lane 0 walks the paths (a chain of dependent draws: nothing to share); what a finished path needs done for its residues, and the
+  // loops over the region's arrays before and after, are spread over the wave's 64 lanes
+  const bool walker = !ONE || threadIdx.x == 0;
+  const int tid = (int)threadIdx.x;
   // (two typed reads under a uniform branch rather than one generic pointer: an LDS read, not a flat load that happens to land there)
 #define MATV(idx) ((ONE && in_lds) ? mr_mat[(idx)] : mat[(idx)])
   const int Q = e.Q, Lr = e.Lr, Lw = ONE ? e.Lr : wd.rows - 1;
@@ -302,11 +306,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
 #define DOM_IJ(d) (*(BIG ? &Gdom_ij[(d)] : &dom_ij[(d) < MR_MAXD ? (d) : 0][lane]))
 #define DOM_KM(d) (*(BIG ? &Gdom_km[(d)] : &dom_km[(d) < MR_MAXD ? (d) : 0][lane]))
-  for (int pos = 0; pos < Lr; pos++) n2[pos] = 0.0f;
-  for (uint32_t z = 0; z <= hmask; z++) Shslot[z] = 0;
+  if constexpr (ONE) {
+    for (int pos = tid; pos < Lr; pos += 64) n2[pos] = 0.0f;
+    for (uint32_t z = (uint32_t)tid; z <= hmask; z += 64) Shslot[z] = 0;
+    __threadfence_block();
+    __syncthreads();
+  } else {
+    for (int pos = 0; pos < Lr; pos++) n2[pos] = 0.0f;
+    for (uint32_t z = 0; z <= hmask; z++) Shslot[z] = 0;
+  }
   uint32_t rng = rnd_mix3(42u, 87654321u, 12345678u);
   if (rng == 0) rng = 42;
-  int ntup = 0, nsamp = 0, status = 0;
+  int ntup = 0, nsamp = 0, status = walker ? 0 : 9;         // (9: a lane that does not walk)
   const unsigned short dgm[16] = {1, 2, 4, 8, 0, 5, 10, 3, 12, 6, 9, 11, 14, 7, 13, 15};
   // Seq::code() walks the read's exception list through global loads on every call: the residue loop below would pay that for
   // every residue of every path of a read that has a single N (15 % of the bench's reads have one)
@@ -438,15 +449,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
           { float v4_[4];
 #pragma unroll
             for (int x = 0; x < 4; x++) { float v = vhsum(sv[x]); v += xfactor; v4_[x] = v; }
-            Sdn2[nd - 1] = (f4){v4_[0], v4_[1], v4_[2], v4_[3]}; }
+            if constexpr (ONE) dn2_one[nd - 1 < MR_MAXD ? nd - 1 : 0] = (f4){v4_[0], v4_[1], v4_[2], v4_[3]};
+            else Sdn2[nd - 1] = (f4){v4_[0], v4_[1], v4_[2], v4_[3]}; }
         }
       }
     }
     const unsigned long long tk1 = wall_clock64();
     tk_walk += tk1 - tk0;
-    if (status) continue;
+    if constexpr (ONE) { if (__shfl(status, 0, 64) != 0) continue; }      // (the walker's status decides for the wave)
+    else if (status) continue;
     // ---- after the path, all lanes together: its samples ...
-    for (int d = 0; d < nd; d++) {
+    for (int d = 0; d < (walker ? nd : 0); d++) {
       if (nsamp >= capS) { status = 3; break; }
       const uint32_t ij = DOM_IJ(d), km = (uint32_t)DOM_KM(d);
       const unsigned long long key = pack_tup((int)(ij & 0xffff), (int)(ij >> 16), (int)(km & 0xff), (int)(km >> 8));   // relative to the region
@@ -467,10 +480,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
       Stid[nsamp] = (idx_t)tix; Stidx[nsamp] = (uint8_t)t; nsamp++;
     }
     tk_dedupe += wall_clock64() - tk1;
-    if (status) continue;
+    if constexpr (ONE) { if (__shfl(status, 0, 64) != 0) continue; }
+    else if (status) continue;
     // ... and its residues' null2 terms.  As published: residues up to AND INCLUDING a domain's first one count as outside
     // (+1), the rest of the domain by its null2 odds; a residue takes exactly one term per path, so their order is free.
-    {
+    if constexpr (ONE) {
+      // one residue per lane and round: the path's domains come from the walker (LDS), a residue's terms still arrive in path order --
+      // the same lane sends them, one per path -- so every sum is the one lane 0 alone would have formed
+      const int ndw = __shfl(nd, 0, 64);
+      __syncthreads();                                       // (the walker's dom_ij / dn2_one are written)
+      for (int pos = Lw - tid; pos >= 1; pos -= 64) {
+        if (pos > Lr) continue;
+        float v = 1.0f;
+        int d = 0;
+        while (d < ndw && pos <= (int)(DOM_IJ(d) & 0xffff)) d++;
+        if (d < ndw && pos <= (int)(DOM_IJ(d) >> 16)) {
+          const int p0 = e.off + pos - 1;
+          int x;
+          if (e.sq.nexc <= 2) {
+            const uint32_t cw = e.sq.w[p0 >> 4];
+            x = (int)((cw >> (2 * (p0 & 15))) & 3u);
+            x = p0 == ex0p ? ex0c : x; x = p0 == ex1p ? ex1c : x;
+          } else x = e.sq.code(p0);
+          const f4 n2d = dn2_one[d < MR_MAXD ? d : 0];
+          if (x < 4) v = comp4(n2d, x);
+          else {
+            float acc = 0.f; int ndg = 0;
+#pragma unroll
+            for (int y = 0; y < 4; y++) if (dgm[x] >> y & 1) { acc += comp4(n2d, y); ndg++; }
+            v = acc / (float)ndg;
+          }
+        }
+        __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(n2 + pos - 1), v);
+      }
+      __syncthreads();                                       // (before the walker's next path overwrites the domains)
+    } else {
       int d = 0, dl = -1;
       f4 n2d = (f4){0.f, 0.f, 0.f, 0.f};                       // the null2 odds of domain dl
       uint32_t cw = 0; int cwi = -1;
@@ -514,17 +558,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
   const unsigned long long tk2 = wall_clock64();
 
+  if constexpr (ONE) status = __shfl(status, 0, 64);        // (from here on every lane carries the walker's)
   MrOut out;
   out.status = status; out.nenv = 0; out.big = -1;
   if constexpr (BIG) out.big = bg.envoff;
 #pragma unroll
   for (int z = 0; z < MRENV; z++) { out.ei[z] = 0; out.ej[z] = 0; }
   if (status != 0) {
-    for (int pos = 0; pos < Lr; pos++) n2[pos] = 0.0f;
-    a.out[e.mi] = out;
+    for (int pos = ONE ? tid : 0; pos < Lr; pos += ONE ? 64 : 1) n2[pos] = 0.0f;
+    if (walker) a.out[e.mi] = out;
     return;
   }
-  for (int pos = 0; pos < Lr; pos++) n2[pos] = det_logf(n2[pos] / (float)200);
+  for (int pos = ONE ? tid : 0; pos < Lr; pos += ONE ? 64 : 1) n2[pos] = det_logf(n2[pos] / (float)200);
+  if (!walker) return;                                      // (the clustering below is the walker's alone)
 
   // ---- single-linkage clustering over the DISTINCT tuples.  Copies of one tuple always share their neighbours, so they
   // fall into one component -- except an isolated tuple that does not link to itself (model span under 5 nodes): there

@@ -253,7 +253,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   WaveDesc wd;
   if constexpr (ONE) { wd.prof = -1; wd.first = wave0 + (int64_t)(gridDim.x - 1 - blockIdx.x); wd.count = 1; wd.rows = 0; }
   else wd = a.waves[wave0 + (gridDim.x - 1 - blockIdx.x)];                 // longest regions first
-  const int lane = ONE ? 0 : (int)threadIdx.x;
+  // COOP (a wave of a lazy round: 2 - 8 regions, the other lanes used to leave at once): lane t serves region t mod P2 of the wave as
+  // helper t / P2 of its G = 64 / P2; helper 0 is the region's walker.  Helpers take part in nothing but the loops over the region's
+  // residues and arrays (below); the per-lane LDS columns and the scratch block they index are their walker's.
+  const bool coop = !ONE && !BIG && wd.count <= 8;
+  int P2 = 1; while (P2 < wd.count) P2 <<= 1;
+  const int G = coop ? 64 / P2 : 1, hlp = coop ? (int)threadIdx.x / P2 : 0;
+  const int lane = ONE ? 0 : (coop ? (int)threadIdx.x % P2 : (int)threadIdx.x);
   const MrLane e = mr_lane(a, wd, lane);
   const f4 *mat = (const f4 *)a.slab + e.r0 * MRV;                          // the region's matrix: [row 0..Lr][MRV]
   bool in_lds = false;
@@ -269,7 +275,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
   // ONE: lane 0 walks the paths (a chain of dependent draws: nothing to share); what a finished path needs done for its residues, and the
   // loops over the region's arrays before and after, are spread over the wave's 64 lanes
-  const bool walker = !ONE || threadIdx.x == 0;
+  const bool walker = ONE ? threadIdx.x == 0 : hlp == 0;
   const int tid = (int)threadIdx.x;
   // (two typed reads under a uniform branch rather than one generic pointer: an LDS read, not a flat load that happens to land there)
 #define MATV(idx) ((ONE && in_lds) ? mr_mat[(idx)] : mat[(idx)])
@@ -309,6 +315,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   if constexpr (ONE) {
     for (int pos = tid; pos < Lr; pos += 64) n2[pos] = 0.0f;
     for (uint32_t z = (uint32_t)tid; z <= hmask; z += 64) Shslot[z] = 0;
+    __threadfence_block();
+    __syncthreads();
+  } else if (coop) {
+    for (int pos = hlp; pos < Lr; pos += G) n2[pos] = 0.0f;
+    for (uint32_t z = (uint32_t)hlp; z <= hmask; z += (uint32_t)G) Shslot[z] = 0;
     __threadfence_block();
     __syncthreads();
   } else {
@@ -457,9 +468,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const unsigned long long tk1 = wall_clock64();
     tk_walk += tk1 - tk0;
     if constexpr (ONE) { if (__shfl(status, 0, 64) != 0) continue; }      // (the walker's status decides for the wave)
-    else if (status) continue;
+    else if (!coop && status) continue;                                    // (COOP: no lane leaves the path early -- predicates below)
     // ---- after the path, all lanes together: its samples ...
-    for (int d = 0; d < (walker ? nd : 0); d++) {
+    for (int d = 0; d < ((walker && status == 0) ? nd : 0); d++) {
       if (nsamp >= capS) { status = 3; break; }
       const uint32_t ij = DOM_IJ(d), km = (uint32_t)DOM_KM(d);
       const unsigned long long key = pack_tup((int)(ij & 0xffff), (int)(ij >> 16), (int)(km & 0xff), (int)(km >> 8));   // relative to the region
@@ -481,7 +492,50 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
     tk_dedupe += wall_clock64() - tk1;
     if constexpr (ONE) { if (__shfl(status, 0, 64) != 0) continue; }
-    else if (status) continue;
+    else if (!coop && status) continue;
+    if (!ONE && !BIG && coop) {
+      // the region's helpers share its residues: helper h takes positions Lr - h, Lr - h - G, ...  The path's domains are in the walker's
+      // LDS column; a domain's null2 odds are the walker's to read (its own stores) and reach the helpers through the wave.  A residue's
+      // terms still come from ONE lane, one per path, in path order: every sum is the one the walker alone would have formed.
+      const int wok = __shfl((int)(walker && status == 0), lane, 64);
+      const int ndw = __shfl(nd, lane, 64);
+      __syncthreads();                                       // (the walkers' dom_ij columns are written)
+      for (int dd = 0; dd <= MR_MAXD; dd++) {                // domain dd of the path; dd == its number of domains: the residues outside all
+        if (__ballot(wok && dd <= ndw) == 0ull) break;
+        f4 q = (f4){1.0f, 1.0f, 1.0f, 1.0f};
+        if (walker && wok && dd < ndw) q = Sdn2[dd];
+        const float qx = __shfl(q.x, lane, 64), qy = __shfl(q.y, lane, 64), qz = __shfl(q.z, lane, 64), qw = __shfl(q.w, lane, 64);
+        if (!wok || dd > ndw) continue;
+        const f4 n2d = (f4){qx, qy, qz, qw};
+        for (int pos = Lr - hlp; pos >= 1; pos -= G) {
+          int d = 0;
+          while (d < ndw && pos <= (int)(DOM_IJ(d) & 0xffff)) d++;
+          const bool inside = d < ndw && pos <= (int)(DOM_IJ(d) >> 16);
+          if (inside ? d != dd : dd != ndw) continue;        // (this round is another domain's, or the outside residues')
+          float v = 1.0f;
+          if (inside) {
+            const int p0 = e.off + pos - 1;
+            int x;
+            if (e.sq.nexc <= 2) {
+              const uint32_t cw = e.sq.w[p0 >> 4];
+              x = (int)((cw >> (2 * (p0 & 15))) & 3u);
+              x = p0 == ex0p ? ex0c : x; x = p0 == ex1p ? ex1c : x;
+            } else x = e.sq.code(p0);
+            if (x < 4) v = comp4(n2d, x);
+            else {
+              float acc = 0.f; int ndg = 0;
+#pragma unroll
+              for (int y = 0; y < 4; y++) if (dgm[x] >> y & 1) { acc += comp4(n2d, y); ndg++; }
+              v = acc / (float)ndg;
+            }
+          }
+          __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float *)(n2 + pos - 1), v);
+        }
+      }
+      __syncthreads();                                       // (before the walkers' next path overwrites the columns)
+      tk_close += wall_clock64() - tk1;
+      continue;
+    }
     // ... and its residues' null2 terms.  As published: residues up to AND INCLUDING a domain's first one count as outside
     // (+1), the rest of the domain by its null2 odds; a residue takes exactly one term per path, so their order is free.
     if constexpr (ONE) {
@@ -559,17 +613,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const unsigned long long tk2 = wall_clock64();
 
   if constexpr (ONE) status = __shfl(status, 0, 64);        // (from here on every lane carries the walker's)
+  else if (coop) status = __shfl(status, lane, 64);
+  if (ONE || coop) __threadfence();                         // (the residues' sums are read below by other lanes than sent their terms)
   MrOut out;
   out.status = status; out.nenv = 0; out.big = -1;
   if constexpr (BIG) out.big = bg.envoff;
 #pragma unroll
   for (int z = 0; z < MRENV; z++) { out.ei[z] = 0; out.ej[z] = 0; }
   if (status != 0) {
-    for (int pos = ONE ? tid : 0; pos < Lr; pos += ONE ? 64 : 1) n2[pos] = 0.0f;
+    for (int pos = ONE ? tid : hlp; pos < Lr; pos += ONE ? 64 : G) n2[pos] = 0.0f;
     if (walker) a.out[e.mi] = out;
     return;
   }
-  for (int pos = ONE ? tid : 0; pos < Lr; pos += ONE ? 64 : 1) n2[pos] = det_logf(n2[pos] / (float)200);
+  for (int pos = ONE ? tid : hlp; pos < Lr; pos += ONE ? 64 : G) n2[pos] = det_logf(n2[pos] / (float)200);
   if (!walker) return;                                      // (the clustering below is the walker's alone)
 
   // ---- single-linkage clustering over the DISTINCT tuples.  Copies of one tuple always share their neighbours, so they

@@ -2393,7 +2393,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
       // 64 they are 16 - 120 waves on a chip of 1 024 SIMDs, each walking 200 x ~125 dependent steps for its lanes' 200 x ~60.  The kernel holds
       // four waves per SIMD: as few lanes per wave as keep every wave resident at once (ITSX_MR_WAVES, 4 096; never under two lanes) --
       // less of the phase divergence, the same latency per step (10 M reads: 215 -> 168 ms per step; a full table's waves stay at 64 lanes)
-      static const int64_t waves_target = sw_get("ITSX_MR_WAVES") ? atoll(sw_get("ITSX_MR_WAVES")) : 4096;
+      const int64_t waves_target = sw_get("ITSX_MR_WAVES") ? atoll(sw_get("ITSX_MR_WAVES")) : 4096;       // (read at every search: the tests walk every layout)
       const int lanes_norm = waves_target <= 0 ? MR_LANES : (int)std::max<int64_t>(2, std::min<int64_t>(MR_LANES, (NU + waves_target - 1) / waves_target));
       std::vector<WaveDesc> mw;
       std::vector<int64_t> wfirst;
@@ -2437,7 +2437,7 @@ static int domain_pipeline(itsx_ctx *ctx, const PairList &pl, const int32_t *d_s
         if (mrdbg) { HIPCHK(ctx->w_counters.alloc(8)); HIPCHK(hipMemsetAsync(ctx->w_counters.p, 0, 64, st)); ma.dbg = (unsigned long long *)ctx->w_counters.p; }
         // a small batch (a shard of a million reads, a chunk of a streaming run) cannot hide a path's chain of dependent matrix reads
         // behind other waves: its regions are walked one per wave with the matrix in LDS (k_ensemble.hip: k_mr_trace<., true>)
-        static const int64_t one_max = sw_get("ITSX_MR_ONE_MAX") ? atoll(sw_get("ITSX_MR_ONE_MAX")) : 2048;      // (10 M reads: 6 400 and 21 500 regions in the two rounds took 252 and 531 ms this way, 212 in waves of 64)
+        const int64_t one_max = sw_get("ITSX_MR_ONE_MAX") ? atoll(sw_get("ITSX_MR_ONE_MAX")) : 2048;      // (10 M reads: 6 400 and 21 500 regions in the two rounds took 252 and 531 ms this way, 212 in waves of 64)
         const int64_t nreg = wfirst[(size_t)w1] - wfirst[(size_t)w0];
         const bool one = nreg <= one_max;
         if (one) ma.lds_bytes = (int32_t)std::min<int64_t>(40 << 10, (int64_t)mw[(size_t)w1 - 1].rows * MRV * 16);

@@ -60,7 +60,7 @@ static const Switch g_sw[] = {
   {"ITSX_MSV_BWD_WHOLE", SW_TUNING, "=1: the MSV filter's Backward chains copy their whole read to LDS first (A/B arm: same cells)"},
   {"ITSX_LAZY_TOPUP_ALL", SW_TUNING, "=0: a profile whose undecided rows need most of its pairs is left to the full count (itsx_lazy_complete) instead of taking all its unevaluated pairs in the top-up round (same rows)"},
   {"ITSX_MR_WAVES", SW_TUNING, "ensemble stage: waves a batch is spread over (lanes per wave = regions / this, 2 .. 64); 0 = waves of 64 lanes"},
-  {"ITSX_MR_ONE_MAX", SW_TUNING, "ensemble stage: regions above this length get a wave of their own"},
+  {"ITSX_MR_ONE_MAX", SW_TUNING, "ensemble stage: a batch of at most this many regions (default 2048) is walked one region per wave with the matrix in LDS; 0 = never"},
   {"ITSX_CL_NOSCORE", SW_TUNING, "clustering: skips the score-only pre-pass (A/B arm; the walk then aligns every candidate: same outcomes)"},
   {"ITSX_CL_NOPRECHECK", SW_TUNING, "clustering: skips the certificate pre-check (A/B arm: same outcomes)"},
   {"ITSX_CL_CAPACITY", SW_TUNING, "clustering: candidate-list capacity"},

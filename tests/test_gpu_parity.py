@@ -417,16 +417,24 @@ def test_chunked_search_is_identical_to_one_chunk(engine, t_hmm_text, monkeypatc
     assert np.array_equal(start, us[uniq_of]) and np.array_equal(stop, ue[uniq_of])
 
 
-def test_multidomain_regions_are_resolved_by_traceback_clustering(engine, t_hmm_text, monkeypatch):
+@pytest.mark.parametrize("layout", ["one_per_wave", "two_per_wave", "seven_per_wave", "sixty_four_per_wave"])
+def test_multidomain_regions_are_resolved_by_traceback_clustering(engine, t_hmm_text, monkeypatch, layout):
     """hmmsearch resolves a region whose posterior suggests several domains by 200 stochastic tracebacks + clustering
     (region_trace_ensemble).  Engine (k_ensemble.hip) and oracle must agree on every envelope, every per-residue null2
     sum (domcorrection, seq_bias) and every score -- the random stream included -- on a workload with hundreds of such
-    regions; and with the stage switched off on both sides they must agree on the old one-envelope behaviour."""
+    regions; and with the stage switched off on both sides they must agree on the old one-envelope behaviour.
+    The kernel lays a batch out in four ways (a small batch one region per wave; a lazy round's few thousand regions 2 - 8 per wave, the
+    other lanes helping; a full table's 64 per wave): every layout must give the same bits."""
+    if layout != "one_per_wave":
+        monkeypatch.setenv("ITSX_MR_ONE_MAX", "0")
+        monkeypatch.setenv("ITSX_MR_WAVES", {"two_per_wave": "4096", "seven_per_wave": "128", "sixty_four_per_wave": "0"}[layout])
     blob, offs = synth.make_reads(t_hmm_text, 3000, seed=5, fixed_len=0, len_range=(300, 580))
     seqs = synth.to_strings(blob, offs)
     hmm = _its2_subset(t_hmm_text)
     res = _run_both(engine, hmm, seqs, threads=os.cpu_count() or 8)
     _compare(engine, res)
+    if layout != "one_per_wave":
+        return
     st = engine.stats()
     assert res.counts["multidomain"] > 300
     assert st["n_mr_clustered"] == res.counts["multidomain"] and st["n_mr_failed"] == 0

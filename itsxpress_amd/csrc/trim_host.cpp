@@ -172,8 +172,14 @@ int itsx_write_trimmed_fastq(const char *seq_path, const char *out_path, int com
       return ITSX_OK;
     }
     if (rc != ITSX_E_FORMAT) return rc;
+    // the pool's writer object met a malformed record: a read-only walk names it (the output is NOT opened a second time -- what the
+    // object wrote before the record stays as it is, as after the single-threaded walk below; round 5's advisor)
+    Rec bad; int64_t k = 0; int rr;
+    while ((rr = in.next(bad)) == 1) k++;
+    g_trim_error = rr < 0 ? "malformed FASTQ record " + std::to_string(k) : std::string("malformed FASTQ text");
+    return ITSX_E_FORMAT;
   }
-  if (!out.open(out_path, compression)) return ITSX_E_IO;        // (the single-threaded way through; ALSO taken after the pool's writer object met a malformed record -- the output is then opened a second time, truncated, and this walk names the record: a pipe's reader has seen partial data by then; the call fails with ITSX_E_FORMAT either way)
+  if (!out.open(out_path, compression)) return ITSX_E_IO;        // (the single-threaded way through: one I/O thread, or a text below ITSX_WRITE_MIN_MB)
   Rec rec; int64_t i = 0, nw = 0, tot = 0; int rc;
   while ((rc = in.next(rec)) == 1) {
     if (i >= n_records) { g_trim_error = "more records in the file than coordinates"; return ITSX_E_ARG; }
